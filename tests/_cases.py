@@ -1,0 +1,70 @@
+"""Load tests/golden/*.npz into oracle LayerSpecs (shared by CPU and GPU tests)."""
+import glob
+import json
+import os
+
+import numpy as np
+
+from oracle import vptq_oracle as vo
+from _proc import proc_values
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def golden_names():
+    return sorted(os.path.splitext(os.path.basename(p))[0]
+                  for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+
+
+def _proc_codebook(spec, dtype):
+    n = spec["n"]
+    v = proc_values(n, spec["seed"], spec["scale"]) + np.float32(spec["mean"])
+    return vo.from_f32(v, dtype)
+
+
+def load_golden(name):
+    """-> (LayerSpec, x_bits [1,T,I], y_bits [1,T,O], cfg dict, W_head)"""
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    cfg = json.loads(bytes(z["config"]).decode())
+    dt = cfg["dtype"]
+    C, k, kr, v = (cfg["num_codebooks"], cfg["num_centroids"],
+                   cfg["num_res_centroids"], cfg["vector_len"])
+
+    def cb(key, count):
+        if key in cfg["proc"]:
+            sp = dict(cfg["proc"][key], n=C * count * v)
+            return _proc_codebook(sp, dt).reshape(C, count, v)
+        return z[key].reshape(C, count, v)
+
+    L = vo.LayerSpec(
+        cfg["in_features"], cfg["out_features"], v, k, kr, C, cfg["group_size"],
+        cfg["outlier_size"], cfg["outlier_vector_len"], cfg["num_outlier_centroids"], dt)
+    L.indices = z["indices"]
+    L.centroids = cb("centroids", k)
+    if kr > 0:
+        L.res_centroids = cb("res_centroids", kr)
+    if L.enable_outlier:
+        L.outlier_indices = z["outlier_indices"]
+        L.outlier_centroids = z["outlier_centroids"].reshape(
+            1, cfg["num_outlier_centroids"], cfg["outlier_vector_len"])
+    if cfg["enable_perm"]:
+        L.perm = z["perm"]
+    if cfg["enable_norm"]:
+        L.weight_scale = z["weight_scale"]
+        L.weight_bias = z["weight_bias"]
+    if cfg["has_bias"]:
+        L.bias = z["bias"]
+    return L, z["x"], z["y"], cfg, z["W_head"]
+
+
+def rel_err(y_bits, ref_bits, dtype):
+    """max|Δ| / max|ref|  (the BASELINE.md §5 parity metric)."""
+    a = vo.to_f32(y_bits, dtype).astype(np.float64)
+    b = vo.to_f32(ref_bits, dtype).astype(np.float64)
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-30))
+
+
+def bit_identical_frac(y_bits, ref_bits):
+    a = np.ascontiguousarray(y_bits).view(np.uint16).ravel()
+    b = np.ascontiguousarray(ref_bits).view(np.uint16).ravel()
+    return float(np.mean(a == b))

@@ -1,0 +1,97 @@
+"""Pin the oracle against the real reference (golden vectors + live import)."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from oracle import vptq_oracle as vo
+from _cases import golden_names, load_golden, rel_err, bit_identical_frac
+from _refshim import reference_available
+
+# fp16: 1 ulp ~ 4.9e-4 relative; bf16: 3.9e-3.  The reference's F.linear and the
+# oracle's float64 dot differ only by summation order -> <= ~1 output ulp.
+Y_TOL = {"f16": 1e-3, "bf16": 8e-3}
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_oracle_dequant_bit_exact_vs_reference(name):
+    L, x, y, cfg, W_head = load_golden(name)
+    W = vo.dequant(L)
+    assert W.shape == (cfg["out_features"], cfg["in_features"])
+    assert (W[:16] == W_head).all()
+    assert hashlib.sha256(W.tobytes()).hexdigest() == cfg["W_sha256"]
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_oracle_forward_vs_reference(name):
+    L, x, y, cfg, _ = load_golden(name)
+    out = vo.forward(L, x)
+    assert out.shape == y.shape
+    assert rel_err(out, y, cfg["dtype"]) <= Y_TOL[cfg["dtype"]]
+    # near bit-identity: only summation-order noise remains
+    assert bit_identical_frac(out, y) >= 0.90
+
+
+def test_pack_unpack_roundtrip_and_edges():
+    rng = np.random.default_rng(7)
+    for ib, rb, G in [(8, 8, 64), (12, 0, 7), (13, 8, 33), (16, 8, 5), (16, 16, 3),
+                      (4, 2, 1), (10, 4, 96), (15, 12, 17), (1, 0, 40)]:
+        idx = rng.integers(0, 1 << ib, size=(2, 3, G))
+        r = rng.integers(0, 1 << rb, size=(2, 3, G)) if rb else None
+        p = vo.pack_indices(idx, ib, r, rb)
+        assert p.dtype == np.int32 and p.shape == (2, 3, (G * (ib + rb) + 31) // 32)
+        a, b = vo.unpack_indices(p, ib, G, rb, ref_residual_mask_quirk=False)
+        assert (a == idx).all()
+        if rb:
+            assert (b == r).all()
+    # all-ones / zero patterns and the max index survive
+    for val in (0, (1 << 16) - 1):
+        idx = np.full((1, 1, 9), val)
+        p = vo.pack_indices(idx, 16, idx, 16)
+        a, b = vo.unpack_indices(p, 16, 9, 16)
+        assert (a == val).all() and (b == val).all()
+
+
+def test_residual_mask_quirk_documented():
+    """pack.py:137 masks the residual with index_bits; differs only if rb>ib."""
+    idx = np.array([[[3, 1]]]); r = np.array([[[200, 77]]])
+    p = vo.pack_indices(idx, 2, r, 8)
+    _, rq = vo.unpack_indices(p, 2, 2, 8, ref_residual_mask_quirk=True)
+    _, rc = vo.unpack_indices(p, 2, 2, 8, ref_residual_mask_quirk=False)
+    assert (rc == r).all() and (rq == (r & 3)).all()
+
+
+@pytest.mark.skipif(not reference_available(), reason="/root/reference not mounted (GPU box)")
+def test_oracle_vs_live_reference_random_layers():
+    import torch
+    from _refshim import load_reference
+    import gen_golden as gg
+    vptq = load_reference()
+    cases = [
+        ("r1", 640, 136, dict(vector_lens=[-1, 8], num_centroids=[-1, 256], num_res_centroids=[-1, 256], group_num=1, outlier_size=0, enable_norm=True, enable_perm=True, bias=True), "f16", 2, "ref-test"),
+        ("r2", 8 + 3 * 64, 70, dict(vector_lens=[2, 10], num_centroids=[16, 512], num_res_centroids=[-1, 64], group_num=3, outlier_size=8, enable_norm=True, enable_perm=False, bias=False), "bf16", 1, "llm"),
+        ("r3", 192, 66, dict(vector_lens=[-1, 2], num_centroids=[-1, 16], num_res_centroids=[-1, -1], group_num=1, outlier_size=0, enable_norm=False, enable_perm=True, bias=False), "f16", 4, "ref-test"),
+    ]
+    for ci, (name, I, O, kw, dtype, tokens, dist) in enumerate(cases):
+        m, x, proc = gg.build(vptq, name, I, O, kw, dtype, tokens, dist, seed=99 + ci)
+        with torch.no_grad():
+            W = gg.ref_dequant(vptq, m)
+            y = m(x)
+        L = vo.LayerSpec(I, O, m.vector_len, m.num_centroids, m.num_res_centroids, m.num_codebooks,
+                         m.group_size, m.outlier_size, m.outlier_vector_len, m.num_outlier_centroids, dtype)
+        L.indices = gg.bits(m.indices)
+        L.centroids = gg.bits(m.centroids.weight).reshape(m.num_codebooks, m.num_centroids, m.vector_len)
+        if m.enable_residual:
+            L.res_centroids = gg.bits(m.res_centroids.weight).reshape(m.num_codebooks, m.num_res_centroids, m.vector_len)
+        if m.enable_outlier:
+            L.outlier_indices = gg.bits(m.outlier_indices)
+            L.outlier_centroids = gg.bits(m.outlier_centroids.weight)
+        if m.enable_perm:
+            L.perm = gg.bits(m.perm)
+        if m.enable_norm:
+            L.weight_scale = gg.bits(m.weight_scale); L.weight_bias = gg.bits(m.weight_bias)
+        if m.bias is not None:
+            L.bias = gg.bits(m.bias)
+        assert (vo.dequant(L) == gg.bits(W)).all(), name
+        out = vo.forward(L, gg.bits(x))
+        assert rel_err(out, gg.bits(y), dtype) <= Y_TOL[dtype], name
