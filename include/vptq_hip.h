@@ -1,0 +1,182 @@
+/*
+ * vptq_hip.h — C ABI of libvptq_hip.so: the MI355X (gfx950) replacement for the
+ * native extension behind microsoft/VPTQ's `vptq.ops` hot path.
+ *
+ * Drop-in boundary.  The reference binds three C++/CUDA entry points through
+ * pybind11 (csrc/ops.cc:44-55); each function below replaces one of them:
+ *
+ *   vptq_quant_gemv     <- `quant_gemv`    = wquant_act16_gemv     csrc/ops.cc:20-30,
+ *                                            csrc/quant_gemv.cu:241-294
+ *   vptq_dequant        <- `dequant`                                csrc/ops.cc:9-18,
+ *                                            csrc/dequant.cu:227-287
+ *   vptq_quant_gemv_v2  <- `quant_gemv_v2`                          csrc/ops.cc:32-38,
+ *                                            csrc/quant_gemv_v2.cu:25-180
+ *
+ * Plain C: raw device pointers + sizes, no torch / pybind / C++ types.
+ *
+ * Ownership ... the caller owns every buffer (inputs, outputs, workspace); the
+ *               library allocates nothing and keeps no per-call state.  The
+ *               reference ops allocate their own output (quant_gemv.cu:206).
+ * Streams ..... every launch goes to the hipStream_t passed as `stream`
+ *               (NULL = the default stream).  Asynchronous, no host sync, no
+ *               host read of device data => hipGraph-capturable.  The reference
+ *               uses at::cuda::getCurrentCUDAStream() (quant_gemv.cu:180).
+ * Errors ...... return 0 on success; < 0 = VPTQ_E_* validation error (nothing
+ *               launched); > 0 = hipError_t from the launch.  A message is kept
+ *               per thread in vptq_last_error().  The reference throws
+ *               c10::Error via TORCH_CHECK (csrc/util/common.h:11-19).
+ * Threading ... re-entrant; no globals besides one-time kernel attribute setup.
+ */
+#ifndef VPTQ_HIP_H
+#define VPTQ_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VPTQ_ABI_VERSION 1
+
+#if defined(__GNUC__)
+#define VPTQ_API __attribute__((visibility("default")))
+#else
+#define VPTQ_API
+#endif
+
+/* element type of activations / codebooks / scales / outputs */
+enum { VPTQ_DTYPE_F16 = 0, VPTQ_DTYPE_BF16 = 1 };
+
+/* error codes (negative) */
+enum {
+  VPTQ_OK = 0,
+  VPTQ_E_NULL = -1,        /* required pointer is NULL            */
+  VPTQ_E_SHAPE = -2,       /* inconsistent shapes / sizes         */
+  VPTQ_E_UNSUPPORTED = -3, /* valid but no kernel for this combo  */
+  VPTQ_E_ALIGN = -4,       /* pointer not aligned as required     */
+  VPTQ_E_TOKENS = -5,      /* tokens outside [1, VPTQ_GEMV_MAX_TOKENS] */
+  VPTQ_E_WORKSPACE = -6    /* workspace too small                 */
+};
+
+/* flags for vptq_quant_gemv / vptq_quant_gemv_v2 */
+enum {
+  /* Default arithmetic reproduces the reference CPU path's roundings: every
+   * weight is rebuilt as r16(r16(r16(c+r)*scale)+bias) in the 16-bit type, then
+   * x*w is accumulated in fp32 and rounded once.  FAST_MATH folds scale/bias
+   * into fp32 (fewer VALU ops, <=1e-3 max-normalised, not bit-equivalent). */
+  VPTQ_GEMV_FAST_MATH = 1 << 0,
+  /* force the generic kernel (testing / A-B) */
+  VPTQ_GEMV_FORCE_GENERIC = 1 << 1
+};
+
+#define VPTQ_GEMV_MAX_TOKENS 8
+
+/*
+ * One VQuantLinear layer in the reference's on-disk tensor formats
+ * (vptq/layers/vqlinear.py:97-240).  All pointers are DEVICE pointers; nullable
+ * ones are marked.  I = outlier_size + num_codebooks * group_size.
+ *
+ *   Wq[n*v+t, S + cb*G + g] = centroids[cb, idx, t] + res_centroids[cb, ridx, t]
+ *   Wq[m*ov+t, g]           = outlier_centroids[0, outlier_indices[0,m,g], t]   (g < S)
+ *   W[o, j] = Wq[o, inv_perm[j]] * weight_scale[j] + weight_bias[j]
+ *   y[., o] = sum_j x[., j] * W[o, j] + bias[o]
+ *
+ * indices: int32 [C, N, row_words]; each (cb, n) row is a little-endian bit
+ * stream, element g = bits [g*T, (g+1)*T), T = index_bits + res_bits,
+ * value = (ridx << index_bits) | idx   (vptq/utils/pack.py:26-67).
+ */
+typedef struct VptqLayerDesc {
+  int32_t in_features;           /* I */
+  int32_t out_features;          /* O */
+  int32_t vector_len;            /* v: even, 2..16 */
+  int32_t num_codebooks;         /* C = group_num */
+  int32_t group_size;            /* G */
+  int32_t num_centroids;         /* k (power of two, <= 65536) */
+  int32_t num_res_centroids;     /* kr; 0 = no residual codebook */
+  int32_t index_bits;            /* log2 k  */
+  int32_t res_bits;              /* log2 kr */
+  int32_t row_words;             /* ceil(G*T/32) */
+  int32_t num_indices;           /* N = ceil(O / v) */
+  int32_t outlier_size;          /* S; 0 = no outliers */
+  int32_t outlier_vector_len;    /* ov */
+  int32_t num_outlier_centroids; /* ko */
+  int32_t num_outlier_indices;   /* M = ceil(O / ov) */
+  int32_t dtype;                 /* VPTQ_DTYPE_* */
+
+  const int32_t* indices;          /* [C, N, row_words]                        */
+  const void* centroids;           /* [C, k, v]                                 */
+  const void* res_centroids;       /* [C, kr, v]            NULL iff kr == 0    */
+  const uint16_t* outlier_indices; /* [1, M, S]             NULL iff S == 0     */
+  const void* outlier_centroids;   /* [1, ko, ov]           NULL iff S == 0     */
+  const uint16_t* perm;            /* [I] uint16            NULL = identity     */
+  const uint16_t* inv_perm;        /* [I] argsort(perm)     needed by dequant when perm != NULL */
+  const void* weight_scale;        /* [I]   NULL (with weight_bias) = no norm   */
+  const void* weight_bias;         /* [I]                                       */
+  const void* bias;                /* [O]                   NULL = none         */
+} VptqLayerDesc;
+
+/*
+ * v2 wire format (tests/test_quant_gemv.py:49-109, csrc/quant_gemv_v2.cu:25-180):
+ * UNPACKED indices laid out [N][I]; one codebook; residual ids uint8 or uint16.
+ *   W^T[i, n*v+t] = centroids[ids[n*I+i], t] + res_centroids[rids[n*I+i], t]
+ *   W^T = scale[i] * W^T + sbias[i];  y = x @ W^T + bias
+ */
+typedef struct VptqV2Desc {
+  int32_t in_features;
+  int32_t out_features;
+  int32_t vector_len;
+  int32_t num_centroids;
+  int32_t num_res_centroids; /* 0 = none */
+  int32_t res_index_bytes;   /* 1 (uint8) or 2 (uint16) */
+  int32_t dtype;
+  int32_t reserved;
+  const uint16_t* indices;     /* [N * I] */
+  const void* centroids;       /* [1, k, v] */
+  const void* res_indices;     /* [N * I] uint8/uint16, NULL iff kr == 0 */
+  const void* res_centroids;   /* [1, kr, v] */
+  const void* scale_weights;   /* [I] nullable */
+  const void* scale_bias;      /* [I] nullable */
+  const void* bias;            /* [O] nullable */
+} VptqV2Desc;
+
+VPTQ_API int vptq_abi_version(void);
+
+/* thread-local message for the last non-zero return on this thread */
+VPTQ_API const char* vptq_last_error(void);
+
+/*
+ * y[tokens, O] = x[tokens, I] @ W^T + bias, fused dequant, tokens in
+ * [1, VPTQ_GEMV_MAX_TOKENS].  x, y dense row-major in desc->dtype.
+ * workspace may be NULL (no kernel needs one today; kept for split-K variants);
+ * use vptq_quant_gemv_workspace_bytes() to size it.
+ */
+VPTQ_API int vptq_quant_gemv(const VptqLayerDesc* desc, const void* x, void* y, int tokens,
+                    int flags, void* workspace, size_t workspace_bytes, void* stream);
+
+VPTQ_API size_t vptq_quant_gemv_workspace_bytes(const VptqLayerDesc* desc, int tokens, int flags);
+
+/*
+ * n independent layers in ONE launch (q/k/v or gate/up projections of a decoder
+ * layer, or any batch of VQuantLinear GEMVs).  descs is a HOST array; x[i], y[i]
+ * are device pointers for layer i.  Every layer must be eligible for the same
+ * kernel family (checked); n <= VPTQ_GROUP_MAX.
+ */
+#define VPTQ_GROUP_MAX 64
+VPTQ_API int vptq_quant_gemv_grouped(const VptqLayerDesc* descs, int n, const void* const* x,
+                            void* const* y, int tokens, int flags, void* stream);
+
+/* W[O, I] dense, row-major, desc->dtype: the reference CPU path's bits. */
+VPTQ_API int vptq_dequant(const VptqLayerDesc* desc, void* W, void* stream);
+
+VPTQ_API int vptq_quant_gemv_v2(const VptqV2Desc* desc, const void* x, void* y, int tokens,
+                       int flags, void* stream);
+
+/* name of the kernel vptq_quant_gemv would launch for (desc, tokens, flags);
+ * static string, for tests / profiles.  NULL if unsupported. */
+VPTQ_API const char* vptq_quant_gemv_kernel_name(const VptqLayerDesc* desc, int tokens, int flags);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VPTQ_HIP_H */

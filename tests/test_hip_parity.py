@@ -1,0 +1,281 @@
+"""GPU parity: the HIP path (through the C ABI) against the oracle and the golden
+vectors produced by the real reference.  Run with `pytest -m gpu` on an MI355X.
+
+Tolerances: outputs within 1e-3 of the reference CPU path,
+measured as max|d| / max|ref| for fp16 (1 fp16 ulp ~ 4.9e-4); bf16 has 8 bits of
+mantissa (ulp 3.9e-3) so its bar is 8e-3.  Dequantised weights are bit-exact.
+"""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vptq_oracle as vo
+from _cases import golden_names, load_golden, rel_err, bit_identical_frac
+from _gpu_util import (spec_to_module, bits_to_tensor, tensor_to_bits, gemv_abi, kernel_name,
+                       TORCH_DT)
+
+pytestmark = pytest.mark.gpu
+TOL = {"f16": 1e-3, "bf16": 8e-3}
+FAST, GENERIC = 1, 2
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from vptq_amd import _backend as B
+    B.lib()  # fail loudly if libvptq_hip.so is missing
+    return torch.device("cuda", 0)
+
+
+# ---------------------------------------------------------------- golden vectors
+@pytest.mark.parametrize("name", golden_names())
+def test_dequant_bit_exact_vs_reference_golden(name, dev):
+    L, x, y, cfg, W_head = load_golden(name)
+    m = spec_to_module(L, dev)
+    W = tensor_to_bits(m.dequant())
+    assert W.shape == (cfg["out_features"], cfg["in_features"])
+    assert (W[:16] == W_head).all()
+    assert hashlib.sha256(W.tobytes()).hexdigest() == cfg["W_sha256"]
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_forward_vs_reference_golden(name, dev):
+    L, x, y, cfg, _ = load_golden(name)
+    dt = cfg["dtype"]
+    m = spec_to_module(L, dev)
+    xt = bits_to_tensor(x, dt, dev).reshape(x.shape)
+    out = tensor_to_bits(m(xt))
+    assert out.shape == y.shape
+    err = rel_err(out, y, dt)
+    assert err <= TOL[dt], f"{name}: {err:.3e}"
+    # against the oracle too (same numbers, different summation order)
+    assert rel_err(out, vo.forward(L, x), dt) <= TOL[dt]
+
+
+@pytest.mark.parametrize("name", [n for n in golden_names() if n.startswith("canon")])
+def test_canonical_layers_take_the_specialised_kernel(name, dev):
+    L, x, y, cfg, _ = load_golden(name)
+    m = spec_to_module(L, dev)
+    assert kernel_name(m, cfg["tokens"]).startswith("gemv_k256_kernel")
+    assert kernel_name(m, cfg["tokens"], GENERIC) == "gemv_generic_kernel"
+    xt = bits_to_tensor(x, cfg["dtype"], dev).reshape(x.shape)
+    a = tensor_to_bits(gemv_abi(m, xt, 0))
+    b = tensor_to_bits(gemv_abi(m, xt, GENERIC))
+    # both rebuild identical weights; only the fp32 summation order differs
+    assert rel_err(a, b, cfg["dtype"]) <= TOL[cfg["dtype"]] / 2
+    assert bit_identical_frac(a, b) > 0.9
+    for out in (a, b):
+        assert rel_err(out, y, cfg["dtype"]) <= TOL[cfg["dtype"]]
+
+
+# ---------------------------------------------------------------- seeded layers vs oracle
+CASES = [
+    # I, O, kwargs, tokens
+    (1024, 512, dict(), 1),
+    (1024, 512, dict(enable_perm=True, bias=True), 2),
+    (4096, 264, dict(), 1),                       # one full sweep, rows not a multiple of 4
+    (4104, 64, dict(), 3),                        # G not a multiple of the sweep (tail lanes)
+    (8192 + 512, 40, dict(dist="llm"), 1),        # > one iteration of two sweeps
+    (512, 1000, dict(dtype="bf16", dist="llm"), 1),
+    (768, 136, dict(num_centroids=4096, num_res_centroids=0, vector_len=6), 4),
+    (640, 250, dict(num_centroids=65536, num_res_centroids=256, dist="llm"), 1),   # T=24, padding
+    (512, 96, dict(num_centroids=8192, num_res_centroids=4096, vector_len=12, dist="llm"), 8),
+    (16 + 2 * 256, 100, dict(num_codebooks=2, outlier_size=16, outlier_vector_len=4,
+                             num_outlier_centroids=64, enable_perm=True, bias=True), 1),
+    (256, 64, dict(enable_norm=False, num_res_centroids=0, num_centroids=16, vector_len=2), 1),
+    (1024, 256, dict(vector_len=16, num_centroids=65536, num_res_centroids=65536, dist="llm"), 2),
+]
+
+
+@pytest.mark.parametrize("I,O,kw,tokens", CASES)
+def test_gemv_and_dequant_vs_oracle(I, O, kw, tokens, dev):
+    kw = dict(kw)
+    dist = kw.pop("dist", "ref-test")
+    L = vo.make_layer(I, O, dist=dist, seed=I + O, **kw)
+    dt = L.dtype
+    rng = np.random.default_rng(5)
+    xs = (0.02 + 0.5 * rng.standard_normal((1, tokens, I))) if dist == "ref-test" \
+        else rng.standard_normal((1, tokens, I))
+    x = vo.from_f32(xs.astype(np.float32), dt)
+    m = spec_to_module(L, dev)
+    W_ref = vo.dequant(L, ref_residual_mask_quirk=False)
+    assert (tensor_to_bits(m.dequant()) == W_ref).all(), "dequant must be bit-exact"
+    want = vo.gemv(W_ref, x, dt, L.bias)
+    got = tensor_to_bits(m(bits_to_tensor(x, dt, dev).reshape(x.shape)))
+    assert got.shape == want.shape
+    err = rel_err(got, want, dt)
+    assert err <= TOL[dt], f"{err:.3e}"
+
+
+@pytest.mark.parametrize("tokens", [1, 2, 3, 4, 5, 8, 9, 33])
+def test_token_counts_gemv_and_gemm_paths(tokens, dev):
+    """1..8 tokens: fused GEMV; more: dequant + F.linear (reference switches at 3)."""
+    L = vo.make_layer(1024, 256, dist="llm", seed=11, bias=True)
+    x = vo.from_f32(np.random.default_rng(tokens).standard_normal((2, tokens, 1024))
+                    .astype(np.float32), "f16")[:1]
+    m = spec_to_module(L, dev)
+    got = tensor_to_bits(m(bits_to_tensor(x, "f16", dev).reshape(x.shape)))
+    want = vo.forward(L, x)
+    assert rel_err(got, want, "f16") <= 1e-3
+
+
+def test_fast_math_flag_within_tolerance(dev):
+    for dist in ("ref-test", "llm"):
+        L = vo.make_layer(4096, 512, dist=dist, seed=3)
+        x = vo.from_f32((np.random.default_rng(1).standard_normal((1, 1, 4096)) *
+                         (0.5 if dist == "ref-test" else 1.0)).astype(np.float32), "f16")
+        m = spec_to_module(L, dev)
+        xt = bits_to_tensor(x, "f16", dev).reshape(x.shape)
+        want = vo.forward(L, x)
+        exact = tensor_to_bits(gemv_abi(m, xt, 0))
+        fast = tensor_to_bits(gemv_abi(m, xt, FAST))
+        assert rel_err(exact, want, "f16") <= 2.5e-4       # rounding-exact weights
+        assert rel_err(fast, want, "f16") <= 1e-3          # folded fp32 form
+        assert bit_identical_frac(exact, want) >= 0.95
+
+
+def test_edge_index_patterns(dev):
+    """all-zero / all-ones streams, cyclic arange (the reference test's pattern)."""
+    I, O = 1024, 512
+    for pattern in ("zeros", "ones", "cyclic"):
+        L = vo.make_layer(I, O, dist="llm", seed=9)
+        if pattern == "zeros":
+            L.indices = np.zeros_like(L.indices)
+        elif pattern == "ones":
+            L.indices = np.full_like(L.indices, -1)
+        else:
+            idx = (np.arange(L.num_indices * I) % 256).reshape(1, L.num_indices, I)
+            L.indices = vo.pack_indices(idx, 8, (idx * 7 + 3) % 256, 8)
+        x = vo.from_f32(np.random.default_rng(2).standard_normal((1, 1, I)).astype(np.float32), "f16")
+        m = spec_to_module(L, dev)
+        assert (tensor_to_bits(m.dequant()) == vo.dequant(L)).all()
+        got = tensor_to_bits(m(bits_to_tensor(x, "f16", dev).reshape(x.shape)))
+        assert rel_err(got, vo.forward(L, x), "f16") <= 1e-3
+
+
+# ---------------------------------------------------------------- BASELINE sizes
+@pytest.mark.parametrize("H", [4096, 8192])
+def test_full_size_layers_properties(H, dev):
+    """At BASELINE.json sizes the numpy oracle is slow, so: (a) oracle on a random
+    subset of vector-rows, (b) HIP GEMV == HIP dequant followed by an fp32 matmul
+    (two independent kernels), (c) specialised == generic kernel."""
+    L = vo.make_layer(H, H, dist="llm", seed=H)
+    rng = np.random.default_rng(7)
+    x = vo.from_f32(rng.standard_normal((1, 1, H)).astype(np.float32), "f16")
+    m = spec_to_module(L, dev)
+    assert kernel_name(m, 1).startswith("gemv_k256_kernel")
+    xt = bits_to_tensor(x, "f16", dev).reshape(x.shape)
+    y = m(xt)
+    got = tensor_to_bits(y)
+    # (a) oracle on 48 random vector-rows
+    rows = np.sort(rng.choice(L.num_indices, 48, replace=False))
+    sub = vo.LayerSpec(H, 48 * 8, 8, 256, 256, 1, H, dtype="f16")
+    sub.indices = L.indices[:, rows, :]
+    sub.centroids, sub.res_centroids = L.centroids, L.res_centroids
+    sub.weight_scale, sub.weight_bias = L.weight_scale, L.weight_bias
+    want = vo.forward(sub, x).reshape(48, 8)
+    mine = got.reshape(-1, 8)[rows]
+    scale = np.abs(vo.to_f32(got, "f16")).max()
+    d = np.abs(vo.to_f32(mine, "f16") - vo.to_f32(want, "f16")).max()
+    assert d / scale <= 1e-3
+    # (b) dequant + fp32 matmul on the GPU
+    W = m.dequant()
+    ref = (xt.float().reshape(1, H) @ W.float().t()).reshape(-1)
+    assert ((y.float().reshape(-1) - ref).abs().max() / ref.abs().max()).item() <= 1e-3
+    # (c) generic kernel
+    g = gemv_abi(m, xt, GENERIC)
+    assert ((y.float() - g.float()).abs().max() / ref.abs().max()).item() <= 5e-4
+    # W sub-block bit-exact vs oracle
+    Wb = tensor_to_bits(W).reshape(L.num_indices, 8, H)[rows].reshape(48 * 8, H)
+    assert (Wb == vo.dequant(sub)).all()
+
+
+def test_grouped_launch_matches_single(dev):
+    from vptq_amd import _backend as B
+    import ctypes as C
+    shapes = [(2048, 1024), (2048, 256), (2048, 256)]       # q / k / v of one decoder layer
+    mods, xs, singles = [], [], []
+    x = bits_to_tensor(vo.from_f32(np.random.default_rng(0).standard_normal((1, 1, 2048))
+                                   .astype(np.float32), "f16"), "f16", dev).reshape(1, 1, 2048)
+    for i, (I, O) in enumerate(shapes):
+        m = spec_to_module(vo.make_layer(I, O, dist="llm", seed=20 + i), dev)
+        mods.append(m)
+        singles.append(m(x))
+    descs = (B.LayerDesc * len(mods))()
+    keep = []
+    for i, m in enumerate(mods):
+        from _gpu_util import module_desc
+        d, k = module_desc(m)
+        descs[i] = d
+        keep.append(k)
+    ys = [torch.empty_like(s) for s in singles]
+    xp = (C.c_void_p * 3)(*[x.data_ptr()] * 3)
+    yp = (C.c_void_p * 3)(*[t.data_ptr() for t in ys])
+    B.check(B.lib().vptq_quant_gemv_grouped(descs, 3, xp, yp, 1, 0,
+                                            B.current_stream_ptr(dev)), "grouped")
+    torch.cuda.synchronize()
+    for a, b in zip(singles, ys):
+        assert torch.equal(a, b)
+
+
+def test_hipgraph_capture_of_the_forward(dev):
+    L = vo.make_layer(4096, 4096, dist="llm", seed=1)
+    m = spec_to_module(L, dev)
+    x = torch.randn(1, 1, 4096, device=dev, dtype=torch.float16)
+    eager = m(x)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        m(x)  # warm-up on the side stream
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=s):
+            out = m(x)
+    x.copy_(torch.randn_like(x))
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, m(x)) and not torch.equal(out, eager)
+
+
+# ---------------------------------------------------------------- v2 wire format
+V2_CONFIGS = [
+    dict(in_features=1024, out_features=2048, num_centroids=8192, num_res_centroids=256),  # uint8 ids
+    dict(in_features=1024, out_features=1024, num_centroids=8192, num_res_centroids=512),  # uint16 ids
+]
+
+
+@pytest.mark.parametrize("cfg", V2_CONFIGS)
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_quant_gemv_v2_reference_test_shapes(cfg, dtype, dev):
+    """Same data recipe as the reference's only kernel test
+    (tests/test_quant_gemv.py:112-171): seed 1234, normal(0.02, 0.5), cyclic ids."""
+    import vptq_amd
+    torch.manual_seed(1234)
+    I, O, k, kr, v = (cfg["in_features"], cfg["out_features"], cfg["num_centroids"],
+                      cfg["num_res_centroids"], 8)
+    dt = TORCH_DT[dtype]
+
+    def nrm(*shape):
+        return torch.normal(mean=0.02, std=0.5, size=shape, device=dev, dtype=dt)
+
+    x, cent, rcent = nrm(1, 1, I), nrm(1, k, v), nrm(1, kr, v)
+    sw, sb = nrm(I, 1), nrm(I, 1)
+    n = I * O // v
+    ids = torch.arange(k, device=dev, dtype=torch.int32).repeat(n // k).to(torch.uint16)
+    rids = torch.arange(kr, device=dev, dtype=torch.int32).repeat(n // kr).to(
+        torch.uint16 if kr > 256 else torch.uint8)
+    out = vptq_amd.ops.quant_gemv_v2(
+        x=x, bias=None, indices=ids, centroids=cent, residual_indices=rids,
+        residual_centroids=rcent, scale_weights=sw, scale_bias=sb, vector_len=v,
+        num_codebooks=1, num_centroids=k, num_residual_centroids=kr, out_features=O)
+    want = vo.gemv_v2_ground_truth(
+        tensor_to_bits(x), None, ids.cpu().numpy().astype(np.int64), tensor_to_bits(cent),
+        rids.cpu().numpy().astype(np.int64), tensor_to_bits(rcent), tensor_to_bits(sw),
+        tensor_to_bits(sb), v, O, dtype)
+    got = tensor_to_bits(out)
+    assert rel_err(got, want, dtype) <= TOL[dtype]
+    # the reference's own (loose) criterion: rtol = atol = 0.2
+    a, b = vo.to_f32(got, dtype), vo.to_f32(want, dtype)
+    assert np.allclose(a, b, rtol=0.2, atol=0.2)

@@ -1,0 +1,189 @@
+"""CPU-side checks: C ABI exports, host format tools, module contract, loud failure."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import vptq_amd
+from vptq_amd import _backend as B
+from vptq_amd.utils.pack import pack_index, unpack_index_tensor
+from oracle import vptq_oracle as vo
+from _cases import golden_names, load_golden
+from _gpu_util import spec_to_module
+from _refshim import reference_available
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "vptq_hip.h")).read()
+    return sorted(set(re.findall(r"VPTQ_API[^;(]*?\b(vptq_\w+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol():
+    syms = _declared_symbols()
+    assert len(syms) >= 8, syms
+    assert os.path.exists(B.LIB_PATH), "build libvptq_hip.so first (__graft_entry__.build())"
+    lib = ctypes.CDLL(B.LIB_PATH)
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/vptq_hip.h but not exported"
+    assert sorted(B.EXPORTS) == syms, "python binding table out of sync with the header"
+    lib.vptq_abi_version.restype = ctypes.c_int
+    assert lib.vptq_abi_version() == B.ABI_VERSION == 1
+
+
+def test_ctypes_struct_layout_matches_header():
+    # 16 int32 + 10 pointers; 8 int32 + 7 pointers
+    assert ctypes.sizeof(B.LayerDesc) == 16 * 4 + 10 * 8
+    assert ctypes.sizeof(B.V2Desc) == 8 * 4 + 7 * 8
+    hdr = open(os.path.join(ROOT, "include", "vptq_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    body = hdr[hdr.index("typedef struct VptqLayerDesc {"):hdr.index("} VptqLayerDesc;")]
+    names = re.findall(r"\b(\w+);", body)
+    assert names == [n for n, _ in B.LayerDesc._fields_]
+    body = hdr[hdr.index("typedef struct VptqV2Desc {"):hdr.index("} VptqV2Desc;")]
+    names = re.findall(r"\b(\w+);", body)
+    assert names == [n for n, _ in B.V2Desc._fields_]
+
+
+def test_validation_errors_without_gpu():
+    """The C ABI validates before launching: exercisable with no device."""
+    lib = B.lib()
+    d = B.LayerDesc()
+    rc = lib.vptq_quant_gemv(d, None, None, 1, 0, None, 0, None)
+    assert rc < 0 and b"NULL" in lib.vptq_last_error()
+    d.indices, d.centroids = 16, 16   # fake non-null pointers; nothing is dereferenced
+    d.dtype = 7
+    assert lib.vptq_quant_gemv(d, 16, 16, 1, 0, None, 0, None) == -3
+    d.dtype = 0
+    d.vector_len = 7
+    assert lib.vptq_quant_gemv(d, 16, 16, 1, 0, None, 0, None) == -3
+    d.vector_len, d.in_features, d.out_features = 8, 64, 64
+    d.num_codebooks, d.group_size = 1, 32           # 32 != 64
+    assert lib.vptq_quant_gemv(d, 16, 16, 1, 0, None, 0, None) == -2
+    d.group_size = 64
+    d.num_centroids, d.index_bits = 256, 8
+    d.row_words, d.num_indices = 16, 8
+    assert lib.vptq_quant_gemv(d, 16, 16, 0, 0, None, 0, None) == -5      # tokens
+    assert lib.vptq_quant_gemv(d, 16, 16, 99, 0, None, 0, None) == -5
+    d.row_words = 3
+    assert lib.vptq_quant_gemv(d, 16, 16, 1, 0, None, 0, None) == -2      # row too short
+    d.row_words = 16
+    d.perm = 16
+    assert lib.vptq_dequant(d, 16, None) == -1                             # needs inv_perm
+    assert lib.vptq_quant_gemv_kernel_name(d, 1, 0) == b"gemv_generic_kernel"
+    v2 = B.V2Desc()
+    assert lib.vptq_quant_gemv_v2(v2, 16, 16, 1, 0, None) == -1
+    v2.indices = v2.centroids = 16
+    v2.vector_len, v2.in_features, v2.out_features, v2.num_centroids = 8, 32, 64, 8192
+    assert lib.vptq_quant_gemv_v2(v2, 16, 16, 16, 0, None) == -5           # tokens < 16
+
+
+def test_cpu_tensors_raise_no_silent_fallback():
+    L, x, y, cfg, _ = load_golden("canon_k256x2")
+    m = spec_to_module(L, "cpu")
+    xt = torch.zeros(1, 1, L.in_features, dtype=torch.float16)
+    with pytest.raises(RuntimeError, match="no CPU fallback|ROCm devices only"):
+        m(xt)
+    with pytest.raises(RuntimeError):
+        m.dequant()
+
+
+@pytest.mark.parametrize("ib,rb,G", [(8, 8, 64), (12, 0, 7), (13, 8, 33), (16, 8, 5),
+                                     (16, 16, 3), (4, 2, 1), (10, 4, 96), (12, 12, 128)])
+def test_pack_tools_match_oracle(ib, rb, G):
+    rng = np.random.default_rng(ib * 100 + rb)
+    idx = rng.integers(0, 1 << ib, size=(2, 3, G))
+    r = rng.integers(0, 1 << rb, size=(2, 3, G)) if rb else None
+    want = vo.pack_indices(idx, ib, r, rb)
+    ti = torch.from_numpy(idx.astype(np.uint16).view(np.int16))
+    tr = torch.from_numpy(r.astype(np.uint16).view(np.int16)) if rb else None
+    got = pack_index(ti, ib, tr, rb)
+    assert got.dtype == torch.int32 and (got.numpy() == want).all()
+    a, b = unpack_index_tensor(got, ib, G, rb, G)
+    assert (a.numpy() == idx).all()
+    if rb:
+        assert (b.numpy() == r).all()
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_module_state_dict_contract(name):
+    """Names / shapes / dtypes are the on-disk contract of HF checkpoints."""
+    L, x, y, cfg, _ = load_golden(name)
+    m = spec_to_module(L, "cpu")
+    sd = m.state_dict()
+    I, O, v, C = L.in_features, L.out_features, L.vector_len, L.num_codebooks
+    T = L.index_bits + L.res_bits
+    assert sd["indices"].dtype == torch.int32
+    assert tuple(sd["indices"].shape) == (C, L.num_indices, (L.group_size * T + 31) // 32)
+    assert tuple(sd["centroids.weight"].shape) == (C, L.num_centroids * v)
+    assert ("res_centroids.weight" in sd) == (L.num_res_centroids > 0)
+    assert "res_indices" not in sd
+    if L.perm is not None:
+        assert sd["perm"].dtype == torch.int16 and tuple(sd["perm"].shape) == (I,)
+    if L.enable_outlier:
+        assert sd["outlier_indices"].dtype == torch.int16
+        assert tuple(sd["outlier_centroids.weight"].shape) == (
+            1, L.num_outlier_centroids * L.outlier_vector_len)
+    if L.weight_scale is not None:
+        assert tuple(sd["weight_scale"].shape) == (I,) and tuple(sd["weight_bias"].shape) == (I,)
+    assert ("bias" in sd) == (L.bias is not None)
+
+
+@pytest.mark.skipif(not reference_available(), reason="/root/reference not mounted")
+def test_module_matches_reference_state_dict_and_meta_init():
+    import gen_golden as gg
+    from _refshim import load_reference
+    ref = load_reference()
+    for name, I, O, kw, dtype, tokens, dist in gg.CASES:
+        C, S = kw["group_num"], kw["outlier_size"]
+        G = (I - S) // C
+        common = dict(group_size=G, indices_as_float=False, is_indice_packed=True,
+                      dtype=gg.TORCH_DT[dtype], enable_proxy_error=False, **kw)
+        rm = ref.VQuantLinear(I, O, **common)
+        with torch.device("meta"):
+            mm = vptq_amd.VQuantLinear(I, O, **common)
+        rs, ms = rm.state_dict(), mm.state_dict()
+        assert list(rs) == list(ms), name
+        for k in rs:
+            assert rs[k].shape == ms[k].shape and rs[k].dtype == ms[k].dtype, (name, k)
+        for attr in ("padding", "num_indices", "outlier_padding", "vector_len", "num_codebooks",
+                     "num_centroids", "num_res_centroids", "enable_outlier", "enable_residual"):
+            assert getattr(rm, attr) == getattr(mm, attr), (name, attr)
+
+
+def test_vptq_alias_for_hf():
+    import sys
+    # other tests may have imported the REFERENCE under the name `vptq`
+    saved = {k: sys.modules.pop(k) for k in list(sys.modules)
+             if k == "vptq" or k.startswith("vptq.")}
+    try:
+        _check_alias()
+    finally:
+        for k in [k for k in sys.modules if k == "vptq" or k.startswith("vptq.")]:
+            del sys.modules[k]
+        sys.modules.update(saved)
+
+
+def _check_alias():
+    import vptq
+    assert vptq.__file__.startswith(ROOT)
+    assert vptq.VQuantLinear is vptq_amd.VQuantLinear
+    from packaging.version import Version
+    assert Version(vptq.__version__) >= Version("0.0.4")
+    import vptq.ops
+    assert vptq.ops.quant_gemm is vptq_amd.ops.quant_gemm
+    assert hasattr(vptq.ops, "dequant") and hasattr(vptq.ops, "quant_gemv_v2")
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: the package must not reference it."""
+    pkg = os.path.join(ROOT, "vptq_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dp, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f

@@ -1,0 +1,139 @@
+#!/usr/bin/env python3
+"""Kernel A/B micro-benchmark for the decode GEMV (GPU box only).
+
+    python tools/microbench.py --hidden 8192 [--ring 32] [--iters 20]
+
+Times, with HIP events on the launch stream, for each arithmetic/kernel variant:
+  ring   : R distinct layers (R * packed bytes >= 512 MiB so neither L2 nor the
+           256 MiB Infinity Cache can hold them), one launch per layer,
+           replayed from a hipGraph  -> us per launch INCLUDING launch gaps
+  hot    : the same layer over and over (cache resident)
+  group  : the R layers in ceil(R/32) grouped launches
+Env knobs read by the library at first use: VPTQ_K256_TAB=0|1, VPTQ_K256_REDUCE=0|1.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import vptq_amd  # noqa: E402
+from vptq_amd import _backend as B  # noqa: E402
+
+
+def make_layers(H, R, dev, perm=False):
+    g = torch.Generator(device=dev).manual_seed(1234)
+    layers = []
+    for _ in range(R):
+        m = vptq_amd.VQuantLinear(H, H, vector_lens=[-1, 8], num_centroids=[-1, 256],
+                                  num_res_centroids=[-1, 256], group_num=1, group_size=H,
+                                  outlier_size=0, indices_as_float=False, enable_norm=True,
+                                  enable_perm=perm, is_indice_packed=True, bias=False,
+                                  dtype=torch.float16, device=dev, enable_proxy_error=False)
+        m.indices.data = torch.randint(-2**31, 2**31 - 1, m.indices.shape, generator=g,
+                                       device=dev, dtype=torch.int64).to(torch.int32)
+        m.centroids.weight.data = (torch.randn(m.centroids.weight.shape, generator=g, device=dev) * 0.02).half()
+        m.res_centroids.weight.data = (torch.randn(m.res_centroids.weight.shape, generator=g, device=dev) * 0.005).half()
+        m.weight_scale.data = (1 + 0.1 * torch.randn(H, generator=g, device=dev)).half()
+        m.weight_bias.data = (0.01 * torch.randn(H, generator=g, device=dev)).half()
+        if perm:
+            m.perm.data = torch.randperm(H, generator=g, device=dev).to(torch.int32).to(torch.int16)
+        layers.append(m)
+    return layers
+
+
+def alg_bytes(H, perm=False):
+    return H // 8 * (H * 16 // 32) * 4 + 2 * 256 * 8 * 2 + 2 * H + 4 * H + (2 * H if perm else 0) + 2 * H
+
+
+def time_graph(fn, iters, warm=3):
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            fn()
+        g.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(s)
+        for _ in range(iters):
+            g.replay()
+        e1.record(s)
+        torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / iters  # us per replay
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--hidden", type=int, default=8192)
+    ap.add_argument("--ring", type=int, default=0)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--perm", action="store_true")
+    ap.add_argument("--out", default="")
+    a = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    H = a.hidden
+    idx_bytes = H // 8 * H * 2
+    R = a.ring or max(2, (512 << 20) // idx_bytes)
+    layers = make_layers(H, R, dev, a.perm)
+    x = torch.randn(1, 1, H, device=dev, dtype=torch.float16)
+    ab = alg_bytes(H, a.perm)
+    lib = B.lib()
+    st = None
+    res = dict(hidden=H, ring=R, alg_bytes=ab, env={k: v for k, v in os.environ.items() if k.startswith("VPTQ_")})
+
+    # calibration: plain device copy of 1 GiB
+    src = torch.empty(1 << 28, dtype=torch.float32, device=dev); dst = torch.empty_like(src)
+    t = time_graph(lambda: dst.copy_(src), 10)
+    res["copy_1GiB_TBps"] = 2 * src.numel() * 4 / t / 1e6
+    del src, dst
+
+    from tests_gpu_util import module_desc  # noqa
+    descs, keeps, ys = [], [], []
+    for m in layers:
+        d, k = module_desc(m)
+        descs.append(d); keeps.append(k); ys.append(torch.empty(1, 1, H, device=dev, dtype=torch.float16))
+
+    def launch_one(i, flags):
+        rc = lib.vptq_quant_gemv(descs[i], x.data_ptr(), ys[i].data_ptr(), 1, flags, None, 0,
+                                 torch.cuda.current_stream().cuda_stream)
+        assert rc == 0, lib.vptq_last_error()
+
+    arr = (B.LayerDesc * R)(*descs)
+    xp = (C.c_void_p * R)(*[x.data_ptr()] * R)
+    yp = (C.c_void_p * R)(*[y.data_ptr() for y in ys])
+
+    def launch_group(flags):
+        rc = lib.vptq_quant_gemv_grouped(arr, R, xp, yp, 1, flags,
+                                         torch.cuda.current_stream().cuda_stream)
+        assert rc == 0, lib.vptq_last_error()
+
+    for name, flags in (("exact", 0), ("fast", 1), ("generic", 2)):
+        ring = time_graph(lambda: [launch_one(i, flags) for i in range(R)], a.iters) / R
+        hot = time_graph(lambda: [launch_one(0, flags) for _ in range(R)], a.iters) / R
+        r = dict(ring_us=ring, ring_TBps=ab / ring / 1e6, hot_us=hot, hot_TBps=ab / hot / 1e6)
+        if flags != 2:
+            grp = time_graph(lambda: launch_group(flags), a.iters) / R
+            r.update(group_us=grp, group_TBps=ab / grp / 1e6)
+        res[name] = r
+        print(name, json.dumps(r), flush=True)
+    print(json.dumps(res))
+    if a.out:
+        os.makedirs(os.path.dirname(a.out), exist_ok=True)
+        with open(a.out, "w") as f:
+            json.dump(res, f, indent=1)
+
+
+if __name__ == "__main__":
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _gpu_util
+    sys.modules["tests_gpu_util"] = _gpu_util
+    main()

@@ -1,0 +1,197 @@
+"""ctypes binding of libvptq_hip.so (C ABI: include/vptq_hip.h).
+
+This is the only place the package talks to native code.  There is NO CPU or
+pure-torch fallback: if the library is missing, or a tensor is not on a ROCm
+device, the ops raise (the reference instead prints a warning and silently runs
+"extremely slow" torch code, vptq/ops/quant_gemm.py:28-40).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvptq_hip.so")
+
+ABI_VERSION = 1
+DTYPE_F16, DTYPE_BF16 = 0, 1
+GEMV_FAST_MATH = 1 << 0
+GEMV_FORCE_GENERIC = 1 << 1
+GEMV_MAX_TOKENS = 8
+GROUP_MAX = 64
+
+_vp = C.c_void_p
+
+
+class LayerDesc(C.Structure):
+    """Mirror of `VptqLayerDesc` (include/vptq_hip.h)."""
+    _fields_ = [(n, C.c_int32) for n in (
+        "in_features", "out_features", "vector_len", "num_codebooks", "group_size",
+        "num_centroids", "num_res_centroids", "index_bits", "res_bits", "row_words",
+        "num_indices", "outlier_size", "outlier_vector_len", "num_outlier_centroids",
+        "num_outlier_indices", "dtype")] + [(n, _vp) for n in (
+            "indices", "centroids", "res_centroids", "outlier_indices", "outlier_centroids",
+            "perm", "inv_perm", "weight_scale", "weight_bias", "bias")]
+
+
+class V2Desc(C.Structure):
+    """Mirror of `VptqV2Desc`."""
+    _fields_ = [(n, C.c_int32) for n in (
+        "in_features", "out_features", "vector_len", "num_centroids", "num_res_centroids",
+        "res_index_bytes", "dtype", "reserved")] + [(n, _vp) for n in (
+            "indices", "centroids", "res_indices", "res_centroids", "scale_weights",
+            "scale_bias", "bias")]
+
+
+# every symbol include/vptq_hip.h declares: (restype, argtypes)
+EXPORTS = {
+    "vptq_abi_version": (C.c_int, []),
+    "vptq_last_error": (C.c_char_p, []),
+    "vptq_quant_gemv": (C.c_int, [C.POINTER(LayerDesc), _vp, _vp, C.c_int, C.c_int, _vp,
+                                  C.c_size_t, _vp]),
+    "vptq_quant_gemv_workspace_bytes": (C.c_size_t, [C.POINTER(LayerDesc), C.c_int, C.c_int]),
+    "vptq_quant_gemv_grouped": (C.c_int, [C.POINTER(LayerDesc), C.c_int, C.POINTER(_vp),
+                                          C.POINTER(_vp), C.c_int, C.c_int, _vp]),
+    "vptq_dequant": (C.c_int, [C.POINTER(LayerDesc), _vp, _vp]),
+    "vptq_quant_gemv_v2": (C.c_int, [C.POINTER(V2Desc), _vp, _vp, C.c_int, C.c_int, _vp]),
+    "vptq_quant_gemv_kernel_name": (C.c_char_p, [C.POINTER(LayerDesc), C.c_int, C.c_int]),
+}
+
+_lib = None
+
+
+class VptqBackendError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libvptq_hip.so once; raise loudly if it is not there."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise VptqBackendError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` or `make -C vptq_amd/csrc`.  vptq_amd has no CPU / torch fallback.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in EXPORTS.items():
+            fn = getattr(l, name)  # AttributeError = ABI mismatch, also loud
+            fn.restype, fn.argtypes = res, args
+        if l.vptq_abi_version() != ABI_VERSION:
+            raise VptqBackendError(
+                f"ABI mismatch: library {l.vptq_abi_version()} vs binding {ABI_VERSION}")
+        _lib = l
+    return _lib
+
+
+def is_available() -> bool:
+    return os.path.exists(LIB_PATH)
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = lib().vptq_last_error().decode(errors="replace")
+        raise RuntimeError(f"{what} failed (code {rc}): {msg}")
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    if dt == torch.float16:
+        return DTYPE_F16
+    if dt == torch.bfloat16:
+        return DTYPE_BF16
+    raise TypeError(f"vptq_amd supports float16 / bfloat16 activations, got {dt}")
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def require_device(*tensors: Optional[torch.Tensor]):
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise VptqBackendError(
+                "vptq_amd runs on ROCm devices only; got a tensor on "
+                f"{t.device}.  There is no CPU fallback.")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError(f"tensors on different devices: {dev} vs {t.device}")
+        if not t.is_contiguous():
+            raise RuntimeError("vptq_amd needs contiguous tensors")
+    return dev
+
+
+def current_stream_ptr(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+_invperm_cache = {}
+
+
+def inverse_perm(perm: torch.Tensor) -> torch.Tensor:
+    """argsort(perm) as int16 (uint16 bit pattern), cached per tensor version.
+
+    The reference recomputes this with a sort kernel on EVERY forward
+    (vptq/ops/quant_gemm.py:208-211)."""
+    key = (perm.data_ptr(), perm._version, perm.numel(), perm.device)
+    hit = _invperm_cache.get(key)
+    if hit is None:
+        p = perm.view(torch.int16).to(torch.int64) & 0xFFFF
+        inv = torch.argsort(p)
+        # store the uint16 bit pattern in an int16 tensor
+        hit = torch.where(inv >= 32768, inv - 65536, inv).to(torch.int16)
+        if len(_invperm_cache) > 4096:
+            _invperm_cache.clear()
+        _invperm_cache[key] = hit
+    return hit
+
+
+def make_layer_desc(*, indices, centroids, res_centroids, outlier_indices, outlier_centroids,
+                    perm, weight_scale, weight_bias, bias, in_features, out_features,
+                    vector_len, num_codebooks, num_centroids, num_res_centroids, group_size,
+                    outlier_size, outlier_vector_len, num_outlier_centroids,
+                    need_inv_perm=False):
+    """Build a LayerDesc from reference-format tensors.  Returns (desc, keepalive)."""
+    if indices.dtype != torch.int32:
+        # reference: TORCH_CHECK_EQ(q_indice.dtype(), torch::kInt) (csrc/quant_gemv.cu:258)
+        raise RuntimeError("`indices` must be packed int32 (is_indice_packed=True)")
+    d = LayerDesc()
+    d.in_features, d.out_features = in_features, out_features
+    d.vector_len, d.num_codebooks, d.group_size = vector_len, num_codebooks, group_size
+    d.num_centroids = num_centroids
+    kr = num_res_centroids if (res_centroids is not None and num_res_centroids > 0) else 0
+    d.num_res_centroids = kr
+    d.index_bits = int(math.ceil(math.log2(num_centroids)))
+    d.res_bits = int(math.ceil(math.log2(kr))) if kr > 0 else 0
+    d.row_words = indices.shape[-1]
+    d.num_indices = (out_features + vector_len - 1) // vector_len
+    has_out = outlier_centroids is not None and outlier_size > 0
+    d.outlier_size = outlier_size if has_out else 0
+    d.outlier_vector_len = outlier_vector_len if has_out else 0
+    d.num_outlier_centroids = num_outlier_centroids if has_out else 0
+    d.num_outlier_indices = ((out_features + outlier_vector_len - 1) // outlier_vector_len
+                             if has_out else 0)
+    d.dtype = dtype_code(centroids.dtype)
+    keep = [indices, centroids, res_centroids, outlier_indices, outlier_centroids, perm,
+            weight_scale, weight_bias, bias]
+    d.indices, d.centroids = _ptr(indices), _ptr(centroids)
+    d.res_centroids = _ptr(res_centroids) if kr > 0 else None
+    d.outlier_indices = _ptr(outlier_indices) if has_out else None
+    d.outlier_centroids = _ptr(outlier_centroids) if has_out else None
+    d.perm = _ptr(perm)
+    d.inv_perm = None
+    if perm is not None and need_inv_perm:
+        inv = inverse_perm(perm)
+        keep.append(inv)
+        d.inv_perm = _ptr(inv)
+    norm = weight_scale is not None and weight_bias is not None
+    d.weight_scale = _ptr(weight_scale) if norm else None
+    d.weight_bias = _ptr(weight_bias) if norm else None
+    d.bias = _ptr(bias)
+    return d, keep

@@ -1,0 +1,206 @@
+// C ABI of libvptq_hip.so (declared in include/vptq_hip.h): argument validation,
+// kernel selection, launch.  No allocation, no synchronisation, no torch.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "kernels.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+int hip_fail(hipError_t e, const char* what) {
+  snprintf(g_err, sizeof(g_err), "%s: %s (hipError %d)", what, hipGetErrorString(e), (int)e);
+  return (int)e;
+}
+
+bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+int ilog2(int v) { int b = 0; while ((1 << b) < v) ++b; return b; }
+
+// Shape / pointer checks shared by gemv and dequant.  Mirrors what the reference
+// asserts with TORCH_CHECK (csrc/quant_gemv.cu:252-282, csrc/dequant.cu:239-275)
+// plus the shape algebra of VQuantLinear.__init__ (vptq/layers/vqlinear.py:97-240).
+int validate_layer(const VptqLayerDesc* d) {
+  if (!d) return fail(VPTQ_E_NULL, "desc is NULL");
+  if (!d->indices || !d->centroids) return fail(VPTQ_E_NULL, "indices/centroids is NULL");
+  if (d->dtype != VPTQ_DTYPE_F16 && d->dtype != VPTQ_DTYPE_BF16)
+    return fail(VPTQ_E_UNSUPPORTED, "dtype %d: only f16 (0) / bf16 (1)", d->dtype);
+  const int v = d->vector_len;
+  if (!(v == 2 || v == 4 || v == 6 || v == 8 || v == 10 || v == 12 || v == 16))
+    return fail(VPTQ_E_UNSUPPORTED, "un-supported vector_len %d", v);
+  if (d->in_features <= 0 || d->out_features <= 0 || d->num_codebooks <= 0 || d->group_size <= 0)
+    return fail(VPTQ_E_SHAPE, "non-positive dimension");
+  if (d->outlier_size < 0 ||
+      d->in_features != d->outlier_size + d->num_codebooks * d->group_size)
+    return fail(VPTQ_E_SHAPE, "in_features %d != outlier_size %d + %d*%d", d->in_features,
+                d->outlier_size, d->num_codebooks, d->group_size);
+  if (!pow2(d->num_centroids) || d->num_centroids > 65536)
+    return fail(VPTQ_E_SHAPE, "num_centroids %d must be a power of two <= 65536",
+                d->num_centroids);
+  if (d->index_bits != ilog2(d->num_centroids))
+    return fail(VPTQ_E_SHAPE, "index_bits %d != log2(num_centroids)", d->index_bits);
+  if (d->num_res_centroids < 0 ||
+      (d->num_res_centroids > 0 &&
+       (!pow2(d->num_res_centroids) || d->num_res_centroids > 65536)))
+    return fail(VPTQ_E_SHAPE, "num_res_centroids %d must be 0 or a power of two <= 65536",
+                d->num_res_centroids);
+  if (d->res_bits != (d->num_res_centroids > 0 ? ilog2(d->num_res_centroids) : 0))
+    return fail(VPTQ_E_SHAPE, "res_bits %d != log2(num_res_centroids)", d->res_bits);
+  if ((d->num_res_centroids > 0) != (d->res_centroids != nullptr))
+    return fail(VPTQ_E_NULL, "res_centroids must be set iff num_res_centroids > 0");
+  const int T = d->index_bits + d->res_bits;
+  if (T < 1 || T > 32) return fail(VPTQ_E_SHAPE, "total index bits %d outside [1, 32]", T);
+  const long long need_words = ((long long)d->group_size * T + 31) / 32;
+  if (d->row_words < need_words)
+    return fail(VPTQ_E_SHAPE, "row_words %d < ceil(group_size*bits/32) = %lld", d->row_words,
+                need_words);
+  if (d->num_indices != (d->out_features + v - 1) / v)
+    return fail(VPTQ_E_SHAPE, "num_indices %d != ceil(out_features/vector_len)", d->num_indices);
+  if (d->outlier_size > 0) {
+    if (!d->outlier_indices || !d->outlier_centroids)
+      return fail(VPTQ_E_NULL, "outlier tensors required when outlier_size > 0");
+    if (d->outlier_vector_len < 1 || d->num_outlier_centroids < 1 ||
+        d->num_outlier_centroids > 65536)
+      return fail(VPTQ_E_SHAPE, "bad outlier codebook shape");
+    if (d->num_outlier_indices !=
+        (d->out_features + d->outlier_vector_len - 1) / d->outlier_vector_len)
+      return fail(VPTQ_E_SHAPE, "num_outlier_indices != ceil(out_features/outlier_vector_len)");
+  }
+  if ((d->weight_scale != nullptr) != (d->weight_bias != nullptr))
+    return fail(VPTQ_E_NULL, "weight_scale and weight_bias must both be set or both NULL");
+  if (d->perm && d->in_features > 65536)
+    return fail(VPTQ_E_SHAPE, "perm is uint16: in_features must be <= 65536");
+  if (((uintptr_t)d->indices | (uintptr_t)d->centroids | (uintptr_t)d->res_centroids) & 3)
+    return fail(VPTQ_E_ALIGN, "indices / codebooks must be 4-byte aligned");
+  return VPTQ_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vptq_abi_version(void) { return VPTQ_ABI_VERSION; }
+
+const char* vptq_last_error(void) { return g_err; }
+
+size_t vptq_quant_gemv_workspace_bytes(const VptqLayerDesc*, int, int) { return 0; }
+
+const char* vptq_quant_gemv_kernel_name(const VptqLayerDesc* d, int tokens, int flags) {
+  if (validate_layer(d) != VPTQ_OK || tokens < 1 || tokens > VPTQ_GEMV_MAX_TOKENS) return nullptr;
+  if (!(flags & VPTQ_GEMV_FORCE_GENERIC) && vptq::gemv_k256_eligible(*d, tokens))
+    return vptq::gemv_k256_name(*d, tokens, flags);
+  return "gemv_generic_kernel";
+}
+
+int vptq_quant_gemv(const VptqLayerDesc* d, const void* x, void* y, int tokens, int flags,
+                    void* workspace, size_t workspace_bytes, void* stream) {
+  (void)workspace; (void)workspace_bytes;
+  int rc = validate_layer(d);
+  if (rc) return rc;
+  if (!x || !y) return fail(VPTQ_E_NULL, "x / y is NULL");
+  if (tokens < 1 || tokens > VPTQ_GEMV_MAX_TOKENS)
+    return fail(VPTQ_E_TOKENS, "tokens %d outside [1, %d]: use vptq_dequant + GEMM", tokens,
+                VPTQ_GEMV_MAX_TOKENS);
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e;
+  if (!(flags & VPTQ_GEMV_FORCE_GENERIC) && vptq::gemv_k256_eligible(*d, tokens) &&
+      (((uintptr_t)x) & 15) == 0) {
+    e = vptq::launch_gemv_k256(d, 1, &x, &y, tokens, flags, st);
+    if (e != hipSuccess) return hip_fail(e, "gemv_k256 launch");
+    return VPTQ_OK;
+  }
+  e = vptq::launch_gemv_generic(*d, x, y, tokens, st);
+  if (e != hipSuccess) return hip_fail(e, "gemv_generic launch");
+  return VPTQ_OK;
+}
+
+int vptq_quant_gemv_grouped(const VptqLayerDesc* descs, int n, const void* const* x,
+                            void* const* y, int tokens, int flags, void* stream) {
+  if (!descs || !x || !y) return fail(VPTQ_E_NULL, "descs / x / y is NULL");
+  if (n < 1 || n > VPTQ_GROUP_MAX) return fail(VPTQ_E_SHAPE, "n %d outside [1, %d]", n, VPTQ_GROUP_MAX);
+  if (tokens < 1 || tokens > VPTQ_GEMV_MAX_TOKENS)
+    return fail(VPTQ_E_TOKENS, "tokens %d outside [1, %d]", tokens, VPTQ_GEMV_MAX_TOKENS);
+  bool all_fast = !(flags & VPTQ_GEMV_FORCE_GENERIC);
+  for (int i = 0; i < n; ++i) {
+    int rc = validate_layer(&descs[i]);
+    if (rc) return rc;
+    if (!x[i] || !y[i]) return fail(VPTQ_E_NULL, "x[%d] / y[%d] is NULL", i, i);
+    if (descs[i].dtype != descs[0].dtype)
+      return fail(VPTQ_E_UNSUPPORTED, "grouped layers must share one dtype");
+    all_fast = all_fast && vptq::gemv_k256_eligible(descs[i], tokens) &&
+               (((uintptr_t)x[i]) & 15) == 0;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (all_fast) {
+    // one launch for up to 32 layers
+    for (int i0 = 0; i0 < n; i0 += 32) {
+      const int m = n - i0 < 32 ? n - i0 : 32;
+      hipError_t e = vptq::launch_gemv_k256(descs + i0, m, x + i0, y + i0, tokens, flags, st);
+      if (e != hipSuccess) return hip_fail(e, "gemv_k256 grouped launch");
+    }
+    return VPTQ_OK;
+  }
+  for (int i = 0; i < n; ++i) {
+    hipError_t e = vptq::launch_gemv_generic(descs[i], x[i], y[i], tokens, st);
+    if (e != hipSuccess) return hip_fail(e, "gemv_generic launch");
+  }
+  return VPTQ_OK;
+}
+
+int vptq_dequant(const VptqLayerDesc* d, void* W, void* stream) {
+  int rc = validate_layer(d);
+  if (rc) return rc;
+  if (!W) return fail(VPTQ_E_NULL, "W is NULL");
+  if (d->perm && !d->inv_perm)
+    return fail(VPTQ_E_NULL, "dequant needs inv_perm = argsort(perm) when perm is set");
+  hipError_t e = vptq::launch_dequant(*d, W, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "dequant launch");
+  return VPTQ_OK;
+}
+
+int vptq_quant_gemv_v2(const VptqV2Desc* d, const void* x, void* y, int tokens, int flags,
+                       void* stream) {
+  (void)flags;
+  if (!d) return fail(VPTQ_E_NULL, "desc is NULL");
+  if (!d->indices || !d->centroids || !x || !y)
+    return fail(VPTQ_E_NULL, "indices / centroids / x / y is NULL");
+  if (d->dtype != VPTQ_DTYPE_F16 && d->dtype != VPTQ_DTYPE_BF16)
+    return fail(VPTQ_E_UNSUPPORTED, "dtype %d", d->dtype);
+  // the reference instantiates v in {4, 8, 16} (csrc/dispatch_macros.h:12-89)
+  if (!(d->vector_len == 4 || d->vector_len == 8 || d->vector_len == 16))
+    return fail(VPTQ_E_UNSUPPORTED, "un-supported vector_len %d (v2: 4, 8, 16)", d->vector_len);
+  if (d->in_features <= 0 || d->out_features <= 0 || d->out_features % d->vector_len)
+    return fail(VPTQ_E_SHAPE, "out_features must be a positive multiple of vector_len");
+  if (d->num_centroids < 1 || d->num_centroids > 65536)
+    return fail(VPTQ_E_SHAPE, "num_centroids %d", d->num_centroids);
+  if (d->num_res_centroids > 0) {
+    if (!d->res_indices || !d->res_centroids)
+      return fail(VPTQ_E_NULL, "residual tensors required when num_res_centroids > 0");
+    if (d->res_index_bytes != 1 && d->res_index_bytes != 2)
+      return fail(VPTQ_E_SHAPE, "res_index_bytes must be 1 or 2");
+    if (d->res_index_bytes == 1 && d->num_res_centroids > 256)
+      return fail(VPTQ_E_SHAPE, "uint8 residual ids need num_res_centroids <= 256");
+  }
+  // reference: "tokens < 16" (vptq/ops/quant_gemm.py:338, csrc/quant_gemv_v2.cu:58)
+  if (tokens < 1 || tokens >= 16)
+    return fail(VPTQ_E_TOKENS, "tokens %d outside [1, 15]", tokens);
+  hipStream_t st = (hipStream_t)stream;
+  const size_t es = 2;
+  for (int t0 = 0; t0 < tokens; t0 += 8) {
+    const int m = tokens - t0 < 8 ? tokens - t0 : 8;
+    hipError_t e = vptq::launch_gemv_v2(*d, (const char*)x + (size_t)t0 * d->in_features * es,
+                                        (char*)y + (size_t)t0 * d->out_features * es, m, st);
+    if (e != hipSuccess) return hip_fail(e, "gemv_v2 launch");
+  }
+  return VPTQ_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,200 @@
+// Device-side helpers shared by the gfx950 kernels (wave64, CDNA4).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/vptq_hip.h"
+
+// The 16-bit arithmetic below must round after EVERY op (that is what the
+// reference CPU path does); never let the compiler fuse a*b+c into one fma.
+#pragma clang fp contract(off)
+
+namespace vptq {
+
+typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kWave = 64;
+
+// ---- 16-bit element types: a "pair" is two elements in one 32-bit register ----
+struct F16 {
+  static constexpr int kDtype = VPTQ_DTYPE_F16;
+  // packed pair ops: one VALU instruction each (v_pk_add_f16 / v_pk_mul_f16)
+  static __device__ __forceinline__ uint32_t add2(uint32_t a, uint32_t b) {
+    h2_t r = __builtin_bit_cast(h2_t, a) + __builtin_bit_cast(h2_t, b);
+    return __builtin_bit_cast(uint32_t, r);
+  }
+  static __device__ __forceinline__ uint32_t mul2(uint32_t a, uint32_t b) {
+    h2_t r = __builtin_bit_cast(h2_t, a) * __builtin_bit_cast(h2_t, b);
+    return __builtin_bit_cast(uint32_t, r);
+  }
+  static __device__ __forceinline__ float lo(uint32_t p) {
+    return (float)__builtin_bit_cast(h2_t, p).x;
+  }
+  static __device__ __forceinline__ float hi(uint32_t p) {
+    return (float)__builtin_bit_cast(h2_t, p).y;
+  }
+  static __device__ __forceinline__ float to_float(uint16_t b) {
+    return (float)__builtin_bit_cast(_Float16, b);
+  }
+  static __device__ __forceinline__ uint16_t from_float(float f) {
+    return __builtin_bit_cast(uint16_t, (_Float16)f);  // RNE
+  }
+  // acc + lo(p)*xf : lowers to v_fma_mix_f32 (f16 source, f32 accumulate)
+  static __device__ __forceinline__ float fma_lo(uint32_t p, float xf, float acc) {
+    return __builtin_fmaf(lo(p), xf, acc);
+  }
+  static __device__ __forceinline__ float fma_hi(uint32_t p, float xf, float acc) {
+    return __builtin_fmaf(hi(p), xf, acc);
+  }
+};
+
+struct BF16 {
+  static constexpr int kDtype = VPTQ_DTYPE_BF16;
+  static __device__ __forceinline__ float lo(uint32_t p) { return __uint_as_float(p << 16); }
+  static __device__ __forceinline__ float hi(uint32_t p) {
+    return __uint_as_float(p & 0xffff0000u);
+  }
+  static __device__ __forceinline__ float to_float(uint16_t b) {
+    return __uint_as_float((uint32_t)b << 16);
+  }
+  // fp32 -> bf16 RNE in hardware: v_cvt_pk_bf16_f32 (gfx950)
+  static __device__ __forceinline__ uint32_t pack(float l, float h) {
+    typedef __bf16 bf2_t __attribute__((ext_vector_type(2)));
+    typedef float f2_t __attribute__((ext_vector_type(2)));
+    const f2_t v = {l, h};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf2_t));
+  }
+  static __device__ __forceinline__ uint16_t from_float(float f) {
+    return (uint16_t)pack(f, 0.f);
+  }
+  // torch's CPU bf16 ops: widen to fp32, operate, round back (RNE)
+  static __device__ __forceinline__ uint32_t add2(uint32_t a, uint32_t b) {
+    return pack(lo(a) + lo(b), hi(a) + hi(b));
+  }
+  static __device__ __forceinline__ uint32_t mul2(uint32_t a, uint32_t b) {
+    return pack(lo(a) * lo(b), hi(a) * hi(b));
+  }
+  static __device__ __forceinline__ float fma_lo(uint32_t p, float xf, float acc) {
+    return __builtin_fmaf(lo(p), xf, acc);
+  }
+  static __device__ __forceinline__ float fma_hi(uint32_t p, float xf, float acc) {
+    return __builtin_fmaf(hi(p), xf, acc);
+  }
+};
+
+// broadcast one 16-bit element into both halves of a register
+static __device__ __forceinline__ uint32_t splat16(uint16_t v) {
+  return (uint32_t)v * 0x00010001u;
+}
+
+// ---- LDS access by absolute byte address (no symbol + offset add per access) ----
+typedef __attribute__((address_space(3))) u32x4 lds_u32x4_t;
+typedef __attribute__((address_space(3))) float lds_f32_t;
+static __device__ __forceinline__ u32x4 lds_load16(uint32_t byte_addr) {
+  return *(const lds_u32x4_t*)(uintptr_t)byte_addr;  // ds_read_b128
+}
+static __device__ __forceinline__ void lds_store16(uint32_t byte_addr, u32x4 v) {
+  *(lds_u32x4_t*)(uintptr_t)byte_addr = v;  // ds_write_b128
+}
+
+// ---- wave64 reductions -------------------------------------------------------
+static __device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// x + (x rotated right by N lanes inside each row of 16 lanes): one v_add_f32 with
+// a DPP row_ror modifier.  ror 8,4,2,1 in sequence = all-reduce over the row.
+template <int N>
+static __device__ __forceinline__ float row_ror_add(float x) {
+  const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x120 + N, 0xf, 0xf, false);
+  return x + __int_as_float(moved);
+}
+static __device__ __forceinline__ float row16_allsum(float x) {
+  x = row_ror_add<8>(x);
+  x = row_ror_add<4>(x);
+  x = row_ror_add<2>(x);
+  return row_ror_add<1>(x);
+}
+
+// Reduce NV per-lane partials over the 64 lanes of a wave in ~2*NV VALU ops
+// (a shuffle tree costs 12*NV).  Halving exchanges use the gfx950 lane-swap
+// instructions: v_permlane32_swap(a, b) leaves a = [a.lo32 | b.lo32],
+// b = [a.hi32 | b.hi32], so a + b holds sum(a) in lanes 0-31 and sum(b) in lanes
+// 32-63; v_permlane16_swap does the same for odd/even rows of 16 lanes.
+// On return v[0..M) of a lane in row q = lane >> 4 holds the wave totals of the
+// original entries [base(q), base(q) + M); see wave_reduce_layout().
+template <int NV>
+struct WaveReduce {
+  static constexpr bool kS32 = NV >= 16;
+  static constexpr int kN1 = kS32 ? NV / 2 : NV;
+  static constexpr bool kS16 = kN1 >= 16;
+  static constexpr int kM = kS16 ? kN1 / 2 : kN1;  // values left per lane
+
+  static __device__ __forceinline__ void run(float (&v)[NV]) {
+    if (kS32) {
+#pragma unroll
+      for (int i = 0; i < NV / 2; ++i) {
+        auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]),
+                                                  __float_as_uint(v[i + NV / 2]), false, false);
+        v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(v[i]),
+                                                  false, false);
+        v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+      }
+    }
+    if (kS16) {
+#pragma unroll
+      for (int i = 0; i < kN1 / 2; ++i) {
+        auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[i]),
+                                                  __float_as_uint(v[i + kN1 / 2]), false, false);
+        v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < kN1; ++i) {
+        auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[i]), __float_as_uint(v[i]),
+                                                  false, false);
+        v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < kM; ++i) v[i] = row16_allsum(v[i]);
+  }
+  // first original entry held by row q (0..3) after run(); rows that hold
+  // duplicates (no halving on that bit) report the same base.
+  static __device__ __forceinline__ int base(int q) {
+    int off = 0;
+    if (kS32) off += (q >> 1) * (NV / 2);
+    if (kS16) off += (q & 1) * (kN1 / 2);
+    return off;
+  }
+  // does row q hold a unique slice (is it a designated writer)?
+  static __device__ __forceinline__ bool writer(int q) {
+    return (kS32 || (q >> 1) == 0) && (kS16 || (q & 1) == 0);
+  }
+};
+
+// ---- packed index bit stream (vptq/utils/pack.py:26-67) ------------------------
+// element g of a row = bits [g*T, (g+1)*T) of the little-endian word stream.
+// Reads word wi and, only when the element straddles, word wi+1 (which then
+// exists inside the row): never touches memory past the row, unlike the
+// reference's iterator (csrc/util/cuda_utils.cuh:131).
+static __device__ __forceinline__ uint32_t unpack_elem(const uint32_t* __restrict__ row, int g,
+                                                       int T) {
+  const uint32_t bit = (uint32_t)g * (uint32_t)T;
+  const uint32_t wi = bit >> 5, sh = bit & 31u;
+  uint64_t w = row[wi];
+  if (sh + (uint32_t)T > 32u) w |= (uint64_t)row[wi + 1] << 32;
+  const uint32_t mask = T >= 32 ? 0xffffffffu : ((1u << T) - 1u);
+  return (uint32_t)(w >> sh) & mask;
+}
+
+}  // namespace vptq

@@ -1,0 +1,27 @@
+// Internal launcher prototypes (one per .hip translation unit).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/vptq_hip.h"
+
+namespace vptq {
+
+// gemv_generic.hip — every configuration
+hipError_t launch_gemv_generic(const VptqLayerDesc& d, const void* x, void* y, int tokens,
+                               hipStream_t st);
+
+// gemv_k256.hip — v=8, k=256 (+ kr=256), C=1, no outliers: LDS-resident,
+// bank-conflict-free replicated codebooks.
+bool gemv_k256_eligible(const VptqLayerDesc& d, int tokens);
+const char* gemv_k256_name(const VptqLayerDesc& d, int tokens, int flags);
+hipError_t launch_gemv_k256(const VptqLayerDesc* descs, int n, const void* const* x,
+                            void* const* y, int tokens, int flags, hipStream_t st);
+
+// dequant.hip
+hipError_t launch_dequant(const VptqLayerDesc& d, void* W, hipStream_t st);
+
+// gemv_v2.hip
+hipError_t launch_gemv_v2(const VptqV2Desc& d, const void* x, void* y, int tokens,
+                          hipStream_t st);
+
+}  // namespace vptq

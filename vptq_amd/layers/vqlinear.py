@@ -1,0 +1,199 @@
+"""`VQuantLinear`: drop-in for microsoft/VPTQ's quantised linear layer
+(reference vptq/layers/vqlinear.py:17-240 ctor, :351-397 forward).
+
+What must match the reference byte for byte is the *state-dict contract* HF
+checkpoints rely on — parameter names, shapes and dtypes:
+
+    centroids.weight       [C, k*v]            fp16/bf16
+    res_centroids.weight   [C, kr*v]           (when num_res_centroids[1] > 0)
+    indices                [C, N, ceil(G*T/32)] int32   (packed: idx | ridx << log2 k)
+    outlier_centroids.weight [1, ko*ov], outlier_indices [1, M, S] int16
+    perm                   [I] int16 (uint16 bit pattern)
+    weight_scale, weight_bias [I];  bias [O]
+
+and the constructor keyword arguments HF's `replace_with_vptq_linear` passes
+(transformers/integrations/vptq.py).  The module may be built on the `meta`
+device; nothing derived from tensor contents is computed in `__init__`.
+
+Only the inference path is implemented: packed indices, `vector_quant_dim="out"`.
+The reference's layer-wise fine-tuning helpers (proxy_error_forward,
+set_l2_indices, init_parameters from k-means dictionaries) belong to the
+quantisation algorithm, which is not part of this hot path.
+"""
+from __future__ import annotations
+
+import math
+from typing import Sequence
+
+import torch
+import torch.nn as nn
+from torch.nn.parameter import Parameter
+
+from vptq_amd import ops
+
+
+class VQuantLinear(nn.Module):
+    def __init__(
+        self,
+        in_features: int,
+        out_features: int,
+        vector_lens: Sequence[int],
+        num_centroids: Sequence[int],
+        num_res_centroids: Sequence[int],
+        group_num: int,
+        group_size: int,
+        outlier_size: int,
+        indices_as_float: bool,
+        enable_norm: bool = False,
+        enable_perm: bool = False,
+        is_indice_packed: bool = False,
+        bias: bool = False,
+        vector_quant_dim: str = "out",
+        device=None,
+        dtype=None,
+        enable_proxy_error=True,
+        **unused_kwargs,  # e.g. `norm_dim`, written by the reference's pack tools
+    ):
+        super().__init__()
+        if vector_quant_dim not in ("in", "out"):
+            raise ValueError("vector_quant_dim must be 'in' or 'out'.")
+        if vector_quant_dim == "in":
+            raise RuntimeError("Not implemented yet.")
+        if not is_indice_packed:
+            raise RuntimeError(
+                "vptq_amd.VQuantLinear supports packed indices only (is_indice_packed=True): "
+                "that is the format of every published VPTQ checkpoint; the reference's "
+                "unpacked mode exists for fine-tuning.")
+        fk = {"device": device, "dtype": dtype}
+        self.vector_quant_dim = vector_quant_dim
+        self.in_features, self.out_features = in_features, out_features
+        self.enable_proxy_error = enable_proxy_error
+        self.indices_as_float = indices_as_float
+        self.is_indice_packed = True
+        index_type = torch.float16 if indices_as_float else torch.int16
+
+        if bias:
+            self.bias = Parameter(torch.empty(out_features, **fk))
+        else:
+            self.register_parameter("bias", None)
+
+        # main codebook(s): second element of the (outlier, main) pairs
+        self.vector_len = vector_lens[1]
+        self.num_centroids = num_centroids[1]
+        self.group_num = self.num_codebooks = group_num
+        self.group_size = group_size
+        self.centroids = nn.Embedding(group_num, self.num_centroids * self.vector_len, **fk)
+
+        # outlier columns: first element of the pairs
+        self.outlier_size = outlier_size
+        self.outlier_vector_len = vector_lens[0]
+        self.num_outlier_centroids = num_centroids[0]
+        self.outlier_num_res_centroids = num_res_centroids[0]
+        self.enable_outlier = bool(self.outlier_vector_len > 1 and self.num_outlier_centroids > 0)
+        self.outlier_padding = 0
+        self.ouliter_num_indices = 0  # (sic) attribute name kept from the reference
+        self.outlier_centroids = None
+        self.outlier_indices = None
+        if self.enable_outlier:
+            if self.outlier_num_res_centroids != -1:
+                raise ValueError("Current implementation does not support residual "
+                                 "quantization on outliers yet.")
+            self.outlier_padding = (-out_features) % self.outlier_vector_len
+            self.ouliter_num_indices = (out_features + self.outlier_padding) // self.outlier_vector_len
+            self.outlier_centroids = nn.Embedding(
+                1, self.num_outlier_centroids * self.outlier_vector_len, **fk)
+            self.outlier_indices = Parameter(
+                torch.empty((1, self.ouliter_num_indices, outlier_size), dtype=index_type,
+                            device=device), requires_grad=False)
+
+        # residual codebook (indices ride inside the packed stream)
+        self.num_res_centroids = num_res_centroids[1]
+        self.enable_residual = self.num_res_centroids > 0
+        self.res_indices = None
+        if self.enable_residual:
+            self.res_centroids = nn.Embedding(
+                group_num, self.num_res_centroids * self.vector_len, **fk)
+        else:
+            self.register_parameter("res_centroids", None)
+
+        self.enable_perm = enable_perm
+        if enable_perm:
+            self.perm = Parameter(torch.arange(in_features, device=device).to(torch.int16),
+                                  requires_grad=False)
+
+        self.enable_norm = enable_norm
+        self.weight_scale = self.weight_bias = None
+        if enable_norm:
+            self.weight_scale = Parameter(torch.empty(in_features, **fk))
+            self.weight_bias = Parameter(torch.empty(in_features, **fk))
+
+        self.padding = (-out_features) % self.vector_len
+        self.num_indices = (out_features + self.padding) // self.vector_len
+        self.index_bits = int(math.log2(self.num_centroids))
+        self.res_index_bits = int(math.log2(self.num_res_centroids)) if self.enable_residual else 0
+        self.total_index_bits = self.index_bits + self.res_index_bits
+        packed_groupsize = math.ceil(group_size * self.total_index_bits / 32)
+        self.indices = Parameter(
+            torch.empty((group_num, self.num_indices, packed_groupsize), dtype=torch.int32,
+                        device=device), requires_grad=False)
+
+    def forward(self, x: torch.Tensor, W=None, H=None) -> torch.Tensor:
+        """x [..., in_features] fp16/bf16 -> [..., out_features]."""
+        if self.enable_proxy_error:
+            raise RuntimeError(
+                "enable_proxy_error=True selects the reference's layer-wise fine-tuning debug "
+                "path, which is outside this inference package; construct the layer with "
+                "enable_proxy_error=False (HF does).")
+        return ops.quant_gemm(
+            x,
+            bias=self.bias,
+            indices=self.indices,
+            centroids=self.centroids.weight,
+            outlier_indices=self.outlier_indices,
+            outlier_centroids=self.outlier_centroids.weight if self.enable_outlier else None,
+            residual_indices=None,
+            residual_centroids=self.res_centroids.weight if self.enable_residual else None,
+            perm=self.perm if self.enable_perm else None,
+            weight_scale=self.weight_scale,
+            weight_bias=self.weight_bias,
+            vector_len=self.vector_len,
+            outlier_vector_len=self.outlier_vector_len,
+            num_codebooks=self.num_codebooks,
+            num_centroids=self.num_centroids,
+            num_outlier_centroids=self.num_outlier_centroids,
+            num_res_centroids=self.num_res_centroids,
+            is_indice_packed=True,
+            group_size=self.group_size,
+            outlier_size=self.outlier_size,
+            in_features=self.in_features,
+            out_features=self.out_features,
+            padding=self.padding,
+            outlier_padding=self.outlier_padding,
+            vector_quant_dim=self.vector_quant_dim,
+        )
+
+    def dequant(self) -> torch.Tensor:
+        """Dense W[out_features, in_features] (what the reference calls
+        `ops.dequant(...)` with this layer's fields)."""
+        return ops.dequant(
+            indices=self.indices, centroids=self.centroids.weight,
+            outlier_indices=self.outlier_indices,
+            outlier_centroids=self.outlier_centroids.weight if self.enable_outlier else None,
+            res_indices=None,
+            res_centroids=self.res_centroids.weight if self.enable_residual else None,
+            perm=self.perm if self.enable_perm else None, weight_scale=self.weight_scale,
+            weight_bias=self.weight_bias, is_indice_packed=True,
+            enable_outlier=self.enable_outlier, enable_residual=self.enable_residual,
+            enable_perm=self.enable_perm, enable_norm=self.enable_norm,
+            num_centroids=self.num_centroids, num_outlier_centroids=self.num_outlier_centroids,
+            num_res_centroids=self.num_res_centroids, padding=self.padding,
+            outlier_padding=self.outlier_padding, num_codebooks=self.num_codebooks,
+            group_size=self.group_size, outlier_size=self.outlier_size,
+            vector_len=self.vector_len, outlier_vector_len=self.outlier_vector_len)
+
+    def extra_repr(self) -> str:
+        return (f"in_features={self.in_features}, out_features={self.out_features}, "
+                f"v={self.vector_len}, k={self.num_centroids}, k_res={self.num_res_centroids}, "
+                f"codebooks={self.num_codebooks}, group_size={self.group_size}, "
+                f"outlier_size={self.outlier_size}, perm={self.enable_perm}, "
+                f"norm={self.enable_norm}")
