@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""Decode-GEMV benchmark for the VPTQ hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--hidden 8192] [--mode single|grouped]
+
+Workload (BASELINE.json configs[1] at the hidden size the north-star target is
+quoted on): one VQuantLinear H x H, vector_len 8, k = 256 + 256 residual
+centroids (2 bits / weight), enable_norm, batch = 1, seq = 1, fp16.
+A *step* is one decode token through a RING of R distinct layers
+(R * packed-index bytes >= 512 MiB, so neither the 32 MiB of L2 nor the 256 MiB
+Infinity Cache can hold the weights between uses): R fused dequant+GEMV
+launches through the C ABI, captured once in a hipGraph and replayed.
+  --mode single  : one launch per layer (the reference's operator granularity)
+  --mode grouped : layers launched 4 at a time with vptq_quant_gemv_grouped
+                   (q/k/v/o-style fusion of independent projections)
+Inputs and weights are resident in HBM before the timed region.  With N > 1
+(torchrun, one rank per GPU) every rank owns its own ring: independent layers, no
+data-path collective, weak scaling; the time is the max over ranks.
+
+Prints ONE JSON line; see README / DESIGN.md §6 for the fields.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def alg_bytes(H):
+    """Algorithmic bytes of one H x H launch (DESIGN.md §5 / SURVEY.md §8d):
+    packed indices + both codebooks + x + scale + bias + y."""
+    return (H // 8) * (H * 16 // 32) * 4 + 2 * 256 * 8 * 2 + 2 * H + 4 * H + 2 * H
+
+
+def make_ring(H, R, dev, seed):
+    import vptq_amd
+    g = torch.Generator(device=dev).manual_seed(seed)
+    layers = []
+    for _ in range(R):
+        m = vptq_amd.VQuantLinear(
+            H, H, vector_lens=[-1, 8], num_centroids=[-1, 256], num_res_centroids=[-1, 256],
+            group_num=1, group_size=H, outlier_size=0, indices_as_float=False, enable_norm=True,
+            enable_perm=False, is_indice_packed=True, bias=False, dtype=torch.float16,
+            device=dev, enable_proxy_error=False)
+        m.indices.data = torch.randint(-2**31, 2**31 - 1, m.indices.shape, generator=g,
+                                       device=dev, dtype=torch.int64).to(torch.int32)
+        m.centroids.weight.data = (torch.randn(m.centroids.weight.shape, generator=g, device=dev) * 0.02).half()
+        m.res_centroids.weight.data = (torch.randn(m.res_centroids.weight.shape, generator=g, device=dev) * 0.005).half()
+        m.weight_scale.data = (1 + 0.1 * torch.randn(H, generator=g, device=dev)).half()
+        m.weight_bias.data = (0.01 * torch.randn(H, generator=g, device=dev)).half()
+        layers.append(m.eval())
+    return layers
+
+
+def cpu_baseline(layer, x, y_gpu, H):
+    """The reference's CPU algorithm (dequant to dense W, then linear), as restated by
+    the C oracle (oracle/vptq_oracle.c), timed on this box's host cores.  Also returns
+    the parity error of the GPU result against it."""
+    from oracle import c_oracle as co
+    from oracle import vptq_oracle as vo
+    if not co.available():
+        return None, None
+    L = vo.LayerSpec(H, H, 8, 256, 256, 1, H, dtype="f16")
+    to_np = lambda t, dt: t.detach().cpu().contiguous().view(torch.int16).numpy().view(dt)  # noqa: E731
+    L.indices = layer.indices.detach().cpu().numpy()
+    L.centroids = to_np(layer.centroids.weight, np.uint16).reshape(1, 256, 8)
+    L.res_centroids = to_np(layer.res_centroids.weight, np.uint16).reshape(1, 256, 8)
+    L.weight_scale = to_np(layer.weight_scale, np.uint16)
+    L.weight_bias = to_np(layer.weight_bias, np.uint16)
+    xb = to_np(x, np.uint16)
+    scratch = np.empty((H, H), dtype=np.uint16)
+    cores = co.lib().vo_num_threads()
+    y = co.forward(L, xb, scratch=scratch)          # warm-up (page-in)
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        y = co.forward(L, xb, scratch=scratch)
+        times.append(time.perf_counter() - t0)
+    t = sorted(times)[1]
+    yg = to_np(y_gpu, np.uint16).reshape(-1)
+    a = vo.to_f32(yg, "f16").astype(np.float64)
+    b = vo.to_f32(y.reshape(-1), "f16").astype(np.float64)
+    rel = float(np.abs(a - b).max() / np.abs(b).max())
+    base = {"value": alg_bytes(H) / t / 1e9, "unit": "GB/s", "cores": int(cores), "kind": "port",
+            "sample": f"1 VQuantLinear {H}x{H} forward (dequant to dense W + linear, C oracle, "
+                      f"OpenMP {cores} threads), median of 3, {t * 1e3:.0f} ms each"}
+    return base, rel
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--hidden", type=int, default=8192)
+    ap.add_argument("--ring", type=int, default=0)
+    ap.add_argument("--mode", choices=["single", "grouped"], default="single")
+    ap.add_argument("--group", type=int, default=4)
+    ap.add_argument("--fast-math", action="store_true",
+                    help="folded fp32 arithmetic (VPTQ_GEMV_FAST_MATH); not the default path")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from vptq_amd import _backend as B
+    from _gpu_util import module_desc
+    lib = B.lib()
+    H = a.hidden
+    idx_bytes = (H // 8) * H * 2
+    R = a.ring or max(2, (512 << 20) // idx_bytes)
+    layers = make_ring(H, R, dev, seed=1234 + rank)
+    x = torch.randn(1, 1, H, device=dev, dtype=torch.float16,
+                    generator=torch.Generator(device=dev).manual_seed(7))
+    ys = [torch.empty(1, 1, H, device=dev, dtype=torch.float16) for _ in range(R)]
+    descs, keeps = [], []
+    for m in layers:
+        d, k = module_desc(m)
+        descs.append(d)
+        keeps.append(k)
+    flags = B.GEMV_FAST_MATH if a.fast_math else 0
+    kname = lib.vptq_quant_gemv_kernel_name(descs[0], 1, flags).decode()
+
+    stream = torch.cuda.Stream(device=dev)
+    if a.mode == "single":
+        launches_per_step = R
+
+        def one_pass():
+            sp = torch.cuda.current_stream().cuda_stream
+            for i in range(R):
+                rc = lib.vptq_quant_gemv(descs[i], x.data_ptr(), ys[i].data_ptr(), 1, flags,
+                                         None, 0, sp)
+                assert rc == 0, lib.vptq_last_error()
+    else:
+        chunks = []
+        for i0 in range(0, R, a.group):
+            m = min(a.group, R - i0)
+            chunks.append((m, (B.LayerDesc * m)(*descs[i0:i0 + m]),
+                           (C.c_void_p * m)(*[x.data_ptr()] * m),
+                           (C.c_void_p * m)(*[t.data_ptr() for t in ys[i0:i0 + m]])))
+        launches_per_step = len(chunks)
+
+        def one_pass():
+            sp = torch.cuda.current_stream().cuda_stream
+            for m, arr, xp, yp in chunks:
+                rc = lib.vptq_quant_gemv_grouped(arr, m, xp, yp, 1, flags, sp)
+                assert rc == 0, lib.vptq_last_error()
+
+    with torch.cuda.stream(stream):
+        one_pass()
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=stream):
+            one_pass()
+        for _ in range(a.warmup):
+            graph.replay()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record(stream)
+        for _ in range(a.steps):
+            graph.replay()
+        e1.record(stream)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+    ev_ms = e0.elapsed_time(e1)
+    if dist is not None:
+        tt = torch.tensor([wall, ev_ms], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        wall, ev_ms = tt.tolist()
+
+    ab = alg_bytes(H)
+    total_bytes = world * ab * R * a.steps
+    value = total_bytes / wall / 1e9
+    us_per_launch = ev_ms * 1e3 / (a.steps * launches_per_step)
+    bytes_per_launch = ab * R / launches_per_step
+    achieved = bytes_per_launch / us_per_launch / 1e3     # GB/s
+    out = {
+        "metric": "decode GEMV effective GB/s (VQuantLinear 2-bit, batch 1)",
+        "value": value, "unit": "GB/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": wall * 1e3 / a.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+        "config": {"workload": f"VQuantLinear {H}x{H} v=8 k=256+256 (2-bit) batch=1 seq=1 fp16, "
+                               f"ring of {R} distinct layers per GPU ({R * idx_bytes >> 20} MiB of "
+                               f"packed indices), 1 step = 1 pass over the ring",
+                   "hidden": H, "ring": R, "mode": a.mode, "launches_per_step": launches_per_step,
+                   "kernel": kname, "arithmetic": "fast_math" if a.fast_math else "reference-rounding",
+                   "parallelism": f"{world} x independent rings (no collective)"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                     "bytes_per_launch": bytes_per_launch, "us_per_launch": us_per_launch,
+                     "note": "us_per_launch = HIP-event time over the timed region / launches "
+                             "(includes inter-kernel gaps); kernel is VALU-issue bound, see DESIGN.md §4"},
+    }
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        torch.cuda.synchronize()
+        base, rel = cpu_baseline(layers[0], x, ys[0], H)
+        if base is not None:
+            out["cpu_baseline"] = base
+            out["parity_rel_err_vs_cpu_oracle"] = rel
+            assert rel <= 1e-3, f"GPU result differs from the CPU oracle: {rel}"
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

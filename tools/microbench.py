@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--ring", type=int, default=0)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--perm", action="store_true")
+    ap.add_argument("--group", type=int, default=32)
     ap.add_argument("--out", default="")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -107,14 +108,17 @@ def main():
                                  torch.cuda.current_stream().cuda_stream)
         assert rc == 0, lib.vptq_last_error()
 
-    arr = (B.LayerDesc * R)(*descs)
-    xp = (C.c_void_p * R)(*[x.data_ptr()] * R)
-    yp = (C.c_void_p * R)(*[y.data_ptr() for y in ys])
+    chunks = []
+    for i0 in range(0, R, a.group):
+        m = min(a.group, R - i0)
+        chunks.append((m, (B.LayerDesc * m)(*descs[i0:i0 + m]), (C.c_void_p * m)(*[x.data_ptr()] * m),
+                       (C.c_void_p * m)(*[y.data_ptr() for y in ys[i0:i0 + m]])))
 
     def launch_group(flags):
-        rc = lib.vptq_quant_gemv_grouped(arr, R, xp, yp, 1, flags,
-                                         torch.cuda.current_stream().cuda_stream)
-        assert rc == 0, lib.vptq_last_error()
+        for m, arr, xp, yp in chunks:
+            rc = lib.vptq_quant_gemv_grouped(arr, m, xp, yp, 1, flags,
+                                             torch.cuda.current_stream().cuda_stream)
+            assert rc == 0, lib.vptq_last_error()
 
     for name, flags in (("exact", 0), ("fast", 1), ("generic", 2)):
         ring = time_graph(lambda: [launch_one(i, flags) for i in range(R)], a.iters) / R

@@ -48,6 +48,31 @@ struct F16 {
   static __device__ __forceinline__ float fma_hi(uint32_t p, float xf, float acc) {
     return __builtin_fmaf(hi(p), xf, acc);
   }
+  // ---- "broadcast one half of a pair register" forms: the half select folds into
+  // the instruction's op_sel bits, so no splat register / extra VALU op is needed.
+  static __device__ __forceinline__ float half_of(uint32_t pair, int h) {
+    const h2_t p = __builtin_bit_cast(h2_t, pair);
+    return (float)(h ? p.y : p.x);
+  }
+  static __device__ __forceinline__ h2_t bcast(uint32_t pair, int h) {
+    const h2_t p = __builtin_bit_cast(h2_t, pair);
+    return h ? __builtin_shufflevector(p, p, 1, 1) : __builtin_shufflevector(p, p, 0, 0);
+  }
+  static __device__ __forceinline__ uint32_t mul2_bcast(uint32_t a, uint32_t pair, int h) {
+    const h2_t r = __builtin_bit_cast(h2_t, a) * bcast(pair, h);
+    return __builtin_bit_cast(uint32_t, r);
+  }
+  static __device__ __forceinline__ uint32_t add2_bcast(uint32_t a, uint32_t pair, int h) {
+    const h2_t r = __builtin_bit_cast(h2_t, a) + bcast(pair, h);
+    return __builtin_bit_cast(uint32_t, r);
+  }
+  // acc + lo/hi(w) * half h of an f16 pair register: one v_fma_mix_f32
+  static __device__ __forceinline__ float fma_lo_h(uint32_t w, uint32_t xpair, int h, float acc) {
+    return __builtin_fmaf(lo(w), half_of(xpair, h), acc);
+  }
+  static __device__ __forceinline__ float fma_hi_h(uint32_t w, uint32_t xpair, int h, float acc) {
+    return __builtin_fmaf(hi(w), half_of(xpair, h), acc);
+  }
 };
 
 struct BF16 {
@@ -81,6 +106,23 @@ struct BF16 {
   }
   static __device__ __forceinline__ float fma_hi(uint32_t p, float xf, float acc) {
     return __builtin_fmaf(hi(p), xf, acc);
+  }
+  static __device__ __forceinline__ float half_of(uint32_t pair, int h) {
+    return h ? hi(pair) : lo(pair);
+  }
+  static __device__ __forceinline__ uint32_t mul2_bcast(uint32_t a, uint32_t pair, int h) {
+    const float s = half_of(pair, h);
+    return pack(lo(a) * s, hi(a) * s);
+  }
+  static __device__ __forceinline__ uint32_t add2_bcast(uint32_t a, uint32_t pair, int h) {
+    const float s = half_of(pair, h);
+    return pack(lo(a) + s, hi(a) + s);
+  }
+  static __device__ __forceinline__ float fma_lo_h(uint32_t w, uint32_t xpair, int h, float acc) {
+    return __builtin_fmaf(lo(w), half_of(xpair, h), acc);
+  }
+  static __device__ __forceinline__ float fma_hi_h(uint32_t w, uint32_t xpair, int h, float acc) {
+    return __builtin_fmaf(hi(w), half_of(xpair, h), acc);
   }
 };
 

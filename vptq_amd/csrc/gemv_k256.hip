@@ -5,21 +5,30 @@
 // Replaces WqA16WithOutliers_PackIndice + tmp.sum(-1)
 // (reference csrc/kernels/quant_gemv.cuh:11-186, csrc/quant_gemv.cu:203-235).
 //
-// Design:
-//  * one 512-thread workgroup per CU owns ROWS complete vector-rows (8*ROWS
-//    outputs) over ALL input columns -> no split-K buffer, no second kernel;
-//  * every lane streams 16-byte pieces of the packed index rows (8 column
-//    indices per load, 1 KiB per wave instruction, fully coalesced); all loads
-//    of an iteration are issued before the first use so the whole slab of a
-//    workgroup is in flight at once;
-//  * both codebooks live in LDS, REPLICATED 16x in a bank-partitioned image
-//    (entry e, replica q at byte e*256 + q*16; lane l always reads replica
-//    l & 15): the two ds_read_b128 gathers per index are bank-conflict-free by
-//    construction, for any index pattern (a plain 4-KiB table costs ~3x);
+// Design (numbers from tools/ubench.hip on MI355X):
+//  * the kernel is VALU-issue bound, not HBM bound: rebuilding 8 weights with the
+//    reference's three roundings costs 22 VALU instructions per 2-byte index pair
+//    and a SIMD issues one packed-f16 / fma instruction per ~2.3 ns only with
+//    >= 4 waves resident (5.1 ns with one).  Everything below serves occupancy
+//    and instruction count:
+//  * 512-thread workgroups, 2 per CU (4 waves / SIMD, <= 128 VGPRs), each owning
+//    ROWS complete vector-rows (8*ROWS outputs) over ALL input columns -> no
+//    split-K buffer, no second kernel;
+//  * every lane streams 16-byte pieces of the packed index rows (8 column indices
+//    per load, 1 KiB per wave instruction, fully coalesced), all loads of an
+//    iteration issued before the first use;
+//  * both codebooks live in ONE 64 KiB LDS image of 256 bank rows: row e holds
+//    8 replicas of main entry e (slots 0-7) and 8 replicas of residual entry e
+//    (slots 8-15); lane l reads replica l & 7, so main and residual gathers never
+//    collide and a ds_read_b128 group sees at most a 2-way conflict for ANY index
+//    pattern (a plain 4 KiB table: ~3x serialisation);
 //  * the LDS address of a gather is ONE v_perm_b32 (index byte -> bits 8..15,
-//    lane slot -> bits 4..7, table -> bit 16);
+//    lane slot / table -> bits 4..7);
 //  * weights are rebuilt with the reference CPU path's roundings
-//    (r16(r16(r16(c+r)*s)+b), packed fp16 VALU) and x*w accumulates in fp32.
+//    (r16(r16(r16(c+r)*s)+b), packed f16 VALU with op_sel broadcasts) and x*w is
+//    accumulated in fp32 by v_fma_mix_f32;
+//  * the 8*ROWS*TOK partial sums of a lane are reduced over the wave with the
+//    gfx950 lane-swap instructions (~2 ops per value instead of 12).
 #include "common.h"
 #include "kernels.h"
 
@@ -30,6 +39,8 @@ constexpr int kWaves = kThreads / 64;
 constexpr int kSweepCols = kThreads * 8;  // columns covered by one sweep of the WG
 constexpr int kSW = 2;                    // sweeps issued back-to-back per iteration
 constexpr int kMaxGroup = 32;
+constexpr int kTableBytes = 65536;        // 256 rows x 256 B
+constexpr int kScratchOff = kTableBytes;
 
 struct K256Layer {
   const uint32_t* idx;    // [N, row_words]
@@ -52,38 +63,21 @@ struct K256Params {
   K256Layer layer[kMaxGroup];
 };
 
-// LDS image ---------------------------------------------------------------------
-// TAB == 1: [2 tables][256 entries][16 replicas][16 B] = 128 KiB, then scratch.
-// TAB == 0: [2 tables][256 entries][16 B]               =   8 KiB, then scratch.
-template <int TAB>
-struct Lds {
-  static constexpr int kTableBytes = TAB ? 65536 : 4096;
-  static constexpr int kScratchOff = 2 * kTableBytes;
-};
-
-// one element: gather both codebook entries (two ds_read_b128)
-template <int TAB>
+// both gathers of one element: index byte h*2 -> main entry, byte h*2+1 -> residual
 static __device__ __forceinline__ void gather(uint32_t w, int h, uint32_t baseC, uint32_t baseR,
                                               u32x4& cv, u32x4& rv) {
-  uint32_t aC, aR;
-  if (TAB == 1) {
-    // D = {0, base.b2, w.byte, base.b0}: (index << 8) | lane slot | table bit
-    aC = __builtin_amdgcn_perm(w, baseC, h ? 0x0c020600u : 0x0c020400u);
-    aR = __builtin_amdgcn_perm(w, baseR, h ? 0x0c020700u : 0x0c020500u);
-  } else {
-    aC = ((w >> (16 * h)) & 0xffu) << 4;
-    aR = (((w >> (16 * h + 8)) & 0xffu) << 4) + Lds<0>::kTableBytes;
-  }
+  // D = {0, 0, w.byte, base.b0}: (index << 8) | slot
+  const uint32_t aC = __builtin_amdgcn_perm(w, baseC, h ? 0x0c0c0600u : 0x0c0c0400u);
+  const uint32_t aR = __builtin_amdgcn_perm(w, baseR, h ? 0x0c0c0700u : 0x0c0c0500u);
   cv = lds_load16(aC);
   rv = lds_load16(aR);
 }
 
-template <typename DT, int ROWS, int TOK, bool FAST, int TAB, int RED>
-__global__ __launch_bounds__(kThreads) void gemv_k256_kernel(const K256Params P) {
+template <typename DT, int ROWS, int TOK, bool FAST>
+__global__ __launch_bounds__(kThreads, 4) void gemv_k256_kernel(const K256Params P) {
   // The dynamic LDS segment starts at byte 0 (the kernel has no static LDS), so
-  // gathers address LDS absolutely; `smem` is only used to size the allocation.
+  // gathers address LDS absolutely; `smem` only sizes the allocation.
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  using L = Lds<TAB>;
 
   // ---- which layer / row group is this workgroup? (wave-uniform) ----
   const int bid = blockIdx.x;
@@ -111,15 +105,15 @@ __global__ __launch_bounds__(kThreads) void gemv_k256_kernel(const K256Params P)
       for (int i = 0; i < 8; ++i) acc[t][r][i] = 0.f;
   }
 
-  // gather address bases: lane slot in bits 4..7, table select in bit 16
-  const uint32_t baseC = (uint32_t)(lane & 15) << 4;
-  const uint32_t baseR = baseC | (uint32_t)L::kTableBytes;
+  // gather address bases: replica slot in bits 4..6, residual half of the row: bit 7
+  const uint32_t baseC = (uint32_t)(lane & 7) << 4;
+  const uint32_t baseR = baseC | 0x80u;
 
   bool tables_ready = false;
 
   for (int base = 0; base < G; base += kSW * kSweepCols) {
     // ---- 2. issue every global load of this iteration ----
-    u32x4 xs_raw[kSW][TOK], s_raw[kSW], b_raw[kSW];
+    u32x4 x_raw[kSW][TOK], s_raw[kSW], b_raw[kSW];
     u32x4 iw[kSW][ROWS];
     bool valid[kSW];
 #pragma unroll
@@ -132,7 +126,7 @@ __global__ __launch_bounds__(kThreads) void gemv_k256_kernel(const K256Params P)
           b_raw[sw] = *(const u32x4*)(Ly.wbias + col0);
 #pragma unroll
           for (int t = 0; t < TOK; ++t)
-            if (t < tokens) xs_raw[sw][t] = *(const u32x4*)(Ly.x + (size_t)t * G + col0);
+            if (t < tokens) x_raw[sw][t] = *(const u32x4*)(Ly.x + (size_t)t * G + col0);
         } else {
           // column c of the quantised matrix multiplies input feature perm[c]
           const u32x4 pv = *(const u32x4*)(Ly.perm + col0);
@@ -144,37 +138,28 @@ __global__ __launch_bounds__(kThreads) void gemv_k256_kernel(const K256Params P)
 #pragma unroll
             for (int t = 0; t < TOK; ++t)
               if (t < tokens)
-                xs_raw[sw][t][q] = (uint32_t)Ly.x[(size_t)t * G + j0] |
-                                   ((uint32_t)Ly.x[(size_t)t * G + j1] << 16);
+                x_raw[sw][t][q] = (uint32_t)Ly.x[(size_t)t * G + j0] |
+                                  ((uint32_t)Ly.x[(size_t)t * G + j1] << 16);
           }
         }
-      }
-    }
 #pragma unroll
-    for (int sw = 0; sw < kSW; ++sw) {
-      const int col0 = base + sw * kSweepCols + tid * 8;
-#pragma unroll
-      for (int r = 0; r < ROWS; ++r) {
-        // rows past N (last workgroup) re-read row N-1; their results are dropped
-        const int row = row0 + r < N ? row0 + r : N - 1;
-        if (valid[sw])
+        for (int r = 0; r < ROWS; ++r) {
+          // rows past N (last workgroup) re-read row N-1; their results are dropped
+          const int row = row0 + r < N ? row0 + r : N - 1;
           iw[sw][r] = *(const u32x4*)(Ly.idx + (size_t)row * Ly.row_words + (col0 >> 1));
+        }
       }
     }
 
     // ---- 3. build the LDS codebook image (first iteration only) ----
     if (!tables_ready) {
       tables_ready = true;
-      if (TAB == 1) {
-        // thread t owns the 256-byte bank row of entry t: 16 replicas.  The
-        // replica order is rotated by the lane id so the 8 lanes of a
-        // ds_write_b128 group hit 8 different 16-byte slots.
-        const uint32_t rowp = (tid >> 8) * L::kTableBytes + (tid & 255) * 256;
+      // thread t owns half a bank row: 8 replicas of its entry.  The replica
+      // order is rotated by the lane id so the 8 lanes of a ds_write_b128 group
+      // hit 8 different 16-byte slots.
+      const uint32_t rowp = (tid & 255) * 256 + (tid >> 8) * 128;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) lds_store16(rowp + (((q + lane) & 15) << 4), centry);
-      } else {
-        lds_store16((tid >> 8) * L::kTableBytes + (tid & 255) * 16, centry);
-      }
+      for (int q = 0; q < 8; ++q) lds_store16(rowp + (((q + lane) & 7) << 4), centry);
       __syncthreads();
     }
 
@@ -182,76 +167,74 @@ __global__ __launch_bounds__(kThreads) void gemv_k256_kernel(const K256Params P)
 #pragma unroll
     for (int sw = 0; sw < kSW; ++sw) {
       if (!valid[sw]) continue;
-      // per-column scale / bias pairs and activations for this sweep
-      uint32_t s2[8], b2[8];
-      float xf[TOK][8];
+      float xs[TOK][8];  // FAST only: x * scale in fp32
+      if (FAST) {
 #pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const uint32_t sp = s_raw[sw][c >> 1], bp = b_raw[sw][c >> 1];
-        const uint16_t sv = (c & 1) ? (uint16_t)(sp >> 16) : (uint16_t)sp;
-        const uint16_t bv = (c & 1) ? (uint16_t)(bp >> 16) : (uint16_t)bp;
-        s2[c] = splat16(sv);
-        b2[c] = splat16(bv);
+        for (int c = 0; c < 8; ++c) {
+          const float sv = DT::half_of(s_raw[sw][c >> 1], c & 1);
+          const float bv = DT::half_of(b_raw[sw][c >> 1], c & 1);
 #pragma unroll
-        for (int t = 0; t < TOK; ++t) {
-          float xv = 0.f;
-          if (t < tokens) {
-            const uint32_t xp = xs_raw[sw][t][c >> 1];
-            xv = (c & 1) ? DT::hi(xp) : DT::lo(xp);
-          }
-          if (FAST) {
+          for (int t = 0; t < TOK; ++t) {
+            const float xv = t < tokens ? DT::half_of(x_raw[sw][t][c >> 1], c & 1) : 0.f;
             // folded form: y = sum (x*s)*(c+r) + sum x*b   (fp32)
-            accb[t] = __builtin_fmaf(xv, DT::to_float(bv), accb[t]);
-            xv = xv * DT::to_float(sv);
+            accb[t] = __builtin_fmaf(xv, bv, accb[t]);
+            xs[t][c] = xv * sv;
           }
-          xf[t][c] = xv;
         }
       }
-      // ROWS*2 half-groups of 4 elements; the gathers of half-group g+1 are
-      // issued before the arithmetic of half-group g (LDS latency ~ one
-      // half-group of VALU work).
-      constexpr int NH = ROWS * 2;
-      u32x4 cv[2][4], rv[2][4];
+      // ROWS*4 units of one index word (2 elements, 4 gathers); the gathers of
+      // unit u+1 are issued before the arithmetic of unit u.
+      constexpr int NU = ROWS * 4;
+      u32x4 cv[2][2], rv[2][2];
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        gather<TAB>(iw[sw][0][e >> 1], e & 1, baseC, baseR, cv[0][e], rv[0][e]);
+      for (int e = 0; e < 2; ++e) gather(iw[sw][0][0], e, baseC, baseR, cv[0][e], rv[0][e]);
 #pragma unroll
-      for (int g = 0; g < NH; ++g) {
-        const int r = g >> 1, kh = g & 1;
-        if (g + 1 < NH) {
-          const int r1 = (g + 1) >> 1, kh1 = (g + 1) & 1;
+      for (int u = 0; u < NU; ++u) {
+        const int r = u >> 2, k = u & 3;
+        if (u + 1 < NU) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-            gather<TAB>(iw[sw][r1][kh1 * 2 + (e >> 1)], e & 1, baseC, baseR, cv[(g + 1) & 1][e],
-                        rv[(g + 1) & 1][e]);
+          for (int e = 0; e < 2; ++e)
+            gather(iw[sw][(u + 1) >> 2][(u + 1) & 3], e, baseC, baseR, cv[(u + 1) & 1][e],
+                   rv[(u + 1) & 1][e]);
         }
-        // stage-major order: the 16 independent pair-chains of the half-group
-        // advance together, so dependent packed-f16 ops are never back-to-back
-        uint32_t w2[4][4];
+        // stage-major order: the 8 independent pair-chains of the unit advance
+        // together, so dependent packed-f16 ops are never back-to-back
+        uint32_t w2[2][4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+        for (int e = 0; e < 2; ++e)
 #pragma unroll
-          for (int p = 0; p < 4; ++p) w2[e][p] = DT::add2(cv[g & 1][e][p], rv[g & 1][e][p]);
+          for (int p = 0; p < 4; ++p) w2[e][p] = DT::add2(cv[u & 1][e][p], rv[u & 1][e][p]);
         if (!FAST) {
+          // column 2k+e uses half e of pair register k of scale / bias
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
+          for (int e = 0; e < 2; ++e)
 #pragma unroll
-            for (int p = 0; p < 4; ++p) w2[e][p] = DT::mul2(w2[e][p], s2[kh * 4 + e]);
+            for (int p = 0; p < 4; ++p) w2[e][p] = DT::mul2_bcast(w2[e][p], s_raw[sw][k], e);
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
+          for (int e = 0; e < 2; ++e)
 #pragma unroll
-            for (int p = 0; p < 4; ++p) w2[e][p] = DT::add2(w2[e][p], b2[kh * 4 + e]);
+            for (int p = 0; p < 4; ++p) w2[e][p] = DT::add2_bcast(w2[e][p], b_raw[sw][k], e);
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int c = kh * 4 + e;
+        for (int e = 0; e < 2; ++e) {
 #pragma unroll
-          for (int t = 0; t < TOK; ++t)
+          for (int t = 0; t < TOK; ++t) {
+            if (t < tokens || TOK == 1) {
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-              acc[t][r][2 * p] = DT::fma_lo(w2[e][p], xf[t][c], acc[t][r][2 * p]);
-              acc[t][r][2 * p + 1] = DT::fma_hi(w2[e][p], xf[t][c], acc[t][r][2 * p + 1]);
+              for (int p = 0; p < 4; ++p) {
+                if (FAST) {
+                  acc[t][r][2 * p] = DT::fma_lo(w2[e][p], xs[t][2 * k + e], acc[t][r][2 * p]);
+                  acc[t][r][2 * p + 1] =
+                      DT::fma_hi(w2[e][p], xs[t][2 * k + e], acc[t][r][2 * p + 1]);
+                } else {
+                  acc[t][r][2 * p] =
+                      DT::fma_lo_h(w2[e][p], x_raw[sw][t][k], e, acc[t][r][2 * p]);
+                  acc[t][r][2 * p + 1] =
+                      DT::fma_hi_h(w2[e][p], x_raw[sw][t][k], e, acc[t][r][2 * p + 1]);
+                }
+              }
             }
+          }
         }
       }
     }
@@ -260,9 +243,9 @@ __global__ __launch_bounds__(kThreads) void gemv_k256_kernel(const K256Params P)
   // ---- 5. reduce over the workgroup's lanes and store ----
   constexpr int kVals = TOK * ROWS * 8;
   constexpr int kStride = kVals + TOK;  // floats per wave in the scratch area
-  const uint32_t red0 = L::kScratchOff;
-  float* red = (float*)(smem + L::kScratchOff);  // [kWaves][kStride]
-  if (RED == 1) {
+  const uint32_t red0 = kScratchOff;
+  float* red = (float*)(smem + kScratchOff);  // [kWaves][kStride]
+  {
     float v[kVals];
 #pragma unroll
     for (int t = 0; t < TOK; ++t)
@@ -280,16 +263,6 @@ __global__ __launch_bounds__(kThreads) void gemv_k256_kernel(const K256Params P)
         lds_store16(a + i * 4, u32x4{__float_as_uint(v[i]), __float_as_uint(v[i + 1]),
                                      __float_as_uint(v[i + 2]), __float_as_uint(v[i + 3])});
     }
-  } else {
-#pragma unroll
-    for (int t = 0; t < TOK; ++t)
-#pragma unroll
-      for (int r = 0; r < ROWS; ++r)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const float sum = wave_sum(acc[t][r][i]);
-          if (lane == 0) red[wave * kStride + (t * ROWS + r) * 8 + i] = sum;
-        }
   }
   if (FAST) {
 #pragma unroll
@@ -327,39 +300,16 @@ bool gemv_k256_eligible(const VptqLayerDesc& d, int tokens) {
                           (uintptr_t)d.weight_bias | (uintptr_t)d.perm) & 15) == 0;
 }
 
-static int tab_mode() {
-  static int m = -1;
-  if (m < 0) {
-    const char* e = getenv("VPTQ_K256_TAB");
-    m = (e && e[0] == '0') ? 0 : 1;
-  }
-  return m;
+// ROWS per workgroup: 2 when that still leaves >= 512 workgroups (two per CU) and
+// the instantiation stays spill-free under the 128-VGPR budget (f16, one token).
+static int pick_rows(int n_rows_total, int tok, bool f16) {
+  return (f16 && tok == 1 && (n_rows_total + 1) / 2 >= 512) ? 2 : 1;
 }
 
-static int red_mode() {  // VPTQ_K256_REDUCE=0: plain shuffle tree (A/B, debugging)
-  static int m = -1;
-  if (m < 0) {
-    const char* e = getenv("VPTQ_K256_REDUCE");
-    m = (e && e[0] == '0') ? 0 : 1;
-  }
-  return m;
-}
-
-// ROWS is chosen so the grid is about one workgroup per CU (256 CUs).
-static int pick_rows(int n_rows_total, int tokens, bool f16) {
-  int rows = 4;
-  while (rows > 1 && (n_rows_total + rows - 1) / rows < 256) rows >>= 1;
-  // accumulators per lane = 8 * rows * tok: keep the kernel spill-free
-  const int tok = tokens > 2 ? 4 : tokens;
-  const int cap = f16 ? (tok == 4 ? 4 : 8) : 4;
-  while (rows > 1 && rows * tok > cap) rows >>= 1;
-  return rows;
-}
-
-template <typename DT, int ROWS, int TOK, bool FAST, int TAB, int RED>
+template <typename DT, int ROWS, int TOK, bool FAST>
 static hipError_t launch_inst(const K256Params& P, int grid, hipStream_t st) {
-  auto kern = gemv_k256_kernel<DT, ROWS, TOK, FAST, TAB, RED>;
-  constexpr int lds = Lds<TAB>::kScratchOff + kWaves * (TOK * ROWS * 8 + TOK) * 4;
+  auto kern = gemv_k256_kernel<DT, ROWS, TOK, FAST>;
+  constexpr int lds = kScratchOff + kWaves * (TOK * ROWS * 8 + TOK) * 4;
   static bool attr_set = false;  // benign race: idempotent
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern,
@@ -371,26 +321,16 @@ static hipError_t launch_inst(const K256Params& P, int grid, hipStream_t st) {
   return hipGetLastError();
 }
 
-#define K256_CASE(DT, R, T, F, TB)                                   \
-  if (rows == R && tok == T && fast == F && tab == TB) {               \
-    if (red) return launch_inst<DT, R, T, F, TB, 1>(P, grid, st);      \
-    return launch_inst<DT, R, T, F, TB, 0>(P, grid, st);               \
-  }
+#define K256_CASE(DT, R, T, F) \
+  if (rows == R && tok == T && fast == F) return launch_inst<DT, R, T, F>(P, grid, st);
 
 template <typename DT, bool ALLOW_FAST>
-static hipError_t dispatch(const K256Params& P, int grid, int rows, int tok, bool fast, int tab,
-                           int red, hipStream_t st) {
-  K256_CASE(DT, 1, 1, false, 1) K256_CASE(DT, 2, 1, false, 1) K256_CASE(DT, 4, 1, false, 1)
-  K256_CASE(DT, 1, 2, false, 1) K256_CASE(DT, 2, 2, false, 1)
-  K256_CASE(DT, 1, 4, false, 1)
-  if constexpr (ALLOW_FAST) { K256_CASE(DT, 4, 2, false, 1) }
+static hipError_t dispatch(const K256Params& P, int grid, int rows, int tok, bool fast,
+                           hipStream_t st) {
+  K256_CASE(DT, 1, 1, false) K256_CASE(DT, 1, 2, false) K256_CASE(DT, 1, 4, false)
   if constexpr (ALLOW_FAST) {
-    K256_CASE(DT, 1, 1, true, 1) K256_CASE(DT, 2, 1, true, 1) K256_CASE(DT, 4, 1, true, 1)
-    K256_CASE(DT, 1, 2, true, 1) K256_CASE(DT, 2, 2, true, 1) K256_CASE(DT, 4, 2, true, 1)
-    K256_CASE(DT, 1, 4, true, 1)
-    // plain (un-replicated) tables: A/B baseline, tokens == 1 only
-    K256_CASE(DT, 1, 1, false, 0) K256_CASE(DT, 2, 1, false, 0) K256_CASE(DT, 4, 1, false, 0)
-    K256_CASE(DT, 1, 1, true, 0) K256_CASE(DT, 2, 1, true, 0) K256_CASE(DT, 4, 1, true, 0)
+    K256_CASE(DT, 2, 1, false)
+    K256_CASE(DT, 1, 1, true) K256_CASE(DT, 2, 1, true) K256_CASE(DT, 1, 2, true)
   }
   return hipErrorInvalidValue;
 }
@@ -409,7 +349,8 @@ hipError_t launch_gemv_k256(const VptqLayerDesc* descs, int n, const void* const
   int total_rows = 0;
   for (int i = 0; i < n; ++i) total_rows += descs[i].num_indices;
   const int tok = tokens > 2 ? 4 : tokens;
-  const int rows = pick_rows(total_rows, tokens, descs[0].dtype == VPTQ_DTYPE_F16);
+  const bool f16 = descs[0].dtype == VPTQ_DTYPE_F16;
+  const int rows = pick_rows(total_rows, tok, f16);
   int grid = 0;
   for (int i = 0; i < n; ++i) {
     const VptqLayerDesc& d = descs[i];
@@ -431,12 +372,10 @@ hipError_t launch_gemv_k256(const VptqLayerDesc* descs, int n, const void* const
     Ly.pad_ = 0;
     grid += (d.num_indices + rows - 1) / rows;
   }
-  const bool f16 = descs[0].dtype == VPTQ_DTYPE_F16;
-  const bool fast = f16 && (flags & VPTQ_GEMV_FAST_MATH);
-  int tab = tab_mode();
-  if (!f16 || tok != 1) tab = 1;
-  return f16 ? dispatch<F16, true>(P, grid, rows, tok, fast, tab, red_mode(), st)
-             : dispatch<BF16, false>(P, grid, rows, tok, false, tab, red_mode(), st);
+  // the folded-arithmetic instantiations exist for 1-2 tokens
+  const bool fast = f16 && tok <= 2 && (flags & VPTQ_GEMV_FAST_MATH);
+  return f16 ? dispatch<F16, true>(P, grid, rows, tok, fast, st)
+             : dispatch<BF16, false>(P, grid, rows, tok, false, st);
 }
 
 }  // namespace vptq
