@@ -43,6 +43,26 @@ def alg_bytes(H):
     return (H // 8) * (H * 16 // 32) * 4 + 2 * 256 * 8 * 2 + 2 * H + 4 * H + 2 * H
 
 
+def shard_ring(total_layers, rank, world):
+    """Layer-parallel sharding: independent VQuantLinear layers are dealt round-robin to
+    ranks; no rank ever needs another rank's layer (no data-path collective)."""
+    return list(range(rank, total_layers, world))
+
+
+def reduce_times(wall_s, event_ms, dist_mod=None, device="cpu"):
+    """max over ranks of (wall seconds, HIP-event milliseconds)."""
+    if dist_mod is None:
+        return wall_s, event_ms
+    tt = torch.tensor([wall_s, event_ms], device=device, dtype=torch.float64)
+    dist_mod.all_reduce(tt, op=dist_mod.ReduceOp.MAX)
+    return tuple(tt.tolist())
+
+
+def job_throughput_gbps(world, bytes_per_launch_layer, layers_per_rank, steps, wall_s):
+    """Whole-job GB/s: every rank streams its own ring `steps` times in `wall_s`."""
+    return world * bytes_per_launch_layer * layers_per_rank * steps / wall_s / 1e9
+
+
 def make_ring(H, R, dev, seed):
     import vptq_amd
     g = torch.Generator(device=dev).manual_seed(seed)
@@ -194,14 +214,10 @@ def main():
         torch.cuda.synchronize()
         wall = time.perf_counter() - t0
     ev_ms = e0.elapsed_time(e1)
-    if dist is not None:
-        tt = torch.tensor([wall, ev_ms], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        wall, ev_ms = tt.tolist()
+    wall, ev_ms = reduce_times(wall, ev_ms, dist, dev)
 
     ab = alg_bytes(H)
-    total_bytes = world * ab * R * a.steps
-    value = total_bytes / wall / 1e9
+    value = job_throughput_gbps(world, ab, R, a.steps, wall)
     us_per_launch = ev_ms * 1e3 / (a.steps * launches_per_step)
     bytes_per_launch = ab * R / launches_per_step
     achieved = bytes_per_launch / us_per_launch / 1e3     # GB/s
@@ -222,6 +238,12 @@ def main():
                      "note": "us_per_launch = HIP-event time over the timed region / launches "
                              "(includes inter-kernel gaps); kernel is VALU-issue bound, see DESIGN.md §4"},
     }
+    pmc = os.path.join(ROOT, "profiles", "r01", f"bench_h{H}_{a.mode}_pmc_summary.json")
+    if os.path.exists(pmc) and not a.fast_math:
+        # HBM bytes per launch from a separate rocprofv3 --pmc run of this same command
+        # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); see the file's _note
+        out["roofline"]["traffic"] = json.load(open(pmc)).get("hbm_bytes_corrected")
+        out["roofline"]["traffic_source"] = os.path.relpath(pmc, ROOT)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         torch.cuda.synchronize()
         base, rel = cpu_baseline(layers[0], x, ys[0], H)
