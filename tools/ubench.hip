@@ -27,6 +27,7 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, unsigned seed) {
   for (int i = 0; i < UNROLL; ++i) { r[i] = (t * 2654435761u + i * 40503u + seed) & 0x3bff3bffu; f[i] = 1.0f + (float)(t & 15) * 0.001f + i; }
   unsigned a = 0x3c003c00u ^ (seed & 1), b = 0x38003800u | (seed & 2);
   float fa = 1.0001f, fb = 0.9999f;
+  float fa2[2] = {1.0001f, 0.9998f}, fb2[2] = {1e-3f, 2e-3f};
   f4 acc4[4]; for (int i = 0; i < 4; ++i) acc4[i] = f4{0, 0, 0, 0};
   __shared__ __attribute__((aligned(16))) unsigned lds[4096 * 4];
   if (OP >= 20) { for (int i = threadIdx.x; i < 4096 * 4; i += 256) lds[i] = i * seed; __syncthreads(); }
@@ -73,6 +74,10 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, unsigned seed) {
 #define S(i) asm volatile("v_add_f16 %0, %0, %1" : "+v"(r[i]) : "v"(a));
       REP16(S)
 #undef S
+    } else if (OP == 13) {
+      // 16 x v_pk_fma_f32 (2 fp32 FMAs per lane per instruction)
+      for (int j = 0; j < 16; j += 2) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(*(double*)&f[j]) : "v"(*(double*)&fa2), "v"(*(double*)&fb2));
+      for (int j = 0; j < 16; j += 2) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(*(double*)&f[j]) : "v"(*(double*)&fb2), "v"(*(double*)&fa2));
     } else if (OP == 10) {  // 16 x mfma 4x4x4 (16 blocks) f16
       h4 av = __builtin_bit_cast(h4, (unsigned long long)a | ((unsigned long long)b << 32));
       h4 bv = __builtin_bit_cast(h4, (unsigned long long)b | ((unsigned long long)a << 32));
@@ -146,7 +151,7 @@ double run(const char* name, int waves_per_simd, int iters) {
   return ns;
 }
 
-#define RUN(OP, NAME) for (int w : {1, 2, 4}) run<OP>(NAME, w, 20000);
+#define RUN(OP, NAME) for (int w : {2, 4, 8}) run<OP>(NAME, w, 20000);
 
 int main() {
   hipDeviceProp_t p; CHECK(hipGetDeviceProperties(&p, 0));
@@ -154,7 +159,7 @@ int main() {
   RUN(0, "v_fma_f32") RUN(1, "v_pk_add_f16") RUN(2, "v_pk_mul_f16") RUN(3, "v_pk_fma_f16")
   RUN(4, "v_fma_mix_f32") RUN(5, "v_perm_b32") RUN(6, "v_and_b32") RUN(7, "v_dot2_f32_f16")
   RUN(8, "v_cvt_f32_f16") RUN(9, "v_add_f16") RUN(10, "mfma_f32_4x4x4f16") RUN(11, "mfma_f32_16x16x32_f16")
-  RUN(12, "16 pk_add + 8 mfma4x4x4") RUN(20, "ds_read_b128 partitioned") RUN(21, "ds_read_b128 random")
+  RUN(13, "v_pk_fma_f32") RUN(12, "16 pk_add + 8 mfma4x4x4") RUN(20, "ds_read_b128 partitioned") RUN(21, "ds_read_b128 random")
   RUN(22, "ds_write_b128 rotating")
   return 0;
 }

@@ -129,6 +129,7 @@ int vptq_quant_gemv_grouped(const VptqLayerDesc* descs, int n, const void* const
   if (tokens < 1 || tokens > VPTQ_GEMV_MAX_TOKENS)
     return fail(VPTQ_E_TOKENS, "tokens %d outside [1, %d]", tokens, VPTQ_GEMV_MAX_TOKENS);
   bool all_fast = !(flags & VPTQ_GEMV_FORCE_GENERIC);
+  bool same_perm = true;  // one instantiation serves the whole group
   for (int i = 0; i < n; ++i) {
     int rc = validate_layer(&descs[i]);
     if (rc) return rc;
@@ -137,8 +138,16 @@ int vptq_quant_gemv_grouped(const VptqLayerDesc* descs, int n, const void* const
       return fail(VPTQ_E_UNSUPPORTED, "grouped layers must share one dtype");
     all_fast = all_fast && vptq::gemv_k256_eligible(descs[i], tokens) &&
                (((uintptr_t)x[i]) & 15) == 0;
+    same_perm = same_perm && ((descs[i].perm != nullptr) == (descs[0].perm != nullptr));
   }
   hipStream_t st = (hipStream_t)stream;
+  if (all_fast && !same_perm) {
+    for (int i = 0; i < n; ++i) {
+      hipError_t e = vptq::launch_gemv_k256(descs + i, 1, x + i, y + i, tokens, flags, st);
+      if (e != hipSuccess) return hip_fail(e, "gemv_k256 launch");
+    }
+    return VPTQ_OK;
+  }
   if (all_fast) {
     // one launch for up to 32 layers
     for (int i0 = 0; i0 < n; i0 += 32) {

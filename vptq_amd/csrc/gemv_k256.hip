@@ -37,7 +37,6 @@ namespace vptq {
 constexpr int kThreads = 512;
 constexpr int kWaves = kThreads / 64;
 constexpr int kSweepCols = kThreads * 8;  // columns covered by one sweep of the WG
-constexpr int kSW = 2;                    // sweeps issued back-to-back per iteration
 constexpr int kMaxGroup = 32;
 constexpr int kTableBytes = 65536;        // 256 rows x 256 B
 constexpr int kScratchOff = kTableBytes;
@@ -73,7 +72,20 @@ static __device__ __forceinline__ void gather(uint32_t w, int h, uint32_t baseC,
   rv = lds_load16(aR);
 }
 
-template <typename DT, int ROWS, int TOK, bool FAST>
+// 16-byte load of 8 consecutive 16-bit values, or (PERM) a gather of 8 values through
+// the permutation: column c of the quantised matrix multiplies input feature perm[c].
+template <bool PERM>
+static __device__ __forceinline__ u32x4 load8(const uint16_t* __restrict__ p, int col0,
+                                              const u32x4& pv) {
+  if (!PERM) return *(const u32x4*)(p + col0);
+  u32x4 r;
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    r[q] = (uint32_t)p[pv[q] & 0xffffu] | ((uint32_t)p[pv[q] >> 16] << 16);
+  return r;
+}
+
+template <typename DT, int ROWS, int TOK, int SW, bool PERM, bool FAST>
 __global__ __launch_bounds__(kThreads, 4) void gemv_k256_kernel(const K256Params P) {
   // The dynamic LDS segment starts at byte 0 (the kernel has no static LDS), so
   // gathers address LDS absolutely; `smem` only sizes the allocation.
@@ -89,10 +101,20 @@ __global__ __launch_bounds__(kThreads, 4) void gemv_k256_kernel(const K256Params
   const int row0 = (bid - Ly.wg_begin) * ROWS;
   const int G = Ly.G, N = Ly.N, O = Ly.O;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t* const idx_base = Ly.idx;
+  const uint16_t* const xp = Ly.x;
+  const uint16_t* const sp = Ly.scale;
+  const uint16_t* const bp = Ly.wbias;
+  const uint16_t* const pp = Ly.perm;
+  const size_t row_words = (size_t)Ly.row_words;
 
-  // ---- 1. codebook entry for the LDS image: thread t loads entry t ----
-  const uint32_t* csrc = (tid < 256 ? Ly.cent : Ly.rcent) + (tid & 255) * 4;
-  const u32x4 centry = *(const u32x4*)csrc;
+  // ---- 1. codebook entry for the LDS image: thread t loads entry t.  Both table
+  // pointers are read as scalars; the per-thread choice is an offset, so the load
+  // does not wait on a vector fetch of the pointer itself. ----
+  const char* const cent0 = (const char*)Ly.cent;
+  const ptrdiff_t rdelta = (const char*)Ly.rcent - cent0;
+  const u32x4 centry =
+      *(const u32x4*)(cent0 + (tid < 256 ? (ptrdiff_t)0 : rdelta) + (size_t)(tid & 255) * 16);
 
   float acc[TOK][ROWS][8];
   float accb[TOK];
@@ -109,51 +131,37 @@ __global__ __launch_bounds__(kThreads, 4) void gemv_k256_kernel(const K256Params
   const uint32_t baseC = (uint32_t)(lane & 7) << 4;
   const uint32_t baseR = baseC | 0x80u;
 
-  bool tables_ready = false;
-
-  for (int base = 0; base < G; base += kSW * kSweepCols) {
+  // Straight-line body: no load is predicated.  Lanes past the last column re-read the
+  // last 8 columns with x forced to 0; rows past N re-read row N-1 and are not stored.
+  for (int base = 0; base < G; base += SW * kSweepCols) {
     // ---- 2. issue every global load of this iteration ----
-    u32x4 x_raw[kSW][TOK], s_raw[kSW], b_raw[kSW];
-    u32x4 iw[kSW][ROWS];
-    bool valid[kSW];
+    u32x4 x_raw[SW][TOK], s_raw[SW], b_raw[SW];
+    u32x4 iw[SW][ROWS];
 #pragma unroll
-    for (int sw = 0; sw < kSW; ++sw) {
-      const int col0 = base + sw * kSweepCols + tid * 8;
-      valid[sw] = col0 < G;  // G % 8 == 0 (checked on the host)
-      if (valid[sw]) {
-        if (Ly.perm == nullptr) {
-          s_raw[sw] = *(const u32x4*)(Ly.scale + col0);
-          b_raw[sw] = *(const u32x4*)(Ly.wbias + col0);
+    for (int sw = 0; sw < SW; ++sw) {
+      const int want = base + sw * kSweepCols + tid * 8;
+      const bool valid = want < G;  // G % 8 == 0 (checked on the host)
+      const int col0 = valid ? want : G - 8;
+      u32x4 pv = u32x4{0, 0, 0, 0};
+      if (PERM) pv = *(const u32x4*)(pp + col0);
+      s_raw[sw] = load8<PERM>(sp, col0, pv);
+      b_raw[sw] = load8<PERM>(bp, col0, pv);
 #pragma unroll
-          for (int t = 0; t < TOK; ++t)
-            if (t < tokens) x_raw[sw][t] = *(const u32x4*)(Ly.x + (size_t)t * G + col0);
-        } else {
-          // column c of the quantised matrix multiplies input feature perm[c]
-          const u32x4 pv = *(const u32x4*)(Ly.perm + col0);
+      for (int t = 0; t < TOK; ++t) {
+        const int te = t < tokens ? t : tokens - 1;  // spare token slots repeat the last row
+        const u32x4 xv = load8<PERM>(xp + (size_t)te * G, col0, pv);
+        const uint32_t keep = valid ? 0xffffffffu : 0u;
+        x_raw[sw][t] = u32x4{xv[0] & keep, xv[1] & keep, xv[2] & keep, xv[3] & keep};
+      }
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const uint32_t j0 = pv[q] & 0xffffu, j1 = pv[q] >> 16;
-            s_raw[sw][q] = (uint32_t)Ly.scale[j0] | ((uint32_t)Ly.scale[j1] << 16);
-            b_raw[sw][q] = (uint32_t)Ly.wbias[j0] | ((uint32_t)Ly.wbias[j1] << 16);
-#pragma unroll
-            for (int t = 0; t < TOK; ++t)
-              if (t < tokens)
-                x_raw[sw][t][q] = (uint32_t)Ly.x[(size_t)t * G + j0] |
-                                  ((uint32_t)Ly.x[(size_t)t * G + j1] << 16);
-          }
-        }
-#pragma unroll
-        for (int r = 0; r < ROWS; ++r) {
-          // rows past N (last workgroup) re-read row N-1; their results are dropped
-          const int row = row0 + r < N ? row0 + r : N - 1;
-          iw[sw][r] = *(const u32x4*)(Ly.idx + (size_t)row * Ly.row_words + (col0 >> 1));
-        }
+      for (int r = 0; r < ROWS; ++r) {
+        const int row = row0 + r < N ? row0 + r : N - 1;
+        iw[sw][r] = *(const u32x4*)(idx_base + (size_t)row * row_words + (col0 >> 1));
       }
     }
 
-    // ---- 3. build the LDS codebook image (first iteration only) ----
-    if (!tables_ready) {
-      tables_ready = true;
+    // ---- 3. build the LDS codebook image (first iteration only; uniform branch) ----
+    if (base == 0) {
       // thread t owns half a bank row: 8 replicas of its entry.  The replica
       // order is rotated by the lane id so the 8 lanes of a ds_write_b128 group
       // hit 8 different 16-byte slots.
@@ -165,8 +173,7 @@ __global__ __launch_bounds__(kThreads, 4) void gemv_k256_kernel(const K256Params
 
     // ---- 4. dequantise + accumulate ----
 #pragma unroll
-    for (int sw = 0; sw < kSW; ++sw) {
-      if (!valid[sw]) continue;
+    for (int sw = 0; sw < SW; ++sw) {
       float xs[TOK][8];  // FAST only: x * scale in fp32
       if (FAST) {
 #pragma unroll
@@ -175,7 +182,7 @@ __global__ __launch_bounds__(kThreads, 4) void gemv_k256_kernel(const K256Params
           const float bv = DT::half_of(b_raw[sw][c >> 1], c & 1);
 #pragma unroll
           for (int t = 0; t < TOK; ++t) {
-            const float xv = t < tokens ? DT::half_of(x_raw[sw][t][c >> 1], c & 1) : 0.f;
+            const float xv = DT::half_of(x_raw[sw][t][c >> 1], c & 1);
             // folded form: y = sum (x*s)*(c+r) + sum x*b   (fp32)
             accb[t] = __builtin_fmaf(xv, bv, accb[t]);
             xs[t][c] = xv * sv;
@@ -219,19 +226,16 @@ __global__ __launch_bounds__(kThreads, 4) void gemv_k256_kernel(const K256Params
         for (int e = 0; e < 2; ++e) {
 #pragma unroll
           for (int t = 0; t < TOK; ++t) {
-            if (t < tokens || TOK == 1) {
 #pragma unroll
-              for (int p = 0; p < 4; ++p) {
-                if (FAST) {
-                  acc[t][r][2 * p] = DT::fma_lo(w2[e][p], xs[t][2 * k + e], acc[t][r][2 * p]);
-                  acc[t][r][2 * p + 1] =
-                      DT::fma_hi(w2[e][p], xs[t][2 * k + e], acc[t][r][2 * p + 1]);
-                } else {
-                  acc[t][r][2 * p] =
-                      DT::fma_lo_h(w2[e][p], x_raw[sw][t][k], e, acc[t][r][2 * p]);
-                  acc[t][r][2 * p + 1] =
-                      DT::fma_hi_h(w2[e][p], x_raw[sw][t][k], e, acc[t][r][2 * p + 1]);
-                }
+            for (int p = 0; p < 4; ++p) {
+              if (FAST) {
+                acc[t][r][2 * p] = DT::fma_lo(w2[e][p], xs[t][2 * k + e], acc[t][r][2 * p]);
+                acc[t][r][2 * p + 1] =
+                    DT::fma_hi(w2[e][p], xs[t][2 * k + e], acc[t][r][2 * p + 1]);
+              } else {
+                acc[t][r][2 * p] = DT::fma_lo_h(w2[e][p], x_raw[sw][t][k], e, acc[t][r][2 * p]);
+                acc[t][r][2 * p + 1] =
+                    DT::fma_hi_h(w2[e][p], x_raw[sw][t][k], e, acc[t][r][2 * p + 1]);
               }
             }
           }
@@ -306,9 +310,9 @@ static int pick_rows(int n_rows_total, int tok, bool f16) {
   return (f16 && tok == 1 && (n_rows_total + 1) / 2 >= 512) ? 2 : 1;
 }
 
-template <typename DT, int ROWS, int TOK, bool FAST>
+template <typename DT, int ROWS, int TOK, int SW, bool PERM, bool FAST>
 static hipError_t launch_inst(const K256Params& P, int grid, hipStream_t st) {
-  auto kern = gemv_k256_kernel<DT, ROWS, TOK, FAST>;
+  auto kern = gemv_k256_kernel<DT, ROWS, TOK, SW, PERM, FAST>;
   constexpr int lds = kScratchOff + kWaves * (TOK * ROWS * 8 + TOK) * 4;
   static bool attr_set = false;  // benign race: idempotent
   if (!attr_set) {
@@ -321,12 +325,22 @@ static hipError_t launch_inst(const K256Params& P, int grid, hipStream_t st) {
   return hipGetLastError();
 }
 
+template <typename DT, int ROWS, int TOK, bool FAST>
+static hipError_t launch_shape(const K256Params& P, int grid, int sw, bool perm, hipStream_t st) {
+  if (sw == 1) {
+    return perm ? launch_inst<DT, ROWS, TOK, 1, true, FAST>(P, grid, st)
+                : launch_inst<DT, ROWS, TOK, 1, false, FAST>(P, grid, st);
+  }
+  return perm ? launch_inst<DT, ROWS, TOK, 2, true, FAST>(P, grid, st)
+              : launch_inst<DT, ROWS, TOK, 2, false, FAST>(P, grid, st);
+}
+
 #define K256_CASE(DT, R, T, F) \
-  if (rows == R && tok == T && fast == F) return launch_inst<DT, R, T, F>(P, grid, st);
+  if (rows == R && tok == T && fast == F) return launch_shape<DT, R, T, F>(P, grid, sw, perm, st);
 
 template <typename DT, bool ALLOW_FAST>
-static hipError_t dispatch(const K256Params& P, int grid, int rows, int tok, bool fast,
-                           hipStream_t st) {
+static hipError_t dispatch(const K256Params& P, int grid, int rows, int tok, bool fast, int sw,
+                           bool perm, hipStream_t st) {
   K256_CASE(DT, 1, 1, false) K256_CASE(DT, 1, 2, false) K256_CASE(DT, 1, 4, false)
   if constexpr (ALLOW_FAST) {
     K256_CASE(DT, 2, 1, false)
@@ -374,8 +388,18 @@ hipError_t launch_gemv_k256(const VptqLayerDesc* descs, int n, const void* const
   }
   // the folded-arithmetic instantiations exist for 1-2 tokens
   const bool fast = f16 && tok <= 2 && (flags & VPTQ_GEMV_FAST_MATH);
-  return f16 ? dispatch<F16, true>(P, grid, rows, tok, fast, st)
-             : dispatch<BF16, false>(P, grid, rows, tok, false, st);
+  // all layers of a group share one instantiation: widest column count decides the
+  // sweeps per iteration, any permutation selects the gather variant (grouped layers
+  // must agree on it, checked by the caller)
+  int maxG = 0;
+  bool perm = false;
+  for (int i = 0; i < n; ++i) {
+    maxG = descs[i].group_size > maxG ? descs[i].group_size : maxG;
+    perm = perm || descs[i].perm != nullptr;
+  }
+  const int sw = maxG > kSweepCols ? 2 : 1;
+  return f16 ? dispatch<F16, true>(P, grid, rows, tok, fast, sw, perm, st)
+             : dispatch<BF16, false>(P, grid, rows, tok, false, sw, perm, st);
 }
 
 }  // namespace vptq
