@@ -130,6 +130,8 @@ def main():
     ap.add_argument("--fast-math", action="store_true",
                     help="folded fp32 arithmetic (VPTQ_GEMV_FAST_MATH); not the default path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prefetch", action="store_true",
+                    help="do not let layer i read layer i+1's indices ahead (chain_prefetch)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -157,8 +159,10 @@ def main():
                     generator=torch.Generator(device=dev).manual_seed(7))
     ys = [torch.empty(1, 1, H, device=dev, dtype=torch.float16) for _ in range(R)]
     descs, keeps = [], []
-    for m in layers:
-        d, k = module_desc(m)
+    for i, m in enumerate(layers):
+        # decode order is known: layer i warms L2 / Infinity Cache with layer i+1's indices
+        nxt = None if a.no_prefetch else layers[(i + 1) % R].indices
+        d, k = module_desc(m, prefetch=nxt)
         descs.append(d)
         keeps.append(k)
     flags = B.GEMV_FAST_MATH if a.fast_math else 0
@@ -231,6 +235,7 @@ def main():
                                f"packed indices), 1 step = 1 pass over the ring",
                    "hidden": H, "ring": R, "mode": a.mode, "launches_per_step": launches_per_step,
                    "kernel": kname, "arithmetic": "fast_math" if a.fast_math else "reference-rounding",
+                   "read_ahead_next_layer": not a.no_prefetch,
                    "parallelism": f"{world} x independent rings (no collective)"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": None,

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define VPTQ_ABI_VERSION 1
+#define VPTQ_ABI_VERSION 2
 
 #if defined(__GNUC__)
 #define VPTQ_API __attribute__((visibility("default")))
@@ -114,6 +114,11 @@ typedef struct VptqLayerDesc {
   const void* weight_scale;        /* [I]   NULL (with weight_bias) = no norm   */
   const void* weight_bias;         /* [I]                                       */
   const void* bias;                /* [O]                   NULL = none         */
+  /* Optional derived state (all nullable; results never depend on them): */
+  const void* scale_permuted;      /* [I] weight_scale[perm[c]]: lets the GEMV read scale in  */
+  const void* bias_permuted;       /* [I] weight_bias[perm[c]]   column order (perm != NULL)  */
+  const void* prefetch;            /* read-only range the GEMV may touch to warm L2 / Infinity  */
+  int64_t prefetch_bytes;          /* Cache for the NEXT launch (e.g. the next layer's indices) */
 } VptqLayerDesc;
 
 /*

@@ -18,7 +18,8 @@ class Desc(C.Structure):  # VptqLayerDesc with HOST pointers (include/vptq_hip.h
         "num_indices", "outlier_size", "outlier_vector_len", "num_outlier_centroids",
         "num_outlier_indices", "dtype")] + [(n, _vp) for n in (
             "indices", "centroids", "res_centroids", "outlier_indices", "outlier_centroids",
-            "perm", "inv_perm", "weight_scale", "weight_bias", "bias")]
+            "perm", "inv_perm", "weight_scale", "weight_bias", "bias", "scale_permuted",
+            "bias_permuted", "prefetch")] + [("prefetch_bytes", C.c_int64)]
 
 
 _lib = None

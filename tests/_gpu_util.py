@@ -55,7 +55,7 @@ def spec_to_module(L, device):
     return m.eval()
 
 
-def module_desc(m, need_inv_perm=False):
+def module_desc(m, need_inv_perm=False, prefetch=None):
     """C-ABI descriptor of a vptq_amd.VQuantLinear (tests call the ABI directly
     to reach flags the Python API does not expose)."""
     from vptq_amd import _backend as B
@@ -71,7 +71,8 @@ def module_desc(m, need_inv_perm=False):
         num_res_centroids=m.num_res_centroids if m.enable_residual else 0,
         group_size=m.group_size, outlier_size=m.outlier_size,
         outlier_vector_len=m.outlier_vector_len,
-        num_outlier_centroids=m.num_outlier_centroids, need_inv_perm=need_inv_perm)
+        num_outlier_centroids=m.num_outlier_centroids, need_inv_perm=need_inv_perm,
+        prefetch=prefetch)
 
 
 def gemv_abi(m, x, flags=0):

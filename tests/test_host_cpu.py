@@ -32,12 +32,12 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, s), f"{s} declared in include/vptq_hip.h but not exported"
     assert sorted(B.EXPORTS) == syms, "python binding table out of sync with the header"
     lib.vptq_abi_version.restype = ctypes.c_int
-    assert lib.vptq_abi_version() == B.ABI_VERSION == 1
+    assert lib.vptq_abi_version() == B.ABI_VERSION == 2
 
 
 def test_ctypes_struct_layout_matches_header():
-    # 16 int32 + 10 pointers; 8 int32 + 7 pointers
-    assert ctypes.sizeof(B.LayerDesc) == 16 * 4 + 10 * 8
+    # 16 int32 + 13 pointers + int64; 8 int32 + 7 pointers
+    assert ctypes.sizeof(B.LayerDesc) == 16 * 4 + 13 * 8 + 8
     assert ctypes.sizeof(B.V2Desc) == 8 * 4 + 7 * 8
     hdr = open(os.path.join(ROOT, "include", "vptq_hip.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
@@ -153,6 +153,22 @@ def test_module_matches_reference_state_dict_and_meta_init():
         for attr in ("padding", "num_indices", "outlier_padding", "vector_len", "num_codebooks",
                      "num_centroids", "num_res_centroids", "enable_outlier", "enable_residual"):
             assert getattr(rm, attr) == getattr(mm, attr), (name, attr)
+
+
+def test_derived_state_cache_follows_the_tensor_not_the_address():
+    """inv_perm / permuted scale are cached on the owning tensor object: a new tensor that
+    happens to reuse a freed tensor's address must not see stale derived state."""
+    for _ in range(20):
+        perm = torch.randperm(64).to(torch.int32).to(torch.int16)
+        t = torch.randn(64).half()
+        assert torch.equal(B.inverse_perm(perm).long(), torch.argsort(perm.long()))
+        assert torch.equal(B.permuted_norm(perm, t, "scale"), t[perm.long()])
+        del perm, t
+    perm = torch.randperm(64).to(torch.int32).to(torch.int16)
+    first = B.inverse_perm(perm)
+    assert B.inverse_perm(perm) is first                      # cached
+    perm.data = torch.randperm(64).to(torch.int32).to(torch.int16)
+    assert torch.equal(B.inverse_perm(perm).long(), torch.argsort(perm.long()))
 
 
 def test_vptq_alias_for_hf():

@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--perm", action="store_true")
     ap.add_argument("--group", type=int, default=32)
+    ap.add_argument("--prefetch", action="store_true")
     ap.add_argument("--out", default="")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -99,8 +100,8 @@ def main():
 
     from tests_gpu_util import module_desc  # noqa
     descs, keeps, ys = [], [], []
-    for m in layers:
-        d, k = module_desc(m)
+    for i, m in enumerate(layers):
+        d, k = module_desc(m, prefetch=layers[(i + 1) % R].indices if a.prefetch else None)
         descs.append(d); keeps.append(k); ys.append(torch.empty(1, 1, H, device=dev, dtype=torch.float16))
 
     def launch_one(i, flags):

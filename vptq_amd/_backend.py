@@ -17,7 +17,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvptq_hip.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 DTYPE_F16, DTYPE_BF16 = 0, 1
 GEMV_FAST_MATH = 1 << 0
 GEMV_FORCE_GENERIC = 1 << 1
@@ -35,7 +35,8 @@ class LayerDesc(C.Structure):
         "num_indices", "outlier_size", "outlier_vector_len", "num_outlier_centroids",
         "num_outlier_indices", "dtype")] + [(n, _vp) for n in (
             "indices", "centroids", "res_centroids", "outlier_indices", "outlier_centroids",
-            "perm", "inv_perm", "weight_scale", "weight_bias", "bias")]
+            "perm", "inv_perm", "weight_scale", "weight_bias", "bias", "scale_permuted",
+            "bias_permuted", "prefetch")] + [("prefetch_bytes", C.c_int64)]
 
 
 class V2Desc(C.Structure):
@@ -131,7 +132,19 @@ def current_stream_ptr(device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
 
-_invperm_cache = {}
+def _derived(owner: torch.Tensor, name: str, key, build):
+    """Derived state cached ON the owning tensor object (so it dies with it and is never
+    confused with another tensor that later reuses the same address), re-built when the
+    owner's storage pointer or version counter changes."""
+    slot = getattr(owner, "_vptq_derived", None)
+    if slot is None:
+        slot = {}
+        owner._vptq_derived = slot
+    hit = slot.get(name)
+    if hit is None or hit[0] != key:
+        hit = (key, build())
+        slot[name] = hit
+    return hit[1]
 
 
 def inverse_perm(perm: torch.Tensor) -> torch.Tensor:
@@ -139,24 +152,29 @@ def inverse_perm(perm: torch.Tensor) -> torch.Tensor:
 
     The reference recomputes this with a sort kernel on EVERY forward
     (vptq/ops/quant_gemm.py:208-211)."""
-    key = (perm.data_ptr(), perm._version, perm.numel(), perm.device)
-    hit = _invperm_cache.get(key)
-    if hit is None:
-        p = perm.view(torch.int16).to(torch.int64) & 0xFFFF
+    def build():
+        p = perm.detach().view(torch.int16).to(torch.int64) & 0xFFFF
         inv = torch.argsort(p)
         # store the uint16 bit pattern in an int16 tensor
-        hit = torch.where(inv >= 32768, inv - 65536, inv).to(torch.int16)
-        if len(_invperm_cache) > 4096:
-            _invperm_cache.clear()
-        _invperm_cache[key] = hit
-    return hit
+        return torch.where(inv >= 32768, inv - 65536, inv).to(torch.int16)
+    return _derived(perm, "inv_perm", (perm.data_ptr(), perm._version, perm.numel()), build)
+
+
+def permuted_norm(perm: torch.Tensor, t: torch.Tensor, name: str) -> torch.Tensor:
+    """t[perm[c]] in column order (derived state): lets the GEMV read scale / bias with
+    coalesced loads when a permutation is present."""
+    def build():
+        idx = perm.detach().view(torch.int16).to(torch.int64) & 0xFFFF
+        return t.detach()[idx].contiguous()
+    key = (perm.data_ptr(), perm._version, t.data_ptr(), t._version, t.numel())
+    return _derived(t, "permuted_" + name, key, build)
 
 
 def make_layer_desc(*, indices, centroids, res_centroids, outlier_indices, outlier_centroids,
                     perm, weight_scale, weight_bias, bias, in_features, out_features,
                     vector_len, num_codebooks, num_centroids, num_res_centroids, group_size,
                     outlier_size, outlier_vector_len, num_outlier_centroids,
-                    need_inv_perm=False):
+                    need_inv_perm=False, prefetch=None):
     """Build a LayerDesc from reference-format tensors.  Returns (desc, keepalive)."""
     if indices.dtype != torch.int32:
         # reference: TORCH_CHECK_EQ(q_indice.dtype(), torch::kInt) (csrc/quant_gemv.cu:258)
@@ -194,4 +212,14 @@ def make_layer_desc(*, indices, centroids, res_centroids, outlier_indices, outli
     d.weight_scale = _ptr(weight_scale) if norm else None
     d.weight_bias = _ptr(weight_bias) if norm else None
     d.bias = _ptr(bias)
+    d.scale_permuted = d.bias_permuted = None
+    if perm is not None and norm and not need_inv_perm:
+        sp = permuted_norm(perm, weight_scale, "scale")
+        bp = permuted_norm(perm, weight_bias, "bias")
+        keep += [sp, bp]
+        d.scale_permuted, d.bias_permuted = _ptr(sp), _ptr(bp)
+    d.prefetch, d.prefetch_bytes = None, 0
+    if prefetch is not None:
+        keep.append(prefetch)
+        d.prefetch, d.prefetch_bytes = prefetch.data_ptr(), prefetch.numel() * prefetch.element_size()
     return d, keep

@@ -95,7 +95,7 @@ size_t vptq_quant_gemv_workspace_bytes(const VptqLayerDesc*, int, int) { return 
 
 const char* vptq_quant_gemv_kernel_name(const VptqLayerDesc* d, int tokens, int flags) {
   if (validate_layer(d) != VPTQ_OK || tokens < 1 || tokens > VPTQ_GEMV_MAX_TOKENS) return nullptr;
-  if (!(flags & VPTQ_GEMV_FORCE_GENERIC) && vptq::gemv_k256_eligible(*d, tokens))
+  if (!(flags & VPTQ_GEMV_FORCE_GENERIC) && vptq::gemv_k256_eligible(*d, tokens > 4 ? 4 : tokens))
     return vptq::gemv_k256_name(*d, tokens, flags);
   return "gemv_generic_kernel";
 }
@@ -111,10 +111,18 @@ int vptq_quant_gemv(const VptqLayerDesc* d, const void* x, void* y, int tokens, 
                 VPTQ_GEMV_MAX_TOKENS);
   hipStream_t st = (hipStream_t)stream;
   hipError_t e;
-  if (!(flags & VPTQ_GEMV_FORCE_GENERIC) && vptq::gemv_k256_eligible(*d, tokens) &&
-      (((uintptr_t)x) & 15) == 0) {
-    e = vptq::launch_gemv_k256(d, 1, &x, &y, tokens, flags, st);
-    if (e != hipSuccess) return hip_fail(e, "gemv_k256 launch");
+  // the specialised kernel takes up to 4 tokens per launch; 5..8 tokens = two launches
+  // (still far cheaper than the generic kernel or a dense dequant + GEMM)
+  const int chunk = tokens > 4 ? 4 : tokens;
+  if (!(flags & VPTQ_GEMV_FORCE_GENERIC) && vptq::gemv_k256_eligible(*d, chunk) &&
+      (((uintptr_t)x) & 15) == 0 && (tokens <= 4 || (d->in_features % 8) == 0)) {
+    for (int t0 = 0; t0 < tokens; t0 += 4) {
+      const int m = tokens - t0 < 4 ? tokens - t0 : 4;
+      const void* xc = (const char*)x + (size_t)t0 * d->in_features * 2;
+      void* yc = (char*)y + (size_t)t0 * d->out_features * 2;
+      e = vptq::launch_gemv_k256(d, 1, &xc, &yc, m, flags, st);
+      if (e != hipSuccess) return hip_fail(e, "gemv_k256 launch");
+    }
     return VPTQ_OK;
   }
   e = vptq::launch_gemv_generic(*d, x, y, tokens, st);

@@ -51,9 +51,11 @@ struct K256Layer {
   const uint16_t* wbias;  // [I]
   const uint16_t* bias;   // [O] or null
   const uint16_t* perm;   // [I] or null
+  const char* pf;         // read-ahead range (next layer's indices) or null
+  long long pf_bytes;
   int N, G, O, row_words;
   int wg_begin;  // first workgroup id of this layer
-  int pad_;
+  int pf_chunk;  // read-ahead bytes per workgroup (multiple of 128)
 };
 
 struct K256Params {
@@ -131,6 +133,7 @@ __global__ __launch_bounds__(kThreads, 4) void gemv_k256_kernel(const K256Params
   const uint32_t baseC = (uint32_t)(lane & 7) << 4;
   const uint32_t baseR = baseC | 0x80u;
 
+  uint32_t pf_word = 0;
   // Straight-line body: no load is predicated.  Lanes past the last column re-read the
   // last 8 columns with x forced to 0; rows past N re-read row N-1 and are not stored.
   for (int base = 0; base < G; base += SW * kSweepCols) {
@@ -142,10 +145,12 @@ __global__ __launch_bounds__(kThreads, 4) void gemv_k256_kernel(const K256Params
       const int want = base + sw * kSweepCols + tid * 8;
       const bool valid = want < G;  // G % 8 == 0 (checked on the host)
       const int col0 = valid ? want : G - 8;
+      // PERM: sp / bp already hold scale[perm[c]] / bias[perm[c]] (derived state,
+      // VptqLayerDesc.scale_permuted); only the activations are gathered.
       u32x4 pv = u32x4{0, 0, 0, 0};
       if (PERM) pv = *(const u32x4*)(pp + col0);
-      s_raw[sw] = load8<PERM>(sp, col0, pv);
-      b_raw[sw] = load8<PERM>(bp, col0, pv);
+      s_raw[sw] = *(const u32x4*)(sp + col0);
+      b_raw[sw] = *(const u32x4*)(bp + col0);
 #pragma unroll
       for (int t = 0; t < TOK; ++t) {
         const int te = t < tokens ? t : tokens - 1;  // spare token slots repeat the last row
@@ -169,6 +174,16 @@ __global__ __launch_bounds__(kThreads, 4) void gemv_k256_kernel(const K256Params
 #pragma unroll
       for (int q = 0; q < 8; ++q) lds_store16(rowp + (((q + lane) & 7) << 4), centry);
       __syncthreads();
+      // read-ahead for the NEXT launch, issued after the image is built (this
+      // workgroup's own loads are in flight ahead of it): one word per 128-byte line of
+      // this workgroup's share of the range (the rows it will own if the next layer has
+      // this layer's shape -> same XCD L2; otherwise the Infinity Cache still helps).
+      // Unconditional, address-clamped load; its value is only "used" in a branch that
+      // is never taken, so nothing ever waits for it.
+      const long long want = (long long)(bid - Ly.wg_begin) * Ly.pf_chunk + (long long)tid * 128;
+      const bool in = tid * 128 < Ly.pf_chunk && want + 4 <= Ly.pf_bytes;
+      const char* pa = in ? Ly.pf + want : (const char*)cent0;
+      pf_word = *(const uint32_t*)pa;
     }
 
     // ---- 4. dequantise + accumulate ----
@@ -291,6 +306,7 @@ __global__ __launch_bounds__(kThreads, 4) void gemv_k256_kernel(const K256Params
       Ly.y[(size_t)t * O + o] = DT::from_float(sum);
     }
   }
+  if (tokens == 0x7fffffff) Ly.y[0] = (uint16_t)pf_word;  // never true: keeps the read-ahead alive
 }
 
 // ---- host side -------------------------------------------------------------------
@@ -298,6 +314,8 @@ bool gemv_k256_eligible(const VptqLayerDesc& d, int tokens) {
   return d.vector_len == 8 && d.num_centroids == 256 && d.num_res_centroids == 256 &&
          d.index_bits == 8 && d.res_bits == 8 && d.num_codebooks == 1 && d.outlier_size == 0 &&
          d.weight_scale != nullptr && d.weight_bias != nullptr && (d.group_size % 8) == 0 &&
+         (d.perm == nullptr || (d.scale_permuted != nullptr && d.bias_permuted != nullptr &&
+                                (((uintptr_t)d.scale_permuted | (uintptr_t)d.bias_permuted) & 15) == 0)) &&
          d.group_size == d.in_features && d.row_words == d.group_size / 2 && tokens >= 1 &&
          tokens <= 4 && (((uintptr_t)d.indices | (uintptr_t)d.centroids |
                           (uintptr_t)d.res_centroids | (uintptr_t)d.weight_scale |
@@ -374,8 +392,8 @@ hipError_t launch_gemv_k256(const VptqLayerDesc* descs, int n, const void* const
     Ly.rcent = (const uint32_t*)d.res_centroids;
     Ly.x = (const uint16_t*)x[i];
     Ly.y = (uint16_t*)y[i];
-    Ly.scale = (const uint16_t*)d.weight_scale;
-    Ly.wbias = (const uint16_t*)d.weight_bias;
+    Ly.scale = (const uint16_t*)(d.perm ? d.scale_permuted : d.weight_scale);
+    Ly.wbias = (const uint16_t*)(d.perm ? d.bias_permuted : d.weight_bias);
     Ly.bias = (const uint16_t*)d.bias;
     Ly.perm = d.perm;
     Ly.N = d.num_indices;
@@ -383,8 +401,13 @@ hipError_t launch_gemv_k256(const VptqLayerDesc* descs, int n, const void* const
     Ly.O = d.out_features;
     Ly.row_words = d.row_words;
     Ly.wg_begin = grid;
-    Ly.pad_ = 0;
-    grid += (d.num_indices + rows - 1) / rows;
+    const int n_wg = (d.num_indices + rows - 1) / rows;
+    Ly.pf = (const char*)d.prefetch;
+    Ly.pf_bytes = d.prefetch ? d.prefetch_bytes : 0;
+    long long chunk = d.prefetch ? (d.prefetch_bytes + n_wg - 1) / n_wg : 0;
+    chunk = (chunk + 127) / 128 * 128;
+    Ly.pf_chunk = (int)(chunk > kThreads * 128 ? kThreads * 128 : chunk);  // one line per thread
+    grid += n_wg;
   }
   // the folded-arithmetic instantiations exist for 1-2 tokens
   const bool fast = f16 && tok <= 2 && (flags & VPTQ_GEMV_FAST_MATH);

@@ -1,3 +1,3 @@
-from vptq_amd.layers.vqlinear import VQuantLinear
+from vptq_amd.layers.vqlinear import VQuantLinear, chain_prefetch
 
-__all__ = ["VQuantLinear"]
+__all__ = ["VQuantLinear", "chain_prefetch"]

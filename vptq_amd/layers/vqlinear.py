@@ -32,6 +32,15 @@ from torch.nn.parameter import Parameter
 from vptq_amd import ops
 
 
+def chain_prefetch(layers, circular: bool = False):
+    """Tell each layer which one runs next so that its fused GEMV reads the next layer's
+    packed indices ahead into L2 / Infinity Cache (pure performance hint)."""
+    layers = list(layers)
+    for a, b in zip(layers, layers[1:] + ([layers[0]] if circular else [None])):
+        object.__setattr__(a, "_prefetch_next", b)
+    return layers
+
+
 class VQuantLinear(nn.Module):
     def __init__(
         self,
@@ -136,6 +145,9 @@ class VQuantLinear(nn.Module):
         self.indices = Parameter(
             torch.empty((group_num, self.num_indices, packed_groupsize), dtype=torch.int32,
                         device=device), requires_grad=False)
+        # optional: the layer that runs after this one (set by `chain_prefetch`); its packed
+        # indices are read ahead by this layer's GEMV.  Not a parameter / buffer.
+        self._prefetch_next = None
 
     def forward(self, x: torch.Tensor, W=None, H=None) -> torch.Tensor:
         """x [..., in_features] fp16/bf16 -> [..., out_features]."""
@@ -170,6 +182,7 @@ class VQuantLinear(nn.Module):
             padding=self.padding,
             outlier_padding=self.outlier_padding,
             vector_quant_dim=self.vector_quant_dim,
+            prefetch=None if self._prefetch_next is None else self._prefetch_next.indices,
         )
 
     def dequant(self) -> torch.Tensor:

@@ -122,9 +122,13 @@ def quant_gemm(
     padding: int,
     outlier_padding: int,
     vector_quant_dim: str = "out",
+    prefetch: Optional[torch.Tensor] = None,
 ) -> torch.Tensor:
     """y = x @ W^T + bias with W dequantised on the fly (reference
-    vptq/ops/quant_gemm.py:161-275).  x: [..., in_features] fp16/bf16."""
+    vptq/ops/quant_gemm.py:161-275).  x: [..., in_features] fp16/bf16.
+
+    `prefetch` (extension, optional): a tensor the fused GEMV may read ahead to warm
+    L2 / Infinity Cache for the NEXT launch, typically the next layer's `indices`."""
     if vector_quant_dim == "in":
         raise ValueError("Not implemented yet.")
     if not is_indice_packed or residual_indices is not None:
@@ -151,7 +155,7 @@ def quant_gemm(
             num_res_centroids=num_res_centroids if enable_residual else 0,
             group_size=group_size, outlier_size=outlier_size if enable_outlier else 0,
             outlier_vector_len=outlier_vector_len,
-            num_outlier_centroids=num_outlier_centroids)
+            num_outlier_centroids=num_outlier_centroids, prefetch=prefetch)
         y = torch.empty(x.shape[:-1] + (out_features,), dtype=x.dtype, device=dev)
         with torch.cuda.device(dev):
             B.check(B.lib().vptq_quant_gemv(desc, x.data_ptr(), y.data_ptr(), tokens, _FLAGS,
