@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""BASELINE config #3: Llama-3-8B-shaped decode loop on ONE MI355X with every decoder
+nn.Linear replaced by a 2-bit VQuantLinear (random indices / centroids — there is no
+network for checkpoints), through Hugging Face Transformers' own VPTQ integration:
+
+    transformers.integrations.vptq.replace_with_vptq_linear  ->  `from vptq import VQuantLinear`
+
+which resolves to this repository's class (the `vptq` alias package).  Reports TTFT
+(prompt through dequant + hipBLASLt GEMM) and decode tokens/s, eager and with the decode step
+captured in a hipGraph.
+
+    python tools/llama_decode.py [--layers 32] [--prompt 128] [--new 256]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def build_model(layers, dev, k=256, kr=256, perm=False):
+    from transformers import LlamaConfig, LlamaForCausalLM
+    from transformers.integrations.vptq import replace_with_vptq_linear
+    from transformers.models.llama.modeling_llama import LlamaRotaryEmbedding
+    from transformers.utils.quantization_config import VptqConfig
+    import vptq  # the alias package of this repository
+    assert vptq.__file__.startswith(ROOT), vptq.__file__
+
+    cfg = LlamaConfig(hidden_size=4096, intermediate_size=14336, num_hidden_layers=layers,
+                      num_attention_heads=32, num_key_value_heads=8, vocab_size=128256,
+                      max_position_embeddings=8192, rope_theta=500000.0, rms_norm_eps=1e-5,
+                      tie_word_embeddings=False)
+    cfg._attn_implementation = "sdpa"
+    with torch.device("meta"):
+        model = LlamaForCausalLM(cfg)
+    per_layer = {}
+    for name, mod in model.named_modules():
+        if isinstance(mod, torch.nn.Linear) and name != "lm_head":
+            per_layer[name] = dict(vector_lens=[-1, 8], num_centroids=[-1, k],
+                                   num_res_centroids=[-1, kr], group_num=1,
+                                   group_size=mod.in_features, outlier_size=0,
+                                   indices_as_float=False, enable_norm=True, enable_perm=perm,
+                                   is_indice_packed=True)
+    qc = VptqConfig(config_for_layers=per_layer, shared_layer_config={},
+                    modules_to_not_convert=["lm_head"])
+    try:
+        replace_with_vptq_linear(model, modules_to_not_convert=["lm_head"], quantization_config=qc)
+    except KeyError:
+        # transformers 5.15.0 indexes `model._modules[<dotted name>]` (integrations/vptq.py:71)
+        # and fails on any nested model; do exactly what it would have done: build
+        # `vptq.VQuantLinear` on meta with the same keyword arguments and swap it in.
+        for name, lp in per_layer.items():
+            old = model.get_submodule(name)
+            with torch.device("meta"):
+                new = vptq.VQuantLinear(
+                    old.in_features, old.out_features, vector_lens=lp["vector_lens"],
+                    num_centroids=lp["num_centroids"], num_res_centroids=lp["num_res_centroids"],
+                    group_num=lp["group_num"], group_size=lp["group_size"],
+                    outlier_size=lp["outlier_size"], indices_as_float=lp["indices_as_float"],
+                    enable_norm=lp["enable_norm"], enable_perm=lp["enable_perm"],
+                    is_indice_packed=True, enable_proxy_error=False, bias=old.bias is not None)
+            model.set_submodule(name, new)
+    model = model.to_empty(device=dev)
+    g = torch.Generator(device=dev).manual_seed(0)
+    qlayers = []
+    with torch.no_grad():
+        for name, mod in model.named_modules():
+            if isinstance(mod, vptq.VQuantLinear):
+                mod.indices.data = torch.randint(-2**31, 2**31 - 1, mod.indices.shape, generator=g,
+                                                 device=dev, dtype=torch.int64).to(torch.int32)
+                mod.centroids.weight.data = (torch.randn(mod.centroids.weight.shape, generator=g, device=dev) * 0.02).half()
+                mod.res_centroids.weight.data = (torch.randn(mod.res_centroids.weight.shape, generator=g, device=dev) * 0.005).half()
+                I = mod.in_features
+                mod.weight_scale.data = (1 + 0.1 * torch.randn(I, generator=g, device=dev)).half()
+                mod.weight_bias.data = (0.002 * torch.randn(I, generator=g, device=dev)).half()
+                if perm:
+                    mod.perm.data = torch.randperm(I, generator=g, device=dev).to(torch.int32).to(torch.int16)
+                qlayers.append(mod)
+        for name, p in model.named_parameters():
+            if p.dtype == torch.float32:          # embeddings, norms, lm_head
+                if "norm" in name:
+                    p.data = torch.ones(p.shape, device=dev, dtype=torch.float16)
+                else:
+                    p.data = (torch.randn(p.shape, generator=g, device=dev) * 0.02).half()
+    model.model.rotary_emb = LlamaRotaryEmbedding(config=cfg, device=dev)
+    vptq.layers.chain_prefetch(qlayers, circular=True)
+    return model.eval(), cfg, qlayers
+
+
+@torch.no_grad()
+def run(args):
+    from transformers import StaticCache
+    dev = torch.device("cuda", 0)
+    def stage(msg):
+        print(f"[stage] {msg}", file=sys.stderr, flush=True)
+    stage("build")
+    model, cfg, qlayers = build_model(args.layers, dev, perm=args.perm)
+    torch.cuda.synchronize()
+    stage("built")
+    qbytes = sum(m.indices.numel() * 4 for m in qlayers)
+    maxlen = args.prompt + 2 * args.new + 80   # eager steps + captured replays share one cache
+    prompt = torch.randint(0, cfg.vocab_size, (1, args.prompt), device=dev)
+
+    def fresh_cache():
+        return StaticCache(config=cfg, max_cache_len=maxlen)
+
+    # ---- TTFT: prompt (tokens > 8 -> dequant + F.linear per layer) ----
+    cache = fresh_cache()
+    pos = torch.arange(args.prompt, device=dev)
+    stage("prompt forward")
+    out = model(input_ids=prompt, past_key_values=cache, cache_position=pos, use_cache=True)
+    torch.cuda.synchronize()
+    stage("prompt done")
+    cache = fresh_cache()
+    t0 = time.perf_counter()
+    out = model(input_ids=prompt, past_key_values=cache, cache_position=pos, use_cache=True)
+    tok = out.logits[:, -1].argmax(-1, keepdim=True)
+    torch.cuda.synchronize()
+    ttft = time.perf_counter() - t0
+
+    # ---- eager decode ----
+    def step(tok, p):
+        o = model(input_ids=tok, past_key_values=cache, cache_position=p, use_cache=True)
+        return o.logits[:, -1].argmax(-1, keepdim=True)
+
+    p = torch.tensor([args.prompt], device=dev)
+    stage("eager decode")
+    for _ in range(3):
+        tok = step(tok, p); p += 1
+    torch.cuda.synchronize()
+    n_eager = min(args.new, 64)
+    t0 = time.perf_counter()
+    for _ in range(n_eager):
+        tok = step(tok, p); p += 1
+    torch.cuda.synchronize()
+    eager_tps = n_eager / (time.perf_counter() - t0)
+
+    # ---- hipGraph decode: one captured step, replayed ----
+    graph_tps = None
+    stage("graph capture")
+    try:
+        s_tok = tok.clone()
+        s_pos = p.clone()
+        stream = torch.cuda.Stream()
+        with torch.cuda.stream(stream):
+            for _ in range(2):
+                s_out = step(s_tok, s_pos)
+            torch.cuda.synchronize()
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr, stream=stream):
+                s_out = step(s_tok, s_pos)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.new):
+                gr.replay()
+                s_tok.copy_(s_out)
+                s_pos += 1
+            torch.cuda.synchronize()
+            graph_tps = args.new / (time.perf_counter() - t0)
+    except Exception as e:  # report, do not hide
+        graph_tps = f"capture failed: {type(e).__name__}: {e}"
+
+    lm_head_bytes = cfg.vocab_size * cfg.hidden_size * 2
+    res = dict(model=f"Llama-3-8B shapes, {args.layers} layers, 2-bit VQuantLinear (v8 k256+256)"
+                     + (" +perm" if args.perm else ""),
+               quantized_linears=len(qlayers), packed_index_GB=qbytes / 1e9,
+               lm_head_GB=lm_head_bytes / 1e9, prompt=args.prompt, new_tokens=args.new,
+               ttft_ms=ttft * 1e3, decode_tok_s_eager=eager_tps, decode_tok_s_hipgraph=graph_tps)
+    if isinstance(graph_tps, float):
+        res["hipgraph_weight_GBps"] = (qbytes + lm_head_bytes) * graph_tps / 1e9
+    print(json.dumps(res))
+    if args.out:
+        os.makedirs(os.path.dirname(args.out), exist_ok=True)
+        json.dump(res, open(args.out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--layers", type=int, default=32)
+    ap.add_argument("--prompt", type=int, default=128)
+    ap.add_argument("--new", type=int, default=256)
+    ap.add_argument("--perm", action="store_true")
+    ap.add_argument("--out", default="")
+    run(ap.parse_args())

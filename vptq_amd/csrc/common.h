@@ -162,65 +162,65 @@ static __device__ __forceinline__ float row16_allsum(float x) {
   return row_ror_add<1>(x);
 }
 
-// Reduce NV per-lane partials over the 64 lanes of a wave in ~2*NV VALU ops
-// (a shuffle tree costs 12*NV).  Halving exchanges use the gfx950 lane-swap
-// instructions: v_permlane32_swap(a, b) leaves a = [a.lo32 | b.lo32],
-// b = [a.hi32 | b.hi32], so a + b holds sum(a) in lanes 0-31 and sum(b) in lanes
-// 32-63; v_permlane16_swap does the same for odd/even rows of 16 lanes.
-// On return v[0..M) of a lane in row q = lane >> 4 holds the wave totals of the
-// original entries [base(q), base(q) + M); see wave_reduce_layout().
+// Full reduce-scatter of NV (8, 16, 32 or 64) per-lane partials over the 64 lanes of a
+// wave: every step halves the values a lane carries, so the whole reduction costs ~2*NV
+// VALU ops (a shuffle tree costs 12*NV and measured 5.7 us per launch).  Lane-pair
+// exchanges: v_permlane32_swap / v_permlane16_swap (gfx950) for lane bits 5 and 4
+// (swap(a, b) leaves a = [a.lo | b.lo], b = [a.hi | b.hi]: a + b = sum(a) in the low
+// half, sum(b) in the high half), DPP row_mirror / row_half_mirror / quad_perm for
+// bits 3..0.  On return v[0] of lane l holds the wave total of original entry
+// l >> kShift (replicated over the low kShift lane bits).
+template <int CTRL>
+static __device__ __forceinline__ float dpp_mov(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+
 template <int NV>
 struct WaveReduce {
-  static constexpr bool kS32 = NV >= 16;
-  static constexpr int kN1 = kS32 ? NV / 2 : NV;
-  static constexpr bool kS16 = kN1 >= 16;
-  static constexpr int kM = kS16 ? kN1 / 2 : kN1;  // values left per lane
+  static_assert(NV == 8 || NV == 16 || NV == 32 || NV == 64, "NV must be 8..64, power of two");
+  static constexpr int kLog = NV == 8 ? 3 : NV == 16 ? 4 : NV == 32 ? 5 : 6;
+  static constexpr int kShift = 6 - kLog;
 
-  static __device__ __forceinline__ void run(float (&v)[NV]) {
-    if (kS32) {
+  // one DPP halving step on lane bit BIT (3..0): lanes with the bit clear keep the first
+  // half of v[0..n), the others the second half; each adds its partner's copy.
+  template <int BIT, int n>
+  static __device__ __forceinline__ void halve_dpp(float (&v)[NV], int lane) {
+    constexpr int ctrl = BIT == 3 ? 0x140 /*row_mirror*/ : BIT == 2 ? 0x141 /*row_half_mirror*/
+                         : BIT == 1 ? 0x4E /*quad_perm [2,3,0,1]*/ : 0xB1 /*quad_perm [1,0,3,2]*/;
+    const bool up = (lane >> BIT) & 1;
 #pragma unroll
-      for (int i = 0; i < NV / 2; ++i) {
-        auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]),
-                                                  __float_as_uint(v[i + NV / 2]), false, false);
-        v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < NV; ++i) {
-        auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(v[i]),
-                                                  false, false);
-        v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-      }
+    for (int i = 0; i < n / 2; ++i) {
+      const float keep = up ? v[i + n / 2] : v[i];
+      const float send = up ? v[i] : v[i + n / 2];
+      v[i] = keep + dpp_mov<ctrl>(send);
     }
-    if (kS16) {
+  }
+  template <int BIT>
+  static __device__ __forceinline__ void butterfly_dpp(float& x) {
+    constexpr int ctrl = BIT == 3 ? 0x140 : BIT == 2 ? 0x141 : BIT == 1 ? 0x4E : 0xB1;
+    x = x + dpp_mov<ctrl>(x);
+  }
+
+  static __device__ __forceinline__ void run(float (&v)[NV], int lane) {
+    // bit 5
 #pragma unroll
-      for (int i = 0; i < kN1 / 2; ++i) {
-        auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[i]),
-                                                  __float_as_uint(v[i + kN1 / 2]), false, false);
-        v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < kN1; ++i) {
-        auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[i]), __float_as_uint(v[i]),
-                                                  false, false);
-        v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-      }
+    for (int i = 0; i < NV / 2; ++i) {
+      auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]),
+                                                __float_as_uint(v[i + NV / 2]), false, false);
+      v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
     }
+    // bit 4
 #pragma unroll
-    for (int i = 0; i < kM; ++i) v[i] = row16_allsum(v[i]);
-  }
-  // first original entry held by row q (0..3) after run(); rows that hold
-  // duplicates (no halving on that bit) report the same base.
-  static __device__ __forceinline__ int base(int q) {
-    int off = 0;
-    if (kS32) off += (q >> 1) * (NV / 2);
-    if (kS16) off += (q & 1) * (kN1 / 2);
-    return off;
-  }
-  // does row q hold a unique slice (is it a designated writer)?
-  static __device__ __forceinline__ bool writer(int q) {
-    return (kS32 || (q >> 1) == 0) && (kS16 || (q & 1) == 0);
+    for (int i = 0; i < NV / 4; ++i) {
+      auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[i]),
+                                                __float_as_uint(v[i + NV / 4]), false, false);
+      v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    constexpr int n3 = NV / 4;  // values left before the bit-3 step (>= 2)
+    halve_dpp<3, n3>(v, lane);
+    if (n3 / 2 >= 2) halve_dpp<2, (n3 / 2 >= 2 ? n3 / 2 : 2)>(v, lane); else butterfly_dpp<2>(v[0]);
+    if (n3 / 4 >= 2) halve_dpp<1, (n3 / 4 >= 2 ? n3 / 4 : 2)>(v, lane); else butterfly_dpp<1>(v[0]);
+    if (n3 / 8 >= 2) halve_dpp<0, (n3 / 8 >= 2 ? n3 / 8 : 2)>(v, lane); else butterfly_dpp<0>(v[0]);
   }
 };
 

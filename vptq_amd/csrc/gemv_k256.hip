@@ -262,7 +262,6 @@ __global__ __launch_bounds__(kThreads, 4) void gemv_k256_kernel(const K256Params
   // ---- 5. reduce over the workgroup's lanes and store ----
   constexpr int kVals = TOK * ROWS * 8;
   constexpr int kStride = kVals + TOK;  // floats per wave in the scratch area
-  const uint32_t red0 = kScratchOff;
   float* red = (float*)(smem + kScratchOff);  // [kWaves][kStride]
   {
     float v[kVals];
@@ -273,15 +272,9 @@ __global__ __launch_bounds__(kThreads, 4) void gemv_k256_kernel(const K256Params
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[(t * ROWS + r) * 8 + i] = acc[t][r][i];
     using WR = WaveReduce<kVals>;
-    WR::run(v);
-    const int q = lane >> 4;
-    if ((lane & 15) == 0 && WR::writer(q)) {
-      const uint32_t a = red0 + (wave * kStride + WR::base(q)) * 4;
-#pragma unroll
-      for (int i = 0; i < WR::kM; i += 4)
-        lds_store16(a + i * 4, u32x4{__float_as_uint(v[i]), __float_as_uint(v[i + 1]),
-                                     __float_as_uint(v[i + 2]), __float_as_uint(v[i + 3])});
-    }
+    WR::run(v, lane);
+    // lane l now holds the wave total of partial l >> kShift
+    if ((lane & ((1 << WR::kShift) - 1)) == 0) red[wave * kStride + (lane >> WR::kShift)] = v[0];
   }
   if (FAST) {
 #pragma unroll
