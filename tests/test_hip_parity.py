@@ -86,6 +86,13 @@ CASES = [
                              num_outlier_centroids=64, enable_perm=True, bias=True), 1),
     (256, 64, dict(enable_norm=False, num_res_centroids=0, num_centroids=16, vector_len=2), 1),
     (1024, 256, dict(vector_len=16, num_centroids=65536, num_res_centroids=65536, dist="llm"), 2),
+    # large-codebook v=8 formats -> gemv_gather_kernel (T = 16 / 24 / 32)
+    (2048, 512, dict(num_centroids=65536, num_res_centroids=0, dist="llm"), 1),
+    (2056, 136, dict(num_centroids=65536, num_res_centroids=0, dist="llm", enable_perm=True, bias=True), 3),
+    (1024, 2048 * 8, dict(num_centroids=65536, num_res_centroids=256, dist="llm"), 1),      # ROWS = 2
+    (1032, 264, dict(num_centroids=65536, num_res_centroids=256, enable_perm=True), 2),
+    (1024, 256, dict(num_centroids=65536, num_res_centroids=65536, dist="llm"), 4),
+    (512, 96, dict(num_centroids=65536, num_res_centroids=65536, dtype="bf16", dist="llm"), 7),
 ]
 
 
@@ -100,6 +107,8 @@ def test_gemv_and_dequant_vs_oracle(I, O, kw, tokens, dev):
         else rng.standard_normal((1, tokens, I))
     x = vo.from_f32(xs.astype(np.float32), dt)
     m = spec_to_module(L, dev)
+    if L.num_centroids == 65536 and L.vector_len == 8 and L.num_res_centroids in (0, 256, 65536):
+        assert kernel_name(m, tokens) == "gemv_gather_kernel"
     W_ref = vo.dequant(L, ref_residual_mask_quirk=False)
     assert (tensor_to_bits(m.dequant()) == W_ref).all(), "dequant must be bit-exact"
     want = vo.gemv(W_ref, x, dt, L.bias)

@@ -26,19 +26,20 @@ import vptq_amd  # noqa: E402
 from vptq_amd import _backend as B  # noqa: E402
 
 
-def make_layers(H, R, dev, perm=False):
+def make_layers(H, R, dev, perm=False, k=256, kr=256):
     g = torch.Generator(device=dev).manual_seed(1234)
     layers = []
     for _ in range(R):
-        m = vptq_amd.VQuantLinear(H, H, vector_lens=[-1, 8], num_centroids=[-1, 256],
-                                  num_res_centroids=[-1, 256], group_num=1, group_size=H,
+        m = vptq_amd.VQuantLinear(H, H, vector_lens=[-1, 8], num_centroids=[-1, k],
+                                  num_res_centroids=[-1, kr if kr > 0 else -1], group_num=1, group_size=H,
                                   outlier_size=0, indices_as_float=False, enable_norm=True,
                                   enable_perm=perm, is_indice_packed=True, bias=False,
                                   dtype=torch.float16, device=dev, enable_proxy_error=False)
         m.indices.data = torch.randint(-2**31, 2**31 - 1, m.indices.shape, generator=g,
                                        device=dev, dtype=torch.int64).to(torch.int32)
         m.centroids.weight.data = (torch.randn(m.centroids.weight.shape, generator=g, device=dev) * 0.02).half()
-        m.res_centroids.weight.data = (torch.randn(m.res_centroids.weight.shape, generator=g, device=dev) * 0.005).half()
+        if kr > 0:
+            m.res_centroids.weight.data = (torch.randn(m.res_centroids.weight.shape, generator=g, device=dev) * 0.005).half()
         m.weight_scale.data = (1 + 0.1 * torch.randn(H, generator=g, device=dev)).half()
         m.weight_bias.data = (0.01 * torch.randn(H, generator=g, device=dev)).half()
         if perm:
@@ -47,8 +48,10 @@ def make_layers(H, R, dev, perm=False):
     return layers
 
 
-def alg_bytes(H, perm=False):
-    return H // 8 * (H * 16 // 32) * 4 + 2 * 256 * 8 * 2 + 2 * H + 4 * H + (2 * H if perm else 0) + 2 * H
+def alg_bytes(H, perm=False, k=256, kr=256):
+    import math
+    T = int(math.log2(k)) + (int(math.log2(kr)) if kr > 0 else 0)
+    return H // 8 * (H * T // 32) * 4 + (k + max(kr, 0)) * 8 * 2 + 2 * H + 4 * H + (2 * H if perm else 0) + 2 * H
 
 
 def time_graph(fn, iters, warm=3):
@@ -79,15 +82,19 @@ def main():
     ap.add_argument("--perm", action="store_true")
     ap.add_argument("--group", type=int, default=32)
     ap.add_argument("--prefetch", action="store_true")
+    ap.add_argument("--k", type=int, default=256)
+    ap.add_argument("--kr", type=int, default=256)
     ap.add_argument("--out", default="")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     H = a.hidden
-    idx_bytes = H // 8 * H * 2
+    import math
+    Tb = int(math.log2(a.k)) + (int(math.log2(a.kr)) if a.kr > 0 else 0)
+    idx_bytes = H // 8 * H * Tb // 8
     R = a.ring or max(2, (512 << 20) // idx_bytes)
-    layers = make_layers(H, R, dev, a.perm)
+    layers = make_layers(H, R, dev, a.perm, a.k, a.kr)
     x = torch.randn(1, 1, H, device=dev, dtype=torch.float16)
-    ab = alg_bytes(H, a.perm)
+    ab = alg_bytes(H, a.perm, a.k, a.kr)
     lib = B.lib()
     st = None
     res = dict(hidden=H, ring=R, alg_bytes=ab, env={k: v for k, v in os.environ.items() if k.startswith("VPTQ_")})
@@ -121,7 +128,8 @@ def main():
                                              torch.cuda.current_stream().cuda_stream)
             assert rc == 0, lib.vptq_last_error()
 
-    for name, flags in (("exact", 0), ("fast", 1), ("generic", 2)):
+    variants = (("exact", 0), ("fast", 1), ("generic", 2)) if a.k == 256 else (("exact", 0), ("generic", 2))
+    for name, flags in variants:
         ring = time_graph(lambda: [launch_one(i, flags) for i in range(R)], a.iters) / R
         hot = time_graph(lambda: [launch_one(0, flags) for _ in range(R)], a.iters) / R
         r = dict(ring_us=ring, ring_TBps=ab / ring / 1e6, hot_us=hot, hot_TBps=ab / hot / 1e6)

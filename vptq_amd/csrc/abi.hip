@@ -97,6 +97,8 @@ const char* vptq_quant_gemv_kernel_name(const VptqLayerDesc* d, int tokens, int 
   if (validate_layer(d) != VPTQ_OK || tokens < 1 || tokens > VPTQ_GEMV_MAX_TOKENS) return nullptr;
   if (!(flags & VPTQ_GEMV_FORCE_GENERIC) && vptq::gemv_k256_eligible(*d, tokens > 4 ? 4 : tokens))
     return vptq::gemv_k256_name(*d, tokens, flags);
+  if (!(flags & VPTQ_GEMV_FORCE_GENERIC) && vptq::gemv_gather_eligible(*d, tokens > 4 ? 4 : tokens))
+    return "gemv_gather_kernel";
   return "gemv_generic_kernel";
 }
 
@@ -122,6 +124,16 @@ int vptq_quant_gemv(const VptqLayerDesc* d, const void* x, void* y, int tokens, 
       void* yc = (char*)y + (size_t)t0 * d->out_features * 2;
       e = vptq::launch_gemv_k256(d, 1, &xc, &yc, m, flags, st);
       if (e != hipSuccess) return hip_fail(e, "gemv_k256 launch");
+    }
+    return VPTQ_OK;
+  }
+  if (!(flags & VPTQ_GEMV_FORCE_GENERIC) && vptq::gemv_gather_eligible(*d, chunk) &&
+      (((uintptr_t)x) & 3) == 0) {
+    for (int t0 = 0; t0 < tokens; t0 += 4) {
+      const int m = tokens - t0 < 4 ? tokens - t0 : 4;
+      e = vptq::launch_gemv_gather(*d, (const char*)x + (size_t)t0 * d->in_features * 2,
+                                   (char*)y + (size_t)t0 * d->out_features * 2, m, st);
+      if (e != hipSuccess) return hip_fail(e, "gemv_gather launch");
     }
     return VPTQ_OK;
   }
@@ -166,8 +178,8 @@ int vptq_quant_gemv_grouped(const VptqLayerDesc* descs, int n, const void* const
     return VPTQ_OK;
   }
   for (int i = 0; i < n; ++i) {
-    hipError_t e = vptq::launch_gemv_generic(descs[i], x[i], y[i], tokens, st);
-    if (e != hipSuccess) return hip_fail(e, "gemv_generic launch");
+    const int rc = vptq_quant_gemv(&descs[i], x[i], y[i], tokens, flags, nullptr, 0, stream);
+    if (rc) return rc;
   }
   return VPTQ_OK;
 }

@@ -17,6 +17,12 @@ const char* gemv_k256_name(const VptqLayerDesc& d, int tokens, int flags);
 hipError_t launch_gemv_k256(const VptqLayerDesc* descs, int n, const void* const* x,
                             void* const* y, int tokens, int flags, hipStream_t st);
 
+// gemv_gather.hip — v=8, k=65536 (+ residual 0 / 256 / 65536), C=1, no outliers:
+// centroid rows gathered from L2.
+bool gemv_gather_eligible(const VptqLayerDesc& d, int tokens);
+hipError_t launch_gemv_gather(const VptqLayerDesc& d, const void* x, void* y, int tokens,
+                              hipStream_t st);
+
 // dequant.hip
 hipError_t launch_dequant(const VptqLayerDesc& d, void* W, hipStream_t st);
 
