@@ -246,6 +246,18 @@ def test_read_ahead_hint_does_not_change_results(dev):
     assert "_prefetch_next" not in mods[0].state_dict() and len(list(mods[0].children())) <= 3
 
 
+def test_absorb_perm_on_device(dev):
+    from vptq_amd.utils.pack import absorb_perm_layer
+    L = vo.make_layer(2048, 512, dist="llm", seed=77, enable_perm=True)
+    m = spec_to_module(L, dev)
+    x = torch.randn(1, 1, 2048, device=dev, dtype=torch.float16)
+    W0, y0 = m.dequant(), m(x)
+    assert absorb_perm_layer(m)
+    assert torch.equal(m.dequant(), W0)                    # identical dense weight
+    y1 = m(x)
+    assert ((y1.float() - y0.float()).abs().max() / y0.float().abs().max()).item() <= 5e-4
+
+
 def test_hipgraph_capture_of_the_forward(dev):
     L = vo.make_layer(4096, 4096, dist="llm", seed=1)
     m = spec_to_module(L, dev)

@@ -171,6 +171,23 @@ def test_derived_state_cache_follows_the_tensor_not_the_address():
     assert torch.equal(B.inverse_perm(perm).long(), torch.argsort(perm.long()))
 
 
+def test_absorb_perm_matches_oracle_weight():
+    """Folding perm into the index order leaves the dense weight unchanged (oracle)."""
+    from vptq_amd.utils.pack import absorb_perm_layer
+    L = vo.make_layer(256, 64, dist="llm", seed=5, enable_perm=True, num_centroids=4096,
+                      num_res_centroids=256)
+    W_before = vo.dequant(L)
+    m = spec_to_module(L, "cpu")
+    assert absorb_perm_layer(m) and m.enable_perm is False and m.perm is None
+    assert "perm" not in m.state_dict()
+    L2 = vo.LayerSpec(256, 64, 8, 4096, 256, 1, 256, dtype="f16")
+    L2.indices = m.indices.numpy()
+    L2.centroids, L2.res_centroids = L.centroids, L.res_centroids
+    L2.weight_scale, L2.weight_bias = L.weight_scale, L.weight_bias
+    assert (vo.dequant(L2) == W_before).all()
+    assert absorb_perm_layer(m) is False          # idempotent: nothing left to absorb
+
+
 def test_vptq_alias_for_hf():
     import sys
     # other tests may have imported the REFERENCE under the name `vptq`

@@ -1,3 +1,3 @@
-from vptq_amd.utils.pack import pack_index, unpack_index_tensor
+from vptq_amd.utils.pack import absorb_perm, absorb_perm_layer, pack_index, unpack_index_tensor
 
-__all__ = ["pack_index", "unpack_index_tensor"]
+__all__ = ["pack_index", "unpack_index_tensor", "absorb_perm_layer", "absorb_perm"]

@@ -18,7 +18,7 @@ from typing import Optional, Tuple
 
 import torch
 
-__all__ = ["pack_index", "unpack_index_tensor"]
+__all__ = ["pack_index", "unpack_index_tensor", "absorb_perm_layer", "absorb_perm"]
 
 
 def _as_u16_int64(t: torch.Tensor, index_dtype: torch.dtype) -> torch.Tensor:
@@ -96,3 +96,53 @@ def unpack_index_tensor(
     if res_bits > 0:
         res_indices = (val >> index_bits) & ((1 << index_bits) - 1)
     return indices, res_indices
+
+
+def absorb_perm_layer(layer) -> bool:
+    """Fold a layer's input permutation into the order of its packed index columns and
+    drop `perm` (reference vptq/utils/pack.py:284-394).
+
+    W[o, j] = Wq[o, argsort(perm)[j]] * scale[j] + bias[j]: re-ordering the index columns
+    by argsort(perm) gives the same W with the identity permutation; scale / bias are
+    indexed by the final column and stay as they are.  Like the reference this only
+    applies to single-codebook layers (`group_num == 1`, pack.py:288-293).
+    Returns True when the layer was rewritten.
+    """
+    if not getattr(layer, "enable_perm", False):
+        return False
+    if layer.group_num > 1 or getattr(layer, "enable_outlier", False):
+        return False
+    inv = torch.argsort(layer.perm.detach().view(torch.int16).to(torch.int64) & 0xFFFF)
+    idx, ridx = unpack_index_tensor(layer.indices.detach(), layer.index_bits, layer.group_size,
+                                    layer.res_index_bits, layer.group_size)
+    idx = idx[..., inv]
+    if ridx is not None:
+        ridx = ridx[..., inv]
+    packed = pack_index(idx, layer.index_bits, ridx, layer.res_index_bits, index_dtype=torch.uint16)
+    if packed.shape != layer.indices.shape:
+        raise ValueError(f"Packed shape {tuple(packed.shape)} doesn't match original shape "
+                         f"{tuple(layer.indices.shape)}")
+    layer.indices.data = packed.to(layer.indices.device)
+    if layer.enable_norm and not hasattr(layer, "norm_dim"):
+        layer.norm_dim = 0      # attribute the reference's tools leave behind (pack.py:387-388)
+    layer.enable_perm = False
+    layer.perm = None
+    return True
+
+
+def absorb_perm(model):
+    """absorb_perm_layer over every VQuantLinear of `model`, then clear `enable_perm` in the
+    model's `quantization_config` (reference vptq/utils/pack.py:397-433)."""
+    from vptq_amd.layers.vqlinear import VQuantLinear
+    absorbed = False
+    for _, module in model.named_modules():
+        if isinstance(module, VQuantLinear):
+            absorbed = absorb_perm_layer(module) or absorbed
+    qc = getattr(getattr(model, "config", None), "quantization_config", None)
+    if absorbed and qc is not None:
+        qd = qc if isinstance(qc, dict) else getattr(qc, "__dict__", {})
+        for key in ("config_for_layers", "shared_layer_config"):
+            for layer_cfg in (qd.get(key) or {}).values():
+                if isinstance(layer_cfg, dict) and layer_cfg.get("enable_perm"):
+                    layer_cfg["enable_perm"] = False
+    return model
