@@ -277,6 +277,32 @@ def test_hipgraph_capture_of_the_forward(dev):
     assert torch.equal(out, m(x)) and not torch.equal(out, eager)
 
 
+def test_loader_end_to_end_vs_dense_model(dev, tmp_path):
+    """vptq.AutoModelForCausalLM.from_pretrained on a synthetic VPTQ checkpoint: logits of
+    the quantised model == logits of the same model with every VQuantLinear replaced by a
+    dense nn.Linear holding its dequantised weight (decode and prefill routes)."""
+    import copy
+    import vptq_amd
+    from _ckpt import write_tiny_checkpoint
+    write_tiny_checkpoint(str(tmp_path))
+    model = vptq_amd.AutoModelForCausalLM.from_pretrained(str(tmp_path), device=str(dev),
+                                                          link_prefetch=True)
+    dense = copy.deepcopy(model)
+    for name, m in list(dense.named_modules()):
+        if isinstance(m, vptq_amd.VQuantLinear):
+            lin = torch.nn.Linear(m.in_features, m.out_features, bias=False, device=dev,
+                                  dtype=torch.float16)
+            lin.weight.data = m.dequant()
+            dense.set_submodule(name, lin)
+    with torch.no_grad():
+        for T in (1, 3, 12):
+            ids = torch.randint(0, model.config.vocab_size, (1, T), device=dev)
+            a = model(input_ids=ids).logits.float()
+            b = dense(input_ids=ids).logits.float()
+            assert torch.isfinite(a).all()
+            assert ((a - b).abs().max() / b.abs().max()).item() <= 5e-3, T
+
+
 # ---------------------------------------------------------------- v2 wire format
 V2_CONFIGS = [
     dict(in_features=1024, out_features=2048, num_centroids=8192, num_res_centroids=256),  # uint8 ids

@@ -1,0 +1,33 @@
+"""vptq.AutoModelForCausalLM.from_pretrained on a synthetic checkpoint (CPU: structure + tensors)."""
+import torch
+
+import vptq_amd
+from _ckpt import write_tiny_checkpoint
+
+
+def test_loader_builds_and_loads_synthetic_checkpoint(tmp_path):
+    state, per_layer = write_tiny_checkpoint(str(tmp_path))
+    model = vptq_amd.AutoModelForCausalLM.from_pretrained(str(tmp_path), device="cpu")
+    qmods = {n: m for n, m in model.named_modules() if isinstance(m, vptq_amd.VQuantLinear)}
+    assert sorted(qmods) == sorted(per_layer) and len(qmods) == 2 * 7
+    sd = model.state_dict()
+    for k, v in state.items():
+        assert k in sd and sd[k].dtype == v.dtype and torch.equal(sd[k].cpu(), v), k
+    assert not any(p.is_meta for p in model.parameters())
+    # rotary buffer rebuilt (not meta / garbage)
+    inv = [b for n, b in model.named_buffers() if n.endswith("inv_freq")][0]
+    assert torch.isfinite(inv).all() and inv[0] == 1.0
+    assert model.lm_head.weight.dtype == torch.float16 and isinstance(model.lm_head, torch.nn.Linear)
+    assert not model.training
+
+
+def test_loader_rejects_non_vptq_and_missing(tmp_path):
+    import json, pytest
+    with pytest.raises(FileNotFoundError):
+        vptq_amd.AutoModelForCausalLM.from_pretrained(str(tmp_path / "nope"))
+    write_tiny_checkpoint(str(tmp_path))
+    cfg = json.load(open(tmp_path / "config.json"))
+    del cfg["quantization_config"]
+    json.dump(cfg, open(tmp_path / "config.json", "w"))
+    with pytest.raises(ValueError, match="quantization_config"):
+        vptq_amd.AutoModelForCausalLM.from_pretrained(str(tmp_path), device="cpu")

@@ -7,6 +7,6 @@ hand-written HIP kernels (vptq_amd/csrc) behind the C ABI in include/vptq_hip.h.
 __version__ = "0.0.5.post1"
 
 from vptq_amd import ops  # noqa: E402
-from vptq_amd.layers import VQuantLinear  # noqa: E402
+from vptq_amd.layers import AutoModelForCausalLM, VQuantLinear  # noqa: E402
 
-__all__ = ["VQuantLinear", "ops", "__version__"]
+__all__ = ["AutoModelForCausalLM", "VQuantLinear", "ops", "__version__"]

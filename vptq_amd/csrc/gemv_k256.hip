@@ -61,6 +61,8 @@ struct K256Layer {
 struct K256Params {
   int n_layers;
   int tokens;
+  int debug;  // VPTQ_K256_DEBUG: 1 = return at once, 2 = loads + LDS image only (timing probes)
+  int pad_;
   K256Layer layer[kMaxGroup];
 };
 
@@ -93,6 +95,7 @@ __global__ __launch_bounds__(kThreads, 4) void gemv_k256_kernel(const K256Params
   // gathers address LDS absolutely; `smem` only sizes the allocation.
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
+  if (P.debug == 1) return;
   // ---- which layer / row group is this workgroup? (wave-uniform) ----
   const int bid = blockIdx.x;
   int li = 0;
@@ -186,6 +189,17 @@ __global__ __launch_bounds__(kThreads, 4) void gemv_k256_kernel(const K256Params
       pf_word = *(const uint32_t*)pa;
     }
 
+    if (P.debug == 2) {  // probe: consume the loads, skip the arithmetic
+      uint32_t z = 0;
+#pragma unroll
+      for (int sw = 0; sw < SW; ++sw) {
+        z ^= s_raw[sw][0] ^ b_raw[sw][1] ^ x_raw[sw][0][2];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) z ^= iw[sw][r][0] ^ iw[sw][r][3];
+      }
+      acc[0][0][0] += (float)(z & 1);
+      continue;
+    }
     // ---- 4. dequantise + accumulate ----
 #pragma unroll
     for (int sw = 0; sw < SW; ++sw) {
@@ -371,6 +385,10 @@ hipError_t launch_gemv_k256(const VptqLayerDesc* descs, int n, const void* const
   K256Params P;
   P.n_layers = n;
   P.tokens = tokens;
+  static int dbg = -1;
+  if (dbg < 0) { const char* e = getenv("VPTQ_K256_DEBUG"); dbg = e ? atoi(e) : 0; }
+  P.debug = dbg;
+  P.pad_ = 0;
   int total_rows = 0;
   for (int i = 0; i < n; ++i) total_rows += descs[i].num_indices;
   const int tok = tokens > 2 ? 4 : tokens;

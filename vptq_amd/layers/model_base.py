@@ -1,0 +1,114 @@
+"""Checkpoint loader: `vptq.AutoModelForCausalLM.from_pretrained` for VPTQ checkpoints
+(reference vptq/layers/model_base.py:93-199).
+
+Same observable behaviour for the single-device case: read `config.json`, build the model
+without allocating weights, swap every module named in `quantization_config.config_for_layers`
+(or whose tail name is in `shared_layer_config`, model_base.py:41-45) for a `VQuantLinear`
+built from that entry's keyword arguments, load the safetensors shards, return `model.eval()`.
+
+Not carried over: accelerate's multi-GPU layer placement (`device_map="auto"`,
+model_base.py:165-194) — sequential placement, not part of the fused-GEMV hot path — and the
+hub download (`snapshot_download`; there is no network here, pass a local directory).
+"""
+from __future__ import annotations
+
+import glob
+import json
+import os
+from typing import Optional
+
+import torch
+
+from vptq_amd.layers.vqlinear import VQuantLinear, chain_prefetch
+
+
+def make_quant_linear(module: torch.nn.Module, config_for_layers: dict, shared_layer_config: dict,
+                      target_layer=VQuantLinear, dtype=None) -> int:
+    """Replace, in place, every sub-module with a quantisation entry.  Returns the count."""
+    n = 0
+    for module_name, sub_module in list(module.named_modules()):
+        tail = module_name.split(".")[-1]
+        conf = config_for_layers.get(module_name)
+        if conf is None and tail in shared_layer_config:
+            conf = shared_layer_config[tail]
+        if conf is None or not module_name:
+            continue
+        w = getattr(sub_module, "weight", None)
+        kw = dict(conf)
+        kw.setdefault("is_indice_packed", True)
+        new = target_layer(**kw, enable_proxy_error=False,
+                           dtype=dtype if dtype is not None else (w.dtype if w is not None else None))
+        module.set_submodule(module_name, new)
+        n += 1
+    return n
+
+
+def _checkpoint_files(path: str):
+    idx = glob.glob(os.path.join(path, "*.safetensors.index.json"))
+    if idx:
+        with open(idx[0]) as f:
+            files = sorted(set(json.load(f)["weight_map"].values()))
+        return [os.path.join(path, f) for f in files]
+    files = sorted(glob.glob(os.path.join(path, "*.safetensors")))
+    if not files:
+        raise FileNotFoundError(f"no *.safetensors under {path}")
+    return files
+
+
+class AutoModelForCausalLM:
+    """`vptq.AutoModelForCausalLM` (reference vptq/__init__.py:7-14)."""
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path: str, *model_args,
+                        device: Optional[str] = None, dtype: Optional[torch.dtype] = None,
+                        link_prefetch: bool = False, **kwargs):
+        import transformers
+        from safetensors.torch import load_file
+
+        path = str(pretrained_model_name_or_path)
+        if not os.path.isdir(path):
+            raise FileNotFoundError(
+                f"{path} is not a local directory (no hub access in this build: download the "
+                "checkpoint and pass its path)")
+        conf = transformers.AutoConfig.from_pretrained(path)
+        qc = getattr(conf, "quantization_config", None)
+        if qc is None:
+            raise ValueError("config.json has no quantization_config: not a VPTQ checkpoint")
+        qd = qc if isinstance(qc, dict) else qc.to_dict()
+        if dtype is None:
+            dtype = getattr(conf, "dtype", None) or getattr(conf, "torch_dtype", None) or torch.float16
+        if isinstance(dtype, str):
+            dtype = getattr(torch, dtype)
+        if device is None:
+            device = "cuda:0" if torch.cuda.is_available() else "cpu"
+
+        # HF must not try to quantise by itself: we do the replacement below
+        plain = conf.__class__.from_dict({k: v for k, v in conf.to_dict().items()
+                                          if k != "quantization_config"})
+        with torch.device("meta"):
+            model = transformers.AutoModelForCausalLM.from_config(plain, *model_args, dtype=dtype)
+            replaced = make_quant_linear(model, qd.get("config_for_layers", {}) or {},
+                                         qd.get("shared_layer_config", {}) or {}, dtype=dtype)
+        if replaced == 0:
+            raise ValueError("quantization_config names no module of this model")
+        model = model.to_empty(device=device)
+
+        state = {}
+        for f in _checkpoint_files(path):
+            state.update(load_file(f, device=str(device)))
+        missing, unexpected = model.load_state_dict(state, strict=False, assign=True)
+        tied = getattr(plain, "tie_word_embeddings", False)
+        missing = [k for k in missing if not (tied and k.startswith("lm_head."))]
+        if missing or unexpected:
+            raise RuntimeError(f"checkpoint does not match the model: missing {missing[:8]} "
+                               f"unexpected {unexpected[:8]}")
+        if tied:
+            model.tie_weights()
+        # non-persistent buffers (rotary inv_freq) were created on meta: rebuild them
+        for name, mod in list(model.named_modules()):
+            if type(mod).__name__.endswith("RotaryEmbedding"):
+                model.set_submodule(name, type(mod)(config=plain).to(device))
+        model.config.quantization_config = qd
+        if link_prefetch:
+            chain_prefetch([m for m in model.modules() if isinstance(m, VQuantLinear)], circular=True)
+        return model.eval()
