@@ -1,4 +1,5 @@
 import os
+import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,3 +10,15 @@ for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run through gpurun)")
+
+
+def pytest_sessionstart(session):
+    """Build the native pieces if a fresh checkout has not done so yet (the .so files are
+    git-ignored): the HIP library (hipcc cross-compiles gfx950 without a GPU) and the C oracle."""
+    jobs = str(min(8, os.cpu_count() or 1))
+    if not os.path.exists(os.path.join(ROOT, "vptq_amd", "libvptq_hip.so")):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "vptq_amd", "csrc"), "-j", jobs],
+                       check=True, stdout=subprocess.DEVNULL)
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_build", "libvptq_oracle.so")):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True,
+                       stdout=subprocess.DEVNULL)

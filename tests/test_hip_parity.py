@@ -164,6 +164,29 @@ def test_edge_index_patterns(dev):
         assert rel_err(got, vo.forward(L, x), "f16") <= 1e-3
 
 
+def test_empty_and_extreme_inputs(dev):
+    """zero tokens; the widest layer a uint16 permutation allows (I = 65536); the largest
+    index values of a 65536-entry codebook."""
+    L = vo.make_layer(1024, 256, dist="llm", seed=3, bias=True)
+    m = spec_to_module(L, dev)
+    y = m(torch.empty(2, 0, 1024, device=dev, dtype=torch.float16))
+    assert tuple(y.shape) == (2, 0, 256)
+    # I = 65536 with perm (max for uint16), 2 tokens, padded O
+    L = vo.make_layer(65536, 60, dist="llm", seed=4, enable_perm=True)
+    x = vo.from_f32(np.random.default_rng(4).standard_normal((1, 2, 65536)).astype(np.float32), "f16")
+    m = spec_to_module(L, dev)
+    got = tensor_to_bits(m(bits_to_tensor(x, "f16", dev).reshape(x.shape)))
+    assert rel_err(got, vo.forward(L, x), "f16") <= 1e-3
+    # k = 65536: every index = 65535 / residual = 255
+    L = vo.make_layer(512, 128, dist="llm", seed=5, num_centroids=65536, num_res_centroids=256)
+    L.indices = np.full_like(L.indices, -1)
+    x = vo.from_f32(np.random.default_rng(5).standard_normal((1, 1, 512)).astype(np.float32), "f16")
+    m = spec_to_module(L, dev)
+    assert (tensor_to_bits(m.dequant()) == vo.dequant(L)).all()
+    got = tensor_to_bits(m(bits_to_tensor(x, "f16", dev).reshape(x.shape)))
+    assert rel_err(got, vo.forward(L, x), "f16") <= 1e-3
+
+
 # ---------------------------------------------------------------- BASELINE sizes
 @pytest.mark.parametrize("H", [4096, 8192])
 def test_full_size_layers_properties(H, dev):
