@@ -61,8 +61,6 @@ struct K256Layer {
 struct K256Params {
   int n_layers;
   int tokens;
-  int debug;  // VPTQ_K256_DEBUG: 1 = return at once, 2 = loads + LDS image only (timing probes)
-  int pad_;
   K256Layer layer[kMaxGroup];
 };
 
@@ -78,10 +76,16 @@ static __device__ __forceinline__ void gather(uint32_t w, int h, uint32_t baseC,
 
 // 16-byte load of 8 consecutive 16-bit values, or (PERM) a gather of 8 values through
 // the permutation: column c of the quantised matrix multiplies input feature perm[c].
+// 16 bytes at base + byte_off: 32-bit zero-extended offset against a wave-uniform base
+// selects the scalar-base addressing form (no 64-bit vector add per load).
+static __device__ __forceinline__ u32x4 ld16(const void* base, uint32_t byte_off) {
+  return *(const u32x4*)((const char*)base + byte_off);
+}
+
 template <bool PERM>
 static __device__ __forceinline__ u32x4 load8(const uint16_t* __restrict__ p, int col0,
                                               const u32x4& pv) {
-  if (!PERM) return *(const u32x4*)(p + col0);
+  if (!PERM) return ld16(p, (uint32_t)col0 * 2u);
   u32x4 r;
 #pragma unroll
   for (int q = 0; q < 4; ++q)
@@ -95,7 +99,6 @@ __global__ __launch_bounds__(kThreads, 4) void gemv_k256_kernel(const K256Params
   // gathers address LDS absolutely; `smem` only sizes the allocation.
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
-  if (P.debug == 1) return;
   // ---- which layer / row group is this workgroup? (wave-uniform) ----
   const int bid = blockIdx.x;
   int li = 0;
@@ -151,9 +154,9 @@ __global__ __launch_bounds__(kThreads, 4) void gemv_k256_kernel(const K256Params
       // PERM: sp / bp already hold scale[perm[c]] / bias[perm[c]] (derived state,
       // VptqLayerDesc.scale_permuted); only the activations are gathered.
       u32x4 pv = u32x4{0, 0, 0, 0};
-      if (PERM) pv = *(const u32x4*)(pp + col0);
-      s_raw[sw] = *(const u32x4*)(sp + col0);
-      b_raw[sw] = *(const u32x4*)(bp + col0);
+      if (PERM) pv = ld16(pp, (uint32_t)col0 * 2u);
+      s_raw[sw] = ld16(sp, (uint32_t)col0 * 2u);
+      b_raw[sw] = ld16(bp, (uint32_t)col0 * 2u);
 #pragma unroll
       for (int t = 0; t < TOK; ++t) {
         const int te = t < tokens ? t : tokens - 1;  // spare token slots repeat the last row
@@ -163,8 +166,8 @@ __global__ __launch_bounds__(kThreads, 4) void gemv_k256_kernel(const K256Params
       }
 #pragma unroll
       for (int r = 0; r < ROWS; ++r) {
-        const int row = row0 + r < N ? row0 + r : N - 1;
-        iw[sw][r] = *(const u32x4*)(idx_base + (size_t)row * row_words + (col0 >> 1));
+        const int row = row0 + r < N ? row0 + r : N - 1;   // wave-uniform
+        iw[sw][r] = ld16(idx_base + (size_t)row * row_words, (uint32_t)col0 * 2u);
       }
     }
 
@@ -189,17 +192,6 @@ __global__ __launch_bounds__(kThreads, 4) void gemv_k256_kernel(const K256Params
       pf_word = *(const uint32_t*)pa;
     }
 
-    if (P.debug == 2) {  // probe: consume the loads, skip the arithmetic
-      uint32_t z = 0;
-#pragma unroll
-      for (int sw = 0; sw < SW; ++sw) {
-        z ^= s_raw[sw][0] ^ b_raw[sw][1] ^ x_raw[sw][0][2];
-#pragma unroll
-        for (int r = 0; r < ROWS; ++r) z ^= iw[sw][r][0] ^ iw[sw][r][3];
-      }
-      acc[0][0][0] += (float)(z & 1);
-      continue;
-    }
     // ---- 4. dequantise + accumulate ----
 #pragma unroll
     for (int sw = 0; sw < SW; ++sw) {
@@ -332,6 +324,10 @@ bool gemv_k256_eligible(const VptqLayerDesc& d, int tokens) {
 // ROWS per workgroup: 2 when that still leaves >= 512 workgroups (two per CU) and
 // the instantiation stays spill-free under the 128-VGPR budget (f16, one token).
 static int pick_rows(int n_rows_total, int tok, bool f16) {
+  static int forced = -1;  // VPTQ_K256_ROWS=1|2: tuning override
+  if (forced < 0) { const char* e = getenv("VPTQ_K256_ROWS"); forced = e ? atoi(e) : 0; }
+  if (forced == 2 && f16 && tok == 1) return 2;
+  if (forced == 1) return 1;
   return (f16 && tok == 1 && (n_rows_total + 1) / 2 >= 512) ? 2 : 1;
 }
 
@@ -385,10 +381,6 @@ hipError_t launch_gemv_k256(const VptqLayerDesc* descs, int n, const void* const
   K256Params P;
   P.n_layers = n;
   P.tokens = tokens;
-  static int dbg = -1;
-  if (dbg < 0) { const char* e = getenv("VPTQ_K256_DEBUG"); dbg = e ? atoi(e) : 0; }
-  P.debug = dbg;
-  P.pad_ = 0;
   int total_rows = 0;
   for (int i = 0; i < n; ++i) total_rows += descs[i].num_indices;
   const int tok = tokens > 2 ? 4 : tokens;

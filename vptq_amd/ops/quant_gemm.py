@@ -25,10 +25,6 @@ __all__ = ["dequant", "quant_gemm", "quant_gemv_v2"]
 _FLAGS = B.GEMV_FAST_MATH if os.environ.get("VPTQ_FAST_MATH", "0") == "1" else 0
 
 
-def _view3(t: Optional[torch.Tensor], a: int, b: int, c: int):
-    return None if t is None else t.view(a, b, c)
-
-
 def dequant(
     indices: torch.Tensor,
     centroids: torch.Tensor,
