@@ -98,6 +98,11 @@ __global__ __launch_bounds__(kThreads, 4) void gemv_k256_kernel(const K256Params
   // The dynamic LDS segment starts at byte 0 (the kernel has no static LDS), so
   // gathers address LDS absolutely; `smem` only sizes the allocation.
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  {
+    // absolute LDS addressing is only valid if that holds; folds to nothing when it does
+    typedef __attribute__((address_space(3))) unsigned char lds_u8_t;
+    if ((uint32_t)(uintptr_t)(lds_u8_t*)smem != 0u) __builtin_trap();
+  }
 
   // ---- which layer / row group is this workgroup? (wave-uniform) ----
   const int bid = blockIdx.x;
