@@ -21,6 +21,31 @@ def test_loader_builds_and_loads_synthetic_checkpoint(tmp_path):
     assert not model.training
 
 
+def test_loader_absorb_perm_option(tmp_path):
+    write_tiny_checkpoint(str(tmp_path))
+    a = vptq_amd.AutoModelForCausalLM.from_pretrained(str(tmp_path), device="cpu")
+    b = vptq_amd.AutoModelForCausalLM.from_pretrained(str(tmp_path), device="cpu", absorb_perm=True)
+    qa = [m for m in a.modules() if isinstance(m, vptq_amd.VQuantLinear)]
+    qb = [m for m in b.modules() if isinstance(m, vptq_amd.VQuantLinear)]
+    assert all(m.enable_perm for m in qa) and not any(m.enable_perm for m in qb)
+    assert all("perm" not in m.state_dict() for m in qb)
+    cfg = b.config.quantization_config["config_for_layers"]
+    assert not any(v["enable_perm"] for v in cfg.values())
+    # same dense weight (oracle) for one layer
+    from oracle import vptq_oracle as vo
+    import numpy as np
+    def spec(m):
+        L = vo.LayerSpec(m.in_features, m.out_features, 8, 256, 256, 1, m.group_size, dtype="f16")
+        u16 = lambda t: t.detach().contiguous().view(torch.int16).numpy().view(np.uint16)
+        L.indices = m.indices.detach().numpy()
+        L.centroids = u16(m.centroids.weight).reshape(1, 256, 8)
+        L.res_centroids = u16(m.res_centroids.weight).reshape(1, 256, 8)
+        L.weight_scale, L.weight_bias = u16(m.weight_scale), u16(m.weight_bias)
+        L.perm = u16(m.perm) if m.enable_perm else None
+        return L
+    assert (vo.dequant(spec(qa[3])) == vo.dequant(spec(qb[3]))).all()
+
+
 def test_loader_rejects_non_vptq_and_missing(tmp_path):
     import json, pytest
     with pytest.raises(FileNotFoundError):

@@ -340,12 +340,15 @@ template <typename DT, int ROWS, int TOK, int SW, bool PERM, bool FAST>
 static hipError_t launch_inst(const K256Params& P, int grid, hipStream_t st) {
   auto kern = gemv_k256_kernel<DT, ROWS, TOK, SW, PERM, FAST>;
   constexpr int lds = kScratchOff + kWaves * (TOK * ROWS * 8 + TOK) * 4;
-  static bool attr_set = false;  // benign race: idempotent
-  if (!attr_set) {
+  // > 64 KiB of dynamic LDS must be enabled once per device (benign race: idempotent)
+  static bool attr_set[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (!attr_set[dev]) {
     hipError_t e = hipFuncSetAttribute((const void*)kern,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    attr_set[dev] = true;
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, st, P);
   return hipGetLastError();

@@ -61,7 +61,7 @@ class AutoModelForCausalLM:
     @classmethod
     def from_pretrained(cls, pretrained_model_name_or_path: str, *model_args,
                         device: Optional[str] = None, dtype: Optional[torch.dtype] = None,
-                        link_prefetch: bool = False, **kwargs):
+                        link_prefetch: bool = False, absorb_perm: bool = False, **kwargs):
         import transformers
         from safetensors.torch import load_file
 
@@ -109,6 +109,11 @@ class AutoModelForCausalLM:
             if type(mod).__name__.endswith("RotaryEmbedding"):
                 model.set_submodule(name, type(mod)(config=plain).to(device))
         model.config.quantization_config = qd
+        if absorb_perm:
+            # fold every layer's input permutation into its index order (same dense weight,
+            # no per-token activation gather; what the reference's tools/pre_process.py does)
+            from vptq_amd.utils.pack import absorb_perm as _absorb
+            _absorb(model)
         if link_prefetch:
             chain_prefetch([m for m in model.modules() if isinstance(m, VQuantLinear)], circular=True)
         return model.eval()
