@@ -242,7 +242,11 @@ def main():
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                      "bytes_per_launch": bytes_per_launch, "us_per_launch": us_per_launch,
                      "note": "us_per_launch = HIP-event time over the timed region / launches "
-                             "(includes inter-kernel gaps); kernel is VALU-issue bound, see DESIGN.md §4"},
+                             "(includes inter-kernel gaps); kernel is VALU-issue bound, see DESIGN.md §4",
+                     "valu": {"instr_per_index_pair": 14 if a.fast_math else 22,
+                              "ns_per_instr_per_simd_at_4_waves": 2.25,
+                              "floor_us_per_launch": (H // 8) * H * (14 if a.fast_math else 22)
+                              / (1024 * 64) * 2.25e-3}},
     }
     pmc = os.path.join(ROOT, "profiles", "r01", f"bench_h{H}_{a.mode}_pmc_summary.json")
     if os.path.exists(pmc) and not a.fast_math and not a.prefetch:
