@@ -55,7 +55,9 @@ struct K256Layer {
   long long pf_bytes;
   int N, G, O, row_words;
   int wg_begin;  // first workgroup id of this layer
-  int pf_chunk;  // read-ahead bytes per workgroup (multiple of 128)
+  int pf_chunk;  // read-ahead stride per workgroup in bytes (multiple of 128)
+  int pf_len;    // bytes actually touched per workgroup (<= pf_chunk)
+  int pad_;
 };
 
 struct K256Params {
@@ -192,7 +194,7 @@ __global__ __launch_bounds__(kThreads, 4) void gemv_k256_kernel(const K256Params
       // Unconditional, address-clamped load; its value is only "used" in a branch that
       // is never taken, so nothing ever waits for it.
       const long long want = (long long)(bid - Ly.wg_begin) * Ly.pf_chunk + (long long)tid * 128;
-      const bool in = tid * 128 < Ly.pf_chunk && want + 4 <= Ly.pf_bytes;
+      const bool in = tid * 128 < Ly.pf_len && want + 4 <= Ly.pf_bytes;
       const char* pa = in ? Ly.pf + want : (const char*)cent0;
       pf_word = *(const uint32_t*)pa;
     }
@@ -417,7 +419,13 @@ hipError_t launch_gemv_k256(const VptqLayerDesc* descs, int n, const void* const
     Ly.pf_bytes = d.prefetch ? d.prefetch_bytes : 0;
     long long chunk = d.prefetch ? (d.prefetch_bytes + n_wg - 1) / n_wg : 0;
     chunk = (chunk + 127) / 128 * 128;
-    Ly.pf_chunk = (int)(chunk > kThreads * 128 ? kThreads * 128 : chunk);  // one line per thread
+    Ly.pf_chunk = (int)chunk;
+    static int pf_cap = -1;  // VPTQ_PF_BYTES: cap on the bytes each workgroup reads ahead
+    if (pf_cap < 0) { const char* e = getenv("VPTQ_PF_BYTES"); pf_cap = e ? atoi(e) : kThreads * 128; }
+    long long len = chunk < pf_cap ? chunk : pf_cap;
+    if (len > kThreads * 128) len = kThreads * 128;  // one line per thread
+    Ly.pf_len = (int)len;
+    Ly.pad_ = 0;
     grid += n_wg;
   }
   // the folded-arithmetic instantiations exist for 1-2 tokens
