@@ -252,6 +252,37 @@ def test_grouped_launch_matches_single(dev):
         assert torch.equal(a, b)
 
 
+def test_grouped_launch_mixed_shapes_and_tokens(dev):
+    """One grouped launch over layers of different widths (the sweep count is chosen by the
+    widest), different heights, 2 tokens, one of them with an odd row count."""
+    from vptq_amd import _backend as B
+    from _gpu_util import module_desc
+    import ctypes as C
+    shapes = [(8192 + 1024, 264), (1024, 2048), (4096, 512), (2048, 40)]
+    mods, xs, want = [], [], []
+    for i, (I, O) in enumerate(shapes):
+        L = vo.make_layer(I, O, dist="llm", seed=60 + i, bias=(i % 2 == 0))
+        m = spec_to_module(L, dev)
+        xb = vo.from_f32(np.random.default_rng(i).standard_normal((1, 2, I)).astype(np.float32), "f16")
+        mods.append(m)
+        xs.append(bits_to_tensor(xb, "f16", dev).reshape(1, 2, I))
+        want.append(vo.forward(L, xb))
+    descs = (B.LayerDesc * len(mods))()
+    keep = []
+    for i, m in enumerate(mods):
+        d, k = module_desc(m)
+        descs[i] = d
+        keep.append(k)
+    ys = [torch.empty(1, 2, O, device=dev, dtype=torch.float16) for _, O in shapes]
+    xp = (C.c_void_p * 4)(*[t.data_ptr() for t in xs])
+    yp = (C.c_void_p * 4)(*[t.data_ptr() for t in ys])
+    B.check(B.lib().vptq_quant_gemv_grouped(descs, 4, xp, yp, 2, 0, B.current_stream_ptr(dev)),
+            "grouped")
+    torch.cuda.synchronize()
+    for y, w in zip(ys, want):
+        assert rel_err(tensor_to_bits(y), w, "f16") <= 1e-3
+
+
 def test_read_ahead_hint_does_not_change_results(dev):
     """chain_prefetch is a pure performance hint (also with a range smaller / larger than
     the layer's own index tensor and with perm)."""
