@@ -29,6 +29,7 @@ import torch
 import torch.nn as nn
 from torch.nn.parameter import Parameter
 
+from vptq_amd import _backend as B
 from vptq_amd import ops
 
 
@@ -156,6 +157,9 @@ class VQuantLinear(nn.Module):
                 "enable_proxy_error=True selects the reference's layer-wise fine-tuning debug "
                 "path, which is outside this inference package; construct the layer with "
                 "enable_proxy_error=False (HF does).")
+        tokens = x.numel() // x.shape[-1] if x.shape[-1] else 0
+        if 1 <= tokens <= B.GEMV_MAX_TOKENS and x.is_cuda:
+            return self._gemv_cached(x, tokens)
         return ops.quant_gemm(
             x,
             bias=self.bias,
@@ -184,6 +188,57 @@ class VQuantLinear(nn.Module):
             vector_quant_dim=self.vector_quant_dim,
             prefetch=None if self._prefetch_next is None else self._prefetch_next.indices,
         )
+
+    def _gemv_cached(self, x: torch.Tensor, tokens: int) -> torch.Tensor:
+        """Decode fast path: identical to `ops.quant_gemm` for 1..8 tokens, but the C-ABI
+        descriptor (and the derived state it points at) is built once per layer and reused
+        while the parameter storages stay the same — building it costs ~25 us of Python per
+        call, several times the kernel itself."""
+        if x.shape[-1] != self.in_features:
+            raise RuntimeError(f"x has {x.shape[-1]} features, layer expects {self.in_features}")
+        cw = self.centroids.weight
+        if x.dtype != cw.dtype:
+            raise RuntimeError(f"activation dtype {x.dtype} != weight dtype {cw.dtype}")
+        if not x.is_contiguous():
+            x = x.contiguous()
+        nxt = self._prefetch_next
+        tensors = (self.indices, cw, self.res_centroids.weight if self.enable_residual else None,
+                   self.outlier_indices,
+                   self.outlier_centroids.weight if self.enable_outlier else None,
+                   self.perm if self.enable_perm else None, self.weight_scale, self.weight_bias,
+                   self.bias, None if nxt is None else nxt.indices)
+        key = tuple(0 if t is None else t.data_ptr() for t in tensors)
+        cache = self.__dict__.get("_desc_cache")
+        if cache is None or cache[0] != key:
+            dev = B.require_device(x, *tensors)
+            desc, keep = B.make_layer_desc(
+                indices=tensors[0], centroids=tensors[1], res_centroids=tensors[2],
+                outlier_indices=tensors[3], outlier_centroids=tensors[4], perm=tensors[5],
+                weight_scale=tensors[6], weight_bias=tensors[7], bias=tensors[8],
+                in_features=self.in_features, out_features=self.out_features,
+                vector_len=self.vector_len, num_codebooks=self.num_codebooks,
+                num_centroids=self.num_centroids,
+                num_res_centroids=self.num_res_centroids if self.enable_residual else 0,
+                group_size=self.group_size,
+                outlier_size=self.outlier_size if self.enable_outlier else 0,
+                outlier_vector_len=self.outlier_vector_len,
+                num_outlier_centroids=self.num_outlier_centroids, prefetch=tensors[9])
+            cache = (key, desc, keep, dev, B.lib().vptq_quant_gemv)
+            self.__dict__["_desc_cache"] = cache
+        _, desc, _, dev, fn = cache
+        if x.device != dev:
+            raise RuntimeError(f"tensors on different devices: {dev} vs {x.device}")
+        y = torch.empty(x.shape[:-1] + (self.out_features,), dtype=x.dtype, device=dev)
+        if torch.cuda.current_device() != dev.index:
+            with torch.cuda.device(dev):
+                rc = fn(desc, x.data_ptr(), y.data_ptr(), tokens, ops.quant_gemm_flags(), None, 0,
+                        torch.cuda.current_stream(dev).cuda_stream)
+        else:
+            rc = fn(desc, x.data_ptr(), y.data_ptr(), tokens, ops.quant_gemm_flags(), None, 0,
+                    torch.cuda.current_stream(dev).cuda_stream)
+        if rc:
+            B.check(rc, "vptq_quant_gemv")
+        return y
 
     def dequant(self) -> torch.Tensor:
         """Dense W[out_features, in_features] (what the reference calls

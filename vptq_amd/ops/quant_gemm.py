@@ -25,6 +25,11 @@ __all__ = ["dequant", "quant_gemm", "quant_gemv_v2"]
 _FLAGS = B.GEMV_FAST_MATH if os.environ.get("VPTQ_FAST_MATH", "0") == "1" else 0
 
 
+def quant_gemm_flags() -> int:
+    """flags passed to vptq_quant_gemv by this process (VPTQ_FAST_MATH=1 -> folded arithmetic)"""
+    return _FLAGS
+
+
 def dequant(
     indices: torch.Tensor,
     centroids: torch.Tensor,
