@@ -439,7 +439,9 @@ hipError_t launch_gemv_k256(const VptqLayerDesc* descs, int n, const void* const
     maxG = descs[i].group_size > maxG ? descs[i].group_size : maxG;
     perm = perm || descs[i].perm != nullptr;
   }
-  const int sw = maxG > kSweepCols ? 2 : 1;
+  // two sweeps per iteration keep more loads in flight, but the 4-token instantiation
+  // only stays spill-free with one
+  const int sw = (maxG > kSweepCols && tok != 4) ? 2 : 1;
   return f16 ? dispatch<F16, true>(P, grid, rows, tok, fast, sw, perm, st)
              : dispatch<BF16, false>(P, grid, rows, tok, false, sw, perm, st);
 }
