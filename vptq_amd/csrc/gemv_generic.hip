@@ -38,50 +38,8 @@ __global__ __launch_bounds__(256) void gemv_generic_kernel(const VptqLayerDesc d
 #pragma unroll
     for (int i = 0; i < V; ++i) acc[t][i] = 0.f;
 
-  for (int c = tid; c < I; c += 256) {
-    const int j = d.perm ? (int)d.perm[c] : c;
-    uint32_t w2[VP];
-    if (c < S) {
-      // outlier column: W[m*ov+tt, c] = outlier_centroids[oidx[m, c], tt]
-      const int ov = d.outlier_vector_len;
-#pragma unroll
-      for (int p = 0; p < VP; ++p) {
-        uint32_t pr = 0;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int o = n * V + 2 * p + h;
-          uint16_t e = 0;
-          if (o < O) {
-            const int m = o / ov, tt = o - m * ov;
-            const uint32_t oi = d.outlier_indices[(size_t)m * S + c];
-            e = ocent[(size_t)oi * ov + tt];
-          }
-          pr |= (uint32_t)e << (16 * h);
-        }
-        w2[p] = pr;
-      }
-    } else {
-      const int cc = c - S;
-      const int cb = cc / G, g = cc - cb * G;
-      const uint32_t* row =
-          (const uint32_t*)d.indices + ((size_t)cb * d.num_indices + n) * d.row_words;
-      const uint32_t e = unpack_elem(row, g, T);
-      const uint32_t idx = e & imask;
-      const uint32_t* cp = cent + ((size_t)cb * d.num_centroids + idx) * VP;
-#pragma unroll
-      for (int p = 0; p < VP; ++p) w2[p] = cp[p];
-      if (rmask) {
-        const uint32_t ridx = (e >> d.index_bits) & rmask;
-        const uint32_t* rp = rcent + ((size_t)cb * d.num_res_centroids + ridx) * VP;
-#pragma unroll
-        for (int p = 0; p < VP; ++p) w2[p] = DT::add2(w2[p], rp[p]);
-      }
-    }
-    if (norm) {
-      const uint32_t s2 = splat16(scale[j]), b2 = splat16(wbias[j]);
-#pragma unroll
-      for (int p = 0; p < VP; ++p) w2[p] = DT::add2(DT::mul2(w2[p], s2), b2);
-    }
+  // accumulate one rebuilt weight vector against the activations of input feature j
+  auto accumulate = [&](const uint32_t (&w2)[VP], int j) {
 #pragma unroll
     for (int t = 0; t < TOK; ++t) {
       if (t < tokens) {
@@ -91,6 +49,82 @@ __global__ __launch_bounds__(256) void gemv_generic_kernel(const VptqLayerDesc d
           acc[t][2 * p] = DT::fma_lo(w2[p], xf, acc[t][2 * p]);
           acc[t][2 * p + 1] = DT::fma_hi(w2[p], xf, acc[t][2 * p + 1]);
         }
+      }
+    }
+  };
+  auto normalise = [&](uint32_t (&w2)[VP], int j) {
+    if (norm) {
+      const uint32_t s2 = splat16(scale[j]), b2 = splat16(wbias[j]);
+#pragma unroll
+      for (int p = 0; p < VP; ++p) w2[p] = DT::add2(DT::mul2(w2[p], s2), b2);
+    }
+  };
+
+  // ---- outlier columns (c < S): W[m*ov+tt, c] = outlier_centroids[oidx[m, c], tt] ----
+  for (int c = tid; c < S; c += 256) {
+    const int j = d.perm ? (int)d.perm[c] : c;
+    const int ov = d.outlier_vector_len;
+    uint32_t w2[VP];
+#pragma unroll
+    for (int p = 0; p < VP; ++p) {
+      uint32_t pr = 0;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int o = n * V + 2 * p + h;
+        uint16_t e = 0;
+        if (o < O) {
+          const int m = o / ov, tt = o - m * ov;
+          const uint32_t oi = d.outlier_indices[(size_t)m * S + c];
+          e = ocent[(size_t)oi * ov + tt];
+        }
+        pr |= (uint32_t)e << (16 * h);
+      }
+      w2[p] = pr;
+    }
+    normalise(w2, j);
+    accumulate(w2, j);
+  }
+
+  // ---- codebook columns: kU independent index -> gather chains in flight per thread ----
+  constexpr int kU = 4;
+  const int IC = I - S;  // = C * G
+  for (int c0 = tid; c0 < IC; c0 += 256 * kU) {
+    uint32_t e[kU];
+    int j[kU], cbv[kU];
+    bool ok[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const int cc = c0 + u * 256;
+      ok[u] = cc < IC;
+      const int ccl = ok[u] ? cc : IC - 1;          // clamped: loads stay in bounds
+      const int cb = ccl / G, g = ccl - cb * G;
+      cbv[u] = cb;
+      const uint32_t* row =
+          (const uint32_t*)d.indices + ((size_t)cb * d.num_indices + n) * d.row_words;
+      e[u] = unpack_elem(row, g, T);
+      j[u] = d.perm ? (int)d.perm[S + ccl] : S + ccl;
+    }
+    uint32_t w2[kU][VP];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const uint32_t* cp = cent + ((size_t)cbv[u] * d.num_centroids + (e[u] & imask)) * VP;
+#pragma unroll
+      for (int p = 0; p < VP; ++p) w2[u][p] = cp[p];
+    }
+    if (rmask) {
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const uint32_t ridx = (e[u] >> d.index_bits) & rmask;
+        const uint32_t* rp = rcent + ((size_t)cbv[u] * d.num_res_centroids + ridx) * VP;
+#pragma unroll
+        for (int p = 0; p < VP; ++p) w2[u][p] = DT::add2(w2[u][p], rp[p]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      if (ok[u]) {
+        normalise(w2[u], j[u]);
+        accumulate(w2[u], j[u]);
       }
     }
   }
