@@ -312,6 +312,25 @@ def test_absorb_perm_on_device(dev):
     assert ((y1.float() - y0.float()).abs().max() / y0.float().abs().max()).item() <= 5e-4
 
 
+def test_deterministic_and_stream_safe(dev):
+    """Fixed summation order => bit-identical results run to run, also when two streams
+    launch different layers concurrently (the library keeps no per-call state)."""
+    mods = [spec_to_module(vo.make_layer(4096, 1024, dist="llm", seed=90 + i), dev) for i in range(2)]
+    x = torch.randn(1, 1, 4096, device=dev, dtype=torch.float16)
+    ref = [m(x).clone() for m in mods]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for _ in range(25):
+        outs = []
+        for m, st in zip(mods, streams):
+            st.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st):
+                outs.append(m(x))
+        torch.cuda.synchronize()
+        for o, r in zip(outs, ref):
+            assert torch.equal(o, r)
+
+
 def test_hipgraph_capture_of_the_forward(dev):
     L = vo.make_layer(4096, 4096, dist="llm", seed=1)
     m = spec_to_module(L, dev)
