@@ -13,6 +13,10 @@ launches through the C ABI, captured once in a hipGraph and replayed.
   --mode single  : one launch per layer (the reference's operator granularity)
   --mode grouped : layers launched 4 at a time with vptq_quant_gemv_grouped
                    (q/k/v/o-style fusion of independent projections)
+  --mode tp      : BASELINE config #5 flavour: every layer is cut into N slices of its output
+                   rows (vptq_amd.utils.shard.shard_out_features), one per rank, and the slices
+                   are re-assembled with an RCCL all-gather per layer; strong scaling (total
+                   work fixed), expected NOT to scale at batch 1
 Inputs and weights are resident in HBM before the timed region.  With N > 1
 (torchrun, one rank per GPU) every rank owns its own ring: independent layers, no
 data-path collective, weak scaling; the time is the max over ranks.
@@ -125,7 +129,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--hidden", type=int, default=8192)
     ap.add_argument("--ring", type=int, default=0)
-    ap.add_argument("--mode", choices=["single", "grouped"], default="single")
+    ap.add_argument("--mode", choices=["single", "grouped", "tp"], default="single")
     ap.add_argument("--group", type=int, default=4)
     ap.add_argument("--fast-math", action="store_true",
                     help="folded fp32 arithmetic (VPTQ_GEMV_FAST_MATH); not the default path")
@@ -155,10 +159,17 @@ def main():
     H = a.hidden
     idx_bytes = (H // 8) * H * 2
     R = a.ring or max(2, (512 << 20) // idx_bytes)
-    layers = make_ring(H, R, dev, seed=1234 + rank)
+    # tp: all ranks build the same layers, each keeps its slice of the output rows
+    layers = make_ring(H, R, dev, seed=1234 + (0 if a.mode == "tp" else rank))
+    if a.mode == "tp":
+        from vptq_amd.utils.shard import shard_out_features
+        layers = [shard_out_features(m, rank, world) for m in layers]
+        torch.cuda.empty_cache()
     x = torch.randn(1, 1, H, device=dev, dtype=torch.float16,
                     generator=torch.Generator(device=dev).manual_seed(7))
-    ys = [torch.empty(1, 1, H, device=dev, dtype=torch.float16) for _ in range(R)]
+    ys = [torch.empty(1, 1, layers[i].out_features, device=dev, dtype=torch.float16)
+          for i in range(R)]
+    y_full = torch.empty(H, device=dev, dtype=torch.float16) if a.mode == "tp" else None
     descs, keeps = [], []
     for i, m in enumerate(layers):
         # decode order is known: layer i warms L2 / Infinity Cache with layer i+1's indices
@@ -170,7 +181,20 @@ def main():
     kname = lib.vptq_quant_gemv_kernel_name(descs[0], 1, flags).decode()
 
     stream = torch.cuda.Stream(device=dev)
-    if a.mode == "single":
+    if a.mode == "tp":
+        launches_per_step = R
+        if H // 8 % world:
+            raise SystemExit("tp mode needs the vector-row count divisible by the world size")
+
+        def one_pass():
+            sp = torch.cuda.current_stream().cuda_stream
+            for i in range(R):
+                rc = lib.vptq_quant_gemv(descs[i], x.data_ptr(), ys[i].data_ptr(), 1, flags,
+                                         None, 0, sp)
+                assert rc == 0, lib.vptq_last_error()
+                if dist is not None:
+                    dist.all_gather_into_tensor(y_full, ys[i].view(-1))
+    elif a.mode == "single":
         launches_per_step = R
 
         def one_pass():
@@ -194,12 +218,23 @@ def main():
                 rc = lib.vptq_quant_gemv_grouped(arr, m, xp, yp, 1, flags, sp)
                 assert rc == 0, lib.vptq_last_error()
 
+    class _Eager:  # same interface as a captured graph
+        def replay(self):
+            one_pass()
+
     with torch.cuda.stream(stream):
         one_pass()
         torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=stream):
-            one_pass()
+        captured = True
+        try:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=stream):
+                one_pass()
+        except Exception:
+            if a.mode != "tp":
+                raise
+            captured, graph = False, _Eager()  # collectives that refuse capture: eager launches
+            torch.cuda.synchronize()
         for _ in range(a.warmup):
             graph.replay()
         torch.cuda.synchronize()
@@ -222,14 +257,18 @@ def main():
     wall, ev_ms = reduce_times(wall, ev_ms, dist, dev)
 
     ab = alg_bytes(H)
-    value = job_throughput_gbps(world, ab, R, a.steps, wall)
+    if a.mode == "tp":   # strong scaling: the ring is processed once per step by all ranks together
+        value = job_throughput_gbps(1, ab, R, a.steps, wall)
+    else:
+        value = job_throughput_gbps(world, ab, R, a.steps, wall)
     us_per_launch = ev_ms * 1e3 / (a.steps * launches_per_step)
-    bytes_per_launch = ab * R / launches_per_step
+    bytes_per_launch = ab * R / launches_per_step / (world if a.mode == "tp" else 1)
     achieved = bytes_per_launch / us_per_launch / 1e3     # GB/s
     out = {
         "metric": "decode GEMV effective GB/s (VQuantLinear 2-bit, batch 1)",
         "value": value, "unit": "GB/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": wall * 1e3 / a.steps, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": wall * 1e3 / a.steps, "higher_is_better": True,
+        "scaling": "strong" if a.mode == "tp" else "weak",
         "vs_baseline": None, "dtype": "f16", "data": "synthetic",
         "config": {"workload": f"VQuantLinear {H}x{H} v=8 k=256+256 (2-bit) batch=1 seq=1 fp16, "
                                f"ring of {R} distinct layers per GPU ({R * idx_bytes >> 20} MiB of "
@@ -237,7 +276,10 @@ def main():
                    "hidden": H, "ring": R, "mode": a.mode, "launches_per_step": launches_per_step,
                    "kernel": kname, "arithmetic": "fast_math" if a.fast_math else "reference-rounding",
                    "read_ahead_next_layer": bool(a.prefetch),
-                   "parallelism": f"{world} x independent rings (no collective)"},
+                   "hipgraph": captured,
+                   "parallelism": (f"tp{world}: output rows of every layer split over {world} ranks, "
+                                   "RCCL all-gather per layer") if a.mode == "tp" else
+                                  f"{world} x independent rings (no collective)"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                      "bytes_per_launch": bytes_per_launch, "us_per_launch": us_per_launch,

@@ -91,3 +91,29 @@ def kernel_name(m, tokens=1, flags=0):
     desc, keep = module_desc(m)
     n = B.lib().vptq_quant_gemv_kernel_name(desc, tokens, flags)
     return None if n is None else n.decode()
+
+
+def module_to_spec(m):
+    """vptq_amd.VQuantLinear (any device) -> oracle LayerSpec with the same bits."""
+    from oracle import vptq_oracle as vo
+    dtype = "f16" if m.centroids.weight.dtype == torch.float16 else "bf16"
+    u16 = lambda t: t.detach().cpu().contiguous().view(torch.int16).numpy().view(np.uint16)  # noqa: E731
+    L = vo.LayerSpec(m.in_features, m.out_features, m.vector_len, m.num_centroids,
+                     m.num_res_centroids if m.enable_residual else -1, m.num_codebooks,
+                     m.group_size, m.outlier_size if m.enable_outlier else 0,
+                     m.outlier_vector_len, m.num_outlier_centroids, dtype)
+    L.indices = m.indices.detach().cpu().numpy()
+    L.centroids = u16(m.centroids.weight).reshape(m.num_codebooks, m.num_centroids, m.vector_len)
+    if m.enable_residual:
+        L.res_centroids = u16(m.res_centroids.weight).reshape(m.num_codebooks, m.num_res_centroids, m.vector_len)
+    if m.enable_outlier:
+        L.outlier_indices = u16(m.outlier_indices)
+        L.outlier_centroids = u16(m.outlier_centroids.weight).reshape(
+            1, m.num_outlier_centroids, m.outlier_vector_len)
+    if m.enable_perm:
+        L.perm = u16(m.perm)
+    if m.enable_norm:
+        L.weight_scale, L.weight_bias = u16(m.weight_scale), u16(m.weight_bias)
+    if m.bias is not None:
+        L.bias = u16(m.bias)
+    return L
