@@ -58,7 +58,7 @@ def test_forward_vs_reference_golden(name, dev):
 def test_canonical_layers_take_the_specialised_kernel(name, dev):
     L, x, y, cfg, _ = load_golden(name)
     m = spec_to_module(L, dev)
-    assert kernel_name(m, cfg["tokens"]).startswith("gemv_k256_kernel")
+    assert kernel_name(m, cfg["tokens"]).startswith("gemv_k256")
     assert kernel_name(m, cfg["tokens"], GENERIC) == "gemv_generic_kernel"
     xt = bits_to_tensor(x, cfg["dtype"], dev).reshape(x.shape)
     a = tensor_to_bits(gemv_abi(m, xt, 0))
@@ -197,7 +197,7 @@ def test_full_size_layers_properties(H, dev):
     rng = np.random.default_rng(7)
     x = vo.from_f32(rng.standard_normal((1, 1, H)).astype(np.float32), "f16")
     m = spec_to_module(L, dev)
-    assert kernel_name(m, 1).startswith("gemv_k256_kernel")
+    assert kernel_name(m, 1).startswith("gemv_k256")
     xt = bits_to_tensor(x, "f16", dev).reshape(x.shape)
     y = m(xt)
     got = tensor_to_bits(y)

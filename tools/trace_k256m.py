@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Phase timeline of gemv_k256m_kernel (GPU box only).
+
+Needs the trace build of the library (every wave stamps the 100 MHz wall clock at its phase
+boundaries into the buffer passed as the read-ahead range):
+
+    make -C vptq_amd/csrc trace          # -> tools/_build/libvptq_hip_trace.so
+    python tools/trace_k256m.py --hidden 8192 [--fast]
+
+Prints, for one launch in the middle of a ring of cold layers, when (us after the first wave
+of the launch started) the waves passed each boundary: min / median / max over all waves.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from vptq_amd import _backend as B  # noqa: E402
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import microbench as mb  # noqa: E402  (make_layers)
+from _gpu_util import module_desc  # noqa: E402
+
+PHASES = ["start", "first loads issued", "LDS image built", "accumulate done", "wave reduced", "after barrier"]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--hidden", type=int, default=8192)
+    ap.add_argument("--ring", type=int, default=0)
+    ap.add_argument("--fast", action="store_true")
+    ap.add_argument("--hot", action="store_true", help="same layer every launch")
+    ap.add_argument("--kernel", default="mfma", choices=["mfma", "valu"])
+    ap.add_argument("--out", default="")
+    a = ap.parse_args()
+    os.environ["VPTQ_K256_KERNEL"] = a.kernel
+    dev = torch.device("cuda", 0)
+    H = a.hidden
+    lib = C.CDLL(os.path.join(ROOT, "tools", "_build", "libvptq_hip_trace.so"))
+    res, args = B.EXPORTS["vptq_quant_gemv"]
+    lib.vptq_quant_gemv.restype, lib.vptq_quant_gemv.argtypes = res, args
+    lib.vptq_last_error.restype = C.c_char_p
+    R = a.ring or max(2, (512 << 20) // (H // 8 * H * 2))
+    layers = mb.make_layers(H, R, dev)
+    x = torch.randn(1, 1, H, device=dev, dtype=torch.float16)
+    # workgroup geometry of the kernel traced: (rows per workgroup, waves per workgroup)
+    rows, nw = (4, 16) if a.kernel == "mfma" else ((2 if H // 16 >= 512 else 1), 8)
+    n_wg = (H // 8 + rows - 1) // rows
+    bufs = [torch.zeros(n_wg * nw * 8, dtype=torch.int64, device=dev) for _ in range(R)]
+    descs, keeps = [], []
+    for i, m in enumerate(layers):
+        d, k = module_desc(layers[0] if a.hot else m, prefetch=bufs[i])
+        descs.append(d); keeps.append(k)
+    y = torch.empty(1, 1, H, device=dev, dtype=torch.float16)
+    st = torch.cuda.current_stream().cuda_stream
+    flags = 1 if a.fast else 0
+    for rep in range(3):
+        for i in range(R):
+            rc = lib.vptq_quant_gemv(descs[i], x.data_ptr(), y.data_ptr(), 1, flags, None, 0, st)
+            assert rc == 0, lib.vptq_last_error()
+    torch.cuda.synchronize()
+    out = dict(hidden=H, ring=R, fast=a.fast, hot=a.hot, phases={})
+    mid = R // 2
+    t = bufs[mid].view(n_wg * nw, 8)[:, :6].cpu().double() * 0.01  # us
+    prev_end = bufs[mid - 1].view(n_wg * nw, 8)[:, 5].cpu().double().max().item() * 0.01
+    t0 = t[:, 0].min().item()
+    print(f"{a.kernel} H={H} ring={R} fast={a.fast} hot={a.hot}: previous launch's last wave ended "
+          f"{t0 - prev_end:+.2f} us before this launch's first wave started")
+    for k, name in enumerate(PHASES):
+        v = (t[:, k] - t0)
+        q = [v.min().item(), v.median().item(), v.max().item()]
+        out["phases"][name] = q
+        print(f"  {name:18s} min {q[0]:6.2f}  median {q[1]:6.2f}  max {q[2]:6.2f} us")
+    nxt = bufs[mid + 1].view(n_wg * nw, 8)[:, 0].cpu().double().min().item() * 0.01
+    out["launch_period_us"] = nxt - t0
+    print(f"  next launch's first wave started {nxt - t0:.2f} us after this one's")
+    if a.out:
+        json.dump(out, open(a.out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -14,6 +14,9 @@ namespace vptq {
 typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+typedef short s4_t __attribute__((ext_vector_type(4)));
 
 constexpr int kWave = 64;
 
@@ -73,6 +76,17 @@ struct F16 {
   static __device__ __forceinline__ float fma_hi_h(uint32_t w, uint32_t xpair, int h, float acc) {
     return __builtin_fmaf(hi(w), half_of(xpair, h), acc);
   }
+  // c + lo(a)*lo(b) + hi(a)*hi(b) in fp32: v_dot2_f32_f16
+  static __device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float c) {
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(h2_t, a), __builtin_bit_cast(h2_t, b), c, false);
+  }
+  // 16 independent 4x4x4 products, fp32 accumulate: v_mfma_f32_4x4x4_16b_f16.  Block b =
+  // lanes 4b..4b+3; lane i supplies row i of the first matrix and column i of the second,
+  // and receives column i of the result (register r = row r).
+  static __device__ __forceinline__ f32x4 mfma4(u32x2 a, u32x2 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_4x4x4f16(__builtin_bit_cast(h4_t, a), __builtin_bit_cast(h4_t, b),
+                                              c, 0, 0, 0);
+  }
 };
 
 struct BF16 {
@@ -123,6 +137,13 @@ struct BF16 {
   }
   static __device__ __forceinline__ float fma_hi_h(uint32_t w, uint32_t xpair, int h, float acc) {
     return __builtin_fmaf(hi(w), half_of(xpair, h), acc);
+  }
+  static __device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float c) {
+    return __builtin_fmaf(lo(a), lo(b), __builtin_fmaf(hi(a), hi(b), c));
+  }
+  static __device__ __forceinline__ f32x4 mfma4(u32x2 a, u32x2 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(s4_t, a),
+                                                  __builtin_bit_cast(s4_t, b), c, 0, 0, 0);
   }
 };
 

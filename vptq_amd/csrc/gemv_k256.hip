@@ -31,41 +31,13 @@
 //    gfx950 lane-swap instructions (~2 ops per value instead of 12).
 #include "common.h"
 #include "kernels.h"
+#include "k256.h"
 
 namespace vptq {
 
 constexpr int kThreads = 512;
 constexpr int kWaves = kThreads / 64;
 constexpr int kSweepCols = kThreads * 8;  // columns covered by one sweep of the WG
-constexpr int kMaxGroup = 32;
-constexpr int kTableBytes = 65536;        // 256 rows x 256 B
-constexpr int kScratchOff = kTableBytes;
-
-struct K256Layer {
-  const uint32_t* idx;    // [N, row_words]
-  const uint32_t* cent;   // [256, 8] as 4 dwords per entry
-  const uint32_t* rcent;  // [256, 8]
-  const uint16_t* x;      // [tokens, I]
-  uint16_t* y;            // [tokens, O]
-  const uint16_t* scale;  // [I]
-  const uint16_t* wbias;  // [I]
-  const uint16_t* bias;   // [O] or null
-  const uint16_t* perm;   // [I] or null
-  const char* pf;         // read-ahead range (next layer's indices) or null
-  long long pf_bytes;
-  int N, G, O, row_words;
-  int wg_begin;  // first workgroup id of this layer
-  int pf_chunk;  // read-ahead stride per workgroup in bytes (multiple of 128)
-  int pf_len;    // bytes actually touched per workgroup (<= pf_chunk)
-  int pad_;
-};
-
-struct K256Params {
-  int n_layers;
-  int tokens;
-  K256Layer layer[kMaxGroup];
-};
-
 // both gathers of one element: index byte h*2 -> main entry, byte h*2+1 -> residual
 static __device__ __forceinline__ void gather(uint32_t w, int h, uint32_t baseC, uint32_t baseR,
                                               u32x4& cv, u32x4& rv) {
@@ -81,17 +53,18 @@ static __device__ __forceinline__ void gather(uint32_t w, int h, uint32_t baseC,
 // 16 bytes at base + byte_off: 32-bit zero-extended offset against a wave-uniform base
 // selects the scalar-base addressing form (no 64-bit vector add per load).
 static __device__ __forceinline__ u32x4 ld16(const void* base, uint32_t byte_off) {
-  return *(const u32x4*)((const char*)base + byte_off);
+  return *(const u32x4*)as_global((const char*)base + byte_off);
 }
 
 template <bool PERM>
 static __device__ __forceinline__ u32x4 load8(const uint16_t* __restrict__ p, int col0,
                                               const u32x4& pv) {
   if (!PERM) return ld16(p, (uint32_t)col0 * 2u);
+  const uint16_t* const g = as_global(p);
   u32x4 r;
 #pragma unroll
   for (int q = 0; q < 4; ++q)
-    r[q] = (uint32_t)p[pv[q] & 0xffffu] | ((uint32_t)p[pv[q] >> 16] << 16);
+    r[q] = (uint32_t)g[pv[q] & 0xffffu] | ((uint32_t)g[pv[q] >> 16] << 16);
   return r;
 }
 
@@ -106,14 +79,14 @@ __global__ __launch_bounds__(kThreads, 4) void gemv_k256_kernel(const K256Params
     if ((uint32_t)(uintptr_t)(lds_u8_t*)smem != 0u) __builtin_trap();
   }
 
-  // ---- which layer / row group is this workgroup? (wave-uniform) ----
+  // ---- layer = blockIdx.y, row group = blockIdx.x: every kernel argument sits at an
+  // offset known at wave start, so all scalar loads go out in one batch (a search through
+  // the layer table costs one dependent kernarg round trip per step) ----
+  int tokens;
+  const K256Layer Ly = load_layer_args(tokens);
   const int bid = blockIdx.x;
-  int li = 0;
-  for (int l = 1; l < P.n_layers; ++l)
-    if (bid >= P.layer[l].wg_begin) li = l;
-  const K256Layer& Ly = P.layer[li];
-  const int tokens = P.tokens;
-  const int row0 = (bid - Ly.wg_begin) * ROWS;
+  const int row0 = bid * ROWS;
+  if (row0 >= Ly.N) return;  // grid.x is the largest row-group count of the group
   const int G = Ly.G, N = Ly.N, O = Ly.O;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t* const idx_base = Ly.idx;
@@ -123,13 +96,14 @@ __global__ __launch_bounds__(kThreads, 4) void gemv_k256_kernel(const K256Params
   const uint16_t* const pp = Ly.perm;
   const size_t row_words = (size_t)Ly.row_words;
 
+  K256_STAMP(kWaves, 0, tid);
   // ---- 1. codebook entry for the LDS image: thread t loads entry t.  Both table
   // pointers are read as scalars; the per-thread choice is an offset, so the load
   // does not wait on a vector fetch of the pointer itself. ----
   const char* const cent0 = (const char*)Ly.cent;
   const ptrdiff_t rdelta = (const char*)Ly.rcent - cent0;
   const u32x4 centry =
-      *(const u32x4*)(cent0 + (tid < 256 ? (ptrdiff_t)0 : rdelta) + (size_t)(tid & 255) * 16);
+      *(const u32x4*)as_global(cent0 + (tid < 256 ? (ptrdiff_t)0 : rdelta) + (size_t)(tid & 255) * 16);
 
   float acc[TOK][ROWS][8];
   float accb[TOK];
@@ -180,6 +154,7 @@ __global__ __launch_bounds__(kThreads, 4) void gemv_k256_kernel(const K256Params
 
     // ---- 3. build the LDS codebook image (first iteration only; uniform branch) ----
     if (base == 0) {
+      K256_STAMP(kWaves, 1, tid);
       // thread t owns half a bank row: 8 replicas of its entry.  The replica
       // order is rotated by the lane id so the 8 lanes of a ds_write_b128 group
       // hit 8 different 16-byte slots.
@@ -187,16 +162,19 @@ __global__ __launch_bounds__(kThreads, 4) void gemv_k256_kernel(const K256Params
 #pragma unroll
       for (int q = 0; q < 8; ++q) lds_store16(rowp + (((q + lane) & 7) << 4), centry);
       __syncthreads();
+      K256_STAMP(kWaves, 2, tid);
+#ifndef VPTQ_K256_TRACE
       // read-ahead for the NEXT launch, issued after the image is built (this
       // workgroup's own loads are in flight ahead of it): one word per 128-byte line of
       // this workgroup's share of the range (the rows it will own if the next layer has
       // this layer's shape -> same XCD L2; otherwise the Infinity Cache still helps).
       // Unconditional, address-clamped load; its value is only "used" in a branch that
       // is never taken, so nothing ever waits for it.
-      const long long want = (long long)(bid - Ly.wg_begin) * Ly.pf_chunk + (long long)tid * 128;
+      const long long want = (long long)bid * Ly.pf_chunk + (long long)tid * 128;
       const bool in = tid * 128 < Ly.pf_len && want + 4 <= Ly.pf_bytes;
       const char* pa = in ? Ly.pf + want : (const char*)cent0;
-      pf_word = *(const uint32_t*)pa;
+      pf_word = *(const uint32_t*)as_global(pa);
+#endif
     }
 
     // ---- 4. dequantise + accumulate ----
@@ -272,6 +250,7 @@ __global__ __launch_bounds__(kThreads, 4) void gemv_k256_kernel(const K256Params
     }
   }
 
+  K256_STAMP(kWaves, 3, acc[0][0][0] + acc[0][0][1]);
   // ---- 5. reduce over the workgroup's lanes and store ----
   constexpr int kVals = TOK * ROWS * 8;
   constexpr int kStride = kVals + TOK;  // floats per wave in the scratch area
@@ -296,7 +275,9 @@ __global__ __launch_bounds__(kThreads, 4) void gemv_k256_kernel(const K256Params
       if (lane == 0) red[wave * kStride + kVals + t] = sum;
     }
   }
+  K256_STAMP(kWaves, 4, tid);
   __syncthreads();
+  K256_STAMP(kWaves, 5, tid);
   if (tid < kVals) {
     const int t = tid / (ROWS * 8), rem = tid - t * (ROWS * 8);
     const int row = row0 + (rem >> 3);
@@ -352,7 +333,7 @@ static hipError_t launch_inst(const K256Params& P, int grid, hipStream_t st) {
     if (e != hipSuccess) return e;
     attr_set[dev] = true;
   }
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, st, P);
+  hipLaunchKernelGGL(kern, dim3(grid, P.n_layers), dim3(kThreads), lds, st, P);
   return hipGetLastError();
 }
 
@@ -380,9 +361,25 @@ static hipError_t dispatch(const K256Params& P, int grid, int rows, int tok, boo
   return hipErrorInvalidValue;
 }
 
+// MFMA-accumulate kernel (gemv_k256m.hip) or the VALU kernel above?
+// VPTQ_K256_KERNEL=valu|mfma; default valu (the MFMA kernel ties on one 8192^2 layer,
+// loses on 4096^2: its 128 KiB image allows one workgroup per CU, profiles/r01/).
+static bool use_mfma_kernel(int tok, bool f16, bool fast, int max_cols) {
+  static int forced = -1;
+  if (forced < 0) {
+    const char* e = getenv("VPTQ_K256_KERNEL");
+    forced = !e ? 0 : (e[0] == 'v' ? 1 : e[0] == 'm' ? 2 : 0);
+  }
+  if (forced != 2) return false;
+  return gemv_k256m_supported(tok, f16, fast, max_cols);
+}
+
 const char* gemv_k256_name(const VptqLayerDesc& d, int tokens, int flags) {
-  (void)d; (void)tokens;
-  return (flags & VPTQ_GEMV_FAST_MATH) ? "gemv_k256_kernel<fast>" : "gemv_k256_kernel";
+  const int tok = tokens > 2 ? 4 : tokens;
+  const bool f16 = d.dtype == VPTQ_DTYPE_F16;
+  const bool fast = f16 && tok <= 2 && (flags & VPTQ_GEMV_FAST_MATH);
+  if (use_mfma_kernel(tok, f16, fast, d.group_size)) return fast ? "gemv_k256m_kernel<fast>" : "gemv_k256m_kernel";
+  return fast ? "gemv_k256_kernel<fast>" : "gemv_k256_kernel";
 }
 
 hipError_t launch_gemv_k256(const VptqLayerDesc* descs, int n, const void* const* x,
@@ -395,7 +392,17 @@ hipError_t launch_gemv_k256(const VptqLayerDesc* descs, int n, const void* const
   for (int i = 0; i < n; ++i) total_rows += descs[i].num_indices;
   const int tok = tokens > 2 ? 4 : tokens;
   const bool f16 = descs[0].dtype == VPTQ_DTYPE_F16;
-  const int rows = pick_rows(total_rows, tok, f16);
+  // the folded-arithmetic instantiations exist for 1-2 tokens
+  const bool fast = f16 && tok <= 2 && (flags & VPTQ_GEMV_FAST_MATH);
+  int maxG = 0;
+  bool perm = false;
+  for (int i = 0; i < n; ++i) {
+    maxG = descs[i].group_size > maxG ? descs[i].group_size : maxG;
+    perm = perm || descs[i].perm != nullptr;
+  }
+  const bool mfma = use_mfma_kernel(tok, f16, fast, maxG);
+  const int rows = mfma ? kMRows : pick_rows(total_rows, tok, f16);
+  const int wg_threads = mfma ? 1024 : kThreads;
   int grid = 0;
   for (int i = 0; i < n; ++i) {
     const VptqLayerDesc& d = descs[i];
@@ -413,34 +420,27 @@ hipError_t launch_gemv_k256(const VptqLayerDesc* descs, int n, const void* const
     Ly.G = d.group_size;
     Ly.O = d.out_features;
     Ly.row_words = d.row_words;
-    Ly.wg_begin = grid;
     const int n_wg = (d.num_indices + rows - 1) / rows;
+    Ly.wg_begin = 0;
     Ly.pf = (const char*)d.prefetch;
     Ly.pf_bytes = d.prefetch ? d.prefetch_bytes : 0;
     long long chunk = d.prefetch ? (d.prefetch_bytes + n_wg - 1) / n_wg : 0;
     chunk = (chunk + 127) / 128 * 128;
     Ly.pf_chunk = (int)chunk;
     static int pf_cap = -1;  // VPTQ_PF_BYTES: cap on the bytes each workgroup reads ahead
-    if (pf_cap < 0) { const char* e = getenv("VPTQ_PF_BYTES"); pf_cap = e ? atoi(e) : kThreads * 128; }
+    if (pf_cap < 0) { const char* e = getenv("VPTQ_PF_BYTES"); pf_cap = e ? atoi(e) : 1 << 30; }
     long long len = chunk < pf_cap ? chunk : pf_cap;
-    if (len > kThreads * 128) len = kThreads * 128;  // one line per thread
+    if (len > wg_threads * 128) len = wg_threads * 128;  // one line per thread
     Ly.pf_len = (int)len;
     Ly.pad_ = 0;
-    grid += n_wg;
+    grid = n_wg > grid ? n_wg : grid;  // grid.x; grid.y = layer
   }
-  // the folded-arithmetic instantiations exist for 1-2 tokens
-  const bool fast = f16 && tok <= 2 && (flags & VPTQ_GEMV_FAST_MATH);
   // all layers of a group share one instantiation: widest column count decides the
   // sweeps per iteration, any permutation selects the gather variant (grouped layers
   // must agree on it, checked by the caller)
-  int maxG = 0;
-  bool perm = false;
-  for (int i = 0; i < n; ++i) {
-    maxG = descs[i].group_size > maxG ? descs[i].group_size : maxG;
-    perm = perm || descs[i].perm != nullptr;
-  }
   // two sweeps per iteration keep more loads in flight, but the 4-token instantiation
   // only stays spill-free with one
+  if (mfma) return launch_gemv_k256m(P, grid, tok, f16, fast, maxG, perm, st);
   const int sw = (maxG > kSweepCols && tok != 4) ? 2 : 1;
   return f16 ? dispatch<F16, true>(P, grid, rows, tok, fast, sw, perm, st)
              : dispatch<BF16, false>(P, grid, rows, tok, false, sw, perm, st);
