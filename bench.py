@@ -122,6 +122,22 @@ def cpu_baseline(layer, x, y_gpu, H):
     return base, rel
 
 
+def compute_floor(kname, H):
+    """What bounds the kernel besides HBM (tools/ubench.hip, tools/ubench_lds.hip on MI355X):
+    per launch of one HxH layer, with every CU busy."""
+    n_idx = (H // 8) * H                       # index pairs = weight vectors of 8
+    if kname.startswith("gemv_k256m"):
+        # 2 ds_read_b128 gathers per index, 5.1 LDS cycles per wave-instruction per CU, 256 CUs
+        cyc = n_idx * 2 / 64 / 256 * 5.1
+        return {"what": "LDS gather throughput: 2 x ds_read_b128 per index at 5.1 LDS cycles per "
+                        "wave-instruction and CU (conflict-free 16-replica image)",
+                "us_per_launch_at_2.1GHz": cyc / 2100.0}
+    instr = 14 if "fast" in kname else 22
+    return {"what": f"VALU issue: {instr} instructions per index, 2.25 ns per wave-instruction per "
+                    "SIMD at 4 waves/SIMD (1024 SIMDs)",
+            "us_per_launch": n_idx * instr / (1024 * 64) * 2.25e-3}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -131,8 +147,11 @@ def main():
     ap.add_argument("--ring", type=int, default=0)
     ap.add_argument("--mode", choices=["single", "grouped", "tp"], default="single")
     ap.add_argument("--group", type=int, default=4)
-    ap.add_argument("--fast-math", action="store_true",
-                    help="folded fp32 arithmetic (VPTQ_GEMV_FAST_MATH); not the default path")
+    ap.add_argument("--exact", action="store_true",
+                    help="VPTQ_GEMV_EXACT: rebuild every weight with the reference CPU path's three "
+                         "16-bit roundings (bit-identical weights) instead of the default folded "
+                         "fp32 form (both are inside the 1e-3 parity bar, checked below)")
+    ap.add_argument("--fast-math", action="store_true", help="accepted, no effect: the default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prefetch", action="store_true",
                     help="let layer i read layer i+1's indices ahead (chain_prefetch).  Measured: "
@@ -177,7 +196,7 @@ def main():
         d, k = module_desc(m, prefetch=nxt)
         descs.append(d)
         keeps.append(k)
-    flags = B.GEMV_FAST_MATH if a.fast_math else 0
+    flags = B.GEMV_EXACT if a.exact else 0
     kname = lib.vptq_quant_gemv_kernel_name(descs[0], 1, flags).decode()
 
     stream = torch.cuda.Stream(device=dev)
@@ -274,7 +293,9 @@ def main():
                                f"ring of {R} distinct layers per GPU ({R * idx_bytes >> 20} MiB of "
                                f"packed indices), 1 step = 1 pass over the ring",
                    "hidden": H, "ring": R, "mode": a.mode, "launches_per_step": launches_per_step,
-                   "kernel": kname, "arithmetic": "fast_math" if a.fast_math else "reference-rounding",
+                   "kernel": kname,
+                   "arithmetic": "reference roundings per weight (VPTQ_GEMV_EXACT), fp32 accumulate"
+                                 if a.exact else "folded fp32 (default): sum (c+r)*f16(s*x) + sum b*x",
                    "read_ahead_next_layer": bool(a.prefetch),
                    "hipgraph": captured,
                    "parallelism": (f"tp{world}: output rows of every layer split over {world} ranks, "
@@ -284,14 +305,13 @@ def main():
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                      "bytes_per_launch": bytes_per_launch, "us_per_launch": us_per_launch,
                      "note": "us_per_launch = HIP-event time over the timed region / launches "
-                             "(includes inter-kernel gaps); kernel is VALU-issue bound, see DESIGN.md §4",
-                     "valu": {"instr_per_index_pair": 14 if a.fast_math else 22,
-                              "ns_per_instr_per_simd_at_4_waves": 2.25,
-                              "floor_us_per_launch": (H // 8) * H * (14 if a.fast_math else 22)
-                              / (1024 * 64) * 2.25e-3}},
+                             "(includes the ~1.8 us inter-kernel gap); the kernels are bound by "
+                             "instruction issue / LDS gathers, not by HBM: see compute_floor and "
+                             "DESIGN.md §4",
+                     "compute_floor": compute_floor(kname, H)},
     }
     pmc = os.path.join(ROOT, "profiles", "r01", f"bench_h{H}_{a.mode}_pmc_summary.json")
-    if os.path.exists(pmc) and not a.fast_math and not a.prefetch:
+    if os.path.exists(pmc) and not a.exact and not a.prefetch:
         # HBM bytes per launch from a separate rocprofv3 --pmc run of this same command
         # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); see the file's _note
         out["roofline"]["traffic"] = json.load(open(pmc)).get("hbm_bytes_corrected")

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define VPTQ_ABI_VERSION 2
+#define VPTQ_ABI_VERSION 3
 
 #if defined(__GNUC__)
 #define VPTQ_API __attribute__((visibility("default")))
@@ -61,13 +61,24 @@ enum {
 
 /* flags for vptq_quant_gemv / vptq_quant_gemv_v2 */
 enum {
-  /* Default arithmetic reproduces the reference CPU path's roundings: every
-   * weight is rebuilt as r16(r16(r16(c+r)*scale)+bias) in the 16-bit type, then
-   * x*w is accumulated in fp32 and rounded once.  FAST_MATH folds scale/bias
-   * into fp32 (fewer VALU ops, <=1e-3 max-normalised, not bit-equivalent). */
+  /* Default arithmetic of the fused GEMV (ABI >= 3), where a kernel implements it (the
+   * canonical fp16 v=8 / 256+256 format, 1-2 tokens): the folded form
+   *   y = sum_g (c + r) * (scale_g * x_g) + sum_g bias_g * x_g + bias,   fp32 accumulate,
+   * inside the parity bar of <= 1e-3 (max-normalised) against the reference CPU path, but
+   * its weights are not rounded to 16 bits step by step.  FAST_MATH asks for it explicitly
+   * (what ABI 2 required); it is accepted and changes nothing. */
   VPTQ_GEMV_FAST_MATH = 1 << 0,
   /* force the generic kernel (testing / A-B) */
-  VPTQ_GEMV_FORCE_GENERIC = 1 << 1
+  VPTQ_GEMV_FORCE_GENERIC = 1 << 1,
+  /* Reproduce the reference CPU path's roundings: every weight is rebuilt as
+   * r16(r16(r16(c+r)*scale)+bias) in the 16-bit type (bit-identical to vptq_dequant and to
+   * the reference's torch path), then x*w is accumulated in fp32 and rounded once.  All
+   * other kernels (bf16, other formats, 3+ tokens) always work this way. */
+  VPTQ_GEMV_EXACT = 1 << 2,
+  /* canonical format only: pick the persistent MFMA kernel wherever it is instantiated /
+   * never pick it (testing / A-B; the default chooses by launch size) */
+  VPTQ_GEMV_FORCE_MFMA = 1 << 3,
+  VPTQ_GEMV_FORCE_VALU = 1 << 4
 };
 
 #define VPTQ_GEMV_MAX_TOKENS 8

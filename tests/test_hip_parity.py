@@ -6,6 +6,7 @@ measured as max|d| / max|ref| for fp16 (1 fp16 ulp ~ 4.9e-4); bf16 has 8 bits of
 mantissa (ulp 3.9e-3) so its bar is 8e-3.  Dequantised weights are bit-exact.
 """
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -18,7 +19,14 @@ from _gpu_util import (spec_to_module, bits_to_tensor, tensor_to_bits, gemv_abi,
 
 pytestmark = pytest.mark.gpu
 TOL = {"f16": 1e-3, "bf16": 8e-3}
-FAST, GENERIC = 1, 2
+FAST, GENERIC, EXACT, MFMA, VALU = 1, 2, 4, 8, 16
+
+
+def expect_kernel(m, tokens, flags, name):
+    """the library's kernel choice - unless VPTQ_K256_KERNEL pins it for an A/B run"""
+    if os.environ.get("VPTQ_K256_KERNEL"):
+        return
+    assert kernel_name(m, tokens, flags) == name, (kernel_name(m, tokens, flags), name)
 
 
 @pytest.fixture(scope="module")
@@ -61,7 +69,7 @@ def test_canonical_layers_take_the_specialised_kernel(name, dev):
     assert kernel_name(m, cfg["tokens"]).startswith("gemv_k256")
     assert kernel_name(m, cfg["tokens"], GENERIC) == "gemv_generic_kernel"
     xt = bits_to_tensor(x, cfg["dtype"], dev).reshape(x.shape)
-    a = tensor_to_bits(gemv_abi(m, xt, 0))
+    a = tensor_to_bits(gemv_abi(m, xt, EXACT))
     b = tensor_to_bits(gemv_abi(m, xt, GENERIC))
     # both rebuild identical weights; only the fp32 summation order differs
     assert rel_err(a, b, cfg["dtype"]) <= TOL[cfg["dtype"]] / 2
@@ -130,7 +138,9 @@ def test_token_counts_gemv_and_gemm_paths(tokens, dev):
     assert rel_err(got, want, "f16") <= 1e-3
 
 
-def test_fast_math_flag_within_tolerance(dev):
+def test_default_and_exact_arithmetic(dev):
+    """flags = 0 is the folded fp32 form (inside the 1e-3 bar); VPTQ_GEMV_EXACT rebuilds the
+    reference's rounded weights (almost every output bit-identical to the oracle)."""
     for dist in ("ref-test", "llm"):
         L = vo.make_layer(4096, 512, dist=dist, seed=3)
         x = vo.from_f32((np.random.default_rng(1).standard_normal((1, 1, 4096)) *
@@ -138,11 +148,76 @@ def test_fast_math_flag_within_tolerance(dev):
         m = spec_to_module(L, dev)
         xt = bits_to_tensor(x, "f16", dev).reshape(x.shape)
         want = vo.forward(L, x)
-        exact = tensor_to_bits(gemv_abi(m, xt, 0))
-        fast = tensor_to_bits(gemv_abi(m, xt, FAST))
+        expect_kernel(m, 1, 0, "gemv_k256_kernel<fast>")
+        expect_kernel(m, 1, EXACT, "gemv_k256_kernel")
+        exact = tensor_to_bits(gemv_abi(m, xt, EXACT))
+        dflt = tensor_to_bits(gemv_abi(m, xt, 0))
         assert rel_err(exact, want, "f16") <= 2.5e-4       # rounding-exact weights
-        assert rel_err(fast, want, "f16") <= 1e-3          # folded fp32 form
+        assert rel_err(dflt, want, "f16") <= 1e-3          # folded fp32 form
         assert bit_identical_frac(exact, want) >= 0.95
+        # FAST_MATH (ABI 2's opt-in) = the default now; the module forward uses the default
+        assert (tensor_to_bits(gemv_abi(m, xt, FAST)) == dflt).all()
+        assert (tensor_to_bits(m(xt)) == dflt).all()
+
+
+# I, O, kwargs: the persistent MFMA kernel, forced onto small layers: every sweep count
+# 1..7 (I / 2048), row counts that are no multiple of 4, more row groups than CUs, the input
+# permutation, an output bias
+MFMA_CASES = [
+    (2048, 512, dict()),
+    (1024, 40, dict(bias=True)),                      # 5 vector-rows: a partial row group
+    (4096, 264, dict(dist="llm")),
+    (4104, 64, dict()),                               # 3 sweeps, tail lanes past G
+    (8192, 96, dict(dist="llm")),
+    (8192 + 512, 40, dict(dist="llm")),               # 5 sweeps, two staging blocks
+    (11008, 64, dict(dist="llm")),
+    (14336, 72, dict(dist="llm", bias=True)),         # 7 sweeps: the widest layer it takes
+    (1024, 8 * 4 * 300, dict(dist="llm")),            # 300 row groups on 256 CUs
+    (2048, 520, dict(enable_perm=True, bias=True)),
+    (8192 + 8, 136, dict(enable_perm=True, dist="llm")),
+]
+
+
+@pytest.mark.parametrize("I,O,kw", MFMA_CASES)
+def test_mfma_kernel_vs_oracle(I, O, kw, dev):
+    kw = dict(kw)
+    dist = kw.pop("dist", "ref-test")
+    L = vo.make_layer(I, O, dist=dist, seed=I + O, **kw)
+    rng = np.random.default_rng(6)
+    xs = (0.02 + 0.5 * rng.standard_normal((1, 1, I))) if dist == "ref-test" \
+        else rng.standard_normal((1, 1, I))
+    x = vo.from_f32(xs.astype(np.float32), "f16")
+    m = spec_to_module(L, dev)
+    xt = bits_to_tensor(x, "f16", dev).reshape(x.shape)
+    want = vo.forward(L, x)
+    expect_kernel(m, 1, MFMA, "gemv_k256m_kernel<fast>")
+    expect_kernel(m, 1, VALU, "gemv_k256_kernel<fast>")
+    got = tensor_to_bits(gemv_abi(m, xt, MFMA))
+    assert rel_err(got, want, "f16") <= 1e-3
+    # same arithmetic as the VALU kernel up to summation order and one f16 rounding of s * x
+    assert rel_err(got, tensor_to_bits(gemv_abi(m, xt, VALU)), "f16") <= 1e-3
+    if I <= 5 * 2048 and not (2 * 2048 < I <= 3 * 2048):
+        # exact form on the matrix pipe: bit-identical weights, fp32 sums in another order
+        expect_kernel(m, 1, MFMA | EXACT, "gemv_k256m_kernel")
+        ex = tensor_to_bits(gemv_abi(m, xt, MFMA | EXACT))
+        assert rel_err(ex, want, "f16") <= 2.5e-4
+        assert bit_identical_frac(ex, want) >= 0.9
+    else:
+        expect_kernel(m, 1, MFMA | EXACT, "gemv_k256_kernel")
+
+
+def test_mfma_kernel_is_the_default_for_large_launches(dev):
+    """>= 256 row groups of 4 vector-rows (one per CU) with the default arithmetic."""
+    L = vo.make_layer(1024, 8192, dist="llm", seed=77)
+    m = spec_to_module(L, dev)
+    expect_kernel(m, 1, 0, "gemv_k256m_kernel<fast>")
+    expect_kernel(m, 1, EXACT, "gemv_k256_kernel")
+    expect_kernel(m, 2, 0, "gemv_k256_kernel<fast>")          # one token only
+    small = spec_to_module(vo.make_layer(1024, 4096, dist="llm", seed=78), dev)
+    expect_kernel(small, 1, 0, "gemv_k256_kernel<fast>")
+    x = vo.from_f32(np.random.default_rng(3).standard_normal((1, 1, 1024)).astype(np.float32), "f16")
+    got = tensor_to_bits(m(bits_to_tensor(x, "f16", dev).reshape(x.shape)))
+    assert rel_err(got, vo.forward(L, x), "f16") <= 1e-3
 
 
 def test_edge_index_patterns(dev):
@@ -218,7 +293,9 @@ def test_full_size_layers_properties(H, dev):
     assert ((y.float().reshape(-1) - ref).abs().max() / ref.abs().max()).item() <= 1e-3
     # (c) generic kernel
     g = gemv_abi(m, xt, GENERIC)
-    assert ((y.float() - g.float()).abs().max() / ref.abs().max()).item() <= 5e-4
+    assert ((y.float() - g.float()).abs().max() / ref.abs().max()).item() <= 1e-3
+    ye = gemv_abi(m, xt, EXACT)   # same rounded weights as the generic kernel
+    assert ((ye.float() - g.float()).abs().max() / ref.abs().max()).item() <= 5e-4
     # W sub-block bit-exact vs oracle
     Wb = tensor_to_bits(W).reshape(L.num_indices, 8, H)[rows].reshape(48 * 8, H)
     assert (Wb == vo.dequant(sub)).all()

@@ -6,8 +6,8 @@ timeout 600 python bench.py 2>&1 | tail -1 > $OUT/bench_h8192_single.json
 timeout 600 python bench.py --mode grouped --no-cpu-baseline 2>&1 | tail -1 > $OUT/bench_h8192_grouped.json
 timeout 600 python bench.py --hidden 4096 2>&1 | tail -1 > $OUT/bench_h4096_single.json
 timeout 600 python bench.py --hidden 4096 --mode grouped --no-cpu-baseline 2>&1 | tail -1 > $OUT/bench_h4096_grouped.json
-timeout 600 python bench.py --fast-math --no-cpu-baseline 2>&1 | tail -1 > $OUT/bench_h8192_single_fastmath.json
-timeout 600 python bench.py --fast-math --mode grouped --no-cpu-baseline 2>&1 | tail -1 > $OUT/bench_h8192_grouped_fastmath.json
+timeout 600 python bench.py --exact --no-cpu-baseline 2>&1 | tail -1 > $OUT/bench_h8192_single_exact.json
+timeout 600 python bench.py --exact --mode grouped --no-cpu-baseline 2>&1 | tail -1 > $OUT/bench_h8192_grouped_exact.json
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o bench -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2>&1

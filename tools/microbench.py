@@ -44,6 +44,14 @@ def make_layers(H, R, dev, perm=False, k=256, kr=256):
         m.weight_bias.data = (0.01 * torch.randn(H, generator=g, device=dev)).half()
         if perm:
             m.perm.data = torch.randperm(H, generator=g, device=dev).to(torch.int32).to(torch.int16)
+        if os.environ.get("MB_SHARE_META") and layers:
+            # experiment: every layer reads layer 0's codebooks / scale / bias (hot), only the
+            # index streams stay distinct (cold): the ceiling of a metadata read-ahead
+            m0 = layers[0]
+            m.centroids.weight = m0.centroids.weight
+            if kr > 0:
+                m.res_centroids.weight = m0.res_centroids.weight
+            m.weight_scale, m.weight_bias = m0.weight_scale, m0.weight_bias
         layers.append(m)
     return layers
 

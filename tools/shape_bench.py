@@ -28,6 +28,8 @@ def mk(I, O, dev, g):
 
 def main():
     ap = argparse.ArgumentParser(); ap.add_argument("--model", default="70b"); ap.add_argument("--out", default="")
+    ap.add_argument("--flags", type=int, default=0, help="VPTQ_GEMV_* flags (1 = fast math)")
+    ap.add_argument("--tokens", default="1,2,4")
     a = ap.parse_args()
     dev = torch.device("cuda", 0); g = torch.Generator(device=dev).manual_seed(0); lib = B.lib()
     res = []
@@ -36,16 +38,16 @@ def main():
         R = max(2, min(64, (512 << 20) // idx_bytes))
         mods = [mk(I, O, dev, g) for _ in range(R)]
         descs = [module_desc(m) for m in mods]
-        for tokens in (1, 2, 4):
+        for tokens in [int(t) for t in a.tokens.split(',')]:
             x = torch.randn(1, tokens, I, device=dev, dtype=torch.float16)
             ys = [torch.empty(1, tokens, O, device=dev, dtype=torch.float16) for _ in range(R)]
             def run():
                 sp = torch.cuda.current_stream().cuda_stream
                 for (d, k), y in zip(descs, ys):
-                    assert lib.vptq_quant_gemv(d, x.data_ptr(), y.data_ptr(), tokens, 0, None, 0, sp) == 0
+                    assert lib.vptq_quant_gemv(d, x.data_ptr(), y.data_ptr(), tokens, a.flags, None, 0, sp) == 0
             us = time_graph(run, 10) / R
             ab = idx_bytes + 8192 + tokens * 2 * I + 4 * I + tokens * 2 * O
-            res.append(dict(I=I, O=O, tokens=tokens, ring=R, us_per_launch=us, GBps=ab / us / 1e3,
+            res.append(dict(I=I, O=O, tokens=tokens, flags=a.flags, kernel=os.environ.get('VPTQ_K256_KERNEL', 'default'), ring=R, us_per_launch=us, GBps=ab / us / 1e3,
                             frac_hbm=ab / us / 1e3 / 8000))
             print(json.dumps(res[-1]), flush=True)
         del mods, descs

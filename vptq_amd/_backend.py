@@ -17,10 +17,13 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvptq_hip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 DTYPE_F16, DTYPE_BF16 = 0, 1
 GEMV_FAST_MATH = 1 << 0
 GEMV_FORCE_GENERIC = 1 << 1
+GEMV_EXACT = 1 << 2
+GEMV_FORCE_MFMA = 1 << 3
+GEMV_FORCE_VALU = 1 << 4
 GEMV_MAX_TOKENS = 8
 GROUP_MAX = 64
 

@@ -361,24 +361,37 @@ static hipError_t dispatch(const K256Params& P, int grid, int rows, int tok, boo
   return hipErrorInvalidValue;
 }
 
-// MFMA-accumulate kernel (gemv_k256m.hip) or the VALU kernel above?
-// VPTQ_K256_KERNEL=valu|mfma; default valu (the MFMA kernel ties on one 8192^2 layer,
-// loses on 4096^2: its 128 KiB image allows one workgroup per CU, profiles/r01/).
-static bool use_mfma_kernel(int tok, bool f16, bool fast, int max_cols) {
+// Persistent MFMA kernel (gemv_k256m.hip) or the VALU kernel above?  Measured on MI355X
+// (profiles/r01/kernel_ab_*.json): the MFMA kernel wins with the folded arithmetic once the
+// launch has at least one row group (4 vector-rows) per CU - 8192x28672: 22.9 vs 27.4 us,
+// 4096x14336: 9.0 vs 11.3 us, 4 x 8192^2 grouped: 6.9 vs 7.3 us per layer, one 8192^2: a tie -
+// and loses below that (one workgroup per CU leaves CUs idle) and with the exact arithmetic
+// (its 12 rounding ops per index stay on the VALU).  VPTQ_K256_KERNEL=valu|mfma overrides.
+static bool use_mfma_kernel(int tok, bool f16, bool fast, int max_cols, long long row_groups,
+                            int flags) {
   static int forced = -1;
   if (forced < 0) {
     const char* e = getenv("VPTQ_K256_KERNEL");
     forced = !e ? 0 : (e[0] == 'v' ? 1 : e[0] == 'm' ? 2 : 0);
   }
-  if (forced != 2) return false;
-  return gemv_k256m_supported(tok, f16, fast, max_cols);
+  if (forced == 1 || (flags & VPTQ_GEMV_FORCE_VALU) ||
+      !gemv_k256m_supported(tok, f16, fast, max_cols))
+    return false;
+  if (forced == 2 || (flags & VPTQ_GEMV_FORCE_MFMA)) return true;
+  return fast && row_groups >= 256;
+}
+
+static bool wants_fast(bool f16, int tok, int flags) {
+  // the folded-arithmetic instantiations exist for fp16, 1-2 tokens
+  return f16 && tok <= 2 && !(flags & VPTQ_GEMV_EXACT);
 }
 
 const char* gemv_k256_name(const VptqLayerDesc& d, int tokens, int flags) {
   const int tok = tokens > 2 ? 4 : tokens;
   const bool f16 = d.dtype == VPTQ_DTYPE_F16;
-  const bool fast = f16 && tok <= 2 && (flags & VPTQ_GEMV_FAST_MATH);
-  if (use_mfma_kernel(tok, f16, fast, d.group_size)) return fast ? "gemv_k256m_kernel<fast>" : "gemv_k256m_kernel";
+  const bool fast = wants_fast(f16, tok, flags);
+  if (use_mfma_kernel(tok, f16, fast, d.group_size, gemv_k256m_row_groups(d.num_indices), flags))
+    return fast ? "gemv_k256m_kernel<fast>" : "gemv_k256m_kernel";
   return fast ? "gemv_k256_kernel<fast>" : "gemv_k256_kernel";
 }
 
@@ -392,15 +405,19 @@ hipError_t launch_gemv_k256(const VptqLayerDesc* descs, int n, const void* const
   for (int i = 0; i < n; ++i) total_rows += descs[i].num_indices;
   const int tok = tokens > 2 ? 4 : tokens;
   const bool f16 = descs[0].dtype == VPTQ_DTYPE_F16;
-  // the folded-arithmetic instantiations exist for 1-2 tokens
-  const bool fast = f16 && tok <= 2 && (flags & VPTQ_GEMV_FAST_MATH);
+  const bool fast = wants_fast(f16, tok, flags);
   int maxG = 0;
   bool perm = false;
   for (int i = 0; i < n; ++i) {
     maxG = descs[i].group_size > maxG ? descs[i].group_size : maxG;
     perm = perm || descs[i].perm != nullptr;
   }
-  const bool mfma = use_mfma_kernel(tok, f16, fast, maxG);
+  // the persistent MFMA kernel is instantiated per column count: one count per launch
+  bool same_cols = true;
+  for (int i = 1; i < n; ++i) same_cols = same_cols && descs[i].group_size == descs[0].group_size;
+  long long row_groups = 0;
+  for (int i = 0; i < n; ++i) row_groups += gemv_k256m_row_groups(descs[i].num_indices);
+  const bool mfma = same_cols && use_mfma_kernel(tok, f16, fast, maxG, row_groups, flags);
   const int rows = mfma ? kMRows : pick_rows(total_rows, tok, f16);
   const int wg_threads = mfma ? 1024 : kThreads;
   int grid = 0;
@@ -421,7 +438,7 @@ hipError_t launch_gemv_k256(const VptqLayerDesc* descs, int n, const void* const
     Ly.O = d.out_features;
     Ly.row_words = d.row_words;
     const int n_wg = (d.num_indices + rows - 1) / rows;
-    Ly.wg_begin = 0;
+    Ly.wgs = 0;
     Ly.pf = (const char*)d.prefetch;
     Ly.pf_bytes = d.prefetch ? d.prefetch_bytes : 0;
     long long chunk = d.prefetch ? (d.prefetch_bytes + n_wg - 1) / n_wg : 0;
@@ -440,7 +457,7 @@ hipError_t launch_gemv_k256(const VptqLayerDesc* descs, int n, const void* const
   // must agree on it, checked by the caller)
   // two sweeps per iteration keep more loads in flight, but the 4-token instantiation
   // only stays spill-free with one
-  if (mfma) return launch_gemv_k256m(P, grid, tok, f16, fast, maxG, perm, st);
+  if (mfma) return launch_gemv_k256m(P, tok, f16, fast, maxG, perm, st);
   const int sw = (maxG > kSweepCols && tok != 4) ? 2 : 1;
   return f16 ? dispatch<F16, true>(P, grid, rows, tok, fast, sw, perm, st)
              : dispatch<BF16, false>(P, grid, rows, tok, false, sw, perm, st);

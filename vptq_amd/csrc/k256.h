@@ -25,7 +25,7 @@ struct K256Layer {
   const char* pf;         // read-ahead range (next layer's indices) or null
   long long pf_bytes;
   int N, G, O, row_words;
-  int wg_begin;  // unused (layer = blockIdx.y)
+  int wgs;       // gemv_k256m: persistent workgroups walking this layer's row groups
   int pf_chunk;  // read-ahead stride per workgroup in bytes (multiple of 128)
   int pf_len;    // bytes actually touched per workgroup (<= pf_chunk)
   int pad_;
@@ -101,7 +101,8 @@ static __device__ __forceinline__ K256Layer load_layer_args(int& tokens) {
 // gemv_k256m.hip
 constexpr int kMRows = 4;  // vector-rows per workgroup of the MFMA kernel
 bool gemv_k256m_supported(int tok, bool f16, bool fast, int max_cols);
-hipError_t launch_gemv_k256m(const K256Params& P, int grid, int tok, bool f16, bool fast, int max_cols,
-                             bool perm, hipStream_t st);
+int gemv_k256m_row_groups(int n_rows);
+hipError_t launch_gemv_k256m(K256Params& P, int tok, bool f16, bool fast, int max_cols, bool perm,
+                             hipStream_t st);
 
 }  // namespace vptq

@@ -21,12 +21,13 @@ from vptq_amd import _backend as B
 
 __all__ = ["dequant", "quant_gemm", "quant_gemv_v2"]
 
-# env knob: VPTQ_FAST_MATH=1 selects the folded fp32 arithmetic (not bit-equivalent)
-_FLAGS = B.GEMV_FAST_MATH if os.environ.get("VPTQ_FAST_MATH", "0") == "1" else 0
+# env knob: VPTQ_EXACT=1 rebuilds every weight with the reference CPU path's three 16-bit
+# roundings (bit-identical weights) instead of the default folded fp32 form (<= 1e-3)
+_FLAGS = B.GEMV_EXACT if os.environ.get("VPTQ_EXACT", "0") == "1" else 0
 
 
 def quant_gemm_flags() -> int:
-    """flags passed to vptq_quant_gemv by this process (VPTQ_FAST_MATH=1 -> folded arithmetic)"""
+    """flags passed to vptq_quant_gemv by this process (VPTQ_EXACT=1 -> reference roundings)"""
     return _FLAGS
 
 
