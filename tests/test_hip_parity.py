@@ -211,7 +211,7 @@ def test_mfma_kernel_is_the_default_for_large_launches(dev):
     L = vo.make_layer(1024, 8192, dist="llm", seed=77)
     m = spec_to_module(L, dev)
     expect_kernel(m, 1, 0, "gemv_k256m_kernel<fast>")
-    expect_kernel(m, 1, EXACT, "gemv_k256_kernel")
+    expect_kernel(m, 1, EXACT, "gemv_k256m_kernel")
     expect_kernel(m, 2, 0, "gemv_k256_kernel<fast>")          # one token only
     small = spec_to_module(vo.make_layer(1024, 4096, dist="llm", seed=78), dev)
     expect_kernel(small, 1, 0, "gemv_k256_kernel<fast>")

@@ -136,7 +136,10 @@ def main():
                                              torch.cuda.current_stream().cuda_stream)
             assert rc == 0, lib.vptq_last_error()
 
-    variants = (("exact", 0), ("fast", 1), ("generic", 2)) if a.k == 256 else (("exact", 0), ("generic", 2))
+    # VPTQ_GEMV_* flags: 0 = default (folded arithmetic, kernel chosen by launch size),
+    # 4 = EXACT, 8 = FORCE_MFMA, 16 = FORCE_VALU, 2 = FORCE_GENERIC
+    variants = ((("default", 0), ("valu", 16), ("mfma", 8), ("exact", 4), ("exact_mfma", 12), ("generic", 2))
+                if a.k == 256 else (("default", 0), ("generic", 2)))
     for name, flags in variants:
         ring = time_graph(lambda: [launch_one(i, flags) for i in range(R)], a.iters) / R
         hot = time_graph(lambda: [launch_one(0, flags) for _ in range(R)], a.iters) / R

@@ -15,7 +15,8 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvptq_hip.so")
+# VPTQ_HIP_LIB: load another build of the library (A/B runs of tools/)
+LIB_PATH = os.environ.get("VPTQ_HIP_LIB") or os.path.join(_HERE, "libvptq_hip.so")
 
 ABI_VERSION = 3
 DTYPE_F16, DTYPE_BF16 = 0, 1

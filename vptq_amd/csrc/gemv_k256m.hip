@@ -29,9 +29,10 @@
 //  * persistent: one workgroup per CU (the CUs are shared out between the layers of a grouped
 //    launch in proportion to their rows); it builds the image and stages the activations
 //    once, then walks row groups bid, bid + wgs, ... of 4 vector-rows (32
-//    outputs) each.  The packed index words stream through a register queue NS sweeps (one
-//    row group) deep: while sweep s of this row group is consumed, sweep s of the NEXT row
-//    group is requested, so HBM never idles between row groups.  Queue loads and their
+//    outputs) each.  The packed index words stream through a register queue of NS slots (one
+//    row group), D = 2 sweeps in flight: while sweep s is consumed, the sweep D positions
+//    further down the stream - of this row group or the NEXT one - is requested, so HBM
+//    never idles between row groups.  Queue loads and their
 //    s_waitcnt vmcnt(N) are written as inline assembly: vmcnt retires in order, so "all but
 //    the N youngest have landed" is exact here, whereas the compiler - which cannot see
 //    across the loop back-edge - would wait for ALL outstanding loads, i.e. serialise HBM
@@ -90,6 +91,13 @@ __global__ __launch_bounds__(kMThreads) void gemv_k256m_kernel(const K256Params 
     if ((uint32_t)(uintptr_t)(lds_u8_t*)smem != 0u) __builtin_trap();  // absolute LDS addressing
   }
   constexpr int LPS = FAST ? 1 : 3;  // queue loads per sweep (index words [+ scale + bias])
+  // sweeps in flight per wave.  Bandwidth x latency is ~35 KB per CU; 2 sweeps (32 KiB) cover
+  // it, and a deeper queue only backs up the vector-memory pipe: waves then sit in load issue
+  // and reach the prologue barrier microseconds late (tools/trace_k256m.py).
+#ifndef VPTQ_K256M_DEPTH
+#define VPTQ_K256M_DEPTH 2
+#endif
+  constexpr int D = NS < VPTQ_K256M_DEPTH ? NS : VPTQ_K256M_DEPTH;
   constexpr int NQ = FAST ? 1 : NS;  // scale / bias queue slots
 
   // layer = blockIdx.y; all kernel arguments in one batch of scalar loads (k256.h)
@@ -202,13 +210,13 @@ __global__ __launch_bounds__(kMThreads) void gemv_k256m_kernel(const K256Params 
       q_wait<kStageLoads>(centry);
       write_image();
 #pragma unroll
-      for (int s = 0; s < NS; ++s) issue_sweep(s, bid);
+      for (int s = 0; s < D; ++s) issue_sweep(s, bid);
       K256_STAMP(kMWaves, 1, tid);
-      // everything older than the NS * LPS queue loads has landed
+      // everything older than the D * LPS queue loads has landed
 #pragma unroll
       for (int k = 0; k < NST; ++k) {
-        if (FAST) q_wait<NS * LPS>(st_x[k], st_s[k], st_b[k]);
-        else q_wait<NS * LPS>(st_x[k]);
+        if (FAST) q_wait<D * LPS>(st_x[k], st_s[k], st_b[k]);
+        else q_wait<D * LPS>(st_x[k]);
       }
     }
     float accb = 0.f;
@@ -238,7 +246,7 @@ __global__ __launch_bounds__(kMThreads) void gemv_k256m_kernel(const K256Params 
     if (PERM) {
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int s = 0; s < NS; ++s) issue_sweep(s, bid);
+      for (int s = 0; s < D; ++s) issue_sweep(s, bid);
       K256_STAMP(kMWaves, 1, tid);
     }
   }
@@ -336,31 +344,35 @@ __global__ __launch_bounds__(kMThreads) void gemv_k256m_kernel(const K256Params 
 
   int rg = bid;
   bool first = true;
-  // steady state: a next row group exists; its sweep s is requested as soon as slot s is free,
-  // so NS - 1 younger sweeps are always in flight behind the one being consumed
+  // steady state: a next row group exists.  When sweep s is consumed, the sweep D positions
+  // further down the stream (same row group, or the next one) is requested into its slot, so
+  // exactly D - 1 younger sweeps are in flight behind the one being waited for.
   for (; rg + step < n_groups; rg += step) {
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-      if (FAST) q_wait<(NS - 1) * LPS>(iw[s]);
-      else q_wait<(NS - 1) * LPS>(iw[s], s_raw[FAST ? 0 : s], b_raw[FAST ? 0 : s]);
+      if (FAST) q_wait<(D - 1) * LPS>(iw[s]);
+      else q_wait<(D - 1) * LPS>(iw[s], s_raw[FAST ? 0 : s], b_raw[FAST ? 0 : s]);
       sweep(s, acc0, acc1);
-      issue_sweep(s, rg + step);
+      if (s + D < NS) issue_sweep(s + D, rg);
+      else issue_sweep(s + D - NS, rg + step);
     }
     finish(rg, acc0, acc1, first);
     first = false;
   }
   {
-    // last row group of this workgroup: the queue drains (NS - 1 - s younger sweeps; spelled
-    // out per slot because the count must be an immediate)
+    // last row group of this workgroup: the queue drains (min(D - 1, NS - 1 - s) younger
+    // sweeps; spelled out per slot because the count must be an immediate)
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #define K256M_LAST(S)                                                                      \
   if (S < NS) {                                                                            \
-    constexpr int kYounger = (NS - 1 - S > 0 ? NS - 1 - S : 0) * LPS;                       \
+    constexpr int kLeft = NS - 1 - S > 0 ? NS - 1 - S : 0;                                  \
+    constexpr int kYounger = (kLeft < D - 1 ? kLeft : D - 1) * LPS;                         \
     constexpr int kS = S < NS ? S : 0;                                                     \
     if (FAST) q_wait<kYounger>(iw[kS]);                                                    \
     else q_wait<kYounger>(iw[kS], s_raw[FAST ? 0 : kS], b_raw[FAST ? 0 : kS]);             \
     sweep(kS, acc0, acc1);                                                                 \
+    if (S + D < NS) issue_sweep(S + D < NS ? S + D : 0, rg);                                \
   }
     K256M_LAST(0) K256M_LAST(1) K256M_LAST(2) K256M_LAST(3)
     K256M_LAST(4) K256M_LAST(5) K256M_LAST(6)
