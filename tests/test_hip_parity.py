@@ -493,3 +493,65 @@ def test_quant_gemv_v2_reference_test_shapes(cfg, dtype, dev):
     # the reference's own (loose) criterion: rtol = atol = 0.2
     a, b = vo.to_f32(got, dtype), vo.to_f32(want, dtype)
     assert np.allclose(a, b, rtol=0.2, atol=0.2)
+
+
+def test_sibling_groups_share_one_launch(dev):
+    """link_siblings: q/k/v (and gate/up) of a block are computed by the first one called; the
+    others hand out their share for the SAME tensor object and launch on their own otherwise."""
+    import vptq_amd
+
+    class Block(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            mk = lambda O, seed: spec_to_module(vo.make_layer(1024, O, dist="llm", seed=seed), dev)  # noqa: E731
+            self.q_proj, self.k_proj, self.v_proj = mk(1024, 1), mk(256, 2), mk(256, 3)
+            self.gate_proj, self.up_proj = mk(2048, 4), mk(2048, 5)
+            self.o_proj = mk(1024, 6)
+
+    blk = Block()
+    names = ["q_proj", "k_proj", "v_proj", "gate_proj", "up_proj", "o_proj"]
+    x = bits_to_tensor(vo.from_f32(np.random.default_rng(0).standard_normal((1, 1, 1024))
+                                   .astype(np.float32), "f16"), "f16", dev).reshape(1, 1, 1024)
+    x2 = x * 0.5
+    want = {n: getattr(blk, n)(x) for n in names}
+    want2 = {n: getattr(blk, n)(x2) for n in names}
+    assert vptq_amd.layers.link_siblings(blk) == 2
+    assert blk.q_proj._siblings is blk.v_proj._siblings and "_siblings" not in blk.o_proj.__dict__
+    calls = []
+    lib = vptq_amd._backend.lib()
+    real = lib.vptq_quant_gemv_grouped
+    grp = blk.q_proj._siblings
+
+    def same(a, b):   # 1 fp16 ulp of the largest output: 3+ tokens use the exact arithmetic
+        return rel_err(tensor_to_bits(a), tensor_to_bits(b), "f16") <= 1e-3
+
+    # usual order; then another order; then the same member twice; then a different tensor between
+    for order, xs in ((names, [x] * 6), (["v_proj", "q_proj", "k_proj", "up_proj", "gate_proj"], [x] * 5),
+                      (["q_proj", "q_proj", "k_proj"], [x] * 3),
+                      (["q_proj", "k_proj", "v_proj"], [x, x2, x])):
+        for n, xi in zip(order, xs):
+            got = getattr(blk, n)(xi)
+            assert same(got, (want if xi is x else want2)[n]), n
+    # an in-place update of x invalidates what the group still holds
+    xm = x.clone()
+    q = blk.q_proj(xm)
+    xm.mul_(0.5)
+    k = blk.k_proj(xm)
+    assert same(q, want["q_proj"]) and same(k, want2["k_proj"])
+    # 2 tokens through the group, 8 tokens past it
+    xt = torch.cat([x, x2], dim=1)
+    qq, kk = blk.q_proj(xt), blk.k_proj(xt)
+    assert same(qq[:, :1], want["q_proj"]) and same(kk[:, 1:], want2["k_proj"])
+    x8 = x.expand(1, 8, 1024).contiguous()
+    assert same(blk.v_proj(x8)[:, 3:4], want["v_proj"])
+    # under hipGraph capture the members of a group become one kernel node
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            outs = [getattr(blk, n)(x) for n in names]
+        g.replay()
+    torch.cuda.synchronize()
+    for n, o in zip(names, outs):
+        assert same(o, want[n]), n
+    assert grp._x is None or grp._out == {}

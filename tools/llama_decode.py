@@ -100,6 +100,11 @@ def run(args):
         print(f"[stage] {msg}", file=sys.stderr, flush=True)
     stage("build")
     model, cfg, qlayers = build_model(args.layers, dev, perm=args.perm)
+    fused = 0
+    if args.fuse:
+        import vptq
+        fused = vptq.layers.link_siblings(model)
+        stage(f"{fused} sibling groups linked")
     torch.cuda.synchronize()
     stage("built")
     qbytes = sum(m.indices.numel() * 4 for m in qlayers)
@@ -170,7 +175,8 @@ def run(args):
                      + (" +perm" if args.perm else ""),
                quantized_linears=len(qlayers), packed_index_GB=qbytes / 1e9,
                lm_head_GB=lm_head_bytes / 1e9, prompt=args.prompt, new_tokens=args.new,
-               ttft_ms=ttft * 1e3, decode_tok_s_eager=eager_tps, decode_tok_s_hipgraph=graph_tps)
+               ttft_ms=ttft * 1e3, decode_tok_s_eager=eager_tps, decode_tok_s_hipgraph=graph_tps,
+               sibling_groups=fused)
     if isinstance(graph_tps, float):
         res["hipgraph_weight_GBps"] = (qbytes + lm_head_bytes) * graph_tps / 1e9
     print(json.dumps(res))
@@ -185,5 +191,6 @@ if __name__ == "__main__":
     ap.add_argument("--prompt", type=int, default=128)
     ap.add_argument("--new", type=int, default=256)
     ap.add_argument("--perm", action="store_true")
+    ap.add_argument("--fuse", action="store_true", help="link_siblings: q/k/v and gate/up share one grouped launch")
     ap.add_argument("--out", default="")
     run(ap.parse_args())

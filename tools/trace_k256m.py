@@ -33,7 +33,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--hidden", type=int, default=8192)
     ap.add_argument("--ring", type=int, default=0)
-    ap.add_argument("--fast", action="store_true")
+    ap.add_argument("--exact", action="store_true", help="VPTQ_GEMV_EXACT instead of the default arithmetic")
+    ap.add_argument("--fast", action="store_true", help="accepted, no effect: the default")
     ap.add_argument("--hot", action="store_true", help="same layer every launch")
     ap.add_argument("--kernel", default="mfma", choices=["mfma", "valu"])
     ap.add_argument("--out", default="")
@@ -58,18 +59,18 @@ def main():
         descs.append(d); keeps.append(k)
     y = torch.empty(1, 1, H, device=dev, dtype=torch.float16)
     st = torch.cuda.current_stream().cuda_stream
-    flags = 1 if a.fast else 0
+    flags = 4 if a.exact else 0
     for rep in range(3):
         for i in range(R):
             rc = lib.vptq_quant_gemv(descs[i], x.data_ptr(), y.data_ptr(), 1, flags, None, 0, st)
             assert rc == 0, lib.vptq_last_error()
     torch.cuda.synchronize()
-    out = dict(hidden=H, ring=R, fast=a.fast, hot=a.hot, phases={})
+    out = dict(hidden=H, ring=R, exact=a.exact, hot=a.hot, phases={})
     mid = R // 2
     t = bufs[mid].view(n_wg * nw, 8)[:, :6].cpu().double() * 0.01  # us
     prev_end = bufs[mid - 1].view(n_wg * nw, 8)[:, 5].cpu().double().max().item() * 0.01
     t0 = t[:, 0].min().item()
-    print(f"{a.kernel} H={H} ring={R} fast={a.fast} hot={a.hot}: previous launch's last wave ended "
+    print(f"{a.kernel} H={H} ring={R} exact={a.exact} hot={a.hot}: previous launch's last wave ended "
           f"{t0 - prev_end:+.2f} us before this launch's first wave started")
     for k, name in enumerate(PHASES):
         if (t[:, k] == 0).all():

@@ -19,7 +19,7 @@ from typing import Optional
 
 import torch
 
-from vptq_amd.layers.vqlinear import VQuantLinear, chain_prefetch
+from vptq_amd.layers.vqlinear import VQuantLinear, chain_prefetch, link_siblings
 
 
 def make_quant_linear(module: torch.nn.Module, config_for_layers: dict, shared_layer_config: dict,
@@ -61,7 +61,8 @@ class AutoModelForCausalLM:
     @classmethod
     def from_pretrained(cls, pretrained_model_name_or_path: str, *model_args,
                         device: Optional[str] = None, dtype: Optional[torch.dtype] = None,
-                        link_prefetch: bool = False, absorb_perm: bool = False, **kwargs):
+                        link_prefetch: bool = False, absorb_perm: bool = False,
+                        fuse_siblings: bool = False, **kwargs):
         import transformers
         from safetensors.torch import load_file
 
@@ -114,6 +115,9 @@ class AutoModelForCausalLM:
             # no per-token activation gather; what the reference's tools/pre_process.py does)
             from vptq_amd.utils.pack import absorb_perm as _absorb
             _absorb(model)
+        if fuse_siblings:
+            # q/k/v and gate/up of a block read the same activation: one grouped launch each
+            link_siblings(model)
         if link_prefetch:
             chain_prefetch([m for m in model.modules() if isinstance(m, VQuantLinear)], circular=True)
         return model.eval()

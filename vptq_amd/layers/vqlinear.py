@@ -42,6 +42,79 @@ def chain_prefetch(layers, circular: bool = False):
     return layers
 
 
+class SiblingGroup:
+    """Layers that are applied to the SAME activation one after the other (q / k / v, gate / up).
+    The first member called with a tensor launches all members in one grouped kernel
+    (`vptq_quant_gemv_grouped`: their workgroups share the launch, the prologue and the HBM
+    stream); the others return their share of that launch when they are called with the very
+    same tensor object (held alive, version checked), and fall back to their own launch
+    otherwise.  Pure scheduling: the arithmetic per layer is that of a single launch."""
+    MAX_TOKENS = 4
+
+    def __init__(self, members):
+        self.members = list(members)
+        self._x = None
+        self._version = -1
+        self._out = {}
+        self._arrays = None
+
+    def forward(self, layer, x, tokens):
+        if self._x is x and x._version == self._version and id(layer) in self._out:
+            y = self._out.pop(id(layer))
+            if not self._out:
+                self._x = None
+            return y
+        xc = layer._check_activation(x)
+        caches = [m._descriptor() for m in self.members]
+        dev = caches[0][3]
+        if any(c[3] != dev for c in caches) or xc.device != dev or \
+                any(m.in_features != layer.in_features for m in self.members):
+            raise RuntimeError("sibling layers must share the device and the input width")
+        key = tuple(id(c[1]) for c in caches)
+        if self._arrays is None or self._arrays[0] != key:
+            import ctypes as C
+            n = len(caches)
+            self._arrays = (key, (B.LayerDesc * n)(*[c[1] for c in caches]), (C.c_void_p * n)(),
+                            (C.c_void_p * n)(), B.lib().vptq_quant_gemv_grouped)
+        _, descs, xp, yp, fn = self._arrays
+        ys = [torch.empty(xc.shape[:-1] + (m.out_features,), dtype=xc.dtype, device=dev)
+              for m in self.members]
+        for i, y in enumerate(ys):
+            xp[i] = xc.data_ptr()
+            yp[i] = y.data_ptr()
+        with torch.cuda.device(dev):
+            rc = fn(descs, len(ys), xp, yp, tokens, ops.quant_gemm_flags(),
+                    torch.cuda.current_stream(dev).cuda_stream)
+        if rc:
+            B.check(rc, "vptq_quant_gemv_grouped")
+        self._x, self._version = x, x._version
+        self._keep_x = xc
+        self._out = {id(m): y for m, y in zip(self.members, ys) if m is not layer}
+        return ys[self.members.index(layer)]
+
+
+SIBLING_PATTERNS = (("q_proj", "k_proj", "v_proj"), ("gate_proj", "up_proj"))
+
+
+def link_siblings(model: nn.Module, patterns=SIBLING_PATTERNS) -> int:
+    """Find, under every sub-module of `model`, children named like one of `patterns` that are all
+    `VQuantLinear` layers of the same input width and dtype, and make each set a
+    `SiblingGroup`.  Returns the number of groups.  Decode-time optimisation (1-4 tokens)."""
+    n = 0
+    for parent in model.modules():
+        for names in patterns:
+            kids = [getattr(parent, nm, None) for nm in names]
+            if not all(isinstance(k, VQuantLinear) for k in kids):
+                continue
+            if len({(k.in_features, k.centroids.weight.dtype) for k in kids}) != 1:
+                continue
+            group = SiblingGroup(kids)
+            for k in kids:
+                object.__setattr__(k, "_siblings", group)
+            n += 1
+    return n
+
+
 class VQuantLinear(nn.Module):
     def __init__(
         self,
@@ -189,18 +262,11 @@ class VQuantLinear(nn.Module):
             prefetch=None if self._prefetch_next is None else self._prefetch_next.indices,
         )
 
-    def _gemv_cached(self, x: torch.Tensor, tokens: int) -> torch.Tensor:
-        """Decode fast path: identical to `ops.quant_gemm` for 1..8 tokens, but the C-ABI
-        descriptor (and the derived state it points at) is built once per layer and reused
-        while the parameter storages stay the same — building it costs ~25 us of Python per
-        call, several times the kernel itself."""
-        if x.shape[-1] != self.in_features:
-            raise RuntimeError(f"x has {x.shape[-1]} features, layer expects {self.in_features}")
+    def _descriptor(self):
+        """(desc, device, keep-alive): the C-ABI descriptor of this layer, built once and reused
+        while the parameter storages stay the same (building it costs ~25 us of Python per call,
+        several times the kernel itself)."""
         cw = self.centroids.weight
-        if x.dtype != cw.dtype:
-            raise RuntimeError(f"activation dtype {x.dtype} != weight dtype {cw.dtype}")
-        if not x.is_contiguous():
-            x = x.contiguous()
         nxt = self._prefetch_next
         tensors = (self.indices, cw, self.res_centroids.weight if self.enable_residual else None,
                    self.outlier_indices,
@@ -210,7 +276,7 @@ class VQuantLinear(nn.Module):
         key = tuple(0 if t is None else t.data_ptr() for t in tensors)
         cache = self.__dict__.get("_desc_cache")
         if cache is None or cache[0] != key:
-            dev = B.require_device(x, *tensors)
+            dev = B.require_device(*[t for t in tensors if t is not None])
             desc, keep = B.make_layer_desc(
                 indices=tensors[0], centroids=tensors[1], res_centroids=tensors[2],
                 outlier_indices=tensors[3], outlier_centroids=tensors[4], perm=tensors[5],
@@ -225,7 +291,26 @@ class VQuantLinear(nn.Module):
                 num_outlier_centroids=self.num_outlier_centroids, prefetch=tensors[9])
             cache = (key, desc, keep, dev, B.lib().vptq_quant_gemv)
             self.__dict__["_desc_cache"] = cache
-        _, desc, _, dev, fn = cache
+        return cache
+
+    def _check_activation(self, x: torch.Tensor) -> torch.Tensor:
+        if x.shape[-1] != self.in_features:
+            raise RuntimeError(f"x has {x.shape[-1]} features, layer expects {self.in_features}")
+        cw = self.centroids.weight
+        if x.dtype != cw.dtype:
+            raise RuntimeError(f"activation dtype {x.dtype} != weight dtype {cw.dtype}")
+        if not x.is_cuda:
+            raise RuntimeError("vptq_amd has no CPU path: x must be on the GPU")
+        return x if x.is_contiguous() else x.contiguous()
+
+    def _gemv_cached(self, x: torch.Tensor, tokens: int) -> torch.Tensor:
+        """Decode fast path: identical to `ops.quant_gemm` for 1..8 tokens with a cached
+        descriptor; layers linked by `link_siblings` share one grouped launch."""
+        group = self.__dict__.get("_siblings")
+        if group is not None and tokens <= group.MAX_TOKENS:
+            return group.forward(self, x, tokens)
+        x = self._check_activation(x)
+        _, desc, _, dev, fn = self._descriptor()
         if x.device != dev:
             raise RuntimeError(f"tensors on different devices: {dev} vs {x.device}")
         y = torch.empty(x.shape[:-1] + (self.out_features,), dtype=x.dtype, device=dev)
