@@ -49,7 +49,9 @@ constexpr int kMSweepCols = kMWaves * 16 * 8;  // 2048: 16 blocks (column chunks
 constexpr int kMTableBytes = 131072;
 constexpr int kMMaxLds = 163840;   // 160 KiB per CU
 constexpr int kMMaxCols = 14336;   // staged activations must fit beside the image
-constexpr int kMRedBytes = kMWaves * 32 * 4 + kMWaves * 4;
+constexpr int kMRedSlot = kMWaves * 32 * 4;   // one row group's cross-wave partials
+constexpr int kMRedFixed = kMWaves * 4 + 64;  // sum b * x per wave + slot counters
+constexpr int kMMaxSlots = 4;
 
 static __device__ __forceinline__ u32x4 ldg16(const void* base, uint32_t byte_off) {
   return *(const u32x4*)as_global((const char*)base + byte_off);
@@ -97,7 +99,11 @@ __global__ __launch_bounds__(kMThreads) void gemv_k256m_kernel(const K256Params 
 #ifndef VPTQ_K256M_DEPTH
 #define VPTQ_K256M_DEPTH 2
 #endif
-  constexpr int D = NS < VPTQ_K256M_DEPTH ? NS : VPTQ_K256M_DEPTH;
+#ifndef VPTQ_K256M_DEPTH_PROLOGUE
+#define VPTQ_K256M_DEPTH_PROLOGUE 2
+#endif
+  constexpr int D = NS < VPTQ_K256M_DEPTH ? NS : VPTQ_K256M_DEPTH;  // steady state
+  constexpr int DP = D < VPTQ_K256M_DEPTH_PROLOGUE ? D : VPTQ_K256M_DEPTH_PROLOGUE;  // before the barrier
   constexpr int NQ = FAST ? 1 : NS;  // scale / bias queue slots
 
   // layer = blockIdx.y; all kernel arguments in one batch of scalar loads (k256.h)
@@ -131,8 +137,11 @@ __global__ __launch_bounds__(kMThreads) void gemv_k256m_kernel(const K256Params 
   // columns past G) + a 16-byte dump slot | cross-wave scratch
   const uint32_t xs_off = kMTableBytes;
   const uint32_t red_off = xs_off + (uint32_t)G * 2u + 32u;
-  float* const red = (float*)(smem + red_off);  // [kMWaves][32]
-  float* const red_b = red + kMWaves * 32;      // [kMWaves]: sum b * x per wave
+  float* const red_b = (float*)(smem + red_off);        // [kMWaves]: sum b * x per wave
+  uint32_t* const slot_cnt = (uint32_t*)(red_b + kMWaves);   // [kMMaxSlots] waves that have arrived
+  uint32_t* const slot_done = slot_cnt + kMMaxSlots;         // [kMMaxSlots] row groups finished + 1
+  float* const red = (float*)(slot_done + kMMaxSlots + 8);   // [K][kMWaves][32]
+  const int K = Ly.pad_;  // partial-sum slots that fit into LDS (1..kMMaxSlots, host)
 
   // ---- 2. the index queue: slot s holds sweep s (2048 columns x 4 rows, 16 bytes per lane)
   u32x4 iw[NS], s_raw[NQ], b_raw[NQ];
@@ -210,13 +219,13 @@ __global__ __launch_bounds__(kMThreads) void gemv_k256m_kernel(const K256Params 
       q_wait<kStageLoads>(centry);
       write_image();
 #pragma unroll
-      for (int s = 0; s < D; ++s) issue_sweep(s, bid);
+      for (int s = 0; s < DP; ++s) issue_sweep(s, bid);
       K256_STAMP(kMWaves, 1, tid);
-      // everything older than the D * LPS queue loads has landed
+      // everything older than the DP * LPS queue loads has landed
 #pragma unroll
       for (int k = 0; k < NST; ++k) {
-        if (FAST) q_wait<D * LPS>(st_x[k], st_s[k], st_b[k]);
-        else q_wait<D * LPS>(st_x[k]);
+        if (FAST) q_wait<DP * LPS>(st_x[k], st_s[k], st_b[k]);
+        else q_wait<DP * LPS>(st_x[k]);
       }
     }
     float accb = 0.f;
@@ -239,6 +248,7 @@ __global__ __launch_bounds__(kMThreads) void gemv_k256m_kernel(const K256Params 
       lds_store16(xs_off + (uint32_t)(valid ? want : G + 8) * 2u, v);
     }
     if (tid == 0) lds_store16(xs_off + (uint32_t)G * 2u, u32x4{0, 0, 0, 0});
+    if (tid < 2 * kMMaxSlots) slot_cnt[tid] = 0u;
     if (FAST) {
       const float sum = wave_sum(accb);
       if (lane == 0) red_b[wave] = sum;
@@ -246,12 +256,15 @@ __global__ __launch_bounds__(kMThreads) void gemv_k256m_kernel(const K256Params 
     if (PERM) {
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int s = 0; s < D; ++s) issue_sweep(s, bid);
+      for (int s = 0; s < DP; ++s) issue_sweep(s, bid);
       K256_STAMP(kMWaves, 1, tid);
     }
   }
   __syncthreads();
   K256_STAMP(kMWaves, 2, tid);
+  // past the barrier the queue is filled to its steady-state depth
+#pragma unroll
+  for (int s = DP; s < D; ++s) issue_sweep(s, bid);
 
   // ---- 4. row groups ----
   // one sweep: 8 indices per lane (2 gathers each, kAhead indices ahead of the arithmetic)
@@ -301,7 +314,13 @@ __global__ __launch_bounds__(kMThreads) void gemv_k256m_kernel(const K256Params 
   // lane (blk, j) holds 8 partial outputs (t = 0..7) of vector-row j.  Lane bits 5 and 4 by
   // swap-and-add (halving the values carried), bits 3 and 2 by DPP row rotations, which keep
   // lane & 3: afterwards lane l holds outputs 4*bit5 + 2*bit4 + {0, 1} of row l & 3.
-  auto finish = [&](int rg, const f32x4& acc0, const f32x4& acc1, bool first) {
+  // Across the waves WITHOUT a barrier: a barrier per row group makes every wave wait for the
+  // slowest one, and the SIMDs serve their waves oldest-first, so the waves of a workgroup
+  // finish a row group more than a microsecond apart.  Instead each wave drops its 32 partials
+  // into slot q % K (q = how many row groups this workgroup has finished) and bumps the slot's
+  // LDS counter; the wave that arrives last sums the 16 x 32 partials, stores the 32 outputs
+  // and releases the slot.  A wave only waits when it is K row groups ahead of the slowest.
+  auto finish = [&](int rg, int q, const f32x4& acc0, const f32x4& acc1) {
     float v[8];
 #pragma unroll
     for (int i = 0; i < 4; ++i) { v[i] = acc0[i]; v[4 + i] = acc1[i]; }
@@ -319,31 +338,49 @@ __global__ __launch_bounds__(kMThreads) void gemv_k256m_kernel(const K256Params 
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) v[i] = row_ror_add<4>(row_ror_add<8>(v[i]));
-    if (!first) __syncthreads();  // the previous row group's sums have been read
+    const int slot = q % K;
+    if (q >= K) {
+      // the slot's previous user (row group number q - K of this workgroup) must be stored
+      while (__hip_atomic_load(&slot_done[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <
+             (uint32_t)(q - K + 1))
+        __builtin_amdgcn_s_sleep(2);
+    }
+    float* const rs = red + slot * (kMWaves * 32);
     if ((lane & 12) == 0) {
       const int o8 = ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2;
-      red[wave * 32 + j * 8 + o8] = v[0];
-      red[wave * 32 + j * 8 + o8 + 1] = v[1];
+      rs[wave * 32 + j * 8 + o8] = v[0];
+      rs[wave * 32 + j * 8 + o8 + 1] = v[1];
     }
-    __syncthreads();
-    if (tid < 32) {
-      const int row = rg * kMRows + (tid >> 3);
-      const int o = row * 8 + (tid & 7);
-      float sum = 0.f;
+    uint32_t arrived = 0;
+    if (lane == 0)
+      arrived = __hip_atomic_fetch_add(&slot_cnt[slot], 1u, __ATOMIC_ACQ_REL,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+    arrived = __builtin_amdgcn_readfirstlane(arrived);
+    if (arrived == kMWaves - 1) {  // last wave of this row group: wave-uniform branch
+      if (lane < 32) {
+        const int row = rg * kMRows + (lane >> 3);
+        const int o = row * 8 + (lane & 7);
+        float sum = 0.f;
 #pragma unroll
-      for (int w = 0; w < kMWaves; ++w) {
-        sum += red[w * 32 + tid];
-        if (FAST) sum += red_b[w];
+        for (int w = 0; w < kMWaves; ++w) {
+          sum += rs[w * 32 + lane];
+          if (FAST) sum += red_b[w];
+        }
+        if (row < N && o < O) {
+          if (Ly.bias) sum += DT::to_float(as_global(Ly.bias)[o]);
+          as_global(Ly.y)[o] = DT::from_float(sum);
+        }
       }
-      if (row < N && o < O) {
-        if (Ly.bias) sum += DT::to_float(as_global(Ly.bias)[o]);
-        as_global(Ly.y)[o] = DT::from_float(sum);
+      if (lane == 0) {
+        slot_cnt[slot] = 0u;
+        __hip_atomic_store(&slot_done[slot], (uint32_t)(q + 1), __ATOMIC_RELEASE,
+                           __HIP_MEMORY_SCOPE_WORKGROUP);
       }
     }
   };
 
   int rg = bid;
-  bool first = true;
+  int q = 0;  // row groups this workgroup has finished
   // steady state: a next row group exists.  When sweep s is consumed, the sweep D positions
   // further down the stream (same row group, or the next one) is requested into its slot, so
   // exactly D - 1 younger sweeps are in flight behind the one being waited for.
@@ -357,8 +394,8 @@ __global__ __launch_bounds__(kMThreads) void gemv_k256m_kernel(const K256Params 
       if (s + D < NS) issue_sweep(s + D, rg);
       else issue_sweep(s + D - NS, rg + step);
     }
-    finish(rg, acc0, acc1, first);
-    first = false;
+    finish(rg, q, acc0, acc1);
+    ++q;
   }
   {
     // last row group of this workgroup: the queue drains (min(D - 1, NS - 1 - s) younger
@@ -378,7 +415,7 @@ __global__ __launch_bounds__(kMThreads) void gemv_k256m_kernel(const K256Params 
     K256M_LAST(4) K256M_LAST(5) K256M_LAST(6)
 #undef K256M_LAST
     K256_STAMP(kMWaves, 3, acc0[0] + acc1[0]);
-    finish(rg, acc0, acc1, first);
+    finish(rg, q, acc0, acc1);
     K256_STAMP(kMWaves, 5, tid);
   }
 
@@ -411,8 +448,12 @@ static int device_cus() {
 template <typename DT, int NS, int NST, bool PERM, bool FAST>
 static hipError_t launch_m(const K256Params& P, int gx, int max_cols, hipStream_t st) {
   auto kern = gemv_k256m_kernel<DT, NS, NST, PERM, FAST>;
-  const int lds = kMTableBytes + max_cols * 2 + 32 + kMRedBytes;
-  if (lds > kMMaxLds) return hipErrorInvalidValue;
+  const int fixed = kMTableBytes + max_cols * 2 + 32 + kMRedFixed;
+  int slots = (kMMaxLds - fixed) / kMRedSlot;
+  if (slots < 1) return hipErrorInvalidValue;
+  if (slots > kMMaxSlots) slots = kMMaxSlots;
+  if (slots != P.layer[0].pad_) return hipErrorInvalidValue;  // set by launch_gemv_k256m
+  const int lds = fixed + slots * kMRedSlot;
   static bool attr_set[64] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
@@ -466,6 +507,8 @@ hipError_t launch_gemv_k256m(K256Params& P, int tok, bool f16, bool fast, int ma
     if (share < 1) share = 1;
     if (share > groups) share = groups;
     P.layer[i].wgs = (int)share;
+    int slots = (kMMaxLds - (kMTableBytes + max_cols * 2 + 32 + kMRedFixed)) / kMRedSlot;
+    P.layer[i].pad_ = slots > kMMaxSlots ? kMMaxSlots : slots;
     gx = (int)share > gx ? (int)share : gx;
   }
   return fast ? launch_m_shape<F16, true>(P, gx, perm, max_cols, st)

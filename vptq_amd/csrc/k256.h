@@ -28,7 +28,7 @@ struct K256Layer {
   int wgs;       // gemv_k256m: persistent workgroups walking this layer's row groups
   int pf_chunk;  // read-ahead stride per workgroup in bytes (multiple of 128)
   int pf_len;    // bytes actually touched per workgroup (<= pf_chunk)
-  int pad_;
+  int pad_;      // gemv_k256m: cross-wave partial-sum slots in LDS
 };
 
 struct K256Params {
