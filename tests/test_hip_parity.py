@@ -196,14 +196,12 @@ def test_mfma_kernel_vs_oracle(I, O, kw, dev):
     assert rel_err(got, want, "f16") <= 1e-3
     # same arithmetic as the VALU kernel up to summation order and one f16 rounding of s * x
     assert rel_err(got, tensor_to_bits(gemv_abi(m, xt, VALU)), "f16") <= 1e-3
-    if I <= 5 * 2048 and not (2 * 2048 < I <= 3 * 2048):
-        # exact form on the matrix pipe: bit-identical weights, fp32 sums in another order
-        expect_kernel(m, 1, MFMA | EXACT, "gemv_k256m_kernel")
-        ex = tensor_to_bits(gemv_abi(m, xt, MFMA | EXACT))
-        assert rel_err(ex, want, "f16") <= 2.5e-4
-        assert bit_identical_frac(ex, want) >= 0.9
-    else:
-        expect_kernel(m, 1, MFMA | EXACT, "gemv_k256_kernel")
+    # exact form on the matrix pipe (up to 5 column sweeps): bit-identical weights, fp32 sums
+    # in another order
+    expect_kernel(m, 1, MFMA | EXACT, "gemv_k256m_kernel" if I <= 5 * 2048 else "gemv_k256_kernel")
+    ex = tensor_to_bits(gemv_abi(m, xt, MFMA | EXACT))
+    assert rel_err(ex, want, "f16") <= 2.5e-4
+    assert bit_identical_frac(ex, want) >= 0.9
 
 
 def test_mfma_kernel_is_the_default_for_large_launches(dev):

@@ -32,11 +32,13 @@
 //    outputs) each.  The packed index words stream through a register queue of NS slots (one
 //    row group), D = 2 sweeps in flight: while sweep s is consumed, the sweep D positions
 //    further down the stream - of this row group or the NEXT one - is requested, so HBM
-//    never idles between row groups.  Queue loads and their
-//    s_waitcnt vmcnt(N) are written as inline assembly: vmcnt retires in order, so "all but
-//    the N youngest have landed" is exact here, whereas the compiler - which cannot see
-//    across the loop back-edge - would wait for ALL outstanding loads, i.e. serialise HBM
-//    latency with compute.
+//    never idles between row groups.  Every region between two waits is straight-line code
+//    with a fixed, unconditional set of loads (no predicated load, no LDS-DMA) fenced by
+//    sched_barriers: that is what lets the compiler emit the exact in-order count,
+//    s_waitcnt vmcnt(D - 1), in the steady-state loop; any conditional load or visible LDS-DMA
+//    in flight made it wait for ALL loads, i.e. serialised HBM latency with compute.
+#include <type_traits>
+
 #include "common.h"
 #include "kernels.h"
 #include "k256.h"
@@ -69,20 +71,13 @@ static __device__ __forceinline__ u32x4 ldg8x16(const uint16_t* __restrict__ p, 
   return r;
 }
 
-// queue load: 16 bytes at (wave-uniform base) + (32-bit lane offset), invisible to the
-// compiler's wait-count bookkeeping (see the file comment); paired with q_wait<N>
+// Queue load: 16 bytes at (wave-uniform base) + (32-bit lane offset).  An ordinary load whose
+// wait the compiler places (see the file comment).  A version with inline-assembly loads and
+// hand-written s_waitcnt counts was faster to write and unsafe: nothing stops the register
+// allocator from copying a loaded register between the load and its wait, and the hardware
+// does not interlock - it produced wrong sums on some runs.
 static __device__ __forceinline__ void q_load(u32x4& dst, const void* sbase, uint32_t voff) {
-  asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(dst) : "v"(voff), "s"(sbase) : "memory");
-}
-// wait until at most N vector-memory operations of this wave are outstanding; the registers
-// are tied to the statement so that no use of them can move above it
-template <int N>
-static __device__ __forceinline__ void q_wait(u32x4& a) {
-  asm volatile("s_waitcnt vmcnt(%1)" : "+v"(a) : "n"(N) : "memory");
-}
-template <int N>
-static __device__ __forceinline__ void q_wait(u32x4& a, u32x4& b, u32x4& c) {
-  asm volatile("s_waitcnt vmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(N) : "memory");
+  dst = *(const u32x4*)as_global((const char*)sbase + voff);
 }
 
 template <typename DT, int NS, int NST, bool PERM, bool FAST>
@@ -92,7 +87,6 @@ __global__ __launch_bounds__(kMThreads) void gemv_k256m_kernel(const K256Params 
     typedef __attribute__((address_space(3))) unsigned char lds_u8_t;
     if ((uint32_t)(uintptr_t)(lds_u8_t*)smem != 0u) __builtin_trap();  // absolute LDS addressing
   }
-  constexpr int LPS = FAST ? 1 : 3;  // queue loads per sweep (index words [+ scale + bias])
   // sweeps in flight per wave.  Bandwidth x latency is ~35 KB per CU; 2 sweeps (32 KiB) cover
   // it, and a deeper queue only backs up the vector-memory pipe: waves then sit in load issue
   // and reach the prologue barrier microseconds late (tools/trace_k256m.py).
@@ -176,7 +170,6 @@ __global__ __launch_bounds__(kMThreads) void gemv_k256m_kernel(const K256Params 
   // later.  (An LDS-DMA fill, global_load_lds_dwordx4, was slower still.)
   {
     constexpr int kStageCols = kMThreads * 8;
-    constexpr int kStageLoads = NST * (FAST ? 3 : 1);
     u32x4 st_x[NST], st_s[NST], st_b[NST], centry;
     const char* const c0 = (const char*)Ly.cent;
     const uint32_t cent_off = (uint32_t)((tid >> 1) & 255) * 16u;
@@ -216,17 +209,13 @@ __global__ __launch_bounds__(kMThreads) void gemv_k256m_kernel(const K256Params 
         }
         q_load(st_x[k], Ly.x, off);
       }
-      q_wait<kStageLoads>(centry);
+      __builtin_amdgcn_sched_barrier(0);
       write_image();
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int s = 0; s < DP; ++s) issue_sweep(s, bid);
+      __builtin_amdgcn_sched_barrier(0);
       K256_STAMP(kMWaves, 1, tid);
-      // everything older than the DP * LPS queue loads has landed
-#pragma unroll
-      for (int k = 0; k < NST; ++k) {
-        if (FAST) q_wait<DP * LPS>(st_x[k], st_s[k], st_b[k]);
-        else q_wait<DP * LPS>(st_x[k]);
-      }
     }
     float accb = 0.f;
 #pragma unroll
@@ -260,7 +249,9 @@ __global__ __launch_bounds__(kMThreads) void gemv_k256m_kernel(const K256Params 
       K256_STAMP(kMWaves, 1, tid);
     }
   }
+  __builtin_amdgcn_sched_barrier(0);  // nothing that waits for index words above the barrier
   __syncthreads();
+  __builtin_amdgcn_sched_barrier(0);
   K256_STAMP(kMWaves, 2, tid);
   // past the barrier the queue is filled to its steady-state depth
 #pragma unroll
@@ -268,9 +259,20 @@ __global__ __launch_bounds__(kMThreads) void gemv_k256m_kernel(const K256Params 
 
   // ---- 4. row groups ----
   // one sweep: 8 indices per lane (2 gathers each, kAhead indices ahead of the arithmetic)
-  auto sweep = [&](int s, f32x4& acc0, f32x4& acc1) {
+  // The MFMA x operands depend on the column only, not on the row group: a workgroup that
+  // walks several row groups builds them during the first one (2 v_perm_b32 per index) and
+  // keeps them in registers (16 per sweep) - afterwards an index costs 2 perms + 4 MFMA.
+  // Only while they fit beside the rest (<= 4 sweeps, folded form).
+#ifndef VPTQ_K256M_CACHE_XO
+#define VPTQ_K256M_CACHE_XO 1
+#endif
+  constexpr bool kCacheXo = VPTQ_K256M_CACHE_XO && FAST && NS <= 4;
+  u32x2 xo_cache[kCacheXo ? NS : 1][8];
+  auto sweep = [&](auto first_c, int s, f32x4& acc0, f32x4& acc1) {
+    constexpr bool kBuild = !kCacheXo || decltype(first_c)::value;
     const int want = s * kMSweepCols + (wave * 16 + blk) * 8;
-    const u32x4 xq = lds_load16(xs_off + (uint32_t)(want < G ? want : G) * 2u);  // past G: zeros
+    u32x4 xq = u32x4{0, 0, 0, 0};
+    if (kBuild) xq = lds_load16(xs_off + (uint32_t)(want < G ? want : G) * 2u);  // past G: zeros
     const u32x4 words = iw[s];
     constexpr int kAhead = 3;
     u32x4 cv[kAhead + 1], rv[kAhead + 1];
@@ -289,8 +291,14 @@ __global__ __launch_bounds__(kMThreads) void gemv_k256m_kernel(const K256Params 
       if (u + kAhead < 8) gather(u + kAhead);
       const int q = u >> 1, h = u & 1;
       const u32x4 c = cv[u % (kAhead + 1)], r = rv[u % (kAhead + 1)];
-      const u32x2 xo = {__builtin_amdgcn_perm(xq[q], 0u, selA[h]),
-                        __builtin_amdgcn_perm(xq[q], 0u, selB[h])};
+      u32x2 xo;
+      if (kBuild) {
+        xo = u32x2{__builtin_amdgcn_perm(xq[q], 0u, selA[h]),
+                   __builtin_amdgcn_perm(xq[q], 0u, selB[h])};
+        if (kCacheXo) xo_cache[kCacheXo ? s : 0][u] = xo;
+      } else {
+        xo = xo_cache[kCacheXo ? s : 0][u];
+      }
       if (FAST) {
         acc0 = DT::mfma4(xo, u32x2{c[0], c[1]}, acc0);
         acc1 = DT::mfma4(xo, u32x2{c[2], c[3]}, acc1);
@@ -379,45 +387,42 @@ __global__ __launch_bounds__(kMThreads) void gemv_k256m_kernel(const K256Params 
     }
   };
 
+  // One row group.  LAST = no further row group for this workgroup (the queue drains);
+  // otherwise, when sweep s is consumed, the sweep D positions further down the stream - same
+  // row group or the next one - is requested into its slot, so D - 1 younger sweeps are in
+  // flight behind the one being waited for.  The sched_barriers keep load issue, gathers and
+  // arithmetic in this order (without them the scheduler hoists loads and gathers until the
+  // kernel spills).
+  auto row_group = [&](auto first_c, auto last_c, int rg, int q) {
+    constexpr bool LAST = decltype(last_c)::value;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#define K256M_STEP(S)                                                                          \
+  if constexpr (S < NS) {                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+    sweep(first_c, S, acc0, acc1);                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+    if constexpr (S + D < NS) issue_sweep(S + D, rg);                                          \
+    else if constexpr (!LAST) issue_sweep(S + D - NS, rg + step);                              \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+  }
+    K256M_STEP(0) K256M_STEP(1) K256M_STEP(2) K256M_STEP(3)
+    K256M_STEP(4) K256M_STEP(5) K256M_STEP(6)
+#undef K256M_STEP
+    if (LAST) K256_STAMP(kMWaves, 3, acc0[0] + acc1[0]);
+    finish(rg, q, acc0, acc1);
+  };
+  using yes = std::integral_constant<bool, true>;
+  using no = std::integral_constant<bool, false>;
   int rg = bid;
-  int q = 0;  // row groups this workgroup has finished
-  // steady state: a next row group exists.  When sweep s is consumed, the sweep D positions
-  // further down the stream (same row group, or the next one) is requested into its slot, so
-  // exactly D - 1 younger sweeps are in flight behind the one being waited for.
-  for (; rg + step < n_groups; rg += step) {
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      if (FAST) q_wait<(D - 1) * LPS>(iw[s]);
-      else q_wait<(D - 1) * LPS>(iw[s], s_raw[FAST ? 0 : s], b_raw[FAST ? 0 : s]);
-      sweep(s, acc0, acc1);
-      if (s + D < NS) issue_sweep(s + D, rg);
-      else issue_sweep(s + D - NS, rg + step);
-    }
-    finish(rg, q, acc0, acc1);
-    ++q;
+  if (rg + step >= n_groups) {
+    row_group(yes{}, yes{}, rg, 0);
+  } else {
+    row_group(yes{}, no{}, rg, 0);
+    int q = 1;
+    for (rg += step; rg + step < n_groups; rg += step, ++q) row_group(no{}, no{}, rg, q);
+    row_group(no{}, yes{}, rg, q);
   }
-  {
-    // last row group of this workgroup: the queue drains (min(D - 1, NS - 1 - s) younger
-    // sweeps; spelled out per slot because the count must be an immediate)
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#define K256M_LAST(S)                                                                      \
-  if (S < NS) {                                                                            \
-    constexpr int kLeft = NS - 1 - S > 0 ? NS - 1 - S : 0;                                  \
-    constexpr int kYounger = (kLeft < D - 1 ? kLeft : D - 1) * LPS;                         \
-    constexpr int kS = S < NS ? S : 0;                                                     \
-    if (FAST) q_wait<kYounger>(iw[kS]);                                                    \
-    else q_wait<kYounger>(iw[kS], s_raw[FAST ? 0 : kS], b_raw[FAST ? 0 : kS]);             \
-    sweep(kS, acc0, acc1);                                                                 \
-    if (S + D < NS) issue_sweep(S + D < NS ? S + D : 0, rg);                                \
-  }
-    K256M_LAST(0) K256M_LAST(1) K256M_LAST(2) K256M_LAST(3)
-    K256M_LAST(4) K256M_LAST(5) K256M_LAST(6)
-#undef K256M_LAST
-    K256_STAMP(kMWaves, 3, acc0[0] + acc1[0]);
-    finish(rg, q, acc0, acc1);
-    K256_STAMP(kMWaves, 5, tid);
-  }
+  K256_STAMP(kMWaves, 5, tid);
 
 #ifndef VPTQ_K256_TRACE
   {
@@ -481,9 +486,8 @@ static hipError_t launch_m_shape(const K256Params& P, int gx, bool perm, int max
 }
 
 bool gemv_k256m_supported(int tok, bool f16, bool fast, int max_cols) {
-  const int ns = (max_cols + kMSweepCols - 1) / kMSweepCols;
-  // the exact form queues scale and bias with the index words: 3 and >= 6 sweeps spill
-  if (!fast && (ns == 3 || ns > 5)) return false;
+  // the exact form queues scale and bias with the index words: 6 and 7 sweeps spill
+  if (!fast && max_cols > 5 * kMSweepCols) return false;
   return f16 && tok == 1 && max_cols <= kMMaxCols;
 }
 
