@@ -230,6 +230,7 @@ def main():
                            (C.c_void_p * m)(*[x.data_ptr()] * m),
                            (C.c_void_p * m)(*[t.data_ptr() for t in ys[i0:i0 + m]])))
         launches_per_step = len(chunks)
+        kname = lib.vptq_quant_gemv_grouped_kernel_name(chunks[0][1], chunks[0][0], 1, flags).decode()
 
         def one_pass():
             sp = torch.cuda.current_stream().cuda_stream

@@ -191,6 +191,10 @@ VPTQ_API int vptq_quant_gemv_v2(const VptqV2Desc* desc, const void* x, void* y, 
 /* name of the kernel vptq_quant_gemv would launch for (desc, tokens, flags);
  * static string, for tests / profiles.  NULL if unsupported. */
 VPTQ_API const char* vptq_quant_gemv_kernel_name(const VptqLayerDesc* desc, int tokens, int flags);
+/* same for vptq_quant_gemv_grouped (the kernel choice depends on the whole group); "per-layer"
+ * when the group is not served by one launch */
+VPTQ_API const char* vptq_quant_gemv_grouped_kernel_name(const VptqLayerDesc* descs, int n, int tokens,
+                                                int flags);
 
 #ifdef __cplusplus
 }

@@ -204,6 +204,23 @@ def test_mfma_kernel_vs_oracle(I, O, kw, dev):
     assert bit_identical_frac(ex, want) >= 0.9
 
 
+@pytest.mark.parametrize("I,O", [(8192, 8192), (4096, 14336), (2048, 9600)])
+def test_mfma_kernel_is_deterministic(I, O, dev):
+    """The persistent kernel hands partial sums from wave to wave through LDS counters and streams
+    its index words through a register queue: 25 launches over the same inputs (1 to 4 row
+    groups per workgroup) must give the same bits every time, in both arithmetic forms."""
+    L = vo.make_layer(I, O, dist="llm", seed=I ^ O)
+    m = spec_to_module(L, dev)
+    x = bits_to_tensor(vo.from_f32(np.random.default_rng(9).standard_normal((1, 1, I))
+                                   .astype(np.float32), "f16"), "f16", dev).reshape(1, 1, I)
+    for flags in (MFMA, MFMA | EXACT):
+        first = gemv_abi(m, x, flags)
+        for _ in range(24):
+            assert torch.equal(gemv_abi(m, x, flags), first)
+        ref = gemv_abi(m, x, (flags & EXACT) | VALU)
+        assert rel_err(tensor_to_bits(first), tensor_to_bits(ref), "f16") <= 1e-3
+
+
 def test_mfma_kernel_is_the_default_for_large_launches(dev):
     """>= 256 row groups of 4 vector-rows (one per CU) with the default arithmetic."""
     L = vo.make_layer(1024, 8192, dist="llm", seed=77)

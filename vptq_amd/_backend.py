@@ -64,6 +64,7 @@ EXPORTS = {
     "vptq_dequant": (C.c_int, [C.POINTER(LayerDesc), _vp, _vp]),
     "vptq_quant_gemv_v2": (C.c_int, [C.POINTER(V2Desc), _vp, _vp, C.c_int, C.c_int, _vp]),
     "vptq_quant_gemv_kernel_name": (C.c_char_p, [C.POINTER(LayerDesc), C.c_int, C.c_int]),
+    "vptq_quant_gemv_grouped_kernel_name": (C.c_char_p, [C.POINTER(LayerDesc), C.c_int, C.c_int, C.c_int]),
 }
 
 _lib = None

@@ -102,6 +102,19 @@ const char* vptq_quant_gemv_kernel_name(const VptqLayerDesc* d, int tokens, int 
   return "gemv_generic_kernel";
 }
 
+const char* vptq_quant_gemv_grouped_kernel_name(const VptqLayerDesc* descs, int n, int tokens,
+                                                int flags) {
+  if (!descs || n < 1 || n > 32 || tokens < 1 || tokens > VPTQ_GEMV_MAX_TOKENS) return nullptr;
+  bool one_launch = !(flags & VPTQ_GEMV_FORCE_GENERIC);
+  for (int i = 0; i < n; ++i) {
+    if (validate_layer(&descs[i]) != VPTQ_OK) return nullptr;
+    one_launch = one_launch && descs[i].dtype == descs[0].dtype &&
+                 vptq::gemv_k256_eligible(descs[i], tokens) &&
+                 ((descs[i].perm != nullptr) == (descs[0].perm != nullptr));
+  }
+  return one_launch ? vptq::gemv_k256_group_name(descs, n, tokens, flags) : "per-layer";
+}
+
 int vptq_quant_gemv(const VptqLayerDesc* d, const void* x, void* y, int tokens, int flags,
                     void* workspace, size_t workspace_bytes, void* stream) {
   (void)workspace; (void)workspace_bytes;

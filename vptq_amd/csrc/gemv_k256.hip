@@ -396,6 +396,24 @@ const char* gemv_k256_name(const VptqLayerDesc& d, int tokens, int flags) {
   return fast ? "gemv_k256_kernel<fast>" : "gemv_k256_kernel";
 }
 
+// which kernel one grouped launch of these layers uses (mirrors launch_gemv_k256)
+const char* gemv_k256_group_name(const VptqLayerDesc* descs, int n, int tokens, int flags) {
+  const int tok = tokens > 2 ? 4 : tokens;
+  const bool f16 = descs[0].dtype == VPTQ_DTYPE_F16;
+  const bool fast = wants_fast(f16, tok, flags);
+  int maxG = 0;
+  bool same_cols = true;
+  long long row_groups = 0;
+  for (int i = 0; i < n; ++i) {
+    maxG = descs[i].group_size > maxG ? descs[i].group_size : maxG;
+    same_cols = same_cols && descs[i].group_size == descs[0].group_size;
+    row_groups += gemv_k256m_row_groups(descs[i].num_indices);
+  }
+  if (same_cols && use_mfma_kernel(tok, f16, fast, maxG, row_groups, flags))
+    return fast ? "gemv_k256m_kernel<fast>" : "gemv_k256m_kernel";
+  return fast ? "gemv_k256_kernel<fast>" : "gemv_k256_kernel";
+}
+
 hipError_t launch_gemv_k256(const VptqLayerDesc* descs, int n, const void* const* x,
                             void* const* y, int tokens, int flags, hipStream_t st) {
   if (n < 1 || n > kMaxGroup) return hipErrorInvalidValue;

@@ -14,6 +14,7 @@ hipError_t launch_gemv_generic(const VptqLayerDesc& d, const void* x, void* y, i
 // bank-conflict-free replicated codebooks.
 bool gemv_k256_eligible(const VptqLayerDesc& d, int tokens);
 const char* gemv_k256_name(const VptqLayerDesc& d, int tokens, int flags);
+const char* gemv_k256_group_name(const VptqLayerDesc* descs, int n, int tokens, int flags);
 hipError_t launch_gemv_k256(const VptqLayerDesc* descs, int n, const void* const* x,
                             void* const* y, int tokens, int flags, hipStream_t st);
 
