@@ -200,7 +200,7 @@ def test_mfma_kernel_vs_oracle(I, O, kw, dev):
     # in another order
     expect_kernel(m, 1, MFMA | EXACT, "gemv_k256m_kernel" if I <= 5 * 2048 else "gemv_k256_kernel")
     ex = tensor_to_bits(gemv_abi(m, xt, MFMA | EXACT))
-    assert rel_err(ex, want, "f16") <= 2.5e-4
+    assert rel_err(ex, want, "f16") <= 5e-4      # same weights; a flipped last bit at most
     assert bit_identical_frac(ex, want) >= 0.9
 
 

@@ -468,7 +468,7 @@ hipError_t launch_gemv_k256(const VptqLayerDesc* descs, int n, const void* const
     long long len = chunk < pf_cap ? chunk : pf_cap;
     if (len > wg_threads * 128) len = wg_threads * 128;  // one line per thread
     Ly.pf_len = (int)len;
-    Ly.pad_ = 0;
+    Ly.slots = 0;
     grid = n_wg > grid ? n_wg : grid;  // grid.x; grid.y = layer
   }
   // all layers of a group share one instantiation: widest column count decides the

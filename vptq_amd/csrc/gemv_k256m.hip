@@ -135,7 +135,7 @@ __global__ __launch_bounds__(kMThreads) void gemv_k256m_kernel(const K256Params 
   uint32_t* const slot_cnt = (uint32_t*)(red_b + kMWaves);   // [kMMaxSlots] waves that have arrived
   uint32_t* const slot_done = slot_cnt + kMMaxSlots;         // [kMMaxSlots] row groups finished + 1
   float* const red = (float*)(slot_done + kMMaxSlots + 8);   // [K][kMWaves][32]
-  const int K = Ly.pad_;  // partial-sum slots that fit into LDS (1..kMMaxSlots, host)
+  const int K = Ly.slots;  // partial-sum slots that fit into LDS (1..kMMaxSlots, host)
 
   // ---- 2. the index queue: slot s holds sweep s (2048 columns x 4 rows, 16 bytes per lane)
   u32x4 iw[NS], s_raw[NQ], b_raw[NQ];
@@ -457,7 +457,7 @@ static hipError_t launch_m(const K256Params& P, int gx, int max_cols, hipStream_
   int slots = (kMMaxLds - fixed) / kMRedSlot;
   if (slots < 1) return hipErrorInvalidValue;
   if (slots > kMMaxSlots) slots = kMMaxSlots;
-  if (slots != P.layer[0].pad_) return hipErrorInvalidValue;  // set by launch_gemv_k256m
+  if (slots != P.layer[0].slots) return hipErrorInvalidValue;  // set by launch_gemv_k256m
   const int lds = fixed + slots * kMRedSlot;
   static bool attr_set[64] = {};
   int dev = 0;
@@ -512,7 +512,7 @@ hipError_t launch_gemv_k256m(K256Params& P, int tok, bool f16, bool fast, int ma
     if (share > groups) share = groups;
     P.layer[i].wgs = (int)share;
     int slots = (kMMaxLds - (kMTableBytes + max_cols * 2 + 32 + kMRedFixed)) / kMRedSlot;
-    P.layer[i].pad_ = slots > kMMaxSlots ? kMMaxSlots : slots;
+    P.layer[i].slots = slots > kMMaxSlots ? kMMaxSlots : slots;
     gx = (int)share > gx ? (int)share : gx;
   }
   return fast ? launch_m_shape<F16, true>(P, gx, perm, max_cols, st)

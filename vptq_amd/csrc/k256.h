@@ -28,7 +28,7 @@ struct K256Layer {
   int wgs;       // gemv_k256m: persistent workgroups walking this layer's row groups
   int pf_chunk;  // read-ahead stride per workgroup in bytes (multiple of 128)
   int pf_len;    // bytes actually touched per workgroup (<= pf_chunk)
-  int pad_;      // gemv_k256m: cross-wave partial-sum slots in LDS
+  int slots;      // gemv_k256m: cross-wave partial-sum slots in LDS
 };
 
 struct K256Params {
@@ -37,16 +37,18 @@ struct K256Params {
   K256Layer layer[kMaxGroup];
 };
 
-// This workgroup's layer (blockIdx.y) and the token count, fetched from the kernel-argument
-// segment with ONE batch of scalar loads and one wait.  Left to the compiler, the fields are
-// loaded where they are first used: four dependent kernarg round trips before the first
-// vector load can be issued (measured: 1.3-1.7 us median, tools/trace_k256m.py).
-// the pointers come back as plain integers: tell the compiler they are global (not flat)
+// A pointer that came out of inline assembly or integer arithmetic is "flat" to the compiler
+// (flat_load: slower, and counted in lgkmcnt as well): say that it is global.
 template <typename T>
 static __device__ __forceinline__ T* as_global(T* p) {
   typedef T __attribute__((address_space(1))) global_t;
   return (T*)(global_t*)(uintptr_t)p;
 }
+// This workgroup's layer (blockIdx.y) and the token count, fetched from the kernel-argument
+// segment with ONE batch of scalar loads and one wait (inside the same asm statement, so no
+// register is read before it has landed).  Left to the compiler, the fields are loaded where
+// they are first used: four dependent kernarg round trips before the first vector load can be
+// issued (measured: 1.3-1.7 us median, tools/trace_k256m.py).
 static __device__ __forceinline__ K256Layer load_layer_args(int& tokens) {
   static_assert(sizeof(K256Layer) == 120 && offsetof(K256Params, layer) == 8, "kernarg layout");
   typedef int i16_t __attribute__((ext_vector_type(16)));
