@@ -222,7 +222,8 @@ def test_mfma_kernel_is_deterministic(I, O, dev):
 
 
 def test_mfma_kernel_is_the_default_for_large_launches(dev):
-    """>= 256 row groups of 4 vector-rows (one per CU) with the default arithmetic."""
+    """From 144 row groups of 4 vector-rows on (where the VALU kernel needs a second round of
+    workgroups), in both arithmetic forms, one token."""
     L = vo.make_layer(1024, 8192, dist="llm", seed=77)
     m = spec_to_module(L, dev)
     expect_kernel(m, 1, 0, "gemv_k256m_kernel<fast>")

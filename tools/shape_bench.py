@@ -30,10 +30,13 @@ def main():
     ap = argparse.ArgumentParser(); ap.add_argument("--model", default="70b"); ap.add_argument("--out", default="")
     ap.add_argument("--flags", type=int, default=0, help="VPTQ_GEMV_* flags (1 = fast math)")
     ap.add_argument("--tokens", default="1,2,4")
+    ap.add_argument("--shapes", default="", help="I,O;I,O;... instead of --model")
     a = ap.parse_args()
     dev = torch.device("cuda", 0); g = torch.Generator(device=dev).manual_seed(0); lib = B.lib()
     res = []
-    for I, O in SHAPES[a.model]:
+    shapes = ([tuple(int(v) for v in p.split(',')) for p in a.shapes.split(';')] if a.shapes
+              else SHAPES[a.model])
+    for I, O in shapes:
         idx_bytes = (O // 8) * I * 2
         R = max(2, min(64, (512 << 20) // idx_bytes))
         mods = [mk(I, O, dev, g) for _ in range(R)]

@@ -363,10 +363,12 @@ static hipError_t dispatch(const K256Params& P, int grid, int rows, int tok, boo
 
 // Persistent MFMA kernel (gemv_k256m.hip) or the VALU kernel above?  Measured on MI355X
 // (profiles/r01/kernel_ab_h*.json, shapes_llama3_*.json): the MFMA kernel wins once the launch
-// has at least one row group (4 vector-rows) per CU - one 8192^2 layer 8.2 vs 10.0 us (exact
+// is large enough - one 8192^2 layer 8.2 vs 10.0 us (exact
 // arithmetic 9.4 vs 10.5), 4 x 8192^2 grouped 5.6 vs 7.1 us per layer, 8192x28672 20.6 vs
 // 27.4 us, 4096x14336 8.2 vs 11.3 us - and loses below that (one workgroup per CU leaves CUs
-// idle: 4096^2 5.4 vs 5.0 us).  VPTQ_K256_KERNEL=valu|mfma and the FORCE flags override.
+// idle: 4096^2 5.3 vs 4.9 us).  The crossover sits where the VALU kernel needs a second round of
+// workgroups (more than 512 vector-rows): 8192x5120 (160 row groups) 7.4 vs 9.1 us, 8192x4096
+// (128) 7.3 vs 7.0 us.  VPTQ_K256_KERNEL=valu|mfma and the FORCE flags override.
 static bool use_mfma_kernel(int tok, bool f16, bool fast, int max_cols, long long row_groups,
                             int flags) {
   static int forced = -1;
@@ -379,7 +381,7 @@ static bool use_mfma_kernel(int tok, bool f16, bool fast, int max_cols, long lon
     return false;
   if (forced == 2 || (flags & VPTQ_GEMV_FORCE_MFMA)) return true;
   (void)fast;
-  return row_groups >= 256;
+  return row_groups >= 144;
 }
 
 static bool wants_fast(bool f16, int tok, int flags) {
