@@ -171,7 +171,11 @@ MFMA_CASES = [
     (8192, 96, dict(dist="llm")),
     (8192 + 512, 40, dict(dist="llm")),               # 5 sweeps, two staging blocks
     (11008, 64, dict(dist="llm")),
-    (14336, 72, dict(dist="llm", bias=True)),         # 7 sweeps: the widest layer it takes
+    (14336, 72, dict(dist="llm", bias=True)),         # 7 sweeps: the widest layer staged in LDS
+    (16384, 40, dict(dist="llm")),                    # wider: column blocks, x through the queue
+    (28672, 72, dict(dist="llm", bias=True)),         # Llama-3-70B down_proj width
+    (20480 + 8, 136, dict(dist="llm")),               # last column block almost empty
+    (16384, 32, dict(enable_perm=True)),              # wide + permutation: the VALU kernel
     (1024, 8 * 4 * 300, dict(dist="llm")),            # 300 row groups on 256 CUs
     (2048, 520, dict(enable_perm=True, bias=True)),
     (8192 + 8, 136, dict(enable_perm=True, dist="llm")),
@@ -190,7 +194,8 @@ def test_mfma_kernel_vs_oracle(I, O, kw, dev):
     m = spec_to_module(L, dev)
     xt = bits_to_tensor(x, "f16", dev).reshape(x.shape)
     want = vo.forward(L, x)
-    expect_kernel(m, 1, MFMA, "gemv_k256m_kernel<fast>")
+    wide_perm = I > 14336 and kw.get("enable_perm", False)
+    expect_kernel(m, 1, MFMA, "gemv_k256_kernel<fast>" if wide_perm else "gemv_k256m_kernel<fast>")
     expect_kernel(m, 1, VALU, "gemv_k256_kernel<fast>")
     got = tensor_to_bits(gemv_abi(m, xt, MFMA))
     assert rel_err(got, want, "f16") <= 1e-3
@@ -204,7 +209,7 @@ def test_mfma_kernel_vs_oracle(I, O, kw, dev):
     assert bit_identical_frac(ex, want) >= 0.9
 
 
-@pytest.mark.parametrize("I,O", [(8192, 8192), (4096, 14336), (2048, 9600)])
+@pytest.mark.parametrize("I,O", [(8192, 8192), (4096, 14336), (2048, 9600), (28672, 2048)])
 def test_mfma_kernel_is_deterministic(I, O, dev):
     """The persistent kernel hands partial sums from wave to wave through LDS counters and streams
     its index words through a register queue: 25 launches over the same inputs (1 to 4 row

@@ -369,15 +369,15 @@ static hipError_t dispatch(const K256Params& P, int grid, int rows, int tok, boo
 // idle: 4096^2 5.3 vs 4.9 us).  The crossover sits where the VALU kernel needs a second round of
 // workgroups (more than 512 vector-rows): 8192x5120 (160 row groups) 7.4 vs 9.1 us, 8192x4096
 // (128) 7.3 vs 7.0 us.  VPTQ_K256_KERNEL=valu|mfma and the FORCE flags override.
-static bool use_mfma_kernel(int tok, bool f16, bool fast, int max_cols, long long row_groups,
-                            int flags) {
+static bool use_mfma_kernel(int tok, bool f16, bool fast, int max_cols, bool perm,
+                            long long row_groups, int flags) {
   static int forced = -1;
   if (forced < 0) {
     const char* e = getenv("VPTQ_K256_KERNEL");
     forced = !e ? 0 : (e[0] == 'v' ? 1 : e[0] == 'm' ? 2 : 0);
   }
   if (forced == 1 || (flags & VPTQ_GEMV_FORCE_VALU) ||
-      !gemv_k256m_supported(tok, f16, fast, max_cols))
+      !gemv_k256m_supported(tok, f16, fast, max_cols, perm))
     return false;
   if (forced == 2 || (flags & VPTQ_GEMV_FORCE_MFMA)) return true;
   (void)fast;
@@ -393,7 +393,8 @@ const char* gemv_k256_name(const VptqLayerDesc& d, int tokens, int flags) {
   const int tok = tokens > 2 ? 4 : tokens;
   const bool f16 = d.dtype == VPTQ_DTYPE_F16;
   const bool fast = wants_fast(f16, tok, flags);
-  if (use_mfma_kernel(tok, f16, fast, d.group_size, gemv_k256m_row_groups(d.num_indices), flags))
+  if (use_mfma_kernel(tok, f16, fast, d.group_size, d.perm != nullptr,
+                      gemv_k256m_row_groups(d.num_indices), flags))
     return fast ? "gemv_k256m_kernel<fast>" : "gemv_k256m_kernel";
   return fast ? "gemv_k256_kernel<fast>" : "gemv_k256_kernel";
 }
@@ -411,7 +412,9 @@ const char* gemv_k256_group_name(const VptqLayerDesc* descs, int n, int tokens, 
     same_cols = same_cols && descs[i].group_size == descs[0].group_size;
     row_groups += gemv_k256m_row_groups(descs[i].num_indices);
   }
-  if (same_cols && use_mfma_kernel(tok, f16, fast, maxG, row_groups, flags))
+  bool any_perm = false;
+  for (int i = 0; i < n; ++i) any_perm = any_perm || descs[i].perm != nullptr;
+  if (same_cols && use_mfma_kernel(tok, f16, fast, maxG, any_perm, row_groups, flags))
     return fast ? "gemv_k256m_kernel<fast>" : "gemv_k256m_kernel";
   return fast ? "gemv_k256_kernel<fast>" : "gemv_k256_kernel";
 }
@@ -438,7 +441,7 @@ hipError_t launch_gemv_k256(const VptqLayerDesc* descs, int n, const void* const
   for (int i = 1; i < n; ++i) same_cols = same_cols && descs[i].group_size == descs[0].group_size;
   long long row_groups = 0;
   for (int i = 0; i < n; ++i) row_groups += gemv_k256m_row_groups(descs[i].num_indices);
-  const bool mfma = same_cols && use_mfma_kernel(tok, f16, fast, maxG, row_groups, flags);
+  const bool mfma = same_cols && use_mfma_kernel(tok, f16, fast, maxG, perm, row_groups, flags);
   const int rows = mfma ? kMRows : pick_rows(total_rows, tok, f16);
   const int wg_threads = mfma ? 1024 : kThreads;
   int grid = 0;

@@ -98,7 +98,12 @@ __global__ __launch_bounds__(kMThreads) void gemv_k256m_kernel(const K256Params 
 #endif
   constexpr int D = NS < VPTQ_K256M_DEPTH ? NS : VPTQ_K256M_DEPTH;  // steady state
   constexpr int DP = D < VPTQ_K256M_DEPTH_PROLOGUE ? D : VPTQ_K256M_DEPTH_PROLOGUE;  // before the barrier
-  constexpr int NQ = FAST ? 1 : NS;  // scale / bias queue slots
+  // NST = 0: activations are NOT staged in LDS (more than 14336 columns do not fit beside the
+  // image): the queue carries scale and x next to the index words, a row group is walked in
+  // column blocks of NS sweeps, and the folded form only.
+  constexpr bool STAGE = NST > 0;
+  static_assert(STAGE || FAST, "the unstaged variant exists for the folded arithmetic only");
+  constexpr int NQ = (FAST && STAGE) ? 1 : NS;  // queue slots for scale + (exact: bias | unstaged: x)
 
   // layer = blockIdx.y; all kernel arguments in one batch of scalar loads (k256.h)
   int tokens;
@@ -130,7 +135,7 @@ __global__ __launch_bounds__(kMThreads) void gemv_k256m_kernel(const K256Params 
   // LDS map: [0, 128 KiB) codebook image | G staged activations + 8 zeros (the operand of
   // columns past G) + a 16-byte dump slot | cross-wave scratch
   const uint32_t xs_off = kMTableBytes;
-  const uint32_t red_off = xs_off + (uint32_t)G * 2u + 32u;
+  const uint32_t red_off = xs_off + (STAGE ? (uint32_t)G * 2u + 32u : 0u);
   float* const red_b = (float*)(smem + red_off);        // [kMWaves]: sum b * x per wave
   uint32_t* const slot_cnt = (uint32_t*)(red_b + kMWaves);   // [kMMaxSlots] waves that have arrived
   uint32_t* const slot_done = slot_cnt + kMMaxSlots;         // [kMMaxSlots] row groups finished + 1
@@ -139,22 +144,23 @@ __global__ __launch_bounds__(kMThreads) void gemv_k256m_kernel(const K256Params 
 
   // ---- 2. the index queue: slot s holds sweep s (2048 columns x 4 rows, 16 bytes per lane)
   u32x4 iw[NS], s_raw[NQ], b_raw[NQ];
-  uint32_t col_off[NS];  // byte offset of this lane's 8 columns in a row (clamped)
-#pragma unroll
-  for (int s = 0; s < NS; ++s) {
-    const int want = s * kMSweepCols + (wave * 16 + blk) * 8;
-    col_off[s] = (uint32_t)(want < G ? want : G - 8) * 2u;  // G % 8 == 0 (host check)
-  }
-  auto issue_sweep = [&](int s, int rg) {
-    // rows past N re-read the last row and are not stored
+  const int lane_cols = (wave * 16 + blk) * 8;  // this lane's 8 columns inside a sweep
+  const int n_cblocks = STAGE ? 1 : (G + NS * kMSweepCols - 1) / (NS * kMSweepCols);
+  auto issue_sweep = [&](int s, int rg, int cb) {
+    // rows past N re-read the last row and are not stored; columns past G re-read the last 8
     const int row0 = rg * kMRows;
     const char* const rbase = (const char*)Ly.idx + (size_t)row0 * row_bytes;  // wave-uniform
     const uint32_t roff = (uint32_t)(row0 + j < N ? j : N - 1 - row0) * row_bytes;
+    const int want = (cb * NS + s) * kMSweepCols + lane_cols;
+    const uint32_t coff = (uint32_t)(want < G ? want : G - 8) * 2u;  // G % 8 == 0 (host check)
     if (!FAST) {
-      q_load(s_raw[FAST ? 0 : s], sp, col_off[s]);
-      q_load(b_raw[FAST ? 0 : s], bp, col_off[s]);
+      q_load(s_raw[NQ > 1 ? s : 0], sp, coff);
+      q_load(b_raw[NQ > 1 ? s : 0], bp, coff);
+    } else if (!STAGE) {
+      q_load(s_raw[NQ > 1 ? s : 0], sp, coff);
+      q_load(b_raw[NQ > 1 ? s : 0], Ly.x, coff);
     }
-    q_load(iw[s], rbase, roff + col_off[s]);
+    q_load(iw[s], rbase, roff + coff);
   };
 
   // ---- 3. prologue, once per workgroup.
@@ -170,7 +176,8 @@ __global__ __launch_bounds__(kMThreads) void gemv_k256m_kernel(const K256Params 
   // later.  (An LDS-DMA fill, global_load_lds_dwordx4, was slower still.)
   {
     constexpr int kStageCols = kMThreads * 8;
-    u32x4 st_x[NST], st_s[NST], st_b[NST], centry;
+    constexpr int kSt = NST > 0 ? NST : 1;
+    u32x4 st_x[kSt], st_s[kSt], st_b[kSt], centry;
     const char* const c0 = (const char*)Ly.cent;
     const uint32_t cent_off = (uint32_t)((tid >> 1) & 255) * 16u;
     const uint32_t rowp = ((uint32_t)(tid >> 9) << 16) | ((uint32_t)((tid >> 1) & 255) << 8) |
@@ -213,7 +220,7 @@ __global__ __launch_bounds__(kMThreads) void gemv_k256m_kernel(const K256Params 
       write_image();
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int s = 0; s < DP; ++s) issue_sweep(s, bid);
+      for (int s = 0; s < DP; ++s) issue_sweep(s, bid, 0);
       __builtin_amdgcn_sched_barrier(0);
       K256_STAMP(kMWaves, 1, tid);
     }
@@ -236,7 +243,15 @@ __global__ __launch_bounds__(kMThreads) void gemv_k256m_kernel(const K256Params 
       }
       lds_store16(xs_off + (uint32_t)(valid ? want : G + 8) * 2u, v);
     }
-    if (tid == 0) lds_store16(xs_off + (uint32_t)G * 2u, u32x4{0, 0, 0, 0});
+    if (!STAGE) {
+      // the queue carries x and scale but not the bias: sum b * x in one pass over the columns
+      for (int c = tid * 8; c < G; c += kStageCols) {
+        const u32x4 xv = ldg16(Ly.x, (uint32_t)c * 2u), bv = ldg16(bp, (uint32_t)c * 2u);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) accb = DT::dot2(xv[q], bv[q], accb);
+      }
+    }
+    if (STAGE && tid == 0) lds_store16(xs_off + (uint32_t)G * 2u, u32x4{0, 0, 0, 0});
     if (tid < 2 * kMMaxSlots) slot_cnt[tid] = 0u;
     if (FAST) {
       const float sum = wave_sum(accb);
@@ -245,7 +260,7 @@ __global__ __launch_bounds__(kMThreads) void gemv_k256m_kernel(const K256Params 
     if (PERM) {
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int s = 0; s < DP; ++s) issue_sweep(s, bid);
+      for (int s = 0; s < DP; ++s) issue_sweep(s, bid, 0);
       K256_STAMP(kMWaves, 1, tid);
     }
   }
@@ -255,7 +270,7 @@ __global__ __launch_bounds__(kMThreads) void gemv_k256m_kernel(const K256Params 
   K256_STAMP(kMWaves, 2, tid);
   // past the barrier the queue is filled to its steady-state depth
 #pragma unroll
-  for (int s = DP; s < D; ++s) issue_sweep(s, bid);
+  for (int s = DP; s < D; ++s) issue_sweep(s, bid, 0);
 
   // ---- 4. row groups ----
   // one sweep: 8 indices per lane (2 gathers each, kAhead indices ahead of the arithmetic)
@@ -266,13 +281,20 @@ __global__ __launch_bounds__(kMThreads) void gemv_k256m_kernel(const K256Params 
 #ifndef VPTQ_K256M_CACHE_XO
 #define VPTQ_K256M_CACHE_XO 1
 #endif
-  constexpr bool kCacheXo = VPTQ_K256M_CACHE_XO && FAST && NS <= 4;
+  constexpr bool kCacheXo = VPTQ_K256M_CACHE_XO && FAST && STAGE && NS <= 4;
   u32x2 xo_cache[kCacheXo ? NS : 1][8];
-  auto sweep = [&](auto first_c, int s, f32x4& acc0, f32x4& acc1) {
+  auto sweep = [&](auto first_c, int s, int cb, f32x4& acc0, f32x4& acc1) {
     constexpr bool kBuild = !kCacheXo || decltype(first_c)::value;
-    const int want = s * kMSweepCols + (wave * 16 + blk) * 8;
+    const int want = (cb * NS + s) * kMSweepCols + lane_cols;
     u32x4 xq = u32x4{0, 0, 0, 0};
-    if (kBuild) xq = lds_load16(xs_off + (uint32_t)(want < G ? want : G) * 2u);  // past G: zeros
+    if (STAGE) {
+      if (kBuild) xq = lds_load16(xs_off + (uint32_t)(want < G ? want : G) * 2u);  // past G: zeros
+    } else {
+      const uint32_t keep = want < G ? 0xffffffffu : 0u;  // columns past G contribute 0
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        xq[q] = DT::mul2(b_raw[NQ > 1 ? s : 0][q] & keep, s_raw[NQ > 1 ? s : 0][q]);  // f16(s * x)
+    }
     const u32x4 words = iw[s];
     constexpr int kAhead = 3;
     u32x4 cv[kAhead + 1], rv[kAhead + 1];
@@ -305,7 +327,7 @@ __global__ __launch_bounds__(kMThreads) void gemv_k256m_kernel(const K256Params 
         acc0 = DT::mfma4(xo, u32x2{r[0], r[1]}, acc0);
         acc1 = DT::mfma4(xo, u32x2{r[2], r[3]}, acc1);
       } else {
-        const u32x4 sv = s_raw[FAST ? 0 : s], bv = b_raw[FAST ? 0 : s];
+        const u32x4 sv = s_raw[NQ > 1 ? s : 0], bv = b_raw[NQ > 1 ? s : 0];
         uint32_t w2[4];
 #pragma unroll
         for (int p = 0; p < 4; ++p) w2[p] = DT::add2(c[p], r[p]);
@@ -387,27 +409,36 @@ __global__ __launch_bounds__(kMThreads) void gemv_k256m_kernel(const K256Params 
     }
   };
 
-  // One row group.  LAST = no further row group for this workgroup (the queue drains);
-  // otherwise, when sweep s is consumed, the sweep D positions further down the stream - same
-  // row group or the next one - is requested into its slot, so D - 1 younger sweeps are in
-  // flight behind the one being waited for.  The sched_barriers keep load issue, gathers and
-  // arithmetic in this order (without them the scheduler hoists loads and gathers until the
-  // kernel spills).
-  auto row_group = [&](auto first_c, auto last_c, int rg, int q) {
+  // One row group = n_cblocks column blocks of NS sweeps (one block when the activations are
+  // staged).  LAST = no further row group for this workgroup (the queue drains in its last
+  // block); otherwise, when sweep s is consumed, the sweep D positions further down the
+  // stream - same block, the next block, or the next row group - is requested into its slot,
+  // so D - 1 younger sweeps are in flight behind the one being waited for.  The sched_barriers
+  // keep load issue, gathers and arithmetic in this order (without them the scheduler hoists
+  // loads and gathers until the kernel spills).
+  auto cblock = [&](auto first_c, auto last_c, int rg, int cb, int next_rg, int next_cb, f32x4& acc0,
+                    f32x4& acc1) {
     constexpr bool LAST = decltype(last_c)::value;
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #define K256M_STEP(S)                                                                          \
   if constexpr (S < NS) {                                                                      \
     __builtin_amdgcn_sched_barrier(0);                                                         \
-    sweep(first_c, S, acc0, acc1);                                                             \
+    sweep(first_c, S, cb, acc0, acc1);                                                         \
     __builtin_amdgcn_sched_barrier(0);                                                         \
-    if constexpr (S + D < NS) issue_sweep(S + D, rg);                                          \
-    else if constexpr (!LAST) issue_sweep(S + D - NS, rg + step);                              \
+    if constexpr (S + D < NS) issue_sweep(S + D, rg, cb);                                      \
+    else if constexpr (!LAST) issue_sweep(S + D - NS, next_rg, next_cb);                       \
     __builtin_amdgcn_sched_barrier(0);                                                         \
   }
     K256M_STEP(0) K256M_STEP(1) K256M_STEP(2) K256M_STEP(3)
     K256M_STEP(4) K256M_STEP(5) K256M_STEP(6)
 #undef K256M_STEP
+  };
+  using yes_t = std::integral_constant<bool, true>;
+  using no_t = std::integral_constant<bool, false>;
+  auto row_group = [&](auto first_c, auto last_c, int rg, int q) {
+    constexpr bool LAST = decltype(last_c)::value;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    for (int cb = 0; cb + 1 < n_cblocks; ++cb) cblock(first_c, no_t{}, rg, cb, rg, cb + 1, acc0, acc1);
+    cblock(first_c, last_c, rg, n_cblocks - 1, rg + step, 0, acc0, acc1);
     if (LAST) K256_STAMP(kMWaves, 3, acc0[0] + acc1[0]);
     finish(rg, q, acc0, acc1);
   };
@@ -450,15 +481,20 @@ static int device_cus() {
   return cus[dev];
 }
 
+// LDS bytes before the partial-sum slots: image + staged activations (0 columns: unstaged) +
+// per-wave sum b * x + slot counters
+static int lds_fixed_bytes(int staged_cols) {
+  return kMTableBytes + (staged_cols > 0 ? staged_cols * 2 + 32 : 0) + kMRedFixed;
+}
+
 template <typename DT, int NS, int NST, bool PERM, bool FAST>
 static hipError_t launch_m(const K256Params& P, int gx, int max_cols, hipStream_t st) {
   auto kern = gemv_k256m_kernel<DT, NS, NST, PERM, FAST>;
-  const int fixed = kMTableBytes + max_cols * 2 + 32 + kMRedFixed;
-  int slots = (kMMaxLds - fixed) / kMRedSlot;
-  if (slots < 1) return hipErrorInvalidValue;
-  if (slots > kMMaxSlots) slots = kMMaxSlots;
-  if (slots != P.layer[0].slots) return hipErrorInvalidValue;  // set by launch_gemv_k256m
+  const int fixed = lds_fixed_bytes(NST > 0 ? max_cols : 0);
+  const int slots = P.layer[0].slots;  // set by launch_gemv_k256m
+  if (slots < 1 || slots > kMMaxSlots) return hipErrorInvalidValue;
   const int lds = fixed + slots * kMRedSlot;
+  if (lds > kMMaxLds) return hipErrorInvalidValue;
   static bool attr_set[64] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
@@ -475,6 +511,13 @@ static hipError_t launch_m(const K256Params& P, int gx, int max_cols, hipStream_
 template <typename DT, bool FAST>
 static hipError_t launch_m_shape(const K256Params& P, int gx, bool perm, int max_cols,
                                  hipStream_t st) {
+  if (max_cols > kMMaxCols) {
+    // wider than the LDS can stage: column blocks of 2 sweeps, scale and x through the queue
+    if constexpr (FAST) {
+      if (!perm) return launch_m<DT, 2, 0, false, true>(P, gx, max_cols, st);
+    }
+    return hipErrorInvalidValue;
+  }
   const int ns = (max_cols + kMSweepCols - 1) / kMSweepCols;
 #define K256M_CASE(S, N)                                                          \
   if (ns == S) return perm ? launch_m<DT, S, N, true, FAST>(P, gx, max_cols, st)  \
@@ -485,10 +528,12 @@ static hipError_t launch_m_shape(const K256Params& P, int gx, bool perm, int max
   return hipErrorInvalidValue;
 }
 
-bool gemv_k256m_supported(int tok, bool f16, bool fast, int max_cols) {
+bool gemv_k256m_supported(int tok, bool f16, bool fast, int max_cols, bool perm) {
   // the exact form queues scale and bias with the index words: 6 and 7 sweeps spill
   if (!fast && max_cols > 5 * kMSweepCols) return false;
-  return f16 && tok == 1 && max_cols <= kMMaxCols;
+  // more columns than fit beside the image: unstaged variant (folded form, no permutation)
+  if (max_cols > kMMaxCols && (!fast || perm)) return false;
+  return f16 && tok == 1;
 }
 
 int gemv_k256m_row_groups(int n_rows) { return (n_rows + kMRows - 1) / kMRows; }
@@ -498,7 +543,7 @@ int gemv_k256m_row_groups(int n_rows) { return (n_rows + kMRows - 1) / kMRows; }
 // between the layers in proportion to their row groups.
 hipError_t launch_gemv_k256m(K256Params& P, int tok, bool f16, bool fast, int max_cols, bool perm,
                              hipStream_t st) {
-  if (!gemv_k256m_supported(tok, f16, fast, max_cols)) return hipErrorInvalidValue;
+  if (!gemv_k256m_supported(tok, f16, fast, max_cols, perm)) return hipErrorInvalidValue;
   static int forced_wgs = -1;  // VPTQ_K256M_WGS: tuning override of the CU count
   if (forced_wgs < 0) { const char* e = getenv("VPTQ_K256M_WGS"); forced_wgs = e ? atoi(e) : 0; }
   const int cus = forced_wgs > 0 ? forced_wgs : device_cus();
@@ -511,7 +556,7 @@ hipError_t launch_gemv_k256m(K256Params& P, int tok, bool f16, bool fast, int ma
     if (share < 1) share = 1;
     if (share > groups) share = groups;
     P.layer[i].wgs = (int)share;
-    int slots = (kMMaxLds - (kMTableBytes + max_cols * 2 + 32 + kMRedFixed)) / kMRedSlot;
+    const int slots = (kMMaxLds - lds_fixed_bytes(max_cols > kMMaxCols ? 0 : max_cols)) / kMRedSlot;
     P.layer[i].slots = slots > kMMaxSlots ? kMMaxSlots : slots;
     gx = (int)share > gx ? (int)share : gx;
   }

@@ -102,7 +102,7 @@ static __device__ __forceinline__ K256Layer load_layer_args(int& tokens) {
 
 // gemv_k256m.hip
 constexpr int kMRows = 4;  // vector-rows per workgroup of the MFMA kernel
-bool gemv_k256m_supported(int tok, bool f16, bool fast, int max_cols);
+bool gemv_k256m_supported(int tok, bool f16, bool fast, int max_cols, bool perm);
 int gemv_k256m_row_groups(int n_rows);
 hipError_t launch_gemv_k256m(K256Params& P, int tok, bool f16, bool fast, int max_cols, bool perm,
                              hipStream_t st);
