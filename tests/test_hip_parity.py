@@ -209,7 +209,9 @@ def test_mfma_kernel_vs_oracle(I, O, kw, dev):
     assert bit_identical_frac(ex, want) >= 0.9
 
 
-@pytest.mark.parametrize("I,O", [(8192, 8192), (4096, 14336), (2048, 9600), (28672, 2048)])
+@pytest.mark.parametrize("I,O", [(8192, 8192), (4096, 14336), (2048, 9600), (28672, 2048),
+                                 (1024, 49152),      # 6 row groups per workgroup: slot reuse
+                                 (14336, 12288)])    # one partial-sum slot (K = 1): waves wait
 def test_mfma_kernel_is_deterministic(I, O, dev):
     """The persistent kernel hands partial sums from wave to wave through LDS counters and streams
     its index words through a register queue: 25 launches over the same inputs (1 to 4 row
