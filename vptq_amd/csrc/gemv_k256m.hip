@@ -15,7 +15,7 @@
 //    (layout checked on hardware: tools/mfma_probe.hip).  The four lanes of a block must
 //    share x', so a block is ONE input column of FOUR consecutive vector-rows:
 //    lane = (block = column chunk, j = row).
-//  * folded form (VPTQ_GEMV_FAST_MATH): y = sum_g (c + r) * f16(s_g x_g) + sum_g b_g x_g; the
+//  * folded form (the default arithmetic): y = sum_g (c + r) * f16(s_g x_g) + sum_g b_g x_g; the
 //    main and residual halves are separate MFMAs into the same accumulator, so c + r is never
 //    formed: 4 v_perm_b32 + 4 MFMA per index instead of 14 VALU.  f16(s x) and sum b x are
 //    computed ONCE per workgroup and staged in LDS.
