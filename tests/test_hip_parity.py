@@ -228,6 +228,40 @@ def test_mfma_kernel_is_deterministic(I, O, dev):
         assert rel_err(tensor_to_bits(first), tensor_to_bits(ref), "f16") <= 1e-3
 
 
+@pytest.mark.parametrize("I,O,kw", [
+    (2048, 512, dict()),
+    (4096, 1024, dict(dist="llm", bias=True)),        # 32 row groups: bf16 already takes it
+    (8192 + 512, 264, dict(dist="llm")),
+    (4104, 72, dict(enable_perm=True)),
+    (16384, 64, dict(dist="llm")),                    # wider than the LDS can stage
+])
+def test_mfma_kernel_bf16(I, O, kw, dev):
+    """bf16 goes through the MFMA kernel's folded form (the VALU kernel only has the widened
+    exact arithmetic for bf16); VPTQ_GEMV_EXACT and FORCE_VALU fall back to that."""
+    kw = dict(kw)
+    dist = kw.pop("dist", "ref-test")
+    L = vo.make_layer(I, O, dist=dist, seed=I + O, dtype="bf16", **kw)
+    rng = np.random.default_rng(8)
+    xs = (0.02 + 0.5 * rng.standard_normal((1, 1, I))) if dist == "ref-test" \
+        else rng.standard_normal((1, 1, I))
+    x = vo.from_f32(xs.astype(np.float32), "bf16")
+    m = spec_to_module(L, dev)
+    xt = bits_to_tensor(x, "bf16", dev).reshape(x.shape)
+    want = vo.forward(L, x)
+    expect_kernel(m, 1, MFMA, "gemv_k256m_kernel<fast>")
+    expect_kernel(m, 1, MFMA | EXACT, "gemv_k256_kernel")
+    expect_kernel(m, 1, VALU, "gemv_k256_kernel")
+    expect_kernel(m, 1, 0, "gemv_k256m_kernel<fast>" if (O + 31) // 32 >= 32 else "gemv_k256_kernel")
+    expect_kernel(m, 2, 0, "gemv_k256_kernel")
+    got = tensor_to_bits(gemv_abi(m, xt, MFMA))
+    assert rel_err(got, want, "bf16") <= TOL["bf16"]
+    assert rel_err(tensor_to_bits(gemv_abi(m, xt, VALU)), want, "bf16") <= TOL["bf16"]
+    assert (tensor_to_bits(m(xt)) == tensor_to_bits(gemv_abi(m, xt, 0))).all()
+    first = gemv_abi(m, xt, MFMA)
+    for _ in range(5):
+        assert torch.equal(gemv_abi(m, xt, MFMA), first)
+
+
 def test_mfma_kernel_is_the_default_for_large_launches(dev):
     """From 144 row groups of 4 vector-rows on (where the VALU kernel needs a second round of
     workgroups), in both arithmetic forms, one token."""

@@ -369,54 +369,56 @@ static hipError_t dispatch(const K256Params& P, int grid, int rows, int tok, boo
 // idle: 4096^2 5.3 vs 4.9 us).  The crossover sits where the VALU kernel needs a second round of
 // workgroups (more than 512 vector-rows): 8192x5120 (160 row groups) 7.4 vs 9.1 us, 8192x4096
 // (128) 7.3 vs 7.0 us.  VPTQ_K256_KERNEL=valu|mfma and the FORCE flags override.
-static bool use_mfma_kernel(int tok, bool f16, bool fast, int max_cols, bool perm,
-                            long long row_groups, int flags) {
+// For bf16 the VALU kernel only has the exact form (arithmetic widened to fp32: ~3x the
+// instructions, 23.6 vs 9.4 us per 8192^2 layer); the MFMA kernel's folded form is dtype
+// agnostic, so bf16 takes it from 32 row groups on.
+struct K256Choice {
+  bool mfma;  // persistent MFMA kernel (else the VALU kernel)
+  bool fast;  // folded arithmetic (else the reference's per-weight roundings)
+};
+
+static K256Choice choose_kernel(const VptqLayerDesc* descs, int n, int tokens, int flags) {
   static int forced = -1;
   if (forced < 0) {
     const char* e = getenv("VPTQ_K256_KERNEL");
     forced = !e ? 0 : (e[0] == 'v' ? 1 : e[0] == 'm' ? 2 : 0);
   }
-  if (forced == 1 || (flags & VPTQ_GEMV_FORCE_VALU) ||
-      !gemv_k256m_supported(tok, f16, fast, max_cols, perm))
-    return false;
-  if (forced == 2 || (flags & VPTQ_GEMV_FORCE_MFMA)) return true;
-  (void)fast;
-  return row_groups >= 144;
+  const int tok = tokens > 2 ? 4 : tokens;
+  const bool f16 = descs[0].dtype == VPTQ_DTYPE_F16;
+  // the folded-arithmetic instantiations exist for 1-2 tokens
+  const bool want_fast = tok <= 2 && !(flags & VPTQ_GEMV_EXACT);
+  int max_cols = 0;
+  bool same_cols = true, perm = false;
+  long long row_groups = 0;
+  for (int i = 0; i < n; ++i) {
+    max_cols = descs[i].group_size > max_cols ? descs[i].group_size : max_cols;
+    // the persistent MFMA kernel is instantiated per column count: one count per launch
+    same_cols = same_cols && descs[i].group_size == descs[0].group_size;
+    perm = perm || descs[i].perm != nullptr;
+    row_groups += gemv_k256m_row_groups(descs[i].num_indices);
+  }
+  K256Choice c = {false, f16 && want_fast};  // VALU kernel: folded form for fp16 only
+  if (same_cols && forced != 1 && !(flags & VPTQ_GEMV_FORCE_VALU) &&
+      gemv_k256m_supported(tok, f16, want_fast, max_cols, perm)) {
+    const long long threshold = f16 ? 144 : 32;
+    if (forced == 2 || (flags & VPTQ_GEMV_FORCE_MFMA) || row_groups >= threshold)
+      c = {true, want_fast};
+  }
+  return c;
 }
 
-static bool wants_fast(bool f16, int tok, int flags) {
-  // the folded-arithmetic instantiations exist for fp16, 1-2 tokens
-  return f16 && tok <= 2 && !(flags & VPTQ_GEMV_EXACT);
+static const char* choice_name(K256Choice c) {
+  if (c.mfma) return c.fast ? "gemv_k256m_kernel<fast>" : "gemv_k256m_kernel";
+  return c.fast ? "gemv_k256_kernel<fast>" : "gemv_k256_kernel";
 }
 
 const char* gemv_k256_name(const VptqLayerDesc& d, int tokens, int flags) {
-  const int tok = tokens > 2 ? 4 : tokens;
-  const bool f16 = d.dtype == VPTQ_DTYPE_F16;
-  const bool fast = wants_fast(f16, tok, flags);
-  if (use_mfma_kernel(tok, f16, fast, d.group_size, d.perm != nullptr,
-                      gemv_k256m_row_groups(d.num_indices), flags))
-    return fast ? "gemv_k256m_kernel<fast>" : "gemv_k256m_kernel";
-  return fast ? "gemv_k256_kernel<fast>" : "gemv_k256_kernel";
+  return choice_name(choose_kernel(&d, 1, tokens, flags));
 }
 
-// which kernel one grouped launch of these layers uses (mirrors launch_gemv_k256)
+// which kernel one grouped launch of these layers uses
 const char* gemv_k256_group_name(const VptqLayerDesc* descs, int n, int tokens, int flags) {
-  const int tok = tokens > 2 ? 4 : tokens;
-  const bool f16 = descs[0].dtype == VPTQ_DTYPE_F16;
-  const bool fast = wants_fast(f16, tok, flags);
-  int maxG = 0;
-  bool same_cols = true;
-  long long row_groups = 0;
-  for (int i = 0; i < n; ++i) {
-    maxG = descs[i].group_size > maxG ? descs[i].group_size : maxG;
-    same_cols = same_cols && descs[i].group_size == descs[0].group_size;
-    row_groups += gemv_k256m_row_groups(descs[i].num_indices);
-  }
-  bool any_perm = false;
-  for (int i = 0; i < n; ++i) any_perm = any_perm || descs[i].perm != nullptr;
-  if (same_cols && use_mfma_kernel(tok, f16, fast, maxG, any_perm, row_groups, flags))
-    return fast ? "gemv_k256m_kernel<fast>" : "gemv_k256m_kernel";
-  return fast ? "gemv_k256_kernel<fast>" : "gemv_k256_kernel";
+  return choice_name(choose_kernel(descs, n, tokens, flags));
 }
 
 hipError_t launch_gemv_k256(const VptqLayerDesc* descs, int n, const void* const* x,
@@ -429,19 +431,14 @@ hipError_t launch_gemv_k256(const VptqLayerDesc* descs, int n, const void* const
   for (int i = 0; i < n; ++i) total_rows += descs[i].num_indices;
   const int tok = tokens > 2 ? 4 : tokens;
   const bool f16 = descs[0].dtype == VPTQ_DTYPE_F16;
-  const bool fast = wants_fast(f16, tok, flags);
+  const K256Choice choice = choose_kernel(descs, n, tokens, flags);
+  const bool mfma = choice.mfma, fast = choice.fast;
   int maxG = 0;
   bool perm = false;
   for (int i = 0; i < n; ++i) {
     maxG = descs[i].group_size > maxG ? descs[i].group_size : maxG;
     perm = perm || descs[i].perm != nullptr;
   }
-  // the persistent MFMA kernel is instantiated per column count: one count per launch
-  bool same_cols = true;
-  for (int i = 1; i < n; ++i) same_cols = same_cols && descs[i].group_size == descs[0].group_size;
-  long long row_groups = 0;
-  for (int i = 0; i < n; ++i) row_groups += gemv_k256m_row_groups(descs[i].num_indices);
-  const bool mfma = same_cols && use_mfma_kernel(tok, f16, fast, maxG, perm, row_groups, flags);
   const int rows = mfma ? kMRows : pick_rows(total_rows, tok, f16);
   const int wg_threads = mfma ? 1024 : kThreads;
   int grid = 0;

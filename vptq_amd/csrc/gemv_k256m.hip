@@ -533,7 +533,8 @@ bool gemv_k256m_supported(int tok, bool f16, bool fast, int max_cols, bool perm)
   if (!fast && max_cols > 5 * kMSweepCols) return false;
   // more columns than fit beside the image: unstaged variant (folded form, no permutation)
   if (max_cols > kMMaxCols && (!fast || perm)) return false;
-  return f16 && tok == 1;
+  // bf16: folded form only (its exact form would run the widened arithmetic on the VALU)
+  return tok == 1 && (f16 || fast);
 }
 
 int gemv_k256m_row_groups(int n_rows) { return (n_rows + kMRows - 1) / kMRows; }
@@ -560,6 +561,7 @@ hipError_t launch_gemv_k256m(K256Params& P, int tok, bool f16, bool fast, int ma
     P.layer[i].slots = slots > kMMaxSlots ? kMMaxSlots : slots;
     gx = (int)share > gx ? (int)share : gx;
   }
+  if (!f16) return launch_m_shape<BF16, true>(P, gx, perm, max_cols, st);
   return fast ? launch_m_shape<F16, true>(P, gx, perm, max_cols, st)
               : launch_m_shape<F16, false>(P, gx, perm, max_cols, st);
 }
