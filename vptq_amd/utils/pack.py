@@ -18,7 +18,8 @@ from typing import Optional, Tuple
 
 import torch
 
-__all__ = ["pack_index", "unpack_index_tensor", "absorb_perm_layer", "absorb_perm"]
+__all__ = ["pack_index", "unpack_index_tensor", "dtype_convert", "pack_layer_tensors",
+           "pack_state_dict", "absorb_perm_layer", "absorb_perm"]
 
 
 def _as_u16_int64(t: torch.Tensor, index_dtype: torch.dtype) -> torch.Tensor:
@@ -146,3 +147,69 @@ def absorb_perm(model):
                 if isinstance(layer_cfg, dict) and layer_cfg.get("enable_perm"):
                     layer_cfg["enable_perm"] = False
     return model
+
+
+# ---------------------------------------------------------------------------------------------
+# Offline packing of an UNPACKED checkpoint (what the quantisation algorithm writes) into the
+# packed format the kernels read: the reference's `pack_model` / `convert_idx_dtype`
+# (vptq/utils/pack.py:142-283).  The reference walks live `VQuantLinear` modules; this build's
+# module only exists in packed form (the unpacked mode belongs to the absent quantisation
+# algorithm), so the same conversion is offered on the state dict + `quantization_config`.
+
+def dtype_convert(data: torch.Tensor, from_dtype, to_dtype, as_type) -> torch.Tensor:
+    """reference pack.py:142-144"""
+    return data.view(from_dtype).to(to_dtype).view(as_type)
+
+
+def _convert(t: torch.Tensor, from_dtype, to_dtype, as_type) -> torch.Tensor:
+    # int64 tensors are values, everything else is a bit pattern of `from_dtype`
+    # (reference pack.py:158-169)
+    return dtype_convert(t, t.dtype if t.dtype == torch.int64 else from_dtype, to_dtype, as_type)
+
+
+def pack_layer_tensors(tensors: dict, num_centroids: int, num_res_centroids: int,
+                       from_dtype=torch.uint16, to_dtype=torch.uint16, as_type=torch.int16) -> dict:
+    """One layer: {"indices" [C,N,G], "res_indices" [C,N,G] | None, "outlier_indices" | None,
+    "perm" | None, ...} -> the same dict with `indices` packed to int32 [C,N,ceil(G*T/32)],
+    `res_indices` removed, `outlier_indices` / `perm` converted to `as_type`.  Other entries
+    (codebooks, scale, bias) pass through."""
+    out = dict(tensors)
+    idx = _convert(tensors["indices"], from_dtype, to_dtype, as_type)
+    res = tensors.get("res_indices")
+    if res is not None:
+        res = _convert(res, from_dtype, to_dtype, as_type)
+    for name in ("outlier_indices", "perm"):
+        if tensors.get(name) is not None:
+            out[name] = _convert(tensors[name], from_dtype, to_dtype, as_type)
+    import math
+    out["indices"] = pack_index(
+        indice=idx, index_bits=int(math.log2(num_centroids)), res_indice=res,
+        res_bits=int(math.log2(num_res_centroids)) if res is not None else 0,
+        index_dtype=to_dtype)
+    out.pop("res_indices", None)
+    return out
+
+
+def pack_state_dict(state: dict, config_for_layers: dict, from_dtype=torch.uint16,
+                    to_dtype=torch.uint16, as_type=torch.int16):
+    """Whole checkpoint: `state` = flat state dict with unpacked VQuantLinear tensors,
+    `config_for_layers` = quantization_config["config_for_layers"] (constructor kwargs per layer
+    name).  Returns (new_state, new_config_for_layers) with every listed layer packed and
+    `is_indice_packed=True` (reference convert_idx_dtype, pack.py:147-243)."""
+    new_state = dict(state)
+    new_conf = {}
+    for name, conf in config_for_layers.items():
+        keys = ("indices", "res_indices", "outlier_indices", "perm")
+        layer = {k: state.get(f"{name}.{k}") for k in keys}
+        if layer["indices"] is None:
+            raise KeyError(f"{name}.indices is not in the state dict")
+        k_main = conf["num_centroids"][1]
+        k_res = conf["num_res_centroids"][1]
+        packed = pack_layer_tensors(layer, k_main, k_res if k_res > 0 else 1, from_dtype,
+                                    to_dtype, as_type)
+        for k in keys:
+            new_state.pop(f"{name}.{k}", None)
+            if packed.get(k) is not None:
+                new_state[f"{name}.{k}"] = packed[k]
+        new_conf[name] = dict(conf, is_indice_packed=True)
+    return new_state, new_conf
