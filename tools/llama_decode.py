@@ -23,7 +23,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def build_model(layers, dev, k=256, kr=256, perm=False):
+SIZES = {"8b": dict(hidden_size=4096, intermediate_size=14336, num_attention_heads=32, layers=32),
+         "70b": dict(hidden_size=8192, intermediate_size=28672, num_attention_heads=64, layers=80)}
+
+
+def build_model(layers, dev, k=256, kr=256, perm=False, size="8b"):
     from transformers import LlamaConfig, LlamaForCausalLM
     from transformers.integrations.vptq import replace_with_vptq_linear
     from transformers.models.llama.modeling_llama import LlamaRotaryEmbedding
@@ -31,8 +35,10 @@ def build_model(layers, dev, k=256, kr=256, perm=False):
     import vptq  # the alias package of this repository
     assert vptq.__file__.startswith(ROOT), vptq.__file__
 
-    cfg = LlamaConfig(hidden_size=4096, intermediate_size=14336, num_hidden_layers=layers,
-                      num_attention_heads=32, num_key_value_heads=8, vocab_size=128256,
+    sz = SIZES[size]
+    cfg = LlamaConfig(hidden_size=sz["hidden_size"], intermediate_size=sz["intermediate_size"],
+                      num_hidden_layers=layers or sz["layers"],
+                      num_attention_heads=sz["num_attention_heads"], num_key_value_heads=8, vocab_size=128256,
                       max_position_embeddings=8192, rope_theta=500000.0, rms_norm_eps=1e-5,
                       tie_word_embeddings=False)
     cfg._attn_implementation = "sdpa"
@@ -99,7 +105,7 @@ def run(args):
     def stage(msg):
         print(f"[stage] {msg}", file=sys.stderr, flush=True)
     stage("build")
-    model, cfg, qlayers = build_model(args.layers, dev, perm=args.perm)
+    model, cfg, qlayers = build_model(args.layers, dev, perm=args.perm, size=args.model)
     fused = 0
     if args.fuse:
         import vptq
@@ -171,7 +177,7 @@ def run(args):
         graph_tps = f"capture failed: {type(e).__name__}: {e}"
 
     lm_head_bytes = cfg.vocab_size * cfg.hidden_size * 2
-    res = dict(model=f"Llama-3-8B shapes, {args.layers} layers, 2-bit VQuantLinear (v8 k256+256)"
+    res = dict(model=f"Llama-3-{args.model.upper()} shapes, {cfg.num_hidden_layers} layers, 2-bit VQuantLinear (v8 k256+256)"
                      + (" +perm" if args.perm else ""),
                quantized_linears=len(qlayers), packed_index_GB=qbytes / 1e9,
                lm_head_GB=lm_head_bytes / 1e9, prompt=args.prompt, new_tokens=args.new,
@@ -187,7 +193,8 @@ def run(args):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--layers", type=int, default=32)
+    ap.add_argument("--model", default="8b", choices=sorted(SIZES))
+    ap.add_argument("--layers", type=int, default=0, help="0 = the model's own depth")
     ap.add_argument("--prompt", type=int, default=128)
     ap.add_argument("--new", type=int, default=256)
     ap.add_argument("--perm", action="store_true")
