@@ -145,7 +145,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--hidden", type=int, default=8192)
     ap.add_argument("--ring", type=int, default=0)
-    ap.add_argument("--mode", choices=["single", "grouped", "tp"], default="single")
+    ap.add_argument("--mode", choices=["single", "grouped", "tp", "tp_row"], default="single",
+                    help="tp: output rows of every layer split over the ranks, RCCL all-gather; "
+                         "tp_row: input columns split (row-parallel, BASELINE config #5), RCCL "
+                         "all-reduce of the partial sums")
     ap.add_argument("--group", type=int, default=4)
     ap.add_argument("--exact", action="store_true",
                     help="VPTQ_GEMV_EXACT: rebuild every weight with the reference CPU path's three "
@@ -179,13 +182,21 @@ def main():
     idx_bytes = (H // 8) * H * 2
     R = a.ring or max(2, (512 << 20) // idx_bytes)
     # tp: all ranks build the same layers, each keeps its slice of the output rows
-    layers = make_ring(H, R, dev, seed=1234 + (0 if a.mode == "tp" else rank))
+    tp = a.mode in ("tp", "tp_row")
+    layers = make_ring(H, R, dev, seed=1234 + (0 if tp else rank))
+    if a.mode == "tp_row":
+        from vptq_amd.utils.shard import shard_in_features
+        layers = [shard_in_features(m, rank, world) for m in layers]
+        torch.cuda.empty_cache()
     if a.mode == "tp":
         from vptq_amd.utils.shard import shard_out_features
         layers = [shard_out_features(m, rank, world) for m in layers]
         torch.cuda.empty_cache()
     x = torch.randn(1, 1, H, device=dev, dtype=torch.float16,
                     generator=torch.Generator(device=dev).manual_seed(7))
+    if a.mode == "tp_row":   # every rank multiplies its slice of the input columns
+        g0, g1 = layers[0].shard[1], layers[0].shard[2]
+        x = x[..., g0:g1].contiguous()
     ys = [torch.empty(1, 1, layers[i].out_features, device=dev, dtype=torch.float16)
           for i in range(R)]
     y_full = torch.empty(H, device=dev, dtype=torch.float16) if a.mode == "tp" else None
@@ -200,7 +211,18 @@ def main():
     kname = lib.vptq_quant_gemv_kernel_name(descs[0], 1, flags).decode()
 
     stream = torch.cuda.Stream(device=dev)
-    if a.mode == "tp":
+    if a.mode == "tp_row":
+        launches_per_step = R
+
+        def one_pass():
+            sp = torch.cuda.current_stream().cuda_stream
+            for i in range(R):
+                rc = lib.vptq_quant_gemv(descs[i], x.data_ptr(), ys[i].data_ptr(), 1, flags,
+                                         None, 0, sp)
+                assert rc == 0, lib.vptq_last_error()
+                if dist is not None:
+                    dist.all_reduce(ys[i])      # sum of the ranks' partial outputs
+    elif a.mode == "tp":
         launches_per_step = R
         if H // 8 % world:
             raise SystemExit("tp mode needs the vector-row count divisible by the world size")
@@ -251,7 +273,7 @@ def main():
             with torch.cuda.graph(graph, stream=stream):
                 one_pass()
         except Exception:
-            if a.mode != "tp":
+            if not tp:
                 raise
             captured, graph = False, _Eager()  # collectives that refuse capture: eager launches
             torch.cuda.synchronize()
@@ -277,18 +299,18 @@ def main():
     wall, ev_ms = reduce_times(wall, ev_ms, dist, dev)
 
     ab = alg_bytes(H)
-    if a.mode == "tp":   # strong scaling: the ring is processed once per step by all ranks together
+    if tp:   # strong scaling: the ring is processed once per step by all ranks together
         value = job_throughput_gbps(1, ab, R, a.steps, wall)
     else:
         value = job_throughput_gbps(world, ab, R, a.steps, wall)
     us_per_launch = ev_ms * 1e3 / (a.steps * launches_per_step)
-    bytes_per_launch = ab * R / launches_per_step / (world if a.mode == "tp" else 1)
+    bytes_per_launch = ab * R / launches_per_step / (world if tp else 1)
     achieved = bytes_per_launch / us_per_launch / 1e3     # GB/s
     out = {
         "metric": "decode GEMV effective GB/s (VQuantLinear 2-bit, batch 1)",
         "value": value, "unit": "GB/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": wall * 1e3 / a.steps, "higher_is_better": True,
-        "scaling": "strong" if a.mode == "tp" else "weak",
+        "scaling": "strong" if tp else "weak",
         "vs_baseline": None, "dtype": "f16", "data": "synthetic",
         "config": {"workload": f"VQuantLinear {H}x{H} v=8 k=256+256 (2-bit) batch=1 seq=1 fp16, "
                                f"ring of {R} distinct layers per GPU ({R * idx_bytes >> 20} MiB of "
@@ -301,6 +323,9 @@ def main():
                    "hipgraph": captured,
                    "parallelism": (f"tp{world}: output rows of every layer split over {world} ranks, "
                                    "RCCL all-gather per layer") if a.mode == "tp" else
+                                  (f"tp{world} row-parallel: input columns of every layer split over "
+                                   f"{world} ranks, RCCL all-reduce of the partial outputs per layer")
+                                  if a.mode == "tp_row" else
                                   f"{world} x independent rings (no collective)"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
