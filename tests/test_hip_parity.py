@@ -438,12 +438,13 @@ def test_absorb_perm_on_device(dev):
     from vptq_amd.utils.pack import absorb_perm_layer
     L = vo.make_layer(2048, 512, dist="llm", seed=77, enable_perm=True)
     m = spec_to_module(L, dev)
-    x = torch.randn(1, 1, 2048, device=dev, dtype=torch.float16)
+    x = torch.randn(1, 1, 2048, device=dev, dtype=torch.float16,
+                    generator=torch.Generator(device=dev).manual_seed(5))
     W0, y0 = m.dequant(), m(x)
     assert absorb_perm_layer(m)
     assert torch.equal(m.dequant(), W0)                    # identical dense weight
-    y1 = m(x)
-    assert ((y1.float() - y0.float()).abs().max() / y0.float().abs().max()).item() <= 5e-4
+    y1 = m(x)   # same weights, columns summed in another order: one flipped fp16 bit at most
+    assert ((y1.float() - y0.float()).abs().max() / y0.float().abs().max()).item() <= 1e-3
 
 
 def test_deterministic_and_stream_safe(dev):

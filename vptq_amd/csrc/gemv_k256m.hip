@@ -178,6 +178,7 @@ __global__ __launch_bounds__(kMThreads) void gemv_k256m_kernel(const K256Params 
     constexpr int kStageCols = kMThreads * 8;
     constexpr int kSt = NST > 0 ? NST : 1;
     u32x4 st_x[kSt], st_s[kSt], st_b[kSt], centry;
+    u32x4 st_pv[PERM ? kSt : 1];  // PERM: 8 input-feature numbers (uint16) per staged chunk
     const char* const c0 = (const char*)Ly.cent;
     const uint32_t cent_off = (uint32_t)((tid >> 1) & 255) * 16u;
     const uint32_t rowp = ((uint32_t)(tid >> 9) << 16) | ((uint32_t)((tid >> 1) & 255) << 8) |
@@ -186,35 +187,21 @@ __global__ __launch_bounds__(kMThreads) void gemv_k256m_kernel(const K256Params 
 #pragma unroll
       for (int q = 0; q < 8; ++q) lds_store16(rowp + (((q + lane) & 7) << 4), centry);
     };
-    if (PERM) {
-      // gathered through the permutation with ordinary loads; the queue starts afterwards
-      const ptrdiff_t rdelta = (const char*)Ly.rcent - c0;
-      centry = *(const u32x4*)as_global(c0 + (tid < 512 ? (ptrdiff_t)0 : rdelta) + cent_off);
-#pragma unroll
-      for (int k = 0; k < NST; ++k) {
-        const int want = k * kStageCols + tid * 8;
-        const int col0 = want < G ? want : G - 8;
-        const u32x4 pv = ldg16(Ly.perm, (uint32_t)col0 * 2u);
-        if (FAST) {
-          st_s[k] = ldg16(sp, (uint32_t)col0 * 2u);
-          st_b[k] = ldg16(bp, (uint32_t)col0 * 2u);
-        }
-        st_x[k] = ldg8x16<true>(Ly.x, col0, pv);
-      }
-      write_image();
-    } else {
+    {
       // wave-uniform table choice: waves 0-7 replicate the main codebook, 8-15 the residual
       const char* const tab = __builtin_amdgcn_readfirstlane(wave) < 8 ? c0 : (const char*)Ly.rcent;
       q_load(centry, tab, cent_off);
 #pragma unroll
       for (int k = 0; k < NST; ++k) {
         const int want = k * kStageCols + tid * 8;
-        const uint32_t off = (uint32_t)(want < G ? want : G - 8) * 2u;
+        const int col0 = want < G ? want : G - 8;
+        const uint32_t off = (uint32_t)col0 * 2u;
+        if (PERM) q_load(st_pv[k], Ly.perm, off);
         if (FAST) {
           q_load(st_s[k], sp, off);
           q_load(st_b[k], bp, off);
         }
-        q_load(st_x[k], Ly.x, off);
+        q_load(st_x[k], Ly.x, off);  // PERM: x in its own order, permuted through LDS below
       }
       __builtin_amdgcn_sched_barrier(0);
       write_image();
@@ -223,6 +210,28 @@ __global__ __launch_bounds__(kMThreads) void gemv_k256m_kernel(const K256Params 
       for (int s = 0; s < DP; ++s) issue_sweep(s, bid, 0);
       __builtin_amdgcn_sched_barrier(0);
       K256_STAMP(kMWaves, 1, tid);
+    }
+    if (PERM) {
+      // Column c of the quantised matrix multiplies input feature perm[c].  Gathering x through
+      // the permutation from global memory is 8192 scattered 2-byte loads per workgroup
+      // (+2.3 us); instead x is parked in the staging area in its own order and gathered from
+      // LDS: store, barrier, 8 ds_read_u16 per thread, barrier, then staged like the rest.
+#pragma unroll
+      for (int k = 0; k < NST; ++k) {
+        const int want = k * kStageCols + tid * 8;
+        lds_store16(xs_off + (uint32_t)(want < G ? want : G + 8) * 2u, st_x[k]);
+      }
+      __syncthreads();
+      typedef __attribute__((address_space(3))) const uint16_t lds_u16_t;
+#pragma unroll
+      for (int k = 0; k < NST; ++k)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const uint32_t lo = *(lds_u16_t*)(uintptr_t)(xs_off + (st_pv[k][q] & 0xffffu) * 2u);
+          const uint32_t hi = *(lds_u16_t*)(uintptr_t)(xs_off + (st_pv[k][q] >> 16) * 2u);
+          st_x[k][q] = lo | (hi << 16);
+        }
+      __syncthreads();  // every thread has its activations: the area may be overwritten
     }
     float accb = 0.f;
 #pragma unroll
@@ -256,12 +265,6 @@ __global__ __launch_bounds__(kMThreads) void gemv_k256m_kernel(const K256Params 
     if (FAST) {
       const float sum = wave_sum(accb);
       if (lane == 0) red_b[wave] = sum;
-    }
-    if (PERM) {
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int s = 0; s < DP; ++s) issue_sweep(s, bid, 0);
-      K256_STAMP(kMWaves, 1, tid);
     }
   }
   __builtin_amdgcn_sched_barrier(0);  // nothing that waits for index words above the barrier
