@@ -22,3 +22,15 @@ def pytest_sessionstart(session):
     if not os.path.exists(os.path.join(ROOT, "oracle", "_build", "libvptq_oracle.so")):
         subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True,
                        stdout=subprocess.DEVNULL)
+
+
+import pytest  # noqa: E402
+
+
+@pytest.fixture(autouse=True)
+def _seeded():
+    """Every test starts from the same torch seeds (CPU and GPU): a test that draws inputs with
+    torch.randn / randint sees the same numbers on every run and every box."""
+    import torch
+    torch.manual_seed(20260924)
+    yield
