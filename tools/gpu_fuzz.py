@@ -28,6 +28,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=40)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     rng = np.random.default_rng(a.seed)
@@ -40,18 +41,20 @@ def main():
         if I * O > 40e6:
             O = max(8, int(40e6 // I) // 8 * 8)
         kw = dict(enable_perm=bool(rng.integers(0, 2)), bias=bool(rng.integers(0, 2)))
-        L = vo.make_layer(I, O, dist="llm", seed=1000 + c, **kw)
-        x = vo.from_f32(rng.standard_normal((1, 1, I)).astype(np.float32), "f16")
+        dt = a.dtype
+        tol = 1e-3 if dt == "f16" else 8e-3
+        L = vo.make_layer(I, O, dist="llm", seed=1000 + c, dtype=dt, **kw)
+        x = vo.from_f32(rng.standard_normal((1, 1, I)).astype(np.float32), dt)
         m = spec_to_module(L, dev)
-        xt = bits_to_tensor(x, "f16", dev).reshape(x.shape)
+        xt = bits_to_tensor(x, dt, dev).reshape(x.shape)
         want = vo.forward(L, x)
         line = f"case {c:3d} I={I:6d} O={O:6d} perm={int(kw['enable_perm'])} bias={int(kw['bias'])}:"
         for name, fl in FLAGS.items():
             got = tensor_to_bits(gemv_abi(m, xt, fl))
-            e = rel_err(got, want, "f16")
+            e = rel_err(got, want, dt)
             worst[name] = max(worst[name], e)
             line += f" {name}={e:.1e}"
-            assert e <= 1e-3, (line, kernel_name(m, 1, fl))
+            assert e <= tol, (line, kernel_name(m, 1, fl))
         print(line, flush=True)
     print("worst:", {k: f"{v:.2e}" for k, v in worst.items()})
 
