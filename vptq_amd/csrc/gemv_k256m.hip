@@ -59,18 +59,6 @@ static __device__ __forceinline__ u32x4 ldg16(const void* base, uint32_t byte_of
   return *(const u32x4*)as_global((const char*)base + byte_off);
 }
 
-template <bool PERM>
-static __device__ __forceinline__ u32x4 ldg8x16(const uint16_t* __restrict__ p, int col0,
-                                                const u32x4& pv) {
-  if (!PERM) return ldg16(p, (uint32_t)col0 * 2u);
-  const uint16_t* const g = as_global(p);
-  u32x4 r;
-#pragma unroll
-  for (int q = 0; q < 4; ++q)
-    r[q] = (uint32_t)g[pv[q] & 0xffffu] | ((uint32_t)g[pv[q] >> 16] << 16);
-  return r;
-}
-
 // Queue load: 16 bytes at (wave-uniform base) + (32-bit lane offset).  An ordinary load whose
 // wait the compiler places (see the file comment).  A version with inline-assembly loads and
 // hand-written s_waitcnt counts was faster to write and unsafe: nothing stops the register
@@ -435,7 +423,6 @@ __global__ __launch_bounds__(kMThreads) void gemv_k256m_kernel(const K256Params 
     K256M_STEP(4) K256M_STEP(5) K256M_STEP(6)
 #undef K256M_STEP
   };
-  using yes_t = std::integral_constant<bool, true>;
   using no_t = std::integral_constant<bool, false>;
   auto row_group = [&](auto first_c, auto last_c, int rg, int q) {
     constexpr bool LAST = decltype(last_c)::value;
