@@ -287,7 +287,10 @@ __global__ __launch_bounds__(kMThreads) void gemv_k256m_kernel(const K256Params 
         xq[q] = DT::mul2(b_raw[NQ > 1 ? s : 0][q] & keep, s_raw[NQ > 1 ? s : 0][q]);  // f16(s * x)
     }
     const u32x4 words = iw[s];
-    constexpr int kAhead = 3;
+#ifndef VPTQ_K256M_AHEAD
+#define VPTQ_K256M_AHEAD 3
+#endif
+    constexpr int kAhead = VPTQ_K256M_AHEAD;  // indices whose gathers are in flight ahead of the MFMAs
     u32x4 cv[kAhead + 1], rv[kAhead + 1];
     auto gather = [&](int u) {
       const uint32_t w = words[u >> 1];
@@ -301,7 +304,14 @@ __global__ __launch_bounds__(kMThreads) void gemv_k256m_kernel(const K256Params 
     for (int u = 0; u < kAhead; ++u) gather(u);
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
+      // fenced: left alone, the scheduler sinks the gathers next to their use and the loop
+      // runs with one gather in flight (s_waitcnt lgkmcnt(1)), i.e. at LDS latency
+#ifndef VPTQ_K256M_FENCE_UNITS
+#define VPTQ_K256M_FENCE_UNITS 1
+#endif
+      if (VPTQ_K256M_FENCE_UNITS) __builtin_amdgcn_sched_barrier(0);
       if (u + kAhead < 8) gather(u + kAhead);
+      if (VPTQ_K256M_FENCE_UNITS) __builtin_amdgcn_sched_barrier(0);
       const int q = u >> 1, h = u & 1;
       const u32x4 c = cv[u % (kAhead + 1)], r = rv[u % (kAhead + 1)];
       u32x2 xo;
