@@ -9,6 +9,8 @@
 //     g8r    8 replicas, slot = 2*(lane&7) + (k&1)            (balls-in-bins, 32 KiB)
 //     g4r    4 replicas, slot = 4*(lane&3) + (k&3)            (16 KiB)
 //     g1     no replicas                                      (4 KiB)
+//     g8x    two tables x 8 replicas in one 16-slot row: lanes with bit 3 clear read table A
+//            (slots 0-7), the others table B (slots 8-15)       (conflict free, 64 KiB for BOTH)
 //   scatter-add (ds_add_f32, 4-byte buckets):
 //     a32   32 replicas, lane&31 owns a bank                  (conflict free, 32 KiB)
 //     a16   16 replicas, bank = (lane&15) + 16*(k&1)          (16 KiB)
@@ -32,6 +34,7 @@ __device__ __forceinline__ unsigned addr_of(unsigned k, unsigned lane) {
     case 2: return ((k >> 1) << 8) | ((lane & 7) << 5) | ((k & 1) << 4);            // g8r
     case 3: return ((k >> 2) << 8) | ((lane & 3) << 6) | ((k & 3) << 4);            // g4r
     case 4: return k << 4;                                                          // g1
+    case 5: return (k << 8) | ((((lane >> 3) & 1) * 8 + (lane & 7)) << 4);          // g8x: 16 slots from 2 x 8 replicas
     case 10: return (k << 7) | ((lane & 31) << 2);                                  // a32
     case 11: return (k << 6) | ((lane & 15) << 2);                                  // a16: dword = 16k + rho -> bank = rho + 16*(k&1)
     case 12: return (k << 5) | ((lane & 7) << 2);                                   // a8
@@ -111,7 +114,7 @@ int main() {
   printf("%s CUs=%d clock=%d kHz (64 KiB LDS per 512-thread block: 1-2 blocks = 2-4 waves per SIMD)\n", p.gcnArchName,
          p.multiProcessorCount, p.clockRate);
   RUN(0, "gather b128 g16") RUN(1, "gather b128 g8p") RUN(2, "gather b128 g8r") RUN(3, "gather b128 g4r")
-  RUN(4, "gather b128 g1")
+  RUN(4, "gather b128 g1") RUN(5, "gather b128 g8x")
   RUN(10, "ds_add_f32 a32") RUN(11, "ds_add_f32 a16") RUN(12, "ds_add_f32 a8") RUN(13, "ds_add_f32 a4")
   RUN(14, "ds_add_f32 a1") RUN(20, "ds_pk_add_f16 a32") RUN(21, "ds_pk_add_f16 a8") RUN(30, "ds_add_rtn_f32 a32")
   return 0;

@@ -22,10 +22,11 @@
 //  * exact form: the reference's three roundings r16(r16(r16(c+r)*s)+b) stay packed-f16 VALU
 //    (12 ops), the 8 fp32 FMAs become 2 MFMAs (f16 x f16 products are exact in fp32, so the
 //    sum is the same fma chain): 16 VALU + 2 MFMA instead of 22 VALU.
-//  * 1024-thread workgroups, one per CU (4 waves / SIMD).  The LDS image holds 16 replicas of
-//    both codebooks (128 KiB, address = table << 16 | entry << 8 | replica << 4, replica =
-//    lane & 15): every lane of a ds_read_b128 group reads its own bank quad -> conflict free
-//    (5.1 LDS cycles per gather).
+//  * 1024-thread workgroups, one per CU (4 waves / SIMD).  The LDS image holds 8 replicas of
+//    each codebook in one 256-byte row per entry (64 KiB); the two gathers of an index are
+//    split across the lanes (bit 3 of the lane id picks main-then-residual or residual-then-
+//    main), so every lane of a ds_read_b128 group reads its own bank quad -> conflict free
+//    (4.8-5.1 LDS cycles per gather) with half the image of a 16-replica layout.
 //  * persistent: one workgroup per CU (the CUs are shared out between the layers of a grouped
 //    launch in proportion to their rows); it builds the image and stages the activations
 //    once, then walks row groups bid, bid + wgs, ... of 4 vector-rows (32
@@ -48,7 +49,7 @@ namespace vptq {
 constexpr int kMThreads = 1024;
 constexpr int kMWaves = kMThreads / 64;
 constexpr int kMSweepCols = kMWaves * 16 * 8;  // 2048: 16 blocks (column chunks of 8) per wave
-constexpr int kMTableBytes = 131072;
+constexpr int kMTableBytes = 65536;  // 256 rows x (8 main + 8 residual replicas) x 16 B
 constexpr int kMMaxLds = 163840;   // 160 KiB per CU
 constexpr int kMMaxCols = 14336;   // staged activations must fit beside the image
 constexpr int kMRedSlot = kMWaves * 32 * 4;   // one row group's cross-wave partials
@@ -111,8 +112,21 @@ __global__ __launch_bounds__(kMThreads) void gemv_k256m_kernel(const K256Params 
   K256_STAMP(kMWaves, 0, tid);
 
   // gather address = perm(word, base, sel): {0, base.b2 = table, index byte, base.b0 = replica}
-  const uint32_t baseC = (uint32_t)(lane & 15) << 4;
-  const uint32_t baseR = baseC | 0x10000u;
+  // Image row e = 8 replicas of main entry e (16-byte slots 0-7) + 8 replicas of residual entry
+  // e (slots 8-15).  The two gathers of an index are split ACROSS the lanes: in gather A the
+  // lanes with bit 3 clear fetch the main entry (slot lane & 7) and the others the residual
+  // entry (slot 8 + (lane & 7)); gather B is the complement.  Every 16-lane group of a
+  // ds_read_b128 then touches 16 different slots - conflict free with 64 KiB instead of the
+  // 128 KiB a 16-replica image of both tables needs (tools/ubench_lds.hip: 4.8-5.1 cycles
+  // either way) - and it does not matter which register holds which: both are accumulated
+  // with the same x operand (exact form: added).
+  const uint32_t hi = (lane >> 3) & 1u;
+  const uint32_t baseA = ((hi << 3) | (lane & 7u)) << 4;
+  const uint32_t baseB = (((hi ^ 1u) << 3) | (lane & 7u)) << 4;
+  // selector {0, 0, word.byte[p], base.byte0}: index byte 2h is the main index of the word's
+  // element h, byte 2h + 1 its residual index
+  const uint32_t selGA[2] = {0x0c0c0400u | (hi << 8), 0x0c0c0600u | (hi << 8)};
+  const uint32_t selGB[2] = {0x0c0c0400u | ((hi ^ 1u) << 8), 0x0c0c0600u | ((hi ^ 1u) << 8)};
   // x operand of the MFMA: x' * e_j as two packed pairs, cut out of a packed x' register
   // (column parity h picks the half) by one v_perm_b32 with a per-lane selector
   const uint32_t selA[2] = {j == 0 ? 0x0c0c0504u : j == 1 ? 0x05040c0cu : 0x0c0c0c0cu,
@@ -152,9 +166,9 @@ __global__ __launch_bounds__(kMThreads) void gemv_k256m_kernel(const K256Params 
   };
 
   // ---- 3. prologue, once per workgroup.
-  //  * LDS codebook image: thread t replicates entry (t >> 1) & 255 of table t >> 9 into 8 of
-  //    its 16 slots (rotated by the lane id: the 8 lanes of a ds_write_b128 group hit 8
-  //    different slots).
+  //  * LDS codebook image: thread t replicates entry (t >> 1) & 255 of table t >> 9 into 4 of
+  //    its 8 slots (rotated so that the 8 lanes of a ds_write_b128 group hit 8 different
+  //    slots).
   //  * activations: thread t stages columns 8t.. of each 8192-column block.  FAST stages
   //    f16(s * x) and sums b * x; the exact form stages x itself.
   // Order (tools/trace_k256m.py): the codebook entry and the activations are requested
@@ -169,11 +183,11 @@ __global__ __launch_bounds__(kMThreads) void gemv_k256m_kernel(const K256Params 
     u32x4 st_pv[PERM ? kSt : 1];  // PERM: 8 input-feature numbers (uint16) per staged chunk
     const char* const c0 = (const char*)Ly.cent;
     const uint32_t cent_off = (uint32_t)((tid >> 1) & 255) * 16u;
-    const uint32_t rowp = ((uint32_t)(tid >> 9) << 16) | ((uint32_t)((tid >> 1) & 255) << 8) |
-                          ((uint32_t)(tid & 1) << 7);
+    const uint32_t rowp = ((uint32_t)((tid >> 1) & 255) << 8) | ((uint32_t)(tid >> 9) << 7) |
+                          ((uint32_t)(tid & 1) << 6);
     auto write_image = [&]() {
 #pragma unroll
-      for (int q = 0; q < 8; ++q) lds_store16(rowp + (((q + lane) & 7) << 4), centry);
+      for (int q = 0; q < 4; ++q) lds_store16(rowp + (((q + (lane >> 1)) & 3) << 4), centry);
     };
     {
       // wave-uniform table choice: waves 0-7 replicate the main codebook, 8-15 the residual
@@ -288,15 +302,17 @@ __global__ __launch_bounds__(kMThreads) void gemv_k256m_kernel(const K256Params 
     }
     const u32x4 words = iw[s];
 #ifndef VPTQ_K256M_AHEAD
-#define VPTQ_K256M_AHEAD 3
+#define VPTQ_K256M_AHEAD 2
 #endif
-    constexpr int kAhead = VPTQ_K256M_AHEAD;  // indices whose gathers are in flight ahead of the MFMAs
+    // indices whose gathers are in flight ahead of the MFMAs (the exact form has 12 more
+    // registers of scale / bias per sweep in its queue: one less)
+    constexpr int kAhead = FAST ? VPTQ_K256M_AHEAD : VPTQ_K256M_AHEAD - 1;
     u32x4 cv[kAhead + 1], rv[kAhead + 1];
     auto gather = [&](int u) {
       const uint32_t w = words[u >> 1];
       const int h = u & 1;
-      const uint32_t aC = __builtin_amdgcn_perm(w, baseC, h ? 0x0c020600u : 0x0c020400u);
-      const uint32_t aR = __builtin_amdgcn_perm(w, baseR, h ? 0x0c020700u : 0x0c020500u);
+      const uint32_t aC = __builtin_amdgcn_perm(w, baseA, selGA[h]);
+      const uint32_t aR = __builtin_amdgcn_perm(w, baseB, selGB[h]);
       cv[u % (kAhead + 1)] = lds_load16(aC);
       rv[u % (kAhead + 1)] = lds_load16(aR);
     };
