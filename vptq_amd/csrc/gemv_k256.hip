@@ -39,11 +39,16 @@ constexpr int kThreads = 512;
 constexpr int kWaves = kThreads / 64;
 constexpr int kSweepCols = kThreads * 8;  // columns covered by one sweep of the WG
 // both gathers of one element: index byte h*2 -> main entry, byte h*2+1 -> residual
+// The two gathers are split ACROSS the lanes: in the first, lanes with bit 3 clear fetch the
+// main entry (slot lane & 7) and the others the residual entry (slot 8 + (lane & 7)); the second
+// is the complement.  Every 16-lane group of a ds_read_b128 then touches 16 different slots
+// (conflict free: 5 instead of 8.8 LDS cycles per gather, tools/ubench_lds.hip), and since the
+// two entries are only ever added it does not matter which register holds which.
 static __device__ __forceinline__ void gather(uint32_t w, int h, uint32_t baseC, uint32_t baseR,
-                                              u32x4& cv, u32x4& rv) {
-  // D = {0, 0, w.byte, base.b0}: (index << 8) | slot
-  const uint32_t aC = __builtin_amdgcn_perm(w, baseC, h ? 0x0c0c0600u : 0x0c0c0400u);
-  const uint32_t aR = __builtin_amdgcn_perm(w, baseR, h ? 0x0c0c0700u : 0x0c0c0500u);
+                                              uint32_t selC, uint32_t selR, u32x4& cv, u32x4& rv) {
+  // D = {0, 0, w.byte, base.b0}: (index << 8) | slot; element h of the word = bytes 2h, 2h + 1
+  const uint32_t aC = __builtin_amdgcn_perm(w, baseC, h ? selC + 0x200u : selC);
+  const uint32_t aR = __builtin_amdgcn_perm(w, baseR, h ? selR + 0x200u : selR);
   cv = lds_load16(aC);
   rv = lds_load16(aR);
 }
@@ -117,8 +122,10 @@ __global__ __launch_bounds__(kThreads, 4) void gemv_k256_kernel(const K256Params
   }
 
   // gather address bases: replica slot in bits 4..6, residual half of the row: bit 7
-  const uint32_t baseC = (uint32_t)(lane & 7) << 4;
-  const uint32_t baseR = baseC | 0x80u;
+  const uint32_t hi = (uint32_t)(lane >> 3) & 1u;
+  const uint32_t baseC = ((hi << 3) | (uint32_t)(lane & 7)) << 4;
+  const uint32_t baseR = baseC ^ 0x80u;
+  const uint32_t selC = 0x0c0c0400u | (hi << 8), selR = 0x0c0c0400u | ((hi ^ 1u) << 8);
 
   uint32_t pf_word = 0;
   // Straight-line body: no load is predicated.  Lanes past the last column re-read the
@@ -200,14 +207,14 @@ __global__ __launch_bounds__(kThreads, 4) void gemv_k256_kernel(const K256Params
       constexpr int NU = ROWS * 4;
       u32x4 cv[2][2], rv[2][2];
 #pragma unroll
-      for (int e = 0; e < 2; ++e) gather(iw[sw][0][0], e, baseC, baseR, cv[0][e], rv[0][e]);
+      for (int e = 0; e < 2; ++e) gather(iw[sw][0][0], e, baseC, baseR, selC, selR, cv[0][e], rv[0][e]);
 #pragma unroll
       for (int u = 0; u < NU; ++u) {
         const int r = u >> 2, k = u & 3;
         if (u + 1 < NU) {
 #pragma unroll
           for (int e = 0; e < 2; ++e)
-            gather(iw[sw][(u + 1) >> 2][(u + 1) & 3], e, baseC, baseR, cv[(u + 1) & 1][e],
+            gather(iw[sw][(u + 1) >> 2][(u + 1) & 3], e, baseC, baseR, selC, selR, cv[(u + 1) & 1][e],
                    rv[(u + 1) & 1][e]);
         }
         // stage-major order: the 8 independent pair-chains of the unit advance
