@@ -252,7 +252,7 @@ def test_mfma_kernel_bf16(I, O, kw, dev):
     expect_kernel(m, 1, MFMA | EXACT, "gemv_k256_kernel")
     expect_kernel(m, 1, VALU, "gemv_k256_kernel")
     expect_kernel(m, 1, 0, "gemv_k256m_kernel<fast>" if (O + 31) // 32 >= 32 else "gemv_k256_kernel")
-    expect_kernel(m, 2, 0, "gemv_k256_kernel")
+    expect_kernel(m, 2, 0, "gemv_k256m_kernel<fast>" if (O + 31) // 32 >= 32 else "gemv_k256_kernel")
     got = tensor_to_bits(gemv_abi(m, xt, MFMA))
     assert rel_err(got, want, "bf16") <= TOL["bf16"]
     assert rel_err(tensor_to_bits(gemv_abi(m, xt, VALU)), want, "bf16") <= TOL["bf16"]
@@ -262,6 +262,66 @@ def test_mfma_kernel_bf16(I, O, kw, dev):
         assert torch.equal(gemv_abi(m, xt, MFMA), first)
 
 
+MFMA_TOKEN_CASES = [
+    # I, O, kwargs, tokens
+    (2048, 512, dict(), 2),
+    (1024, 40, dict(bias=True), 3),                   # 5 vector-rows: a partial row group
+    (4104, 64, dict(), 4),                            # tail lanes past G
+    (8192, 96, dict(dist="llm"), 2),
+    (8192, 264, dict(dist="llm", bias=True), 4),
+    (8192 + 512, 40, dict(dist="llm"), 3),            # two staging blocks
+    (11008, 64, dict(dist="llm"), 4),                 # 4 token slots: the widest that fit (1 slot)
+    (14336, 72, dict(dist="llm"), 2),                 # 2 token slots, 7 sweeps
+    (1024, 8 * 4 * 300, dict(dist="llm"), 4),         # 300 row groups on 256 CUs
+    (2048, 520, dict(enable_perm=True, bias=True), 2),
+    (8192 + 8, 136, dict(enable_perm=True, dist="llm"), 4),
+]
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("I,O,kw,tokens", MFMA_TOKEN_CASES)
+def test_mfma_kernel_several_tokens(I, O, kw, tokens, dt, dev):
+    """2-4 activation rows per launch: the MFMA kernel's contraction form (token = row of the
+    4x4x4 block), folded arithmetic, against the oracle and against the VALU kernel; every
+    token row must equal the one-token launch of that row up to the summation order."""
+    kw = dict(kw)
+    dist = kw.pop("dist", "ref-test")
+    L = vo.make_layer(I, O, dist=dist, seed=I + O + tokens, dtype=dt, **kw)
+    rng = np.random.default_rng(tokens)
+    xs = (0.02 + 0.5 * rng.standard_normal((1, tokens, I))) if dist == "ref-test" \
+        else rng.standard_normal((1, tokens, I))
+    x = vo.from_f32(xs.astype(np.float32), dt)
+    m = spec_to_module(L, dev)
+    xt = bits_to_tensor(x, dt, dev).reshape(x.shape)
+    want = vo.forward(L, x)
+    expect_kernel(m, tokens, MFMA, "gemv_k256m_kernel<fast>")
+    expect_kernel(m, tokens, MFMA | EXACT, "gemv_k256_kernel")   # exact form: VALU kernel
+    got_t = gemv_abi(m, xt, MFMA)
+    got = tensor_to_bits(got_t)
+    assert got.shape == want.shape
+    assert rel_err(got, want, dt) <= TOL[dt]
+    assert rel_err(got, tensor_to_bits(gemv_abi(m, xt, VALU)), dt) <= TOL[dt]
+    for t in range(tokens):
+        one = tensor_to_bits(gemv_abi(m, xt[:, t:t + 1].contiguous(), MFMA))
+        assert rel_err(got[:, t:t + 1], one, dt) <= TOL[dt]   # summation order: an ulp at most
+    for _ in range(5):
+        assert torch.equal(gemv_abi(m, xt, MFMA), got_t)
+
+
+def test_mfma_kernel_several_tokens_limits(dev):
+    """Where the token slots do not fit beside the codebook image the VALU kernel serves."""
+    Lw = vo.make_layer(14336, 64, dist="llm", seed=5)
+    wide = spec_to_module(Lw, dev)
+    expect_kernel(wide, 2, MFMA, "gemv_k256m_kernel<fast>")
+    expect_kernel(wide, 4, MFMA, "gemv_k256_kernel")              # 4 x 28 KiB of activations
+    wider = spec_to_module(vo.make_layer(16384, 64, dist="llm", seed=6), dev)
+    expect_kernel(wider, 1, MFMA, "gemv_k256m_kernel<fast>")      # unstaged: one token only
+    expect_kernel(wider, 2, MFMA, "gemv_k256_kernel<fast>")
+    x = vo.from_f32(np.random.default_rng(4).standard_normal((1, 4, 14336)).astype(np.float32), "f16")
+    got = tensor_to_bits(gemv_abi(wide, bits_to_tensor(x, "f16", dev).reshape(x.shape), MFMA))
+    assert rel_err(got, vo.forward(Lw, x), "f16") <= 1e-3
+
+
 def test_mfma_kernel_is_the_default_for_large_launches(dev):
     """From 144 row groups of 4 vector-rows on (where the VALU kernel needs a second round of
     workgroups), in both arithmetic forms, one token."""
@@ -269,7 +329,9 @@ def test_mfma_kernel_is_the_default_for_large_launches(dev):
     m = spec_to_module(L, dev)
     expect_kernel(m, 1, 0, "gemv_k256m_kernel<fast>")
     expect_kernel(m, 1, EXACT, "gemv_k256m_kernel")
-    expect_kernel(m, 2, 0, "gemv_k256_kernel<fast>")          # one token only
+    expect_kernel(m, 2, 0, "gemv_k256m_kernel<fast>")         # several tokens: folded form only
+    expect_kernel(m, 4, 0, "gemv_k256m_kernel<fast>")
+    expect_kernel(m, 4, EXACT, "gemv_k256_kernel")
     small = spec_to_module(vo.make_layer(1024, 4096, dist="llm", seed=78), dev)
     expect_kernel(small, 1, 0, "gemv_k256_kernel<fast>")
     x = vo.from_f32(np.random.default_rng(3).standard_normal((1, 1, 1024)).astype(np.float32), "f16")

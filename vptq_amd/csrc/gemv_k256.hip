@@ -392,8 +392,7 @@ static K256Choice choose_kernel(const VptqLayerDesc* descs, int n, int tokens, i
   }
   const int tok = tokens > 2 ? 4 : tokens;
   const bool f16 = descs[0].dtype == VPTQ_DTYPE_F16;
-  // the folded-arithmetic instantiations exist for 1-2 tokens
-  const bool want_fast = tok <= 2 && !(flags & VPTQ_GEMV_EXACT);
+  const bool exact = (flags & VPTQ_GEMV_EXACT) != 0;
   int max_cols = 0;
   bool same_cols = true, perm = false;
   long long row_groups = 0;
@@ -404,12 +403,16 @@ static K256Choice choose_kernel(const VptqLayerDesc* descs, int n, int tokens, i
     perm = perm || descs[i].perm != nullptr;
     row_groups += gemv_k256m_row_groups(descs[i].num_indices);
   }
-  K256Choice c = {false, f16 && want_fast};  // VALU kernel: folded form for fp16 only
+  // VALU kernel: its folded-arithmetic instantiations exist for fp16, 1-2 tokens
+  K256Choice c = {false, f16 && tok <= 2 && !exact};
   if (same_cols && forced != 1 && !(flags & VPTQ_GEMV_FORCE_VALU) &&
-      gemv_k256m_supported(tok, f16, want_fast, max_cols, perm)) {
+      gemv_k256m_supported(tok, f16, !exact, max_cols, perm)) {
+    // fp16: from 144 row groups on (where the VALU kernel needs a second round of workgroups;
+    // below, its shorter prologue wins - 4096^2, 2 tokens: 6.0 vs 6.9 us).  bf16: the VALU
+    // kernel runs widened arithmetic, the MFMA kernel's folded form is dtype agnostic.
     const long long threshold = f16 ? 144 : 32;
     if (forced == 2 || (flags & VPTQ_GEMV_FORCE_MFMA) || row_groups >= threshold)
-      c = {true, want_fast};
+      c = {true, !exact};
   }
   return c;
 }

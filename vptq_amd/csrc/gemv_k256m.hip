@@ -52,8 +52,7 @@ constexpr int kMSweepCols = kMWaves * 16 * 8;  // 2048: 16 blocks (column chunks
 constexpr int kMTableBytes = 65536;  // 256 rows x (8 main + 8 residual replicas) x 16 B
 constexpr int kMMaxLds = 163840;   // 160 KiB per CU
 constexpr int kMMaxCols = 14336;   // staged activations must fit beside the image
-constexpr int kMRedSlot = kMWaves * 32 * 4;   // one row group's cross-wave partials
-constexpr int kMRedFixed = kMWaves * 4 + 64;  // sum b * x per wave + slot counters
+constexpr int kMRedSlot = kMWaves * 32 * 4;   // one row group's cross-wave partials, per token
 constexpr int kMMaxSlots = 4;
 
 static __device__ __forceinline__ u32x4 ldg16(const void* base, uint32_t byte_off) {
@@ -69,7 +68,7 @@ static __device__ __forceinline__ void q_load(u32x4& dst, const void* sbase, uin
   dst = *(const u32x4*)as_global((const char*)sbase + voff);
 }
 
-template <typename DT, int NS, int NST, bool PERM, bool FAST>
+template <typename DT, int NS, int NST, bool PERM, bool FAST, int TOK>
 __global__ __launch_bounds__(kMThreads) void gemv_k256m_kernel(const K256Params P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   {
@@ -92,6 +91,10 @@ __global__ __launch_bounds__(kMThreads) void gemv_k256m_kernel(const K256Params 
   // column blocks of NS sweeps, and the folded form only.
   constexpr bool STAGE = NST > 0;
   static_assert(STAGE || FAST, "the unstaged variant exists for the folded arithmetic only");
+  // TOK = 2 / 4: up to TOK activation rows per launch (folded form, staged).  The MFMA is then a
+  // real contraction - see sweep() - and costs the same for 2, 3 or 4 tokens.
+  static_assert(TOK == 1 || TOK == 2 || TOK == 4, "token slots");
+  static_assert(TOK == 1 || (STAGE && FAST), "several tokens: folded form, staged activations");
   constexpr int NQ = (FAST && STAGE) ? 1 : NS;  // queue slots for scale + (exact: bias | unstaged: x)
 
   // layer = blockIdx.y; all kernel arguments in one batch of scalar loads (k256.h)
@@ -134,14 +137,15 @@ __global__ __launch_bounds__(kMThreads) void gemv_k256m_kernel(const K256Params 
   const uint32_t selB[2] = {j == 2 ? 0x0c0c0504u : j == 3 ? 0x05040c0cu : 0x0c0c0c0cu,
                             j == 2 ? 0x0c0c0706u : j == 3 ? 0x07060c0cu : 0x0c0c0c0cu};
 
-  // LDS map: [0, 128 KiB) codebook image | G staged activations + 8 zeros (the operand of
-  // columns past G) + a 16-byte dump slot | cross-wave scratch
+  // LDS map: [0, 64 KiB) codebook image | per token: G staged activations + 8 zeros (the
+  // operand of columns past G) + a 16-byte dump slot | cross-wave scratch
   const uint32_t xs_off = kMTableBytes;
-  const uint32_t red_off = xs_off + (STAGE ? (uint32_t)G * 2u + 32u : 0u);
-  float* const red_b = (float*)(smem + red_off);        // [kMWaves]: sum b * x per wave
-  uint32_t* const slot_cnt = (uint32_t*)(red_b + kMWaves);   // [kMMaxSlots] waves that have arrived
+  const uint32_t xs_stride = (uint32_t)G * 2u + 32u;
+  const uint32_t red_off = xs_off + (STAGE ? TOK * xs_stride : 0u);
+  float* const red_b = (float*)(smem + red_off);        // [TOK][kMWaves]: sum b * x per wave
+  uint32_t* const slot_cnt = (uint32_t*)(red_b + TOK * kMWaves);  // [kMMaxSlots] waves that have arrived
   uint32_t* const slot_done = slot_cnt + kMMaxSlots;         // [kMMaxSlots] row groups finished + 1
-  float* const red = (float*)(slot_done + kMMaxSlots + 8);   // [K][kMWaves][32]
+  float* const red = (float*)(slot_done + kMMaxSlots + 8);   // [K][TOK][kMWaves][32]
   const int K = Ly.slots;  // partial-sum slots that fit into LDS (1..kMMaxSlots, host)
 
   // ---- 2. the index queue: slot s holds sweep s (2048 columns x 4 rows, 16 bytes per lane)
@@ -179,7 +183,7 @@ __global__ __launch_bounds__(kMThreads) void gemv_k256m_kernel(const K256Params 
   {
     constexpr int kStageCols = kMThreads * 8;
     constexpr int kSt = NST > 0 ? NST : 1;
-    u32x4 st_x[kSt], st_s[kSt], st_b[kSt], centry;
+    u32x4 st_x[kSt][TOK], st_s[kSt], st_b[kSt], centry;
     u32x4 st_pv[PERM ? kSt : 1];  // PERM: 8 input-feature numbers (uint16) per staged chunk
     const char* const c0 = (const char*)Ly.cent;
     const uint32_t cent_off = (uint32_t)((tid >> 1) & 255) * 16u;
@@ -203,7 +207,11 @@ __global__ __launch_bounds__(kMThreads) void gemv_k256m_kernel(const K256Params 
           q_load(st_s[k], sp, off);
           q_load(st_b[k], bp, off);
         }
-        q_load(st_x[k], Ly.x, off);  // PERM: x in its own order, permuted through LDS below
+        // PERM: x in its own order, permuted through LDS below.  Token slots past `tokens`
+        // repeat the last row (their outputs are not stored).
+#pragma unroll
+        for (int t = 0; t < TOK; ++t)
+          q_load(st_x[k][t], (const char*)Ly.x + (size_t)(t < tokens ? t : tokens - 1) * (size_t)G * 2u, off);
       }
       __builtin_amdgcn_sched_barrier(0);
       write_image();
@@ -221,52 +229,65 @@ __global__ __launch_bounds__(kMThreads) void gemv_k256m_kernel(const K256Params 
 #pragma unroll
       for (int k = 0; k < NST; ++k) {
         const int want = k * kStageCols + tid * 8;
-        lds_store16(xs_off + (uint32_t)(want < G ? want : G + 8) * 2u, st_x[k]);
+#pragma unroll
+        for (int t = 0; t < TOK; ++t)
+          lds_store16(xs_off + t * xs_stride + (uint32_t)(want < G ? want : G + 8) * 2u, st_x[k][t]);
       }
       __syncthreads();
       typedef __attribute__((address_space(3))) const uint16_t lds_u16_t;
 #pragma unroll
       for (int k = 0; k < NST; ++k)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const uint32_t lo = *(lds_u16_t*)(uintptr_t)(xs_off + (st_pv[k][q] & 0xffffu) * 2u);
-          const uint32_t hi = *(lds_u16_t*)(uintptr_t)(xs_off + (st_pv[k][q] >> 16) * 2u);
-          st_x[k][q] = lo | (hi << 16);
-        }
+        for (int t = 0; t < TOK; ++t)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const uint32_t xt = xs_off + t * xs_stride;
+            const uint32_t lo = *(lds_u16_t*)(uintptr_t)(xt + (st_pv[k][q] & 0xffffu) * 2u);
+            const uint32_t hi = *(lds_u16_t*)(uintptr_t)(xt + (st_pv[k][q] >> 16) * 2u);
+            st_x[k][t][q] = lo | (hi << 16);
+          }
       __syncthreads();  // every thread has its activations: the area may be overwritten
     }
-    float accb = 0.f;
+    float accb[TOK];
+#pragma unroll
+    for (int t = 0; t < TOK; ++t) accb[t] = 0.f;
 #pragma unroll
     for (int k = 0; k < NST; ++k) {
       const int want = k * kStageCols + tid * 8;
       const bool valid = want < G;
       // columns past G: x = 0 (adds nothing to sum b * x), the store goes to the dump slot
       const uint32_t keep = valid ? 0xffffffffu : 0u;
-      u32x4 v = st_x[k];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) v[q] &= keep;
-      if (FAST) {
+      for (int t = 0; t < TOK; ++t) {
+        u32x4 v = st_x[k][t];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          accb = DT::dot2(v[q], st_b[k][q], accb);  // sum b * x
-          v[q] = DT::mul2(v[q], st_s[k][q]);        // f16(s * x)
+        for (int q = 0; q < 4; ++q) v[q] &= keep;
+        if (FAST) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            accb[t] = DT::dot2(v[q], st_b[k][q], accb[t]);  // sum b * x
+            v[q] = DT::mul2(v[q], st_s[k][q]);              // f16(s * x)
+          }
         }
+        lds_store16(xs_off + t * xs_stride + (uint32_t)(valid ? want : G + 8) * 2u, v);
       }
-      lds_store16(xs_off + (uint32_t)(valid ? want : G + 8) * 2u, v);
     }
     if (!STAGE) {
       // the queue carries x and scale but not the bias: sum b * x in one pass over the columns
       for (int c = tid * 8; c < G; c += kStageCols) {
         const u32x4 xv = ldg16(Ly.x, (uint32_t)c * 2u), bv = ldg16(bp, (uint32_t)c * 2u);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) accb = DT::dot2(xv[q], bv[q], accb);
+        for (int q = 0; q < 4; ++q) accb[0] = DT::dot2(xv[q], bv[q], accb[0]);
       }
     }
-    if (STAGE && tid == 0) lds_store16(xs_off + (uint32_t)G * 2u, u32x4{0, 0, 0, 0});
+    if (STAGE && tid < TOK) lds_store16(xs_off + tid * xs_stride + (uint32_t)G * 2u, u32x4{0, 0, 0, 0});
     if (tid < 2 * kMMaxSlots) slot_cnt[tid] = 0u;
     if (FAST) {
-      const float sum = wave_sum(accb);
-      if (lane == 0) red_b[wave] = sum;
+#pragma unroll
+      for (int t = 0; t < TOK; ++t) {
+        const float sum = wave_sum(accb[t]);
+        if (lane == 0) red_b[t * kMWaves + wave] = sum;
+      }
     }
   }
   __builtin_amdgcn_sched_barrier(0);  // nothing that waits for index words above the barrier
@@ -286,9 +307,66 @@ __global__ __launch_bounds__(kMThreads) void gemv_k256m_kernel(const K256Params 
 #ifndef VPTQ_K256M_CACHE_XO
 #define VPTQ_K256M_CACHE_XO 1
 #endif
-  constexpr bool kCacheXo = VPTQ_K256M_CACHE_XO && FAST && STAGE && NS <= 4;
+  constexpr bool kCacheXo = VPTQ_K256M_CACHE_XO && FAST && STAGE && NS <= 4 && TOK == 1;
   u32x2 xo_cache[kCacheXo ? NS : 1][8];
-  auto sweep = [&](auto first_c, int s, int cb, f32x4& acc0, f32x4& acc1) {
+  // one token: acc.a[0 / 1][i] = output 0-3 / 4-7 of this lane's vector-row; several tokens:
+  // acc.a[e][t] = output e of this lane's vector-row for token t
+  struct Acc { f32x4 a[TOK == 1 ? 2 : 8]; };
+  // Several tokens (TOK = 2 / 4): here the 4x4x4 MFMA is a real contraction.  Lane i of a block
+  // supplies token i's f16(s * x) of TWO columns, twice (A row i = {x'[c0], x'[c1], x'[c0],
+  // x'[c1]}); lane j supplies, for ONE output element e, {W_A[c0][e], W_A[c1][e], W_B[c0][e],
+  // W_B[c1][e]} of ITS vector-row (W_A / W_B = the two gathers of an index, i.e. main and
+  // residual entry in either order).  D[i][j] += x'_i[c0] (c + r)[c0][e] + x'_i[c1] (c + r)[c1][e]:
+  // lane j accumulates output e of its row for all four tokens.  The gathered entries hold 8
+  // elements of one column, the operand wants one element of 2 columns: 8 v_perm_b32 per
+  // index transpose them; with the 2 address perms that is 10 VALU + 4 MFMA per index for up to
+  // four tokens (one token: 2-4 VALU + 4 MFMA).
+  auto sweep_tokens = [&](int s, Acc& acc) {
+    const int want = s * kMSweepCols + lane_cols;
+    // this lane supplies the activations of token j (slots past TOK: the last one; unused rows)
+    const uint32_t xt = xs_off + (uint32_t)(j < TOK ? j : TOK - 1) * xs_stride;
+    const u32x4 xq = lds_load16(xt + (uint32_t)(want < G ? want : G) * 2u);  // past G: zeros
+    const u32x4 words = iw[s];
+    u32x4 ga[2][2], gb[2][2];  // [pair parity][column of the pair]
+    auto gather_pair = [&](int p) {
+      const uint32_t w = words[p];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        ga[p & 1][h] = lds_load16(__builtin_amdgcn_perm(w, baseA, selGA[h]));
+        gb[p & 1][h] = lds_load16(__builtin_amdgcn_perm(w, baseB, selGB[h]));
+      }
+    };
+    gather_pair(0);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (p + 1 < 4) gather_pair(p + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      const u32x2 xa = u32x2{xq[p], xq[p]};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint32_t a0 = ga[p & 1][0][q], a1 = ga[p & 1][1][q];
+        const uint32_t b0 = gb[p & 1][0][q], b1 = gb[p & 1][1][q];
+        // elements 2q (low halves) and 2q + 1 (high halves) of the pair's two columns
+        const u32x2 wlo = u32x2{__builtin_amdgcn_perm(a1, a0, 0x05040100u),
+                                __builtin_amdgcn_perm(b1, b0, 0x05040100u)};
+        const u32x2 whi = u32x2{__builtin_amdgcn_perm(a1, a0, 0x07060302u),
+                                __builtin_amdgcn_perm(b1, b0, 0x07060302u)};
+        constexpr int kE = TOK == 1 ? 0 : 2;  // (never run with one token)
+        acc.a[kE * q] = DT::mfma4(xa, wlo, acc.a[kE * q]);
+        acc.a[kE * q + kE / 2] = DT::mfma4(xa, whi, acc.a[kE * q + kE / 2]);
+        // (fenced: the scheduler would transpose the whole pair first - 12 more live registers)
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+  auto sweep = [&](auto first_c, int s, int cb, Acc& acc) {
+    if constexpr (TOK > 1) {
+      sweep_tokens(s, acc);
+      return;
+    }
+    f32x4& acc0 = acc.a[0];
+    f32x4& acc1 = acc.a[1];
     constexpr bool kBuild = !kCacheXo || decltype(first_c)::value;
     const int want = (cb * NS + s) * kMSweepCols + lane_cols;
     u32x4 xq = u32x4{0, 0, 0, 0};
@@ -367,24 +445,33 @@ __global__ __launch_bounds__(kMThreads) void gemv_k256m_kernel(const K256Params 
   // into slot q % K (q = how many row groups this workgroup has finished) and bumps the slot's
   // LDS counter; the wave that arrives last sums the 16 x 32 partials, stores the 32 outputs
   // and releases the slot.  A wave only waits when it is K row groups ahead of the slowest.
-  auto finish = [&](int rg, int q, const f32x4& acc0, const f32x4& acc1) {
-    float v[8];
+  auto finish = [&](int rg, int q, const Acc& acc) {
+    // v[e * TOK + t]: output e of this lane's vector-row, token t
+    constexpr int NV = 8 * TOK;
+    float v[NV];
+    if constexpr (TOK == 1) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { v[i] = acc0[i]; v[4 + i] = acc1[i]; }
+      for (int i = 0; i < 4; ++i) { v[i] = acc.a[0][i]; v[4 + i] = acc.a[1][i]; }
+    } else {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 4]),
+      for (int e = 0; e < 8; ++e)
+#pragma unroll
+        for (int t = 0; t < TOK; ++t) v[e * TOK + t] = acc.a[e][t];
+    }
+#pragma unroll
+    for (int i = 0; i < NV / 2; ++i) {
+      auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(v[i + NV / 2]),
                                                 false, false);
       v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 2]),
+    for (int i = 0; i < NV / 4; ++i) {
+      auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[i]), __float_as_uint(v[i + NV / 4]),
                                                 false, false);
       v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) v[i] = row_ror_add<4>(row_ror_add<8>(v[i]));
+    for (int i = 0; i < NV / 4; ++i) v[i] = row_ror_add<4>(row_ror_add<8>(v[i]));
     const int slot = q % K;
     if (q >= K) {
       // the slot's previous user (row group number q - K of this workgroup) must be stored
@@ -392,11 +479,14 @@ __global__ __launch_bounds__(kMThreads) void gemv_k256m_kernel(const K256Params 
              (uint32_t)(q - K + 1))
         __builtin_amdgcn_s_sleep(2);
     }
-    float* const rs = red + slot * (kMWaves * 32);
+    float* const rs = red + slot * (TOK * kMWaves * 32);  // [TOK][kMWaves][32]
     if ((lane & 12) == 0) {
       const int o8 = ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2;
-      rs[wave * 32 + j * 8 + o8] = v[0];
-      rs[wave * 32 + j * 8 + o8 + 1] = v[1];
+#pragma unroll
+      for (int t = 0; t < TOK; ++t) {
+        rs[(t * kMWaves + wave) * 32 + j * 8 + o8] = v[t];
+        rs[(t * kMWaves + wave) * 32 + j * 8 + o8 + 1] = v[TOK + t];
+      }
     }
     uint32_t arrived = 0;
     if (lane == 0)
@@ -407,15 +497,18 @@ __global__ __launch_bounds__(kMThreads) void gemv_k256m_kernel(const K256Params 
       if (lane < 32) {
         const int row = rg * kMRows + (lane >> 3);
         const int o = row * 8 + (lane & 7);
-        float sum = 0.f;
 #pragma unroll
-        for (int w = 0; w < kMWaves; ++w) {
-          sum += rs[w * 32 + lane];
-          if (FAST) sum += red_b[w];
-        }
-        if (row < N && o < O) {
-          if (Ly.bias) sum += DT::to_float(as_global(Ly.bias)[o]);
-          as_global(Ly.y)[o] = DT::from_float(sum);
+        for (int t = 0; t < TOK; ++t) {
+          float sum = 0.f;
+#pragma unroll
+          for (int w = 0; w < kMWaves; ++w) {
+            sum += rs[(t * kMWaves + w) * 32 + lane];
+            if (FAST) sum += red_b[t * kMWaves + w];
+          }
+          if (row < N && o < O && t < tokens) {
+            if (Ly.bias) sum += DT::to_float(as_global(Ly.bias)[o]);
+            as_global(Ly.y)[(size_t)t * O + o] = DT::from_float(sum);
+          }
         }
       }
       if (lane == 0) {
@@ -433,13 +526,12 @@ __global__ __launch_bounds__(kMThreads) void gemv_k256m_kernel(const K256Params 
   // so D - 1 younger sweeps are in flight behind the one being waited for.  The sched_barriers
   // keep load issue, gathers and arithmetic in this order (without them the scheduler hoists
   // loads and gathers until the kernel spills).
-  auto cblock = [&](auto first_c, auto last_c, int rg, int cb, int next_rg, int next_cb, f32x4& acc0,
-                    f32x4& acc1) {
+  auto cblock = [&](auto first_c, auto last_c, int rg, int cb, int next_rg, int next_cb, Acc& acc) {
     constexpr bool LAST = decltype(last_c)::value;
 #define K256M_STEP(S)                                                                          \
   if constexpr (S < NS) {                                                                      \
     __builtin_amdgcn_sched_barrier(0);                                                         \
-    sweep(first_c, S, cb, acc0, acc1);                                                         \
+    sweep(first_c, S, cb, acc);                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                         \
     if constexpr (S + D < NS) issue_sweep(S + D, rg, cb);                                      \
     else if constexpr (!LAST) issue_sweep(S + D - NS, next_rg, next_cb);                       \
@@ -452,11 +544,13 @@ __global__ __launch_bounds__(kMThreads) void gemv_k256m_kernel(const K256Params 
   using no_t = std::integral_constant<bool, false>;
   auto row_group = [&](auto first_c, auto last_c, int rg, int q) {
     constexpr bool LAST = decltype(last_c)::value;
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    for (int cb = 0; cb + 1 < n_cblocks; ++cb) cblock(first_c, no_t{}, rg, cb, rg, cb + 1, acc0, acc1);
-    cblock(first_c, last_c, rg, n_cblocks - 1, rg + step, 0, acc0, acc1);
-    if (LAST) K256_STAMP(kMWaves, 3, acc0[0] + acc1[0]);
-    finish(rg, q, acc0, acc1);
+    Acc acc;
+#pragma unroll
+    for (int i = 0; i < (TOK == 1 ? 2 : 8); ++i) acc.a[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int cb = 0; cb + 1 < n_cblocks; ++cb) cblock(first_c, no_t{}, rg, cb, rg, cb + 1, acc);
+    cblock(first_c, last_c, rg, n_cblocks - 1, rg + step, 0, acc);
+    if (LAST) K256_STAMP(kMWaves, 3, acc.a[0][0] + acc.a[1][0]);
+    finish(rg, q, acc);
   };
   using yes = std::integral_constant<bool, true>;
   using no = std::integral_constant<bool, false>;
@@ -497,19 +591,19 @@ static int device_cus() {
   return cus[dev];
 }
 
-// LDS bytes before the partial-sum slots: image + staged activations (0 columns: unstaged) +
-// per-wave sum b * x + slot counters
-static int lds_fixed_bytes(int staged_cols) {
-  return kMTableBytes + (staged_cols > 0 ? staged_cols * 2 + 32 : 0) + kMRedFixed;
+// LDS bytes before the partial-sum slots: image + per token the staged activations (0 columns:
+// unstaged) and the per-wave sum b * x + slot counters
+static int lds_fixed_bytes(int staged_cols, int tok) {
+  return kMTableBytes + (staged_cols > 0 ? tok * (staged_cols * 2 + 32) : 0) + tok * kMWaves * 4 + 64;
 }
 
-template <typename DT, int NS, int NST, bool PERM, bool FAST>
+template <typename DT, int NS, int NST, bool PERM, bool FAST, int TOK>
 static hipError_t launch_m(const K256Params& P, int gx, int max_cols, hipStream_t st) {
-  auto kern = gemv_k256m_kernel<DT, NS, NST, PERM, FAST>;
-  const int fixed = lds_fixed_bytes(NST > 0 ? max_cols : 0);
+  auto kern = gemv_k256m_kernel<DT, NS, NST, PERM, FAST, TOK>;
+  const int fixed = lds_fixed_bytes(NST > 0 ? max_cols : 0, TOK);
   const int slots = P.layer[0].slots;  // set by launch_gemv_k256m
   if (slots < 1 || slots > kMMaxSlots) return hipErrorInvalidValue;
-  const int lds = fixed + slots * kMRedSlot;
+  const int lds = fixed + slots * kMRedSlot * TOK;
   if (lds > kMMaxLds) return hipErrorInvalidValue;
   static bool attr_set[64] = {};
   int dev = 0;
@@ -524,33 +618,44 @@ static hipError_t launch_m(const K256Params& P, int gx, int max_cols, hipStream_
   return hipGetLastError();
 }
 
-template <typename DT, bool FAST>
+template <typename DT, bool FAST, int TOK>
 static hipError_t launch_m_shape(const K256Params& P, int gx, bool perm, int max_cols,
                                  hipStream_t st) {
   if (max_cols > kMMaxCols) {
     // wider than the LDS can stage: column blocks of 2 sweeps, scale and x through the queue
-    if constexpr (FAST) {
-      if (!perm) return launch_m<DT, 2, 0, false, true>(P, gx, max_cols, st);
+    if constexpr (FAST && TOK == 1) {
+      if (!perm) return launch_m<DT, 2, 0, false, true, 1>(P, gx, max_cols, st);
     }
     return hipErrorInvalidValue;
   }
   const int ns = (max_cols + kMSweepCols - 1) / kMSweepCols;
-#define K256M_CASE(S, N)                                                          \
-  if (ns == S) return perm ? launch_m<DT, S, N, true, FAST>(P, gx, max_cols, st)  \
-                           : launch_m<DT, S, N, false, FAST>(P, gx, max_cols, st);
+#define K256M_CASE(S, N)                                                               \
+  if (ns == S) return perm ? launch_m<DT, S, N, true, FAST, TOK>(P, gx, max_cols, st)  \
+                           : launch_m<DT, S, N, false, FAST, TOK>(P, gx, max_cols, st);
   K256M_CASE(1, 1) K256M_CASE(2, 1) K256M_CASE(3, 1) K256M_CASE(4, 1)
   K256M_CASE(5, 2) K256M_CASE(6, 2) K256M_CASE(7, 2)
 #undef K256M_CASE
   return hipErrorInvalidValue;
 }
 
+// partial-sum slots that fit beside everything else (0: the shape does not fit at all)
+static int lds_slots(int tok, int max_cols) {
+  const int left = kMMaxLds - lds_fixed_bytes(max_cols > kMMaxCols ? 0 : max_cols, tok);
+  const int slots = left < 0 ? 0 : left / (kMRedSlot * tok);
+  return slots > kMMaxSlots ? kMMaxSlots : slots;
+}
+
+// tok = token slots of the instantiation (1, 2 or 4)
 bool gemv_k256m_supported(int tok, bool f16, bool fast, int max_cols, bool perm) {
   // the exact form queues scale and bias with the index words: 6 and 7 sweeps spill
   if (!fast && max_cols > 5 * kMSweepCols) return false;
   // more columns than fit beside the image: unstaged variant (folded form, no permutation)
-  if (max_cols > kMMaxCols && (!fast || perm)) return false;
+  if (max_cols > kMMaxCols && (!fast || perm || tok > 1)) return false;
+  // several tokens: folded form, one staged copy of the activations per token slot
+  if (tok != 1 && !((tok == 2 || tok == 4) && fast)) return false;
+  if (lds_slots(tok, max_cols) < 1) return false;
   // bf16: folded form only (its exact form would run the widened arithmetic on the VALU)
-  return tok == 1 && (f16 || fast);
+  return f16 || fast;
 }
 
 int gemv_k256m_row_groups(int n_rows) { return (n_rows + kMRows - 1) / kMRows; }
@@ -573,13 +678,19 @@ hipError_t launch_gemv_k256m(K256Params& P, int tok, bool f16, bool fast, int ma
     if (share < 1) share = 1;
     if (share > groups) share = groups;
     P.layer[i].wgs = (int)share;
-    const int slots = (kMMaxLds - lds_fixed_bytes(max_cols > kMMaxCols ? 0 : max_cols)) / kMRedSlot;
-    P.layer[i].slots = slots > kMMaxSlots ? kMMaxSlots : slots;
+    P.layer[i].slots = lds_slots(tok, max_cols);
     gx = (int)share > gx ? (int)share : gx;
   }
-  if (!f16) return launch_m_shape<BF16, true>(P, gx, perm, max_cols, st);
-  return fast ? launch_m_shape<F16, true>(P, gx, perm, max_cols, st)
-              : launch_m_shape<F16, false>(P, gx, perm, max_cols, st);
+  if (tok == 1) {
+    if (!f16) return launch_m_shape<BF16, true, 1>(P, gx, perm, max_cols, st);
+    return fast ? launch_m_shape<F16, true, 1>(P, gx, perm, max_cols, st)
+                : launch_m_shape<F16, false, 1>(P, gx, perm, max_cols, st);
+  }
+  if (tok == 2)
+    return f16 ? launch_m_shape<F16, true, 2>(P, gx, perm, max_cols, st)
+               : launch_m_shape<BF16, true, 2>(P, gx, perm, max_cols, st);
+  return f16 ? launch_m_shape<F16, true, 4>(P, gx, perm, max_cols, st)
+             : launch_m_shape<BF16, true, 4>(P, gx, perm, max_cols, st);
 }
 
 }  // namespace vptq
