@@ -83,7 +83,9 @@ enum {
   VPTQ_GEMV_FORCE_VALU = 1 << 4
 };
 
-#define VPTQ_GEMV_MAX_TOKENS 8
+/* most tokens vptq_quant_gemv accepts; whether the fused GEMV is also the FASTER path for a
+ * layer at a token count is what vptq_quant_gemv_max_tokens() answers */
+#define VPTQ_GEMV_MAX_TOKENS 16
 
 /*
  * One VQuantLinear layer in the reference's on-disk tensor formats
@@ -173,6 +175,15 @@ VPTQ_API int vptq_quant_gemv(const VptqLayerDesc* desc, const void* x, void* y, 
                     int flags, void* workspace, size_t workspace_bytes, void* stream);
 
 VPTQ_API size_t vptq_quant_gemv_workspace_bytes(const VptqLayerDesc* desc, int tokens, int flags);
+
+/*
+ * Largest token count for which vptq_quant_gemv is the path to take for this layer; above it
+ * vptq_dequant + a dense GEMM is faster (the reference switches at 3 for every format,
+ * vptq/ops/quant_gemm.py:213).  16 for the canonical v=8 / 256+256 format (its kernels take 4
+ * tokens per launch at 1.3-1.5x the cost of one; measured crossover 20-24 tokens,
+ * tools/tokens_crossover.py), 8 for every other format.  0 if desc is invalid.
+ */
+VPTQ_API int vptq_quant_gemv_max_tokens(const VptqLayerDesc* desc);
 
 /*
  * n independent layers in ONE launch (q/k/v or gate/up projections of a decoder

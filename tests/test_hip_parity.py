@@ -15,7 +15,7 @@ import torch
 from oracle import vptq_oracle as vo
 from _cases import golden_names, load_golden, rel_err, bit_identical_frac
 from _gpu_util import (spec_to_module, bits_to_tensor, tensor_to_bits, gemv_abi, kernel_name,
-                       TORCH_DT)
+                       module_desc, TORCH_DT)
 
 pytestmark = pytest.mark.gpu
 TOL = {"f16": 1e-3, "bf16": 8e-3}
@@ -126,16 +126,27 @@ def test_gemv_and_dequant_vs_oracle(I, O, kw, tokens, dev):
     assert err <= TOL[dt], f"{err:.3e}"
 
 
-@pytest.mark.parametrize("tokens", [1, 2, 3, 4, 5, 8, 9, 33])
-def test_token_counts_gemv_and_gemm_paths(tokens, dev):
-    """1..8 tokens: fused GEMV; more: dequant + F.linear (reference switches at 3)."""
-    L = vo.make_layer(1024, 256, dist="llm", seed=11, bias=True)
+@pytest.mark.parametrize("k", [256, 65536])
+@pytest.mark.parametrize("tokens", [1, 2, 3, 4, 5, 8, 9, 13, 16, 17, 33])
+def test_token_counts_gemv_and_gemm_paths(tokens, k, dev):
+    """1..8 tokens (canonical 256 + 256 format: 1..16): fused GEMV; more: dequant + F.linear (the
+    reference switches at 3).  Module forward and the functional op agree."""
+    from vptq_amd import _backend as B
+    kw = dict(num_res_centroids=256) if k == 256 else dict(num_centroids=65536, num_res_centroids=-1)
+    L = vo.make_layer(1024, 256, dist="llm", seed=11, bias=True, **kw)
     x = vo.from_f32(np.random.default_rng(tokens).standard_normal((2, tokens, 1024))
                     .astype(np.float32), "f16")[:1]
     m = spec_to_module(L, dev)
-    got = tensor_to_bits(m(bits_to_tensor(x, "f16", dev).reshape(x.shape)))
+    desc, keep = module_desc(m)
+    assert B.lib().vptq_quant_gemv_max_tokens(desc) == (16 if k == 256 else 8)
+    xt = bits_to_tensor(x, "f16", dev).reshape(x.shape)
+    got = tensor_to_bits(m(xt))
     want = vo.forward(L, x)
     assert rel_err(got, want, "f16") <= 1e-3
+    if tokens <= 16:   # the C ABI accepts up to 16 tokens for every format
+        assert rel_err(tensor_to_bits(gemv_abi(m, xt, 0)), want, "f16") <= 1e-3
+        if tokens <= (16 if k == 256 else 8):
+            assert (tensor_to_bits(gemv_abi(m, xt, 0)) == got).all()   # forward took the GEMV
 
 
 def test_default_and_exact_arithmetic(dev):

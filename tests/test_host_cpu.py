@@ -75,6 +75,8 @@ def test_validation_errors_without_gpu():
     d.perm = 16
     assert lib.vptq_dequant(d, 16, None) == -1                             # needs inv_perm
     assert lib.vptq_quant_gemv_kernel_name(d, 1, 0) == b"gemv_generic_kernel"
+    assert lib.vptq_quant_gemv_max_tokens(d) == 8                          # not the canonical format
+    assert lib.vptq_quant_gemv_max_tokens(B.LayerDesc()) == 0
     v2 = B.V2Desc()
     assert lib.vptq_quant_gemv_v2(v2, 16, 16, 1, 0, None) == -1
     v2.indices = v2.centroids = 16

@@ -25,7 +25,8 @@ GEMV_FORCE_GENERIC = 1 << 1
 GEMV_EXACT = 1 << 2
 GEMV_FORCE_MFMA = 1 << 3
 GEMV_FORCE_VALU = 1 << 4
-GEMV_MAX_TOKENS = 8
+GEMV_MAX_TOKENS = 16       # what vptq_quant_gemv accepts; per layer: vptq_quant_gemv_max_tokens
+GEMV_ANY_FORMAT_TOKENS = 8  # the fused GEMV is the faster path for every format up to here
 GROUP_MAX = 64
 
 _vp = C.c_void_p
@@ -59,6 +60,7 @@ EXPORTS = {
     "vptq_quant_gemv": (C.c_int, [C.POINTER(LayerDesc), _vp, _vp, C.c_int, C.c_int, _vp,
                                   C.c_size_t, _vp]),
     "vptq_quant_gemv_workspace_bytes": (C.c_size_t, [C.POINTER(LayerDesc), C.c_int, C.c_int]),
+    "vptq_quant_gemv_max_tokens": (C.c_int, [C.POINTER(LayerDesc)]),
     "vptq_quant_gemv_grouped": (C.c_int, [C.POINTER(LayerDesc), C.c_int, C.POINTER(_vp),
                                           C.POINTER(_vp), C.c_int, C.c_int, _vp]),
     "vptq_dequant": (C.c_int, [C.POINTER(LayerDesc), _vp, _vp]),

@@ -93,6 +93,11 @@ const char* vptq_last_error(void) { return g_err; }
 
 size_t vptq_quant_gemv_workspace_bytes(const VptqLayerDesc*, int, int) { return 0; }
 
+int vptq_quant_gemv_max_tokens(const VptqLayerDesc* d) {
+  if (validate_layer(d) != VPTQ_OK) return 0;
+  return vptq::gemv_k256_eligible(*d, 4) ? VPTQ_GEMV_MAX_TOKENS : 8;
+}
+
 const char* vptq_quant_gemv_kernel_name(const VptqLayerDesc* d, int tokens, int flags) {
   if (validate_layer(d) != VPTQ_OK || tokens < 1 || tokens > VPTQ_GEMV_MAX_TOKENS) return nullptr;
   if (!(flags & VPTQ_GEMV_FORCE_GENERIC) && vptq::gemv_k256_eligible(*d, tokens > 4 ? 4 : tokens))
@@ -126,8 +131,8 @@ int vptq_quant_gemv(const VptqLayerDesc* d, const void* x, void* y, int tokens, 
                 VPTQ_GEMV_MAX_TOKENS);
   hipStream_t st = (hipStream_t)stream;
   hipError_t e;
-  // the specialised kernel takes up to 4 tokens per launch; 5..8 tokens = two launches
-  // (still far cheaper than the generic kernel or a dense dequant + GEMM)
+  // the specialised kernels take up to 4 tokens per launch; more tokens = more launches
+  // (up to 16 tokens still cheaper than a dense dequant + GEMM, tools/tokens_crossover.py)
   const int chunk = tokens > 4 ? 4 : tokens;
   if (!(flags & VPTQ_GEMV_FORCE_GENERIC) && vptq::gemv_k256_eligible(*d, chunk) &&
       (((uintptr_t)x) & 15) == 0 && (tokens <= 4 || (d->in_features % 8) == 0)) {
@@ -150,8 +155,12 @@ int vptq_quant_gemv(const VptqLayerDesc* d, const void* x, void* y, int tokens, 
     }
     return VPTQ_OK;
   }
-  e = vptq::launch_gemv_generic(*d, x, y, tokens, st);
-  if (e != hipSuccess) return hip_fail(e, "gemv_generic launch");
+  for (int t0 = 0; t0 < tokens; t0 += 8) {  // the generic kernel takes up to 8 tokens per launch
+    const int m = tokens - t0 < 8 ? tokens - t0 : 8;
+    e = vptq::launch_gemv_generic(*d, (const char*)x + (size_t)t0 * d->in_features * 2,
+                                  (char*)y + (size_t)t0 * d->out_features * 2, m, st);
+    if (e != hipSuccess) return hip_fail(e, "gemv_generic launch");
+  }
   return VPTQ_OK;
 }
 

@@ -231,7 +231,8 @@ class VQuantLinear(nn.Module):
                 "path, which is outside this inference package; construct the layer with "
                 "enable_proxy_error=False (HF does).")
         tokens = x.numel() // x.shape[-1] if x.shape[-1] else 0
-        if 1 <= tokens <= B.GEMV_MAX_TOKENS and x.is_cuda:
+        if 1 <= tokens <= B.GEMV_MAX_TOKENS and x.is_cuda and \
+                (tokens <= B.GEMV_ANY_FORMAT_TOKENS or tokens <= self._descriptor()[5]):
             return self._gemv_cached(x, tokens)
         return ops.quant_gemm(
             x,
@@ -289,7 +290,8 @@ class VQuantLinear(nn.Module):
                 outlier_size=self.outlier_size if self.enable_outlier else 0,
                 outlier_vector_len=self.outlier_vector_len,
                 num_outlier_centroids=self.num_outlier_centroids, prefetch=tensors[9])
-            cache = (key, desc, keep, dev, B.lib().vptq_quant_gemv)
+            cache = (key, desc, keep, dev, B.lib().vptq_quant_gemv,
+                     B.lib().vptq_quant_gemv_max_tokens(desc))
             self.__dict__["_desc_cache"] = cache
         return cache
 
@@ -304,13 +306,13 @@ class VQuantLinear(nn.Module):
         return x if x.is_contiguous() else x.contiguous()
 
     def _gemv_cached(self, x: torch.Tensor, tokens: int) -> torch.Tensor:
-        """Decode fast path: identical to `ops.quant_gemm` for 1..8 tokens with a cached
+        """Decode fast path: identical to `ops.quant_gemm` for 1..8 (canonical format: 16) tokens with a cached
         descriptor; layers linked by `link_siblings` share one grouped launch."""
         group = self.__dict__.get("_siblings")
         if group is not None and tokens <= group.MAX_TOKENS:
             return group.forward(self, x, tokens)
         x = self._check_activation(x)
-        _, desc, _, dev, fn = self._descriptor()
+        _, desc, _, dev, fn, _ = self._descriptor()
         if x.device != dev:
             raise RuntimeError(f"tensors on different devices: {dev} vs {x.device}")
         y = torch.empty(x.shape[:-1] + (self.out_features,), dtype=x.dtype, device=dev)

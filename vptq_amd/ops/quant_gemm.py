@@ -4,7 +4,8 @@ hand-written HIP kernels through the C ABI in include/vptq_hip.h.
 
 Differences from the reference, on purpose:
 * no torch fallback — a missing library or a CPU tensor raises;
-* the fused GEMV serves 1..8 tokens (the reference: < 3, quant_gemm.py:213)
+* the fused GEMV serves 1..8 tokens, the canonical 256+256 format 1..16 (`vptq_quant_gemv_max_tokens`;
+  the reference: < 3, quant_gemm.py:213)
   because one workgroup reuses each rebuilt weight for every token, the
   kernel stays HBM-bound; above that, dequant + `F.linear` (hipBLASLt);
 * `argsort(perm)` is cached instead of recomputed per call (quant_gemm.py:208-211).
@@ -147,6 +148,7 @@ def quant_gemm(
     dev = B.require_device(x, bias, indices, centroids, outlier_indices, outlier_centroids,
                            residual_centroids, perm, weight_scale, weight_bias)
 
+    desc = None
     if 1 <= tokens <= B.GEMV_MAX_TOKENS:
         desc, keep = B.make_layer_desc(
             indices=indices, centroids=centroids, res_centroids=residual_centroids,
@@ -158,6 +160,9 @@ def quant_gemm(
             group_size=group_size, outlier_size=outlier_size if enable_outlier else 0,
             outlier_vector_len=outlier_vector_len,
             num_outlier_centroids=num_outlier_centroids, prefetch=prefetch)
+        if tokens > B.GEMV_ANY_FORMAT_TOKENS and tokens > B.lib().vptq_quant_gemv_max_tokens(desc):
+            desc = None  # 9-16 tokens: only the canonical format's GEMV still beats dequant + GEMM
+    if desc is not None:
         y = torch.empty(x.shape[:-1] + (out_features,), dtype=x.dtype, device=dev)
         with torch.cuda.device(dev):
             B.check(B.lib().vptq_quant_gemv(desc, x.data_ptr(), y.data_ptr(), tokens, _FLAGS,
