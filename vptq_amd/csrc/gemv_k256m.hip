@@ -180,9 +180,16 @@ __global__ __launch_bounds__(kMThreads) void gemv_k256m_kernel(const K256Params 
   // and only then does the index queue go out - a wave issues in order, and behind a
   // backed-up vector-memory queue the image, which all 16 waves wait for, was built 1.5-3 us
   // later.  (An LDS-DMA fill, global_load_lds_dwordx4, was slower still.)
+  //  * sum b * x (one token, folded form): the bias values are requested BEHIND the first index
+  //    sweeps and the dot product waits until the first sweep has been consumed (late_bias
+  //    below).  Loaded with the rest, these 16 KiB per workgroup - the same lines for all 256
+  //    workgroups at the same moment, like x and scale - delayed the prologue barrier by
+  //    0.6-0.7 us per launch (timing experiment without the load: 8.4 -> 7.8 us).
+  constexpr int kStageCols = kMThreads * 8;
+  constexpr int kSt = NST > 0 ? NST : 1;
+  constexpr bool kLateB = FAST && STAGE && TOK == 1;
+  u32x4 late_x[kLateB ? kSt : 1], late_b[kLateB ? kSt : 1];
   {
-    constexpr int kStageCols = kMThreads * 8;
-    constexpr int kSt = NST > 0 ? NST : 1;
     u32x4 st_x[kSt][TOK], st_s[kSt], st_b[kSt], centry;
     u32x4 st_pv[PERM ? kSt : 1];  // PERM: 8 input-feature numbers (uint16) per staged chunk
     const char* const c0 = (const char*)Ly.cent;
@@ -205,7 +212,7 @@ __global__ __launch_bounds__(kMThreads) void gemv_k256m_kernel(const K256Params 
         if (PERM) q_load(st_pv[k], Ly.perm, off);
         if (FAST) {
           q_load(st_s[k], sp, off);
-          q_load(st_b[k], bp, off);
+          if (!kLateB) q_load(st_b[k], bp, off);
         }
         // PERM: x in its own order, permuted through LDS below.  Token slots past `tokens`
         // repeat the last row (their outputs are not stored).
@@ -218,6 +225,13 @@ __global__ __launch_bounds__(kMThreads) void gemv_k256m_kernel(const K256Params 
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int s = 0; s < DP; ++s) issue_sweep(s, bid, 0);
+      if (kLateB) {
+#pragma unroll
+        for (int k = 0; k < NST; ++k) {
+          const int want = k * kStageCols + tid * 8;
+          q_load(late_b[k], bp, (uint32_t)(want < G ? want : G - 8) * 2u);
+        }
+      }
       __builtin_amdgcn_sched_barrier(0);
       K256_STAMP(kMWaves, 1, tid);
     }
@@ -262,11 +276,12 @@ __global__ __launch_bounds__(kMThreads) void gemv_k256m_kernel(const K256Params 
         u32x4 v = st_x[k][t];
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] &= keep;
+        if (kLateB) late_x[k] = v;
         if (FAST) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            accb[t] = DT::dot2(v[q], st_b[k][q], accb[t]);  // sum b * x
-            v[q] = DT::mul2(v[q], st_s[k][q]);              // f16(s * x)
+            if (!kLateB) accb[t] = DT::dot2(v[q], st_b[k][q], accb[t]);  // sum b * x
+            v[q] = DT::mul2(v[q], st_s[k][q]);                           // f16(s * x)
           }
         }
         lds_store16(xs_off + t * xs_stride + (uint32_t)(valid ? want : G + 8) * 2u, v);
@@ -282,7 +297,7 @@ __global__ __launch_bounds__(kMThreads) void gemv_k256m_kernel(const K256Params 
     }
     if (STAGE && tid < TOK) lds_store16(xs_off + tid * xs_stride + (uint32_t)G * 2u, u32x4{0, 0, 0, 0});
     if (tid < 2 * kMMaxSlots) slot_cnt[tid] = 0u;
-    if (FAST) {
+    if (FAST && !kLateB) {
 #pragma unroll
       for (int t = 0; t < TOK; ++t) {
         const float sum = wave_sum(accb[t]);
@@ -290,6 +305,18 @@ __global__ __launch_bounds__(kMThreads) void gemv_k256m_kernel(const K256Params 
       }
     }
   }
+  // kLateB: this wave's share of sum b * x, once the bias values are there.  No barrier: the
+  // value is read by the wave that arrives LAST at the first row group's slot counter, and
+  // every wave writes it before it bumps that counter.
+  auto late_bias = [&]() {
+    float accb = 0.f;
+#pragma unroll
+    for (int k = 0; k < NST; ++k)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) accb = DT::dot2(late_x[k][q], late_b[k][q], accb);
+    const float sum = wave_sum(accb);
+    if (lane == 0) red_b[wave] = sum;
+  };
   __builtin_amdgcn_sched_barrier(0);  // nothing that waits for index words above the barrier
   __syncthreads();
   __builtin_amdgcn_sched_barrier(0);
@@ -536,6 +563,10 @@ __global__ __launch_bounds__(kMThreads) void gemv_k256m_kernel(const K256Params 
     if constexpr (S + D < NS) issue_sweep(S + D, rg, cb);                                      \
     else if constexpr (!LAST) issue_sweep(S + D - NS, next_rg, next_cb);                       \
     __builtin_amdgcn_sched_barrier(0);                                                         \
+    if constexpr (S == 0 && kLateB && decltype(first_c)::value) {                              \
+      late_bias();                                                                             \
+      __builtin_amdgcn_sched_barrier(0);                                                       \
+    }                                                                                          \
   }
     K256M_STEP(0) K256M_STEP(1) K256M_STEP(2) K256M_STEP(3)
     K256M_STEP(4) K256M_STEP(5) K256M_STEP(6)
