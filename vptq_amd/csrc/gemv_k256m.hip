@@ -68,8 +68,10 @@ static __device__ __forceinline__ void q_load(u32x4& dst, const void* sbase, uin
   dst = *(const u32x4*)as_global((const char*)sbase + voff);
 }
 
+// The kernel proper; Ly = this workgroup's layer, however its arguments arrived (see the two
+// __global__ entry points below).
 template <typename DT, int NS, int NST, bool PERM, bool FAST, int TOK>
-__global__ __launch_bounds__(kMThreads) void gemv_k256m_kernel(const K256Params P) {
+static __device__ __forceinline__ void gemv_k256m_body(const K256Layer& Ly, const int tokens) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   {
     typedef __attribute__((address_space(3))) unsigned char lds_u8_t;
@@ -97,9 +99,6 @@ __global__ __launch_bounds__(kMThreads) void gemv_k256m_kernel(const K256Params 
   static_assert(TOK == 1 || (STAGE && FAST), "several tokens: folded form, staged activations");
   constexpr int NQ = (FAST && STAGE) ? 1 : NS;  // queue slots for scale + (exact: bias | unstaged: x)
 
-  // layer = blockIdx.y; all kernel arguments in one batch of scalar loads (k256.h)
-  int tokens;
-  const K256Layer Ly = load_layer_args(tokens);
   const int bid = blockIdx.x;
   const int G = Ly.G, N = Ly.N, O = Ly.O;
   const int n_groups = (N + kMRows - 1) / kMRows;
@@ -218,7 +217,7 @@ __global__ __launch_bounds__(kMThreads) void gemv_k256m_kernel(const K256Params 
         // repeat the last row (their outputs are not stored).
 #pragma unroll
         for (int t = 0; t < TOK; ++t)
-          q_load(st_x[k][t], (const char*)Ly.x + (size_t)(t < tokens ? t : tokens - 1) * (size_t)G * 2u, off);
+          q_load(st_x[k][t], (const char*)Ly.x + (TOK == 1 ? (size_t)0 : (size_t)(t < tokens ? t : tokens - 1) * (size_t)G * 2u), off);
       }
       __builtin_amdgcn_sched_barrier(0);
       write_image();
@@ -609,6 +608,35 @@ __global__ __launch_bounds__(kMThreads) void gemv_k256m_kernel(const K256Params 
 #endif
 }
 
+// Grouped launches (and 2-4 tokens): layer = blockIdx.y, all of its arguments in one batch of
+// scalar loads (k256.h).
+template <typename DT, int NS, int NST, bool PERM, bool FAST, int TOK>
+__global__ __launch_bounds__(kMThreads) void gemv_k256m_kernel(const K256Params P) {
+  int tokens;
+  const K256Layer Ly = load_layer_args(tokens);
+  gemv_k256m_body<DT, NS, NST, PERM, FAST, TOK>(Ly, tokens);
+}
+
+// One layer, one token: what the workgroup needs before its first vector loads comes as 14
+// dwords of scalar kernel arguments, which are PRELOADED into SGPRs at wave launch
+// (-mllvm -amdgpu-kernarg-preload-count=16, Makefile; 16 user SGPRs minus the segment pointer):
+// the kernel starts without the round trip to the kernel-argument segment (~0.3 us per launch).
+// The rest of the layer is fetched by ordinary scalar loads, waited for where first used.
+template <typename DT, int NS, int NST, bool PERM, bool FAST>
+__global__ __launch_bounds__(kMThreads) void gemv_k256m_kernel_1(
+    const uint32_t* h_cent, const uint32_t* h_rcent, const uint16_t* h_x, const uint16_t* h_scale,
+    int h_N, int h_G, int h_O, int h_row_words, int h_wgs, int h_slots, const K256Params P) {
+  K256Layer Ly = P.layer[0];
+  Ly.cent = h_cent; Ly.rcent = h_rcent; Ly.x = h_x; Ly.scale = h_scale;
+  Ly.N = h_N; Ly.G = h_G; Ly.O = h_O; Ly.row_words = h_row_words;
+  Ly.wgs = h_wgs; Ly.slots = h_slots;
+  Ly.idx = as_global(Ly.idx); Ly.cent = as_global(Ly.cent); Ly.rcent = as_global(Ly.rcent);
+  Ly.x = as_global(Ly.x); Ly.y = as_global(Ly.y); Ly.scale = as_global(Ly.scale);
+  Ly.wbias = as_global(Ly.wbias); Ly.bias = as_global(Ly.bias); Ly.perm = as_global(Ly.perm);
+  Ly.pf = as_global(Ly.pf);
+  gemv_k256m_body<DT, NS, NST, PERM, FAST, 1>(Ly, P.tokens);
+}
+
 // ---- host side -------------------------------------------------------------------
 static int device_cus() {
   static int cus[64] = {};
@@ -630,21 +658,33 @@ static int lds_fixed_bytes(int staged_cols, int tok) {
 
 template <typename DT, int NS, int NST, bool PERM, bool FAST, int TOK>
 static hipError_t launch_m(const K256Params& P, int gx, int max_cols, hipStream_t st) {
-  auto kern = gemv_k256m_kernel<DT, NS, NST, PERM, FAST, TOK>;
   const int fixed = lds_fixed_bytes(NST > 0 ? max_cols : 0, TOK);
   const int slots = P.layer[0].slots;  // set by launch_gemv_k256m
   if (slots < 1 || slots > kMMaxSlots) return hipErrorInvalidValue;
   const int lds = fixed + slots * kMRedSlot * TOK;
   if (lds > kMMaxLds) return hipErrorInvalidValue;
-  static bool attr_set[64] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-  if (!attr_set[dev]) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, kMMaxLds);
-    if (e != hipSuccess) return e;
-    attr_set[dev] = true;
+  auto allow_lds = [&](const void* kern, bool& done) {
+    if (done) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, kMMaxLds);
+    done = e == hipSuccess;
+    return e;
+  };
+  if constexpr (TOK == 1) {
+    if (P.n_layers == 1) {  // the preloaded-argument entry point
+      auto kern = gemv_k256m_kernel_1<DT, NS, NST, PERM, FAST>;
+      static bool attr_set[64] = {};
+      if (hipError_t e = allow_lds((const void*)kern, attr_set[dev]); e != hipSuccess) return e;
+      const K256Layer& L0 = P.layer[0];
+      hipLaunchKernelGGL(kern, dim3(gx, 1), dim3(kMThreads), lds, st, L0.cent, L0.rcent, L0.x, L0.scale,
+                         L0.N, L0.G, L0.O, L0.row_words, L0.wgs, L0.slots, P);
+      return hipGetLastError();
+    }
   }
+  auto kern = gemv_k256m_kernel<DT, NS, NST, PERM, FAST, TOK>;
+  static bool attr_set[64] = {};
+  if (hipError_t e = allow_lds((const void*)kern, attr_set[dev]); e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(gx, P.n_layers), dim3(kMThreads), lds, st, P);
   return hipGetLastError();
 }
@@ -674,6 +714,43 @@ static int lds_slots(int tok, int max_cols) {
   const int left = kMMaxLds - lds_fixed_bytes(max_cols > kMMaxCols ? 0 : max_cols, tok);
   const int slots = left < 0 ? 0 : left / (kMRedSlot * tok);
   return slots > kMMaxSlots ? kMMaxSlots : slots;
+}
+
+// The instantiations are spread over four translation units (Makefile: -DVPTQ_K256M_PART=1..4
+// on this same file) so that they compile side by side; PART 0 = everything in one.
+#ifndef VPTQ_K256M_PART
+#define VPTQ_K256M_PART 0
+#endif
+#define K256M_PART(n) (VPTQ_K256M_PART == 0 || VPTQ_K256M_PART == (n))
+hipError_t k256m_f16_fast(const K256Params& P, int gx, bool perm, int max_cols, hipStream_t st);
+hipError_t k256m_f16_exact(const K256Params& P, int gx, bool perm, int max_cols, hipStream_t st);
+hipError_t k256m_bf16(const K256Params& P, int gx, bool perm, int max_cols, hipStream_t st);
+hipError_t k256m_f16_tokens(const K256Params& P, int tok, int gx, bool perm, int max_cols, hipStream_t st);
+hipError_t k256m_bf16_tokens(const K256Params& P, int tok, int gx, bool perm, int max_cols, hipStream_t st);
+
+#if K256M_PART(2)
+hipError_t k256m_f16_exact(const K256Params& P, int gx, bool perm, int max_cols, hipStream_t st) {
+  return launch_m_shape<F16, false, 1>(P, gx, perm, max_cols, st);
+}
+hipError_t k256m_bf16(const K256Params& P, int gx, bool perm, int max_cols, hipStream_t st) {
+  return launch_m_shape<BF16, true, 1>(P, gx, perm, max_cols, st);
+}
+#endif
+#if K256M_PART(3)
+hipError_t k256m_f16_tokens(const K256Params& P, int tok, int gx, bool perm, int max_cols, hipStream_t st) {
+  return tok == 2 ? launch_m_shape<F16, true, 2>(P, gx, perm, max_cols, st)
+                  : launch_m_shape<F16, true, 4>(P, gx, perm, max_cols, st);
+}
+#endif
+#if K256M_PART(4)
+hipError_t k256m_bf16_tokens(const K256Params& P, int tok, int gx, bool perm, int max_cols, hipStream_t st) {
+  return tok == 2 ? launch_m_shape<BF16, true, 2>(P, gx, perm, max_cols, st)
+                  : launch_m_shape<BF16, true, 4>(P, gx, perm, max_cols, st);
+}
+#endif
+#if K256M_PART(1)
+hipError_t k256m_f16_fast(const K256Params& P, int gx, bool perm, int max_cols, hipStream_t st) {
+  return launch_m_shape<F16, true, 1>(P, gx, perm, max_cols, st);
 }
 
 // tok = token slots of the instantiation (1, 2 or 4)
@@ -712,16 +789,12 @@ hipError_t launch_gemv_k256m(K256Params& P, int tok, bool f16, bool fast, int ma
     P.layer[i].slots = lds_slots(tok, max_cols);
     gx = (int)share > gx ? (int)share : gx;
   }
-  if (tok == 1) {
-    if (!f16) return launch_m_shape<BF16, true, 1>(P, gx, perm, max_cols, st);
-    return fast ? launch_m_shape<F16, true, 1>(P, gx, perm, max_cols, st)
-                : launch_m_shape<F16, false, 1>(P, gx, perm, max_cols, st);
-  }
-  if (tok == 2)
-    return f16 ? launch_m_shape<F16, true, 2>(P, gx, perm, max_cols, st)
-               : launch_m_shape<BF16, true, 2>(P, gx, perm, max_cols, st);
-  return f16 ? launch_m_shape<F16, true, 4>(P, gx, perm, max_cols, st)
-             : launch_m_shape<BF16, true, 4>(P, gx, perm, max_cols, st);
+  if (tok != 1)
+    return f16 ? k256m_f16_tokens(P, tok, gx, perm, max_cols, st)
+               : k256m_bf16_tokens(P, tok, gx, perm, max_cols, st);
+  if (!f16) return k256m_bf16(P, gx, perm, max_cols, st);
+  return fast ? k256m_f16_fast(P, gx, perm, max_cols, st) : k256m_f16_exact(P, gx, perm, max_cols, st);
 }
+#endif  // part 1
 
 }  // namespace vptq
