@@ -74,7 +74,7 @@ static __device__ __forceinline__ u32x4 load8(const uint16_t* __restrict__ p, in
 }
 
 template <typename DT, int ROWS, int TOK, int SW, bool PERM, bool FAST>
-__global__ __launch_bounds__(kThreads, 4) void gemv_k256_kernel(const K256Params P) {
+static __device__ __forceinline__ void gemv_k256_body(const K256Layer& Ly, const int tokens) {
   // The dynamic LDS segment starts at byte 0 (the kernel has no static LDS), so
   // gathers address LDS absolutely; `smem` only sizes the allocation.
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -84,11 +84,7 @@ __global__ __launch_bounds__(kThreads, 4) void gemv_k256_kernel(const K256Params
     if ((uint32_t)(uintptr_t)(lds_u8_t*)smem != 0u) __builtin_trap();
   }
 
-  // ---- layer = blockIdx.y, row group = blockIdx.x: every kernel argument sits at an
-  // offset known at wave start, so all scalar loads go out in one batch (a search through
-  // the layer table costs one dependent kernarg round trip per step) ----
-  int tokens;
-  const K256Layer Ly = load_layer_args(tokens);
+  // ---- row group = blockIdx.x ----
   const int bid = blockIdx.x;
   const int row0 = bid * ROWS;
   if (row0 >= Ly.N) return;  // grid.x is the largest row-group count of the group
@@ -147,7 +143,7 @@ __global__ __launch_bounds__(kThreads, 4) void gemv_k256_kernel(const K256Params
       b_raw[sw] = ld16(bp, (uint32_t)col0 * 2u);
 #pragma unroll
       for (int t = 0; t < TOK; ++t) {
-        const int te = t < tokens ? t : tokens - 1;  // spare token slots repeat the last row
+        const int te = TOK == 1 ? 0 : (t < tokens ? t : tokens - 1);  // spare token slots repeat the last row
         const u32x4 xv = load8<PERM>(xp + (size_t)te * G, col0, pv);
         const uint32_t keep = valid ? 0xffffffffu : 0u;
         x_raw[sw][t] = u32x4{xv[0] & keep, xv[1] & keep, xv[2] & keep, xv[3] & keep};
@@ -303,6 +299,35 @@ __global__ __launch_bounds__(kThreads, 4) void gemv_k256_kernel(const K256Params
   if (tokens == 0x7fffffff) Ly.y[0] = (uint16_t)pf_word;  // never true: keeps the read-ahead alive
 }
 
+// Entry point of grouped launches (and of 2-4 tokens): layer = blockIdx.y.  Every kernel
+// argument sits at an offset known at wave start, so all scalar loads go out in one batch (a
+// search through the layer table costs one dependent kernarg round trip per step).
+template <typename DT, int ROWS, int TOK, int SW, bool PERM, bool FAST>
+__global__ __launch_bounds__(kThreads, 4) void gemv_k256_kernel(const K256Params P) {
+  int tokens;
+  const K256Layer Ly = load_layer_args(tokens);
+  gemv_k256_body<DT, ROWS, TOK, SW, PERM, FAST>(Ly, tokens);
+}
+
+// Entry point of a single-layer, one-token launch: the pointers and sizes the first loads need
+// are 14 dwords of scalar arguments, delivered in SGPRs at wave launch (kernarg preload, see
+// gemv_k256m_kernel_1) - no round trip to the kernel-argument segment before the first load
+// (~0.3 of the ~5 us of a 4096^2 launch).
+template <typename DT, int ROWS, int SW, bool PERM, bool FAST>
+__global__ __launch_bounds__(kThreads, 4) void gemv_k256_kernel_1(
+    const uint32_t* h_cent, const uint32_t* h_rcent, const uint32_t* h_idx, const uint16_t* h_x,
+    const uint16_t* h_scale, const uint16_t* h_wbias, int h_N, int h_G, const K256Params P) {
+  K256Layer Ly = P.layer[0];
+  Ly.cent = h_cent; Ly.rcent = h_rcent; Ly.idx = h_idx; Ly.x = h_x; Ly.scale = h_scale;
+  Ly.wbias = h_wbias; Ly.N = h_N; Ly.G = h_G;
+  Ly.row_words = h_G >> 1;  // 16 index bits per column (gemv_k256_eligible)
+  Ly.idx = as_global(Ly.idx); Ly.cent = as_global(Ly.cent); Ly.rcent = as_global(Ly.rcent);
+  Ly.x = as_global(Ly.x); Ly.y = as_global(Ly.y); Ly.scale = as_global(Ly.scale);
+  Ly.wbias = as_global(Ly.wbias); Ly.bias = as_global(Ly.bias); Ly.perm = as_global(Ly.perm);
+  Ly.pf = as_global(Ly.pf);
+  gemv_k256_body<DT, ROWS, 1, SW, PERM, FAST>(Ly, P.tokens);
+}
+
 // ---- host side -------------------------------------------------------------------
 bool gemv_k256_eligible(const VptqLayerDesc& d, int tokens) {
   return d.vector_len == 8 && d.num_centroids == 256 && d.num_res_centroids == 256 &&
@@ -328,18 +353,30 @@ static int pick_rows(int n_rows_total, int tok, bool f16) {
 
 template <typename DT, int ROWS, int TOK, int SW, bool PERM, bool FAST>
 static hipError_t launch_inst(const K256Params& P, int grid, hipStream_t st) {
-  auto kern = gemv_k256_kernel<DT, ROWS, TOK, SW, PERM, FAST>;
   constexpr int lds = kScratchOff + kWaves * (TOK * ROWS * 8 + TOK) * 4;
   // > 64 KiB of dynamic LDS must be enabled once per device (benign race: idempotent)
-  static bool attr_set[64] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-  if (!attr_set[dev]) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return e;
-    attr_set[dev] = true;
+  auto allow_lds = [&](const void* kern, bool& done) {
+    if (done) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    done = e == hipSuccess;
+    return e;
+  };
+  if constexpr (TOK == 1) {
+    if (P.n_layers == 1) {  // the preloaded-argument entry point
+      auto kern = gemv_k256_kernel_1<DT, ROWS, SW, PERM, FAST>;
+      static bool attr_set[64] = {};
+      if (hipError_t e = allow_lds((const void*)kern, attr_set[dev]); e != hipSuccess) return e;
+      const K256Layer& L0 = P.layer[0];
+      hipLaunchKernelGGL(kern, dim3(grid, 1), dim3(kThreads), lds, st, L0.cent, L0.rcent, L0.idx, L0.x,
+                         L0.scale, L0.wbias, L0.N, L0.G, P);
+      return hipGetLastError();
+    }
   }
+  auto kern = gemv_k256_kernel<DT, ROWS, TOK, SW, PERM, FAST>;
+  static bool attr_set[64] = {};
+  if (hipError_t e = allow_lds((const void*)kern, attr_set[dev]); e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(grid, P.n_layers), dim3(kThreads), lds, st, P);
   return hipGetLastError();
 }
