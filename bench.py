@@ -129,8 +129,11 @@ def compute_floor(kname, H):
     if kname.startswith("gemv_k256m"):
         # 2 ds_read_b128 gathers per index, 5.1 LDS cycles per wave-instruction per CU, 256 CUs
         cyc = n_idx * 2 / 64 / 256 * 5.1
+        # and the SIMD issue slots next to it: 4 MFMA 4x4x4 (8 cycles each) + 2-4 v_perm_b32 per
+        # index-wave, 128 index-waves per SIMD and 8192^2 layer, which the SIMD does not overlap
         return {"what": "LDS gather throughput: 2 x ds_read_b128 per index at 5.1 LDS cycles per "
-                        "wave-instruction and CU (conflict-free 16-replica image)",
+                        "wave-instruction and CU (conflict-free lane-split 8-replica image); SIMD "
+                        "issue (4 MFMA + 2-4 VALU per index) is the same order, see DESIGN.md 4.1",
                 "us_per_launch_at_2.1GHz": cyc / 2100.0}
     instr = 14 if "fast" in kname else 22
     return {"what": f"VALU issue: {instr} instructions per index, 2.25 ns per wave-instruction per "

@@ -144,9 +144,11 @@ def test_token_counts_gemv_and_gemm_paths(tokens, k, dev):
     want = vo.forward(L, x)
     assert rel_err(got, want, "f16") <= 1e-3
     if tokens <= 16:   # the C ABI accepts up to 16 tokens for every format
-        assert rel_err(tensor_to_bits(gemv_abi(m, xt, 0)), want, "f16") <= 1e-3
+        from vptq_amd import ops
+        flags = ops.quant_gemm_flags()   # what the module forward passes (VPTQ_EXACT=1: exact)
+        assert rel_err(tensor_to_bits(gemv_abi(m, xt, flags)), want, "f16") <= 1e-3
         if tokens <= (16 if k == 256 else 8):
-            assert (tensor_to_bits(gemv_abi(m, xt, 0)) == got).all()   # forward took the GEMV
+            assert (tensor_to_bits(gemv_abi(m, xt, flags)) == got).all()   # forward took the GEMV
 
 
 def test_default_and_exact_arithmetic(dev):
