@@ -22,6 +22,13 @@ TOL = {"f16": 1e-3, "bf16": 8e-3}
 FAST, GENERIC, EXACT, MFMA, VALU = 1, 2, 4, 8, 16
 
 
+def module_flags():
+    """the flags the module forward passes to the library (VPTQ_EXACT=1 in the environment
+    switches the whole process to the reference's roundings)"""
+    from vptq_amd import ops
+    return ops.quant_gemm_flags()
+
+
 def expect_kernel(m, tokens, flags, name):
     """the library's kernel choice - unless VPTQ_K256_KERNEL pins it for an A/B run"""
     if os.environ.get("VPTQ_K256_KERNEL"):
@@ -144,8 +151,7 @@ def test_token_counts_gemv_and_gemm_paths(tokens, k, dev):
     want = vo.forward(L, x)
     assert rel_err(got, want, "f16") <= 1e-3
     if tokens <= 16:   # the C ABI accepts up to 16 tokens for every format
-        from vptq_amd import ops
-        flags = ops.quant_gemm_flags()   # what the module forward passes (VPTQ_EXACT=1: exact)
+        flags = module_flags()   # what the module forward passes (VPTQ_EXACT=1: exact)
         assert rel_err(tensor_to_bits(gemv_abi(m, xt, flags)), want, "f16") <= 1e-3
         if tokens <= (16 if k == 256 else 8):
             assert (tensor_to_bits(gemv_abi(m, xt, flags)) == got).all()   # forward took the GEMV
@@ -170,7 +176,7 @@ def test_default_and_exact_arithmetic(dev):
         assert bit_identical_frac(exact, want) >= 0.95
         # FAST_MATH (ABI 2's opt-in) = the default now; the module forward uses the default
         assert (tensor_to_bits(gemv_abi(m, xt, FAST)) == dflt).all()
-        assert (tensor_to_bits(m(xt)) == dflt).all()
+        assert (tensor_to_bits(m(xt)) == (exact if module_flags() & EXACT else dflt)).all()
 
 
 # I, O, kwargs: the persistent MFMA kernel, forced onto small layers: every sweep count
@@ -269,7 +275,7 @@ def test_mfma_kernel_bf16(I, O, kw, dev):
     got = tensor_to_bits(gemv_abi(m, xt, MFMA))
     assert rel_err(got, want, "bf16") <= TOL["bf16"]
     assert rel_err(tensor_to_bits(gemv_abi(m, xt, VALU)), want, "bf16") <= TOL["bf16"]
-    assert (tensor_to_bits(m(xt)) == tensor_to_bits(gemv_abi(m, xt, 0))).all()
+    assert (tensor_to_bits(m(xt)) == tensor_to_bits(gemv_abi(m, xt, module_flags()))).all()
     first = gemv_abi(m, xt, MFMA)
     for _ in range(5):
         assert torch.equal(gemv_abi(m, xt, MFMA), first)
@@ -454,7 +460,7 @@ def test_grouped_launch_matches_single(dev):
     ys = [torch.empty_like(s) for s in singles]
     xp = (C.c_void_p * 3)(*[x.data_ptr()] * 3)
     yp = (C.c_void_p * 3)(*[t.data_ptr() for t in ys])
-    B.check(B.lib().vptq_quant_gemv_grouped(descs, 3, xp, yp, 1, 0,
+    B.check(B.lib().vptq_quant_gemv_grouped(descs, 3, xp, yp, 1, module_flags(),
                                             B.current_stream_ptr(dev)), "grouped")
     torch.cuda.synchronize()
     for a, b in zip(singles, ys):
