@@ -19,16 +19,23 @@
 //    iteration issued before the first use;
 //  * both codebooks live in ONE 64 KiB LDS image of 256 bank rows: row e holds
 //    8 replicas of main entry e (slots 0-7) and 8 replicas of residual entry e
-//    (slots 8-15); lane l reads replica l & 7, so main and residual gathers never
-//    collide and a ds_read_b128 group sees at most a 2-way conflict for ANY index
-//    pattern (a plain 4 KiB table: ~3x serialisation);
+//    (slots 8-15).  The two gathers of an index are split across the lanes: lanes with
+//    bit 3 clear fetch the main entry first (slot l & 7) and the residual entry second
+//    (slot 8 + (l & 7)), the others the other way round, so every 16-lane group of a
+//    ds_read_b128 touches 16 different slots - conflict free for ANY index pattern
+//    (all lanes on one table: 2-way conflicts, 8.8 instead of 5 LDS cycles; a plain
+//    4 KiB table: ~3x serialisation).  Which register holds which entry does not
+//    matter, the two are added (exact form) or accumulated with the same x (folded);
 //  * the LDS address of a gather is ONE v_perm_b32 (index byte -> bits 8..15,
 //    lane slot / table -> bits 4..7);
 //  * weights are rebuilt with the reference CPU path's roundings
 //    (r16(r16(r16(c+r)*s)+b), packed f16 VALU with op_sel broadcasts) and x*w is
 //    accumulated in fp32 by v_fma_mix_f32;
 //  * the 8*ROWS*TOK partial sums of a lane are reduced over the wave with the
-//    gfx950 lane-swap instructions (~2 ops per value instead of 12).
+//    gfx950 lane-swap instructions (~2 ops per value instead of 12);
+//  * two entry points share the body: gemv_k256_kernel (layer = blockIdx.y, grouped
+//    launches, 2-4 tokens) and gemv_k256_kernel_1 (one layer, one token: the arguments the
+//    first loads need are preloaded into SGPRs at wave launch).
 #include "common.h"
 #include "kernels.h"
 #include "k256.h"

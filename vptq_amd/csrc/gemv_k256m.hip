@@ -3,9 +3,8 @@
 // (csrc/kernels/quant_gemv.cuh:11-186, csrc/quant_gemv.cu:203-235).
 //
 // Why a second kernel: gemv_k256.hip is bound by VALU issue (22 instructions per index in
-// the exact form, 14 folded; tools/ubench.hip), by 2-way LDS bank conflicts of its 8-replica
-// codebook image (8.8 LDS cycles per gather, tools/ubench_lds.hip) and, on large layers, by
-// paying its prologue (64 KiB image, activations) once per 2 vector-rows.  Here
+// the exact form, 14 folded; tools/ubench.hip) and, on large layers, by paying its prologue
+// (64 KiB image, activations) once per 1-2 vector-rows.  Here
 //  * the multiply-accumulate moves to the matrix pipe.  A GEMV is no contraction for MFMA,
 //    but v_mfma_f32_4x4x4_16b_f16 computes 16 independent 4x4 blocks D = X * W + D per
 //    instruction; with X = x' * I (lane i of a block supplies x' * e_i) and W = the four
@@ -38,6 +37,10 @@
 //    sched_barriers: that is what lets the compiler emit the exact in-order count,
 //    s_waitcnt vmcnt(D - 1), in the steady-state loop; any conditional load or visible LDS-DMA
 //    in flight made it wait for ALL loads, i.e. serialised HBM latency with compute.
+//  * 2-4 tokens per launch (TOK): the same MFMA as a real contraction over two columns and the
+//    two tables, token = block row (sweep_tokens below).
+//  * two entry points share the body: gemv_k256m_kernel (layer = blockIdx.y, grouped launches)
+//    and gemv_k256m_kernel_1 (one layer, one token: arguments preloaded into SGPRs).
 #include <type_traits>
 
 #include "common.h"
