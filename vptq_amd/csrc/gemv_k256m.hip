@@ -513,8 +513,8 @@ static __device__ __forceinline__ void gemv_k256m_body(const K256Layer& Ly, cons
       const int o8 = ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2;
 #pragma unroll
       for (int t = 0; t < TOK; ++t) {
-        rs[(t * kMWaves + wave) * 32 + j * 8 + o8] = v[t];
-        rs[(t * kMWaves + wave) * 32 + j * 8 + o8 + 1] = v[TOK + t];
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        *(f32x2*)&rs[(t * kMWaves + wave) * 32 + j * 8 + o8] = f32x2{v[t], v[TOK + t]};  // ds_write_b64
       }
     }
     uint32_t arrived = 0;
@@ -523,22 +523,37 @@ static __device__ __forceinline__ void gemv_k256m_body(const K256Layer& Ly, cons
                                        __HIP_MEMORY_SCOPE_WORKGROUP);
     arrived = __builtin_amdgcn_readfirstlane(arrived);
     if (arrived == kMWaves - 1) {  // last wave of this row group: wave-uniform branch
-      if (lane < 32) {
-        const int row = rg * kMRows + (lane >> 3);
-        const int o = row * 8 + (lane & 7);
+      // This is the tail of the kernel when the row group is the workgroup's last one: keep the
+      // dependent chain short.  All 64 lanes: lane (half, o) sums 8 of the 16 waves' partials of
+      // output o as a tree (8 LDS reads in flight, 3 add levels), one lane swap joins the halves;
+      // sum b * x over the waves is a 16-lane DPP sum.  (A serial 32-add chain in 32 lanes cost
+      // ~0.3 us per launch.)
+      static_assert(kMWaves == 16, "final sum: 2 halves x 8 waves");
+      // (the lane number afresh: the copy made at kernel start would have to live in a register,
+      // or in scratch, until here)
+      const int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+      const int half = ln >> 5, ol = ln & 31;
+      const int row = rg * kMRows + (ol >> 3);
+      const int o = row * 8 + (ol & 7);
+      const bool store = ln < 32 && row < N && o < O;
+      float sum[TOK];
 #pragma unroll
-        for (int t = 0; t < TOK; ++t) {
-          float sum = 0.f;
+      for (int t = 0; t < TOK; ++t) {
+        const float* const ps = rs + (t * kMWaves + half * 8) * 32 + ol;
+        const float s0 = (ps[0] + ps[32]) + (ps[64] + ps[96]);
+        const float s1 = (ps[128] + ps[160]) + (ps[192] + ps[224]);
+        sum[t] = s0 + s1;
+      }
+      float bdot[TOK];  // sum b * x: the 16 waves' shares, added up in every 16-lane row
 #pragma unroll
-          for (int w = 0; w < kMWaves; ++w) {
-            sum += rs[(t * kMWaves + w) * 32 + lane];
-            if (FAST) sum += red_b[t * kMWaves + w];
-          }
-          if (row < N && o < O && t < tokens) {
-            if (Ly.bias) sum += DT::to_float(as_global(Ly.bias)[o]);
-            as_global(Ly.y)[(size_t)t * O + o] = DT::from_float(sum);
-          }
-        }
+      for (int t = 0; t < TOK; ++t) bdot[t] = FAST ? row16_allsum(red_b[t * kMWaves + (ln & 15)]) : 0.f;
+      float bv = 0.f;
+      if (store && Ly.bias) bv = DT::to_float(as_global(Ly.bias)[o]);
+#pragma unroll
+      for (int t = 0; t < TOK; ++t) {
+        auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(sum[t]), __float_as_uint(sum[t]), false, false);
+        const float total = (__uint_as_float(r[0]) + __uint_as_float(r[1])) + bdot[t];
+        if (store && t < tokens) as_global(Ly.y)[(size_t)t * O + o] = DT::from_float(total + bv);
       }
       if (lane == 0) {
         slot_cnt[slot] = 0u;
