@@ -163,11 +163,6 @@ static __device__ __forceinline__ void lds_store16(uint32_t byte_addr, u32x4 v) 
 }
 
 // ---- wave64 reductions -------------------------------------------------------
-static __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
-}
 
 // x + (x rotated right by N lanes inside each row of 16 lanes): one v_add_f32 with
 // a DPP row_ror modifier.  ror 8,4,2,1 in sequence = all-reduce over the row.
@@ -181,6 +176,17 @@ static __device__ __forceinline__ float row16_allsum(float x) {
   x = row_ror_add<4>(x);
   x = row_ror_add<2>(x);
   return row_ror_add<1>(x);
+}
+// Sum over the 64 lanes, returned in every lane: 4 DPP adds inside the rows of 16, then the
+// gfx950 lane swaps join rows 0+1 / 2+3 and the two halves (swap(v, v) leaves [lo | lo] and
+// [hi | hi]).  6 dependent VALU ops; a __shfl_xor butterfly is 6 dependent ds_bpermute_b32
+// round trips (~0.3 us - it was a tenth of a 4096^2 launch, tools/trace_k256m.py).
+static __device__ __forceinline__ float wave_sum(float v) {
+  v = row16_allsum(v);
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
 // Full reduce-scatter of NV (8, 16, 32 or 64) per-lane partials over the 64 lanes of a

@@ -293,12 +293,16 @@ static __device__ __forceinline__ void gemv_k256_body(const K256Layer& Ly, const
     const int row = row0 + (rem >> 3);
     const int o = row * 8 + (rem & 7);
     if (t < tokens && row < N && o < O) {
-      float sum = 0.f;
+      // the tail of the kernel: pairwise sums (3 levels) instead of one chain of 16 adds
+      static_assert(kWaves == 8, "final sum");
+      float p[kWaves], pb[kWaves];
 #pragma unroll
       for (int w = 0; w < kWaves; ++w) {
-        sum += red[w * kStride + tid];
-        if (FAST) sum += red[w * kStride + kVals + t];
+        p[w] = red[w * kStride + tid];
+        pb[w] = FAST ? red[w * kStride + kVals + t] : 0.f;
       }
+      float sum = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+      if (FAST) sum += ((pb[0] + pb[1]) + (pb[2] + pb[3])) + ((pb[4] + pb[5]) + (pb[6] + pb[7]));
       if (Ly.bias) sum += DT::to_float(Ly.bias[o]);
       Ly.y[(size_t)t * O + o] = DT::from_float(sum);
     }
@@ -394,8 +398,12 @@ static hipError_t launch_shape(const K256Params& P, int grid, int sw, bool perm,
     return perm ? launch_inst<DT, ROWS, TOK, 1, true, FAST>(P, grid, st)
                 : launch_inst<DT, ROWS, TOK, 1, false, FAST>(P, grid, st);
   }
-  return perm ? launch_inst<DT, ROWS, TOK, 2, true, FAST>(P, grid, st)
-              : launch_inst<DT, ROWS, TOK, 2, false, FAST>(P, grid, st);
+  if constexpr (TOK == 4) {
+    return hipErrorInvalidValue;  // never chosen (launch_gemv_k256): two sweeps x 4 tokens spill
+  } else {
+    return perm ? launch_inst<DT, ROWS, TOK, 2, true, FAST>(P, grid, st)
+                : launch_inst<DT, ROWS, TOK, 2, false, FAST>(P, grid, st);
+  }
 }
 
 #define K256_CASE(DT, R, T, F) \
