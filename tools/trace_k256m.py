@@ -26,7 +26,9 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import microbench as mb  # noqa: E402  (make_layers)
 from _gpu_util import module_desc  # noqa: E402
 
-PHASES = ["start", "first loads issued", "LDS image built", "accumulate done", "wave reduced", "after barrier"]
+PHASES = ["start", "first loads issued", "LDS image built", "accumulate done", "wave reduced", "after barrier",
+          "activations arrived", "at the prologue barrier"]
+ORDER = [0, 1, 6, 7, 2, 3, 4, 5]   # print in program order
 
 
 def main():
@@ -67,18 +69,22 @@ def main():
     torch.cuda.synchronize()
     out = dict(hidden=H, ring=R, exact=a.exact, hot=a.hot, phases={})
     mid = R // 2
-    t = bufs[mid].view(n_wg * nw, 8)[:, :6].cpu().double() * 0.01  # us
+    t = bufs[mid].view(n_wg * nw, 8).cpu().double() * 0.01  # us
     prev_end = bufs[mid - 1].view(n_wg * nw, 8)[:, 5].cpu().double().max().item() * 0.01
     t0 = t[:, 0].min().item()
     print(f"{a.kernel} H={H} ring={R} exact={a.exact} hot={a.hot}: previous launch's last wave ended "
           f"{t0 - prev_end:+.2f} us before this launch's first wave started")
-    for k, name in enumerate(PHASES):
+    for k in ORDER:
+        name = PHASES[k]
         if (t[:, k] == 0).all():
             continue  # boundary not stamped by this kernel
         v = (t[:, k] - t0)
         q = [v.min().item(), v.median().item(), v.max().item()]
-        out["phases"][name] = q
-        print(f"  {name:18s} min {q[0]:6.2f}  median {q[1]:6.2f}  max {q[2]:6.2f} us")
+        # the slowest wave of each workgroup (what a barrier or the end of the kernel waits for)
+        w = v.view(n_wg, nw).max(dim=1).values
+        out["phases"][name] = q + [w.min().item(), w.median().item(), w.max().item()]
+        print(f"  {name:24s} min {q[0]:6.2f}  median {q[1]:6.2f}  max {q[2]:6.2f} us   slowest wave per "
+              f"workgroup: {w.min().item():5.2f} / {w.median().item():5.2f} / {w.max().item():5.2f}")
     nxt = bufs[mid + 1].view(n_wg * nw, 8)[:, 0].cpu().double().min().item() * 0.01
     out["launch_period_us"] = nxt - t0
     print(f"  next launch's first wave started {nxt - t0:.2f} us after this one's")

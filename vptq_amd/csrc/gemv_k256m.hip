@@ -267,6 +267,7 @@ static __device__ __forceinline__ void gemv_k256m_body(const K256Layer& Ly, cons
     float accb[TOK];
 #pragma unroll
     for (int t = 0; t < TOK; ++t) accb[t] = 0.f;
+    K256_STAMP(kMWaves, 6, st_x[0][0][0]);  // (trace build) the activations have arrived
 #pragma unroll
     for (int k = 0; k < NST; ++k) {
       const int want = k * kStageCols + tid * 8;
@@ -320,6 +321,7 @@ static __device__ __forceinline__ void gemv_k256m_body(const K256Layer& Ly, cons
     if (lane == 0) red_b[wave] = sum;
   };
   __builtin_amdgcn_sched_barrier(0);  // nothing that waits for index words above the barrier
+  K256_STAMP(kMWaves, 7, tid);        // (trace build) this wave is at the barrier
   __syncthreads();
   __builtin_amdgcn_sched_barrier(0);
   K256_STAMP(kMWaves, 2, tid);
