@@ -339,8 +339,15 @@ def main():
                              "DESIGN.md §4",
                      "compute_floor": compute_floor(kname, H)},
     }
-    pmc = os.path.join(ROOT, "profiles", "r01", f"bench_h{H}_{a.mode}_pmc_summary.json")
-    if os.path.exists(pmc) and not a.exact and not a.prefetch:
+    # the newest round's summary of this configuration
+    rounds = sorted(d for d in os.listdir(os.path.join(ROOT, "profiles")) if d[:1] == "r" and d[1:].isdigit())
+    pmc = ""
+    for rd in reversed(rounds):
+        cand = os.path.join(ROOT, "profiles", rd, f"bench_h{H}_{a.mode}_pmc_summary.json")
+        if os.path.exists(cand):
+            pmc = cand
+            break
+    if pmc and not a.exact and not a.prefetch:
         # HBM bytes per launch from a separate rocprofv3 --pmc run of this same command
         # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); see the file's _note
         out["roofline"]["traffic"] = json.load(open(pmc)).get("hbm_bytes_corrected")
