@@ -49,6 +49,56 @@ def test_ctypes_struct_layout_matches_header():
     assert names == [n for n, _ in B.V2Desc._fields_]
 
 
+def _canonical_desc(I=4096, O=4096, dtype=0, perm=False):
+    """A descriptor of the canonical 2-bit format with fake (aligned, never dereferenced) pointers."""
+    d = B.LayerDesc()
+    d.in_features, d.out_features, d.vector_len, d.num_codebooks, d.group_size = I, O, 8, 1, I
+    d.num_centroids, d.num_res_centroids, d.index_bits, d.res_bits = 256, 256, 8, 8
+    d.row_words, d.num_indices, d.dtype = I // 2, O // 8, dtype
+    d.indices, d.centroids, d.res_centroids = 1 << 20, 2 << 20, 3 << 20
+    d.weight_scale, d.weight_bias = 4 << 20, 5 << 20
+    if perm:
+        d.perm, d.scale_permuted, d.bias_permuted = 6 << 20, 7 << 20, 8 << 20
+    return d
+
+
+def test_kernel_choice_without_gpu():
+    """Which kernel a call would use is host logic (vptq_quant_gemv_kernel_name launches nothing):
+    the persistent MFMA kernel from 144 row groups on (bf16: 32), 1-4 tokens in its folded form,
+    the exact form and small launches on the VALU kernel; the fused path up to 16 tokens."""
+    if os.environ.get("VPTQ_K256_KERNEL"):
+        pytest.skip("the kernel choice is pinned by VPTQ_K256_KERNEL")
+    lib = B.lib()
+    name = lambda d, tok, fl=0: lib.vptq_quant_gemv_kernel_name(d, tok, fl)  # noqa: E731
+    big, small = _canonical_desc(8192, 8192), _canonical_desc(4096, 4096)
+    assert lib.vptq_quant_gemv_max_tokens(big) == 16
+    for tok in (1, 2, 3, 4):
+        assert name(big, tok) == b"gemv_k256m_kernel<fast>"
+        assert name(small, tok) == (b"gemv_k256_kernel<fast>" if tok <= 2 else b"gemv_k256_kernel")
+    assert name(big, 1, B.GEMV_EXACT) == b"gemv_k256m_kernel"
+    assert name(big, 2, B.GEMV_EXACT) == b"gemv_k256_kernel"        # several tokens: exact on the VALU
+    assert name(big, 1, B.GEMV_FORCE_VALU) == b"gemv_k256_kernel<fast>"
+    assert name(small, 1, B.GEMV_FORCE_MFMA) == b"gemv_k256m_kernel<fast>"
+    assert name(big, 1, B.GEMV_FORCE_GENERIC) == b"gemv_generic_kernel"
+    assert name(big, 16) is not None and name(big, 17) is None
+    # bf16: folded form in the MFMA kernel from 32 row groups (128 vector-rows) on
+    assert name(_canonical_desc(4096, 1024, dtype=1), 1) == b"gemv_k256m_kernel<fast>"
+    assert name(_canonical_desc(4096, 512, dtype=1), 1) == b"gemv_k256_kernel"
+    # token slots that do not fit beside the codebook image / columns that cannot be staged
+    wide = _canonical_desc(14336, 8192)
+    assert name(wide, 2) == b"gemv_k256m_kernel<fast>" and name(wide, 4) == b"gemv_k256_kernel"
+    wider = _canonical_desc(28672, 8192)
+    assert name(wider, 1) == b"gemv_k256m_kernel<fast>" and name(wider, 2) == b"gemv_k256_kernel<fast>"
+    assert name(_canonical_desc(28672, 8192, perm=True), 1) == b"gemv_k256_kernel<fast>"
+    # grouped: the decision is taken for the whole launch
+    descs = (B.LayerDesc * 3)(_canonical_desc(4096, 4096), _canonical_desc(4096, 1024),
+                              _canonical_desc(4096, 1024))
+    assert lib.vptq_quant_gemv_grouped_kernel_name(descs, 3, 1, 0) == b"gemv_k256m_kernel<fast>"  # 192 row groups
+    assert lib.vptq_quant_gemv_grouped_kernel_name(descs, 2, 1, 0) == b"gemv_k256m_kernel<fast>"  # 160
+    two = (B.LayerDesc * 2)(_canonical_desc(4096, 1024), _canonical_desc(4096, 1024))
+    assert lib.vptq_quant_gemv_grouped_kernel_name(two, 2, 1, 0) == b"gemv_k256_kernel<fast>"     # 64
+
+
 def test_validation_errors_without_gpu():
     """The C ABI validates before launching: exercisable with no device."""
     lib = B.lib()
