@@ -44,6 +44,10 @@ CASES = [
     ("v4_k256_nores", 264, 64, dict(vector_lens=[-1, 4], num_centroids=[-1, 256], num_res_centroids=[-1, -1], group_num=1, outlier_size=0, enable_norm=True, enable_perm=False, bias=False), "f16", 3, "ref-test"),
     ("c2_outlier_perm_bias_pad", 16 + 2 * 160, 44, dict(vector_lens=[4, 8], num_centroids=[64, 256], num_res_centroids=[-1, 256], group_num=2, outlier_size=16, enable_norm=True, enable_perm=True, bias=True), "f16", 1, "ref-test"),
     ("c4_k1024_r16", 4 * 96, 96, dict(vector_lens=[-1, 8], num_centroids=[-1, 1024], num_res_centroids=[-1, 16], group_num=4, outlier_size=0, enable_norm=True, enable_perm=False, bias=False), "f16", 5, "llm"),
+    # several tokens through the canonical format (the 2-4-token kernels; 16 tokens = launches of 4)
+    ("canon_t4_bias", 2048, 96, dict(vector_lens=[-1, 8], num_centroids=[-1, 256], num_res_centroids=[-1, 256], group_num=1, outlier_size=0, enable_norm=True, enable_perm=False, bias=True), "f16", 4, "llm"),
+    ("canon_t16_perm", 1024, 136, dict(vector_lens=[-1, 8], num_centroids=[-1, 256], num_res_centroids=[-1, 256], group_num=1, outlier_size=0, enable_norm=True, enable_perm=True, bias=False), "f16", 16, "ref-test"),
+    ("canon_bf16_t2", 4104, 64, dict(vector_lens=[-1, 8], num_centroids=[-1, 256], num_res_centroids=[-1, 256], group_num=1, outlier_size=0, enable_norm=True, enable_perm=False, bias=False), "bf16", 2, "llm"),
 ]
 
 TORCH_DT = {"f16": torch.float16, "bf16": torch.bfloat16}

@@ -179,6 +179,23 @@ def test_default_and_exact_arithmetic(dev):
         assert (tensor_to_bits(m(xt)) == (exact if module_flags() & EXACT else dflt)).all()
 
 
+@pytest.mark.parametrize("name", [n for n in golden_names() if n.startswith("canon")])
+def test_canonical_goldens_through_both_kernels(name, dev):
+    """The real reference's outputs (1, 2, 4 and 16 tokens, fp16 / bf16, perm, bias) against the
+    persistent MFMA kernel and the VALU kernel, each in both arithmetic forms."""
+    L, x, y, cfg, _ = load_golden(name)
+    dt = cfg["dtype"]
+    m = spec_to_module(L, dev)
+    xt = bits_to_tensor(x, dt, dev).reshape(x.shape)
+    for flags in (MFMA, VALU, MFMA | EXACT, VALU | EXACT):
+        out = tensor_to_bits(gemv_abi(m, xt, flags))
+        assert out.shape == y.shape
+        err = rel_err(out, y, dt)
+        assert err <= TOL[dt], f"{name} flags={flags}: {err:.3e}"
+    if cfg["tokens"] <= 4:
+        expect_kernel(m, cfg["tokens"], MFMA, "gemv_k256m_kernel<fast>")
+
+
 # I, O, kwargs: the persistent MFMA kernel, forced onto small layers: every sweep count
 # 1..7 (I / 2048), row counts that are no multiple of 4, more row groups than CUs, the input
 # permutation, an output bias
