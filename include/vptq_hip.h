@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define VPTQ_ABI_VERSION 3
+#define VPTQ_ABI_VERSION 4
 
 #if defined(__GNUC__)
 #define VPTQ_API __attribute__((visibility("default")))
@@ -80,7 +80,12 @@ enum {
   /* canonical format only: pick the persistent MFMA kernel wherever it is instantiated /
    * never pick it (testing / A-B; the default chooses by launch size) */
   VPTQ_GEMV_FORCE_MFMA = 1 << 3,
-  VPTQ_GEMV_FORCE_VALU = 1 << 4
+  VPTQ_GEMV_FORCE_VALU = 1 << 4,
+  /* y is float32 [tokens, O]: the fp32 sums (output bias included when desc->bias is set) are
+   * stored un-rounded.  For callers that combine several launches before the one rounding of
+   * the reference's F.linear - the partial outputs of a row-parallel (input-column) shard,
+   * summed by an all-reduce.  Every kernel honours it (ABI >= 4). */
+  VPTQ_GEMV_OUT_F32 = 1 << 5
 };
 
 /* most tokens vptq_quant_gemv accepts; whether the fused GEMV is also the FASTER path for a

@@ -315,10 +315,13 @@ def gemv_v2_ground_truth(x_bits, bias_bits, indices, centroids, res_indices,
     I = x.shape[-1]
     wt = dequant_v2(indices, centroids, res_indices, res_centroids, scale,
                     sbias, I, out_features, vector_len, dtype)
-    y = x.astype(np.float64) @ wt.astype(np.float64)
+    # `out[i, j, :] = vec @ weights` stores a `dtype` tensor: one rounding per output
+    # (tests/test_quant_gemv.py:101-104), and only then `out += bias` (:106-107), a second
+    # `dtype` op with its own rounding - pinned by tests/golden/v2/f16_k8192_r512_t2_bias.npz.
+    y = round_to((x.astype(np.float64) @ wt.astype(np.float64)).astype(np.float32), dtype)
     if bias_bits is not None:
-        y = y + to_f32(bias_bits, dtype).astype(np.float64).reshape(1, -1)
-    return from_f32(y.astype(np.float32), dtype)
+        y = round_to(y + to_f32(bias_bits, dtype).reshape(1, -1), dtype)
+    return from_f32(y, dtype)
 
 
 # --------------------------------------------------------------------------

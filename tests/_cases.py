@@ -68,3 +68,61 @@ def bit_identical_frac(y_bits, ref_bits):
     a = np.ascontiguousarray(y_bits).view(np.uint16).ravel()
     b = np.ascontiguousarray(ref_bits).view(np.uint16).ravel()
     return float(np.mean(a == b))
+
+
+# ---- reference goldens at BASELINE sizes (tests/golden/gen_golden_big.py) ------------------
+BIG_DIR = os.path.join(GOLDEN_DIR, "big")
+
+
+def big_names():
+    return sorted(os.path.splitext(os.path.basename(p))[0]
+                  for p in glob.glob(os.path.join(BIG_DIR, "*.npz")))
+
+
+def load_big(name):
+    """-> (LayerSpec, x_bits [1,T,I], y_bits [1,T,O] from the real reference, cfg, W_head).
+    Every input is rebuilt procedurally (tests/golden/_proc.py:big_tensors); the fixture holds
+    the reference's output and the sha256 of its dense W."""
+    from _proc import big_tensors
+    z = np.load(os.path.join(BIG_DIR, name + ".npz"))
+    cfg = json.loads(bytes(z["config"]).decode())
+    I, O, dt = cfg["in_features"], cfg["out_features"], cfg["dtype"]
+    v, k, kr = cfg["vector_len"], cfg["num_centroids"], cfg["num_res_centroids"]
+    t = big_tensors(I, O, v, k, kr, cfg["perm"], cfg["bias"], cfg["tokens"], dt, cfg["dist"],
+                    cfg["seed"])
+    L = vo.LayerSpec(I, O, v, k, kr, 1, I, 0, -1, -1, dt)
+    L.indices = t["indices"]
+    L.centroids = t["centroids"].reshape(1, k, v)
+    L.res_centroids = t["res_centroids"].reshape(1, kr, v)
+    L.weight_scale, L.weight_bias = t["weight_scale"], t["weight_bias"]
+    if cfg["perm"]:
+        L.perm = t["perm"]
+    if cfg["bias"]:
+        L.bias = t["bias"]
+    return L, t["x"].reshape(1, cfg["tokens"], I), z["y"], cfg, z["W_head"]
+
+
+# ---- v2 wire format: outputs of the reference test file's ground_truth ----------------------
+V2_DIR = os.path.join(GOLDEN_DIR, "v2")
+
+
+def v2_names():
+    return sorted(os.path.splitext(os.path.basename(p))[0]
+                  for p in glob.glob(os.path.join(V2_DIR, "*.npz")))
+
+
+def load_v2(name):
+    """-> dict: cfg, uint16 bit patterns x / centroids / res_centroids / scale_weights /
+    scale_bias / bias (or None) / y (the reference's ground truth), and the index arrays
+    (the reference's cyclic pattern, tests/test_quant_gemv.py:21-31)."""
+    z = np.load(os.path.join(V2_DIR, name + ".npz"))
+    cfg = json.loads(bytes(z["config"]).decode())
+    n = cfg["in_features"] * cfg["out_features"] // cfg["vector_len"]
+    k, kr = cfg["num_centroids"], cfg["num_res_centroids"]
+    d = {key: z[key] for key in ("x", "centroids", "res_centroids", "scale_weights", "scale_bias", "y")}
+    d["bias"] = z["bias"] if "bias" in z.files else None
+    d["cfg"] = cfg
+    d["indices"] = np.tile(np.arange(k, dtype=np.int64), n // k).astype(np.uint16)
+    d["res_indices"] = np.tile(np.arange(kr, dtype=np.int64), n // kr).astype(
+        np.uint16 if cfg["res_index_dtype"] == "uint16" else np.uint8)
+    return d

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, s), f"{s} declared in include/vptq_hip.h but not exported"
     assert sorted(B.EXPORTS) == syms, "python binding table out of sync with the header"
     lib.vptq_abi_version.restype = ctypes.c_int
-    assert lib.vptq_abi_version() == B.ABI_VERSION == 3
+    assert lib.vptq_abi_version() == B.ABI_VERSION == 4
 
 
 def test_ctypes_struct_layout_matches_header():
@@ -240,6 +240,36 @@ def test_absorb_perm_matches_oracle_weight():
     assert absorb_perm_layer(m) is False          # idempotent: nothing left to absorb
 
 
+def test_absorb_perm_keeps_wide_residual_indices():
+    """More residual than main centroids (res_bits > index_bits): the reference's Python unpack
+    masks the residual with index_bits (pack.py:137); the tool that REWRITES indices must not."""
+    from vptq_amd.utils.pack import absorb_perm_layer
+    L = vo.make_layer(128, 32, dist="llm", seed=11, enable_perm=True, num_centroids=16,
+                      num_res_centroids=256)
+    W_before = vo.dequant(L, ref_residual_mask_quirk=False)   # the kernels' (res_bits) mask
+    m = spec_to_module(L, "cpu")
+    assert absorb_perm_layer(m)
+    L2 = vo.LayerSpec(128, 32, 8, 16, 256, 1, 128, dtype="f16")
+    L2.indices = m.indices.numpy()
+    L2.centroids, L2.res_centroids = L.centroids, L.res_centroids
+    L2.weight_scale, L2.weight_bias = L.weight_scale, L.weight_bias
+    assert (vo.dequant(L2, ref_residual_mask_quirk=False) == W_before).all()
+
+
+def test_tensor_version_tolerates_inference_tensors():
+    t = torch.zeros(4)
+    v0 = B.tensor_version(t)
+    t.add_(1)
+    assert B.tensor_version(t) == v0 + 1 and B.tensor_version(None) == 0
+    with torch.inference_mode():
+        u = torch.zeros(4)
+    assert B.tensor_version(u) == -1
+    perm = torch.randperm(32).to(torch.int32).to(torch.int16)
+    with torch.inference_mode():
+        pi = perm.clone()
+        assert torch.equal(B.inverse_perm(pi).long(), torch.argsort(pi.long()))
+
+
 def test_vptq_alias_for_hf():
     import sys
     # other tests may have imported the REFERENCE under the name `vptq`
@@ -262,6 +292,18 @@ def _check_alias():
     import vptq.ops
     assert vptq.ops.quant_gemm is vptq_amd.ops.quant_gemm
     assert hasattr(vptq.ops, "dequant") and hasattr(vptq.ops, "quant_gemv_v2")
+    # the reference's canonical LEAF import paths give the same objects (not a second copy of
+    # the module whose classes fail isinstance checks)
+    from vptq.layers.vqlinear import VQuantLinear as leaf_cls
+    from vptq.layers.model_base import AutoModelForCausalLM as leaf_auto
+    from vptq.ops.quant_gemm import quant_gemm as leaf_op
+    from vptq.utils.pack import pack_index as leaf_pack
+    import importlib
+    importlib.import_module("vptq_amd.utils.pack")
+    assert leaf_cls is vptq_amd.VQuantLinear and leaf_auto is vptq_amd.AutoModelForCausalLM
+    assert leaf_op is vptq_amd.ops.quant_gemm and leaf_pack is vptq_amd.utils.pack.pack_index
+    import sys
+    assert sys.modules["vptq.layers.vqlinear"] is sys.modules["vptq_amd.layers.vqlinear"]
 
 
 def test_product_never_imports_oracle():

@@ -5,7 +5,8 @@ import numpy as np
 import pytest
 
 from oracle import vptq_oracle as vo
-from _cases import golden_names, load_golden, rel_err, bit_identical_frac
+from _cases import (golden_names, load_golden, rel_err, bit_identical_frac, big_names, load_big,
+                    v2_names, load_v2)
 from _refshim import reference_available
 
 # fp16: 1 ulp ~ 4.9e-4 relative; bf16: 3.9e-3.  The reference's F.linear and the
@@ -95,3 +96,102 @@ def test_oracle_vs_live_reference_random_layers():
         assert (vo.dequant(L) == gg.bits(W)).all(), name
         out = vo.forward(L, gg.bits(x))
         assert rel_err(out, gg.bits(y), dtype) <= Y_TOL[dtype], name
+
+
+# ---------------------------------------------------------------- BASELINE sizes
+@pytest.mark.parametrize("name", big_names())
+def test_c_oracle_vs_reference_at_baseline_sizes(name):
+    """hidden 4096 / 8192 (BASELINE configs[0], [1]): the reference's own dense W (sha256) and
+    forward output, every input procedural (tests/golden/gen_golden_big.py)."""
+    from oracle import c_oracle as co
+    if not co.available():
+        pytest.skip("run __graft_entry__.build() first")
+    L, x, y, cfg, W_head = load_big(name)
+    W = co.dequant(L)
+    assert (W[:2] == W_head).all()
+    assert hashlib.sha256(W.tobytes()).hexdigest() == cfg["W_sha256"]
+    out = co.forward(L, x)
+    assert rel_err(out, y, cfg["dtype"]) <= Y_TOL[cfg["dtype"]]
+    assert bit_identical_frac(out, y) >= 0.98
+
+
+@pytest.mark.parametrize("name", [n for n in big_names() if n.startswith("h4096")])
+def test_numpy_oracle_vs_reference_at_hidden_4096(name):
+    L, x, y, cfg, W_head = load_big(name)
+    W = vo.dequant(L)
+    assert hashlib.sha256(W.tobytes()).hexdigest() == cfg["W_sha256"]
+    out = vo.forward(L, x)
+    assert rel_err(out, y, cfg["dtype"]) <= Y_TOL[cfg["dtype"]]
+    assert bit_identical_frac(out, y) >= 0.98
+
+
+# ---------------------------------------------------------------- v2 wire format
+def _v2_oracle(d):
+    c = d["cfg"]
+    return vo.gemv_v2_ground_truth(
+        d["x"], d["bias"], d["indices"].astype(np.int64), d["centroids"],
+        d["res_indices"].astype(np.int64), d["res_centroids"], d["scale_weights"], d["scale_bias"],
+        c["vector_len"], c["out_features"], c["dtype"])
+
+
+@pytest.mark.parametrize("name", v2_names())
+def test_v2_oracle_vs_reference_ground_truth_fixture(name):
+    """`gemv_v2_ground_truth` against the output of the reference test file's `ground_truth`
+    (tests/test_quant_gemv.py:49-109) on that file's own data recipe - the pin of the v2 oracle."""
+    d = load_v2(name)
+    dt = d["cfg"]["dtype"]
+    out = _v2_oracle(d).reshape(d["y"].shape)
+    assert rel_err(out, d["y"], dt) <= Y_TOL[dt]
+    assert bit_identical_frac(out, d["y"]) >= 0.98
+
+
+@pytest.mark.skipif(not reference_available(), reason="/root/reference not mounted (GPU box)")
+def test_v2_oracle_vs_live_reference_ground_truth():
+    import torch
+    import gen_golden as gg
+    import gen_golden_v2 as g2
+    rt = g2.load_reference_test_module()
+    for dtype, k, kr, I, O, T in (("bf16", 512, 256, 128, 64, 1), ("f16", 1024, 512, 256, 32, 3)):
+        cfg = dict(in_features=I, out_features=O, num_centroids=k, num_res_centroids=kr, length=T,
+                   vector_length=8, device=torch.device("cpu"), dtype=gg.TORCH_DT[dtype])
+        d = rt.create_test_data(cfg)
+        y = rt.ground_truth(x=d["x"], bias=None, indices=d["indices"], centroids=d["centroids"],
+                            res_indices=d["residual_indices"], res_centroids=d["residual_centroids"],
+                            scale_weights=d["scale_weights"], scale_bias=d["scale_bias"],
+                            vector_len=8, out_features=O)
+        out = vo.gemv_v2_ground_truth(
+            gg.bits(d["x"]), None, d["indices"].numpy().astype(np.int64), gg.bits(d["centroids"]),
+            d["residual_indices"].numpy().astype(np.int64), gg.bits(d["residual_centroids"]),
+            gg.bits(d["scale_weights"]), gg.bits(d["scale_bias"]), 8, O, dtype)
+        assert (out.reshape(-1) == gg.bits(y).reshape(-1)).all(), (dtype, k, kr)
+
+
+@pytest.mark.skipif(not reference_available(), reason="/root/reference not mounted (GPU box)")
+def test_reference_test_file_binds_to_this_package():
+    """The reference's kernel test (tests/test_quant_gemv.py), loaded UNMODIFIED with `vptq`
+    resolving to this repo's alias package: it imports, and the keyword set it passes to
+    `vptq.ops.quant_gemv_v2(**test_data)` (:236) binds to our signature.  (Running it needs a
+    GPU and the reference tree on the same box - there is no such box; the GPU test
+    `test_quant_gemv_v2_reference_fixture` replays its data and its comparison instead.)"""
+    import importlib.util
+    import inspect
+    import os
+    import sys
+    import torch
+    from _refshim import REFERENCE_PATH
+    saved = {k: sys.modules.pop(k) for k in list(sys.modules) if k == "vptq" or k.startswith("vptq.")}
+    try:
+        import vptq  # the alias at the repo root
+        assert "vptq_amd" in vptq.VQuantLinear.__module__
+        spec = importlib.util.spec_from_file_location(
+            "ref_test_quant_gemv_alias", os.path.join(REFERENCE_PATH, "tests", "test_quant_gemv.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        d = mod.create_test_data(dict(in_features=64, out_features=64, num_centroids=64,
+                                      num_res_centroids=16, device=torch.device("cpu")))
+        inspect.signature(vptq.ops.quant_gemv_v2).bind(**d)   # TypeError on a mismatch
+        assert mod.test_configs and callable(mod.test_quant_gemv)
+    finally:
+        for k in [k for k in sys.modules if k == "vptq" or k.startswith("vptq.")]:
+            del sys.modules[k]
+        sys.modules.update(saved)

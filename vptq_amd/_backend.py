@@ -18,13 +18,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # VPTQ_HIP_LIB: load another build of the library (A/B runs of tools/)
 LIB_PATH = os.environ.get("VPTQ_HIP_LIB") or os.path.join(_HERE, "libvptq_hip.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 DTYPE_F16, DTYPE_BF16 = 0, 1
 GEMV_FAST_MATH = 1 << 0
 GEMV_FORCE_GENERIC = 1 << 1
 GEMV_EXACT = 1 << 2
 GEMV_FORCE_MFMA = 1 << 3
 GEMV_FORCE_VALU = 1 << 4
+GEMV_OUT_F32 = 1 << 5     # y is float32: un-rounded sums (row-parallel partial outputs)
 GEMV_MAX_TOKENS = 16       # what vptq_quant_gemv accepts; per layer: vptq_quant_gemv_max_tokens
 GEMV_ANY_FORMAT_TOKENS = 8  # the fused GEMV is the faster path for every format up to here
 GROUP_MAX = 64
@@ -139,6 +140,18 @@ def current_stream_ptr(device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
 
+def tensor_version(t: Optional[torch.Tensor]) -> int:
+    """`t._version`, or -1 for tensors that do not track one (created under
+    `torch.inference_mode()`: reading `_version` raises there).  Such tensors can only be
+    written in place inside inference mode; derived state is then keyed on the storage
+    pointer alone."""
+    if t is None:
+        return 0
+    if t.is_inference():
+        return -1
+    return t._version
+
+
 def _derived(owner: torch.Tensor, name: str, key, build):
     """Derived state cached ON the owning tensor object (so it dies with it and is never
     confused with another tensor that later reuses the same address), re-built when the
@@ -164,7 +177,7 @@ def inverse_perm(perm: torch.Tensor) -> torch.Tensor:
         inv = torch.argsort(p)
         # store the uint16 bit pattern in an int16 tensor
         return torch.where(inv >= 32768, inv - 65536, inv).to(torch.int16)
-    return _derived(perm, "inv_perm", (perm.data_ptr(), perm._version, perm.numel()), build)
+    return _derived(perm, "inv_perm", (perm.data_ptr(), tensor_version(perm), perm.numel()), build)
 
 
 def permuted_norm(perm: torch.Tensor, t: torch.Tensor, name: str) -> torch.Tensor:
@@ -173,7 +186,7 @@ def permuted_norm(perm: torch.Tensor, t: torch.Tensor, name: str) -> torch.Tenso
     def build():
         idx = perm.detach().view(torch.int16).to(torch.int64) & 0xFFFF
         return t.detach()[idx].contiguous()
-    key = (perm.data_ptr(), perm._version, t.data_ptr(), t._version, t.numel())
+    key = (perm.data_ptr(), tensor_version(perm), t.data_ptr(), tensor_version(t), t.numel())
     return _derived(t, "permuted_" + name, key, build)
 
 

@@ -131,6 +131,8 @@ int vptq_quant_gemv(const VptqLayerDesc* d, const void* x, void* y, int tokens, 
                 VPTQ_GEMV_MAX_TOKENS);
   hipStream_t st = (hipStream_t)stream;
   hipError_t e;
+  const bool out_f32 = (flags & VPTQ_GEMV_OUT_F32) != 0;
+  const size_t yes = out_f32 ? 4 : 2;  // bytes per output element
   // the specialised kernels take up to 4 tokens per launch; more tokens = more launches
   // (up to 16 tokens still cheaper than a dense dequant + GEMM, tools/tokens_crossover.py)
   const int chunk = tokens > 4 ? 4 : tokens;
@@ -139,7 +141,7 @@ int vptq_quant_gemv(const VptqLayerDesc* d, const void* x, void* y, int tokens, 
     for (int t0 = 0; t0 < tokens; t0 += 4) {
       const int m = tokens - t0 < 4 ? tokens - t0 : 4;
       const void* xc = (const char*)x + (size_t)t0 * d->in_features * 2;
-      void* yc = (char*)y + (size_t)t0 * d->out_features * 2;
+      void* yc = (char*)y + (size_t)t0 * d->out_features * yes;
       e = vptq::launch_gemv_k256(d, 1, &xc, &yc, m, flags, st);
       if (e != hipSuccess) return hip_fail(e, "gemv_k256 launch");
     }
@@ -150,7 +152,7 @@ int vptq_quant_gemv(const VptqLayerDesc* d, const void* x, void* y, int tokens, 
     for (int t0 = 0; t0 < tokens; t0 += 4) {
       const int m = tokens - t0 < 4 ? tokens - t0 : 4;
       e = vptq::launch_gemv_gather(*d, (const char*)x + (size_t)t0 * d->in_features * 2,
-                                   (char*)y + (size_t)t0 * d->out_features * 2, m, st);
+                                   (char*)y + (size_t)t0 * d->out_features * yes, m, out_f32, st);
       if (e != hipSuccess) return hip_fail(e, "gemv_gather launch");
     }
     return VPTQ_OK;
@@ -158,7 +160,7 @@ int vptq_quant_gemv(const VptqLayerDesc* d, const void* x, void* y, int tokens, 
   for (int t0 = 0; t0 < tokens; t0 += 8) {  // the generic kernel takes up to 8 tokens per launch
     const int m = tokens - t0 < 8 ? tokens - t0 : 8;
     e = vptq::launch_gemv_generic(*d, (const char*)x + (size_t)t0 * d->in_features * 2,
-                                  (char*)y + (size_t)t0 * d->out_features * 2, m, st);
+                                  (char*)y + (size_t)t0 * d->out_features * yes, m, out_f32, st);
     if (e != hipSuccess) return hip_fail(e, "gemv_generic launch");
   }
   return VPTQ_OK;
@@ -219,7 +221,7 @@ int vptq_dequant(const VptqLayerDesc* d, void* W, void* stream) {
 
 int vptq_quant_gemv_v2(const VptqV2Desc* d, const void* x, void* y, int tokens, int flags,
                        void* stream) {
-  (void)flags;
+  const bool out_f32 = (flags & VPTQ_GEMV_OUT_F32) != 0;
   if (!d) return fail(VPTQ_E_NULL, "desc is NULL");
   if (!d->indices || !d->centroids || !x || !y)
     return fail(VPTQ_E_NULL, "indices / centroids / x / y is NULL");
@@ -248,7 +250,8 @@ int vptq_quant_gemv_v2(const VptqV2Desc* d, const void* x, void* y, int tokens, 
   for (int t0 = 0; t0 < tokens; t0 += 8) {
     const int m = tokens - t0 < 8 ? tokens - t0 : 8;
     hipError_t e = vptq::launch_gemv_v2(*d, (const char*)x + (size_t)t0 * d->in_features * es,
-                                        (char*)y + (size_t)t0 * d->out_features * es, m, st);
+                                        (char*)y + (size_t)t0 * d->out_features * (out_f32 ? 4 : es), m,
+                                        out_f32, st);
     if (e != hipSuccess) return hip_fail(e, "gemv_v2 launch");
   }
   return VPTQ_OK;

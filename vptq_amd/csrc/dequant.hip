@@ -2,80 +2,108 @@
 // path produces (vptq/ops/quant_gemm.py:43-158), bit for bit.
 //
 // Replaces DequantizeWithOutliers_PackIndice (reference csrc/kernels/dequant.cuh:9-115,
-// launcher csrc/dequant.cu:154-225).  One thread per (vector-row n, output
-// column j): lanes run along j so each of the v stores of a wave is one
-// contiguous 128-byte segment of a W row; with a permutation the READ side is
-// the gather (inv_perm[j] -> index element), the write side stays coalesced.
+// launcher csrc/dequant.cu:154-225).  Lanes run along the output columns; with a
+// permutation the READ side is the gather (inv_perm[j] -> index element), the write side
+// stays coalesced.
 #include "common.h"
 #include "kernels.h"
 
 namespace vptq {
 
+// One thread = 8 consecutive output columns j0..j0+7 of one vector-row n: 8 index elements
+// (contiguous in the bit stream unless a permutation scatters them), 8 centroid gathers, and
+// after an in-register transposition (one v_perm_b32 per output dword) V stores of 16 bytes -
+// a wave writes 1 KiB contiguous per W row.  (The first version stored 2 bytes per lane: 128 B
+// per wave-instruction, 1.9-2.8 TB/s.)  Rows run along blockIdx.x together with the column
+// blocks, so neither dimension meets the 65535 limit of grid.y / grid.z.
 template <typename DT, int V>
 __global__ __launch_bounds__(256) void dequant_kernel(const VptqLayerDesc d,
-                                                      uint16_t* __restrict__ W) {
+                                                      uint16_t* __restrict__ W, const int col_blocks) {
   constexpr int VP = V / 2;
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  const int n = blockIdx.y;
+  const int n = blockIdx.x / col_blocks;
+  const int j0 = ((blockIdx.x - n * col_blocks) * 256 + threadIdx.x) * 8;
   const int I = d.in_features, O = d.out_features, S = d.outlier_size, G = d.group_size;
-  if (j >= I) return;
-  const int c = d.inv_perm ? (int)d.inv_perm[j] : j;
+  if (j0 >= I) return;
   const int T = d.index_bits + d.res_bits;
-  uint32_t w2[VP];
-  if (c < S) {
-    const int ov = d.outlier_vector_len;
-    const uint16_t* ocent = (const uint16_t*)d.outlier_centroids;
+  uint32_t w2[8][VP];  // [column][row pair]
 #pragma unroll
-    for (int p = 0; p < VP; ++p) {
-      uint32_t pr = 0;
+  for (int q = 0; q < 8; ++q) {
+    const int j = j0 + q < I ? j0 + q : I - 1;  // ragged last chunk: recompute the last column
+    const int c = d.inv_perm ? (int)d.inv_perm[j] : j;
+    if (c < S) {
+      const int ov = d.outlier_vector_len;
+      const uint16_t* ocent = (const uint16_t*)d.outlier_centroids;
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int o = n * V + 2 * p + h;
-        uint16_t e = 0;
-        if (o < O) {
-          const int m = o / ov, tt = o - m * ov;
-          e = ocent[(size_t)d.outlier_indices[(size_t)m * S + c] * ov + tt];
+      for (int p = 0; p < VP; ++p) {
+        uint32_t pr = 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int o = n * V + 2 * p + h;
+          uint16_t e = 0;
+          if (o < O) {
+            const int m = o / ov, tt = o - m * ov;
+            e = ocent[(size_t)d.outlier_indices[(size_t)m * S + c] * ov + tt];
+          }
+          pr |= (uint32_t)e << (16 * h);
         }
-        pr |= (uint32_t)e << (16 * h);
+        w2[q][p] = pr;
       }
-      w2[p] = pr;
+    } else {
+      const int cc = c - S;
+      const int cb = cc / G, g = cc - cb * G;
+      const uint32_t* row =
+          (const uint32_t*)d.indices + ((size_t)cb * d.num_indices + n) * d.row_words;
+      const uint32_t e = unpack_elem(row, g, T);
+      const uint32_t idx = e & ((1u << d.index_bits) - 1u);
+      const uint32_t* cp = (const uint32_t*)d.centroids + ((size_t)cb * d.num_centroids + idx) * VP;
+#pragma unroll
+      for (int p = 0; p < VP; ++p) w2[q][p] = cp[p];
+      if (d.res_bits) {
+        const uint32_t ridx = (e >> d.index_bits) & ((1u << d.res_bits) - 1u);
+        const uint32_t* rp =
+            (const uint32_t*)d.res_centroids + ((size_t)cb * d.num_res_centroids + ridx) * VP;
+#pragma unroll
+        for (int p = 0; p < VP; ++p) w2[q][p] = DT::add2(w2[q][p], rp[p]);
+      }
     }
-  } else {
-    const int cc = c - S;
-    const int cb = cc / G, g = cc - cb * G;
-    const uint32_t* row =
-        (const uint32_t*)d.indices + ((size_t)cb * d.num_indices + n) * d.row_words;
-    const uint32_t e = unpack_elem(row, g, T);
-    const uint32_t idx = e & ((1u << d.index_bits) - 1u);
-    const uint32_t* cp = (const uint32_t*)d.centroids + ((size_t)cb * d.num_centroids + idx) * VP;
+    if (d.weight_scale) {
+      const uint32_t s2 = splat16(((const uint16_t*)d.weight_scale)[j]);
+      const uint32_t b2 = splat16(((const uint16_t*)d.weight_bias)[j]);
 #pragma unroll
-    for (int p = 0; p < VP; ++p) w2[p] = cp[p];
-    if (d.res_bits) {
-      const uint32_t ridx = (e >> d.index_bits) & ((1u << d.res_bits) - 1u);
-      const uint32_t* rp =
-          (const uint32_t*)d.res_centroids + ((size_t)cb * d.num_res_centroids + ridx) * VP;
-#pragma unroll
-      for (int p = 0; p < VP; ++p) w2[p] = DT::add2(w2[p], rp[p]);
+      for (int p = 0; p < VP; ++p) w2[q][p] = DT::add2(DT::mul2(w2[q][p], s2), b2);
     }
   }
-  if (d.weight_scale) {
-    const uint32_t s2 = splat16(((const uint16_t*)d.weight_scale)[j]);
-    const uint32_t b2 = splat16(((const uint16_t*)d.weight_bias)[j]);
-#pragma unroll
-    for (int p = 0; p < VP; ++p) w2[p] = DT::add2(DT::mul2(w2[p], s2), b2);
-  }
+  const bool full = j0 + 8 <= I && (I & 7) == 0;  // 16-byte aligned, whole chunk inside the row
 #pragma unroll
   for (int p = 0; p < VP; ++p) {
-    const int o = n * V + 2 * p;
-    if (o < O) W[(size_t)o * I + j] = (uint16_t)w2[p];
-    if (o + 1 < O) W[(size_t)(o + 1) * I + j] = (uint16_t)(w2[p] >> 16);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int o = n * V + 2 * p + h;
+      if (o >= O) continue;
+      // row o of the 8 columns: the low (h = 0) or high halves of w2[0..7][p]
+      u32x4 r;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        r[k] = __builtin_amdgcn_perm(w2[2 * k + 1][p], w2[2 * k][p], h ? 0x07060302u : 0x05040100u);
+      uint16_t* const dst = W + (size_t)o * I + j0;
+      if (full) {
+        *(u32x4*)dst = r;
+      } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          if (j0 + q < I) dst[q] = (uint16_t)(r[q >> 1] >> (16 * (q & 1)));
+      }
+    }
   }
 }
 
 template <typename DT, int V>
 static hipError_t launch_v(const VptqLayerDesc& d, void* W, hipStream_t st) {
-  dim3 grid((d.in_features + 255) / 256, d.num_indices), block(256);
-  hipLaunchKernelGGL((dequant_kernel<DT, V>), grid, block, 0, st, d, (uint16_t*)W);
+  const int col_blocks = (d.in_features + 2047) / 2048;
+  const long long blocks = (long long)col_blocks * d.num_indices;
+  if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+  hipLaunchKernelGGL((dequant_kernel<DT, V>), dim3((unsigned)blocks), dim3(256), 0, st, d, (uint16_t*)W,
+                     col_blocks);
   return hipGetLastError();
 }
 

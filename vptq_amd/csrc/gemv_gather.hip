@@ -33,7 +33,7 @@ struct GatherParams {
   const uint16_t* wbias;  // [I]
   const uint16_t* bias;   // [O] or null
   const uint16_t* perm;   // [I] or null
-  int N, G, O, row_words, tokens;
+  int N, G, O, row_words, tokens, out_f32;
 };
 
 // Format traits: NW 32-bit words per lane hold E elements of T bits.
@@ -162,7 +162,8 @@ __global__ __launch_bounds__(kGThreads) void gemv_gather_kernel(const GatherPara
     if (t < tokens && row < N && o < O) {
       float sum = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
       if (P.bias) sum += DT::to_float(P.bias[o]);
-      P.y[(size_t)t * O + o] = DT::from_float(sum);
+      if (P.out_f32) ((float*)P.y)[(size_t)t * O + o] = sum;
+      else P.y[(size_t)t * O + o] = DT::from_float(sum);
     }
   }
 }
@@ -220,7 +221,7 @@ static hipError_t launch_dt(const GatherParams& P, int T, bool perm, hipStream_t
   }
 }
 
-hipError_t launch_gemv_gather(const VptqLayerDesc& d, const void* x, void* y, int tokens,
+hipError_t launch_gemv_gather(const VptqLayerDesc& d, const void* x, void* y, int tokens, bool out_f32,
                               hipStream_t st) {
   GatherParams P;
   P.idx = (const uint32_t*)d.indices;
@@ -237,6 +238,7 @@ hipError_t launch_gemv_gather(const VptqLayerDesc& d, const void* x, void* y, in
   P.O = d.out_features;
   P.row_words = d.row_words;
   P.tokens = tokens;
+  P.out_f32 = out_f32 ? 1 : 0;
   const int T = gather_T(d);
   return d.dtype == VPTQ_DTYPE_F16 ? launch_dt<F16>(P, T, d.perm != nullptr, st)
                                    : launch_dt<BF16>(P, T, d.perm != nullptr, st);

@@ -17,7 +17,8 @@ namespace vptq {
 template <typename DT, int V, int TOK>
 __global__ __launch_bounds__(256) void gemv_generic_kernel(const VptqLayerDesc d,
                                                            const uint16_t* __restrict__ x,
-                                                           uint16_t* __restrict__ y, int tokens) {
+                                                           uint16_t* __restrict__ y, int tokens,
+                                                           const int out_f32) {
   constexpr int VP = V / 2;
   const int n = blockIdx.x;
   const int tid = threadIdx.x;
@@ -145,47 +146,48 @@ __global__ __launch_bounds__(256) void gemv_generic_kernel(const VptqLayerDesc d
     if (t < tokens && o < O) {
       float s = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
       if (d.bias) s += DT::to_float(((const uint16_t*)d.bias)[o]);
-      y[(size_t)t * O + o] = DT::from_float(s);
+      if (out_f32) ((float*)y)[(size_t)t * O + o] = s;
+      else y[(size_t)t * O + o] = DT::from_float(s);
     }
   }
 }
 
 template <typename DT, int V>
-static hipError_t launch_v(const VptqLayerDesc& d, const void* x, void* y, int tokens,
+static hipError_t launch_v(const VptqLayerDesc& d, const void* x, void* y, int tokens, bool out_f32,
                            hipStream_t st) {
   dim3 grid(d.num_indices), block(256);
   const uint16_t* xp = (const uint16_t*)x;
   uint16_t* yp = (uint16_t*)y;
   if (tokens == 1)
-    hipLaunchKernelGGL((gemv_generic_kernel<DT, V, 1>), grid, block, 0, st, d, xp, yp, tokens);
+    hipLaunchKernelGGL((gemv_generic_kernel<DT, V, 1>), grid, block, 0, st, d, xp, yp, tokens, (int)out_f32);
   else if (tokens == 2)
-    hipLaunchKernelGGL((gemv_generic_kernel<DT, V, 2>), grid, block, 0, st, d, xp, yp, tokens);
+    hipLaunchKernelGGL((gemv_generic_kernel<DT, V, 2>), grid, block, 0, st, d, xp, yp, tokens, (int)out_f32);
   else if (tokens <= 4)
-    hipLaunchKernelGGL((gemv_generic_kernel<DT, V, 4>), grid, block, 0, st, d, xp, yp, tokens);
+    hipLaunchKernelGGL((gemv_generic_kernel<DT, V, 4>), grid, block, 0, st, d, xp, yp, tokens, (int)out_f32);
   else
-    hipLaunchKernelGGL((gemv_generic_kernel<DT, V, 8>), grid, block, 0, st, d, xp, yp, tokens);
+    hipLaunchKernelGGL((gemv_generic_kernel<DT, V, 8>), grid, block, 0, st, d, xp, yp, tokens, (int)out_f32);
   return hipGetLastError();
 }
 
 template <typename DT>
-static hipError_t launch_dt(const VptqLayerDesc& d, const void* x, void* y, int tokens,
+static hipError_t launch_dt(const VptqLayerDesc& d, const void* x, void* y, int tokens, bool out_f32,
                             hipStream_t st) {
   switch (d.vector_len) {
-    case 2: return launch_v<DT, 2>(d, x, y, tokens, st);
-    case 4: return launch_v<DT, 4>(d, x, y, tokens, st);
-    case 6: return launch_v<DT, 6>(d, x, y, tokens, st);
-    case 8: return launch_v<DT, 8>(d, x, y, tokens, st);
-    case 10: return launch_v<DT, 10>(d, x, y, tokens, st);
-    case 12: return launch_v<DT, 12>(d, x, y, tokens, st);
-    case 16: return launch_v<DT, 16>(d, x, y, tokens, st);
+    case 2: return launch_v<DT, 2>(d, x, y, tokens, out_f32, st);
+    case 4: return launch_v<DT, 4>(d, x, y, tokens, out_f32, st);
+    case 6: return launch_v<DT, 6>(d, x, y, tokens, out_f32, st);
+    case 8: return launch_v<DT, 8>(d, x, y, tokens, out_f32, st);
+    case 10: return launch_v<DT, 10>(d, x, y, tokens, out_f32, st);
+    case 12: return launch_v<DT, 12>(d, x, y, tokens, out_f32, st);
+    case 16: return launch_v<DT, 16>(d, x, y, tokens, out_f32, st);
     default: return hipErrorInvalidValue;
   }
 }
 
-hipError_t launch_gemv_generic(const VptqLayerDesc& d, const void* x, void* y, int tokens,
+hipError_t launch_gemv_generic(const VptqLayerDesc& d, const void* x, void* y, int tokens, bool out_f32,
                                hipStream_t st) {
-  return d.dtype == VPTQ_DTYPE_F16 ? launch_dt<F16>(d, x, y, tokens, st)
-                                   : launch_dt<BF16>(d, x, y, tokens, st);
+  return d.dtype == VPTQ_DTYPE_F16 ? launch_dt<F16>(d, x, y, tokens, out_f32, st)
+                                   : launch_dt<BF16>(d, x, y, tokens, out_f32, st);
 }
 
 }  // namespace vptq

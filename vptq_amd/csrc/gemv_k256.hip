@@ -81,7 +81,9 @@ static __device__ __forceinline__ u32x4 load8(const uint16_t* __restrict__ p, in
 }
 
 template <typename DT, int ROWS, int TOK, int SW, bool PERM, bool FAST>
-static __device__ __forceinline__ void gemv_k256_body(const K256Layer& Ly, const int tokens) {
+static __device__ __forceinline__ void gemv_k256_body(const K256Layer& Ly, const int tokens_arg) {
+  const int tokens = tokens_arg & (kOutF32Bit - 1);
+  const bool out_f32 = (tokens_arg & kOutF32Bit) != 0;
   // The dynamic LDS segment starts at byte 0 (the kernel has no static LDS), so
   // gathers address LDS absolutely; `smem` only sizes the allocation.
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -304,7 +306,8 @@ static __device__ __forceinline__ void gemv_k256_body(const K256Layer& Ly, const
       float sum = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
       if (FAST) sum += ((pb[0] + pb[1]) + (pb[2] + pb[3])) + ((pb[4] + pb[5]) + (pb[6] + pb[7]));
       if (Ly.bias) sum += DT::to_float(Ly.bias[o]);
-      Ly.y[(size_t)t * O + o] = DT::from_float(sum);
+      if (out_f32) ((float*)Ly.y)[(size_t)t * O + o] = sum;
+      else Ly.y[(size_t)t * O + o] = DT::from_float(sum);
     }
   }
   if (tokens == 0x7fffffff) Ly.y[0] = (uint16_t)pf_word;  // never true: keeps the read-ahead alive
@@ -488,7 +491,7 @@ hipError_t launch_gemv_k256(const VptqLayerDesc* descs, int n, const void* const
   if (n < 1 || n > kMaxGroup) return hipErrorInvalidValue;
   K256Params P;
   P.n_layers = n;
-  P.tokens = tokens;
+  P.tokens = tokens | ((flags & VPTQ_GEMV_OUT_F32) ? kOutF32Bit : 0);
   int total_rows = 0;
   for (int i = 0; i < n; ++i) total_rows += descs[i].num_indices;
   const int tok = tokens > 2 ? 4 : tokens;

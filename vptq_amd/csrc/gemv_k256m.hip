@@ -74,7 +74,9 @@ static __device__ __forceinline__ void q_load(u32x4& dst, const void* sbase, uin
 // The kernel proper; Ly = this workgroup's layer, however its arguments arrived (see the two
 // __global__ entry points below).
 template <typename DT, int NS, int NST, bool PERM, bool FAST, int TOK>
-static __device__ __forceinline__ void gemv_k256m_body(const K256Layer& Ly, const int tokens) {
+static __device__ __forceinline__ void gemv_k256m_body(const K256Layer& Ly, const int tokens_arg) {
+  const int tokens = tokens_arg & (kOutF32Bit - 1);
+  const bool out_f32 = (tokens_arg & kOutF32Bit) != 0;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   {
     typedef __attribute__((address_space(3))) unsigned char lds_u8_t;
@@ -555,7 +557,10 @@ static __device__ __forceinline__ void gemv_k256m_body(const K256Layer& Ly, cons
       for (int t = 0; t < TOK; ++t) {
         auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(sum[t]), __float_as_uint(sum[t]), false, false);
         const float total = (__uint_as_float(r[0]) + __uint_as_float(r[1])) + bdot[t];
-        if (store && t < tokens) as_global(Ly.y)[(size_t)t * O + o] = DT::from_float(total + bv);
+        if (store && t < tokens) {
+          if (out_f32) ((float*)as_global(Ly.y))[(size_t)t * O + o] = total + bv;
+          else as_global(Ly.y)[(size_t)t * O + o] = DT::from_float(total + bv);
+        }
       }
       if (lane == 0) {
         slot_cnt[slot] = 0u;

@@ -31,6 +31,11 @@ struct K256Layer {
   int slots;      // gemv_k256m: cross-wave partial-sum slots in LDS
 };
 
+// K256Params::tokens: token count in the low 16 bits; kOutF32Bit set = y is float32
+// [tokens, O] (VPTQ_GEMV_OUT_F32: un-rounded sums, e.g. the partial outputs of a row-parallel
+// shard that are rounded once after the all-reduce)
+constexpr int kOutF32Bit = 1 << 16;
+
 struct K256Params {
   int n_layers;
   int tokens;

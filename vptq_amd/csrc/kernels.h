@@ -8,7 +8,7 @@ namespace vptq {
 
 // gemv_generic.hip — every configuration
 hipError_t launch_gemv_generic(const VptqLayerDesc& d, const void* x, void* y, int tokens,
-                               hipStream_t st);
+                               bool out_f32, hipStream_t st);
 
 // gemv_k256.hip — v=8, k=256 (+ kr=256), C=1, no outliers: LDS-resident,
 // bank-conflict-free replicated codebooks.
@@ -22,13 +22,13 @@ hipError_t launch_gemv_k256(const VptqLayerDesc* descs, int n, const void* const
 // centroid rows gathered from L2.
 bool gemv_gather_eligible(const VptqLayerDesc& d, int tokens);
 hipError_t launch_gemv_gather(const VptqLayerDesc& d, const void* x, void* y, int tokens,
-                              hipStream_t st);
+                              bool out_f32, hipStream_t st);
 
 // dequant.hip
 hipError_t launch_dequant(const VptqLayerDesc& d, void* W, hipStream_t st);
 
 // gemv_v2.hip
 hipError_t launch_gemv_v2(const VptqV2Desc& d, const void* x, void* y, int tokens,
-                          hipStream_t st);
+                          bool out_f32, hipStream_t st);
 
 }  // namespace vptq

@@ -59,7 +59,8 @@ class SiblingGroup:
         self._arrays = None
 
     def forward(self, layer, x, tokens):
-        if self._x is x and x._version == self._version and id(layer) in self._out:
+        # (tensors made under inference_mode track no version: identity alone then)
+        if self._x is x and B.tensor_version(x) == self._version and id(layer) in self._out:
             y = self._out.pop(id(layer))
             if not self._out:
                 self._x = None
@@ -70,7 +71,7 @@ class SiblingGroup:
         if any(c[3] != dev for c in caches) or xc.device != dev or \
                 any(m.in_features != layer.in_features for m in self.members):
             raise RuntimeError("sibling layers must share the device and the input width")
-        key = tuple(id(c[1]) for c in caches)
+        key = tuple(c[6] for c in caches)  # descriptor generations: a rebuilt descriptor never matches
         if self._arrays is None or self._arrays[0] != key:
             import ctypes as C
             n = len(caches)
@@ -87,7 +88,7 @@ class SiblingGroup:
                     torch.cuda.current_stream(dev).cuda_stream)
         if rc:
             B.check(rc, "vptq_quant_gemv_grouped")
-        self._x, self._version = x, x._version
+        self._x, self._version = x, B.tensor_version(x)
         self._keep_x = xc
         self._out = {id(m): y for m, y in zip(self.members, ys) if m is not layer}
         return ys[self.members.index(layer)]
@@ -116,6 +117,8 @@ def link_siblings(model: nn.Module, patterns=SIBLING_PATTERNS) -> int:
 
 
 class VQuantLinear(nn.Module):
+    _desc_generation = 0  # bumped for every descriptor built (SiblingGroup keys on it)
+
     def __init__(
         self,
         in_features: int,
@@ -274,7 +277,10 @@ class VQuantLinear(nn.Module):
                    self.outlier_centroids.weight if self.enable_outlier else None,
                    self.perm if self.enable_perm else None, self.weight_scale, self.weight_bias,
                    self.bias, None if nxt is None else nxt.indices)
-        key = tuple(0 if t is None else t.data_ptr() for t in tensors)
+        # storage pointers AND version counters: the descriptor embeds pointers to derived
+        # copies (scale / bias in column order for `perm` layers), which an in-place update of
+        # the parameters (load_state_dict's copy_, an optimizer step) must invalidate
+        key = tuple(0 if t is None else (t.data_ptr(), B.tensor_version(t)) for t in tensors)
         cache = self.__dict__.get("_desc_cache")
         if cache is None or cache[0] != key:
             dev = B.require_device(*[t for t in tensors if t is not None])
@@ -290,8 +296,9 @@ class VQuantLinear(nn.Module):
                 outlier_size=self.outlier_size if self.enable_outlier else 0,
                 outlier_vector_len=self.outlier_vector_len,
                 num_outlier_centroids=self.num_outlier_centroids, prefetch=tensors[9])
+            VQuantLinear._desc_generation += 1
             cache = (key, desc, keep, dev, B.lib().vptq_quant_gemv,
-                     B.lib().vptq_quant_gemv_max_tokens(desc))
+                     B.lib().vptq_quant_gemv_max_tokens(desc), VQuantLinear._desc_generation)
             self.__dict__["_desc_cache"] = cache
         return cache
 
@@ -312,7 +319,7 @@ class VQuantLinear(nn.Module):
         if group is not None and tokens <= group.MAX_TOKENS:
             return group.forward(self, x, tokens)
         x = self._check_activation(x)
-        _, desc, _, dev, fn, _ = self._descriptor()
+        _, desc, _, dev, fn, _, _ = self._descriptor()
         if x.device != dev:
             raise RuntimeError(f"tensors on different devices: {dev} vs {x.device}")
         y = torch.empty(x.shape[:-1] + (self.out_features,), dtype=x.dtype, device=dev)

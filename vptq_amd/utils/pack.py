@@ -60,11 +60,10 @@ def pack_index(
     out = torch.where(out >= 2**31, out - 2**32, out).to(torch.int32)
     out = out.reshape(*lead, W)
     # same self-check as the reference (pack.py:69-101): the stream round-trips
-    back, rback = unpack_index_tensor(out, index_bits, G, res_bits, G)
+    back, rback = unpack_index_tensor(out, index_bits, G, res_bits, G, res_mask_bits=res_bits)
     assert torch.equal(back, merged & ((1 << index_bits) - 1))
     if res_indice is not None:
-        assert torch.equal(rback, (merged >> index_bits) & ((1 << min(res_bits, index_bits)) - 1)) \
-            or res_bits > index_bits
+        assert torch.equal(rback, (merged >> index_bits) & ((1 << res_bits) - 1))
     return out
 
 
@@ -74,11 +73,16 @@ def unpack_index_tensor(
     num_elements: int,
     res_bits: int = 0,
     num_res_elements: int = 0,
+    *,
+    res_mask_bits: Optional[int] = None,
 ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     """int32 [C,N,W] -> (idx int64 [C,N,G], res_idx int64 [C,N,G] | None).
 
     Keeps the reference's behaviour of masking the residual with `index_bits`
-    (pack.py:137); identical whenever res_bits <= index_bits.
+    (pack.py:137); identical whenever res_bits <= index_bits.  Tools that REWRITE a
+    checkpoint's indices (`absorb_perm_layer`) pass `res_mask_bits=res_bits`, the mask the
+    kernels use (reference csrc/kernels/quant_gemv.cuh:120-121), so that a layer with more
+    residual than main centroids is not truncated.
     """
     total_bits = index_bits + res_bits
     G = num_elements
@@ -95,7 +99,8 @@ def unpack_index_tensor(
     indices = val & ((1 << index_bits) - 1)
     res_indices = None
     if res_bits > 0:
-        res_indices = (val >> index_bits) & ((1 << index_bits) - 1)
+        mb = index_bits if res_mask_bits is None else res_mask_bits
+        res_indices = (val >> index_bits) & ((1 << mb) - 1)
     return indices, res_indices
 
 
@@ -115,7 +120,8 @@ def absorb_perm_layer(layer) -> bool:
         return False
     inv = torch.argsort(layer.perm.detach().view(torch.int16).to(torch.int64) & 0xFFFF)
     idx, ridx = unpack_index_tensor(layer.indices.detach(), layer.index_bits, layer.group_size,
-                                    layer.res_index_bits, layer.group_size)
+                                    layer.res_index_bits, layer.group_size,
+                                    res_mask_bits=layer.res_index_bits)
     idx = idx[..., inv]
     if ridx is not None:
         ridx = ridx[..., inv]

@@ -103,3 +103,36 @@ def shard_in_features(layer: VQuantLinear, rank: int, world: int) -> VQuantLinea
         new.bias = layer.bias
     new.shard = ("in", g0, g0 + Gs)
     return new
+
+
+def forward_partial_f32(layer: VQuantLinear, x: torch.Tensor) -> torch.Tensor:
+    """`layer(x)` with the output left in float32, i.e. BEFORE the one rounding of the
+    reference's `F.linear` (vptq/ops/quant_gemm.py:274): `VPTQ_GEMV_OUT_F32` of the fused
+    GEMV.  What a row-parallel rank contributes to the all-reduce.  1..16 tokens."""
+    from vptq_amd import _backend as B
+    from vptq_amd import ops
+    xc = layer._check_activation(x)
+    tokens = xc.numel() // xc.shape[-1]
+    if not 1 <= tokens <= B.GEMV_MAX_TOKENS:
+        raise RuntimeError(f"forward_partial_f32 takes 1..{B.GEMV_MAX_TOKENS} tokens, got {tokens}")
+    _, desc, _, dev, fn, _, _ = layer._descriptor()
+    y = torch.empty(xc.shape[:-1] + (layer.out_features,), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        B.check(fn(desc, xc.data_ptr(), y.data_ptr(), tokens,
+                   ops.quant_gemm_flags() | B.GEMV_OUT_F32, None, 0,
+                   torch.cuda.current_stream(dev).cuda_stream), "vptq_quant_gemv")
+    return y
+
+
+def row_parallel_forward(shard: VQuantLinear, x_full: torch.Tensor, group=None) -> torch.Tensor:
+    """One row-parallel (input-column sharded) layer step on this rank: slice x, fused GEMV
+    with fp32 partial output, all-reduce (RCCL over xGMI when the process group is "nccl"),
+    ONE rounding to the activation dtype - the single exchange step of BASELINE config #5
+    (SURVEY.md 8e).  `shard` = shard_in_features(layer, rank, world); its output bias lives on
+    rank 0 and rides inside rank 0's partial sum."""
+    import torch.distributed as dist
+    g0, g1 = shard.shard[1], shard.shard[2]
+    part = forward_partial_f32(shard, x_full[..., g0:g1])
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(part, op=dist.ReduceOp.SUM, group=group)
+    return part.to(x_full.dtype)
