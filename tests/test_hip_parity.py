@@ -774,6 +774,10 @@ def test_quant_gemv_v2_reference_fixture(name, dev):
     }
     out2 = vptq.ops.quant_gemv_v2(**test_data)
     assert out2.dtype == tdt and tuple(out2.shape) == (1, T, O)
+    # 15 tokens (the op's maximum) = chunks of 4 (fp16) / 2 (bf16) through the same kernel
+    x15 = test_data["x"][:, :1].expand(1, 15, I).contiguous()
+    out15 = vptq.ops.quant_gemv_v2(**dict(test_data, x=x15))
+    assert torch.equal(out15[:, 14], out2[:, 0]) and torch.equal(out15[:, 3], out2[:, 0])
     got = tensor_to_bits(out2)
     a, b = vo.to_f32(got, dt), vo.to_f32(d["y"], dt)
     assert np.allclose(a, b, rtol=0.2, atol=0.2)          # the reference's criterion
@@ -893,3 +897,71 @@ def test_shards_through_the_hip_kernels(world, dev):
                                        .astype(np.float32), "f16"), "f16", dev).reshape(1, 2, 512)
         p = forward_partial_f32(m, x)
         assert torch.equal(p.to(torch.float16), m(x))
+
+
+# ---------------------------------------------------------------- LDS-resident codebooks (k <= 8192)
+LDS_CASES = [
+    # I, O, kwargs, tokens     (T = index_bits + res_bits: 12, 13, 20, 21 (two splits), 22)
+    (1024, 512, dict(num_centroids=4096, num_res_centroids=0), 1),
+    (1024, 520, dict(num_centroids=8192, num_res_centroids=0, bias=True), 2),
+    (2048, 1024, dict(num_centroids=4096, num_res_centroids=256, dist="llm"), 1),
+    (520, 136, dict(num_centroids=4096, num_res_centroids=512, enable_perm=True), 3),     # T=21, ib=12
+    (1024, 2048, dict(num_centroids=8192, num_res_centroids=256), 1),                      # reference test shape
+    (360, 72, dict(num_centroids=8192, num_res_centroids=256, enable_perm=True, bias=True), 4),
+    (1024, 1024, dict(num_centroids=8192, num_res_centroids=512, dist="llm"), 1),          # T=22
+    (4096 + 8, 264, dict(num_centroids=8192, num_res_centroids=512), 5),                   # ragged chunk, 5 tokens
+    (512, 40, dict(num_centroids=1024, num_res_centroids=4, enable_norm=False), 1),        # T=12 as 10 + 2
+    (8192, 8192, dict(num_centroids=8192, num_res_centroids=256, dist="llm"), 1),          # BASELINE size
+    (1024, 4096 * 8, dict(num_centroids=4096, num_res_centroids=256, dist="llm"), 2),      # 16 rows per group
+    (1024, 512, dict(num_centroids=8192, num_res_centroids=256, dtype="bf16", dist="llm"), 1),
+    (776, 200, dict(num_centroids=4096, num_res_centroids=512, dtype="bf16", dist="llm", enable_perm=True, bias=True), 3),
+]
+
+
+@pytest.mark.parametrize("I,O,kw,tokens", LDS_CASES)
+def test_lds_resident_kernel_vs_oracle(I, O, kw, tokens, dev):
+    """v = 8, one codebook, 256 < k <= 8192, kr <= 512: both codebooks LDS-resident
+    (gemv_lds.hip; the reference's v2 kernel design, csrc/kernels/quant_gemv_v2.cuh:85-94, for the
+    packed format).  fp16 = the reference's roundings (>= 95 % of the outputs bit-identical)."""
+    kw = dict(kw)
+    dist = kw.pop("dist", "ref-test")
+    L = vo.make_layer(I, O, dist=dist, seed=I + O + 7, **kw)
+    dt = L.dtype
+    rng = np.random.default_rng(11)
+    xs = (0.02 + 0.5 * rng.standard_normal((1, tokens, I))) if dist == "ref-test" \
+        else rng.standard_normal((1, tokens, I))
+    x = vo.from_f32(xs.astype(np.float32), dt)
+    m = spec_to_module(L, dev)
+    assert kernel_name(m, tokens) == "gemv_lds_kernel", kernel_name(m, tokens)
+    assert kernel_name(m, tokens, GENERIC) == "gemv_generic_kernel"
+    if dt == "bf16":
+        assert kernel_name(m, tokens, EXACT) == "gemv_generic_kernel"
+    xt = bits_to_tensor(x, dt, dev).reshape(x.shape)
+    if I * O <= 4096 * 4096:
+        W_ref = vo.dequant(L, ref_residual_mask_quirk=False)
+        want = vo.gemv(W_ref, x, dt, L.bias)
+    else:
+        from oracle import c_oracle as co
+        want = co.forward(L, x, quirk=False)
+    got = tensor_to_bits(m(xt))
+    assert got.shape == want.shape
+    err = rel_err(got, want, dt)
+    assert err <= TOL[dt], f"{err:.3e}"
+    if dt == "f16":
+        assert bit_identical_frac(got, want) >= 0.95
+    # same as the generic kernel (the A/B partner) and as fp32 output rounded once
+    gen = tensor_to_bits(gemv_abi(m, xt, GENERIC))
+    assert rel_err(got, gen, dt) <= TOL[dt]
+    from vptq_amd.utils.shard import forward_partial_f32
+    assert torch.equal(forward_partial_f32(m, xt).to(xt.dtype), m(xt))
+
+
+def test_lds_kernel_golden_and_determinism(dev):
+    L, x, y, cfg, _ = load_golden("k8192_r256_t21")
+    m = spec_to_module(L, dev)
+    assert kernel_name(m, cfg["tokens"]) == "gemv_lds_kernel"
+    xt = bits_to_tensor(x, cfg["dtype"], dev).reshape(x.shape)
+    outs = [tensor_to_bits(m(xt)) for _ in range(10)]
+    assert all((o == outs[0]).all() for o in outs)
+    assert rel_err(outs[0], y, cfg["dtype"]) <= TOL[cfg["dtype"]]
+    assert bit_identical_frac(outs[0], y) >= 0.9

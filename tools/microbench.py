@@ -93,6 +93,8 @@ def main():
     ap.add_argument("--k", type=int, default=256)
     ap.add_argument("--kr", type=int, default=256)
     ap.add_argument("--out", default="")
+    ap.add_argument("--variants", default="", help="comma list (default,valu,mfma,exact,exact_mfma,generic); empty = all")
+    ap.add_argument("--no-copy", action="store_true", help="skip the 1 GiB copy calibration")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     H = a.hidden
@@ -108,10 +110,11 @@ def main():
     res = dict(hidden=H, ring=R, alg_bytes=ab, env={k: v for k, v in os.environ.items() if k.startswith("VPTQ_")})
 
     # calibration: plain device copy of 1 GiB
-    src = torch.empty(1 << 28, dtype=torch.float32, device=dev); dst = torch.empty_like(src)
-    t = time_graph(lambda: dst.copy_(src), 10)
-    res["copy_1GiB_TBps"] = 2 * src.numel() * 4 / t / 1e6
-    del src, dst
+    if not a.no_copy:
+        src = torch.empty(1 << 28, dtype=torch.float32, device=dev); dst = torch.empty_like(src)
+        t = time_graph(lambda: dst.copy_(src), 10)
+        res["copy_1GiB_TBps"] = 2 * src.numel() * 4 / t / 1e6
+        del src, dst
 
     from tests_gpu_util import module_desc  # noqa
     descs, keeps, ys = [], [], []
@@ -140,6 +143,8 @@ def main():
     # 4 = EXACT, 8 = FORCE_MFMA, 16 = FORCE_VALU, 2 = FORCE_GENERIC
     variants = ((("default", 0), ("valu", 16), ("mfma", 8), ("exact", 4), ("exact_mfma", 12), ("generic", 2))
                 if a.k == 256 else (("default", 0), ("generic", 2)))
+    if a.variants:
+        variants = tuple(v for v in variants if v[0] in a.variants.split(","))
     for name, flags in variants:
         ring = time_graph(lambda: [launch_one(i, flags) for i in range(R)], a.iters) / R
         hot = time_graph(lambda: [launch_one(0, flags) for _ in range(R)], a.iters) / R

@@ -104,6 +104,8 @@ const char* vptq_quant_gemv_kernel_name(const VptqLayerDesc* d, int tokens, int 
     return vptq::gemv_k256_name(*d, tokens, flags);
   if (!(flags & VPTQ_GEMV_FORCE_GENERIC) && vptq::gemv_gather_eligible(*d, tokens > 4 ? 4 : tokens))
     return "gemv_gather_kernel";
+  if (!(flags & VPTQ_GEMV_FORCE_GENERIC) && vptq::gemv_lds_eligible(*d, tokens > 4 ? 4 : tokens, flags))
+    return "gemv_lds_kernel";
   return "gemv_generic_kernel";
 }
 
@@ -154,6 +156,17 @@ int vptq_quant_gemv(const VptqLayerDesc* d, const void* x, void* y, int tokens, 
       e = vptq::launch_gemv_gather(*d, (const char*)x + (size_t)t0 * d->in_features * 2,
                                    (char*)y + (size_t)t0 * d->out_features * yes, m, out_f32, st);
       if (e != hipSuccess) return hip_fail(e, "gemv_gather launch");
+    }
+    return VPTQ_OK;
+  }
+  if (!(flags & VPTQ_GEMV_FORCE_GENERIC) && vptq::gemv_lds_eligible(*d, chunk, flags) &&
+      (((uintptr_t)x) & 15) == 0) {
+    const int step = vptq::gemv_lds_max_chunk(d->dtype);
+    for (int t0 = 0; t0 < tokens; t0 += step) {
+      const int m = tokens - t0 < step ? tokens - t0 : step;
+      e = vptq::launch_gemv_lds(*d, (const char*)x + (size_t)t0 * d->in_features * 2,
+                                (char*)y + (size_t)t0 * d->out_features * yes, m, out_f32, st);
+      if (e != hipSuccess) return hip_fail(e, "gemv_lds launch");
     }
     return VPTQ_OK;
   }
@@ -247,6 +260,19 @@ int vptq_quant_gemv_v2(const VptqV2Desc* d, const void* x, void* y, int tokens, 
     return fail(VPTQ_E_TOKENS, "tokens %d outside [1, 15]", tokens);
   hipStream_t st = (hipStream_t)stream;
   const size_t es = 2;
+  if (!(flags & VPTQ_GEMV_FORCE_GENERIC) && vptq::gemv_lds_v2_eligible(*d, tokens > 4 ? 4 : tokens) &&
+      (((uintptr_t)x) & 15) == 0) {
+    // codebooks LDS-resident (what the reference's kernel does, quant_gemv_v2.cuh:85-94)
+    const int step = vptq::gemv_lds_max_chunk(d->dtype);
+    for (int t0 = 0; t0 < tokens; t0 += step) {
+      const int m = tokens - t0 < step ? tokens - t0 : step;
+      hipError_t e = vptq::launch_gemv_lds_v2(*d, (const char*)x + (size_t)t0 * d->in_features * es,
+                                              (char*)y + (size_t)t0 * d->out_features * (out_f32 ? 4 : es),
+                                              m, out_f32, st);
+      if (e != hipSuccess) return hip_fail(e, "gemv_lds (v2) launch");
+    }
+    return VPTQ_OK;
+  }
   for (int t0 = 0; t0 < tokens; t0 += 8) {
     const int m = tokens - t0 < 8 ? tokens - t0 : 8;
     hipError_t e = vptq::launch_gemv_v2(*d, (const char*)x + (size_t)t0 * d->in_features * es,

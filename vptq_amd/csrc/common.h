@@ -147,6 +147,13 @@ struct BF16 {
   }
 };
 
+// A pointer that came out of inline assembly or integer arithmetic is "flat" to the compiler
+// (flat_load: slower, and counted in lgkmcnt as well): say that it is global.
+template <typename T>
+static __device__ __forceinline__ T* as_global(T* p) {
+  typedef T __attribute__((address_space(1))) global_t;
+  return (T*)(global_t*)(uintptr_t)p;
+}
 // broadcast one 16-bit element into both halves of a register
 static __device__ __forceinline__ uint32_t splat16(uint16_t v) {
   return (uint32_t)v * 0x00010001u;

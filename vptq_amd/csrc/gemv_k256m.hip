@@ -57,6 +57,14 @@ constexpr int kMMaxLds = 163840;   // 160 KiB per CU
 constexpr int kMMaxCols = 14336;   // staged activations must fit beside the image
 constexpr int kMRedSlot = kMWaves * 32 * 4;   // one row group's cross-wave partials, per token
 constexpr int kMMaxSlots = 4;
+// VPTQ_K256M_XDUP: one token - the staged activations are kept as DUPLICATED pairs (x, x), one
+// dword per column, so that the MFMA x operand (x * e_j) is two v_and_b32 with per-lane
+// constant masks instead of two v_perm_b32 (a three-source VOP3: ~5.5 vs ~3.3 cycles per
+// wave-instruction, tools/ubench.hip).  Costs 2 more bytes of LDS per column.
+#ifndef VPTQ_K256M_XDUP
+#define VPTQ_K256M_XDUP 0
+#endif
+constexpr int kMXBytes1 = VPTQ_K256M_XDUP ? 4 : 2;  // staged bytes per column, one token
 
 static __device__ __forceinline__ u32x4 ldg16(const void* base, uint32_t byte_off) {
   return *(const u32x4*)as_global((const char*)base + byte_off);
@@ -69,6 +77,19 @@ static __device__ __forceinline__ u32x4 ldg16(const void* base, uint32_t byte_of
 // does not interlock - it produced wrong sums on some runs.
 static __device__ __forceinline__ void q_load(u32x4& dst, const void* sbase, uint32_t voff) {
   dst = *(const u32x4*)as_global((const char*)sbase + voff);
+}
+// The packed index words are read exactly once per launch, by one CU: non-temporal, so that
+// they do not push the codebooks / activations / scales every workgroup re-reads out of L2
+// (guide, "nt-weights": -5...10 % per decode layer).
+#ifndef VPTQ_K256M_NT
+#define VPTQ_K256M_NT 0
+#endif
+static __device__ __forceinline__ void q_load_stream(u32x4& dst, const void* sbase, uint32_t voff) {
+#if VPTQ_K256M_NT
+  dst = __builtin_nontemporal_load((const u32x4*)as_global((const char*)sbase + voff));
+#else
+  q_load(dst, sbase, voff);
+#endif
 }
 
 // The kernel proper; Ly = this workgroup's layer, however its arguments arrived (see the two
@@ -144,7 +165,11 @@ static __device__ __forceinline__ void gemv_k256m_body(const K256Layer& Ly, cons
   // LDS map: [0, 64 KiB) codebook image | per token: G staged activations + 8 zeros (the
   // operand of columns past G) + a 16-byte dump slot | cross-wave scratch
   const uint32_t xs_off = kMTableBytes;
-  const uint32_t xs_stride = (uint32_t)G * 2u + 32u;
+  constexpr bool kXDup = VPTQ_K256M_XDUP && TOK == 1 && STAGE;
+  constexpr uint32_t kXB = kXDup ? 4u : 2u;  // staged bytes per column
+  const uint32_t xs_stride = (uint32_t)G * kXB + 32u;
+  const uint32_t maskA = j == 0 ? 0x0000ffffu : j == 1 ? 0xffff0000u : 0u;
+  const uint32_t maskB = j == 2 ? 0x0000ffffu : j == 3 ? 0xffff0000u : 0u;
   const uint32_t red_off = xs_off + (STAGE ? TOK * xs_stride : 0u);
   float* const red_b = (float*)(smem + red_off);        // [TOK][kMWaves]: sum b * x per wave
   uint32_t* const slot_cnt = (uint32_t*)(red_b + TOK * kMWaves);  // [kMMaxSlots] waves that have arrived
@@ -170,7 +195,7 @@ static __device__ __forceinline__ void gemv_k256m_body(const K256Layer& Ly, cons
       q_load(s_raw[NQ > 1 ? s : 0], sp, coff);
       q_load(b_raw[NQ > 1 ? s : 0], Ly.x, coff);
     }
-    q_load(iw[s], rbase, roff + coff);
+    q_load_stream(iw[s], rbase, roff + coff);
   };
 
   // ---- 3. prologue, once per workgroup.
@@ -289,7 +314,17 @@ static __device__ __forceinline__ void gemv_k256m_body(const K256Layer& Ly, cons
             v[q] = DT::mul2(v[q], st_s[k][q]);                           // f16(s * x)
           }
         }
-        lds_store16(xs_off + t * xs_stride + (uint32_t)(valid ? want : G + 8) * 2u, v);
+        if constexpr (kXDup) {
+          // (x_c, x_c) per column: 32 bytes per thread
+          const uint32_t a = xs_off + (uint32_t)(valid ? want : G + 4) * 4u;
+          lds_store16(a, u32x4{__builtin_amdgcn_perm(v[0], v[0], 0x01000100u), __builtin_amdgcn_perm(v[0], v[0], 0x03020302u),
+                               __builtin_amdgcn_perm(v[1], v[1], 0x01000100u), __builtin_amdgcn_perm(v[1], v[1], 0x03020302u)});
+          if (valid)
+            lds_store16(a + 16u, u32x4{__builtin_amdgcn_perm(v[2], v[2], 0x01000100u), __builtin_amdgcn_perm(v[2], v[2], 0x03020302u),
+                                       __builtin_amdgcn_perm(v[3], v[3], 0x01000100u), __builtin_amdgcn_perm(v[3], v[3], 0x03020302u)});
+        } else {
+          lds_store16(xs_off + t * xs_stride + (uint32_t)(valid ? want : G + 8) * 2u, v);
+        }
       }
     }
     if (!STAGE) {
@@ -300,7 +335,7 @@ static __device__ __forceinline__ void gemv_k256m_body(const K256Layer& Ly, cons
         for (int q = 0; q < 4; ++q) accb[0] = DT::dot2(xv[q], bv[q], accb[0]);
       }
     }
-    if (STAGE && tid < TOK) lds_store16(xs_off + tid * xs_stride + (uint32_t)G * 2u, u32x4{0, 0, 0, 0});
+    if (STAGE && tid < TOK) lds_store16(xs_off + tid * xs_stride + (uint32_t)G * kXB, u32x4{0, 0, 0, 0});
     if (tid < 2 * kMMaxSlots) slot_cnt[tid] = 0u;
     if (FAST && !kLateB) {
 #pragma unroll
@@ -344,7 +379,19 @@ static __device__ __forceinline__ void gemv_k256m_body(const K256Layer& Ly, cons
   u32x2 xo_cache[kCacheXo ? NS : 1][8];
   // one token: acc.a[0 / 1][i] = output 0-3 / 4-7 of this lane's vector-row; several tokens:
   // acc.a[e][t] = output e of this lane's vector-row for token t
-  struct Acc { f32x4 a[TOK == 1 ? 2 : 8]; };
+  // VPTQ_K256M_ACC4: the four MFMAs of an index go to four accumulators (main / residual x
+  // low / high half), joined in finish(): no MFMA reads the result of the one two places
+  // before it.  VPTQ_K256M_ADDFORM: c + r by four v_pk_add_f16 (the reference's first rounding),
+  // then two MFMAs.
+#ifndef VPTQ_K256M_ACC4
+#define VPTQ_K256M_ACC4 0
+#endif
+#ifndef VPTQ_K256M_ADDFORM
+#define VPTQ_K256M_ADDFORM 0
+#endif
+  constexpr bool kAcc4 = VPTQ_K256M_ACC4 && FAST && TOK == 1 && !VPTQ_K256M_ADDFORM;
+  constexpr int kNAcc = TOK == 1 ? (kAcc4 ? 4 : 2) : 8;
+  struct Acc { f32x4 a[kNAcc]; };
   // Several tokens (TOK = 2 / 4): here the 4x4x4 MFMA is a real contraction.  Lane i of a block
   // supplies token i's f16(s * x) of TWO columns, twice (A row i = {x'[c0], x'[c1], x'[c0],
   // x'[c1]}); lane j supplies, for ONE output element e, {W_A[c0][e], W_A[c1][e], W_B[c0][e],
@@ -402,9 +449,12 @@ static __device__ __forceinline__ void gemv_k256m_body(const K256Layer& Ly, cons
     f32x4& acc1 = acc.a[1];
     constexpr bool kBuild = !kCacheXo || decltype(first_c)::value;
     const int want = (cb * NS + s) * kMSweepCols + lane_cols;
-    u32x4 xq = u32x4{0, 0, 0, 0};
+    u32x4 xq = u32x4{0, 0, 0, 0}, xq2 = u32x4{0, 0, 0, 0};
     if (STAGE) {
-      if (kBuild) xq = lds_load16(xs_off + (uint32_t)(want < G ? want : G) * 2u);  // past G: zeros
+      if (kBuild) {
+        xq = lds_load16(xs_off + (uint32_t)(want < G ? want : G) * kXB);  // past G: zeros
+        if (kXDup) xq2 = want < G ? lds_load16(xs_off + (uint32_t)want * 4u + 16u) : xq;
+      }
     } else {
       const uint32_t keep = want < G ? 0xffffffffu : 0u;  // columns past G contribute 0
 #pragma unroll
@@ -443,17 +493,30 @@ static __device__ __forceinline__ void gemv_k256m_body(const K256Layer& Ly, cons
       const u32x4 c = cv[u % (kAhead + 1)], r = rv[u % (kAhead + 1)];
       u32x2 xo;
       if (kBuild) {
-        xo = u32x2{__builtin_amdgcn_perm(xq[q], 0u, selA[h]),
-                   __builtin_amdgcn_perm(xq[q], 0u, selB[h])};
+        if constexpr (kXDup) {
+          const uint32_t xd = u < 4 ? xq[u & 3] : xq2[u & 3];  // (x_u, x_u)
+          xo = u32x2{xd & maskA, xd & maskB};
+        } else {
+          xo = u32x2{__builtin_amdgcn_perm(xq[q], 0u, selA[h]),
+                     __builtin_amdgcn_perm(xq[q], 0u, selB[h])};
+        }
         if (kCacheXo) xo_cache[kCacheXo ? s : 0][u] = xo;
       } else {
         xo = xo_cache[kCacheXo ? s : 0][u];
       }
-      if (FAST) {
+      if (FAST && VPTQ_K256M_ADDFORM && std::is_same<DT, F16>::value) {
+        uint32_t w2[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) w2[p] = DT::add2(c[p], r[p]);
+        acc0 = DT::mfma4(xo, u32x2{w2[0], w2[1]}, acc0);
+        acc1 = DT::mfma4(xo, u32x2{w2[2], w2[3]}, acc1);
+      } else if (FAST) {
+        f32x4& acc2 = acc.a[kAcc4 ? 2 : 0];
+        f32x4& acc3 = acc.a[kAcc4 ? 3 : 1];
         acc0 = DT::mfma4(xo, u32x2{c[0], c[1]}, acc0);
         acc1 = DT::mfma4(xo, u32x2{c[2], c[3]}, acc1);
-        acc0 = DT::mfma4(xo, u32x2{r[0], r[1]}, acc0);
-        acc1 = DT::mfma4(xo, u32x2{r[2], r[3]}, acc1);
+        acc2 = DT::mfma4(xo, u32x2{r[0], r[1]}, acc2);
+        acc3 = DT::mfma4(xo, u32x2{r[2], r[3]}, acc3);
       } else {
         const u32x4 sv = s_raw[NQ > 1 ? s : 0], bv = b_raw[NQ > 1 ? s : 0];
         uint32_t w2[4];
@@ -484,7 +547,10 @@ static __device__ __forceinline__ void gemv_k256m_body(const K256Layer& Ly, cons
     float v[NV];
     if constexpr (TOK == 1) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { v[i] = acc.a[0][i]; v[4 + i] = acc.a[1][i]; }
+      for (int i = 0; i < 4; ++i) {
+        v[i] = kAcc4 ? acc.a[0][i] + acc.a[kAcc4 ? 2 : 0][i] : acc.a[0][i];
+        v[4 + i] = kAcc4 ? acc.a[1][i] + acc.a[kAcc4 ? 3 : 1][i] : acc.a[1][i];
+      }
     } else {
 #pragma unroll
       for (int e = 0; e < 8; ++e)
@@ -601,7 +667,7 @@ static __device__ __forceinline__ void gemv_k256m_body(const K256Layer& Ly, cons
     constexpr bool LAST = decltype(last_c)::value;
     Acc acc;
 #pragma unroll
-    for (int i = 0; i < (TOK == 1 ? 2 : 8); ++i) acc.a[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < kNAcc; ++i) acc.a[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int cb = 0; cb + 1 < n_cblocks; ++cb) cblock(first_c, no_t{}, rg, cb, rg, cb + 1, acc);
     cblock(first_c, last_c, rg, n_cblocks - 1, rg + step, 0, acc);
     if (LAST) K256_STAMP(kMWaves, 3, acc.a[0][0] + acc.a[1][0]);
@@ -678,7 +744,8 @@ static int device_cus() {
 // LDS bytes before the partial-sum slots: image + per token the staged activations (0 columns:
 // unstaged) and the per-wave sum b * x + slot counters
 static int lds_fixed_bytes(int staged_cols, int tok) {
-  return kMTableBytes + (staged_cols > 0 ? tok * (staged_cols * 2 + 32) : 0) + tok * kMWaves * 4 + 64;
+  const int xb = tok == 1 ? kMXBytes1 : 2;
+  return kMTableBytes + (staged_cols > 0 ? tok * (staged_cols * xb + 32) : 0) + tok * kMWaves * 4 + 64;
 }
 
 template <typename DT, int NS, int NST, bool PERM, bool FAST, int TOK>

@@ -1,0 +1,538 @@
+// Fused dequant + GEMV with LDS-RESIDENT codebooks for the mid-size formats: v = 8, one
+// codebook, 256 < k <= 8192 main centroids, 0..512 residual centroids, packed bit stream
+// (T = index_bits + res_bits in {12, 13, 20, 21, 22}) or the unpacked v2 wire format
+// (uint16 ids [N][I], uint8 / uint16 residual ids).
+//
+// Replaces, for these formats, WqA16WithOutliers_PackIndice (reference
+// csrc/kernels/quant_gemv.cuh:11-186) and ke_quant_gemv_v2 (csrc/kernels/quant_gemv_v2.cuh:
+// 15-184; traits csrc/kernels/quant_gemv_traits.cuh:83-214; dispatch csrc/dispatch_macros.h:
+// 12-89) - the reference's only TESTED configuration (tests/test_quant_gemv.py:196-219:
+// k = 8192, kr = 256 / 512, v = 8).  The reference stages the whole 128 KiB codebook into
+// shared memory in EVERY one of its N blocks (N x 132 KiB of L2 -> smem traffic for 2 MiB of
+// indices); gemv_generic.hip / gemv_v2.hip gather through L1 / L2 instead (54 us per 8192^2
+// layer).  Here:
+//  * persistent: one 1024-thread workgroup per CU copies both codebooks into LDS ONCE
+//    (k * 16 + kr * 16 bytes <= 136 KiB of the 160 KiB), then walks row groups
+//    bid, bid + grid, ...  A row group is RW vector-rows (1..16, chosen by the host so that
+//    there are at least as many row groups as CUs); each row is shared by 16 / RW waves,
+//    which take interleaved chunks of 512 columns.
+//  * lane = 8 consecutive columns of one vector-row: one 16-byte ds_read_b128 gather per
+//    codebook and column (un-replicated tables: ~2.5x the conflict-free gather time, still
+//    several times faster than an L2 gather), 8 fp32 accumulators per token.
+//  * index words: a lane's 8 elements are 8 T bits = a window of <= 7 consecutive 32-bit
+//    words starting at a multiple of 8 bits; neighbouring lanes read neighbouring windows
+//    (coalesced: every byte of a touched line is used by this or the adjacent instruction).
+//    The window is shifted to bit 0 once, then every element sits at a compile-time position.
+//    The index stream is read once by one CU: non-temporal loads, so that it does not evict
+//    x / scale / bias, which every wave re-reads from L1 / L2 (they are NOT staged in LDS:
+//    the codebooks own it).
+//  * arithmetic.  fp16: the reference CPU path's roundings, w = r16(r16(r16(c + r) * s) + b)
+//    in packed f16 (bit-identical to vptq_dequant), then x * w accumulated in fp32 - the LDS
+//    gathers, not the VALU, bound this kernel, so the bit-equivalent form is free here.
+//    bf16 (no packed bf16 VALU on gfx950): folded form in fp32,
+//    y = sum_g (c + r) * (s_g x_g) + sum_g b_g x_g  (inside the bf16 parity bar; VPTQ_GEMV_EXACT
+//    routes bf16 to the generic kernel).
+#include <type_traits>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace vptq {
+
+constexpr int kLThreads = 1024;
+constexpr int kLWaves = kLThreads / 64;
+constexpr int kLChunk = 64 * 8;           // columns per wave step
+constexpr int kLMaxLds = 163840;
+constexpr int kFmtV2None = 100, kFmtV2U8 = 101, kFmtV2U16 = 102;  // FMT < 100: packed, T = FMT
+
+struct LdsParams {
+  const uint32_t* idx;    // packed: int32 [N][row_words];  v2: uint16 ids [N][G]
+  const void* ridx;       // v2: uint8 / uint16 residual ids [N][G] (NULL: none)
+  const uint32_t* cent;   // [k][8]
+  const uint32_t* rcent;  // [kr][8] or NULL
+  const uint16_t* x;      // [tokens][G]
+  void* y;                // [tokens][O] (dtype, or float when out_f32)
+  const uint16_t* scale;  // [G] in COLUMN order (perm: scale_permuted) or NULL
+  const uint16_t* wbias;  // [G] in column order or NULL
+  const uint16_t* wbias_plain;  // [G] in input-feature order (sum b * x needs no permutation)
+  const uint16_t* bias;   // [O] or NULL
+  const uint16_t* perm;   // [G] or NULL
+  int N, G, O, row_words, k, kr, ib, rb, tokens, out_f32, RW, n_groups;
+};
+
+typedef uint32_t u32a4 __attribute__((aligned(4)));
+
+// ---- index fetch + decode -----------------------------------------------------------
+// RAW words a lane holds for its 8 elements
+template <int FMT>
+struct IdxWindow {
+  static constexpr bool kPacked = FMT < 100;
+  static constexpr int T = kPacked ? FMT : 16;
+  static constexpr bool kAligned = (8 * T) % 32 == 0;            // window starts on a word
+  static constexpr int W = kPacked ? (8 * T + (kAligned ? 0 : 24) + 31) / 32 : 4;
+  static constexpr int RWORDS = FMT == kFmtV2U8 ? 2 : FMT == kFmtV2U16 ? 4 : 0;
+  uint32_t w[W];
+  uint32_t r[RWORDS > 0 ? RWORDS : 1];
+  uint32_t off;   // packed, unaligned: bit offset of element 0 inside w[0]
+  bool slow;      // packed: the window would run past the row - decode element by element
+};
+
+template <int FMT>
+static __device__ __forceinline__ void fetch_window(IdxWindow<FMT>& q, const LdsParams& P, int row,
+                                                    int g0) {
+  using Q = IdxWindow<FMT>;
+  if constexpr (Q::kPacked) {
+    const uint32_t bit = (uint32_t)g0 * (uint32_t)Q::T;
+    const uint32_t w0 = bit >> 5;
+    q.off = bit & 31u;
+    q.slow = (int)w0 + Q::W > P.row_words;
+    // a window past the row end is re-read from the start of the row (in bounds) and ignored
+    const uint32_t* p = P.idx + (size_t)row * P.row_words + (q.slow ? 0u : w0);
+#pragma unroll
+    for (int i = 0; i < Q::W; ++i)
+      q.w[i] = __builtin_nontemporal_load((const u32a4*)as_global(p + i));
+  } else {
+    const uint32_t* p = (const uint32_t*)((const uint16_t*)P.idx + (size_t)row * P.G + g0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q.w[i] = __builtin_nontemporal_load(as_global(p + i));
+    if constexpr (Q::RWORDS > 0) {
+      const size_t e = (size_t)row * P.G + g0;
+      const uint32_t* rp = (const uint32_t*)((const char*)P.ridx + e * (FMT == kFmtV2U8 ? 1 : 2));
+#pragma unroll
+      for (int i = 0; i < Q::RWORDS; ++i) q.r[i] = __builtin_nontemporal_load(as_global(rp + i));
+    }
+    q.off = 0;
+    q.slow = false;
+  }
+}
+
+// Decoding: normalise the window once (element 0 at bit 0), then element e sits at the
+// compile-time position e * T.  -> LDS byte addresses of the main / residual entry.
+template <int FMT>
+struct IdxDecoded {
+  using Q = IdxWindow<FMT>;
+  uint32_t w[Q::W];
+  uint32_t r[Q::RWORDS > 0 ? Q::RWORDS : 1];
+};
+
+template <int FMT>
+static __device__ __forceinline__ void normalise_window(IdxDecoded<FMT>& d, const IdxWindow<FMT>& q,
+                                                        const LdsParams& P, int row, int g0) {
+  using Q = IdxWindow<FMT>;
+  if constexpr (Q::kPacked) {
+    constexpr int T = Q::T;
+    if (q.slow) {
+      // the window would cross the row end: rebuild an aligned window element by element
+      const uint32_t* rowp = P.idx + (size_t)row * P.row_words;
+      uint64_t acc = 0;
+      int have = 0, wi = 0;
+#pragma unroll
+      for (int i = 0; i < Q::W; ++i) d.w[i] = 0;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const uint32_t v = unpack_elem(rowp, g0 + e < P.G ? g0 + e : P.G - 1, T);
+        acc |= (uint64_t)v << have;
+        have += T;
+        if (have >= 32) {
+          d.w[wi < Q::W ? wi : Q::W - 1] = (uint32_t)acc;
+          acc >>= 32; have -= 32; ++wi;
+        }
+      }
+      if (have > 0 && wi < Q::W) d.w[wi] = (uint32_t)acc;
+    } else if constexpr (Q::kAligned) {
+#pragma unroll
+      for (int i = 0; i < Q::W; ++i) d.w[i] = q.w[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i + 1 < Q::W; ++i) d.w[i] = __builtin_amdgcn_alignbit(q.w[i + 1], q.w[i], q.off);
+      d.w[Q::W - 1] = q.w[Q::W - 1] >> q.off;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) d.w[i] = q.w[i];
+#pragma unroll
+    for (int i = 0; i < (Q::RWORDS > 0 ? Q::RWORDS : 1); ++i) d.r[i] = q.r[i];
+  }
+}
+
+template <int FMT, int E>
+static __device__ __forceinline__ void decode_elem(const IdxDecoded<FMT>& d, const LdsParams& P,
+                                                   uint32_t res_base, uint32_t& am, uint32_t& ar) {
+  using Q = IdxWindow<FMT>;
+  if constexpr (Q::kPacked) {
+    constexpr int T = Q::T;
+    constexpr uint32_t mask = T >= 32 ? 0xffffffffu : ((1u << T) - 1u);
+    constexpr int wi = (T * E) >> 5, sh = (T * E) & 31;
+    uint32_t val;
+    if constexpr (sh + T <= 32) val = __builtin_amdgcn_ubfe(d.w[wi], (uint32_t)sh, (uint32_t)T);
+    else val = __builtin_amdgcn_alignbit(d.w[wi + 1 < Q::W ? wi + 1 : wi], d.w[wi], (uint32_t)sh) & mask;
+    am = (val & ((1u << P.ib) - 1u)) << 4;
+    ar = res_base + ((val >> P.ib) << 4);
+  } else {
+    am = __builtin_amdgcn_ubfe(d.w[E >> 1], (uint32_t)(16 * (E & 1)), 16u) << 4;
+    if constexpr (FMT == kFmtV2U8)
+      ar = res_base + (__builtin_amdgcn_ubfe(d.r[E >> 2], (uint32_t)(8 * (E & 3)), 8u) << 4);
+    else if constexpr (FMT == kFmtV2U16)
+      ar = res_base + (__builtin_amdgcn_ubfe(d.r[E >> 1], (uint32_t)(16 * (E & 1)), 16u) << 4);
+    else
+      ar = res_base;
+  }
+}
+
+// ---- the kernel -----------------------------------------------------------------------
+template <typename DT, int FMT, int TOK>
+__global__ __launch_bounds__(kLThreads) void gemv_lds_kernel(const LdsParams P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lsmem[];
+  {
+    typedef __attribute__((address_space(3))) unsigned char lds_u8_t;
+    if ((uint32_t)(uintptr_t)(lds_u8_t*)lsmem != 0u) __builtin_trap();  // absolute LDS addressing
+  }
+  constexpr bool kF16 = std::is_same<DT, F16>::value;
+  constexpr int NV = 8 * TOK;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int G = P.G, N = P.N, O = P.O, tokens = P.tokens;
+  const bool has_res = P.kr > 0;
+
+  // LDS map: main table | residual table | red[kLWaves][NV] | bdot[TOK][kLWaves] | bsum[TOK]
+  const uint32_t res_base = (uint32_t)P.k * 16u;
+  const uint32_t red_off = res_base + (uint32_t)P.kr * 16u;
+  float* const red = (float*)(lsmem + red_off);
+  float* const bdot_w = red + kLWaves * NV;
+  float* const bsum = bdot_w + TOK * kLWaves;
+
+  // ---- prologue: both codebooks into LDS, 4 entries per thread in flight
+  {
+    const int total = P.k + P.kr;
+    for (int i0 = tid; i0 < total; i0 += 4 * kLThreads) {
+      u32x4 e[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * kLThreads;
+        const int ic = i < total ? i : total - 1;
+        const uint32_t* src = ic < P.k ? P.cent + (size_t)ic * 4 : P.rcent + (size_t)(ic - P.k) * 4;
+        e[u] = *(const u32x4*)as_global(src);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * kLThreads;
+        if (i < total) lds_store16((uint32_t)i * 16u, e[u]);
+      }
+    }
+  }
+  // bf16 folded form: sum_g b_g x_g once per workgroup (input-feature order: no permutation)
+  if constexpr (!kF16) {
+    float accb[TOK];
+#pragma unroll
+    for (int t = 0; t < TOK; ++t) accb[t] = 0.f;
+    if (P.wbias_plain) {
+      for (int c = tid * 8; c < G; c += kLThreads * 8) {
+        const u32x4 bv = *(const u32x4*)as_global(P.wbias_plain + c);
+#pragma unroll
+        for (int t = 0; t < TOK; ++t) {
+          const u32x4 xv = *(const u32x4*)as_global(P.x + (size_t)(t < tokens ? t : tokens - 1) * G + c);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) accb[t] = DT::dot2(xv[q], bv[q], accb[t]);
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < TOK; ++t) {
+      const float s = wave_sum(accb[t]);
+      if (lane == 0) bdot_w[t * kLWaves + wave] = s;
+    }
+  }
+  __syncthreads();
+  if constexpr (!kF16) {
+    if (tid < TOK) {
+      float s = 0.f;
+      for (int w = 0; w < kLWaves; ++w) s += bdot_w[tid * kLWaves + w];
+      bsum[tid] = s;
+    }
+  }
+
+  // ---- row groups
+  const int RW = P.RW;            // rows per group (power of two, 1..16)
+  const int PW = kLWaves / RW;    // waves per row
+  const int rw = wave / PW, part = wave - rw * PW;
+  const int n_chunks = (G + kLChunk - 1) / kLChunk;
+
+  for (int rg = blockIdx.x; rg < P.n_groups; rg += gridDim.x) {
+    const int row = rg * RW + rw;
+    const int rowc = row < N ? row : N - 1;  // spare rows recompute the last one (not stored)
+    float acc[TOK][8];
+#pragma unroll
+    for (int t = 0; t < TOK; ++t)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[t][i] = 0.f;
+
+    IdxWindow<FMT> nxt;
+    if (part < n_chunks) {
+      const int g0 = part * kLChunk + lane * 8;
+      fetch_window<FMT>(nxt, P, rowc, g0 < G ? g0 : G - 8);
+    }
+    for (int ch = part; ch < n_chunks; ch += PW) {
+      const IdxWindow<FMT> cur = nxt;
+      const int g0r = ch * kLChunk + lane * 8;
+      const bool valid = g0r < G;
+      const int g0 = valid ? g0r : G - 8;  // lanes past G redo the last 8 columns with x = 0
+      // activations / scale / bias of the lane's 8 columns (L1 / L2 resident)
+      u32x4 xr[TOK], sr = {0, 0, 0, 0}, br = {0, 0, 0, 0};
+      if (P.perm) {
+        const u32x4 pv = *(const u32x4*)as_global(P.perm + g0);
+#pragma unroll
+        for (int t = 0; t < TOK; ++t) {
+          const uint16_t* xt = as_global(P.x + (size_t)(t < tokens ? t : tokens - 1) * G);
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            xr[t][q] = (uint32_t)xt[pv[q] & 0xffffu] | ((uint32_t)xt[pv[q] >> 16] << 16);
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < TOK; ++t)
+          xr[t] = *(const u32x4*)as_global(P.x + (size_t)(t < tokens ? t : tokens - 1) * G + g0);
+      }
+      if (P.scale) sr = *(const u32x4*)as_global(P.scale + g0);
+      if (P.wbias) br = *(const u32x4*)as_global(P.wbias + g0);
+      // next chunk's index words
+      if (ch + PW < n_chunks) {
+        const int gn = (ch + PW) * kLChunk + lane * 8;
+        fetch_window<FMT>(nxt, P, rowc, gn < G ? gn : G - 8);
+      }
+      if (!valid) {
+#pragma unroll
+        for (int t = 0; t < TOK; ++t) xr[t] = u32x4{0, 0, 0, 0};
+      }
+      IdxDecoded<FMT> dec;
+      normalise_window<FMT>(dec, cur, P, rowc, g0);
+      // gathers kGB elements at a time (fewer with more token accumulators: no spills)
+      constexpr int kGB = kF16 ? (TOK == 4 ? 2 : 4) : (TOK == 1 ? 4 : 2);
+      auto batch = [&](auto e0c) {
+        constexpr int e0 = decltype(e0c)::value;
+        u32x4 cv[kGB], rv[kGB];
+        auto gather1 = [&](auto uc) {
+          constexpr int u = decltype(uc)::value;
+          uint32_t am, ar;
+          decode_elem<FMT, e0 + u>(dec, P, res_base, am, ar);
+          cv[u] = lds_load16(am);
+          if (has_res) rv[u] = lds_load16(ar);
+        };
+        gather1(std::integral_constant<int, 0>{});
+        if constexpr (kGB > 1) gather1(std::integral_constant<int, 1>{});
+        if constexpr (kGB > 2) { gather1(std::integral_constant<int, 2>{}); gather1(std::integral_constant<int, 3>{}); }
+#pragma unroll
+        for (int u = 0; u < kGB; ++u) {
+          const int e = e0 + u, q = e >> 1, h = e & 1;
+          if constexpr (kF16) {
+            uint32_t w2[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) w2[p] = has_res ? DT::add2(cv[u][p], rv[u][p]) : cv[u][p];
+            if (P.scale) {
+#pragma unroll
+              for (int p = 0; p < 4; ++p) w2[p] = DT::mul2_bcast(w2[p], sr[q], h);
+            }
+            if (P.wbias) {
+#pragma unroll
+              for (int p = 0; p < 4; ++p) w2[p] = DT::add2_bcast(w2[p], br[q], h);
+            }
+#pragma unroll
+            for (int t = 0; t < TOK; ++t)
+#pragma unroll
+              for (int p = 0; p < 4; ++p) {
+                acc[t][2 * p] = DT::fma_lo_h(w2[p], xr[t][q], h, acc[t][2 * p]);
+                acc[t][2 * p + 1] = DT::fma_hi_h(w2[p], xr[t][q], h, acc[t][2 * p + 1]);
+              }
+          } else {
+            const float sf = P.scale ? DT::half_of(sr[q], h) : 1.f;
+            float xs[TOK];
+#pragma unroll
+            for (int t = 0; t < TOK; ++t) xs[t] = sf * DT::half_of(xr[t][q], h);
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+              float wl = DT::lo(cv[u][p]), wh = DT::hi(cv[u][p]);
+              if (has_res) { wl += DT::lo(rv[u][p]); wh += DT::hi(rv[u][p]); }
+#pragma unroll
+              for (int t = 0; t < TOK; ++t) {
+                acc[t][2 * p] = __builtin_fmaf(wl, xs[t], acc[t][2 * p]);
+                acc[t][2 * p + 1] = __builtin_fmaf(wh, xs[t], acc[t][2 * p + 1]);
+              }
+            }
+          }
+        }
+      };
+      batch(std::integral_constant<int, 0>{});
+      if constexpr (kGB < 8) batch(std::integral_constant<int, kGB>{});
+      if constexpr (kGB < 4) { batch(std::integral_constant<int, 2 * kGB>{}); batch(std::integral_constant<int, 3 * kGB>{}); }
+    }
+    // ---- reduce: over the lanes of the wave, then over the PW waves of the row
+    float v[NV];
+#pragma unroll
+    for (int t = 0; t < TOK; ++t)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[t * 8 + i] = acc[t][i];
+    WaveReduce<NV>::run(v, lane);
+    constexpr int kShift = WaveReduce<NV>::kShift;
+    if ((lane & ((1 << kShift) - 1)) == 0) red[wave * NV + (lane >> kShift)] = v[0];
+    __syncthreads();
+    if (tid < RW * NV) {
+      const int r2 = tid / NV, ent = tid - r2 * NV;
+      const int t = ent >> 3, i = ent & 7;
+      const int orow = rg * RW + r2;
+      const int o = orow * 8 + i;
+      if (t < tokens && orow < N && o < O) {
+        float s = 0.f;
+        for (int p = 0; p < PW; ++p) s += red[(r2 * PW + p) * NV + ent];
+        if constexpr (!kF16) s += bsum[t];
+        if (P.bias) s += DT::to_float(as_global(P.bias)[o]);
+        if (P.out_f32) ((float*)as_global((uint16_t*)P.y))[(size_t)t * O + o] = s;
+        else as_global((uint16_t*)P.y)[(size_t)t * O + o] = DT::from_float(s);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ---- host side ------------------------------------------------------------------------
+static int lds_cus() {
+  static int cus[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (!cus[dev]) {
+    hipDeviceProp_t p;
+    cus[dev] = hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0
+                   ? p.multiProcessorCount : 256;
+  }
+  return cus[dev];
+}
+
+static int lds_bytes(int k, int kr, int tok) {
+  return (k + kr) * 16 + (kLWaves * 8 * tok + tok * kLWaves + tok + 16) * 4;
+}
+
+static bool lds_fmt_ok(int fmt) {
+  return fmt == 12 || fmt == 13 || fmt == 20 || fmt == 21 || fmt == 22 || fmt == kFmtV2None ||
+         fmt == kFmtV2U8 || fmt == kFmtV2U16;
+}
+
+template <typename DT, int FMT, int TOK>
+static hipError_t launch_lds_t(const LdsParams& P, int grid, int lds, hipStream_t st) {
+  auto kern = gemv_lds_kernel<DT, FMT, TOK>;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  static bool attr_set[64] = {};
+  if (!attr_set[dev]) {
+    const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kLMaxLds);
+    if (e != hipSuccess) return e;
+    attr_set[dev] = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(kLThreads), lds, st, P);
+  return hipGetLastError();
+}
+
+template <typename DT, int FMT>
+static hipError_t launch_lds_fmt(const LdsParams& P, int tok, int grid, int lds, hipStream_t st) {
+  if (tok == 1) return launch_lds_t<DT, FMT, 1>(P, grid, lds, st);
+  if (tok == 2) return launch_lds_t<DT, FMT, 2>(P, grid, lds, st);
+  // four token slots: fp16 only (the widened bf16 arithmetic would spill)
+  if constexpr (std::is_same<DT, F16>::value) return launch_lds_t<DT, FMT, 4>(P, grid, lds, st);
+  return hipErrorInvalidValue;
+}
+
+template <typename DT>
+static hipError_t launch_lds_dt(const LdsParams& P, int fmt, int tok, int grid, int lds, hipStream_t st) {
+  switch (fmt) {
+    case 12: return launch_lds_fmt<DT, 12>(P, tok, grid, lds, st);
+    case 13: return launch_lds_fmt<DT, 13>(P, tok, grid, lds, st);
+    case 20: return launch_lds_fmt<DT, 20>(P, tok, grid, lds, st);
+    case 21: return launch_lds_fmt<DT, 21>(P, tok, grid, lds, st);
+    case 22: return launch_lds_fmt<DT, 22>(P, tok, grid, lds, st);
+    case kFmtV2None: return launch_lds_fmt<DT, kFmtV2None>(P, tok, grid, lds, st);
+    case kFmtV2U8: return launch_lds_fmt<DT, kFmtV2U8>(P, tok, grid, lds, st);
+    case kFmtV2U16: return launch_lds_fmt<DT, kFmtV2U16>(P, tok, grid, lds, st);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+// common tail: row-group geometry + launch (tokens <= 4 per launch)
+static hipError_t launch_lds(LdsParams& P, int fmt, bool f16, hipStream_t st) {
+  if (!f16 && P.tokens > 2) return hipErrorInvalidValue;  // (bf16: 2 token slots, see gemv_lds_max_chunk)
+  const int tok = P.tokens > 2 ? 4 : P.tokens;
+  const int lds = lds_bytes(P.k, P.kr, tok);
+  if (lds > kLMaxLds || !lds_fmt_ok(fmt)) return hipErrorInvalidValue;
+  const int cus = lds_cus();
+  int RW = kLWaves;
+  while (RW > 1 && (P.N + RW - 1) / RW < cus) RW >>= 1;
+  P.RW = RW;
+  P.n_groups = (P.N + RW - 1) / RW;
+  const int grid = P.n_groups < cus ? P.n_groups : cus;
+  return f16 ? launch_lds_dt<F16>(P, fmt, tok, grid, lds, st) : launch_lds_dt<BF16>(P, fmt, tok, grid, lds, st);
+}
+
+// tokens one launch takes: 4 (fp16) / 2 (bf16)
+int gemv_lds_max_chunk(int dtype) { return dtype == VPTQ_DTYPE_F16 ? 4 : 2; }
+
+bool gemv_lds_eligible(const VptqLayerDesc& d, int tokens, int flags) {
+  if (d.vector_len != 8 || d.num_codebooks != 1 || d.outlier_size != 0) return false;
+  if (d.num_centroids <= 256 || d.num_centroids > 8192 || d.num_res_centroids > 512) return false;
+  if (d.group_size != d.in_features || (d.group_size & 7)) return false;
+  if (!lds_fmt_ok(d.index_bits + d.res_bits)) return false;
+  if (lds_bytes(d.num_centroids, d.num_res_centroids, 4) > kLMaxLds) return false;
+  if ((d.weight_scale != nullptr) && d.perm && !(d.scale_permuted && d.bias_permuted)) return false;
+  // bf16 computes the folded form here: the caller asked for the reference's roundings
+  if (d.dtype != VPTQ_DTYPE_F16 && (flags & VPTQ_GEMV_EXACT)) return false;
+  if ((((uintptr_t)d.centroids | (uintptr_t)d.res_centroids) & 15) != 0) return false;
+  return tokens >= 1 && tokens <= 4;
+}
+
+hipError_t launch_gemv_lds(const VptqLayerDesc& d, const void* x, void* y, int tokens, bool out_f32,
+                           hipStream_t st) {
+  LdsParams P = {};
+  P.idx = (const uint32_t*)d.indices;
+  P.ridx = nullptr;
+  P.cent = (const uint32_t*)d.centroids;
+  P.rcent = (const uint32_t*)d.res_centroids;
+  P.x = (const uint16_t*)x;
+  P.y = y;
+  const bool norm = d.weight_scale != nullptr;
+  P.scale = (const uint16_t*)(norm ? (d.perm ? d.scale_permuted : d.weight_scale) : nullptr);
+  P.wbias = (const uint16_t*)(norm ? (d.perm ? d.bias_permuted : d.weight_bias) : nullptr);
+  P.wbias_plain = (const uint16_t*)(norm ? d.weight_bias : nullptr);
+  P.bias = (const uint16_t*)d.bias;
+  P.perm = d.perm;
+  P.N = d.num_indices; P.G = d.group_size; P.O = d.out_features; P.row_words = d.row_words;
+  P.k = d.num_centroids; P.kr = d.num_res_centroids; P.ib = d.index_bits; P.rb = d.res_bits;
+  P.tokens = tokens; P.out_f32 = out_f32 ? 1 : 0;
+  return launch_lds(P, d.index_bits + d.res_bits, d.dtype == VPTQ_DTYPE_F16, st);
+}
+
+bool gemv_lds_v2_eligible(const VptqV2Desc& d, int tokens) {
+  if (d.vector_len != 8 || d.num_centroids < 1 || d.num_centroids > 8192 || d.num_res_centroids > 512)
+    return false;
+  if ((d.in_features & 7) || lds_bytes(d.num_centroids, d.num_res_centroids, 4) > kLMaxLds) return false;
+  if ((((uintptr_t)d.centroids | (uintptr_t)d.res_centroids | (uintptr_t)d.indices) & 15) != 0) return false;
+  if (d.num_res_centroids > 0 && (((uintptr_t)d.res_indices) & 7) != 0) return false;
+  return tokens >= 1 && tokens <= 4;
+}
+
+hipError_t launch_gemv_lds_v2(const VptqV2Desc& d, const void* x, void* y, int tokens, bool out_f32,
+                              hipStream_t st) {
+  LdsParams P = {};
+  P.idx = (const uint32_t*)d.indices;
+  P.ridx = d.num_res_centroids > 0 ? d.res_indices : nullptr;
+  P.cent = (const uint32_t*)d.centroids;
+  P.rcent = (const uint32_t*)(d.num_res_centroids > 0 ? d.res_centroids : nullptr);
+  P.x = (const uint16_t*)x;
+  P.y = y;
+  P.scale = (const uint16_t*)d.scale_weights;
+  P.wbias = (const uint16_t*)d.scale_bias;
+  P.wbias_plain = (const uint16_t*)d.scale_bias;
+  P.bias = (const uint16_t*)d.bias;
+  P.perm = nullptr;
+  P.N = d.out_features / 8; P.G = d.in_features; P.O = d.out_features; P.row_words = 0;
+  P.k = d.num_centroids; P.kr = d.num_res_centroids > 0 ? d.num_res_centroids : 0;
+  P.ib = 16; P.rb = 0;
+  P.tokens = tokens; P.out_f32 = out_f32 ? 1 : 0;
+  const int fmt = d.num_res_centroids <= 0 ? kFmtV2None : d.res_index_bytes == 1 ? kFmtV2U8 : kFmtV2U16;
+  return launch_lds(P, fmt, d.dtype == VPTQ_DTYPE_F16, st);
+}
+
+}  // namespace vptq

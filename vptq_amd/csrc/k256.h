@@ -42,13 +42,6 @@ struct K256Params {
   K256Layer layer[kMaxGroup];
 };
 
-// A pointer that came out of inline assembly or integer arithmetic is "flat" to the compiler
-// (flat_load: slower, and counted in lgkmcnt as well): say that it is global.
-template <typename T>
-static __device__ __forceinline__ T* as_global(T* p) {
-  typedef T __attribute__((address_space(1))) global_t;
-  return (T*)(global_t*)(uintptr_t)p;
-}
 // This workgroup's layer (blockIdx.y) and the token count, fetched from the kernel-argument
 // segment with ONE batch of scalar loads and one wait (inside the same asm statement, so no
 // register is read before it has landed).  Left to the compiler, the fields are loaded where

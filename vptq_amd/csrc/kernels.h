@@ -24,6 +24,16 @@ bool gemv_gather_eligible(const VptqLayerDesc& d, int tokens);
 hipError_t launch_gemv_gather(const VptqLayerDesc& d, const void* x, void* y, int tokens,
                               bool out_f32, hipStream_t st);
 
+// gemv_lds.hip - v=8, one codebook, 256 < k <= 8192, kr <= 512: both codebooks LDS-resident,
+// packed bit stream (T in {12, 13, 20, 21, 22}) or the v2 wire format
+bool gemv_lds_eligible(const VptqLayerDesc& d, int tokens, int flags);
+int gemv_lds_max_chunk(int dtype);
+hipError_t launch_gemv_lds(const VptqLayerDesc& d, const void* x, void* y, int tokens, bool out_f32,
+                           hipStream_t st);
+bool gemv_lds_v2_eligible(const VptqV2Desc& d, int tokens);
+hipError_t launch_gemv_lds_v2(const VptqV2Desc& d, const void* x, void* y, int tokens, bool out_f32,
+                              hipStream_t st);
+
 // dequant.hip
 hipError_t launch_dequant(const VptqLayerDesc& d, void* W, hipStream_t st);
 
