@@ -88,9 +88,11 @@ enum {
   VPTQ_GEMV_OUT_F32 = 1 << 5
 };
 
-/* most tokens vptq_quant_gemv accepts; whether the fused GEMV is also the FASTER path for a
- * layer at a token count is what vptq_quant_gemv_max_tokens() answers */
-#define VPTQ_GEMV_MAX_TOKENS 16
+/* most tokens vptq_quant_gemv accepts (fp16 layers of the canonical format; every other layer:
+ * VPTQ_GEMV_MAX_TOKENS_ANY); whether the fused path is also the FASTER one for a layer at a
+ * token count is what vptq_quant_gemv_max_tokens() answers */
+#define VPTQ_GEMV_MAX_TOKENS 64
+#define VPTQ_GEMV_MAX_TOKENS_ANY 16
 
 /*
  * One VQuantLinear layer in the reference's on-disk tensor formats
@@ -184,9 +186,11 @@ VPTQ_API size_t vptq_quant_gemv_workspace_bytes(const VptqLayerDesc* desc, int t
 /*
  * Largest token count for which vptq_quant_gemv is the path to take for this layer; above it
  * vptq_dequant + a dense GEMM is faster (the reference switches at 3 for every format,
- * vptq/ops/quant_gemm.py:213).  16 for the canonical v=8 / 256+256 format (its kernels take 4
- * tokens per launch at 1.3-1.5x the cost of one; measured crossover 20-24 tokens,
- * tools/tokens_crossover.py), 8 for every other format.  0 if desc is invalid.
+ * vptq/ops/quant_gemm.py:213).  48 for fp16 layers of the canonical v=8 / 256+256 format (5+
+ * tokens = launches of the batched-decode kernel, 16 tokens each: 18 us per 8192^2 layer and
+ * launch against 76-80 us for dequant + GEMM; measured crossover 48-64 tokens,
+ * tools/tokens_crossover.py), 16 for its bf16 layers (launches of <= 4 tokens), 8 for every
+ * other format.  0 if desc is invalid.
  */
 VPTQ_API int vptq_quant_gemv_max_tokens(const VptqLayerDesc* desc);
 

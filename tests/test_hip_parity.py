@@ -73,7 +73,7 @@ def test_forward_vs_reference_golden(name, dev):
 def test_canonical_layers_take_the_specialised_kernel(name, dev):
     L, x, y, cfg, _ = load_golden(name)
     m = spec_to_module(L, dev)
-    assert kernel_name(m, cfg["tokens"]).startswith("gemv_k256")
+    assert kernel_name(m, cfg["tokens"]).startswith("gemv_k256" if cfg["tokens"] <= 4 else "gemm_k256")
     assert kernel_name(m, cfg["tokens"], GENERIC) == "gemv_generic_kernel"
     xt = bits_to_tensor(x, cfg["dtype"], dev).reshape(x.shape)
     a = tensor_to_bits(gemv_abi(m, xt, EXACT))
@@ -134,10 +134,11 @@ def test_gemv_and_dequant_vs_oracle(I, O, kw, tokens, dev):
 
 
 @pytest.mark.parametrize("k", [256, 65536])
-@pytest.mark.parametrize("tokens", [1, 2, 3, 4, 5, 8, 9, 13, 16, 17, 33])
+@pytest.mark.parametrize("tokens", [1, 2, 3, 4, 5, 8, 9, 13, 16, 17, 33, 49])
 def test_token_counts_gemv_and_gemm_paths(tokens, k, dev):
-    """1..8 tokens (canonical 256 + 256 format: 1..16): fused GEMV; more: dequant + F.linear (the
-    reference switches at 3).  Module forward and the functional op agree."""
+    """1..8 tokens (canonical 256 + 256 format: 1..48, from 5 on the batched-decode kernel in launches
+    of 16): fused; more: dequant + F.linear (the reference switches at 3).  Module forward and the
+    functional op agree."""
     from vptq_amd import _backend as B
     kw = dict(num_res_centroids=256) if k == 256 else dict(num_centroids=65536, num_res_centroids=-1)
     L = vo.make_layer(1024, 256, dist="llm", seed=11, bias=True, **kw)
@@ -145,16 +146,16 @@ def test_token_counts_gemv_and_gemm_paths(tokens, k, dev):
                     .astype(np.float32), "f16")[:1]
     m = spec_to_module(L, dev)
     desc, keep = module_desc(m)
-    assert B.lib().vptq_quant_gemv_max_tokens(desc) == (16 if k == 256 else 8)
+    assert B.lib().vptq_quant_gemv_max_tokens(desc) == (48 if k == 256 else 8)
     xt = bits_to_tensor(x, "f16", dev).reshape(x.shape)
     got = tensor_to_bits(m(xt))
     want = vo.forward(L, x)
     assert rel_err(got, want, "f16") <= 1e-3
-    if tokens <= 16:   # the C ABI accepts up to 16 tokens for every format
+    if tokens <= 16 or k == 256:   # the C ABI accepts up to 16 tokens for every format (canonical fp16: 64)
         flags = module_flags()   # what the module forward passes (VPTQ_EXACT=1: exact)
         assert rel_err(tensor_to_bits(gemv_abi(m, xt, flags)), want, "f16") <= 1e-3
-        if tokens <= (16 if k == 256 else 8):
-            assert (tensor_to_bits(gemv_abi(m, xt, flags)) == got).all()   # forward took the GEMV
+        if tokens <= (48 if k == 256 else 8):
+            assert (tensor_to_bits(gemv_abi(m, xt, flags)) == got).all()   # forward took the fused path
 
 
 def test_default_and_exact_arithmetic(dev):
@@ -965,3 +966,60 @@ def test_lds_kernel_golden_and_determinism(dev):
     assert all((o == outs[0]).all() for o in outs)
     assert rel_err(outs[0], y, cfg["dtype"]) <= TOL[cfg["dtype"]]
     assert bit_identical_frac(outs[0], y) >= 0.9
+
+
+# ---------------------------------------------------------------- batched decode: 5-16 tokens, one launch
+GEMM_CASES = [
+    # I, O, kwargs, tokens
+    (1024, 256, dict(bias=True), 5),
+    (2048, 1032, dict(), 16),                       # rows not a multiple of the 4-row group
+    (4104, 264, dict(enable_perm=True), 9),         # ragged last tile of 1024 columns + permutation
+    (8192, 8192, dict(dist="llm"), 16),             # BASELINE size, one row group per workgroup
+    (1024, 12288, dict(dist="llm", bias=True), 7),  # 384 row groups: 2 per workgroup on some CUs
+    (512, 8 * 4 * 1100, dict(dist="llm"), 13),      # 1100 row groups: two passes of <= 4 groups
+    (14336, 512, dict(dist="llm"), 6),              # 14 tiles
+]
+
+
+@pytest.mark.parametrize("I,O,kw,tokens", GEMM_CASES)
+def test_batched_decode_kernel_vs_oracle(I, O, kw, tokens, dev):
+    """gemm_k256_kernel (canonical format, fp16, 5-16 tokens in one launch): dequantised tiles with
+    the reference's roundings -> LDS -> v_mfma_f32_16x16x16_f16, i.e. the arithmetic of the
+    reference's own path for these token counts, dequant + F.linear (quant_gemm.py:231-274)."""
+    kw = dict(kw)
+    dist = kw.pop("dist", "ref-test")
+    L = vo.make_layer(I, O, dist=dist, seed=I + O + tokens, **kw)
+    rng = np.random.default_rng(tokens)
+    xs = (0.02 + 0.5 * rng.standard_normal((1, tokens, I))) if dist == "ref-test" \
+        else rng.standard_normal((1, tokens, I))
+    x = vo.from_f32(xs.astype(np.float32), "f16")
+    m = spec_to_module(L, dev)
+    assert kernel_name(m, tokens) == "gemm_k256_kernel"
+    xt = bits_to_tensor(x, "f16", dev).reshape(x.shape)
+    got = m(xt)
+    # bit-level partner on the GPU: HIP dequant (bit-exact W) + fp32 matmul, rounded once
+    W = m.dequant().float()
+    ref = (xt.float() @ W.t())
+    if m.bias is not None:
+        ref = ref + m.bias.float()
+    ref16 = tensor_to_bits(ref.to(torch.float16))
+    gb = tensor_to_bits(got)
+    assert rel_err(gb, ref16, "f16") <= 1e-3 and bit_identical_frac(gb, ref16) >= 0.95   # (1 ulp of the largest output = 9.8e-4)
+    if I * O <= 2048 * 2048:
+        assert rel_err(gb, vo.forward(L, x), "f16") <= 1e-3
+    # every token row equals that token alone through the one-token kernel (exact form)
+    one = tensor_to_bits(gemv_abi(m, xt[:, tokens - 1:tokens].contiguous(), EXACT))
+    assert rel_err(gb[:, tokens - 1:tokens], one, "f16") <= 1e-3
+    # fp32 output
+    from vptq_amd.utils.shard import forward_partial_f32
+    assert torch.equal(forward_partial_f32(m, xt).to(torch.float16), got)
+    # determinism
+    assert torch.equal(m(xt), got)
+
+
+def test_batched_decode_golden_16_tokens(dev):
+    L, x, y, cfg, _ = load_golden("canon_t16_perm")
+    m = spec_to_module(L, dev)
+    assert kernel_name(m, 16) == "gemm_k256_kernel" and kernel_name(m, 4).startswith("gemv_k256")
+    out = tensor_to_bits(m(bits_to_tensor(x, "f16", dev).reshape(x.shape)))
+    assert rel_err(out, y, "f16") <= 1e-3 and bit_identical_frac(out, y) >= 0.9

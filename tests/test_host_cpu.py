@@ -71,7 +71,8 @@ def test_kernel_choice_without_gpu():
     lib = B.lib()
     name = lambda d, tok, fl=0: lib.vptq_quant_gemv_kernel_name(d, tok, fl)  # noqa: E731
     big, small = _canonical_desc(8192, 8192), _canonical_desc(4096, 4096)
-    assert lib.vptq_quant_gemv_max_tokens(big) == 16
+    assert lib.vptq_quant_gemv_max_tokens(big) == 48
+    assert lib.vptq_quant_gemv_max_tokens(_canonical_desc(8192, 8192, dtype=1)) == 16   # bf16: <= 4-token launches
     for tok in (1, 2, 3, 4):
         assert name(big, tok) == b"gemv_k256m_kernel<fast>"
         assert name(small, tok) == (b"gemv_k256_kernel<fast>" if tok <= 2 else b"gemv_k256_kernel")
@@ -80,7 +81,9 @@ def test_kernel_choice_without_gpu():
     assert name(big, 1, B.GEMV_FORCE_VALU) == b"gemv_k256_kernel<fast>"
     assert name(small, 1, B.GEMV_FORCE_MFMA) == b"gemv_k256m_kernel<fast>"
     assert name(big, 1, B.GEMV_FORCE_GENERIC) == b"gemv_generic_kernel"
-    assert name(big, 16) is not None and name(big, 17) is None
+    assert name(big, 4) == b"gemv_k256m_kernel<fast>" and name(big, 5) == name(big, 16) == b"gemm_k256_kernel"
+    assert name(big, 64) == b"gemm_k256_kernel" and name(big, 65) is None          # launches of 16 tokens
+    assert name(_canonical_desc(8192, 8192, dtype=1), 16) is not None and name(_canonical_desc(8192, 8192, dtype=1), 17) is None
     # bf16: folded form in the MFMA kernel from 32 row groups (128 vector-rows) on
     assert name(_canonical_desc(4096, 1024, dtype=1), 1) == b"gemv_k256m_kernel<fast>"
     assert name(_canonical_desc(4096, 512, dtype=1), 1) == b"gemv_k256_kernel"

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Where does the fused GEMV (chunks of <= 4 tokens, one launch each) stop beating
+"""Where does the fused GEMV / batched-decode kernel (calls of <= 16 tokens) stop beating
 dequant + dense GEMM?  Per shape and token count, a ring of distinct layers, hipGraph replay.
 
     python tools/tokens_crossover.py --shapes "4096,4096;8192,8192" --tokens 4,8,12,16,24,32
@@ -34,8 +34,8 @@ def main():
 
             def gemv():
                 for d, _ in descs:
-                    for t0 in range(0, T, 4):
-                        m = min(4, T - t0)
+                    for t0 in range(0, T, 16):   # the library takes <= 16 tokens per call
+                        m = min(16, T - t0)
                         B.check(lib.vptq_quant_gemv(d, x[0, t0].data_ptr(), y[0, t0].data_ptr(), m, 0, None, 0,
                                                     torch.cuda.current_stream().cuda_stream), "gemv")
 

@@ -26,7 +26,7 @@ GEMV_EXACT = 1 << 2
 GEMV_FORCE_MFMA = 1 << 3
 GEMV_FORCE_VALU = 1 << 4
 GEMV_OUT_F32 = 1 << 5     # y is float32: un-rounded sums (row-parallel partial outputs)
-GEMV_MAX_TOKENS = 16       # what vptq_quant_gemv accepts; per layer: vptq_quant_gemv_max_tokens
+GEMV_MAX_TOKENS = 64       # most vptq_quant_gemv accepts (any layer: 16); per layer: vptq_quant_gemv_max_tokens
 GEMV_ANY_FORMAT_TOKENS = 8  # the fused GEMV is the faster path for every format up to here
 GROUP_MAX = 64
 

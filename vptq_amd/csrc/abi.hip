@@ -2,6 +2,7 @@
 // kernel selection, launch.  No allocation, no synchronisation, no torch.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "kernels.h"
 
@@ -95,11 +96,16 @@ size_t vptq_quant_gemv_workspace_bytes(const VptqLayerDesc*, int, int) { return 
 
 int vptq_quant_gemv_max_tokens(const VptqLayerDesc* d) {
   if (validate_layer(d) != VPTQ_OK) return 0;
-  return vptq::gemv_k256_eligible(*d, 4) ? VPTQ_GEMV_MAX_TOKENS : 8;
+  if (vptq::gemm_k256_eligible(*d, 16, 0)) return 48;
+  return vptq::gemv_k256_eligible(*d, 4) ? VPTQ_GEMV_MAX_TOKENS_ANY : 8;
 }
 
 const char* vptq_quant_gemv_kernel_name(const VptqLayerDesc* d, int tokens, int flags) {
   if (validate_layer(d) != VPTQ_OK || tokens < 1 || tokens > VPTQ_GEMV_MAX_TOKENS) return nullptr;
+  if (!(flags & (VPTQ_GEMV_FORCE_GENERIC | VPTQ_GEMV_FORCE_VALU | VPTQ_GEMV_FORCE_MFMA)) && tokens >= 5 &&
+      vptq::gemm_k256_eligible(*d, tokens > 16 ? 16 : tokens, flags))
+    return "gemm_k256_kernel";
+  if (tokens > VPTQ_GEMV_MAX_TOKENS_ANY) return nullptr;
   if (!(flags & VPTQ_GEMV_FORCE_GENERIC) && vptq::gemv_k256_eligible(*d, tokens > 4 ? 4 : tokens))
     return vptq::gemv_k256_name(*d, tokens, flags);
   if (!(flags & VPTQ_GEMV_FORCE_GENERIC) && vptq::gemv_gather_eligible(*d, tokens > 4 ? 4 : tokens))
@@ -111,7 +117,7 @@ const char* vptq_quant_gemv_kernel_name(const VptqLayerDesc* d, int tokens, int 
 
 const char* vptq_quant_gemv_grouped_kernel_name(const VptqLayerDesc* descs, int n, int tokens,
                                                 int flags) {
-  if (!descs || n < 1 || n > 32 || tokens < 1 || tokens > VPTQ_GEMV_MAX_TOKENS) return nullptr;
+  if (!descs || n < 1 || n > 32 || tokens < 1 || tokens > VPTQ_GEMV_MAX_TOKENS_ANY) return nullptr;
   bool one_launch = !(flags & VPTQ_GEMV_FORCE_GENERIC);
   for (int i = 0; i < n; ++i) {
     if (validate_layer(&descs[i]) != VPTQ_OK) return nullptr;
@@ -135,6 +141,24 @@ int vptq_quant_gemv(const VptqLayerDesc* d, const void* x, void* y, int tokens, 
   hipError_t e;
   const bool out_f32 = (flags & VPTQ_GEMV_OUT_F32) != 0;
   const size_t yes = out_f32 ? 4 : 2;  // bytes per output element
+  // canonical format, fp16, 5-16 tokens: ONE launch of the batched-decode kernel (tokens = the
+  // M dimension of a 16x16x16 MFMA; reference arithmetic)
+  static int batch_min = -1;  // VPTQ_GEMM_MIN_TOKENS: smallest token count that takes it
+  if (batch_min < 0) { const char* ev = getenv("VPTQ_GEMM_MIN_TOKENS"); batch_min = ev ? atoi(ev) : 5; }
+  if (!(flags & (VPTQ_GEMV_FORCE_GENERIC | VPTQ_GEMV_FORCE_VALU | VPTQ_GEMV_FORCE_MFMA)) &&
+      tokens >= batch_min && vptq::gemm_k256_eligible(*d, tokens > 16 ? 16 : tokens, flags) &&
+      (((uintptr_t)x) & 15) == 0) {
+    for (int t0 = 0; t0 < tokens; t0 += 16) {   // 16 tokens per launch
+      const int m = tokens - t0 < 16 ? tokens - t0 : 16;
+      e = vptq::launch_gemm_k256(*d, (const char*)x + (size_t)t0 * d->in_features * 2,
+                                 (char*)y + (size_t)t0 * d->out_features * yes, m, out_f32, st);
+      if (e != hipSuccess) return hip_fail(e, "gemm_k256 launch");
+    }
+    return VPTQ_OK;
+  }
+  if (tokens > VPTQ_GEMV_MAX_TOKENS_ANY)
+    return fail(VPTQ_E_TOKENS, "tokens %d outside [1, %d] for this layer: use vptq_dequant + GEMM", tokens,
+                VPTQ_GEMV_MAX_TOKENS_ANY);
   // the specialised kernels take up to 4 tokens per launch; more tokens = more launches
   // (up to 16 tokens still cheaper than a dense dequant + GEMM, tools/tokens_crossover.py)
   const int chunk = tokens > 4 ? 4 : tokens;
@@ -183,8 +207,8 @@ int vptq_quant_gemv_grouped(const VptqLayerDesc* descs, int n, const void* const
                             void* const* y, int tokens, int flags, void* stream) {
   if (!descs || !x || !y) return fail(VPTQ_E_NULL, "descs / x / y is NULL");
   if (n < 1 || n > VPTQ_GROUP_MAX) return fail(VPTQ_E_SHAPE, "n %d outside [1, %d]", n, VPTQ_GROUP_MAX);
-  if (tokens < 1 || tokens > VPTQ_GEMV_MAX_TOKENS)
-    return fail(VPTQ_E_TOKENS, "tokens %d outside [1, %d]", tokens, VPTQ_GEMV_MAX_TOKENS);
+  if (tokens < 1 || tokens > VPTQ_GEMV_MAX_TOKENS_ANY)
+    return fail(VPTQ_E_TOKENS, "tokens %d outside [1, %d]", tokens, VPTQ_GEMV_MAX_TOKENS_ANY);
   bool all_fast = !(flags & VPTQ_GEMV_FORCE_GENERIC);
   bool same_perm = true;  // one instantiation serves the whole group
   for (int i = 0; i < n; ++i) {

@@ -34,6 +34,11 @@ bool gemv_lds_v2_eligible(const VptqV2Desc& d, int tokens);
 hipError_t launch_gemv_lds_v2(const VptqV2Desc& d, const void* x, void* y, int tokens, bool out_f32,
                               hipStream_t st);
 
+// gemm_k256.hip - canonical format, fp16, up to 16 tokens in one launch (tokens = MFMA M)
+bool gemm_k256_eligible(const VptqLayerDesc& d, int tokens, int flags);
+hipError_t launch_gemm_k256(const VptqLayerDesc& d, const void* x, void* y, int tokens, bool out_f32,
+                            hipStream_t st);
+
 // dequant.hip
 hipError_t launch_dequant(const VptqLayerDesc& d, void* W, hipStream_t st);
 
