@@ -1,27 +1,32 @@
 #!/usr/bin/env python3
 """Decode-GEMV benchmark for the VPTQ hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--hidden 8192] [--mode single|grouped]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--hidden 8192] [--mode ...]
 
-Workload (BASELINE.json configs[1] at the hidden size the north-star target is
-quoted on): one VQuantLinear H x H, vector_len 8, k = 256 + 256 residual
-centroids (2 bits / weight), enable_norm, batch = 1, seq = 1, fp16.
-A *step* is one decode token through a RING of R distinct layers
-(R * packed-index bytes >= 512 MiB, so neither the 32 MiB of L2 nor the 256 MiB
-Infinity Cache can hold the weights between uses): R fused dequant+GEMV
-launches through the C ABI, captured once in a hipGraph and replayed.
-  --mode single  : one launch per layer (the reference's operator granularity)
+N = 1 (default): BASELINE.json configs[1] at the hidden size the north-star target is quoted on:
+one VQuantLinear H x H, vector_len 8, k = 256 + 256 residual centroids (2 bits / weight),
+enable_norm, batch = 1, seq = 1, fp16.  A *step* is one decode token through a RING of R
+distinct layers (R x packed-index bytes >= 512 MiB, so neither the 32 MiB of L2 nor the 256 MiB
+Infinity Cache can hold the weights between uses): R fused dequant + GEMV launches through the
+C ABI, captured once in a hipGraph and replayed.  After W warm-up steps, `--regions` (5) timed
+regions of EXACTLY K steps each are run, every one bracketed by a barrier + synchronize; the
+line reports the MEDIAN region (all of them are listed under "regions_ms_per_step").
+  --mode single  : one launch per layer (the reference's operator granularity)          [N = 1 default]
   --mode grouped : layers launched 4 at a time with vptq_quant_gemv_grouped
-                   (q/k/v/o-style fusion of independent projections)
-  --mode tp      : BASELINE config #5 flavour: every layer is cut into N slices of its output
-                   rows (vptq_amd.utils.shard.shard_out_features), one per rank, and the slices
-                   are re-assembled with an RCCL all-gather per layer; strong scaling (total
-                   work fixed), expected NOT to scale at batch 1
-Inputs and weights are resident in HBM before the timed region.  With N > 1
-(torchrun, one rank per GPU) every rank owns its own ring: independent layers, no
-data-path collective, weak scaling; the time is the max over ranks.
+  --mode tp_row  : BASELINE config #5: the linear projections of Llama-3-70B decoder layers
+                   (q / o 8192^2, k / v 1024 x 8192, gate / up 28672 x 8192, down 8192 x 28672),
+                   every projection cut row-parallel (input columns, vptq_amd.utils.shard.
+                   shard_in_features) over the N ranks: fused GEMV with fp32 partial output ->
+                   RCCL all-reduce over xGMI -> one rounding.  Strong scaling (total work fixed). [N > 1 default]
+  --mode tp      : output rows split over the ranks, RCCL all-gather per layer (strong scaling)
+  --mode rings   : every rank its own ring of independent layers, no collective (weak scaling);
+                   with N > 1 this line is also attached to the tp_row line as "weak_scaling"
+Extras (N = 1, unless --no-extras): the same measurement at hidden 4096 (BASELINE configs[0/1]),
+with the reference's roundings (VPTQ_GEMV_EXACT), grouped x4, 16 tokens (batched-decode kernel),
+the k = 8192 + 256 format (LDS-resident codebooks), and tp_row on one GPU (the strong-scaling
+baseline), each a short ring of its own.
 
-Prints ONE JSON line; see README / DESIGN.md §6 for the fields.
+Inputs and weights are resident in HBM before the timed region.  Prints ONE JSON line.
 """
 import argparse
 import ctypes as C
@@ -39,12 +44,15 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md)
+LLAMA70B = dict(hidden=8192, ffn=28672, kv=1024)
 
 
-def alg_bytes(H):
-    """Algorithmic bytes of one H x H launch (DESIGN.md §5 / SURVEY.md §8d):
-    packed indices + both codebooks + x + scale + bias + y."""
-    return (H // 8) * (H * 16 // 32) * 4 + 2 * 256 * 8 * 2 + 2 * H + 4 * H + 2 * H
+def alg_bytes(I, O=None, k=256, kr=256, tokens=1):
+    """Algorithmic bytes of one launch (DESIGN.md section 5 / SURVEY.md 8d): packed indices + both
+    codebooks + x + scale + bias + y."""
+    O = I if O is None else O
+    T = int(np.log2(k)) + (int(np.log2(kr)) if kr > 0 else 0)
+    return (O // 8) * ((I * T + 31) // 32) * 4 + (k + max(kr, 0)) * 8 * 2 + tokens * 2 * I + 4 * I + tokens * 2 * O
 
 
 def shard_ring(total_layers, rank, world):
@@ -67,78 +75,306 @@ def job_throughput_gbps(world, bytes_per_launch_layer, layers_per_rank, steps, w
     return world * bytes_per_launch_layer * layers_per_rank * steps / wall_s / 1e9
 
 
-def make_ring(H, R, dev, seed):
+def make_layer(I, O, dev, g, k=256, kr=256):
     import vptq_amd
-    g = torch.Generator(device=dev).manual_seed(seed)
-    layers = []
-    for _ in range(R):
-        m = vptq_amd.VQuantLinear(
-            H, H, vector_lens=[-1, 8], num_centroids=[-1, 256], num_res_centroids=[-1, 256],
-            group_num=1, group_size=H, outlier_size=0, indices_as_float=False, enable_norm=True,
-            enable_perm=False, is_indice_packed=True, bias=False, dtype=torch.float16,
-            device=dev, enable_proxy_error=False)
-        m.indices.data = torch.randint(-2**31, 2**31 - 1, m.indices.shape, generator=g,
-                                       device=dev, dtype=torch.int64).to(torch.int32)
-        m.centroids.weight.data = (torch.randn(m.centroids.weight.shape, generator=g, device=dev) * 0.02).half()
+    m = vptq_amd.VQuantLinear(
+        I, O, vector_lens=[-1, 8], num_centroids=[-1, k], num_res_centroids=[-1, kr if kr > 0 else -1],
+        group_num=1, group_size=I, outlier_size=0, indices_as_float=False, enable_norm=True,
+        enable_perm=False, is_indice_packed=True, bias=False, dtype=torch.float16,
+        device=dev, enable_proxy_error=False)
+    m.indices.data = torch.randint(-2**31, 2**31 - 1, m.indices.shape, generator=g,
+                                   device=dev, dtype=torch.int64).to(torch.int32)
+    m.centroids.weight.data = (torch.randn(m.centroids.weight.shape, generator=g, device=dev) * 0.02).half()
+    if kr > 0:
         m.res_centroids.weight.data = (torch.randn(m.res_centroids.weight.shape, generator=g, device=dev) * 0.005).half()
-        m.weight_scale.data = (1 + 0.1 * torch.randn(H, generator=g, device=dev)).half()
-        m.weight_bias.data = (0.01 * torch.randn(H, generator=g, device=dev)).half()
-        layers.append(m.eval())
-    return layers
+    m.weight_scale.data = (1 + 0.1 * torch.randn(I, generator=g, device=dev)).half()
+    m.weight_bias.data = (0.01 * torch.randn(I, generator=g, device=dev)).half()
+    return m.eval()
+
+
+def make_ring(H, R, dev, seed, k=256, kr=256):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    return [make_layer(H, H, dev, g, k, kr) for _ in range(R)]
+
+
+def layer_spec(layer):
+    """vptq_amd.VQuantLinear (canonical-style, one codebook) -> oracle LayerSpec"""
+    from oracle import vptq_oracle as vo
+    to_np = lambda t: t.detach().cpu().contiguous().view(torch.int16).numpy().view(np.uint16)  # noqa: E731
+    k, kr = layer.num_centroids, layer.num_res_centroids
+    L = vo.LayerSpec(layer.in_features, layer.out_features, 8, k, kr, 1, layer.in_features, dtype="f16")
+    L.indices = layer.indices.detach().cpu().numpy()
+    L.centroids = to_np(layer.centroids.weight).reshape(1, k, 8)
+    L.res_centroids = to_np(layer.res_centroids.weight).reshape(1, kr, 8)
+    L.weight_scale, L.weight_bias = to_np(layer.weight_scale), to_np(layer.weight_bias)
+    return L
+
+
+def rel_err_bits(y_gpu, y_ref_bits):
+    from oracle import vptq_oracle as vo
+    a = y_gpu.detach().float().cpu().numpy().reshape(-1).astype(np.float64)
+    b = vo.to_f32(np.asarray(y_ref_bits).reshape(-1), "f16").astype(np.float64)
+    return float(np.abs(a - b).max() / np.abs(b).max())
 
 
 def cpu_baseline(layer, x, y_gpu, H):
-    """The reference's CPU algorithm (dequant to dense W, then linear), as restated by
-    the C oracle (oracle/vptq_oracle.c), timed on this box's host cores.  Also returns
-    the parity error of the GPU result against it."""
+    """The reference's CPU path on THIS box's host cores, one H x H forward, median of 3:
+    * `cpu_baseline`: the torch restatement of the reference's own tensor-op sequence
+      (oracle/torch_ref.py: one-element-per-bit unpack, gathers, add, scale, bias, F.linear -
+      vptq/ops/quant_gemm.py:43-158, 231-274; pinned on the reference's goldens), torch's thread
+      pool pinned to the core count it reports;
+    * `cpu_baseline_c_port`: the C oracle (oracle/vptq_oracle.c, OpenMP) - a fairer, leaner CPU
+      implementation of the same arithmetic; ours, not the reference's.
+    Also returns the parity error of the GPU result against the C oracle."""
     from oracle import c_oracle as co
-    from oracle import vptq_oracle as vo
-    if not co.available():
-        return None, None
-    L = vo.LayerSpec(H, H, 8, 256, 256, 1, H, dtype="f16")
-    to_np = lambda t, dt: t.detach().cpu().contiguous().view(torch.int16).numpy().view(dt)  # noqa: E731
-    L.indices = layer.indices.detach().cpu().numpy()
-    L.centroids = to_np(layer.centroids.weight, np.uint16).reshape(1, 256, 8)
-    L.res_centroids = to_np(layer.res_centroids.weight, np.uint16).reshape(1, 256, 8)
-    L.weight_scale = to_np(layer.weight_scale, np.uint16)
-    L.weight_bias = to_np(layer.weight_bias, np.uint16)
-    xb = to_np(x, np.uint16)
-    scratch = np.empty((H, H), dtype=np.uint16)
-    cores = co.lib().vo_num_threads()
-    y = co.forward(L, xb, scratch=scratch)          # warm-up (page-in)
-    times = []
-    for _ in range(3):
-        t0 = time.perf_counter()
-        y = co.forward(L, xb, scratch=scratch)
-        times.append(time.perf_counter() - t0)
-    t = sorted(times)[1]
-    yg = to_np(y_gpu, np.uint16).reshape(-1)
-    a = vo.to_f32(yg, "f16").astype(np.float64)
-    b = vo.to_f32(y.reshape(-1), "f16").astype(np.float64)
-    rel = float(np.abs(a - b).max() / np.abs(b).max())
-    base = {"value": alg_bytes(H) / t / 1e9, "unit": "GB/s", "cores": int(cores), "kind": "port",
-            "sample": f"1 VQuantLinear {H}x{H} forward (dequant to dense W + linear, C oracle, "
-                      f"OpenMP {cores} threads), median of 3, {t * 1e3:.0f} ms each"}
-    return base, rel
+    from oracle import torch_ref as tr
+    ab = alg_bytes(H)
+    out = {}
+    # ---- torch restatement
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cpu = lambda t: None if t is None else t.detach().cpu()  # noqa: E731
+    args = (cpu(layer.indices), cpu(layer.centroids.weight), cpu(layer.res_centroids.weight),
+            cpu(layer.weight_scale), cpu(layer.weight_bias))
+    kw = dict(num_centroids=256, num_res_centroids=256, vector_len=8, group_size=H, out_features=H)
+    xc = cpu(x)
+    with torch.no_grad():
+        y_t = tr.forward(xc, *args, **kw)      # warm-up
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            y_t = tr.forward(xc, *args, **kw)
+            ts.append(time.perf_counter() - t0)
+    t = sorted(ts)[1]
+    out["cpu_baseline"] = {
+        "value": ab / t / 1e9, "unit": "GB/s", "cores": int(torch.get_num_threads()), "kind": "port",
+        "sample": f"1 VQuantLinear {H}x{H} forward, torch restatement of the reference's CPU tensor-op "
+                  f"sequence (oracle/torch_ref.py), torch threads = {torch.get_num_threads()} "
+                  f"(os.cpu_count() = {cores}), median of 3, {t * 1e3:.0f} ms each"}
+    rel_t = float(((y_gpu.detach().float().cpu() - y_t.float()).abs().max() / y_t.float().abs().max()).item())
+    out["parity_rel_err_vs_torch_restatement"] = rel_t
+    # ---- C port
+    rel = None
+    if co.available():
+        L = layer_spec(layer)
+        xb = xc.contiguous().view(torch.int16).numpy().view(np.uint16)
+        scratch = np.empty((H, H), dtype=np.uint16)
+        threads = co.lib().vo_num_threads()
+        y = co.forward(L, xb, scratch=scratch)          # warm-up (page-in)
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            y = co.forward(L, xb, scratch=scratch)
+            ts.append(time.perf_counter() - t0)
+        t = sorted(ts)[1]
+        rel = rel_err_bits(y_gpu, y)
+        out["cpu_baseline_c_port"] = {
+            "value": ab / t / 1e9, "unit": "GB/s", "cores": int(threads), "kind": "port",
+            "sample": f"same forward, C oracle (oracle/vptq_oracle.c: dequant to dense W + linear), "
+                      f"OpenMP {threads} threads, median of 3, {t * 1e3:.0f} ms each"}
+        out["parity_rel_err_vs_cpu_oracle"] = rel
+    return out, (rel if rel is not None else rel_t)
 
 
 def compute_floor(kname, H):
-    """What bounds the kernel besides HBM (tools/ubench.hip, tools/ubench_lds.hip on MI355X):
-    per launch of one HxH layer, with every CU busy."""
+    """What bounds the kernel besides HBM (tools/ubench*.hip on MI355X, profiles/r02/): per launch of
+    one HxH layer, with every CU busy."""
     n_idx = (H // 8) * H                       # index pairs = weight vectors of 8
     if kname.startswith("gemv_k256m"):
-        # 2 ds_read_b128 gathers per index, 5.1 LDS cycles per wave-instruction per CU, 256 CUs
-        cyc = n_idx * 2 / 64 / 256 * 5.1
-        # and the SIMD issue slots next to it: 4 MFMA 4x4x4 (8 cycles each) + 2-4 v_perm_b32 per
-        # index-wave, 128 index-waves per SIMD and 8192^2 layer, which the SIMD does not overlap
-        return {"what": "LDS gather throughput: 2 x ds_read_b128 per index at 5.1 LDS cycles per "
-                        "wave-instruction and CU (conflict-free lane-split 8-replica image); SIMD "
-                        "issue (4 MFMA + 2-4 VALU per index) is the same order, see DESIGN.md 4.1",
-                "us_per_launch_at_2.1GHz": cyc / 2100.0}
+        return {"what": "instruction issue: 4 MFMA 4x4x4 + 4 v_perm_b32 + 2 ds_read_b128 per index on one "
+                        "SIMD issue port = 27 ns per index-wave and SIMD (tools/ubench_loop.hip), beside 2 "
+                        "LDS gathers per index at 5.1 cycles per wave-instruction and CU; plus what a "
+                        "launch that ONLY streams these bytes costs (tools/ubench_stream.hip, "
+                        "profiles/r02/ubench_stream_8192.txt: 4.1-5.0 us per 16 MiB launch incl. the "
+                        "1.8 us boundary)",
+                "us_per_launch_issue": n_idx / 64 / 1024 * 27e-3,
+                "us_per_launch_pure_stream": 4.65}
     instr = 14 if "fast" in kname else 22
     return {"what": f"VALU issue: {instr} instructions per index, 2.25 ns per wave-instruction per "
                     "SIMD at 4 waves/SIMD (1024 SIMDs)",
             "us_per_launch": n_idx * instr / (1024 * 64) * 2.25e-3}
+
+
+class Timer:
+    """hipGraph capture of `one_pass`, W warm-up replays, then `regions` timed regions of exactly
+    `steps` replays, each bracketed by a barrier + synchronize; HIP events on the launch stream;
+    max over ranks."""
+
+    def __init__(self, dev, dist=None, allow_eager=False):
+        self.dev, self.dist, self.allow_eager = dev, dist, allow_eager
+        self.stream = torch.cuda.Stream(device=dev)
+
+    def run(self, one_pass, steps, warmup, regions):
+        dist = self.dist
+
+        class _Eager:  # same interface as a captured graph
+            def replay(self):
+                one_pass()
+
+        res = []
+        with torch.cuda.stream(self.stream):
+            one_pass()
+            torch.cuda.synchronize()
+            captured = True
+            try:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=self.stream):
+                    one_pass()
+            except Exception:
+                if not self.allow_eager:
+                    raise
+                captured, graph = False, _Eager()  # collectives that refuse capture: eager launches
+                torch.cuda.synchronize()
+            for _ in range(warmup):
+                graph.replay()
+            for _ in range(regions):
+                torch.cuda.synchronize()
+                if dist is not None:
+                    dist.barrier()
+                torch.cuda.synchronize()
+                e0 = torch.cuda.Event(enable_timing=True)
+                e1 = torch.cuda.Event(enable_timing=True)
+                t0 = time.perf_counter()
+                e0.record(self.stream)
+                for _ in range(steps):
+                    graph.replay()
+                e1.record(self.stream)
+                torch.cuda.synchronize()
+                if dist is not None:
+                    dist.barrier()
+                torch.cuda.synchronize()
+                wall = time.perf_counter() - t0
+                res.append(reduce_times(wall, e0.elapsed_time(e1), dist, self.dev))
+        res.sort(key=lambda r: r[0])
+        med = res[len(res) // 2]
+        return dict(wall_s=med[0], event_ms=med[1], captured=captured,
+                    regions_ms_per_step=[r[0] * 1e3 / steps for r in res])
+
+
+def bench_ring(lib, B, dev, timer, H, mode, flags, steps, warmup, regions, rank=0, world=1, group=4,
+               tokens=1, k=256, kr=256, ring=0, tp_split=None, prefetch=False):
+    """One ring measurement; returns (result dict, layers, x, ys)."""
+    from _gpu_util import module_desc
+    T = int(np.log2(k)) + (int(np.log2(kr)) if kr > 0 else 0)
+    idx_bytes = (H // 8) * (H * T // 32) * 4
+    R = ring or max(2, (512 << 20) // idx_bytes)
+    layers = make_ring(H, R, dev, seed=1234 + (0 if tp_split else rank), k=k, kr=kr)
+    if tp_split == "out":
+        from vptq_amd.utils.shard import shard_out_features
+        layers = [shard_out_features(m, rank, world) for m in layers]
+        torch.cuda.empty_cache()
+    x = torch.randn(1, tokens, H, device=dev, dtype=torch.float16,
+                    generator=torch.Generator(device=dev).manual_seed(7))
+    ys = [torch.empty(1, tokens, layers[i].out_features, device=dev, dtype=torch.float16) for i in range(R)]
+    y_full = torch.empty(H, device=dev, dtype=torch.float16) if tp_split == "out" else None
+    descs, keeps = [], []
+    for i, m in enumerate(layers):
+        d, kk = module_desc(m, prefetch=layers[(i + 1) % R].indices if prefetch else None)
+        descs.append(d)
+        keeps.append(kk)
+    kname = lib.vptq_quant_gemv_kernel_name(descs[0], tokens, flags).decode()
+    dist = timer.dist
+    if mode == "grouped":
+        chunks = []
+        for i0 in range(0, R, group):
+            m = min(group, R - i0)
+            chunks.append((m, (B.LayerDesc * m)(*descs[i0:i0 + m]),
+                           (C.c_void_p * m)(*[x.data_ptr()] * m),
+                           (C.c_void_p * m)(*[t.data_ptr() for t in ys[i0:i0 + m]])))
+        launches = len(chunks)
+        kname = lib.vptq_quant_gemv_grouped_kernel_name(chunks[0][1], chunks[0][0], tokens, flags).decode()
+
+        def one_pass():
+            sp = torch.cuda.current_stream().cuda_stream
+            for m, arr, xp, yp in chunks:
+                rc = lib.vptq_quant_gemv_grouped(arr, m, xp, yp, tokens, flags, sp)
+                assert rc == 0, lib.vptq_last_error()
+    else:
+        launches = R
+
+        def one_pass():
+            sp = torch.cuda.current_stream().cuda_stream
+            for i in range(R):
+                rc = lib.vptq_quant_gemv(descs[i], x.data_ptr(), ys[i].data_ptr(), tokens, flags, None, 0, sp)
+                assert rc == 0, lib.vptq_last_error()
+                if tp_split == "out" and dist is not None:
+                    dist.all_gather_into_tensor(y_full, ys[i].view(-1))
+    t = timer.run(one_pass, steps, warmup, regions)
+    ab = alg_bytes(H, H, k, kr, tokens)
+    strong = tp_split is not None
+    value = job_throughput_gbps(1 if strong else world, ab, R, steps, t["wall_s"])
+    us_per_launch = t["event_ms"] * 1e3 / (steps * launches)
+    bytes_per_launch = ab * R / launches / (world if strong else 1)
+    res = dict(value=value, ms_per_step=t["wall_s"] * 1e3 / steps, us_per_launch=us_per_launch,
+               bytes_per_launch=bytes_per_launch, achieved=bytes_per_launch / us_per_launch / 1e3,
+               kernel=kname, ring=R, launches_per_step=launches, hipgraph=t["captured"],
+               regions_ms_per_step=t["regions_ms_per_step"], idx_mib=R * idx_bytes >> 20)
+    return res, layers, x, ys, keeps
+
+
+def llama70b_projections():
+    H, Fd, KV = LLAMA70B["hidden"], LLAMA70B["ffn"], LLAMA70B["kv"]
+    return [("q_proj", H, H), ("k_proj", KV, H), ("v_proj", KV, H), ("o_proj", H, H),
+            ("gate_proj", Fd, H), ("up_proj", Fd, H), ("down_proj", H, Fd)]   # (name, O, I)
+
+
+def bench_tp_row(lib, B, dev, timer, rank, world, n_layers, flags, steps, warmup, regions, check=True):
+    """BASELINE config #5 (see the module docstring).  Every rank builds the SAME full projections
+    (common seed; the permutation is already absorbed: enable_perm = False) and keeps its slice of
+    the input columns; per projection: fused GEMV of the slice with fp32 partial output
+    (VPTQ_GEMV_OUT_F32) -> all-reduce (RCCL over xGMI) -> one rounding to fp16."""
+    from vptq_amd.utils.shard import shard_in_features
+    from _gpu_util import module_desc
+    dist = timer.dist
+    projs = llama70b_projections()
+    g = torch.Generator(device=dev).manual_seed(4321)
+    shards, xs, parts, ys, descs, keeps, full0 = [], [], [], [], [], [], None
+    for li in range(n_layers):
+        for (name, O, I) in projs:
+            m = make_layer(I, O, dev, g)
+            if li == 0 and name == "k_proj":
+                full0 = m                      # kept whole for the parity check
+            s = shard_in_features(m, rank, world)
+            x = torch.randn(1, 1, I, device=dev, dtype=torch.float16, generator=g)
+            g0, g1 = s.shard[1], s.shard[2]
+            if li == 0 and name == "k_proj":
+                x_full0 = x
+            shards.append(s)
+            xs.append(x[..., g0:g1].contiguous())
+            parts.append(torch.empty(1, 1, O, device=dev, dtype=torch.float32))
+            ys.append(torch.empty(1, 1, O, device=dev, dtype=torch.float16))
+            d, kk = module_desc(s)
+            descs.append(d)
+            keeps.append(kk)
+            del m
+        torch.cuda.empty_cache()
+    n = len(shards)
+    fl = flags | B.GEMV_OUT_F32
+
+    def one_pass():
+        sp = torch.cuda.current_stream().cuda_stream
+        for i in range(n):
+            rc = lib.vptq_quant_gemv(descs[i], xs[i].data_ptr(), parts[i].data_ptr(), 1, fl, None, 0, sp)
+            assert rc == 0, lib.vptq_last_error()
+            if dist is not None:
+                dist.all_reduce(parts[i])       # fp32 partial sums over the ranks
+            ys[i].copy_(parts[i])               # the ONE rounding (reference: F.linear's)
+    t = timer.run(one_pass, steps, warmup, regions)
+    ab = sum(alg_bytes(I, O) for (_, O, I) in projs) * n_layers
+    res = dict(value=ab * steps / t["wall_s"] / 1e9, ms_per_step=t["wall_s"] * 1e3 / steps,
+               us_per_decoder_layer=t["event_ms"] * 1e3 / steps / n_layers,
+               decoder_layers=n_layers, projections=[p[0] for p in projs], hipgraph=t["captured"],
+               alg_bytes_per_step=ab, regions_ms_per_step=t["regions_ms_per_step"],
+               all_reduce="fp32 partial outputs, one RCCL all-reduce per projection" if world > 1 else "none (1 rank)")
+    if check and rank == 0:
+        from oracle import c_oracle as co
+        if co.available():
+            L = layer_spec(full0)
+            xb = x_full0.detach().cpu().contiguous().view(torch.int16).numpy().view(np.uint16)
+            want = co.forward(L, xb)
+            res["parity_rel_err_vs_cpu_oracle"] = rel_err_bits(ys[1], want)   # k_proj of layer 0
+            assert res["parity_rel_err_vs_cpu_oracle"] <= 1e-3, res
+    return res
 
 
 def main():
@@ -146,30 +382,28 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--regions", type=int, default=5, help="timed regions of K steps; the median is reported")
     ap.add_argument("--hidden", type=int, default=8192)
     ap.add_argument("--ring", type=int, default=0)
-    ap.add_argument("--mode", choices=["single", "grouped", "tp", "tp_row"], default="single",
-                    help="tp: output rows of every layer split over the ranks, RCCL all-gather; "
-                         "tp_row: input columns split (row-parallel, BASELINE config #5), RCCL "
-                         "all-reduce of the partial sums")
+    ap.add_argument("--mode", choices=["auto", "single", "grouped", "tp", "tp_row", "rings"], default="auto")
     ap.add_argument("--group", type=int, default=4)
+    ap.add_argument("--tp-layers", type=int, default=20,
+                    help="tp_row: Llama-3-70B decoder layers in the ring (20 = 4.3 GB of packed indices)")
     ap.add_argument("--exact", action="store_true",
                     help="VPTQ_GEMV_EXACT: rebuild every weight with the reference CPU path's three "
                          "16-bit roundings (bit-identical weights) instead of the default folded "
                          "fp32 form (both are inside the 1e-3 parity bar, checked below)")
     ap.add_argument("--fast-math", action="store_true", help="accepted, no effect: the default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--prefetch", action="store_true",
-                    help="let layer i read layer i+1's indices ahead (chain_prefetch).  Measured: "
-                         "+2 %% throughput but 2x L2-fabric fetch traffic, so it is off by default")
+    ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--prefetch", action="store_true")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if world != a.gpus and world == 1 and a.gpus > 1:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -177,188 +411,131 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
+    mode = a.mode
+    if mode == "auto":
+        mode = "single" if world == 1 else "tp_row"
 
     from vptq_amd import _backend as B
-    from _gpu_util import module_desc
     lib = B.lib()
     H = a.hidden
-    idx_bytes = (H // 8) * H * 2
-    R = a.ring or max(2, (512 << 20) // idx_bytes)
-    # tp: all ranks build the same layers, each keeps its slice of the output rows
-    tp = a.mode in ("tp", "tp_row")
-    layers = make_ring(H, R, dev, seed=1234 + (0 if tp else rank))
-    if a.mode == "tp_row":
-        from vptq_amd.utils.shard import shard_in_features
-        layers = [shard_in_features(m, rank, world) for m in layers]
-        torch.cuda.empty_cache()
-    if a.mode == "tp":
-        from vptq_amd.utils.shard import shard_out_features
-        layers = [shard_out_features(m, rank, world) for m in layers]
-        torch.cuda.empty_cache()
-    x = torch.randn(1, 1, H, device=dev, dtype=torch.float16,
-                    generator=torch.Generator(device=dev).manual_seed(7))
-    if a.mode == "tp_row":   # every rank multiplies its slice of the input columns
-        g0, g1 = layers[0].shard[1], layers[0].shard[2]
-        x = x[..., g0:g1].contiguous()
-    ys = [torch.empty(1, 1, layers[i].out_features, device=dev, dtype=torch.float16)
-          for i in range(R)]
-    y_full = torch.empty(H, device=dev, dtype=torch.float16) if a.mode == "tp" else None
-    descs, keeps = [], []
-    for i, m in enumerate(layers):
-        # decode order is known: layer i warms L2 / Infinity Cache with layer i+1's indices
-        nxt = layers[(i + 1) % R].indices if a.prefetch else None
-        d, k = module_desc(m, prefetch=nxt)
-        descs.append(d)
-        keeps.append(k)
     flags = B.GEMV_EXACT if a.exact else 0
-    kname = lib.vptq_quant_gemv_kernel_name(descs[0], 1, flags).decode()
+    timer = Timer(dev, dist, allow_eager=mode in ("tp", "tp_row"))
+    arithmetic = ("reference roundings per weight (VPTQ_GEMV_EXACT), fp32 accumulate" if a.exact else
+                  "folded fp32 (default): sum (c+r)*f16(s*x) + sum b*x - inside the 1e-3 max-normalised "
+                  "parity bar (measured 5-6e-4), not bit-equivalent; see extras.exact for the "
+                  "bit-equivalent form")
 
-    stream = torch.cuda.Stream(device=dev)
-    if a.mode == "tp_row":
-        launches_per_step = R
-
-        def one_pass():
-            sp = torch.cuda.current_stream().cuda_stream
-            for i in range(R):
-                rc = lib.vptq_quant_gemv(descs[i], x.data_ptr(), ys[i].data_ptr(), 1, flags,
-                                         None, 0, sp)
-                assert rc == 0, lib.vptq_last_error()
-                if dist is not None:
-                    dist.all_reduce(ys[i])      # sum of the ranks' partial outputs
-    elif a.mode == "tp":
-        launches_per_step = R
-        if H // 8 % world:
-            raise SystemExit("tp mode needs the vector-row count divisible by the world size")
-
-        def one_pass():
-            sp = torch.cuda.current_stream().cuda_stream
-            for i in range(R):
-                rc = lib.vptq_quant_gemv(descs[i], x.data_ptr(), ys[i].data_ptr(), 1, flags,
-                                         None, 0, sp)
-                assert rc == 0, lib.vptq_last_error()
-                if dist is not None:
-                    dist.all_gather_into_tensor(y_full, ys[i].view(-1))
-    elif a.mode == "single":
-        launches_per_step = R
-
-        def one_pass():
-            sp = torch.cuda.current_stream().cuda_stream
-            for i in range(R):
-                rc = lib.vptq_quant_gemv(descs[i], x.data_ptr(), ys[i].data_ptr(), 1, flags,
-                                         None, 0, sp)
-                assert rc == 0, lib.vptq_last_error()
-    else:
-        chunks = []
-        for i0 in range(0, R, a.group):
-            m = min(a.group, R - i0)
-            chunks.append((m, (B.LayerDesc * m)(*descs[i0:i0 + m]),
-                           (C.c_void_p * m)(*[x.data_ptr()] * m),
-                           (C.c_void_p * m)(*[t.data_ptr() for t in ys[i0:i0 + m]])))
-        launches_per_step = len(chunks)
-        kname = lib.vptq_quant_gemv_grouped_kernel_name(chunks[0][1], chunks[0][0], 1, flags).decode()
-
-        def one_pass():
-            sp = torch.cuda.current_stream().cuda_stream
-            for m, arr, xp, yp in chunks:
-                rc = lib.vptq_quant_gemv_grouped(arr, m, xp, yp, 1, flags, sp)
-                assert rc == 0, lib.vptq_last_error()
-
-    class _Eager:  # same interface as a captured graph
-        def replay(self):
-            one_pass()
-
-    with torch.cuda.stream(stream):
-        one_pass()
-        torch.cuda.synchronize()
-        captured = True
-        try:
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=stream):
-                one_pass()
-        except Exception:
-            if not tp:
-                raise
-            captured, graph = False, _Eager()  # collectives that refuse capture: eager launches
-            torch.cuda.synchronize()
-        for _ in range(a.warmup):
-            graph.replay()
-        torch.cuda.synchronize()
+    if mode == "tp_row":
+        r = bench_tp_row(lib, B, dev, timer, rank, world, a.tp_layers, flags, a.steps, a.warmup, a.regions)
+        out = {
+            "metric": "decode GEMV effective GB/s (VQuantLinear 2-bit, batch 1)",
+            "value": r["value"], "unit": "GB/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"Llama-3-70B shaped decoder layers x {a.tp_layers} (q/o 8192^2, k/v 1024x8192, "
+                                   "gate/up 28672x8192, down 8192x28672; v=8 k=256+256, 2-bit), batch=1 seq=1 fp16, "
+                                   f"every projection row-parallel over {world} rank(s): fused GEMV with fp32 partial "
+                                   "output -> RCCL all-reduce -> one rounding; 1 step = 1 token through all layers' "
+                                   "projections", "mode": "tp_row", "decoder_layers": a.tp_layers,
+                       "hipgraph": r["hipgraph"], "arithmetic": arithmetic,
+                       "parallelism": f"tp{world} row-parallel (input columns), RCCL all-reduce per projection",
+                       "strong_scaling_baseline": "python bench.py --mode tp_row --gpus 1 (also: extras.tp_row_n1 of "
+                                                  "the N = 1 line)"},
+            "regions_ms_per_step": r["regions_ms_per_step"],
+            "roofline": {"bound": "hbm", "achieved": r["value"] / world, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": r["value"] / world / HBM_PEAK_GBPS, "traffic": None,
+                         "note": "per GPU: whole-job algorithmic bytes / N / time, collectives included"},
+            "tp_row": {k: v for k, v in r.items() if k != "regions_ms_per_step"},
+        }
+        if world > 1 and not a.no_extras:
+            w, *_ = bench_ring(lib, B, dev, Timer(dev, dist), H, "single", flags, max(5, a.steps // 4), 5, 3,
+                               rank=rank, world=world)
+            out["weak_scaling"] = {"what": f"{world} x independent rings of 8192^2 layers, no collective",
+                                   "value": w["value"], "unit": "GB/s", "us_per_launch": w["us_per_launch"],
+                                   "scaling": "weak"}
+        if rank == 0:
+            print(json.dumps(out))
         if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        e0 = torch.cuda.Event(enable_timing=True)
-        e1 = torch.cuda.Event(enable_timing=True)
-        t0 = time.perf_counter()
-        e0.record(stream)
-        for _ in range(a.steps):
-            graph.replay()
-        e1.record(stream)
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        wall = time.perf_counter() - t0
-    ev_ms = e0.elapsed_time(e1)
-    wall, ev_ms = reduce_times(wall, ev_ms, dist, dev)
+            dist.destroy_process_group()
+        return
 
-    ab = alg_bytes(H)
-    if tp:   # strong scaling: the ring is processed once per step by all ranks together
-        value = job_throughput_gbps(1, ab, R, a.steps, wall)
-    else:
-        value = job_throughput_gbps(world, ab, R, a.steps, wall)
-    us_per_launch = ev_ms * 1e3 / (a.steps * launches_per_step)
-    bytes_per_launch = ab * R / launches_per_step / (world if tp else 1)
-    achieved = bytes_per_launch / us_per_launch / 1e3     # GB/s
+    tp_split = "out" if mode == "tp" else None
+    if mode == "tp" and H // 8 % world:
+        raise SystemExit("tp mode needs the vector-row count divisible by the world size")
+    r, layers, x, ys, keeps = bench_ring(lib, B, dev, timer, H, "grouped" if mode == "grouped" else "single",
+                                         flags, a.steps, a.warmup, a.regions, rank=rank, world=world, group=a.group,
+                                         ring=a.ring, tp_split=tp_split, prefetch=a.prefetch)
     out = {
         "metric": "decode GEMV effective GB/s (VQuantLinear 2-bit, batch 1)",
-        "value": value, "unit": "GB/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": wall * 1e3 / a.steps, "higher_is_better": True,
-        "scaling": "strong" if tp else "weak",
+        "value": r["value"], "unit": "GB/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": r["ms_per_step"], "higher_is_better": True,
+        "scaling": "strong" if tp_split else "weak",
         "vs_baseline": None, "dtype": "f16", "data": "synthetic",
         "config": {"workload": f"VQuantLinear {H}x{H} v=8 k=256+256 (2-bit) batch=1 seq=1 fp16, "
-                               f"ring of {R} distinct layers per GPU ({R * idx_bytes >> 20} MiB of "
+                               f"ring of {r['ring']} distinct layers per GPU ({r['idx_mib']} MiB of "
                                f"packed indices), 1 step = 1 pass over the ring",
-                   "hidden": H, "ring": R, "mode": a.mode, "launches_per_step": launches_per_step,
-                   "kernel": kname,
-                   "arithmetic": "reference roundings per weight (VPTQ_GEMV_EXACT), fp32 accumulate"
-                                 if a.exact else "folded fp32 (default): sum (c+r)*f16(s*x) + sum b*x",
-                   "read_ahead_next_layer": bool(a.prefetch),
-                   "hipgraph": captured,
+                   "hidden": H, "ring": r["ring"], "mode": mode, "launches_per_step": r["launches_per_step"],
+                   "kernel": r["kernel"], "arithmetic": arithmetic,
+                   "read_ahead_next_layer": bool(a.prefetch), "hipgraph": r["hipgraph"],
+                   "timing": f"median of {a.regions} regions of {a.steps} steps",
                    "parallelism": (f"tp{world}: output rows of every layer split over {world} ranks, "
-                                   "RCCL all-gather per layer") if a.mode == "tp" else
-                                  (f"tp{world} row-parallel: input columns of every layer split over "
-                                   f"{world} ranks, RCCL all-reduce of the partial outputs per layer")
-                                  if a.mode == "tp_row" else
+                                   "RCCL all-gather per layer") if mode == "tp" else
                                   f"{world} x independent rings (no collective)"},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                     "bytes_per_launch": bytes_per_launch, "us_per_launch": us_per_launch,
-                     "note": "us_per_launch = HIP-event time over the timed region / launches "
-                             "(includes the ~1.8 us inter-kernel gap); the kernels are bound by "
-                             "instruction issue / LDS gathers, not by HBM: see compute_floor and "
-                             "DESIGN.md §4",
-                     "compute_floor": compute_floor(kname, H)},
+        "regions_ms_per_step": r["regions_ms_per_step"],
+        "roofline": {"bound": "hbm", "achieved": r["achieved"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": r["achieved"] / HBM_PEAK_GBPS, "traffic": None,
+                     "bytes_per_launch": r["bytes_per_launch"], "us_per_launch": r["us_per_launch"],
+                     "note": "us_per_launch = HIP-event time over the (median) timed region / launches, i.e. "
+                             "INCLUDING the kernel boundary (an empty kernel in the same graph: 1.8 us per "
+                             "launch, profiles/r02/ubench_stream_8192.txt); rocprofv3's kernel-only duration is "
+                             "shorter by the idle part of that boundary.  The kernel is bound by instruction "
+                             "issue / LDS gathers and per-launch latency, not by HBM: compute_floor, DESIGN.md 4",
+                     "compute_floor": compute_floor(r["kernel"], H)},
     }
-    # the newest round's summary of this configuration
+    # the newest round's PMC summary of this configuration
     rounds = sorted(d for d in os.listdir(os.path.join(ROOT, "profiles")) if d[:1] == "r" and d[1:].isdigit())
-    pmc = ""
     for rd in reversed(rounds):
-        cand = os.path.join(ROOT, "profiles", rd, f"bench_h{H}_{a.mode}_pmc_summary.json")
-        if os.path.exists(cand):
-            pmc = cand
+        cand = os.path.join(ROOT, "profiles", rd, f"bench_h{H}_{mode}_pmc_summary.json")
+        if os.path.exists(cand) and not a.exact and not a.prefetch:
+            # HBM bytes per launch from a separate rocprofv3 --pmc run of this same command
+            # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); see the file's _note
+            out["roofline"]["traffic"] = json.load(open(cand)).get("hbm_bytes_corrected")
+            out["roofline"]["traffic_source"] = os.path.relpath(cand, ROOT)
             break
-    if pmc and not a.exact and not a.prefetch:
-        # HBM bytes per launch from a separate rocprofv3 --pmc run of this same command
-        # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); see the file's _note
-        out["roofline"]["traffic"] = json.load(open(pmc)).get("hbm_bytes_corrected")
-        out["roofline"]["traffic_source"] = os.path.relpath(pmc, ROOT)
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and mode in ("single", "grouped"):
         torch.cuda.synchronize()
         base, rel = cpu_baseline(layers[0], x, ys[0], H)
-        if base is not None:
-            out["cpu_baseline"] = base
-            out["parity_rel_err_vs_cpu_oracle"] = rel
-            assert rel <= 1e-3, f"GPU result differs from the CPU oracle: {rel}"
+        out.update(base)
+        assert rel <= 1e-3, f"GPU result differs from the CPU oracle: {rel}"
+    if world == 1 and not a.no_extras and mode == "single" and not a.exact:
+        del layers, ys, keeps
+        torch.cuda.empty_cache()
+        ex = {}
+        st, wu, rg = max(10, a.steps // 4), 5, 3
+
+        def short(res, nbytes=None):
+            return {"GBps": res["achieved"], "frac_of_8TBps": res["achieved"] / HBM_PEAK_GBPS,
+                    "us_per_launch": res["us_per_launch"], "kernel": res["kernel"]}
+        for key, kw in (("h4096", dict(H=4096, mode="single", flags=0)),
+                        ("exact", dict(H=H, mode="single", flags=B.GEMV_EXACT)),
+                        ("grouped_x4", dict(H=H, mode="grouped", flags=0)),
+                        ("tokens16", dict(H=H, mode="single", flags=0, tokens=16)),
+                        ("k8192_r256", dict(H=H, mode="single", flags=0, k=8192, kr=256))):
+            kw = dict(kw)
+            rr, *_ = bench_ring(lib, B, dev, Timer(dev), kw.pop("H"), kw.pop("mode"), kw.pop("flags"), st, wu, rg, **kw)
+            ex[key] = short(rr)
+            torch.cuda.empty_cache()
+        ex["h4096"]["what"] = "VQuantLinear 4096x4096 (BASELINE configs[0]/[1] shape), single launch per layer"
+        ex["exact"]["what"] = "VPTQ_GEMV_EXACT: the reference's three roundings per weight (bit-equivalent form)"
+        ex["grouped_x4"]["what"] = "4 independent layers per launch (vptq_quant_gemv_grouped), us per LAYER = us_per_launch / 4"
+        ex["tokens16"]["what"] = "16 tokens per launch (batched-decode kernel), bytes incl. 16 x and y rows"
+        ex["k8192_r256"]["what"] = "k = 8192 + 256 (T = 21 bits), LDS-resident codebooks"
+        tr = bench_tp_row(lib, B, dev, Timer(dev), 0, 1, 4, 0, st, wu, rg)
+        ex["tp_row_n1"] = {"what": "Llama-3-70B shaped decoder layers (x4) on ONE GPU through the row-parallel code "
+                                   "path (world size 1): the strong-scaling baseline of --gpus N",
+                           "GBps": tr["value"], "us_per_decoder_layer": tr["us_per_decoder_layer"],
+                           "parity_rel_err_vs_cpu_oracle": tr.get("parity_rel_err_vs_cpu_oracle")}
+        out["extras"] = ex
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:

@@ -195,3 +195,29 @@ def test_reference_test_file_binds_to_this_package():
         for k in [k for k in sys.modules if k == "vptq" or k.startswith("vptq.")]:
             del sys.modules[k]
         sys.modules.update(saved)
+
+
+# ---------------------------------------------------------------- torch restatement (bench.py's cpu_baseline)
+@pytest.mark.parametrize("name", ["canon_k256x2", "canon_llm", "canon_bf16", "canon_t4_bias", "k8192_r256_t21",
+                                  "k65536_nores_nonorm"])
+def test_torch_restatement_vs_reference_golden(name):
+    """oracle/torch_ref.py - the same tensor-op sequence as the reference's CPU path, what
+    bench.py times as `cpu_baseline` - reproduces the real reference's W bit for bit and its y."""
+    import torch
+    from oracle import torch_ref as tr
+    L, x, y, cfg, W_head = load_golden(name)
+    dt = torch.float16 if cfg["dtype"] == "f16" else torch.bfloat16
+    t16 = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int16).copy()).view(dt)  # noqa: E731
+    kw = dict(num_centroids=L.num_centroids, num_res_centroids=max(L.num_res_centroids, 0), vector_len=L.vector_len,
+              group_size=L.group_size, out_features=L.out_features)
+    args = (torch.from_numpy(L.indices.copy()), t16(L.centroids),
+            t16(L.res_centroids) if L.num_res_centroids > 0 else None,
+            t16(L.weight_scale) if L.weight_scale is not None else None,
+            t16(L.weight_bias) if L.weight_bias is not None else None)
+    W = tr.dequant(*args, **kw)
+    Wb = W.contiguous().view(torch.int16).numpy().view(np.uint16)
+    assert hashlib.sha256(Wb.tobytes()).hexdigest() == cfg["W_sha256"]
+    out = tr.forward(t16(x).reshape(x.shape), *args, bias=t16(L.bias) if L.bias is not None else None, **kw)
+    ob = out.contiguous().view(torch.int16).numpy().view(np.uint16)
+    assert rel_err(ob, y, cfg["dtype"]) <= Y_TOL[cfg["dtype"]]
+    assert bit_identical_frac(ob, y) >= 0.9
