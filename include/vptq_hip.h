@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define VPTQ_ABI_VERSION 4
+#define VPTQ_ABI_VERSION 5
 
 #if defined(__GNUC__)
 #define VPTQ_API __attribute__((visibility("default")))
@@ -203,6 +203,20 @@ VPTQ_API int vptq_quant_gemv_max_tokens(const VptqLayerDesc* desc);
 #define VPTQ_GROUP_MAX 64
 VPTQ_API int vptq_quant_gemv_grouped(const VptqLayerDesc* descs, int n, const void* const* x,
                             void* const* y, int tokens, int flags, void* stream);
+
+/*
+ * Many tokens (prefill): y[tokens, O] = x[tokens, I] @ W^T + bias with the dequantisation FUSED
+ * into the GEMM - replaces `dequant` + F.linear of the reference (vptq/ops/quant_gemm.py:231-274),
+ * which materialises the dense W (2 O I bytes) on every call.  Canonical v=8 / 256+256 format
+ * without a permutation (absorb it first); fp16: the tile holds the reference's bits
+ * r16(r16(r16(c+r)*s)+b), fp32 accumulate; bf16: folded form.  bf16 needs a workspace of
+ * vptq_quant_gemm_workspace_bytes() (tokens floats).  vptq_quant_gemm_supported() = 1 when a
+ * fused kernel exists for the layer; otherwise use vptq_dequant + a dense GEMM.
+ */
+VPTQ_API int vptq_quant_gemm_supported(const VptqLayerDesc* desc);
+VPTQ_API size_t vptq_quant_gemm_workspace_bytes(const VptqLayerDesc* desc, int tokens);
+VPTQ_API int vptq_quant_gemm(const VptqLayerDesc* desc, const void* x, void* y, int tokens, int flags,
+                    void* workspace, size_t workspace_bytes, void* stream);
 
 /* W[O, I] dense, row-major, desc->dtype: the reference CPU path's bits. */
 VPTQ_API int vptq_dequant(const VptqLayerDesc* desc, void* W, void* stream);

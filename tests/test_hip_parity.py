@@ -1023,3 +1023,78 @@ def test_batched_decode_golden_16_tokens(dev):
     assert kernel_name(m, 16) == "gemm_k256_kernel" and kernel_name(m, 4).startswith("gemv_k256")
     out = tensor_to_bits(m(bits_to_tensor(x, "f16", dev).reshape(x.shape)))
     assert rel_err(out, y, "f16") <= 1e-3 and bit_identical_frac(out, y) >= 0.9
+
+
+# ---------------------------------------------------------------- fused dequant + GEMM (prefill)
+FUSED_CASES = [
+    # I, O, kwargs, tokens
+    (1024, 1024, dict(), 128),
+    (1024, 1000, dict(bias=True), 300),            # ragged N tile (125 vector-rows), ragged M tile
+    (4104, 264, dict(dist="llm"), 77),             # K not a multiple of the 64-column step
+    (2048, 512, dict(dtype="bf16", dist="llm", bias=True), 200),
+    (8192, 2048, dict(dist="llm"), 512),
+    (512, 8192, dict(dtype="bf16", dist="llm"), 1000),
+]
+
+
+@pytest.mark.parametrize("I,O,kw,tokens", FUSED_CASES)
+def test_fused_dequant_gemm_vs_dequant_plus_matmul(I, O, kw, tokens, dev):
+    """vptq_quant_gemm (dequantised tile -> LDS -> 32x32x16 MFMA) against the reference's structure for
+    many tokens, dequant + matmul (quant_gemm.py:231-274): HIP dequant (bit-exact W) + fp32 matmul."""
+    from vptq_amd import _backend as B
+    from vptq_amd import ops
+    kw = dict(kw)
+    dist = kw.pop("dist", "ref-test")
+    L = vo.make_layer(I, O, dist=dist, seed=I + O + tokens, **kw)
+    dt = L.dtype
+    rng = np.random.default_rng(tokens)
+    xs = (0.02 + 0.5 * rng.standard_normal((1, tokens, I))) if dist == "ref-test" \
+        else rng.standard_normal((1, tokens, I))
+    x = vo.from_f32(xs.astype(np.float32), dt)
+    m = spec_to_module(L, dev)
+    desc, keep = module_desc(m)
+    assert B.lib().vptq_quant_gemm_supported(desc) == 1
+    xt = bits_to_tensor(x, dt, dev).reshape(x.shape)
+    got = ops.quant_gemm_fused(xt, desc, O)
+    W = m.dequant().float()
+    ref = xt.float() @ W.t()
+    if m.bias is not None:
+        ref = ref + m.bias.float()
+    gb, rb = tensor_to_bits(got), tensor_to_bits(ref.to(xt.dtype))
+    err = rel_err(gb, rb, dt)
+    assert err <= TOL[dt], f"{err:.3e}"
+    if dt == "f16":
+        assert bit_identical_frac(gb, rb) >= 0.95
+    # the module's forward takes this path when it is enabled (VPTQ_FUSED_GEMM_MAX_TOKENS; off by
+    # default: hipBLASLt wins on MI355X) and the dense route otherwise
+    import sys
+    qg = sys.modules["vptq_amd.ops.quant_gemm"]     # (the package attribute of that name is the function)
+    old = qg._FUSED_GEMM_MAX_TOKENS
+    try:
+        qg._FUSED_GEMM_MAX_TOKENS = 4096
+        assert torch.equal(m(xt), got)
+        qg._FUSED_GEMM_MAX_TOKENS = 0
+        assert rel_err(tensor_to_bits(m(xt)), rb, dt) <= TOL[dt]
+    finally:
+        qg._FUSED_GEMM_MAX_TOKENS = old
+    # a few rows against the CPU oracle
+    if I * O <= 2048 * 1024:
+        want = vo.forward(L, x[:, :3])
+        assert rel_err(gb[:, :3], want, dt) <= TOL[dt]
+
+
+def test_fused_gemm_unsupported_layers_fall_back(dev):
+    from vptq_amd import _backend as B
+    L = vo.make_layer(512, 256, dist="llm", seed=3, enable_perm=True)
+    m = spec_to_module(L, dev)
+    desc, keep = module_desc(m)
+    assert B.lib().vptq_quant_gemm_supported(desc) == 0
+    x = torch.randn(1, 100, 512, device=dev, dtype=torch.float16)
+    y = m(x)                                    # dequant + F.linear
+    ref = x.float() @ m.dequant().float().t()
+    assert rel_err(tensor_to_bits(y), tensor_to_bits(ref.half()), "f16") <= 1e-3
+    L2 = vo.make_layer(512, 256, dist="llm", seed=3, num_centroids=4096, num_res_centroids=0)
+    d2, k2 = module_desc(spec_to_module(L2, dev))
+    assert B.lib().vptq_quant_gemm_supported(d2) == 0
+    rc = B.lib().vptq_quant_gemm(d2, x.data_ptr(), y.data_ptr(), 100, 0, None, 0, None)
+    assert rc == -3

@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # VPTQ_HIP_LIB: load another build of the library (A/B runs of tools/)
 LIB_PATH = os.environ.get("VPTQ_HIP_LIB") or os.path.join(_HERE, "libvptq_hip.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 DTYPE_F16, DTYPE_BF16 = 0, 1
 GEMV_FAST_MATH = 1 << 0
 GEMV_FORCE_GENERIC = 1 << 1
@@ -65,6 +65,9 @@ EXPORTS = {
     "vptq_quant_gemv_grouped": (C.c_int, [C.POINTER(LayerDesc), C.c_int, C.POINTER(_vp),
                                           C.POINTER(_vp), C.c_int, C.c_int, _vp]),
     "vptq_dequant": (C.c_int, [C.POINTER(LayerDesc), _vp, _vp]),
+    "vptq_quant_gemm_supported": (C.c_int, [C.POINTER(LayerDesc)]),
+    "vptq_quant_gemm_workspace_bytes": (C.c_size_t, [C.POINTER(LayerDesc), C.c_int]),
+    "vptq_quant_gemm": (C.c_int, [C.POINTER(LayerDesc), _vp, _vp, C.c_int, C.c_int, _vp, C.c_size_t, _vp]),
     "vptq_quant_gemv_v2": (C.c_int, [C.POINTER(V2Desc), _vp, _vp, C.c_int, C.c_int, _vp]),
     "vptq_quant_gemv_kernel_name": (C.c_char_p, [C.POINTER(LayerDesc), C.c_int, C.c_int]),
     "vptq_quant_gemv_grouped_kernel_name": (C.c_char_p, [C.POINTER(LayerDesc), C.c_int, C.c_int, C.c_int]),

@@ -245,6 +245,33 @@ int vptq_quant_gemv_grouped(const VptqLayerDesc* descs, int n, const void* const
   return VPTQ_OK;
 }
 
+int vptq_quant_gemm_supported(const VptqLayerDesc* d) {
+  return validate_layer(d) == VPTQ_OK && vptq::gemm_fused_eligible(*d) ? 1 : 0;
+}
+
+size_t vptq_quant_gemm_workspace_bytes(const VptqLayerDesc* d, int tokens) {
+  if (validate_layer(d) != VPTQ_OK || tokens < 1) return 0;
+  return vptq::gemm_fused_workspace_bytes(*d, tokens);
+}
+
+int vptq_quant_gemm(const VptqLayerDesc* d, const void* x, void* y, int tokens, int flags, void* workspace,
+                    size_t workspace_bytes, void* stream) {
+  (void)flags;
+  int rc = validate_layer(d);
+  if (rc) return rc;
+  if (!x || !y) return fail(VPTQ_E_NULL, "x / y is NULL");
+  if (tokens < 1) return fail(VPTQ_E_TOKENS, "tokens %d < 1", tokens);
+  if (!vptq::gemm_fused_eligible(*d))
+    return fail(VPTQ_E_UNSUPPORTED, "no fused GEMM for this layer: use vptq_dequant + a dense GEMM");
+  if ((((uintptr_t)x) & 15) != 0) return fail(VPTQ_E_ALIGN, "x must be 16-byte aligned");
+  if (workspace_bytes < vptq::gemm_fused_workspace_bytes(*d, tokens) ||
+      (vptq::gemm_fused_workspace_bytes(*d, tokens) > 0 && !workspace))
+    return fail(VPTQ_E_WORKSPACE, "workspace of %zu bytes needed", vptq::gemm_fused_workspace_bytes(*d, tokens));
+  hipError_t e = vptq::launch_gemm_fused(*d, x, y, tokens, workspace, workspace_bytes, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "gemm_fused launch");
+  return VPTQ_OK;
+}
+
 int vptq_dequant(const VptqLayerDesc* d, void* W, void* stream) {
   int rc = validate_layer(d);
   if (rc) return rc;

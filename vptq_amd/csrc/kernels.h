@@ -39,6 +39,12 @@ bool gemm_k256_eligible(const VptqLayerDesc& d, int tokens, int flags);
 hipError_t launch_gemm_k256(const VptqLayerDesc& d, const void* x, void* y, int tokens, bool out_f32,
                             hipStream_t st);
 
+// gemm_fused.hip - canonical format, many tokens: dequantised tile -> LDS -> 32x32x16 MFMA
+bool gemm_fused_eligible(const VptqLayerDesc& d);
+size_t gemm_fused_workspace_bytes(const VptqLayerDesc& d, int tokens);
+hipError_t launch_gemm_fused(const VptqLayerDesc& d, const void* x, void* y, int tokens, void* workspace,
+                             size_t workspace_bytes, hipStream_t st);
+
 // dequant.hip
 hipError_t launch_dequant(const VptqLayerDesc& d, void* W, hipStream_t st);
 

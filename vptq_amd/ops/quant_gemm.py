@@ -25,6 +25,13 @@ __all__ = ["dequant", "quant_gemm", "quant_gemv_v2"]
 # env knob: VPTQ_EXACT=1 rebuilds every weight with the reference CPU path's three 16-bit
 # roundings (bit-identical weights) instead of the default folded fp32 form (<= 1e-3)
 _FLAGS = B.GEMV_EXACT if os.environ.get("VPTQ_EXACT", "0") == "1" else 0
+# Most tokens the fused dequant + GEMM kernel (vptq_quant_gemm, gemm_fused.hip) is used for by
+# `quant_gemm`; above it: HIP dequant + hipBLASLt.  0 = never, the default: measured on MI355X
+# (tools/prefill_bench.py, profiles/r02/prefill_fused_vs_dense.json) the fused kernel ties the dense
+# route around 512-1024 tokens and loses elsewhere (0.84 vs 1.39 PFLOP/s at 8192 tokens), so the
+# vendor GEMM stays the default; VPTQ_FUSED_GEMM_MAX_TOKENS=<n> routes up to n tokens through it
+# (no dense W is materialised: 2 O I bytes less memory per call).
+_FUSED_GEMM_MAX_TOKENS = int(os.environ.get("VPTQ_FUSED_GEMM_MAX_TOKENS", "0"))
 
 
 def quant_gemm_flags() -> int:
@@ -171,6 +178,20 @@ def quant_gemm(
         del keep
         return y
 
+    # many tokens: dequantisation fused into the GEMM where a kernel exists (canonical format)
+    if _FUSED_GEMM_MAX_TOKENS >= tokens >= 1 and perm is None:
+        fdesc, fkeep = B.make_layer_desc(
+            indices=indices, centroids=centroids, res_centroids=residual_centroids,
+            outlier_indices=outlier_indices, outlier_centroids=outlier_centroids, perm=None,
+            weight_scale=weight_scale, weight_bias=weight_bias, bias=bias,
+            in_features=in_features, out_features=out_features, vector_len=vector_len,
+            num_codebooks=num_codebooks, num_centroids=num_centroids,
+            num_res_centroids=num_res_centroids if enable_residual else 0,
+            group_size=group_size, outlier_size=outlier_size if enable_outlier else 0,
+            outlier_vector_len=outlier_vector_len, num_outlier_centroids=num_outlier_centroids)
+        if B.lib().vptq_quant_gemm_supported(fdesc):
+            return quant_gemm_fused(x, fdesc, out_features)
+
     weight = dequant(
         indices=indices, centroids=centroids, outlier_indices=outlier_indices,
         outlier_centroids=outlier_centroids, res_indices=None,
@@ -184,6 +205,22 @@ def quant_gemm(
         outlier_size=outlier_size, vector_len=vector_len,
         outlier_vector_len=outlier_vector_len, vector_quant_dim=vector_quant_dim)
     return F.linear(x, weight, bias)
+
+
+def quant_gemm_fused(x: torch.Tensor, desc, out_features: int) -> torch.Tensor:
+    """y = x @ W^T + bias for any number of tokens with the dequantisation fused into the GEMM
+    (`vptq_quant_gemm`: dequantised tile -> LDS -> MFMA; replaces the reference's dequant +
+    F.linear, vptq/ops/quant_gemm.py:231-274).  `desc` = a LayerDesc of a supported layer."""
+    tokens = x.numel() // x.shape[-1]
+    dev = x.device
+    y = torch.empty(x.shape[:-1] + (out_features,), dtype=x.dtype, device=dev)
+    ws_bytes = B.lib().vptq_quant_gemm_workspace_bytes(desc, tokens)
+    ws = torch.empty(max(ws_bytes, 4) // 4, dtype=torch.float32, device=dev) if ws_bytes else None
+    with torch.cuda.device(dev):
+        B.check(B.lib().vptq_quant_gemm(desc, x.data_ptr(), y.data_ptr(), tokens, _FLAGS,
+                                        None if ws is None else ws.data_ptr(), ws_bytes,
+                                        B.current_stream_ptr(dev)), "vptq_quant_gemm")
+    return y
 
 
 def quant_gemv_v2(
