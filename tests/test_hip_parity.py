@@ -1098,3 +1098,36 @@ def test_fused_gemm_unsupported_layers_fall_back(dev):
     assert B.lib().vptq_quant_gemm_supported(d2) == 0
     rc = B.lib().vptq_quant_gemm(d2, x.data_ptr(), y.data_ptr(), 100, 0, None, 0, None)
     assert rc == -3
+
+
+# ---------------------------------------------------------------- Hugging Face's own loading route
+def test_hf_from_pretrained_vptq_route(dev, tmp_path):
+    """transformers.AutoModelForCausalLM.from_pretrained on a synthetic VPTQ checkpoint
+    (config.json with quantization_config + model.safetensors): HF's VptqHfQuantizer builds
+    `vptq.VQuantLinear` (= this package through the `vptq` alias) on meta and loads the tensors by
+    state-dict name; logits equal those of this package's own loader and of the dense model.
+    (reference flow: vptq/layers/model_base.py:93-199; HF: integrations/vptq.py, quantizers/quantizer_vptq.py)"""
+    import vptq
+    import vptq_amd
+    from _ckpt import write_tiny_checkpoint
+    from _hf_route import hf_from_pretrained
+    write_tiny_checkpoint(str(tmp_path), perm=True)
+    model, upstream_bug = hf_from_pretrained(str(tmp_path), dtype=torch.float16, device_map={"": dev.index or 0})
+    print("transformers' replace_with_vptq_linear needed the one-line fix:", upstream_bug)
+    model = model.eval()
+    qlayers = [m for m in model.modules() if isinstance(m, vptq_amd.VQuantLinear)]
+    assert len(qlayers) == 2 * 7 and all(type(m) is vptq.VQuantLinear for m in qlayers)
+    assert all(m.indices.is_cuda and m.indices.dtype == torch.int32 and m.perm.dtype == torch.int16 for m in qlayers)
+    assert isinstance(model.lm_head, torch.nn.Linear)
+    own = vptq_amd.AutoModelForCausalLM.from_pretrained(str(tmp_path), device=str(dev))
+    with torch.no_grad():
+        for T in (1, 3, 7, 20):
+            ids = torch.randint(0, model.config.vocab_size, (1, T), device=dev)
+            a, b = model(input_ids=ids).logits.float(), own(input_ids=ids).logits.float()
+            assert torch.isfinite(a).all()
+            assert ((a - b).abs().max() / b.abs().max()).item() <= 2e-3, T
+        # decode loop through HF generate (greedy): same tokens from both models
+        ids = torch.randint(0, model.config.vocab_size, (1, 5), device=dev)
+        ga = model.generate(ids, max_new_tokens=8, do_sample=False)
+        gb = own.generate(ids, max_new_tokens=8, do_sample=False)
+        assert ga.shape == (1, 13) and (ga == gb).float().mean().item() >= 0.9

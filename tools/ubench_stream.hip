@@ -29,8 +29,10 @@ __global__ __launch_bounds__(1024) void stream_persistent(const char* __restrict
     const char* p = base + (size_t)(rg * 4 + j) * row_bytes + chunk * 16;
     u32x4 q[DEPTH];
 #pragma unroll
-    for (int s = 0; s < DEPTH; ++s)
-      q[s] = NT ? __builtin_nontemporal_load((const u32x4*)(p + s * 4096)) : *(const u32x4*)(p + s * 4096);
+    for (int s = 0; s < DEPTH; ++s) {
+      const int sc = s < sweeps ? s : sweeps - 1;   // fewer sweeps than slots: re-read the last one
+      q[s] = NT ? __builtin_nontemporal_load((const u32x4*)(p + sc * 4096)) : *(const u32x4*)(p + sc * 4096);
+    }
     for (int s = 0; s < sweeps; s += DEPTH) {
 #pragma unroll
       for (int d = 0; d < DEPTH; ++d) {

@@ -82,7 +82,7 @@ static __device__ __forceinline__ void q_load(u32x4& dst, const void* sbase, uin
 // they do not push the codebooks / activations / scales every workgroup re-reads out of L2
 // (guide, "nt-weights": -5...10 % per decode layer).
 #ifndef VPTQ_K256M_NT
-#define VPTQ_K256M_NT 0
+#define VPTQ_K256M_NT 1
 #endif
 static __device__ __forceinline__ void q_load_stream(u32x4& dst, const void* sbase, uint32_t voff) {
 #if VPTQ_K256M_NT
