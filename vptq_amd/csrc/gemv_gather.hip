@@ -55,6 +55,13 @@ static __device__ __forceinline__ uint32_t elem(const uint32_t (&w)[Fmt<T>::NW],
   }
 }
 
+// A/B knob (tools/gpu_r2_gather.sh): 1 = centroid gathers bypass the vector L1 (nt), 2 = the index
+// words too.  Measured: 79 / 63 us per 8192^2 layer against 39.6 us with plain loads - the 9.5 % of
+// gathers that hit in L1 and the L1's request merging matter; off.
+#ifndef VPTQ_GATHER_NT
+#define VPTQ_GATHER_NT 0
+#endif
+
 template <typename DT, int T, int ROWS, int TOK, bool PERM>
 __global__ __launch_bounds__(kGThreads) void gemv_gather_kernel(const GatherParams P) {
   using F = Fmt<T>;
@@ -108,7 +115,7 @@ __global__ __launch_bounds__(kGThreads) void gemv_gather_kernel(const GatherPara
       const int row = row0 + r < N ? row0 + r : N - 1;
       const uint32_t* src = P.idx + (size_t)row * P.row_words + (size_t)col0 * T / 32;
 #pragma unroll
-      for (int q = 0; q < NW; ++q) w[r][q] = src[q];
+      for (int q = 0; q < NW; ++q) w[r][q] = VPTQ_GATHER_NT == 2 ? __builtin_nontemporal_load(src + q) : src[q];
     }
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
@@ -117,7 +124,8 @@ __global__ __launch_bounds__(kGThreads) void gemv_gather_kernel(const GatherPara
 #pragma unroll
       for (int e = 0; e < E; ++e) {
         const uint32_t v = elem<T>(w[r], e);
-        cv[e] = *(const u32x4*)(P.cent + (size_t)(v & 0xffffu) * 16);
+        if (VPTQ_GATHER_NT) cv[e] = __builtin_nontemporal_load((const u32x4*)(P.cent + (size_t)(v & 0xffffu) * 16));
+        else cv[e] = *(const u32x4*)(P.cent + (size_t)(v & 0xffffu) * 16);
         if (RES) rv[e] = *(const u32x4*)(P.rcent + (size_t)(T == 24 ? (v >> 16) & 0xffu : v >> 16) * 16);
       }
 #pragma unroll
