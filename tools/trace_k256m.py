@@ -44,7 +44,7 @@ def main():
     os.environ["VPTQ_K256_KERNEL"] = a.kernel
     dev = torch.device("cuda", 0)
     H = a.hidden
-    lib = C.CDLL(os.path.join(ROOT, "tools", "_build", "libvptq_hip_trace.so"))
+    lib = C.CDLL(os.environ.get("VPTQ_TRACE_LIB") or os.path.join(ROOT, "tools", "_build", "libvptq_hip_trace.so"))
     res, args = B.EXPORTS["vptq_quant_gemv"]
     lib.vptq_quant_gemv.restype, lib.vptq_quant_gemv.argtypes = res, args
     lib.vptq_last_error.restype = C.c_char_p
