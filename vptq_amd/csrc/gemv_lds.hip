@@ -304,8 +304,12 @@ __global__ __launch_bounds__(kLThreads) void gemv_lds_kernel(const LdsParams P) 
       }
       IdxDecoded<FMT> dec;
       normalise_window<FMT>(dec, cur, P, rowc, g0);
-      // gathers kGB elements at a time (fewer with more token accumulators: no spills)
-      constexpr int kGB = kF16 ? (TOK == 4 ? 2 : 4) : (TOK == 1 ? 4 : 2);
+      // gathers kGB elements at a time: all 16 gathers of a chunk in flight for one fp16 token
+      // (+1...5 % over 8 in flight), fewer with more token accumulators (no spills)
+#ifndef VPTQ_LDS_GB1
+#define VPTQ_LDS_GB1 8
+#endif
+      constexpr int kGB = kF16 ? (TOK == 4 ? 2 : TOK == 1 ? VPTQ_LDS_GB1 : 4) : (TOK == 1 ? 4 : 2);
       auto batch = [&](auto e0c) {
         constexpr int e0 = decltype(e0c)::value;
         u32x4 cv[kGB], rv[kGB];
@@ -319,6 +323,10 @@ __global__ __launch_bounds__(kLThreads) void gemv_lds_kernel(const LdsParams P) 
         gather1(std::integral_constant<int, 0>{});
         if constexpr (kGB > 1) gather1(std::integral_constant<int, 1>{});
         if constexpr (kGB > 2) { gather1(std::integral_constant<int, 2>{}); gather1(std::integral_constant<int, 3>{}); }
+        if constexpr (kGB > 4) {
+          gather1(std::integral_constant<int, 4>{}); gather1(std::integral_constant<int, 5>{});
+          gather1(std::integral_constant<int, 6>{}); gather1(std::integral_constant<int, 7>{});
+        }
 #pragma unroll
         for (int u = 0; u < kGB; ++u) {
           const int e = e0 + u, q = e >> 1, h = e & 1;
