@@ -66,6 +66,22 @@ constexpr int kMMaxSlots = 4;
 #endif
 constexpr int kMXBytes1 = VPTQ_K256M_XDUP ? 4 : 2;  // staged bytes per column, one token
 
+// Timing-only ablations (tools/gpu_ablate.sh; the RESULTS of such a build are wrong): bit 0 no
+// MFMAs, bit 1 no LDS gathers (the addresses are still computed), bit 2 no epilogue, bit 3 no
+// index loads, bit 4 only the two main-table MFMAs, bit 5 only one MFMA per index.  What they
+// measured (profiles/r02/k256m_ablation_*.txt): every instruction of the inner loop costs its
+// issue time - the four 2-pass MFMAs 27-30 SIMD cycles per index-wave, the two gathers 12 - and
+// little of it hides behind anything else.
+#ifndef VPTQ_K256M_ABLATE
+#define VPTQ_K256M_ABLATE 0
+#endif
+constexpr bool kAblNoMfma = (VPTQ_K256M_ABLATE & 1) != 0;
+constexpr bool kAblNoGather = (VPTQ_K256M_ABLATE & 2) != 0;
+constexpr bool kAblNoFinish = (VPTQ_K256M_ABLATE & 4) != 0;
+constexpr bool kAblNoIndex = (VPTQ_K256M_ABLATE & 8) != 0;
+constexpr bool kAblHalfMfma = (VPTQ_K256M_ABLATE & 16) != 0;
+constexpr bool kAblQuarterMfma = (VPTQ_K256M_ABLATE & 32) != 0;
+
 static __device__ __forceinline__ u32x4 ldg16(const void* base, uint32_t byte_off) {
   return *(const u32x4*)as_global((const char*)base + byte_off);
 }
@@ -104,16 +120,26 @@ static __device__ __forceinline__ void gemv_k256m_body(const K256Layer& Ly, cons
     if ((uint32_t)(uintptr_t)(lds_u8_t*)smem != 0u) __builtin_trap();  // absolute LDS addressing
   }
   // sweeps in flight per wave.  Bandwidth x latency is ~35 KB per CU; 2 sweeps (32 KiB) cover
-  // it, and a deeper queue only backs up the vector-memory pipe: waves then sit in load issue
-  // and reach the prologue barrier microseconds late (tools/trace_k256m.py).
+  // it; a deeper queue in the steady state changes nothing (3 or 4 sweeps: same launch time,
+  // same grouped time - the loop is bound by instruction issue, not by bytes in flight).
+  // In the PROLOGUE every index load that is in flight before a wave's activations have arrived
+  // delays them, and with them the barrier all 16 waves wait at: requesting the first sweep
+  // right behind the image (DP = 1, the round-1 order had DP = 2) costs 0.2-0.5 us per launch
+  // against requesting it once the wave has staged its activations (DS); two sweeps at that
+  // point, or none before the barrier, are slower again (same-box A/B of all five orders:
+  // profiles/r02/k256m_prologue_order_ab.txt; 8192^2 single launch 7.6-8.8 -> 7.0-7.7 us).
 #ifndef VPTQ_K256M_DEPTH
 #define VPTQ_K256M_DEPTH 2
 #endif
 #ifndef VPTQ_K256M_DEPTH_PROLOGUE
-#define VPTQ_K256M_DEPTH_PROLOGUE 2
+#define VPTQ_K256M_DEPTH_PROLOGUE 0
+#endif
+#ifndef VPTQ_K256M_DEPTH_STAGED
+#define VPTQ_K256M_DEPTH_STAGED 1
 #endif
   constexpr int D = NS < VPTQ_K256M_DEPTH ? NS : VPTQ_K256M_DEPTH;  // steady state
-  constexpr int DP = D < VPTQ_K256M_DEPTH_PROLOGUE ? D : VPTQ_K256M_DEPTH_PROLOGUE;  // before the barrier
+  constexpr int DP = D < VPTQ_K256M_DEPTH_PROLOGUE ? D : VPTQ_K256M_DEPTH_PROLOGUE;  // behind the image
+  constexpr int DS = DP + VPTQ_K256M_DEPTH_STAGED < D ? DP + VPTQ_K256M_DEPTH_STAGED : D;  // + behind the staging
   // NST = 0: activations are NOT staged in LDS (more than 14336 columns do not fit beside the
   // image): the queue carries scale and x next to the index words, a row group is walked in
   // column blocks of NS sweeps, and the folded form only.
@@ -130,7 +156,8 @@ static __device__ __forceinline__ void gemv_k256m_body(const K256Layer& Ly, cons
   const int n_groups = (N + kMRows - 1) / kMRows;
   const int step = Ly.wgs;  // this layer's share of the CUs (<= n_groups)
   if (bid >= step) return;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: an SGPR
   const int j = lane & 3;     // vector-row inside the group = position inside the MFMA block
   const int blk = lane >> 2;  // MFMA block = chunk of 8 columns
   const uint16_t* const sp = Ly.scale;
@@ -195,7 +222,12 @@ static __device__ __forceinline__ void gemv_k256m_body(const K256Layer& Ly, cons
       q_load(s_raw[NQ > 1 ? s : 0], sp, coff);
       q_load(b_raw[NQ > 1 ? s : 0], Ly.x, coff);
     }
-    q_load_stream(iw[s], rbase, roff + coff);
+    if constexpr (kAblNoIndex) {
+      iw[s] = u32x4{roff + coff, coff * 2654435761u, roff ^ 0x5a5a5a5au, coff + 0x01234567u};
+      asm volatile("" : "+v"(iw[s]));
+    } else {
+      q_load_stream(iw[s], rbase, roff + coff);
+    }
   };
 
   // ---- 3. prologue, once per workgroup.
@@ -206,12 +238,14 @@ static __device__ __forceinline__ void gemv_k256m_body(const K256Layer& Ly, cons
   //    f16(s * x) and sums b * x; the exact form stages x itself.
   // Order (tools/trace_k256m.py): the codebook entry and the activations are requested
   // together (two cold misses overlap), the image is written as soon as the entry is there,
-  // and only then does the index queue go out - a wave issues in order, and behind a
-  // backed-up vector-memory queue the image, which all 16 waves wait for, was built 1.5-3 us
-  // later.  (An LDS-DMA fill, global_load_lds_dwordx4, was slower still.)
-  //  * sum b * x (one token, folded form): the bias values are requested BEHIND the first index
-  //    sweeps and the dot product waits until the first sweep has been consumed (late_bias
-  //    below).  Loaded with the rest, these 16 KiB per workgroup - the same lines for all 256
+  // the activations are staged, and only then does the index queue go out (DP / DS above) - a
+  // wave issues in order, and behind a backed-up vector-memory queue the image and the
+  // activations, which all 16 waves wait for, arrived 0.5-3 us later.  (An LDS-DMA fill,
+  // global_load_lds_dwordx4, was slower still.)
+  //  * sum b * x (one token, folded form): the bias values are requested behind the image write
+  //    (round 1: behind the first index sweeps; with those now requested after the staging it is
+  //    the same place) and the dot product waits until the first sweep has been consumed
+  //    (late_bias below).  Loaded with the rest, these 16 KiB per workgroup - the same lines for all 256
   //    workgroups at the same moment, like x and scale - delayed the prologue barrier by
   //    0.6-0.7 us per launch (timing experiment without the load: 8.4 -> 7.8 us).
   constexpr int kStageCols = kMThreads * 8;
@@ -357,6 +391,9 @@ static __device__ __forceinline__ void gemv_k256m_body(const K256Layer& Ly, cons
     const float sum = wave_sum(accb);
     if (lane == 0) red_b[wave] = sum;
   };
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int s = DP; s < DS; ++s) issue_sweep(s, bid, 0);  // this wave's activations are staged
   __builtin_amdgcn_sched_barrier(0);  // nothing that waits for index words above the barrier
   K256_STAMP(kMWaves, 7, tid);        // (trace build) this wave is at the barrier
   __syncthreads();
@@ -364,7 +401,7 @@ static __device__ __forceinline__ void gemv_k256m_body(const K256Layer& Ly, cons
   K256_STAMP(kMWaves, 2, tid);
   // past the barrier the queue is filled to its steady-state depth
 #pragma unroll
-  for (int s = DP; s < D; ++s) issue_sweep(s, bid, 0);
+  for (int s = DS; s < D; ++s) issue_sweep(s, bid, 0);
 
   // ---- 4. row groups ----
   // one sweep: 8 indices per lane (2 gathers each, kAhead indices ahead of the arithmetic)
@@ -474,8 +511,14 @@ static __device__ __forceinline__ void gemv_k256m_body(const K256Layer& Ly, cons
       const int h = u & 1;
       const uint32_t aC = __builtin_amdgcn_perm(w, baseA, selGA[h]);
       const uint32_t aR = __builtin_amdgcn_perm(w, baseB, selGB[h]);
-      cv[u % (kAhead + 1)] = lds_load16(aC);
-      rv[u % (kAhead + 1)] = lds_load16(aR);
+      if constexpr (kAblNoGather) {
+        asm volatile("" :: "v"(aC), "v"(aR));
+        cv[u % (kAhead + 1)] = words;
+        rv[u % (kAhead + 1)] = words;
+      } else {
+        cv[u % (kAhead + 1)] = lds_load16(aC);
+        rv[u % (kAhead + 1)] = lds_load16(aR);
+      }
     };
 #pragma unroll
     for (int u = 0; u < kAhead; ++u) gather(u);
@@ -510,13 +553,19 @@ static __device__ __forceinline__ void gemv_k256m_body(const K256Layer& Ly, cons
         for (int p = 0; p < 4; ++p) w2[p] = DT::add2(c[p], r[p]);
         acc0 = DT::mfma4(xo, u32x2{w2[0], w2[1]}, acc0);
         acc1 = DT::mfma4(xo, u32x2{w2[2], w2[3]}, acc1);
+      } else if (FAST && kAblNoMfma) {
+        asm volatile("" :: "v"(c), "v"(r), "v"(xo));
       } else if (FAST) {
         f32x4& acc2 = acc.a[kAcc4 ? 2 : 0];
         f32x4& acc3 = acc.a[kAcc4 ? 3 : 1];
         acc0 = DT::mfma4(xo, u32x2{c[0], c[1]}, acc0);
-        acc1 = DT::mfma4(xo, u32x2{c[2], c[3]}, acc1);
-        acc2 = DT::mfma4(xo, u32x2{r[0], r[1]}, acc2);
-        acc3 = DT::mfma4(xo, u32x2{r[2], r[3]}, acc3);
+        if constexpr (!kAblQuarterMfma) acc1 = DT::mfma4(xo, u32x2{c[2], c[3]}, acc1);
+        if constexpr (!kAblHalfMfma && !kAblQuarterMfma) {
+          acc2 = DT::mfma4(xo, u32x2{r[0], r[1]}, acc2);
+          acc3 = DT::mfma4(xo, u32x2{r[2], r[3]}, acc3);
+        } else {
+          asm volatile("" :: "v"(r), "v"(c));
+        }
       } else {
         const u32x4 sv = s_raw[NQ > 1 ? s : 0], bv = b_raw[NQ > 1 ? s : 0];
         uint32_t w2[4];
@@ -671,7 +720,11 @@ static __device__ __forceinline__ void gemv_k256m_body(const K256Layer& Ly, cons
     for (int cb = 0; cb + 1 < n_cblocks; ++cb) cblock(first_c, no_t{}, rg, cb, rg, cb + 1, acc);
     cblock(first_c, last_c, rg, n_cblocks - 1, rg + step, 0, acc);
     if (LAST) K256_STAMP(kMWaves, 3, acc.a[0][0] + acc.a[1][0]);
-    finish(rg, q, acc);
+    if constexpr (kAblNoFinish) {
+      if (acc.a[0][0] + acc.a[1][3] == 1234.5f) as_global(Ly.y)[tid] = 1;
+    } else {
+      finish(rg, q, acc);
+    }
   };
   using yes = std::integral_constant<bool, true>;
   using no = std::integral_constant<bool, false>;
