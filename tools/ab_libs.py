@@ -78,7 +78,13 @@ def main():
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     H = a.hidden
-    libs = [(kv.split("=")[0], load(kv.split("=")[1])) for kv in a.libs.split(",")]
+    # name=path or name=path@flags (VPTQ_GEMV_* flags of that entry, e.g. 8 = FORCE_MFMA, 16 = FORCE_VALU)
+    libs, lib_flags = [], {}
+    for kv in a.libs.split(","):
+        name, path = kv.split("=")
+        path, _, fl = path.partition("@")
+        libs.append((name, load(path)))
+        lib_flags[name] = int(fl) if fl else a.flags
     idx_bytes = H // 8 * H * 2
     R = max(2, (512 << 20) // idx_bytes)
     R = (R // a.group) * a.group
@@ -100,14 +106,14 @@ def main():
     outs = {}
     for name, l in libs:
         y = torch.zeros(1, 1, H, device=dev, dtype=torch.float16)
-        rc = l.vptq_quant_gemv(descs[0], x.data_ptr(), y.data_ptr(), 1, a.flags, None, 0,
+        rc = l.vptq_quant_gemv(descs[0], x.data_ptr(), y.data_ptr(), 1, lib_flags[name], None, 0,
                                torch.cuda.current_stream().cuda_stream)
         assert rc == 0, l.vptq_last_error()
         torch.cuda.synchronize()
         outs[name] = y.float().reshape(-1)
         err = float((outs[name] - ref).abs().max() / ref.abs().max())
         d0 = float((outs[name] - outs[libs[0][0]]).abs().max() / ref.abs().max())
-        kn = l.vptq_quant_gemv_kernel_name(descs[0], 1, a.flags)
+        kn = l.vptq_quant_gemv_kernel_name(descs[0], 1, lib_flags[name])
         print(f"parity {name:12s} kernel={kn.decode() if kn else None} rel_err_vs_dequant={err:.2e} "
               f"vs_{libs[0][0]}={d0:.2e}", flush=True)
         assert a.no_parity or err <= 1e-3, (name, err)
@@ -115,8 +121,10 @@ def main():
     graphs = {}
     ys = [torch.empty(1, 1, H, device=dev, dtype=torch.float16) for _ in range(R)]
     for name, l in libs:
-        def one(i, l=l):
-            rc = l.vptq_quant_gemv(descs[i], x.data_ptr(), ys[i].data_ptr(), 1, a.flags, None, 0,
+        fl = lib_flags[name]
+
+        def one(i, l=l, fl=fl):
+            rc = l.vptq_quant_gemv(descs[i], x.data_ptr(), ys[i].data_ptr(), 1, fl, None, 0,
                                    torch.cuda.current_stream().cuda_stream)
             assert rc == 0, l.vptq_last_error()
         chunks = []
@@ -125,9 +133,9 @@ def main():
             chunks.append((m, (B.LayerDesc * m)(*descs[i0:i0 + m]), (C.c_void_p * m)(*[x.data_ptr()] * m),
                            (C.c_void_p * m)(*[y.data_ptr() for y in ys[i0:i0 + m]])))
 
-        def grouped(l=l, chunks=chunks):
+        def grouped(l=l, chunks=chunks, fl=fl):
             for m, arr, xp, yp in chunks:
-                rc = l.vptq_quant_gemv_grouped(arr, m, xp, yp, 1, a.flags,
+                rc = l.vptq_quant_gemv_grouped(arr, m, xp, yp, 1, fl,
                                                torch.cuda.current_stream().cuda_stream)
                 assert rc == 0, l.vptq_last_error()
         keeps.append(chunks)

@@ -76,7 +76,7 @@ def main():
           f"{t0 - prev_end:+.2f} us before this launch's first wave started")
     for k in ORDER:
         name = PHASES[k]
-        if (t[:, k] == 0).all():
+        if (t[:, k] == 0).all() or (k == 4 and a.kernel == "mfma"):
             continue  # boundary not stamped by this kernel
         v = (t[:, k] - t0)
         q = [v.min().item(), v.median().item(), v.max().item()]
@@ -85,6 +85,15 @@ def main():
         out["phases"][name] = q + [w.min().item(), w.median().item(), w.max().item()]
         print(f"  {name:24s} min {q[0]:6.2f}  median {q[1]:6.2f}  max {q[2]:6.2f} us   slowest wave per "
               f"workgroup: {w.min().item():5.2f} / {w.median().item():5.2f} / {w.max().item():5.2f}")
+    if a.kernel == "mfma":
+        # slot 4 of the MFMA kernel: shader-clock (s_memtime) cycles between "LDS image built" and "accumulate done"
+        cyc = t[:, 4] / 0.01
+        dt = t[:, 3] - t[:, 2]
+        ok = dt > 0
+        mhz = (cyc[ok] / dt[ok])
+        out["accumulate_clock_MHz"] = [mhz.min().item(), mhz.median().item(), mhz.max().item()]
+        print(f"  s_memtime rate during the accumulate phase: min {mhz.min().item():.0f}  median {mhz.median().item():.0f}  "
+              f"max {mhz.max().item():.0f} counts per us; accumulate phase median {cyc[ok].median().item():.0f} counts")
     nxt = bufs[mid + 1].view(n_wg * nw, 8)[:, 0].cpu().double().min().item() * 0.01
     out["launch_period_us"] = nxt - t0
     print(f"  next launch's first wave started {nxt - t0:.2f} us after this one's")

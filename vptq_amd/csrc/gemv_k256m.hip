@@ -399,6 +399,12 @@ static __device__ __forceinline__ void gemv_k256m_body(const K256Layer& Ly, cons
   __syncthreads();
   __builtin_amdgcn_sched_barrier(0);
   K256_STAMP(kMWaves, 2, tid);
+#ifdef VPTQ_K256_TRACE
+  // (trace build) shader-clock cycles of the accumulate phase: with the wall-clock stamps 2 and 3
+  // this gives the clock the CU actually ran at
+  unsigned long long clk2_;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(clk2_) : "v"(tid) : "memory");
+#endif
   // past the barrier the queue is filled to its steady-state depth
 #pragma unroll
   for (int s = DS; s < D; ++s) issue_sweep(s, bid, 0);
@@ -720,6 +726,13 @@ static __device__ __forceinline__ void gemv_k256m_body(const K256Layer& Ly, cons
     for (int cb = 0; cb + 1 < n_cblocks; ++cb) cblock(first_c, no_t{}, rg, cb, rg, cb + 1, acc);
     cblock(first_c, last_c, rg, n_cblocks - 1, rg + step, 0, acc);
     if (LAST) K256_STAMP(kMWaves, 3, acc.a[0][0] + acc.a[1][0]);
+#ifdef VPTQ_K256_TRACE
+    if (LAST) {
+      unsigned long long clk3_;
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(clk3_) : "v"(acc.a[0][0] + acc.a[1][0]) : "memory");
+      if (lane == 0) ((unsigned long long*)Ly.pf)[((size_t)bid * kMWaves + wave) * 8 + 4] = clk3_ - clk2_;
+    }
+#endif
     if constexpr (kAblNoFinish) {
       if (acc.a[0][0] + acc.a[1][3] == 1234.5f) as_global(Ly.y)[tid] = 1;
     } else {
