@@ -23,8 +23,9 @@ line reports the MEDIAN region (all of them are listed under "regions_ms_per_ste
                    with N > 1 this line is also attached to the tp_row line as "weak_scaling"
 Extras (N = 1, unless --no-extras): the same measurement at hidden 4096 (BASELINE configs[0/1]),
 with the reference's roundings (VPTQ_GEMV_EXACT), grouped x4, 16 tokens (batched-decode kernel),
-the k = 8192 + 256 format (LDS-resident codebooks), and tp_row on one GPU (the strong-scaling
-baseline), each a short ring of its own.
+the k = 8192 + 256 format (LDS-resident codebooks), tp_row on one GPU (the strong-scaling
+baseline), each a short ring of its own, and the Llama-3-8B shaped decode loop (BASELINE
+configs[2]: tokens/s + TTFT of the whole model, tools/llama_decode.py in a process of its own).
 
 Inputs and weights are resident in HBM before the timed region.  Prints ONE JSON line.
 """
@@ -53,6 +54,26 @@ def alg_bytes(I, O=None, k=256, kr=256, tokens=1):
     O = I if O is None else O
     T = int(np.log2(k)) + (int(np.log2(kr)) if kr > 0 else 0)
     return (O // 8) * ((I * T + 31) // 32) * 4 + (k + max(kr, 0)) * 8 * 2 + tokens * 2 * I + 4 * I + tokens * 2 * O
+
+
+def model_decode_extra(timeout_s=240):
+    """BASELINE configs[2]: the Llama-3-8B shaped decode loop of tools/llama_decode.py (all 32 decoder
+    layers, every nn.Linear a 2-bit VQuantLinear through HF Transformers' VPTQ route, sibling projections
+    in grouped launches, decode step replayed from a hipGraph) in a process of its own, after the timed
+    regions of this one.  tokens/s and TTFT of the WHOLE model: HF's own eager kernels (norms, RoPE,
+    SDPA, cache update) and the fp16 lm_head are in it, the VQuantLinear launches are about a quarter."""
+    import subprocess
+    try:
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "llama_decode.py"), "--fuse", "--new", "128"],
+                           capture_output=True, text=True, timeout=timeout_s)
+        line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+        d = json.loads(line)
+        return {"what": d["model"] + ", prompt 128, 128 new tokens, batch 1, one GPU; tools/llama_decode.py --fuse",
+                "tokens_per_s": d["decode_tok_s_hipgraph"], "tokens_per_s_eager": d["decode_tok_s_eager"],
+                "ttft_ms": d["ttft_ms"], "packed_index_GB": d["packed_index_GB"],
+                "weight_GBps": d.get("hipgraph_weight_GBps")}
+    except Exception as e:  # the headline line must not depend on transformers being importable
+        return {"error": f"{type(e).__name__}: {e}"[:300]}
 
 
 def shard_ring(total_layers, rank, world):
@@ -535,6 +556,7 @@ def main():
                                    "path (world size 1): the strong-scaling baseline of --gpus N",
                            "GBps": tr["value"], "us_per_decoder_layer": tr["us_per_decoder_layer"],
                            "parity_rel_err_vs_cpu_oracle": tr.get("parity_rel_err_vs_cpu_oracle")}
+        ex["llama3_8b_decode"] = model_decode_extra()
         out["extras"] = ex
     if rank == 0:
         print(json.dumps(out))

@@ -968,6 +968,66 @@ def test_lds_kernel_golden_and_determinism(dev):
     assert bit_identical_frac(outs[0], y) >= 0.9
 
 
+# ---------------------------------------------------------------- L2-gather kernel for the other large formats
+GATHERX_CASES = [
+    # I, O, kwargs, tokens      v = 8 / 16, any index width T, several codebook groups, no outliers
+    (1024, 512, dict(vector_len=16, num_centroids=65536, num_res_centroids=65536, dist="llm"), 1),   # v16-k65536-65536, T = 32
+    (1024, 520, dict(vector_len=16, num_centroids=65536, num_res_centroids=32768, dist="llm", bias=True), 2),  # T = 31, padded O
+    (2048, 256, dict(vector_len=16, num_centroids=65536, num_res_centroids=1024, dist="llm"), 1),    # T = 26
+    (1024, 256, dict(vector_len=16, num_centroids=65536, num_res_centroids=0), 3),                   # T = 16
+    (1028, 264, dict(vector_len=8, num_centroids=32768, num_res_centroids=0, enable_perm=True), 1),  # T = 15, ragged piece
+    (520, 136, dict(vector_len=8, num_centroids=65536, num_res_centroids=1024, enable_perm=True, bias=True), 4),  # T = 26
+    (1024, 512, dict(vector_len=8, num_centroids=16384, num_res_centroids=16384, dist="llm"), 1),    # T = 28
+    (2048, 128, dict(vector_len=8, num_centroids=4096, num_res_centroids=4096, num_codebooks=2), 2),  # two codebook groups, T = 24
+    (1024, 64, dict(vector_len=16, num_centroids=256, num_res_centroids=256, num_codebooks=4, enable_perm=True), 1),
+    (512, 48, dict(vector_len=8, num_centroids=1024, num_res_centroids=4, enable_norm=False, num_codebooks=2), 5),  # no norm, 5 tokens
+    (4, 8, dict(vector_len=8, num_centroids=256, num_res_centroids=0), 1),                             # one piece of one lane
+    (1024, 768, dict(vector_len=12, num_centroids=65536, num_res_centroids=4096, dist="llm"), 1),     # v12-k65536-4096, T = 28
+    (1032, 100, dict(vector_len=12, num_centroids=4096, num_res_centroids=0, enable_perm=True, bias=True), 4),  # v = 12, padded O
+    (512, 120, dict(vector_len=12, num_centroids=65536, num_res_centroids=256, dtype="bf16", dist="llm"), 2),
+    (8192, 8192, dict(vector_len=16, num_centroids=65536, num_res_centroids=65536, dist="llm"), 1),  # BASELINE size
+    (1024, 512, dict(vector_len=16, num_centroids=65536, num_res_centroids=4096, dtype="bf16", dist="llm"), 1),
+    (776, 200, dict(vector_len=8, num_centroids=32768, num_res_centroids=512, dtype="bf16", dist="llm", enable_perm=True, bias=True), 3),
+]
+
+
+@pytest.mark.parametrize("I,O,kw,tokens", GATHERX_CASES)
+def test_gatherx_kernel_vs_oracle(I, O, kw, tokens, dev):
+    """v = 8 / 16, any codebook sizes (total index width 8 ... 32), one or several codebook groups,
+    no outliers: gemv_gatherx.hip (L2 gathers, window unpack for any width) instead of the generic
+    kernel - the reference's template space csrc/quant_gemv.cu:42-132.  Reference roundings."""
+    kw = dict(kw)
+    dist = kw.pop("dist", "ref-test")
+    L = vo.make_layer(I, O, dist=dist, seed=I + O + 13, **kw)
+    dt = L.dtype
+    rng = np.random.default_rng(17)
+    xs = (0.02 + 0.5 * rng.standard_normal((1, tokens, I))) if dist == "ref-test" \
+        else rng.standard_normal((1, tokens, I))
+    x = vo.from_f32(xs.astype(np.float32), dt)
+    m = spec_to_module(L, dev)
+    assert kernel_name(m, tokens) == "gemv_gatherx_kernel", kernel_name(m, tokens)
+    assert kernel_name(m, tokens, GENERIC) == "gemv_generic_kernel"
+    xt = bits_to_tensor(x, dt, dev).reshape(x.shape)
+    if I * O <= 4096 * 4096:
+        W_ref = vo.dequant(L, ref_residual_mask_quirk=False)
+        want = vo.gemv(W_ref, x, dt, L.bias)
+    else:
+        from oracle import c_oracle as co
+        want = co.forward(L, x, quirk=False)
+    got = tensor_to_bits(m(xt))
+    assert got.shape == want.shape
+    err = rel_err(got, want, dt)
+    assert err <= TOL[dt], f"{err:.3e}"
+    if dt == "f16":
+        assert bit_identical_frac(got, want) >= 0.95
+    gen = tensor_to_bits(gemv_abi(m, xt, GENERIC))
+    assert rel_err(got, gen, dt) <= TOL[dt]
+    from vptq_amd.utils.shard import forward_partial_f32
+    assert torch.equal(forward_partial_f32(m, xt).to(xt.dtype), m(xt))
+    outs = [tensor_to_bits(m(xt)) for _ in range(3)]
+    assert all((o == outs[0]).all() for o in outs)
+
+
 # ---------------------------------------------------------------- batched decode: 5-16 tokens, one launch
 GEMM_CASES = [
     # I, O, kwargs, tokens

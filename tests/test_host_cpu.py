@@ -127,7 +127,11 @@ def test_validation_errors_without_gpu():
     d.row_words = 16
     d.perm = 16
     assert lib.vptq_dequant(d, 16, None) == -1                             # needs inv_perm
-    assert lib.vptq_quant_gemv_kernel_name(d, 1, 0) == b"gemv_generic_kernel"
+    assert lib.vptq_quant_gemv_kernel_name(d, 1, 0) == b"gemv_gatherx_kernel"   # v = 8, no outliers
+    assert lib.vptq_quant_gemv_kernel_name(d, 1, B.GEMV_FORCE_GENERIC) == b"gemv_generic_kernel"
+    d.vector_len, d.num_indices = 4, 16
+    assert lib.vptq_quant_gemv_kernel_name(d, 1, 0) == b"gemv_generic_kernel"   # v = 4
+    d.vector_len, d.num_indices = 8, 8
     assert lib.vptq_quant_gemv_max_tokens(d) == 8                          # not the canonical format
     assert lib.vptq_quant_gemv_max_tokens(B.LayerDesc()) == 0
     v2 = B.V2Desc()

@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""Decode GEMV timing per index FORMAT (GPU box only): vector length, codebook sizes, codebook groups.
+
+    python tools/format_bench.py [--hidden 8192] [--formats v16-k65536-65536,v8-k32768-0,...] [--tokens 1]
+
+For every format a ring of distinct layers (>= 512 MiB of packed indices, capped at 32 layers) is launched
+one layer per launch from a hipGraph, with the library's kernel choice and with VPTQ_GEMV_FORCE_GENERIC.
+Prints one JSON line per format: kernel, us per launch, GB/s of the algorithmic bytes."""
+import argparse
+import json
+import math
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tools"))
+import vptq_amd  # noqa: E402
+from vptq_amd import _backend as B  # noqa: E402
+from _gpu_util import module_desc  # noqa: E402
+from microbench import time_graph  # noqa: E402
+
+
+def make(H, O, v, k, kr, C, dev, g):
+    m = vptq_amd.VQuantLinear(H, O, vector_lens=[-1, v], num_centroids=[-1, k],
+                              num_res_centroids=[-1, kr if kr > 0 else -1], group_num=C, group_size=H // C,
+                              outlier_size=0, indices_as_float=False, enable_norm=True, enable_perm=False,
+                              is_indice_packed=True, bias=False, dtype=torch.float16, device=dev,
+                              enable_proxy_error=False)
+    m.indices.data = torch.randint(-2**31, 2**31 - 1, m.indices.shape, generator=g, device=dev,
+                                   dtype=torch.int64).to(torch.int32)
+    m.centroids.weight.data = (torch.randn(m.centroids.weight.shape, generator=g, device=dev) * 0.02).half()
+    if kr > 0:
+        m.res_centroids.weight.data = (torch.randn(m.res_centroids.weight.shape, generator=g, device=dev) * 0.005).half()
+    m.weight_scale.data = (1 + 0.1 * torch.randn(H, generator=g, device=dev)).half()
+    m.weight_bias.data = (0.01 * torch.randn(H, generator=g, device=dev)).half()
+    return m
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--hidden", type=int, default=8192)
+    ap.add_argument("--formats", default="v16-k65536-65536,v16-k65536-32768,v16-k65536-1024,v16-k65536-0,v8-k65536-1024,"
+                                         "v8-k32768-0,v8-k16384-16384,v8-k65536-256,v8-k4096-4096-c2,v12-k65536-4096")
+    ap.add_argument("--tokens", type=int, default=1)
+    ap.add_argument("--out", default="")
+    a = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    lib = B.lib()
+    H = a.hidden
+    res = []
+    for f in a.formats.split(","):
+        parts = f.split("-")
+        v, k, kr = int(parts[0][1:]), int(parts[1][1:]), int(parts[2])
+        C = int(parts[3][1:]) if len(parts) > 3 else 1
+        T = int(math.log2(k)) + (int(math.log2(kr)) if kr > 0 else 0)
+        idx_bytes = (H // v) * C * ((H // C * T + 31) // 32) * 4
+        R = max(2, min(32, (512 << 20) // idx_bytes))
+        g = torch.Generator(device=dev).manual_seed(0)
+        mods = [make(H, H, v, k, kr, C, dev, g) for _ in range(R)]
+        descs = [module_desc(m) for m in mods]
+        x = torch.randn(1, a.tokens, H, device=dev, dtype=torch.float16)
+        ys = [torch.empty(1, a.tokens, H, device=dev, dtype=torch.float16) for _ in range(R)]
+        ab = idx_bytes + C * (k + max(kr, 0)) * v * 2 + a.tokens * 2 * H + 4 * H + a.tokens * 2 * H
+        row = dict(format=f, hidden=H, tokens=a.tokens, T=T, ring=R, alg_bytes=ab)
+        for name, flags in (("default", 0), ("generic", B.GEMV_FORCE_GENERIC)):
+            def run(flags=flags):
+                sp = torch.cuda.current_stream().cuda_stream
+                for (d, kp), y in zip(descs, ys):
+                    assert lib.vptq_quant_gemv(d, x.data_ptr(), y.data_ptr(), a.tokens, flags, None, 0, sp) == 0, \
+                        lib.vptq_last_error()
+            us = time_graph(run, 5) / R
+            kn = lib.vptq_quant_gemv_kernel_name(descs[0][0], a.tokens, flags)
+            row[name] = dict(kernel=kn.decode() if kn else None, us_per_launch=us, GBps=ab / us / 1e3)
+        y0 = ys[0].clone()
+        run(0)
+        torch.cuda.synchronize()
+        row["max_rel_diff_default_vs_generic"] = float((ys[0].float() - y0.float()).abs().max() / y0.float().abs().max())
+        res.append(row)
+        print(json.dumps(row), flush=True)
+        del mods, descs, ys
+        torch.cuda.empty_cache()
+    if a.out:
+        os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
+        json.dump(res, open(a.out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -112,6 +112,8 @@ const char* vptq_quant_gemv_kernel_name(const VptqLayerDesc* d, int tokens, int 
     return "gemv_gather_kernel";
   if (!(flags & VPTQ_GEMV_FORCE_GENERIC) && vptq::gemv_lds_eligible(*d, tokens > 4 ? 4 : tokens, flags))
     return "gemv_lds_kernel";
+  if (!(flags & VPTQ_GEMV_FORCE_GENERIC) && vptq::gemv_gatherx_eligible(*d, tokens > 4 ? 4 : tokens))
+    return "gemv_gatherx_kernel";
   return "gemv_generic_kernel";
 }
 
@@ -191,6 +193,16 @@ int vptq_quant_gemv(const VptqLayerDesc* d, const void* x, void* y, int tokens, 
       e = vptq::launch_gemv_lds(*d, (const char*)x + (size_t)t0 * d->in_features * 2,
                                 (char*)y + (size_t)t0 * d->out_features * yes, m, out_f32, st);
       if (e != hipSuccess) return hip_fail(e, "gemv_lds launch");
+    }
+    return VPTQ_OK;
+  }
+  if (!(flags & VPTQ_GEMV_FORCE_GENERIC) && vptq::gemv_gatherx_eligible(*d, chunk) &&
+      (((uintptr_t)x) & 3) == 0) {
+    for (int t0 = 0; t0 < tokens; t0 += 4) {
+      const int m = tokens - t0 < 4 ? tokens - t0 : 4;
+      e = vptq::launch_gemv_gatherx(*d, (const char*)x + (size_t)t0 * d->in_features * 2,
+                                    (char*)y + (size_t)t0 * d->out_features * yes, m, out_f32, st);
+      if (e != hipSuccess) return hip_fail(e, "gemv_gatherx launch");
     }
     return VPTQ_OK;
   }

@@ -1,0 +1,264 @@
+// Fused dequant + GEMV for the large-codebook formats gemv_gather.hip does not take: vector
+// length 8, 12 or 16, any main codebook up to 65536 entries, any residual codebook (none ... 65536
+// entries, i.e. ANY total index width T = index_bits + res_bits <= 32, not only 16 / 24 / 32), one
+// or several codebook groups, no outlier columns.  These are the formats of the larger published
+// checkpoints ("v16-k65536-65536", "v16-k65536-32768", "v12-k65536-4096", "v8-k32768-0", ...), which
+// ran on gemv_generic.hip (one dependent index -> gather chain per element, 0.04 of the roofline).
+//
+// Replaces WqA16WithOutliers_PackIndice for those template cases (reference
+// csrc/kernels/quant_gemv.cuh:11-186; its dispatch over index_bits x res_bits x vector length:
+// csrc/quant_gemv.cu:42-132).
+//
+// Same decomposition as gemv_gather.hip - a 256-thread workgroup owns one complete vector-row over
+// all input columns, codebook rows are gathered from L2 with 16-byte loads, all gathers of a piece
+// are in flight before the first is used, the reference's roundings, fp32 accumulation, lane-swap
+// reduce-scatter - with an index path for arbitrary T:
+//  * a lane takes 4 consecutive elements = 4 T bits, a window of <= 5 consecutive 32-bit words that
+//    starts at bit 4 T lane (a multiple of 4 bits); neighbouring lanes read neighbouring windows.
+//    The window is shifted to bit 0 once (v_alignbit_b32 with the lane's offset); element e then
+//    sits at bit e T, a WAVE-UNIFORM position: the word selection is scalar control flow, not a
+//    per-lane register index.  A window that would run past the row end is read word by word with
+//    the word number clamped (the bits that matter are inside the row by construction).
+//  * vector length 16: an entry is two 16-byte loads, 16 accumulators per token; vector length 12:
+//    a 16-byte + an 8-byte load (24-byte entries are 8-byte aligned), 12 accumulators, padded to 16
+//    for the wave reduction.
+#include "common.h"
+#include "kernels.h"
+
+namespace vptq {
+
+constexpr int kXThreads = 256;
+constexpr int kXE = 4;  // elements per lane and piece
+
+struct GatherXParams {
+  const uint32_t* idx;    // [C, N, row_words]
+  const char* cent;       // [C, k, V] 2 V bytes per entry
+  const char* rcent;      // [C, kr, V] or null
+  const uint16_t* x;      // [tokens, I]
+  void* y;                // [tokens, O] (dtype, or float when out_f32)
+  const uint16_t* scale;  // [I] in column order (perm: scale_permuted) or null (no norm)
+  const uint16_t* wbias;  // [I] or null
+  const uint16_t* bias;   // [O] or null
+  const uint16_t* perm;   // [I] or null
+  int N, G, C, I, O, row_words, k, kr, ib, rb, tokens, out_f32;
+};
+
+typedef uint32_t u32_a4 __attribute__((aligned(4)));
+typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+
+// one codebook entry (V halves = V / 2 words): 16-byte loads; the 24-byte entries of vector
+// length 12 are only 8-byte aligned: one 16-byte load at that alignment + one 8-byte load (three
+// 8-byte loads were slower than the generic kernel: the gathers are bound by lane addresses per
+// clock, not by bytes)
+typedef uint32_t u32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
+typedef uint32_t u32x2_a8 __attribute__((ext_vector_type(2), aligned(8)));
+template <int V>
+static __device__ __forceinline__ void load_entry(uint32_t (&w)[V / 2], const char* p) {
+  if constexpr (V == 12) {
+    const u32x4_a8 a = *(const u32x4_a8*)p;
+    const u32x2_a8 b = *(const u32x2_a8*)(p + 16);
+    w[0] = a[0]; w[1] = a[1]; w[2] = a[2]; w[3] = a[3]; w[4] = b[0]; w[5] = b[1];
+  } else {
+#pragma unroll
+    for (int q = 0; q < V / 8; ++q) {
+      const u32x4 a = *(const u32x4*)(p + q * 16);
+      w[4 * q] = a[0]; w[4 * q + 1] = a[1]; w[4 * q + 2] = a[2]; w[4 * q + 3] = a[3];
+    }
+  }
+}
+
+// element at the wave-uniform bit position p of the normalised window n[0..3] (T <= 32 bits)
+static __device__ __forceinline__ uint32_t window_elem(const uint32_t (&n)[4], int p, int T) {
+  const int wi = p >> 5, s = p & 31;
+  const uint32_t lo = wi == 0 ? n[0] : wi == 1 ? n[1] : wi == 2 ? n[2] : n[3];
+  const uint32_t hi = wi == 0 ? n[1] : wi == 1 ? n[2] : wi == 2 ? n[3] : 0u;
+  const uint32_t mask = T >= 32 ? 0xffffffffu : ((1u << T) - 1u);
+  return __builtin_amdgcn_alignbit(hi, lo, (uint32_t)s) & mask;
+}
+
+template <typename DT, int V, int TOK, bool PERM>
+__global__ __launch_bounds__(kXThreads) void gemv_gatherx_kernel(const GatherXParams P) {
+  static_assert(V == 8 || V == 12 || V == 16, "vector length");
+  constexpr int E = kXE;
+  constexpr int VW = V / 2;             // 32-bit words per entry
+  constexpr int VP = V == 12 ? 16 : V;  // accumulators padded to a power of two (wave reduction)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int row = blockIdx.x;
+  const int G = P.G, N = P.N, O = P.O, tokens = P.tokens;
+  const int T = P.ib + P.rb;
+  const uint32_t mmask = (1u << P.ib) - 1u;
+  const bool has_res = P.kr > 0, has_norm = P.scale != nullptr;
+
+  float acc[TOK][V];
+#pragma unroll
+  for (int t = 0; t < TOK; ++t)
+#pragma unroll
+    for (int i = 0; i < V; ++i) acc[t][i] = 0.f;
+
+  for (int cb = 0; cb < P.C; ++cb) {
+    const uint32_t* const rowp = as_global(P.idx + ((size_t)cb * N + row) * P.row_words);
+    const char* const centb = as_global(P.cent + (size_t)cb * P.k * (V * 2));
+    const char* const rcentb = has_res ? as_global(P.rcent + (size_t)cb * P.kr * (V * 2)) : nullptr;
+    for (int base = 0; base < G; base += kXThreads * E) {
+      const int want = base + tid * E;
+      const bool valid = want < G;  // G % 4 == 0 (host check): whole pieces
+      const int col0 = valid ? want : G - E;
+      const int col = cb * G + col0;  // position in scale / bias / x
+      // per-column scale / bias / activations: E halves each
+      uint32_t sp[E / 2] = {0, 0}, bp[E / 2] = {0, 0}, xp[TOK][E / 2];
+      if (has_norm) {
+        const u32x2_a4 sv = *(const u32x2_a4*)as_global(P.scale + col);
+        const u32x2_a4 bv = *(const u32x2_a4*)as_global(P.wbias + col);
+        sp[0] = sv[0]; sp[1] = sv[1]; bp[0] = bv[0]; bp[1] = bv[1];
+      }
+#pragma unroll
+      for (int t = 0; t < TOK; ++t) {
+        const uint16_t* xr = as_global(P.x + (size_t)(t < tokens ? t : tokens - 1) * P.I);
+        const uint32_t keep = valid ? 0xffffffffu : 0u;
+        if (PERM) {
+          const u32x2_a4 pv = *(const u32x2_a4*)as_global(P.perm + col);
+#pragma unroll
+          for (int q = 0; q < E / 2; ++q)
+            xp[t][q] = ((uint32_t)xr[pv[q] & 0xffffu] | ((uint32_t)xr[pv[q] >> 16] << 16)) & keep;
+        } else {
+          const u32x2_a4 xv = *(const u32x2_a4*)as_global(xr + col);
+          xp[t][0] = xv[0] & keep; xp[t][1] = xv[1] & keep;
+        }
+      }
+      // index window of the lane's 4 elements
+      uint32_t n[4];
+      {
+        const uint32_t bit = (uint32_t)col0 * (uint32_t)T;
+        const int w0 = (int)(bit >> 5);
+        const uint32_t off = bit & 31u;
+        uint32_t w[5];
+        const int last = P.row_words - 1;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) w[i] = *(const u32_a4*)(rowp + (w0 + i < last ? w0 + i : last));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) n[i] = __builtin_amdgcn_alignbit(w[i + 1], w[i], off);
+      }
+      uint32_t mi[E], ri[E];
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const uint32_t v = e == 0 ? (n[0] & (T >= 32 ? 0xffffffffu : ((1u << T) - 1u))) : window_elem(n, e * T, T);
+        mi[e] = (v & mmask) * (uint32_t)(V * 2);
+        ri[e] = (v >> P.ib) * (uint32_t)(V * 2);
+      }
+      // all gathers of the piece first (V = 16: two elements at a time), then the arithmetic
+      constexpr int GB = V == 8 ? 4 : 2;  // (4 for the wider entries too: no gain, 64 more registers)
+#pragma unroll
+      for (int e0 = 0; e0 < E; e0 += GB) {
+        uint32_t cv[GB][VW], rv[GB][VW];
+#pragma unroll
+        for (int u = 0; u < GB; ++u) {
+          load_entry<V>(cv[u], centb + mi[e0 + u]);
+          if (has_res) load_entry<V>(rv[u], rcentb + ri[e0 + u]);
+        }
+#pragma unroll
+        for (int u = 0; u < GB; ++u) {
+          const int e = e0 + u;
+          uint32_t w2[VW];
+#pragma unroll
+          for (int p = 0; p < VW; ++p) w2[p] = has_res ? DT::add2(cv[u][p], rv[u][p]) : cv[u][p];
+          if (has_norm) {
+#pragma unroll
+            for (int p = 0; p < VW; ++p) w2[p] = DT::mul2_bcast(w2[p], sp[e >> 1], e & 1);
+#pragma unroll
+            for (int p = 0; p < VW; ++p) w2[p] = DT::add2_bcast(w2[p], bp[e >> 1], e & 1);
+          }
+#pragma unroll
+          for (int t = 0; t < TOK; ++t)
+#pragma unroll
+            for (int p = 0; p < VW; ++p) {
+              acc[t][2 * p] = DT::fma_lo_h(w2[p], xp[t][e >> 1], e & 1, acc[t][2 * p]);
+              acc[t][2 * p + 1] = DT::fma_hi_h(w2[p], xp[t][e >> 1], e & 1, acc[t][2 * p + 1]);
+            }
+        }
+      }
+    }
+  }
+
+  constexpr int kVals = TOK * VP;
+  __shared__ float red[kXThreads / 64][kVals];
+  {
+    float v[kVals];
+#pragma unroll
+    for (int t = 0; t < TOK; ++t)
+#pragma unroll
+      for (int i = 0; i < VP; ++i) v[t * VP + i] = i < V ? acc[t][i < V ? i : 0] : 0.f;
+    using WR = WaveReduce<kVals>;
+    WR::run(v, lane);
+    if ((lane & ((1 << WR::kShift) - 1)) == 0) red[wave][lane >> WR::kShift] = v[0];
+  }
+  __syncthreads();
+  if (tid < kVals) {
+    const int t = tid / VP, i = tid - t * VP;
+    const int o = row * V + i;
+    if (t < tokens && i < V && o < O) {
+      float sum = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+      if (P.bias) sum += DT::to_float(as_global(P.bias)[o]);
+      if (P.out_f32) ((float*)as_global((char*)P.y))[(size_t)t * O + o] = sum;
+      else ((uint16_t*)as_global((char*)P.y))[(size_t)t * O + o] = DT::from_float(sum);
+    }
+  }
+}
+
+// ---- host side -------------------------------------------------------------------
+bool gemv_gatherx_eligible(const VptqLayerDesc& d, int tokens) {
+  const int v = d.vector_len;
+  const bool norm = d.weight_scale != nullptr && d.weight_bias != nullptr;
+  return (v == 8 || v == 12 || v == 16) && d.outlier_size == 0 && d.num_codebooks >= 1 && (d.group_size % kXE) == 0 &&
+         d.in_features == d.num_codebooks * d.group_size && d.index_bits + d.res_bits <= 32 &&
+         (long long)d.row_words * 32 >= (long long)d.group_size * (d.index_bits + d.res_bits) &&
+         d.num_indices * v >= d.out_features && tokens >= 1 && tokens <= 4 &&
+         (d.perm == nullptr || !norm || (d.scale_permuted != nullptr && d.bias_permuted != nullptr)) &&
+         (((uintptr_t)d.centroids | (uintptr_t)d.res_centroids) & (v == 12 ? 7 : 15)) == 0 &&
+         (((uintptr_t)d.indices | (uintptr_t)d.weight_scale | (uintptr_t)d.weight_bias |
+           (uintptr_t)d.scale_permuted | (uintptr_t)d.bias_permuted | (uintptr_t)d.perm) & 3) == 0;
+}
+
+template <typename DT, int V, int TOK>
+static hipError_t launch_x(const GatherXParams& P, bool perm, hipStream_t st) {
+  const dim3 grid(P.N), block(kXThreads);
+  if (perm) hipLaunchKernelGGL((gemv_gatherx_kernel<DT, V, TOK, true>), grid, block, 0, st, P);
+  else hipLaunchKernelGGL((gemv_gatherx_kernel<DT, V, TOK, false>), grid, block, 0, st, P);
+  return hipGetLastError();
+}
+
+template <typename DT, int V>
+static hipError_t launch_xv(const GatherXParams& P, bool perm, hipStream_t st) {
+  const int tok = P.tokens > 2 ? 4 : P.tokens;
+  if (tok == 1) return launch_x<DT, V, 1>(P, perm, st);
+  if (tok == 2) return launch_x<DT, V, 2>(P, perm, st);
+  return launch_x<DT, V, 4>(P, perm, st);
+}
+
+hipError_t launch_gemv_gatherx(const VptqLayerDesc& d, const void* x, void* y, int tokens, bool out_f32,
+                               hipStream_t st) {
+  GatherXParams P;
+  const bool norm = d.weight_scale != nullptr && d.weight_bias != nullptr;
+  P.idx = (const uint32_t*)d.indices;
+  P.cent = (const char*)d.centroids;
+  P.rcent = d.num_res_centroids > 0 ? (const char*)d.res_centroids : nullptr;
+  P.x = (const uint16_t*)x;
+  P.y = y;
+  P.scale = norm ? (const uint16_t*)(d.perm ? d.scale_permuted : d.weight_scale) : nullptr;
+  P.wbias = norm ? (const uint16_t*)(d.perm ? d.bias_permuted : d.weight_bias) : nullptr;
+  P.bias = (const uint16_t*)d.bias;
+  P.perm = d.perm;
+  P.N = d.num_indices; P.G = d.group_size; P.C = d.num_codebooks; P.I = d.in_features; P.O = d.out_features;
+  P.row_words = d.row_words;
+  P.k = d.num_centroids; P.kr = d.num_res_centroids; P.ib = d.index_bits; P.rb = d.res_bits;
+  P.tokens = tokens;
+  P.out_f32 = out_f32 ? 1 : 0;
+  const bool perm = d.perm != nullptr;
+  const int v = d.vector_len;
+  if (d.dtype == VPTQ_DTYPE_F16)
+    return v == 8 ? launch_xv<F16, 8>(P, perm, st) : v == 12 ? launch_xv<F16, 12>(P, perm, st)
+                                                             : launch_xv<F16, 16>(P, perm, st);
+  return v == 8 ? launch_xv<BF16, 8>(P, perm, st) : v == 12 ? launch_xv<BF16, 12>(P, perm, st)
+                                                            : launch_xv<BF16, 16>(P, perm, st);
+}
+
+}  // namespace vptq

@@ -24,6 +24,12 @@ bool gemv_gather_eligible(const VptqLayerDesc& d, int tokens);
 hipError_t launch_gemv_gather(const VptqLayerDesc& d, const void* x, void* y, int tokens,
                               bool out_f32, hipStream_t st);
 
+// gemv_gatherx.hip - v = 8 / 12 / 16, any codebook sizes (any total index width), several codebook
+// groups, no outliers: codebook rows gathered from L2 (what gemv_gather / gemv_lds do not take)
+bool gemv_gatherx_eligible(const VptqLayerDesc& d, int tokens);
+hipError_t launch_gemv_gatherx(const VptqLayerDesc& d, const void* x, void* y, int tokens,
+                               bool out_f32, hipStream_t st);
+
 // gemv_lds.hip - v=8, one codebook, 256 < k <= 8192, kr <= 512: both codebooks LDS-resident,
 // packed bit stream (T in {12, 13, 20, 21, 22}) or the v2 wire format
 bool gemv_lds_eligible(const VptqLayerDesc& d, int tokens, int flags);
