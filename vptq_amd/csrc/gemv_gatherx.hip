@@ -45,6 +45,7 @@ struct GatherXParams {
 
 typedef uint32_t u32_a4 __attribute__((aligned(4)));
 typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 
 // one codebook entry (V halves = V / 2 words): 16-byte loads; the 24-byte entries of vector
 // length 12 are only 8-byte aligned: one 16-byte load at that alignment + one 8-byte load (three
@@ -88,6 +89,9 @@ __global__ __launch_bounds__(kXThreads) void gemv_gatherx_kernel(const GatherXPa
   const int T = P.ib + P.rb;
   const uint32_t mmask = (1u << P.ib) - 1u;
   const bool has_res = P.kr > 0, has_norm = P.scale != nullptr;
+  // window offsets are multiples of gcd(4 T, 32): the largest one + 4 T bits must fit 4 words
+  const int g32 = (4 * T) & -(4 * T) & 31 ? ((4 * T) & -(4 * T)) : 32;
+  const bool need5 = 4 * T > 96 + g32;
 
   float acc[TOK][V];
 #pragma unroll
@@ -133,8 +137,17 @@ __global__ __launch_bounds__(kXThreads) void gemv_gatherx_kernel(const GatherXPa
         const uint32_t off = bit & 31u;
         uint32_t w[5];
         const int last = P.row_words - 1;
+        if (w0 + 4 <= last) {
+          // one 16-byte load at 4-byte alignment (+ the fifth word where some lane's window
+          // reaches it: 4 T + offset > 128, a property of T alone): the gathers of this kernel are
+          // bound by lane addresses per clock, five 4-byte loads per piece were a fifth of them
+          const u32x4_a4 a = *(const u32x4_a4*)(rowp + w0);
+          w[0] = a[0]; w[1] = a[1]; w[2] = a[2]; w[3] = a[3];
+          w[4] = need5 ? *(const u32_a4*)(rowp + w0 + 4) : 0u;
+        } else {
 #pragma unroll
-        for (int i = 0; i < 5; ++i) w[i] = *(const u32_a4*)(rowp + (w0 + i < last ? w0 + i : last));
+          for (int i = 0; i < 5; ++i) w[i] = *(const u32_a4*)(rowp + (w0 + i < last ? w0 + i : last));
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) n[i] = __builtin_amdgcn_alignbit(w[i + 1], w[i], off);
       }
