@@ -202,13 +202,14 @@ def compute_floor(kname, H):
     one HxH layer, with every CU busy."""
     n_idx = (H // 8) * H                       # index pairs = weight vectors of 8
     if kname.startswith("gemv_k256m"):
-        return {"what": "instruction issue: 4 MFMA 4x4x4 + 4 v_perm_b32 + 2 ds_read_b128 per index on one "
-                        "SIMD issue port = 27 ns per index-wave and SIMD (tools/ubench_loop.hip), beside 2 "
-                        "LDS gathers per index at 5.1 cycles per wave-instruction and CU; plus what a "
+        return {"what": "instruction issue on the SIMD's VALU / MFMA port: per index 4 MFMA 4x4x4 (8 cycles each) + 4 "
+                        "v_perm_b32 + 2 ds_read_b128 ~ 60 cycles per index-wave at the ~1.9 GHz the CUs hold in this "
+                        "kernel (trace build, s_memtime); timing-only ablations show the costs ADD, little hides behind "
+                        "anything else (profiles/r02/k256m_ablation_8192.txt: no MFMAs -1.5 us per launch, no gathers "
+                        "-1.0, neither -2.3); a launch needs 128 index-waves per SIMD at 8192^2.  Beside it: what a "
                         "launch that ONLY streams these bytes costs (tools/ubench_stream.hip, "
-                        "profiles/r02/ubench_stream_8192.txt: 4.1-5.0 us per 16 MiB launch incl. the "
-                        "1.8 us boundary)",
-                "us_per_launch_issue": n_idx / 64 / 1024 * 27e-3,
+                        "profiles/r02/ubench_stream_8192.txt: 4.1-5.0 us per 16 MiB launch incl. the 1.8 us boundary)",
+                "us_per_launch_issue": n_idx / 64 / 1024 * 60 / 1.9e3,
                 "us_per_launch_pure_stream": 4.65}
     instr = 14 if "fast" in kname else 22
     return {"what": f"VALU issue: {instr} instructions per index, 2.25 ns per wave-instruction per "
