@@ -102,6 +102,56 @@ def test_kernel_choice_without_gpu():
     assert lib.vptq_quant_gemv_grouped_kernel_name(two, 2, 1, 0) == b"gemv_k256_kernel<fast>"     # 64
 
 
+def _format_desc(v, k, kr, I=4096, O=4096, C=1, outliers=0, norm=True):
+    """A descriptor of an arbitrary index format with fake aligned pointers."""
+    import math
+    d = B.LayerDesc()
+    ib, rb = int(math.log2(k)), (int(math.log2(kr)) if kr else 0)
+    G = (I - outliers) // C
+    d.in_features, d.out_features, d.vector_len, d.num_codebooks, d.group_size = I, O, v, C, G
+    d.num_centroids, d.num_res_centroids, d.index_bits, d.res_bits = k, kr, ib, rb
+    d.row_words, d.num_indices, d.dtype = (G * (ib + rb) + 31) // 32, (O + v - 1) // v, 0
+    d.indices, d.centroids = 1 << 20, 2 << 20
+    d.res_centroids = (3 << 20) if kr else None
+    if norm:
+        d.weight_scale, d.weight_bias = 4 << 20, 5 << 20
+    if outliers:
+        d.outlier_size, d.outlier_vector_len, d.num_outlier_centroids = outliers, v, 1024
+        d.num_outlier_indices = d.num_indices
+        d.outlier_indices, d.outlier_centroids = 6 << 20, 7 << 20
+    return d
+
+
+def test_format_routing_without_gpu():
+    """Which kernel serves which index format (host logic only): canonical -> k = 256 kernels, v = 8 with
+    k = 65536 and 16 / 24 / 32 index bits -> gather, k <= 8192 + kr <= 512 -> LDS-resident, the other
+    v = 8 / 12 / 16 formats without outlier columns -> gatherx, the rest -> generic."""
+    lib = B.lib()
+    name = lambda d, tok=1, fl=0: lib.vptq_quant_gemv_kernel_name(d, tok, fl)  # noqa: E731
+    assert name(_format_desc(8, 256, 256)).startswith(b"gemv_k256")
+    assert name(_format_desc(8, 65536, 0)) == name(_format_desc(8, 65536, 256)) == \
+        name(_format_desc(8, 65536, 65536)) == b"gemv_gather_kernel"
+    assert name(_format_desc(8, 8192, 256)) == name(_format_desc(8, 4096, 512)) == b"gemv_lds_kernel"
+    for v, k, kr in ((16, 65536, 65536), (16, 65536, 32768), (16, 65536, 1024), (16, 65536, 0),
+                     (12, 65536, 4096), (8, 65536, 1024), (8, 32768, 0), (8, 16384, 16384), (8, 8192, 1024),
+                     (16, 256, 256), (8, 256, 0)):
+        d = _format_desc(v, k, kr, I=4096, O=v * 512)
+        for tok in (1, 2, 3, 4, 5, 8):
+            assert name(d, tok) == b"gemv_gatherx_kernel", (v, k, kr, tok)
+        assert name(d, 1, B.GEMV_FORCE_GENERIC) == b"gemv_generic_kernel"
+        assert name(d, 16) == b"gemv_gatherx_kernel" and name(d, 17) is None   # launches of <= 4 tokens
+        assert lib.vptq_quant_gemv_max_tokens(d) == 8                           # beyond: dequant + GEMM is faster
+    assert name(_format_desc(8, 4096, 4096, C=2)) == b"gemv_gatherx_kernel"          # two codebook groups
+    assert name(_format_desc(8, 1024, 4, norm=False)) == b"gemv_lds_kernel"
+    assert name(_format_desc(16, 1024, 4, O=16 * 64, norm=False)) == b"gemv_gatherx_kernel"   # no norm
+    # outlier columns, other vector lengths, column counts that are no multiple of 4: generic
+    assert name(_format_desc(8, 65536, 256, outliers=128)) == b"gemv_generic_kernel"
+    assert name(_format_desc(16, 65536, 65536, O=16 * 256, outliers=64)) == b"gemv_generic_kernel"
+    for v in (2, 4, 6, 10):
+        assert name(_format_desc(v, 4096, 0, O=v * 256)) == b"gemv_generic_kernel"
+    assert name(_format_desc(16, 65536, 0, I=4098, O=16 * 64)) == b"gemv_generic_kernel"
+
+
 def test_validation_errors_without_gpu():
     """The C ABI validates before launching: exercisable with no device."""
     lib = B.lib()
