@@ -982,6 +982,15 @@ GATHERX_CASES = [
     (1024, 64, dict(vector_len=16, num_centroids=256, num_res_centroids=256, num_codebooks=4, enable_perm=True), 1),
     (512, 48, dict(vector_len=8, num_centroids=1024, num_res_centroids=4, enable_norm=False, num_codebooks=2), 5),  # no norm, 5 tokens
     (4, 8, dict(vector_len=8, num_centroids=256, num_res_centroids=0), 1),                             # one piece of one lane
+    # outlier columns with a codebook of the same vector length
+    (1024 + 128, 512, dict(vector_len=8, num_centroids=65536, num_res_centroids=256, outlier_size=128, outlier_vector_len=8,
+                           num_outlier_centroids=1024, dist="llm"), 1),
+    (512 + 64, 264, dict(vector_len=16, num_centroids=65536, num_res_centroids=4096, outlier_size=64, outlier_vector_len=16,
+                         num_outlier_centroids=256, enable_perm=True, bias=True), 3),
+    (1024 + 300, 96, dict(vector_len=12, num_centroids=4096, num_res_centroids=0, outlier_size=300, outlier_vector_len=12,
+                          num_outlier_centroids=4096, enable_perm=True, dtype="bf16", dist="llm"), 2),   # 300 > 256 outlier columns
+    (512 + 32, 128, dict(vector_len=8, num_centroids=1024, num_res_centroids=1024, num_codebooks=2, outlier_size=32,
+                         outlier_vector_len=8, num_outlier_centroids=16, enable_norm=False), 1),
     (1024, 768, dict(vector_len=12, num_centroids=65536, num_res_centroids=4096, dist="llm"), 1),     # v12-k65536-4096, T = 28
     (1032, 100, dict(vector_len=12, num_centroids=4096, num_res_centroids=0, enable_perm=True, bias=True), 4),  # v = 12, padded O
     (512, 120, dict(vector_len=12, num_centroids=65536, num_res_centroids=256, dtype="bf16", dist="llm"), 2),

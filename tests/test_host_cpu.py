@@ -125,7 +125,7 @@ def _format_desc(v, k, kr, I=4096, O=4096, C=1, outliers=0, norm=True):
 def test_format_routing_without_gpu():
     """Which kernel serves which index format (host logic only): canonical -> k = 256 kernels, v = 8 with
     k = 65536 and 16 / 24 / 32 index bits -> gather, k <= 8192 + kr <= 512 -> LDS-resident, the other
-    v = 8 / 12 / 16 formats without outlier columns -> gatherx, the rest -> generic."""
+    v = 8 / 12 / 16 formats (outlier columns of the same vector length included) -> gatherx, the rest -> generic."""
     lib = B.lib()
     name = lambda d, tok=1, fl=0: lib.vptq_quant_gemv_kernel_name(d, tok, fl)  # noqa: E731
     assert name(_format_desc(8, 256, 256)).startswith(b"gemv_k256")
@@ -145,8 +145,12 @@ def test_format_routing_without_gpu():
     assert name(_format_desc(8, 1024, 4, norm=False)) == b"gemv_lds_kernel"
     assert name(_format_desc(16, 1024, 4, O=16 * 64, norm=False)) == b"gemv_gatherx_kernel"   # no norm
     # outlier columns, other vector lengths, column counts that are no multiple of 4: generic
-    assert name(_format_desc(8, 65536, 256, outliers=128)) == b"gemv_generic_kernel"
-    assert name(_format_desc(16, 65536, 65536, O=16 * 256, outliers=64)) == b"gemv_generic_kernel"
+    assert name(_format_desc(8, 65536, 256, outliers=128)) == b"gemv_gatherx_kernel"   # same vector length
+    assert name(_format_desc(16, 65536, 65536, O=16 * 256, outliers=64)) == b"gemv_gatherx_kernel"
+    mixed = _format_desc(8, 65536, 256, outliers=128)
+    mixed.outlier_vector_len, mixed.num_outlier_indices = 4, 4096 // 4
+    assert name(mixed) == b"gemv_generic_kernel"                                      # another vector length
+    assert name(_format_desc(8, 65536, 256, I=4096 + 2, outliers=130)) == b"gemv_generic_kernel"
     for v in (2, 4, 6, 10):
         assert name(_format_desc(v, 4096, 0, O=v * 256)) == b"gemv_generic_kernel"
     assert name(_format_desc(16, 65536, 0, I=4098, O=16 * 64)) == b"gemv_generic_kernel"

@@ -1,7 +1,7 @@
 // Fused dequant + GEMV for the large-codebook formats gemv_gather.hip does not take: vector
 // length 8, 12 or 16, any main codebook up to 65536 entries, any residual codebook (none ... 65536
 // entries, i.e. ANY total index width T = index_bits + res_bits <= 32, not only 16 / 24 / 32), one
-// or several codebook groups, no outlier columns.  These are the formats of the larger published
+// or several codebook groups, outlier columns whose codebook has the same vector length.  These are the formats of the larger published
 // checkpoints ("v16-k65536-65536", "v16-k65536-32768", "v12-k65536-4096", "v8-k32768-0", ...), which
 // ran on gemv_generic.hip (one dependent index -> gather chain per element, 0.04 of the roofline).
 //
@@ -40,7 +40,9 @@ struct GatherXParams {
   const uint16_t* wbias;  // [I] or null
   const uint16_t* bias;   // [O] or null
   const uint16_t* perm;   // [I] or null
-  int N, G, C, I, O, row_words, k, kr, ib, rb, tokens, out_f32;
+  const uint16_t* oidx;   // [N, S] outlier indices (uint16) or null
+  const char* ocent;      // [ko, V] outlier codebook or null
+  int N, G, C, I, O, S, row_words, k, kr, ib, rb, tokens, out_f32;
 };
 
 typedef uint32_t u32_a4 __attribute__((aligned(4)));
@@ -99,6 +101,29 @@ __global__ __launch_bounds__(kXThreads) void gemv_gatherx_kernel(const GatherXPa
 #pragma unroll
     for (int i = 0; i < V; ++i) acc[t][i] = 0.f;
 
+  // ---- outlier columns (the first S input columns, their own codebook of the same vector length;
+  // reference quant_gemv.cuh:52-86): one column per lane and step - they are 1-3 % of the layer
+  for (int c = tid; c < P.S; c += kXThreads) {
+    const uint32_t oi = as_global(P.oidx)[(size_t)row * P.S + c];
+    uint32_t w2[VW];
+    load_entry<V>(w2, as_global(P.ocent) + (size_t)oi * (V * 2));
+    if (has_norm) {
+      const uint32_t s2 = splat16(as_global(P.scale)[c]), b2 = splat16(as_global(P.wbias)[c]);
+#pragma unroll
+      for (int p = 0; p < VW; ++p) w2[p] = DT::add2(DT::mul2(w2[p], s2), b2);
+    }
+    const int j = PERM ? (int)as_global(P.perm)[c] : c;
+#pragma unroll
+    for (int t = 0; t < TOK; ++t) {
+      const float xf = DT::to_float(as_global(P.x)[(size_t)(t < tokens ? t : tokens - 1) * P.I + j]);
+#pragma unroll
+      for (int p = 0; p < VW; ++p) {
+        acc[t][2 * p] = DT::fma_lo(w2[p], xf, acc[t][2 * p]);
+        acc[t][2 * p + 1] = DT::fma_hi(w2[p], xf, acc[t][2 * p + 1]);
+      }
+    }
+  }
+
   for (int cb = 0; cb < P.C; ++cb) {
     const uint32_t* const rowp = as_global(P.idx + ((size_t)cb * N + row) * P.row_words);
     const char* const centb = as_global(P.cent + (size_t)cb * P.k * (V * 2));
@@ -107,7 +132,7 @@ __global__ __launch_bounds__(kXThreads) void gemv_gatherx_kernel(const GatherXPa
       const int want = base + tid * E;
       const bool valid = want < G;  // G % 4 == 0 (host check): whole pieces
       const int col0 = valid ? want : G - E;
-      const int col = cb * G + col0;  // position in scale / bias / x
+      const int col = P.S + cb * G + col0;  // position in scale / bias / x
       // per-column scale / bias / activations: E halves each
       uint32_t sp[E / 2] = {0, 0}, bp[E / 2] = {0, 0}, xp[TOK][E / 2];
       if (has_norm) {
@@ -221,8 +246,13 @@ __global__ __launch_bounds__(kXThreads) void gemv_gatherx_kernel(const GatherXPa
 bool gemv_gatherx_eligible(const VptqLayerDesc& d, int tokens) {
   const int v = d.vector_len;
   const bool norm = d.weight_scale != nullptr && d.weight_bias != nullptr;
-  return (v == 8 || v == 12 || v == 16) && d.outlier_size == 0 && d.num_codebooks >= 1 && (d.group_size % kXE) == 0 &&
-         d.in_features == d.num_codebooks * d.group_size && d.index_bits + d.res_bits <= 32 &&
+  const bool outl = d.outlier_size > 0;
+  if (outl && (d.outlier_vector_len != v || (d.outlier_size % kXE) != 0 || !d.outlier_indices || !d.outlier_centroids ||
+               d.num_outlier_indices != d.num_indices || (((uintptr_t)d.outlier_centroids) & (v == 12 ? 7 : 15)) != 0 ||
+               (((uintptr_t)d.outlier_indices) & 1) != 0))
+    return false;
+  return (v == 8 || v == 12 || v == 16) && d.num_codebooks >= 1 && (d.group_size % kXE) == 0 &&
+         d.in_features == d.outlier_size + d.num_codebooks * d.group_size && d.index_bits + d.res_bits <= 32 &&
          (long long)d.row_words * 32 >= (long long)d.group_size * (d.index_bits + d.res_bits) &&
          d.num_indices * v >= d.out_features && tokens >= 1 && tokens <= 4 &&
          (d.perm == nullptr || !norm || (d.scale_permuted != nullptr && d.bias_permuted != nullptr)) &&
@@ -260,6 +290,9 @@ hipError_t launch_gemv_gatherx(const VptqLayerDesc& d, const void* x, void* y, i
   P.wbias = norm ? (const uint16_t*)(d.perm ? d.bias_permuted : d.weight_bias) : nullptr;
   P.bias = (const uint16_t*)d.bias;
   P.perm = d.perm;
+  P.oidx = d.outlier_size > 0 ? (const uint16_t*)d.outlier_indices : nullptr;
+  P.ocent = d.outlier_size > 0 ? (const char*)d.outlier_centroids : nullptr;
+  P.S = d.outlier_size;
   P.N = d.num_indices; P.G = d.group_size; P.C = d.num_codebooks; P.I = d.in_features; P.O = d.out_features;
   P.row_words = d.row_words;
   P.k = d.num_centroids; P.kr = d.num_res_centroids; P.ib = d.index_bits; P.rb = d.res_bits;

@@ -25,7 +25,7 @@ hipError_t launch_gemv_gather(const VptqLayerDesc& d, const void* x, void* y, in
                               bool out_f32, hipStream_t st);
 
 // gemv_gatherx.hip - v = 8 / 12 / 16, any codebook sizes (any total index width), several codebook
-// groups, no outliers: codebook rows gathered from L2 (what gemv_gather / gemv_lds do not take)
+// groups, outlier columns of the same vector length: codebook rows gathered from L2 (what gemv_gather / gemv_lds do not take)
 bool gemv_gatherx_eligible(const VptqLayerDesc& d, int tokens);
 hipError_t launch_gemv_gatherx(const VptqLayerDesc& d, const void* x, void* y, int tokens,
                                bool out_f32, hipStream_t st);
