@@ -340,61 +340,86 @@ def llama70b_projections():
             ("gate_proj", Fd, H), ("up_proj", Fd, H), ("down_proj", H, Fd)]   # (name, O, I)
 
 
-def bench_tp_row(lib, B, dev, timer, rank, world, n_layers, flags, steps, warmup, regions, check=True):
+def bench_tp_row(lib, B, dev, timer, rank, world, n_layers, flags, steps, warmup, regions, check=True,
+                 fuse_siblings=True):
     """BASELINE config #5 (see the module docstring).  Every rank builds the SAME full projections
     (common seed; the permutation is already absorbed: enable_perm = False) and keeps its slice of
     the input columns; per projection: fused GEMV of the slice with fp32 partial output
-    (VPTQ_GEMV_OUT_F32) -> all-reduce (RCCL over xGMI) -> one rounding to fp16."""
+    (VPTQ_GEMV_OUT_F32) -> all-reduce (RCCL over xGMI) -> one rounding to fp16.
+    fuse_siblings (default): q / k / v and gate / up - projections of the same input - go out as ONE
+    grouped launch (vptq_quant_gemv_grouped) into one contiguous fp32 buffer, ONE all-reduce and one
+    rounding each: 4 launches + 4 collectives per decoder layer instead of 7 + 7 (the collectives are
+    latency-bound at batch 1: fewer, larger ones)."""
     from vptq_amd.utils.shard import shard_in_features
     from _gpu_util import module_desc
     dist = timer.dist
     projs = llama70b_projections()
+    groups = [[0, 1, 2], [3], [4, 5], [6]] if fuse_siblings else [[i] for i in range(len(projs))]
     g = torch.Generator(device=dev).manual_seed(4321)
-    shards, xs, parts, ys, descs, keeps, full0 = [], [], [], [], [], [], None
+    calls, keeps, full0, x_full0, y_k0 = [], [], None, None, None
     for li in range(n_layers):
+        mods = []
         for (name, O, I) in projs:
             m = make_layer(I, O, dev, g)
             if li == 0 and name == "k_proj":
                 full0 = m                      # kept whole for the parity check
-            s = shard_in_features(m, rank, world)
-            x = torch.randn(1, 1, I, device=dev, dtype=torch.float16, generator=g)
-            g0, g1 = s.shard[1], s.shard[2]
-            if li == 0 and name == "k_proj":
-                x_full0 = x
-            shards.append(s)
-            xs.append(x[..., g0:g1].contiguous())
-            parts.append(torch.empty(1, 1, O, device=dev, dtype=torch.float32))
-            ys.append(torch.empty(1, 1, O, device=dev, dtype=torch.float16))
-            d, kk = module_desc(s)
-            descs.append(d)
-            keeps.append(kk)
+            mods.append((shard_in_features(m, rank, world), O, I))
             del m
+        for grp in groups:
+            I = mods[grp[0]][2]
+            x = torch.randn(1, 1, I, device=dev, dtype=torch.float16, generator=g)   # siblings share their input
+            s0 = mods[grp[0]][0]
+            xs = x[..., s0.shard[1]:s0.shard[2]].contiguous()
+            Os = [mods[i][1] for i in grp]
+            part = torch.empty(1, 1, sum(Os), device=dev, dtype=torch.float32)
+            y = torch.empty(1, 1, sum(Os), device=dev, dtype=torch.float16)
+            ds = []
+            for i in grp:
+                d, kk = module_desc(mods[i][0])
+                ds.append(d); keeps.append((kk, mods[i][0]))
+            offs = [sum(Os[:j]) for j in range(len(grp))]
+            arr = (B.LayerDesc * len(grp))(*ds)
+            xp = (C.c_void_p * len(grp))(*[xs.data_ptr()] * len(grp))
+            yp = (C.c_void_p * len(grp))(*[part.data_ptr() + 4 * o for o in offs])
+            calls.append((len(grp), arr, xp, yp, part, y))
+            keeps.append((xs, part, y))
+            if li == 0 and 1 in grp:
+                x_full0 = x
+                o = offs[grp.index(1)]
+                y_k0 = y[..., o:o + Os[grp.index(1)]]
+        del mods
         torch.cuda.empty_cache()
-    n = len(shards)
     fl = flags | B.GEMV_OUT_F32
 
     def one_pass():
         sp = torch.cuda.current_stream().cuda_stream
-        for i in range(n):
-            rc = lib.vptq_quant_gemv(descs[i], xs[i].data_ptr(), parts[i].data_ptr(), 1, fl, None, 0, sp)
+        for (m, arr, xp, yp, part, y) in calls:
+            if m == 1:
+                rc = lib.vptq_quant_gemv(arr, xp[0], yp[0], 1, fl, None, 0, sp)
+            else:
+                rc = lib.vptq_quant_gemv_grouped(arr, m, xp, yp, 1, fl, sp)
             assert rc == 0, lib.vptq_last_error()
             if dist is not None:
-                dist.all_reduce(parts[i])       # fp32 partial sums over the ranks
-            ys[i].copy_(parts[i])               # the ONE rounding (reference: F.linear's)
+                dist.all_reduce(part)           # fp32 partial sums over the ranks
+            y.copy_(part)                       # the ONE rounding (reference: F.linear's)
     t = timer.run(one_pass, steps, warmup, regions)
     ab = sum(alg_bytes(I, O) for (_, O, I) in projs) * n_layers
+    per_layer = len(groups)
     res = dict(value=ab * steps / t["wall_s"] / 1e9, ms_per_step=t["wall_s"] * 1e3 / steps,
                us_per_decoder_layer=t["event_ms"] * 1e3 / steps / n_layers,
                decoder_layers=n_layers, projections=[p[0] for p in projs], hipgraph=t["captured"],
                alg_bytes_per_step=ab, regions_ms_per_step=t["regions_ms_per_step"],
-               all_reduce="fp32 partial outputs, one RCCL all-reduce per projection" if world > 1 else "none (1 rank)")
+               launches_per_decoder_layer=per_layer,
+               all_reduce=(f"fp32 partial outputs, {per_layer} RCCL all-reduces per decoder layer "
+                           "(q+k+v, o, gate+up, down)" if fuse_siblings else
+                           "fp32 partial outputs, one RCCL all-reduce per projection") if world > 1 else "none (1 rank)")
     if check and rank == 0:
         from oracle import c_oracle as co
         if co.available():
             L = layer_spec(full0)
             xb = x_full0.detach().cpu().contiguous().view(torch.int16).numpy().view(np.uint16)
             want = co.forward(L, xb)
-            res["parity_rel_err_vs_cpu_oracle"] = rel_err_bits(ys[1], want)   # k_proj of layer 0
+            res["parity_rel_err_vs_cpu_oracle"] = rel_err_bits(y_k0.contiguous(), want)   # k_proj of layer 0
             assert res["parity_rel_err_vs_cpu_oracle"] <= 1e-3, res
     return res
 
