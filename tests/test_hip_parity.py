@@ -900,6 +900,48 @@ def test_shards_through_the_hip_kernels(world, dev):
         assert torch.equal(p.to(torch.float16), m(x))
 
 
+@pytest.mark.parametrize("world", [1, 2, 8])
+def test_row_parallel_sibling_groups_in_one_launch(world, dev):
+    """bench.py --mode tp_row: the row-parallel shards of sibling projections (q / k / v: one input,
+    different row counts) go out as ONE grouped launch with fp32 partial outputs into one contiguous
+    buffer (vptq_quant_gemv_grouped + VPTQ_GEMV_OUT_F32), are summed over the ranks (the all-reduce) and
+    rounded once: every projection must come out as the full layer does, and as the oracle says."""
+    import ctypes as C
+    from vptq_amd import _backend as B
+    from vptq_amd.utils.shard import shard_in_features
+    I, Os = 4096, (2048, 256, 256)
+    Ls = [vo.make_layer(I, O, dist="llm", seed=50 + i) for i, O in enumerate(Os)]
+    ms = [spec_to_module(L, dev) for L in Ls]
+    xb = vo.from_f32(np.random.default_rng(5).standard_normal((1, 1, I)).astype(np.float32), "f16")
+    x = bits_to_tensor(xb, "f16", dev).reshape(1, 1, I)
+    lib = B.lib()
+    acc = torch.zeros(1, 1, sum(Os), dtype=torch.float32, device=dev)
+    for r in range(world):
+        shards = [shard_in_features(m, r, world) for m in ms]
+        xs = x[..., shards[0].shard[1]:shards[0].shard[2]].contiguous()
+        part = torch.full((1, 1, sum(Os)), float("nan"), dtype=torch.float32, device=dev)
+        ds, keep = [], []
+        for s in shards:
+            d, k = module_desc(s)
+            ds.append(d); keep.append(k)
+        offs = [sum(Os[:j]) for j in range(len(Os))]
+        arr = (B.LayerDesc * 3)(*ds)
+        xp = (C.c_void_p * 3)(*[xs.data_ptr()] * 3)
+        yp = (C.c_void_p * 3)(*[part.data_ptr() + 4 * o for o in offs])
+        rc = lib.vptq_quant_gemv_grouped(arr, 3, xp, yp, 1, B.GEMV_OUT_F32, B.current_stream_ptr(dev))
+        assert rc == 0, lib.vptq_last_error()
+        torch.cuda.synchronize()
+        assert torch.isfinite(part).all()
+        acc += part
+    y = acc.to(torch.float16)
+    o = 0
+    for L, m, O in zip(Ls, ms, Os):
+        got = tensor_to_bits(y[..., o:o + O].contiguous())
+        assert rel_err(got, tensor_to_bits(m(x)), "f16") <= 1e-3
+        assert rel_err(got, vo.forward(L, xb), "f16") <= 1e-3
+        o += O
+
+
 # ---------------------------------------------------------------- LDS-resident codebooks (k <= 8192)
 LDS_CASES = [
     # I, O, kwargs, tokens     (T = index_bits + res_bits: 12, 13, 20, 21 (two splits), 22)
