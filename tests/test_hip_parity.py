@@ -977,8 +977,8 @@ def test_lds_resident_kernel_vs_oracle(I, O, kw, tokens, dev):
     m = spec_to_module(L, dev)
     assert kernel_name(m, tokens) == "gemv_lds_kernel", kernel_name(m, tokens)
     assert kernel_name(m, tokens, GENERIC) == "gemv_generic_kernel"
-    if dt == "bf16":
-        assert kernel_name(m, tokens, EXACT) == "gemv_generic_kernel"
+    if dt == "bf16":   # the reference's roundings for bf16: the L2-gather kernel has them
+        assert kernel_name(m, tokens, EXACT) == "gemv_gatherx_kernel"
     xt = bits_to_tensor(x, dt, dev).reshape(x.shape)
     if I * O <= 4096 * 4096:
         W_ref = vo.dequant(L, ref_residual_mask_quirk=False)
