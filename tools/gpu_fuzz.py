@@ -5,6 +5,7 @@
 
 Random widths (multiples of 8 up to 30000), heights, permutation / output bias, every kernel
 and arithmetic flag combination; prints the worst max-normalised error per flag set.
+--formats: random index formats (vector length, codebook sizes, groups, outlier columns, ...) instead.
 """
 import argparse
 import os
@@ -24,13 +25,61 @@ from _gpu_util import spec_to_module, bits_to_tensor, tensor_to_bits, gemv_abi, 
 FLAGS = {"default": 0, "exact": 4, "mfma": 8, "mfma+exact": 12, "valu": 16, "valu+exact": 20}
 
 
+def fuzz_formats(a, dev):
+    """Random index FORMATS (vector length, codebook sizes, codebook groups, outlier columns, norm, perm, bias,
+    1-6 tokens) through the library's kernel choice and through the generic kernel, against the oracle."""
+    rng = np.random.default_rng(a.seed)
+    used, worst = {}, 0.0
+    for c in range(a.cases):
+        v = int(rng.choice([8, 8, 12, 16, 16, 4, 6]))
+        ib = int(rng.integers(4, 17))
+        rb = int(rng.choice([0, 0, int(rng.integers(2, 17))]))
+        if ib + rb > 32:
+            rb = 32 - ib
+        C = int(rng.choice([1, 1, 1, 2, 3]))
+        G = 4 * int(rng.integers(1, 300)) if rng.integers(0, 4) else 2 * int(rng.integers(1, 300))
+        S = int(rng.choice([0, 0, 4 * int(rng.integers(1, 40))]))
+        O = int(rng.integers(1, 40)) * v - int(rng.integers(0, v))
+        O = max(O, 1)
+        kw = dict(vector_len=v, num_centroids=1 << ib, num_res_centroids=(1 << rb) if rb else 0, num_codebooks=C,
+                  enable_perm=bool(rng.integers(0, 2)), enable_norm=bool(rng.integers(0, 4)), bias=bool(rng.integers(0, 2)))
+        if S:
+            kw.update(outlier_size=S, outlier_vector_len=v if rng.integers(0, 3) else int(rng.choice([4, 8])),
+                      num_outlier_centroids=1 << int(rng.integers(2, 11)))
+        I = S + C * G
+        dt = a.dtype
+        tol = 1e-3 if dt == "f16" else 8e-3
+        tokens = int(rng.integers(1, 7))
+        try:
+            L = vo.make_layer(I, O, dist="llm" if rng.integers(0, 2) else "ref-test", seed=2000 + c, dtype=dt, **kw)
+        except AssertionError:
+            continue
+        x = vo.from_f32((0.3 * rng.standard_normal((1, tokens, I))).astype(np.float32), dt)
+        m = spec_to_module(L, dev)
+        xt = bits_to_tensor(x, dt, dev).reshape(x.shape)
+        want = vo.gemv(vo.dequant(L, ref_residual_mask_quirk=False), x, dt, L.bias)
+        kn = kernel_name(m, tokens)
+        used[kn] = used.get(kn, 0) + 1
+        line = f"case {c:3d} v={v} k=2^{ib} kr=2^{rb} C={C} G={G} S={S} O={O} tok={tokens} {kn}:"
+        for name, fl in (("default", 0), ("generic", 2)):
+            e = rel_err(tensor_to_bits(gemv_abi(m, xt, fl)), want, dt)
+            worst = max(worst, e)
+            line += f" {name}={e:.1e}"
+            assert e <= tol, (line, kw)
+        print(line, flush=True)
+    print("kernels used:", used, "worst:", f"{worst:.2e}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=40)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
+    ap.add_argument("--formats", action="store_true", help="random index formats instead of the canonical one")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
+    if a.formats:
+        return fuzz_formats(a, dev)
     rng = np.random.default_rng(a.seed)
     worst = {k: 0.0 for k in FLAGS}
     for c in range(a.cases):
