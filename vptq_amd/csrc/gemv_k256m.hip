@@ -68,7 +68,8 @@ constexpr int kMXBytes1 = VPTQ_K256M_XDUP ? 4 : 2;  // staged bytes per column, 
 
 // Timing-only ablations (tools/gpu_ablate.sh; the RESULTS of such a build are wrong): bit 0 no
 // MFMAs, bit 1 no LDS gathers (the addresses are still computed), bit 2 no epilogue, bit 3 no
-// index loads, bit 4 only the two main-table MFMAs, bit 5 only one MFMA per index.  What they
+// index loads, bit 4 only the two main-table MFMAs, bit 5 only one MFMA per index, bit 6 no bias
+// load (sum b x), bit 7 no scale load.  What they
 // measured (profiles/r02/k256m_ablation_*.txt): every instruction of the inner loop costs its
 // issue time - the four 2-pass MFMAs 27-30 SIMD cycles per index-wave, the two gathers 12 - and
 // little of it hides behind anything else.
@@ -81,6 +82,8 @@ constexpr bool kAblNoFinish = (VPTQ_K256M_ABLATE & 4) != 0;
 constexpr bool kAblNoIndex = (VPTQ_K256M_ABLATE & 8) != 0;
 constexpr bool kAblHalfMfma = (VPTQ_K256M_ABLATE & 16) != 0;
 constexpr bool kAblQuarterMfma = (VPTQ_K256M_ABLATE & 32) != 0;
+constexpr bool kAblNoBias = (VPTQ_K256M_ABLATE & 64) != 0;    // the per-column bias values are not loaded
+constexpr bool kAblNoScale = (VPTQ_K256M_ABLATE & 128) != 0;  // the per-column scales are not loaded
 
 static __device__ __forceinline__ u32x4 ldg16(const void* base, uint32_t byte_off) {
   return *(const u32x4*)as_global((const char*)base + byte_off);
@@ -274,7 +277,8 @@ static __device__ __forceinline__ void gemv_k256m_body(const K256Layer& Ly, cons
         const uint32_t off = (uint32_t)col0 * 2u;
         if (PERM) q_load(st_pv[k], Ly.perm, off);
         if (FAST) {
-          q_load(st_s[k], sp, off);
+          if constexpr (kAblNoScale) st_s[k] = u32x4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
+          else q_load(st_s[k], sp, off);
           if (!kLateB) q_load(st_b[k], bp, off);
         }
         // PERM: x in its own order, permuted through LDS below.  Token slots past `tokens`
@@ -292,7 +296,8 @@ static __device__ __forceinline__ void gemv_k256m_body(const K256Layer& Ly, cons
 #pragma unroll
         for (int k = 0; k < NST; ++k) {
           const int want = k * kStageCols + tid * 8;
-          q_load(late_b[k], bp, (uint32_t)(want < G ? want : G - 8) * 2u);
+          if constexpr (kAblNoBias) late_b[k] = u32x4{0, 0, 0, 0};
+          else q_load(late_b[k], bp, (uint32_t)(want < G ? want : G - 8) * 2u);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
