@@ -26,7 +26,7 @@ import vptq_amd  # noqa: E402
 from vptq_amd import _backend as B  # noqa: E402
 
 
-def make_layers(H, R, dev, perm=False, k=256, kr=256):
+def make_layers(H, R, dev, perm=False, k=256, kr=256, dtype=torch.float16):
     g = torch.Generator(device=dev).manual_seed(1234)
     layers = []
     for _ in range(R):
@@ -34,14 +34,14 @@ def make_layers(H, R, dev, perm=False, k=256, kr=256):
                                   num_res_centroids=[-1, kr if kr > 0 else -1], group_num=1, group_size=H,
                                   outlier_size=0, indices_as_float=False, enable_norm=True,
                                   enable_perm=perm, is_indice_packed=True, bias=False,
-                                  dtype=torch.float16, device=dev, enable_proxy_error=False)
+                                  dtype=dtype, device=dev, enable_proxy_error=False)
         m.indices.data = torch.randint(-2**31, 2**31 - 1, m.indices.shape, generator=g,
                                        device=dev, dtype=torch.int64).to(torch.int32)
-        m.centroids.weight.data = (torch.randn(m.centroids.weight.shape, generator=g, device=dev) * 0.02).half()
+        m.centroids.weight.data = (torch.randn(m.centroids.weight.shape, generator=g, device=dev) * 0.02).to(dtype)
         if kr > 0:
-            m.res_centroids.weight.data = (torch.randn(m.res_centroids.weight.shape, generator=g, device=dev) * 0.005).half()
-        m.weight_scale.data = (1 + 0.1 * torch.randn(H, generator=g, device=dev)).half()
-        m.weight_bias.data = (0.01 * torch.randn(H, generator=g, device=dev)).half()
+            m.res_centroids.weight.data = (torch.randn(m.res_centroids.weight.shape, generator=g, device=dev) * 0.005).to(dtype)
+        m.weight_scale.data = (1 + 0.1 * torch.randn(H, generator=g, device=dev)).to(dtype)
+        m.weight_bias.data = (0.01 * torch.randn(H, generator=g, device=dev)).to(dtype)
         if perm:
             m.perm.data = torch.randperm(H, generator=g, device=dev).to(torch.int32).to(torch.int16)
         if os.environ.get("MB_SHARE_META") and layers:

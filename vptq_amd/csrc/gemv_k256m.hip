@@ -457,7 +457,11 @@ static __device__ __forceinline__ void gemv_k256m_body(const K256Layer& Ly, cons
     const u32x4 words = iw[s];
     u32x4 ga[2][2], gb[2][2];  // [pair parity][column of the pair]
     auto gather_pair = [&](int p) {
-      const uint32_t w = words[p];
+      // (the empty asm keeps the compiler from deriving all 16 gather addresses of the sweep ahead
+      // of the first fence: with 8 accumulators they no longer fit, it spilled them, and every
+      // scratch reload waited with vmcnt(0), i.e. for the index sweep requested just before)
+      uint32_t w = words[p];
+      asm volatile("" : "+v"(w));
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         ga[p & 1][h] = lds_load16(__builtin_amdgcn_perm(w, baseA, selGA[h]));
