@@ -22,19 +22,19 @@ from _gpu_util import module_desc  # noqa: E402
 from microbench import time_graph  # noqa: E402
 
 
-def make(H, O, v, k, kr, C, dev, g):
+def make(H, O, v, k, kr, C, dev, g, dtype=torch.float16):
     m = vptq_amd.VQuantLinear(H, O, vector_lens=[-1, v], num_centroids=[-1, k],
                               num_res_centroids=[-1, kr if kr > 0 else -1], group_num=C, group_size=H // C,
                               outlier_size=0, indices_as_float=False, enable_norm=True, enable_perm=False,
-                              is_indice_packed=True, bias=False, dtype=torch.float16, device=dev,
+                              is_indice_packed=True, bias=False, dtype=dtype, device=dev,
                               enable_proxy_error=False)
     m.indices.data = torch.randint(-2**31, 2**31 - 1, m.indices.shape, generator=g, device=dev,
                                    dtype=torch.int64).to(torch.int32)
-    m.centroids.weight.data = (torch.randn(m.centroids.weight.shape, generator=g, device=dev) * 0.02).half()
+    m.centroids.weight.data = (torch.randn(m.centroids.weight.shape, generator=g, device=dev) * 0.02).to(dtype)
     if kr > 0:
-        m.res_centroids.weight.data = (torch.randn(m.res_centroids.weight.shape, generator=g, device=dev) * 0.005).half()
-    m.weight_scale.data = (1 + 0.1 * torch.randn(H, generator=g, device=dev)).half()
-    m.weight_bias.data = (0.01 * torch.randn(H, generator=g, device=dev)).half()
+        m.res_centroids.weight.data = (torch.randn(m.res_centroids.weight.shape, generator=g, device=dev) * 0.005).to(dtype)
+    m.weight_scale.data = (1 + 0.1 * torch.randn(H, generator=g, device=dev)).to(dtype)
+    m.weight_bias.data = (0.01 * torch.randn(H, generator=g, device=dev)).to(dtype)
     return m
 
 
@@ -44,11 +44,13 @@ def main():
     ap.add_argument("--formats", default="v16-k65536-65536,v16-k65536-32768,v16-k65536-1024,v16-k65536-0,v8-k65536-1024,"
                                          "v8-k32768-0,v8-k16384-16384,v8-k65536-256,v8-k4096-4096-c2,v12-k65536-4096")
     ap.add_argument("--tokens", type=int, default=1)
+    ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
     ap.add_argument("--out", default="")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     lib = B.lib()
     H = a.hidden
+    tdt = torch.float16 if a.dtype == "f16" else torch.bfloat16
     res = []
     for f in a.formats.split(","):
         parts = f.split("-")
@@ -58,12 +60,12 @@ def main():
         idx_bytes = (H // v) * C * ((H // C * T + 31) // 32) * 4
         R = max(2, min(32, (512 << 20) // idx_bytes))
         g = torch.Generator(device=dev).manual_seed(0)
-        mods = [make(H, H, v, k, kr, C, dev, g) for _ in range(R)]
+        mods = [make(H, H, v, k, kr, C, dev, g, tdt) for _ in range(R)]
         descs = [module_desc(m) for m in mods]
-        x = torch.randn(1, a.tokens, H, device=dev, dtype=torch.float16)
-        ys = [torch.empty(1, a.tokens, H, device=dev, dtype=torch.float16) for _ in range(R)]
+        x = torch.randn(1, a.tokens, H, device=dev, dtype=tdt)
+        ys = [torch.empty(1, a.tokens, H, device=dev, dtype=tdt) for _ in range(R)]
         ab = idx_bytes + C * (k + max(kr, 0)) * v * 2 + a.tokens * 2 * H + 4 * H + a.tokens * 2 * H
-        row = dict(format=f, hidden=H, tokens=a.tokens, T=T, ring=R, alg_bytes=ab)
+        row = dict(format=f, hidden=H, tokens=a.tokens, dtype=a.dtype, T=T, ring=R, alg_bytes=ab)
         for name, flags in (("default", 0), ("generic", B.GEMV_FORCE_GENERIC)):
             def run(flags=flags):
                 sp = torch.cuda.current_stream().cuda_stream
