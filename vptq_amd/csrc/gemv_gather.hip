@@ -37,21 +37,25 @@ struct GatherParams {
 };
 
 // Format traits: NW 32-bit words per lane hold E elements of T bits.
-template <int T> struct Fmt;
-template <> struct Fmt<16> { static constexpr int NW = 4, E = 8; };
-template <> struct Fmt<24> { static constexpr int NW = 3, E = 4; };
-template <> struct Fmt<32> { static constexpr int NW = 4, E = 4; };
+// (WIDE: 8 elements of 24 bits = 6 words per lane and piece instead of 4 in 3: the per-column
+// scale / bias / x loads and the index load are amortised over twice the gathers - one token,
+// wide rows only; with two or more token rows in registers, or few pieces per row, it loses.)
+template <int T, bool WIDE = false> struct Fmt;
+template <bool W> struct Fmt<16, W> { static constexpr int NW = 4, E = 8; };
+template <bool W> struct Fmt<24, W> { static constexpr int E = W ? 8 : 4, NW = E * 3 / 4; };
+template <bool W> struct Fmt<32, W> { static constexpr int NW = 4, E = 4; };
 
-template <int T>
-static __device__ __forceinline__ uint32_t elem(const uint32_t (&w)[Fmt<T>::NW], int e) {
+template <int T, int NW>
+static __device__ __forceinline__ uint32_t elem(const uint32_t (&w)[NW], int e) {
   if (T == 16) return (e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffffu);
   if (T == 32) return w[e];
   // T == 24: 4 elements in 3 words
-  switch (e) {
-    case 0: return w[0] & 0xffffffu;
-    case 1: return __builtin_amdgcn_alignbit(w[1], w[0], 24) & 0xffffffu;
-    case 2: return __builtin_amdgcn_alignbit(w[2], w[1], 16) & 0xffffffu;
-    default: return w[2] >> 8;
+  const int b = (e >> 2) * 3;
+  switch (e & 3) {
+    case 0: return w[b] & 0xffffffu;
+    case 1: return __builtin_amdgcn_alignbit(w[b + 1], w[b], 24) & 0xffffffu;
+    case 2: return __builtin_amdgcn_alignbit(w[b + 2], w[b + 1], 16) & 0xffffffu;
+    default: return w[b + 2] >> 8;
   }
 }
 
@@ -62,9 +66,13 @@ static __device__ __forceinline__ uint32_t elem(const uint32_t (&w)[Fmt<T>::NW],
 #define VPTQ_GATHER_NT 0
 #endif
 
-template <typename DT, int T, int ROWS, int TOK, bool PERM>
+#ifndef VPTQ_GATHER_RES_LDS
+#define VPTQ_GATHER_RES_LDS 1
+#endif
+
+template <typename DT, int T, int ROWS, int TOK, bool PERM, bool WIDE = false>
 __global__ __launch_bounds__(kGThreads) void gemv_gather_kernel(const GatherParams P) {
-  using F = Fmt<T>;
+  using F = Fmt<T, WIDE>;
   constexpr int E = F::E, NW = F::NW;
   constexpr bool RES = T > 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -78,6 +86,16 @@ __global__ __launch_bounds__(kGThreads) void gemv_gather_kernel(const GatherPara
     for (int r = 0; r < ROWS; ++r)
 #pragma unroll
       for (int i = 0; i < 8; ++i) acc[t][r][i] = 0.f;
+
+  // T = 24 ("v8-k65536-256"): the 256-entry residual table (4 KiB) is copied into LDS once per
+  // workgroup and gathered from there.  These kernels are bound by lane ADDRESSES per clock in the
+  // vector-memory pipe (one per CU and cycle): the residual gathers were a third of them.
+  constexpr bool kResLds = T == 24 && VPTQ_GATHER_RES_LDS;
+  __shared__ u32x4 rtab[kResLds ? 256 : 1];
+  if constexpr (kResLds) {
+    rtab[tid] = *(const u32x4*)(P.rcent + (size_t)tid * 16);   // kGThreads == 256 entries
+    __syncthreads();
+  }
 
   for (int base = 0; base < G; base += kGThreads * E) {
     const int want = base + tid * E;
@@ -123,10 +141,11 @@ __global__ __launch_bounds__(kGThreads) void gemv_gather_kernel(const GatherPara
       u32x4 cv[E], rv[E];
 #pragma unroll
       for (int e = 0; e < E; ++e) {
-        const uint32_t v = elem<T>(w[r], e);
+        const uint32_t v = elem<T, NW>(w[r], e);
         if (VPTQ_GATHER_NT) cv[e] = __builtin_nontemporal_load((const u32x4*)(P.cent + (size_t)(v & 0xffffu) * 16));
         else cv[e] = *(const u32x4*)(P.cent + (size_t)(v & 0xffffu) * 16);
-        if (RES) rv[e] = *(const u32x4*)(P.rcent + (size_t)(T == 24 ? (v >> 16) & 0xffu : v >> 16) * 16);
+        if constexpr (kResLds) rv[e] = rtab[(v >> 16) & 0xffu];
+        else if (RES) rv[e] = *(const u32x4*)(P.rcent + (size_t)(T == 24 ? (v >> 16) & 0xffu : v >> 16) * 16);
       }
 #pragma unroll
       for (int e = 0; e < E; ++e) {
@@ -212,6 +231,20 @@ static hipError_t launch_t(const GatherParams& P, bool perm, hipStream_t st) {
   const int tok = P.tokens > 2 ? 4 : P.tokens;
   // ROWS = 2 amortises the per-column scale / bias / x loads when there are enough rows
   if (tok == 1) {
+    if constexpr (T == 24) {
+      // 8 elements per lane and piece: 8192^2 45.3 -> 42.3 us; loses on short rows (4096: two pieces)
+      if (P.G >= 6144) {
+        const dim3 grid((P.N + (P.N >= 2048 ? 2 : 1) - 1) / (P.N >= 2048 ? 2 : 1)), block(kGThreads);
+        if (P.N >= 2048) {
+          if (perm) hipLaunchKernelGGL((gemv_gather_kernel<DT, 24, 2, 1, true, true>), grid, block, 0, st, P);
+          else hipLaunchKernelGGL((gemv_gather_kernel<DT, 24, 2, 1, false, true>), grid, block, 0, st, P);
+        } else {
+          if (perm) hipLaunchKernelGGL((gemv_gather_kernel<DT, 24, 1, 1, true, true>), grid, block, 0, st, P);
+          else hipLaunchKernelGGL((gemv_gather_kernel<DT, 24, 1, 1, false, true>), grid, block, 0, st, P);
+        }
+        return hipGetLastError();
+      }
+    }
     if (P.N >= 2048) return launch_rt<DT, T, 2, 1>(P, perm, st);
     return launch_rt<DT, T, 1, 1>(P, perm, st);
   }
