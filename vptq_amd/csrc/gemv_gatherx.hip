@@ -43,7 +43,10 @@ struct GatherXParams {
   const uint16_t* oidx;   // [N, S] outlier indices (uint16) or null
   const char* ocent;      // [ko, V] outlier codebook or null
   int N, G, C, I, O, S, row_words, k, kr, ib, rb, tokens, out_f32;
+  int res_lds;            // the residual table (<= 32 KiB) is copied into LDS and gathered from there
 };
+
+constexpr int kXResLdsMax = 32768;
 
 typedef uint32_t u32_a4 __attribute__((aligned(4)));
 typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
@@ -68,6 +71,15 @@ static __device__ __forceinline__ void load_entry(uint32_t (&w)[V / 2], const ch
       w[4 * q] = a[0]; w[4 * q + 1] = a[1]; w[4 * q + 2] = a[2]; w[4 * q + 3] = a[3];
     }
   }
+}
+
+// the same entry out of the LDS copy of a table (byte offset inside the dynamic LDS segment)
+template <int V>
+static __device__ __forceinline__ void load_entry_lds(uint32_t (&w)[V / 2], const unsigned char* tab, uint32_t off) {
+  typedef __attribute__((address_space(3))) const uint32_t lds_u32_t;
+  lds_u32_t* p = (lds_u32_t*)(tab + off);
+#pragma unroll
+  for (int i = 0; i < V / 2; ++i) w[i] = p[i];   // merged into ds_read_b128 / b64 by the compiler
 }
 
 // element at the wave-uniform bit position p of the normalised window n[0..3] (T <= 32 bits)
@@ -100,6 +112,11 @@ __global__ __launch_bounds__(kXThreads) void gemv_gatherx_kernel(const GatherXPa
   for (int t = 0; t < TOK; ++t)
 #pragma unroll
     for (int i = 0; i < V; ++i) acc[t][i] = 0.f;
+  // small residual tables (<= 32 KiB: kr <= 2048 / 1024 / 1024 entries of 8 / 12 / 16 halves) are
+  // copied into LDS per workgroup and codebook group: the kernel is bound by lane addresses per clock
+  // in the vector-memory pipe, the copy costs kr of them, the gathers it replaces G each
+  extern __shared__ __attribute__((aligned(16))) unsigned char xsmem[];
+  const bool res_lds = P.res_lds != 0;
 
   // ---- outlier columns (the first S input columns, their own codebook of the same vector length;
   // reference quant_gemv.cuh:52-86): one column per lane and step - they are 1-3 % of the layer
@@ -128,6 +145,13 @@ __global__ __launch_bounds__(kXThreads) void gemv_gatherx_kernel(const GatherXPa
     const uint32_t* const rowp = as_global(P.idx + ((size_t)cb * N + row) * P.row_words);
     const char* const centb = as_global(P.cent + (size_t)cb * P.k * (V * 2));
     const char* const rcentb = has_res ? as_global(P.rcent + (size_t)cb * P.kr * (V * 2)) : nullptr;
+    if (res_lds) {
+      if (cb > 0) __syncthreads();   // the previous group's table is no longer read
+      const int n16 = P.kr * (V * 2) / 16;
+      for (int i = tid; i < n16; i += kXThreads)
+        *(__attribute__((address_space(3))) u32x4*)(xsmem + (size_t)i * 16) = *(const u32x4*)(rcentb + (size_t)i * 16);
+      __syncthreads();
+    }
     for (int base = 0; base < G; base += kXThreads * E) {
       const int want = base + tid * E;
       const bool valid = want < G;  // G % 4 == 0 (host check): whole pieces
@@ -191,7 +215,8 @@ __global__ __launch_bounds__(kXThreads) void gemv_gatherx_kernel(const GatherXPa
 #pragma unroll
         for (int u = 0; u < GB; ++u) {
           load_entry<V>(cv[u], centb + mi[e0 + u]);
-          if (has_res) load_entry<V>(rv[u], rcentb + ri[e0 + u]);
+          if (res_lds) load_entry_lds<V>(rv[u], xsmem, ri[e0 + u]);
+          else if (has_res) load_entry<V>(rv[u], rcentb + ri[e0 + u]);
         }
 #pragma unroll
         for (int u = 0; u < GB; ++u) {
@@ -264,8 +289,9 @@ bool gemv_gatherx_eligible(const VptqLayerDesc& d, int tokens) {
 template <typename DT, int V, int TOK>
 static hipError_t launch_x(const GatherXParams& P, bool perm, hipStream_t st) {
   const dim3 grid(P.N), block(kXThreads);
-  if (perm) hipLaunchKernelGGL((gemv_gatherx_kernel<DT, V, TOK, true>), grid, block, 0, st, P);
-  else hipLaunchKernelGGL((gemv_gatherx_kernel<DT, V, TOK, false>), grid, block, 0, st, P);
+  const int lds = P.res_lds ? P.kr * (V * 2) : 0;
+  if (perm) hipLaunchKernelGGL((gemv_gatherx_kernel<DT, V, TOK, true>), grid, block, lds, st, P);
+  else hipLaunchKernelGGL((gemv_gatherx_kernel<DT, V, TOK, false>), grid, block, lds, st, P);
   return hipGetLastError();
 }
 
@@ -298,6 +324,9 @@ hipError_t launch_gemv_gatherx(const VptqLayerDesc& d, const void* x, void* y, i
   P.k = d.num_centroids; P.kr = d.num_res_centroids; P.ib = d.index_bits; P.rb = d.res_bits;
   P.tokens = tokens;
   P.out_f32 = out_f32 ? 1 : 0;
+  // (12-half entries are read with 16 + 8 bytes from LDS as well: the table must hold whole 16-byte units)
+  const int res_bytes = d.num_res_centroids * d.vector_len * 2;
+  P.res_lds = (res_bytes > 0 && res_bytes <= kXResLdsMax && (res_bytes % 16) == 0) ? 1 : 0;
   const bool perm = d.perm != nullptr;
   const int v = d.vector_len;
   if (d.dtype == VPTQ_DTYPE_F16)
