@@ -16,15 +16,48 @@ namespace vptq {
 // a wave writes 1 KiB contiguous per W row.  (The first version stored 2 bytes per lane: 128 B
 // per wave-instruction, 1.9-2.8 TB/s.)  Rows run along blockIdx.x together with the column
 // blocks, so neither dimension meets the 65535 limit of grid.y / grid.z.
-template <typename DT, int V>
+// LDSTAB: one codebook group whose two tables together are <= 16 KiB (the canonical 2-bit format:
+// 8 KiB) - every workgroup copies them into LDS first and gathers from there.  The 16 random
+// 16-byte gathers per thread through L1 set the pace of the first version (one lane address per clock
+// in the vector-memory pipe: 55 us per 8192^2 layer, 2.4 TB/s of the 6 TB/s the stores could take).
+constexpr int kDqLdsMax = 16384;
+
+template <typename DT, int V, bool LDSTAB>
 __global__ __launch_bounds__(256) void dequant_kernel(const VptqLayerDesc d,
                                                       uint16_t* __restrict__ W, const int col_blocks) {
   constexpr int VP = V / 2;
   const int n = blockIdx.x / col_blocks;
   const int j0 = ((blockIdx.x - n * col_blocks) * 256 + threadIdx.x) * 8;
   const int I = d.in_features, O = d.out_features, S = d.outlier_size, G = d.group_size;
+  extern __shared__ __attribute__((aligned(16))) uint32_t dq_tab[];   // [k][VP] | [kr][VP]
+  if constexpr (LDSTAB) {
+    const int nm = d.num_centroids * VP, nr = d.num_res_centroids * VP;
+    const uint32_t* cm = (const uint32_t*)d.centroids;
+    const uint32_t* cr = (const uint32_t*)d.res_centroids;
+    for (int i = threadIdx.x; i < nm + nr; i += 256) dq_tab[i] = i < nm ? cm[i] : cr[i - nm];
+    __syncthreads();
+  }
   if (j0 >= I) return;
   const int T = d.index_bits + d.res_bits;
+  const bool full = j0 + 8 <= I && (I & 7) == 0;  // 16-byte aligned, whole chunk inside the row
+  // scale / bias of the 8 output columns: contiguous whatever the permutation - two 16-byte loads
+  // instead of sixteen 2-byte ones (the kernel is paced by lane addresses, not bytes)
+  u32x4 sv8 = {0, 0, 0, 0}, bv8 = {0, 0, 0, 0};
+  const bool vec_norm = full && d.weight_scale != nullptr &&
+                        ((((uintptr_t)d.weight_scale | (uintptr_t)d.weight_bias) & 15) == 0);
+  if (vec_norm) {
+    sv8 = *(const u32x4*)((const uint16_t*)d.weight_scale + j0);
+    bv8 = *(const u32x4*)((const uint16_t*)d.weight_bias + j0);
+  }
+  // 16-bit elements, no permutation, no outlier columns: the thread's 8 index elements are one
+  // aligned 16-byte piece of the row
+  u32x4 iw8 = {0, 0, 0, 0};
+  const bool vec_idx = full && T == 16 && !d.inv_perm && S == 0 && (G & 7) == 0 &&
+                       ((((uintptr_t)d.indices) & 15) == 0) && ((d.row_words & 3) == 0);
+  if (vec_idx) {
+    const int cb = j0 / G, g = j0 - cb * G;
+    iw8 = *(const u32x4*)((const uint32_t*)d.indices + ((size_t)cb * d.num_indices + n) * d.row_words + (g >> 1));
+  }
   uint32_t w2[8][VP];  // [column][row pair]
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
@@ -53,27 +86,40 @@ __global__ __launch_bounds__(256) void dequant_kernel(const VptqLayerDesc d,
       const int cb = cc / G, g = cc - cb * G;
       const uint32_t* row =
           (const uint32_t*)d.indices + ((size_t)cb * d.num_indices + n) * d.row_words;
-      const uint32_t e = unpack_elem(row, g, T);
+      const uint32_t e = vec_idx ? ((iw8[q >> 1] >> (16 * (q & 1))) & 0xffffu) : unpack_elem(row, g, T);
       const uint32_t idx = e & ((1u << d.index_bits) - 1u);
-      const uint32_t* cp = (const uint32_t*)d.centroids + ((size_t)cb * d.num_centroids + idx) * VP;
+      if constexpr (LDSTAB) {
+        const uint32_t* cp = dq_tab + (size_t)idx * VP;
 #pragma unroll
-      for (int p = 0; p < VP; ++p) w2[q][p] = cp[p];
-      if (d.res_bits) {
-        const uint32_t ridx = (e >> d.index_bits) & ((1u << d.res_bits) - 1u);
-        const uint32_t* rp =
-            (const uint32_t*)d.res_centroids + ((size_t)cb * d.num_res_centroids + ridx) * VP;
+        for (int p = 0; p < VP; ++p) w2[q][p] = cp[p];
+        if (d.res_bits) {
+          const uint32_t ridx = (e >> d.index_bits) & ((1u << d.res_bits) - 1u);
+          const uint32_t* rp = dq_tab + (size_t)(d.num_centroids + ridx) * VP;
 #pragma unroll
-        for (int p = 0; p < VP; ++p) w2[q][p] = DT::add2(w2[q][p], rp[p]);
+          for (int p = 0; p < VP; ++p) w2[q][p] = DT::add2(w2[q][p], rp[p]);
+        }
+      } else {
+        const uint32_t* cp = (const uint32_t*)d.centroids + ((size_t)cb * d.num_centroids + idx) * VP;
+#pragma unroll
+        for (int p = 0; p < VP; ++p) w2[q][p] = cp[p];
+        if (d.res_bits) {
+          const uint32_t ridx = (e >> d.index_bits) & ((1u << d.res_bits) - 1u);
+          const uint32_t* rp =
+              (const uint32_t*)d.res_centroids + ((size_t)cb * d.num_res_centroids + ridx) * VP;
+#pragma unroll
+          for (int p = 0; p < VP; ++p) w2[q][p] = DT::add2(w2[q][p], rp[p]);
+        }
       }
     }
     if (d.weight_scale) {
-      const uint32_t s2 = splat16(((const uint16_t*)d.weight_scale)[j]);
-      const uint32_t b2 = splat16(((const uint16_t*)d.weight_bias)[j]);
+      const uint32_t s2 = vec_norm ? splat16((uint16_t)(sv8[q >> 1] >> (16 * (q & 1))))
+                                   : splat16(((const uint16_t*)d.weight_scale)[j]);
+      const uint32_t b2 = vec_norm ? splat16((uint16_t)(bv8[q >> 1] >> (16 * (q & 1))))
+                                   : splat16(((const uint16_t*)d.weight_bias)[j]);
 #pragma unroll
       for (int p = 0; p < VP; ++p) w2[q][p] = DT::add2(DT::mul2(w2[q][p], s2), b2);
     }
   }
-  const bool full = j0 + 8 <= I && (I & 7) == 0;  // 16-byte aligned, whole chunk inside the row
 #pragma unroll
   for (int p = 0; p < VP; ++p) {
 #pragma unroll
@@ -102,8 +148,13 @@ static hipError_t launch_v(const VptqLayerDesc& d, void* W, hipStream_t st) {
   const int col_blocks = (d.in_features + 2047) / 2048;
   const long long blocks = (long long)col_blocks * d.num_indices;
   if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-  hipLaunchKernelGGL((dequant_kernel<DT, V>), dim3((unsigned)blocks), dim3(256), 0, st, d, (uint16_t*)W,
-                     col_blocks);
+  const int tab_bytes = (d.num_centroids + d.num_res_centroids) * V * 2;
+  if (d.num_codebooks == 1 && tab_bytes <= kDqLdsMax)
+    hipLaunchKernelGGL((dequant_kernel<DT, V, true>), dim3((unsigned)blocks), dim3(256), tab_bytes, st, d,
+                       (uint16_t*)W, col_blocks);
+  else
+    hipLaunchKernelGGL((dequant_kernel<DT, V, false>), dim3((unsigned)blocks), dim3(256), 0, st, d, (uint16_t*)W,
+                       col_blocks);
   return hipGetLastError();
 }
 
