@@ -1039,14 +1039,37 @@ GATHERX_CASES = [
     (8192, 8192, dict(vector_len=16, num_centroids=65536, num_res_centroids=65536, dist="llm"), 1),  # BASELINE size
     (1024, 512, dict(vector_len=16, num_centroids=65536, num_res_centroids=4096, dtype="bf16", dist="llm"), 1),
     (776, 200, dict(vector_len=8, num_centroids=32768, num_res_centroids=512, dtype="bf16", dist="llm", enable_perm=True, bias=True), 3),
+    # the other vector lengths the reference dispatches (csrc/quant_gemv.cu:210-233): 2, 4, 6, 10
+    (1024, 384, dict(vector_len=6, num_centroids=4096, num_res_centroids=0, dist="llm"), 1),          # v6-k4096-0, T = 12
+    (1032, 100, dict(vector_len=6, num_centroids=65536, num_res_centroids=256, enable_perm=True, bias=True), 3),  # padded O, T = 24
+    (512, 120, dict(vector_len=6, num_centroids=1024, num_res_centroids=1024, num_codebooks=2, dtype="bf16", dist="llm"), 2),
+    (2048, 256, dict(vector_len=4, num_centroids=65536, num_res_centroids=0, dist="llm"), 1),          # 8-byte entries
+    (520, 132, dict(vector_len=4, num_centroids=256, num_res_centroids=16, enable_perm=True, bias=True), 4),
+    (1024, 64, dict(vector_len=4, num_centroids=4096, num_res_centroids=4096, dtype="bf16", enable_norm=False), 2),
+    (1024, 250, dict(vector_len=10, num_centroids=65536, num_res_centroids=1024, dist="llm", bias=True), 1),   # 20-byte entries, T = 26
+    (516, 90, dict(vector_len=10, num_centroids=4096, num_res_centroids=0, enable_perm=True, dtype="bf16"), 3),
+    (1024, 66, dict(vector_len=2, num_centroids=256, num_res_centroids=0), 1),                           # 4-byte entries
+    (512, 34, dict(vector_len=2, num_centroids=4096, num_res_centroids=64, enable_perm=True, bias=True, dist="llm"), 2),
+    (512 + 32, 96, dict(vector_len=6, num_centroids=4096, num_res_centroids=0, outlier_size=32, outlier_vector_len=6,
+                        num_outlier_centroids=64), 1),
+    # outlier codebooks of vector length 4 - the only one the reference's kernel takes (csrc/quant_gemv.cu:186-189)
+    (1024 + 128, 512, dict(vector_len=8, num_centroids=65536, num_res_centroids=256, outlier_size=128, outlier_vector_len=4,
+                           num_outlier_centroids=4096, dist="llm"), 1),
+    (512 + 64, 260, dict(vector_len=8, num_centroids=4096, num_res_centroids=4096, outlier_size=64, outlier_vector_len=4,
+                         num_outlier_centroids=256, enable_perm=True, bias=True), 3),        # padded O: outlier rows end inside a vector-row
+    (1024 + 300, 96, dict(vector_len=12, num_centroids=4096, num_res_centroids=0, outlier_size=300, outlier_vector_len=4,
+                          num_outlier_centroids=1024, enable_perm=True, dtype="bf16", dist="llm"), 2),
+    (512 + 32, 136, dict(vector_len=16, num_centroids=65536, num_res_centroids=1024, outlier_size=32, outlier_vector_len=4,
+                         num_outlier_centroids=16, enable_norm=False), 4),                   # O = 136: 8.5 vector-rows of 16
 ]
 
 
 @pytest.mark.parametrize("I,O,kw,tokens", GATHERX_CASES)
 def test_gatherx_kernel_vs_oracle(I, O, kw, tokens, dev):
-    """v = 8 / 16, any codebook sizes (total index width 8 ... 32), one or several codebook groups,
-    no outliers: gemv_gatherx.hip (L2 gathers, window unpack for any width) instead of the generic
-    kernel - the reference's template space csrc/quant_gemv.cu:42-132.  Reference roundings."""
+    """Every vector length the reference dispatches (2 ... 16), any codebook sizes (total index width
+    8 ... 32), one or several codebook groups, outlier columns with a codebook of the same vector length
+    or of vector length 4: gemv_gatherx.hip (L2 gathers, window unpack for any width) instead of the
+    generic kernel - the reference's template space csrc/quant_gemv.cu:42-132, 186-233.  Reference roundings."""
     kw = dict(kw)
     dist = kw.pop("dist", "ref-test")
     L = vo.make_layer(I, O, dist=dist, seed=I + O + 13, **kw)

@@ -125,7 +125,8 @@ def _format_desc(v, k, kr, I=4096, O=4096, C=1, outliers=0, norm=True):
 def test_format_routing_without_gpu():
     """Which kernel serves which index format (host logic only): canonical -> k = 256 kernels, v = 8 with
     k = 65536 and 16 / 24 / 32 index bits -> gather, k <= 8192 + kr <= 512 -> LDS-resident, the other
-    v = 8 / 12 / 16 formats (outlier columns of the same vector length included) -> gatherx, the rest -> generic."""
+    formats of every vector length (outlier columns of the same vector length, or of vector length 4 under
+    v = 8 / 12 / 16, included) -> gatherx, the rest -> generic."""
     lib = B.lib()
     name = lambda d, tok=1, fl=0: lib.vptq_quant_gemv_kernel_name(d, tok, fl)  # noqa: E731
     assert name(_format_desc(8, 256, 256)).startswith(b"gemv_k256")
@@ -144,15 +145,27 @@ def test_format_routing_without_gpu():
     assert name(_format_desc(8, 4096, 4096, C=2)) == b"gemv_gatherx_kernel"          # two codebook groups
     assert name(_format_desc(8, 1024, 4, norm=False)) == b"gemv_lds_kernel"
     assert name(_format_desc(16, 1024, 4, O=16 * 64, norm=False)) == b"gemv_gatherx_kernel"   # no norm
-    # outlier columns, other vector lengths, column counts that are no multiple of 4: generic
+    # outlier columns
     assert name(_format_desc(8, 65536, 256, outliers=128)) == b"gemv_gatherx_kernel"   # same vector length
     assert name(_format_desc(16, 65536, 65536, O=16 * 256, outliers=64)) == b"gemv_gatherx_kernel"
     mixed = _format_desc(8, 65536, 256, outliers=128)
     mixed.outlier_vector_len, mixed.num_outlier_indices = 4, 4096 // 4
-    assert name(mixed) == b"gemv_generic_kernel"                                      # another vector length
+    assert name(mixed) == b"gemv_gatherx_kernel"          # vector length 4 (the reference kernel's only one) under 8
+    for v in (12, 16):
+        m4 = _format_desc(v, 65536, 4096, O=v * 128, outliers=64)
+        m4.outlier_vector_len, m4.num_outlier_indices = 4, v * 128 // 4
+        assert name(m4) == b"gemv_gatherx_kernel"
+    m6 = _format_desc(6, 4096, 0, O=6 * 128, outliers=64)
+    m6.outlier_vector_len, m6.num_outlier_indices = 4, 6 * 128 // 4
+    assert name(m6) == b"gemv_generic_kernel"             # outlier rows straddle the vector-rows of length 6
+    m2 = _format_desc(8, 65536, 256, outliers=128)
+    m2.outlier_vector_len, m2.num_outlier_indices = 2, 4096 // 2
+    assert name(m2) == b"gemv_generic_kernel"             # another outlier vector length
+    # column counts that are no multiple of 4: generic
     assert name(_format_desc(8, 65536, 256, I=4096 + 2, outliers=130)) == b"gemv_generic_kernel"
-    for v in (2, 4, 6, 10):
-        assert name(_format_desc(v, 4096, 0, O=v * 256)) == b"gemv_generic_kernel"
+    for v in (2, 4, 6, 10):                               # every vector length the reference dispatches
+        for k, kr in ((4096, 0), (65536, 256), (256, 256)):
+            assert name(_format_desc(v, k, kr, O=v * 256)) == b"gemv_gatherx_kernel", (v, k, kr)
     assert name(_format_desc(16, 65536, 0, I=4098, O=16 * 64)) == b"gemv_generic_kernel"
 
 
@@ -184,7 +197,12 @@ def test_validation_errors_without_gpu():
     assert lib.vptq_quant_gemv_kernel_name(d, 1, 0) == b"gemv_gatherx_kernel"   # v = 8, no outliers
     assert lib.vptq_quant_gemv_kernel_name(d, 1, B.GEMV_FORCE_GENERIC) == b"gemv_generic_kernel"
     d.vector_len, d.num_indices = 4, 16
-    assert lib.vptq_quant_gemv_kernel_name(d, 1, 0) == b"gemv_generic_kernel"   # v = 4
+    assert lib.vptq_quant_gemv_kernel_name(d, 1, 0) == b"gemv_gatherx_kernel"   # v = 4
+    d.group_size = d.in_features = 66
+    d.row_words = 17
+    assert lib.vptq_quant_gemv_kernel_name(d, 1, 0) == b"gemv_generic_kernel"   # 66 columns: no whole pieces of 4
+    d.group_size = d.in_features = 64
+    d.row_words = 16
     d.vector_len, d.num_indices = 8, 8
     assert lib.vptq_quant_gemv_max_tokens(d) == 8                          # not the canonical format
     assert lib.vptq_quant_gemv_max_tokens(B.LayerDesc()) == 0

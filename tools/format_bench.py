@@ -22,10 +22,10 @@ from _gpu_util import module_desc  # noqa: E402
 from microbench import time_graph  # noqa: E402
 
 
-def make(H, O, v, k, kr, C, dev, g, dtype=torch.float16):
-    m = vptq_amd.VQuantLinear(H, O, vector_lens=[-1, v], num_centroids=[-1, k],
-                              num_res_centroids=[-1, kr if kr > 0 else -1], group_num=C, group_size=H // C,
-                              outlier_size=0, indices_as_float=False, enable_norm=True, enable_perm=False,
+def make(H, O, v, k, kr, C, dev, g, dtype=torch.float16, S=0, ov=4, ko=4096):
+    m = vptq_amd.VQuantLinear(H, O, vector_lens=[ov if S else -1, v], num_centroids=[ko if S else -1, k],
+                              num_res_centroids=[-1, kr if kr > 0 else -1], group_num=C, group_size=(H - S) // C,
+                              outlier_size=S, indices_as_float=False, enable_norm=True, enable_perm=False,
                               is_indice_packed=True, bias=False, dtype=dtype, device=dev,
                               enable_proxy_error=False)
     m.indices.data = torch.randint(-2**31, 2**31 - 1, m.indices.shape, generator=g, device=dev,
@@ -33,6 +33,10 @@ def make(H, O, v, k, kr, C, dev, g, dtype=torch.float16):
     m.centroids.weight.data = (torch.randn(m.centroids.weight.shape, generator=g, device=dev) * 0.02).to(dtype)
     if kr > 0:
         m.res_centroids.weight.data = (torch.randn(m.res_centroids.weight.shape, generator=g, device=dev) * 0.005).to(dtype)
+    if S:
+        m.outlier_centroids.weight.data = (torch.randn(m.outlier_centroids.weight.shape, generator=g, device=dev) * 0.05).to(dtype)
+        m.outlier_indices.data = torch.randint(0, ko, m.outlier_indices.shape, generator=g, device=dev,
+                                               dtype=torch.int64).to(torch.int16)   # uint16 bit patterns
     m.weight_scale.data = (1 + 0.1 * torch.randn(H, generator=g, device=dev)).to(dtype)
     m.weight_bias.data = (0.01 * torch.randn(H, generator=g, device=dev)).to(dtype)
     return m
@@ -55,16 +59,23 @@ def main():
     for f in a.formats.split(","):
         parts = f.split("-")
         v, k, kr = int(parts[0][1:]), int(parts[1][1:]), int(parts[2])
-        C = int(parts[3][1:]) if len(parts) > 3 else 1
+        # optional suffixes: -c<codebook groups>, -o<outlier columns> (vector length 4, 4096 entries), -ov<their vector length>
+        C = S = 0
+        ov = 4
+        for q in parts[3:]:
+            if q.startswith("c"): C = int(q[1:])
+            elif q.startswith("ov"): ov = int(q[2:])
+            elif q.startswith("o"): S = int(q[1:])
+        C = C or 1
         T = int(math.log2(k)) + (int(math.log2(kr)) if kr > 0 else 0)
-        idx_bytes = (H // v) * C * ((H // C * T + 31) // 32) * 4
+        idx_bytes = (H // v) * C * (((H - S) // C * T + 31) // 32) * 4 + (H // ov) * S * 2
         R = max(2, min(32, (512 << 20) // idx_bytes))
         g = torch.Generator(device=dev).manual_seed(0)
-        mods = [make(H, H, v, k, kr, C, dev, g, tdt) for _ in range(R)]
+        mods = [make(H, H, v, k, kr, C, dev, g, tdt, S, ov) for _ in range(R)]
         descs = [module_desc(m) for m in mods]
         x = torch.randn(1, a.tokens, H, device=dev, dtype=tdt)
         ys = [torch.empty(1, a.tokens, H, device=dev, dtype=tdt) for _ in range(R)]
-        ab = idx_bytes + C * (k + max(kr, 0)) * v * 2 + a.tokens * 2 * H + 4 * H + a.tokens * 2 * H
+        ab = idx_bytes + C * (k + max(kr, 0)) * v * 2 + (4096 * ov * 2 if S else 0) + a.tokens * 2 * H + 4 * H + a.tokens * 2 * H
         row = dict(format=f, hidden=H, tokens=a.tokens, dtype=a.dtype, T=T, ring=R, alg_bytes=ab)
         for name, flags in (("default", 0), ("generic", B.GEMV_FORCE_GENERIC)):
             def run(flags=flags):

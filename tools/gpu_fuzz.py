@@ -31,7 +31,7 @@ def fuzz_formats(a, dev):
     rng = np.random.default_rng(a.seed)
     used, worst = {}, 0.0
     for c in range(a.cases):
-        v = int(rng.choice([8, 8, 12, 16, 16, 4, 6]))
+        v = int(rng.choice([8, 8, 12, 16, 16, 4, 6, 2, 10]))
         ib = int(rng.integers(4, 17))
         rb = int(rng.choice([0, 0, int(rng.integers(2, 17))]))
         if ib + rb > 32:

@@ -1,9 +1,12 @@
-// Fused dequant + GEMV for the large-codebook formats gemv_gather.hip does not take: vector
-// length 8, 12 or 16, any main codebook up to 65536 entries, any residual codebook (none ... 65536
-// entries, i.e. ANY total index width T = index_bits + res_bits <= 32, not only 16 / 24 / 32), one
-// or several codebook groups, outlier columns whose codebook has the same vector length.  These are the formats of the larger published
-// checkpoints ("v16-k65536-65536", "v16-k65536-32768", "v12-k65536-4096", "v8-k32768-0", ...), which
-// ran on gemv_generic.hip (one dependent index -> gather chain per element, 0.04 of the roofline).
+// Fused dequant + GEMV for every format the specialised kernels do not take: any vector length the
+// reference dispatches (2, 4, 6, 8, 10, 12, 16: csrc/quant_gemv.cu:210-233), any main codebook up to
+// 65536 entries, any residual codebook (none ... 65536 entries, i.e. ANY total index width
+// T = index_bits + res_bits <= 32, not only 16 / 24 / 32), one or several codebook groups, outlier
+// columns whose codebook has the layer's vector length or vector length 4 (the only one the
+// reference's kernel takes, csrc/quant_gemv.cu:186-189) under a vector length of 8 / 12 / 16.  These
+// are the formats of the larger published checkpoints ("v16-k65536-65536", "v16-k65536-32768",
+// "v12-k65536-4096", "v8-k32768-0", "v6-k4096-0", ...), which ran on gemv_generic.hip (one dependent
+// index -> gather chain per element, 0.04 of the roofline).
 //
 // Replaces WqA16WithOutliers_PackIndice for those template cases (reference
 // csrc/kernels/quant_gemv.cuh:11-186; its dispatch over index_bits x res_bits x vector length:
@@ -21,7 +24,8 @@
 //    the word number clamped (the bits that matter are inside the row by construction).
 //  * vector length 16: an entry is two 16-byte loads, 16 accumulators per token; vector length 12:
 //    a 16-byte + an 8-byte load (24-byte entries are 8-byte aligned), 12 accumulators, padded to 16
-//    for the wave reduction.
+//    for the wave reduction; 10: 16 + 4 bytes; 6: one 12-byte load; 4 / 2: one 8- / 4-byte load
+//    (accumulators padded to 8).
 #include "common.h"
 #include "kernels.h"
 
@@ -41,8 +45,9 @@ struct GatherXParams {
   const uint16_t* bias;   // [O] or null
   const uint16_t* perm;   // [I] or null
   const uint16_t* oidx;   // [N, S] outlier indices (uint16) or null
-  const char* ocent;      // [ko, V] outlier codebook or null
+  const char* ocent;      // [ko, ov] outlier codebook or null
   int N, G, C, I, O, S, row_words, k, kr, ib, rb, tokens, out_f32;
+  int ov, M;              // outlier vector length (V or 4) and rows of oidx (= ceil(O / ov))
   int res_lds;            // the residual table (<= 32 KiB) is copied into LDS and gathered from there
 };
 
@@ -58,12 +63,24 @@ typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 // clock, not by bytes)
 typedef uint32_t u32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
 typedef uint32_t u32x2_a8 __attribute__((ext_vector_type(2), aligned(8)));
+typedef uint32_t u32x3_a4 __attribute__((ext_vector_type(3), aligned(4)));
 template <int V>
 static __device__ __forceinline__ void load_entry(uint32_t (&w)[V / 2], const char* p) {
   if constexpr (V == 12) {
     const u32x4_a8 a = *(const u32x4_a8*)p;
     const u32x2_a8 b = *(const u32x2_a8*)(p + 16);
     w[0] = a[0]; w[1] = a[1]; w[2] = a[2]; w[3] = a[3]; w[4] = b[0]; w[5] = b[1];
+  } else if constexpr (V == 10) {   // 20-byte entries, 4-byte aligned
+    const u32x4_a4 a = *(const u32x4_a4*)p;
+    w[0] = a[0]; w[1] = a[1]; w[2] = a[2]; w[3] = a[3]; w[4] = *(const u32_a4*)(p + 16);
+  } else if constexpr (V == 6) {    // 12-byte entries: one global_load_dwordx3
+    const u32x3_a4 a = *(const u32x3_a4*)p;
+    w[0] = a[0]; w[1] = a[1]; w[2] = a[2];
+  } else if constexpr (V == 4) {
+    const u32x2_a8 a = *(const u32x2_a8*)p;
+    w[0] = a[0]; w[1] = a[1];
+  } else if constexpr (V == 2) {
+    w[0] = *(const u32_a4*)p;
   } else {
 #pragma unroll
     for (int q = 0; q < V / 8; ++q) {
@@ -93,10 +110,10 @@ static __device__ __forceinline__ uint32_t window_elem(const uint32_t (&n)[4], i
 
 template <typename DT, int V, int TOK, bool PERM>
 __global__ __launch_bounds__(kXThreads) void gemv_gatherx_kernel(const GatherXParams P) {
-  static_assert(V == 8 || V == 12 || V == 16, "vector length");
+  static_assert(V == 2 || V == 4 || V == 6 || V == 8 || V == 10 || V == 12 || V == 16, "vector length");
   constexpr int E = kXE;
   constexpr int VW = V / 2;             // 32-bit words per entry
-  constexpr int VP = V == 12 ? 16 : V;  // accumulators padded to a power of two (wave reduction)
+  constexpr int VP = V <= 8 ? 8 : 16;   // accumulators padded to a power of two >= 8 (wave reduction)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int row = blockIdx.x;
   const int G = P.G, N = P.N, O = P.O, tokens = P.tokens;
@@ -118,12 +135,25 @@ __global__ __launch_bounds__(kXThreads) void gemv_gatherx_kernel(const GatherXPa
   extern __shared__ __attribute__((aligned(16))) unsigned char xsmem[];
   const bool res_lds = P.res_lds != 0;
 
-  // ---- outlier columns (the first S input columns, their own codebook of the same vector length;
-  // reference quant_gemv.cuh:52-86): one column per lane and step - they are 1-3 % of the layer
+  // ---- outlier columns (the first S input columns, their own codebook; reference
+  // quant_gemv.cuh:52-86): one column per lane and step - they are 1-3 % of the layer.  The codebook
+  // has either the layer's vector length (one entry per column) or vector length 4 (V / 4 entries of
+  // 8 bytes out of V / 4 consecutive rows of the outlier indices).
   for (int c = tid; c < P.S; c += kXThreads) {
-    const uint32_t oi = as_global(P.oidx)[(size_t)row * P.S + c];
     uint32_t w2[VW];
-    load_entry<V>(w2, as_global(P.ocent) + (size_t)oi * (V * 2));
+    if (P.ov == V) {
+      const uint32_t oi = as_global(P.oidx)[(size_t)row * P.S + c];
+      load_entry<V>(w2, as_global(P.ocent) + (size_t)oi * (V * 2));
+    } else if constexpr (V % 4 == 0 && V > 4) {
+#pragma unroll
+      for (int r = 0; r < V / 4; ++r) {
+        // rows past the last outlier row belong to outputs >= O, which are not stored: any value does
+        const int m = row * (V / 4) + r;
+        const uint32_t oi = as_global(P.oidx)[(size_t)(m < P.M ? m : P.M - 1) * P.S + c];
+        const u32x2_a8 e2 = *(const u32x2_a8*)(as_global(P.ocent) + (size_t)oi * 8);
+        w2[2 * r] = e2[0]; w2[2 * r + 1] = e2[1];
+      }
+    }
     if (has_norm) {
       const uint32_t s2 = splat16(as_global(P.scale)[c]), b2 = splat16(as_global(P.wbias)[c]);
 #pragma unroll
@@ -208,7 +238,7 @@ __global__ __launch_bounds__(kXThreads) void gemv_gatherx_kernel(const GatherXPa
         ri[e] = (v >> P.ib) * (uint32_t)(V * 2);
       }
       // all gathers of the piece first (V = 16: two elements at a time), then the arithmetic
-      constexpr int GB = V == 8 ? 4 : 2;  // (4 for the wider entries too: no gain, 64 more registers)
+      constexpr int GB = V <= 8 ? 4 : 2;  // (4 for the wider entries too: no gain, 64 more registers)
 #pragma unroll
       for (int e0 = 0; e0 < E; e0 += GB) {
         uint32_t cv[GB][VW], rv[GB][VW];
@@ -268,20 +298,30 @@ __global__ __launch_bounds__(kXThreads) void gemv_gatherx_kernel(const GatherXPa
 }
 
 // ---- host side -------------------------------------------------------------------
+// codebook entries are 2 v bytes: the alignment the entry loads of load_entry<v> assume
+static int entry_align(int v) { return v == 8 || v == 16 ? 16 : (v == 4 || v == 12) ? 8 : 4; }
+
 bool gemv_gatherx_eligible(const VptqLayerDesc& d, int tokens) {
   const int v = d.vector_len;
   const bool norm = d.weight_scale != nullptr && d.weight_bias != nullptr;
   const bool outl = d.outlier_size > 0;
-  if (outl && (d.outlier_vector_len != v || (d.outlier_size % kXE) != 0 || !d.outlier_indices || !d.outlier_centroids ||
-               d.num_outlier_indices != d.num_indices || (((uintptr_t)d.outlier_centroids) & (v == 12 ? 7 : 15)) != 0 ||
-               (((uintptr_t)d.outlier_indices) & 1) != 0))
-    return false;
-  return (v == 8 || v == 12 || v == 16) && d.num_codebooks >= 1 && (d.group_size % kXE) == 0 &&
+  const bool vlen = v == 2 || v == 4 || v == 6 || v == 8 || v == 10 || v == 12 || v == 16;
+  if (!vlen) return false;
+  if (outl) {
+    const int ov = d.outlier_vector_len;
+    const bool same = ov == v && d.num_outlier_indices == d.num_indices;
+    const bool four = ov == 4 && v > 4 && (v % 4) == 0 && d.num_outlier_indices >= 1 &&
+                      (long long)d.num_outlier_indices * 4 >= d.out_features;
+    if (!(same || four) || (d.outlier_size % kXE) != 0 || !d.outlier_indices || !d.outlier_centroids ||
+        (((uintptr_t)d.outlier_centroids) & (entry_align(ov) - 1)) != 0 || (((uintptr_t)d.outlier_indices) & 1) != 0)
+      return false;
+  }
+  return d.num_codebooks >= 1 && (d.group_size % kXE) == 0 &&
          d.in_features == d.outlier_size + d.num_codebooks * d.group_size && d.index_bits + d.res_bits <= 32 &&
          (long long)d.row_words * 32 >= (long long)d.group_size * (d.index_bits + d.res_bits) &&
          d.num_indices * v >= d.out_features && tokens >= 1 && tokens <= 4 &&
          (d.perm == nullptr || !norm || (d.scale_permuted != nullptr && d.bias_permuted != nullptr)) &&
-         (((uintptr_t)d.centroids | (uintptr_t)d.res_centroids) & (v == 12 ? 7 : 15)) == 0 &&
+         (((uintptr_t)d.centroids | (uintptr_t)d.res_centroids) & (entry_align(v) - 1)) == 0 &&
          (((uintptr_t)d.indices | (uintptr_t)d.weight_scale | (uintptr_t)d.weight_bias |
            (uintptr_t)d.scale_permuted | (uintptr_t)d.bias_permuted | (uintptr_t)d.perm) & 3) == 0;
 }
@@ -303,6 +343,20 @@ static hipError_t launch_xv(const GatherXParams& P, bool perm, hipStream_t st) {
   return launch_x<DT, V, 4>(P, perm, st);
 }
 
+template <typename DT>
+static hipError_t launch_xdt(const GatherXParams& P, int v, bool perm, hipStream_t st) {
+  switch (v) {
+    case 2: return launch_xv<DT, 2>(P, perm, st);
+    case 4: return launch_xv<DT, 4>(P, perm, st);
+    case 6: return launch_xv<DT, 6>(P, perm, st);
+    case 8: return launch_xv<DT, 8>(P, perm, st);
+    case 10: return launch_xv<DT, 10>(P, perm, st);
+    case 12: return launch_xv<DT, 12>(P, perm, st);
+    case 16: return launch_xv<DT, 16>(P, perm, st);
+    default: return hipErrorInvalidValue;
+  }
+}
+
 hipError_t launch_gemv_gatherx(const VptqLayerDesc& d, const void* x, void* y, int tokens, bool out_f32,
                                hipStream_t st) {
   GatherXParams P;
@@ -319,6 +373,8 @@ hipError_t launch_gemv_gatherx(const VptqLayerDesc& d, const void* x, void* y, i
   P.oidx = d.outlier_size > 0 ? (const uint16_t*)d.outlier_indices : nullptr;
   P.ocent = d.outlier_size > 0 ? (const char*)d.outlier_centroids : nullptr;
   P.S = d.outlier_size;
+  P.ov = d.outlier_size > 0 ? d.outlier_vector_len : 0;
+  P.M = d.outlier_size > 0 ? d.num_outlier_indices : 0;
   P.N = d.num_indices; P.G = d.group_size; P.C = d.num_codebooks; P.I = d.in_features; P.O = d.out_features;
   P.row_words = d.row_words;
   P.k = d.num_centroids; P.kr = d.num_res_centroids; P.ib = d.index_bits; P.rb = d.res_bits;
@@ -329,11 +385,7 @@ hipError_t launch_gemv_gatherx(const VptqLayerDesc& d, const void* x, void* y, i
   P.res_lds = (res_bytes > 0 && res_bytes <= kXResLdsMax && (res_bytes % 16) == 0) ? 1 : 0;
   const bool perm = d.perm != nullptr;
   const int v = d.vector_len;
-  if (d.dtype == VPTQ_DTYPE_F16)
-    return v == 8 ? launch_xv<F16, 8>(P, perm, st) : v == 12 ? launch_xv<F16, 12>(P, perm, st)
-                                                             : launch_xv<F16, 16>(P, perm, st);
-  return v == 8 ? launch_xv<BF16, 8>(P, perm, st) : v == 12 ? launch_xv<BF16, 12>(P, perm, st)
-                                                            : launch_xv<BF16, 16>(P, perm, st);
+  return d.dtype == VPTQ_DTYPE_F16 ? launch_xdt<F16>(P, v, perm, st) : launch_xdt<BF16>(P, v, perm, st);
 }
 
 }  // namespace vptq
