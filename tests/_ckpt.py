@@ -59,3 +59,21 @@ def write_tiny_checkpoint(path, hidden=256, inter=512, layers=2, heads=4, kv_hea
     with open(os.path.join(path, "config.json"), "w") as f:
         json.dump(cd, f)
     return state, per_layer
+
+
+def write_tiny_tokenizer(path, vocab=320, chat_template=True):
+    """A word-level tokenizer of `vocab` entries (w0, w1, ... + specials) saved the Hugging Face way
+    (tokenizer.json + tokenizer_config.json), optionally with a minimal chat template."""
+    from tokenizers import Tokenizer, models, pre_tokenizers
+    from transformers import PreTrainedTokenizerFast
+    specials = ["<unk>", "<s>", "</s>", "<|system|>", "<|user|>", "<|assistant|>"]
+    words = specials + [f"w{i}" for i in range(vocab - len(specials))]
+    tok = Tokenizer(models.WordLevel({w: i for i, w in enumerate(words)}, unk_token="<unk>"))
+    tok.pre_tokenizer = pre_tokenizers.WhitespaceSplit()
+    fast = PreTrainedTokenizerFast(tokenizer_object=tok, unk_token="<unk>", bos_token="<s>", eos_token="</s>",
+                                   pad_token="</s>")
+    if chat_template:
+        fast.chat_template = ("{% for m in messages %}<|{{ m['role'] }}|> {{ m['content'] }} {% endfor %}"
+                              "{% if add_generation_prompt %}<|assistant|> {% endif %}")
+    fast.save_pretrained(path)
+    return fast

@@ -1265,3 +1265,36 @@ def test_hf_from_pretrained_vptq_route(dev, tmp_path):
         ga = model.generate(ids, max_new_tokens=8, do_sample=False)
         gb = own.generate(ids, max_new_tokens=8, do_sample=False)
         assert ga.shape == (1, 13) and (ga == gb).float().mean().item() >= 0.9
+
+
+# ---------------------------------------------------------------- `python -m vptq`
+def test_command_line_prompt_and_chat(dev, tmp_path, capsys):
+    """The reference's command line (vptq/app_utils.py:56-110, 165-189) on a synthetic checkpoint with a
+    word-level tokenizer: a prompt completion (100 greedy tokens, streamed) equals `generate` on this
+    package's loader, and a scripted two-turn chat goes through the tokenizer's chat template."""
+    import vptq_amd
+    import vptq_amd.app_utils as app
+    from _ckpt import write_tiny_checkpoint, write_tiny_tokenizer
+    write_tiny_checkpoint(str(tmp_path), perm=False)
+    tok = write_tiny_tokenizer(str(tmp_path))
+    out = app.main(["--model", str(tmp_path), "--prompt", "w1 w2 w3 w4"])
+    text = capsys.readouterr().out
+    assert out.shape == (1, 4 + 100) and "w1 w2 w3 w4" in text
+    model = vptq_amd.AutoModelForCausalLM.from_pretrained(str(tmp_path), device=str(dev))
+    ids = tok("w1 w2 w3 w4", return_tensors="pt").input_ids.to(dev)
+    want = model.generate(ids, max_new_tokens=100, do_sample=False, pad_token_id=2)
+    assert (out[:, :want.shape[1]].cpu() == want.cpu()).float().mean().item() >= 0.9
+    assert any(isinstance(m, vptq_amd.VQuantLinear) for m in model.modules())
+    # chat: scripted input, two turns, then `exit`
+    lines = iter(["w10 w11", "w12", "exit"])
+    args = app.define_basic_args().parse_args(["--model", str(tmp_path), "--chat", "--chat-system-prompt", "w9"])
+    torch.manual_seed(0)
+    history = app.chat_loop(model, tok, args, read=lambda prompt: next(lines))
+    roles = [m["role"] for m in history]
+    assert roles == ["system", "user", "assistant", "user", "assistant"], roles
+    assert history[0]["content"] == "w9" and history[3]["content"] == "w12"
+    assert "Press 'exit' to quit" in capsys.readouterr().out
+    # a tokenizer without a chat template falls back to the prompt completion
+    tok.chat_template = None
+    out2 = app.chat_loop(model, tok, args)
+    assert out2.shape[1] > 1 and "no chat_template" in capsys.readouterr().out

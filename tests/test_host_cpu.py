@@ -393,3 +393,38 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 src = open(os.path.join(dp, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_command_line_options_match_the_reference():
+    """`python -m vptq`: same options and defaults as the reference's parser (vptq/app_utils.py:17-53);
+    compared live when the reference is mounted, against its documented set otherwise."""
+    import importlib.util
+    import sys
+    import vptq_amd.app_utils as app
+    # other tests may have imported the REFERENCE under the name `vptq`
+    saved = {k: sys.modules.pop(k) for k in list(sys.modules) if k == "vptq" or k.startswith("vptq.")}
+    try:
+        import vptq
+        assert vptq.__file__.startswith(ROOT)
+        assert vptq.app_utils is app and importlib.util.find_spec("vptq.__main__") is not None
+    finally:
+        for k in [k for k in sys.modules if k == "vptq" or k.startswith("vptq.")]:
+            del sys.modules[k]
+        sys.modules.update(saved)
+    want = {"model": None, "tokenizer": "", "prompt": "once upon a time, there ", "chat": False,
+            "chat_system_prompt": "you are a math teacher."}
+    ours = {a.dest: a.default for a in app.define_basic_args()._actions if a.dest != "help"}
+    assert ours == want
+    ref_file = "/root/reference/vptq/app_utils.py"
+    if os.path.exists(ref_file):
+        import re
+        src = open(ref_file).read()
+        flags = set(re.findall(r'"(--[a-z-]+)"', src))
+        mine = {s for a in app.define_basic_args()._actions for s in a.option_strings if s.startswith("--")}
+        assert flags == mine - {"--help"}, (flags, mine)
+    ns = app.define_basic_args().parse_args(["--model", "m", "--chat", "--chat-system-prompt", "s"])
+    assert ns.model == "m" and ns.chat and ns.chat_system_prompt == "s" and ns.tokenizer == ""
+    with pytest.raises(SystemExit):
+        app.define_basic_args().parse_args([])      # --model is required
+    for fn in ("define_basic_args", "eval_prompt", "chat_loop", "get_chat_loop_generator", "get_valid_args", "main"):
+        assert callable(getattr(app, fn))

@@ -7,12 +7,14 @@ import sys
 import vptq_amd
 from vptq_amd import AutoModelForCausalLM, VQuantLinear, __version__, ops  # noqa: F401
 from vptq_amd import layers, utils  # noqa: F401
+from vptq_amd import app_utils  # noqa: F401
 
 import vptq_amd.layers.model_base  # noqa: E402,F401
 import vptq_amd.layers.vqlinear  # noqa: E402,F401
 import vptq_amd.ops.quant_gemm  # noqa: E402,F401
 import vptq_amd.utils.pack  # noqa: E402,F401
 import vptq_amd.utils.shard  # noqa: E402,F401
+import vptq_amd.app_utils  # noqa: E402,F401
 
 # Every module of the package under its reference name, leaves included: without the leaves
 # `from vptq.layers.vqlinear import VQuantLinear` (the reference's canonical import path)
