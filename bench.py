@@ -238,15 +238,38 @@ class Timer:
             one_pass()
             torch.cuda.synchronize()
             captured = True
+            # gloo collectives (VPTQ_BENCH_SAME_GPU test runs) cannot be captured, and a refused capture
+            # leaves this ROCm runtime unusable (the recovery below segfaulted in 2 of 2 trials): do not try.
+            # VPTQ_BENCH_NO_GRAPH=1 forces eager launches for a backend that turns out to refuse as well.
+            no_graph = os.environ.get("VPTQ_BENCH_NO_GRAPH") == "1" or \
+                (dist is not None and dist.get_backend() == "gloo")
             try:
+                if no_graph and self.allow_eager:
+                    raise RuntimeError("capture skipped")
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph, stream=self.stream):
                     one_pass()
-            except Exception:
+            except Exception as e:
                 if not self.allow_eager:
                     raise
                 captured, graph = False, _Eager()  # collectives that refuse capture: eager launches
+                print(f"[bench] hipGraph capture refused ({type(e).__name__}); eager launches", file=sys.stderr, flush=True)
+        if not captured and not no_graph:
+            # The failed capture leaves (a) its error as the runtime's "last error" - the next launch check,
+            # this library's and torch's alike, would report it - and (b) the capture stream invalidated:
+            # consume the one, continue on a fresh stream.
+            import ctypes
+            hip = ctypes.CDLL("libamdhip64.so")
+            for _ in range(4):
+                if hip.hipGetLastError() == 0:
+                    break
+            try:
                 torch.cuda.synchronize()
+            except Exception:
+                pass
+            hip.hipGetLastError()
+            self.stream = torch.cuda.Stream(device=self.dev)
+        with torch.cuda.stream(self.stream):
             for _ in range(warmup):
                 graph.replay()
             for _ in range(regions):
@@ -452,12 +475,21 @@ def main():
     if world != a.gpus and world == 1 and a.gpus > 1:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     assert torch.cuda.is_available(), "bench.py needs a GPU"
+    # VPTQ_BENCH_SAME_GPU=1 (test knob, tools/gpu_bench_2ranks.sh): every rank on GPU 0 with gloo collectives, so
+    # that the N > 1 code path (shards by rank, collectives inside the timed region, parity of the reduced
+    # result, max over ranks) runs end to end on a one-GPU box.  The numbers of such a run mean nothing.
+    same_gpu = os.environ.get("VPTQ_BENCH_SAME_GPU") == "1"
+    if same_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if same_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     mode = a.mode
     if mode == "auto":
         mode = "single" if world == 1 else "tp_row"
