@@ -469,6 +469,16 @@ def main():
     ap.add_argument("--prefetch", action="store_true")
     a = ap.parse_args()
 
+    # stdout carries exactly ONE line, the JSON: everything else written to file descriptor 1 - RCCL prints
+    # its version banner there, hipBLASLt / MIOpen may warn - goes to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(obj) + "\n").encode())
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -533,7 +543,7 @@ def main():
                                    "value": w["value"], "unit": "GB/s", "us_per_launch": w["us_per_launch"],
                                    "scaling": "weak"}
         if rank == 0:
-            print(json.dumps(out))
+            emit(out)
         if dist is not None:
             dist.destroy_process_group()
         return
@@ -617,7 +627,7 @@ def main():
         ex["llama3_8b_decode"] = model_decode_extra()
         out["extras"] = ex
     if rank == 0:
-        print(json.dumps(out))
+        emit(out)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -614,6 +614,9 @@ def test_loader_end_to_end_vs_dense_model(dev, tmp_path):
 V2_CONFIGS = [
     dict(in_features=1024, out_features=2048, num_centroids=8192, num_res_centroids=256),  # uint8 ids
     dict(in_features=1024, out_features=1024, num_centroids=8192, num_res_centroids=512),  # uint16 ids
+    # >= 1024 vector-rows: one token takes the MFMA variant of the LDS-resident kernel (folded form)
+    dict(in_features=1024, out_features=8192, num_centroids=8192, num_res_centroids=256),
+    dict(in_features=2048 + 64, out_features=8192 + 8 * 3, num_centroids=4096, num_res_centroids=512),
 ]
 
 
@@ -634,8 +637,8 @@ def test_quant_gemv_v2_reference_test_shapes(cfg, dtype, dev):
     x, cent, rcent = nrm(1, 1, I), nrm(1, k, v), nrm(1, kr, v)
     sw, sb = nrm(I, 1), nrm(I, 1)
     n = I * O // v
-    ids = torch.arange(k, device=dev, dtype=torch.int32).repeat(n // k).to(torch.uint16)
-    rids = torch.arange(kr, device=dev, dtype=torch.int32).repeat(n // kr).to(
+    ids = torch.arange(k, device=dev, dtype=torch.int32).repeat(n // k + 1)[:n].to(torch.uint16)
+    rids = torch.arange(kr, device=dev, dtype=torch.int32).repeat(n // kr + 1)[:n].to(
         torch.uint16 if kr > 256 else torch.uint8)
     out = vptq_amd.ops.quant_gemv_v2(
         x=x, bias=None, indices=ids, centroids=cent, residual_indices=rids,
@@ -975,10 +978,14 @@ def test_lds_resident_kernel_vs_oracle(I, O, kw, tokens, dev):
         else rng.standard_normal((1, tokens, I))
     x = vo.from_f32(xs.astype(np.float32), dt)
     m = spec_to_module(L, dev)
-    assert kernel_name(m, tokens) == "gemv_lds_kernel", kernel_name(m, tokens)
+    # one token on >= 1024 vector-rows: the MFMA variant (folded form); else the reference's roundings
+    folded = tokens == 1 and O >= 8192 and I <= 8192
+    assert kernel_name(m, tokens) == ("gemv_lds_mfma_kernel" if folded else "gemv_lds_kernel"), kernel_name(m, tokens)
     assert kernel_name(m, tokens, GENERIC) == "gemv_generic_kernel"
     if dt == "bf16":   # the reference's roundings for bf16: the L2-gather kernel has them
         assert kernel_name(m, tokens, EXACT) == "gemv_gatherx_kernel"
+    else:
+        assert kernel_name(m, tokens, EXACT) == "gemv_lds_kernel"
     xt = bits_to_tensor(x, dt, dev).reshape(x.shape)
     if I * O <= 4096 * 4096:
         W_ref = vo.dequant(L, ref_residual_mask_quirk=False)
@@ -991,12 +998,66 @@ def test_lds_resident_kernel_vs_oracle(I, O, kw, tokens, dev):
     err = rel_err(got, want, dt)
     assert err <= TOL[dt], f"{err:.3e}"
     if dt == "f16":
-        assert bit_identical_frac(got, want) >= 0.95
+        ex = tensor_to_bits(gemv_abi(m, xt, EXACT))
+        assert bit_identical_frac(ex, want) >= 0.95
+        if not folded or (module_flags() & EXACT):
+            assert bit_identical_frac(got, want) >= 0.95
     # same as the generic kernel (the A/B partner) and as fp32 output rounded once
     gen = tensor_to_bits(gemv_abi(m, xt, GENERIC))
     assert rel_err(got, gen, dt) <= TOL[dt]
     from vptq_amd.utils.shard import forward_partial_f32
     assert torch.equal(forward_partial_f32(m, xt).to(xt.dtype), m(xt))
+
+
+LDS_MFMA_CASES = [
+    # I, O, kwargs: one token, >= 1024 vector-rows -> gemv_lds_mfma_kernel (folded form, MFMA accumulate)
+    (1024, 8192, dict(num_centroids=4096, num_res_centroids=0)),                                 # T = 12, no residual
+    (1000, 8200, dict(num_centroids=8192, num_res_centroids=0, bias=True)),                      # T = 13, ragged step, spare rows
+    (2048, 8192, dict(num_centroids=4096, num_res_centroids=256, dist="llm", enable_perm=True)),  # T = 20, permutation
+    (520, 8192 + 16, dict(num_centroids=4096, num_res_centroids=512, enable_perm=True, bias=True)),  # T = 21 as 12 + 9
+    (4096, 8192, dict(num_centroids=8192, num_res_centroids=512, dist="llm")),                   # T = 22
+    (512, 16384, dict(num_centroids=1024, num_res_centroids=4, enable_norm=False)),              # no norm, 8 rows per group
+    (256, 8 * 4096 + 24, dict(num_centroids=4096, num_res_centroids=256, dist="llm", bias=True)),  # 16 rows per group, spare rows
+    (8192 + 2048, 8192, dict(num_centroids=4096, num_res_centroids=256, dist="llm")),            # two staging passes
+    (1024, 8192, dict(num_centroids=8192, num_res_centroids=256, dtype="bf16", dist="llm")),
+    (776, 8192 + 8, dict(num_centroids=4096, num_res_centroids=512, dtype="bf16", dist="llm", enable_perm=True, bias=True)),
+]
+
+
+@pytest.mark.parametrize("I,O,kw", LDS_MFMA_CASES)
+def test_lds_resident_mfma_kernel_vs_oracle(I, O, kw, dev):
+    """gemv_lds_mfma_kernel: one token in the default (folded) arithmetic with the multiply-accumulate on
+    the matrix pipe, codebooks LDS-resident, f16(s x) staged; against the oracle (<= 1e-3 / 8e-3), the
+    kernel with the reference's roundings (VPTQ_GEMV_EXACT), the generic kernel; deterministic; fp32 output."""
+    kw = dict(kw)
+    dist = kw.pop("dist", "ref-test")
+    L = vo.make_layer(I, O, dist=dist, seed=I + O + 5, **kw)
+    dt = L.dtype
+    rng = np.random.default_rng(23)
+    xs = (0.02 + 0.5 * rng.standard_normal((1, 1, I))) if dist == "ref-test" else rng.standard_normal((1, 1, I))
+    x = vo.from_f32(xs.astype(np.float32), dt)
+    m = spec_to_module(L, dev)
+    assert kernel_name(m, 1) == "gemv_lds_mfma_kernel", kernel_name(m, 1)
+    assert kernel_name(m, 2) == "gemv_lds_kernel"
+    xt = bits_to_tensor(x, dt, dev).reshape(x.shape)
+    from oracle import c_oracle as co
+    want = co.forward(L, x, quirk=False)
+    got = tensor_to_bits(gemv_abi(m, xt, 0))
+    err = rel_err(got, want, dt)
+    assert err <= TOL[dt], f"{err:.3e}"
+    gen = tensor_to_bits(gemv_abi(m, xt, GENERIC))
+    assert rel_err(got, gen, dt) <= TOL[dt]
+    if dt == "f16":
+        ex = tensor_to_bits(gemv_abi(m, xt, EXACT))
+        assert bit_identical_frac(ex, want) >= 0.95 and rel_err(got, ex, dt) <= TOL[dt]
+    outs = [tensor_to_bits(gemv_abi(m, xt, 0)) for _ in range(3)]
+    assert all((o == got).all() for o in outs)
+    from vptq_amd import _backend as B
+    y32 = torch.empty(1, 1, O, dtype=torch.float32, device=dev)
+    desc, keep = module_desc(m)
+    B.check(B.lib().vptq_quant_gemv(desc, xt.data_ptr(), y32.data_ptr(), 1, B.GEMV_OUT_F32, None, 0,
+                                    B.current_stream_ptr(dev)), "vptq_quant_gemv")
+    assert (tensor_to_bits(y32.to(xt.dtype)) == got).all()
 
 
 def test_lds_kernel_golden_and_determinism(dev):

@@ -133,6 +133,10 @@ def test_format_routing_without_gpu():
     assert name(_format_desc(8, 65536, 0)) == name(_format_desc(8, 65536, 256)) == \
         name(_format_desc(8, 65536, 65536)) == b"gemv_gather_kernel"
     assert name(_format_desc(8, 8192, 256)) == name(_format_desc(8, 4096, 512)) == b"gemv_lds_kernel"
+    # ... one token in the default arithmetic on >= 1024 vector-rows: its MFMA variant (folded form)
+    big = _format_desc(8, 8192, 256, I=8192, O=8192)
+    assert name(big) == b"gemv_lds_mfma_kernel" and name(big, 2) == name(big, 1, B.GEMV_EXACT) == b"gemv_lds_kernel"
+    assert name(_format_desc(8, 8192, 256, I=16384, O=8192)) == b"gemv_lds_kernel"   # no LDS left for the activations
     for v, k, kr in ((16, 65536, 65536), (16, 65536, 32768), (16, 65536, 1024), (16, 65536, 0),
                      (12, 65536, 4096), (8, 65536, 1024), (8, 32768, 0), (8, 16384, 16384), (8, 8192, 1024),
                      (16, 256, 256), (8, 256, 0)):

@@ -111,7 +111,7 @@ const char* vptq_quant_gemv_kernel_name(const VptqLayerDesc* d, int tokens, int 
   if (!(flags & VPTQ_GEMV_FORCE_GENERIC) && vptq::gemv_gather_eligible(*d, tokens > 4 ? 4 : tokens))
     return "gemv_gather_kernel";
   if (!(flags & VPTQ_GEMV_FORCE_GENERIC) && vptq::gemv_lds_eligible(*d, tokens > 4 ? 4 : tokens, flags))
-    return "gemv_lds_kernel";
+    return vptq::gemv_lds_name(*d, tokens, flags);
   if (!(flags & VPTQ_GEMV_FORCE_GENERIC) && vptq::gemv_gatherx_eligible(*d, tokens > 4 ? 4 : tokens))
     return "gemv_gatherx_kernel";
   return "gemv_generic_kernel";
@@ -188,10 +188,12 @@ int vptq_quant_gemv(const VptqLayerDesc* d, const void* x, void* y, int tokens, 
   if (!(flags & VPTQ_GEMV_FORCE_GENERIC) && vptq::gemv_lds_eligible(*d, chunk, flags) &&
       (((uintptr_t)x) & 15) == 0) {
     const int step = vptq::gemv_lds_max_chunk(d->dtype);
+    // every token of one call in the same arithmetic: the one-token MFMA form only for one-token calls
+    const int lflags = tokens > 1 ? (flags | VPTQ_GEMV_EXACT) : flags;
     for (int t0 = 0; t0 < tokens; t0 += step) {
       const int m = tokens - t0 < step ? tokens - t0 : step;
       e = vptq::launch_gemv_lds(*d, (const char*)x + (size_t)t0 * d->in_features * 2,
-                                (char*)y + (size_t)t0 * d->out_features * yes, m, out_f32, st);
+                                (char*)y + (size_t)t0 * d->out_features * yes, m, out_f32, lflags, st);
       if (e != hipSuccess) return hip_fail(e, "gemv_lds launch");
     }
     return VPTQ_OK;
@@ -327,11 +329,12 @@ int vptq_quant_gemv_v2(const VptqV2Desc* d, const void* x, void* y, int tokens, 
       (((uintptr_t)x) & 15) == 0) {
     // codebooks LDS-resident (what the reference's kernel does, quant_gemv_v2.cuh:85-94)
     const int step = vptq::gemv_lds_max_chunk(d->dtype);
+    const int lflags = tokens > 1 ? (flags | VPTQ_GEMV_EXACT) : flags;
     for (int t0 = 0; t0 < tokens; t0 += step) {
       const int m = tokens - t0 < step ? tokens - t0 : step;
       hipError_t e = vptq::launch_gemv_lds_v2(*d, (const char*)x + (size_t)t0 * d->in_features * es,
                                               (char*)y + (size_t)t0 * d->out_features * (out_f32 ? 4 : es),
-                                              m, out_f32, st);
+                                              m, out_f32, lflags, st);
       if (e != hipSuccess) return hip_fail(e, "gemv_lds (v2) launch");
     }
     return VPTQ_OK;

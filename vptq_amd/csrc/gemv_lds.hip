@@ -399,6 +399,232 @@ __global__ __launch_bounds__(kLThreads) void gemv_lds_kernel(const LdsParams P) 
   }
 }
 
+// ---- one token, folded form, MFMA accumulate ---------------------------------------------
+// The kernel above spends ~37 VALU instructions per index in the reference's roundings (PMC: VALU
+// busy 73 % of the launch, LDS 24 %).  One token in the default arithmetic takes the route of
+// gemv_k256m.hip instead:
+//   y = sum_g (c + r) * f16(s_g x_g) + sum_g b_g x_g + bias        (fp32 accumulation)
+// with the multiply-accumulate on the matrix pipe: lane = (column chunk blk = lane >> 2, vector-row
+// j = lane & 3); v_mfma_f32_4x4x4 with X = x' * e_j and W = the gathered halves accumulates x' times
+// the lane's own four weights (16 independent blocks; gemv_k256m.hip's file comment).  f16(s x) is
+// staged in LDS once per workgroup behind the codebooks (2 bytes per column), sum b x is computed
+// once.  Per index: the address arithmetic, two operand perms and 4 (no residual: 2) MFMAs.
+// Needs row groups of >= 4 vector-rows (N >= 4 x CUs) and LDS for the staged activations; VPTQ_GEMV_EXACT,
+// 2-4 tokens and smaller layers keep the kernel above.
+constexpr int kLMCols = 128;       // columns per wave step: 16 chunks of 8
+constexpr int kLMStageIt = 4;      // staging passes of 8192 columns (G <= 32768)
+
+static int lds_mfma_bytes(int k, int kr, int G) {
+  return (k + kr) * 16 + G * 2 + 16 + (kLWaves * 32 + kLWaves + 16) * 4;
+}
+
+template <typename DT, int FMT>
+__global__ __launch_bounds__(kLThreads) void gemv_lds_mfma_kernel(const LdsParams P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lsmem[];
+  {
+    typedef __attribute__((address_space(3))) unsigned char lds_u8_t;
+    if ((uint32_t)(uintptr_t)(lds_u8_t*)lsmem != 0u) __builtin_trap();  // absolute LDS addressing
+  }
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 3, blk = lane >> 2;
+  const int G = P.G, N = P.N, O = P.O;
+  const bool has_res = P.kr > 0;
+
+  // LDS map: main table | residual table | f16(s x): G halves + 8 zeros | red[kLWaves][32] | bdot[kLWaves] | bsum
+  const uint32_t res_base = (uint32_t)P.k * 16u;
+  const uint32_t xs_off = res_base + (uint32_t)P.kr * 16u;
+  const uint32_t red_off = xs_off + (uint32_t)G * 2u + 16u;
+  float* const red = (float*)(lsmem + red_off);
+  float* const bdot_w = red + kLWaves * 32;
+  float* const bsum = bdot_w + kLWaves;
+
+  // row groups of RW = 4 * sets vector-rows; the 16 / sets waves of a set take interleaved steps of
+  // 128 columns
+  const int RW = P.RW;
+  const int sets = RW >> 2;
+  const int PW = kLWaves / sets;
+  const int set = wave / PW, part = wave - set * PW;
+  const int n_steps = (G + kLMCols - 1) / kLMCols;
+  // (requesting the first row group's first index window ahead of the prologue, so that its HBM latency
+  // passes while the codebooks are copied, changed nothing: +-0.3 us either way over four formats)
+  // ---- prologue: codebooks into LDS (4 entries per thread in flight), activations staged
+  {
+    const int total = P.k + P.kr;
+    for (int i0 = tid; i0 < total; i0 += 4 * kLThreads) {
+      u32x4 e[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * kLThreads;
+        const int ic = i < total ? i : total - 1;
+        const uint32_t* src = ic < P.k ? P.cent + (size_t)ic * 4 : P.rcent + (size_t)(ic - P.k) * 4;
+        e[u] = *(const u32x4*)as_global(src);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * kLThreads;
+        if (i < total) lds_store16((uint32_t)i * 16u, e[u]);
+      }
+    }
+  }
+  {
+    // sum b x in input-feature order; x' = f16(s x) in COLUMN order (perm: x parked in LDS in its own
+    // order first, gathered through the permutation from there - 8192 scattered 2-byte global loads
+    // per workgroup cost microseconds)
+    float accb = 0.f;
+    u32x4 xv[kLMStageIt];
+#pragma unroll
+    for (int it = 0; it < kLMStageIt; ++it) {
+      const int c = (it * kLThreads + tid) * 8;
+      if (c < G) {
+        xv[it] = *(const u32x4*)as_global(P.x + c);
+        if (P.wbias_plain) {
+          const u32x4 bv = *(const u32x4*)as_global(P.wbias_plain + c);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) accb = DT::dot2(xv[it][q], bv[q], accb);
+        }
+      }
+    }
+    if (P.perm) {
+#pragma unroll
+      for (int it = 0; it < kLMStageIt; ++it) {
+        const int c = (it * kLThreads + tid) * 8;
+        if (c < G) lds_store16(xs_off + (uint32_t)c * 2u, xv[it]);
+      }
+      __syncthreads();
+      typedef __attribute__((address_space(3))) const uint16_t lds_u16_t;
+#pragma unroll
+      for (int it = 0; it < kLMStageIt; ++it) {
+        const int c = (it * kLThreads + tid) * 8;
+        if (c < G) {
+          const u32x4 pv = *(const u32x4*)as_global(P.perm + c);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const uint32_t lo = *(lds_u16_t*)(uintptr_t)(xs_off + (pv[q] & 0xffffu) * 2u);
+            const uint32_t hi = *(lds_u16_t*)(uintptr_t)(xs_off + (pv[q] >> 16) * 2u);
+            xv[it][q] = lo | (hi << 16);
+          }
+        }
+      }
+      __syncthreads();   // every thread has its activations: the area may be overwritten
+    }
+#pragma unroll
+    for (int it = 0; it < kLMStageIt; ++it) {
+      const int c = (it * kLThreads + tid) * 8;
+      if (c < G) {
+        u32x4 v = xv[it];
+        if (P.scale) {
+          const u32x4 sv = *(const u32x4*)as_global(P.scale + c);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = DT::mul2(v[q], sv[q]);
+        }
+        lds_store16(xs_off + (uint32_t)c * 2u, v);
+      }
+    }
+    if (tid == 0) lds_store16(xs_off + (uint32_t)G * 2u, u32x4{0, 0, 0, 0});  // the operand of columns past G
+    const float sb = wave_sum(accb);
+    if (lane == 0) bdot_w[wave] = sb;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float sb = 0.f;
+    for (int w = 0; w < kLWaves; ++w) sb += bdot_w[w];
+    bsum[0] = sb;
+  }
+
+  // x operand of the MFMA: x' * e_j as two packed pairs cut out of a packed x' register
+  const uint32_t selA[2] = {j == 0 ? 0x0c0c0504u : j == 1 ? 0x05040c0cu : 0x0c0c0c0cu,
+                            j == 0 ? 0x0c0c0706u : j == 1 ? 0x07060c0cu : 0x0c0c0c0cu};
+  const uint32_t selB[2] = {j == 2 ? 0x0c0c0504u : j == 3 ? 0x05040c0cu : 0x0c0c0c0cu,
+                            j == 2 ? 0x0c0c0706u : j == 3 ? 0x07060c0cu : 0x0c0c0c0cu};
+
+  for (int rg = blockIdx.x; rg < P.n_groups; rg += gridDim.x) {
+    const int row = rg * RW + set * 4 + j;
+    const int rowc = row < N ? row : N - 1;  // spare rows recompute the last one (not stored)
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+
+    IdxWindow<FMT> nxt;
+    if (part < n_steps) {
+      const int g0 = part * kLMCols + blk * 8;
+      fetch_window<FMT>(nxt, P, rowc, g0 < G ? g0 : G - 8);
+    }
+    for (int st = part; st < n_steps; st += PW) {
+      const IdxWindow<FMT> cur = nxt;
+      const int g0r = st * kLMCols + blk * 8;
+      const bool valid = g0r < G;
+      const int g0 = valid ? g0r : G - 8;     // chunks past G redo the last one against x' = 0
+      const u32x4 xq = lds_load16(xs_off + (uint32_t)(valid ? g0r : G) * 2u);
+      if (st + PW < n_steps) {
+        const int gn = (st + PW) * kLMCols + blk * 8;
+        fetch_window<FMT>(nxt, P, rowc, gn < G ? gn : G - 8);
+      }
+      IdxDecoded<FMT> dec;
+      normalise_window<FMT>(dec, cur, P, rowc, g0);
+      u32x4 cv[8], rv[8];
+      auto gather1 = [&](auto ec) {
+        constexpr int e = decltype(ec)::value;
+        uint32_t am, ar;
+        decode_elem<FMT, e>(dec, P, res_base, am, ar);
+        cv[e] = lds_load16(am);
+        if (has_res) rv[e] = lds_load16(ar);
+      };
+      gather1(std::integral_constant<int, 0>{}); gather1(std::integral_constant<int, 1>{});
+      gather1(std::integral_constant<int, 2>{}); gather1(std::integral_constant<int, 3>{});
+      gather1(std::integral_constant<int, 4>{}); gather1(std::integral_constant<int, 5>{});
+      gather1(std::integral_constant<int, 6>{}); gather1(std::integral_constant<int, 7>{});
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int q = e >> 1, h = e & 1;
+        const u32x2 xo = {__builtin_amdgcn_perm(xq[q], 0u, selA[h]), __builtin_amdgcn_perm(xq[q], 0u, selB[h])};
+        acc0 = DT::mfma4(xo, u32x2{cv[e][0], cv[e][1]}, acc0);
+        acc1 = DT::mfma4(xo, u32x2{cv[e][2], cv[e][3]}, acc1);
+        if (has_res) {
+          acc0 = DT::mfma4(xo, u32x2{rv[e][0], rv[e][1]}, acc0);
+          acc1 = DT::mfma4(xo, u32x2{rv[e][2], rv[e][3]}, acc1);
+        }
+      }
+    }
+    // ---- reduce over the 16 column chunks of the wave: lane bits 5 and 4 by swap-and-add (halving the
+    // values carried), bits 3 and 2 by DPP row rotations, which keep lane & 3; afterwards lane l holds
+    // outputs 4 * bit5 + 2 * bit4 + {0, 1} of vector-row l & 3.  Then over the PW waves of the set.
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[i] = acc0[i]; v[4 + i] = acc1[i]; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 4]), false, false);
+      v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 2]), false, false);
+      v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) v[i] = row_ror_add<4>(row_ror_add<8>(v[i]));
+    if ((lane & 12) == 0) {
+      const int t0 = ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2;
+      red[(wave * 4 + j) * 8 + t0] = v[0];
+      red[(wave * 4 + j) * 8 + t0 + 1] = v[1];
+    }
+    __syncthreads();
+    if (tid < RW * 8) {
+      const int r2 = tid >> 3, i = tid & 7;
+      const int orow = rg * RW + r2;
+      const int o = orow * 8 + i;
+      if (orow < N && o < O) {
+        const int st2 = r2 >> 2, j2 = r2 & 3;
+        float sum = 0.f;
+        for (int p = 0; p < PW; ++p) sum += red[((st2 * PW + p) * 4 + j2) * 8 + i];
+        sum += bsum[0];
+        if (P.bias) sum += DT::to_float(as_global(P.bias)[o]);
+        if (P.out_f32) ((float*)as_global((uint16_t*)P.y))[o] = sum;
+        else as_global((uint16_t*)P.y)[o] = DT::from_float(sum);
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // ---- host side ------------------------------------------------------------------------
 static int lds_cus() {
   static int cus[64] = {};
@@ -410,6 +636,13 @@ static int lds_cus() {
                    ? p.multiProcessorCount : 256;
   }
   return cus[dev];
+}
+
+static int lds_rows_per_group(int N) {
+  const int cus = lds_cus();
+  int RW = kLWaves;
+  while (RW > 1 && (N + RW - 1) / RW < cus) RW >>= 1;
+  return RW;
 }
 
 static int lds_bytes(int k, int kr, int tok) {
@@ -460,18 +693,62 @@ static hipError_t launch_lds_dt(const LdsParams& P, int fmt, int tok, int grid, 
   }
 }
 
+template <typename DT, int FMT>
+static hipError_t launch_lds_mfma_t(const LdsParams& P, int grid, int lds, hipStream_t st) {
+  auto kern = gemv_lds_mfma_kernel<DT, FMT>;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  static bool attr_set[64] = {};
+  if (!attr_set[dev]) {
+    const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kLMaxLds);
+    if (e != hipSuccess) return e;
+    attr_set[dev] = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(kLThreads), lds, st, P);
+  return hipGetLastError();
+}
+
+template <typename DT>
+static hipError_t launch_lds_mfma_dt(const LdsParams& P, int fmt, int grid, int lds, hipStream_t st) {
+  switch (fmt) {
+    case 12: return launch_lds_mfma_t<DT, 12>(P, grid, lds, st);
+    case 13: return launch_lds_mfma_t<DT, 13>(P, grid, lds, st);
+    case 20: return launch_lds_mfma_t<DT, 20>(P, grid, lds, st);
+    case 21: return launch_lds_mfma_t<DT, 21>(P, grid, lds, st);
+    case 22: return launch_lds_mfma_t<DT, 22>(P, grid, lds, st);
+    case kFmtV2None: return launch_lds_mfma_t<DT, kFmtV2None>(P, grid, lds, st);
+    case kFmtV2U8: return launch_lds_mfma_t<DT, kFmtV2U8>(P, grid, lds, st);
+    case kFmtV2U16: return launch_lds_mfma_t<DT, kFmtV2U16>(P, grid, lds, st);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+// one token in the default arithmetic on a layer with row groups of >= 4 vector-rows: the MFMA kernel
+static bool lds_use_mfma(const LdsParams& P, int RW, bool exact) {
+  static int force = -1;   // VPTQ_LDS_KERNEL=valu|mfma (A/B runs)
+  if (force < 0) {
+    const char* ev = getenv("VPTQ_LDS_KERNEL");
+    force = ev && ev[0] == 'v' ? 1 : 0;
+  }
+  return force != 1 && P.tokens == 1 && !exact && RW >= 4 && P.G <= kLMStageIt * kLThreads * 8 &&
+         lds_mfma_bytes(P.k, P.kr, P.G) <= kLMaxLds && (((uintptr_t)P.x | (uintptr_t)P.scale | (uintptr_t)P.wbias_plain | (uintptr_t)P.perm) & 15) == 0;
+}
+
 // common tail: row-group geometry + launch (tokens <= 4 per launch)
-static hipError_t launch_lds(LdsParams& P, int fmt, bool f16, hipStream_t st) {
+static hipError_t launch_lds(LdsParams& P, int fmt, bool f16, bool exact, hipStream_t st) {
   if (!f16 && P.tokens > 2) return hipErrorInvalidValue;  // (bf16: 2 token slots, see gemv_lds_max_chunk)
   const int tok = P.tokens > 2 ? 4 : P.tokens;
   const int lds = lds_bytes(P.k, P.kr, tok);
   if (lds > kLMaxLds || !lds_fmt_ok(fmt)) return hipErrorInvalidValue;
   const int cus = lds_cus();
-  int RW = kLWaves;
-  while (RW > 1 && (P.N + RW - 1) / RW < cus) RW >>= 1;
+  const int RW = lds_rows_per_group(P.N);
   P.RW = RW;
   P.n_groups = (P.N + RW - 1) / RW;
   const int grid = P.n_groups < cus ? P.n_groups : cus;
+  if (lds_use_mfma(P, RW, exact)) {
+    const int ldsm = lds_mfma_bytes(P.k, P.kr, P.G);
+    return f16 ? launch_lds_mfma_dt<F16>(P, fmt, grid, ldsm, st) : launch_lds_mfma_dt<BF16>(P, fmt, grid, ldsm, st);
+  }
   return f16 ? launch_lds_dt<F16>(P, fmt, tok, grid, lds, st) : launch_lds_dt<BF16>(P, fmt, tok, grid, lds, st);
 }
 
@@ -491,8 +768,16 @@ bool gemv_lds_eligible(const VptqLayerDesc& d, int tokens, int flags) {
   return tokens >= 1 && tokens <= 4;
 }
 
+// which of the two kernels a one-call launch of `tokens` tokens takes (host logic, no launch)
+const char* gemv_lds_name(const VptqLayerDesc& d, int tokens, int flags) {
+  LdsParams P = {};
+  P.k = d.num_centroids; P.kr = d.num_res_centroids; P.G = d.group_size; P.tokens = tokens;
+  const bool exact = (flags & VPTQ_GEMV_EXACT) != 0 || tokens > 1;
+  return lds_use_mfma(P, lds_rows_per_group(d.num_indices), exact) ? "gemv_lds_mfma_kernel" : "gemv_lds_kernel";
+}
+
 hipError_t launch_gemv_lds(const VptqLayerDesc& d, const void* x, void* y, int tokens, bool out_f32,
-                           hipStream_t st) {
+                           int flags, hipStream_t st) {
   LdsParams P = {};
   P.idx = (const uint32_t*)d.indices;
   P.ridx = nullptr;
@@ -509,7 +794,7 @@ hipError_t launch_gemv_lds(const VptqLayerDesc& d, const void* x, void* y, int t
   P.N = d.num_indices; P.G = d.group_size; P.O = d.out_features; P.row_words = d.row_words;
   P.k = d.num_centroids; P.kr = d.num_res_centroids; P.ib = d.index_bits; P.rb = d.res_bits;
   P.tokens = tokens; P.out_f32 = out_f32 ? 1 : 0;
-  return launch_lds(P, d.index_bits + d.res_bits, d.dtype == VPTQ_DTYPE_F16, st);
+  return launch_lds(P, d.index_bits + d.res_bits, d.dtype == VPTQ_DTYPE_F16, (flags & VPTQ_GEMV_EXACT) != 0, st);
 }
 
 bool gemv_lds_v2_eligible(const VptqV2Desc& d, int tokens) {
@@ -522,7 +807,7 @@ bool gemv_lds_v2_eligible(const VptqV2Desc& d, int tokens) {
 }
 
 hipError_t launch_gemv_lds_v2(const VptqV2Desc& d, const void* x, void* y, int tokens, bool out_f32,
-                              hipStream_t st) {
+                              int flags, hipStream_t st) {
   LdsParams P = {};
   P.idx = (const uint32_t*)d.indices;
   P.ridx = d.num_res_centroids > 0 ? d.res_indices : nullptr;
@@ -540,7 +825,7 @@ hipError_t launch_gemv_lds_v2(const VptqV2Desc& d, const void* x, void* y, int t
   P.ib = 16; P.rb = 0;
   P.tokens = tokens; P.out_f32 = out_f32 ? 1 : 0;
   const int fmt = d.num_res_centroids <= 0 ? kFmtV2None : d.res_index_bytes == 1 ? kFmtV2U8 : kFmtV2U16;
-  return launch_lds(P, fmt, d.dtype == VPTQ_DTYPE_F16, st);
+  return launch_lds(P, fmt, d.dtype == VPTQ_DTYPE_F16, (flags & VPTQ_GEMV_EXACT) != 0, st);
 }
 
 }  // namespace vptq

@@ -34,11 +34,13 @@ hipError_t launch_gemv_gatherx(const VptqLayerDesc& d, const void* x, void* y, i
 // packed bit stream (T in {12, 13, 20, 21, 22}) or the v2 wire format
 bool gemv_lds_eligible(const VptqLayerDesc& d, int tokens, int flags);
 int gemv_lds_max_chunk(int dtype);
+const char* gemv_lds_name(const VptqLayerDesc& d, int tokens, int flags);
+// flags: VPTQ_GEMV_EXACT keeps one-token launches on the kernel with the reference's roundings
 hipError_t launch_gemv_lds(const VptqLayerDesc& d, const void* x, void* y, int tokens, bool out_f32,
-                           hipStream_t st);
+                           int flags, hipStream_t st);
 bool gemv_lds_v2_eligible(const VptqV2Desc& d, int tokens);
 hipError_t launch_gemv_lds_v2(const VptqV2Desc& d, const void* x, void* y, int tokens, bool out_f32,
-                              hipStream_t st);
+                              int flags, hipStream_t st);
 
 // gemm_k256.hip - canonical format, fp16, up to 16 tokens in one launch (tokens = MFMA M)
 bool gemm_k256_eligible(const VptqLayerDesc& d, int tokens, int flags);
