@@ -542,20 +542,33 @@ __global__ __launch_bounds__(kLThreads) void gemv_lds_mfma_kernel(const LdsParam
     const int rowc = row < N ? row : N - 1;  // spare rows recompute the last one (not stored)
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 
-    IdxWindow<FMT> nxt;
-    if (part < n_steps) {
-      const int g0 = part * kLMCols + blk * 8;
-      fetch_window<FMT>(nxt, P, rowc, g0 < G ? g0 : G - 8);
-    }
+    // index windows: one step ahead of the arithmetic (two steps ahead - 2 x 21-28 KiB in flight per CU -
+    // measured SLOWER, 14.9 vs 13.7 us at k = 8192 + 256: as in gemv_k256m.hip, a deeper request burst at the
+    // start of a short kernel delays the first data more than it hides later latency;
+    // profiles/r02/gemv_lds_mfma_ab.txt)
+#ifndef VPTQ_LDS_MFMA_DEPTH
+#define VPTQ_LDS_MFMA_DEPTH 1
+#endif
+    IdxWindow<FMT> nxt, nxt2;
+    auto fetch_step = [&](IdxWindow<FMT>& q, int st) {
+      if (st < n_steps) {
+        const int g0 = st * kLMCols + blk * 8;
+        fetch_window<FMT>(q, P, rowc, g0 < G ? g0 : G - 8);
+      }
+    };
+    fetch_step(nxt, part);
+    if (VPTQ_LDS_MFMA_DEPTH > 1) fetch_step(nxt2, part + PW);
     for (int st = part; st < n_steps; st += PW) {
       const IdxWindow<FMT> cur = nxt;
       const int g0r = st * kLMCols + blk * 8;
       const bool valid = g0r < G;
       const int g0 = valid ? g0r : G - 8;     // chunks past G redo the last one against x' = 0
       const u32x4 xq = lds_load16(xs_off + (uint32_t)(valid ? g0r : G) * 2u);
-      if (st + PW < n_steps) {
-        const int gn = (st + PW) * kLMCols + blk * 8;
-        fetch_window<FMT>(nxt, P, rowc, gn < G ? gn : G - 8);
+      if (VPTQ_LDS_MFMA_DEPTH > 1) {
+        nxt = nxt2;
+        fetch_step(nxt2, st + 2 * PW);
+      } else {
+        fetch_step(nxt, st + PW);
       }
       IdxDecoded<FMT> dec;
       normalise_window<FMT>(dec, cur, P, rowc, g0);
