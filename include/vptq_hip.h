@@ -63,7 +63,9 @@ enum {
 enum {
   /* Default arithmetic of the fused GEMV (ABI >= 3), where a kernel implements it (the
    * canonical v=8 / 256+256 format: fp16 with 1-2 tokens on any launch and with 3-4 tokens on
-   * launches of >= 576 vector-rows, bf16 with 1-4 tokens on launches of >= 128 vector-rows):
+   * launches of >= 576 vector-rows, bf16 with 1-4 tokens on launches of >= 128 vector-rows;
+   * the LDS-resident formats v=8, 256 < k <= 8192, kr <= 512: one-token calls on layers of
+   * >= 1024 vector-rows, bf16 always):
    * the folded form
    *   y = sum_g (c + r) * (scale_g * x_g) + sum_g bias_g * x_g + bias,   fp32 accumulate,
    * inside the parity bar of <= 1e-3 (max-normalised) against the reference CPU path, but
@@ -75,7 +77,8 @@ enum {
   /* Reproduce the reference CPU path's roundings: every weight is rebuilt as
    * r16(r16(r16(c+r)*scale)+bias) in the 16-bit type (bit-identical to vptq_dequant and to
    * the reference's torch path), then x*w is accumulated in fp32 and rounded once.  All
-   * other kernels (other formats, small layers with 3+ tokens or bf16) always work this way. */
+   * other kernels (other formats, small layers with 3+ tokens or bf16) always work this way;
+   * bf16 layers of the LDS-resident formats are routed to the L2-gather kernel for it. */
   VPTQ_GEMV_EXACT = 1 << 2,
   /* canonical format only: pick the persistent MFMA kernel wherever it is instantiated /
    * never pick it (testing / A-B; the default chooses by launch size) */
