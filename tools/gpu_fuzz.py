@@ -70,14 +70,49 @@ def fuzz_formats(a, dev):
     print("kernels used:", used, "worst:", f"{worst:.2e}")
 
 
+def fuzz_lds_tall(a, dev):
+    """Tall layers (>= 1024 vector-rows) of the LDS-resident formats, one token: gemv_lds_mfma_kernel (folded form)
+    against the C oracle, the kernel with the reference's roundings and the generic kernel."""
+    from oracle import c_oracle as co
+    rng = np.random.default_rng(a.seed)
+    used, worst = {}, 0.0
+    fmts = [(4096, 0), (8192, 0), (4096, 256), (8192, 256), (4096, 512), (2048, 512), (8192, 512), (1024, 4), (512, 16)]
+    for c in range(a.cases):
+        k, kr = fmts[int(rng.integers(0, len(fmts)))]
+        I = 8 * int(rng.integers(2, 1100))
+        O = 8192 + int(rng.choice([0, 8, 24, 8 * int(rng.integers(1, 1100)), int(rng.integers(1, 64))]))
+        kw = dict(num_centroids=k, num_res_centroids=kr, enable_perm=bool(rng.integers(0, 2)),
+                  enable_norm=bool(rng.integers(0, 4)), bias=bool(rng.integers(0, 2)))
+        dt = a.dtype
+        tol = 1e-3 if dt == "f16" else 8e-3
+        L = vo.make_layer(I, O, dist="llm" if rng.integers(0, 2) else "ref-test", seed=3000 + c, dtype=dt, **kw)
+        x = vo.from_f32((0.3 * rng.standard_normal((1, 1, I))).astype(np.float32), dt)
+        m = spec_to_module(L, dev)
+        xt = bits_to_tensor(x, dt, dev).reshape(x.shape)
+        want = co.forward(L, x, quirk=False)
+        kn = kernel_name(m, 1)
+        used[kn] = used.get(kn, 0) + 1
+        line = f"case {c:3d} k={k} kr={kr} I={I} O={O} perm={int(kw['enable_perm'])} norm={int(kw['enable_norm'])} bias={int(kw['bias'])} {kn}:"
+        for name, fl in (("default", 0), ("exact", 4), ("generic", 2)):
+            e = rel_err(tensor_to_bits(gemv_abi(m, xt, fl)), want, dt)
+            worst = max(worst, e)
+            line += f" {name}={e:.1e}"
+            assert e <= tol, (line, kw)
+        print(line, flush=True)
+    print("kernels used:", used, "worst:", f"{worst:.2e}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=40)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
     ap.add_argument("--formats", action="store_true", help="random index formats instead of the canonical one")
+    ap.add_argument("--lds-tall", action="store_true", help="tall layers of the LDS-resident formats (gemv_lds_mfma_kernel)")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
+    if a.lds_tall:
+        return fuzz_lds_tall(a, dev)
     if a.formats:
         return fuzz_formats(a, dev)
     rng = np.random.default_rng(a.seed)
