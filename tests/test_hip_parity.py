@@ -108,6 +108,12 @@ CASES = [
     (1032, 264, dict(num_centroids=65536, num_res_centroids=256, enable_perm=True), 2),
     (1024, 256, dict(num_centroids=65536, num_res_centroids=65536, dist="llm"), 4),
     (512, 96, dict(num_centroids=65536, num_res_centroids=65536, dtype="bf16", dist="llm"), 7),
+    # 5-8 tokens: one pass over the indices with 8 token slots; 9-16: two
+    (2048, 264, dict(num_centroids=65536, num_res_centroids=256, dist="llm", bias=True), 5),
+    (1032, 512, dict(num_centroids=65536, num_res_centroids=0, enable_perm=True), 8),
+    (1024, 128, dict(num_centroids=65536, num_res_centroids=65536, dist="llm"), 6),
+    (776, 200, dict(num_centroids=65536, num_res_centroids=256, dtype="bf16", dist="llm", enable_perm=True), 8),
+    (1024, 256, dict(num_centroids=65536, num_res_centroids=256, dist="llm"), 13),
 ]
 
 
@@ -127,10 +133,13 @@ def test_gemv_and_dequant_vs_oracle(I, O, kw, tokens, dev):
     W_ref = vo.dequant(L, ref_residual_mask_quirk=False)
     assert (tensor_to_bits(m.dequant()) == W_ref).all(), "dequant must be bit-exact"
     want = vo.gemv(W_ref, x, dt, L.bias)
-    got = tensor_to_bits(m(bits_to_tensor(x, dt, dev).reshape(x.shape)))
+    xt = bits_to_tensor(x, dt, dev).reshape(x.shape)
+    got = tensor_to_bits(m(xt))
     assert got.shape == want.shape
     err = rel_err(got, want, dt)
     assert err <= TOL[dt], f"{err:.3e}"
+    if tokens > 4:   # the fused route through the C ABI whatever route the module takes at this count
+        assert rel_err(tensor_to_bits(gemv_abi(m, xt, module_flags())), want, dt) <= TOL[dt]
 
 
 @pytest.mark.parametrize("k", [256, 65536])
@@ -1122,6 +1131,13 @@ GATHERX_CASES = [
                           num_outlier_centroids=1024, enable_perm=True, dtype="bf16", dist="llm"), 2),
     (512 + 32, 136, dict(vector_len=16, num_centroids=65536, num_res_centroids=1024, outlier_size=32, outlier_vector_len=4,
                          num_outlier_centroids=16, enable_norm=False), 4),                   # O = 136: 8.5 vector-rows of 16
+    # 5-8 tokens in one launch for v <= 8 (8 token slots), two launches of 4 for the longer vectors
+    (1024, 264, dict(vector_len=8, num_centroids=32768, num_res_centroids=512, dist="llm", bias=True), 7),
+    (520, 132, dict(vector_len=4, num_centroids=65536, num_res_centroids=0, enable_perm=True), 8),
+    (1032, 96, dict(vector_len=6, num_centroids=4096, num_res_centroids=4096, num_codebooks=2, dtype="bf16", dist="llm"), 6),
+    (1024, 256, dict(vector_len=16, num_centroids=65536, num_res_centroids=65536, dist="llm"), 6),
+    (512 + 64, 128, dict(vector_len=8, num_centroids=4096, num_res_centroids=4096, outlier_size=64, outlier_vector_len=4,
+                         num_outlier_centroids=256, enable_perm=True), 5),
 ]
 
 

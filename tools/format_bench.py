@@ -49,6 +49,7 @@ def main():
                                          "v8-k32768-0,v8-k16384-16384,v8-k65536-256,v8-k4096-4096-c2,v12-k65536-4096")
     ap.add_argument("--tokens", type=int, default=1)
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
+    ap.add_argument("--dense", action="store_true", help="also time vptq_dequant + F.linear at this token count")
     ap.add_argument("--out", default="")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -86,6 +87,19 @@ def main():
             us = time_graph(run, 5) / R
             kn = lib.vptq_quant_gemv_kernel_name(descs[0][0], a.tokens, flags)
             row[name] = dict(kernel=kn.decode() if kn else None, us_per_launch=us, GBps=ab / us / 1e3)
+        if a.dense:
+            # the other route of ops.quant_gemm: dense W by vptq_dequant, then F.linear (hipBLASLt)
+            import torch.nn.functional as F
+            W = torch.empty(H, H, device=dev, dtype=tdt)
+            descs_inv = [module_desc(m, need_inv_perm=True) for m in mods]
+
+            def dense():
+                sp = torch.cuda.current_stream().cuda_stream
+                for (d, kp), y in zip(descs_inv, ys):
+                    assert lib.vptq_dequant(d, W.data_ptr(), sp) == 0, lib.vptq_last_error()
+                    y.copy_(F.linear(x, W))
+            us = time_graph(dense, 5) / R
+            row["dense"] = dict(kernel="dequant + F.linear", us_per_launch=us)
         y0 = ys[0].clone()
         run(0)
         torch.cuda.synchronize()

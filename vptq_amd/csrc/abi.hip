@@ -108,11 +108,11 @@ const char* vptq_quant_gemv_kernel_name(const VptqLayerDesc* d, int tokens, int 
   if (tokens > VPTQ_GEMV_MAX_TOKENS_ANY) return nullptr;
   if (!(flags & VPTQ_GEMV_FORCE_GENERIC) && vptq::gemv_k256_eligible(*d, tokens > 4 ? 4 : tokens))
     return vptq::gemv_k256_name(*d, tokens, flags);
-  if (!(flags & VPTQ_GEMV_FORCE_GENERIC) && vptq::gemv_gather_eligible(*d, tokens > 4 ? 4 : tokens))
+  if (!(flags & VPTQ_GEMV_FORCE_GENERIC) && vptq::gemv_gather_eligible(*d, tokens > 8 ? 8 : tokens))
     return "gemv_gather_kernel";
   if (!(flags & VPTQ_GEMV_FORCE_GENERIC) && vptq::gemv_lds_eligible(*d, tokens > 4 ? 4 : tokens, flags))
     return vptq::gemv_lds_name(*d, tokens, flags);
-  if (!(flags & VPTQ_GEMV_FORCE_GENERIC) && vptq::gemv_gatherx_eligible(*d, tokens > 4 ? 4 : tokens))
+  if (!(flags & VPTQ_GEMV_FORCE_GENERIC) && vptq::gemv_gatherx_eligible(*d, tokens > 4 ? 4 : tokens))   // (4 fits every launch size)
     return "gemv_gatherx_kernel";
   return "gemv_generic_kernel";
 }
@@ -177,8 +177,8 @@ int vptq_quant_gemv(const VptqLayerDesc* d, const void* x, void* y, int tokens, 
   }
   if (!(flags & VPTQ_GEMV_FORCE_GENERIC) && vptq::gemv_gather_eligible(*d, chunk) &&
       (((uintptr_t)x) & 3) == 0) {
-    for (int t0 = 0; t0 < tokens; t0 += 4) {
-      const int m = tokens - t0 < 4 ? tokens - t0 : 4;
+    for (int t0 = 0; t0 < tokens; t0 += 8) {   // up to 8 tokens per pass over the indices
+      const int m = tokens - t0 < 8 ? tokens - t0 : 8;
       e = vptq::launch_gemv_gather(*d, (const char*)x + (size_t)t0 * d->in_features * 2,
                                    (char*)y + (size_t)t0 * d->out_features * yes, m, out_f32, st);
       if (e != hipSuccess) return hip_fail(e, "gemv_gather launch");
@@ -200,8 +200,9 @@ int vptq_quant_gemv(const VptqLayerDesc* d, const void* x, void* y, int tokens, 
   }
   if (!(flags & VPTQ_GEMV_FORCE_GENERIC) && vptq::gemv_gatherx_eligible(*d, chunk) &&
       (((uintptr_t)x) & 3) == 0) {
-    for (int t0 = 0; t0 < tokens; t0 += 4) {
-      const int m = tokens - t0 < 4 ? tokens - t0 : 4;
+    const int step = vptq::gemv_gatherx_max_chunk(*d);   // 8 token slots for v <= 8, else 4
+    for (int t0 = 0; t0 < tokens; t0 += step) {
+      const int m = tokens - t0 < step ? tokens - t0 : step;
       e = vptq::launch_gemv_gatherx(*d, (const char*)x + (size_t)t0 * d->in_features * 2,
                                     (char*)y + (size_t)t0 * d->out_features * yes, m, out_f32, st);
       if (e != hipSuccess) return hip_fail(e, "gemv_gatherx launch");

@@ -209,7 +209,7 @@ bool gemv_gather_eligible(const VptqLayerDesc& d, int tokens) {
   return T != 0 && d.vector_len == 8 && d.num_codebooks == 1 && d.outlier_size == 0 &&
          d.weight_scale != nullptr && d.weight_bias != nullptr && (d.group_size % 8) == 0 &&
          d.group_size == d.in_features && (long long)d.row_words * 32 == (long long)d.group_size * T &&
-         tokens >= 1 && tokens <= 4 &&
+         tokens >= 1 && tokens <= 8 &&
          (d.perm == nullptr || (d.scale_permuted != nullptr && d.bias_permuted != nullptr)) &&
          (((uintptr_t)d.indices | (uintptr_t)d.centroids | (uintptr_t)d.res_centroids) & 15) == 0 &&
          (((uintptr_t)d.weight_scale | (uintptr_t)d.weight_bias | (uintptr_t)d.scale_permuted |
@@ -228,7 +228,9 @@ static hipError_t launch_rt(const GatherParams& P, bool perm, hipStream_t st) {
 
 template <typename DT, int T>
 static hipError_t launch_t(const GatherParams& P, bool perm, hipStream_t st) {
-  const int tok = P.tokens > 2 ? 4 : P.tokens;
+  // token slots per launch: 1, 2, 4 or 8 (5-8 tokens in ONE pass over the indices and gathers - the
+  // gathers, not the FMAs, bound these kernels: two launches of <= 4 tokens cost twice)
+  const int tok = P.tokens > 4 ? 8 : P.tokens > 2 ? 4 : P.tokens;
   // ROWS = 2 amortises the per-column scale / bias / x loads when there are enough rows
   if (tok == 1) {
     if constexpr (T == 24) {
@@ -249,7 +251,8 @@ static hipError_t launch_t(const GatherParams& P, bool perm, hipStream_t st) {
     return launch_rt<DT, T, 1, 1>(P, perm, st);
   }
   if (tok == 2) return launch_rt<DT, T, 1, 2>(P, perm, st);
-  return launch_rt<DT, T, 1, 4>(P, perm, st);
+  if (tok == 4) return launch_rt<DT, T, 1, 4>(P, perm, st);
+  return launch_rt<DT, T, 1, 8>(P, perm, st);
 }
 
 template <typename DT>

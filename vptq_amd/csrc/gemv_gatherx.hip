@@ -110,6 +110,7 @@ static __device__ __forceinline__ uint32_t window_elem(const uint32_t (&n)[4], i
 
 template <typename DT, int V, int TOK, bool PERM>
 __global__ __launch_bounds__(kXThreads) void gemv_gatherx_kernel(const GatherXParams P) {
+  static_assert(TOK == 1 || TOK == 2 || TOK == 4 || (TOK == 8 && V <= 8), "token slots");
   static_assert(V == 2 || V == 4 || V == 6 || V == 8 || V == 10 || V == 12 || V == 16, "vector length");
   constexpr int E = kXE;
   constexpr int VW = V / 2;             // 32-bit words per entry
@@ -298,6 +299,9 @@ __global__ __launch_bounds__(kXThreads) void gemv_gatherx_kernel(const GatherXPa
 }
 
 // ---- host side -------------------------------------------------------------------
+// token slots of one launch: 8 for the short vectors (<= 64 accumulators), 4 for v = 10 / 12 / 16
+int gemv_gatherx_max_chunk(const VptqLayerDesc& d) { return d.vector_len <= 8 ? 8 : 4; }
+
 // codebook entries are 2 v bytes: the alignment the entry loads of load_entry<v> assume
 static int entry_align(int v) { return v == 8 || v == 16 ? 16 : (v == 4 || v == 12) ? 8 : 4; }
 
@@ -319,7 +323,7 @@ bool gemv_gatherx_eligible(const VptqLayerDesc& d, int tokens) {
   return d.num_codebooks >= 1 && (d.group_size % kXE) == 0 &&
          d.in_features == d.outlier_size + d.num_codebooks * d.group_size && d.index_bits + d.res_bits <= 32 &&
          (long long)d.row_words * 32 >= (long long)d.group_size * (d.index_bits + d.res_bits) &&
-         d.num_indices * v >= d.out_features && tokens >= 1 && tokens <= 4 &&
+         d.num_indices * v >= d.out_features && tokens >= 1 && tokens <= gemv_gatherx_max_chunk(d) &&
          (d.perm == nullptr || !norm || (d.scale_permuted != nullptr && d.bias_permuted != nullptr)) &&
          (((uintptr_t)d.centroids | (uintptr_t)d.res_centroids) & (entry_align(v) - 1)) == 0 &&
          (((uintptr_t)d.indices | (uintptr_t)d.weight_scale | (uintptr_t)d.weight_bias |
@@ -337,10 +341,12 @@ static hipError_t launch_x(const GatherXParams& P, bool perm, hipStream_t st) {
 
 template <typename DT, int V>
 static hipError_t launch_xv(const GatherXParams& P, bool perm, hipStream_t st) {
-  const int tok = P.tokens > 2 ? 4 : P.tokens;
+  const int tok = P.tokens > 4 ? 8 : P.tokens > 2 ? 4 : P.tokens;
   if (tok == 1) return launch_x<DT, V, 1>(P, perm, st);
   if (tok == 2) return launch_x<DT, V, 2>(P, perm, st);
-  return launch_x<DT, V, 4>(P, perm, st);
+  if (tok == 4) return launch_x<DT, V, 4>(P, perm, st);
+  if constexpr (V <= 8) return launch_x<DT, V, 8>(P, perm, st);
+  return hipErrorInvalidValue;
 }
 
 template <typename DT>

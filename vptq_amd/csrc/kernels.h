@@ -24,9 +24,10 @@ bool gemv_gather_eligible(const VptqLayerDesc& d, int tokens);
 hipError_t launch_gemv_gather(const VptqLayerDesc& d, const void* x, void* y, int tokens,
                               bool out_f32, hipStream_t st);
 
-// gemv_gatherx.hip - v = 8 / 12 / 16, any codebook sizes (any total index width), several codebook
+// gemv_gatherx.hip - every vector length, any codebook sizes (any total index width), several codebook
 // groups, outlier columns of the same vector length: codebook rows gathered from L2 (what gemv_gather / gemv_lds do not take)
 bool gemv_gatherx_eligible(const VptqLayerDesc& d, int tokens);
+int gemv_gatherx_max_chunk(const VptqLayerDesc& d);   // token slots of one launch: 8 (v <= 8) or 4
 hipError_t launch_gemv_gatherx(const VptqLayerDesc& d, const void* x, void* y, int tokens,
                                bool out_f32, hipStream_t st);
 
