@@ -1131,6 +1131,9 @@ GATHERX_CASES = [
                           num_outlier_centroids=1024, enable_perm=True, dtype="bf16", dist="llm"), 2),
     (512 + 32, 136, dict(vector_len=16, num_centroids=65536, num_res_centroids=1024, outlier_size=32, outlier_vector_len=4,
                          num_outlier_centroids=16, enable_norm=False), 4),                   # O = 136: 8.5 vector-rows of 16
+    # one token of a long vector on few vector-rows and >= 4096 columns
+    (4096 + 8, 1200, dict(vector_len=12, num_centroids=65536, num_res_centroids=4096, dist="llm", enable_perm=True, bias=True), 1),
+    (4096, 1000, dict(vector_len=10, num_centroids=4096, num_res_centroids=256, dtype="bf16", dist="llm"), 1),
     # 5-8 tokens in one launch for v <= 8 (8 token slots), two launches of 4 for the longer vectors
     (1024, 264, dict(vector_len=8, num_centroids=32768, num_res_centroids=512, dist="llm", bias=True), 7),
     (520, 132, dict(vector_len=4, num_centroids=65536, num_res_centroids=0, enable_perm=True), 8),

@@ -239,7 +239,10 @@ __global__ __launch_bounds__(kXThreads) void gemv_gatherx_kernel(const GatherXPa
         ri[e] = (v >> P.ib) * (uint32_t)(V * 2);
       }
       // all gathers of the piece first (V = 16: two elements at a time), then the arithmetic
-      constexpr int GB = V <= 8 ? 4 : 2;  // (4 for the wider entries too: no gain, 64 more registers)
+      constexpr int GB = V <= 8 ? 4 : 2;  // (4 for the wider entries too: no gain, 64 more registers; 512-thread
+                                          // workgroups for the 512 vector-rows of a v = 16 layer of 8192 outputs -
+                                          // twice the waves per CU - measured no gain either: the L2 / Infinity Cache
+                                          // path of the gathers, not the occupancy, sets the pace)
 #pragma unroll
       for (int e0 = 0; e0 < E; e0 += GB) {
         uint32_t cv[GB][VW], rv[GB][VW];
