@@ -79,12 +79,24 @@ def big_names():
                   for p in glob.glob(os.path.join(BIG_DIR, "*.npz")))
 
 
-def load_big(name):
+FMT_DIR = os.path.join(GOLDEN_DIR, "fmt")   # tests/golden/gen_golden_fmt.py: the other formats
+
+
+def fmt_names():
+    return sorted(os.path.splitext(os.path.basename(p))[0]
+                  for p in glob.glob(os.path.join(FMT_DIR, "*.npz")))
+
+
+def load_fmt(name):
+    return load_big(name, FMT_DIR)
+
+
+def load_big(name, directory=None):
     """-> (LayerSpec, x_bits [1,T,I], y_bits [1,T,O] from the real reference, cfg, W_head).
     Every input is rebuilt procedurally (tests/golden/_proc.py:big_tensors); the fixture holds
     the reference's output and the sha256 of its dense W."""
     from _proc import big_tensors
-    z = np.load(os.path.join(BIG_DIR, name + ".npz"))
+    z = np.load(os.path.join(directory or BIG_DIR, name + ".npz"))
     cfg = json.loads(bytes(z["config"]).decode())
     I, O, dt = cfg["in_features"], cfg["out_features"], cfg["dtype"]
     v, k, kr = cfg["vector_len"], cfg["num_centroids"], cfg["num_res_centroids"]

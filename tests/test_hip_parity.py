@@ -727,7 +727,7 @@ def test_sibling_groups_share_one_launch(dev):
 
 
 # ---------------------------------------------------------------- BASELINE sizes vs the reference
-from _cases import big_names, load_big, v2_names, load_v2  # noqa: E402
+from _cases import big_names, load_big, v2_names, load_v2, fmt_names, load_fmt  # noqa: E402
 
 
 @pytest.mark.parametrize("name", big_names())
@@ -752,6 +752,41 @@ def test_baseline_size_goldens_every_kernel_and_form(name, dev):
         seen[flags] = (kernel_name(m, cfg["tokens"], flags), err, bit_identical_frac(got, y))
         assert err <= TOL[dt], (flags, seen[flags])
     # the reference's roundings reproduce (nearly) its bits; fp32-accumulated order aside
+    if dt == "f16":
+        assert seen[EXACT][2] >= 0.95 and seen[GENERIC][2] >= 0.95, seen
+    print(name, seen)
+
+
+FMT_KERNELS = {"t1_k8192_r256_8192x1024": "gemv_lds_mfma_kernel", "t1_k4096_r512_perm_bias": "gemv_lds_mfma_kernel",
+               "t1_k8192_r256_bf16": "gemv_lds_mfma_kernel", "t8_k65536_r256": "gemv_gather_kernel",
+               "t5_k65536_r65536_perm": "gemv_gather_kernel", "t7_v6_k4096_r16": "gemv_gatherx_kernel",
+               "t1_v10_k4096_r256": "gemv_gatherx_kernel", "t2_v2_k256_r16_perm": "gemv_gatherx_kernel",
+               "t8_v4_k4096_r256_bf16": "gemv_gatherx_kernel"}
+
+
+@pytest.mark.parametrize("name", fmt_names())
+def test_reference_goldens_other_formats(name, dev):
+    """The kernels of the non-canonical formats against the REAL reference's outputs (procedural inputs,
+    tests/golden/gen_golden_fmt.py): dense W bit for bit (sha256); forward through the library's kernel
+    choice (the one named in FMT_KERNELS), with the reference's roundings, through the generic kernel and
+    through the module's own route."""
+    L, x, y, cfg, W_head = load_fmt(name)
+    dt, tokens = cfg["dtype"], cfg["tokens"]
+    m = spec_to_module(L, dev)
+    W = tensor_to_bits(m.dequant())
+    assert (W[:2] == W_head).all()
+    assert hashlib.sha256(W.tobytes()).hexdigest() == cfg["W_sha256"]
+    del W
+    assert kernel_name(m, tokens) == FMT_KERNELS[name], kernel_name(m, tokens)
+    xt = bits_to_tensor(x, dt, dev).reshape(x.shape)
+    out = tensor_to_bits(m(xt))
+    assert rel_err(out, y, dt) <= TOL[dt], f"module route: {rel_err(out, y, dt):.3e}"
+    seen = {}
+    for flags in (0, EXACT, GENERIC):
+        got = tensor_to_bits(gemv_abi(m, xt, flags))
+        err = rel_err(got, y, dt)
+        seen[flags] = (kernel_name(m, tokens, flags), err, bit_identical_frac(got, y))
+        assert err <= TOL[dt], (flags, seen[flags])
     if dt == "f16":
         assert seen[EXACT][2] >= 0.95 and seen[GENERIC][2] >= 0.95, seen
     print(name, seen)

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from oracle import vptq_oracle as vo
-from _cases import (golden_names, load_golden, rel_err, bit_identical_frac, big_names, load_big,
+from _cases import (golden_names, load_golden, rel_err, bit_identical_frac, big_names, load_big, fmt_names, load_fmt,
                     v2_names, load_v2)
 from _refshim import reference_available
 
@@ -123,6 +123,27 @@ def test_numpy_oracle_vs_reference_at_hidden_4096(name):
     out = vo.forward(L, x)
     assert rel_err(out, y, cfg["dtype"]) <= Y_TOL[cfg["dtype"]]
     assert bit_identical_frac(out, y) >= 0.98
+
+
+@pytest.mark.parametrize("name", fmt_names())
+def test_oracles_vs_reference_other_formats(name):
+    """The non-canonical formats at the sizes / token counts where their own kernels run (tall layers of the
+    LDS-resident formats, 5-8 tokens of the k = 65536 formats, vector lengths 2 / 4 / 6 / 10): the reference's
+    dense W (sha256) and forward output, every input procedural (tests/golden/gen_golden_fmt.py); numpy and C."""
+    from oracle import c_oracle as co
+    L, x, y, cfg, W_head = load_fmt(name)
+    dt = cfg["dtype"]
+    W = vo.dequant(L)
+    assert (W[:2] == W_head).all()
+    assert hashlib.sha256(W.tobytes()).hexdigest() == cfg["W_sha256"]
+    out = vo.gemv(W, x, dt, L.bias)
+    assert rel_err(out, y, dt) <= Y_TOL[dt]
+    assert bit_identical_frac(out, y) >= 0.98
+    if co.available():
+        Wc = co.dequant(L)
+        assert hashlib.sha256(Wc.tobytes()).hexdigest() == cfg["W_sha256"]
+        outc = co.forward(L, x)
+        assert rel_err(outc, y, dt) <= Y_TOL[dt] and bit_identical_frac(outc, y) >= 0.98
 
 
 # ---------------------------------------------------------------- v2 wire format
