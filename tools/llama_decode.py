@@ -48,7 +48,7 @@ def build_model(layers, dev, k=256, kr=256, perm=False, size="8b"):
     for name, mod in model.named_modules():
         if isinstance(mod, torch.nn.Linear) and name != "lm_head":
             per_layer[name] = dict(vector_lens=[-1, 8], num_centroids=[-1, k],
-                                   num_res_centroids=[-1, kr], group_num=1,
+                                   num_res_centroids=[-1, kr if kr > 0 else -1], group_num=1,
                                    group_size=mod.in_features, outlier_size=0,
                                    indices_as_float=False, enable_norm=True, enable_perm=perm,
                                    is_indice_packed=True)
@@ -80,7 +80,8 @@ def build_model(layers, dev, k=256, kr=256, perm=False, size="8b"):
                 mod.indices.data = torch.randint(-2**31, 2**31 - 1, mod.indices.shape, generator=g,
                                                  device=dev, dtype=torch.int64).to(torch.int32)
                 mod.centroids.weight.data = (torch.randn(mod.centroids.weight.shape, generator=g, device=dev) * 0.02).half()
-                mod.res_centroids.weight.data = (torch.randn(mod.res_centroids.weight.shape, generator=g, device=dev) * 0.005).half()
+                if mod.enable_residual:
+                    mod.res_centroids.weight.data = (torch.randn(mod.res_centroids.weight.shape, generator=g, device=dev) * 0.005).half()
                 I = mod.in_features
                 mod.weight_scale.data = (1 + 0.1 * torch.randn(I, generator=g, device=dev)).half()
                 mod.weight_bias.data = (0.002 * torch.randn(I, generator=g, device=dev)).half()
@@ -105,7 +106,7 @@ def run(args):
     def stage(msg):
         print(f"[stage] {msg}", file=sys.stderr, flush=True)
     stage("build")
-    model, cfg, qlayers = build_model(args.layers, dev, perm=args.perm, size=args.model)
+    model, cfg, qlayers = build_model(args.layers, dev, k=args.k, kr=args.kr, perm=args.perm, size=args.model)
     fused = 0
     if args.fuse:
         import vptq
@@ -177,7 +178,7 @@ def run(args):
         graph_tps = f"capture failed: {type(e).__name__}: {e}"
 
     lm_head_bytes = cfg.vocab_size * cfg.hidden_size * 2
-    res = dict(model=f"Llama-3-{args.model.upper()} shapes, {cfg.num_hidden_layers} layers, 2-bit VQuantLinear (v8 k256+256)"
+    res = dict(model=f"Llama-3-{args.model.upper()} shapes, {cfg.num_hidden_layers} layers, VQuantLinear v8-k{args.k}-{args.kr}" + (" (2-bit)" if (args.k, args.kr) == (256, 256) else "")
                      + (" +perm" if args.perm else ""),
                quantized_linears=len(qlayers), packed_index_GB=qbytes / 1e9,
                lm_head_GB=lm_head_bytes / 1e9, prompt=args.prompt, new_tokens=args.new,
@@ -198,6 +199,8 @@ if __name__ == "__main__":
     ap.add_argument("--prompt", type=int, default=128)
     ap.add_argument("--new", type=int, default=256)
     ap.add_argument("--perm", action="store_true")
+    ap.add_argument("--k", type=int, default=256, help="main codebook entries (v = 8): 256 = the 2-bit format, 65536 = the published 3-bit ones")
+    ap.add_argument("--kr", type=int, default=256, help="residual codebook entries")
     ap.add_argument("--fuse", action="store_true", help="link_siblings: q/k/v and gate/up share one grouped launch")
     ap.add_argument("--out", default="")
     run(ap.parse_args())
