@@ -42,6 +42,11 @@ def chain_prefetch(layers, circular: bool = False):
     return layers
 
 
+def _raw_stream(device_index: int) -> int:
+    """hipStream_t of torch's current stream on `device_index` (no Stream object)."""
+    return torch._C._cuda_getCurrentRawStream(device_index)
+
+
 class SiblingGroup:
     """Layers that are applied to the SAME activation one after the other (q / k / v, gate / up).
     The first member called with a tensor launches all members in one grouped kernel
@@ -83,9 +88,12 @@ class SiblingGroup:
         for i, y in enumerate(ys):
             xp[i] = xc.data_ptr()
             yp[i] = y.data_ptr()
-        with torch.cuda.device(dev):
-            rc = fn(descs, len(ys), xp, yp, tokens, ops.quant_gemm_flags(),
-                    torch.cuda.current_stream(dev).cuda_stream)
+        dev_index = caches[0][8]
+        if torch.cuda.current_device() != dev_index:
+            with torch.cuda.device(dev):
+                rc = fn(descs, len(ys), xp, yp, tokens, ops.quant_gemm_flags(), B.current_stream_ptr(dev))
+        else:
+            rc = fn(descs, len(ys), xp, yp, tokens, ops.quant_gemm_flags(), _raw_stream(dev_index))
         if rc:
             B.check(rc, "vptq_quant_gemv_grouped")
         self._x, self._version = x, B.tensor_version(x)
@@ -270,17 +278,24 @@ class VQuantLinear(nn.Module):
         """(desc, device, keep-alive): the C-ABI descriptor of this layer, built once and reused
         while the parameter storages stay the same (building it costs ~25 us of Python per call,
         several times the kernel itself)."""
-        cw = self.centroids.weight
+        # parameters straight out of the module's dicts: nn.Module.__getattr__ costs ~0.4 us per name,
+        # ten names per call were a third of this function (tools/py_overhead.py)
+        P, M = self._parameters, self._modules
         nxt = self._prefetch_next
-        tensors = (self.indices, cw, self.res_centroids.weight if self.enable_residual else None,
-                   self.outlier_indices,
-                   self.outlier_centroids.weight if self.enable_outlier else None,
-                   self.perm if self.enable_perm else None, self.weight_scale, self.weight_bias,
-                   self.bias, None if nxt is None else nxt.indices)
-        # storage pointers AND version counters: the descriptor embeds pointers to derived
-        # copies (scale / bias in column order for `perm` layers), which an in-place update of
-        # the parameters (load_state_dict's copy_, an optimizer step) must invalidate
-        key = tuple(0 if t is None else (t.data_ptr(), B.tensor_version(t)) for t in tensors)
+        # (an absent tensor is either a None entry of _parameters or a plain None attribute: .get covers both)
+        perm = P.get("perm") if self.enable_perm else None
+        tensors = (P["indices"], M["centroids"]._parameters["weight"],
+                   M["res_centroids"]._parameters["weight"] if self.enable_residual else None,
+                   P.get("outlier_indices"),
+                   M["outlier_centroids"]._parameters["weight"] if self.enable_outlier else None,
+                   perm, P.get("weight_scale"), P.get("weight_bias"),
+                   P.get("bias"), None if nxt is None else nxt._parameters["indices"])
+        # storage pointers of everything; version counters of the tensors the descriptor holds DERIVED
+        # copies of (scale / bias in column order for `perm` layers), which an in-place update of the
+        # parameters (load_state_dict's copy_, an optimizer step) must invalidate
+        key = tuple(0 if t is None else t.data_ptr() for t in tensors)
+        if perm is not None:
+            key += (B.tensor_version(perm), B.tensor_version(tensors[6]), B.tensor_version(tensors[7]))
         cache = self.__dict__.get("_desc_cache")
         if cache is None or cache[0] != key:
             dev = B.require_device(*[t for t in tensors if t is not None])
@@ -298,7 +313,8 @@ class VQuantLinear(nn.Module):
                 num_outlier_centroids=self.num_outlier_centroids, prefetch=tensors[9])
             VQuantLinear._desc_generation += 1
             cache = (key, desc, keep, dev, B.lib().vptq_quant_gemv,
-                     B.lib().vptq_quant_gemv_max_tokens(desc), VQuantLinear._desc_generation)
+                     B.lib().vptq_quant_gemv_max_tokens(desc), VQuantLinear._desc_generation,
+                     tensors[1].dtype, dev.index if dev.index is not None else torch.cuda.current_device())
             self.__dict__["_desc_cache"] = cache
         return cache
 
@@ -318,18 +334,28 @@ class VQuantLinear(nn.Module):
         group = self.__dict__.get("_siblings")
         if group is not None and tokens <= group.MAX_TOKENS:
             return group.forward(self, x, tokens)
-        x = self._check_activation(x)
-        _, desc, _, dev, fn, _, _ = self._descriptor()
+        _, desc, _, dev, fn, _, _, wdtype, dev_index = self._descriptor()
+        # (the checks of _check_activation against the cached dtype / device: no module attribute look-ups)
+        if x.shape[-1] != self.in_features:
+            raise RuntimeError(f"x has {x.shape[-1]} features, layer expects {self.in_features}")
+        if x.dtype != wdtype:
+            raise RuntimeError(f"activation dtype {x.dtype} != weight dtype {wdtype}")
         if x.device != dev:
+            if not x.is_cuda:
+                raise RuntimeError("vptq_amd has no CPU path: x must be on the GPU")
             raise RuntimeError(f"tensors on different devices: {dev} vs {x.device}")
-        y = torch.empty(x.shape[:-1] + (self.out_features,), dtype=x.dtype, device=dev)
-        if torch.cuda.current_device() != dev.index:
+        if not x.is_contiguous():
+            x = x.contiguous()
+        y = torch.empty(x.shape[:-1] + (self.out_features,), dtype=wdtype, device=dev)
+        # the current stream of the layer's device as a raw handle (torch.cuda.current_stream builds a
+        # Stream object per call: 4 us of the 15 this function took)
+        if torch.cuda.current_device() != dev_index:
             with torch.cuda.device(dev):
                 rc = fn(desc, x.data_ptr(), y.data_ptr(), tokens, ops.quant_gemm_flags(), None, 0,
-                        torch.cuda.current_stream(dev).cuda_stream)
+                        B.current_stream_ptr(dev))
         else:
             rc = fn(desc, x.data_ptr(), y.data_ptr(), tokens, ops.quant_gemm_flags(), None, 0,
-                    torch.cuda.current_stream(dev).cuda_stream)
+                    _raw_stream(dev_index))
         if rc:
             B.check(rc, "vptq_quant_gemv")
         return y

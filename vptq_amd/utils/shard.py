@@ -115,7 +115,7 @@ def forward_partial_f32(layer: VQuantLinear, x: torch.Tensor) -> torch.Tensor:
     tokens = xc.numel() // xc.shape[-1]
     if not 1 <= tokens <= B.GEMV_MAX_TOKENS:
         raise RuntimeError(f"forward_partial_f32 takes 1..{B.GEMV_MAX_TOKENS} tokens, got {tokens}")
-    _, desc, _, dev, fn, _, _ = layer._descriptor()
+    _, desc, _, dev, fn = layer._descriptor()[:5]
     y = torch.empty(xc.shape[:-1] + (layer.out_features,), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         B.check(fn(desc, xc.data_ptr(), y.data_ptr(), tokens,
