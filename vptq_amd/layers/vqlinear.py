@@ -245,6 +245,8 @@ class VQuantLinear(nn.Module):
         if 1 <= tokens <= B.GEMV_MAX_TOKENS and x.is_cuda and \
                 (tokens <= B.GEMV_ANY_FORMAT_TOKENS or tokens <= self._descriptor()[5]):
             return self._gemv_cached(x, tokens)
+        if tokens >= 1 and x.is_cuda and ops.fused_gemm_max_tokens() < tokens:
+            return self._dense_cached(x)
         return ops.quant_gemm(
             x,
             bias=self.bias,
@@ -359,6 +361,49 @@ class VQuantLinear(nn.Module):
         if rc:
             B.check(rc, "vptq_quant_gemv")
         return y
+
+    def _dense_cached(self, x: torch.Tensor) -> torch.Tensor:
+        """Many tokens: `vptq_dequant` into a fresh dense W + `F.linear` (the reference's route,
+        vptq/ops/quant_gemm.py:231-274) - what `ops.quant_gemm` does, with the descriptor (and its
+        argsort(perm)) cached: marshalling 28 keyword arguments and rebuilding the descriptor cost
+        ~45 us of Python per layer, a third of the prompt pass of an 8B-shaped model at 128 tokens."""
+        cache = self._descriptor()
+        dev, wdtype, dev_index = cache[3], cache[7], cache[8]
+        if x.shape[-1] != self.in_features:
+            raise RuntimeError(f"x has {x.shape[-1]} features, layer expects {self.in_features}")
+        if x.dtype != wdtype:
+            raise RuntimeError(f"activation dtype {x.dtype} != weight dtype {wdtype}")
+        if x.device != dev:
+            raise RuntimeError(f"tensors on different devices: {dev} vs {x.device}")
+        dense = self.__dict__.get("_desc_dense")
+        if dense is None or dense[0] != cache[6]:
+            P, M = self._parameters, self._modules
+            desc, keep = B.make_layer_desc(
+                indices=P["indices"], centroids=M["centroids"]._parameters["weight"],
+                res_centroids=M["res_centroids"]._parameters["weight"] if self.enable_residual else None,
+                outlier_indices=P.get("outlier_indices"),
+                outlier_centroids=M["outlier_centroids"]._parameters["weight"] if self.enable_outlier else None,
+                perm=P.get("perm") if self.enable_perm else None,
+                weight_scale=P.get("weight_scale"), weight_bias=P.get("weight_bias"), bias=None,
+                in_features=self.in_features, out_features=self.out_features,
+                vector_len=self.vector_len, num_codebooks=self.num_codebooks,
+                num_centroids=self.num_centroids,
+                num_res_centroids=self.num_res_centroids if self.enable_residual else 0,
+                group_size=self.group_size,
+                outlier_size=self.outlier_size if self.enable_outlier else 0,
+                outlier_vector_len=self.outlier_vector_len,
+                num_outlier_centroids=self.num_outlier_centroids, need_inv_perm=True)
+            dense = (cache[6], desc, keep, B.lib().vptq_dequant)
+            self.__dict__["_desc_dense"] = dense
+        W = torch.empty((self.out_features, self.in_features), dtype=wdtype, device=dev)
+        if torch.cuda.current_device() != dev_index:
+            with torch.cuda.device(dev):
+                rc = dense[3](dense[1], W.data_ptr(), B.current_stream_ptr(dev))
+        else:
+            rc = dense[3](dense[1], W.data_ptr(), _raw_stream(dev_index))
+        if rc:
+            B.check(rc, "vptq_dequant")
+        return torch.nn.functional.linear(x, W, self._parameters.get("bias"))
 
     def dequant(self) -> torch.Tensor:
         """Dense W[out_features, in_features] (what the reference calls

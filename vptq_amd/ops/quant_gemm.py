@@ -106,6 +106,11 @@ def dequant(
     return W
 
 
+def fused_gemm_max_tokens() -> int:
+    """token count up to which many-token calls take the fused dequant-GEMM (VPTQ_FUSED_GEMM_MAX_TOKENS; 0 = never)"""
+    return _FUSED_GEMM_MAX_TOKENS
+
+
 def quant_gemm(
     x: torch.Tensor,
     bias: Optional[torch.Tensor],
