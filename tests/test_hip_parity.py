@@ -842,11 +842,17 @@ def test_in_place_parameter_updates_invalidate_the_descriptor(dev):
     x = bits_to_tensor(vo.from_f32(np.random.default_rng(3).standard_normal((1, 1, 1024))
                                    .astype(np.float32), "f16"), "f16", dev).reshape(1, 1, 1024)
     xb = tensor_to_bits(x)
+    # (the many-token route - cached dequant descriptor with argsort(perm) + F.linear - follows too)
+    x70 = bits_to_tensor(vo.from_f32(np.random.default_rng(8).standard_normal((1, 70, 1024))
+                                     .astype(np.float32), "f16"), "f16", dev).reshape(1, 70, 1024)
+    x70b = tensor_to_bits(x70)
     assert rel_err(tensor_to_bits(m(x)), vo.forward(L, xb), "f16") <= 1e-3
+    assert rel_err(tensor_to_bits(m(x70)), vo.forward(L, x70b), "f16") <= 1e-3
     # 1. in-place scaling of weight_scale
     with torch.no_grad():
         m.weight_scale.mul_(2.0)
     assert rel_err(tensor_to_bits(m(x)), vo.forward(module_to_spec(m), xb), "f16") <= 1e-3
+    assert rel_err(tensor_to_bits(m(x70)), vo.forward(module_to_spec(m), x70b), "f16") <= 1e-3
     # 2. load_state_dict (default assign=False -> copy_ into the same storages)
     L2 = vo.make_layer(1024, 512, dist="llm", seed=6, enable_perm=True, bias=True)
     m2 = spec_to_module(L2, dev)
@@ -859,6 +865,7 @@ def test_in_place_parameter_updates_invalidate_the_descriptor(dev):
         m.perm.copy_(torch.from_numpy(np.random.default_rng(9).permutation(1024).astype(np.uint16)
                                       .view(np.int16)).to(dev))
     assert rel_err(tensor_to_bits(m(x)), vo.forward(module_to_spec(m), xb), "f16") <= 1e-3
+    assert rel_err(tensor_to_bits(m(x70)), vo.forward(module_to_spec(m), x70b), "f16") <= 1e-3
     # sibling groups copy descriptors by value: they follow as well
     import vptq_amd
 
