@@ -22,3 +22,25 @@ with torch.no_grad():
     for _ in range(2000): m(x)
     pr.disable()
 pstats.Stats(pr).sort_stats("cumulative").print_stats(14)
+
+# sibling group (q / k / v through one grouped launch): Python cost of the three forward calls
+class Blk(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.q_proj, self.k_proj, self.v_proj = mk(4096, 4096, dev, g), mk(4096, 1024, dev, g), mk(4096, 1024, dev, g)
+blk = Blk()
+assert vptq_amd.layers.link_siblings(blk) == 1
+with torch.no_grad():
+    def qkv():
+        blk.q_proj(x); blk.k_proj(x); blk.v_proj(x)
+    for _ in range(200): qkv()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3000): qkv()
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    print(f"q + k + v through a sibling group: {(t1 - t0) / 3000 * 1e6:.1f} us per triple to enqueue")
+    pr = cProfile.Profile(); pr.enable()
+    for _ in range(1000): qkv()
+    pr.disable()
+pstats.Stats(pr).sort_stats("tottime").print_stats(10)

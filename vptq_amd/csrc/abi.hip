@@ -100,21 +100,45 @@ int vptq_quant_gemv_max_tokens(const VptqLayerDesc* d) {
   return vptq::gemv_k256_eligible(*d, 4) ? VPTQ_GEMV_MAX_TOKENS_ANY : 8;
 }
 
+// ---- which kernel family serves (layer, tokens, flags): ONE decision for vptq_quant_gemv and for
+// vptq_quant_gemv_kernel_name (x = NULL there: the activation pointer is assumed aligned) ----
+enum Route { kRouteNone, kRouteGemmK256, kRouteK256, kRouteGather, kRouteLds, kRouteGatherX, kRouteGeneric };
+
+static int batch_min_tokens() {
+  static int v = -1;  // VPTQ_GEMM_MIN_TOKENS: smallest token count that takes the batched-decode kernel
+  if (v < 0) { const char* ev = getenv("VPTQ_GEMM_MIN_TOKENS"); v = ev ? atoi(ev) : 5; }
+  return v;
+}
+
+static Route route_gemv(const VptqLayerDesc& d, int tokens, int flags, const void* x) {
+  const uintptr_t xa = (uintptr_t)x;   // 0 when unknown
+  const bool forced_generic = (flags & VPTQ_GEMV_FORCE_GENERIC) != 0;
+  // canonical format, fp16, 5-16 tokens: ONE launch of the batched-decode kernel per 16 tokens
+  if (!(flags & (VPTQ_GEMV_FORCE_GENERIC | VPTQ_GEMV_FORCE_VALU | VPTQ_GEMV_FORCE_MFMA)) &&
+      tokens >= batch_min_tokens() && vptq::gemm_k256_eligible(d, tokens > 16 ? 16 : tokens, flags) && (xa & 15) == 0)
+    return kRouteGemmK256;
+  if (tokens > VPTQ_GEMV_MAX_TOKENS_ANY) return kRouteNone;
+  const int chunk4 = tokens > 4 ? 4 : tokens;
+  if (!forced_generic && vptq::gemv_k256_eligible(d, chunk4) && (xa & 15) == 0 &&
+      (tokens <= 4 || (d.in_features % 8) == 0))
+    return kRouteK256;
+  if (!forced_generic && vptq::gemv_gather_eligible(d, tokens > 8 ? 8 : tokens) && (xa & 3) == 0) return kRouteGather;
+  if (!forced_generic && vptq::gemv_lds_eligible(d, chunk4, flags) && (xa & 15) == 0) return kRouteLds;
+  if (!forced_generic && vptq::gemv_gatherx_eligible(d, chunk4) && (xa & 3) == 0) return kRouteGatherX;   // (4 fits every launch size)
+  return kRouteGeneric;
+}
+
 const char* vptq_quant_gemv_kernel_name(const VptqLayerDesc* d, int tokens, int flags) {
   if (validate_layer(d) != VPTQ_OK || tokens < 1 || tokens > VPTQ_GEMV_MAX_TOKENS) return nullptr;
-  if (!(flags & (VPTQ_GEMV_FORCE_GENERIC | VPTQ_GEMV_FORCE_VALU | VPTQ_GEMV_FORCE_MFMA)) && tokens >= 5 &&
-      vptq::gemm_k256_eligible(*d, tokens > 16 ? 16 : tokens, flags))
-    return "gemm_k256_kernel";
-  if (tokens > VPTQ_GEMV_MAX_TOKENS_ANY) return nullptr;
-  if (!(flags & VPTQ_GEMV_FORCE_GENERIC) && vptq::gemv_k256_eligible(*d, tokens > 4 ? 4 : tokens))
-    return vptq::gemv_k256_name(*d, tokens, flags);
-  if (!(flags & VPTQ_GEMV_FORCE_GENERIC) && vptq::gemv_gather_eligible(*d, tokens > 8 ? 8 : tokens))
-    return "gemv_gather_kernel";
-  if (!(flags & VPTQ_GEMV_FORCE_GENERIC) && vptq::gemv_lds_eligible(*d, tokens > 4 ? 4 : tokens, flags))
-    return vptq::gemv_lds_name(*d, tokens, flags);
-  if (!(flags & VPTQ_GEMV_FORCE_GENERIC) && vptq::gemv_gatherx_eligible(*d, tokens > 4 ? 4 : tokens))   // (4 fits every launch size)
-    return "gemv_gatherx_kernel";
-  return "gemv_generic_kernel";
+  switch (route_gemv(*d, tokens, flags, nullptr)) {
+    case kRouteGemmK256: return "gemm_k256_kernel";
+    case kRouteK256: return vptq::gemv_k256_name(*d, tokens, flags);
+    case kRouteGather: return "gemv_gather_kernel";
+    case kRouteLds: return vptq::gemv_lds_name(*d, tokens, flags);
+    case kRouteGatherX: return "gemv_gatherx_kernel";
+    case kRouteGeneric: return "gemv_generic_kernel";
+    default: return nullptr;
+  }
 }
 
 const char* vptq_quant_gemv_grouped_kernel_name(const VptqLayerDesc* descs, int n, int tokens,
@@ -140,82 +164,46 @@ int vptq_quant_gemv(const VptqLayerDesc* d, const void* x, void* y, int tokens, 
     return fail(VPTQ_E_TOKENS, "tokens %d outside [1, %d]: use vptq_dequant + GEMM", tokens,
                 VPTQ_GEMV_MAX_TOKENS);
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e;
+  hipError_t e = hipSuccess;
   const bool out_f32 = (flags & VPTQ_GEMV_OUT_F32) != 0;
   const size_t yes = out_f32 ? 4 : 2;  // bytes per output element
-  // canonical format, fp16, 5-16 tokens: ONE launch of the batched-decode kernel (tokens = the
-  // M dimension of a 16x16x16 MFMA; reference arithmetic)
-  static int batch_min = -1;  // VPTQ_GEMM_MIN_TOKENS: smallest token count that takes it
-  if (batch_min < 0) { const char* ev = getenv("VPTQ_GEMM_MIN_TOKENS"); batch_min = ev ? atoi(ev) : 5; }
-  if (!(flags & (VPTQ_GEMV_FORCE_GENERIC | VPTQ_GEMV_FORCE_VALU | VPTQ_GEMV_FORCE_MFMA)) &&
-      tokens >= batch_min && vptq::gemm_k256_eligible(*d, tokens > 16 ? 16 : tokens, flags) &&
-      (((uintptr_t)x) & 15) == 0) {
-    for (int t0 = 0; t0 < tokens; t0 += 16) {   // 16 tokens per launch
-      const int m = tokens - t0 < 16 ? tokens - t0 : 16;
-      e = vptq::launch_gemm_k256(*d, (const char*)x + (size_t)t0 * d->in_features * 2,
-                                 (char*)y + (size_t)t0 * d->out_features * yes, m, out_f32, st);
-      if (e != hipSuccess) return hip_fail(e, "gemm_k256 launch");
-    }
-    return VPTQ_OK;
-  }
-  if (tokens > VPTQ_GEMV_MAX_TOKENS_ANY)
-    return fail(VPTQ_E_TOKENS, "tokens %d outside [1, %d] for this layer: use vptq_dequant + GEMM", tokens,
-                VPTQ_GEMV_MAX_TOKENS_ANY);
-  // the specialised kernels take up to 4 tokens per launch; more tokens = more launches
-  // (up to 16 tokens still cheaper than a dense dequant + GEMM, tools/tokens_crossover.py)
-  const int chunk = tokens > 4 ? 4 : tokens;
-  if (!(flags & VPTQ_GEMV_FORCE_GENERIC) && vptq::gemv_k256_eligible(*d, chunk) &&
-      (((uintptr_t)x) & 15) == 0 && (tokens <= 4 || (d->in_features % 8) == 0)) {
-    for (int t0 = 0; t0 < tokens; t0 += 4) {
-      const int m = tokens - t0 < 4 ? tokens - t0 : 4;
-      const void* xc = (const char*)x + (size_t)t0 * d->in_features * 2;
-      void* yc = (char*)y + (size_t)t0 * d->out_features * yes;
-      e = vptq::launch_gemv_k256(d, 1, &xc, &yc, m, flags, st);
-      if (e != hipSuccess) return hip_fail(e, "gemv_k256 launch");
-    }
-    return VPTQ_OK;
-  }
-  if (!(flags & VPTQ_GEMV_FORCE_GENERIC) && vptq::gemv_gather_eligible(*d, chunk) &&
-      (((uintptr_t)x) & 3) == 0) {
-    for (int t0 = 0; t0 < tokens; t0 += 8) {   // up to 8 tokens per pass over the indices
-      const int m = tokens - t0 < 8 ? tokens - t0 : 8;
-      e = vptq::launch_gemv_gather(*d, (const char*)x + (size_t)t0 * d->in_features * 2,
-                                   (char*)y + (size_t)t0 * d->out_features * yes, m, out_f32, st);
-      if (e != hipSuccess) return hip_fail(e, "gemv_gather launch");
-    }
-    return VPTQ_OK;
-  }
-  if (!(flags & VPTQ_GEMV_FORCE_GENERIC) && vptq::gemv_lds_eligible(*d, chunk, flags) &&
-      (((uintptr_t)x) & 15) == 0) {
-    const int step = vptq::gemv_lds_max_chunk(d->dtype);
-    // every token of one call in the same arithmetic: the one-token MFMA form only for one-token calls
-    const int lflags = tokens > 1 ? (flags | VPTQ_GEMV_EXACT) : flags;
+  const size_t xrow = (size_t)d->in_features * 2, yrow = (size_t)d->out_features * yes;
+  // tokens are served in launches of `step` tokens (more tokens = more launches; up to 16 tokens still
+  // cheaper than a dense dequant + GEMM for the canonical format, tools/tokens_crossover.py)
+  auto chunks = [&](int step, const char* what, auto&& launch) -> int {
     for (int t0 = 0; t0 < tokens; t0 += step) {
       const int m = tokens - t0 < step ? tokens - t0 : step;
-      e = vptq::launch_gemv_lds(*d, (const char*)x + (size_t)t0 * d->in_features * 2,
-                                (char*)y + (size_t)t0 * d->out_features * yes, m, out_f32, lflags, st);
-      if (e != hipSuccess) return hip_fail(e, "gemv_lds launch");
+      e = launch((const char*)x + (size_t)t0 * xrow, (char*)y + (size_t)t0 * yrow, m);
+      if (e != hipSuccess) return hip_fail(e, what);
     }
     return VPTQ_OK;
-  }
-  if (!(flags & VPTQ_GEMV_FORCE_GENERIC) && vptq::gemv_gatherx_eligible(*d, chunk) &&
-      (((uintptr_t)x) & 3) == 0) {
-    const int step = vptq::gemv_gatherx_max_chunk(*d);   // 8 token slots for v <= 8, else 4
-    for (int t0 = 0; t0 < tokens; t0 += step) {
-      const int m = tokens - t0 < step ? tokens - t0 : step;
-      e = vptq::launch_gemv_gatherx(*d, (const char*)x + (size_t)t0 * d->in_features * 2,
-                                    (char*)y + (size_t)t0 * d->out_features * yes, m, out_f32, st);
-      if (e != hipSuccess) return hip_fail(e, "gemv_gatherx launch");
+  };
+  switch (route_gemv(*d, tokens, flags, x)) {
+    case kRouteGemmK256:   // tokens = the M dimension of a 16x16x16 MFMA; reference arithmetic
+      return chunks(16, "gemm_k256 launch", [&](const void* xc, void* yc, int m) {
+        return vptq::launch_gemm_k256(*d, xc, yc, m, out_f32, st); });
+    case kRouteK256:
+      return chunks(4, "gemv_k256 launch", [&](const void* xc, void* yc, int m) {
+        return vptq::launch_gemv_k256(d, 1, &xc, &yc, m, flags, st); });
+    case kRouteGather:     // up to 8 tokens per pass over the indices
+      return chunks(8, "gemv_gather launch", [&](const void* xc, void* yc, int m) {
+        return vptq::launch_gemv_gather(*d, xc, yc, m, out_f32, st); });
+    case kRouteLds: {
+      // every token of one call in the same arithmetic: the one-token MFMA form only for one-token calls
+      const int lflags = tokens > 1 ? (flags | VPTQ_GEMV_EXACT) : flags;
+      return chunks(vptq::gemv_lds_max_chunk(d->dtype), "gemv_lds launch", [&](const void* xc, void* yc, int m) {
+        return vptq::launch_gemv_lds(*d, xc, yc, m, out_f32, lflags, st); });
     }
-    return VPTQ_OK;
+    case kRouteGatherX:    // 8 token slots for v <= 8, else 4
+      return chunks(vptq::gemv_gatherx_max_chunk(*d), "gemv_gatherx launch", [&](const void* xc, void* yc, int m) {
+        return vptq::launch_gemv_gatherx(*d, xc, yc, m, out_f32, st); });
+    case kRouteGeneric:    // the generic kernel takes up to 8 tokens per launch
+      return chunks(8, "gemv_generic launch", [&](const void* xc, void* yc, int m) {
+        return vptq::launch_gemv_generic(*d, xc, yc, m, out_f32, st); });
+    default:
+      return fail(VPTQ_E_TOKENS, "tokens %d outside [1, %d] for this layer: use vptq_dequant + GEMM", tokens,
+                  VPTQ_GEMV_MAX_TOKENS_ANY);
   }
-  for (int t0 = 0; t0 < tokens; t0 += 8) {  // the generic kernel takes up to 8 tokens per launch
-    const int m = tokens - t0 < 8 ? tokens - t0 : 8;
-    e = vptq::launch_gemv_generic(*d, (const char*)x + (size_t)t0 * d->in_features * 2,
-                                  (char*)y + (size_t)t0 * d->out_features * yes, m, out_f32, st);
-    if (e != hipSuccess) return hip_fail(e, "gemv_generic launch");
-  }
-  return VPTQ_OK;
 }
 
 int vptq_quant_gemv_grouped(const VptqLayerDesc* descs, int n, const void* const* x,
