@@ -432,3 +432,55 @@ def test_command_line_options_match_the_reference():
         app.define_basic_args().parse_args([])      # --model is required
     for fn in ("define_basic_args", "eval_prompt", "chat_loop", "get_chat_loop_generator", "get_valid_args", "main"):
         assert callable(getattr(app, fn))
+
+
+def test_command_line_chat_loop_logic_without_gpu(capsys):
+    """chat_loop / eval_prompt with stand-ins for model and tokenizer: turns alternate, the reply is what follows
+    the prompt tokens, `exit` / an empty line end the chat, no chat template -> prompt completion (reference
+    vptq/app_utils.py:65-110)."""
+    import types
+    import vptq_amd.app_utils as app
+
+    class Tok:
+        chat_template = "x"
+
+        def __call__(self, text, return_tensors=None):
+            class Enc(dict):
+                def to(self, dev):
+                    return self
+            return Enc(input_ids=torch.tensor([[1, 2, 3]]))
+
+        def apply_chat_template(self, messages, add_generation_prompt=True, return_tensors=None):
+            self.last = [dict(m) for m in messages]
+            return torch.arange(len(messages) * 2).reshape(1, -1)
+
+        def batch_decode(self, ids, skip_special_tokens=True):
+            return ["reply-%d" % ids.shape[-1]]
+
+        def decode(self, *a, **k):
+            return ""
+
+    class Model:
+        device = torch.device("cpu")
+
+        def generate(self, ids=None, streamer=None, max_new_tokens=0, **kw):
+            self.kw = dict(kw, max_new_tokens=max_new_tokens)
+            base = ids if ids is not None else kw["input_ids"]
+            return torch.cat([base, torch.zeros(1, 3, dtype=base.dtype)], dim=1)
+
+    tok, model = Tok(), Model()
+    args = app.define_basic_args().parse_args(["--model", "m", "--chat", "--chat-system-prompt", "sys"])
+    lines = iter(["hello", "again", ""])
+    hist = app.chat_loop(model, tok, args, read=lambda p: next(lines))
+    assert [m["role"] for m in hist] == ["system", "user", "assistant", "user", "assistant"]
+    assert hist[0]["content"] == "sys" and hist[1]["content"] == "hello" and hist[2]["content"] == "reply-3"
+    assert model.kw["max_new_tokens"] == 500 and model.kw["do_sample"] is True and model.kw["pad_token_id"] == 2
+    assert tok.last[-1] == {"role": "user", "content": "again"}
+    # prompt completion: 100 greedy tokens
+    args2 = app.define_basic_args().parse_args(["--model", "m", "--prompt", "p"])
+    out = app.chat_loop(model, tok, args2)
+    assert out.shape == (1, 6) and model.kw["max_new_tokens"] == 100 and "do_sample" not in model.kw
+    # no chat template: falls back to the prompt completion with a warning
+    tok.chat_template = None
+    out = app.chat_loop(model, tok, args)
+    assert out.shape == (1, 6) and "no chat_template" in capsys.readouterr().out
