@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define VPTQ_ABI_VERSION 5
+#define VPTQ_ABI_VERSION 6
 
 #if defined(__GNUC__)
 #define VPTQ_API __attribute__((visibility("default")))
@@ -88,7 +88,10 @@ enum {
    * stored un-rounded.  For callers that combine several launches before the one rounding of
    * the reference's F.linear - the partial outputs of a row-parallel (input-column) shard,
    * summed by an all-reduce.  Every kernel honours it (ABI >= 4). */
-  VPTQ_GEMV_OUT_F32 = 1 << 5
+  VPTQ_GEMV_OUT_F32 = 1 << 5,
+  /* vptq_quant_gemv_chain only: layer i + 1 reads what layer i wrote (x[i + 1] aliases y[i]);
+   * without it the layers of a chain must be independent of each other (ABI >= 6) */
+  VPTQ_GEMV_CHAIN_DEPENDENT = 1 << 6
 };
 
 /* most tokens vptq_quant_gemv accepts (fp16 layers of the canonical format; every other layer:
@@ -206,6 +209,31 @@ VPTQ_API int vptq_quant_gemv_max_tokens(const VptqLayerDesc* desc);
 #define VPTQ_GROUP_MAX 64
 VPTQ_API int vptq_quant_gemv_grouped(const VptqLayerDesc* descs, int n, const void* const* x,
                             void* const* y, int tokens, int flags, void* stream);
+
+/*
+ * n layers walked ONE AFTER THE OTHER by a single persistent launch (ABI >= 6): what the reference
+ * does as n calls of `quant_gemv` (vptq/ops/quant_gemm.py:214-228, one per VQuantLinear of a decode
+ * step), each of which pays a launch boundary, a prologue (codebooks into shared memory,
+ * activations) and an epilogue.  Here every workgroup streams layer i's index words and, while it
+ * does, requests layer i + 1's codebooks, activations and first index words, so HBM never idles
+ * between layers.  Results are those of n vptq_quant_gemv calls in order (same arithmetic).
+ *   - independent layers (default): no layer reads another layer's output (q / k / v, gate / up,
+ *     a ring of benchmark layers): the layers overlap freely.
+ *   - VPTQ_GEMV_CHAIN_DEPENDENT: x[i + 1] may be y[i]; a device-scope arrival counter per layer
+ *     orders them.  Needs workspace of vptq_quant_gemv_chain_workspace_bytes(n, flags) bytes (the
+ *     call clears it on the stream).
+ * Served by one launch per <= 32 layers when every layer is of the canonical v=8 / 256+256 format,
+ * one dtype, without a permutation (absorb it first), tokens == 1
+ * (vptq_quant_gemv_chain_kernel_name says "gemv_k256t_kernel"); anything else is executed as n
+ * vptq_quant_gemv calls ("per-layer").  descs is a HOST array; x[i], y[i] device pointers.
+ */
+#define VPTQ_CHAIN_MAX 1024
+VPTQ_API int vptq_quant_gemv_chain(const VptqLayerDesc* descs, int n, const void* const* x,
+                          void* const* y, int tokens, int flags, void* workspace,
+                          size_t workspace_bytes, void* stream);
+VPTQ_API size_t vptq_quant_gemv_chain_workspace_bytes(int n, int flags);
+VPTQ_API const char* vptq_quant_gemv_chain_kernel_name(const VptqLayerDesc* descs, int n, int tokens,
+                                              int flags);
 
 /*
  * Many tokens (prefill): y[tokens, O] = x[tokens, I] @ W^T + bias with the dequantisation FUSED

@@ -1,0 +1,192 @@
+"""GPU parity of the persistent layer-chain launch (`vptq_quant_gemv_chain`, gemv_k256t.hip):
+every layer of a chain against the oracle / the reference goldens, through the C ABI.
+
+Bar as everywhere: max|d| / max|ref| <= 1e-3 (fp16), 8e-3 (bf16)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vptq_oracle as vo
+from _cases import rel_err, big_names, load_big
+from _gpu_util import spec_to_module, bits_to_tensor, tensor_to_bits, gemv_abi
+
+pytestmark = pytest.mark.gpu
+TOL = {"f16": 1e-3, "bf16": 8e-3}
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from vptq_amd import _backend as B
+    B.lib()
+    return torch.device("cuda", 0)
+
+
+def _x(I, dt, dist, seed, tokens=1):
+    rng = np.random.default_rng(seed)
+    xs = (0.02 + 0.5 * rng.standard_normal((1, tokens, I))) if dist == "ref-test" else rng.standard_normal((1, tokens, I))
+    return vo.from_f32(xs.astype(np.float32), dt)
+
+
+# (I, O, kwargs): shapes that hit every edge of the kernel's stream: rows not a multiple of 4
+# (partial row group), columns not a multiple of 2048 (partial sweep), one and several sweeps,
+# fewer / more row groups than workgroups, output bias
+SHAPES = [
+    (1024, 512, dict()),
+    (4096, 264, dict()),
+    (4104, 64, dict(bias=True)),
+    (8192 + 512, 40, dict(dist="llm")),
+    (512, 1000, dict(dist="llm", bias=True)),
+    (2048, 2048 * 5, dict(dist="llm")),      # 1280 row groups: several per workgroup
+    (6144, 24, dict()),
+    (256, 8, dict()),                        # one row group, one partial sweep
+]
+
+
+def _build(shapes, dt, dev):
+    Ls, ms, xs = [], [], []
+    for i, (I, O, kw) in enumerate(shapes):
+        kw = dict(kw)
+        dist = kw.pop("dist", "ref-test")
+        L = vo.make_layer(I, O, dist=dist, seed=1000 + 7 * i + I + O, dtype=dt, **kw)
+        Ls.append(L)
+        ms.append(spec_to_module(L, dev))
+        xs.append(_x(I, dt, dist, 31 + i))
+    return Ls, ms, xs
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+def test_independent_chain_every_layer_vs_oracle(dt, dev):
+    from vptq_amd.ops.chain import GemvChain
+    Ls, ms, xs = _build(SHAPES, dt, dev)
+    chain = GemvChain(ms)
+    assert chain.kernel_name(1, 0) == "gemv_k256t_kernel"
+    xt = [bits_to_tensor(x, dt, dev).reshape(x.shape) for x in xs]
+    ys = chain(xt, flags=0)
+    torch.cuda.synchronize()
+    for L, x, y in zip(Ls, xs, ys):
+        want = vo.forward(L, x)
+        err = rel_err(tensor_to_bits(y), want, dt)
+        assert err <= TOL[dt], f"{L.in_features}x{L.out_features}: {err:.3e}"
+    # the same layers in another order and as single-layer chains: same bits (every layer's sums are
+    # formed in the same order wherever it sits in the stream)
+    order = [3, 0, 5, 7, 1, 6, 2, 4]
+    ys2 = GemvChain([ms[i] for i in order])([xt[i] for i in order], flags=0)
+    for j, i in enumerate(order):
+        assert torch.equal(ys2[j].view(torch.int16), ys[i].view(torch.int16))
+    for i in (0, 2, 5):
+        y1 = GemvChain([ms[i]])([xt[i]], flags=0)[0]
+        assert torch.equal(y1.view(torch.int16), ys[i].view(torch.int16))
+
+
+def test_chain_float32_outputs(dev):
+    from vptq_amd.ops.chain import GemvChain
+    from vptq_amd import _backend as B
+    Ls, ms, xs = _build(SHAPES[:4], "f16", dev)
+    xt = [bits_to_tensor(x, "f16", dev).reshape(x.shape) for x in xs]
+    y16 = GemvChain(ms)(xt, flags=0)
+    y32 = GemvChain(ms)(xt, flags=B.GEMV_OUT_F32)
+    for a, b in zip(y16, y32):
+        assert b.dtype == torch.float32
+        assert torch.equal(b.half().view(torch.int16), a.view(torch.int16))   # one rounding of the same sums
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+def test_dependent_chain(dt, dev):
+    """x of layer i + 1 is y of layer i: every layer against the oracle applied to the GPU's own
+    previous output (so the per-layer bar applies), and against the same layers launched one by one."""
+    from vptq_amd.ops.chain import GemvChain
+    dims = [1024, 2048, 512, 4096, 264, 1032, 1024]
+    shapes = [(dims[i], dims[i + 1], dict(dist="llm", bias=(i % 3 == 1))) for i in range(len(dims) - 1)]
+    Ls, ms, _ = _build(shapes, dt, dev)
+    x0 = _x(dims[0], dt, "llm", 5)
+    xt = bits_to_tensor(x0, dt, dev).reshape(x0.shape)
+    chain = GemvChain(ms, dependent=True)
+    assert chain.kernel_name(1, 0) == "gemv_k256t_kernel"
+    for rep in range(3):   # (the arrival counters are cleared by every call)
+        ys = chain([xt], flags=0)
+        torch.cuda.synchronize()
+        xin = x0
+        for L, y in zip(Ls, ys):
+            want = vo.forward(L, xin)
+            err = rel_err(tensor_to_bits(y), want, dt)
+            assert err <= TOL[dt], f"rep {rep} {L.in_features}x{L.out_features}: {err:.3e}"
+            xin = tensor_to_bits(y).reshape(1, 1, -1)
+    # layer by layer through single-layer chains: identical bits
+    xi = xt
+    for m, y in zip(ms, ys):
+        y1 = GemvChain([m])([xi], flags=0)[0]
+        assert torch.equal(y1.view(torch.int16), y.view(torch.int16))
+        xi = y1
+
+
+@pytest.mark.parametrize("name", big_names())
+def test_chain_on_reference_goldens_at_baseline_sizes(name, dev):
+    """hidden 4096 / 8192 layers whose y comes from the real reference (tests/golden/gen_golden_big.py):
+    one-token, permutation-free cases through the chain launch, alone and 6 times in a row."""
+    from vptq_amd.ops.chain import GemvChain
+    L, x, y, cfg, _ = load_big(name)
+    if cfg["tokens"] != 1 or cfg["perm"]:
+        pytest.skip("the chain kernel takes one token, no permutation")
+    dt = cfg["dtype"]
+    m = spec_to_module(L, dev)
+    xt = bits_to_tensor(x, dt, dev).reshape(x.shape)
+    chain = GemvChain([m] * 6)
+    assert chain.kernel_name(1, 0) == "gemv_k256t_kernel"
+    ys = chain([xt] * 6, flags=0)
+    torch.cuda.synchronize()
+    err = rel_err(tensor_to_bits(ys[0]), y, dt)
+    assert err <= TOL[dt], f"{name}: {err:.3e}"
+    for o in ys[1:]:
+        assert torch.equal(o.view(torch.int16), ys[0].view(torch.int16))
+    # against the library's one-launch-per-layer default (another kernel, same arithmetic form)
+    ref = gemv_abi(m, xt, 0)
+    assert rel_err(tensor_to_bits(ys[0]), tensor_to_bits(ref), dt) <= TOL[dt]
+
+
+def test_chain_falls_back_layer_by_layer(dev):
+    """a chain the one-launch kernel does not take (another format in it, 2 tokens) is executed as
+    single launches by the library: same results as the modules' forward"""
+    from vptq_amd.ops.chain import GemvChain
+    La = vo.make_layer(1024, 256, seed=3)
+    Lb = vo.make_layer(1024, 256, seed=4, num_centroids=4096, num_res_centroids=0, vector_len=6)
+    ma, mb = spec_to_module(La, dev), spec_to_module(Lb, dev)
+    xa = bits_to_tensor(_x(1024, "f16", "ref-test", 1), "f16", dev).reshape(1, 1, 1024)
+    chain = GemvChain([ma, mb])
+    assert chain.kernel_name(1, 0) == "per-layer"
+    ya, yb = chain([xa, xa])
+    assert torch.equal(ya, ma(xa)) and torch.equal(yb, mb(xa))
+    x2 = bits_to_tensor(_x(1024, "f16", "ref-test", 2, tokens=2), "f16", dev).reshape(1, 2, 1024)
+    c2 = GemvChain([ma, ma])
+    assert c2.kernel_name(2, 0) == "per-layer"
+    y2 = c2([x2, x2])
+    assert torch.equal(y2[0], ma(x2)) and torch.equal(y2[1], ma(x2))
+
+
+def test_chain_in_a_hipgraph_and_long_chains(dev):
+    """40 layers = two launches; captured once, replayed with new activations"""
+    from vptq_amd.ops.chain import GemvChain
+    L = vo.make_layer(2048, 1024, seed=11, dist="llm")
+    m = spec_to_module(L, dev)
+    n = 40
+    xs = [torch.zeros(1, 1, 2048, dtype=torch.float16, device=dev) for _ in range(n)]
+    ys = [torch.empty(1, 1, 1024, dtype=torch.float16, device=dev) for _ in range(n)]
+    chain = GemvChain([m] * n)
+    chain(xs, ys, flags=0)          # warm-up outside the capture
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            chain(xs, ys, flags=0)
+    for rep in range(2):
+        vals = [_x(2048, "f16", "llm", 100 + rep * n + i) for i in range(n)]
+        for xt, v in zip(xs, vals):
+            xt.copy_(bits_to_tensor(v, "f16", dev).reshape(1, 1, 2048))
+        g.replay()
+        torch.cuda.synchronize()
+        for i in (0, 17, 31, 32, 39):
+            err = rel_err(tensor_to_bits(ys[i]), vo.forward(L, vals[i]), "f16")
+            assert err <= 1e-3, (rep, i, err)

@@ -1,0 +1,125 @@
+#!/usr/bin/env python3
+"""Ring of R distinct layers, one decode token per layer, every mode captured in a hipGraph and
+replayed interleaved on the same box: us per layer for
+  single : one vptq_quant_gemv launch per layer (the library's default kernel)
+  t1     : one launch of the chain kernel (gemv_k256t) per layer
+  chainN : the ring as launches of N layers each (independent layers)
+  dep    : the ring as ONE dependent chain (x of layer i + 1 is y of layer i)
+python tools/chain_bench.py --hidden 8192 [--rows O] [--ring 32] [--reps 5] [--libs name=path,...]"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--hidden", type=int, default=8192)
+    ap.add_argument("--rows", type=int, default=0)
+    ap.add_argument("--ring", type=int, default=0)
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--modes", default="single,t1,chain4,chain32,dep")
+    ap.add_argument("--bf16", action="store_true")
+    ap.add_argument("--out", default="")
+    a = ap.parse_args()
+    import bench
+    from vptq_amd.ops.chain import GemvChain
+    from vptq_amd import _backend as B
+    dev = torch.device("cuda", 0)
+    I = a.hidden
+    O = a.rows or I
+    R = a.ring or max(4, (512 << 20) // (O // 8 * I * 2))
+    g = torch.Generator(device=dev).manual_seed(1)
+    ring = [bench.make_layer(I, O, dev, g) for _ in range(R)]
+    if a.bf16:
+        for m in ring:
+            m.to(torch.bfloat16)
+    dt = torch.bfloat16 if a.bf16 else torch.float16
+    x = torch.randn(1, 1, I, device=dev, generator=g).to(dt)
+    xs = [x] * R
+    ys = [torch.empty(1, 1, O, dtype=dt, device=dev) for _ in range(R)]
+    alg = bench.alg_bytes(I, O)
+
+    def run_single():
+        for m, y in zip(ring, ys):
+            d = m._descriptor()
+            B.check(d[4](d[1], x.data_ptr(), y.data_ptr(), 1, 0, None, 0, B.current_stream_ptr(dev)), "gemv")
+
+    chains = {}
+
+    def run_chain(n, dependent=False):
+        key = (n, dependent)
+        if key not in chains:
+            if dependent:
+                assert I == O
+                chains[key] = [GemvChain(ring, dependent=True)]
+            else:
+                chains[key] = [GemvChain(ring[i:i + n]) for i in range(0, R, n)]
+        if dependent:
+            chains[key][0]([x], ys, flags=0)
+        else:
+            for i, c in enumerate(chains[key]):
+                c(xs[i * n:(i + 1) * n], ys[i * n:(i + 1) * n], flags=0)
+
+    modes = {}
+    for name in a.modes.split(","):
+        if name == "single":
+            modes[name] = run_single
+        elif name == "t1":
+            modes[name] = lambda: run_chain(1)
+        elif name.startswith("chain"):
+            n = int(name[5:])
+            modes[name] = (lambda n: (lambda: run_chain(n)))(n)
+        elif name == "dep":
+            modes[name] = lambda: run_chain(R, True)
+    graphs = {}
+    s = torch.cuda.Stream()
+    ref = None
+    parity = {}
+    for name, fn in modes.items():
+        fn()
+        torch.cuda.synchronize()
+        if name != "dep":
+            out = torch.stack([y.float() for y in ys])
+            if ref is None:
+                ref = out
+            parity[name] = float((out - ref).abs().max() / ref.abs().max())
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(s):
+            with torch.cuda.graph(gr, stream=s):
+                fn()
+        graphs[name] = gr
+    res = {k: [] for k in graphs}
+    for rep in range(a.reps):
+        for name, gr in graphs.items():
+            gr.replay()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(a.iters):
+                gr.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            res[name].append(e0.elapsed_time(e1) * 1e3 / (a.iters * R))
+    summary = {"hidden": I, "rows": O, "ring": R, "alg_bytes": alg, "dtype": str(dt)}
+    for name, v in res.items():
+        v = sorted(v)
+        med = v[len(v) // 2]
+        summary[name] = {"us_per_layer": round(med, 3), "min": round(v[0], 3), "max": round(v[-1], 3),
+                         "GBps": round(alg / med / 1e3, 1), "frac_8TBps": round(alg / med / 1e3 / 8000, 3),
+                         "parity_vs_first": parity.get(name)}
+        print(f"{name:10s} {med:8.3f} us/layer  ({v[0]:.3f} .. {v[-1]:.3f})  {alg / med / 1e3:8.1f} GB/s  "
+              f"frac {alg / med / 1e3 / 8000:.3f}  parity {parity.get(name)}")
+    if a.out:
+        with open(a.out, "w") as f:
+            json.dump(summary, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # VPTQ_HIP_LIB: load another build of the library (A/B runs of tools/)
 LIB_PATH = os.environ.get("VPTQ_HIP_LIB") or os.path.join(_HERE, "libvptq_hip.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 DTYPE_F16, DTYPE_BF16 = 0, 1
 GEMV_FAST_MATH = 1 << 0
 GEMV_FORCE_GENERIC = 1 << 1
@@ -28,7 +28,9 @@ GEMV_FORCE_VALU = 1 << 4
 GEMV_OUT_F32 = 1 << 5     # y is float32: un-rounded sums (row-parallel partial outputs)
 GEMV_MAX_TOKENS = 64       # most vptq_quant_gemv accepts (any layer: 16); per layer: vptq_quant_gemv_max_tokens
 GEMV_ANY_FORMAT_TOKENS = 8  # the fused GEMV is the faster path for every format up to here
+GEMV_CHAIN_DEPENDENT = 1 << 6  # vptq_quant_gemv_chain: layer i + 1 reads what layer i wrote
 GROUP_MAX = 64
+CHAIN_MAX = 1024
 
 _vp = C.c_void_p
 
@@ -64,6 +66,10 @@ EXPORTS = {
     "vptq_quant_gemv_max_tokens": (C.c_int, [C.POINTER(LayerDesc)]),
     "vptq_quant_gemv_grouped": (C.c_int, [C.POINTER(LayerDesc), C.c_int, C.POINTER(_vp),
                                           C.POINTER(_vp), C.c_int, C.c_int, _vp]),
+    "vptq_quant_gemv_chain": (C.c_int, [C.POINTER(LayerDesc), C.c_int, C.POINTER(_vp), C.POINTER(_vp),
+                                        C.c_int, C.c_int, _vp, C.c_size_t, _vp]),
+    "vptq_quant_gemv_chain_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "vptq_quant_gemv_chain_kernel_name": (C.c_char_p, [C.POINTER(LayerDesc), C.c_int, C.c_int, C.c_int]),
     "vptq_dequant": (C.c_int, [C.POINTER(LayerDesc), _vp, _vp]),
     "vptq_quant_gemm_supported": (C.c_int, [C.POINTER(LayerDesc)]),
     "vptq_quant_gemm_workspace_bytes": (C.c_size_t, [C.POINTER(LayerDesc), C.c_int]),

@@ -143,7 +143,7 @@ const char* vptq_quant_gemv_kernel_name(const VptqLayerDesc* d, int tokens, int 
 
 const char* vptq_quant_gemv_grouped_kernel_name(const VptqLayerDesc* descs, int n, int tokens,
                                                 int flags) {
-  if (!descs || n < 1 || n > 32 || tokens < 1 || tokens > VPTQ_GEMV_MAX_TOKENS_ANY) return nullptr;
+  if (!descs || n < 1 || n > VPTQ_GROUP_MAX || tokens < 1 || tokens > VPTQ_GEMV_MAX_TOKENS_ANY) return nullptr;
   bool one_launch = !(flags & VPTQ_GEMV_FORCE_GENERIC);
   for (int i = 0; i < n; ++i) {
     if (validate_layer(&descs[i]) != VPTQ_OK) return nullptr;
@@ -244,6 +244,65 @@ int vptq_quant_gemv_grouped(const VptqLayerDesc* descs, int n, const void* const
   for (int i = 0; i < n; ++i) {
     const int rc = vptq_quant_gemv(&descs[i], x[i], y[i], tokens, flags, nullptr, 0, stream);
     if (rc) return rc;
+  }
+  return VPTQ_OK;
+}
+
+// ---- chain: one persistent launch per <= 32 layers (gemv_k256t.hip), else layer by layer ----
+static bool chain_one_kernel(const VptqLayerDesc* descs, int n, const void* const* x, int tokens, int flags) {
+  if (tokens != 1 || (flags & (VPTQ_GEMV_FORCE_GENERIC | VPTQ_GEMV_EXACT | VPTQ_GEMV_FORCE_VALU))) return false;
+  for (int i = 0; i < n; ++i) {
+    if (descs[i].dtype != descs[0].dtype || !vptq::gemv_k256t_eligible(descs[i], tokens)) return false;
+    if (x && (((uintptr_t)x[i]) & 3) != 0) return false;
+  }
+  return true;
+}
+
+size_t vptq_quant_gemv_chain_workspace_bytes(int n, int flags) {
+  return (flags & VPTQ_GEMV_CHAIN_DEPENDENT) && n > 0 ? (size_t)n * 4 : 0;
+}
+
+const char* vptq_quant_gemv_chain_kernel_name(const VptqLayerDesc* descs, int n, int tokens, int flags) {
+  if (!descs || n < 1 || n > VPTQ_CHAIN_MAX || tokens < 1 || tokens > VPTQ_GEMV_MAX_TOKENS) return nullptr;
+  for (int i = 0; i < n; ++i)
+    if (validate_layer(&descs[i]) != VPTQ_OK) return nullptr;
+  return chain_one_kernel(descs, n, nullptr, tokens, flags) ? "gemv_k256t_kernel" : "per-layer";
+}
+
+int vptq_quant_gemv_chain(const VptqLayerDesc* descs, int n, const void* const* x, void* const* y,
+                          int tokens, int flags, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!descs || !x || !y) return fail(VPTQ_E_NULL, "descs / x / y is NULL");
+  if (n < 1 || n > VPTQ_CHAIN_MAX) return fail(VPTQ_E_SHAPE, "n %d outside [1, %d]", n, VPTQ_CHAIN_MAX);
+  if (tokens < 1 || tokens > VPTQ_GEMV_MAX_TOKENS)
+    return fail(VPTQ_E_TOKENS, "tokens %d outside [1, %d]", tokens, VPTQ_GEMV_MAX_TOKENS);
+  for (int i = 0; i < n; ++i) {
+    const int rc = validate_layer(&descs[i]);
+    if (rc) return rc;
+    if (!x[i] || !y[i]) return fail(VPTQ_E_NULL, "x[%d] / y[%d] is NULL", i, i);
+  }
+  const bool dependent = (flags & VPTQ_GEMV_CHAIN_DEPENDENT) != 0;
+  const int lflags = flags & ~VPTQ_GEMV_CHAIN_DEPENDENT;
+  hipStream_t st = (hipStream_t)stream;
+  if (!chain_one_kernel(descs, n, x, tokens, flags)) {
+    // stream order is the dependency
+    for (int i = 0; i < n; ++i) {
+      const int rc = vptq_quant_gemv(&descs[i], x[i], y[i], tokens, lflags, nullptr, 0, stream);
+      if (rc) return rc;
+    }
+    return VPTQ_OK;
+  }
+  if (dependent) {
+    const size_t need = vptq_quant_gemv_chain_workspace_bytes(n, flags);
+    if (!workspace || workspace_bytes < need || (((uintptr_t)workspace) & 3) != 0)
+      return fail(VPTQ_E_WORKSPACE, "dependent chain: workspace of %zu bytes (4-byte aligned) needed", need);
+    const hipError_t e = hipMemsetAsync(workspace, 0, need, st);
+    if (e != hipSuccess) return hip_fail(e, "chain workspace clear");
+  }
+  for (int i0 = 0; i0 < n; i0 += 32) {
+    const int m = n - i0 < 32 ? n - i0 : 32;
+    const hipError_t e = vptq::launch_gemv_k256t(descs + i0, m, x + i0, y + i0, lflags, dependent,
+                                                 dependent ? (uint32_t*)workspace + i0 : nullptr, st);
+    if (e != hipSuccess) return hip_fail(e, "gemv_k256t launch");
   }
   return VPTQ_OK;
 }
