@@ -1,0 +1,14 @@
+#!/bin/bash
+# round 3, session 4: the chain kernel with incremental cursors (a step's bookkeeping = a handful of instructions)
+OUT=gpurun_out/r3d; mkdir -p $OUT
+B=$PWD/tools/_build
+VPTQ_HIP_LIB=$B/libvptq_hip_lim.so timeout 900 python -m pytest tests/test_chain_gpu.py -x -q -m gpu 2>&1 | tail -8 | tee $OUT/test_chain_lim.txt
+timeout 300 python tools/chain_bench.py --hidden 8192 --out $OUT/chain_8192_d4.json 2>&1 | grep -v amdgpu.ids | tee $OUT/chain_8192_d4.txt
+for v in d2 d3 d6 abl1 abl2 abl3 abl15; do
+  echo "--- $v"
+  VPTQ_HIP_LIB=$B/libvptq_hip_$v.so timeout 300 python tools/chain_bench.py --hidden 8192 --modes t1,chain32 --out $OUT/chain_8192_$v.json 2>&1 | grep -v amdgpu.ids | tee $OUT/chain_8192_$v.txt
+done
+echo "--- tall layer 65536 x 8192"
+timeout 300 python tools/chain_bench.py --hidden 8192 --rows 65536 --ring 4 --modes single,t1 --out $OUT/tall.json 2>&1 | grep -v amdgpu.ids | tee $OUT/tall.txt
+VPTQ_HIP_LIB=$B/libvptq_hip_abl15.so timeout 300 python tools/chain_bench.py --hidden 8192 --rows 65536 --ring 4 --modes t1 --out $OUT/tall_abl15.json 2>&1 | grep -v amdgpu.ids | tee $OUT/tall_abl15.txt
+timeout 300 python tools/chain_bench.py --hidden 4096 --modes single,t1,chain8,chain32,dep --out $OUT/chain_4096.json 2>&1 | grep -v amdgpu.ids | tee $OUT/chain_4096.txt

@@ -301,7 +301,8 @@ int vptq_quant_gemv_chain(const VptqLayerDesc* descs, int n, const void* const* 
   for (int i0 = 0; i0 < n; i0 += 32) {
     const int m = n - i0 < 32 ? n - i0 : 32;
     const hipError_t e = vptq::launch_gemv_k256t(descs + i0, m, x + i0, y + i0, lflags, dependent,
-                                                 dependent ? (uint32_t*)workspace + i0 : nullptr, st);
+                                                 dependent ? (uint32_t*)workspace + i0
+                                                           : (getenv("VPTQ_K256T_PROF") ? (uint32_t*)workspace : nullptr), st);
     if (e != hipSuccess) return hip_fail(e, "gemv_k256t launch");
   }
   return VPTQ_OK;

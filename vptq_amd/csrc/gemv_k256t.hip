@@ -51,11 +51,12 @@ constexpr int kTSweepCols = kTWaves * kTBlockCols;   // 2048
 constexpr uint32_t kTImgBytes = 65536;               // 256 rows x 16 units x 16 B
 constexpr uint32_t kTXsOff = 2 * kTImgBytes;         // wave-private activation slots
 constexpr uint32_t kTXsWave = 256;
-constexpr int kTSlots = 2;                           // cross-wave partial-sum slots
+constexpr int kTSlots = 4;                           // cross-wave partial-sum slots
 constexpr uint32_t kTRedOff = kTXsOff + kTWaves * kTXsWave;
 constexpr uint32_t kTRedBOff = kTRedOff + kTSlots * kTWaves * 32 * 4;
 constexpr uint32_t kTCntOff = kTRedBOff + kTSlots * kTWaves * 4;
-constexpr uint32_t kTLdsBytes = kTCntOff + 64;
+constexpr uint32_t kTTabOff = kTCntOff + 64;            // the launch's layer arguments, 128 B per layer
+constexpr uint32_t kTLdsBytes = kTTabOff + kMaxGroup * 128;
 
 // transposing-gather convention (tools/tr_probe.hip prints what the hardware does):
 // 0: source lane 4e + c -> result lane 4c + m, element e (ck_tile's Quad16 encoding)
@@ -68,13 +69,38 @@ constexpr uint32_t kTLdsBytes = kTCntOff + 64;
 #ifndef VPTQ_K256T_ROTH
 #define VPTQ_K256T_ROTH 1
 #endif
-// timing-only ablations (results wrong): bit 0 no MFMAs, bit 1 no gathers
+// timing-only ablations (results wrong): bit 0 no MFMAs, bit 1 no gathers, bit 2 no x / scale / bias loads,
+// bit 3 no waits for the image hand-over between the waves, bit 4 index words read as 1 KiB contiguous per wave
 #ifndef VPTQ_K256T_ABLATE
 #define VPTQ_K256T_ABLATE 0
+#endif
+// sweeps in flight per wave (16 bytes of index words + 12 bytes of x / scale / bias per lane each):
+// bandwidth x latency under load is ~2.3 us x 21 GB/s per CU = 48 KiB = 3 sweeps of the 16 waves
+#ifndef VPTQ_K256T_DEPTH
+#define VPTQ_K256T_DEPTH 4
 #endif
 #ifndef VPTQ_K256T_SPIN_LIMIT
 #define VPTQ_K256T_SPIN_LIMIT 0
 #endif
+// profiling build (tools/chain_prof.py): every wave adds up the shader-clock cycles it spends
+// waiting for its index words, consuming a sweep, requesting the next one and in the rare paths,
+// and stores them at P.sync[(workgroup * 16 + wave) * 8 ...] (non-dependent launches)
+#ifndef VPTQ_K256T_PROF
+#define VPTQ_K256T_PROF 0
+#endif
+// the sweep's arithmetic: 1 = gather with ds_read_b128, accumulate with v_mfma_f32_4x4x4 as 64 x 4 FMAs
+// (the loop of gemv_k256m.hip); 0 = transposing gather + v_mfma_f32_16x16x32 (file comment).  In
+// isolation (tools/ubench_loop_t.hip, 4 waves per SIMD, no HBM): 34.6 against 46.8 SIMD cycles per
+// index-wave - both sit on the LDS (32 cycles per index-wave and SIMD for the 2 KiB of gathered
+// entries) and the matrix pipe (32), the 4x4x4 form overlaps them better.
+#ifndef VPTQ_K256T_LOOP
+#define VPTQ_K256T_LOOP 1
+#endif
+#ifndef VPTQ_K256T_BALANCE
+#define VPTQ_K256T_BALANCE 1
+#endif
+constexpr int kTDepth = VPTQ_K256T_DEPTH;            // queue slots = sweeps in flight
+static_assert(kTDepth >= 2 && kTDepth <= 8, "queue depth");
 
 struct K256TParams {
   int n_layers;
@@ -136,11 +162,30 @@ static __device__ __forceinline__ K256Layer t_load_layer(int L) {
   return Ly;
 }
 
+// ... and out of the copy in LDS (kTTabOff; filled once per workgroup): a trip to the kernel-argument
+// segment costs ~0.4 us, and a wave makes three of them per layer it enters
+static __device__ __forceinline__ K256Layer t_load_layer_lds(int L) {
+  const uint32_t a = kTTabOff + (uint32_t)L * 128u;
+  uint32_t w[32];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const u32x4 v = lds_load16(a + 16u * i);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[4 * i + j] = (uint32_t)__builtin_amdgcn_readfirstlane((int)v[j]);
+  }
+  K256Layer Ly;
+  __builtin_memcpy((char*)&Ly, w, sizeof(K256Layer));
+  Ly.idx = as_global(Ly.idx); Ly.cent = as_global(Ly.cent); Ly.rcent = as_global(Ly.rcent);
+  Ly.x = as_global(Ly.x); Ly.y = as_global(Ly.y); Ly.scale = as_global(Ly.scale);
+  Ly.wbias = as_global(Ly.wbias); Ly.bias = as_global(Ly.bias);
+  return Ly;
+}
+
 // position in the workgroup's flat stream of sweeps; everything is wave-uniform
 struct TCursor {
   int L;    // layer; n_layers = past the end
   int rg;   // row group (4 vector-rows)
-  int s;    // sweep inside the row group
+  int re;   // end of this workgroup's block of row groups in layer L
   int ns;   // sweeps per row group of layer L
   int ng;   // row groups of layer L
 };
@@ -189,6 +234,22 @@ __global__ __launch_bounds__(kTThreads) void gemv_k256t_kernel(const K256TParams
   // what this lane HOLDS after a read: vector-row c' of its group; chunk of read h = h ^ (c' & 1)
   const uint32_t hold_h = VPTQ_K256T_ROTH ? (res_c & 1u) : 0u;
 
+  // ---- (VPTQ_K256T_LOOP = 1) lane = (column chunk blk = lane >> 2, vector-row j = lane & 3); the two
+  // gathers of an index are split across the lanes: in gather A the lanes with bit 3 clear fetch the
+  // main entry (unit lane & 7), the others the residual entry (unit 8 + (lane & 7)); gather B is the
+  // complement: every 16-lane group of a ds_read_b128 touches 16 different units (gemv_k256m.hip)
+  const uint32_t jrow = (uint32_t)lane & 3u;
+  const uint32_t hi8 = ((uint32_t)lane >> 3) & 1u;
+  uint32_t baseA = ((hi8 << 3) | ((uint32_t)lane & 7u)) << 4;            // byte 2 = image buffer
+  uint32_t baseB = (((hi8 ^ 1u) << 3) | ((uint32_t)lane & 7u)) << 4;
+  const uint32_t selGA[2] = {0x0c020400u | (hi8 << 8), 0x0c020600u | (hi8 << 8)};
+  const uint32_t selGB[2] = {0x0c020400u | ((hi8 ^ 1u) << 8), 0x0c020600u | ((hi8 ^ 1u) << 8)};
+  // x operand of the 4x4x4 MFMA: x' * e_j as two packed pairs, cut out of a packed x' register
+  const uint32_t selA[2] = {jrow == 0 ? 0x0c0c0504u : jrow == 1 ? 0x05040c0cu : 0x0c0c0c0cu,
+                            jrow == 0 ? 0x0c0c0706u : jrow == 1 ? 0x07060c0cu : 0x0c0c0c0cu};
+  const uint32_t selB[2] = {jrow == 2 ? 0x0c0c0504u : jrow == 3 ? 0x05040c0cu : 0x0c0c0c0cu,
+                            jrow == 2 ? 0x0c0c0706u : jrow == 3 ? 0x07060c0cu : 0x0c0c0c0cu};
+
   // ---- LDS map: [0, 64 Ki) image buffer 0 | [64 Ki, 128 Ki) image buffer 1 | per wave 256 B of
   // staged activations | partial-sum slots | counters
   const uint32_t xs_base = kTXsOff + (uint32_t)wave * kTXsWave;
@@ -198,40 +259,63 @@ __global__ __launch_bounds__(kTThreads) void gemv_k256t_kernel(const K256TParams
   // tiles 2 (lane & 3) and + 1 -> pair p = lane & 3, group j >> 2, e = j & 3
   const uint32_t st_addr = xs_base + (((uint32_t)lane & 3u) << 6) + (((uint32_t)lane >> 4) << 4) +
                            ((((uint32_t)lane >> 2) & 3u) << 1);
+  // (VPTQ_K256T_LOOP = 1: the slot in column order; lane (blk, j) reads the 16 bytes of its chunk)
+  const uint32_t st_addr1 = xs_base + (uint32_t)lane * 4u;
+  const uint32_t xq_addr = xs_base + ((uint32_t)lane >> 2) * 16u;
   float* const red = (float*)(smem + kTRedOff);      // [slot][wave][32]
   float* const red_b = (float*)(smem + kTRedBOff);   // [slot][wave]
-  uint32_t* const slot_cnt = (uint32_t*)(smem + kTCntOff);  // [2] waves arrived
-  uint32_t* const slot_done = slot_cnt + 2;                 // [2] row groups finished
-  uint32_t* const free_cnt = slot_cnt + 4;                  // [2] waves that left a layer of image buffer b
-  uint32_t* const ready_cnt = slot_cnt + 6;                 // [2] waves whose part of a fill has landed
+  uint32_t* const slot_cnt = (uint32_t*)(smem + kTCntOff);  // [kTSlots] waves arrived
+  uint32_t* const slot_done = slot_cnt + kTSlots;           // [kTSlots] row groups finished
+  uint32_t* const free_cnt = slot_cnt + 2 * kTSlots;        // [2] waves that left a layer of image buffer b
+  uint32_t* const ready_cnt = free_cnt + 2;                 // [2] waves whose part of a fill has landed
+  uint32_t* const dep_seen = free_cnt + 4;                  // DEP: last layer whose producers wave 0 has seen arrive
 
   // ---- the flat stream ----
-  // first layer >= c.L in which this workgroup owns a row group: its row groups are r0, r0 + W, ...
-  // with r0 = (bid - first workgroup of the layer) mod W (K256Layer::wgs = the running total of
-  // row groups mod W: the layers continue each other's round robin).  Returns that layer's
+  // first layer >= c.L in which this workgroup owns row groups: a block of K256Layer::pf_chunk
+  // consecutive ones, block number (bid - first workgroup of the layer) mod W (K256Layer::wgs = the
+  // running total of blocks mod W: the layers continue each other's round robin, so that layers
+  // that need fewer than W blocks run side by side on different workgroups).  Returns that layer's
   // arguments (undefined past the end).
-  auto enter_layer = [&](TCursor& c) -> K256Layer {
-    K256Layer Ly = t_load_layer(c.L < n_layers ? c.L : n_layers - 1);
+  auto enter_layer = [&](TCursor& c, auto from_lds) -> K256Layer {
+    constexpr bool kLds = decltype(from_lds)::value;
+    const int L0 = c.L < n_layers ? c.L : n_layers - 1;
+    K256Layer Ly = kLds ? t_load_layer_lds(L0) : t_load_layer(L0);
     while (c.L < n_layers) {
       c.ng = (Ly.N + 3) >> 2;
       c.ns = (Ly.G + kTSweepCols - 1) / kTSweepCols;
       int r0 = bid - Ly.wgs;
       if (r0 < 0) r0 += W;
-      if (r0 < c.ng) { c.rg = r0; c.s = 0; break; }
-      if (++c.L < n_layers) Ly = t_load_layer(c.L);
+      r0 *= Ly.pf_chunk;
+      if (r0 < c.ng) { c.rg = r0; c.re = r0 + Ly.pf_chunk < c.ng ? r0 + Ly.pf_chunk : c.ng; break; }
+      if (++c.L < n_layers) Ly = kLds ? t_load_layer_lds(c.L) : t_load_layer(c.L);
     }
     return Ly;
   };
+  using from_args = std::integral_constant<bool, false>;
+  using from_table = std::integral_constant<bool, true>;
+  // the layer table into LDS: one dword per thread (kMaxGroup x 30 <= 1024)
+  {
+    static_assert(kMaxGroup * 30 <= kTThreads, "one dword of the layer table per thread");
+    const int tl = tid >> 5, tw = tid & 31;
+    if (tl < n_layers && tw < 30) {
+      const uint32_t* const src = (const uint32_t*)as_global(
+          (const char*)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr() + 16 + tl * 120 + tw * 4);
+      *(lds_u32_t*)(uintptr_t)(kTTabOff + (uint32_t)tl * 128u + (uint32_t)tw * 4u) = *src;
+    }
+  }
 
-  TCursor ci{0, 0, 0, 1, 1};   // issue position: always a valid sweep (it stops on the last one)
-  bool ci_end = false;
+  // Issue side (D sweeps ahead of the consume side): cursor + incremental state, so that a
+  // step costs a handful of instructions and everything rare sits behind ONE branch.
+  TCursor ci{0, 0, 0, 1, 1};   // row group being requested
+  bool ci_end = false;         // the stream has ended: the last row group is re-requested (harmless
+                               // re-reads keep every step's set of loads the same)
   TIssueL Li;
   {
-    const K256Layer L0 = enter_layer(ci);
+    const K256Layer L0 = enter_layer(ci, from_args{});
     if (ci.L >= n_layers) return;     // (whole workgroup: nothing to do)
     Li = t_issue_of(L0);
   }
-  TCursor cc = ci;             // consume position
+  TCursor cc = ci;             // row group being consumed
   TConsL Lc;
   TFillL Lf;
   {
@@ -239,21 +323,39 @@ __global__ __launch_bounds__(kTThreads) void gemv_k256t_kernel(const K256TParams
     Lc = t_cons_of(L0);
     Lf = TFillL{L0.cent, L0.rcent};
   }
-  auto advance_issue = [&]() {
-    if (ci_end) return;
-    TCursor n = ci;
-    if (++n.s < n.ns) { ci = n; return; }
-    n.s = 0;
-    n.rg += W;
-    if (n.rg < n.ng) { ci = n; return; }
-    ++n.L;
-    const K256Layer Ln = enter_layer(n);
-    if (n.L < n_layers) { ci = n; Li = t_issue_of(Ln); }
-    else ci_end = true;   // past the end: harmless re-reads keep every step's set of loads the same
+  const uint32_t lane_chunk2 = (kg * 4u + src_e) * 16u;   // byte offset of this lane's 8 index elements in a block
+  uint32_t i_rowoff = 0;   // per lane: byte offset of its vector-row in the layer's index tensor
+  int i_col2 = 0;          // byte offset (2 x column) of the wave's block in the sweep to request
+  int i_left = 0;          // sweeps of the row group still to request
+  int i_max8 = 0, i_max2 = 0;   // 2 (G - 8), 2 (G - 2): columns past G re-read the last ones
+  auto issue_row_group = [&]() {
+    const int row0 = ci.rg * 4;
+    const int r = row0 + (int)src_c < Li.N ? row0 + (int)src_c : Li.N - 1;   // rows past N re-read the last row
+    i_rowoff = (uint32_t)r * ((uint32_t)Li.row_words * 4u);
+    i_col2 = wave * (kTBlockCols * 2);
+    i_left = ci.ns;
+    i_max8 = (Li.G - 8) * 2;
+    i_max2 = (Li.G - 2) * 2;
+  };
+  issue_row_group();
+  auto issue_next_row_group = [&]() {   // cold
+    if (!ci_end) {
+      TCursor n = ci;
+      n.rg += 1;
+      if (n.rg >= n.re) {
+        ++n.L;
+        const K256Layer Ln = enter_layer(n, from_table{});
+        if (n.L < n_layers) { ci = n; Li = t_issue_of(Ln); }
+        else ci_end = true;
+      } else {
+        ci = n;
+      }
+    }
+    issue_row_group();
   };
 
-  if (tid < 8) slot_cnt[tid] = 0u;
-  __syncthreads();   // the only barrier: counters zeroed before anybody bumps them
+  if (tid < 16) slot_cnt[tid] = 0u;
+  __syncthreads();   // the only barrier: counters zeroed and the layer table in LDS before anybody uses them
 
   // ---- image fill by LDS-DMA: wave w brings rows 16 w .. 16 w + 15 (4 instructions of 4 rows;
   // lane l = unit l & 15 of row l >> 4: 16 bytes of entry (row) of table (unit >> 3)).  Issued as
@@ -273,66 +375,118 @@ __global__ __launch_bounds__(kTThreads) void gemv_k256t_kernel(const K256TParams
                    : "=&s"(keep_m0) : "v"(v), "s"(d) : "memory");
     }
   };
+  // Hand-over between the waves goes through LDS only, and a wave's LDS operations execute in
+  // order: the fences below are restricted to the local address space.  An ordinary workgroup-scope
+  // release also waits for every global load in flight (s_waitcnt vmcnt(0)) - here that is the whole
+  // queue of index words requested ahead, i.e. a full memory latency at every row-group end, layer
+  // switch and image hand-over (measured: 40 % of a wave's cycles went there).
+  auto lds_release = [&]() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); };
+  auto lds_acquire = [&]() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); };
   auto lds_inc = [&](uint32_t* p) {
-    if (lane == 0) __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    lds_release();
+    if (lane == 0) __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   };
   // VPTQ_K256T_SPIN_LIMIT (bring-up builds only): give up a wait after that many polls, so that a
   // protocol error shows as wrong results instead of a hung GPU
   auto lds_wait_ge = [&](uint32_t* p, uint32_t need) {
+    if constexpr ((VPTQ_K256T_ABLATE & 8) != 0) { if (p == free_cnt || p == free_cnt + 1 || p == ready_cnt || p == ready_cnt + 1) return; }
 #if VPTQ_K256T_SPIN_LIMIT
     for (int it = 0; it < VPTQ_K256T_SPIN_LIMIT; ++it) {
-      if (__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= need) break;
+      if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= need) break;
       __builtin_amdgcn_s_sleep(1);
     }
 #else
-    while (__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need)
+    while (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need)
       __builtin_amdgcn_s_sleep(1);
 #endif
+    lds_acquire();
   };
 
   // ---- loads of one sweep: 16 bytes of index words (8 columns of this lane's vector-row), and
-  // for columns 2 lane, 2 lane + 1 of the wave's block: x, scale, bias.  Rows past N re-read
-  // the last row (not stored), columns past G re-read the last ones with x forced to 0.
-  u32x4 iw[2];
-  uint32_t xr[2], sr[2], br[2];
-  int q_layer[2] = {0, 0};    // DEP: layer and sweep of the item in each queue slot
-  int q_sweep[2] = {0, 0};
-  const uint32_t lane_chunk = (kg * 4u + src_e) * 8u;   // first of this lane's 8 columns inside the block
-  auto load_x = [&](auto slot_c, const uint16_t* xp, int G, int s) {
+  // for columns 2 lane, 2 lane + 1 of the wave's block: x, scale, bias.
+#if VPTQ_K256T_PROF
+  unsigned long long pf_vm = 0, pf_tv = 0;
+  auto now = [&](uint32_t dep) -> unsigned long long {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : "v"(dep) : "memory");
+    return t;
+  };
+#endif
+  constexpr int D = kTDepth;
+  u32x4 iw[D];
+  uint32_t xr[D], sr[D], br[D];
+  int q_layer[D], q_col2[D];   // DEP: layer and block offset of the sweep in each queue slot
+  auto load_x = [&](auto slot_c, const uint16_t* xp, int max2, int col2) {
     constexpr int S = decltype(slot_c)::value;
-    const int want2 = s * kTSweepCols + wave * kTBlockCols + 2 * lane;
-    xr[S] = *(const uint32_t*)as_global((const char*)xp + (uint32_t)(want2 < G ? want2 : G - 2) * 2u);
+    const int want = col2 + 4 * lane;
+    xr[S] = *(const uint32_t*)as_global((const char*)xp + (uint32_t)(want < max2 ? want : max2));
   };
   auto issue = [&](auto slot_c) {
     constexpr int S = decltype(slot_c)::value;
-    const int colbase = ci.s * kTSweepCols + wave * kTBlockCols;
-    const int row0 = ci.rg * 4;
-    const uint32_t row_bytes = (uint32_t)Li.row_words * 4u;
-    const char* const rbase = (const char*)Li.idx + (size_t)row0 * row_bytes;  // wave-uniform
-    const uint32_t roff = (uint32_t)(row0 + (int)src_c < Li.N ? (int)src_c : Li.N - 1 - row0) * row_bytes;
-    const int want = colbase + (int)lane_chunk;
-    const uint32_t coff = (uint32_t)(want < Li.G ? want : Li.G - 8) * 2u;
-    const int want2 = colbase + 2 * lane;
-    const uint32_t c2 = (uint32_t)(want2 < Li.G ? want2 : Li.G - 2) * 2u;
-    load_x(slot_c, Li.x, Li.G, ci.s);
-    sr[S] = *(const uint32_t*)as_global((const char*)Li.scale + c2);
-    br[S] = *(const uint32_t*)as_global((const char*)Li.wbias + c2);
-    iw[S] = __builtin_nontemporal_load((const u32x4*)as_global(rbase + roff + coff));
-    if (DEP) { q_layer[S] = ci.L; q_sweep[S] = ci.s; }
+    const int want = i_col2 + (int)lane_chunk2;
+    const uint32_t coff = (uint32_t)(want < i_max8 ? want : i_max8);
+    const int want2 = i_col2 + 4 * lane;
+    const uint32_t c2 = (uint32_t)(want2 < i_max2 ? want2 : i_max2);
+    if constexpr ((VPTQ_K256T_ABLATE & 4) != 0) {
+      xr[S] = c2; sr[S] = 0x3c003c00u; br[S] = c2 ^ 0x1234u;
+      asm volatile("" : "+v"(xr[S]), "+v"(sr[S]), "+v"(br[S]));
+    } else {
+      xr[S] = *(const uint32_t*)as_global((const char*)Li.x + c2);
+      sr[S] = *(const uint32_t*)as_global((const char*)Li.scale + c2);
+      br[S] = *(const uint32_t*)as_global((const char*)Li.wbias + c2);
+    }
+    if constexpr ((VPTQ_K256T_ABLATE & 16) != 0) {
+      // timing only: the same bytes of the row group, but 1 KiB contiguous per wave and 16 KiB per sweep
+      const uint32_t rg_base = (uint32_t)(ci.rg * 4) * ((uint32_t)Li.row_words * 4u);
+      const uint32_t off = (uint32_t)(i_col2 / (kTBlockCols * 2)) * 1024u + (uint32_t)lane * 16u;   // sweep * 16 KiB + wave KiB
+      iw[S] = __builtin_nontemporal_load((const u32x4*)as_global((const char*)Li.idx + (rg_base + off)));
+    } else {
+      iw[S] = __builtin_nontemporal_load((const u32x4*)as_global((const char*)Li.idx + (i_rowoff + coff)));
+    }
+    if (DEP) { q_layer[S] = ci_end ? -1 : ci.L; q_col2[S] = i_col2; }
+#if VPTQ_K256T_PROF
+    if (pf_tv) pf_vm += now(coff) - pf_tv;   // (pf_tv: stamped by the step right before issue())
+#endif
+    i_col2 += kTSweepCols * 2;
+    if (--i_left == 0) issue_next_row_group();
   };
 
   // ---- state of the consume side
   f32x4 acc[2];
   float accb = 0.f;
+  int c_col = wave * kTBlockCols;   // first column of the wave's block in the sweep being consumed
+  int c_left = cc.ns;               // sweeps of the row group still to consume
+  bool done = false;
   uint32_t use = 0;            // how many layers this workgroup has entered before the current one
   uint32_t q_done = 0;         // row groups this workgroup has finished
   bool fill_pending = false;   // the next layer's image has not been requested yet
-  bool land_pending = false;   // requested, not yet known to have landed
+  int land_steps = 0;          // > 0: a fill was requested D - land_steps step ends ago
+#if VPTQ_K256T_PROF
+  unsigned long long pf_wait = 0, pf_cons = 0, pf_issue = 0, pf_cold = 0, pf_steps = 0, pf_t0 = 0;
+  unsigned long long pf_fwait = 0, pf_fred = 0, pf_ffinal = 0, pf_l0 = 0, pf_l1 = 0, pf_l2 = 0;
+#endif
+  // "everything but the youngest n sweeps' loads has landed".  vmcnt retires in order: at the end
+  // of the j-th step after a fill (each step requests kLPS loads) the fill is older than j + 1
+  // sweeps; at j = D - 1 those are exactly the D sweeps in flight.
+  constexpr int kLPS = (VPTQ_K256T_ABLATE & 4) ? 1 : 4;   // vector loads per sweep
+  auto wait_all_but = [&](int steps) {
+    switch (steps) {
+      case 1: asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kLPS * 1) : "memory"); break;
+      case 2: asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kLPS * 2) : "memory"); break;
+      case 3: asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kLPS * 3) : "memory"); break;
+      case 4: asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kLPS * 4) : "memory"); break;
+      case 5: asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kLPS * 5) : "memory"); break;
+      case 6: asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kLPS * 6) : "memory"); break;
+      case 7: asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kLPS * 7) : "memory"); break;
+      case 8: asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kLPS * 8) : "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+  };
   TCursor cf = cc;             // next layer with work (its image goes to buffer (use + 1) & 1)
   auto plan_fill = [&]() {
     cf = cc;
     cf.L = cc.L + 1;
-    const K256Layer Ln = enter_layer(cf);
+    const K256Layer Ln = enter_layer(cf, from_table{});
     Lf = TFillL{Ln.cent, Ln.rcent};
     fill_pending = cf.L < n_layers;
   };
@@ -342,19 +496,65 @@ __global__ __launch_bounds__(kTThreads) void gemv_k256t_kernel(const K256TParams
   // instead of a barrier (see gemv_k256m.hip): the wave that arrives last sums and stores.
   auto finish = [&]() {
     const int rg = cc.rg;
-    const uint32_t slot = q_done & 1u;
+    const uint32_t slot = q_done % (uint32_t)kTSlots;
+#if VPTQ_K256T_PROF
+    const unsigned long long f0 = now(0);
+#endif
     if (q_done >= (uint32_t)kTSlots) lds_wait_ge(&slot_done[slot], q_done - (uint32_t)kTSlots + 1u);
+#if VPTQ_K256T_PROF
+    const unsigned long long f1 = now(0);
+    pf_fwait += f1 - f0;
+#endif
     float* const rs = red + slot * (kTWaves * 32) + wave * 32;
-    if (lane < 16) {
+    if constexpr (VPTQ_K256T_LOOP == 1) {
+      // lane (blk, j) holds 8 partial outputs of vector-row j for its column chunk: sum over the 16
+      // chunks of the wave.  Lane bits 5 and 4 by swap-and-add (halving the values carried), bits 3
+      // and 2 by DPP row rotations: afterwards lane l holds outputs 4 bit5 + 2 bit4 + {0, 1} of row l & 3
+      float v[8];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { v[i] = acc[0][i]; v[4 + i] = acc[1][i]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 4]), false, false);
+        v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 2]), false, false);
+        v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) v[i] = row_ror_add<4>(row_ror_add<8>(v[i]));
+      if ((lane & 12) == 0) {
+        const int o8 = ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2;
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        *(f32x2*)&rs[jrow * 8u + (uint32_t)o8] = f32x2{v[0], v[1]};
+      }
+    } else if (lane < 16) {
       rs[res_c * 8u + ((0u ^ hold_h) << 2) + res_m] = acc[0][0];
       rs[res_c * 8u + ((1u ^ hold_h) << 2) + res_m] = acc[1][0];
     }
     const float sb = wave_sum(accb);
     if (lane == 0) red_b[slot * kTWaves + wave] = sb;
     uint32_t arrived = 0;
+    lds_release();
     if (lane == 0)
-      arrived = __hip_atomic_fetch_add(&slot_cnt[slot], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+      arrived = __hip_atomic_fetch_add(&slot_cnt[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     arrived = __builtin_amdgcn_readfirstlane(arrived);
+    lds_acquire();
+#if VPTQ_K256T_BALANCE
+    // The SIMDs serve their waves oldest first, so the waves of a workgroup drift apart until the
+    // fast ones wait for the slow ones at every hand-over.  Issue priority for the next row group
+    // by arrival order at this one: the early ones yield.
+    if (arrived < 4u) __builtin_amdgcn_s_setprio(0);
+    else if (arrived < 8u) __builtin_amdgcn_s_setprio(1);
+    else if (arrived < 12u) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(3);
+#endif
+#if VPTQ_K256T_PROF
+    const unsigned long long f2 = now(arrived);
+    pf_fred += f2 - f1;
+#endif
     if (arrived == (uint32_t)kTWaves - 1u) {
       const int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
       const int half = ln >> 5, ol = ln & 31;
@@ -381,9 +581,13 @@ __global__ __launch_bounds__(kTThreads) void gemv_k256t_kernel(const K256TParams
       }
       if (lane == 0) {
         slot_cnt[slot] = 0u;
-        __hip_atomic_store(&slot_done[slot], q_done + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        lds_release();
+        __hip_atomic_store(&slot_done[slot], q_done + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
     }
+#if VPTQ_K256T_PROF
+    pf_ffinal += now(0) - f2;
+#endif
     ++q_done;
   };
 
@@ -391,10 +595,9 @@ __global__ __launch_bounds__(kTThreads) void gemv_k256t_kernel(const K256TParams
   // {X, Y} x {chunk, other chunk}) and 4 MFMAs of K = 32 (the two tiles of the pair side by side)
   auto consume = [&](auto slot_c) {
     constexpr int S = decltype(slot_c)::value;
-    const int colbase = cc.s * kTSweepCols + wave * kTBlockCols;
     // activations: f16(s x) of this lane's two columns into the wave's slot, sum b x
     {
-      const uint32_t keep = colbase + 2 * lane < Lc.G ? 0xffffffffu : 0u;
+      const uint32_t keep = c_col + 2 * lane < Lc.G ? 0xffffffffu : 0u;
       const uint32_t xv = xr[S] & keep;
       accb = DT::dot2(xv, br[S], accb);
       // (anchored here: left alone, the compiler sinks this towards its use in finish(), keeps the
@@ -402,10 +605,52 @@ __global__ __launch_bounds__(kTThreads) void gemv_k256t_kernel(const K256TParams
       // loads the step has just issued)
       asm volatile("" : "+v"(accb));
       const uint32_t xs = DT::mul2(xv, sr[S]);
-      *(lds_u16_t*)(uintptr_t)st_addr = (uint16_t)(xs & 0xffffu);
-      *(lds_u16_t*)(uintptr_t)(st_addr + 8u) = (uint16_t)(xs >> 16);
+      if constexpr (VPTQ_K256T_LOOP == 1) {
+        *(lds_u32_t*)(uintptr_t)st_addr1 = xs;
+      } else {
+        *(lds_u16_t*)(uintptr_t)st_addr = (uint16_t)(xs & 0xffffu);
+        *(lds_u16_t*)(uintptr_t)(st_addr + 8u) = (uint16_t)(xs >> 16);
+      }
     }
     const u32x4 words = iw[S];
+    if constexpr (VPTQ_K256T_LOOP == 1) {
+      // 8 indices per lane: 2 gathers each, two indices ahead of the arithmetic; per index 2 perms for
+      // the addresses, 2 for the x operand, 4 MFMAs (main / residual entry x outputs 0-3 / 4-7)
+      const u32x4 xq = lds_load16(xq_addr);
+      u32x4 cv[3], rv[3];
+      auto gather = [&](int u) {
+        const uint32_t w = words[u >> 1];
+        const uint32_t aC = __builtin_amdgcn_perm(w, baseA, selGA[u & 1]);
+        const uint32_t aR = __builtin_amdgcn_perm(w, baseB, selGB[u & 1]);
+        if constexpr ((VPTQ_K256T_ABLATE & 2) != 0) {
+          asm volatile("" :: "v"(aC), "v"(aR));
+          cv[u % 3] = words; rv[u % 3] = words;
+        } else {
+          cv[u % 3] = lds_load16(aC);
+          rv[u % 3] = lds_load16(aR);
+        }
+      };
+      gather(0);
+      gather(1);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (u + 2 < 8) gather(u + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        const u32x4 c = cv[u % 3], r = rv[u % 3];
+        const u32x2 xo = u32x2{__builtin_amdgcn_perm(xq[u >> 1], 0u, selA[u & 1]),
+                               __builtin_amdgcn_perm(xq[u >> 1], 0u, selB[u & 1])};
+        if constexpr ((VPTQ_K256T_ABLATE & 1) != 0) {
+          asm volatile("" :: "v"(c), "v"(r), "v"(xo));
+        } else {
+          acc[0] = DT::mfma4(xo, u32x2{c[0], c[1]}, acc[0]);
+          acc[1] = DT::mfma4(xo, u32x2{c[2], c[3]}, acc[1]);
+          acc[0] = DT::mfma4(xo, u32x2{r[0], r[1]}, acc[0]);
+          acc[1] = DT::mfma4(xo, u32x2{r[2], r[3]}, acc[1]);
+        }
+      }
+      return;
+    }
     u32x2 g[2][2][2][2];   // [pair parity][tile of the pair][read X / Y][first / second chunk]
     u32x4 xa[2];
     auto gather_pair = [&](int p) {
@@ -458,29 +703,57 @@ __global__ __launch_bounds__(kTThreads) void gemv_k256t_kernel(const K256TParams
   // (their index words, scales and bias values were requested ahead; x could not be)
   auto dep_enter = [&](int L) {
     if (L == 0) return;
-    const int need = (P.layer[L - 1].N + 3) >> 2;
+    // one wave per workgroup polls the device-scope counter (4096 waves polling one line starve
+    // the atomics that feed it); the others wait for its word in LDS
+    if (wave == 0) {
+      const int need = (P.layer[L - 1].N + 3) >> 2;
 #if VPTQ_K256T_SPIN_LIMIT
-    for (int it = 0; it < VPTQ_K256T_SPIN_LIMIT; ++it) {
-      if ((int)__hip_atomic_load(&P.sync[L - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= need) break;
-      __builtin_amdgcn_s_sleep(2);
-    }
+      for (int it = 0; it < VPTQ_K256T_SPIN_LIMIT; ++it) {
+        if ((int)__hip_atomic_load(&P.sync[L - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= need) break;
+        __builtin_amdgcn_s_sleep(4);
+      }
 #else
-    while ((int)__hip_atomic_load(&P.sync[L - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < need)
-      __builtin_amdgcn_s_sleep(2);
+      while ((int)__hip_atomic_load(&P.sync[L - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < need)
+        __builtin_amdgcn_s_sleep(4);
 #endif
+      lds_release();
+      if (lane == 0) __hip_atomic_store(dep_seen, (uint32_t)L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else {
+      lds_wait_ge(dep_seen, (uint32_t)L);
+      // (this wave's own acquire: its L1 may hold stale lines of the activation buffer)
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
     const uint16_t* const xp = as_global(P.layer[L].x);
-    const int G = P.layer[L].G;
-    if (q_layer[0] == L) load_x(std::integral_constant<int, 0>{}, xp, G, q_sweep[0]);
-    if (q_layer[1] == L) load_x(std::integral_constant<int, 1>{}, xp, G, q_sweep[1]);
+    const int max2 = (P.layer[L].G - 2) * 2;
+    auto reload = [&](auto slot_c) {
+      constexpr int S = decltype(slot_c)::value;
+      if (q_layer[S] == L) load_x(slot_c, xp, max2, q_col2[S]);
+    };
+    reload(std::integral_constant<int, 0>{});
+    reload(std::integral_constant<int, 1>{});
+    if constexpr (D > 2) reload(std::integral_constant<int, (D > 2 ? 2 : 0)>{});
+    if constexpr (D > 3) reload(std::integral_constant<int, (D > 3 ? 3 : 0)>{});
+    if constexpr (D > 4) reload(std::integral_constant<int, (D > 4 ? 4 : 0)>{});
+    if constexpr (D > 5) reload(std::integral_constant<int, (D > 5 ? 5 : 0)>{});
+    if constexpr (D > 6) reload(std::integral_constant<int, (D > 6 ? 6 : 0)>{});
+    if constexpr (D > 7) reload(std::integral_constant<int, (D > 7 ? 7 : 0)>{});
   };
 
-  // ---- prologue: image of the first layer into buffer 0, first two sweeps requested
+  // ---- prologue: image of the first layer into buffer 0, first D sweeps requested
   fill_image(Lf, 0u);
-  issue(std::integral_constant<int, 0>{});
-  advance_issue();
-  issue(std::integral_constant<int, 1>{});
-  advance_issue();
-  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // the 4 fill instructions are older than the 8 loads above
+  auto issue_first = [&](auto slot_c) {
+    issue(slot_c);
+    __builtin_amdgcn_sched_barrier(0);   // (the slots in issue order: the counted waits of the loop rely on it)
+  };
+  issue_first(std::integral_constant<int, 0>{});
+  issue_first(std::integral_constant<int, 1>{});
+  if constexpr (D > 2) issue_first(std::integral_constant<int, (D > 2 ? 2 : 0)>{});
+  if constexpr (D > 3) issue_first(std::integral_constant<int, (D > 3 ? 3 : 0)>{});
+  if constexpr (D > 4) issue_first(std::integral_constant<int, (D > 4 ? 4 : 0)>{});
+  if constexpr (D > 5) issue_first(std::integral_constant<int, (D > 5 ? 5 : 0)>{});
+  if constexpr (D > 6) issue_first(std::integral_constant<int, (D > 6 ? 6 : 0)>{});
+  if constexpr (D > 7) issue_first(std::integral_constant<int, (D > 7 ? 7 : 0)>{});
+  wait_all_but(D);   // the 4 fill instructions are older than the loads above
   lds_inc(&ready_cnt[0]);
   plan_fill();
   acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -488,76 +761,144 @@ __global__ __launch_bounds__(kTThreads) void gemv_k256t_kernel(const K256TParams
   if (DEP) dep_enter(cc.L);
   lds_wait_ge(&ready_cnt[0], (uint32_t)kTWaves);
 
-  // ---- main loop: one step = wait for sweep k, consume it, request sweep k + 2 into its queue
-  // slot, then the rare events (row group done, layer done, image fill)
-  auto step = [&](auto slot_c) {
-    __builtin_amdgcn_sched_barrier(0);
-    consume(slot_c);
-    __builtin_amdgcn_sched_barrier(0);
-    // a fill issued one step ago is older than the loads the wait above left in flight
-    if (land_pending) {
-      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      lds_inc(&ready_cnt[(use + 1u) & 1u]);
-      land_pending = false;
-    }
-    // the next layer's image, as soon as its buffer is free: every wave has left the layer before
-    // the current one (BEFORE this step's loads: a younger invisible load would make the next
-    // step's counted wait cover those too)
+  // ---- rare events, each behind one branch of the step
+  // the next layer's image: requested as soon as its buffer is free (every wave has left the layer
+  // before the current one), BEFORE the step's loads (a younger invisible load would make the next
+  // step's counted wait cover those too); D step ends later only the D sweeps in flight are younger
+  // than it, so it has landed once everything older has - which a wave that keeps pace has waited for
+  auto fill_events_before_issue = [&]() {
     if (fill_pending) {
       const uint32_t nb = (use + 1u) & 1u;
       const uint32_t need = (uint32_t)kTWaves * ((use + 1u) >> 1);
-      if (__hip_atomic_load(&free_cnt[nb], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= need) {
+      if (__hip_atomic_load(&free_cnt[nb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= need) {
         fill_image(Lf, nb);
         fill_pending = false;
-        land_pending = true;
+        land_steps = D;
       }
     }
-    __builtin_amdgcn_sched_barrier(0);
-    issue(slot_c);
-    advance_issue();
-    __builtin_amdgcn_sched_barrier(0);
-    // consume cursor: row group / layer boundaries.  (A step past the end - the second half of the
-    // last loop iteration when the stream has an odd number of sweeps - has consumed a re-read
-    // sweep into accumulators nobody looks at.  The loop has ONE exit, at its end: an exit between
-    // the two steps becomes, after control-flow structurisation, an edge into the loop header on
-    // which the queue slots are in the other order, and every counted wait of the first step
-    // degrades to vmcnt(0).)
-    if (cc.L >= n_layers) return;
-    if (cc.s + 1 < cc.ns) { ++cc.s; return; }
+  };
+  auto fill_events_after_issue = [&]() {
+    if (land_steps > 0 && --land_steps == 0) {
+      wait_all_but(D);
+      lds_inc(&ready_cnt[(use + 1u) & 1u]);
+    }
+  };
+  // the row group is complete: sums, then the next row group, the next layer, or the end
+  auto row_group_done = [&]() {
     finish();
     acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
     acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
     accb = 0.f;
-    cc.s = 0;
-    if (cc.rg + W < cc.ng) { cc.rg += W; return; }
+    c_col = wave * kTBlockCols;
+    c_left = cc.ns;
+    if (cc.rg + 1 < cc.re) { cc.rg += 1; return; }
+#if VPTQ_K256T_PROF
+    const unsigned long long l0 = now(0);
+#endif
     // leaving the layer: its image buffer is free once every wave has said so
     lds_inc(&free_cnt[use & 1u]);
-    if (cf.L >= n_layers) { cc.L = n_layers; return; }
+    if (cf.L >= n_layers) {
+      // (the steps that remain in this loop iteration consume re-read sweeps into accumulators
+      // nobody looks at.  The loop has ONE exit, at its end: an exit between two steps becomes,
+      // after control-flow structurisation, an edge into the loop header on which the queue slots
+      // are in another order, and every counted wait of the first step degrades to vmcnt(0).)
+      done = true;
+      c_left = 0x7fffffff;
+      return;
+    }
     const uint32_t nb = (use + 1u) & 1u;
     if (fill_pending) {   // (rare: the buffer was not free at any step boundary)
       lds_wait_ge(&free_cnt[nb], (uint32_t)kTWaves * ((use + 1u) >> 1));
       fill_image(Lf, nb);
       fill_pending = false;
-      land_pending = true;
-    }
-    if (land_pending) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       lds_inc(&ready_cnt[nb]);
-      land_pending = false;
+    } else if (land_steps > 0) {
+      // requested D - land_steps step ends ago: that many sweeps are younger than the fill
+      wait_all_but(D - land_steps);
+      lds_inc(&ready_cnt[nb]);
+      land_steps = 0;
     }
     ++use;
     baseX ^= 0x10000u;
     baseY ^= 0x10000u;
+    baseA ^= 0x10000u;
+    baseB ^= 0x10000u;
     cc = cf;
-    Lc = t_cons_of(t_load_layer(cc.L));
+    Lc = t_cons_of(t_load_layer_lds(cc.L));
+    c_left = cc.ns;
     if (DEP) dep_enter(cc.L);
+#if VPTQ_K256T_PROF
+    const unsigned long long l1 = now(Lc.G);
+    pf_l0 += l1 - l0;
+#endif
     lds_wait_ge(&ready_cnt[nb], (uint32_t)kTWaves * ((use >> 1) + 1u));
+#if VPTQ_K256T_PROF
+    const unsigned long long l2 = now(0);
+    pf_l1 += l2 - l1;
+#endif
     plan_fill();
+#if VPTQ_K256T_PROF
+    pf_l2 += now(cf.L) - l2;
+#endif
+  };
+
+#if VPTQ_K256T_PROF
+  pf_t0 = now(0);
+#endif
+  // ---- main loop: one step = wait for sweep k, consume it, request sweep k + D into its queue slot
+  auto step = [&](auto slot_c) {
+    __builtin_amdgcn_sched_barrier(0);
+#if VPTQ_K256T_PROF
+    constexpr int SS = decltype(slot_c)::value;
+    const unsigned long long ta = now(0);
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kLPS * (D - 1)) : "memory");
+    const unsigned long long tb = now(iw[SS][0]);
+    pf_wait += tb - ta;
+#endif
+    consume(slot_c);
+    __builtin_amdgcn_sched_barrier(0);
+#if VPTQ_K256T_PROF
+    const unsigned long long tc = now(__float_as_uint(acc[0][0] + acc[1][0]));
+    pf_cons += tc - tb;
+#endif
+    if (fill_pending) fill_events_before_issue();
+    __builtin_amdgcn_sched_barrier(0);
+#if VPTQ_K256T_PROF
+    pf_tv = now(0);
+#endif
+    issue(slot_c);
+    __builtin_amdgcn_sched_barrier(0);
+#if VPTQ_K256T_PROF
+    const unsigned long long td = now(0);
+    pf_issue += td - tc;
+#endif
+    if (land_steps > 0) fill_events_after_issue();
+    c_col += kTSweepCols;
+    if (--c_left == 0) row_group_done();
+#if VPTQ_K256T_PROF
+    pf_cold += now(0) - td;
+    ++pf_steps;
+#endif
   };
   do {
     step(std::integral_constant<int, 0>{});
     step(std::integral_constant<int, 1>{});
-  } while (cc.L < n_layers);
+    if constexpr (D > 2) step(std::integral_constant<int, (D > 2 ? 2 : 0)>{});
+    if constexpr (D > 3) step(std::integral_constant<int, (D > 3 ? 3 : 0)>{});
+    if constexpr (D > 4) step(std::integral_constant<int, (D > 4 ? 4 : 0)>{});
+    if constexpr (D > 5) step(std::integral_constant<int, (D > 5 ? 5 : 0)>{});
+    if constexpr (D > 6) step(std::integral_constant<int, (D > 6 ? 6 : 0)>{});
+    if constexpr (D > 7) step(std::integral_constant<int, (D > 7 ? 7 : 0)>{});
+  } while (!done);
+#if VPTQ_K256T_PROF
+  if (!DEP && P.sync && lane == 0) {
+    unsigned long long* o = (unsigned long long*)P.sync + ((size_t)bid * kTWaves + wave) * 8;
+    o[0] = pf_wait | (pf_vm << 32); o[1] = pf_cons; o[2] = pf_issue; o[3] = pf_cold; o[4] = pf_steps; o[5] = now(0) - pf_t0;
+    o[6] = (pf_fwait << 32) | (pf_l0 & 0xffffffffull); o[7] = (pf_fred << 32) | (pf_ffinal & 0xffffffffull);
+    o[2] = (pf_issue & 0xffffffffull) | (pf_l1 << 32); o[3] = (pf_cold & 0xffffffffull) | (pf_l2 << 32);
+  }
+#endif
 }
 
 // ---- host side -------------------------------------------------------------------
@@ -566,9 +907,32 @@ bool gemv_k256t_eligible(const VptqLayerDesc& d, int tokens) {
          (((uintptr_t)d.centroids | (uintptr_t)d.res_centroids) & 15) == 0;
 }
 
-int gemv_k256t_grid(const VptqLayerDesc* descs, int n, int cus) {
+// Row groups are dealt to the workgroups in blocks of consecutive ones, `rpw` per workgroup and
+// layer.  Independent layers: at least kTMinSteps sweeps per visit of a layer (the next layer's
+// image is requested at the start of the visit and lands D sweeps later; a layer that gives every
+// workgroup one short row group would make all of them wait for it), so a small layer occupies
+// only some of the workgroups and the next layers run beside it.  Dependent layers follow each
+// other anyway: every layer is spread over all workgroups.
+#ifndef VPTQ_K256T_MIN_STEPS
+#define VPTQ_K256T_MIN_STEPS 8
+#endif
+constexpr int kTMinSteps = VPTQ_K256T_MIN_STEPS;
+static int t_rows_per_wg(const VptqLayerDesc& d, int cus, bool dependent) {
+  const int ng = (d.num_indices + 3) / 4, ns = (d.group_size + kTSweepCols - 1) / kTSweepCols;
+  int rpw = (ng + cus - 1) / cus;
+  if (!dependent) {
+    const int want = (kTMinSteps + ns - 1) / ns;
+    rpw = want > rpw ? want : rpw;
+  }
+  return rpw < 1 ? 1 : rpw;
+}
+
+int gemv_k256t_grid(const VptqLayerDesc* descs, int n, int cus, bool dependent) {
   long long total = 0;
-  for (int i = 0; i < n; ++i) total += (descs[i].num_indices + 3) / 4;
+  for (int i = 0; i < n; ++i) {
+    const int ng = (descs[i].num_indices + 3) / 4, rpw = t_rows_per_wg(descs[i], cus, dependent);
+    total += (ng + rpw - 1) / rpw;
+  }
   return (int)(total < cus ? total : cus);
 }
 
@@ -608,7 +972,7 @@ hipError_t launch_gemv_k256t(const VptqLayerDesc* descs, int n, const void* cons
   static int forced_wgs = -1;  // VPTQ_K256T_WGS: tuning override of the workgroup count
   if (forced_wgs < 0) { const char* e = getenv("VPTQ_K256T_WGS"); forced_wgs = e ? atoi(e) : 0; }
   const int cus = forced_wgs > 0 ? forced_wgs : t_device_cus();
-  const int grid = gemv_k256t_grid(descs, n, cus);
+  const int grid = gemv_k256t_grid(descs, n, cus, dependent);
   K256TParams P;
   P.n_layers = n;
   P.tokens = 1 | ((flags & VPTQ_GEMV_OUT_F32) ? kOutF32Bit : 0);
@@ -632,12 +996,13 @@ hipError_t launch_gemv_k256t(const VptqLayerDesc* descs, int n, const void* cons
     Ly.G = d.group_size;
     Ly.O = d.out_features;
     Ly.row_words = d.row_words;
+    const int rpw = t_rows_per_wg(d, cus, dependent);
     Ly.wgs = (int)(first % grid);
-    Ly.pf_chunk = 0;
+    Ly.pf_chunk = rpw;   // (this kernel: row groups per workgroup)
     Ly.pf_len = 0;
     Ly.slots = 0;
     // dependent chain: every layer starts at workgroup 0 (all of its row groups wait anyway)
-    first = dependent ? 0 : first + (d.num_indices + 3) / 4;
+    first = dependent ? 0 : first + ((d.num_indices + 3) / 4 + rpw - 1) / rpw;
   }
   const bool f16 = descs[0].dtype == VPTQ_DTYPE_F16;
   if (dependent) return f16 ? launch_t<F16, true>(P, grid, st) : launch_t<BF16, true>(P, grid, st);
