@@ -224,7 +224,7 @@ VPTQ_API int vptq_quant_gemv_grouped(const VptqLayerDesc* descs, int n, const vo
  *     call clears it on the stream).
  * Served by one launch per <= 32 layers when every layer is of the canonical v=8 / 256+256 format,
  * one dtype, without a permutation (absorb it first), tokens == 1
- * (vptq_quant_gemv_chain_kernel_name says "gemv_k256t_kernel"); anything else is executed as n
+ * (vptq_quant_gemv_chain_kernel_name says "gemv_k256c_kernel"); anything else is executed as n
  * vptq_quant_gemv calls ("per-layer").  descs is a HOST array; x[i], y[i] device pointers.
  */
 #define VPTQ_CHAIN_MAX 1024

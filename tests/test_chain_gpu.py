@@ -1,4 +1,4 @@
-"""GPU parity of the persistent layer-chain launch (`vptq_quant_gemv_chain`, gemv_k256t.hip):
+"""GPU parity of the persistent layer-chain launch (`vptq_quant_gemv_chain`, gemv_k256c.hip):
 every layer of a chain against the oracle / the reference goldens, through the C ABI.
 
 Bar as everywhere: max|d| / max|ref| <= 1e-3 (fp16), 8e-3 (bf16)."""
@@ -14,6 +14,7 @@ from _gpu_util import spec_to_module, bits_to_tensor, tensor_to_bits, gemv_abi
 
 pytestmark = pytest.mark.gpu
 TOL = {"f16": 1e-3, "bf16": 8e-3}
+CHAIN = 8   # VPTQ_GEMV_FORCE_MFMA: the chain kernel even where the layers are too small to fill the device
 
 
 @pytest.fixture(scope="module")
@@ -62,9 +63,9 @@ def test_independent_chain_every_layer_vs_oracle(dt, dev):
     from vptq_amd.ops.chain import GemvChain
     Ls, ms, xs = _build(SHAPES, dt, dev)
     chain = GemvChain(ms)
-    assert chain.kernel_name(1, 0) == "gemv_k256t_kernel"
+    assert chain.kernel_name(1, CHAIN) == "gemv_k256c_kernel"
     xt = [bits_to_tensor(x, dt, dev).reshape(x.shape) for x in xs]
-    ys = chain(xt, flags=0)
+    ys = chain(xt, flags=CHAIN)
     torch.cuda.synchronize()
     for L, x, y in zip(Ls, xs, ys):
         want = vo.forward(L, x)
@@ -73,11 +74,11 @@ def test_independent_chain_every_layer_vs_oracle(dt, dev):
     # the same layers in another order and as single-layer chains: same bits (every layer's sums are
     # formed in the same order wherever it sits in the stream)
     order = [3, 0, 5, 7, 1, 6, 2, 4]
-    ys2 = GemvChain([ms[i] for i in order])([xt[i] for i in order], flags=0)
+    ys2 = GemvChain([ms[i] for i in order])([xt[i] for i in order], flags=CHAIN)
     for j, i in enumerate(order):
         assert torch.equal(ys2[j].view(torch.int16), ys[i].view(torch.int16))
     for i in (0, 2, 5):
-        y1 = GemvChain([ms[i]])([xt[i]], flags=0)[0]
+        y1 = GemvChain([ms[i]])([xt[i]], flags=CHAIN)[0]
         assert torch.equal(y1.view(torch.int16), ys[i].view(torch.int16))
 
 
@@ -86,8 +87,8 @@ def test_chain_float32_outputs(dev):
     from vptq_amd import _backend as B
     Ls, ms, xs = _build(SHAPES[:4], "f16", dev)
     xt = [bits_to_tensor(x, "f16", dev).reshape(x.shape) for x in xs]
-    y16 = GemvChain(ms)(xt, flags=0)
-    y32 = GemvChain(ms)(xt, flags=B.GEMV_OUT_F32)
+    y16 = GemvChain(ms)(xt, flags=CHAIN)
+    y32 = GemvChain(ms)(xt, flags=B.GEMV_OUT_F32 | CHAIN)
     for a, b in zip(y16, y32):
         assert b.dtype == torch.float32
         assert torch.equal(b.half().view(torch.int16), a.view(torch.int16))   # one rounding of the same sums
@@ -104,9 +105,9 @@ def test_dependent_chain(dt, dev):
     x0 = _x(dims[0], dt, "llm", 5)
     xt = bits_to_tensor(x0, dt, dev).reshape(x0.shape)
     chain = GemvChain(ms, dependent=True)
-    assert chain.kernel_name(1, 0) == "gemv_k256t_kernel"
+    assert chain.kernel_name(1, CHAIN) == "gemv_k256c_kernel"
     for rep in range(3):   # (the arrival counters are cleared by every call)
-        ys = chain([xt], flags=0)
+        ys = chain([xt], flags=CHAIN)
         torch.cuda.synchronize()
         xin = x0
         for L, y in zip(Ls, ys):
@@ -117,7 +118,7 @@ def test_dependent_chain(dt, dev):
     # layer by layer through single-layer chains: identical bits
     xi = xt
     for m, y in zip(ms, ys):
-        y1 = GemvChain([m])([xi], flags=0)[0]
+        y1 = GemvChain([m])([xi], flags=CHAIN)[0]
         assert torch.equal(y1.view(torch.int16), y.view(torch.int16))
         xi = y1
 
@@ -134,8 +135,8 @@ def test_chain_on_reference_goldens_at_baseline_sizes(name, dev):
     m = spec_to_module(L, dev)
     xt = bits_to_tensor(x, dt, dev).reshape(x.shape)
     chain = GemvChain([m] * 6)
-    assert chain.kernel_name(1, 0) == "gemv_k256t_kernel"
-    ys = chain([xt] * 6, flags=0)
+    assert chain.kernel_name(1, CHAIN) == "gemv_k256c_kernel"
+    ys = chain([xt] * 6, flags=CHAIN)
     torch.cuda.synchronize()
     err = rel_err(tensor_to_bits(ys[0]), y, dt)
     assert err <= TOL[dt], f"{name}: {err:.3e}"
@@ -174,13 +175,13 @@ def test_chain_in_a_hipgraph_and_long_chains(dev):
     xs = [torch.zeros(1, 1, 2048, dtype=torch.float16, device=dev) for _ in range(n)]
     ys = [torch.empty(1, 1, 1024, dtype=torch.float16, device=dev) for _ in range(n)]
     chain = GemvChain([m] * n)
-    chain(xs, ys, flags=0)          # warm-up outside the capture
+    chain(xs, ys, flags=CHAIN)          # warm-up outside the capture
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
     s = torch.cuda.Stream()
     with torch.cuda.stream(s):
         with torch.cuda.graph(g, stream=s):
-            chain(xs, ys, flags=0)
+            chain(xs, ys, flags=CHAIN)
     for rep in range(2):
         vals = [_x(2048, "f16", "llm", 100 + rep * n + i) for i in range(n)]
         for xt, v in zip(xs, vals):

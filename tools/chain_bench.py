@@ -2,7 +2,7 @@
 """Ring of R distinct layers, one decode token per layer, every mode captured in a hipGraph and
 replayed interleaved on the same box: us per layer for
   single : one vptq_quant_gemv launch per layer (the library's default kernel)
-  t1     : one launch of the chain kernel (gemv_k256t) per layer
+  t1     : one launch of the chain kernel (gemv_k256c) per layer
   chainN : the ring as launches of N layers each (independent layers)
   dep    : the ring as ONE dependent chain (x of layer i + 1 is y of layer i)
 python tools/chain_bench.py --hidden 8192 [--rows O] [--ring 32] [--reps 5] [--libs name=path,...]"""
@@ -62,10 +62,10 @@ def main():
             else:
                 chains[key] = [GemvChain(ring[i:i + n]) for i in range(0, R, n)]
         if dependent:
-            chains[key][0]([x], ys, flags=0)
+            chains[key][0]([x], ys, flags=8)
         else:
             for i, c in enumerate(chains[key]):
-                c(xs[i * n:(i + 1) * n], ys[i * n:(i + 1) * n], flags=0)
+                c(xs[i * n:(i + 1) * n], ys[i * n:(i + 1) * n], flags=8)
 
     modes = {}
     for name in a.modes.split(","):

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Per-wave cycle accounting of the chain kernel (library built with -DVPTQ_K256T_PROF=1, run with
-VPTQ_K256T_PROF=1): one launch of `--layers` layers, averages over all waves.
-  VPTQ_HIP_LIB=tools/_build/libvptq_hip_prof.so VPTQ_K256T_PROF=1 python tools/chain_prof.py --hidden 8192"""
+"""Per-wave cycle accounting of the chain kernel (library built with -DVPTQ_K256C_PROF=1, run with
+VPTQ_K256C_PROF=1): one launch of `--layers` layers, averages over all waves.
+  VPTQ_HIP_LIB=tools/_build/libvptq_hip_prof.so VPTQ_K256C_PROF=1 python tools/chain_prof.py --hidden 8192"""
 import argparse, ctypes as C, os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

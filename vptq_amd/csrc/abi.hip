@@ -248,25 +248,32 @@ int vptq_quant_gemv_grouped(const VptqLayerDesc* descs, int n, const void* const
   return VPTQ_OK;
 }
 
-// ---- chain: one persistent launch per <= 32 layers (gemv_k256t.hip), else layer by layer ----
+// ---- chain: one persistent launch per <= 32 layers (gemv_k256c.hip), else layer by layer ----
 static bool chain_one_kernel(const VptqLayerDesc* descs, int n, const void* const* x, int tokens, int flags) {
   if (tokens != 1 || (flags & (VPTQ_GEMV_FORCE_GENERIC | VPTQ_GEMV_EXACT | VPTQ_GEMV_FORCE_VALU))) return false;
   for (int i = 0; i < n; ++i) {
-    if (descs[i].dtype != descs[0].dtype || !vptq::gemv_k256t_eligible(descs[i], tokens)) return false;
+    if (descs[i].dtype != descs[0].dtype || !vptq::gemv_k256c_eligible(descs[i], tokens)) return false;
     if (x && (((uintptr_t)x[i]) & 3) != 0) return false;
+  }
+  // a chain that cannot keep the workgroups busy (one small layer, q / k / v of a small model) is better
+  // served by the per-layer kernels; VPTQ_GEMV_FORCE_MFMA takes the chain kernel regardless (tests)
+  if (!(flags & VPTQ_GEMV_FORCE_MFMA)) {
+    const bool dependent = (flags & VPTQ_GEMV_CHAIN_DEPENDENT) != 0;
+    for (int i0 = 0; i0 < n; i0 += 32)
+      if (!vptq::gemv_k256c_fills_device(descs + i0, n - i0 < 32 ? n - i0 : 32, dependent)) return false;
   }
   return true;
 }
 
 size_t vptq_quant_gemv_chain_workspace_bytes(int n, int flags) {
-  return (flags & VPTQ_GEMV_CHAIN_DEPENDENT) && n > 0 ? (size_t)n * 4 : 0;
+  return (flags & VPTQ_GEMV_CHAIN_DEPENDENT) && n > 0 ? (size_t)n * 1024 : 0;   // 256 arrival flags per layer
 }
 
 const char* vptq_quant_gemv_chain_kernel_name(const VptqLayerDesc* descs, int n, int tokens, int flags) {
   if (!descs || n < 1 || n > VPTQ_CHAIN_MAX || tokens < 1 || tokens > VPTQ_GEMV_MAX_TOKENS) return nullptr;
   for (int i = 0; i < n; ++i)
     if (validate_layer(&descs[i]) != VPTQ_OK) return nullptr;
-  return chain_one_kernel(descs, n, nullptr, tokens, flags) ? "gemv_k256t_kernel" : "per-layer";
+  return chain_one_kernel(descs, n, nullptr, tokens, flags) ? "gemv_k256c_kernel" : "per-layer";
 }
 
 int vptq_quant_gemv_chain(const VptqLayerDesc* descs, int n, const void* const* x, void* const* y,
@@ -285,8 +292,9 @@ int vptq_quant_gemv_chain(const VptqLayerDesc* descs, int n, const void* const* 
   hipStream_t st = (hipStream_t)stream;
   if (!chain_one_kernel(descs, n, x, tokens, flags)) {
     // stream order is the dependency
+    const int pflags = lflags & ~VPTQ_GEMV_FORCE_MFMA;
     for (int i = 0; i < n; ++i) {
-      const int rc = vptq_quant_gemv(&descs[i], x[i], y[i], tokens, lflags, nullptr, 0, stream);
+      const int rc = vptq_quant_gemv(&descs[i], x[i], y[i], tokens, pflags, nullptr, 0, stream);
       if (rc) return rc;
     }
     return VPTQ_OK;
@@ -300,10 +308,10 @@ int vptq_quant_gemv_chain(const VptqLayerDesc* descs, int n, const void* const* 
   }
   for (int i0 = 0; i0 < n; i0 += 32) {
     const int m = n - i0 < 32 ? n - i0 : 32;
-    const hipError_t e = vptq::launch_gemv_k256t(descs + i0, m, x + i0, y + i0, lflags, dependent,
-                                                 dependent ? (uint32_t*)workspace + i0
-                                                           : (getenv("VPTQ_K256T_PROF") ? (uint32_t*)workspace : nullptr), st);
-    if (e != hipSuccess) return hip_fail(e, "gemv_k256t launch");
+    const hipError_t e = vptq::launch_gemv_k256c(descs + i0, m, x + i0, y + i0, lflags, dependent,
+                                                 dependent ? (uint32_t*)workspace + (size_t)i0 * 256
+                                                           : (getenv("VPTQ_K256C_PROF") ? (uint32_t*)workspace : nullptr), st);
+    if (e != hipSuccess) return hip_fail(e, "gemv_k256c launch");
   }
   return VPTQ_OK;
 }

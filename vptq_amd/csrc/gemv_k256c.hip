@@ -1,0 +1,921 @@
+// Fused dequant + GEMV for the canonical "2-bit" VPTQ format (v = 8, 256 + 256 centroids):
+// ONE persistent launch that walks a CHAIN of layers.  Same contract as gemv_k256m.hip /
+// gemv_k256.hip, same reference: n calls of `quant_gemv` (vptq/ops/quant_gemm.py:214-228), each
+// of them csrc/kernels/quant_gemv.cuh:11-186 + the tmp.sum of csrc/quant_gemv.cu:203-235.
+//
+// Why.  One launch per layer (gemv_k256m.hip) pays, per 8192^2 layer, ~3 us of launch boundary,
+// prologue (codebook image, activations) and epilogue around ~4 us of accumulation - and a
+// workgroup that streams 64 KiB cannot keep HBM busy while it does the other things.  Here a
+// workgroup's work is ONE FLAT STREAM OF SWEEPS over (layer, row group, sweep):
+//  * a wave owns 128 consecutive columns of a sweep (16 waves = 2048 columns) for kCRows = 8
+//    vector-rows: per sweep and lane two 16-byte index loads (8 columns of vector-rows j and
+//    4 + j), and 4 bytes each of x, scale and bias (columns 2 lane, 2 lane + 1 of its block).
+//    Everything is requested kCDepth sweeps ahead, across row-group and layer boundaries, into a
+//    register queue with static slots (the loop is unrolled by the depth), so that every wait is
+//    the counted, in-order `s_waitcnt vmcnt(n)`.
+//  * the wave stages f16(scale * x) of its own 128 columns itself (wave-private 256-byte LDS slot:
+//    a wave's LDS operations execute in order, no barrier), and sums bias * x on the way.
+//  * arithmetic = the folded form of gemv_k256m.hip: lane = (column chunk of 8, vector-row j);
+//    v_mfma_f32_4x4x4 with X = x' * I as 64 x 4 FMAs, main and residual entry gathered with
+//    ds_read_b128 from the conflict-free lane-split image (row e = 8 replicas of main entry e +
+//    8 of residual entry e).  Two row subgroups per sweep share the x operand (2 of the 6
+//    v_perm_b32 per index pair) and halve the per-sweep bookkeeping per byte.
+//    [A transposing gather (ds_read_b64_tr_b16: result lane (row, output) gets 4 columns of one
+//    output = the B operand of a real contraction over columns, v_mfma_f32_16x16x32 with
+//    identical A rows, no x-operand perms, no cross-lane reduction) was built first and measured:
+//    46.8 against 34.6 SIMD cycles per index-wave in isolation (tools/ubench_loop_t.hip; both sit
+//    on the LDS - 2 KiB of gathered entries per index-wave - and the matrix pipe, 32 cycles each;
+//    the 4x4x4 form overlaps them better), no difference inside the kernel; DESIGN.md section 4.9.]
+//  * the NEXT layer's codebook image is filled into the second image buffer by LDS-DMA
+//    (global_load_lds_dwordx4: no registers, issued as inline assembly because a DMA the compiler
+//    can see makes it wait for every load in flight) as soon as every wave has left the layer
+//    that used the buffer; kCDepth sweeps later only younger loads are in flight (vmcnt retires in
+//    order), so the fill has landed.  Hand-over between the waves (image free / image landed,
+//    partial sums) goes through LDS counters with fences restricted to the LOCAL address space -
+//    an ordinary workgroup-scope release also waits for every global load in flight, i.e. for the
+//    whole queue.
+//  * row groups are dealt to the workgroups in blocks of consecutive ones, at least kCMinSteps
+//    sweeps per visit of a layer; a layer that needs fewer blocks than there are workgroups
+//    leaves the rest to the next layers (independent chains: q / k / v, gate / up, a ring).
+//  * the SIMDs serve their waves oldest first, so the waves of a workgroup drift apart until the
+//    fast ones wait at every hand-over: issue priority by arrival order at the last row group.
+//  * DEP = dependent chain (x of layer i + 1 is y of layer i): outputs are stored write-through at
+//    device scope, one arrival flag per workgroup and layer, x is read with device-coherent loads;
+//    index words, scales and the image of the next layer are still requested ahead.  Measured:
+//    11.5 us per 8192^2 layer - the hand-over through memory costs ~6 us per layer, more than the
+//    kernel boundary it replaces (7.3 us with one launch per layer): exists for completeness.
+#include <type_traits>
+
+#include "common.h"
+#include "kernels.h"
+#include "k256.h"
+
+namespace vptq {
+
+constexpr int kCThreads = 1024;
+constexpr int kCWaves = kCThreads / 64;
+constexpr int kCBlockCols = 128;                     // columns of one wave per sweep
+constexpr int kCSweepCols = kCWaves * kCBlockCols;   // 2048
+#ifndef VPTQ_K256C_SUB
+#define VPTQ_K256C_SUB 2
+#endif
+constexpr int kCSub = VPTQ_K256C_SUB;                // row subgroups (4 vector-rows each) per row group
+constexpr int kCRows = 4 * kCSub;                    // vector-rows per row group
+constexpr int kCOut = 8 * kCRows;                    // outputs per row group
+static_assert(kCSub == 1 || kCSub == 2, "row subgroups per sweep");
+// sweeps in flight per wave: bandwidth x latency is ~48 KiB per CU
+#ifndef VPTQ_K256C_DEPTH
+#define VPTQ_K256C_DEPTH 3
+#endif
+constexpr int kCDepth = VPTQ_K256C_DEPTH;
+static_assert(kCDepth >= 2 && kCDepth <= 6, "queue depth");
+constexpr int kCSlots = 4;                           // cross-wave partial-sum slots
+constexpr uint32_t kCImgBytes = 65536;               // 256 rows x 16 units x 16 B
+constexpr uint32_t kCXsOff = 2 * kCImgBytes;         // wave-private activation slots
+constexpr uint32_t kCXsWave = 256;
+constexpr uint32_t kCRedOff = kCXsOff + kCWaves * kCXsWave;
+constexpr uint32_t kCRedBOff = kCRedOff + kCSlots * kCWaves * kCOut * 4;
+constexpr uint32_t kCCntOff = kCRedBOff + kCSlots * kCWaves * 4;
+constexpr uint32_t kCTabOff = kCCntOff + 64;         // the launch's layer arguments, 128 B per layer
+constexpr uint32_t kCLdsBytes = kCTabOff + kMaxGroup * 128;
+static_assert(kCLdsBytes <= 163840, "LDS");
+constexpr int kCFlagStride = 256;   // DEP: arrival flags per layer (one per workgroup)
+
+// timing-only ablations (results wrong): bit 0 no MFMAs, bit 1 no gathers, bit 2 no x / scale /
+// bias loads, bit 3 no waits for the image hand-over between the waves
+#ifndef VPTQ_K256C_ABLATE
+#define VPTQ_K256C_ABLATE 0
+#endif
+// bring-up builds: give up a wait after that many polls, so that a protocol error shows as wrong
+// results instead of a hung GPU
+#ifndef VPTQ_K256C_SPIN_LIMIT
+#define VPTQ_K256C_SPIN_LIMIT 0
+#endif
+// profiling build (tools/chain_prof.py): every wave adds up the shader-clock cycles it spends
+// waiting for its index words, consuming a sweep, requesting the next one and in the rare paths,
+// and stores them at P.sync[(workgroup * 16 + wave) * 8 ...] (non-dependent launches)
+#ifndef VPTQ_K256C_PROF
+#define VPTQ_K256C_PROF 0
+#endif
+#ifndef VPTQ_K256C_BALANCE
+#define VPTQ_K256C_BALANCE 1
+#endif
+
+struct K256CParams {
+  int n_layers;
+  int tokens;        // token count | kOutF32Bit
+  uint32_t* sync;    // DEP: kCFlagStride arrival flags per layer (zeroed before the launch)
+  K256Layer layer[kMaxGroup];
+};
+
+typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
+
+// layer L of the kernel arguments in one batch of scalar loads (see k256.h:load_layer_args) ...
+static __device__ __forceinline__ K256Layer c_load_layer(int L) {
+  static_assert(sizeof(K256Layer) == 120 && offsetof(K256CParams, layer) == 16, "kernarg layout");
+  typedef int i16_t __attribute__((ext_vector_type(16)));
+  typedef int i8_t __attribute__((ext_vector_type(8)));
+  typedef int i4_t __attribute__((ext_vector_type(4)));
+  typedef int i2_t __attribute__((ext_vector_type(2)));
+  L = __builtin_amdgcn_readfirstlane(L);   // (wave-uniform by construction; the compiler cannot always prove it)
+  const char __attribute__((address_space(4)))* lp =
+      (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + 16 +
+      (size_t)L * sizeof(K256Layer);
+  i16_t a; i8_t b; i4_t c; i2_t d;
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile(
+      "s_load_dwordx16 %0, %4, 0x0\n\t"
+      "s_load_dwordx8 %1, %4, 0x40\n\t"
+      "s_load_dwordx4 %2, %4, 0x60\n\t"
+      "s_load_dwordx2 %3, %4, 0x70\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&s"(a), "=&s"(b), "=&s"(c), "=&s"(d)
+      : "s"(lp)
+      : "memory");
+#else
+  a = i16_t{}; b = i8_t{}; c = i4_t{}; d = i2_t{}; (void)lp;
+#endif
+  K256Layer Ly;
+  __builtin_memcpy((char*)&Ly, &a, 64);
+  __builtin_memcpy((char*)&Ly + 64, &b, 32);
+  __builtin_memcpy((char*)&Ly + 96, &c, 16);
+  __builtin_memcpy((char*)&Ly + 112, &d, 8);
+  Ly.idx = as_global(Ly.idx); Ly.cent = as_global(Ly.cent); Ly.rcent = as_global(Ly.rcent);
+  Ly.x = as_global(Ly.x); Ly.y = as_global(Ly.y); Ly.scale = as_global(Ly.scale);
+  Ly.wbias = as_global(Ly.wbias); Ly.bias = as_global(Ly.bias);
+  return Ly;
+}
+// ... and out of the copy in LDS (kCTabOff; filled once per workgroup): a trip to the
+// kernel-argument segment costs ~0.4 us, and a wave looks at several layers per layer it enters
+static __device__ __forceinline__ K256Layer c_load_layer_lds(int L) {
+  L = __builtin_amdgcn_readfirstlane(L);
+  const uint32_t a = kCTabOff + (uint32_t)L * 128u;
+  uint32_t w[32];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const u32x4 v = lds_load16(a + 16u * i);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[4 * i + j] = (uint32_t)__builtin_amdgcn_readfirstlane((int)v[j]);
+  }
+  K256Layer Ly;
+  __builtin_memcpy((char*)&Ly, w, sizeof(K256Layer));
+  Ly.idx = as_global(Ly.idx); Ly.cent = as_global(Ly.cent); Ly.rcent = as_global(Ly.rcent);
+  Ly.x = as_global(Ly.x); Ly.y = as_global(Ly.y); Ly.scale = as_global(Ly.scale);
+  Ly.wbias = as_global(Ly.wbias); Ly.bias = as_global(Ly.bias);
+  return Ly;
+}
+
+// position in the workgroup's flat stream; everything is wave-uniform
+struct CCursor {
+  int L;    // layer; n_layers = past the end
+  int rg;   // row group (kCRows vector-rows)
+  int re;   // end of this workgroup's block of row groups in layer L
+  int ns;   // sweeps per row group of layer L
+  int ng;   // row groups of layer L
+};
+// the fields of a layer each side needs (the rest of a K256Layer dies right after the load)
+struct CIssueL { const uint32_t* idx; const uint16_t* x; const uint16_t* scale; const uint16_t* wbias; int N, G, row_words; };
+struct CConsL { uint16_t* y; const uint16_t* bias; int N, G, O; };
+struct CFillL { const uint32_t* cent; const uint32_t* rcent; };
+static __device__ __forceinline__ CIssueL c_issue_of(const K256Layer& L) {
+  return CIssueL{L.idx, L.x, L.scale, L.wbias, L.N, L.G, L.row_words};
+}
+static __device__ __forceinline__ CConsL c_cons_of(const K256Layer& L) { return CConsL{L.y, L.bias, L.N, L.G, L.O}; }
+
+// f(slot 0), f(slot 1), ... f(slot kCDepth - 1) with the slot as a compile-time constant
+template <typename F>
+static __device__ __forceinline__ void c_for_slots(F&& f) {
+  f(std::integral_constant<int, 0>{});
+  f(std::integral_constant<int, 1>{});
+  if constexpr (kCDepth > 2) f(std::integral_constant<int, (kCDepth > 2 ? 2 : 0)>{});
+  if constexpr (kCDepth > 3) f(std::integral_constant<int, (kCDepth > 3 ? 3 : 0)>{});
+  if constexpr (kCDepth > 4) f(std::integral_constant<int, (kCDepth > 4 ? 4 : 0)>{});
+  if constexpr (kCDepth > 5) f(std::integral_constant<int, (kCDepth > 5 ? 5 : 0)>{});
+}
+
+template <typename DT, bool DEP>
+__global__ __launch_bounds__(kCThreads) void gemv_k256c_kernel(const K256CParams P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  {
+    typedef __attribute__((address_space(3))) unsigned char lds_u8_t;
+    if ((uint32_t)(uintptr_t)(lds_u8_t*)smem != 0u) __builtin_trap();  // absolute LDS addressing
+  }
+  constexpr int D = kCDepth;
+  const int n_layers = P.n_layers;
+  const bool out_f32 = (P.tokens & kOutF32Bit) != 0;
+  // (a local copy: a lambda that refers to the by-value kernel argument P takes its address, and the
+  // compiler then copies the whole 3.8 KB struct to scratch memory)
+  uint32_t* const sync = as_global(P.sync);
+  const int W = (int)gridDim.x, bid = (int)blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // ---- lane = (column chunk blk = lane >> 2, vector-row j = lane & 3).  The two gathers of an index
+  // are split across the lanes: in gather A the lanes with bit 3 clear fetch the main entry (unit
+  // lane & 7 of image row e), the others the residual entry (unit 8 + (lane & 7)); gather B is the
+  // complement: every 16-lane group of a ds_read_b128 touches 16 different units (gemv_k256m.hip).
+  // address = {0, base.byte2 = image buffer, index byte, base.byte0}; dword q of the index words holds
+  // columns 2q (bytes 0 = main, 1 = residual index) and 2q + 1 (bytes 2, 3)
+  const uint32_t jrow = (uint32_t)lane & 3u;
+  const uint32_t hi8 = ((uint32_t)lane >> 3) & 1u;
+  uint32_t baseA = ((hi8 << 3) | ((uint32_t)lane & 7u)) << 4;
+  uint32_t baseB = (((hi8 ^ 1u) << 3) | ((uint32_t)lane & 7u)) << 4;
+  const uint32_t selGA[2] = {0x0c020400u | (hi8 << 8), 0x0c020600u | (hi8 << 8)};
+  const uint32_t selGB[2] = {0x0c020400u | ((hi8 ^ 1u) << 8), 0x0c020600u | ((hi8 ^ 1u) << 8)};
+  // x operand of the 4x4x4 MFMA: x' * e_j as two packed pairs, cut out of a packed x' register
+  const uint32_t selA[2] = {jrow == 0 ? 0x0c0c0504u : jrow == 1 ? 0x05040c0cu : 0x0c0c0c0cu,
+                            jrow == 0 ? 0x0c0c0706u : jrow == 1 ? 0x07060c0cu : 0x0c0c0c0cu};
+  const uint32_t selB[2] = {jrow == 2 ? 0x0c0c0504u : jrow == 3 ? 0x05040c0cu : 0x0c0c0c0cu,
+                            jrow == 2 ? 0x0c0c0706u : jrow == 3 ? 0x07060c0cu : 0x0c0c0c0cu};
+
+  // ---- LDS map: [0, 64 Ki) image buffer 0 | [64 Ki, 128 Ki) image buffer 1 | per wave 256 B of
+  // staged activations | partial-sum slots | counters | layer table
+  const uint32_t xs_base = kCXsOff + (uint32_t)wave * kCXsWave;
+  const uint32_t st_addr = xs_base + (uint32_t)lane * 4u;           // this lane stages columns 2 lane, 2 lane + 1
+  const uint32_t xq_addr = xs_base + ((uint32_t)lane >> 2) * 16u;   // ... and reads the 16 bytes of its chunk
+  float* const red = (float*)(smem + kCRedOff);      // [slot][wave][kCOut]
+  float* const red_b = (float*)(smem + kCRedBOff);   // [slot][wave]
+  uint32_t* const slot_cnt = (uint32_t*)(smem + kCCntOff);  // [kCSlots] waves arrived
+  uint32_t* const slot_done = slot_cnt + kCSlots;           // [kCSlots] row groups finished
+  uint32_t* const free_cnt = slot_cnt + 2 * kCSlots;        // [2] waves that left a layer of image buffer b
+  uint32_t* const ready_cnt = free_cnt + 2;                 // [2] waves whose part of a fill has landed
+  uint32_t* const dep_seen = free_cnt + 4;                  // DEP: last layer whose producers wave 0 has seen arrive
+
+  // ---- the flat stream ----
+  // first layer >= c.L in which this workgroup owns row groups: a block of K256Layer::pf_chunk
+  // consecutive ones, block number (bid - first workgroup of the layer) mod W (K256Layer::wgs = the
+  // running total of blocks mod W: the layers continue each other's round robin, so that layers
+  // that need fewer than W blocks run side by side on different workgroups).  Returns that layer's
+  // arguments (undefined past the end).
+  auto enter_layer = [&](CCursor& c, auto from_lds) __attribute__((always_inline)) -> K256Layer {
+    constexpr bool kLds = decltype(from_lds)::value;
+    const int L0 = c.L < n_layers ? c.L : n_layers - 1;
+    K256Layer Ly = kLds ? c_load_layer_lds(L0) : c_load_layer(L0);
+    while (c.L < n_layers) {
+      c.ng = (Ly.N + kCRows - 1) / kCRows;
+      c.ns = (Ly.G + kCSweepCols - 1) / kCSweepCols;
+      int r0 = bid - Ly.wgs;
+      if (r0 < 0) r0 += W;
+      r0 *= Ly.pf_chunk;
+      if (r0 < c.ng) { c.rg = r0; c.re = r0 + Ly.pf_chunk < c.ng ? r0 + Ly.pf_chunk : c.ng; break; }
+      if (++c.L < n_layers) Ly = kLds ? c_load_layer_lds(c.L) : c_load_layer(c.L);
+    }
+    return Ly;
+  };
+  using from_args = std::integral_constant<bool, false>;
+  using from_table = std::integral_constant<bool, true>;
+  // the layer table into LDS: one dword per thread (kMaxGroup x 30 <= 1024)
+  {
+    static_assert(kMaxGroup * 30 <= kCThreads, "one dword of the layer table per thread");
+    const int tl = tid >> 5, tw = tid & 31;
+    if (tl < n_layers && tw < 30) {
+      const uint32_t* const src = (const uint32_t*)as_global(
+          (const char*)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr() + 16 + tl * 120 + tw * 4);
+      *(lds_u32_t*)(uintptr_t)(kCTabOff + (uint32_t)tl * 128u + (uint32_t)tw * 4u) = *src;
+    }
+  }
+
+  // Issue side (D sweeps ahead of the consume side): cursor + incremental state, so that a step
+  // costs a handful of instructions and everything rare sits behind ONE branch.
+  CCursor ci{0, 0, 0, 1, 1};   // row group being requested
+  bool ci_end = false;         // the stream has ended: the last row group is re-requested (harmless
+                               // re-reads keep every step's set of loads the same)
+  CIssueL Li;
+  {
+    const K256Layer L0 = enter_layer(ci, from_args{});
+    if (ci.L >= n_layers) return;     // (whole workgroup: nothing to do)
+    Li = c_issue_of(L0);
+  }
+  CCursor cc = ci;             // row group being consumed
+  CConsL Lc;
+  CFillL Lf;
+  {
+    const K256Layer L0 = c_load_layer(cc.L);
+    Lc = c_cons_of(L0);
+    Lf = CFillL{L0.cent, L0.rcent};
+  }
+  const uint32_t lane_chunk2 = ((uint32_t)lane >> 2) * 16u;   // byte offset of this lane's 8 index elements in a block
+  uint32_t i_rowoff[kCSub];   // per lane: byte offset of its vector-row (subgroup q) in the layer's index tensor
+  int i_col2 = 0;             // byte offset (2 x column) of the wave's block in the sweep to request
+  int i_left = 0;             // sweeps of the row group still to request
+  int i_max8 = 0, i_max2 = 0;   // 2 (G - 8), 2 (G - 2): columns past G re-read the last ones
+  auto issue_row_group = [&]() __attribute__((always_inline)) {
+    const int row0 = ci.rg * kCRows;
+#pragma unroll
+    for (int q = 0; q < kCSub; ++q) {
+      const int want = row0 + 4 * q + (int)jrow;
+      const int r = want < Li.N ? want : Li.N - 1;   // rows past N re-read the last row (not stored)
+      i_rowoff[q] = (uint32_t)r * ((uint32_t)Li.row_words * 4u);
+    }
+    i_col2 = wave * (kCBlockCols * 2);
+    i_left = ci.ns;
+    i_max8 = (Li.G - 8) * 2;
+    i_max2 = (Li.G - 2) * 2;
+  };
+  issue_row_group();
+  auto issue_next_row_group = [&]() {   // cold
+    if (!ci_end) {
+      CCursor n = ci;
+      n.rg += 1;
+      if (n.rg >= n.re) {
+        ++n.L;
+        const K256Layer Ln = enter_layer(n, from_table{});
+        if (n.L < n_layers) { ci = n; Li = c_issue_of(Ln); }
+        else ci_end = true;
+      } else {
+        ci = n;
+      }
+    }
+    issue_row_group();
+  };
+
+  if (tid < 16) slot_cnt[tid] = 0u;
+  __syncthreads();   // the only barrier: counters zeroed and the layer table in LDS before anybody uses them
+
+  // ---- image fill by LDS-DMA: wave w brings rows 16 w .. 16 w + 15 (4 instructions of 4 rows;
+  // lane l = unit l & 15 of row l >> 4: 16 bytes of entry (row) of table (unit >> 3)).  Invisible
+  // loads can only make the compiler's counted waits stricter, never looser (vmcnt retires in order).
+  auto fill_image = [&](const CFillL& F, uint32_t buf) __attribute__((always_inline)) {
+    const uint32_t unit = (uint32_t)lane & 15u, r4 = (uint32_t)lane >> 4;
+    // (table choice by arithmetic: as a per-lane select of two pointers the compiler built a two-entry
+    // array in scratch memory and indexed it - a scratch load, waited for with vmcnt(0))
+    const uint64_t tc = (uint64_t)(uintptr_t)F.cent, tr = (uint64_t)(uintptr_t)F.rcent;
+    const uint64_t pick = (unit >> 3) ? ~0ull : 0ull;
+    const uint64_t va = tc + ((tr - tc) & pick) + (uint64_t)(((uint32_t)wave * 16u + r4) * 16u);
+    const uint32_t dst = buf * kCImgBytes + (uint32_t)wave * 16u * 256u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t d = (uint32_t)__builtin_amdgcn_readfirstlane((int)(dst + (uint32_t)i * 1024u));
+      const uint64_t v = va + (uint64_t)(i * 64);
+      uint32_t keep_m0;   // (M0 belongs to the compiler: saved and restored inside the statement)
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep_m0) : "v"(v), "s"(d) : "memory");
+    }
+  };
+  // Hand-over between the waves goes through LDS only, and a wave's LDS operations execute in
+  // order: fences restricted to the local address space.  An ordinary workgroup-scope release also
+  // waits for every global load in flight (s_waitcnt vmcnt(0)) - here the whole queue of index
+  // words requested ahead.
+  auto lds_release = [&]() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); };
+  auto lds_acquire = [&]() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); };
+  auto lds_inc = [&](uint32_t* p) __attribute__((always_inline)) {
+    lds_release();
+    if (lane == 0) __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+  auto lds_wait_ge = [&](uint32_t* p, uint32_t need) __attribute__((always_inline)) {
+    if constexpr ((VPTQ_K256C_ABLATE & 8) != 0) { if (p >= free_cnt && p < free_cnt + 4) return; }
+#if VPTQ_K256C_SPIN_LIMIT
+    for (int it = 0; it < VPTQ_K256C_SPIN_LIMIT; ++it) {
+      if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= need) break;
+      __builtin_amdgcn_s_sleep(1);
+    }
+#else
+    while (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need)
+      __builtin_amdgcn_s_sleep(1);
+#endif
+    lds_acquire();
+  };
+
+#if VPTQ_K256C_PROF
+  unsigned long long pf_wait = 0, pf_cons = 0, pf_issue = 0, pf_cold = 0, pf_steps = 0, pf_t0 = 0;
+  auto now = [&](uint32_t dep) -> unsigned long long {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : "v"(dep) : "memory");
+    return t;
+  };
+#endif
+
+  // ---- loads of one sweep
+  u32x4 iw[D][kCSub];
+  uint32_t xr[D], sr[D], br[D];
+  int q_layer[D], q_col2[D];   // DEP: layer and block offset of the sweep in each queue slot
+  constexpr int kLPS = ((VPTQ_K256C_ABLATE & 4) ? 0 : 3) + kCSub;   // vector loads per sweep
+  auto load_x = [&](auto slot_c, const uint16_t* xp, int max2, int col2) __attribute__((always_inline)) {
+    constexpr int S = decltype(slot_c)::value;
+    const int want = col2 + 4 * lane;
+    const uint32_t* const xa32 = (const uint32_t*)as_global((const char*)xp + (uint32_t)(want < max2 ? want : max2));
+    // DEP: another workgroup wrote it in this launch - a device-coherent load (sc1)
+    xr[S] = DEP ? __hip_atomic_load(xa32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *xa32;
+  };
+  auto issue = [&](auto slot_c) __attribute__((always_inline)) {
+    constexpr int S = decltype(slot_c)::value;
+    const int want = i_col2 + (int)lane_chunk2;
+    const uint32_t coff = (uint32_t)(want < i_max8 ? want : i_max8);
+    if constexpr ((VPTQ_K256C_ABLATE & 4) != 0) {
+      xr[S] = coff; sr[S] = 0x3c003c00u; br[S] = coff ^ 0x1234u;
+      asm volatile("" : "+v"(xr[S]), "+v"(sr[S]), "+v"(br[S]));
+    } else {
+      const int want2 = i_col2 + 4 * lane;
+      const uint32_t c2 = (uint32_t)(want2 < i_max2 ? want2 : i_max2);
+      load_x(slot_c, Li.x, i_max2, i_col2);
+      sr[S] = *(const uint32_t*)as_global((const char*)Li.scale + c2);
+      br[S] = *(const uint32_t*)as_global((const char*)Li.wbias + c2);
+    }
+#pragma unroll
+    for (int q = 0; q < kCSub; ++q)
+      iw[S][q] = __builtin_nontemporal_load((const u32x4*)as_global((const char*)Li.idx + (i_rowoff[q] + coff)));
+    if (DEP) { q_layer[S] = ci_end ? -1 : ci.L; q_col2[S] = i_col2; }
+    i_col2 += kCSweepCols * 2;
+    if (--i_left == 0) issue_next_row_group();
+  };
+
+  // ---- state of the consume side
+  f32x4 acc[kCSub][2];   // [subgroup][outputs 0-3 / 4-7 of this lane's vector-row]
+  float accb = 0.f;
+  auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < kCSub; ++q) { acc[q][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[q][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    accb = 0.f;
+  };
+  int c_col = wave * kCBlockCols;   // first column of the wave's block in the sweep being consumed
+  int c_left = cc.ns;               // sweeps of the row group still to consume
+  bool done = false;
+  uint32_t use = 0;            // how many layers this workgroup has entered before the current one
+  uint32_t q_done = 0;         // row groups this workgroup has finished
+  bool fill_pending = false;   // the next layer's image has not been requested yet
+  int land_steps = 0;          // > 0: a fill was requested D - land_steps step ends ago
+  // "everything but the youngest n sweeps' loads has landed".  vmcnt retires in order: at the end
+  // of the j-th step after a fill the fill is older than j + 1 sweeps; at j = D - 1 those are
+  // exactly the D sweeps in flight.
+  auto wait_all_but = [&](int steps) __attribute__((always_inline)) {
+    switch (steps) {
+      case 1: asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kLPS * 1) : "memory"); break;
+      case 2: asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kLPS * 2) : "memory"); break;
+      case 3: asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kLPS * 3) : "memory"); break;
+      case 4: asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kLPS * 4) : "memory"); break;
+      case 5: asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kLPS * 5) : "memory"); break;
+      case 6: asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kLPS * 6) : "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+  };
+  static_assert(kLPS * kCDepth <= 63, "vmcnt is a 6-bit counter");
+  CCursor cf = cc;             // next layer with work (its image goes to buffer (use + 1) & 1)
+  auto plan_fill = [&]() __attribute__((always_inline)) {
+    cf = cc;
+    cf.L = cc.L + 1;
+    const K256Layer Ln = enter_layer(cf, from_table{});
+    Lf = CFillL{Ln.cent, Ln.rcent};
+    fill_pending = cf.L < n_layers;
+  };
+
+  // reduce over the 16 waves and store.  Per subgroup lane (blk, j) holds 8 partial outputs of
+  // vector-row j for its column chunk: sum over the 16 chunks of the wave - lane bits 5 and 4 by
+  // swap-and-add (halving the values carried), bits 3 and 2 by DPP row rotations.  Across the waves
+  // through LDS slots + arrival counters instead of a barrier (gemv_k256m.hip): the wave that
+  // arrives last sums and stores.
+  auto finish = [&]() __attribute__((always_inline)) {
+    const int rg = cc.rg;
+    const uint32_t slot = q_done % (uint32_t)kCSlots;
+    if (q_done >= (uint32_t)kCSlots) lds_wait_ge(&slot_done[slot], q_done - (uint32_t)kCSlots + 1u);
+    float* const rs = red + (slot * kCWaves + wave) * kCOut;
+#pragma unroll
+    for (int q = 0; q < kCSub; ++q) {
+      float v[8];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { v[i] = acc[q][0][i]; v[4 + i] = acc[q][1][i]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 4]), false, false);
+        v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 2]), false, false);
+        v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) v[i] = row_ror_add<4>(row_ror_add<8>(v[i]));
+      if ((lane & 12) == 0) {   // lane l now holds outputs 4 bit5 + 2 bit4 + {0, 1} of row l & 3
+        const int o8 = ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2;
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        *(f32x2*)&rs[q * 32 + (int)jrow * 8 + o8] = f32x2{v[0], v[1]};
+      }
+    }
+    const float sb = wave_sum(accb);
+    if (lane == 0) red_b[slot * kCWaves + wave] = sb;
+    uint32_t arrived = 0;
+    lds_release();
+    if (lane == 0)
+      arrived = __hip_atomic_fetch_add(&slot_cnt[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    arrived = __builtin_amdgcn_readfirstlane(arrived);
+    lds_acquire();
+#if VPTQ_K256C_BALANCE
+    // issue priority for the next row group by arrival order at this one: the early ones yield
+    if (arrived < 4u) __builtin_amdgcn_s_setprio(0);
+    else if (arrived < 8u) __builtin_amdgcn_s_setprio(1);
+    else if (arrived < 12u) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(3);
+#endif
+    if (arrived == (uint32_t)kCWaves - 1u) {
+      const int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+      const float* const pr = red + slot * (kCWaves * kCOut);
+      float sum;
+      int ol;   // output of the row group this lane stores
+      bool mine;
+      if constexpr (kCSub == 2) {
+        // 64 outputs: lane = output, 16 partials each, summed as a tree
+        ol = ln; mine = true;
+        float s[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          s[k] = (pr[(4 * k) * kCOut + ol] + pr[(4 * k + 1) * kCOut + ol]) + (pr[(4 * k + 2) * kCOut + ol] + pr[(4 * k + 3) * kCOut + ol]);
+        sum = (s[0] + s[1]) + (s[2] + s[3]);
+      } else {
+        // 32 outputs: lane (half, o) sums 8 of the 16 waves' partials, one lane swap joins the halves
+        const int half = ln >> 5;
+        ol = ln & 31; mine = ln < 32;
+        const float* const ps = pr + (half * 8) * kCOut + ol;
+        const float s0 = (ps[0] + ps[kCOut]) + (ps[2 * kCOut] + ps[3 * kCOut]);
+        const float s1 = (ps[4 * kCOut] + ps[5 * kCOut]) + (ps[6 * kCOut] + ps[7 * kCOut]);
+        const float hs = s0 + s1;
+        auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(hs), __float_as_uint(hs), false, false);
+        sum = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+      }
+      const int row = rg * kCRows + (ol >> 3);
+      const int o = row * 8 + (ol & 7);
+      const bool store = mine && row < Lc.N && o < Lc.O;
+      const float bdot = row16_allsum(red_b[slot * kCWaves + (ln & 15)]);
+      float bv = 0.f;
+      if (store && Lc.bias) bv = DT::to_float(as_global(Lc.bias)[o]);
+      const float total = sum + bdot;
+      if (store) {
+        if (out_f32) ((float*)as_global(Lc.y))[o] = total + bv;
+        else if (DEP)   // write-through at device scope (sc1): another workgroup reads it in this launch
+          __hip_atomic_store(as_global(Lc.y) + o, DT::from_float(total + bv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else as_global(Lc.y)[o] = DT::from_float(total + bv);
+      }
+      if (DEP) {
+        // the write-through stores of this wave have reached memory (every storing wave drains)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (cc.rg + 1 == cc.re) {
+          // this workgroup's part of the layer is stored: raise its flag (device scope).  The
+          // finalising waves of a workgroup's row groups are ordered through slot_done, so all
+          // earlier row groups' stores were drained before this point.  No release fence: an
+          // agent-scope release writes the L2 back (buffer_wbl2, ~1.3 us, serialised per XCD:
+          // 41 us per layer for 256 workgroups); one flag word per workgroup instead of a counter:
+          // 256 atomic increments of one word are serialised at the memory side (53 us per layer).
+          if (lane == 0)
+            __hip_atomic_store(&sync[(size_t)cc.L * kCFlagStride + (uint32_t)bid], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      if (lane == 0) {
+        slot_cnt[slot] = 0u;
+        lds_release();
+        __hip_atomic_store(&slot_done[slot], q_done + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+    ++q_done;
+  };
+
+  // ---- one sweep of this wave: 8 columns x kCSub vector-rows per lane.  A unit = one index: 2 perms
+  // for the gather addresses, 2 gathers (two units ahead of the arithmetic), 4 MFMAs (main /
+  // residual entry x outputs 0-3 / 4-7); the x operand (2 perms) is built once per column and
+  // shared by the subgroups.
+  auto consume = [&](auto slot_c) __attribute__((always_inline)) {
+    constexpr int S = decltype(slot_c)::value;
+    {
+      // activations: f16(s x) of this lane's two columns into the wave's slot, sum b x
+      const uint32_t keep = c_col + 2 * lane < Lc.G ? 0xffffffffu : 0u;
+      const uint32_t xv = xr[S] & keep;
+      accb = DT::dot2(xv, br[S], accb);
+      // (anchored here: left alone, the compiler sinks this towards its use in finish(), keeps the
+      // loaded register alive across the loop edge and copies it there - behind a wait for the
+      // loads the step has just issued)
+      asm volatile("" : "+v"(accb));
+      *(lds_u32_t*)(uintptr_t)st_addr = DT::mul2(xv, sr[S]);
+    }
+    const u32x4 xq = lds_load16(xq_addr);
+    constexpr int kUnits = 8 * kCSub, kAhead = 2, kNB = kAhead + 1;
+    u32x4 cv[kNB], rv[kNB];
+    auto gather = [&](int t) {   // unit t = column t / kCSub of subgroup t % kCSub
+      const int u = t / kCSub, q = t % kCSub;
+      const uint32_t w = iw[S][q][u >> 1];
+      const uint32_t aC = __builtin_amdgcn_perm(w, baseA, selGA[u & 1]);
+      const uint32_t aR = __builtin_amdgcn_perm(w, baseB, selGB[u & 1]);
+      if constexpr ((VPTQ_K256C_ABLATE & 2) != 0) {
+        asm volatile("" :: "v"(aC), "v"(aR));
+        cv[t % kNB] = iw[S][q]; rv[t % kNB] = iw[S][q];
+      } else {
+        cv[t % kNB] = lds_load16(aC);
+        rv[t % kNB] = lds_load16(aR);
+      }
+    };
+#pragma unroll
+    for (int t = 0; t < kAhead; ++t) gather(t);
+    u32x2 xo = u32x2{0u, 0u};
+#pragma unroll
+    for (int t = 0; t < kUnits; ++t) {
+      // fenced: left alone, the scheduler sinks the gathers next to their use (LDS latency exposed)
+      __builtin_amdgcn_sched_barrier(0);
+      if (t + kAhead < kUnits) gather(t + kAhead);
+      __builtin_amdgcn_sched_barrier(0);
+      const int u = t / kCSub, q = t % kCSub;
+      if (q == 0)
+        xo = u32x2{__builtin_amdgcn_perm(xq[u >> 1], 0u, selA[u & 1]), __builtin_amdgcn_perm(xq[u >> 1], 0u, selB[u & 1])};
+      const u32x4 c = cv[t % kNB], r = rv[t % kNB];
+      if constexpr ((VPTQ_K256C_ABLATE & 1) != 0) {
+        asm volatile("" :: "v"(c), "v"(r), "v"(xo));
+      } else {
+        acc[q][0] = DT::mfma4(xo, u32x2{c[0], c[1]}, acc[q][0]);
+        acc[q][1] = DT::mfma4(xo, u32x2{c[2], c[3]}, acc[q][1]);
+        acc[q][0] = DT::mfma4(xo, u32x2{r[0], r[1]}, acc[q][0]);
+        acc[q][1] = DT::mfma4(xo, u32x2{r[2], r[3]}, acc[q][1]);
+      }
+    }
+  };
+
+  // DEP: layer L > 0 reads what layer L - 1 of this launch wrote: wait until every workgroup that
+  // owns a part of it has raised its flag, then fetch x for the sweeps of layer L that are already
+  // in the queue (their index words, scales and bias values were requested ahead; x could not be)
+  auto dep_enter = [&](int L) __attribute__((always_inline)) {
+    if (L == 0) return;
+    // one wave per workgroup polls (4096 waves polling starve the stores that feed them); the
+    // others wait for its word in LDS
+    if (wave == 0) {
+      // the workgroups that own a block of layer L - 1: 0 .. blocks - 1 (every layer of a dependent
+      // chain starts at workgroup 0); lane i looks at the flags of workgroups 4i .. 4i + 3
+      // (out of the table in LDS: indexing the by-value kernel argument P.layer[] with a run-time
+      // index makes the compiler copy the whole array to scratch memory)
+      const K256Layer Lp = c_load_layer_lds(L - 1);
+      const int ng = (Lp.N + kCRows - 1) / kCRows, rpw = Lp.pf_chunk;
+      const int blocks = (ng + rpw - 1) / rpw;
+      const uint32_t* const fl = sync + (size_t)(L - 1) * kCFlagStride + 4 * lane;
+      for (int it = 0; VPTQ_K256C_SPIN_LIMIT == 0 || it < (VPTQ_K256C_SPIN_LIMIT ? VPTQ_K256C_SPIN_LIMIT : 1); ++it) {
+        u32x4 f;
+        // (coherent at device scope: sc0 sc1; relaxed polls; no acquire fence - ~1.7 us per workgroup:
+        // the only data another workgroup produced is x, read with device-coherent loads)
+        asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(f) : "v"(fl) : "memory");
+        bool ok = true;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ok = ok && (f[q] != 0u || 4 * lane + q >= blocks);
+        if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
+        __builtin_amdgcn_s_sleep(8);
+      }
+      lds_release();
+      if (lane == 0) __hip_atomic_store(dep_seen, (uint32_t)L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else {
+      lds_wait_ge(dep_seen, (uint32_t)L);
+    }
+    const K256Layer Lx = c_load_layer_lds(L);
+    const uint16_t* const xp = Lx.x;
+    const int max2 = (Lx.G - 2) * 2;
+    auto reload = [&](auto slot_c) __attribute__((always_inline)) {
+      constexpr int S = decltype(slot_c)::value;
+      if (q_layer[S] == L) load_x(slot_c, xp, max2, q_col2[S]);
+    };
+    reload(std::integral_constant<int, 0>{});
+    reload(std::integral_constant<int, 1>{});
+    if constexpr (D > 2) reload(std::integral_constant<int, (D > 2 ? 2 : 0)>{});
+    if constexpr (D > 3) reload(std::integral_constant<int, (D > 3 ? 3 : 0)>{});
+    if constexpr (D > 4) reload(std::integral_constant<int, (D > 4 ? 4 : 0)>{});
+    if constexpr (D > 5) reload(std::integral_constant<int, (D > 5 ? 5 : 0)>{});
+  };
+
+  // ---- prologue: image of the first layer into buffer 0, first D sweeps requested
+  fill_image(Lf, 0u);
+  c_for_slots([&](auto slot_c) {
+    issue(slot_c);
+    __builtin_amdgcn_sched_barrier(0);   // (the slots in issue order: the counted waits of the loop rely on it)
+  });
+  wait_all_but(D);   // the 4 fill instructions are older than the loads above
+  lds_inc(&ready_cnt[0]);
+  plan_fill();
+  zero_acc();
+  if (DEP) dep_enter(cc.L);
+  lds_wait_ge(&ready_cnt[0], (uint32_t)kCWaves);
+
+  // ---- rare events, each behind one branch of the step
+  // the next layer's image: requested as soon as its buffer is free (every wave has left the layer
+  // before the current one), BEFORE the step's loads (a younger invisible load would make the next
+  // step's counted wait cover those too); D step ends later only the D sweeps in flight are younger
+  // than it, so it has landed once everything older has - which a wave that keeps pace has waited for
+  auto fill_events_before_issue = [&]() __attribute__((always_inline)) {
+    const uint32_t nb = (use + 1u) & 1u;
+    const uint32_t need = (uint32_t)kCWaves * ((use + 1u) >> 1);
+    if (__hip_atomic_load(&free_cnt[nb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= need) {
+      fill_image(Lf, nb);
+      fill_pending = false;
+      land_steps = D;
+    }
+  };
+  auto fill_events_after_issue = [&]() __attribute__((always_inline)) {
+    if (--land_steps == 0) {
+      wait_all_but(D);
+      lds_inc(&ready_cnt[(use + 1u) & 1u]);
+    }
+  };
+  // the row group is complete: sums, then the next row group, the next layer, or the end
+  auto row_group_done = [&]() __attribute__((always_inline)) {
+    finish();
+    zero_acc();
+    c_col = wave * kCBlockCols;
+    c_left = cc.ns;
+    if (cc.rg + 1 < cc.re) { cc.rg += 1; return; }
+    // leaving the layer: its image buffer is free once every wave has said so
+    lds_inc(&free_cnt[use & 1u]);
+    if (cf.L >= n_layers) {
+      // (the steps that remain in this loop iteration consume re-read sweeps into accumulators
+      // nobody looks at.  The loop has ONE exit, at its end: an exit between two steps becomes,
+      // after control-flow structurisation, an edge into the loop header on which the queue slots
+      // are in another order, and every counted wait of the first step degrades to vmcnt(0).)
+      done = true;
+      c_left = 0x7fffffff;
+      return;
+    }
+    const uint32_t nb = (use + 1u) & 1u;
+    if (fill_pending) {   // (rare: the buffer was not free at any step boundary)
+      lds_wait_ge(&free_cnt[nb], (uint32_t)kCWaves * ((use + 1u) >> 1));
+      fill_image(Lf, nb);
+      fill_pending = false;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      lds_inc(&ready_cnt[nb]);
+    } else if (land_steps > 0) {
+      // requested D - land_steps step ends ago: that many sweeps are younger than the fill
+      wait_all_but(D - land_steps);
+      lds_inc(&ready_cnt[nb]);
+      land_steps = 0;
+    }
+    ++use;
+    baseA ^= 0x10000u;
+    baseB ^= 0x10000u;
+    cc = cf;
+    Lc = c_cons_of(c_load_layer_lds(cc.L));
+    c_left = cc.ns;
+    if (DEP) dep_enter(cc.L);
+    lds_wait_ge(&ready_cnt[nb], (uint32_t)kCWaves * ((use >> 1) + 1u));
+    plan_fill();
+  };
+
+#if VPTQ_K256C_PROF
+  pf_t0 = now(0);
+#endif
+  // ---- main loop: one step = wait for sweep k, consume it, request sweep k + D into its queue slot
+  auto step = [&](auto slot_c) __attribute__((always_inline)) {
+    __builtin_amdgcn_sched_barrier(0);
+#if VPTQ_K256C_PROF
+    constexpr int SS = decltype(slot_c)::value;
+    const unsigned long long ta = now(0);
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kLPS * (D - 1)) : "memory");
+    const unsigned long long tb = now(iw[SS][0][0]);
+    pf_wait += tb - ta;
+#endif
+    consume(slot_c);
+    __builtin_amdgcn_sched_barrier(0);
+#if VPTQ_K256C_PROF
+    const unsigned long long tc = now(__float_as_uint(acc[0][0][0] + acc[0][1][0]));
+    pf_cons += tc - tb;
+#endif
+    if (fill_pending) fill_events_before_issue();
+    __builtin_amdgcn_sched_barrier(0);
+    issue(slot_c);
+    __builtin_amdgcn_sched_barrier(0);
+#if VPTQ_K256C_PROF
+    const unsigned long long td = now(0);
+    pf_issue += td - tc;
+#endif
+    if (land_steps > 0) fill_events_after_issue();
+    c_col += kCSweepCols;
+    if (--c_left == 0) row_group_done();
+#if VPTQ_K256C_PROF
+    pf_cold += now(0) - td;
+    ++pf_steps;
+#endif
+  };
+  do {
+    c_for_slots(step);
+  } while (!done);
+#if VPTQ_K256C_PROF
+  if (!DEP && sync && lane == 0) {
+    unsigned long long* o = (unsigned long long*)sync + ((size_t)bid * kCWaves + wave) * 8;
+    o[0] = pf_wait; o[1] = pf_cons; o[2] = pf_issue; o[3] = pf_cold; o[4] = pf_steps; o[5] = now(0) - pf_t0;
+  }
+#endif
+}
+
+// ---- host side -------------------------------------------------------------------
+bool gemv_k256c_eligible(const VptqLayerDesc& d, int tokens) {
+  return tokens == 1 && d.perm == nullptr && gemv_k256_eligible(d, 1) &&
+         (((uintptr_t)d.centroids | (uintptr_t)d.res_centroids) & 15) == 0;
+}
+
+// Row groups are dealt to the workgroups in blocks of consecutive ones, `rpw` per workgroup and
+// layer.  Independent layers: at least kCMinSteps sweeps per visit of a layer (the next layer's
+// image is requested at the start of the visit and lands D sweeps later; a layer that gives every
+// workgroup one short row group would make all of them wait for it), so a small layer occupies
+// only some of the workgroups and the next layers run beside it.  Dependent layers follow each
+// other anyway: every layer is spread over all workgroups.
+#ifndef VPTQ_K256C_MIN_STEPS
+#define VPTQ_K256C_MIN_STEPS 8
+#endif
+constexpr int kCMinSteps = VPTQ_K256C_MIN_STEPS;
+static int c_groups(const VptqLayerDesc& d) { return (d.num_indices + kCRows - 1) / kCRows; }
+static int c_rows_per_wg(const VptqLayerDesc& d, int cus, bool wide) {
+  const int ng = c_groups(d), ns = (d.group_size + kCSweepCols - 1) / kCSweepCols;
+  int rpw = (ng + cus - 1) / cus;
+  if (wide) {
+    const int want = (kCMinSteps + ns - 1) / ns;
+    rpw = want > rpw ? want : rpw;
+  }
+  return rpw < 1 ? 1 : rpw;
+}
+static long long c_blocks(const VptqLayerDesc* descs, int n, int cus, bool wide) {
+  long long total = 0;
+  for (int i = 0; i < n; ++i) {
+    const int rpw = c_rows_per_wg(descs[i], cus, wide);
+    total += (c_groups(descs[i]) + rpw - 1) / rpw;
+  }
+  return total;
+}
+
+static int c_device_cus() {
+  static int cus[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (!cus[dev]) {
+    hipDeviceProp_t p;
+    cus[dev] = hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0
+                   ? p.multiProcessorCount : 256;
+  }
+  return cus[dev];
+}
+
+static int c_workgroups(bool dependent) {
+  static int forced_wgs = -1;  // VPTQ_K256C_WGS: tuning override of the workgroup count
+  if (forced_wgs < 0) { const char* e = getenv("VPTQ_K256C_WGS"); forced_wgs = e ? atoi(e) : 0; }
+  const int cus = forced_wgs > 0 ? forced_wgs : c_device_cus();
+  return dependent && cus > kCFlagStride ? kCFlagStride : cus;
+}
+
+// wide blocks (>= kCMinSteps sweeps per visit) only while they still give every workgroup twice
+// its share of blocks, and never for a dependent chain
+static bool c_wide(const VptqLayerDesc* descs, int n, int cus, bool dependent) {
+  return !dependent && c_blocks(descs, n, cus, true) >= 2ll * cus;
+}
+// does one launch of these layers fill the device (>= 3/4 of the workgroups busy)?
+bool gemv_k256c_fills_device(const VptqLayerDesc* descs, int n, bool dependent) {
+  const int cus = c_workgroups(dependent);
+  return 4 * c_blocks(descs, n, cus, c_wide(descs, n, cus, dependent)) >= 3ll * cus;
+}
+
+template <typename DT, bool DEP>
+static hipError_t launch_c(const K256CParams& P, int grid, hipStream_t st) {
+  auto kern = gemv_k256c_kernel<DT, DEP>;
+  static bool attr_set[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (!attr_set[dev]) {
+    const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)kCLdsBytes);
+    if (e != hipSuccess) return e;
+    attr_set[dev] = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(kCThreads), kCLdsBytes, st, P);
+  return hipGetLastError();
+}
+
+// n <= kMaxGroup layers, all gemv_k256c_eligible and of one dtype; sync = kCFlagStride flags per
+// layer (zeroed by the caller's memset node) when dependent
+hipError_t launch_gemv_k256c(const VptqLayerDesc* descs, int n, const void* const* x, void* const* y,
+                             int flags, bool dependent, uint32_t* sync, hipStream_t st) {
+  if (n < 1 || n > kMaxGroup) return hipErrorInvalidValue;
+  const int cus = c_workgroups(dependent);
+  const bool wide = c_wide(descs, n, cus, dependent);
+  const long long total = c_blocks(descs, n, cus, wide);
+  const int grid = (int)(total < cus ? total : cus);
+  K256CParams P;
+  P.n_layers = n;
+  P.tokens = 1 | ((flags & VPTQ_GEMV_OUT_F32) ? kOutF32Bit : 0);
+  P.sync = sync;
+  long long first = 0;   // workgroup that owns block 0 of the layer
+  for (int i = 0; i < n; ++i) {
+    const VptqLayerDesc& d = descs[i];
+    K256Layer& Ly = P.layer[i];
+    Ly.idx = (const uint32_t*)d.indices;
+    Ly.cent = (const uint32_t*)d.centroids;
+    Ly.rcent = (const uint32_t*)d.res_centroids;
+    Ly.x = (const uint16_t*)x[i];
+    Ly.y = (uint16_t*)y[i];
+    Ly.scale = (const uint16_t*)d.weight_scale;
+    Ly.wbias = (const uint16_t*)d.weight_bias;
+    Ly.bias = (const uint16_t*)d.bias;
+    Ly.perm = nullptr;
+    Ly.pf = nullptr;
+    Ly.pf_bytes = 0;
+    Ly.N = d.num_indices;
+    Ly.G = d.group_size;
+    Ly.O = d.out_features;
+    Ly.row_words = d.row_words;
+    const int rpw = c_rows_per_wg(d, cus, wide);
+    Ly.wgs = (int)(first % grid);
+    Ly.pf_chunk = rpw;   // (this kernel: row groups per workgroup)
+    Ly.pf_len = 0;
+    Ly.slots = 0;
+    // dependent chain: every layer starts at workgroup 0 (all of its row groups wait anyway)
+    first = dependent ? 0 : first + (c_groups(d) + rpw - 1) / rpw;
+  }
+  const bool f16 = descs[0].dtype == VPTQ_DTYPE_F16;
+  if (dependent) return f16 ? launch_c<F16, true>(P, grid, st) : launch_c<BF16, true>(P, grid, st);
+  return f16 ? launch_c<F16, false>(P, grid, st) : launch_c<BF16, false>(P, grid, st);
+}
+
+}  // namespace vptq

@@ -18,11 +18,12 @@ const char* gemv_k256_group_name(const VptqLayerDesc* descs, int n, int tokens, 
 hipError_t launch_gemv_k256(const VptqLayerDesc* descs, int n, const void* const* x,
                             void* const* y, int tokens, int flags, hipStream_t st);
 
-// gemv_k256t.hip - the same format, one token, no permutation: ONE persistent launch that walks a
-// chain of layers (transposing LDS gather -> 16x16x32 MFMA; the next layer's image and index words
-// requested while the current one streams).  n <= 32 layers of one dtype per launch.
-bool gemv_k256t_eligible(const VptqLayerDesc& d, int tokens);
-hipError_t launch_gemv_k256t(const VptqLayerDesc* descs, int n, const void* const* x, void* const* y,
+// gemv_k256c.hip - the same format, one token, no permutation: ONE persistent launch that walks a
+// chain of layers (next layer's codebook image, activations and index words requested while the current
+// one streams).  n <= 32 layers of one dtype per launch.
+bool gemv_k256c_eligible(const VptqLayerDesc& d, int tokens);
+bool gemv_k256c_fills_device(const VptqLayerDesc* descs, int n, bool dependent);
+hipError_t launch_gemv_k256c(const VptqLayerDesc* descs, int n, const void* const* x, void* const* y,
                              int flags, bool dependent, uint32_t* sync, hipStream_t st);
 
 // gemv_gather.hip — v=8, k=65536 (+ residual 0 / 256 / 65536), C=1, no outliers:

@@ -5,7 +5,7 @@ The reference runs a decode step as one `quant_gemv` call per layer
 shared memory and an epilogue.  `GemvChain` hands the library a LIST of layers; for the canonical
 v=8 / 256+256 format it becomes one launch whose workgroups walk the layers one after the other
 and request layer i + 1's codebooks, activations and first index words while layer i streams
-(`vptq_amd/csrc/gemv_k256t.hip`); anything else is executed layer by layer by the library.
+(`vptq_amd/csrc/gemv_k256c.hip`); anything else is executed layer by layer by the library.
 Pure scheduling: per layer the results are those of `VQuantLinear.forward`.
 
     chain = GemvChain([q_proj, k_proj, v_proj])          # independent layers
