@@ -11,7 +11,11 @@ Infinity Cache can hold the weights between uses): R fused dequant + GEMV launch
 C ABI, captured once in a hipGraph and replayed.  After W warm-up steps, `--regions` (5) timed
 regions of EXACTLY K steps each are run, every one bracketed by a barrier + synchronize; the
 line reports the MEDIAN region (all of them are listed under "regions_ms_per_step").
-  --mode single  : one launch per layer (the reference's operator granularity)          [N = 1 default]
+  --mode chain   : the ring as ONE persistent launch that walks its layers one after the other
+                   (vptq_quant_gemv_chain, independent layers: the next layer's codebooks, activations
+                   and first index words are requested while the current one streams)     [N = 1 default]
+  --mode single  : one launch per layer (the reference's operator granularity)
+  --mode chain_dep : the same launch with every layer reading the previous one's output (dependent chain)
   --mode grouped : layers launched 4 at a time with vptq_quant_gemv_grouped
   --mode tp_row  : BASELINE config #5: the linear projections of Llama-3-70B decoder layers
                    (q / o 8192^2, k / v 1024 x 8192, gate / up 28672 x 8192, down 8192 x 28672),
@@ -21,11 +25,13 @@ line reports the MEDIAN region (all of them are listed under "regions_ms_per_ste
   --mode tp      : output rows split over the ranks, RCCL all-gather per layer (strong scaling)
   --mode rings   : every rank its own ring of independent layers, no collective (weak scaling);
                    with N > 1 this line is also attached to the tp_row line as "weak_scaling"
-Extras (N = 1, unless --no-extras): the same measurement at hidden 4096 (BASELINE configs[0/1]),
-with the reference's roundings (VPTQ_GEMV_EXACT), grouped x4, 16 tokens (batched-decode kernel),
-the k = 8192 + 256 format (LDS-resident codebooks), tp_row on one GPU (the strong-scaling
-baseline), each a short ring of its own, and the Llama-3-8B shaped decode loop (BASELINE
-configs[2]: tokens/s + TTFT of the whole model, tools/llama_decode.py in a process of its own).
+Extras (N = 1, unless --no-extras): one launch per layer, the dependent chain, hidden 4096 (BASELINE
+configs[0/1]; chain and single), the reference's roundings (VPTQ_GEMV_EXACT), grouped x4, 16 tokens
+(batched-decode kernel), the k = 8192 + 256 format (LDS-resident codebooks), tp_row on one GPU (the
+strong-scaling baseline), each a short ring of its own; the prefill configuration (BASELINE configs[3]:
+batch 4 x seq 2048 through 4096x4096 and 14336x4096, bf16, TFLOP/s of both routes) and the
+Llama-3-8B shaped decode loop (BASELINE configs[2]: tokens/s + TTFT of the whole model,
+tools/llama_decode.py in a process of its own).
 
 Inputs and weights are resident in HBM before the timed region.  Prints ONE JSON line.
 """
@@ -64,16 +70,63 @@ def model_decode_extra(timeout_s=240):
     SDPA, cache update) and the fp16 lm_head are in it, the VQuantLinear launches are about a quarter."""
     import subprocess
     try:
-        p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "llama_decode.py"), "--fuse", "--new", "128"],
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "llama_decode.py"), "--fuse", "--new", "256"],
                            capture_output=True, text=True, timeout=timeout_s)
         line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
         d = json.loads(line)
-        return {"what": d["model"] + ", prompt 128, 128 new tokens, batch 1, one GPU; tools/llama_decode.py --fuse",
+        return {"what": d["model"] + ", prompt 128, 256 new tokens, batch 1, one GPU; tools/llama_decode.py --fuse",
                 "tokens_per_s": d["decode_tok_s_hipgraph"], "tokens_per_s_eager": d["decode_tok_s_eager"],
                 "ttft_ms": d["ttft_ms"], "packed_index_GB": d["packed_index_GB"],
                 "weight_GBps": d.get("hipgraph_weight_GBps")}
     except Exception as e:  # the headline line must not depend on transformers being importable
         return {"error": f"{type(e).__name__}: {e}"[:300]}
+
+
+def prefill_extra(dev, tokens=8192):
+    """BASELINE configs[3]: batch 4 x seq 2048 (8192 tokens) through one VQuantLinear 4096x4096 and one
+    14336x4096, bf16, both routes: HIP dequant to a dense W + hipBLASLt GEMM (the reference's structure,
+    vptq/ops/quant_gemm.py:231-274; the module's default) and the fused dequant-tile -> LDS -> MFMA GEMM
+    (vptq_quant_gemm).  TFLOP/s = 2 x tokens x I x O / time; MFMA-busy figures come from the committed
+    rocprofv3 PMC summary of the same shapes."""
+    from vptq_amd import ops
+    g = torch.Generator(device=dev).manual_seed(11)
+    out = {"what": f"batch 4 x seq 2048 = {tokens} tokens, bf16, VQuantLinear v=8 k=256+256; dense = vptq_dequant + "
+                   "hipBLASLt (default route), fused = vptq_quant_gemm (gemm_fused.hip, opt-in)", "shapes": {}}
+    for (O, I) in ((4096, 4096), (14336, 4096)):
+        m = make_layer(I, O, dev, g, dtype=torch.bfloat16)
+        x = torch.randn(4, tokens // 4, I, device=dev, dtype=torch.bfloat16, generator=g)
+        desc = m._descriptor()[1]
+
+        def t_us(fn, iters=5):
+            for _ in range(2):
+                fn()
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(iters):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); fn(); e1.record()
+                torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1) * 1e3)
+            return sorted(ts)[len(ts) // 2]
+        with torch.no_grad():
+            dense = t_us(lambda: m(x))
+            fused = t_us(lambda: ops.quant_gemm_fused(x, desc, O))
+            yd, yf = m(x), ops.quant_gemm_fused(x, desc, O)
+        flops = 2.0 * tokens * I * O
+        out["shapes"][f"{O}x{I}"] = {
+            "dense_us": dense, "dense_TFLOPs": flops / dense / 1e6, "dense_frac_of_2500TF": flops / dense / 1e6 / 2500,
+            "fused_us": fused, "fused_TFLOPs": flops / fused / 1e6, "fused_frac_of_2500TF": flops / fused / 1e6 / 2500,
+            "fused_vs_dense_rel_diff": float(((yf.float() - yd.float()).abs().max() / yd.float().abs().max()).item())}
+        del m, x, yd, yf
+        torch.cuda.empty_cache()
+    rounds = sorted(d for d in os.listdir(os.path.join(ROOT, "profiles")) if d[:1] == "r" and d[1:].isdigit())
+    for rd in reversed(rounds):
+        cand = os.path.join(ROOT, "profiles", rd, "prefill_bf16_pmc_summary.json")
+        if os.path.exists(cand):
+            out["mfma_busy"] = json.load(open(cand))
+            out["mfma_busy_source"] = os.path.relpath(cand, ROOT)
+            break
+    return out
 
 
 def shard_ring(total_layers, rank, world):
@@ -96,21 +149,27 @@ def job_throughput_gbps(world, bytes_per_launch_layer, layers_per_rank, steps, w
     return world * bytes_per_launch_layer * layers_per_rank * steps / wall_s / 1e9
 
 
-def make_layer(I, O, dev, g, k=256, kr=256):
+def make_layer(I, O, dev, g, k=256, kr=256, dtype=torch.float16):
     import vptq_amd
     m = vptq_amd.VQuantLinear(
         I, O, vector_lens=[-1, 8], num_centroids=[-1, k], num_res_centroids=[-1, kr if kr > 0 else -1],
         group_num=1, group_size=I, outlier_size=0, indices_as_float=False, enable_norm=True,
-        enable_perm=False, is_indice_packed=True, bias=False, dtype=torch.float16,
+        enable_perm=False, is_indice_packed=True, bias=False, dtype=dtype,
         device=dev, enable_proxy_error=False)
     m.indices.data = torch.randint(-2**31, 2**31 - 1, m.indices.shape, generator=g,
                                    device=dev, dtype=torch.int64).to(torch.int32)
-    m.centroids.weight.data = (torch.randn(m.centroids.weight.shape, generator=g, device=dev) * 0.02).half()
+    m.centroids.weight.data = (torch.randn(m.centroids.weight.shape, generator=g, device=dev) * 0.02).to(dtype)
     if kr > 0:
-        m.res_centroids.weight.data = (torch.randn(m.res_centroids.weight.shape, generator=g, device=dev) * 0.005).half()
-    m.weight_scale.data = (1 + 0.1 * torch.randn(I, generator=g, device=dev)).half()
-    m.weight_bias.data = (0.01 * torch.randn(I, generator=g, device=dev)).half()
+        m.res_centroids.weight.data = (torch.randn(m.res_centroids.weight.shape, generator=g, device=dev) * 0.005).to(dtype)
+    m.weight_scale.data = (1 + 0.1 * torch.randn(I, generator=g, device=dev)).to(dtype)
+    m.weight_bias.data = (0.01 * torch.randn(I, generator=g, device=dev)).to(dtype)
     return m.eval()
+
+
+def layer_desc(m):
+    """(C-ABI descriptor, keep-alive) of a vptq_amd.VQuantLinear: the module's own cached descriptor"""
+    c = m._descriptor()
+    return c[1], (m, c[2])
 
 
 def make_ring(H, R, dev, seed, k=256, kr=256):
@@ -151,27 +210,38 @@ def cpu_baseline(layer, x, y_gpu, H):
     from oracle import torch_ref as tr
     ab = alg_bytes(H)
     out = {}
-    # ---- torch restatement
+    # ---- torch restatement, at the thread count that is FASTEST on this box (the reference's CPU path as
+    # well as this host runs it - an over-subscribed pool is not the reference's speed)
     cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
     cpu = lambda t: None if t is None else t.detach().cpu()  # noqa: E731
     args = (cpu(layer.indices), cpu(layer.centroids.weight), cpu(layer.res_centroids.weight),
             cpu(layer.weight_scale), cpu(layer.weight_bias))
     kw = dict(num_centroids=256, num_res_centroids=256, vector_len=8, group_size=H, out_features=H)
     xc = cpu(x)
+    sweep = {}
     with torch.no_grad():
-        y_t = tr.forward(xc, *args, **kw)      # warm-up
-        ts = []
-        for _ in range(3):
+        torch.set_num_threads(min(cores, 32))
+        y_t = tr.forward(xc, *args, **kw)      # warm-up (page-in)
+        for n in sorted({n for n in (8, 16, 32, 64, cores) if n <= cores}):
+            torch.set_num_threads(n)
+            t0 = time.perf_counter()
+            y_t = tr.forward(xc, *args, **kw)
+            sweep[n] = time.perf_counter() - t0
+        best = min(sweep, key=sweep.get)
+        torch.set_num_threads(best)
+        ts = [sweep[best]]
+        for _ in range(2):
             t0 = time.perf_counter()
             y_t = tr.forward(xc, *args, **kw)
             ts.append(time.perf_counter() - t0)
     t = sorted(ts)[1]
     out["cpu_baseline"] = {
-        "value": ab / t / 1e9, "unit": "GB/s", "cores": int(torch.get_num_threads()), "kind": "port",
+        "value": ab / t / 1e9, "unit": "GB/s", "cores": int(best), "kind": "port",
         "sample": f"1 VQuantLinear {H}x{H} forward, torch restatement of the reference's CPU tensor-op "
-                  f"sequence (oracle/torch_ref.py), torch threads = {torch.get_num_threads()} "
-                  f"(os.cpu_count() = {cores}), median of 3, {t * 1e3:.0f} ms each"}
+                  f"sequence (oracle/torch_ref.py), {best} torch threads = the fastest of "
+                  f"{ {n: round(v, 2) for n, v in sweep.items()} } s per forward (os.cpu_count() = {cores}), "
+                  f"median of 3 at that count: {t * 1e3:.0f} ms"}
+    torch.set_num_threads(min(cores, 32))
     rel_t = float(((y_gpu.detach().float().cpu() - y_t.float()).abs().max() / y_t.float().abs().max()).item())
     out["parity_rel_err_vs_torch_restatement"] = rel_t
     # ---- C port
@@ -297,9 +367,8 @@ class Timer:
 
 
 def bench_ring(lib, B, dev, timer, H, mode, flags, steps, warmup, regions, rank=0, world=1, group=4,
-               tokens=1, k=256, kr=256, ring=0, tp_split=None, prefetch=False):
-    """One ring measurement; returns (result dict, layers, x, ys)."""
-    from _gpu_util import module_desc
+               tokens=1, k=256, kr=256, ring=0, tp_split=None, prefetch=False, chain=32):
+    """One ring measurement; returns (result dict, layers, x, ys).  mode: single | grouped | chain | chain_dep"""
     T = int(np.log2(k)) + (int(np.log2(kr)) if kr > 0 else 0)
     idx_bytes = (H // 8) * (H * T // 32) * 4
     R = ring or max(2, (512 << 20) // idx_bytes)
@@ -313,8 +382,11 @@ def bench_ring(lib, B, dev, timer, H, mode, flags, steps, warmup, regions, rank=
     ys = [torch.empty(1, tokens, layers[i].out_features, device=dev, dtype=torch.float16) for i in range(R)]
     y_full = torch.empty(H, device=dev, dtype=torch.float16) if tp_split == "out" else None
     descs, keeps = [], []
+    if prefetch:
+        from vptq_amd.layers.vqlinear import chain_prefetch
+        chain_prefetch(layers, circular=True)
     for i, m in enumerate(layers):
-        d, kk = module_desc(m, prefetch=layers[(i + 1) % R].indices if prefetch else None)
+        d, kk = layer_desc(m)
         descs.append(d)
         keeps.append(kk)
     kname = lib.vptq_quant_gemv_kernel_name(descs[0], tokens, flags).decode()
@@ -333,6 +405,29 @@ def bench_ring(lib, B, dev, timer, H, mode, flags, steps, warmup, regions, rank=
             sp = torch.cuda.current_stream().cuda_stream
             for m, arr, xp, yp in chunks:
                 rc = lib.vptq_quant_gemv_grouped(arr, m, xp, yp, tokens, flags, sp)
+                assert rc == 0, lib.vptq_last_error()
+    elif mode in ("chain", "chain_dep"):
+        # the ring as launches of `chain` layers each (32 = the most one launch takes); dependent: layer
+        # i + 1 reads layer i's output
+        dep = mode == "chain_dep"
+        cflags = flags | (B.GEMV_CHAIN_DEPENDENT if dep else 0)
+        wsb = lib.vptq_quant_gemv_chain_workspace_bytes(R, cflags)
+        ws = torch.zeros(max(wsb, 4) // 4, dtype=torch.int32, device=dev) if wsb else None
+        per = R if dep else min(chain, 32, R)      # layers per call (a dependent chain is ONE call; the
+        chunks = []                                # library cuts calls of more than 32 layers itself)
+        for i0 in range(0, R, per):
+            m = min(per, R - i0)
+            chunks.append((m, (B.LayerDesc * m)(*descs[i0:i0 + m]),
+                           (C.c_void_p * m)(*[(ys[i - 1] if dep and i > 0 else x).data_ptr() for i in range(i0, i0 + m)]),
+                           (C.c_void_p * m)(*[t.data_ptr() for t in ys[i0:i0 + m]])))
+        launches = sum((m + 31) // 32 for m, *_ in chunks)
+        kname = lib.vptq_quant_gemv_chain_kernel_name(chunks[0][1], chunks[0][0], tokens, cflags).decode()
+        keeps.append((chunks, ws))
+
+        def one_pass():
+            sp = torch.cuda.current_stream().cuda_stream
+            for m, arr, xp, yp in chunks:
+                rc = lib.vptq_quant_gemv_chain(arr, m, xp, yp, tokens, cflags, None if ws is None else ws.data_ptr(), wsb, sp)
                 assert rc == 0, lib.vptq_last_error()
     else:
         launches = R
@@ -353,6 +448,7 @@ def bench_ring(lib, B, dev, timer, H, mode, flags, steps, warmup, regions, rank=
     res = dict(value=value, ms_per_step=t["wall_s"] * 1e3 / steps, us_per_launch=us_per_launch,
                bytes_per_launch=bytes_per_launch, achieved=bytes_per_launch / us_per_launch / 1e3,
                kernel=kname, ring=R, launches_per_step=launches, hipgraph=t["captured"],
+               us_per_layer=t["event_ms"] * 1e3 / (steps * R),
                regions_ms_per_step=t["regions_ms_per_step"], idx_mib=R * idx_bytes >> 20)
     return res, layers, x, ys, keeps
 
@@ -374,7 +470,6 @@ def bench_tp_row(lib, B, dev, timer, rank, world, n_layers, flags, steps, warmup
     rounding each: 4 launches + 4 collectives per decoder layer instead of 7 + 7 (the collectives are
     latency-bound at batch 1: fewer, larger ones)."""
     from vptq_amd.utils.shard import shard_in_features
-    from _gpu_util import module_desc
     dist = timer.dist
     projs = llama70b_projections()
     groups = [[0, 1, 2], [3], [4, 5], [6]] if fuse_siblings else [[i] for i in range(len(projs))]
@@ -398,7 +493,7 @@ def bench_tp_row(lib, B, dev, timer, rank, world, n_layers, flags, steps, warmup
             y = torch.empty(1, 1, sum(Os), device=dev, dtype=torch.float16)
             ds = []
             for i in grp:
-                d, kk = module_desc(mods[i][0])
+                d, kk = layer_desc(mods[i][0])
                 ds.append(d); keeps.append((kk, mods[i][0]))
             offs = [sum(Os[:j]) for j in range(len(grp))]
             arr = (B.LayerDesc * len(grp))(*ds)
@@ -455,7 +550,8 @@ def main():
     ap.add_argument("--regions", type=int, default=5, help="timed regions of K steps; the median is reported")
     ap.add_argument("--hidden", type=int, default=8192)
     ap.add_argument("--ring", type=int, default=0)
-    ap.add_argument("--mode", choices=["auto", "single", "grouped", "tp", "tp_row", "rings"], default="auto")
+    ap.add_argument("--mode", choices=["auto", "chain", "chain_dep", "single", "grouped", "tp", "tp_row", "rings"], default="auto")
+    ap.add_argument("--chain", type=int, default=32, help="chain: layers per launch (<= 32)")
     ap.add_argument("--group", type=int, default=4)
     ap.add_argument("--tp-layers", type=int, default=20,
                     help="tp_row: Llama-3-70B decoder layers in the ring (20 = 4.3 GB of packed indices)")
@@ -502,7 +598,9 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
     mode = a.mode
     if mode == "auto":
-        mode = "single" if world == 1 else "tp_row"
+        mode = "chain" if world == 1 else "tp_row"
+    if mode == "rings":
+        mode = "single"
 
     from vptq_amd import _backend as B
     lib = B.lib()
@@ -551,9 +649,11 @@ def main():
     tp_split = "out" if mode == "tp" else None
     if mode == "tp" and H // 8 % world:
         raise SystemExit("tp mode needs the vector-row count divisible by the world size")
-    r, layers, x, ys, keeps = bench_ring(lib, B, dev, timer, H, "grouped" if mode == "grouped" else "single",
+    r, layers, x, ys, keeps = bench_ring(lib, B, dev, timer, H, mode if mode in ("grouped", "chain", "chain_dep") else "single",
                                          flags, a.steps, a.warmup, a.regions, rank=rank, world=world, group=a.group,
-                                         ring=a.ring, tp_split=tp_split, prefetch=a.prefetch)
+                                         ring=a.ring, tp_split=tp_split, prefetch=a.prefetch, chain=a.chain)
+    chain_mode = mode in ("chain", "chain_dep")
+    mode_name = (f"chain{min(a.chain, 32, r['ring'])}" if mode == "chain" else mode)
     out = {
         "metric": "decode GEMV effective GB/s (VQuantLinear 2-bit, batch 1)",
         "value": r["value"], "unit": "GB/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -562,8 +662,12 @@ def main():
         "vs_baseline": None, "dtype": "f16", "data": "synthetic",
         "config": {"workload": f"VQuantLinear {H}x{H} v=8 k=256+256 (2-bit) batch=1 seq=1 fp16, "
                                f"ring of {r['ring']} distinct layers per GPU ({r['idx_mib']} MiB of "
-                               f"packed indices), 1 step = 1 pass over the ring",
-                   "hidden": H, "ring": r["ring"], "mode": mode, "launches_per_step": r["launches_per_step"],
+                               f"packed indices), 1 step = 1 pass over the ring"
+                               + (f" = {r['launches_per_step']} persistent launch(es) walking "
+                                  f"{'dependent' if mode == 'chain_dep' else 'independent'} layers one after the other"
+                                  if chain_mode else ""),
+                   "hidden": H, "ring": r["ring"], "mode": mode_name, "launches_per_step": r["launches_per_step"],
+                   "us_per_layer": r["us_per_layer"],
                    "kernel": r["kernel"], "arithmetic": arithmetic,
                    "read_ahead_next_layer": bool(a.prefetch), "hipgraph": r["hipgraph"],
                    "timing": f"median of {a.regions} regions of {a.steps} steps",
@@ -574,29 +678,37 @@ def main():
         "roofline": {"bound": "hbm", "achieved": r["achieved"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": r["achieved"] / HBM_PEAK_GBPS, "traffic": None,
                      "bytes_per_launch": r["bytes_per_launch"], "us_per_launch": r["us_per_launch"],
-                     "note": "us_per_launch = HIP-event time over the (median) timed region / launches, i.e. "
-                             "INCLUDING the kernel boundary (an empty kernel in the same graph: 1.8 us per "
-                             "launch, profiles/r02/ubench_stream_8192.txt); rocprofv3's kernel-only duration is "
-                             "shorter by the idle part of that boundary.  The kernel is bound by instruction "
-                             "issue / LDS gathers and per-launch latency, not by HBM: compute_floor, DESIGN.md 4",
-                     "compute_floor": compute_floor(r["kernel"], H)},
+                     "note": ("one launch = the whole ring (32 layers): bytes_per_launch = 32 x the algorithmic bytes of a "
+                              "layer (SURVEY 8d), us_per_launch = HIP-event time over the (median) timed region / launches; "
+                              "what bounds it: DESIGN.md 4.9 (per-wave instruction latency between hand-overs, the LDS "
+                              "(2 KiB of gathered entries per index-wave) and the matrix pipe, 32 SIMD cycles per index-wave "
+                              "each; a pure stream of the same bytes runs at 6.7 TB/s, tools/ubench_stream2.hip)") if chain_mode else
+                             ("us_per_launch = HIP-event time over the (median) timed region / launches, i.e. "
+                              "INCLUDING the kernel boundary (an empty kernel in the same graph: 1.8 us per "
+                              "launch, profiles/r02/ubench_stream_8192.txt); rocprofv3's kernel-only duration is "
+                              "shorter by the idle part of that boundary.  The kernel is bound by instruction "
+                              "issue / LDS gathers and per-launch latency, not by HBM: compute_floor, DESIGN.md 4"),
+                     "compute_floor": None if chain_mode else compute_floor(r["kernel"], H)},
     }
     # the newest round's PMC summary of this configuration
     rounds = sorted(d for d in os.listdir(os.path.join(ROOT, "profiles")) if d[:1] == "r" and d[1:].isdigit())
     for rd in reversed(rounds):
-        cand = os.path.join(ROOT, "profiles", rd, f"bench_h{H}_{mode}_pmc_summary.json")
+        cand = os.path.join(ROOT, "profiles", rd, f"bench_h{H}_{'chain' if chain_mode else mode}_pmc_summary.json")
         if os.path.exists(cand) and not a.exact and not a.prefetch:
             # HBM bytes per launch from a separate rocprofv3 --pmc run of this same command
             # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); see the file's _note
             out["roofline"]["traffic"] = json.load(open(cand)).get("hbm_bytes_corrected")
             out["roofline"]["traffic_source"] = os.path.relpath(cand, ROOT)
             break
-    if rank == 0 and world == 1 and not a.no_cpu_baseline and mode in ("single", "grouped"):
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and mode in ("single", "grouped", "chain", "chain_dep"):
         torch.cuda.synchronize()
-        base, rel = cpu_baseline(layers[0], x, ys[0], H)
+        # parity on the LAST layer of the ring (of the chain), against the C oracle on the same bits
+        x_last = ys[-2] if mode == "chain_dep" else x
+        base, rel = cpu_baseline(layers[-1], x_last, ys[-1], H)
         out.update(base)
+        out["parity_checked_on"] = f"layer {len(layers) - 1} (the last) of the ring"
         assert rel <= 1e-3, f"GPU result differs from the CPU oracle: {rel}"
-    if world == 1 and not a.no_extras and mode == "single" and not a.exact:
+    if world == 1 and not a.no_extras and mode in ("single", "chain") and not a.exact:
         del layers, ys, keeps
         torch.cuda.empty_cache()
         ex = {}
@@ -605,7 +717,10 @@ def main():
         def short(res, nbytes=None):
             return {"GBps": res["achieved"], "frac_of_8TBps": res["achieved"] / HBM_PEAK_GBPS,
                     "us_per_launch": res["us_per_launch"], "kernel": res["kernel"]}
-        for key, kw in (("h4096", dict(H=4096, mode="single", flags=0)),
+        for key, kw in (("single_launch_per_layer", dict(H=H, mode="single", flags=0)),
+                        ("chain_dependent", dict(H=H, mode="chain_dep", flags=0)),
+                        ("h4096_chain", dict(H=4096, mode="chain", flags=0)),
+                        ("h4096", dict(H=4096, mode="single", flags=0)),
                         ("exact", dict(H=H, mode="single", flags=B.GEMV_EXACT)),
                         ("grouped_x4", dict(H=H, mode="grouped", flags=0)),
                         ("tokens16", dict(H=H, mode="single", flags=0, tokens=16)),
@@ -613,7 +728,13 @@ def main():
             kw = dict(kw)
             rr, *_ = bench_ring(lib, B, dev, Timer(dev), kw.pop("H"), kw.pop("mode"), kw.pop("flags"), st, wu, rg, **kw)
             ex[key] = short(rr)
+            ex[key]["us_per_layer"] = rr["us_per_layer"]
             torch.cuda.empty_cache()
+        ex["single_launch_per_layer"]["what"] = ("the same ring, one vptq_quant_gemv launch per layer (the reference's operator "
+                                                  "granularity; the round-1 / round-2 headline)")
+        ex["chain_dependent"]["what"] = ("the same ring as ONE dependent chain (x of layer i + 1 = y of layer i): device-scope "
+                                         "hand-over per layer inside the launch; us_per_launch is the whole chain")
+        ex["h4096_chain"]["what"] = "VQuantLinear 4096x4096 (BASELINE configs[0]/[1] shape), ring of 128 layers as 4 chain launches"
         ex["h4096"]["what"] = "VQuantLinear 4096x4096 (BASELINE configs[0]/[1] shape), single launch per layer"
         ex["exact"]["what"] = "VPTQ_GEMV_EXACT: the reference's three roundings per weight (bit-equivalent form)"
         ex["grouped_x4"]["what"] = "4 independent layers per launch (vptq_quant_gemv_grouped), us per LAYER = us_per_launch / 4"
@@ -624,6 +745,10 @@ def main():
                                    "path (world size 1): the strong-scaling baseline of --gpus N",
                            "GBps": tr["value"], "us_per_decoder_layer": tr["us_per_decoder_layer"],
                            "parity_rel_err_vs_cpu_oracle": tr.get("parity_rel_err_vs_cpu_oracle")}
+        try:
+            ex["prefill"] = prefill_extra(dev)
+        except Exception as e:   # the headline line must not depend on it
+            ex["prefill"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         ex["llama3_8b_decode"] = model_decode_extra()
         out["extras"] = ex
     if rank == 0:
