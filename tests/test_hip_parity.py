@@ -1420,3 +1420,71 @@ def test_command_line_prompt_and_chat(dev, tmp_path, capsys):
     tok.chat_template = None
     out2 = app.chat_loop(model, tok, args)
     assert out2.shape[1] > 1 and "no chat_template" in capsys.readouterr().out
+
+
+# ---------------------------------------------------------------- adversarial families for the default arithmetic
+def _adversarial_layer(I, O, family, seed):
+    """canonical fp16 layers built to stress the folded arithmetic:
+    "plain"; "cyclic" = the reference test's index pattern (/root/reference/tests/test_quant_gemv.py:21-31);
+    "bias4" / "bias16" = |weight_bias| = 4x / 16x rms(weight_scale * (centroid + residual));
+    "bias1.5" = the same construction below the load-time gate"""
+    L = vo.make_layer(I, O, dist="ref-test", seed=seed)
+    rng = np.random.default_rng(seed + 1)
+    if family == "cyclic":
+        N, G = L.num_indices, L.group_size
+        idx = (np.arange(N * G) % 256).reshape(1, N, G)
+        L.indices = vo.pack_indices(idx, 8, idx.copy(), 8)
+    if family.startswith("bias"):
+        ratio = float(family[4:])
+        c, r, s = (vo.to_f32(t, "f16") for t in (L.centroids, L.res_centroids, L.weight_scale))
+        ws = np.sqrt((c ** 2).mean() + (r ** 2).mean()) * np.sqrt((s ** 2).mean())
+        L.weight_bias = vo.from_f32((rng.standard_normal(I) * ratio * ws).astype(np.float32), "f16")
+    return L
+
+
+def _adversarial_x(L, kind, seed):
+    I = L.in_features
+    rng = np.random.default_rng(seed)
+    if kind == "large_mean":
+        xs = 2.0 + 0.5 * rng.standard_normal(I)
+    else:
+        xs = 0.02 + 0.5 * rng.standard_normal(I)
+    if kind == "orthogonal":   # sum b x cancels: what is left of y is the part the reference computes worst
+        b = vo.to_f32(L.weight_bias, "f16").astype(np.float64)
+        xs = xs - b * (xs @ b) / (b @ b)
+    return vo.from_f32(xs.astype(np.float32).reshape(1, 1, I), "f16")
+
+
+ADVERSARIAL = [("plain", "normal"), ("plain", "large_mean"), ("cyclic", "normal"), ("cyclic", "large_mean"),
+               ("bias1.5", "orthogonal"), ("bias4", "normal"), ("bias4", "orthogonal"), ("bias16", "orthogonal")]
+
+
+@pytest.mark.parametrize("family,xkind", ADVERSARIAL)
+@pytest.mark.parametrize("O", [512, 4608])   # the VALU kernel / the persistent MFMA kernel (144 row groups)
+def test_adversarial_families_default_route(family, xkind, O, dev):
+    """The module's default route must stay inside the 1e-3 bar on inputs built against the folded form:
+    bias-dominated layers are recognised at load time (VQuantLinear._folded_form_is_safe) and served in the
+    reference's arithmetic; everything else takes the folded form and must pass as it is."""
+    from vptq_amd.ops.chain import GemvChain
+    I = 4096
+    L = _adversarial_layer(I, O, family, seed=77 + O)
+    x = _adversarial_x(L, xkind, seed=5)
+    want = vo.forward(L, x)
+    m = spec_to_module(L, dev)
+    xt = bits_to_tensor(x, "f16", dev).reshape(x.shape)
+    gated = m._descriptor()[9] != 0
+    assert gated == (family in ("bias4", "bias16")), (family, gated)
+    err = rel_err(tensor_to_bits(m(xt)), want, "f16")
+    assert err <= 1e-3, f"module default route, {family}/{xkind}: {err:.2e}"
+    # the chain API with the same layers (the gate routes bias-dominated ones to the per-layer exact path)
+    ys = GemvChain([m, m])([xt, xt], flags=None if gated else 8)
+    err_c = rel_err(tensor_to_bits(ys[1]), want, "f16")
+    assert err_c <= 1e-3, f"chain route, {family}/{xkind}: {err_c:.2e}"
+    # the folded form itself through the C ABI, whatever the gate says (reported; asserted only below the gate)
+    raw = rel_err(tensor_to_bits(gemv_abi(m, xt, 0)), want, "f16")
+    exact = rel_err(tensor_to_bits(gemv_abi(m, xt, EXACT)), want, "f16")
+    print(f"\n[adversarial] O={O} {family}/{xkind}: default route {err:.2e} (gated={gated}), chain {err_c:.2e}, "
+          f"folded form {raw:.2e}, reference roundings {exact:.2e}")
+    assert exact <= 5e-4
+    if not gated:
+        assert raw <= 1e-3

@@ -6,6 +6,9 @@
 Random widths (multiples of 8 up to 30000), heights, permutation / output bias, every kernel
 and arithmetic flag combination; prints the worst max-normalised error per flag set.
 --formats: random index formats (vector length, codebook sizes, groups, outlier columns, ...) instead.
+--adversarial: families built against the folded arithmetic (bias-dominated layers, large-mean or bias-orthogonal
+activations, the reference test's cyclic indices): worst error per family of the module's default route (with its
+load-time gate), the chain route, the folded form itself and the reference's roundings.
 """
 import argparse
 import os
@@ -102,6 +105,38 @@ def fuzz_lds_tall(a, dev):
     print("kernels used:", used, "worst:", f"{worst:.2e}")
 
 
+def fuzz_adversarial(a, dev):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_hip_parity as T
+    from vptq_amd.ops.chain import GemvChain
+    rng = np.random.default_rng(a.seed)
+    worst = {}
+    fams = T.ADVERSARIAL + [("bias2", "orthogonal"), ("bias3", "orthogonal"), ("bias8", "normal"), ("bias64", "orthogonal")]
+    for c in range(a.cases):
+        family, xkind = fams[c % len(fams)]
+        I = 8 * int(rng.integers(64, 1100))
+        O = 8 * int(rng.choice([int(rng.integers(8, 100)), int(rng.integers(576, 700))]))
+        L = T._adversarial_layer(I, O, family, seed=5000 + c)
+        x = T._adversarial_x(L, xkind, seed=9000 + c)
+        want = vo.forward(L, x)
+        m = spec_to_module(L, dev)
+        xt = bits_to_tensor(x, "f16", dev).reshape(x.shape)
+        gated = m._descriptor()[9] != 0
+        errs = {"default_route": rel_err(tensor_to_bits(m(xt)), want, "f16"),
+                "chain_route": rel_err(tensor_to_bits(GemvChain([m, m])([xt, xt], flags=None if gated else 8)[1]), want, "f16"),
+                "folded_form": rel_err(tensor_to_bits(gemv_abi(m, xt, 0)), want, "f16"),
+                "reference_roundings": rel_err(tensor_to_bits(gemv_abi(m, xt, 4)), want, "f16")}
+        key = f"{family}/{xkind}"
+        w = worst.setdefault(key, {k: 0.0 for k in errs} | {"gated": gated})
+        for k, v in errs.items():
+            w[k] = max(w[k], v)
+        print(f"case {c:3d} I={I:5d} O={O:5d} {key:22s} gated={int(gated)} " + " ".join(f"{k}={v:.1e}" for k, v in errs.items()), flush=True)
+        assert errs["default_route"] <= 1e-3 and errs["chain_route"] <= 1e-3, key
+    print("worst per family:")
+    for k, w in worst.items():
+        print(f"  {k:22s} gated={int(w['gated'])} " + " ".join(f"{n}={v:.2e}" for n, v in w.items() if n != "gated"))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=40)
@@ -109,8 +144,11 @@ def main():
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
     ap.add_argument("--formats", action="store_true", help="random index formats instead of the canonical one")
     ap.add_argument("--lds-tall", action="store_true", help="tall layers of the LDS-resident formats (gemv_lds_mfma_kernel)")
+    ap.add_argument("--adversarial", action="store_true", help="families built against the folded arithmetic")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
+    if a.adversarial:
+        return fuzz_adversarial(a, dev)
     if a.lds_tall:
         return fuzz_lds_tall(a, dev)
     if a.formats:

@@ -48,13 +48,17 @@ class GemvChain:
             flags = B.GEMV_CHAIN_DEPENDENT if self.dependent else 0
             nbytes = B.lib().vptq_quant_gemv_chain_workspace_bytes(n, flags)
             ws = torch.zeros(max(nbytes, 4) // 4, dtype=torch.int32, device=dev) if nbytes else None
+            safe = 0
+            for c in caches:
+                safe |= c[9]   # a bias-dominated layer (VQuantLinear._folded_form_is_safe): reference arithmetic
+            self._safe_flags = safe
             self._state = (key, descs, (C.c_void_p * n)(), (C.c_void_p * n)(), ws, nbytes, dev,
                            caches[0][7], [c[2] for c in caches])
         return self._state
 
     def kernel_name(self, tokens: int = 1, flags: Optional[int] = None) -> Optional[str]:
         _, descs, _, _, _, _, _, _, _ = self._prepare()
-        f = ops.quant_gemm_flags() if flags is None else flags
+        f = (ops.quant_gemm_flags() if flags is None else flags) | self._safe_flags
         if self.dependent:
             f |= B.GEMV_CHAIN_DEPENDENT
         name = B.lib().vptq_quant_gemv_chain_kernel_name(descs, len(self.layers), tokens, f)
@@ -74,7 +78,7 @@ class GemvChain:
             raise ValueError(f"{n} layers need {n} activations")
         x0 = self.layers[0]._check_activation(xs[0])
         tokens = x0.numel() // x0.shape[-1]
-        f = ops.quant_gemm_flags() if flags is None else flags
+        f = (ops.quant_gemm_flags() if flags is None else flags) | self._safe_flags
         out_dtype = torch.float32 if (f & B.GEMV_OUT_F32) else wdtype
         if self.dependent and (f & B.GEMV_OUT_F32):
             raise ValueError("a dependent chain feeds its outputs back in: no float32 outputs")
