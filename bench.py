@@ -460,7 +460,7 @@ def llama70b_projections():
 
 
 def bench_tp_row(lib, B, dev, timer, rank, world, n_layers, flags, steps, warmup, regions, check=True,
-                 fuse_siblings=True):
+                 fuse_siblings=True, pair=False):
     """BASELINE config #5 (see the module docstring).  Every rank builds the SAME full projections
     (common seed; the permutation is already absorbed: enable_perm = False) and keeps its slice of
     the input columns; per projection: fused GEMV of the slice with fp32 partial output
@@ -468,28 +468,38 @@ def bench_tp_row(lib, B, dev, timer, rank, world, n_layers, flags, steps, warmup
     fuse_siblings (default): q / k / v and gate / up - projections of the same input - go out as ONE
     grouped launch (vptq_quant_gemv_grouped) into one contiguous fp32 buffer, ONE all-reduce and one
     rounding each: 4 launches + 4 collectives per decoder layer instead of 7 + 7 (the collectives are
-    latency-bound at batch 1: fewer, larger ones)."""
-    from vptq_amd.utils.shard import shard_in_features
+    latency-bound at batch 1: fewer, larger ones).
+    pair (--mode tp_pair): the Megatron pairing SURVEY 8(e) describes - q / k / v / gate / up cut
+    COLUMN-parallel (output rows, shard_out_features: disjoint output slices, no collective; their
+    consumers o / down are row-parallel over the same split), o / down row-parallel as above: 2
+    all-reduces per decoder layer instead of 4."""
+    from vptq_amd.utils.shard import shard_in_features, shard_out_features
+    col_names = ("q_proj", "k_proj", "v_proj", "gate_proj", "up_proj") if pair else ()
     dist = timer.dist
     projs = llama70b_projections()
     groups = [[0, 1, 2], [3], [4, 5], [6]] if fuse_siblings else [[i] for i in range(len(projs))]
     g = torch.Generator(device=dev).manual_seed(4321)
-    calls, keeps, full0, x_full0, y_k0 = [], [], None, None, None
+    check_names = ("q_proj", "k_proj", "gate_proj", "down_proj")   # one projection of EVERY shape, layer 0
+    calls, keeps, full0, checks = [], [], {}, []
     for li in range(n_layers):
         mods = []
         for (name, O, I) in projs:
             m = make_layer(I, O, dev, g)
-            if li == 0 and name == "k_proj":
-                full0 = m                      # kept whole for the parity check
-            mods.append((shard_in_features(m, rank, world), O, I))
+            if li == 0 and name in check_names and check and rank == 0:
+                full0[name] = m                # kept whole for the parity check
+            if name in col_names:
+                mods.append((shard_out_features(m, rank, world), O, I))
+            else:
+                mods.append((shard_in_features(m, rank, world), O, I))
             del m
         for grp in groups:
             I = mods[grp[0]][2]
             x = torch.randn(1, 1, I, device=dev, dtype=torch.float16, generator=g)   # siblings share their input
             s0 = mods[grp[0]][0]
-            xs = x[..., s0.shard[1]:s0.shard[2]].contiguous()
-            Os = [mods[i][1] for i in grp]
-            part = torch.empty(1, 1, sum(Os), device=dev, dtype=torch.float32)
+            col = s0.shard[0] == "out"
+            xs = x if col else x[..., s0.shard[1]:s0.shard[2]].contiguous()
+            Os = [mods[i][0].out_features for i in grp]   # (column-parallel: this rank's slice of the rows)
+            part = None if col else torch.empty(1, 1, sum(Os), device=dev, dtype=torch.float32)
             y = torch.empty(1, 1, sum(Os), device=dev, dtype=torch.float16)
             ds = []
             for i in grp:
@@ -498,13 +508,16 @@ def bench_tp_row(lib, B, dev, timer, rank, world, n_layers, flags, steps, warmup
             offs = [sum(Os[:j]) for j in range(len(grp))]
             arr = (B.LayerDesc * len(grp))(*ds)
             xp = (C.c_void_p * len(grp))(*[xs.data_ptr()] * len(grp))
-            yp = (C.c_void_p * len(grp))(*[part.data_ptr() + 4 * o for o in offs])
+            yp = (C.c_void_p * len(grp))(*[(y.data_ptr() + 2 * o) if col else (part.data_ptr() + 4 * o) for o in offs])
             calls.append((len(grp), arr, xp, yp, part, y))
             keeps.append((xs, part, y))
-            if li == 0 and 1 in grp:
-                x_full0 = x
-                o = offs[grp.index(1)]
-                y_k0 = y[..., o:o + Os[grp.index(1)]]
+            if li == 0:
+                for pi in grp:
+                    if projs[pi][0] in full0:
+                        o = offs[grp.index(pi)]
+                        sh = mods[pi][0].shard
+                        checks.append((projs[pi][0], x, y[..., o:o + Os[grp.index(pi)]],
+                                       (sh[1], sh[2]) if col else None))
         del mods
         torch.cuda.empty_cache()
     fl = flags | B.GEMV_OUT_F32
@@ -512,32 +525,44 @@ def bench_tp_row(lib, B, dev, timer, rank, world, n_layers, flags, steps, warmup
     def one_pass():
         sp = torch.cuda.current_stream().cuda_stream
         for (m, arr, xp, yp, part, y) in calls:
+            f = flags if part is None else fl   # column-parallel: this rank's rows, rounded in the kernel
             if m == 1:
-                rc = lib.vptq_quant_gemv(arr, xp[0], yp[0], 1, fl, None, 0, sp)
+                rc = lib.vptq_quant_gemv(arr, xp[0], yp[0], 1, f, None, 0, sp)
             else:
-                rc = lib.vptq_quant_gemv_grouped(arr, m, xp, yp, 1, fl, sp)
+                rc = lib.vptq_quant_gemv_grouped(arr, m, xp, yp, 1, f, sp)
             assert rc == 0, lib.vptq_last_error()
+            if part is None:
+                continue
             if dist is not None:
                 dist.all_reduce(part)           # fp32 partial sums over the ranks
             y.copy_(part)                       # the ONE rounding (reference: F.linear's)
     t = timer.run(one_pass, steps, warmup, regions)
     ab = sum(alg_bytes(I, O) for (_, O, I) in projs) * n_layers
     per_layer = len(groups)
+    n_reduce = sum(1 for grp in groups if projs[grp[0]][0] not in col_names)
     res = dict(value=ab * steps / t["wall_s"] / 1e9, ms_per_step=t["wall_s"] * 1e3 / steps,
                us_per_decoder_layer=t["event_ms"] * 1e3 / steps / n_layers,
                decoder_layers=n_layers, projections=[p[0] for p in projs], hipgraph=t["captured"],
                alg_bytes_per_step=ab, regions_ms_per_step=t["regions_ms_per_step"],
                launches_per_decoder_layer=per_layer,
-               all_reduce=(f"fp32 partial outputs, {per_layer} RCCL all-reduces per decoder layer "
-                           "(q+k+v, o, gate+up, down)" if fuse_siblings else
+               all_reduce=((f"q/k/v/gate/up column-parallel (no collective), o / down row-parallel: {n_reduce} RCCL "
+                            "all-reduces of fp32 partial outputs per decoder layer") if pair else
+                           (f"fp32 partial outputs, {per_layer} RCCL all-reduces per decoder layer "
+                            "(q+k+v, o, gate+up, down)") if fuse_siblings else
                            "fp32 partial outputs, one RCCL all-reduce per projection") if world > 1 else "none (1 rank)")
     if check and rank == 0:
         from oracle import c_oracle as co
         if co.available():
-            L = layer_spec(full0)
-            xb = x_full0.detach().cpu().contiguous().view(torch.int16).numpy().view(np.uint16)
-            want = co.forward(L, xb)
-            res["parity_rel_err_vs_cpu_oracle"] = rel_err_bits(y_k0.contiguous(), want)   # k_proj of layer 0
+            errs = {}
+            for name, xf, yv, rows in checks:   # the (reduced) output of one projection of every shape against the C oracle
+                L = layer_spec(full0[name])
+                xb = xf.detach().cpu().contiguous().view(torch.int16).numpy().view(np.uint16)
+                want = co.forward(L, xb)
+                if rows is not None:            # column-parallel: rank 0's slice of the output rows
+                    want = np.ascontiguousarray(want.reshape(-1)[rows[0]:rows[1]])
+                errs[name] = rel_err_bits(yv.contiguous(), want)
+            res["parity_rel_err_vs_cpu_oracle"] = max(errs.values())
+            res["parity_per_projection"] = errs
             assert res["parity_rel_err_vs_cpu_oracle"] <= 1e-3, res
     return res
 
@@ -550,7 +575,7 @@ def main():
     ap.add_argument("--regions", type=int, default=5, help="timed regions of K steps; the median is reported")
     ap.add_argument("--hidden", type=int, default=8192)
     ap.add_argument("--ring", type=int, default=0)
-    ap.add_argument("--mode", choices=["auto", "chain", "chain_dep", "single", "grouped", "tp", "tp_row", "rings"], default="auto")
+    ap.add_argument("--mode", choices=["auto", "chain", "chain_dep", "single", "grouped", "tp", "tp_row", "tp_pair", "rings"], default="auto")
     ap.add_argument("--chain", type=int, default=32, help="chain: layers per launch (<= 32)")
     ap.add_argument("--group", type=int, default=4)
     ap.add_argument("--tp-layers", type=int, default=20,
@@ -606,14 +631,15 @@ def main():
     lib = B.lib()
     H = a.hidden
     flags = B.GEMV_EXACT if a.exact else 0
-    timer = Timer(dev, dist, allow_eager=mode in ("tp", "tp_row"))
+    timer = Timer(dev, dist, allow_eager=mode in ("tp", "tp_row", "tp_pair"))
     arithmetic = ("reference roundings per weight (VPTQ_GEMV_EXACT), fp32 accumulate" if a.exact else
                   "folded fp32 (default): sum (c+r)*f16(s*x) + sum b*x - inside the 1e-3 max-normalised "
                   "parity bar (measured 5-6e-4), not bit-equivalent; see extras.exact for the "
                   "bit-equivalent form")
 
-    if mode == "tp_row":
-        r = bench_tp_row(lib, B, dev, timer, rank, world, a.tp_layers, flags, a.steps, a.warmup, a.regions)
+    if mode in ("tp_row", "tp_pair"):
+        r = bench_tp_row(lib, B, dev, timer, rank, world, a.tp_layers, flags, a.steps, a.warmup, a.regions,
+                         pair=mode == "tp_pair")
         out = {
             "metric": "decode GEMV effective GB/s (VQuantLinear 2-bit, batch 1)",
             "value": r["value"], "unit": "GB/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -623,7 +649,7 @@ def main():
                                    "gate/up 28672x8192, down 8192x28672; v=8 k=256+256, 2-bit), batch=1 seq=1 fp16, "
                                    f"every projection row-parallel over {world} rank(s): fused GEMV with fp32 partial "
                                    "output -> RCCL all-reduce -> one rounding; 1 step = 1 token through all layers' "
-                                   "projections", "mode": "tp_row", "decoder_layers": a.tp_layers,
+                                   "projections", "mode": mode, "decoder_layers": a.tp_layers,
                        "hipgraph": r["hipgraph"], "arithmetic": arithmetic,
                        "parallelism": f"tp{world} row-parallel (input columns), RCCL all-reduce per projection",
                        "strong_scaling_baseline": "python bench.py --mode tp_row --gpus 1 (also: extras.tp_row_n1 of "
@@ -634,6 +660,11 @@ def main():
                          "note": "per GPU: whole-job algorithmic bytes / N / time, collectives included"},
             "tp_row": {k: v for k, v in r.items() if k != "regions_ms_per_step"},
         }
+        if world > 1 and not a.no_extras and mode == "tp_row":
+            # the Megatron pairing (2 all-reduces per decoder layer instead of 4) on the same layers
+            pr = bench_tp_row(lib, B, dev, Timer(dev, dist, allow_eager=True), rank, world, a.tp_layers, flags,
+                              max(5, a.steps // 4), 5, 3, pair=True)
+            out["tp_pair"] = {k: v for k, v in pr.items() if k != "regions_ms_per_step"}
         if world > 1 and not a.no_extras:
             w, *_ = bench_ring(lib, B, dev, Timer(dev, dist), H, "single", flags, max(5, a.steps // 4), 5, 3,
                                rank=rank, world=world)
@@ -740,11 +771,12 @@ def main():
         ex["grouped_x4"]["what"] = "4 independent layers per launch (vptq_quant_gemv_grouped), us per LAYER = us_per_launch / 4"
         ex["tokens16"]["what"] = "16 tokens per launch (batched-decode kernel), bytes incl. 16 x and y rows"
         ex["k8192_r256"]["what"] = "k = 8192 + 256 (T = 21 bits), LDS-resident codebooks"
-        tr = bench_tp_row(lib, B, dev, Timer(dev), 0, 1, 4, 0, st, wu, rg)
-        ex["tp_row_n1"] = {"what": "Llama-3-70B shaped decoder layers (x4) on ONE GPU through the row-parallel code "
-                                   "path (world size 1): the strong-scaling baseline of --gpus N",
+        tr = bench_tp_row(lib, B, dev, Timer(dev), 0, 1, a.tp_layers, 0, st, wu, rg)
+        ex["tp_row_n1"] = {"what": f"Llama-3-70B shaped decoder layers (x{a.tp_layers}, the ring of --gpus N) on ONE GPU "
+                                   "through the row-parallel code path (world size 1): the strong-scaling baseline of --gpus N",
                            "GBps": tr["value"], "us_per_decoder_layer": tr["us_per_decoder_layer"],
-                           "parity_rel_err_vs_cpu_oracle": tr.get("parity_rel_err_vs_cpu_oracle")}
+                           "parity_rel_err_vs_cpu_oracle": tr.get("parity_rel_err_vs_cpu_oracle"),
+                           "parity_per_projection": tr.get("parity_per_projection")}
         try:
             ex["prefill"] = prefill_extra(dev)
         except Exception as e:   # the headline line must not depend on it

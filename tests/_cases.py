@@ -111,7 +111,15 @@ def load_big(name, directory=None):
         L.perm = t["perm"]
     if cfg["bias"]:
         L.bias = t["bias"]
+    # y rows the fixture keeps (gen_golden_big.py:stored_rows): all up to 64 tokens, every 8th + the last beyond
+    T = cfg["tokens"]
+    cfg["y_rows"] = list(range(T)) if T <= 64 else sorted(set(range(0, T, 8)) | {T - 1})
     return L, t["x"].reshape(1, cfg["tokens"], I), z["y"], cfg, z["W_head"]
+
+
+def stored_rows(out_bits, cfg):
+    """the token rows of a full output [1, T, O] that a big fixture stores"""
+    return np.ascontiguousarray(out_bits)[:, cfg["y_rows"], :]
 
 
 # ---- v2 wire format: outputs of the reference test file's ground_truth ----------------------

@@ -37,7 +37,20 @@ BIG_CASES = [
     ("h8192_f16_llm", 8192, 8192, False, False, "f16", 1, "llm"),
     ("h8192_bf16_llm", 8192, 8192, False, False, "bf16", 1, "llm"),
     ("h8192_f16_reftest_t4", 8192, 8192, False, False, "f16", 4, "ref-test"),
+    # round 3: the many-token routes (the reference's dequant + F.linear branch, vptq/ops/quant_gemm.py:231-274);
+    # 256 tokens: every 8th token row of y is stored (+ the last one)
+    ("h4096_f16_llm_t64", 4096, 4096, False, False, "f16", 64, "llm"),
+    ("h4096_bf16_llm_t64", 4096, 4096, False, False, "bf16", 64, "llm"),
+    ("h4096_f16_llm_t256", 4096, 4096, False, False, "f16", 256, "llm"),
+    ("h4096_bf16_llm_t256", 4096, 4096, False, False, "bf16", 256, "llm"),
 ]
+
+
+def stored_rows(tokens):
+    """token rows of y a fixture keeps: all of them up to 64 tokens, every 8th + the last beyond"""
+    if tokens <= 64:
+        return list(range(tokens))
+    return sorted(set(range(0, tokens, 8)) | {tokens - 1})
 
 
 def main():
@@ -45,6 +58,8 @@ def main():
     torch.set_num_threads(1)  # one summation order, whatever the box
     os.makedirs(os.path.join(HERE, "big"), exist_ok=True)
     for ci, (name, I, O, perm, bias, dtype, tokens, dist) in enumerate(BIG_CASES):
+        if os.path.exists(os.path.join(HERE, "big", f"{name}.npz")) and "--force" not in sys.argv:
+            continue   # (existing fixtures are left alone; --force regenerates them bit for bit)
         seed = 4242 + ci
         dt = gg.TORCH_DT[dtype]
         kw = dict(CANON, enable_perm=perm, bias=bias)
@@ -76,7 +91,7 @@ def main():
                    torch=torch.__version__)
         out = os.path.join(HERE, "big", f"{name}.npz")
         np.savez_compressed(out, config=np.frombuffer(json.dumps(cfg).encode(), dtype=np.uint8),
-                            y=gg.bits(y), W_head=Wb[:2].copy())
+                            y=gg.bits(y)[:, stored_rows(tokens), :], W_head=Wb[:2].copy())
         print(f"{name}: y{tuple(y.shape)} -> {os.path.getsize(out) / 1024:.0f} KiB")
 
 

@@ -727,7 +727,7 @@ def test_sibling_groups_share_one_launch(dev):
 
 
 # ---------------------------------------------------------------- BASELINE sizes vs the reference
-from _cases import big_names, load_big, v2_names, load_v2, fmt_names, load_fmt  # noqa: E402
+from _cases import big_names, load_big, v2_names, load_v2, fmt_names, load_fmt, stored_rows  # noqa: E402
 
 
 @pytest.mark.parametrize("name", big_names())
@@ -736,6 +736,8 @@ def test_baseline_size_goldens_every_kernel_and_form(name, dev):
     tests/golden/gen_golden_big.py): dense W bit for bit (sha256), forward through both k = 256
     kernels in both arithmetic forms, the generic kernel and the module's own route."""
     L, x, y, cfg, W_head = load_big(name)
+    if cfg["tokens"] > 4:
+        pytest.skip("many tokens: test_many_token_routes_vs_reference_goldens")
     dt = cfg["dtype"]
     m = spec_to_module(L, dev)
     W = tensor_to_bits(m.dequant())
@@ -755,6 +757,31 @@ def test_baseline_size_goldens_every_kernel_and_form(name, dev):
     if dt == "f16":
         assert seen[EXACT][2] >= 0.95 and seen[GENERIC][2] >= 0.95, seen
     print(name, seen)
+
+
+@pytest.mark.parametrize("name", [n for n in big_names() if n.endswith(("_t64", "_t256"))])
+def test_many_token_routes_vs_reference_goldens(name, dev):
+    """64 and 256 tokens through a 4096^2 layer against the REAL reference's prefill branch (dequant +
+    F.linear, /root/reference/vptq/ops/quant_gemm.py:231-274; fixtures: tests/golden/gen_golden_big.py):
+    the module's own route, the cached dense route, the fused dequant-tile GEMM, and - 64 tokens, fp16 -
+    the batched-decode kernel (4 launches of 16 tokens)."""
+    from vptq_amd import ops
+    L, x, y, cfg, W_head = load_big(name)
+    dt, T = cfg["dtype"], cfg["tokens"]
+    m = spec_to_module(L, dev)
+    assert hashlib.sha256(tensor_to_bits(m.dequant()).tobytes()).hexdigest() == cfg["W_sha256"]
+    xt = bits_to_tensor(x, dt, dev).reshape(x.shape)
+    routes = {"module": lambda: m(xt), "dense_cached": lambda: m._dense_cached(xt),
+              "gemm_fused": lambda: ops.quant_gemm_fused(xt, m._descriptor()[1], L.out_features)}
+    if T <= 64 and dt == "f16":
+        assert kernel_name(m, T) == "gemm_k256_kernel"
+        routes["gemm_k256"] = lambda: gemv_abi(m, xt, 0)
+    errs = {}
+    for rname, fn in routes.items():
+        out = stored_rows(tensor_to_bits(fn()).reshape(1, T, -1), cfg)
+        errs[rname] = rel_err(out, y, dt)
+        assert errs[rname] <= TOL[dt], (rname, errs)
+    print(name, {k: f"{v:.2e}" for k, v in errs.items()})
 
 
 FMT_KERNELS = {"t1_k8192_r256_8192x1024": "gemv_lds_mfma_kernel", "t1_k4096_r512_perm_bias": "gemv_lds_mfma_kernel",

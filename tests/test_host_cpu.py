@@ -62,6 +62,31 @@ def _canonical_desc(I=4096, O=4096, dtype=0, perm=False):
     return d
 
 
+def test_chain_routing_without_gpu():
+    """vptq_quant_gemv_chain_kernel_name is host logic: one persistent launch when every layer is of the
+    canonical format (one dtype, no permutation, one token) AND the chain fills the device; per-layer otherwise."""
+    lib = B.lib()
+
+    def name(descs, tokens=1, flags=0):
+        arr = (B.LayerDesc * len(descs))(*descs)
+        return lib.vptq_quant_gemv_chain_kernel_name(arr, len(descs), tokens, flags)
+    big, small = _canonical_desc(8192, 8192), _canonical_desc(4096, 4096)
+    assert name([big] * 32) == b"gemv_k256c_kernel"
+    assert name([big] * 32, flags=B.GEMV_CHAIN_DEPENDENT) == b"gemv_k256c_kernel"
+    assert name([small] * 32) == b"gemv_k256c_kernel"          # 64 row groups each: 8 layers side by side
+    assert name([big] * 2) == b"gemv_k256c_kernel"             # 2 x 128 row groups of 8 vector-rows
+    assert name([small]) == b"per-layer"                       # 64 row groups cannot fill 256 workgroups ...
+    assert name([small], flags=B.GEMV_FORCE_MFMA) == b"gemv_k256c_kernel"    # ... unless asked for
+    assert name([_canonical_desc(8192, 1024)] * 3) == b"per-layer"           # k / v sized projections
+    assert name([big] * 32, tokens=2) == b"per-layer"
+    assert name([big] * 31 + [_canonical_desc(8192, 8192, perm=True)]) == b"per-layer"
+    assert name([big] * 31 + [_canonical_desc(8192, 8192, dtype=1)]) == b"per-layer"
+    assert name([big] * 32, flags=B.GEMV_EXACT) == b"per-layer"
+    assert name([big] * 40) == b"gemv_k256c_kernel"            # two launches (32 + 8)
+    assert lib.vptq_quant_gemv_chain_workspace_bytes(32, 0) == 0
+    assert lib.vptq_quant_gemv_chain_workspace_bytes(32, B.GEMV_CHAIN_DEPENDENT) == 32 * 1024
+
+
 def test_kernel_choice_without_gpu():
     """Which kernel a call would use is host logic (vptq_quant_gemv_kernel_name launches nothing):
     the persistent MFMA kernel from 144 row groups on (bf16: 32), 1-4 tokens in its folded form,

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from oracle import vptq_oracle as vo
-from _cases import (golden_names, load_golden, rel_err, bit_identical_frac, big_names, load_big, fmt_names, load_fmt,
+from _cases import (golden_names, load_golden, rel_err, bit_identical_frac, big_names, load_big, fmt_names, load_fmt, stored_rows,
                     v2_names, load_v2)
 from _refshim import reference_available
 
@@ -110,7 +110,7 @@ def test_c_oracle_vs_reference_at_baseline_sizes(name):
     W = co.dequant(L)
     assert (W[:2] == W_head).all()
     assert hashlib.sha256(W.tobytes()).hexdigest() == cfg["W_sha256"]
-    out = co.forward(L, x)
+    out = stored_rows(co.forward(L, x), cfg)
     assert rel_err(out, y, cfg["dtype"]) <= Y_TOL[cfg["dtype"]]
     assert bit_identical_frac(out, y) >= 0.98
 
@@ -120,7 +120,7 @@ def test_numpy_oracle_vs_reference_at_hidden_4096(name):
     L, x, y, cfg, W_head = load_big(name)
     W = vo.dequant(L)
     assert hashlib.sha256(W.tobytes()).hexdigest() == cfg["W_sha256"]
-    out = vo.forward(L, x)
+    out = stored_rows(vo.forward(L, x), cfg)
     assert rel_err(out, y, cfg["dtype"]) <= Y_TOL[cfg["dtype"]]
     assert bit_identical_frac(out, y) >= 0.98
 

@@ -105,8 +105,9 @@ int vptq_quant_gemv_max_tokens(const VptqLayerDesc* d) {
 enum Route { kRouteNone, kRouteGemmK256, kRouteK256, kRouteGather, kRouteLds, kRouteGatherX, kRouteGeneric };
 
 static int batch_min_tokens() {
-  static int v = -1;  // VPTQ_GEMM_MIN_TOKENS: smallest token count that takes the batched-decode kernel
-  if (v < 0) { const char* ev = getenv("VPTQ_GEMM_MIN_TOKENS"); v = ev ? atoi(ev) : 5; }
+  static std::atomic<int> v{-1};  // VPTQ_GEMM_MIN_TOKENS: smallest token count that takes the batched-decode kernel
+  // (at most 16: vptq_quant_gemv_max_tokens promises the batched kernel for 17+ tokens of such layers)
+  if (v < 0) { const char* ev = getenv("VPTQ_GEMM_MIN_TOKENS"); const int w = ev ? atoi(ev) : 5; v = w > 16 ? 16 : (w < 1 ? 1 : w); }
   return v;
 }
 

@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void dequant_kernel(const VptqLayerDesc d,
       for (int k = 0; k < 4; ++k)
         r[k] = __builtin_amdgcn_perm(w2[2 * k + 1][p], w2[2 * k][p], h ? 0x07060302u : 0x05040100u);
       uint16_t* const dst = W + (size_t)o * I + j0;
-      if (full) {
+      if (full && (((uintptr_t)W) & 15) == 0) {   // (rows are 2 I bytes, I % 8 == 0: W's alignment is every row's)
         *(u32x4*)dst = r;
       } else {
 #pragma unroll

@@ -408,12 +408,12 @@ hipError_t launch_gemm_fused(const VptqLayerDesc& d, const void* x, void* y, int
   }
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-  static int cus[64] = {};
+  static std::atomic<int> cus[64];
   if (!cus[dev]) {
     hipDeviceProp_t p;
     cus[dev] = hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
   }
-  static bool attr_set[64] = {};
+  static std::atomic<bool> attr_set[64];
   if (!attr_set[dev]) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_fused_kernel<F16>, hipFuncAttributeMaxDynamicSharedMemorySize, kFLds);
     if (e == hipSuccess)
@@ -423,7 +423,8 @@ hipError_t launch_gemm_fused(const VptqLayerDesc& d, const void* x, void* y, int
   }
   const int n_tiles = P.tiles_m * P.tiles_n;
   // one workgroup per CU; kept a multiple of 8 (the XCD count) for the tile walk
-  int grid = n_tiles < cus[dev] ? (n_tiles + 7) / 8 * 8 : cus[dev];
+  const int ncu = cus[dev].load();
+  int grid = n_tiles < ncu ? (n_tiles + 7) / 8 * 8 : ncu;
   if (grid > cus[dev]) grid = cus[dev];
   if (f16) hipLaunchKernelGGL((gemm_fused_kernel<F16>), dim3(grid), dim3(kFThreads), kFLds, st, P);
   else hipLaunchKernelGGL((gemm_fused_kernel<BF16>), dim3(grid), dim3(kFThreads), kFLds, st, P);

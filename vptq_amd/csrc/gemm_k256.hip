@@ -308,12 +308,12 @@ hipError_t launch_gemm_k256(const VptqLayerDesc& d, const void* x, void* y, int 
   P.n_groups = (d.num_indices + kGRows - 1) / kGRows;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-  static int cus[64] = {};
+  static std::atomic<int> cus[64];
   if (!cus[dev]) {
     hipDeviceProp_t p;
     cus[dev] = hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
   }
-  static bool attr_set[64] = {};
+  static std::atomic<bool> attr_set[64];
   if (!attr_set[dev]) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_k256_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kGLds);
     if (e == hipSuccess)
@@ -321,7 +321,8 @@ hipError_t launch_gemm_k256(const VptqLayerDesc& d, const void* x, void* y, int 
     if (e != hipSuccess) return e;
     attr_set[dev] = true;
   }
-  const int grid = P.n_groups < cus[dev] ? P.n_groups : cus[dev];
+  const int ncu = cus[dev].load();
+  const int grid = P.n_groups < ncu ? P.n_groups : ncu;
   if (d.perm) hipLaunchKernelGGL(gemm_k256_kernel<true>, dim3(grid), dim3(kGThreads), kGLds, st, P);
   else hipLaunchKernelGGL(gemm_k256_kernel<false>, dim3(grid), dim3(kGThreads), kGLds, st, P);
   return hipGetLastError();

@@ -358,7 +358,7 @@ bool gemv_k256_eligible(const VptqLayerDesc& d, int tokens) {
 // ROWS per workgroup: 2 when that still leaves >= 512 workgroups (two per CU) and
 // the instantiation stays spill-free under the 128-VGPR budget (f16, one token).
 static int pick_rows(int n_rows_total, int tok, bool f16) {
-  static int forced = -1;  // VPTQ_K256_ROWS=1|2: tuning override
+  static std::atomic<int> forced{-1};  // VPTQ_K256_ROWS=1|2: tuning override
   if (forced < 0) { const char* e = getenv("VPTQ_K256_ROWS"); forced = e ? atoi(e) : 0; }
   if (forced == 2 && f16 && tok == 1) return 2;
   if (forced == 1) return 1;
@@ -371,7 +371,7 @@ static hipError_t launch_inst(const K256Params& P, int grid, hipStream_t st) {
   // > 64 KiB of dynamic LDS must be enabled once per device (benign race: idempotent)
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-  auto allow_lds = [&](const void* kern, bool& done) {
+  auto allow_lds = [&](const void* kern, std::atomic<bool>& done) {
     if (done) return hipSuccess;
     const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     done = e == hipSuccess;
@@ -380,7 +380,7 @@ static hipError_t launch_inst(const K256Params& P, int grid, hipStream_t st) {
   if constexpr (TOK == 1) {
     if (P.n_layers == 1) {  // the preloaded-argument entry point
       auto kern = gemv_k256_kernel_1<DT, ROWS, SW, PERM, FAST>;
-      static bool attr_set[64] = {};
+      static std::atomic<bool> attr_set[64];
       if (hipError_t e = allow_lds((const void*)kern, attr_set[dev]); e != hipSuccess) return e;
       const K256Layer& L0 = P.layer[0];
       hipLaunchKernelGGL(kern, dim3(grid, 1), dim3(kThreads), lds, st, L0.cent, L0.rcent, L0.idx, L0.x,
@@ -389,7 +389,7 @@ static hipError_t launch_inst(const K256Params& P, int grid, hipStream_t st) {
     }
   }
   auto kern = gemv_k256_kernel<DT, ROWS, TOK, SW, PERM, FAST>;
-  static bool attr_set[64] = {};
+  static std::atomic<bool> attr_set[64];
   if (hipError_t e = allow_lds((const void*)kern, attr_set[dev]); e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(grid, P.n_layers), dim3(kThreads), lds, st, P);
   return hipGetLastError();
@@ -440,7 +440,7 @@ struct K256Choice {
 };
 
 static K256Choice choose_kernel(const VptqLayerDesc* descs, int n, int tokens, int flags) {
-  static int forced = -1;
+  static std::atomic<int> forced{-1};
   if (forced < 0) {
     const char* e = getenv("VPTQ_K256_KERNEL");
     forced = !e ? 0 : (e[0] == 'v' ? 1 : e[0] == 'm' ? 2 : 0);
@@ -530,9 +530,10 @@ hipError_t launch_gemv_k256(const VptqLayerDesc* descs, int n, const void* const
     long long chunk = d.prefetch ? (d.prefetch_bytes + n_wg - 1) / n_wg : 0;
     chunk = (chunk + 127) / 128 * 128;
     Ly.pf_chunk = (int)chunk;
-    static int pf_cap = -1;  // VPTQ_PF_BYTES: cap on the bytes each workgroup reads ahead
+    static std::atomic<int> pf_cap{-1};  // VPTQ_PF_BYTES: cap on the bytes each workgroup reads ahead
     if (pf_cap < 0) { const char* e = getenv("VPTQ_PF_BYTES"); pf_cap = e ? atoi(e) : 1 << 30; }
-    long long len = chunk < pf_cap ? chunk : pf_cap;
+    const long long cap = pf_cap.load();
+    long long len = chunk < cap ? chunk : cap;
     if (len > wg_threads * 128) len = wg_threads * 128;  // one line per thread
     Ly.pf_len = (int)len;
     Ly.slots = 0;

@@ -828,7 +828,7 @@ static long long c_blocks(const VptqLayerDesc* descs, int n, int cus, bool wide)
 }
 
 static int c_device_cus() {
-  static int cus[64] = {};
+  static std::atomic<int> cus[64];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
   if (!cus[dev]) {
@@ -840,9 +840,10 @@ static int c_device_cus() {
 }
 
 static int c_workgroups(bool dependent) {
-  static int forced_wgs = -1;  // VPTQ_K256C_WGS: tuning override of the workgroup count
+  static std::atomic<int> forced_wgs{-1};  // VPTQ_K256C_WGS: tuning override of the workgroup count
   if (forced_wgs < 0) { const char* e = getenv("VPTQ_K256C_WGS"); forced_wgs = e ? atoi(e) : 0; }
-  const int cus = forced_wgs > 0 ? forced_wgs : c_device_cus();
+  const int fw = forced_wgs.load();
+  const int cus = fw > 0 ? fw : c_device_cus();
   return dependent && cus > kCFlagStride ? kCFlagStride : cus;
 }
 
@@ -860,7 +861,7 @@ bool gemv_k256c_fills_device(const VptqLayerDesc* descs, int n, bool dependent) 
 template <typename DT, bool DEP>
 static hipError_t launch_c(const K256CParams& P, int grid, hipStream_t st) {
   auto kern = gemv_k256c_kernel<DT, DEP>;
-  static bool attr_set[64] = {};
+  static std::atomic<bool> attr_set[64];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
   if (!attr_set[dev]) {

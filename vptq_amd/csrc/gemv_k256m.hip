@@ -805,7 +805,7 @@ __global__ __launch_bounds__(kMThreads) void gemv_k256m_kernel_1(
 
 // ---- host side -------------------------------------------------------------------
 static int device_cus() {
-  static int cus[64] = {};
+  static std::atomic<int> cus[64];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
   if (!cus[dev]) {
@@ -832,7 +832,7 @@ static hipError_t launch_m(const K256Params& P, int gx, int max_cols, hipStream_
   if (lds > kMMaxLds) return hipErrorInvalidValue;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-  auto allow_lds = [&](const void* kern, bool& done) {
+  auto allow_lds = [&](const void* kern, std::atomic<bool>& done) {
     if (done) return hipSuccess;
     const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, kMMaxLds);
     done = e == hipSuccess;
@@ -841,7 +841,7 @@ static hipError_t launch_m(const K256Params& P, int gx, int max_cols, hipStream_
   if constexpr (TOK == 1) {
     if (P.n_layers == 1) {  // the preloaded-argument entry point
       auto kern = gemv_k256m_kernel_1<DT, NS, NST, PERM, FAST>;
-      static bool attr_set[64] = {};
+      static std::atomic<bool> attr_set[64];
       if (hipError_t e = allow_lds((const void*)kern, attr_set[dev]); e != hipSuccess) return e;
       const K256Layer& L0 = P.layer[0];
       hipLaunchKernelGGL(kern, dim3(gx, 1), dim3(kMThreads), lds, st, L0.cent, L0.rcent, L0.x, L0.scale,
@@ -850,7 +850,7 @@ static hipError_t launch_m(const K256Params& P, int gx, int max_cols, hipStream_
     }
   }
   auto kern = gemv_k256m_kernel<DT, NS, NST, PERM, FAST, TOK>;
-  static bool attr_set[64] = {};
+  static std::atomic<bool> attr_set[64];
   if (hipError_t e = allow_lds((const void*)kern, attr_set[dev]); e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(gx, P.n_layers), dim3(kMThreads), lds, st, P);
   return hipGetLastError();
@@ -941,9 +941,10 @@ int gemv_k256m_row_groups(int n_rows) { return (n_rows + kMRows - 1) / kMRows; }
 hipError_t launch_gemv_k256m(K256Params& P, int tok, bool f16, bool fast, int max_cols, bool perm,
                              hipStream_t st) {
   if (!gemv_k256m_supported(tok, f16, fast, max_cols, perm)) return hipErrorInvalidValue;
-  static int forced_wgs = -1;  // VPTQ_K256M_WGS: tuning override of the CU count
+  static std::atomic<int> forced_wgs{-1};  // VPTQ_K256M_WGS: tuning override of the CU count
   if (forced_wgs < 0) { const char* e = getenv("VPTQ_K256M_WGS"); forced_wgs = e ? atoi(e) : 0; }
-  const int cus = forced_wgs > 0 ? forced_wgs : device_cus();
+  const int fw = forced_wgs.load();
+  const int cus = fw > 0 ? fw : device_cus();
   long long total = 0;
   for (int i = 0; i < P.n_layers; ++i) total += gemv_k256m_row_groups(P.layer[i].N);
   int gx = 0;

@@ -640,7 +640,7 @@ __global__ __launch_bounds__(kLThreads) void gemv_lds_mfma_kernel(const LdsParam
 
 // ---- host side ------------------------------------------------------------------------
 static int lds_cus() {
-  static int cus[64] = {};
+  static std::atomic<int> cus[64];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
   if (!cus[dev]) {
@@ -672,7 +672,7 @@ static hipError_t launch_lds_t(const LdsParams& P, int grid, int lds, hipStream_
   auto kern = gemv_lds_kernel<DT, FMT, TOK>;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-  static bool attr_set[64] = {};
+  static std::atomic<bool> attr_set[64];
   if (!attr_set[dev]) {
     const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kLMaxLds);
     if (e != hipSuccess) return e;
@@ -711,7 +711,7 @@ static hipError_t launch_lds_mfma_t(const LdsParams& P, int grid, int lds, hipSt
   auto kern = gemv_lds_mfma_kernel<DT, FMT>;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-  static bool attr_set[64] = {};
+  static std::atomic<bool> attr_set[64];
   if (!attr_set[dev]) {
     const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kLMaxLds);
     if (e != hipSuccess) return e;
@@ -738,7 +738,7 @@ static hipError_t launch_lds_mfma_dt(const LdsParams& P, int fmt, int grid, int 
 
 // one token in the default arithmetic on a layer with row groups of >= 4 vector-rows: the MFMA kernel
 static bool lds_use_mfma(const LdsParams& P, int RW, bool exact) {
-  static int force = -1;   // VPTQ_LDS_KERNEL=valu|mfma (A/B runs)
+  static std::atomic<int> force{-1};   // VPTQ_LDS_KERNEL=valu|mfma (A/B runs)
   if (force < 0) {
     const char* ev = getenv("VPTQ_LDS_KERNEL");
     force = ev && ev[0] == 'v' ? 1 : 0;
@@ -777,7 +777,9 @@ bool gemv_lds_eligible(const VptqLayerDesc& d, int tokens, int flags) {
   if ((d.weight_scale != nullptr) && d.perm && !(d.scale_permuted && d.bias_permuted)) return false;
   // bf16 computes the folded form here: the caller asked for the reference's roundings
   if (d.dtype != VPTQ_DTYPE_F16 && (flags & VPTQ_GEMV_EXACT)) return false;
-  if ((((uintptr_t)d.centroids | (uintptr_t)d.res_centroids) & 15) != 0) return false;
+  // every tensor the kernels read with 16-byte loads (scale / bias / their permuted copies / perm; the codebooks)
+  if ((((uintptr_t)d.centroids | (uintptr_t)d.res_centroids | (uintptr_t)d.weight_scale | (uintptr_t)d.weight_bias |
+        (uintptr_t)d.scale_permuted | (uintptr_t)d.bias_permuted | (uintptr_t)d.perm) & 15) != 0) return false;
   return tokens >= 1 && tokens <= 4;
 }
 

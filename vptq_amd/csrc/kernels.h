@@ -1,5 +1,6 @@
 // Internal launcher prototypes (one per .hip translation unit).
 #pragma once
+#include <atomic>
 #include <hip/hip_runtime.h>
 
 #include "../../include/vptq_hip.h"

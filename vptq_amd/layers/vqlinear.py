@@ -64,12 +64,19 @@ class SiblingGroup:
         self._arrays = None
 
     def forward(self, layer, x, tokens):
-        # (tensors made under inference_mode track no version: identity alone then)
-        if self._x is x and B.tensor_version(x) == self._version and id(layer) in self._out:
+        # Tensors made under inference_mode track no version (-1): whether x was rewritten in place since the
+        # leader's launch cannot be told then, so sibling outputs are not reused at all - every layer launches
+        # for itself, as without a group.
+        ver = B.tensor_version(x)
+        if ver >= 0 and self._x is x and ver == self._version and id(layer) in self._out:
             y = self._out.pop(id(layer))
             if not self._out:
                 self._x = None
             return y
+        if ver < 0:
+            self._x, self._out = None, {}
+            return None
+        self._out = {}     # a new leader call: whatever an earlier one left unconsumed is stale
         xc = layer._check_activation(x)
         caches = [m._descriptor() for m in self.members]
         dev = caches[0][3]
@@ -363,7 +370,9 @@ class VQuantLinear(nn.Module):
         descriptor; layers linked by `link_siblings` share one grouped launch."""
         group = self.__dict__.get("_siblings")
         if group is not None and tokens <= group.MAX_TOKENS:
-            return group.forward(self, x, tokens)
+            y = group.forward(self, x, tokens)
+            if y is not None:
+                return y
         _, desc, _, dev, fn, _, _, wdtype, dev_index, safe_flags = self._descriptor()
         # (the checks of _check_activation against the cached dtype / device: no module attribute look-ups)
         if x.shape[-1] != self.in_features:
@@ -386,6 +395,10 @@ class VQuantLinear(nn.Module):
         else:
             rc = fn(desc, x.data_ptr(), y.data_ptr(), tokens, ops.quant_gemm_flags() | safe_flags, None, 0,
                     _raw_stream(dev_index))
+        if rc == -5 and tokens > B.GEMV_ANY_FORMAT_TOKENS:
+            # VPTQ_E_TOKENS: the fused path takes this layer's 17+ tokens only under run-time conditions the
+            # descriptor cannot promise (16-byte aligned activations, no FORCE_* flag): the dense route
+            return self._dense_cached(x)
         if rc:
             B.check(rc, "vptq_quant_gemv")
         return y

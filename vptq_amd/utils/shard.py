@@ -108,14 +108,25 @@ def shard_in_features(layer: VQuantLinear, rank: int, world: int) -> VQuantLinea
 def forward_partial_f32(layer: VQuantLinear, x: torch.Tensor) -> torch.Tensor:
     """`layer(x)` with the output left in float32, i.e. BEFORE the one rounding of the
     reference's `F.linear` (vptq/ops/quant_gemm.py:274): `VPTQ_GEMV_OUT_F32` of the fused
-    GEMV.  What a row-parallel rank contributes to the all-reduce.  1..16 tokens."""
+    GEMV.  What a row-parallel rank contributes to the all-reduce.  Any token count."""
     from vptq_amd import _backend as B
     from vptq_amd import ops
     xc = layer._check_activation(x)
     tokens = xc.numel() // xc.shape[-1]
-    if not 1 <= tokens <= B.GEMV_MAX_TOKENS:
-        raise RuntimeError(f"forward_partial_f32 takes 1..{B.GEMV_MAX_TOKENS} tokens, got {tokens}")
-    _, desc, _, dev, fn = layer._descriptor()[:5]
+    if tokens < 1:
+        raise RuntimeError("forward_partial_f32 needs at least one token")
+    cache = layer._descriptor()
+    _, desc, _, dev, fn = cache[:5]
+    # what vptq_quant_gemv takes for THIS layer: 64 tokens for fp16 layers of the canonical format
+    # (vptq_quant_gemv_max_tokens answers 48 for them), 16 for every other layer; beyond that the partial
+    # sum comes from the dense route: dequant + a matmul that accumulates and stays in fp32
+    limit = B.GEMV_MAX_TOKENS if cache[5] >= 48 else 16
+    if tokens > limit:
+        W = layer.dequant().float()
+        y = torch.matmul(xc.float(), W.t())
+        if layer.bias is not None:
+            y = y + layer.bias.float()
+        return y
     y = torch.empty(xc.shape[:-1] + (layer.out_features,), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         B.check(fn(desc, xc.data_ptr(), y.data_ptr(), tokens,
