@@ -35,31 +35,17 @@ def main():
                                               B.current_stream_ptr(dev)), "chain")
         e1.record()
         torch.cuda.synchronize()
-    raw = ws.view(256, 16, 8).cpu()
-    w = raw.clone()
-    vm = (raw[..., 0] >> 32).double().mean().item(); w[..., 0] = raw[..., 0] & 0xffffffff
-    l1 = (raw[..., 2] >> 32).double().mean().item(); w[..., 2] = raw[..., 2] & 0xffffffff
-    l2 = (raw[..., 3] >> 32).double().mean().item(); w[..., 3] = raw[..., 3] & 0xffffffff
-    l0 = (raw[..., 6] & 0xffffffff).double().mean().item()
-    w = w.double()
+    w = ws.view(256, 16, 8).cpu().double()
     us = e0.elapsed_time(e1) * 1e3
     tot = w[..., 5].mean().item()
     print(f"launch {us:.1f} us = {us / n:.2f} us per layer; wave total {tot:.0f} clocks of s_memtime "
           f"({tot / us:.1f} per us)")
-    names = ["wait for index words", "consume", "request next", "rare paths (row group / layer / fill)"]
+    names = ["wait for index words", "consume", "request next (+ fill request, issue-side row group / layer switch)",
+             "rare paths (sums, consume-side row group / layer switch)"]
     steps = w[..., 4].mean().item()
     for i, nm in enumerate(names):
         v = w[..., i].mean().item()
-        print(f"  {nm:40s} {v:12.0f}  {100 * v / tot:5.1f} %   per step {v / steps:8.1f}   per layer {v / n:9.1f}")
-    ws64 = ws.view(256, 16, 8).cpu()
-    print(f"  of request next: the 4 load instructions themselves {vm:.0f} ({100 * vm / tot:.1f} %, {vm / steps:.0f} per step)")
-    fw = (ws64[..., 6] >> 32).double().mean().item()
-    print(f"  layer switch: leave + next layer's arguments {l0:.0f} ({100 * l0 / tot:.1f} %), wait for its image {l1:.0f} "
-          f"({100 * l1 / tot:.1f} %), plan the fill after it {l2:.0f} ({100 * l2 / tot:.1f} %)")
-    fr = (ws64[..., 7] >> 32).double().mean().item()
-    ff = (ws64[..., 7] & 0xffffffff).double().mean().item()
-    print(f"  of the rare paths: wait for a free sum slot {fw:.0f} ({100 * fw / tot:.1f} %), partial sums + arrival {fr:.0f} "
-          f"({100 * fr / tot:.1f} %), final sum / store {ff:.0f} ({100 * ff / tot:.1f} %)")
+        print(f"  {nm:72s} {v:12.0f}  {100 * v / tot:5.1f} %   per step {v / steps:8.1f}   per layer {v / n:9.1f}")
     print(f"  steps per wave {steps:.1f}; slowest wave total {w[..., 5].max().item():.0f}, fastest {w[..., 5].min().item():.0f}")
 
 

@@ -77,12 +77,13 @@ constexpr uint32_t kCRedOff = kCXsOff + kCWaves * kCXsWave;
 constexpr uint32_t kCRedBOff = kCRedOff + kCSlots * kCWaves * kCOut * 4;
 constexpr uint32_t kCCntOff = kCRedBOff + kCSlots * kCWaves * 4;
 constexpr uint32_t kCTabOff = kCCntOff + 64;         // the launch's layer arguments, 128 B per layer
-constexpr uint32_t kCLdsBytes = kCTabOff + kMaxGroup * 128;
+constexpr uint32_t kCHeadOff = kCTabOff + kMaxGroup * 128;   // {first workgroup, row groups per workgroup, N, G} per layer
+constexpr uint32_t kCLdsBytes = kCHeadOff + kMaxGroup * 16;
 static_assert(kCLdsBytes <= 163840, "LDS");
 constexpr int kCFlagStride = 256;   // DEP: arrival flags per layer (one per workgroup)
 
 // timing-only ablations (results wrong): bit 0 no MFMAs, bit 1 no gathers, bit 2 no x / scale /
-// bias loads, bit 3 no waits for the image hand-over between the waves
+// bias loads, bit 3 no waits for the image hand-over between the waves, bit 4 no index loads
 #ifndef VPTQ_K256C_ABLATE
 #define VPTQ_K256C_ABLATE 0
 #endif
@@ -249,18 +250,37 @@ __global__ __launch_bounds__(kCThreads) void gemv_k256c_kernel(const K256CParams
   // arguments (undefined past the end).
   auto enter_layer = [&](CCursor& c, auto from_lds) __attribute__((always_inline)) -> K256Layer {
     constexpr bool kLds = decltype(from_lds)::value;
-    const int L0 = c.L < n_layers ? c.L : n_layers - 1;
-    K256Layer Ly = kLds ? c_load_layer_lds(L0) : c_load_layer(L0);
-    while (c.L < n_layers) {
-      c.ng = (Ly.N + kCRows - 1) / kCRows;
-      c.ns = (Ly.G + kCSweepCols - 1) / kCSweepCols;
-      int r0 = bid - Ly.wgs;
-      if (r0 < 0) r0 += W;
-      r0 *= Ly.pf_chunk;
-      if (r0 < c.ng) { c.rg = r0; c.re = r0 + Ly.pf_chunk < c.ng ? r0 + Ly.pf_chunk : c.ng; break; }
-      if (++c.L < n_layers) Ly = kLds ? c_load_layer_lds(c.L) : c_load_layer(c.L);
+    if constexpr (kLds) {
+      // the search reads 16 bytes per candidate layer (a whole record is 8 LDS reads + 30 readfirstlane,
+      // and with 64 workgroups per layer a workgroup's next layer is the fourth candidate - for each of
+      // the three cursors); the record of the layer it settles on is loaded once
+      while (c.L < n_layers) {
+        const u32x4 h = lds_load16(kCHeadOff + (uint32_t)__builtin_amdgcn_readfirstlane(c.L) * 16u);
+        const int wgs = __builtin_amdgcn_readfirstlane((int)h[0]), rpw = __builtin_amdgcn_readfirstlane((int)h[1]);
+        const int N = __builtin_amdgcn_readfirstlane((int)h[2]), G = __builtin_amdgcn_readfirstlane((int)h[3]);
+        c.ng = (N + kCRows - 1) / kCRows;
+        c.ns = (G + kCSweepCols - 1) / kCSweepCols;
+        int r0 = bid - wgs;
+        if (r0 < 0) r0 += W;
+        r0 *= rpw;
+        if (r0 < c.ng) { c.rg = r0; c.re = r0 + rpw < c.ng ? r0 + rpw : c.ng; break; }
+        ++c.L;
+      }
+      return c_load_layer_lds(c.L < n_layers ? c.L : n_layers - 1);
+    } else {
+      const int L0 = c.L < n_layers ? c.L : n_layers - 1;
+      K256Layer Ly = c_load_layer(L0);
+      while (c.L < n_layers) {
+        c.ng = (Ly.N + kCRows - 1) / kCRows;
+        c.ns = (Ly.G + kCSweepCols - 1) / kCSweepCols;
+        int r0 = bid - Ly.wgs;
+        if (r0 < 0) r0 += W;
+        r0 *= Ly.pf_chunk;
+        if (r0 < c.ng) { c.rg = r0; c.re = r0 + Ly.pf_chunk < c.ng ? r0 + Ly.pf_chunk : c.ng; break; }
+        if (++c.L < n_layers) Ly = c_load_layer(c.L);
+      }
+      return Ly;
     }
-    return Ly;
   };
   using from_args = std::integral_constant<bool, false>;
   using from_table = std::integral_constant<bool, true>;
@@ -271,7 +291,13 @@ __global__ __launch_bounds__(kCThreads) void gemv_k256c_kernel(const K256CParams
     if (tl < n_layers && tw < 30) {
       const uint32_t* const src = (const uint32_t*)as_global(
           (const char*)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr() + 16 + tl * 120 + tw * 4);
-      *(lds_u32_t*)(uintptr_t)(kCTabOff + (uint32_t)tl * 128u + (uint32_t)tw * 4u) = *src;
+      const uint32_t v = *src;
+      *(lds_u32_t*)(uintptr_t)(kCTabOff + (uint32_t)tl * 128u + (uint32_t)tw * 4u) = v;
+      // header copy: N (dword 22), G (23), first workgroup (26), row groups per workgroup (27)
+      static_assert(offsetof(K256Layer, N) == 88 && offsetof(K256Layer, G) == 92 && offsetof(K256Layer, wgs) == 104 &&
+                    offsetof(K256Layer, pf_chunk) == 108, "K256Layer layout");
+      const int hw = tw == 26 ? 0 : tw == 27 ? 1 : tw == 22 ? 2 : tw == 23 ? 3 : -1;
+      if (hw >= 0) *(lds_u32_t*)(uintptr_t)(kCHeadOff + (uint32_t)tl * 16u + (uint32_t)hw * 4u) = v;
     }
   }
 
@@ -389,7 +415,7 @@ __global__ __launch_bounds__(kCThreads) void gemv_k256c_kernel(const K256CParams
   u32x4 iw[D][kCSub];
   uint32_t xr[D], sr[D], br[D];
   int q_layer[D], q_col2[D];   // DEP: layer and block offset of the sweep in each queue slot
-  constexpr int kLPS = ((VPTQ_K256C_ABLATE & 4) ? 0 : 3) + kCSub;   // vector loads per sweep
+  constexpr int kLPS = ((VPTQ_K256C_ABLATE & 4) ? 0 : 3) + ((VPTQ_K256C_ABLATE & 16) ? 0 : kCSub);   // vector loads per sweep
   auto load_x = [&](auto slot_c, const uint16_t* xp, int max2, int col2) __attribute__((always_inline)) {
     constexpr int S = decltype(slot_c)::value;
     const int want = col2 + 4 * lane;
@@ -412,8 +438,14 @@ __global__ __launch_bounds__(kCThreads) void gemv_k256c_kernel(const K256CParams
       br[S] = *(const uint32_t*)as_global((const char*)Li.wbias + c2);
     }
 #pragma unroll
-    for (int q = 0; q < kCSub; ++q)
-      iw[S][q] = __builtin_nontemporal_load((const u32x4*)as_global((const char*)Li.idx + (i_rowoff[q] + coff)));
+    for (int q = 0; q < kCSub; ++q) {
+      if constexpr ((VPTQ_K256C_ABLATE & 16) != 0) {   // no index loads: what the consume side alone can do
+        iw[S][q] = u32x4{i_rowoff[q] + coff, coff * 2654435761u, i_rowoff[q] ^ 0x5a5a5a5au, coff + 0x01234567u};
+        asm volatile("" : "+v"(iw[S][q]));
+      } else {
+        iw[S][q] = __builtin_nontemporal_load((const u32x4*)as_global((const char*)Li.idx + (i_rowoff[q] + coff)));
+      }
+    }
     if (DEP) { q_layer[S] = ci_end ? -1 : ci.L; q_col2[S] = i_col2; }
     i_col2 += kCSweepCols * 2;
     if (--i_left == 0) issue_next_row_group();
