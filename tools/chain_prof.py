@@ -25,7 +25,7 @@ def main():
     descs = (B.LayerDesc * n)(*[m._descriptor()[1] for m in ring])
     xp = (C.c_void_p * n)(*[x.data_ptr()] * n)
     yp = (C.c_void_p * n)(*[y.data_ptr() for y in ys])
-    ws = torch.zeros(256 * 16 * 8, dtype=torch.int64, device=dev)
+    ws = torch.zeros(256 * 16 * 16, dtype=torch.int64, device=dev)
     for rep in range(3):
         ws.zero_()
         torch.cuda.synchronize()
@@ -35,7 +35,7 @@ def main():
                                               B.current_stream_ptr(dev)), "chain")
         e1.record()
         torch.cuda.synchronize()
-    w = ws.view(256, 16, 8).cpu().double()
+    w = ws.view(256, 16, 16).cpu().double()
     us = e0.elapsed_time(e1) * 1e3
     tot = w[..., 5].mean().item()
     print(f"launch {us:.1f} us = {us / n:.2f} us per layer; wave total {tot:.0f} clocks of s_memtime "
@@ -46,6 +46,12 @@ def main():
     for i, nm in enumerate(names):
         v = w[..., i].mean().item()
         print(f"  {nm:72s} {v:12.0f}  {100 * v / tot:5.1f} %   per step {v / steps:8.1f}   per layer {v / n:9.1f}")
+    sub = ["sums: deposit", "sums: store the previous row group (wave q mod 16)", "sums: store the layer's last row group",
+           "leave layer: free + pending fill", "enter layer: arguments", "enter layer: wait for the image",
+           "enter layer: find the next layer", "issue side: find + load the next layer"]
+    for i, nm in enumerate(sub):
+        v = w[..., 8 + i].mean().item()
+        print(f"    {nm:70s} {v:12.0f}  {100 * v / tot:5.1f} %   per layer {v / n:9.1f}   worst wave {w[..., 8 + i].max().item():9.0f}")
     print(f"  steps per wave {steps:.1f}; slowest wave total {w[..., 5].max().item():.0f}, fastest {w[..., 5].min().item():.0f}")
 
 

@@ -76,9 +76,7 @@ constexpr uint32_t kCXsWave = 256;
 constexpr uint32_t kCRedOff = kCXsOff + kCWaves * kCXsWave;
 constexpr uint32_t kCRedBOff = kCRedOff + kCSlots * kCWaves * kCOut * 4;
 constexpr uint32_t kCCntOff = kCRedBOff + kCSlots * kCWaves * 4;
-constexpr uint32_t kCTabOff = kCCntOff + 64;         // the launch's layer arguments, 128 B per layer
-constexpr uint32_t kCHeadOff = kCTabOff + kMaxGroup * 128;   // {first workgroup, row groups per workgroup, N, G} per layer
-constexpr uint32_t kCLdsBytes = kCHeadOff + kMaxGroup * 16;
+constexpr uint32_t kCLdsBytes = kCCntOff + 64;
 static_assert(kCLdsBytes <= 163840, "LDS");
 constexpr int kCFlagStride = 256;   // DEP: arrival flags per layer (one per workgroup)
 
@@ -101,69 +99,105 @@ constexpr int kCFlagStride = 256;   // DEP: arrival flags per layer (one per wor
 #ifndef VPTQ_K256C_BALANCE
 #define VPTQ_K256C_BALANCE 1
 #endif
+// 1: everything outside the consume phase runs at issue priority 3: those instructions compete with the
+// other waves' MFMAs for the issue port and hold nothing another wave needs (measured: 4.91 -> 4.67 us)
+#ifndef VPTQ_K256C_PRIO
+#define VPTQ_K256C_PRIO 1
+#endif
 
+// One layer of the launch: 88 bytes of kernel arguments (the K256Layer of the other kernels carries
+// fields this one has no use for, and 32 of those + the search table would not fit 4 KiB).
+struct CLayerArgs {
+  const uint32_t* idx;
+  const uint32_t* cent;
+  const uint32_t* rcent;
+  const uint16_t* x;
+  uint16_t* y;
+  const uint16_t* scale;
+  const uint16_t* wbias;
+  const uint16_t* bias;
+  int N, G, O, row_words;
+  int wgs;   // workgroup that owns block 0 of the layer
+  int rpw;   // row groups per block
+};
+constexpr int kCHeadPad = 4;   // the layer search reads 4 headers at a time
 struct K256CParams {
   int n_layers;
   int tokens;        // token count | kOutF32Bit
   uint32_t* sync;    // DEP: kCFlagStride arrival flags per layer (zeroed before the launch)
-  K256Layer layer[kMaxGroup];
+  CLayerArgs layer[kMaxGroup];
+  // what the search for a workgroup's next layer needs, 8 bytes per layer:
+  // {first workgroup | row groups per block << 16, row groups | sweeps per row group << 24}
+  uint32_t head[kMaxGroup + kCHeadPad][2];
 };
+static_assert(sizeof(CLayerArgs) == 88 && offsetof(K256CParams, layer) == 16 &&
+              offsetof(K256CParams, head) == 16 + kMaxGroup * 88 && sizeof(K256CParams) <= 4096, "kernarg layout");
 
 typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
+typedef const char __attribute__((address_space(4)))* kernarg_ptr_t;
 
-// layer L of the kernel arguments in one batch of scalar loads (see k256.h:load_layer_args) ...
-static __device__ __forceinline__ K256Layer c_load_layer(int L) {
-  static_assert(sizeof(K256Layer) == 120 && offsetof(K256CParams, layer) == 16, "kernarg layout");
+// Layer L of the kernel arguments in one batch of scalar loads.  Everything a wave looks up on its
+// way through the stream comes out of the kernel-argument segment through the scalar cache: the
+// LDS is the busiest unit of this kernel (a read issued behind 16 waves' gathers comes back late),
+// and indexing the by-value argument struct with a run-time index makes the compiler copy it to
+// scratch memory.
+static __device__ __forceinline__ CLayerArgs c_load_layer(int L) {
   typedef int i16_t __attribute__((ext_vector_type(16)));
-  typedef int i8_t __attribute__((ext_vector_type(8)));
   typedef int i4_t __attribute__((ext_vector_type(4)));
   typedef int i2_t __attribute__((ext_vector_type(2)));
   L = __builtin_amdgcn_readfirstlane(L);   // (wave-uniform by construction; the compiler cannot always prove it)
-  const char __attribute__((address_space(4)))* lp =
-      (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + 16 +
-      (size_t)L * sizeof(K256Layer);
-  i16_t a; i8_t b; i4_t c; i2_t d;
+  const kernarg_ptr_t lp = (kernarg_ptr_t)__builtin_amdgcn_kernarg_segment_ptr() + 16 + (size_t)L * sizeof(CLayerArgs);
+  i16_t a; i4_t b; i2_t c;
 #if defined(__HIP_DEVICE_COMPILE__)
   asm volatile(
-      "s_load_dwordx16 %0, %4, 0x0\n\t"
-      "s_load_dwordx8 %1, %4, 0x40\n\t"
-      "s_load_dwordx4 %2, %4, 0x60\n\t"
-      "s_load_dwordx2 %3, %4, 0x70\n\t"
+      "s_load_dwordx16 %0, %3, 0x0\n\t"
+      "s_load_dwordx4 %1, %3, 0x40\n\t"
+      "s_load_dwordx2 %2, %3, 0x50\n\t"
       "s_waitcnt lgkmcnt(0)"
-      : "=&s"(a), "=&s"(b), "=&s"(c), "=&s"(d)
+      : "=&s"(a), "=&s"(b), "=&s"(c)
       : "s"(lp)
       : "memory");
 #else
-  a = i16_t{}; b = i8_t{}; c = i4_t{}; d = i2_t{}; (void)lp;
+  a = i16_t{}; b = i4_t{}; c = i2_t{}; (void)lp;
 #endif
-  K256Layer Ly;
+  CLayerArgs Ly;
   __builtin_memcpy((char*)&Ly, &a, 64);
-  __builtin_memcpy((char*)&Ly + 64, &b, 32);
-  __builtin_memcpy((char*)&Ly + 96, &c, 16);
-  __builtin_memcpy((char*)&Ly + 112, &d, 8);
+  __builtin_memcpy((char*)&Ly + 64, &b, 16);
+  __builtin_memcpy((char*)&Ly + 80, &c, 8);
   Ly.idx = as_global(Ly.idx); Ly.cent = as_global(Ly.cent); Ly.rcent = as_global(Ly.rcent);
   Ly.x = as_global(Ly.x); Ly.y = as_global(Ly.y); Ly.scale = as_global(Ly.scale);
   Ly.wbias = as_global(Ly.wbias); Ly.bias = as_global(Ly.bias);
   return Ly;
 }
-// ... and out of the copy in LDS (kCTabOff; filled once per workgroup): a trip to the
-// kernel-argument segment costs ~0.4 us, and a wave looks at several layers per layer it enters
-static __device__ __forceinline__ K256Layer c_load_layer_lds(int L) {
+// the two codebook pointers of layer L
+struct CFillL { const uint32_t* cent; const uint32_t* rcent; };
+static __device__ __forceinline__ CFillL c_load_fill(int L) {
+  typedef int i4_t __attribute__((ext_vector_type(4)));
   L = __builtin_amdgcn_readfirstlane(L);
-  const uint32_t a = kCTabOff + (uint32_t)L * 128u;
-  uint32_t w[32];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const u32x4 v = lds_load16(a + 16u * i);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) w[4 * i + j] = (uint32_t)__builtin_amdgcn_readfirstlane((int)v[j]);
-  }
-  K256Layer Ly;
-  __builtin_memcpy((char*)&Ly, w, sizeof(K256Layer));
-  Ly.idx = as_global(Ly.idx); Ly.cent = as_global(Ly.cent); Ly.rcent = as_global(Ly.rcent);
-  Ly.x = as_global(Ly.x); Ly.y = as_global(Ly.y); Ly.scale = as_global(Ly.scale);
-  Ly.wbias = as_global(Ly.wbias); Ly.bias = as_global(Ly.bias);
-  return Ly;
+  const kernarg_ptr_t lp = (kernarg_ptr_t)__builtin_amdgcn_kernarg_segment_ptr() + 16 + (size_t)L * sizeof(CLayerArgs);
+  i4_t a;
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_load_dwordx4 %0, %1, 0x8\n\ts_waitcnt lgkmcnt(0)" : "=&s"(a) : "s"(lp) : "memory");
+#else
+  a = i4_t{}; (void)lp;
+#endif
+  CFillL F;
+  __builtin_memcpy((char*)&F, &a, 16);
+  F.cent = as_global(F.cent); F.rcent = as_global(F.rcent);
+  return F;
+}
+// search headers of layers L .. L + 3 (the table is padded with kCHeadPad empty layers)
+typedef int c_head4_t __attribute__((ext_vector_type(8)));
+static __device__ __forceinline__ c_head4_t c_load_heads(int L) {
+  L = __builtin_amdgcn_readfirstlane(L);
+  const kernarg_ptr_t hp = (kernarg_ptr_t)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(K256CParams, head) + (size_t)L * 8;
+  c_head4_t h;
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(h) : "s"(hp) : "memory");
+#else
+  h = c_head4_t{}; (void)hp;
+#endif
+  return h;
 }
 
 // position in the workgroup's flat stream; everything is wave-uniform
@@ -177,11 +211,10 @@ struct CCursor {
 // the fields of a layer each side needs (the rest of a K256Layer dies right after the load)
 struct CIssueL { const uint32_t* idx; const uint16_t* x; const uint16_t* scale; const uint16_t* wbias; int N, G, row_words; };
 struct CConsL { uint16_t* y; const uint16_t* bias; int N, G, O; };
-struct CFillL { const uint32_t* cent; const uint32_t* rcent; };
-static __device__ __forceinline__ CIssueL c_issue_of(const K256Layer& L) {
+static __device__ __forceinline__ CIssueL c_issue_of(const CLayerArgs& L) {
   return CIssueL{L.idx, L.x, L.scale, L.wbias, L.N, L.G, L.row_words};
 }
-static __device__ __forceinline__ CConsL c_cons_of(const K256Layer& L) { return CConsL{L.y, L.bias, L.N, L.G, L.O}; }
+static __device__ __forceinline__ CConsL c_cons_of(const CLayerArgs& L) { return CConsL{L.y, L.bias, L.N, L.G, L.O}; }
 
 // f(slot 0), f(slot 1), ... f(slot kCDepth - 1) with the slot as a compile-time constant
 template <typename F>
@@ -243,63 +276,49 @@ __global__ __launch_bounds__(kCThreads) void gemv_k256c_kernel(const K256CParams
   uint32_t* const dep_seen = free_cnt + 4;                  // DEP: last layer whose producers wave 0 has seen arrive
 
   // ---- the flat stream ----
-  // first layer >= c.L in which this workgroup owns row groups: a block of K256Layer::pf_chunk
-  // consecutive ones, block number (bid - first workgroup of the layer) mod W (K256Layer::wgs = the
-  // running total of blocks mod W: the layers continue each other's round robin, so that layers
-  // that need fewer than W blocks run side by side on different workgroups).  Returns that layer's
-  // arguments (undefined past the end).
-  auto enter_layer = [&](CCursor& c, auto from_lds) __attribute__((always_inline)) -> K256Layer {
-    constexpr bool kLds = decltype(from_lds)::value;
-    if constexpr (kLds) {
-      // the search reads 16 bytes per candidate layer (a whole record is 8 LDS reads + 30 readfirstlane,
-      // and with 64 workgroups per layer a workgroup's next layer is the fourth candidate - for each of
-      // the three cursors); the record of the layer it settles on is loaded once
-      while (c.L < n_layers) {
-        const u32x4 h = lds_load16(kCHeadOff + (uint32_t)__builtin_amdgcn_readfirstlane(c.L) * 16u);
-        const int wgs = __builtin_amdgcn_readfirstlane((int)h[0]), rpw = __builtin_amdgcn_readfirstlane((int)h[1]);
-        const int N = __builtin_amdgcn_readfirstlane((int)h[2]), G = __builtin_amdgcn_readfirstlane((int)h[3]);
-        c.ng = (N + kCRows - 1) / kCRows;
-        c.ns = (G + kCSweepCols - 1) / kCSweepCols;
+  // first layer >= c.L in which this workgroup owns row groups: a block of `rpw` consecutive ones,
+  // block number (bid - first workgroup of the layer) mod W (CLayerArgs::wgs = the running total of
+  // blocks mod W: the layers continue each other's round robin, so that layers that need fewer than
+  // W blocks run side by side on different workgroups).  With 64 workgroups per layer a workgroup's
+  // next layer is the fourth candidate: four 8-byte headers per scalar load.
+  auto enter_layer = [&](CCursor& c) __attribute__((always_inline)) {
+    while (c.L < n_layers) {
+      const c_head4_t h = c_load_heads(c.L);
+      bool found = false;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (found) continue;
+        const uint32_t h0 = (uint32_t)h[2 * k], h1 = (uint32_t)h[2 * k + 1];
+        const int wgs = (int)(h0 & 0xffffu), rpw = (int)(h0 >> 16);
+        const int ng = (int)(h1 & 0xffffffu), ns = (int)(h1 >> 24);   // (padding: ng = 0)
         int r0 = bid - wgs;
         if (r0 < 0) r0 += W;
         r0 *= rpw;
-        if (r0 < c.ng) { c.rg = r0; c.re = r0 + rpw < c.ng ? r0 + rpw : c.ng; break; }
-        ++c.L;
+        if (r0 < ng) {
+          found = true;
+          c.L += k; c.ng = ng; c.ns = ns; c.rg = r0; c.re = r0 + rpw < ng ? r0 + rpw : ng;
+        }
       }
-      return c_load_layer_lds(c.L < n_layers ? c.L : n_layers - 1);
-    } else {
-      const int L0 = c.L < n_layers ? c.L : n_layers - 1;
-      K256Layer Ly = c_load_layer(L0);
-      while (c.L < n_layers) {
-        c.ng = (Ly.N + kCRows - 1) / kCRows;
-        c.ns = (Ly.G + kCSweepCols - 1) / kCSweepCols;
-        int r0 = bid - Ly.wgs;
-        if (r0 < 0) r0 += W;
-        r0 *= Ly.pf_chunk;
-        if (r0 < c.ng) { c.rg = r0; c.re = r0 + Ly.pf_chunk < c.ng ? r0 + Ly.pf_chunk : c.ng; break; }
-        if (++c.L < n_layers) Ly = c_load_layer(c.L);
-      }
-      return Ly;
+      if (found) break;
+      c.L += 4;
     }
+    if (c.L > n_layers) c.L = n_layers;
   };
-  using from_args = std::integral_constant<bool, false>;
-  using from_table = std::integral_constant<bool, true>;
-  // the layer table into LDS: one dword per thread (kMaxGroup x 30 <= 1024)
-  {
-    static_assert(kMaxGroup * 30 <= kCThreads, "one dword of the layer table per thread");
-    const int tl = tid >> 5, tw = tid & 31;
-    if (tl < n_layers && tw < 30) {
-      const uint32_t* const src = (const uint32_t*)as_global(
-          (const char*)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr() + 16 + tl * 120 + tw * 4);
-      const uint32_t v = *src;
-      *(lds_u32_t*)(uintptr_t)(kCTabOff + (uint32_t)tl * 128u + (uint32_t)tw * 4u) = v;
-      // header copy: N (dword 22), G (23), first workgroup (26), row groups per workgroup (27)
-      static_assert(offsetof(K256Layer, N) == 88 && offsetof(K256Layer, G) == 92 && offsetof(K256Layer, wgs) == 104 &&
-                    offsetof(K256Layer, pf_chunk) == 108, "K256Layer layout");
-      const int hw = tw == 26 ? 0 : tw == 27 ? 1 : tw == 22 ? 2 : tw == 23 ? 3 : -1;
-      if (hw >= 0) *(lds_u32_t*)(uintptr_t)(kCHeadOff + (uint32_t)tl * 16u + (uint32_t)hw * 4u) = v;
-    }
-  }
+
+#if VPTQ_K256C_PROF
+  unsigned long long pf_wait = 0, pf_cons = 0, pf_issue = 0, pf_cold = 0, pf_steps = 0, pf_t0 = 0, pf_last = 0;
+  unsigned long long pf_x[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  auto now = [&](uint32_t dep) -> unsigned long long {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : "v"(dep) : "memory");
+    return t;
+  };
+#define PF_START() (pf_last = now(0))
+#define PF_MARK(i) do { const unsigned long long t_ = now(0); pf_x[i] += t_ - pf_last; pf_last = t_; } while (0)
+#else
+#define PF_START() ((void)0)
+#define PF_MARK(i) ((void)0)
+#endif
 
   // Issue side (D sweeps ahead of the consume side): cursor + incremental state, so that a step
   // costs a handful of instructions and everything rare sits behind ONE branch.
@@ -307,19 +326,17 @@ __global__ __launch_bounds__(kCThreads) void gemv_k256c_kernel(const K256CParams
   bool ci_end = false;         // the stream has ended: the last row group is re-requested (harmless
                                // re-reads keep every step's set of loads the same)
   CIssueL Li;
-  {
-    const K256Layer L0 = enter_layer(ci, from_args{});
-    if (ci.L >= n_layers) return;     // (whole workgroup: nothing to do)
-    Li = c_issue_of(L0);
-  }
-  CCursor cc = ci;             // row group being consumed
   CConsL Lc;
   CFillL Lf;
   {
-    const K256Layer L0 = c_load_layer(cc.L);
+    enter_layer(ci);
+    if (ci.L >= n_layers) return;     // (whole workgroup: nothing to do)
+    const CLayerArgs L0 = c_load_layer(ci.L);
+    Li = c_issue_of(L0);
     Lc = c_cons_of(L0);
     Lf = CFillL{L0.cent, L0.rcent};
   }
+  CCursor cc = ci;             // row group being consumed
   const uint32_t lane_chunk2 = ((uint32_t)lane >> 2) * 16u;   // byte offset of this lane's 8 index elements in a block
   uint32_t i_rowoff[kCSub];   // per lane: byte offset of its vector-row (subgroup q) in the layer's index tensor
   int i_col2 = 0;             // byte offset (2 x column) of the wave's block in the sweep to request
@@ -344,10 +361,12 @@ __global__ __launch_bounds__(kCThreads) void gemv_k256c_kernel(const K256CParams
       CCursor n = ci;
       n.rg += 1;
       if (n.rg >= n.re) {
+        PF_START();
         ++n.L;
-        const K256Layer Ln = enter_layer(n, from_table{});
-        if (n.L < n_layers) { ci = n; Li = c_issue_of(Ln); }
+        enter_layer(n);
+        if (n.L < n_layers) { ci = n; Li = c_issue_of(c_load_layer(n.L)); }
         else ci_end = true;
+        PF_MARK(7);
       } else {
         ci = n;
       }
@@ -356,7 +375,7 @@ __global__ __launch_bounds__(kCThreads) void gemv_k256c_kernel(const K256CParams
   };
 
   if (tid < 16) slot_cnt[tid] = 0u;
-  __syncthreads();   // the only barrier: counters zeroed and the layer table in LDS before anybody uses them
+  __syncthreads();   // the only barrier: counters zeroed before anybody uses them
 
   // ---- image fill by LDS-DMA: wave w brings rows 16 w .. 16 w + 15 (4 instructions of 4 rows;
   // lane l = unit l & 15 of row l >> 4: 16 bytes of entry (row) of table (unit >> 3)).  Invisible
@@ -402,14 +421,6 @@ __global__ __launch_bounds__(kCThreads) void gemv_k256c_kernel(const K256CParams
     lds_acquire();
   };
 
-#if VPTQ_K256C_PROF
-  unsigned long long pf_wait = 0, pf_cons = 0, pf_issue = 0, pf_cold = 0, pf_steps = 0, pf_t0 = 0;
-  auto now = [&](uint32_t dep) -> unsigned long long {
-    unsigned long long t;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : "v"(dep) : "memory");
-    return t;
-  };
-#endif
 
   // ---- loads of one sweep
   u32x4 iw[D][kCSub];
@@ -485,60 +496,41 @@ __global__ __launch_bounds__(kCThreads) void gemv_k256c_kernel(const K256CParams
   auto plan_fill = [&]() __attribute__((always_inline)) {
     cf = cc;
     cf.L = cc.L + 1;
-    const K256Layer Ln = enter_layer(cf, from_table{});
-    Lf = CFillL{Ln.cent, Ln.rcent};
+    enter_layer(cf);
     fill_pending = cf.L < n_layers;
+    if (fill_pending) Lf = c_load_fill(cf.L);
+  };
+
+  // ---- counters, looked at without waiting: lane i of `pre` = counter word i (slot_cnt 0-3,
+  // slot_done 4-7, free_cnt 8-9, ready_cnt 10-11), read at the START of every step - the value is
+  // there when the sweep has been consumed.  A read issued where its value is needed sits behind the
+  // gathers of 16 waves; counters only grow, so an old value can only err towards "not yet" (then
+  // the wave polls, or, for the fill, looks again one step later).
+  uint32_t pre = 0;
+  auto peek_counters = [&]() __attribute__((always_inline)) {
+    pre = __hip_atomic_load((uint32_t*)(smem + kCCntOff) + (lane & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+  auto peeked = [&](uint32_t word) __attribute__((always_inline)) -> uint32_t {
+    return (uint32_t)__builtin_amdgcn_readlane((int)pre, (int)word);
   };
 
   // reduce over the 16 waves and store.  Per subgroup lane (blk, j) holds 8 partial outputs of
   // vector-row j for its column chunk: sum over the 16 chunks of the wave - lane bits 5 and 4 by
   // swap-and-add (halving the values carried), bits 3 and 2 by DPP row rotations.  Across the waves
-  // through LDS slots + arrival counters instead of a barrier (gemv_k256m.hip): the wave that
-  // arrives last sums and stores.
-  auto finish = [&]() __attribute__((always_inline)) {
-    const int rg = cc.rg;
-    const uint32_t slot = q_done % (uint32_t)kCSlots;
-    if (q_done >= (uint32_t)kCSlots) lds_wait_ge(&slot_done[slot], q_done - (uint32_t)kCSlots + 1u);
-    float* const rs = red + (slot * kCWaves + wave) * kCOut;
-#pragma unroll
-    for (int q = 0; q < kCSub; ++q) {
-      float v[8];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { v[i] = acc[q][0][i]; v[4 + i] = acc[q][1][i]; }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 4]), false, false);
-        v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 2]), false, false);
-        v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i) v[i] = row_ror_add<4>(row_ror_add<8>(v[i]));
-      if ((lane & 12) == 0) {   // lane l now holds outputs 4 bit5 + 2 bit4 + {0, 1} of row l & 3
-        const int o8 = ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2;
-        typedef float f32x2 __attribute__((ext_vector_type(2)));
-        *(f32x2*)&rs[q * 32 + (int)jrow * 8 + o8] = f32x2{v[0], v[1]};
-      }
-    }
-    const float sb = wave_sum(accb);
-    if (lane == 0) red_b[slot * kCWaves + wave] = sb;
-    uint32_t arrived = 0;
-    lds_release();
-    if (lane == 0)
-      arrived = __hip_atomic_fetch_add(&slot_cnt[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    arrived = __builtin_amdgcn_readfirstlane(arrived);
-    lds_acquire();
-#if VPTQ_K256C_BALANCE
-    // issue priority for the next row group by arrival order at this one: the early ones yield
-    if (arrived < 4u) __builtin_amdgcn_s_setprio(0);
-    else if (arrived < 8u) __builtin_amdgcn_s_setprio(1);
-    else if (arrived < 12u) __builtin_amdgcn_s_setprio(2);
-    else __builtin_amdgcn_s_setprio(3);
-#endif
-    if (arrived == (uint32_t)kCWaves - 1u) {
+  // through LDS slots + arrival counters instead of a barrier.  Nobody waits for an answer from the
+  // LDS here: a wave deposits its partial sums, counts itself in and goes on; row group q is summed
+  // and stored by wave q mod 16 when it comes back with row group q + 1 (by then the other 15 have
+  // arrived, as a rule), or at once if it was the workgroup's last one of the layer.
+  bool fin_pending = false;    // this wave still has to sum and store row group fin_rg (slot fin_slot)
+  int fin_rg = 0;
+  uint32_t fin_slot = 0, fin_q = 0;
+  int bal = 1;                 // VPTQ_K256C_PRIO: issue priority of this wave's consume phase
+  uint32_t arrived_v = 0;      // lane 0: this wave's arrival number at its last row group (in flight until looked at)
+  auto finalize = [&]() __attribute__((always_inline)) {
+    const uint32_t slot = fin_slot;
+    lds_wait_ge(&slot_cnt[slot], (uint32_t)kCWaves);
+    const int rg = fin_rg;
+    {
       const int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
       const float* const pr = red + slot * (kCWaves * kCOut);
       float sum;
@@ -579,10 +571,11 @@ __global__ __launch_bounds__(kCThreads) void gemv_k256c_kernel(const K256CParams
       if (DEP) {
         // the write-through stores of this wave have reached memory (every storing wave drains)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (cc.rg + 1 == cc.re) {
-          // this workgroup's part of the layer is stored: raise its flag (device scope).  The
-          // finalising waves of a workgroup's row groups are ordered through slot_done, so all
-          // earlier row groups' stores were drained before this point.  No release fence: an
+        if (rg + 1 == cc.re) {
+          // this workgroup's part of the layer is stored: raise its flag (device scope).  The wave
+          // that stores the last row group waits for all 16 waves' partial sums of it, and a wave
+          // deposits those only after it has stored (and drained) the row group it was in charge
+          // of: all earlier row groups' stores were drained before this point.  No release fence: an
           // agent-scope release writes the L2 back (buffer_wbl2, ~1.3 us, serialised per XCD:
           // 41 us per layer for 256 workgroups); one flag word per workgroup instead of a counter:
           // 256 atomic increments of one word are serialised at the memory side (53 us per layer).
@@ -593,10 +586,67 @@ __global__ __launch_bounds__(kCThreads) void gemv_k256c_kernel(const K256CParams
       if (lane == 0) {
         slot_cnt[slot] = 0u;
         lds_release();
-        __hip_atomic_store(&slot_done[slot], q_done + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_store(&slot_done[slot], fin_q + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
     }
+    fin_pending = false;
+  };
+  auto finish = [&]() __attribute__((always_inline)) {
+    PF_START();
+    if (fin_pending) finalize();   // the previous row group (same layer: a layer's last one is not left pending)
+    PF_MARK(1);
+    const uint32_t slot = q_done % (uint32_t)kCSlots;
+    if (q_done >= (uint32_t)kCSlots) {   // the slot's previous row group has been stored
+      const uint32_t need = q_done - (uint32_t)kCSlots + 1u;
+      if (peeked(kCSlots + slot) < need) lds_wait_ge(&slot_done[slot], need);
+    }
+    float* const rs = red + (slot * kCWaves + wave) * kCOut;
+#pragma unroll
+    for (int q = 0; q < kCSub; ++q) {
+      float v[8];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { v[i] = acc[q][0][i]; v[4 + i] = acc[q][1][i]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 4]), false, false);
+        v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 2]), false, false);
+        v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) v[i] = row_ror_add<4>(row_ror_add<8>(v[i]));
+      if ((lane & 12) == 0) {   // lane l now holds outputs 4 bit5 + 2 bit4 + {0, 1} of row l & 3
+        const int o8 = ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2;
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        *(f32x2*)&rs[q * 32 + (int)jrow * 8 + o8] = f32x2{v[0], v[1]};
+      }
+    }
+    const float sb = wave_sum(accb);
+    if (lane == 0) red_b[slot * kCWaves + wave] = sb;
+#if VPTQ_K256C_BALANCE
+    // issue priority for the next row group by arrival order at the PREVIOUS one (its number has
+    // come back by now): the early ones yield
+    const uint32_t before = (uint32_t)__builtin_amdgcn_readfirstlane((int)arrived_v);
+#if VPTQ_K256C_PRIO
+    bal = before < 5u ? 0 : before < 11u ? 1 : 2;
+#else
+    if (before < 4u) __builtin_amdgcn_s_setprio(0);
+    else if (before < 8u) __builtin_amdgcn_s_setprio(1);
+    else if (before < 12u) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(3);
+#endif
+#endif
+    lds_release();
+    if (lane == 0)
+      arrived_v = __hip_atomic_fetch_add(&slot_cnt[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if ((q_done % (uint32_t)kCWaves) == (uint32_t)wave) {
+      fin_pending = true; fin_rg = cc.rg; fin_slot = slot; fin_q = q_done;
+    }
     ++q_done;
+    PF_MARK(0);
   };
 
   // ---- one sweep of this wave: 8 columns x kCSub vector-rows per lane.  A unit = one index: 2 perms
@@ -666,10 +716,8 @@ __global__ __launch_bounds__(kCThreads) void gemv_k256c_kernel(const K256CParams
     if (wave == 0) {
       // the workgroups that own a block of layer L - 1: 0 .. blocks - 1 (every layer of a dependent
       // chain starts at workgroup 0); lane i looks at the flags of workgroups 4i .. 4i + 3
-      // (out of the table in LDS: indexing the by-value kernel argument P.layer[] with a run-time
-      // index makes the compiler copy the whole array to scratch memory)
-      const K256Layer Lp = c_load_layer_lds(L - 1);
-      const int ng = (Lp.N + kCRows - 1) / kCRows, rpw = Lp.pf_chunk;
+      const c_head4_t hp = c_load_heads(L - 1);
+      const int ng = (int)((uint32_t)hp[1] & 0xffffffu), rpw = (int)((uint32_t)hp[0] >> 16);
       const int blocks = (ng + rpw - 1) / rpw;
       const uint32_t* const fl = sync + (size_t)(L - 1) * kCFlagStride + 4 * lane;
       for (int it = 0; VPTQ_K256C_SPIN_LIMIT == 0 || it < (VPTQ_K256C_SPIN_LIMIT ? VPTQ_K256C_SPIN_LIMIT : 1); ++it) {
@@ -688,7 +736,7 @@ __global__ __launch_bounds__(kCThreads) void gemv_k256c_kernel(const K256CParams
     } else {
       lds_wait_ge(dep_seen, (uint32_t)L);
     }
-    const K256Layer Lx = c_load_layer_lds(L);
+    const CLayerArgs Lx = c_load_layer(L);
     const uint16_t* const xp = Lx.x;
     const int max2 = (Lx.G - 2) * 2;
     auto reload = [&](auto slot_c) __attribute__((always_inline)) {
@@ -724,7 +772,8 @@ __global__ __launch_bounds__(kCThreads) void gemv_k256c_kernel(const K256CParams
   auto fill_events_before_issue = [&]() __attribute__((always_inline)) {
     const uint32_t nb = (use + 1u) & 1u;
     const uint32_t need = (uint32_t)kCWaves * ((use + 1u) >> 1);
-    if (__hip_atomic_load(&free_cnt[nb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= need) {
+    if (peeked(2 * kCSlots + nb) >= need) {
+      lds_acquire();
       fill_image(Lf, nb);
       fill_pending = false;
       land_steps = D;
@@ -743,6 +792,8 @@ __global__ __launch_bounds__(kCThreads) void gemv_k256c_kernel(const K256CParams
     c_col = wave * kCBlockCols;
     c_left = cc.ns;
     if (cc.rg + 1 < cc.re) { cc.rg += 1; return; }
+    if (fin_pending) finalize();   // (the layer's arguments are about to change; DEP: its flag is due)
+    PF_MARK(2);
     // leaving the layer: its image buffer is free once every wave has said so
     lds_inc(&free_cnt[use & 1u]);
     if (cf.L >= n_layers) {
@@ -767,15 +818,23 @@ __global__ __launch_bounds__(kCThreads) void gemv_k256c_kernel(const K256CParams
       lds_inc(&ready_cnt[nb]);
       land_steps = 0;
     }
+    PF_MARK(3);
     ++use;
     baseA ^= 0x10000u;
     baseB ^= 0x10000u;
     cc = cf;
-    Lc = c_cons_of(c_load_layer_lds(cc.L));
+    Lc = c_cons_of(c_load_layer(cc.L));
     c_left = cc.ns;
+    PF_MARK(4);
     if (DEP) dep_enter(cc.L);
-    lds_wait_ge(&ready_cnt[nb], (uint32_t)kCWaves * ((use >> 1) + 1u));
+    {
+      const uint32_t need = (uint32_t)kCWaves * ((use >> 1) + 1u);
+      if (peeked(2 * kCSlots + 2 + nb) < need) lds_wait_ge(&ready_cnt[nb], need);
+      else lds_acquire();
+    }
+    PF_MARK(5);
     plan_fill();
+    PF_MARK(6);
   };
 
 #if VPTQ_K256C_PROF
@@ -784,6 +843,8 @@ __global__ __launch_bounds__(kCThreads) void gemv_k256c_kernel(const K256CParams
   // ---- main loop: one step = wait for sweep k, consume it, request sweep k + D into its queue slot
   auto step = [&](auto slot_c) __attribute__((always_inline)) {
     __builtin_amdgcn_sched_barrier(0);
+    peek_counters();
+    __builtin_amdgcn_sched_barrier(0);
 #if VPTQ_K256C_PROF
     constexpr int SS = decltype(slot_c)::value;
     const unsigned long long ta = now(0);
@@ -791,7 +852,15 @@ __global__ __launch_bounds__(kCThreads) void gemv_k256c_kernel(const K256CParams
     const unsigned long long tb = now(iw[SS][0][0]);
     pf_wait += tb - ta;
 #endif
+#if VPTQ_K256C_PRIO
+    if (bal == 0) __builtin_amdgcn_s_setprio(0);
+    else if (bal == 1) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(2);
+#endif
     consume(slot_c);
+#if VPTQ_K256C_PRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
     __builtin_amdgcn_sched_barrier(0);
 #if VPTQ_K256C_PROF
     const unsigned long long tc = now(__float_as_uint(acc[0][0][0] + acc[0][1][0]));
@@ -818,7 +887,9 @@ __global__ __launch_bounds__(kCThreads) void gemv_k256c_kernel(const K256CParams
   } while (!done);
 #if VPTQ_K256C_PROF
   if (!DEP && sync && lane == 0) {
-    unsigned long long* o = (unsigned long long*)sync + ((size_t)bid * kCWaves + wave) * 8;
+    unsigned long long* o = (unsigned long long*)sync + ((size_t)bid * kCWaves + wave) * 16;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[8 + i] = pf_x[i];
     o[0] = pf_wait; o[1] = pf_cons; o[2] = pf_issue; o[3] = pf_cold; o[4] = pf_steps; o[5] = now(0) - pf_t0;
   }
 #endif
@@ -827,7 +898,8 @@ __global__ __launch_bounds__(kCThreads) void gemv_k256c_kernel(const K256CParams
 // ---- host side -------------------------------------------------------------------
 bool gemv_k256c_eligible(const VptqLayerDesc& d, int tokens) {
   return tokens == 1 && d.perm == nullptr && gemv_k256_eligible(d, 1) &&
-         (((uintptr_t)d.centroids | (uintptr_t)d.res_centroids) & 15) == 0;
+         (((uintptr_t)d.centroids | (uintptr_t)d.res_centroids) & 15) == 0 &&
+         d.num_indices <= 0xffffff && d.group_size <= 0xff * kCSweepCols;   // (the search header's fields)
 }
 
 // Row groups are dealt to the workgroups in blocks of consecutive ones, `rpw` per workgroup and
@@ -920,9 +992,10 @@ hipError_t launch_gemv_k256c(const VptqLayerDesc* descs, int n, const void* cons
   P.tokens = 1 | ((flags & VPTQ_GEMV_OUT_F32) ? kOutF32Bit : 0);
   P.sync = sync;
   long long first = 0;   // workgroup that owns block 0 of the layer
+  for (int i = 0; i < kMaxGroup + kCHeadPad; ++i) P.head[i][0] = P.head[i][1] = 0u;
   for (int i = 0; i < n; ++i) {
     const VptqLayerDesc& d = descs[i];
-    K256Layer& Ly = P.layer[i];
+    CLayerArgs& Ly = P.layer[i];
     Ly.idx = (const uint32_t*)d.indices;
     Ly.cent = (const uint32_t*)d.centroids;
     Ly.rcent = (const uint32_t*)d.res_centroids;
@@ -931,20 +1004,19 @@ hipError_t launch_gemv_k256c(const VptqLayerDesc* descs, int n, const void* cons
     Ly.scale = (const uint16_t*)d.weight_scale;
     Ly.wbias = (const uint16_t*)d.weight_bias;
     Ly.bias = (const uint16_t*)d.bias;
-    Ly.perm = nullptr;
-    Ly.pf = nullptr;
-    Ly.pf_bytes = 0;
     Ly.N = d.num_indices;
     Ly.G = d.group_size;
     Ly.O = d.out_features;
     Ly.row_words = d.row_words;
     const int rpw = c_rows_per_wg(d, cus, wide);
+    const int ng = c_groups(d), ns = (d.group_size + kCSweepCols - 1) / kCSweepCols;
+    if (rpw > 0xffff || ng > 0xffffff || ns > 0xff || grid > 0xffff) return hipErrorInvalidValue;
     Ly.wgs = (int)(first % grid);
-    Ly.pf_chunk = rpw;   // (this kernel: row groups per workgroup)
-    Ly.pf_len = 0;
-    Ly.slots = 0;
+    Ly.rpw = rpw;
+    P.head[i][0] = (uint32_t)Ly.wgs | ((uint32_t)rpw << 16);
+    P.head[i][1] = (uint32_t)ng | ((uint32_t)ns << 24);
     // dependent chain: every layer starts at workgroup 0 (all of its row groups wait anyway)
-    first = dependent ? 0 : first + (c_groups(d) + rpw - 1) / rpw;
+    first = dependent ? 0 : first + (ng + rpw - 1) / rpw;
   }
   const bool f16 = descs[0].dtype == VPTQ_DTYPE_F16;
   if (dependent) return f16 ? launch_c<F16, true>(P, grid, st) : launch_c<BF16, true>(P, grid, st);
