@@ -91,7 +91,11 @@ enum {
   VPTQ_GEMV_OUT_F32 = 1 << 5,
   /* vptq_quant_gemv_chain only: layer i + 1 reads what layer i wrote (x[i + 1] aliases y[i]);
    * without it the layers of a chain must be independent of each other (ABI >= 6) */
-  VPTQ_GEMV_CHAIN_DEPENDENT = 1 << 6
+  VPTQ_GEMV_CHAIN_DEPENDENT = 1 << 6,
+  /* take the one-pass batched-decode kernel (gemm_k256t: canonical format, 1-16 tokens per launch,
+   * needs the workspace) wherever it is eligible, not only where it is the fastest (bf16, 5+
+   * tokens): testing / A-B */
+  VPTQ_GEMV_FORCE_BATCHED = 1 << 7
 };
 
 /* most tokens vptq_quant_gemv accepts (fp16 layers of the canonical format; every other layer:
@@ -181,8 +185,12 @@ VPTQ_API const char* vptq_last_error(void);
 /*
  * y[tokens, O] = x[tokens, I] @ W^T + bias, fused dequant, tokens in
  * [1, VPTQ_GEMV_MAX_TOKENS].  x, y dense row-major in desc->dtype.
- * workspace may be NULL (no kernel needs one today; kept for split-K variants);
- * use vptq_quant_gemv_workspace_bytes() to size it.
+ * workspace: optional, never required.  vptq_quant_gemv_workspace_bytes() tells how many bytes
+ * (16-byte aligned, device memory, contents don't matter) let the call take its fastest kernel: for
+ * 2+ tokens of the canonical 256 + 256 format that is gemm_k256t_kernel (up to 16 tokens in ONE pass
+ * over the indices, fp16 and bf16; its pre-pass writes the operand-ordered activations there).
+ * With NULL / fewer bytes the call uses the kernels that need none (same results within the
+ * parity bar).  Launches of one call and calls on one stream may share a workspace.
  */
 VPTQ_API int vptq_quant_gemv(const VptqLayerDesc* desc, const void* x, void* y, int tokens,
                     int flags, void* workspace, size_t workspace_bytes, void* stream);

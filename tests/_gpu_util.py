@@ -75,14 +75,23 @@ def module_desc(m, need_inv_perm=False, prefetch=None):
         prefetch=prefetch)
 
 
-def gemv_abi(m, x, flags=0):
-    """vptq_quant_gemv through the C ABI with explicit flags."""
+def gemv_abi(m, x, flags=0, workspace=True, out_f32=False):
+    """vptq_quant_gemv through the C ABI with explicit flags; workspace=True hands over the scratch buffer
+    vptq_quant_gemv_workspace_bytes asks for (what the kernel-name query assumes), False passes NULL."""
     from vptq_amd import _backend as B
     desc, keep = module_desc(m)
     tokens = x.numel() // x.shape[-1]
-    y = torch.empty(x.shape[:-1] + (m.out_features,), dtype=x.dtype, device=x.device)
-    B.check(B.lib().vptq_quant_gemv(desc, x.data_ptr(), y.data_ptr(), tokens, flags, None, 0,
+    y = torch.empty(x.shape[:-1] + (m.out_features,), dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
+    ws = None
+    if workspace:
+        nb = B.lib().vptq_quant_gemv_workspace_bytes(desc, tokens, flags)
+        if nb:
+            ws = torch.empty(nb, dtype=torch.uint8, device=x.device)
+    B.check(B.lib().vptq_quant_gemv(desc, x.data_ptr(), y.data_ptr(), tokens, flags | (B.GEMV_OUT_F32 if out_f32 else 0),
+                                    None if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel(),
                                     B.current_stream_ptr(x.device)), "vptq_quant_gemv")
+    if ws is not None:
+        torch.cuda.current_stream(x.device).synchronize()   # (the scratch buffer dies with this frame)
     return y
 
 

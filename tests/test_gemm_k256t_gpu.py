@@ -1,0 +1,146 @@
+"""GPU parity of the one-pass batched-decode kernel (gemm_k256t.hip: transposing LDS gathers feeding
+v_mfma_f32_16x16x32 with the TOKEN as the M dimension): 2 ... 16 tokens per launch (17+ = launches of
+16), fp16 and bf16, through the C ABI, against the oracle, the reference's goldens and the library's
+other routes.
+
+Bar as everywhere: max|d| / max|ref| <= 1e-3 (fp16), 8e-3 (bf16)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import vptq_oracle as vo
+from _cases import rel_err, big_names, load_big, load_golden, golden_names, stored_rows
+from _gpu_util import spec_to_module, bits_to_tensor, tensor_to_bits, gemv_abi, kernel_name
+
+pytestmark = pytest.mark.gpu
+TOL = {"f16": 1e-3, "bf16": 8e-3}
+EXACT = 1 << 2
+BATCHED = 1 << 7   # VPTQ_GEMV_FORCE_BATCHED: the kernel under test wherever it is eligible (default: bf16 from 5 tokens)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from vptq_amd import _backend as B
+    B.lib()
+    return torch.device("cuda", 0)
+
+
+def _x(I, dt, dist, seed, tokens):
+    rng = np.random.default_rng(seed)
+    xs = (0.02 + 0.5 * rng.standard_normal((1, tokens, I))) if dist == "ref-test" else rng.standard_normal((1, tokens, I))
+    return vo.from_f32(xs.astype(np.float32), dt)
+
+
+# I, O, kwargs, tokens: partial sweeps (columns no multiple of 2048 / of 128), partial row groups, more row
+# groups than workgroups, permutation, output bias, every kind of token count
+CASES = [
+    (1024, 256, dict(bias=True), 2),
+    (1024, 256, dict(bias=True), 5),
+    (2048, 1032, dict(), 16),
+    (4104, 264, dict(enable_perm=True), 9),
+    (4096, 4096, dict(dist="llm"), 3),
+    (8192, 1024, dict(dist="llm", bias=True), 16),
+    (1024, 12288, dict(dist="llm", bias=True), 7),     # 384 row groups: 2 on some workgroups
+    (512, 8 * 4 * 1100, dict(dist="llm"), 13),         # 1100 row groups: 5 on some
+    (14336, 512, dict(dist="llm"), 6),                 # 7 sweeps
+    (256, 8, dict(), 4),                               # one partial row group, one partial sweep
+    (6152, 40, dict(dist="llm", enable_perm=True, bias=True), 11),
+    (2048, 512, dict(dist="llm"), 17),                 # 16 + 1
+    (2048, 512, dict(dist="llm", bias=True), 40),      # 16 + 16 + 8
+]
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("I,O,kw,tokens", CASES)
+def test_one_pass_batched_decode_vs_oracle(I, O, kw, tokens, dt, dev):
+    kw = dict(kw)
+    dist = kw.pop("dist", "ref-test")
+    L = vo.make_layer(I, O, dist=dist, seed=I + O + tokens, dtype=dt, **kw)
+    x = _x(I, dt, dist, tokens, tokens)
+    m = spec_to_module(L, dev)
+    assert kernel_name(m, tokens, BATCHED) == "gemm_k256t_kernel"
+    assert (kernel_name(m, tokens) == "gemm_k256t_kernel") == (dt == "bf16" and tokens >= 5)
+    default_route = dt == "bf16" and 5 <= tokens <= 32   # (the module switches to dequant + GEMM above vptq_quant_gemv_max_tokens)
+    xt = bits_to_tensor(x, dt, dev).reshape(x.shape)
+    got = gemv_abi(m, xt, BATCHED)
+    torch.cuda.synchronize()
+    gb = tensor_to_bits(got)
+    want = vo.forward(L, x)
+    err = rel_err(gb, want, dt)
+    assert err <= TOL[dt], f"{I}x{O} t{tokens} {dt}: {err:.3e}"
+    # the module's forward: the library's default route (it hands over the scratch buffer) - this kernel, same
+    # bits, where it is the default; another kernel, same results within the bar, elsewhere
+    ym = m(xt)
+    if default_route:
+        assert torch.equal(ym.view(torch.int16), got.view(torch.int16))
+    assert rel_err(tensor_to_bits(ym), want, dt) <= TOL[dt]
+    # every token row against that token alone through the one-token kernels
+    for t in {0, tokens - 1}:
+        one = tensor_to_bits(gemv_abi(m, xt[:, t:t + 1].contiguous(), EXACT))
+        assert rel_err(gb[:, t:t + 1], one, dt) <= TOL[dt]
+    # without a workspace the call is still valid (the kernels that need none), same results within the bar
+    if tokens <= 16 or dt == "f16":   # (bf16 without scratch memory: launches of <= 4 tokens, 16 per call)
+        other = tensor_to_bits(gemv_abi(m, xt, BATCHED, workspace=False))
+        assert rel_err(other, want, dt) <= TOL[dt]
+    # fp32 outputs: one rounding of the same sums
+    y32 = gemv_abi(m, xt, BATCHED, out_f32=True)
+    assert y32.dtype == torch.float32
+    assert torch.equal(y32.to(got.dtype).view(torch.int16), got.view(torch.int16))
+    # determinism
+    assert torch.equal(gemv_abi(m, xt, BATCHED).view(torch.int16), got.view(torch.int16))
+
+
+@pytest.mark.parametrize("name", [n for n in big_names()])
+def test_one_pass_batched_decode_on_reference_goldens_at_baseline_sizes(name, dev):
+    """hidden 4096 / 8192 layers whose y comes from the real reference (tests/golden/gen_golden_big.py):
+    the cases with 2+ tokens (2, 4, 64 and 256 tokens; the latter as launches of 16)."""
+    L, x, y, cfg, _ = load_big(name)
+    if cfg["tokens"] < 2:
+        pytest.skip("one token: the GEMV kernels")
+    dt = cfg["dtype"]
+    m = spec_to_module(L, dev)
+    tokens = cfg["tokens"]
+    xt = bits_to_tensor(x, dt, dev).reshape(x.shape)
+    parts = []
+    for t0 in range(0, tokens, 64):   # (vptq_quant_gemv takes up to 64 tokens per call)
+        n = min(64, tokens - t0)
+        assert kernel_name(m, n, BATCHED) == "gemm_k256t_kernel"
+        parts.append(gemv_abi(m, xt[:, t0:t0 + n].contiguous(), BATCHED))
+    got = stored_rows(tensor_to_bits(torch.cat(parts, dim=1)), cfg)   # (goldens of many tokens store a subset of the rows)
+    err = rel_err(got, y, dt)
+    assert err <= TOL[dt], f"{name}: {err:.3e}"
+
+
+@pytest.mark.parametrize("name", [n for n in golden_names() if n.startswith("canon")])
+def test_one_pass_batched_decode_on_small_reference_goldens(name, dev):
+    L, x, y, cfg, _ = load_golden(name)
+    if cfg["tokens"] < 2:
+        pytest.skip("one token")
+    dt = cfg["dtype"]
+    m = spec_to_module(L, dev)
+    assert kernel_name(m, cfg["tokens"], BATCHED) == "gemm_k256t_kernel"
+    out = tensor_to_bits(gemv_abi(m, bits_to_tensor(x, dt, dev).reshape(x.shape), BATCHED))
+    assert rel_err(out, y, dt) <= TOL[dt]
+
+
+def test_one_pass_batched_decode_in_a_hipgraph(dev):
+    """warm-up allocates the stream's scratch buffer; the captured call uses it on every replay"""
+    L = vo.make_layer(2048, 1024, seed=5, dist="llm", dtype="bf16")
+    m = spec_to_module(L, dev)
+    assert kernel_name(m, 8) == "gemm_k256t_kernel"
+    xs = torch.zeros(1, 8, 2048, dtype=torch.bfloat16, device=dev)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        y0 = m(xs)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            y = m(xs)
+    for rep in range(2):
+        v = _x(2048, "bf16", "llm", 70 + rep, 8)
+        xs.copy_(bits_to_tensor(v, "bf16", dev).reshape(1, 8, 2048))
+        g.replay()
+        torch.cuda.synchronize()
+        assert rel_err(tensor_to_bits(y), vo.forward(L, v), "bf16") <= 8e-3

@@ -97,7 +97,8 @@ def test_kernel_choice_without_gpu():
     name = lambda d, tok, fl=0: lib.vptq_quant_gemv_kernel_name(d, tok, fl)  # noqa: E731
     big, small = _canonical_desc(8192, 8192), _canonical_desc(4096, 4096)
     assert lib.vptq_quant_gemv_max_tokens(big) == 48
-    assert lib.vptq_quant_gemv_max_tokens(_canonical_desc(8192, 8192, dtype=1)) == 16   # bf16: <= 4-token launches
+    bbig = _canonical_desc(8192, 8192, dtype=1)
+    assert lib.vptq_quant_gemv_max_tokens(bbig) == 32   # bf16 (round 3): the one-pass batched-decode kernel
     for tok in (1, 2, 3, 4):
         assert name(big, tok) == b"gemv_k256m_kernel<fast>"
         assert name(small, tok) == (b"gemv_k256_kernel<fast>" if tok <= 2 else b"gemv_k256_kernel")
@@ -108,7 +109,14 @@ def test_kernel_choice_without_gpu():
     assert name(big, 1, B.GEMV_FORCE_GENERIC) == b"gemv_generic_kernel"
     assert name(big, 4) == b"gemv_k256m_kernel<fast>" and name(big, 5) == name(big, 16) == b"gemm_k256_kernel"
     assert name(big, 64) == b"gemm_k256_kernel" and name(big, 65) is None          # launches of 16 tokens
-    assert name(_canonical_desc(8192, 8192, dtype=1), 16) is not None and name(_canonical_desc(8192, 8192, dtype=1), 17) is None
+    # bf16: 2-4 tokens on the GEMV kernels, 5+ in ONE pass (gemm_k256t, launches of 16; wants the workspace
+    # vptq_quant_gemv_workspace_bytes names); fp16 only when forced (its own batched kernel is faster)
+    assert name(bbig, 4) == b"gemv_k256m_kernel<fast>" and name(bbig, 5) == name(bbig, 16) == name(bbig, 64) == b"gemm_k256t_kernel"
+    assert name(bbig, 65) is None and name(bbig, 5, B.GEMV_EXACT) == b"gemv_k256_kernel"
+    assert lib.vptq_quant_gemv_workspace_bytes(bbig, 5, 0) == 64 * 4096 + 256 and lib.vptq_quant_gemv_workspace_bytes(bbig, 4, 0) == 0
+    assert lib.vptq_quant_gemv_workspace_bytes(big, 16, 0) == 0
+    assert name(big, 2, B.GEMV_FORCE_BATCHED) == name(big, 16, B.GEMV_FORCE_BATCHED) == b"gemm_k256t_kernel"
+    assert lib.vptq_quant_gemv_workspace_bytes(big, 2, B.GEMV_FORCE_BATCHED) == 64 * 4096 + 256
     # bf16: folded form in the MFMA kernel from 32 row groups (128 vector-rows) on
     assert name(_canonical_desc(4096, 1024, dtype=1), 1) == b"gemv_k256m_kernel<fast>"
     assert name(_canonical_desc(4096, 512, dtype=1), 1) == b"gemv_k256_kernel"

@@ -29,6 +29,7 @@ GEMV_OUT_F32 = 1 << 5     # y is float32: un-rounded sums (row-parallel partial 
 GEMV_MAX_TOKENS = 64       # most vptq_quant_gemv accepts (any layer: 16); per layer: vptq_quant_gemv_max_tokens
 GEMV_ANY_FORMAT_TOKENS = 8  # the fused GEMV is the faster path for every format up to here
 GEMV_CHAIN_DEPENDENT = 1 << 6  # vptq_quant_gemv_chain: layer i + 1 reads what layer i wrote
+GEMV_FORCE_BATCHED = 1 << 7    # the one-pass batched-decode kernel wherever eligible (tests, A/B)
 GROUP_MAX = 64
 CHAIN_MAX = 1024
 
@@ -143,6 +144,29 @@ def require_device(*tensors: Optional[torch.Tensor]):
         if not t.is_contiguous():
             raise RuntimeError("vptq_amd needs contiguous tensors")
     return dev
+
+
+_GEMV_WS = {}        # (device index, stream handle) -> uint8 tensor
+_GEMV_WS_RETIRED = []   # outgrown buffers stay alive: a captured hipGraph may still point at them
+
+
+def gemv_workspace(dev_index: int, stream_ptr: int, nbytes: int):
+    """(pointer, bytes) of the scratch buffer `vptq_quant_gemv` may use on this (device, stream), or
+    (None, 0).  One buffer per stream: calls on a stream are ordered, so they can share it.  Nothing is
+    allocated while the stream is being captured into a graph (the buffer would belong to the graph's
+    private pool): such a call runs without a workspace, i.e. with the kernels that need none."""
+    if nbytes <= 0:
+        return None, 0
+    key = (dev_index, stream_ptr)
+    t = _GEMV_WS.get(key)
+    if t is None or t.numel() < nbytes:
+        if torch.cuda.is_current_stream_capturing():
+            return None, 0
+        if t is not None:
+            _GEMV_WS_RETIRED.append(t)
+        t = torch.empty(max(int(nbytes), 2 << 20), dtype=torch.uint8, device=torch.device("cuda", dev_index))
+        _GEMV_WS[key] = t
+    return t.data_ptr(), t.numel()
 
 
 def current_stream_ptr(device) -> int:

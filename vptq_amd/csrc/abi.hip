@@ -92,17 +92,17 @@ int vptq_abi_version(void) { return VPTQ_ABI_VERSION; }
 
 const char* vptq_last_error(void) { return g_err; }
 
-size_t vptq_quant_gemv_workspace_bytes(const VptqLayerDesc*, int, int) { return 0; }
-
 int vptq_quant_gemv_max_tokens(const VptqLayerDesc* d) {
   if (validate_layer(d) != VPTQ_OK) return 0;
   if (vptq::gemm_k256_eligible(*d, 16, 0)) return 48;
+  // bf16: 21 us per launch of 16 tokens (gemm_k256t) against ~50 us for dequant + GEMM at 8192^2
+  if (vptq::gemm_k256t_eligible(*d, 16, 0)) return 32;
   return vptq::gemv_k256_eligible(*d, 4) ? VPTQ_GEMV_MAX_TOKENS_ANY : 8;
 }
 
 // ---- which kernel family serves (layer, tokens, flags): ONE decision for vptq_quant_gemv and for
 // vptq_quant_gemv_kernel_name (x = NULL there: the activation pointer is assumed aligned) ----
-enum Route { kRouteNone, kRouteGemmK256, kRouteK256, kRouteGather, kRouteLds, kRouteGatherX, kRouteGeneric };
+enum Route { kRouteNone, kRouteGemmK256T, kRouteGemmK256, kRouteK256, kRouteGather, kRouteLds, kRouteGatherX, kRouteGeneric };
 
 static int batch_min_tokens() {
   static std::atomic<int> v{-1};  // VPTQ_GEMM_MIN_TOKENS: smallest token count that takes the batched-decode kernel
@@ -111,9 +111,32 @@ static int batch_min_tokens() {
   return v;
 }
 
-static Route route_gemv(const VptqLayerDesc& d, int tokens, int flags, const void* x) {
+// Smallest token count that takes the one-pass batched-decode kernel (gemm_k256t.hip).  Measured at 8192^2
+// (profiles/r03/tokens_*): it costs 17 (2-5 tokens) ... 21 us (16 tokens) for either dtype - its pre-pass
+// (4.8 us) and 256 KiB of operand-ordered activations per CU through L2 are what one token's kernel does
+// not have - against 9.4-10.3 us for 2-4 tokens of either dtype, 18 us for 5-16 fp16 tokens (gemm_k256)
+// and 18 (5 tokens) ... 40 us (16) for bf16 as launches of <= 4 tokens: the default route for bf16 from
+// 5 tokens.  VPTQ_GEMMT_MIN_TOKENS_F16 / _BF16 override (tuning), VPTQ_GEMV_FORCE_BATCHED forces.
+static int batch_t_min_tokens(int dtype) {
+  static std::atomic<int> vf{-1}, vb{-1};
+  std::atomic<int>& v = dtype == VPTQ_DTYPE_F16 ? vf : vb;
+  if (v < 0) {
+    const char* ev = getenv(dtype == VPTQ_DTYPE_F16 ? "VPTQ_GEMMT_MIN_TOKENS_F16" : "VPTQ_GEMMT_MIN_TOKENS_BF16");
+    const int w = ev ? atoi(ev) : (dtype == VPTQ_DTYPE_F16 ? VPTQ_GEMV_MAX_TOKENS + 1 : 5);
+    v = w < 1 ? 1 : w;
+  }
+  return v;
+}
+
+// have_ws: the caller's workspace holds vptq_quant_gemv_workspace_bytes (kernel-name queries: assumed)
+static Route route_gemv(const VptqLayerDesc& d, int tokens, int flags, const void* x, bool have_ws) {
   const uintptr_t xa = (uintptr_t)x;   // 0 when unknown
   const bool forced_generic = (flags & VPTQ_GEMV_FORCE_GENERIC) != 0;
+  // canonical format, folded arithmetic: up to 16 tokens in ONE pass over the indices (launches of 16)
+  if (have_ws && !(flags & (VPTQ_GEMV_FORCE_GENERIC | VPTQ_GEMV_FORCE_VALU | VPTQ_GEMV_FORCE_MFMA)) &&
+      ((flags & VPTQ_GEMV_FORCE_BATCHED) || tokens >= batch_t_min_tokens(d.dtype)) &&
+      vptq::gemm_k256t_eligible(d, tokens > 16 ? 16 : tokens, flags) && (xa & 1) == 0)
+    return kRouteGemmK256T;
   // canonical format, fp16, 5-16 tokens: ONE launch of the batched-decode kernel per 16 tokens
   if (!(flags & (VPTQ_GEMV_FORCE_GENERIC | VPTQ_GEMV_FORCE_VALU | VPTQ_GEMV_FORCE_MFMA)) &&
       tokens >= batch_min_tokens() && vptq::gemm_k256_eligible(d, tokens > 16 ? 16 : tokens, flags) && (xa & 15) == 0)
@@ -129,9 +152,15 @@ static Route route_gemv(const VptqLayerDesc& d, int tokens, int flags, const voi
   return kRouteGeneric;
 }
 
+size_t vptq_quant_gemv_workspace_bytes(const VptqLayerDesc* d, int tokens, int flags) {
+  if (validate_layer(d) != VPTQ_OK || tokens < 1 || tokens > VPTQ_GEMV_MAX_TOKENS) return 0;
+  return route_gemv(*d, tokens, flags, nullptr, true) == kRouteGemmK256T ? vptq::gemm_k256t_workspace_bytes(*d) : 0;
+}
+
 const char* vptq_quant_gemv_kernel_name(const VptqLayerDesc* d, int tokens, int flags) {
   if (validate_layer(d) != VPTQ_OK || tokens < 1 || tokens > VPTQ_GEMV_MAX_TOKENS) return nullptr;
-  switch (route_gemv(*d, tokens, flags, nullptr)) {
+  switch (route_gemv(*d, tokens, flags, nullptr, true)) {
+    case kRouteGemmK256T: return "gemm_k256t_kernel";
     case kRouteGemmK256: return "gemm_k256_kernel";
     case kRouteK256: return vptq::gemv_k256_name(*d, tokens, flags);
     case kRouteGather: return "gemv_gather_kernel";
@@ -157,10 +186,12 @@ const char* vptq_quant_gemv_grouped_kernel_name(const VptqLayerDesc* descs, int 
 
 int vptq_quant_gemv(const VptqLayerDesc* d, const void* x, void* y, int tokens, int flags,
                     void* workspace, size_t workspace_bytes, void* stream) {
-  (void)workspace; (void)workspace_bytes;
   int rc = validate_layer(d);
   if (rc) return rc;
   if (!x || !y) return fail(VPTQ_E_NULL, "x / y is NULL");
+  // (a workspace is never required: without it the call takes the kernels that need none)
+  const bool have_ws = workspace && (((uintptr_t)workspace) & 15) == 0 &&
+                       workspace_bytes >= vptq::gemm_k256t_workspace_bytes(*d);
   if (tokens < 1 || tokens > VPTQ_GEMV_MAX_TOKENS)
     return fail(VPTQ_E_TOKENS, "tokens %d outside [1, %d]: use vptq_dequant + GEMM", tokens,
                 VPTQ_GEMV_MAX_TOKENS);
@@ -179,7 +210,11 @@ int vptq_quant_gemv(const VptqLayerDesc* d, const void* x, void* y, int tokens, 
     }
     return VPTQ_OK;
   };
-  switch (route_gemv(*d, tokens, flags, x)) {
+  switch (route_gemv(*d, tokens, flags, x, have_ws)) {
+    case kRouteGemmK256T:  // tokens = the M dimension of a 16x16x32 MFMA fed by transposing gathers; folded arithmetic.
+      // (launches of one call share the workspace: they are ordered on the stream)
+      return chunks(16, "gemm_k256t launch", [&](const void* xc, void* yc, int m) {
+        return vptq::launch_gemm_k256t(*d, xc, yc, m, out_f32, workspace, st); });
     case kRouteGemmK256:   // tokens = the M dimension of a 16x16x16 MFMA; reference arithmetic
       return chunks(16, "gemm_k256 launch", [&](const void* xc, void* yc, int m) {
         return vptq::launch_gemm_k256(*d, xc, yc, m, out_f32, st); });

@@ -52,6 +52,12 @@ bool gemv_lds_v2_eligible(const VptqV2Desc& d, int tokens);
 hipError_t launch_gemv_lds_v2(const VptqV2Desc& d, const void* x, void* y, int tokens, bool out_f32,
                               int flags, hipStream_t st);
 
+// gemm_k256t.hip - canonical format, fp16 / bf16, up to 16 tokens in one pass over the indices (transposing
+// gather -> 16x16x32 MFMA with tokens as M; folded arithmetic; needs a workspace for the operand-ordered activations)
+bool gemm_k256t_eligible(const VptqLayerDesc& d, int tokens, int flags);
+size_t gemm_k256t_workspace_bytes(const VptqLayerDesc& d);
+hipError_t launch_gemm_k256t(const VptqLayerDesc& d, const void* x, void* y, int tokens, bool out_f32, void* ws,
+                             hipStream_t st);
 // gemm_k256.hip - canonical format, fp16, up to 16 tokens in one launch (tokens = MFMA M)
 bool gemm_k256_eligible(const VptqLayerDesc& d, int tokens, int flags);
 hipError_t launch_gemm_k256(const VptqLayerDesc& d, const void* x, void* y, int tokens, bool out_f32,

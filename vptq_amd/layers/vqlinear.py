@@ -327,7 +327,8 @@ class VQuantLinear(nn.Module):
             cache = (key, desc, keep, dev, B.lib().vptq_quant_gemv,
                      B.lib().vptq_quant_gemv_max_tokens(desc), VQuantLinear._desc_generation,
                      tensors[1].dtype, dev.index if dev.index is not None else torch.cuda.current_device(),
-                     0 if self._folded_form_is_safe(tensors) else B.GEMV_EXACT)
+                     0 if self._folded_form_is_safe(tensors) else B.GEMV_EXACT,
+                     B.lib().vptq_quant_gemv_workspace_bytes(desc, 16, 0))   # [10]: scratch bytes of the batched-decode kernel
             self.__dict__["_desc_cache"] = cache
         return cache
 
@@ -373,7 +374,7 @@ class VQuantLinear(nn.Module):
             y = group.forward(self, x, tokens)
             if y is not None:
                 return y
-        _, desc, _, dev, fn, _, _, wdtype, dev_index, safe_flags = self._descriptor()
+        _, desc, _, dev, fn, _, _, wdtype, dev_index, safe_flags, ws_bytes = self._descriptor()
         # (the checks of _check_activation against the cached dtype / device: no module attribute look-ups)
         if x.shape[-1] != self.in_features:
             raise RuntimeError(f"x has {x.shape[-1]} features, layer expects {self.in_features}")
@@ -390,11 +391,14 @@ class VQuantLinear(nn.Module):
         # Stream object per call: 4 us of the 15 this function took)
         if torch.cuda.current_device() != dev_index:
             with torch.cuda.device(dev):
-                rc = fn(desc, x.data_ptr(), y.data_ptr(), tokens, ops.quant_gemm_flags() | safe_flags, None, 0,
-                        B.current_stream_ptr(dev))
+                sp = B.current_stream_ptr(dev)
+                ws, wsb = B.gemv_workspace(dev_index, sp, ws_bytes) if tokens > 1 else (None, 0)
+                rc = fn(desc, x.data_ptr(), y.data_ptr(), tokens, ops.quant_gemm_flags() | safe_flags, ws, wsb, sp)
         else:
-            rc = fn(desc, x.data_ptr(), y.data_ptr(), tokens, ops.quant_gemm_flags() | safe_flags, None, 0,
-                    _raw_stream(dev_index))
+            sp = _raw_stream(dev_index)
+            # 2+ tokens of the canonical format: the one-pass batched-decode kernel wants scratch memory
+            ws, wsb = B.gemv_workspace(dev_index, sp, ws_bytes) if tokens > 1 else (None, 0)
+            rc = fn(desc, x.data_ptr(), y.data_ptr(), tokens, ops.quant_gemm_flags() | safe_flags, ws, wsb, sp)
         if rc == -5 and tokens > B.GEMV_ANY_FORMAT_TOKENS:
             # VPTQ_E_TOKENS: the fused path takes this layer's 17+ tokens only under run-time conditions the
             # descriptor cannot promise (16-byte aligned activations, no FORCE_* flag): the dense route

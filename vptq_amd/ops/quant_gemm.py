@@ -177,8 +177,13 @@ def quant_gemm(
     if desc is not None:
         y = torch.empty(x.shape[:-1] + (out_features,), dtype=x.dtype, device=dev)
         with torch.cuda.device(dev):
+            sp = B.current_stream_ptr(dev)
+            ws, wsb = (None, 0)
+            if tokens > 1:   # the one-pass batched-decode kernel of the canonical format wants scratch memory
+                ws, wsb = B.gemv_workspace(dev.index if dev.index is not None else torch.cuda.current_device(), sp,
+                                           B.lib().vptq_quant_gemv_workspace_bytes(desc, tokens, _FLAGS))
             B.check(B.lib().vptq_quant_gemv(desc, x.data_ptr(), y.data_ptr(), tokens, _FLAGS,
-                                            None, 0, B.current_stream_ptr(dev)),
+                                            ws, wsb, sp),
                     "vptq_quant_gemv")
         del keep
         return y

@@ -120,7 +120,7 @@ def forward_partial_f32(layer: VQuantLinear, x: torch.Tensor) -> torch.Tensor:
     # what vptq_quant_gemv takes for THIS layer: 64 tokens for fp16 layers of the canonical format
     # (vptq_quant_gemv_max_tokens answers 48 for them), 16 for every other layer; beyond that the partial
     # sum comes from the dense route: dequant + a matmul that accumulates and stays in fp32
-    limit = B.GEMV_MAX_TOKENS if cache[5] >= 48 else 16
+    limit = B.GEMV_MAX_TOKENS if cache[5] >= 32 else 16
     if tokens > limit:
         W = layer.dequant().float()
         y = torch.matmul(xc.float(), W.t())
@@ -129,9 +129,10 @@ def forward_partial_f32(layer: VQuantLinear, x: torch.Tensor) -> torch.Tensor:
         return y
     y = torch.empty(xc.shape[:-1] + (layer.out_features,), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
+        sp = torch.cuda.current_stream(dev).cuda_stream
+        ws, wsb = B.gemv_workspace(cache[8], sp, cache[10]) if tokens > 1 else (None, 0)
         B.check(fn(desc, xc.data_ptr(), y.data_ptr(), tokens,
-                   ops.quant_gemm_flags() | B.GEMV_OUT_F32, None, 0,
-                   torch.cuda.current_stream(dev).cuda_stream), "vptq_quant_gemv")
+                   ops.quant_gemm_flags() | B.GEMV_OUT_F32 | cache[9], ws, wsb, sp), "vptq_quant_gemv")
     return y
 
 
