@@ -172,9 +172,9 @@ def layer_desc(m):
     return c[1], (m, c[2])
 
 
-def make_ring(H, R, dev, seed, k=256, kr=256):
+def make_ring(H, R, dev, seed, k=256, kr=256, dtype=torch.float16):
     g = torch.Generator(device=dev).manual_seed(seed)
-    return [make_layer(H, H, dev, g, k, kr) for _ in range(R)]
+    return [make_layer(H, H, dev, g, k, kr, dtype=dtype) for _ in range(R)]
 
 
 def layer_spec(layer):
@@ -367,19 +367,18 @@ class Timer:
 
 
 def bench_ring(lib, B, dev, timer, H, mode, flags, steps, warmup, regions, rank=0, world=1, group=4,
-               tokens=1, k=256, kr=256, ring=0, tp_split=None, prefetch=False, chain=32):
+               tokens=1, k=256, kr=256, ring=0, tp_split=None, prefetch=False, chain=32, dtype=torch.float16):
     """One ring measurement; returns (result dict, layers, x, ys).  mode: single | grouped | chain | chain_dep"""
     T = int(np.log2(k)) + (int(np.log2(kr)) if kr > 0 else 0)
     idx_bytes = (H // 8) * (H * T // 32) * 4
     R = ring or max(2, (512 << 20) // idx_bytes)
-    layers = make_ring(H, R, dev, seed=1234 + (0 if tp_split else rank), k=k, kr=kr)
+    layers = make_ring(H, R, dev, seed=1234 + (0 if tp_split else rank), k=k, kr=kr, dtype=dtype)
     if tp_split == "out":
         from vptq_amd.utils.shard import shard_out_features
         layers = [shard_out_features(m, rank, world) for m in layers]
         torch.cuda.empty_cache()
-    x = torch.randn(1, tokens, H, device=dev, dtype=torch.float16,
-                    generator=torch.Generator(device=dev).manual_seed(7))
-    ys = [torch.empty(1, tokens, layers[i].out_features, device=dev, dtype=torch.float16) for i in range(R)]
+    x = torch.randn(1, tokens, H, device=dev, generator=torch.Generator(device=dev).manual_seed(7)).to(dtype)
+    ys = [torch.empty(1, tokens, layers[i].out_features, device=dev, dtype=dtype) for i in range(R)]
     y_full = torch.empty(H, device=dev, dtype=torch.float16) if tp_split == "out" else None
     descs, keeps = [], []
     if prefetch:
@@ -431,11 +430,16 @@ def bench_ring(lib, B, dev, timer, H, mode, flags, steps, warmup, regions, rank=
                 assert rc == 0, lib.vptq_last_error()
     else:
         launches = R
+        # (scratch memory where the library's route for this call wants it: the one-pass batched-decode kernel)
+        gwsb = lib.vptq_quant_gemv_workspace_bytes(descs[0], tokens, flags)
+        gws = torch.empty(max(gwsb, 16), dtype=torch.uint8, device=dev)
+        keeps.append(gws)
 
         def one_pass():
             sp = torch.cuda.current_stream().cuda_stream
             for i in range(R):
-                rc = lib.vptq_quant_gemv(descs[i], x.data_ptr(), ys[i].data_ptr(), tokens, flags, None, 0, sp)
+                rc = lib.vptq_quant_gemv(descs[i], x.data_ptr(), ys[i].data_ptr(), tokens, flags,
+                                         gws.data_ptr() if gwsb else None, gwsb, sp)
                 assert rc == 0, lib.vptq_last_error()
                 if tp_split == "out" and dist is not None:
                     dist.all_gather_into_tensor(y_full, ys[i].view(-1))
@@ -755,6 +759,7 @@ def main():
                         ("exact", dict(H=H, mode="single", flags=B.GEMV_EXACT)),
                         ("grouped_x4", dict(H=H, mode="grouped", flags=0)),
                         ("tokens16", dict(H=H, mode="single", flags=0, tokens=16)),
+                        ("tokens16_bf16", dict(H=H, mode="single", flags=0, tokens=16, dtype=torch.bfloat16)),
                         ("k8192_r256", dict(H=H, mode="single", flags=0, k=8192, kr=256))):
             kw = dict(kw)
             rr, *_ = bench_ring(lib, B, dev, Timer(dev), kw.pop("H"), kw.pop("mode"), kw.pop("flags"), st, wu, rg, **kw)
@@ -770,6 +775,8 @@ def main():
         ex["exact"]["what"] = "VPTQ_GEMV_EXACT: the reference's three roundings per weight (bit-equivalent form)"
         ex["grouped_x4"]["what"] = "4 independent layers per launch (vptq_quant_gemv_grouped), us per LAYER = us_per_launch / 4"
         ex["tokens16"]["what"] = "16 tokens per launch (batched-decode kernel), bytes incl. 16 x and y rows"
+        ex["tokens16_bf16"]["what"] = ("16 bf16 tokens in one pass over the indices (gemm_k256t: transposing gathers -> 16x16x32 MFMA, "
+                                       "tokens = M; + its pre-pass); round 2: 4 launches of 4 tokens, 39 us")
         ex["k8192_r256"]["what"] = "k = 8192 + 256 (T = 21 bits), LDS-resident codebooks"
         tr = bench_tp_row(lib, B, dev, Timer(dev), 0, 1, a.tp_layers, 0, st, wu, rg)
         ex["tp_row_n1"] = {"what": f"Llama-3-70B shaped decoder layers (x{a.tp_layers}, the ring of --gpus N) on ONE GPU "
