@@ -257,6 +257,35 @@ VPTQ_API size_t vptq_quant_gemm_workspace_bytes(const VptqLayerDesc* desc, int t
 VPTQ_API int vptq_quant_gemm(const VptqLayerDesc* desc, const void* x, void* y, int tokens, int flags,
                     void* workspace, size_t workspace_bytes, void* stream);
 
+/*
+ * One token over a LOAD-TIME DERIVED LAYOUT of a large-codebook layer (v = 8, k = 65536, no residual:
+ * "v8-k65536-0"; ABI >= 6).  The reference gathers centroid rows from a 1 MiB codebook through the
+ * caches (csrc/kernels/quant_gemv.cuh:11-186); here every row's elements are bucketed ONCE per layer by
+ * the top 3 bits of their index, so that a workgroup holds its 8192-entry slice of the codebook in LDS:
+ *   elems  : uint32, for slice s = 0..7, for row n = 0..N-1 (N = desc->num_indices): the elements of row
+ *            n whose index >> 13 == s, in column order, padded to a multiple of 64 with the word
+ *            (column = group_size, local = 0); element word = column | (index & 8191) << 16
+ *   blocks : int32 [8][N], 64-element blocks of (s, n);  first : int32 [8][N], index of its first block
+ *            (prefix sum of `blocks` in (s, n) order)
+ *   rows_per_wave : 1 .. 64 consecutive rows per wave (16 waves per workgroup); the layout does not
+ *            depend on it
+ * (vptq_amd/utils/sliced.py builds it with torch.)  It costs 2x the packed indices in device memory on
+ * top of them; the state-dict tensors are untouched.  workspace: vptq_quant_gemv_sliced_workspace_bytes
+ * (8 x N x 8 floats of partial sums).  Folded arithmetic (parity bar, not bit-equivalent);
+ * vptq_sliced_layout_supported() = 1 for layers this path takes (no permutation, group_size <= 14336).
+ */
+typedef struct VptqSlicedLayout {
+  const void* elems;
+  const void* blocks;
+  const void* first;
+  int32_t rows_per_wave;
+  int32_t reserved;
+} VptqSlicedLayout;
+VPTQ_API int vptq_sliced_layout_supported(const VptqLayerDesc* desc);
+VPTQ_API size_t vptq_quant_gemv_sliced_workspace_bytes(const VptqLayerDesc* desc);
+VPTQ_API int vptq_quant_gemv_sliced(const VptqLayerDesc* desc, const VptqSlicedLayout* layout, const void* x,
+                           void* y, int flags, void* workspace, size_t workspace_bytes, void* stream);
+
 /* W[O, I] dense, row-major, desc->dtype: the reference CPU path's bits. */
 VPTQ_API int vptq_dequant(const VptqLayerDesc* desc, void* W, void* stream);
 

@@ -67,7 +67,7 @@ def big_tensors(I, O, v, k, kr, perm, bias, tokens, dtype, dist, seed):
     the same bits in gen_golden_big.py (which feeds them to the real reference) and in the
     tests.  Returns uint16 bit patterns (int32 for the index words)."""
     N = (O + v - 1) // v
-    T = int(np.log2(k)) + int(np.log2(kr))
+    T = int(np.log2(k)) + (int(np.log2(kr)) if kr > 0 else 0)   # (kr <= 0: no residual codebook)
     W = (I * T + 31) // 32
     p = (dict(c=(0.02, 0.5), r=(0.02, 0.5), s=(0.02, 0.5), b=(0.02, 0.5), x=(0.02, 0.5), o=(0.02, 0.5))
          if dist == "ref-test" else
@@ -79,7 +79,8 @@ def big_tensors(I, O, v, k, kr, perm, bias, tokens, dtype, dist, seed):
 
     out = dict(
         indices=lcg_u32_fast(N * W, seed * 16 + 1).view(np.int32).reshape(1, N, W),
-        centroids=vals(k * v, seed * 16 + 2, "c"), res_centroids=vals(kr * v, seed * 16 + 3, "r"),
+        centroids=vals(k * v, seed * 16 + 2, "c"),
+        res_centroids=vals(kr * v, seed * 16 + 3, "r") if kr > 0 else np.zeros(0, dtype=np.uint16),
         weight_scale=vals(I, seed * 16 + 4, "s"), weight_bias=vals(I, seed * 16 + 5, "b"),
         x=vals(tokens * I, seed * 16 + 6, "x"))
     if perm:

@@ -35,6 +35,9 @@ FMT_CASES = [
     ("t1_v10_k4096_r256", 1024, 1000, 10, 4096, 256, False, True, "f16", 1, "ref-test"),
     ("t2_v2_k256_r16_perm", 512, 258, 2, 256, 16, True, False, "f16", 2, "llm"),
     ("t8_v4_k4096_r256_bf16", 1024, 260, 4, 4096, 256, False, False, "bf16", 8, "llm"),
+    # round 3: v8-k65536-0 (no residual codebook), one token: the layers of the sliced layout (gemv_sliced.hip)
+    ("t1_k65536_r0_4096x4096", 4096, 4096, 8, 65536, 0, False, True, "f16", 1, "llm"),
+    ("t1_k65536_r0_bf16", 2048, 8192 + 8, 8, 65536, 0, False, False, "bf16", 1, "llm"),
 ]
 
 
@@ -42,10 +45,13 @@ def main():
     vptq = load_reference()
     torch.set_num_threads(1)  # one summation order, whatever the box
     os.makedirs(os.path.join(HERE, "fmt"), exist_ok=True)
+    force = "--force" in sys.argv
     for ci, (name, I, O, v, k, kr, perm, bias, dtype, tokens, dist) in enumerate(FMT_CASES):
+        if os.path.exists(os.path.join(HERE, "fmt", f"{name}.npz")) and not force:
+            continue   # (fixtures are immutable once committed)
         seed = 5151 + ci
         dt = gg.TORCH_DT[dtype]
-        kw = dict(vector_lens=[-1, v], num_centroids=[-1, k], num_res_centroids=[-1, kr], group_num=1,
+        kw = dict(vector_lens=[-1, v], num_centroids=[-1, k], num_res_centroids=[-1, kr if kr > 0 else -1], group_num=1,
                   outlier_size=0, enable_norm=True, enable_perm=perm, bias=bias)
         m = vptq.VQuantLinear(I, O, group_size=I, indices_as_float=False, is_indice_packed=True,
                               dtype=dt, enable_proxy_error=False, **kw)
@@ -57,7 +63,8 @@ def main():
         assert tuple(m.indices.shape) == tuple(t["indices"].shape), (m.indices.shape, t["indices"].shape)
         m.indices.data = torch.from_numpy(t["indices"].copy()).reshape(m.indices.shape)
         m.centroids.weight.data = f(t["centroids"]).reshape(m.centroids.weight.shape)
-        m.res_centroids.weight.data = f(t["res_centroids"]).reshape(m.res_centroids.weight.shape)
+        if kr > 0:
+            m.res_centroids.weight.data = f(t["res_centroids"]).reshape(m.res_centroids.weight.shape)
         m.weight_scale.data = f(t["weight_scale"])
         m.weight_bias.data = f(t["weight_bias"])
         if perm:

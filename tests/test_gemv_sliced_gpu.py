@@ -1,0 +1,131 @@
+"""GPU parity of the one-token GEMV over the load-time derived sliced layout of v8-k65536-0 layers
+(vptq_quant_gemv_sliced, gemv_sliced.hip; layout built by vptq_amd/utils/sliced.py): against the oracle, the
+reference's goldens and the library's gather kernel, through the C ABI.
+
+Bar as everywhere: max|d| / max|ref| <= 1e-3 (fp16), 8e-3 (bf16)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import vptq_oracle as vo
+from _cases import rel_err, fmt_names, load_fmt, load_golden
+from _gpu_util import spec_to_module, bits_to_tensor, tensor_to_bits, gemv_abi, kernel_name
+
+pytestmark = pytest.mark.gpu
+TOL = {"f16": 1e-3, "bf16": 8e-3}
+EXACT = 1 << 2
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from vptq_amd import _backend as B
+    B.lib()
+    return torch.device("cuda", 0)
+
+
+def _x(I, dt, dist, seed):
+    rng = np.random.default_rng(seed)
+    xs = (0.02 + 0.5 * rng.standard_normal((1, 1, I))) if dist == "ref-test" else rng.standard_normal((1, 1, I))
+    return vo.from_f32(xs.astype(np.float32), dt)
+
+
+# I, O, kwargs, rows per wave (0 = the builder's choice): rows not a multiple of the 16-wave block, several rows
+# per wave, columns not a multiple of 64, output bias, a narrow layer (most slices of a row nearly empty)
+CASES = [
+    (1024, 256, dict(), 0),
+    (2048, 1032, dict(bias=True), 0),
+    (2048, 1032, dict(bias=True), 3),
+    (4104, 264, dict(dist="llm"), 0),
+    (512, 4096, dict(dist="llm"), 2),
+    (64, 72, dict(), 0),
+    (8192, 512, dict(dist="llm", bias=True), 1),
+    (14336, 128, dict(dist="llm"), 0),
+]
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("I,O,kw,rpw", CASES)
+def test_sliced_layout_gemv_vs_oracle(I, O, kw, rpw, dt, dev):
+    from vptq_amd.utils.sliced import SlicedGemv
+    from vptq_amd import _backend as B
+    kw = dict(kw)
+    dist = kw.pop("dist", "ref-test")
+    L = vo.make_layer(I, O, dist=dist, seed=I + O, dtype=dt, num_centroids=65536, num_res_centroids=0, **kw)
+    x = _x(I, dt, dist, I)
+    m = spec_to_module(L, dev)
+    assert kernel_name(m, 1) == "gemv_gather_kernel"
+    sl = SlicedGemv(m, rows_per_wave=rpw)
+    xt = bits_to_tensor(x, dt, dev).reshape(x.shape)
+    got = sl(xt)
+    torch.cuda.synchronize()
+    want = vo.forward(L, x)
+    err = rel_err(tensor_to_bits(got), want, dt)
+    assert err <= TOL[dt], f"{I}x{O} {dt}: {err:.3e}"
+    # against the library's own route for this layer (gather kernel, the reference's roundings)
+    assert rel_err(tensor_to_bits(got), tensor_to_bits(gemv_abi(m, xt, 0)), dt) <= TOL[dt]
+    # fp32 outputs: one rounding of the same sums; determinism
+    y32 = sl(xt, flags=B.GEMV_OUT_F32)
+    assert y32.dtype == torch.float32 and torch.equal(y32.to(got.dtype).view(torch.int16), got.view(torch.int16))
+    assert torch.equal(sl(xt).view(torch.int16), got.view(torch.int16))
+    # memory: 4 bytes per element + padding, on top of the packed indices
+    assert sl.extra_bytes <= 2.2 * m.indices.numel() * 4 + 8 * 8 * m.indices.shape[1] + 8 * 64 * 4 * m.indices.shape[1]
+
+
+@pytest.mark.parametrize("name", [n for n in fmt_names() if "k65536_r0" in n])
+def test_sliced_layout_gemv_on_reference_goldens(name, dev):
+    """v8-k65536-0 layers whose y comes from the real reference (tests/golden/gen_golden_fmt.py)"""
+    from vptq_amd.utils.sliced import SlicedGemv
+    L, x, y, cfg, _ = load_fmt(name)
+    dt = cfg["dtype"]
+    m = spec_to_module(L, dev)
+    xt = bits_to_tensor(x, dt, dev).reshape(x.shape)
+    got = tensor_to_bits(SlicedGemv(m)(xt))
+    err = rel_err(got, y, dt)
+    assert err <= TOL[dt], f"{name}: {err:.3e}"
+    # ... and the library's default route on the same fixture
+    assert rel_err(tensor_to_bits(gemv_abi(m, xt, 0)), y, dt) <= TOL[dt]
+
+
+def test_sliced_layout_small_reference_golden_and_rejections(dev):
+    from vptq_amd.utils.sliced import SlicedGemv
+    from vptq_amd import _backend as B
+    L, x, y, cfg, _ = load_golden("k65536_nores_nonorm")
+    m = spec_to_module(L, dev)
+    if B.lib().vptq_sliced_layout_supported(m._descriptor()[1]):
+        xt = bits_to_tensor(x, cfg["dtype"], dev).reshape(x.shape)
+        got = tensor_to_bits(SlicedGemv(m)(xt[:, :1].contiguous()))
+        assert rel_err(got, y[:, :1], cfg["dtype"]) <= TOL[cfg["dtype"]]
+    else:   # (no weight_scale / weight_bias: not this path's layer)
+        with pytest.raises(ValueError):
+            SlicedGemv(m)
+    # a canonical 256 + 256 layer is not a sliced-layout layer
+    with pytest.raises(ValueError):
+        SlicedGemv(spec_to_module(vo.make_layer(256, 64, seed=1), dev))
+    # the reference's roundings are not available here
+    Lk = vo.make_layer(512, 128, seed=2, num_centroids=65536, num_res_centroids=0)
+    sl = SlicedGemv(spec_to_module(Lk, dev))
+    with pytest.raises(RuntimeError):
+        sl(torch.zeros(1, 1, 512, dtype=torch.float16, device=dev), flags=EXACT)
+
+
+def test_sliced_layout_in_a_hipgraph(dev):
+    from vptq_amd.utils.sliced import SlicedGemv
+    L = vo.make_layer(2048, 1024, seed=9, dist="llm", num_centroids=65536, num_res_centroids=0)
+    m = spec_to_module(L, dev)
+    sl = SlicedGemv(m)
+    xs = torch.zeros(1, 1, 2048, dtype=torch.float16, device=dev)
+    ys = torch.empty(1, 1, 1024, dtype=torch.float16, device=dev)
+    sl(xs, ys)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            sl(xs, ys)
+    for rep in range(2):
+        v = _x(2048, "f16", "llm", 50 + rep)
+        xs.copy_(bits_to_tensor(v, "f16", dev).reshape(1, 1, 2048))
+        g.replay()
+        torch.cuda.synchronize()
+        assert rel_err(tensor_to_bits(ys), vo.forward(L, v), "f16") <= 1e-3

@@ -356,6 +356,33 @@ int vptq_quant_gemm_supported(const VptqLayerDesc* d) {
   return validate_layer(d) == VPTQ_OK && vptq::gemm_fused_eligible(*d) ? 1 : 0;
 }
 
+int vptq_sliced_layout_supported(const VptqLayerDesc* d) {
+  return validate_layer(d) == VPTQ_OK && vptq::gemv_sliced_eligible(*d) ? 1 : 0;
+}
+
+size_t vptq_quant_gemv_sliced_workspace_bytes(const VptqLayerDesc* d) {
+  return validate_layer(d) == VPTQ_OK && vptq::gemv_sliced_eligible(*d) ? vptq::gemv_sliced_workspace_bytes(*d) : 0;
+}
+
+int vptq_quant_gemv_sliced(const VptqLayerDesc* d, const VptqSlicedLayout* layout, const void* x, void* y, int flags,
+                           void* workspace, size_t workspace_bytes, void* stream) {
+  int rc = validate_layer(d);
+  if (rc) return rc;
+  if (!x || !y || !layout) return fail(VPTQ_E_NULL, "x / y / layout is NULL");
+  if (!vptq::gemv_sliced_eligible(*d))
+    return fail(VPTQ_E_UNSUPPORTED, "the sliced layout serves v8-k65536-0 layers without a permutation, group_size <= 14336");
+  if (flags & (VPTQ_GEMV_EXACT | VPTQ_GEMV_FORCE_GENERIC))
+    return fail(VPTQ_E_UNSUPPORTED, "the sliced path has the folded arithmetic only: use vptq_quant_gemv");
+  const size_t need = vptq::gemv_sliced_workspace_bytes(*d);
+  if (!workspace || workspace_bytes < need || (((uintptr_t)workspace) & 15) != 0)
+    return fail(VPTQ_E_WORKSPACE, "workspace of %zu bytes (16-byte aligned) needed", need);
+  if (layout->rows_per_wave < 1 || layout->rows_per_wave > 64 || !layout->elems || !layout->blocks || !layout->first)
+    return fail(VPTQ_E_UNSUPPORTED, "sliced layout: rows_per_wave in [1, 64] and three tensors");
+  if ((((uintptr_t)x) & 15) != 0) return fail(VPTQ_E_UNSUPPORTED, "x must be 16-byte aligned");
+  const hipError_t e = vptq::launch_gemv_sliced(*d, *layout, x, y, flags, workspace, (hipStream_t)stream);
+  return e == hipSuccess ? VPTQ_OK : hip_fail(e, "gemv_sliced launch");
+}
+
 size_t vptq_quant_gemm_workspace_bytes(const VptqLayerDesc* d, int tokens) {
   if (validate_layer(d) != VPTQ_OK || tokens < 1) return 0;
   return vptq::gemm_fused_workspace_bytes(*d, tokens);

@@ -1,0 +1,313 @@
+// Fused dequant + GEMV for the large-codebook format "v8-k65536-0" (v = 8, 65536 main centroids, no
+// residual; T = 16) over a LOAD-TIME DERIVED LAYOUT that makes every centroid gather LDS-local.
+// Same contract as gemv_gather.hip (reference: WqA16WithOutliers_PackIndice,
+// csrc/kernels/quant_gemv.cuh:11-186, dispatch csrc/quant_gemv.cu:54-132), one token.
+//
+// Why.  A 1 MiB codebook cannot live in LDS, so gemv_gather.hip gathers centroid rows from L2 with one
+// 16-byte load per index: every gather moves a 128-byte line for 16 useful bytes and the launch is
+// bound by the L2 -> L1 fill rate (39.6 us per 8192^2 layer, 0.06 of the HBM roofline).
+// Here the codebook is cut into 8 SLICES of 8192 entries (128 KiB = one workgroup's LDS) and, once per
+// layer (vptq_amd/utils/sliced.py; the on-disk tensors stay the state-dict contract), every row's
+// elements are bucketed by the slice of their index:
+//   elems  : for slice s = 0..7, for row n = 0..N-1: the row's elements whose index lies in slice s,
+//            in column order, padded to a multiple of 64 with (column = G, local index = 0);
+//            one 32-bit word per element = column | (index & 8191) << 16
+//   blocks : [8][N] number of 64-element blocks of (s, n);  first : [8][N] index of its first block
+// = 4 instead of 2 bytes per element (+ ~3 % padding): the layout costs 2x the packed indices in memory
+// on top of them and in HBM traffic per token.  A workgroup owns (slice, block of rows): it copies its
+// slice (LDS-DMA) and f16(scale * x) of all columns into LDS, then each wave streams the CONTIGUOUS
+// element blocks of its consecutive rows through a 16-deep register queue; per element one
+// ds_read_b128 (entry) + one ds_read_u16 (activation) + 8 FMAs in fp32.  Partial sums per (slice, output)
+// go to the caller's workspace; a second small kernel adds the 8 slices in a fixed order, sum b x and the
+// output bias.  Folded arithmetic (gemv_k256m.hip): y = sum c[idx] * f16(s x) + sum b x + bias.
+#include <type_traits>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace vptq {
+
+constexpr int kSLThreads = 1024;
+constexpr int kSLWaves = kSLThreads / 64;
+constexpr int kSLSlices = 8;
+constexpr int kSLSliceEntries = 8192;
+constexpr uint32_t kSLTabBytes = kSLSliceEntries * 16;   // 128 KiB
+constexpr uint32_t kSLXOff = kSLTabBytes;                // staged activations: (G + 64) halves
+constexpr int kSLMaxG = 14336;                           // 128 KiB + 28 KiB + 128 B
+constexpr int kSLQueue = 16;                             // element blocks in flight per wave
+constexpr int kSLMaxRowsPerWave = 64;                    // (their block counts sit in the lanes of one register)
+
+struct SlicedParams {
+  const uint32_t* elems;
+  const int32_t* blocks;    // [8][N]
+  const int32_t* first;     // [8][N]
+  const uint32_t* cent;     // [65536][8] halves
+  const uint16_t* x;
+  const uint16_t* scale;
+  const uint16_t* wbias;
+  const uint16_t* bias;
+  float* partial;           // [8][N * 8]
+  void* y;
+  int N, G, O, rows_per_wave, n_rowblocks, out_f32;
+};
+
+template <typename F>
+static __device__ __forceinline__ void sl_for_slots(F&& f) {
+  f(std::integral_constant<int, 0>{});  f(std::integral_constant<int, 1>{});
+  f(std::integral_constant<int, 2>{});  f(std::integral_constant<int, 3>{});
+  f(std::integral_constant<int, 4>{});  f(std::integral_constant<int, 5>{});
+  f(std::integral_constant<int, 6>{});  f(std::integral_constant<int, 7>{});
+  f(std::integral_constant<int, 8>{});  f(std::integral_constant<int, 9>{});
+  f(std::integral_constant<int, 10>{}); f(std::integral_constant<int, 11>{});
+  f(std::integral_constant<int, 12>{}); f(std::integral_constant<int, 13>{});
+  f(std::integral_constant<int, 14>{}); f(std::integral_constant<int, 15>{});
+}
+
+template <typename DT>
+__global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedParams P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  {
+    typedef __attribute__((address_space(3))) unsigned char lds_u8_t;
+    if ((uint32_t)(uintptr_t)(lds_u8_t*)smem != 0u) __builtin_trap();  // absolute LDS addressing
+  }
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int s = (int)blockIdx.x & (kSLSlices - 1), rb = (int)blockIdx.x >> 3;
+  const int N = P.N, G = P.G;
+  const int rpw = P.rows_per_wave;
+  const int row0 = (rb * kSLWaves + wave) * rpw;   // this wave's first row
+  const int n_rows = row0 >= N ? 0 : (N - row0 < rpw ? N - row0 : rpw);
+
+  // ---- this wave's stream: the blocks of its rows are contiguous in `elems`
+  int my_blocks = 0, total = 0, first_block = 0;
+  if (n_rows > 0) {
+    const int32_t* const bp = as_global(P.blocks) + (size_t)s * N + row0;
+    my_blocks = lane < n_rows ? bp[lane] : 0;           // lane i: blocks of row row0 + i
+    first_block = __builtin_amdgcn_readfirstlane(as_global(P.first)[(size_t)s * N + row0]);
+    int t = my_blocks;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+    total = __builtin_amdgcn_readfirstlane(t);
+  }
+
+  // ---- codebook slice into LDS by LDS-DMA: 128 x 1 KiB, 8 per wave (no registers; older than every
+  // load below, so the counted wait before the barrier covers it)
+  {
+    const uint64_t va = (uint64_t)(uintptr_t)as_global(P.cent) + (uint64_t)s * kSLTabBytes + (uint64_t)wave * 8192u +
+                        (uint64_t)lane * 16u;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const uint32_t d = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)wave * 8192u + (uint32_t)i * 1024u));
+      const uint64_t v = va + (uint64_t)(i * 1024);
+      uint32_t keep_m0;   // (M0 belongs to the compiler: saved and restored inside the statement)
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep_m0) : "v"(v), "s"(d) : "memory");
+    }
+  }
+  // ---- activations: f16(scale * x) of every column, zero for the padding column G
+  {
+    typedef __attribute__((address_space(3))) u32x4 lds_q_t;
+    const int chunks = G >> 3;
+    for (int q = tid; q < chunks + 8; q += kSLThreads) {
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (q < chunks) {
+        const u32x4 xv = *(const u32x4*)(as_global(P.x) + 8 * q);
+        const u32x4 sv = *(const u32x4*)(as_global(P.scale) + 8 * q);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = DT::mul2(xv[i], sv[i]);
+      }
+      *(lds_q_t*)(uintptr_t)(kSLXOff + (uint32_t)q * 16u) = v;
+    }
+  }
+
+  // ---- element queue: block k of the stream -> slot k % 16
+  uint32_t eq[kSLQueue];
+  const uint32_t* const ep = as_global(P.elems) + (size_t)first_block * 64 + lane;
+  const int last = total > 0 ? total - 1 : 0;
+  int i_next = 0;
+  auto issue = [&](auto slot_c) __attribute__((always_inline)) {
+    constexpr int S = decltype(slot_c)::value;
+    const int b = i_next < last ? i_next : last;   // past the end: the last block again (never consumed)
+    eq[S] = __builtin_nontemporal_load(ep + (size_t)b * 64);
+    ++i_next;
+  };
+  sl_for_slots([&](auto slot_c) {
+    issue(slot_c);
+    __builtin_amdgcn_sched_barrier(0);
+  });
+  // the DMA and the staging stores are done before anybody reads LDS (the 16 queue loads stay in flight)
+  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kSLQueue) : "memory");
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int row_i = 0;
+  // rows without elements in this slice store zeros
+  auto store_row = [&]() __attribute__((always_inline)) {
+    // sum over the 64 lanes: swap-and-add halves the values carried (gemv_k256c.hip:finish), then DPP
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = acc[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 4]), false, false);
+      v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 2]), false, false);
+      v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) v[i] = row16_allsum(v[i]);
+    // lane l (any of its row of 16) holds outputs 4 bit5 + 2 bit4 + {0, 1}
+    if ((lane & 15) == 0) {
+      const int o8 = ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2;
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      *(f32x2*)(as_global(P.partial) + ((size_t)s * N + (size_t)(row0 + row_i)) * 8 + o8) = f32x2{v[0], v[1]};
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+  };
+  if (total == 0) {   // none of this wave's rows has an element in this slice: zeros
+    for (; row_i < n_rows; ++row_i) store_row();
+    return;
+  }
+  int left = __builtin_amdgcn_readlane(my_blocks, 0);
+  while (left == 0) {   // (leading rows with no element in this slice)
+    store_row();
+    ++row_i;
+    left = __builtin_amdgcn_readlane(my_blocks, row_i);
+  }
+  int c_next = 0;
+  bool done = false;
+  auto consume = [&](auto slot_c) __attribute__((always_inline)) {
+    constexpr int S = decltype(slot_c)::value;
+    const uint32_t e = eq[S];
+    const u32x4 ent = lds_load16((e >> 16) << 4);
+    typedef __attribute__((address_space(3))) uint16_t lds_h_t;
+    const uint16_t xh = *(const lds_h_t*)(uintptr_t)(kSLXOff + ((e & 0xffffu) << 1));
+    const float xf = DT::to_float(xh);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      acc[2 * i] = __builtin_fmaf(DT::to_float((uint16_t)(ent[i] & 0xffffu)), xf, acc[2 * i]);
+      acc[2 * i + 1] = __builtin_fmaf(DT::to_float((uint16_t)(ent[i] >> 16)), xf, acc[2 * i + 1]);
+    }
+  };
+  auto step = [&](auto slot_c) __attribute__((always_inline)) {
+    __builtin_amdgcn_sched_barrier(0);
+    consume(slot_c);
+    __builtin_amdgcn_sched_barrier(0);
+    issue(slot_c);
+    __builtin_amdgcn_sched_barrier(0);
+    ++c_next;
+    if (--left == 0) {
+      if (!done) store_row();
+      ++row_i;
+      // next row with elements; after the last one the remaining steps of this loop iteration consume
+      // re-read blocks into sums nobody stores (ONE loop exit, at the end: gemv_k256c.hip)
+      left = 0;
+      while (row_i < n_rows && left == 0) {
+        left = __builtin_amdgcn_readlane(my_blocks, row_i);
+        if (left == 0) { store_row(); ++row_i; }
+      }
+      if (row_i >= n_rows) { done = true; left = 0x7fffffff; }
+    }
+  };
+  do {
+    sl_for_slots(step);
+  } while (!done);
+}
+
+// ---- y[o] = sum_s partial[s][o] + sum b x + bias[o] ----------------------------------
+template <typename DT>
+__global__ __launch_bounds__(256) void gemv_sliced_reduce(const float* __restrict__ partial, const uint16_t* __restrict__ x,
+                                                          const uint16_t* __restrict__ wbias, const uint16_t* __restrict__ bias,
+                                                          void* __restrict__ y, int N8, int G, int O, int out_f32) {
+  __shared__ float part[4];
+  const int tid = threadIdx.x;
+  float bd = 0.f;
+  for (int q = tid; q < (G >> 3); q += 256) {
+    const u32x4 xv = *(const u32x4*)(x + 8 * q);
+    const u32x4 bv = *(const u32x4*)(wbias + 8 * q);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bd = DT::dot2(xv[i], bv[i], bd);
+  }
+  bd = wave_sum(bd);
+  if ((tid & 63) == 0) part[tid >> 6] = bd;
+  __syncthreads();
+  const float bdot = (part[0] + part[1]) + (part[2] + part[3]);
+  const int o = blockIdx.x * 256 + tid;
+  if (o >= O) return;
+  float v = 0.f;
+#pragma unroll
+  for (int sl = 0; sl < kSLSlices; ++sl) v += partial[(size_t)sl * N8 + o];
+  v += bdot;
+  if (bias) v += DT::to_float(bias[o]);
+  if (out_f32) ((float*)y)[o] = v;
+  else ((uint16_t*)y)[o] = DT::from_float(v);
+}
+
+// ---- host side -------------------------------------------------------------------
+bool gemv_sliced_eligible(const VptqLayerDesc& d) {
+  return d.vector_len == 8 && d.num_codebooks == 1 && d.outlier_size == 0 && d.num_centroids == 65536 &&
+         d.num_res_centroids == 0 && d.index_bits == 16 && d.weight_scale != nullptr && d.weight_bias != nullptr &&
+         d.perm == nullptr && (d.group_size % 8) == 0 && d.group_size == d.in_features && d.group_size <= kSLMaxG &&
+         d.row_words * 2 == d.group_size &&
+         (((uintptr_t)d.centroids | (uintptr_t)d.weight_scale | (uintptr_t)d.weight_bias) & 15) == 0;
+}
+
+size_t gemv_sliced_workspace_bytes(const VptqLayerDesc& d) {
+  return (size_t)kSLSlices * d.num_indices * 8 * sizeof(float);
+}
+
+hipError_t launch_gemv_sliced(const VptqLayerDesc& d, const VptqSlicedLayout& L, const void* x, void* y, int flags,
+                              void* ws, hipStream_t st) {
+  if (L.rows_per_wave < 1 || L.rows_per_wave > kSLMaxRowsPerWave || !L.elems || !L.blocks || !L.first || !ws ||
+      (((uintptr_t)x) & 15) != 0)
+    return hipErrorInvalidValue;
+  SlicedParams P = {};
+  P.elems = (const uint32_t*)L.elems;
+  P.blocks = (const int32_t*)L.blocks;
+  P.first = (const int32_t*)L.first;
+  P.cent = (const uint32_t*)d.centroids;
+  P.x = (const uint16_t*)x;
+  P.scale = (const uint16_t*)d.weight_scale;
+  P.wbias = (const uint16_t*)d.weight_bias;
+  P.bias = (const uint16_t*)d.bias;
+  P.partial = (float*)ws;
+  P.y = y;
+  P.N = d.num_indices; P.G = d.group_size; P.O = d.out_features;
+  P.rows_per_wave = L.rows_per_wave;
+  const int rows_per_wg = kSLWaves * L.rows_per_wave;
+  P.n_rowblocks = (d.num_indices + rows_per_wg - 1) / rows_per_wg;
+  P.out_f32 = (flags & VPTQ_GEMV_OUT_F32) ? 1 : 0;
+  const uint32_t lds = kSLXOff + (uint32_t)(d.group_size + 64) * 2u;
+  const bool f16 = d.dtype == VPTQ_DTYPE_F16;
+  static std::atomic<bool> attr_set[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (!attr_set[dev]) {
+    const int max_lds = (int)(kSLXOff + (uint32_t)(kSLMaxG + 64) * 2u);
+    hipError_t e = hipFuncSetAttribute((const void*)gemv_sliced_kernel<F16>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)gemv_sliced_kernel<BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    if (e != hipSuccess) return e;
+    attr_set[dev] = true;
+  }
+  const dim3 grid(kSLSlices * P.n_rowblocks), block(kSLThreads);
+  if (f16) hipLaunchKernelGGL(gemv_sliced_kernel<F16>, grid, block, lds, st, P);
+  else hipLaunchKernelGGL(gemv_sliced_kernel<BF16>, grid, block, lds, st, P);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  const dim3 rgrid((d.out_features + 255) / 256);
+  if (f16)
+    hipLaunchKernelGGL(gemv_sliced_reduce<F16>, rgrid, dim3(256), 0, st, (const float*)ws, P.x, P.wbias, P.bias, y,
+                       d.num_indices * 8, d.group_size, d.out_features, P.out_f32);
+  else
+    hipLaunchKernelGGL(gemv_sliced_reduce<BF16>, rgrid, dim3(256), 0, st, (const float*)ws, P.x, P.wbias, P.bias, y,
+                       d.num_indices * 8, d.group_size, d.out_features, P.out_f32);
+  return hipGetLastError();
+}
+
+}  // namespace vptq

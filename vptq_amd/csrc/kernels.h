@@ -52,6 +52,11 @@ bool gemv_lds_v2_eligible(const VptqV2Desc& d, int tokens);
 hipError_t launch_gemv_lds_v2(const VptqV2Desc& d, const void* x, void* y, int tokens, bool out_f32,
                               int flags, hipStream_t st);
 
+// gemv_sliced.hip - v8-k65536-0, one token, over the load-time derived sliced layout (LDS-local gathers)
+bool gemv_sliced_eligible(const VptqLayerDesc& d);
+size_t gemv_sliced_workspace_bytes(const VptqLayerDesc& d);
+hipError_t launch_gemv_sliced(const VptqLayerDesc& d, const VptqSlicedLayout& L, const void* x, void* y, int flags,
+                              void* ws, hipStream_t st);
 // gemm_k256t.hip - canonical format, fp16 / bf16, up to 16 tokens in one pass over the indices (transposing
 // gather -> 16x16x32 MFMA with tokens as M; folded arithmetic; needs a workspace for the operand-ordered activations)
 bool gemm_k256t_eligible(const VptqLayerDesc& d, int tokens, int flags);

@@ -1,0 +1,92 @@
+"""Load-time derived layout for large-codebook layers (v = 8, k = 65536, no residual: "v8-k65536-0"),
+the format family of most published VPTQ checkpoints, and the one-token GEMV over it
+(`vptq_quant_gemv_sliced`, vptq_amd/csrc/gemv_sliced.hip).
+
+The reference gathers centroid rows from the 1 MiB codebook through the caches for every index
+(csrc/kernels/quant_gemv.cuh:11-186); on MI355X that is bound by the L2 -> L1 fill rate (39.6 us per 8192^2
+layer).  Bucketing every row's elements ONCE by the top 3 bits of their index lets a
+workgroup keep its 8192-entry slice of the codebook in LDS.  The state-dict tensors are untouched (they stay
+the contract, and the many-token / dequant paths keep using them); the derived tensors cost 2x the packed
+indices in device memory on top.
+
+    sl = SlicedGemv(layer)          # builds the layout (torch, on the layer's device)
+    y = sl(x)                       # one token; same result as layer(x) within the parity bar
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from vptq_amd import _backend as B
+
+SLICES = 8
+SLICE_BITS = 13
+
+
+def build_sliced_layout(indices: torch.Tensor, group_size: int):
+    """indices: the layer's packed int32 `indices` [1, N, G / 2] (T = 16: two elements per word, element g at
+    bits [16 g, 16 g + 16), vptq/utils/pack.py:26-89).  Returns (elems uint32-as-int32 [blocks * 64],
+    blocks int32 [8, N], first int32 [8, N]) as described in include/vptq_hip.h (VptqSlicedLayout)."""
+    assert indices.dtype == torch.int32 and indices.dim() == 3 and indices.shape[0] == 1
+    dev = indices.device
+    N, G = indices.shape[1], group_size
+    w = indices[0, :, :G // 2].to(torch.int64) & 0xffffffff
+    idx = torch.stack((w & 0xffff, w >> 16), dim=2).reshape(N, G)            # [N, G] main index per column
+    sl = idx >> SLICE_BITS
+    col = torch.arange(G, device=dev, dtype=torch.int64)
+    # columns of a row ordered by (slice, column)
+    order = torch.argsort(sl * G + col[None, :], dim=1)
+    s_sorted = torch.gather(sl, 1, order)
+    word = order | ((torch.gather(idx, 1, order) & ((1 << SLICE_BITS) - 1)) << 16)    # column | local << 16
+    counts = torch.zeros(N, SLICES, dtype=torch.int64, device=dev)
+    counts.scatter_add_(1, sl, torch.ones_like(sl))
+    seg_start = torch.cumsum(counts, 1) - counts                                        # first position of (n, s) in the sorted row
+    blocks = (counts + 63) // 64                                                        # [N, 8]
+    blocks_sn = blocks.t().contiguous()                                                 # [8, N]
+    first_sn = (torch.cumsum(blocks_sn.reshape(-1), 0) - blocks_sn.reshape(-1)).reshape(SLICES, N)
+    total = int(blocks_sn.sum().item())
+    elems = torch.full((max(total, 1) * 64,), G, dtype=torch.int64, device=dev)         # padding: column G, local 0
+    pos = col[None, :] - torch.gather(seg_start, 1, s_sorted)                           # rank inside its (n, s) list
+    rows = torch.arange(N, device=dev)[:, None].expand(N, G)
+    dest = first_sn[s_sorted, rows] * 64 + pos
+    elems[dest.reshape(-1)] = word.reshape(-1)
+    elems32 = (elems & 0xffffffff).to(torch.int64)
+    elems32 = torch.where(elems32 >= (1 << 31), elems32 - (1 << 32), elems32).to(torch.int32)
+    return elems32, blocks_sn.to(torch.int32).contiguous(), first_sn.to(torch.int32).contiguous()
+
+
+def rows_per_wave_for(n_rows: int, workgroups: int = 256) -> int:
+    """consecutive rows per wave so that 8 slices x row blocks of 16 waves give about `workgroups` workgroups"""
+    r = max(1, (n_rows * SLICES + 16 * workgroups - 1) // (16 * workgroups))
+    return min(r, 64)
+
+
+class SlicedGemv:
+    """One-token forward of a v8-k65536-0 `VQuantLinear` over its sliced layout."""
+
+    def __init__(self, layer, rows_per_wave: int = 0):
+        self.layer = layer
+        cache = layer._descriptor()
+        self.desc, self.dev = cache[1], cache[3]
+        if not B.lib().vptq_sliced_layout_supported(self.desc):
+            raise ValueError("the sliced layout serves v8-k65536-0 layers without a permutation, group_size <= 14336")
+        self.elems, self.blocks, self.first = build_sliced_layout(layer.indices.data, layer.group_size)
+        self.layout = B.SlicedLayout(self.elems.data_ptr(), self.blocks.data_ptr(), self.first.data_ptr(),
+                                     rows_per_wave or rows_per_wave_for(self.blocks.shape[1]), 0)
+        nb = B.lib().vptq_quant_gemv_sliced_workspace_bytes(self.desc)
+        self.ws = torch.empty(nb, dtype=torch.uint8, device=self.dev)
+        self.extra_bytes = self.elems.numel() * 4 + self.blocks.numel() * 8
+
+    def __call__(self, x: torch.Tensor, out: torch.Tensor = None, flags: int = 0) -> torch.Tensor:
+        x = self.layer._check_activation(x)
+        if x.numel() != self.layer.in_features:
+            raise ValueError("the sliced path takes one token")
+        if out is None:
+            dt = torch.float32 if (flags & B.GEMV_OUT_F32) else x.dtype
+            out = torch.empty(x.shape[:-1] + (self.layer.out_features,), dtype=dt, device=self.dev)
+        with torch.cuda.device(self.dev):
+            B.check(B.lib().vptq_quant_gemv_sliced(self.desc, C.byref(self.layout), x.data_ptr(), out.data_ptr(), flags,
+                                                   self.ws.data_ptr(), self.ws.numel(), B.current_stream_ptr(self.dev)),
+                    "vptq_quant_gemv_sliced")
+        return out
