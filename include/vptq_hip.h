@@ -263,9 +263,10 @@ VPTQ_API int vptq_quant_gemm(const VptqLayerDesc* desc, const void* x, void* y, 
  * caches (csrc/kernels/quant_gemv.cuh:11-186); here every row's elements are bucketed ONCE per layer by
  * the top 3 bits of their index, so that a workgroup holds its 8192-entry slice of the codebook in LDS:
  *   elems  : uint32, for slice s = 0..7, for row n = 0..N-1 (N = desc->num_indices): the elements of row
- *            n whose index >> 13 == s, in column order, padded to a multiple of 64 with the word
- *            (column = group_size, local = 0); element word = column | (index & 8191) << 16
- *   blocks : int32 [8][N], 64-element blocks of (s, n);  first : int32 [8][N], index of its first block
+ *            n whose index >> 13 == s, in column order, padded to a multiple of the block (64 x
+ *            elems_per_lane elements) with the word (column = group_size, local = 0);
+ *            element word = column | (index & 8191) << 16; 16-byte aligned
+ *   blocks : int32 [8][N], blocks of (s, n);  first : int32 [8][N], index of its first block
  *            (prefix sum of `blocks` in (s, n) order)
  *   rows_per_wave : 1 .. 64 consecutive rows per wave (16 waves per workgroup); the layout does not
  *            depend on it
@@ -279,7 +280,7 @@ typedef struct VptqSlicedLayout {
   const void* blocks;
   const void* first;
   int32_t rows_per_wave;
-  int32_t reserved;
+  int32_t elems_per_lane;   /* 1 (0 = 1), 2 or 4: a block = 64 x elems_per_lane elements */
 } VptqSlicedLayout;
 VPTQ_API int vptq_sliced_layout_supported(const VptqLayerDesc* desc);
 VPTQ_API size_t vptq_quant_gemv_sliced_workspace_bytes(const VptqLayerDesc* desc);

@@ -10,9 +10,11 @@
 // layer (vptq_amd/utils/sliced.py; the on-disk tensors stay the state-dict contract), every row's
 // elements are bucketed by the slice of their index:
 //   elems  : for slice s = 0..7, for row n = 0..N-1: the row's elements whose index lies in slice s,
-//            in column order, padded to a multiple of 64 with (column = G, local index = 0);
-//            one 32-bit word per element = column | (index & 8191) << 16
-//   blocks : [8][N] number of 64-element blocks of (s, n);  first : [8][N] index of its first block
+//            in column order, padded to a multiple of the block (64 x elems_per_lane elements) with
+//            (column = G, local index = 0); one 32-bit word per element = column | (index & 8191) << 16
+//   blocks : [8][N] number of blocks of (s, n);  first : [8][N] index of its first block
+// (elems_per_lane = 4: one 16-byte load per lane and block - with one word per lane the launch was bound by
+// the number of load INSTRUCTIONS, its time proportional to blocks + queue depth per wave)
 // = 4 instead of 2 bytes per element (+ ~3 % padding): the layout costs 2x the packed indices in memory
 // on top of them and in HBM traffic per token.  A workgroup owns (slice, block of rows): it copies its
 // slice (LDS-DMA) and f16(scale * x) of all columns into LDS, then each wave streams the CONTIGUOUS
@@ -34,7 +36,18 @@ constexpr int kSLSliceEntries = 8192;
 constexpr uint32_t kSLTabBytes = kSLSliceEntries * 16;   // 128 KiB
 constexpr uint32_t kSLXOff = kSLTabBytes;                // staged activations: (G + 64) halves
 constexpr int kSLMaxG = 14336;                           // 128 KiB + 28 KiB + 128 B
-constexpr int kSLQueue = 16;                             // element blocks in flight per wave
+// element words per lane in flight (queue depth = this / elems_per_lane blocks).  Same-box A/B with one word per
+// lane and block (profiles/r03/sliced_queue_ab.txt): depth 8 / 16 / 32 = 14.2 / 16.2 / 21.2 us per 8192^2 layer -
+// proportional to (blocks + depth) per wave: every step issues a load, also the `depth` steps past the end of a
+// wave's stream, and the launch was bound by the number of load instructions, not by bytes or latency.
+#ifndef VPTQ_SLICED_QUEUE
+#define VPTQ_SLICED_QUEUE 8
+#endif
+constexpr int kSLQueueWords = VPTQ_SLICED_QUEUE;
+// timing-only ablations (results wrong): bit 0 no gathers / FMAs, bit 1 no slice copy, bit 2 no activation staging
+#ifndef VPTQ_SLICED_ABLATE
+#define VPTQ_SLICED_ABLATE 0
+#endif
 constexpr int kSLMaxRowsPerWave = 64;                    // (their block counts sit in the lanes of one register)
 
 struct SlicedParams {
@@ -51,20 +64,22 @@ struct SlicedParams {
   int N, G, O, rows_per_wave, n_rowblocks, out_f32;
 };
 
-template <typename F>
-static __device__ __forceinline__ void sl_for_slots(F&& f) {
-  f(std::integral_constant<int, 0>{});  f(std::integral_constant<int, 1>{});
-  f(std::integral_constant<int, 2>{});  f(std::integral_constant<int, 3>{});
-  f(std::integral_constant<int, 4>{});  f(std::integral_constant<int, 5>{});
-  f(std::integral_constant<int, 6>{});  f(std::integral_constant<int, 7>{});
-  f(std::integral_constant<int, 8>{});  f(std::integral_constant<int, 9>{});
-  f(std::integral_constant<int, 10>{}); f(std::integral_constant<int, 11>{});
-  f(std::integral_constant<int, 12>{}); f(std::integral_constant<int, 13>{});
-  f(std::integral_constant<int, 14>{}); f(std::integral_constant<int, 15>{});
+// f(slot 0), ... f(slot kSLQueue - 1) with the slot as a compile-time constant
+template <int I0, int I1, typename F>
+static __device__ __forceinline__ void sl_for_range(F&& f) {
+  if constexpr (I1 - I0 == 1) f(std::integral_constant<int, I0>{});
+  else {
+    sl_for_range<I0, (I0 + I1) / 2>(f);
+    sl_for_range<(I0 + I1) / 2, I1>(f);
+  }
 }
+template <int Q, typename F>
+static __device__ __forceinline__ void sl_for_slots(F&& f) { sl_for_range<0, Q>(f); }
 
-template <typename DT>
+template <typename DT, int EPL>
 __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedParams P) {
+  typedef uint32_t evec_t __attribute__((ext_vector_type(EPL)));
+  constexpr int kSLQueue = kSLQueueWords / EPL < 2 ? 2 : kSLQueueWords / EPL;   // blocks in flight per wave
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   {
     typedef __attribute__((address_space(3))) unsigned char lds_u8_t;
@@ -96,7 +111,7 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedPar
     const uint64_t va = (uint64_t)(uintptr_t)as_global(P.cent) + (uint64_t)s * kSLTabBytes + (uint64_t)wave * 8192u +
                         (uint64_t)lane * 16u;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < ((VPTQ_SLICED_ABLATE & 2) ? 0 : 8); ++i) {
       const uint32_t d = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)wave * 8192u + (uint32_t)i * 1024u));
       const uint64_t v = va + (uint64_t)(i * 1024);
       uint32_t keep_m0;   // (M0 belongs to the compiler: saved and restored inside the statement)
@@ -104,42 +119,62 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedPar
                    : "=&s"(keep_m0) : "v"(v), "s"(d) : "memory");
     }
   }
-  // ---- activations: f16(scale * x) of every column, zero for the padding column G
+  // ---- activations: f16(scale * x) of every column, zero for the padding column G; the workgroups of slice 0
+  // also form sum b x (it rides in their partial sums: the second kernel then reads nothing but partial sums)
+  const uint32_t bd_off = kSLXOff + (uint32_t)(G + 64) * 2u;   // 16 floats behind the staged activations
   {
     typedef __attribute__((address_space(3))) u32x4 lds_q_t;
     const int chunks = G >> 3;
+    float bd = 0.f;
     for (int q = tid; q < chunks + 8; q += kSLThreads) {
       u32x4 v = {0u, 0u, 0u, 0u};
-      if (q < chunks) {
+      if (q < chunks && !(VPTQ_SLICED_ABLATE & 4)) {
         const u32x4 xv = *(const u32x4*)(as_global(P.x) + 8 * q);
         const u32x4 sv = *(const u32x4*)(as_global(P.scale) + 8 * q);
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = DT::mul2(xv[i], sv[i]);
+        if (s == 0) {
+          const u32x4 bv = *(const u32x4*)(as_global(P.wbias) + 8 * q);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) bd = DT::dot2(xv[i], bv[i], bd);
+        }
       }
       *(lds_q_t*)(uintptr_t)(kSLXOff + (uint32_t)q * 16u) = v;
     }
+    if (s == 0) {
+      bd = wave_sum(bd);
+      if (lane == 0) *(float*)(smem + bd_off + (uint32_t)wave * 4u) = bd;
+    }
   }
 
-  // ---- element queue: block k of the stream -> slot k % 16
-  uint32_t eq[kSLQueue];
-  const uint32_t* const ep = as_global(P.elems) + (size_t)first_block * 64 + lane;
+  // ---- element queue: block k of the stream -> slot k % kSLQueue
+  evec_t eq[kSLQueue];
+  const evec_t* const ep = (const evec_t*)(as_global(P.elems) + (size_t)first_block * (64 * EPL)) + lane;
   const int last = total > 0 ? total - 1 : 0;
   int i_next = 0;
+  // (past the end of the stream a step still issues its load - every step the same instructions, so the waits
+  // stay counted - of the last block again; one cached word for all lanes instead was measured slower)
   auto issue = [&](auto slot_c) __attribute__((always_inline)) {
     constexpr int S = decltype(slot_c)::value;
-    const int b = i_next < last ? i_next : last;   // past the end: the last block again (never consumed)
-    eq[S] = __builtin_nontemporal_load(ep + (size_t)b * 64);
+    const evec_t* const a = ep + (size_t)(i_next < last ? i_next : last) * 64;
+    eq[S] = __builtin_nontemporal_load(a);
     ++i_next;
   };
-  sl_for_slots([&](auto slot_c) {
+  sl_for_slots<kSLQueue>([&](auto slot_c) {
     issue(slot_c);
     __builtin_amdgcn_sched_barrier(0);
   });
-  // the DMA and the staging stores are done before anybody reads LDS (the 16 queue loads stay in flight)
+  // the DMA and the staging loads are done before anybody reads LDS (the queue loads stay in flight)
   asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kSLQueue) : "memory");
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+  float bdot = 0.f;
+  if (s == 0) {   // (fixed order: the 16 waves' parts)
+    const float* const bp = (const float*)(smem + bd_off);
+#pragma unroll
+    for (int i = 0; i < kSLWaves; ++i) bdot += bp[i];
+  }
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   int row_i = 0;
   // rows without elements in this slice store zeros
@@ -164,7 +199,7 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedPar
     if ((lane & 15) == 0) {
       const int o8 = ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2;
       typedef float f32x2 __attribute__((ext_vector_type(2)));
-      *(f32x2*)(as_global(P.partial) + ((size_t)s * N + (size_t)(row0 + row_i)) * 8 + o8) = f32x2{v[0], v[1]};
+      *(f32x2*)(as_global(P.partial) + ((size_t)s * N + (size_t)(row0 + row_i)) * 8 + o8) = f32x2{v[0] + bdot, v[1] + bdot};
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[i] = 0.f;
@@ -183,15 +218,42 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedPar
   bool done = false;
   auto consume = [&](auto slot_c) __attribute__((always_inline)) {
     constexpr int S = decltype(slot_c)::value;
-    const uint32_t e = eq[S];
-    const u32x4 ent = lds_load16((e >> 16) << 4);
+    const evec_t ev = eq[S];
+    if constexpr ((VPTQ_SLICED_ABLATE & 1) != 0) {
+      acc[0] += __uint_as_float(ev[0]);
+      return;
+    }
     typedef __attribute__((address_space(3))) uint16_t lds_h_t;
-    const uint16_t xh = *(const lds_h_t*)(uintptr_t)(kSLXOff + ((e & 0xffffu) << 1));
-    const float xf = DT::to_float(xh);
+    u32x4 ent[EPL];
+    uint16_t xh[EPL];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      acc[2 * i] = __builtin_fmaf(DT::to_float((uint16_t)(ent[i] & 0xffffu)), xf, acc[2 * i]);
-      acc[2 * i + 1] = __builtin_fmaf(DT::to_float((uint16_t)(ent[i] >> 16)), xf, acc[2 * i + 1]);
+    for (int k = 0; k < EPL; ++k) {
+      const uint32_t e = ev[k];
+      ent[k] = lds_load16((e >> 16) << 4);
+      xh[k] = *(const lds_h_t*)(uintptr_t)(kSLXOff + ((e & 0xffffu) << 1));
+    }
+#pragma unroll
+    for (int k = 0; k < EPL; ++k) {
+      if constexpr (std::is_same<DT, F16>::value) {
+        // v_fma_mix_f32: fp16 x fp16 + fp32 -> fp32 in one instruction (exact product, one rounding: what
+        // fmaf of the converted values gives), halves picked by op_sel
+        const uint32_t xw = xh[k];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float lo = acc[2 * i], hi = acc[2 * i + 1];   // (an asm operand cannot name a captured array element)
+          const uint32_t ew = ent[k][i];
+          asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,1,0]" : "+v"(lo) : "v"(ew), "v"(xw));
+          asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,0]" : "+v"(hi) : "v"(ew), "v"(xw));
+          acc[2 * i] = lo; acc[2 * i + 1] = hi;
+        }
+      } else {
+        const float xf = DT::to_float(xh[k]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          acc[2 * i] = __builtin_fmaf(DT::to_float((uint16_t)(ent[k][i] & 0xffffu)), xf, acc[2 * i]);
+          acc[2 * i + 1] = __builtin_fmaf(DT::to_float((uint16_t)(ent[k][i] >> 16)), xf, acc[2 * i + 1]);
+        }
+      }
     }
   };
   auto step = [&](auto slot_c) __attribute__((always_inline)) {
@@ -215,34 +277,20 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedPar
     }
   };
   do {
-    sl_for_slots(step);
+    sl_for_slots<kSLQueue>(step);
   } while (!done);
 }
 
-// ---- y[o] = sum_s partial[s][o] + sum b x + bias[o] ----------------------------------
+// ---- y[o] = sum_s partial[s][o] + bias[o]  (sum b x rides in slice 0's partial sums) --------
 template <typename DT>
-__global__ __launch_bounds__(256) void gemv_sliced_reduce(const float* __restrict__ partial, const uint16_t* __restrict__ x,
-                                                          const uint16_t* __restrict__ wbias, const uint16_t* __restrict__ bias,
-                                                          void* __restrict__ y, int N8, int G, int O, int out_f32) {
-  __shared__ float part[4];
-  const int tid = threadIdx.x;
-  float bd = 0.f;
-  for (int q = tid; q < (G >> 3); q += 256) {
-    const u32x4 xv = *(const u32x4*)(x + 8 * q);
-    const u32x4 bv = *(const u32x4*)(wbias + 8 * q);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) bd = DT::dot2(xv[i], bv[i], bd);
-  }
-  bd = wave_sum(bd);
-  if ((tid & 63) == 0) part[tid >> 6] = bd;
-  __syncthreads();
-  const float bdot = (part[0] + part[1]) + (part[2] + part[3]);
-  const int o = blockIdx.x * 256 + tid;
+__global__ __launch_bounds__(256) void gemv_sliced_reduce(const float* __restrict__ partial, const uint16_t* __restrict__ bias,
+                                                          void* __restrict__ y, int N8, int O, int out_f32) {
+  const int o = blockIdx.x * 256 + threadIdx.x;
   if (o >= O) return;
-  float v = 0.f;
+  float p[kSLSlices];
 #pragma unroll
-  for (int sl = 0; sl < kSLSlices; ++sl) v += partial[(size_t)sl * N8 + o];
-  v += bdot;
+  for (int sl = 0; sl < kSLSlices; ++sl) p[sl] = partial[(size_t)sl * N8 + o];
+  float v = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
   if (bias) v += DT::to_float(bias[o]);
   if (out_f32) ((float*)y)[o] = v;
   else ((uint16_t*)y)[o] = DT::from_float(v);
@@ -263,8 +311,9 @@ size_t gemv_sliced_workspace_bytes(const VptqLayerDesc& d) {
 
 hipError_t launch_gemv_sliced(const VptqLayerDesc& d, const VptqSlicedLayout& L, const void* x, void* y, int flags,
                               void* ws, hipStream_t st) {
+  const int epl = L.elems_per_lane == 0 ? 1 : L.elems_per_lane;
   if (L.rows_per_wave < 1 || L.rows_per_wave > kSLMaxRowsPerWave || !L.elems || !L.blocks || !L.first || !ws ||
-      (((uintptr_t)x) & 15) != 0)
+      (((uintptr_t)x) & 15) != 0 || (epl != 1 && epl != 2 && epl != 4) || (((uintptr_t)L.elems) & 15) != 0)
     return hipErrorInvalidValue;
   SlicedParams P = {};
   P.elems = (const uint32_t*)L.elems;
@@ -282,31 +331,42 @@ hipError_t launch_gemv_sliced(const VptqLayerDesc& d, const VptqSlicedLayout& L,
   const int rows_per_wg = kSLWaves * L.rows_per_wave;
   P.n_rowblocks = (d.num_indices + rows_per_wg - 1) / rows_per_wg;
   P.out_f32 = (flags & VPTQ_GEMV_OUT_F32) ? 1 : 0;
-  const uint32_t lds = kSLXOff + (uint32_t)(d.group_size + 64) * 2u;
+  const uint32_t lds = kSLXOff + (uint32_t)(d.group_size + 64) * 2u + 64u;
   const bool f16 = d.dtype == VPTQ_DTYPE_F16;
+  const void* kern = nullptr;
+#define SL_PICK(E) (f16 ? (const void*)gemv_sliced_kernel<F16, E> : (const void*)gemv_sliced_kernel<BF16, E>)
+  kern = epl == 1 ? SL_PICK(1) : epl == 2 ? SL_PICK(2) : SL_PICK(4);
+#undef SL_PICK
   static std::atomic<bool> attr_set[64];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
   if (!attr_set[dev]) {
-    const int max_lds = (int)(kSLXOff + (uint32_t)(kSLMaxG + 64) * 2u);
-    hipError_t e = hipFuncSetAttribute((const void*)gemv_sliced_kernel<F16>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute((const void*)gemv_sliced_kernel<BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-    if (e != hipSuccess) return e;
+    const int max_lds = (int)(kSLXOff + (uint32_t)(kSLMaxG + 64) * 2u + 64u);
+    const void* all[6] = {(const void*)gemv_sliced_kernel<F16, 1>, (const void*)gemv_sliced_kernel<F16, 2>,
+                          (const void*)gemv_sliced_kernel<F16, 4>, (const void*)gemv_sliced_kernel<BF16, 1>,
+                          (const void*)gemv_sliced_kernel<BF16, 2>, (const void*)gemv_sliced_kernel<BF16, 4>};
+    for (const void* k : all) {
+      const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+      if (e != hipSuccess) return e;
+    }
     attr_set[dev] = true;
   }
   const dim3 grid(kSLSlices * P.n_rowblocks), block(kSLThreads);
-  if (f16) hipLaunchKernelGGL(gemv_sliced_kernel<F16>, grid, block, lds, st, P);
-  else hipLaunchKernelGGL(gemv_sliced_kernel<BF16>, grid, block, lds, st, P);
+  {
+    SlicedParams Pc = P;
+    void* args[] = {(void*)&Pc};
+    const hipError_t e = hipLaunchKernel(kern, grid, block, args, lds, st);
+    if (e != hipSuccess) return e;
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   const dim3 rgrid((d.out_features + 255) / 256);
   if (f16)
-    hipLaunchKernelGGL(gemv_sliced_reduce<F16>, rgrid, dim3(256), 0, st, (const float*)ws, P.x, P.wbias, P.bias, y,
-                       d.num_indices * 8, d.group_size, d.out_features, P.out_f32);
+    hipLaunchKernelGGL(gemv_sliced_reduce<F16>, rgrid, dim3(256), 0, st, (const float*)ws, P.bias, y,
+                       d.num_indices * 8, d.out_features, P.out_f32);
   else
-    hipLaunchKernelGGL(gemv_sliced_reduce<BF16>, rgrid, dim3(256), 0, st, (const float*)ws, P.x, P.wbias, P.bias, y,
-                       d.num_indices * 8, d.group_size, d.out_features, P.out_f32);
+    hipLaunchKernelGGL(gemv_sliced_reduce<BF16>, rgrid, dim3(256), 0, st, (const float*)ws, P.bias, y,
+                       d.num_indices * 8, d.out_features, P.out_f32);
   return hipGetLastError();
 }
 

@@ -24,9 +24,9 @@ SLICES = 8
 SLICE_BITS = 13
 
 
-def build_sliced_layout(indices: torch.Tensor, group_size: int):
+def build_sliced_layout(indices: torch.Tensor, group_size: int, elems_per_lane: int = 1):
     """indices: the layer's packed int32 `indices` [1, N, G / 2] (T = 16: two elements per word, element g at
-    bits [16 g, 16 g + 16), vptq/utils/pack.py:26-89).  Returns (elems uint32-as-int32 [blocks * 64],
+    bits [16 g, 16 g + 16), vptq/utils/pack.py:26-89).  Returns (elems uint32-as-int32 [blocks * 64 * elems_per_lane],
     blocks int32 [8, N], first int32 [8, N]) as described in include/vptq_hip.h (VptqSlicedLayout)."""
     assert indices.dtype == torch.int32 and indices.dim() == 3 and indices.shape[0] == 1
     dev = indices.device
@@ -35,21 +35,33 @@ def build_sliced_layout(indices: torch.Tensor, group_size: int):
     idx = torch.stack((w & 0xffff, w >> 16), dim=2).reshape(N, G)            # [N, G] main index per column
     sl = idx >> SLICE_BITS
     col = torch.arange(G, device=dev, dtype=torch.int64)
-    # columns of a row ordered by (slice, column)
-    order = torch.argsort(sl * G + col[None, :], dim=1)
+    # Order inside a (row, slice) list is free (a sum): arrange it so that 16 CONSECUTIVE elements - the lanes one
+    # pass of the kernel's ds_read_b128 gather serves - hit 16 different LDS bank groups (entry & 15): elements are
+    # ranked inside their (slice, entry & 15) class and laid out rank-major, i.e. one element of every class in turn.
+    # (Column order gave 3-way conflicts on average: SQ_LDS_BANK_CONFLICT = 60 % of the LDS cycles.)
+    local = idx & ((1 << SLICE_BITS) - 1)
+    cls = local & 15
+    order1 = torch.argsort((sl * 16 + cls) * G + col[None, :], dim=1)
+    seg1 = torch.gather(sl * 16 + cls, 1, order1)                                       # sorted (slice, class) id
+    cnt1 = torch.zeros(N, SLICES * 16, dtype=torch.int64, device=dev)
+    cnt1.scatter_add_(1, seg1, torch.ones_like(seg1))
+    rank1 = col[None, :] - torch.gather(torch.cumsum(cnt1, 1) - cnt1, 1, seg1)          # rank inside the class
+    order2 = torch.argsort(((seg1 >> 4) * G + rank1) * 16 + (seg1 & 15), dim=1)         # (slice, rank, class)
+    order = torch.gather(order1, 1, order2)
     s_sorted = torch.gather(sl, 1, order)
-    word = order | ((torch.gather(idx, 1, order) & ((1 << SLICE_BITS) - 1)) << 16)    # column | local << 16
+    word = order | (torch.gather(local, 1, order) << 16)                                # column | local << 16
     counts = torch.zeros(N, SLICES, dtype=torch.int64, device=dev)
     counts.scatter_add_(1, sl, torch.ones_like(sl))
     seg_start = torch.cumsum(counts, 1) - counts                                        # first position of (n, s) in the sorted row
-    blocks = (counts + 63) // 64                                                        # [N, 8]
+    bs = 64 * elems_per_lane                                                            # elements per block
+    blocks = (counts + bs - 1) // bs                                                    # [N, 8]
     blocks_sn = blocks.t().contiguous()                                                 # [8, N]
     first_sn = (torch.cumsum(blocks_sn.reshape(-1), 0) - blocks_sn.reshape(-1)).reshape(SLICES, N)
     total = int(blocks_sn.sum().item())
-    elems = torch.full((max(total, 1) * 64,), G, dtype=torch.int64, device=dev)         # padding: column G, local 0
+    elems = torch.full((max(total, 1) * bs,), G, dtype=torch.int64, device=dev)         # padding: column G, local 0
     pos = col[None, :] - torch.gather(seg_start, 1, s_sorted)                           # rank inside its (n, s) list
     rows = torch.arange(N, device=dev)[:, None].expand(N, G)
-    dest = first_sn[s_sorted, rows] * 64 + pos
+    dest = first_sn[s_sorted, rows] * bs + pos
     elems[dest.reshape(-1)] = word.reshape(-1)
     elems32 = (elems & 0xffffffff).to(torch.int64)
     elems32 = torch.where(elems32 >= (1 << 31), elems32 - (1 << 32), elems32).to(torch.int32)
@@ -65,15 +77,15 @@ def rows_per_wave_for(n_rows: int, workgroups: int = 256) -> int:
 class SlicedGemv:
     """One-token forward of a v8-k65536-0 `VQuantLinear` over its sliced layout."""
 
-    def __init__(self, layer, rows_per_wave: int = 0):
+    def __init__(self, layer, rows_per_wave: int = 0, elems_per_lane: int = 1):
         self.layer = layer
         cache = layer._descriptor()
         self.desc, self.dev = cache[1], cache[3]
         if not B.lib().vptq_sliced_layout_supported(self.desc):
             raise ValueError("the sliced layout serves v8-k65536-0 layers without a permutation, group_size <= 14336")
-        self.elems, self.blocks, self.first = build_sliced_layout(layer.indices.data, layer.group_size)
+        self.elems, self.blocks, self.first = build_sliced_layout(layer.indices.data, layer.group_size, elems_per_lane)
         self.layout = B.SlicedLayout(self.elems.data_ptr(), self.blocks.data_ptr(), self.first.data_ptr(),
-                                     rows_per_wave or rows_per_wave_for(self.blocks.shape[1]), 0)
+                                     rows_per_wave or rows_per_wave_for(self.blocks.shape[1]), elems_per_lane)
         nb = B.lib().vptq_quant_gemv_sliced_workspace_bytes(self.desc)
         self.ws = torch.empty(nb, dtype=torch.uint8, device=self.dev)
         self.extra_bytes = self.elems.numel() * 4 + self.blocks.numel() * 8
