@@ -258,8 +258,8 @@ VPTQ_API int vptq_quant_gemm(const VptqLayerDesc* desc, const void* x, void* y, 
                     void* workspace, size_t workspace_bytes, void* stream);
 
 /*
- * One token over a LOAD-TIME DERIVED LAYOUT of a large-codebook layer (v = 8, k = 65536, no residual:
- * "v8-k65536-0"; ABI >= 6).  The reference gathers centroid rows from a 1 MiB codebook through the
+ * One token over a LOAD-TIME DERIVED LAYOUT of a large-codebook layer (v = 8, k = 65536, residual none or 256:
+ * "v8-k65536-0" / "v8-k65536-256", the formats of most published checkpoints; ABI >= 6).  The reference gathers centroid rows from a 1 MiB codebook through the
  * caches (csrc/kernels/quant_gemv.cuh:11-186); here every row's elements are bucketed ONCE per layer by
  * the top 3 bits of their index, so that a workgroup holds its 8192-entry slice of the codebook in LDS:
  *   elems  : uint32, for slice s = 0..7, for row n = 0..N-1 (N = desc->num_indices): the elements of row
@@ -273,12 +273,14 @@ VPTQ_API int vptq_quant_gemm(const VptqLayerDesc* desc, const void* x, void* y, 
  * (vptq_amd/utils/sliced.py builds it with torch.)  It costs 2x the packed indices in device memory on
  * top of them; the state-dict tensors are untouched.  workspace: vptq_quant_gemv_sliced_workspace_bytes
  * (8 x N x 8 floats of partial sums).  Folded arithmetic (parity bar, not bit-equivalent);
- * vptq_sliced_layout_supported() = 1 for layers this path takes (no permutation, group_size <= 14336).
+ * vptq_sliced_layout_supported() = 1 for layers this path takes (no permutation, group_size <= 14336; with a
+ * residual codebook <= 14080 and elems_per_lane = 1).
  */
 typedef struct VptqSlicedLayout {
   const void* elems;
   const void* blocks;
   const void* first;
+  const void* res;          /* uint8 per element (same order, padding = 0): residual index; NULL without residual */
   int32_t rows_per_wave;
   int32_t elems_per_lane;   /* 1 (0 = 1), 2 or 4: a block = 64 x elems_per_lane elements */
 } VptqSlicedLayout;

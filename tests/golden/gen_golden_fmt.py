@@ -38,6 +38,9 @@ FMT_CASES = [
     # round 3: v8-k65536-0 (no residual codebook), one token: the layers of the sliced layout (gemv_sliced.hip)
     ("t1_k65536_r0_4096x4096", 4096, 4096, 8, 65536, 0, False, True, "f16", 1, "llm"),
     ("t1_k65536_r0_bf16", 2048, 8192 + 8, 8, 65536, 0, False, False, "bf16", 1, "llm"),
+    # v8-k65536-256 (the format of most published checkpoints), one token
+    ("t1_k65536_r256_4096x4096", 4096, 4096, 8, 65536, 256, False, True, "f16", 1, "llm"),
+    ("t1_k65536_r256_bf16", 2048, 4096 + 8, 8, 65536, 256, False, False, "bf16", 1, "llm"),
 ]
 
 

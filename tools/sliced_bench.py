@@ -16,6 +16,7 @@ ap.add_argument("--shapes", default="8192,8192;4096,4096")
 ap.add_argument("--ring", type=int, default=8)
 ap.add_argument("--rpw", type=int, default=0)
 ap.add_argument("--epl", type=int, default=1)
+ap.add_argument("--kr", type=int, default=0, help="residual centroids: 0 (v8-k65536-0) or 256 (v8-k65536-256)")
 ap.add_argument("--bf16", action="store_true")
 ap.add_argument("--out", default="")
 a = ap.parse_args()
@@ -24,7 +25,7 @@ dt = torch.bfloat16 if a.bf16 else torch.float16
 res = []
 for I, O in [tuple(int(v) for v in p.split(',')) for p in a.shapes.split(';')]:
     R = a.ring
-    layers = [mk(I, O, dev, g, k=65536, kr=0) for _ in range(R)]
+    layers = [mk(I, O, dev, g, k=65536, kr=a.kr) for _ in range(R)]
     if a.bf16:
         layers = [m.to(torch.bfloat16) for m in layers]
     descs = [module_desc(m) for m in layers]
@@ -45,7 +46,7 @@ for I, O in [tuple(int(v) for v in p.split(',')) for p in a.shapes.split(';')]:
     us_d = time_graph(run_default, 10) / R
     us_s = time_graph(run_sliced, 10) / R
     idx_bytes = layers[0].indices.numel() * 4
-    r = dict(I=I, O=O, dtype="bf16" if a.bf16 else "f16", default_us=us_d, default_kernel=lib.vptq_quant_gemv_kernel_name(descs[0][0], 1, 0).decode(),
+    r = dict(I=I, O=O, kr=a.kr, dtype="bf16" if a.bf16 else "f16", default_us=us_d, default_kernel=lib.vptq_quant_gemv_kernel_name(descs[0][0], 1, 0).decode(),
              sliced_us=us_s, speedup=us_d / us_s, rel_diff=err, packed_index_MiB=idx_bytes / 2**20,
              layout_MiB=sls[0].extra_bytes / 2**20, rows_per_wave=sls[0].layout.rows_per_wave, elems_per_lane=a.epl,
              sliced_GBps_of_packed_bytes=idx_bytes / us_s / 1e3, sliced_GBps_of_layout_bytes=sls[0].extra_bytes / us_s / 1e3)

@@ -38,7 +38,7 @@ _vp = C.c_void_p
 
 class SlicedLayout(C.Structure):
     """Mirror of `VptqSlicedLayout` (include/vptq_hip.h)."""
-    _fields_ = [("elems", C.c_void_p), ("blocks", C.c_void_p), ("first", C.c_void_p),
+    _fields_ = [("elems", C.c_void_p), ("blocks", C.c_void_p), ("first", C.c_void_p), ("res", C.c_void_p),
                 ("rows_per_wave", C.c_int32), ("elems_per_lane", C.c_int32)]
 
 

@@ -1,5 +1,6 @@
-// Fused dequant + GEMV for the large-codebook format "v8-k65536-0" (v = 8, 65536 main centroids, no
-// residual; T = 16) over a LOAD-TIME DERIVED LAYOUT that makes every centroid gather LDS-local.
+// Fused dequant + GEMV for the large-codebook formats "v8-k65536-0" (v = 8, 65536 main centroids, no residual;
+// T = 16) and "v8-k65536-256" (+ 256 residual centroids, T = 24: most published checkpoints) over a LOAD-TIME
+// DERIVED LAYOUT that makes every centroid gather LDS-local.
 // Same contract as gemv_gather.hip (reference: WqA16WithOutliers_PackIndice,
 // csrc/kernels/quant_gemv.cuh:11-186, dispatch csrc/quant_gemv.cu:54-132), one token.
 //
@@ -13,6 +14,8 @@
 //            in column order, padded to a multiple of the block (64 x elems_per_lane elements) with
 //            (column = G, local index = 0); one 32-bit word per element = column | (index & 8191) << 16
 //   blocks : [8][N] number of blocks of (s, n);  first : [8][N] index of its first block
+//   res    : (residual formats) one byte per element, same order and padding: its residual index; the 256-entry
+//            residual codebook sits in LDS beside the slice
 // (elems_per_lane = 4: one 16-byte load per lane and block - with one word per lane the launch was bound by
 // the number of load INSTRUCTIONS, its time proportional to blocks + queue depth per wave)
 // = 4 instead of 2 bytes per element (+ ~3 % padding): the layout costs 2x the packed indices in memory
@@ -35,7 +38,8 @@ constexpr int kSLSlices = 8;
 constexpr int kSLSliceEntries = 8192;
 constexpr uint32_t kSLTabBytes = kSLSliceEntries * 16;   // 128 KiB
 constexpr uint32_t kSLXOff = kSLTabBytes;                // staged activations: (G + 64) halves
-constexpr int kSLMaxG = 14336;                           // 128 KiB + 28 KiB + 128 B
+constexpr int kSLMaxG = 14336;                           // 128 KiB + 28 KiB + 192 B
+constexpr int kSLMaxGRes = 14080;                        // ... + the 4 KiB residual codebook: 160 KiB is full at 14240 columns
 // element words per lane in flight (queue depth = this / elems_per_lane blocks).  Same-box A/B with one word per
 // lane and block (profiles/r03/sliced_queue_ab.txt): depth 8 / 16 / 32 = 14.2 / 16.2 / 21.2 us per 8192^2 layer -
 // proportional to (blocks + depth) per wave: every step issues a load, also the `depth` steps past the end of a
@@ -52,6 +56,8 @@ constexpr int kSLMaxRowsPerWave = 64;                    // (their block counts 
 
 struct SlicedParams {
   const uint32_t* elems;
+  const uint8_t* res;       // residual index per element (same order and padding), or null
+  const uint32_t* rcent;    // [256][8] halves, or null
   const int32_t* blocks;    // [8][N]
   const int32_t* first;     // [8][N]
   const uint32_t* cent;     // [65536][8] halves
@@ -76,9 +82,11 @@ static __device__ __forceinline__ void sl_for_range(F&& f) {
 template <int Q, typename F>
 static __device__ __forceinline__ void sl_for_slots(F&& f) { sl_for_range<0, Q>(f); }
 
-template <typename DT, int EPL>
+template <typename DT, int EPL, bool RES>
 __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedParams P) {
+  static_assert(!RES || EPL == 1, "the residual byte stream is read one element per lane");
   typedef uint32_t evec_t __attribute__((ext_vector_type(EPL)));
+  constexpr int kLoadsPerStep = RES ? 2 : 1;
   constexpr int kSLQueue = kSLQueueWords / EPL < 2 ? 2 : kSLQueueWords / EPL;   // blocks in flight per wave
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   {
@@ -119,6 +127,17 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedPar
                    : "=&s"(keep_m0) : "v"(v), "s"(d) : "memory");
     }
   }
+  // residual codebook (256 entries = 4 KiB) behind the activations: waves 0-3 bring 1 KiB each
+  const uint32_t res_off = kSLXOff + (uint32_t)(G + 64) * 2u + 64u;
+  if constexpr (RES) {
+    if (wave < 4) {
+      const uint64_t v = (uint64_t)(uintptr_t)as_global(P.rcent) + (uint64_t)wave * 1024u + (uint64_t)lane * 16u;
+      const uint32_t d = (uint32_t)__builtin_amdgcn_readfirstlane((int)(res_off + (uint32_t)wave * 1024u));
+      uint32_t keep_m0;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep_m0) : "v"(v), "s"(d) : "memory");
+    }
+  }
   // ---- activations: f16(scale * x) of every column, zero for the padding column G; the workgroups of slice 0
   // also form sum b x (it rides in their partial sums: the second kernel then reads nothing but partial sums)
   const uint32_t bd_off = kSLXOff + (uint32_t)(G + 64) * 2u;   // 16 floats behind the staged activations
@@ -149,15 +168,18 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedPar
 
   // ---- element queue: block k of the stream -> slot k % kSLQueue
   evec_t eq[kSLQueue];
+  uint32_t rq[RES ? kSLQueue : 1];
   const evec_t* const ep = (const evec_t*)(as_global(P.elems) + (size_t)first_block * (64 * EPL)) + lane;
+  const uint8_t* const rp = RES ? as_global(P.res) + (size_t)first_block * 64 + lane : nullptr;
   const int last = total > 0 ? total - 1 : 0;
   int i_next = 0;
   // (past the end of the stream a step still issues its load - every step the same instructions, so the waits
   // stay counted - of the last block again; one cached word for all lanes instead was measured slower)
   auto issue = [&](auto slot_c) __attribute__((always_inline)) {
     constexpr int S = decltype(slot_c)::value;
-    const evec_t* const a = ep + (size_t)(i_next < last ? i_next : last) * 64;
-    eq[S] = __builtin_nontemporal_load(a);
+    const size_t b64 = (size_t)(i_next < last ? i_next : last) * 64;
+    eq[S] = __builtin_nontemporal_load(ep + b64);
+    if constexpr (RES) rq[S] = rp[b64];
     ++i_next;
   };
   sl_for_slots<kSLQueue>([&](auto slot_c) {
@@ -165,7 +187,7 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedPar
     __builtin_amdgcn_sched_barrier(0);
   });
   // the DMA and the staging loads are done before anybody reads LDS (the queue loads stay in flight)
-  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kSLQueue) : "memory");
+  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kSLQueue * kLoadsPerStep) : "memory");
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
@@ -225,6 +247,7 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedPar
     }
     typedef __attribute__((address_space(3))) uint16_t lds_h_t;
     u32x4 ent[EPL];
+    u32x4 rent = {0u, 0u, 0u, 0u};
     uint16_t xh[EPL];
 #pragma unroll
     for (int k = 0; k < EPL; ++k) {
@@ -232,6 +255,7 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedPar
       ent[k] = lds_load16((e >> 16) << 4);
       xh[k] = *(const lds_h_t*)(uintptr_t)(kSLXOff + ((e & 0xffffu) << 1));
     }
+    if constexpr (RES) rent = lds_load16(res_off + (rq[S] << 4));
 #pragma unroll
     for (int k = 0; k < EPL; ++k) {
       if constexpr (std::is_same<DT, F16>::value) {
@@ -244,6 +268,11 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedPar
           const uint32_t ew = ent[k][i];
           asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,1,0]" : "+v"(lo) : "v"(ew), "v"(xw));
           asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,0]" : "+v"(hi) : "v"(ew), "v"(xw));
+          if constexpr (RES) {   // (c + r) x = c x + r x: the residual entry into the same sums
+            const uint32_t rw = rent[i];
+            asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,1,0]" : "+v"(lo) : "v"(rw), "v"(xw));
+            asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,0]" : "+v"(hi) : "v"(rw), "v"(xw));
+          }
           acc[2 * i] = lo; acc[2 * i + 1] = hi;
         }
       } else {
@@ -252,6 +281,10 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedPar
         for (int i = 0; i < 4; ++i) {
           acc[2 * i] = __builtin_fmaf(DT::to_float((uint16_t)(ent[k][i] & 0xffffu)), xf, acc[2 * i]);
           acc[2 * i + 1] = __builtin_fmaf(DT::to_float((uint16_t)(ent[k][i] >> 16)), xf, acc[2 * i + 1]);
+          if constexpr (RES) {
+            acc[2 * i] = __builtin_fmaf(DT::to_float((uint16_t)(rent[i] & 0xffffu)), xf, acc[2 * i]);
+            acc[2 * i + 1] = __builtin_fmaf(DT::to_float((uint16_t)(rent[i] >> 16)), xf, acc[2 * i + 1]);
+          }
         }
       }
     }
@@ -297,12 +330,16 @@ __global__ __launch_bounds__(256) void gemv_sliced_reduce(const float* __restric
 }
 
 // ---- host side -------------------------------------------------------------------
+// v8-k65536-0 (T = 16) and v8-k65536-256 (T = 24: the format of most published checkpoints)
 bool gemv_sliced_eligible(const VptqLayerDesc& d) {
+  const bool res = d.num_res_centroids == 256;
   return d.vector_len == 8 && d.num_codebooks == 1 && d.outlier_size == 0 && d.num_centroids == 65536 &&
-         d.num_res_centroids == 0 && d.index_bits == 16 && d.weight_scale != nullptr && d.weight_bias != nullptr &&
-         d.perm == nullptr && (d.group_size % 8) == 0 && d.group_size == d.in_features && d.group_size <= kSLMaxG &&
-         d.row_words * 2 == d.group_size &&
-         (((uintptr_t)d.centroids | (uintptr_t)d.weight_scale | (uintptr_t)d.weight_bias) & 15) == 0;
+         (d.num_res_centroids == 0 || res) && d.index_bits == 16 && (!res || d.res_bits == 8) &&
+         d.weight_scale != nullptr && d.weight_bias != nullptr &&
+         d.perm == nullptr && (d.group_size % 8) == 0 && d.group_size == d.in_features &&
+         d.group_size <= (res ? kSLMaxGRes : kSLMaxG) &&
+         (long long)d.row_words * 32 == (long long)d.group_size * (res ? 24 : 16) &&
+         (((uintptr_t)d.centroids | (uintptr_t)d.res_centroids | (uintptr_t)d.weight_scale | (uintptr_t)d.weight_bias) & 15) == 0;
 }
 
 size_t gemv_sliced_workspace_bytes(const VptqLayerDesc& d) {
@@ -312,11 +349,15 @@ size_t gemv_sliced_workspace_bytes(const VptqLayerDesc& d) {
 hipError_t launch_gemv_sliced(const VptqLayerDesc& d, const VptqSlicedLayout& L, const void* x, void* y, int flags,
                               void* ws, hipStream_t st) {
   const int epl = L.elems_per_lane == 0 ? 1 : L.elems_per_lane;
+  const bool res = d.num_res_centroids == 256;
+  if (res && (epl != 1 || !L.res)) return hipErrorInvalidValue;
   if (L.rows_per_wave < 1 || L.rows_per_wave > kSLMaxRowsPerWave || !L.elems || !L.blocks || !L.first || !ws ||
       (((uintptr_t)x) & 15) != 0 || (epl != 1 && epl != 2 && epl != 4) || (((uintptr_t)L.elems) & 15) != 0)
     return hipErrorInvalidValue;
   SlicedParams P = {};
   P.elems = (const uint32_t*)L.elems;
+  P.res = res ? (const uint8_t*)L.res : nullptr;
+  P.rcent = res ? (const uint32_t*)d.res_centroids : nullptr;
   P.blocks = (const int32_t*)L.blocks;
   P.first = (const int32_t*)L.first;
   P.cent = (const uint32_t*)d.centroids;
@@ -331,20 +372,21 @@ hipError_t launch_gemv_sliced(const VptqLayerDesc& d, const VptqSlicedLayout& L,
   const int rows_per_wg = kSLWaves * L.rows_per_wave;
   P.n_rowblocks = (d.num_indices + rows_per_wg - 1) / rows_per_wg;
   P.out_f32 = (flags & VPTQ_GEMV_OUT_F32) ? 1 : 0;
-  const uint32_t lds = kSLXOff + (uint32_t)(d.group_size + 64) * 2u + 64u;
+  const uint32_t lds = kSLXOff + (uint32_t)(d.group_size + 64) * 2u + 64u + (res ? 4096u : 0u);
   const bool f16 = d.dtype == VPTQ_DTYPE_F16;
   const void* kern = nullptr;
-#define SL_PICK(E) (f16 ? (const void*)gemv_sliced_kernel<F16, E> : (const void*)gemv_sliced_kernel<BF16, E>)
-  kern = epl == 1 ? SL_PICK(1) : epl == 2 ? SL_PICK(2) : SL_PICK(4);
+#define SL_PICK(E, R) (f16 ? (const void*)gemv_sliced_kernel<F16, E, R> : (const void*)gemv_sliced_kernel<BF16, E, R>)
+  kern = res ? SL_PICK(1, true) : epl == 1 ? SL_PICK(1, false) : epl == 2 ? SL_PICK(2, false) : SL_PICK(4, false);
 #undef SL_PICK
   static std::atomic<bool> attr_set[64];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
   if (!attr_set[dev]) {
-    const int max_lds = (int)(kSLXOff + (uint32_t)(kSLMaxG + 64) * 2u + 64u);
-    const void* all[6] = {(const void*)gemv_sliced_kernel<F16, 1>, (const void*)gemv_sliced_kernel<F16, 2>,
-                          (const void*)gemv_sliced_kernel<F16, 4>, (const void*)gemv_sliced_kernel<BF16, 1>,
-                          (const void*)gemv_sliced_kernel<BF16, 2>, (const void*)gemv_sliced_kernel<BF16, 4>};
+    const int max_lds = 163840;
+    const void* all[8] = {(const void*)gemv_sliced_kernel<F16, 1, false>, (const void*)gemv_sliced_kernel<F16, 2, false>,
+                          (const void*)gemv_sliced_kernel<F16, 4, false>, (const void*)gemv_sliced_kernel<BF16, 1, false>,
+                          (const void*)gemv_sliced_kernel<BF16, 2, false>, (const void*)gemv_sliced_kernel<BF16, 4, false>,
+                          (const void*)gemv_sliced_kernel<F16, 1, true>, (const void*)gemv_sliced_kernel<BF16, 1, true>};
     for (const void* k : all) {
       const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
       if (e != hipSuccess) return e;

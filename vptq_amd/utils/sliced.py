@@ -1,13 +1,13 @@
-"""Load-time derived layout for large-codebook layers (v = 8, k = 65536, no residual: "v8-k65536-0"),
-the format family of most published VPTQ checkpoints, and the one-token GEMV over it
+"""Load-time derived layout for large-codebook layers (v = 8, k = 65536, residual none or 256: "v8-k65536-0",
+"v8-k65536-256"), the formats of most published VPTQ checkpoints, and the one-token GEMV over it
 (`vptq_quant_gemv_sliced`, vptq_amd/csrc/gemv_sliced.hip).
 
 The reference gathers centroid rows from the 1 MiB codebook through the caches for every index
 (csrc/kernels/quant_gemv.cuh:11-186); on MI355X that is bound by the L2 -> L1 fill rate (39.6 us per 8192^2
 layer).  Bucketing every row's elements ONCE by the top 3 bits of their index lets a
 workgroup keep its 8192-entry slice of the codebook in LDS.  The state-dict tensors are untouched (they stay
-the contract, and the many-token / dequant paths keep using them); the derived tensors cost 2x the packed
-indices in device memory on top.
+the contract, and the many-token / dequant paths keep using them); the derived tensors cost 2x (T = 16) / 1.7x
+(T = 24: 5 instead of 3 bytes per element) the packed indices in device memory on top.
 
     sl = SlicedGemv(layer)          # builds the layout (torch, on the layer's device)
     y = sl(x)                       # one token; same result as layer(x) within the parity bar
@@ -24,15 +24,19 @@ SLICES = 8
 SLICE_BITS = 13
 
 
-def build_sliced_layout(indices: torch.Tensor, group_size: int, elems_per_lane: int = 1):
-    """indices: the layer's packed int32 `indices` [1, N, G / 2] (T = 16: two elements per word, element g at
-    bits [16 g, 16 g + 16), vptq/utils/pack.py:26-89).  Returns (elems uint32-as-int32 [blocks * 64 * elems_per_lane],
-    blocks int32 [8, N], first int32 [8, N]) as described in include/vptq_hip.h (VptqSlicedLayout)."""
+def build_sliced_layout(indices: torch.Tensor, group_size: int, elems_per_lane: int = 1, residual: bool = False):
+    """indices: the layer's packed int32 `indices` [1, N, row_words]: a little-endian bit stream per row, element g
+    at bits [T g, T g + T) with value (residual index << 16) | main index (vptq/utils/pack.py:26-89); T = 16 without
+    a residual codebook, 24 with 256 residual centroids.  Returns (elems uint32-as-int32 [blocks * 64 *
+    elems_per_lane], blocks int32 [8, N], first int32 [8, N], res uint8 [like elems] or None) as described in
+    include/vptq_hip.h (VptqSlicedLayout)."""
     assert indices.dtype == torch.int32 and indices.dim() == 3 and indices.shape[0] == 1
     dev = indices.device
     N, G = indices.shape[1], group_size
-    w = indices[0, :, :G // 2].to(torch.int64) & 0xffffffff
-    idx = torch.stack((w & 0xffff, w >> 16), dim=2).reshape(N, G)            # [N, G] main index per column
+    nbytes = 3 if residual else 2
+    by = indices[0].contiguous().view(torch.uint8).reshape(N, -1)[:, :nbytes * G].reshape(N, G, nbytes).to(torch.int64)
+    idx = by[:, :, 0] | (by[:, :, 1] << 8)                                    # [N, G] main index per column
+    ridx = by[:, :, 2] if residual else None
     sl = idx >> SLICE_BITS
     col = torch.arange(G, device=dev, dtype=torch.int64)
     # Order inside a (row, slice) list is free (a sum): arrange it so that 16 CONSECUTIVE elements - the lanes one
@@ -65,7 +69,11 @@ def build_sliced_layout(indices: torch.Tensor, group_size: int, elems_per_lane: 
     elems[dest.reshape(-1)] = word.reshape(-1)
     elems32 = (elems & 0xffffffff).to(torch.int64)
     elems32 = torch.where(elems32 >= (1 << 31), elems32 - (1 << 32), elems32).to(torch.int32)
-    return elems32, blocks_sn.to(torch.int32).contiguous(), first_sn.to(torch.int32).contiguous()
+    res = None
+    if residual:
+        res = torch.zeros(elems.numel(), dtype=torch.uint8, device=dev)
+        res[dest.reshape(-1)] = torch.gather(ridx, 1, order).reshape(-1).to(torch.uint8)
+    return elems32, blocks_sn.to(torch.int32).contiguous(), first_sn.to(torch.int32).contiguous(), res
 
 
 def rows_per_wave_for(n_rows: int, workgroups: int = 256) -> int:
@@ -82,13 +90,19 @@ class SlicedGemv:
         cache = layer._descriptor()
         self.desc, self.dev = cache[1], cache[3]
         if not B.lib().vptq_sliced_layout_supported(self.desc):
-            raise ValueError("the sliced layout serves v8-k65536-0 layers without a permutation, group_size <= 14336")
-        self.elems, self.blocks, self.first = build_sliced_layout(layer.indices.data, layer.group_size, elems_per_lane)
+            raise ValueError("the sliced layout serves v8-k65536-0 / v8-k65536-256 layers without a permutation, "
+                             "group_size <= 14336 (14080 with the residual codebook)")
+        residual = bool(layer.enable_residual)
+        if residual and elems_per_lane != 1:
+            raise ValueError("residual formats: one element word per lane and block")
+        self.elems, self.blocks, self.first, self.res = build_sliced_layout(layer.indices.data, layer.group_size,
+                                                                            elems_per_lane, residual)
         self.layout = B.SlicedLayout(self.elems.data_ptr(), self.blocks.data_ptr(), self.first.data_ptr(),
+                                     self.res.data_ptr() if residual else None,
                                      rows_per_wave or rows_per_wave_for(self.blocks.shape[1]), elems_per_lane)
         nb = B.lib().vptq_quant_gemv_sliced_workspace_bytes(self.desc)
         self.ws = torch.empty(nb, dtype=torch.uint8, device=self.dev)
-        self.extra_bytes = self.elems.numel() * 4 + self.blocks.numel() * 8
+        self.extra_bytes = self.elems.numel() * (5 if residual else 4) + self.blocks.numel() * 8
 
     def __call__(self, x: torch.Tensor, out: torch.Tensor = None, flags: int = 0) -> torch.Tensor:
         x = self.layer._check_activation(x)
