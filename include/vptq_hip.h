@@ -262,19 +262,18 @@ VPTQ_API int vptq_quant_gemm(const VptqLayerDesc* desc, const void* x, void* y, 
  * "v8-k65536-0" / "v8-k65536-256", the formats of most published checkpoints; ABI >= 6).  The reference gathers centroid rows from a 1 MiB codebook through the
  * caches (csrc/kernels/quant_gemv.cuh:11-186); here every row's elements are bucketed ONCE per layer by
  * the top 3 bits of their index, so that a workgroup holds its 8192-entry slice of the codebook in LDS:
- *   elems  : uint32, for slice s = 0..7, for row n = 0..N-1 (N = desc->num_indices): the elements of row
- *            n whose index >> 13 == s, in column order, padded to a multiple of the block (64 x
- *            elems_per_lane elements) with the word (column = group_size, local = 0);
- *            element word = column | (index & 8191) << 16; 16-byte aligned
- *   blocks : int32 [8][N], blocks of (s, n);  first : int32 [8][N], index of its first block
+ *   elems  : uint32, for slice s = 0..S-1 (S = 8 or 16; E = 65536 / S entries per slice), for row n = 0..N-1
+ *            (N = desc->num_indices): the elements of row n whose index / E == s, in any order, padded to a
+ *            multiple of 64 with the word (column = group_size, local = 0);
+ *            element word = column | (index mod E) << 16
+ *   blocks : int32 [S][N], 64-element blocks of (s, n);  first : int32 [S][N], index of its first block
  *            (prefix sum of `blocks` in (s, n) order)
  *   rows_per_wave : 1 .. 64 consecutive rows per wave (16 waves per workgroup); the layout does not
  *            depend on it
  * (vptq_amd/utils/sliced.py builds it with torch.)  It costs 2x the packed indices in device memory on
  * top of them; the state-dict tensors are untouched.  workspace: vptq_quant_gemv_sliced_workspace_bytes
- * (8 x N x 8 floats of partial sums).  Folded arithmetic (parity bar, not bit-equivalent);
- * vptq_sliced_layout_supported() = 1 for layers this path takes (no permutation, group_size <= 14336; with a
- * residual codebook <= 14080 and elems_per_lane = 1).
+ * (S x N x 8 floats of partial sums).  Folded arithmetic (parity bar, not bit-equivalent);
+ * Layers this path takes: no permutation, group_size <= 32768.
  */
 typedef struct VptqSlicedLayout {
   const void* elems;
@@ -282,8 +281,12 @@ typedef struct VptqSlicedLayout {
   const void* first;
   const void* res;          /* uint8 per element (same order, padding = 0): residual index; NULL without residual */
   int32_t rows_per_wave;
-  int32_t elems_per_lane;   /* 1 (0 = 1), 2 or 4: a block = 64 x elems_per_lane elements */
+  int32_t elems_per_lane;   /* 1 (or 0): a block = 64 elements */
+  int32_t n_slices;         /* 8 (or 0) / 16: what vptq_sliced_layout_supported() answers for the layer */
+  int32_t reserved;
 } VptqSlicedLayout;
+/* 0 = not a layer of this path; else the number of slices its layout must have: 8 slices of 8192 entries while
+ * the activations fit in LDS beside them (group_size <= 14336, 14080 with a residual codebook), else 16 of 4096 */
 VPTQ_API int vptq_sliced_layout_supported(const VptqLayerDesc* desc);
 VPTQ_API size_t vptq_quant_gemv_sliced_workspace_bytes(const VptqLayerDesc* desc);
 VPTQ_API int vptq_quant_gemv_sliced(const VptqLayerDesc* desc, const VptqSlicedLayout* layout, const void* x,

@@ -40,7 +40,8 @@ CASES = [
     (512, 4096, dict(dist="llm"), 2),
     (64, 72, dict(), 0),
     (8192, 512, dict(dist="llm", bias=True), 1),
-    (14336, 128, dict(dist="llm"), 0),
+    (14336, 128, dict(dist="llm"), 0),          # with a residual codebook: 16 slices of 4096 entries
+    (28672, 64, dict(dist="llm", bias=True), 0),  # 16 slices
 ]
 
 
@@ -52,8 +53,6 @@ def test_sliced_layout_gemv_vs_oracle(I, O, kw, rpw, dt, kr, dev):
     from vptq_amd import _backend as B
     kw = dict(kw)
     dist = kw.pop("dist", "ref-test")
-    if kr and I > 14080:
-        pytest.skip("with the residual codebook in LDS the activations of at most 14080 columns fit")
     L = vo.make_layer(I, O, dist=dist, seed=I + O, dtype=dt, num_centroids=65536, num_res_centroids=kr, **kw)
     x = _x(I, dt, dist, I)
     m = spec_to_module(L, dev)
@@ -65,10 +64,7 @@ def test_sliced_layout_gemv_vs_oracle(I, O, kw, rpw, dt, kr, dev):
     want = vo.forward(L, x)
     err = rel_err(tensor_to_bits(got), want, dt)
     assert err <= TOL[dt], f"{I}x{O} {dt}: {err:.3e}"
-    # the other block sizes (2 and 4 element words per lane and block instead of 1): same sums in another order
-    for epl in (() if kr else (2, 4)):
-        alt = SlicedGemv(m, rows_per_wave=rpw, elems_per_lane=epl)(xt)
-        assert rel_err(tensor_to_bits(alt), want, dt) <= TOL[dt], f"{I}x{O} {dt} epl {epl}"
+    assert sl.slices == (8 if I <= (14080 if kr else 14336) else 16)
     # against the library's own route for this layer (gather kernel, the reference's roundings)
     assert rel_err(tensor_to_bits(got), tensor_to_bits(gemv_abi(m, xt, 0)), dt) <= TOL[dt]
     # fp32 outputs: one rounding of the same sums; determinism
@@ -138,3 +134,29 @@ def test_sliced_layout_in_a_hipgraph(dev):
         g.replay()
         torch.cuda.synchronize()
         assert rel_err(tensor_to_bits(ys), vo.forward(L, v), "f16") <= 1e-3
+
+
+def test_module_forward_takes_the_sliced_layout_when_enabled(dev):
+    """VQuantLinear.enable_sliced_layout(): one-token calls go through the derived layout, everything else (several
+    tokens, dequant) through the state-dict tensors as before; an in-place change of the indices rebuilds it"""
+    L = vo.make_layer(2048, 512, seed=21, dist="llm", num_centroids=65536, num_res_centroids=256, bias=True)
+    m = spec_to_module(L, dev)
+    x1 = _x(2048, "f16", "llm", 3)
+    xt = bits_to_tensor(x1, "f16", dev).reshape(x1.shape)
+    y_default = m(xt)
+    assert m.__dict__.get("_sliced") is None
+    m.enable_sliced_layout()
+    y_sliced = m(xt)
+    assert m.__dict__["_sliced"][1] is not None
+    assert rel_err(tensor_to_bits(y_sliced), vo.forward(L, x1), "f16") <= 1e-3
+    assert rel_err(tensor_to_bits(y_sliced), tensor_to_bits(y_default), "f16") <= 1e-3
+    x3 = torch.cat([xt, xt, xt], dim=1)
+    y3 = m(x3)   # three tokens: the gather kernel
+    assert torch.equal(y3[:, :1].view(torch.int16), y_default.view(torch.int16))
+    # new indices (another storage): the layout follows
+    L2 = vo.make_layer(2048, 512, seed=22, dist="llm", num_centroids=65536, num_res_centroids=256, bias=True)
+    m.indices.data = torch.from_numpy(L2.indices.copy()).to(dev).reshape(m.indices.shape)
+    L.indices = L2.indices
+    assert rel_err(tensor_to_bits(m(xt)), vo.forward(L, x1), "f16") <= 1e-3
+    m.enable_sliced_layout(False)
+    assert m._sliced_gemv() is None

@@ -357,7 +357,7 @@ int vptq_quant_gemm_supported(const VptqLayerDesc* d) {
 }
 
 int vptq_sliced_layout_supported(const VptqLayerDesc* d) {
-  return validate_layer(d) == VPTQ_OK && vptq::gemv_sliced_eligible(*d) ? 1 : 0;
+  return validate_layer(d) == VPTQ_OK && vptq::gemv_sliced_eligible(*d) ? vptq::gemv_sliced_slices(*d) : 0;
 }
 
 size_t vptq_quant_gemv_sliced_workspace_bytes(const VptqLayerDesc* d) {
@@ -370,14 +370,16 @@ int vptq_quant_gemv_sliced(const VptqLayerDesc* d, const VptqSlicedLayout* layou
   if (rc) return rc;
   if (!x || !y || !layout) return fail(VPTQ_E_NULL, "x / y / layout is NULL");
   if (!vptq::gemv_sliced_eligible(*d))
-    return fail(VPTQ_E_UNSUPPORTED, "the sliced layout serves v8-k65536-0 / -256 layers without a permutation, group_size <= 14336 / 14080");
+    return fail(VPTQ_E_UNSUPPORTED, "the sliced layout serves v8-k65536-0 / -256 layers without a permutation, group_size <= 32768");
   if (flags & (VPTQ_GEMV_EXACT | VPTQ_GEMV_FORCE_GENERIC))
     return fail(VPTQ_E_UNSUPPORTED, "the sliced path has the folded arithmetic only: use vptq_quant_gemv");
   const size_t need = vptq::gemv_sliced_workspace_bytes(*d);
   if (!workspace || workspace_bytes < need || (((uintptr_t)workspace) & 15) != 0)
     return fail(VPTQ_E_WORKSPACE, "workspace of %zu bytes (16-byte aligned) needed", need);
-  if (layout->rows_per_wave < 1 || layout->rows_per_wave > 64 || !layout->elems || !layout->blocks || !layout->first)
-    return fail(VPTQ_E_UNSUPPORTED, "sliced layout: rows_per_wave in [1, 64] and three tensors");
+  if (layout->rows_per_wave < 1 || layout->rows_per_wave > 64 || !layout->elems || !layout->blocks || !layout->first ||
+      (layout->n_slices != 0 ? layout->n_slices : 8) != vptq::gemv_sliced_slices(*d))
+    return fail(VPTQ_E_UNSUPPORTED, "sliced layout: rows_per_wave in [1, 64], three tensors, n_slices = %d for this layer",
+                vptq::gemv_sliced_slices(*d));
   if ((((uintptr_t)x) & 15) != 0) return fail(VPTQ_E_UNSUPPORTED, "x must be 16-byte aligned");
   const hipError_t e = vptq::launch_gemv_sliced(*d, *layout, x, y, flags, workspace, (hipStream_t)stream);
   return e == hipSuccess ? VPTQ_OK : hip_fail(e, "gemv_sliced launch");

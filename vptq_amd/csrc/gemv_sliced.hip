@@ -7,17 +7,17 @@
 // Why.  A 1 MiB codebook cannot live in LDS, so gemv_gather.hip gathers centroid rows from L2 with one
 // 16-byte load per index: every gather moves a 128-byte line for 16 useful bytes and the launch is
 // bound by the L2 -> L1 fill rate (39.6 us per 8192^2 layer, 0.06 of the HBM roofline).
-// Here the codebook is cut into 8 SLICES of 8192 entries (128 KiB = one workgroup's LDS) and, once per
+// Here the codebook is cut into 8 SLICES of 8192 entries (128 KiB of a workgroup's LDS; 16 slices of 4096 for
+// layers whose activations do not fit beside that: more than 14336 / 14080 columns) and, once per
 // layer (vptq_amd/utils/sliced.py; the on-disk tensors stay the state-dict contract), every row's
 // elements are bucketed by the slice of their index:
-//   elems  : for slice s = 0..7, for row n = 0..N-1: the row's elements whose index lies in slice s,
-//            in column order, padded to a multiple of the block (64 x elems_per_lane elements) with
-//            (column = G, local index = 0); one 32-bit word per element = column | (index & 8191) << 16
-//   blocks : [8][N] number of blocks of (s, n);  first : [8][N] index of its first block
+//   elems  : for slice s, for row n = 0..N-1: the row's elements whose index lies in slice s, padded to a
+//            multiple of 64 with (column = G, local index = 0); one 32-bit word per element =
+//            column | (index mod slice size) << 16; inside a (s, n) list the order is free - the builder picks
+//            one in which 16 consecutive elements hit different LDS bank groups
+//   blocks : [slices][N] number of 64-element blocks of (s, n);  first : [slices][N] index of its first block
 //   res    : (residual formats) one byte per element, same order and padding: its residual index; the 256-entry
 //            residual codebook sits in LDS beside the slice
-// (elems_per_lane = 4: one 16-byte load per lane and block - with one word per lane the launch was bound by
-// the number of load INSTRUCTIONS, its time proportional to blocks + queue depth per wave)
 // = 4 instead of 2 bytes per element (+ ~3 % padding): the layout costs 2x the packed indices in memory
 // on top of them and in HBM traffic per token.  A workgroup owns (slice, block of rows): it copies its
 // slice (LDS-DMA) and f16(scale * x) of all columns into LDS, then each wave streams the CONTIGUOUS
@@ -34,12 +34,11 @@ namespace vptq {
 
 constexpr int kSLThreads = 1024;
 constexpr int kSLWaves = kSLThreads / 64;
-constexpr int kSLSlices = 8;
-constexpr int kSLSliceEntries = 8192;
-constexpr uint32_t kSLTabBytes = kSLSliceEntries * 16;   // 128 KiB
-constexpr uint32_t kSLXOff = kSLTabBytes;                // staged activations: (G + 64) halves
-constexpr int kSLMaxG = 14336;                           // 128 KiB + 28 KiB + 192 B
-constexpr int kSLMaxGRes = 14080;                        // ... + the 4 KiB residual codebook: 160 KiB is full at 14240 columns
+// 8 slices of 8192 entries (128 KiB of LDS) while the staged activations fit beside them, else 16 slices of 4096
+// (64 KiB): 8 slices hold f16(s x) of 14336 columns (14080 with the 4 KiB residual codebook), 16 slices of 32768
+constexpr int kSLMaxSlices = 16;
+constexpr int kSLMaxG8 = 14336, kSLMaxG8Res = 14080, kSLMaxG16 = 32768;
+constexpr uint32_t kSLLdsLimit = 163840;
 // element words per lane in flight (queue depth = this / elems_per_lane blocks).  Same-box A/B with one word per
 // lane and block (profiles/r03/sliced_queue_ab.txt): depth 8 / 16 / 32 = 14.2 / 16.2 / 21.2 us per 8192^2 layer -
 // proportional to (blocks + depth) per wave: every step issues a load, also the `depth` steps past the end of a
@@ -82,9 +81,12 @@ static __device__ __forceinline__ void sl_for_range(F&& f) {
 template <int Q, typename F>
 static __device__ __forceinline__ void sl_for_slots(F&& f) { sl_for_range<0, Q>(f); }
 
-template <typename DT, int EPL, bool RES>
+template <typename DT, int NSL, bool RES>
 __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedParams P) {
-  static_assert(!RES || EPL == 1, "the residual byte stream is read one element per lane");
+  static_assert(NSL == 8 || NSL == 16, "slices");
+  constexpr int EPL = 1;   // element words per lane and block (2 and 4 - 8 / 16-byte loads - were measured: no difference)
+  constexpr uint32_t kSLTabBytes = (65536u / NSL) * 16u;   // this workgroup's slice of the codebook
+  constexpr uint32_t kSLXOff = kSLTabBytes;                // staged activations: (G + 64) halves
   typedef uint32_t evec_t __attribute__((ext_vector_type(EPL)));
   constexpr int kLoadsPerStep = RES ? 2 : 1;
   constexpr int kSLQueue = kSLQueueWords / EPL < 2 ? 2 : kSLQueueWords / EPL;   // blocks in flight per wave
@@ -95,7 +97,7 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedPar
   }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int s = (int)blockIdx.x & (kSLSlices - 1), rb = (int)blockIdx.x >> 3;
+  const int s = (int)blockIdx.x & (NSL - 1), rb = (int)blockIdx.x / NSL;
   const int N = P.N, G = P.G;
   const int rpw = P.rows_per_wave;
   const int row0 = (rb * kSLWaves + wave) * rpw;   // this wave's first row
@@ -113,14 +115,15 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedPar
     total = __builtin_amdgcn_readfirstlane(t);
   }
 
-  // ---- codebook slice into LDS by LDS-DMA: 128 x 1 KiB, 8 per wave (no registers; older than every
-  // load below, so the counted wait before the barrier covers it)
+  // ---- codebook slice into LDS by LDS-DMA: 1 KiB per instruction, 8 (4) per wave (no registers; older than
+  // every load below, so the counted wait before the barrier covers it)
   {
-    const uint64_t va = (uint64_t)(uintptr_t)as_global(P.cent) + (uint64_t)s * kSLTabBytes + (uint64_t)wave * 8192u +
+    constexpr uint32_t kPerWave = kSLTabBytes / kSLWaves;
+    const uint64_t va = (uint64_t)(uintptr_t)as_global(P.cent) + (uint64_t)s * kSLTabBytes + (uint64_t)wave * kPerWave +
                         (uint64_t)lane * 16u;
 #pragma unroll
-    for (int i = 0; i < ((VPTQ_SLICED_ABLATE & 2) ? 0 : 8); ++i) {
-      const uint32_t d = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)wave * 8192u + (uint32_t)i * 1024u));
+    for (int i = 0; i < ((VPTQ_SLICED_ABLATE & 2) ? 0 : (int)(kPerWave / 1024u)); ++i) {
+      const uint32_t d = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)wave * kPerWave + (uint32_t)i * 1024u));
       const uint64_t v = va + (uint64_t)(i * 1024);
       uint32_t keep_m0;   // (M0 belongs to the compiler: saved and restored inside the statement)
       asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
@@ -315,15 +318,19 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedPar
 }
 
 // ---- y[o] = sum_s partial[s][o] + bias[o]  (sum b x rides in slice 0's partial sums) --------
-template <typename DT>
+template <typename DT, int NSL>
 __global__ __launch_bounds__(256) void gemv_sliced_reduce(const float* __restrict__ partial, const uint16_t* __restrict__ bias,
                                                           void* __restrict__ y, int N8, int O, int out_f32) {
   const int o = blockIdx.x * 256 + threadIdx.x;
   if (o >= O) return;
-  float p[kSLSlices];
+  float p[NSL];
 #pragma unroll
-  for (int sl = 0; sl < kSLSlices; ++sl) p[sl] = partial[(size_t)sl * N8 + o];
-  float v = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+  for (int sl = 0; sl < NSL; ++sl) p[sl] = partial[(size_t)sl * N8 + o];
+#pragma unroll
+  for (int w = NSL / 2; w > 0; w >>= 1)   // (a fixed tree)
+#pragma unroll
+    for (int i = 0; i < w; ++i) p[i] = p[2 * i] + p[2 * i + 1];
+  float v = p[0];
   if (bias) v += DT::to_float(bias[o]);
   if (out_f32) ((float*)y)[o] = v;
   else ((uint16_t*)y)[o] = DT::from_float(v);
@@ -337,22 +344,49 @@ bool gemv_sliced_eligible(const VptqLayerDesc& d) {
          (d.num_res_centroids == 0 || res) && d.index_bits == 16 && (!res || d.res_bits == 8) &&
          d.weight_scale != nullptr && d.weight_bias != nullptr &&
          d.perm == nullptr && (d.group_size % 8) == 0 && d.group_size == d.in_features &&
-         d.group_size <= (res ? kSLMaxGRes : kSLMaxG) &&
+         d.group_size <= kSLMaxG16 &&
          (long long)d.row_words * 32 == (long long)d.group_size * (res ? 24 : 16) &&
          (((uintptr_t)d.centroids | (uintptr_t)d.res_centroids | (uintptr_t)d.weight_scale | (uintptr_t)d.weight_bias) & 15) == 0;
 }
 
+// slices a layout of this layer must have
+int gemv_sliced_slices(const VptqLayerDesc& d) {
+  return d.group_size <= (d.num_res_centroids == 256 ? kSLMaxG8Res : kSLMaxG8) ? 8 : 16;
+}
+
 size_t gemv_sliced_workspace_bytes(const VptqLayerDesc& d) {
-  return (size_t)kSLSlices * d.num_indices * 8 * sizeof(float);
+  return (size_t)gemv_sliced_slices(d) * d.num_indices * 8 * sizeof(float);
+}
+
+template <typename DT, int NSL>
+static hipError_t launch_sl(const SlicedParams& P, bool res, uint32_t lds, hipStream_t st) {
+  static std::atomic<bool> attr_set[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (!attr_set[dev]) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemv_sliced_kernel<DT, NSL, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSLLdsLimit);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)gemv_sliced_kernel<DT, NSL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSLLdsLimit);
+    if (e != hipSuccess) return e;
+    attr_set[dev] = true;
+  }
+  const dim3 grid(NSL * P.n_rowblocks), block(kSLThreads);
+  if (res) hipLaunchKernelGGL((gemv_sliced_kernel<DT, NSL, true>), grid, block, lds, st, P);
+  else hipLaunchKernelGGL((gemv_sliced_kernel<DT, NSL, false>), grid, block, lds, st, P);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((gemv_sliced_reduce<DT, NSL>), dim3((P.O + 255) / 256), dim3(256), 0, st, (const float*)P.partial, P.bias,
+                     P.y, P.N * 8, P.O, P.out_f32);
+  return hipGetLastError();
 }
 
 hipError_t launch_gemv_sliced(const VptqLayerDesc& d, const VptqSlicedLayout& L, const void* x, void* y, int flags,
                               void* ws, hipStream_t st) {
-  const int epl = L.elems_per_lane == 0 ? 1 : L.elems_per_lane;
   const bool res = d.num_res_centroids == 256;
-  if (res && (epl != 1 || !L.res)) return hipErrorInvalidValue;
-  if (L.rows_per_wave < 1 || L.rows_per_wave > kSLMaxRowsPerWave || !L.elems || !L.blocks || !L.first || !ws ||
-      (((uintptr_t)x) & 15) != 0 || (epl != 1 && epl != 2 && epl != 4) || (((uintptr_t)L.elems) & 15) != 0)
+  const int nsl = gemv_sliced_slices(d);
+  if ((L.n_slices != 0 ? L.n_slices : 8) != nsl || (L.elems_per_lane != 0 && L.elems_per_lane != 1) || (res && !L.res) ||
+      L.rows_per_wave < 1 || L.rows_per_wave > kSLMaxRowsPerWave || !L.elems || !L.blocks || !L.first || !ws ||
+      (((uintptr_t)x) & 15) != 0 || (((uintptr_t)L.elems) & 3) != 0)
     return hipErrorInvalidValue;
   SlicedParams P = {};
   P.elems = (const uint32_t*)L.elems;
@@ -372,44 +406,11 @@ hipError_t launch_gemv_sliced(const VptqLayerDesc& d, const VptqSlicedLayout& L,
   const int rows_per_wg = kSLWaves * L.rows_per_wave;
   P.n_rowblocks = (d.num_indices + rows_per_wg - 1) / rows_per_wg;
   P.out_f32 = (flags & VPTQ_GEMV_OUT_F32) ? 1 : 0;
-  const uint32_t lds = kSLXOff + (uint32_t)(d.group_size + 64) * 2u + 64u + (res ? 4096u : 0u);
+  const uint32_t lds = (65536u / (uint32_t)nsl) * 16u + (uint32_t)(d.group_size + 64) * 2u + 64u + (res ? 4096u : 0u);
+  if (lds > kSLLdsLimit) return hipErrorInvalidValue;
   const bool f16 = d.dtype == VPTQ_DTYPE_F16;
-  const void* kern = nullptr;
-#define SL_PICK(E, R) (f16 ? (const void*)gemv_sliced_kernel<F16, E, R> : (const void*)gemv_sliced_kernel<BF16, E, R>)
-  kern = res ? SL_PICK(1, true) : epl == 1 ? SL_PICK(1, false) : epl == 2 ? SL_PICK(2, false) : SL_PICK(4, false);
-#undef SL_PICK
-  static std::atomic<bool> attr_set[64];
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-  if (!attr_set[dev]) {
-    const int max_lds = 163840;
-    const void* all[8] = {(const void*)gemv_sliced_kernel<F16, 1, false>, (const void*)gemv_sliced_kernel<F16, 2, false>,
-                          (const void*)gemv_sliced_kernel<F16, 4, false>, (const void*)gemv_sliced_kernel<BF16, 1, false>,
-                          (const void*)gemv_sliced_kernel<BF16, 2, false>, (const void*)gemv_sliced_kernel<BF16, 4, false>,
-                          (const void*)gemv_sliced_kernel<F16, 1, true>, (const void*)gemv_sliced_kernel<BF16, 1, true>};
-    for (const void* k : all) {
-      const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-      if (e != hipSuccess) return e;
-    }
-    attr_set[dev] = true;
-  }
-  const dim3 grid(kSLSlices * P.n_rowblocks), block(kSLThreads);
-  {
-    SlicedParams Pc = P;
-    void* args[] = {(void*)&Pc};
-    const hipError_t e = hipLaunchKernel(kern, grid, block, args, lds, st);
-    if (e != hipSuccess) return e;
-  }
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return e;
-  const dim3 rgrid((d.out_features + 255) / 256);
-  if (f16)
-    hipLaunchKernelGGL(gemv_sliced_reduce<F16>, rgrid, dim3(256), 0, st, (const float*)ws, P.bias, y,
-                       d.num_indices * 8, d.out_features, P.out_f32);
-  else
-    hipLaunchKernelGGL(gemv_sliced_reduce<BF16>, rgrid, dim3(256), 0, st, (const float*)ws, P.bias, y,
-                       d.num_indices * 8, d.out_features, P.out_f32);
-  return hipGetLastError();
+  if (nsl == 8) return f16 ? launch_sl<F16, 8>(P, res, lds, st) : launch_sl<BF16, 8>(P, res, lds, st);
+  return f16 ? launch_sl<F16, 16>(P, res, lds, st) : launch_sl<BF16, 16>(P, res, lds, st);
 }
 
 }  // namespace vptq

@@ -54,6 +54,7 @@ hipError_t launch_gemv_lds_v2(const VptqV2Desc& d, const void* x, void* y, int t
 
 // gemv_sliced.hip - v8-k65536-0, one token, over the load-time derived sliced layout (LDS-local gathers)
 bool gemv_sliced_eligible(const VptqLayerDesc& d);
+int gemv_sliced_slices(const VptqLayerDesc& d);
 size_t gemv_sliced_workspace_bytes(const VptqLayerDesc& d);
 hipError_t launch_gemv_sliced(const VptqLayerDesc& d, const VptqSlicedLayout& L, const void* x, void* y, int flags,
                               void* ws, hipStream_t st);

@@ -4,8 +4,8 @@
 
 The reference gathers centroid rows from the 1 MiB codebook through the caches for every index
 (csrc/kernels/quant_gemv.cuh:11-186); on MI355X that is bound by the L2 -> L1 fill rate (39.6 us per 8192^2
-layer).  Bucketing every row's elements ONCE by the top 3 bits of their index lets a
-workgroup keep its 8192-entry slice of the codebook in LDS.  The state-dict tensors are untouched (they stay
+layer).  Bucketing every row's elements ONCE by the top 3 (wide layers: 4) bits of their index
+lets a workgroup keep its 8192- (4096-) entry slice of the codebook in LDS.  The state-dict tensors are untouched (they stay
 the contract, and the many-token / dequant paths keep using them); the derived tensors cost 2x (T = 16) / 1.7x
 (T = 24: 5 instead of 3 bytes per element) the packed indices in device memory on top.
 
@@ -20,17 +20,18 @@ import torch
 
 from vptq_amd import _backend as B
 
-SLICES = 8
-SLICE_BITS = 13
+INDEX_BITS = 16   # 65536 main centroids
 
 
-def build_sliced_layout(indices: torch.Tensor, group_size: int, elems_per_lane: int = 1, residual: bool = False):
+def build_sliced_layout(indices: torch.Tensor, group_size: int, slices: int = 8, residual: bool = False):
     """indices: the layer's packed int32 `indices` [1, N, row_words]: a little-endian bit stream per row, element g
     at bits [T g, T g + T) with value (residual index << 16) | main index (vptq/utils/pack.py:26-89); T = 16 without
-    a residual codebook, 24 with 256 residual centroids.  Returns (elems uint32-as-int32 [blocks * 64 *
-    elems_per_lane], blocks int32 [8, N], first int32 [8, N], res uint8 [like elems] or None) as described in
-    include/vptq_hip.h (VptqSlicedLayout)."""
+    a residual codebook, 24 with 256 residual centroids.  slices: 8 or 16 (vptq_sliced_layout_supported tells).
+    Returns (elems uint32-as-int32 [blocks * 64], blocks int32 [slices, N], first int32 [slices, N], res uint8
+    [like elems] or None) as described in include/vptq_hip.h (VptqSlicedLayout)."""
     assert indices.dtype == torch.int32 and indices.dim() == 3 and indices.shape[0] == 1
+    assert slices in (8, 16)
+    SLICES, SLICE_BITS = slices, INDEX_BITS - (3 if slices == 8 else 4)
     dev = indices.device
     N, G = indices.shape[1], group_size
     nbytes = 3 if residual else 2
@@ -57,7 +58,7 @@ def build_sliced_layout(indices: torch.Tensor, group_size: int, elems_per_lane: 
     counts = torch.zeros(N, SLICES, dtype=torch.int64, device=dev)
     counts.scatter_add_(1, sl, torch.ones_like(sl))
     seg_start = torch.cumsum(counts, 1) - counts                                        # first position of (n, s) in the sorted row
-    bs = 64 * elems_per_lane                                                            # elements per block
+    bs = 64                                                                             # elements per block
     blocks = (counts + bs - 1) // bs                                                    # [N, 8]
     blocks_sn = blocks.t().contiguous()                                                 # [8, N]
     first_sn = (torch.cumsum(blocks_sn.reshape(-1), 0) - blocks_sn.reshape(-1)).reshape(SLICES, N)
@@ -76,30 +77,30 @@ def build_sliced_layout(indices: torch.Tensor, group_size: int, elems_per_lane: 
     return elems32, blocks_sn.to(torch.int32).contiguous(), first_sn.to(torch.int32).contiguous(), res
 
 
-def rows_per_wave_for(n_rows: int, workgroups: int = 256) -> int:
-    """consecutive rows per wave so that 8 slices x row blocks of 16 waves give about `workgroups` workgroups"""
-    r = max(1, (n_rows * SLICES + 16 * workgroups - 1) // (16 * workgroups))
+def rows_per_wave_for(n_rows: int, slices: int = 8, workgroups: int = 256) -> int:
+    """consecutive rows per wave so that slices x row blocks of 16 waves give about `workgroups` workgroups"""
+    r = max(1, (n_rows * slices + 16 * workgroups - 1) // (16 * workgroups))
     return min(r, 64)
 
 
 class SlicedGemv:
     """One-token forward of a v8-k65536-0 `VQuantLinear` over its sliced layout."""
 
-    def __init__(self, layer, rows_per_wave: int = 0, elems_per_lane: int = 1):
+    def __init__(self, layer, rows_per_wave: int = 0):
         self.layer = layer
         cache = layer._descriptor()
         self.desc, self.dev = cache[1], cache[3]
-        if not B.lib().vptq_sliced_layout_supported(self.desc):
+        self.slices = B.lib().vptq_sliced_layout_supported(self.desc)
+        if not self.slices:
             raise ValueError("the sliced layout serves v8-k65536-0 / v8-k65536-256 layers without a permutation, "
-                             "group_size <= 14336 (14080 with the residual codebook)")
+                             "group_size <= 32768")
         residual = bool(layer.enable_residual)
-        if residual and elems_per_lane != 1:
-            raise ValueError("residual formats: one element word per lane and block")
         self.elems, self.blocks, self.first, self.res = build_sliced_layout(layer.indices.data, layer.group_size,
-                                                                            elems_per_lane, residual)
+                                                                            self.slices, residual)
         self.layout = B.SlicedLayout(self.elems.data_ptr(), self.blocks.data_ptr(), self.first.data_ptr(),
                                      self.res.data_ptr() if residual else None,
-                                     rows_per_wave or rows_per_wave_for(self.blocks.shape[1]), elems_per_lane)
+                                     rows_per_wave or rows_per_wave_for(self.blocks.shape[1], self.slices), 1,
+                                     self.slices, 0)
         nb = B.lib().vptq_quant_gemv_sliced_workspace_bytes(self.desc)
         self.ws = torch.empty(nb, dtype=torch.uint8, device=self.dev)
         self.extra_bytes = self.elems.numel() * (5 if residual else 4) + self.blocks.numel() * 8
