@@ -129,6 +129,46 @@ def prefill_extra(dev, tokens=8192):
     return out
 
 
+def k65536_extra(lib, B, dev, H, steps, warmup, regions, R=8):
+    """v8-k65536-256 (T = 24 bits, the format of most published checkpoints), H x H, one token: the library's default
+    route (gemv_gather_kernel: centroid gathers through the caches) and the one-token GEMV over the load-time derived
+    sliced layout (gemv_sliced.hip, VQuantLinear.enable_sliced_layout) on the same ring of R distinct layers."""
+    from vptq_amd.utils.sliced import SlicedGemv
+    layers = make_ring(H, R, dev, seed=4321, k=65536, kr=256)
+    x = torch.randn(1, 1, H, device=dev, generator=torch.Generator(device=dev).manual_seed(7)).half()
+    ys = [torch.empty(1, 1, H, device=dev, dtype=torch.float16) for _ in range(R)]
+    descs = [layer_desc(m) for m in layers]
+    sls = [SlicedGemv(m) for m in layers]
+
+    def default_pass():
+        sp = torch.cuda.current_stream().cuda_stream
+        for i in range(R):
+            rc = lib.vptq_quant_gemv(descs[i][0], x.data_ptr(), ys[i].data_ptr(), 1, 0, None, 0, sp)
+            assert rc == 0, lib.vptq_last_error()
+
+    def sliced_pass():
+        for i in range(R):
+            sls[i](x, ys[i])
+    ab = alg_bytes(H, H, 65536, 256, 1)
+    out = {"what": f"VQuantLinear {H}x{H} v=8 k=65536+256 (3-bit, T = 24), ring of {R} layers; GB/s of the PACKED format's "
+                   "algorithmic bytes for both routes (the sliced layout reads 5 instead of 3 bytes per element)"}
+    for key, fn in (("default", default_pass), ("sliced_layout", sliced_pass)):
+        t = Timer(dev).run(fn, steps, warmup, regions)
+        us = t["event_ms"] * 1e3 / (steps * R)
+        out[key] = {"us_per_layer": us, "GBps": ab / us / 1e3, "frac_of_8TBps": ab / us / 1e3 / 8000.0}
+    out["default"]["kernel"] = lib.vptq_quant_gemv_kernel_name(descs[0][0], 1, 0).decode()
+    out["sliced_layout"]["kernel"] = "gemv_sliced_kernel + gemv_sliced_reduce"
+    out["sliced_layout"]["layout_MiB_per_layer"] = sls[0].extra_bytes / 2**20
+    out["sliced_layout"]["packed_index_MiB_per_layer"] = layers[0].indices.numel() * 4 / 2**20
+    sliced_pass()
+    torch.cuda.synchronize()
+    ref = layers[-1](x)
+    out["sliced_vs_default_rel_diff"] = ((ys[-1].float() - ref.float()).abs().max() / ref.float().abs().max()).item()
+    del layers, sls
+    torch.cuda.empty_cache()
+    return out
+
+
 def shard_ring(total_layers, rank, world):
     """Layer-parallel sharding: independent VQuantLinear layers are dealt round-robin to
     ranks; no rank ever needs another rank's layer (no data-path collective)."""
@@ -778,6 +818,7 @@ def main():
         ex["tokens16_bf16"]["what"] = ("16 bf16 tokens in one pass over the indices (gemm_k256t: transposing gathers -> 16x16x32 MFMA, "
                                        "tokens = M; + its pre-pass); round 2: 4 launches of 4 tokens, 39 us")
         ex["k8192_r256"]["what"] = "k = 8192 + 256 (T = 21 bits), LDS-resident codebooks"
+        ex["k65536_r256"] = k65536_extra(lib, B, dev, H, st, wu, rg)
         tr = bench_tp_row(lib, B, dev, Timer(dev), 0, 1, a.tp_layers, 0, st, wu, rg)
         ex["tp_row_n1"] = {"what": f"Llama-3-70B shaped decoder layers (x{a.tp_layers}, the ring of --gpus N) on ONE GPU "
                                    "through the row-parallel code path (world size 1): the strong-scaling baseline of --gpus N",

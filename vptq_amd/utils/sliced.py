@@ -103,17 +103,32 @@ class SlicedGemv:
                                      self.slices, 0)
         nb = B.lib().vptq_quant_gemv_sliced_workspace_bytes(self.desc)
         self.ws = torch.empty(nb, dtype=torch.uint8, device=self.dev)
+        self._fn = B.lib().vptq_quant_gemv_sliced
+        self._lay_ref = C.byref(self.layout)
+        self._ws_ptr, self._ws_bytes = self.ws.data_ptr(), self.ws.numel()
+        self._dtype = cache[7]
+        self._dev_index = cache[8]
         self.extra_bytes = self.elems.numel() * (5 if residual else 4) + self.blocks.numel() * 8
 
     def __call__(self, x: torch.Tensor, out: torch.Tensor = None, flags: int = 0) -> torch.Tensor:
-        x = self.layer._check_activation(x)
-        if x.numel() != self.layer.in_features:
-            raise ValueError("the sliced path takes one token")
+        lay = self.layer
+        # (the checks of VQuantLinear._check_activation, against cached values: this is the per-token path)
+        if x.shape[-1] != lay.in_features or x.numel() != lay.in_features:
+            raise ValueError("the sliced path takes one token of in_features values")
+        if x.dtype != self._dtype or x.device != self.dev:
+            x = lay._check_activation(x)
+        if not x.is_contiguous():
+            x = x.contiguous()
         if out is None:
-            dt = torch.float32 if (flags & B.GEMV_OUT_F32) else x.dtype
-            out = torch.empty(x.shape[:-1] + (self.layer.out_features,), dtype=dt, device=self.dev)
-        with torch.cuda.device(self.dev):
-            B.check(B.lib().vptq_quant_gemv_sliced(self.desc, C.byref(self.layout), x.data_ptr(), out.data_ptr(), flags,
-                                                   self.ws.data_ptr(), self.ws.numel(), B.current_stream_ptr(self.dev)),
-                    "vptq_quant_gemv_sliced")
+            out = torch.empty(x.shape[:-1] + (lay.out_features,), dtype=torch.float32 if (flags & B.GEMV_OUT_F32) else self._dtype,
+                              device=self.dev)
+        if torch.cuda.current_device() != self._dev_index:
+            with torch.cuda.device(self.dev):
+                rc = self._fn(self.desc, self._lay_ref, x.data_ptr(), out.data_ptr(), flags, self._ws_ptr, self._ws_bytes,
+                              B.current_stream_ptr(self.dev))
+        else:
+            rc = self._fn(self.desc, self._lay_ref, x.data_ptr(), out.data_ptr(), flags, self._ws_ptr, self._ws_bytes,
+                          B.current_stream_ptr(self.dev))
+        if rc:
+            B.check(rc, "vptq_quant_gemv_sliced")
         return out
