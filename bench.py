@@ -169,6 +169,52 @@ def k65536_extra(lib, B, dev, H, steps, warmup, regions, R=8):
     return out
 
 
+class SclkSampler:
+    """Shader clock of this GPU during the timed regions (rule DVFS in or out as the box-to-box
+    spread): a thread reads the current level of pp_dpm_sclk every 20 ms.  None where sysfs does not offer it."""
+
+    def __init__(self, dev_index=0):
+        import glob
+        self.paths = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+        self.path = self.paths[dev_index] if dev_index < len(self.paths) else None
+        self.samples, self._stop, self._thread = [], False, None
+
+    def _read(self):
+        try:
+            for line in open(self.path):
+                if line.rstrip().endswith("*"):
+                    return float(line.split(":")[1].lower().replace("mhz", "").replace("*", "").strip())
+        except Exception:
+            return None
+        return None
+
+    def __enter__(self):
+        if self.path is not None:
+            import threading
+
+            def loop():
+                while not self._stop:
+                    v = self._read()
+                    if v is not None:
+                        self.samples.append(v)
+                    time.sleep(0.02)
+            self._thread = threading.Thread(target=loop, daemon=True)
+            self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop = True
+        if self._thread is not None:
+            self._thread.join(timeout=1.0)
+
+    def summary(self):
+        if not self.samples:
+            return None
+        s = sorted(self.samples)
+        return {"samples": len(s), "min_mhz": s[0], "median_mhz": s[len(s) // 2], "max_mhz": s[-1],
+                "source": "pp_dpm_sclk (current level), every 20 ms during warm-up and the timed regions"}
+
+
 def shard_ring(total_layers, rank, world):
     """Layer-parallel sharding: independent VQuantLinear layers are dealt round-robin to
     ranks; no rank ever needs another rank's layer (no data-path collective)."""
@@ -724,9 +770,10 @@ def main():
     tp_split = "out" if mode == "tp" else None
     if mode == "tp" and H // 8 % world:
         raise SystemExit("tp mode needs the vector-row count divisible by the world size")
-    r, layers, x, ys, keeps = bench_ring(lib, B, dev, timer, H, mode if mode in ("grouped", "chain", "chain_dep") else "single",
-                                         flags, a.steps, a.warmup, a.regions, rank=rank, world=world, group=a.group,
-                                         ring=a.ring, tp_split=tp_split, prefetch=a.prefetch, chain=a.chain)
+    with SclkSampler(local_rank) as sclk:
+        r, layers, x, ys, keeps = bench_ring(lib, B, dev, timer, H, mode if mode in ("grouped", "chain", "chain_dep") else "single",
+                                             flags, a.steps, a.warmup, a.regions, rank=rank, world=world, group=a.group,
+                                             ring=a.ring, tp_split=tp_split, prefetch=a.prefetch, chain=a.chain)
     chain_mode = mode in ("chain", "chain_dep")
     mode_name = (f"chain{min(a.chain, 32, r['ring'])}" if mode == "chain" else mode)
     out = {
@@ -750,6 +797,7 @@ def main():
                                    "RCCL all-gather per layer") if mode == "tp" else
                                   f"{world} x independent rings (no collective)"},
         "regions_ms_per_step": r["regions_ms_per_step"],
+        "sclk_during_timed_regions": sclk.summary(),
         "roofline": {"bound": "hbm", "achieved": r["achieved"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": r["achieved"] / HBM_PEAK_GBPS, "traffic": None,
                      "bytes_per_launch": r["bytes_per_launch"], "us_per_launch": r["us_per_launch"],

@@ -788,7 +788,11 @@ FMT_KERNELS = {"t1_k8192_r256_8192x1024": "gemv_lds_mfma_kernel", "t1_k4096_r512
                "t1_k8192_r256_bf16": "gemv_lds_mfma_kernel", "t8_k65536_r256": "gemv_gather_kernel",
                "t5_k65536_r65536_perm": "gemv_gather_kernel", "t7_v6_k4096_r16": "gemv_gatherx_kernel",
                "t1_v10_k4096_r256": "gemv_gatherx_kernel", "t2_v2_k256_r16_perm": "gemv_gatherx_kernel",
-               "t8_v4_k4096_r256_bf16": "gemv_gatherx_kernel"}
+               "t8_v4_k4096_r256_bf16": "gemv_gatherx_kernel",
+               # round 3: one-token fixtures of the k = 65536 formats (also served by gemv_sliced over the derived layout:
+               # tests/test_gemv_sliced_gpu.py)
+               "t1_k65536_r0_4096x4096": "gemv_gather_kernel", "t1_k65536_r0_bf16": "gemv_gather_kernel",
+               "t1_k65536_r256_4096x4096": "gemv_gather_kernel", "t1_k65536_r256_bf16": "gemv_gather_kernel"}
 
 
 @pytest.mark.parametrize("name", fmt_names())

@@ -12,6 +12,17 @@ timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OU
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/pmc_sq -o bench -- $B --steps 5 --warmup 2 > /dev/null 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVES SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/pmc_sq2 -o bench -- $B --steps 5 --warmup 2 > /dev/null 2>&1
 cd $R
+python - <<'PY'
+import csv, json, os, statistics
+out = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out", "r3bench2")
+rows = [r for r in csv.DictReader(open(os.path.join(out, "stats", "bench_kernel_trace.csv"))) if "gemv_k256c_kernel" in r["Kernel_Name"]]
+d = sorted((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows)
+json.dump({"kernel": "gemv_k256c_kernel (one dispatch = 32 layers)", "dispatches": len(d), "mean_us": statistics.mean(d),
+           "median_us": statistics.median(d), "min_us": d[0], "max_us": d[-1], "p10_us": d[len(d) // 10], "p90_us": d[(9 * len(d)) // 10],
+           "source": "rocprofv3 --kernel-trace: End_Timestamp - Start_Timestamp per dispatch of the stats run"},
+          open(os.path.join(out, "bench_h8192_chain_kernel_durations.json"), "w"), indent=1)
+print(open(os.path.join(out, "bench_h8192_chain_kernel_durations.json")).read())
+PY
 rm -f $OUT/*/bench_kernel_trace.csv $OUT/*/bench_agent_info.csv
 python tools/pmc_summary.py $OUT $OUT/bench_h8192_chain_pmc_summary.json
 cut -c1-200 $OUT/stats/bench_kernel_stats.csv | head -4
