@@ -1,4 +1,5 @@
 """vptq.AutoModelForCausalLM.from_pretrained on a synthetic checkpoint (CPU: structure + tensors)."""
+import pytest
 import torch
 
 import vptq_amd
@@ -56,3 +57,21 @@ def test_loader_rejects_non_vptq_and_missing(tmp_path):
     json.dump(cfg, open(tmp_path / "config.json", "w"))
     with pytest.raises(ValueError, match="quantization_config"):
         vptq_amd.AutoModelForCausalLM.from_pretrained(str(tmp_path), device="cpu")
+
+
+def test_loader_device_map_is_honoured_or_refused(tmp_path):
+    """accelerate's multi-device placement (reference vptq/layers/model_base.py:165-194) is not carried over:
+    a device_map that names one device is honoured, one that spreads the model is refused, nothing is silently
+    swallowed"""
+    import warnings
+    write_tiny_checkpoint(str(tmp_path))
+    m = vptq_amd.AutoModelForCausalLM.from_pretrained(str(tmp_path), device_map="cpu")
+    assert next(m.parameters()).device.type == "cpu"
+    m = vptq_amd.AutoModelForCausalLM.from_pretrained(str(tmp_path), device_map={"": "cpu"})
+    assert next(m.parameters()).device.type == "cpu"
+    with pytest.raises(NotImplementedError):
+        vptq_amd.AutoModelForCausalLM.from_pretrained(str(tmp_path), device_map={"model.layers.0": "cuda:0", "lm_head": "cuda:1"})
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        vptq_amd.AutoModelForCausalLM.from_pretrained(str(tmp_path), device="cpu", low_cpu_mem_usage=True)
+    assert any("ignores" in str(x.message) for x in w)

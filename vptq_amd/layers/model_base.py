@@ -66,6 +66,22 @@ class AutoModelForCausalLM:
         import transformers
         from safetensors.torch import load_file
 
+        # accelerate's layer placement over several GPUs (reference vptq/layers/model_base.py:165-194) is not
+        # carried over: a device_map that asks for it is refused instead of being swallowed by **kwargs
+        dm = kwargs.pop("device_map", None)
+        if isinstance(dm, dict) and len({str(v) for v in dm.values()}) > 1:
+            raise NotImplementedError("device_map places the model on several devices: this loader puts a model on ONE "
+                                      "device (pass device=...); shard layers with vptq_amd.utils.shard for tensor parallelism")
+        if isinstance(dm, dict) and dm and device is None:
+            device = str(next(iter(dm.values())))
+        if isinstance(dm, str) and dm not in ("auto", "balanced", "sequential", "balanced_low_0") and device is None:
+            device = dm   # ("cuda:1", "cpu", ...)
+        if isinstance(dm, str) and dm in ("balanced", "sequential", "balanced_low_0") and torch.cuda.device_count() > 1:
+            raise NotImplementedError(f"device_map='{dm}' (multi-GPU placement by accelerate) is not supported: one device per model")
+        # ("auto" on this loader = the one device chosen below, what accelerate does when the model fits one GPU)
+        if kwargs:
+            import warnings
+            warnings.warn(f"vptq_amd.AutoModelForCausalLM.from_pretrained ignores {sorted(kwargs)}", stacklevel=2)
         path = str(pretrained_model_name_or_path)
         if not os.path.isdir(path):
             raise FileNotFoundError(
