@@ -175,12 +175,20 @@ class SclkSampler:
 
     def __init__(self, dev_index=0):
         import glob
-        self.paths = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
-        self.path = self.paths[dev_index] if dev_index < len(self.paths) else None
+        # the measured shader clock (hwmon freq1_input, Hz) where the driver offers it; else the DPM level table
+        # (pp_dpm_sclk: the starred level - on MI300-class parts that is a coarse state, not the live clock)
+        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device"))
+        cards = [c for c in cards if os.path.exists(os.path.join(c, "pp_dpm_sclk"))]
+        self.card = cards[dev_index] if dev_index < len(cards) else None
+        hw = sorted(glob.glob(os.path.join(self.card, "hwmon", "hwmon*", "freq1_input"))) if self.card else []
+        self.path = hw[0] if hw else (os.path.join(self.card, "pp_dpm_sclk") if self.card else None)
+        self.kind = "hwmon freq1_input" if hw else "pp_dpm_sclk (starred level)"
         self.samples, self._stop, self._thread = [], False, None
 
     def _read(self):
         try:
+            if self.kind.startswith("hwmon"):
+                return float(open(self.path).read().strip()) / 1e6
             for line in open(self.path):
                 if line.rstrip().endswith("*"):
                     return float(line.split(":")[1].lower().replace("mhz", "").replace("*", "").strip())
@@ -212,7 +220,7 @@ class SclkSampler:
             return None
         s = sorted(self.samples)
         return {"samples": len(s), "min_mhz": s[0], "median_mhz": s[len(s) // 2], "max_mhz": s[-1],
-                "source": "pp_dpm_sclk (current level), every 20 ms during warm-up and the timed regions"}
+                "source": f"{self.kind}, every 20 ms during warm-up and the timed regions"}
 
 
 def shard_ring(total_layers, rank, world):

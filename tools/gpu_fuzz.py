@@ -25,6 +25,7 @@ from oracle import vptq_oracle as vo  # noqa: E402  (checker only)
 from _cases import rel_err  # noqa: E402
 from _gpu_util import spec_to_module, bits_to_tensor, tensor_to_bits, gemv_abi, kernel_name  # noqa: E402
 
+EXACT = 4
 FLAGS = {"default": 0, "exact": 4, "mfma": 8, "mfma+exact": 12, "valu": 16, "valu+exact": 20}
 
 
@@ -137,6 +138,52 @@ def fuzz_adversarial(a, dev):
         print(f"  {k:22s} gated={int(w['gated'])} " + " ".join(f"{n}={v:.2e}" for n, v in w.items() if n != "gated"))
 
 
+def fuzz_chains(a, dev):
+    """random chains through the persistent launch (vptq_quant_gemv_chain / gemv_k256c_kernel): 2-14 layers of random
+    shapes (partial sweeps / row groups, more or fewer row groups than workgroups, bias), independent and dependent,
+    every layer against the one-launch-per-layer EXACT kernel (<= tol) and - same chain called twice - bit-identical"""
+    from vptq_amd.ops.chain import GemvChain
+    from vptq_amd import _backend as B
+    rng = np.random.default_rng(a.seed)
+    dt = a.dtype
+    tol = 1e-3 if dt == "f16" else 8e-3
+    CHAIN = B.GEMV_FORCE_MFMA   # the chain kernel also where the layers do not fill the device
+    worst = 0.0
+    for c in range(a.cases):
+        dependent = bool(rng.integers(0, 3) == 0)
+        n = int(rng.integers(2, 15))
+        if dependent:
+            dims = [8 * int(rng.integers(16, 700)) for _ in range(n + 1)]
+            shapes = [(dims[i], dims[i + 1]) for i in range(n)]
+        else:
+            shapes = []
+            for _ in range(n):
+                I = int(rng.choice([8 * int(rng.integers(16, 1200)), 2048 * int(rng.integers(1, 5)), 2048 * int(rng.integers(1, 5)) + 8]))
+                O = int(rng.choice([8 * int(rng.integers(1, 120)), 8 * int(rng.integers(120, 1100))]))
+                shapes.append((I, O))
+        Ls = [vo.make_layer(I, O, dist="llm", seed=7000 + 31 * c + i, dtype=dt, bias=bool(rng.integers(0, 2))) for i, (I, O) in enumerate(shapes)]
+        ms = [spec_to_module(L, dev) for L in Ls]
+        xs = [bits_to_tensor(vo.from_f32(rng.standard_normal((1, 1, I)).astype(np.float32), dt), dt, dev).reshape(1, 1, I)
+              for (I, _) in shapes]
+        chain = GemvChain(ms, dependent=dependent)
+        name = chain.kernel_name(1, CHAIN)
+        ys = chain([xs[0]] if dependent else xs, flags=CHAIN)
+        torch.cuda.synchronize()
+        ys2 = chain([xs[0]] if dependent else xs, flags=CHAIN)
+        torch.cuda.synchronize()
+        errs = []
+        xin = xs[0]
+        for i, (m, y, y2) in enumerate(zip(ms, ys, ys2)):
+            assert torch.equal(y.view(torch.int16), y2.view(torch.int16)), (c, i, "not reproducible")
+            ref = gemv_abi(m, xin if dependent else xs[i], EXACT)
+            errs.append(rel_err(tensor_to_bits(y), tensor_to_bits(ref), dt))
+            xin = y
+        worst = max(worst, max(errs))
+        print(f"case {c:3d} {'dep' if dependent else 'ind'} n={n:2d} {name}: max err {max(errs):.2e}  shapes {shapes[:3]}...", flush=True)
+        assert max(errs) <= tol, (c, errs, shapes)
+    print(f"worst: {worst:.2e}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=40)
@@ -145,8 +192,11 @@ def main():
     ap.add_argument("--formats", action="store_true", help="random index formats instead of the canonical one")
     ap.add_argument("--lds-tall", action="store_true", help="tall layers of the LDS-resident formats (gemv_lds_mfma_kernel)")
     ap.add_argument("--adversarial", action="store_true", help="families built against the folded arithmetic")
+    ap.add_argument("--chains", action="store_true", help="random chains through the persistent chain launch")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
+    if a.chains:
+        return fuzz_chains(a, dev)
     if a.adversarial:
         return fuzz_adversarial(a, dev)
     if a.lds_tall:

@@ -5,8 +5,9 @@ cd $R
 timeout 900 python bench.py 2> $OUT/bench_stderr.txt | tail -1 > $OUT/bench_h8192_chain.json
 cut -c1-1500 $OUT/bench_h8192_chain.json; tail -3 $OUT/bench_stderr.txt
 B="python $R/bench.py --no-cpu-baseline --no-extras --regions 1"
+BS="python $R/bench.py --no-cpu-baseline --no-extras"   # the stats pass: the bench's own steps / regions (1000+ dispatches)
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- $B --steps 100 --warmup 10 > /dev/null 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- $BS > $OUT/bench_under_rocprofv3.json 2> /dev/null
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o bench -- $B --steps 5 --warmup 2 > /dev/null 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o bench -- $B --steps 5 --warmup 2 > /dev/null 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/pmc_sq -o bench -- $B --steps 5 --warmup 2 > /dev/null 2>&1
