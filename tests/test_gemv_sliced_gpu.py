@@ -137,14 +137,25 @@ def test_sliced_layout_in_a_hipgraph(dev):
 
 
 def test_module_forward_takes_the_sliced_layout_when_enabled(dev):
-    """VQuantLinear.enable_sliced_layout(): one-token calls go through the derived layout, everything else (several
-    tokens, dequant) through the state-dict tensors as before; an in-place change of the indices rebuilds it"""
+    """VQuantLinear.enable_sliced_layout() - the default (VPTQ_SLICED_LAYOUT=auto) while the layout leaves a quarter
+    of the device memory free: one-token calls go through the derived layout, everything else (several tokens,
+    dequant) through the state-dict tensors as before; an in-place change of the indices rebuilds it"""
+    import vptq_amd.layers.vqlinear as vq
+    L0 = vo.make_layer(1024, 256, seed=20, dist="llm", num_centroids=65536, num_res_centroids=0)
+    m0 = spec_to_module(L0, dev)
+    x0 = _x(1024, "f16", "llm", 4)
+    y0 = m0(bits_to_tensor(x0, "f16", dev).reshape(x0.shape))          # nothing enabled by hand: auto
+    if vq._SLICED_LAYOUT_ENV:
+        assert m0.__dict__["_sliced"][1] is not None
+    assert rel_err(tensor_to_bits(y0), vo.forward(L0, x0), "f16") <= 1e-3
     L = vo.make_layer(2048, 512, seed=21, dist="llm", num_centroids=65536, num_res_centroids=256, bias=True)
     m = spec_to_module(L, dev)
     x1 = _x(2048, "f16", "llm", 3)
     xt = bits_to_tensor(x1, "f16", dev).reshape(x1.shape)
+    m.enable_sliced_layout(False)
     y_default = m(xt)
-    assert m.__dict__.get("_sliced") is None
+    assert m.__dict__.get("_sliced") is None and m._sliced_gemv() is None
+    assert torch.equal(y_default.view(torch.int16), gemv_abi(m, xt, 0).view(torch.int16))   # the gather kernel
     m.enable_sliced_layout()
     y_sliced = m(xt)
     assert m.__dict__["_sliced"][1] is not None

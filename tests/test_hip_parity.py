@@ -164,6 +164,11 @@ def test_token_counts_gemv_and_gemm_paths(tokens, k, dev):
         flags = module_flags()   # what the module forward passes (VPTQ_EXACT=1: exact)
         assert rel_err(tensor_to_bits(gemv_abi(m, xt, flags)), want, "f16") <= 1e-3
         if tokens <= (48 if k == 256 else 8):
+            if k == 65536 and tokens == 1:
+                # (round 3: one token of a k = 65536 layer goes over the load-time derived sliced layout by default -
+                # another kernel, same results within the bar; the gather kernel's bits with it switched off)
+                m.enable_sliced_layout(False)
+                got = tensor_to_bits(m(xt))
             assert (tensor_to_bits(gemv_abi(m, xt, flags)) == got).all()   # forward took the fused path
 
 

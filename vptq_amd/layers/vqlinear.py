@@ -49,8 +49,12 @@ def _raw_stream(device_index: int) -> int:
     return torch._C._cuda_getCurrentRawStream(device_index)
 
 
-# VPTQ_SLICED_LAYOUT=1: every eligible large-codebook layer builds the sliced layout (VQuantLinear.enable_sliced_layout)
-_SLICED_LAYOUT_ENV = os.environ.get("VPTQ_SLICED_LAYOUT", "0") not in ("", "0")
+# VPTQ_SLICED_LAYOUT: "auto" (default) = every eligible large-codebook layer (v8-k65536-0 / -256) builds the sliced
+# layout at its first one-token call while that leaves a quarter of the device memory free (MI355X: 288 GB - the
+# layouts of a 70B 3-bit model are 45 GB); "1" = always; "0" = never (VQuantLinear.enable_sliced_layout per layer)
+_SLICED_LAYOUT_MODE = os.environ.get("VPTQ_SLICED_LAYOUT", "auto").strip().lower() or "auto"
+_SLICED_LAYOUT_ENV = _SLICED_LAYOUT_MODE not in ("0", "off", "false", "no")
+_SLICED_MIN_FREE_FRACTION = 0.25
 
 
 class SiblingGroup:
@@ -390,18 +394,36 @@ class VQuantLinear(nn.Module):
         st = self.__dict__.get("_sliced")
         if st is None or st[0] != cache[6]:   # (a rebuilt descriptor = other tensors: rebuild the layout)
             obj = None
-            if not cache[9] and B.lib().vptq_sliced_layout_supported(cache[1]):
+            if not cache[9] and B.lib().vptq_sliced_layout_supported(cache[1]) and self._sliced_fits(cache, on):
                 from vptq_amd.utils.sliced import SlicedGemv
                 obj = SlicedGemv(self)
             st = (cache[6], obj)
             self.__dict__["_sliced"] = st
         return st[1]
 
+    def _sliced_fits(self, cache, on) -> bool:
+        """auto mode: build only while the layout (5 / 4 bytes per element + the builder's temporaries) leaves
+        _SLICED_MIN_FREE_FRACTION of the device memory free, and never inside a stream capture"""
+        if torch.cuda.is_current_stream_capturing():
+            return False
+        if on is True and "_sliced_on" in self.__dict__ or _SLICED_LAYOUT_MODE in ("1", "on", "true", "yes", "always"):
+            return True
+        free, total = torch.cuda.mem_get_info(cache[3])
+        elems = self.indices.shape[1] * self.group_size
+        need = elems * 5 + elems * 8 * 12   # layout + int64 temporaries of build_sliced_layout
+        return free - need > _SLICED_MIN_FREE_FRACTION * total
+
     def _gemv_cached(self, x: torch.Tensor, tokens: int) -> torch.Tensor:
         """Decode fast path: identical to `ops.quant_gemm` for 1..8 (canonical format: 16) tokens with a cached
         descriptor; layers linked by `link_siblings` share one grouped launch."""
-        if tokens == 1 and (_SLICED_LAYOUT_ENV or "_sliced_on" in self.__dict__):
-            sl = self._sliced_gemv()
+        if tokens == 1 and self.__dict__.get("_sliced_cand", True) and (_SLICED_LAYOUT_ENV or "_sliced_on" in self.__dict__):
+            if "_sliced_cand" not in self.__dict__:
+                # (static module configuration: decided once, so that every other layer pays one dict look-up per call)
+                self.__dict__["_sliced_cand"] = bool(
+                    self.num_centroids == 65536 and self.vector_len == 8 and self.num_codebooks == 1 and
+                    not self.enable_outlier and self.enable_norm and   # (a permutation may still be absorbed later)
+                    (not self.enable_residual or self.num_res_centroids == 256))
+            sl = self._sliced_gemv() if self.__dict__["_sliced_cand"] else None
             if sl is not None and not (ops.quant_gemm_flags() & (B.GEMV_EXACT | B.GEMV_FORCE_GENERIC)):
                 return sl(x)
         group = self.__dict__.get("_siblings")
