@@ -517,3 +517,24 @@ def test_command_line_chat_loop_logic_without_gpu(capsys):
     tok.chat_template = None
     out = app.chat_loop(model, tok, args)
     assert out.shape == (1, 6) and "no chat_template" in capsys.readouterr().out
+
+
+def test_module_copies_and_pickles_without_its_derived_state():
+    """descriptors (ctypes), the sliced layout and sibling links live in the module's __dict__ and are device-bound:
+    copy.deepcopy / pickle carry the parameters and the configuration only; the derived state is rebuilt on demand"""
+    import copy, pickle
+    import vptq_amd
+    m = vptq_amd.VQuantLinear(64, 32, vector_lens=[-1, 8], num_centroids=[-1, 256], num_res_centroids=[-1, 256], group_num=1,
+                              group_size=64, outlier_size=0, indices_as_float=False, enable_norm=True, enable_perm=False,
+                              is_indice_packed=True, bias=True, dtype=torch.float16, device="cpu", enable_proxy_error=False)
+    m.__dict__["_desc_cache"] = ("stand-in", object())
+    m.__dict__["_sliced"] = (1, object())
+    m.__dict__["_sliced_cand"] = True
+    m.enable_sliced_layout(False)
+    m2 = copy.deepcopy(m)
+    assert "_desc_cache" not in m2.__dict__ and "_sliced" not in m2.__dict__ and m2.__dict__["_sliced_on"] is False
+    assert m2.indices is not m.indices and torch.equal(m2.indices, m.indices)
+    m.__dict__["_sliced"] = (1, object())
+    m3 = pickle.loads(pickle.dumps(m))
+    assert "_desc_cache" not in m3.__dict__ and "_sliced" not in m3.__dict__
+    assert sorted(m3.state_dict()) == sorted(m.state_dict())

@@ -376,6 +376,25 @@ class VQuantLinear(nn.Module):
             raise RuntimeError("vptq_amd has no CPU path: x must be on the GPU")
         return x if x.is_contiguous() else x.contiguous()
 
+    # derived, device-bound state (ctypes descriptors, the sliced layout, sibling links) is rebuilt on demand: it is
+    # neither pickled nor deep-copied with the module (torch.save(model), copy.deepcopy(model))
+    _DERIVED_STATE = ("_desc_cache", "_desc_dense", "_sliced", "_sliced_cand", "_siblings")
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        for k in self._DERIVED_STATE:
+            state.pop(k, None)
+        return state
+
+    def __deepcopy__(self, memo):
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k not in self._DERIVED_STATE:
+                new.__dict__[k] = copy.deepcopy(v, memo)
+        return new
+
     def enable_sliced_layout(self, enable: bool = True):
         """Opt this layer in to (out of) the load-time derived "sliced" layout of the large-codebook formats
         v8-k65536-0 / v8-k65536-256 (vptq_amd/utils/sliced.py, gemv_sliced.hip): one-token calls then run 2-2.8x
