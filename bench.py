@@ -162,6 +162,7 @@ def k65536_extra(lib, B, dev, H, steps, warmup, regions, R=8):
     out["sliced_layout"]["packed_index_MiB_per_layer"] = layers[0].indices.numel() * 4 / 2**20
     sliced_pass()
     torch.cuda.synchronize()
+    layers[-1].enable_sliced_layout(False)   # (reference = the gather kernel, not the module's default one-token route)
     ref = layers[-1](x)
     out["sliced_vs_default_rel_diff"] = ((ys[-1].float() - ref.float()).abs().max() / ref.float().abs().max()).item()
     del layers, sls

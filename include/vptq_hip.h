@@ -272,7 +272,9 @@ VPTQ_API int vptq_quant_gemm(const VptqLayerDesc* desc, const void* x, void* y, 
  *            depend on it
  * (vptq_amd/utils/sliced.py builds it with torch.)  It costs 2x the packed indices in device memory on
  * top of them; the state-dict tensors are untouched.  workspace: vptq_quant_gemv_sliced_workspace_bytes
- * (S x N x 8 floats of partial sums).  Folded arithmetic (parity bar, not bit-equivalent);
+ * (S x N x 8 floats of partial sums + arrival counters), 16-byte aligned, ZERO-FILLED ONCE by the caller before
+ * its first use - every call leaves the counters zero; one workspace per layer call in flight (calls on one
+ * stream may share it).  Folded arithmetic (parity bar, not bit-equivalent);
  * Layers this path takes: no permutation, group_size <= 32768.
  */
 typedef struct VptqSlicedLayout {

@@ -31,6 +31,7 @@ for I, O in [tuple(int(v) for v in p.split(',')) for p in a.shapes.split(';')]:
     sls = [SlicedGemv(m, rows_per_wave=a.rpw) for m in layers]
     x = torch.randn(1, 1, I, device=dev).to(dt)
     y = torch.empty(1, 1, O, device=dev, dtype=dt)
+    layers[0].enable_sliced_layout(False)   # (the module's own one-token route would be the sliced one)
     ref = layers[0](x)
     got = sls[0](x)
     err = ((got.float() - ref.float()).abs().max() / ref.float().abs().max()).item()

@@ -23,8 +23,9 @@
 // slice (LDS-DMA) and f16(scale * x) of all columns into LDS, then each wave streams the CONTIGUOUS
 // element blocks of its consecutive rows through a 16-deep register queue; per element one
 // ds_read_b128 (entry) + one ds_read_u16 (activation) + 8 FMAs in fp32.  Partial sums per (slice, output)
-// go to the caller's workspace; a second small kernel adds the 8 slices in a fixed order, sum b x and the
-// output bias.  Folded arithmetic (gemv_k256m.hip): y = sum c[idx] * f16(s x) + sum b x + bias.
+// go to the caller's workspace; the workgroup of a row block that stores them last adds the slices in a fixed
+// order and the output bias (sum b x rides in slice 0's partial sums).  Folded arithmetic (gemv_k256m.hip):
+// y = sum c[idx] * f16(s x) + sum b x + bias.
 #include <type_traits>
 
 #include "common.h"
@@ -64,7 +65,8 @@ struct SlicedParams {
   const uint16_t* scale;
   const uint16_t* wbias;
   const uint16_t* bias;
-  float* partial;           // [8][N * 8]
+  float* partial;           // [slices][N * 8]
+  uint32_t* arrived;        // [row blocks] workgroups of the row block that have stored their partial sums (0 between launches)
   void* y;
   int N, G, O, rows_per_wave, n_rowblocks, out_f32;
 };
@@ -223,24 +225,28 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedPar
     // lane l (any of its row of 16) holds outputs 4 bit5 + 2 bit4 + {0, 1}
     if ((lane & 15) == 0) {
       const int o8 = ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2;
-      typedef float f32x2 __attribute__((ext_vector_type(2)));
-      *(f32x2*)(as_global(P.partial) + ((size_t)s * N + (size_t)(row0 + row_i)) * 8 + o8) = f32x2{v[0] + bdot, v[1] + bdot};
+      // write-through at device scope (sc1): the workgroup that sums the slices may sit on another XCD
+      float* const pp = as_global(P.partial) + ((size_t)s * N + (size_t)(row0 + row_i)) * 8 + o8;
+      __hip_atomic_store(pp, v[0] + bdot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(pp + 1, v[1] + bdot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[i] = 0.f;
   };
+  int left = 0x7fffffff;
+  bool done = false;
   if (total == 0) {   // none of this wave's rows has an element in this slice: zeros
     for (; row_i < n_rows; ++row_i) store_row();
-    return;
-  }
-  int left = __builtin_amdgcn_readlane(my_blocks, 0);
-  while (left == 0) {   // (leading rows with no element in this slice)
-    store_row();
-    ++row_i;
-    left = __builtin_amdgcn_readlane(my_blocks, row_i);
+    done = true;
+  } else {
+    left = __builtin_amdgcn_readlane(my_blocks, 0);
+    while (left == 0) {   // (leading rows with no element in this slice)
+      store_row();
+      ++row_i;
+      left = __builtin_amdgcn_readlane(my_blocks, row_i);
+    }
   }
   int c_next = 0;
-  bool done = false;
   auto consume = [&](auto slot_c) __attribute__((always_inline)) {
     constexpr int S = decltype(slot_c)::value;
     const evec_t ev = eq[S];
@@ -312,28 +318,52 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedPar
       if (row_i >= n_rows) { done = true; left = 0x7fffffff; }
     }
   };
-  do {
+  while (!done) {   // (waves without elements skip it; ONE exit for the others)
     sl_for_slots<kSLQueue>(step);
-  } while (!done);
-}
+  }
 
-// ---- y[o] = sum_s partial[s][o] + bias[o]  (sum b x rides in slice 0's partial sums) --------
-template <typename DT, int NSL>
-__global__ __launch_bounds__(256) void gemv_sliced_reduce(const float* __restrict__ partial, const uint16_t* __restrict__ bias,
-                                                          void* __restrict__ y, int N8, int O, int out_f32) {
-  const int o = blockIdx.x * 256 + threadIdx.x;
-  if (o >= O) return;
-  float p[NSL];
+  // ---- the slices of a row block meet: the workgroup that stores its partial sums LAST adds them up.  Nobody
+  // waits for anybody: every workgroup drains its write-through stores, counts itself in (device-scope atomic)
+  // and leaves unless it was the last of the row block's NSL; that one reads the NSL partial sums per output
+  // with device-coherent loads, adds them in a fixed tree (so the result does not depend on who was last), adds
+  // the output bias and stores y.  A second launch for this step cost 4.3 us of the 14.2 (its reads were the
+  // first touch of what other XCDs had just written, behind a kernel boundary).
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's partial sums have reached memory
+  uint32_t* const flag = (uint32_t*)(smem + bd_off);   // (the sum b x parts are dead by now)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  if (tid == 0) {
+    const uint32_t before = __hip_atomic_fetch_add(as_global(P.arrived) + rb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t lastone = before == (uint32_t)NSL - 1u ? 1u : 0u;
+    if (lastone) __hip_atomic_store(as_global(P.arrived) + rb, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
+    *flag = lastone;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+  if (*flag == 0u) return;
+  {
+    const int rows_wg = kSLWaves * rpw;
+    const int r_first = rb * rows_wg;
+    const int n_out = (N - r_first < rows_wg ? N - r_first : rows_wg) * 8;   // outputs of this row block
+    for (int k = tid; k < n_out; k += kSLThreads) {
+      const size_t o = (size_t)r_first * 8 + k;
+      float p[NSL];
 #pragma unroll
-  for (int sl = 0; sl < NSL; ++sl) p[sl] = partial[(size_t)sl * N8 + o];
+      for (int sl = 0; sl < NSL; ++sl)
+        p[sl] = __hip_atomic_load(as_global(P.partial) + (size_t)sl * N * 8 + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-  for (int w = NSL / 2; w > 0; w >>= 1)   // (a fixed tree)
+      for (int w = NSL / 2; w > 0; w >>= 1)   // (a fixed tree)
 #pragma unroll
-    for (int i = 0; i < w; ++i) p[i] = p[2 * i] + p[2 * i + 1];
-  float v = p[0];
-  if (bias) v += DT::to_float(bias[o]);
-  if (out_f32) ((float*)y)[o] = v;
-  else ((uint16_t*)y)[o] = DT::from_float(v);
+        for (int i = 0; i < w; ++i) p[i] = p[2 * i] + p[2 * i + 1];
+      float v = p[0];
+      if ((int)o < P.O) {
+        if (P.bias) v += DT::to_float(as_global(P.bias)[o]);
+        if (P.out_f32) ((float*)as_global(P.y))[o] = v;
+        else ((uint16_t*)as_global(P.y))[o] = DT::from_float(v);
+      }
+    }
+  }
 }
 
 // ---- host side -------------------------------------------------------------------
@@ -354,8 +384,13 @@ int gemv_sliced_slices(const VptqLayerDesc& d) {
   return d.group_size <= (d.num_res_centroids == 256 ? kSLMaxG8Res : kSLMaxG8) ? 8 : 16;
 }
 
+// partial sums [slices][N x 8] floats + one arrival counter per block of 16 rows (the smallest row block), which must be
+// ZERO before the first launch; every launch leaves them zero
+static size_t sl_partial_bytes(const VptqLayerDesc& d) {
+  return ((size_t)gemv_sliced_slices(d) * d.num_indices * 8 * sizeof(float) + 255) / 256 * 256;
+}
 size_t gemv_sliced_workspace_bytes(const VptqLayerDesc& d) {
-  return (size_t)gemv_sliced_slices(d) * d.num_indices * 8 * sizeof(float);
+  return sl_partial_bytes(d) + ((size_t)(d.num_indices + kSLWaves - 1) / kSLWaves) * sizeof(uint32_t);
 }
 
 template <typename DT, int NSL>
@@ -373,10 +408,6 @@ static hipError_t launch_sl(const SlicedParams& P, bool res, uint32_t lds, hipSt
   const dim3 grid(NSL * P.n_rowblocks), block(kSLThreads);
   if (res) hipLaunchKernelGGL((gemv_sliced_kernel<DT, NSL, true>), grid, block, lds, st, P);
   else hipLaunchKernelGGL((gemv_sliced_kernel<DT, NSL, false>), grid, block, lds, st, P);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((gemv_sliced_reduce<DT, NSL>), dim3((P.O + 255) / 256), dim3(256), 0, st, (const float*)P.partial, P.bias,
-                     P.y, P.N * 8, P.O, P.out_f32);
   return hipGetLastError();
 }
 
@@ -400,6 +431,7 @@ hipError_t launch_gemv_sliced(const VptqLayerDesc& d, const VptqSlicedLayout& L,
   P.wbias = (const uint16_t*)d.weight_bias;
   P.bias = (const uint16_t*)d.bias;
   P.partial = (float*)ws;
+  P.arrived = (uint32_t*)((char*)ws + sl_partial_bytes(d));
   P.y = y;
   P.N = d.num_indices; P.G = d.group_size; P.O = d.out_features;
   P.rows_per_wave = L.rows_per_wave;

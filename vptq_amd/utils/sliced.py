@@ -102,7 +102,7 @@ class SlicedGemv:
                                      rows_per_wave or rows_per_wave_for(self.blocks.shape[1], self.slices), 1,
                                      self.slices, 0)
         nb = B.lib().vptq_quant_gemv_sliced_workspace_bytes(self.desc)
-        self.ws = torch.empty(nb, dtype=torch.uint8, device=self.dev)
+        self.ws = torch.zeros(nb, dtype=torch.uint8, device=self.dev)   # (arrival counters: zero once, every call leaves them zero)
         self._fn = B.lib().vptq_quant_gemv_sliced
         self._lay_ref = C.byref(self.layout)
         self._ws_ptr, self._ws_bytes = self.ws.data_ptr(), self.ws.numel()
