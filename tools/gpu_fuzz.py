@@ -184,6 +184,59 @@ def fuzz_chains(a, dev):
     print(f"worst: {worst:.2e}")
 
 
+def fuzz_sliced(a, dev):
+    """random v8-k65536-0 / -256 layers, one token, over the sliced layout (gemv_sliced_kernel - the module's default
+    one-token route for these formats): against the oracle and the gather kernel, twice (reproducible bits), with
+    random rows-per-wave; skewed index distributions (most elements in one slice, empty slices) included"""
+    from vptq_amd.utils.sliced import SlicedGemv
+    rng = np.random.default_rng(a.seed)
+    dt = a.dtype
+    tol = 1e-3 if dt == "f16" else 8e-3
+    worst = 0.0
+    for c in range(a.cases):
+        kr = int(rng.choice([0, 256]))
+        I = int(rng.choice([8 * int(rng.integers(8, 1800)), 2048 * int(rng.integers(1, 8)), 8 * int(rng.integers(1800, 3600))]))
+        O = int(rng.choice([8 * int(rng.integers(1, 64)), 8 * int(rng.integers(64, 700)) - int(rng.integers(0, 8))]))
+        O = max(O, 8)
+        L = vo.make_layer(I, O, dist="llm", seed=9000 + c, dtype=dt, num_centroids=65536, num_res_centroids=kr,
+                          bias=bool(rng.integers(0, 2)))
+        skew = int(rng.integers(0, 4))
+        if skew:   # rewrite the main indices: 1 = one slice only, 2 = two slices, 3 = 90 % in slice 5
+            N = L.indices.shape[1]
+            idx = rng.integers(0, 65536, size=(N, I), dtype=np.int64)
+            if skew == 1:
+                idx = (idx & 8191) | (3 << 13)
+            elif skew == 2:
+                idx = (idx & 8191) | (rng.integers(0, 2, size=(N, I)) * 7 << 13)
+            else:
+                idx = np.where(rng.random((N, I)) < 0.9, (idx & 8191) | (5 << 13), idx)
+            ridx = rng.integers(0, 256, size=(N, I), dtype=np.int64) if kr else np.zeros((N, I), dtype=np.int64)
+            val = idx | (ridx << 16)
+            nb = 3 if kr else 2
+            by = np.stack([(val >> (8 * k)) & 255 for k in range(nb)], axis=2).astype(np.uint8).reshape(N, I * nb)
+            words = L.indices.shape[2]
+            buf = np.zeros((N, words * 4), dtype=np.uint8)
+            buf[:, :I * nb] = by
+            L.indices = buf.view(np.int32).reshape(1, N, words)
+        x = vo.from_f32(rng.standard_normal((1, 1, I)).astype(np.float32), dt)
+        m = spec_to_module(L, dev)
+        m.enable_sliced_layout(False)
+        xt = bits_to_tensor(x, dt, dev).reshape(x.shape)
+        rpw = int(rng.choice([0, 1, 2, 3, 5]))
+        sl = SlicedGemv(m, rows_per_wave=rpw)
+        got = sl(xt)
+        torch.cuda.synchronize()
+        again = sl(xt)
+        assert torch.equal(got.view(torch.int16), again.view(torch.int16)), (c, "not reproducible")
+        want = vo.forward(L, x)
+        e = rel_err(tensor_to_bits(got), want, dt)
+        e2 = rel_err(tensor_to_bits(got), tensor_to_bits(gemv_abi(m, xt, 0)), dt)
+        worst = max(worst, e)
+        print(f"case {c:3d} I={I:6d} O={O:5d} kr={kr:3d} skew={skew} slices={sl.slices} rpw={sl.layout.rows_per_wave}: oracle {e:.2e} gather {e2:.2e}", flush=True)
+        assert e <= tol and e2 <= tol, (c, e, e2)
+    print(f"worst: {worst:.2e}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=40)
@@ -193,10 +246,13 @@ def main():
     ap.add_argument("--lds-tall", action="store_true", help="tall layers of the LDS-resident formats (gemv_lds_mfma_kernel)")
     ap.add_argument("--adversarial", action="store_true", help="families built against the folded arithmetic")
     ap.add_argument("--chains", action="store_true", help="random chains through the persistent chain launch")
+    ap.add_argument("--sliced", action="store_true", help="random k = 65536 layers over the sliced layout")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     if a.chains:
         return fuzz_chains(a, dev)
+    if a.sliced:
+        return fuzz_sliced(a, dev)
     if a.adversarial:
         return fuzz_adversarial(a, dev)
     if a.lds_tall:
