@@ -381,6 +381,9 @@ bool gemv_sliced_eligible(const VptqLayerDesc& d) {
 
 // slices a layout of this layer must have
 int gemv_sliced_slices(const VptqLayerDesc& d) {
+  static std::atomic<int> force16{-1};   // VPTQ_SLICED_SLICES=16: 16 slices for every layer (A/B)
+  if (force16 < 0) { const char* e = getenv("VPTQ_SLICED_SLICES"); force16 = (e && atoi(e) == 16) ? 1 : 0; }
+  if (force16 == 1) return 16;
   return d.group_size <= (d.num_res_centroids == 256 ? kSLMaxG8Res : kSLMaxG8) ? 8 : 16;
 }
 
