@@ -180,6 +180,26 @@ static __device__ __forceinline__ void decode_elem(const IdxDecoded<FMT>& d, con
 }
 
 // ---- the kernel -----------------------------------------------------------------------
+// Main codebook into LDS by LDS-DMA (global_load_lds_dwordx4: 1 KiB per instruction and wave, no registers, no
+// ds_write): k x 16 bytes, k a multiple of 64.  Issued as inline assembly (a DMA the compiler can see makes it wait
+// for every load in flight); M0 belongs to the compiler: saved and restored inside the statement.  The caller waits
+// with s_waitcnt vmcnt(0) before the barrier that publishes the tables.  (Round 3: the copy through registers,
+// 2 x 4 loads + 8 ds_write_b128 per thread for k = 8192, kept the first index away for ~4 us per launch.)
+#ifndef VPTQ_LDS_DMA
+#define VPTQ_LDS_DMA 1
+#endif
+static __device__ __forceinline__ void lds_dma_table(const uint32_t* cent, int k, int wave, int lane, int n_waves) {
+  const int chunks = k >> 6;   // KiB
+  const uint64_t base = (uint64_t)(uintptr_t)as_global(cent) + (uint64_t)lane * 16u;
+  for (int j = wave; j < chunks; j += n_waves) {
+    const uint32_t d = (uint32_t)__builtin_amdgcn_readfirstlane(j * 1024);
+    const uint64_t v = base + (uint64_t)j * 1024u;
+    uint32_t keep_m0;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep_m0) : "v"(v), "s"(d) : "memory");
+  }
+}
+
 template <typename DT, int FMT, int TOK>
 __global__ __launch_bounds__(kLThreads) void gemv_lds_kernel(const LdsParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lsmem[];
@@ -200,10 +220,13 @@ __global__ __launch_bounds__(kLThreads) void gemv_lds_kernel(const LdsParams P) 
   float* const bdot_w = red + kLWaves * NV;
   float* const bsum = bdot_w + TOK * kLWaves;
 
-  // ---- prologue: both codebooks into LDS, 4 entries per thread in flight
+  // ---- prologue: both codebooks into LDS: the main one by LDS-DMA, the residual one (<= 8 KiB, any size) through
+  // registers, 4 entries per thread in flight
   {
+    const bool dma = VPTQ_LDS_DMA && (P.k & 63) == 0;
+    if (dma) lds_dma_table(P.cent, P.k, __builtin_amdgcn_readfirstlane(wave), lane, kLWaves);
     const int total = P.k + P.kr;
-    for (int i0 = tid; i0 < total; i0 += 4 * kLThreads) {
+    for (int i0 = (dma ? P.k : 0) + tid; i0 < total; i0 += 4 * kLThreads) {
       u32x4 e[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -241,6 +264,7 @@ __global__ __launch_bounds__(kLThreads) void gemv_lds_kernel(const LdsParams P) 
       if (lane == 0) bdot_w[t * kLWaves + wave] = s;
     }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the LDS-DMA of the codebook is invisible to the compiler)
   __syncthreads();
   if constexpr (!kF16) {
     if (tid < TOK) {
@@ -447,10 +471,12 @@ __global__ __launch_bounds__(kLThreads) void gemv_lds_mfma_kernel(const LdsParam
   const int n_steps = (G + kLMCols - 1) / kLMCols;
   // (requesting the first row group's first index window ahead of the prologue, so that its HBM latency
   // passes while the codebooks are copied, changed nothing: +-0.3 us either way over four formats)
-  // ---- prologue: codebooks into LDS (4 entries per thread in flight), activations staged
+  // ---- prologue: codebooks into LDS (the main one by LDS-DMA, the residual one through registers), activations staged
   {
+    const bool dma = VPTQ_LDS_DMA && (P.k & 63) == 0;
+    if (dma) lds_dma_table(P.cent, P.k, __builtin_amdgcn_readfirstlane(wave), lane, kLWaves);
     const int total = P.k + P.kr;
-    for (int i0 = tid; i0 < total; i0 += 4 * kLThreads) {
+    for (int i0 = (dma ? P.k : 0) + tid; i0 < total; i0 += 4 * kLThreads) {
       u32x4 e[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -524,6 +550,7 @@ __global__ __launch_bounds__(kLThreads) void gemv_lds_mfma_kernel(const LdsParam
     const float sb = wave_sum(accb);
     if (lane == 0) bdot_w[wave] = sb;
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the LDS-DMA of the codebook is invisible to the compiler)
   __syncthreads();
   if (tid == 0) {
     float sb = 0.f;
