@@ -151,13 +151,13 @@ def k65536_extra(lib, B, dev, H, steps, warmup, regions, R=8):
             sls[i](x, ys[i])
     ab = alg_bytes(H, H, 65536, 256, 1)
     out = {"what": f"VQuantLinear {H}x{H} v=8 k=65536+256 (3-bit, T = 24), ring of {R} layers; GB/s of the PACKED format's "
-                   "algorithmic bytes for both routes (the sliced layout reads 5 instead of 3 bytes per element)"}
+                   "algorithmic bytes for both routes (the sliced layout reads 4 instead of 3 bytes per element + 8 per block)"}
     for key, fn in (("default", default_pass), ("sliced_layout", sliced_pass)):
         t = Timer(dev).run(fn, steps, warmup, regions)
         us = t["event_ms"] * 1e3 / (steps * R)
         out[key] = {"us_per_layer": us, "GBps": ab / us / 1e3, "frac_of_8TBps": ab / us / 1e3 / 8000.0}
     out["default"]["kernel"] = lib.vptq_quant_gemv_kernel_name(descs[0][0], 1, 0).decode()
-    out["sliced_layout"]["kernel"] = "gemv_sliced_kernel + gemv_sliced_reduce"
+    out["sliced_layout"]["kernel"] = "gemv_sliced_kernel"
     out["sliced_layout"]["layout_MiB_per_layer"] = sls[0].extra_bytes / 2**20
     out["sliced_layout"]["packed_index_MiB_per_layer"] = layers[0].indices.numel() * 4 / 2**20
     sliced_pass()
@@ -221,7 +221,8 @@ class SclkSampler:
             return None
         s = sorted(self.samples)
         return {"samples": len(s), "min_mhz": s[0], "median_mhz": s[len(s) // 2], "max_mhz": s[-1],
-                "source": f"{self.kind}, every 20 ms during warm-up and the timed regions"}
+                "source": f"{self.kind}, every 20 ms during warm-up and the timed regions (raw sysfs reading: boxes of the "
+                          "pool disagree on what it reports - 1.87-1.99 GHz on one, 0.16-0.24 on another under the same load)"}
 
 
 def shard_ring(total_layers, rank, world):
