@@ -151,7 +151,7 @@ def k65536_extra(lib, B, dev, H, steps, warmup, regions, R=8):
             sls[i](x, ys[i])
     ab = alg_bytes(H, H, 65536, 256, 1)
     out = {"what": f"VQuantLinear {H}x{H} v=8 k=65536+256 (3-bit, T = 24), ring of {R} layers; GB/s of the PACKED format's "
-                   "algorithmic bytes for both routes (the sliced layout reads 4 instead of 3 bytes per element + 8 per block)"}
+                   "algorithmic bytes for both routes (the sliced layout reads 5 instead of 3 bytes per element)"}
     for key, fn in (("default", default_pass), ("sliced_layout", sliced_pass)):
         t = Timer(dev).run(fn, steps, warmup, regions)
         us = t["event_ms"] * 1e3 / (steps * R)

@@ -262,30 +262,30 @@ VPTQ_API int vptq_quant_gemm(const VptqLayerDesc* desc, const void* x, void* y, 
  * "v8-k65536-0" / "v8-k65536-256", the formats of most published checkpoints; ABI >= 6).  The reference gathers centroid rows from a 1 MiB codebook through the
  * caches (csrc/kernels/quant_gemv.cuh:11-186); here every row's elements are bucketed ONCE per layer by
  * the top 3 bits of their index, so that a workgroup holds its 8192-entry slice of the codebook in LDS:
- *   S = 8 or 16 slices of E = 65536 / S codebook entries; a row's elements are grouped by (slice, cell of 2048
- *   columns) and cut into blocks of up to 64 consecutive elements of one group:
- *   elems       : uint32, element words in (slice, row, cell, column) order, nothing between the lists, 64 spare
- *                 words at the end; word = column offset in its cell (11 bits) | (index mod E) << 11 |
- *                 residual index << 24
- *   block_start : int32 [blocks], first element of the block;  block_meta : int32 [blocks] = valid elements
- *                 (1..64) | cell << 8;  blocks in (slice, row, cell) order
- *   blocks      : int32 [S][N], blocks of (slice, row);  first : int32 [S][N], index of its first block
- *   rows_per_wave : 1 .. 64 consecutive rows per wave (16 waves per workgroup); the layout does not depend on it
- * (vptq_amd/utils/sliced.py builds it with torch.)  It costs 2.03x (T = 16) / 1.36x (T = 24) the packed indices in
- * device memory on top of them; the state-dict tensors are untouched.  workspace:
- * vptq_quant_gemv_sliced_workspace_bytes (S x N x 8 floats of partial sums + arrival counters), 16-byte aligned,
- * ZERO-FILLED ONCE by the caller before its first use - every call leaves the counters zero; one workspace per
- * layer call in flight (calls on one stream may share it).  Folded arithmetic (parity bar, not bit-equivalent).
+ *   elems  : uint32, for slice s = 0..S-1 (S = 8 or 16; E = 65536 / S entries per slice), for row n = 0..N-1
+ *            (N = desc->num_indices): the elements of row n whose index / E == s, in any order, padded to a
+ *            multiple of 64 with the word (column = group_size, local = 0);
+ *            element word = column | (index mod E) << 16
+ *   blocks : int32 [S][N], 64-element blocks of (s, n);  first : int32 [S][N], index of its first block
+ *            (prefix sum of `blocks` in (s, n) order)
+ *   rows_per_wave : 1 .. 64 consecutive rows per wave (16 waves per workgroup); the layout does not
+ *            depend on it
+ * (vptq_amd/utils/sliced.py builds it with torch.)  It costs 2x the packed indices in device memory on
+ * top of them; the state-dict tensors are untouched.  workspace: vptq_quant_gemv_sliced_workspace_bytes
+ * (S x N x 8 floats of partial sums + arrival counters), 16-byte aligned, ZERO-FILLED ONCE by the caller before
+ * its first use - every call leaves the counters zero; one workspace per layer call in flight (calls on one
+ * stream may share it).  Folded arithmetic (parity bar, not bit-equivalent);
  * Layers this path takes: no permutation, group_size <= 32768.
  */
 typedef struct VptqSlicedLayout {
   const void* elems;
-  const void* block_start;
-  const void* block_meta;
   const void* blocks;
   const void* first;
+  const void* res;          /* uint8 per element (same order, padding = 0): residual index; NULL without residual */
   int32_t rows_per_wave;
-  int32_t n_slices;         /* 8 / 16: what vptq_sliced_layout_supported() answers for the layer */
+  int32_t elems_per_lane;   /* 1 (or 0): a block = 64 elements */
+  int32_t n_slices;         /* 8 (or 0) / 16: what vptq_sliced_layout_supported() answers for the layer */
+  int32_t reserved;
 } VptqSlicedLayout;
 /* 0 = not a layer of this path; else the number of slices its layout must have: 8 slices of 8192 entries while
  * the activations fit in LDS beside them (group_size <= 14336, 14080 with a residual codebook), else 16 of 4096 */

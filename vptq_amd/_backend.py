@@ -38,8 +38,8 @@ _vp = C.c_void_p
 
 class SlicedLayout(C.Structure):
     """Mirror of `VptqSlicedLayout` (include/vptq_hip.h)."""
-    _fields_ = [("elems", C.c_void_p), ("block_start", C.c_void_p), ("block_meta", C.c_void_p), ("blocks", C.c_void_p),
-                ("first", C.c_void_p), ("rows_per_wave", C.c_int32), ("n_slices", C.c_int32)]
+    _fields_ = [("elems", C.c_void_p), ("blocks", C.c_void_p), ("first", C.c_void_p), ("res", C.c_void_p),
+                ("rows_per_wave", C.c_int32), ("elems_per_lane", C.c_int32), ("n_slices", C.c_int32), ("reserved", C.c_int32)]
 
 
 class LayerDesc(C.Structure):

@@ -376,9 +376,9 @@ int vptq_quant_gemv_sliced(const VptqLayerDesc* d, const VptqSlicedLayout* layou
   const size_t need = vptq::gemv_sliced_workspace_bytes(*d);
   if (!workspace || workspace_bytes < need || (((uintptr_t)workspace) & 15) != 0)
     return fail(VPTQ_E_WORKSPACE, "workspace of %zu bytes (16-byte aligned) needed", need);
-  if (layout->rows_per_wave < 1 || layout->rows_per_wave > 64 || !layout->elems || !layout->block_start ||
-      !layout->block_meta || !layout->blocks || !layout->first || layout->n_slices != vptq::gemv_sliced_slices(*d))
-    return fail(VPTQ_E_UNSUPPORTED, "sliced layout: rows_per_wave in [1, 64], five tensors, n_slices = %d for this layer",
+  if (layout->rows_per_wave < 1 || layout->rows_per_wave > 64 || !layout->elems || !layout->blocks || !layout->first ||
+      (layout->n_slices != 0 ? layout->n_slices : 8) != vptq::gemv_sliced_slices(*d))
+    return fail(VPTQ_E_UNSUPPORTED, "sliced layout: rows_per_wave in [1, 64], three tensors, n_slices = %d for this layer",
                 vptq::gemv_sliced_slices(*d));
   if ((((uintptr_t)x) & 15) != 0) return fail(VPTQ_E_UNSUPPORTED, "x must be 16-byte aligned");
   const hipError_t e = vptq::launch_gemv_sliced(*d, *layout, x, y, flags, workspace, (hipStream_t)stream);

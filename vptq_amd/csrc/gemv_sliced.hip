@@ -11,13 +11,15 @@
 // layers whose activations do not fit beside that: more than 14336 / 14080 columns) and, once per
 // layer (vptq_amd/utils/sliced.py; the on-disk tensors stay the state-dict contract), every row's
 // elements are bucketed by the slice of their index:
-//   elems  : element words in (slice, row, cell of 2048 columns, column) order, nothing between the lists:
-//            column offset in its cell | (index mod slice size) << 11 | residual index << 24
-//   block_start / block_meta : per block (up to 64 consecutive elements of one (slice, row, cell)) its first
-//            element and valid count | cell << 8;  blocks / first : [slices][N] blocks of (s, n), index of its first
-// = 4 bytes per element (+ 8 per block) instead of 2 (T = 16) / 3 (T = 24): the layout costs 2.03x / 1.36x the packed
-// indices in memory on top of them and in HBM traffic per token.  (First version: absolute columns + a byte
-// stream of residual indices = 5 bytes per element and two loads per step: 19.1 us per 8192^2 layer of T = 24.)  A workgroup owns (slice, block of rows): it copies its
+//   elems  : for slice s, for row n = 0..N-1: the row's elements whose index lies in slice s, padded to a
+//            multiple of 64 with (column = G, local index = 0); one 32-bit word per element =
+//            column | (index mod slice size) << 16; inside a (s, n) list the order is free - the builder picks
+//            one in which 16 consecutive elements hit different LDS bank groups
+//   blocks : [slices][N] number of 64-element blocks of (s, n);  first : [slices][N] index of its first block
+//   res    : (residual formats) one byte per element, same order and padding: its residual index; the 256-entry
+//            residual codebook sits in LDS beside the slice
+// = 4 instead of 2 bytes per element (+ ~3 % padding): the layout costs 2x the packed indices in memory
+// on top of them and in HBM traffic per token.  A workgroup owns (slice, block of rows): it copies its
 // slice (LDS-DMA) and f16(scale * x) of all columns into LDS, then each wave streams the CONTIGUOUS
 // element blocks of its consecutive rows through a 16-deep register queue; per element one
 // ds_read_b128 (entry) + one ds_read_u16 (activation) + 8 FMAs in fp32.  Partial sums per (slice, output)
@@ -53,9 +55,8 @@ constexpr int kSLQueueWords = VPTQ_SLICED_QUEUE;
 constexpr int kSLMaxRowsPerWave = 64;                    // (their block counts sit in the lanes of one register)
 
 struct SlicedParams {
-  const uint32_t* elems;    // element words: column offset in its cell | local index << 11 | residual index << 24
-  const int32_t* bstart;    // [blocks] first element of the block
-  const int32_t* bmeta;     // [blocks] valid elements (1..64) | cell << 8
+  const uint32_t* elems;
+  const uint8_t* res;       // residual index per element (same order and padding), or null
   const uint32_t* rcent;    // [256][8] halves, or null
   const int32_t* blocks;    // [8][N]
   const int32_t* first;     // [8][N]
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedPar
   constexpr uint32_t kSLTabBytes = (65536u / NSL) * 16u;   // this workgroup's slice of the codebook
   constexpr uint32_t kSLXOff = kSLTabBytes;                // staged activations: (G + 64) halves
   typedef uint32_t evec_t __attribute__((ext_vector_type(EPL)));
-  constexpr int kLoadsPerStep = 1;
+  constexpr int kLoadsPerStep = RES ? 2 : 1;
   constexpr int kSLQueue = kSLQueueWords / EPL < 2 ? 2 : kSLQueueWords / EPL;   // blocks in flight per wave
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   {
@@ -170,33 +171,20 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedPar
     }
   }
 
-  // ---- block headers: lane i of (hd_s, hd_m) = header of block hd_base + i of the stream, 64 at a time.  Fetched
-  // again (rare: streams of more than 64 blocks) only BETWEEN two rounds of the unrolled loop and laundered through
-  // an asm statement: a conditional load whose result the steps read would make the compiler wait for "all loads"
-  // in every step.
-  int hd_s = 0, hd_m = 0, hd_base = 0;
-  const int last = total > 0 ? total - 1 : 0;
-  auto fetch_headers = [&](int base) __attribute__((always_inline)) {
-    const int b = base + lane < last ? base + lane : last;
-    const int ls = as_global(P.bstart)[(size_t)first_block + b];
-    const int lm = as_global(P.bmeta)[(size_t)first_block + b];
-    asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=&v"(hd_s), "=&v"(hd_m) : "v"(ls), "v"(lm));
-    hd_base = base;
-  };
-  fetch_headers(0);
   // ---- element queue: block k of the stream -> slot k % kSLQueue
   evec_t eq[kSLQueue];
-  int qm[kSLQueue];   // valid | cell << 8 of the block in the slot (wave-uniform)
-  const uint32_t* const ep = as_global(P.elems) + lane;
+  uint32_t rq[RES ? kSLQueue : 1];
+  const evec_t* const ep = (const evec_t*)(as_global(P.elems) + (size_t)first_block * (64 * EPL)) + lane;
+  const uint8_t* const rp = RES ? as_global(P.res) + (size_t)first_block * 64 + lane : nullptr;
+  const int last = total > 0 ? total - 1 : 0;
   int i_next = 0;
   // (past the end of the stream a step still issues its load - every step the same instructions, so the waits
   // stay counted - of the last block again; one cached word for all lanes instead was measured slower)
   auto issue = [&](auto slot_c) __attribute__((always_inline)) {
     constexpr int S = decltype(slot_c)::value;
-    const int b = i_next < last ? i_next : last;
-    const int start = __builtin_amdgcn_readlane(hd_s, b - hd_base);
-    qm[S] = __builtin_amdgcn_readlane(hd_m, b - hd_base);
-    eq[S] = evec_t{__builtin_nontemporal_load(ep + (size_t)(uint32_t)start)};
+    const size_t b64 = (size_t)(i_next < last ? i_next : last) * 64;
+    eq[S] = __builtin_nontemporal_load(ep + b64);
+    if constexpr (RES) rq[S] = rp[b64];
     ++i_next;
   };
   sl_for_slots<kSLQueue>([&](auto slot_c) {
@@ -270,15 +258,13 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedPar
     u32x4 ent[EPL];
     u32x4 rent = {0u, 0u, 0u, 0u};
     uint16_t xh[EPL];
-    const int meta = qm[S];
-    const uint32_t cell_off = kSLXOff + ((uint32_t)(meta >> 8) << 12);   // 2048 columns x 2 bytes per cell
-    {
-      const uint32_t e = ev[0];
-      ent[0] = lds_load16(((e >> 11) & 0x1fffu) << 4);
-      const uint16_t xv = *(const lds_h_t*)(uintptr_t)(cell_off + ((e & 0x7ffu) << 1));
-      xh[0] = lane < (meta & 0xff) ? xv : (uint16_t)0;   // lanes past the block's elements hold words of the next list
-      if constexpr (RES) rent = lds_load16(res_off + ((e >> 24) << 4));
+#pragma unroll
+    for (int k = 0; k < EPL; ++k) {
+      const uint32_t e = ev[k];
+      ent[k] = lds_load16((e >> 16) << 4);
+      xh[k] = *(const lds_h_t*)(uintptr_t)(kSLXOff + ((e & 0xffffu) << 1));
     }
+    if constexpr (RES) rent = lds_load16(res_off + (rq[S] << 4));
 #pragma unroll
     for (int k = 0; k < EPL; ++k) {
       if constexpr (std::is_same<DT, F16>::value) {
@@ -333,7 +319,6 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedPar
     }
   };
   while (!done) {   // (waves without elements skip it; ONE exit for the others)
-    if (i_next + kSLQueue > hd_base + 64 && i_next < last) fetch_headers(i_next);   // the next round's requests stay inside the window
     sl_for_slots<kSLQueue>(step);
   }
 
@@ -433,14 +418,13 @@ hipError_t launch_gemv_sliced(const VptqLayerDesc& d, const VptqSlicedLayout& L,
                               void* ws, hipStream_t st) {
   const bool res = d.num_res_centroids == 256;
   const int nsl = gemv_sliced_slices(d);
-  if (L.n_slices != nsl || L.rows_per_wave < 1 || L.rows_per_wave > kSLMaxRowsPerWave || !L.elems || !L.block_start ||
-      !L.block_meta || !L.blocks || !L.first || !ws || (((uintptr_t)x) & 15) != 0 ||
-      ((((uintptr_t)L.elems | (uintptr_t)L.block_start | (uintptr_t)L.block_meta | (uintptr_t)L.blocks | (uintptr_t)L.first)) & 3) != 0)
+  if ((L.n_slices != 0 ? L.n_slices : 8) != nsl || (L.elems_per_lane != 0 && L.elems_per_lane != 1) || (res && !L.res) ||
+      L.rows_per_wave < 1 || L.rows_per_wave > kSLMaxRowsPerWave || !L.elems || !L.blocks || !L.first || !ws ||
+      (((uintptr_t)x) & 15) != 0 || (((uintptr_t)L.elems) & 3) != 0)
     return hipErrorInvalidValue;
   SlicedParams P = {};
   P.elems = (const uint32_t*)L.elems;
-  P.bstart = (const int32_t*)L.block_start;
-  P.bmeta = (const int32_t*)L.block_meta;
+  P.res = res ? (const uint8_t*)L.res : nullptr;
   P.rcent = res ? (const uint32_t*)d.res_centroids : nullptr;
   P.blocks = (const int32_t*)L.blocks;
   P.first = (const int32_t*)L.first;
