@@ -18,10 +18,10 @@
 //   blocks : [slices][N] number of 64-element blocks of (s, n);  first : [slices][N] index of its first block
 //   res    : (residual formats) one byte per element, same order and padding: its residual index; the 256-entry
 //            residual codebook sits in LDS beside the slice
-// = 4 instead of 2 bytes per element (+ ~3 % padding): the layout costs 2x the packed indices in memory
-// on top of them and in HBM traffic per token.  A workgroup owns (slice, block of rows): it copies its
-// slice (LDS-DMA) and f16(scale * x) of all columns into LDS, then each wave streams the CONTIGUOUS
-// element blocks of its consecutive rows through a 16-deep register queue; per element one
+// = 4 instead of 2 bytes per element for T = 16, 5 instead of 3 for T = 24 (+ ~3 % padding): the layout costs
+// 2.06x / 1.72x the packed indices in memory on top of them and in HBM traffic per token.  A workgroup owns
+// (slice, block of rows): it copies its slice (LDS-DMA) and f16(scale * x) of all columns into LDS, then each wave
+// streams the CONTIGUOUS element blocks of its consecutive rows through a register queue; per element one
 // ds_read_b128 (entry) + one ds_read_u16 (activation) + 8 FMAs in fp32.  Partial sums per (slice, output)
 // go to the caller's workspace; the workgroup of a row block that stores them last adds the slices in a fixed
 // order and the output bias (sum b x rides in slice 0's partial sums).  Folded arithmetic (gemv_k256m.hip):
@@ -40,10 +40,10 @@ constexpr int kSLWaves = kSLThreads / 64;
 constexpr int kSLMaxSlices = 16;
 constexpr int kSLMaxG8 = 14336, kSLMaxG8Res = 14080, kSLMaxG16 = 32768;
 constexpr uint32_t kSLLdsLimit = 163840;
-// element words per lane in flight (queue depth = this / elems_per_lane blocks).  Same-box A/B with one word per
-// lane and block (profiles/r03/sliced_queue_ab.txt): depth 8 / 16 / 32 = 14.2 / 16.2 / 21.2 us per 8192^2 layer -
-// proportional to (blocks + depth) per wave: every step issues a load, also the `depth` steps past the end of a
-// wave's stream, and the launch was bound by the number of load instructions, not by bytes or latency.
+// element blocks in flight per wave.  Same-box A/B (profiles/r03/sliced_queue_ab.txt): depth 8 / 16 / 32 = 14.2 /
+// 16.2 / 21.2 us per 8192^2 layer - the unrolled loop runs ceil(blocks / depth) * depth steps, and a wave's stream is
+// only ~34 blocks long: the steps past its end cost as much as real ones (8- and 16-byte loads per lane made no
+// difference: it is the steps, not the load instructions or the bytes).
 #ifndef VPTQ_SLICED_QUEUE
 #define VPTQ_SLICED_QUEUE 8
 #endif
