@@ -300,7 +300,9 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedPar
   };
   auto step = [&](auto slot_c) __attribute__((always_inline)) {
     __builtin_amdgcn_sched_barrier(0);
-    consume(slot_c);
+    // (past the end of the wave's stream the steps of the last round only keep the loads counted: a stream is
+    // ~34 blocks long, so up to depth - 1 idle steps were 15 % of the launch while they still gathered and added)
+    if (!done) consume(slot_c);
     __builtin_amdgcn_sched_barrier(0);
     issue(slot_c);
     __builtin_amdgcn_sched_barrier(0);
