@@ -15,7 +15,7 @@ from _gpu_util import spec_to_module, bits_to_tensor, tensor_to_bits, gemv_abi, 
 pytestmark = pytest.mark.gpu
 TOL = {"f16": 1e-3, "bf16": 8e-3}
 EXACT = 1 << 2
-BATCHED = 1 << 7   # VPTQ_GEMV_FORCE_BATCHED: the kernel under test wherever it is eligible (default: bf16 from 5 tokens)
+BATCHED = 1 << 7   # VPTQ_GEMV_FORCE_BATCHED: the kernel under test wherever it is eligible (default: from 5 tokens)
 
 
 @pytest.fixture(scope="module")
@@ -60,8 +60,8 @@ def test_one_pass_batched_decode_vs_oracle(I, O, kw, tokens, dt, dev):
     x = _x(I, dt, dist, tokens, tokens)
     m = spec_to_module(L, dev)
     assert kernel_name(m, tokens, BATCHED) == "gemm_k256t_kernel"
-    assert (kernel_name(m, tokens) == "gemm_k256t_kernel") == (dt == "bf16" and tokens >= 5)
-    default_route = dt == "bf16" and 5 <= tokens <= 32   # (the module switches to dequant + GEMM above vptq_quant_gemv_max_tokens)
+    assert (kernel_name(m, tokens) == "gemm_k256t_kernel") == (tokens >= 5)
+    default_route = 5 <= tokens <= 48   # (the module switches to dequant + GEMM above vptq_quant_gemv_max_tokens)
     xt = bits_to_tensor(x, dt, dev).reshape(x.shape)
     got = gemv_abi(m, xt, BATCHED)
     torch.cuda.synchronize()

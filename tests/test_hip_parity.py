@@ -778,9 +778,14 @@ def test_many_token_routes_vs_reference_goldens(name, dev):
     xt = bits_to_tensor(x, dt, dev).reshape(x.shape)
     routes = {"module": lambda: m(xt), "dense_cached": lambda: m._dense_cached(xt),
               "gemm_fused": lambda: ops.quant_gemm_fused(xt, m._descriptor()[1], L.out_features)}
-    if T <= 64 and dt == "f16":
-        assert kernel_name(m, T) == "gemm_k256_kernel"
-        routes["gemm_k256"] = lambda: gemv_abi(m, xt, 0)
+    if T <= 64:
+        # the batched-decode kernels (launches of 16 tokens): the one-pass kernel (default from 5 tokens, both dtypes) and,
+        # fp16, the kernel with the reference's roundings
+        assert kernel_name(m, T) == "gemm_k256t_kernel"
+        routes["gemm_k256t"] = lambda: gemv_abi(m, xt, 0)
+        if dt == "f16":
+            assert kernel_name(m, T, EXACT) == "gemm_k256_kernel"
+            routes["gemm_k256"] = lambda: gemv_abi(m, xt, EXACT)
     errs = {}
     for rname, fn in routes.items():
         out = stored_rows(tensor_to_bits(fn()).reshape(1, T, -1), cfg)
@@ -1275,7 +1280,8 @@ GEMM_CASES = [
 
 @pytest.mark.parametrize("I,O,kw,tokens", GEMM_CASES)
 def test_batched_decode_kernel_vs_oracle(I, O, kw, tokens, dev):
-    """gemm_k256_kernel (canonical format, fp16, 5-16 tokens in one launch): dequantised tiles with
+    """gemm_k256_kernel (canonical format, fp16, 5-16 tokens in one launch, VPTQ_GEMV_EXACT: since round 3 the default
+    for these token counts is the one-pass gemm_k256t, tests/test_gemm_k256t_gpu.py): dequantised tiles with
     the reference's roundings -> LDS -> v_mfma_f32_16x16x16_f16, i.e. the arithmetic of the
     reference's own path for these token counts, dequant + F.linear (quant_gemm.py:231-274)."""
     kw = dict(kw)
@@ -1286,9 +1292,10 @@ def test_batched_decode_kernel_vs_oracle(I, O, kw, tokens, dev):
         else rng.standard_normal((1, tokens, I))
     x = vo.from_f32(xs.astype(np.float32), "f16")
     m = spec_to_module(L, dev)
-    assert kernel_name(m, tokens) == "gemm_k256_kernel"
+    assert kernel_name(m, tokens, EXACT) == "gemm_k256_kernel" and kernel_name(m, tokens) == "gemm_k256t_kernel"
     xt = bits_to_tensor(x, "f16", dev).reshape(x.shape)
-    got = m(xt)
+    got = gemv_abi(m, xt, EXACT)
+    assert rel_err(tensor_to_bits(m(xt)), tensor_to_bits(got), "f16") <= 1e-3   # (the module's default route: the one-pass kernel)
     # bit-level partner on the GPU: HIP dequant (bit-exact W) + fp32 matmul, rounded once
     W = m.dequant().float()
     ref = (xt.float() @ W.t())
@@ -1303,18 +1310,22 @@ def test_batched_decode_kernel_vs_oracle(I, O, kw, tokens, dev):
     one = tensor_to_bits(gemv_abi(m, xt[:, tokens - 1:tokens].contiguous(), EXACT))
     assert rel_err(gb[:, tokens - 1:tokens], one, "f16") <= 1e-3
     # fp32 output
+    assert torch.equal(gemv_abi(m, xt, EXACT, out_f32=True).to(torch.float16), got)
     from vptq_amd.utils.shard import forward_partial_f32
-    assert torch.equal(forward_partial_f32(m, xt).to(torch.float16), got)
+    assert torch.equal(forward_partial_f32(m, xt).to(torch.float16), m(xt))   # (default route, fp32 partial sums)
     # determinism
-    assert torch.equal(m(xt), got)
+    assert torch.equal(gemv_abi(m, xt, EXACT), got)
 
 
 def test_batched_decode_golden_16_tokens(dev):
     L, x, y, cfg, _ = load_golden("canon_t16_perm")
     m = spec_to_module(L, dev)
-    assert kernel_name(m, 16) == "gemm_k256_kernel" and kernel_name(m, 4).startswith("gemv_k256")
-    out = tensor_to_bits(m(bits_to_tensor(x, "f16", dev).reshape(x.shape)))
+    assert kernel_name(m, 16, EXACT) == "gemm_k256_kernel" and kernel_name(m, 4).startswith("gemv_k256")
+    xt = bits_to_tensor(x, "f16", dev).reshape(x.shape)
+    out = tensor_to_bits(gemv_abi(m, xt, EXACT))
     assert rel_err(out, y, "f16") <= 1e-3 and bit_identical_frac(out, y) >= 0.9
+    assert kernel_name(m, 16) == "gemm_k256t_kernel"   # the default: one pass, folded arithmetic, permutation applied by its pre-pass
+    assert rel_err(tensor_to_bits(m(xt)), y, "f16") <= 1e-3
 
 
 # ---------------------------------------------------------------- fused dequant + GEMM (prefill)

@@ -98,7 +98,7 @@ def test_kernel_choice_without_gpu():
     big, small = _canonical_desc(8192, 8192), _canonical_desc(4096, 4096)
     assert lib.vptq_quant_gemv_max_tokens(big) == 48
     bbig = _canonical_desc(8192, 8192, dtype=1)
-    assert lib.vptq_quant_gemv_max_tokens(bbig) == 32   # bf16 (round 3): the one-pass batched-decode kernel
+    assert lib.vptq_quant_gemv_max_tokens(bbig) == 48   # bf16 (round 3): the one-pass batched-decode kernel
     for tok in (1, 2, 3, 4):
         assert name(big, tok) == b"gemv_k256m_kernel<fast>"
         assert name(small, tok) == (b"gemv_k256_kernel<fast>" if tok <= 2 else b"gemv_k256_kernel")
@@ -107,14 +107,16 @@ def test_kernel_choice_without_gpu():
     assert name(big, 1, B.GEMV_FORCE_VALU) == b"gemv_k256_kernel<fast>"
     assert name(small, 1, B.GEMV_FORCE_MFMA) == b"gemv_k256m_kernel<fast>"
     assert name(big, 1, B.GEMV_FORCE_GENERIC) == b"gemv_generic_kernel"
-    assert name(big, 4) == b"gemv_k256m_kernel<fast>" and name(big, 5) == name(big, 16) == b"gemm_k256_kernel"
-    assert name(big, 64) == b"gemm_k256_kernel" and name(big, 65) is None          # launches of 16 tokens
-    # bf16: 2-4 tokens on the GEMV kernels, 5+ in ONE pass (gemm_k256t, launches of 16; wants the workspace
-    # vptq_quant_gemv_workspace_bytes names); fp16 only when forced (its own batched kernel is faster)
+    # 5+ tokens: ONE pass over the indices (gemm_k256t, launches of 16; wants the workspace vptq_quant_gemv_workspace_bytes
+    # names); with the reference's roundings: gemm_k256 (fp16)
+    assert name(big, 4) == b"gemv_k256m_kernel<fast>" and name(big, 5) == name(big, 16) == b"gemm_k256t_kernel"
+    assert name(big, 64) == b"gemm_k256t_kernel" and name(big, 65) is None          # launches of 16 tokens
+    assert name(big, 5, B.GEMV_EXACT) == name(big, 64, B.GEMV_EXACT) == b"gemm_k256_kernel"
+    # bf16 likewise (no batched kernel with the reference's roundings: launches of <= 4 tokens then)
     assert name(bbig, 4) == b"gemv_k256m_kernel<fast>" and name(bbig, 5) == name(bbig, 16) == name(bbig, 64) == b"gemm_k256t_kernel"
     assert name(bbig, 65) is None and name(bbig, 5, B.GEMV_EXACT) == b"gemv_k256_kernel"
     assert lib.vptq_quant_gemv_workspace_bytes(bbig, 5, 0) == 64 * 4096 + 256 and lib.vptq_quant_gemv_workspace_bytes(bbig, 4, 0) == 0
-    assert lib.vptq_quant_gemv_workspace_bytes(big, 16, 0) == 0
+    assert lib.vptq_quant_gemv_workspace_bytes(big, 16, 0) == 64 * 4096 + 256 and lib.vptq_quant_gemv_workspace_bytes(big, 16, B.GEMV_EXACT) == 0
     assert name(big, 2, B.GEMV_FORCE_BATCHED) == name(big, 16, B.GEMV_FORCE_BATCHED) == b"gemm_k256t_kernel"
     assert lib.vptq_quant_gemv_workspace_bytes(big, 2, B.GEMV_FORCE_BATCHED) == 64 * 4096 + 256
     # bf16: folded form in the MFMA kernel from 32 row groups (128 vector-rows) on

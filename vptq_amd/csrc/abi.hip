@@ -95,8 +95,8 @@ const char* vptq_last_error(void) { return g_err; }
 int vptq_quant_gemv_max_tokens(const VptqLayerDesc* d) {
   if (validate_layer(d) != VPTQ_OK) return 0;
   if (vptq::gemm_k256_eligible(*d, 16, 0)) return 48;
-  // bf16: 21 us per launch of 16 tokens (gemm_k256t) against ~50 us for dequant + GEMM at 8192^2
-  if (vptq::gemm_k256t_eligible(*d, 16, 0)) return 32;
+  // bf16: 15.6 us per launch of 16 tokens (gemm_k256t) against ~55 us for dequant + GEMM at 8192^2
+  if (vptq::gemm_k256t_eligible(*d, 16, 0)) return 48;
   return vptq::gemv_k256_eligible(*d, 4) ? VPTQ_GEMV_MAX_TOKENS_ANY : 8;
 }
 
@@ -111,18 +111,17 @@ static int batch_min_tokens() {
   return v;
 }
 
-// Smallest token count that takes the one-pass batched-decode kernel (gemm_k256t.hip).  Measured at 8192^2
-// (profiles/r03/tokens_*): it costs 17 (2-5 tokens) ... 21 us (16 tokens) for either dtype - its pre-pass
-// (4.8 us) and 256 KiB of operand-ordered activations per CU through L2 are what one token's kernel does
-// not have - against 9.4-10.3 us for 2-4 tokens of either dtype, 18 us for 5-16 fp16 tokens (gemm_k256)
-// and 18 (5 tokens) ... 40 us (16) for bf16 as launches of <= 4 tokens: the default route for bf16 from
-// 5 tokens.  VPTQ_GEMMT_MIN_TOKENS_F16 / _BF16 override (tuning), VPTQ_GEMV_FORCE_BATCHED forces.
+// Smallest token count that takes the one-pass batched-decode kernel (gemm_k256t.hip).  Measured at 8192^2 / 4096^2
+// (profiles/r03/tokens_*): 13.5 / 9.3 us at 5 tokens ... 15.6 / 10.3 us at 16 for either dtype (its pre-pass is 4.8 us
+// of that) against 9.0-10.3 / 5.2-6.6 us for 2-4 tokens on the GEMV kernels, 17.8-18.5 / 10.4-10.8 us for 5-16 fp16
+// tokens on gemm_k256 and 18-39 us for bf16 as launches of <= 4 tokens: the default route from 5 tokens for both
+// dtypes.  VPTQ_GEMMT_MIN_TOKENS_F16 / _BF16 override (tuning), VPTQ_GEMV_FORCE_BATCHED forces.
 static int batch_t_min_tokens(int dtype) {
   static std::atomic<int> vf{-1}, vb{-1};
   std::atomic<int>& v = dtype == VPTQ_DTYPE_F16 ? vf : vb;
   if (v < 0) {
     const char* ev = getenv(dtype == VPTQ_DTYPE_F16 ? "VPTQ_GEMMT_MIN_TOKENS_F16" : "VPTQ_GEMMT_MIN_TOKENS_BF16");
-    const int w = ev ? atoi(ev) : (dtype == VPTQ_DTYPE_F16 ? VPTQ_GEMV_MAX_TOKENS + 1 : 5);
+    const int w = ev ? atoi(ev) : 5;
     v = w < 1 ? 1 : w;
   }
   return v;

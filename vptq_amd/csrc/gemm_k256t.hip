@@ -44,10 +44,13 @@ constexpr int kBTBlockCols = 128;                      // columns of one wave pe
 constexpr int kBTSweepCols = kBTWaves * kBTBlockCols;  // 2048
 constexpr int kBTRows = 4;                             // vector-rows per row group
 constexpr int kBTTokens = 16;                          // token slots = rows of the MFMA
+// sweeps in flight per wave.  2: a row group of 8192 columns is 4 sweeps = two rounds of the unrolled loop exactly;
+// with 3 the loop ran 6 steps for 4 sweeps and requested 15 loads ahead: 19.9 against 15.6 us per 8192^2 layer at 16
+// tokens, same box (profiles/r03/tokens_k256t_depth_ab.txt); 4 spills registers (25.6 us)
 #ifndef VPTQ_K256BT_DEPTH
-#define VPTQ_K256BT_DEPTH 3
+#define VPTQ_K256BT_DEPTH 2
 #endif
-constexpr int kBTDepth = VPTQ_K256BT_DEPTH;            // sweeps in flight per wave
+constexpr int kBTDepth = VPTQ_K256BT_DEPTH;
 static_assert(kBTDepth >= 2 && kBTDepth <= 4, "queue depth");
 constexpr uint32_t kBTImgBytes = 65536;                // 256 rows x 16 units x 16 B
 constexpr uint32_t kBTRedOff = kBTImgBytes;            // [2][wave][token][32 outputs] floats
@@ -371,7 +374,7 @@ __global__ __launch_bounds__(kBTThreads) void gemm_k256t_kernel(const GemmK256TP
 
   auto step = [&](auto slot_c) __attribute__((always_inline)) {
     __builtin_amdgcn_sched_barrier(0);
-    consume(slot_c);
+    if (!done) consume(slot_c);   // (the steps after the last row group only keep the loads counted)
     __builtin_amdgcn_sched_barrier(0);
     issue(slot_c);
     __builtin_amdgcn_sched_barrier(0);

@@ -120,7 +120,7 @@ def forward_partial_f32(layer: VQuantLinear, x: torch.Tensor) -> torch.Tensor:
     # what vptq_quant_gemv takes for THIS layer: 64 tokens for fp16 layers of the canonical format
     # (vptq_quant_gemv_max_tokens answers 48 for them), 16 for every other layer; beyond that the partial
     # sum comes from the dense route: dequant + a matmul that accumulates and stays in fp32
-    limit = B.GEMV_MAX_TOKENS if cache[5] >= 32 else 16
+    limit = B.GEMV_MAX_TOKENS if cache[5] >= 48 else 16
     if tokens > limit:
         W = layer.dequant().float()
         y = torch.matmul(xc.float(), W.t())
