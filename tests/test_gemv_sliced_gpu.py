@@ -169,5 +169,11 @@ def test_module_forward_takes_the_sliced_layout_when_enabled(dev):
     m.indices.data = torch.from_numpy(L2.indices.copy()).to(dev).reshape(m.indices.shape)
     L.indices = L2.indices
     assert rel_err(tensor_to_bits(m(xt)), vo.forward(L, x1), "f16") <= 1e-3
+    # ... also after an in-place rewrite of the same storage
+    L3 = vo.make_layer(2048, 512, seed=23, dist="llm", num_centroids=65536, num_res_centroids=256, bias=True)
+    with torch.no_grad():
+        m.indices.copy_(torch.from_numpy(L3.indices.copy()).to(dev).reshape(m.indices.shape))
+    L.indices = L3.indices
+    assert rel_err(tensor_to_bits(m(xt)), vo.forward(L, x1), "f16") <= 1e-3
     m.enable_sliced_layout(False)
     assert m._sliced_gemv() is None

@@ -1535,3 +1535,13 @@ def test_adversarial_families_default_route(family, xkind, O, dev):
     assert exact <= 5e-4
     if not gated:
         assert raw <= 1e-3
+    # the functional op (vptq.ops.quant_gemm) applies the same gate, and several tokens (the one-pass batched kernel
+    # is folded arithmetic too) go through it as well
+    import importlib
+    qg = importlib.import_module("vptq_amd.ops.quant_gemm")   # (the package also exports a function of that name)
+    assert (qg._safe_flags(m.centroids.weight, m.res_centroids.weight, m.weight_scale, m.weight_bias) != 0) == gated
+    x6 = np.concatenate([x] * 6, axis=1)
+    x6t = bits_to_tensor(x6, "f16", dev).reshape(x6.shape)
+    y6 = m(x6t)
+    assert rel_err(tensor_to_bits(y6)[:, 5:6], want, "f16") <= 1e-3, f"6 tokens, {family}/{xkind}"
+    assert kernel_name(m, 6, m._descriptor()[9]) == ("gemm_k256_kernel" if gated else "gemm_k256t_kernel")

@@ -411,12 +411,14 @@ class VQuantLinear(nn.Module):
             return None
         cache = self._descriptor()
         st = self.__dict__.get("_sliced")
-        if st is None or st[0] != cache[6]:   # (a rebuilt descriptor = other tensors: rebuild the layout)
+        # (a rebuilt descriptor = other tensors; a bumped version counter = indices rewritten in place: rebuild)
+        stamp = (cache[6], B.tensor_version(self._parameters["indices"]))
+        if st is None or st[0] != stamp:
             obj = None
             if not cache[9] and B.lib().vptq_sliced_layout_supported(cache[1]) and self._sliced_fits(cache, on):
                 from vptq_amd.utils.sliced import SlicedGemv
                 obj = SlicedGemv(self)
-            st = (cache[6], obj)
+            st = (stamp, obj)
             self.__dict__["_sliced"] = st
         return st[1]
 
