@@ -275,7 +275,7 @@ VPTQ_API int vptq_quant_gemm(const VptqLayerDesc* desc, const void* x, void* y, 
  * (S x N x 8 floats of partial sums + arrival counters), 16-byte aligned, ZERO-FILLED ONCE by the caller before
  * its first use - every call leaves the counters zero; one workspace per layer call in flight (calls on one
  * stream may share it).  Folded arithmetic (parity bar, not bit-equivalent);
- * Layers this path takes: no permutation, group_size <= 32768.
+ * Layers this path takes: group_size <= 32768; a permutation is applied while the activations are staged.
  */
 typedef struct VptqSlicedLayout {
   const void* elems;

@@ -40,6 +40,8 @@ CASES = [
     (512, 4096, dict(dist="llm"), 2),
     (64, 72, dict(), 0),
     (8192, 512, dict(dist="llm", bias=True), 1),
+    (2048, 520, dict(dist="llm", enable_perm=True, bias=True), 0),   # a permutation: applied while the activations are staged
+    (6152, 264, dict(enable_perm=True), 2),
     (14336, 128, dict(dist="llm"), 0),          # with a residual codebook: 16 slices of 4096 entries
     (28672, 64, dict(dist="llm", bias=True), 0),  # 16 slices
 ]

@@ -199,7 +199,7 @@ def fuzz_sliced(a, dev):
         O = int(rng.choice([8 * int(rng.integers(1, 64)), 8 * int(rng.integers(64, 700)) - int(rng.integers(0, 8))]))
         O = max(O, 8)
         L = vo.make_layer(I, O, dist="llm", seed=9000 + c, dtype=dt, num_centroids=65536, num_res_centroids=kr,
-                          bias=bool(rng.integers(0, 2)))
+                          bias=bool(rng.integers(0, 2)), enable_perm=bool(rng.integers(0, 3) == 0))
         skew = int(rng.integers(0, 4))
         if skew:   # rewrite the main indices: 1 = one slice only, 2 = two slices, 3 = 90 % in slice 5
             N = L.indices.shape[1]

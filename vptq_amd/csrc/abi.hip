@@ -369,7 +369,7 @@ int vptq_quant_gemv_sliced(const VptqLayerDesc* d, const VptqSlicedLayout* layou
   if (rc) return rc;
   if (!x || !y || !layout) return fail(VPTQ_E_NULL, "x / y / layout is NULL");
   if (!vptq::gemv_sliced_eligible(*d))
-    return fail(VPTQ_E_UNSUPPORTED, "the sliced layout serves v8-k65536-0 / -256 layers without a permutation, group_size <= 32768");
+    return fail(VPTQ_E_UNSUPPORTED, "the sliced layout serves v8-k65536-0 / -256 layers, group_size <= 32768");
   if (flags & (VPTQ_GEMV_EXACT | VPTQ_GEMV_FORCE_GENERIC))
     return fail(VPTQ_E_UNSUPPORTED, "the sliced path has the folded arithmetic only: use vptq_quant_gemv");
   const size_t need = vptq::gemv_sliced_workspace_bytes(*d);

@@ -63,7 +63,8 @@ struct SlicedParams {
   const uint32_t* cent;     // [65536][8] halves
   const uint16_t* x;
   const uint16_t* scale;
-  const uint16_t* wbias;
+  const uint16_t* wbias;    // input-feature order
+  const uint16_t* perm;     // column c of the quantised matrix multiplies input feature perm[c]; `scale` is then in column order
   const uint16_t* bias;
   float* partial;           // [slices][N * 8]
   uint32_t* arrived;        // [row blocks] workgroups of the row block that have stored their partial sums (0 between launches)
@@ -153,15 +154,27 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedPar
     for (int q = tid; q < chunks + 8; q += kSLThreads) {
       u32x4 v = {0u, 0u, 0u, 0u};
       if (q < chunks && !(VPTQ_SLICED_ABLATE & 4)) {
+        // x in input-FEATURE order (sum b x needs nothing else: a permutation only reorders the sum)
         const u32x4 xv = *(const u32x4*)(as_global(P.x) + 8 * q);
-        const u32x4 sv = *(const u32x4*)(as_global(P.scale) + 8 * q);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = DT::mul2(xv[i], sv[i]);
         if (s == 0) {
           const u32x4 bv = *(const u32x4*)(as_global(P.wbias) + 8 * q);
 #pragma unroll
           for (int i = 0; i < 4; ++i) bd = DT::dot2(xv[i], bv[i], bd);
         }
+        // the staged operand is in COLUMN order: column c multiplies feature perm[c] (scale in column order comes
+        // with the descriptor: scale_permuted)
+        u32x4 xc = xv;
+        if (P.perm != nullptr) {
+          const u32x4 pv = *(const u32x4*)(as_global(P.perm) + 8 * q);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const uint32_t lo = as_global(P.x)[pv[i] & 0xffffu], hi = as_global(P.x)[pv[i] >> 16];
+            xc[i] = lo | (hi << 16);
+          }
+        }
+        const u32x4 sv = *(const u32x4*)(as_global(P.scale) + 8 * q);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = DT::mul2(xc[i], sv[i]);
       }
       *(lds_q_t*)(uintptr_t)(kSLXOff + (uint32_t)q * 16u) = v;
     }
@@ -375,10 +388,11 @@ bool gemv_sliced_eligible(const VptqLayerDesc& d) {
   return d.vector_len == 8 && d.num_codebooks == 1 && d.outlier_size == 0 && d.num_centroids == 65536 &&
          (d.num_res_centroids == 0 || res) && d.index_bits == 16 && (!res || d.res_bits == 8) &&
          d.weight_scale != nullptr && d.weight_bias != nullptr &&
-         d.perm == nullptr && (d.group_size % 8) == 0 && d.group_size == d.in_features &&
+         (d.perm == nullptr || d.scale_permuted != nullptr) && (d.group_size % 8) == 0 && d.group_size == d.in_features &&
          d.group_size <= kSLMaxG16 &&
          (long long)d.row_words * 32 == (long long)d.group_size * (res ? 24 : 16) &&
-         (((uintptr_t)d.centroids | (uintptr_t)d.res_centroids | (uintptr_t)d.weight_scale | (uintptr_t)d.weight_bias) & 15) == 0;
+         (((uintptr_t)d.centroids | (uintptr_t)d.res_centroids | (uintptr_t)d.weight_scale | (uintptr_t)d.weight_bias |
+           (uintptr_t)d.perm | (uintptr_t)d.scale_permuted) & 15) == 0;
 }
 
 // slices a layout of this layer must have
@@ -432,8 +446,9 @@ hipError_t launch_gemv_sliced(const VptqLayerDesc& d, const VptqSlicedLayout& L,
   P.first = (const int32_t*)L.first;
   P.cent = (const uint32_t*)d.centroids;
   P.x = (const uint16_t*)x;
-  P.scale = (const uint16_t*)d.weight_scale;
+  P.scale = (const uint16_t*)(d.perm ? d.scale_permuted : d.weight_scale);
   P.wbias = (const uint16_t*)d.weight_bias;
+  P.perm = (const uint16_t*)d.perm;
   P.bias = (const uint16_t*)d.bias;
   P.partial = (float*)ws;
   P.arrived = (uint32_t*)((char*)ws + sl_partial_bytes(d));

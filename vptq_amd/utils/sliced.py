@@ -92,8 +92,7 @@ class SlicedGemv:
         self.desc, self.dev = cache[1], cache[3]
         self.slices = B.lib().vptq_sliced_layout_supported(self.desc)
         if not self.slices:
-            raise ValueError("the sliced layout serves v8-k65536-0 / v8-k65536-256 layers without a permutation, "
-                             "group_size <= 32768")
+            raise ValueError("the sliced layout serves v8-k65536-0 / v8-k65536-256 layers, group_size <= 32768")
         residual = bool(layer.enable_residual)
         self.elems, self.blocks, self.first, self.res = build_sliced_layout(layer.indices.data, layer.group_size,
                                                                             self.slices, residual)
