@@ -101,6 +101,9 @@ constexpr int kCFlagStride = 256;   // DEP: arrival flags per layer (one per wor
 #endif
 // 1: everything outside the consume phase runs at issue priority 3: those instructions compete with the
 // other waves' MFMAs for the issue port and hold nothing another wave needs (measured: 4.91 -> 4.67 us)
+#ifndef VPTQ_K256C_STAGGER
+#define VPTQ_K256C_STAGGER 0
+#endif
 #ifndef VPTQ_K256C_PRIO
 #define VPTQ_K256C_PRIO 1
 #endif
@@ -839,6 +842,11 @@ __global__ __launch_bounds__(kCThreads) void gemv_k256c_kernel(const K256CParams
 
 #if VPTQ_K256C_PROF
   pf_t0 = now(0);
+#endif
+#if VPTQ_K256C_STAGGER
+  // (experiment) the four waves of a SIMD (wave & 3 = SIMD) start a fraction of a step apart, so that one wave's
+  // bookkeeping falls into the others' consume phases
+  for (int g = 0; g < (wave >> 2); ++g) __builtin_amdgcn_s_sleep(VPTQ_K256C_STAGGER);
 #endif
   // ---- main loop: one step = wait for sweep k, consume it, request sweep k + D into its queue slot
   auto step = [&](auto slot_c) __attribute__((always_inline)) {
