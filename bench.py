@@ -170,6 +170,23 @@ def k65536_extra(lib, B, dev, H, steps, warmup, regions, R=8):
     return out
 
 
+def sysfs_card_of_device(dev_index=0):
+    """/sys/class/drm/cardN/device of HIP device `dev_index`, matched by PCI address (a box of the pool shows every GPU
+    of its node in /sys; the first card is not necessarily the one this process runs on).  None if it cannot be told."""
+    import glob
+    try:
+        bus = torch.cuda.get_device_properties(dev_index).pci_bus_id
+        dom = getattr(torch.cuda.get_device_properties(dev_index), "pci_domain_id", 0)
+        devid = getattr(torch.cuda.get_device_properties(dev_index), "pci_device_id", 0)
+        want = f"{dom:04x}:{bus:02x}:{devid:02x}."
+    except Exception:
+        return None
+    for c in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
+        if os.path.basename(os.path.realpath(c)).lower().startswith(want):
+            return c
+    return None
+
+
 class SclkSampler:
     """Shader clock of this GPU during the timed regions (rule DVFS in or out as the box-to-box
     spread): a thread reads the current level of pp_dpm_sclk every 20 ms.  None where sysfs does not offer it."""
@@ -178,13 +195,21 @@ class SclkSampler:
         import glob
         # the measured shader clock (hwmon freq1_input, Hz) where the driver offers it; else the DPM level table
         # (pp_dpm_sclk: the starred level - on MI300-class parts that is a coarse state, not the live clock)
-        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device"))
-        cards = [c for c in cards if os.path.exists(os.path.join(c, "pp_dpm_sclk"))]
-        self.card = cards[dev_index] if dev_index < len(cards) else None
+        self.card = sysfs_card_of_device(dev_index)   # (matched by PCI address: the node's other GPUs are in /sys too)
         hw = sorted(glob.glob(os.path.join(self.card, "hwmon", "hwmon*", "freq1_input"))) if self.card else []
         self.path = hw[0] if hw else (os.path.join(self.card, "pp_dpm_sclk") if self.card else None)
         self.kind = "hwmon freq1_input" if hw else "pp_dpm_sclk (starred level)"
         self.samples, self._stop, self._thread = [], False, None
+        # package power (hwmon power1_input, microwatts; label PPT) and its cap, where the driver offers them
+        pw = sorted(glob.glob(os.path.join(self.card, "hwmon", "hwmon*", "power1_input"))) if self.card else []
+        self.power_path = pw[0] if pw else None
+        self.power_samples = []
+        self.power_cap_w = None
+        if pw:
+            try:
+                self.power_cap_w = float(open(os.path.join(os.path.dirname(pw[0]), "power1_cap")).read().strip()) / 1e6
+            except Exception:
+                pass
 
     def _read(self):
         try:
@@ -206,6 +231,11 @@ class SclkSampler:
                     v = self._read()
                     if v is not None:
                         self.samples.append(v)
+                    if self.power_path is not None:
+                        try:
+                            self.power_samples.append(float(open(self.power_path).read().strip()) / 1e6)
+                        except Exception:
+                            pass
                     time.sleep(0.02)
             self._thread = threading.Thread(target=loop, daemon=True)
             self._thread.start()
@@ -221,8 +251,15 @@ class SclkSampler:
             return None
         s = sorted(self.samples)
         return {"samples": len(s), "min_mhz": s[0], "median_mhz": s[len(s) // 2], "max_mhz": s[-1],
-                "source": f"{self.kind}, every 20 ms during warm-up and the timed regions (raw sysfs reading: boxes of the "
-                          "pool disagree on what it reports - 1.87-1.99 GHz on one, 0.16-0.24 on another under the same load)"}
+                "source": f"{self.kind} of the card whose PCI address is this HIP device's, every 20 ms (before round 3's "
+                          "last session the first card of /sys was read - on a box of the pool that is another GPU of the node)"}
+
+    def power_summary(self):
+        if not self.power_samples:
+            return None
+        s = sorted(self.power_samples)
+        return {"samples": len(s), "median_w": s[len(s) // 2], "max_w": s[-1], "min_w": s[0], "cap_w": self.power_cap_w,
+                "source": "hwmon power1_input (PPT, package power) of the same card, every 20 ms"}
 
 
 def shard_ring(total_layers, rank, world):
@@ -392,6 +429,20 @@ class Timer:
         self.dev, self.dist, self.allow_eager = dev, dist, allow_eager
         self.stream = torch.cuda.Stream(device=dev)
 
+    def soak(self, seconds):
+        """the last workload again, back to back for `seconds` (power / clock readings need a load that lasts longer
+        than the timed regions); returns microseconds per replay"""
+        n = 0
+        with torch.cuda.stream(self.stream):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            while time.perf_counter() - t0 < seconds:
+                for _ in range(50):
+                    self.last_graph.replay()
+                n += 50
+                torch.cuda.synchronize()
+            return (time.perf_counter() - t0) * 1e6 / n
+
     def run(self, one_pass, steps, warmup, regions):
         dist = self.dist
 
@@ -456,6 +507,7 @@ class Timer:
                 torch.cuda.synchronize()
                 wall = time.perf_counter() - t0
                 res.append(reduce_times(wall, e0.elapsed_time(e1), dist, self.dev))
+        self.last_graph = graph
         res.sort(key=lambda r: r[0])
         med = res[len(res) // 2]
         return dict(wall_s=med[0], event_ms=med[1], captured=captured,
@@ -784,6 +836,14 @@ def main():
         r, layers, x, ys, keeps = bench_ring(lib, B, dev, timer, H, mode if mode in ("grouped", "chain", "chain_dep") else "single",
                                              flags, a.steps, a.warmup, a.regions, rank=rank, world=world, group=a.group,
                                              ring=a.ring, tp_split=tp_split, prefetch=a.prefetch, chain=a.chain)
+    soak = None
+    if rank == 0 and world == 1 and os.environ.get("VPTQ_BENCH_SOAK", "1") != "0":
+        # what the package draws and where the shader clock settles while this workload runs back to back for 1.5 s
+        with SclkSampler(local_rank) as sk:
+            us_replay = timer.soak(1.5)
+        if sk.power_summary() is not None or sk.summary() is not None:
+            soak = {"what": "the timed workload replayed back to back for 1.5 s (after the timed regions), hwmon of this GPU sampled every 20 ms",
+                    "us_per_step": us_replay, "power": sk.power_summary(), "sclk": sk.summary()}
     chain_mode = mode in ("chain", "chain_dep")
     mode_name = (f"chain{min(a.chain, 32, r['ring'])}" if mode == "chain" else mode)
     out = {
@@ -808,14 +868,18 @@ def main():
                                   f"{world} x independent rings (no collective)"},
         "regions_ms_per_step": r["regions_ms_per_step"],
         "sclk_during_timed_regions": sclk.summary(),
+        "power_during_timed_regions": sclk.power_summary(),
+        "soak": soak,
         "roofline": {"bound": "hbm", "achieved": r["achieved"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": r["achieved"] / HBM_PEAK_GBPS, "traffic": None,
                      "bytes_per_launch": r["bytes_per_launch"], "us_per_launch": r["us_per_launch"],
                      "note": ("one launch = the whole ring (32 layers): bytes_per_launch = 32 x the algorithmic bytes of a "
                               "layer (SURVEY 8d), us_per_launch = HIP-event time over the (median) timed region / launches; "
-                              "what bounds it: DESIGN.md 4.9 (per-wave instruction latency between hand-overs, the LDS "
-                              "(2 KiB of gathered entries per index-wave) and the matrix pipe, 32 SIMD cycles per index-wave "
-                              "each; a pure stream of the same bytes runs at 6.7 TB/s, tools/ubench_stream2.hip)") if chain_mode else
+                              "what bounds it: the 1400 W package power limit - this kernel draws the cap and the shader clock "
+                              "settles at ~1.6 of 2.4 GHz (`soak` in this line; profiles/r03/power_probe.txt), which is why every "
+                              "restructuring of it lands on the same time; DESIGN.md 4.9.  In SIMD cycles: the LDS (2 KiB of "
+                              "gathered entries per index-wave) and the matrix pipe have a floor of 32 per index-wave each, the "
+                              "kernel needs 57; a pure stream of the same bytes runs at 6.2-6.7 TB/s (tools/ubench_stream2.hip)") if chain_mode else
                              ("us_per_launch = HIP-event time over the (median) timed region / launches, i.e. "
                               "INCLUDING the kernel boundary (an empty kernel in the same graph: 1.8 us per "
                               "launch, profiles/r02/ubench_stream_8192.txt); rocprofv3's kernel-only duration is "

@@ -22,7 +22,7 @@ static __device__ __forceinline__ u32x2 lds_ld8(uint32_t a) {
   return *(const lds_u2_t*)(uintptr_t)a;
 }
 
-template <int MODE, int THREADS>
+template <int MODE, int THREADS, int AH = 2>
 __global__ __launch_bounds__(THREADS) void loop_kernel(float* out, unsigned long long* cyc, int iters, unsigned seed) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -47,19 +47,20 @@ __global__ __launch_bounds__(THREADS) void loop_kernel(float* out, unsigned long
 #pragma unroll
       for (int q = 0; q < 4; ++q) { r = r * 1664525u + 1013904223u; words[q] = r; }
       const u32x4 xq = lds_load16(65536u + (uint32_t)(wave * 16 + (lane >> 2)) * 16u);
-      u32x4 cv[3], rv[3];
+      u32x4 cv[AH + 1], rv[AH + 1];
       auto gather = [&](int u) {
         const uint32_t w = words[u >> 1];
-        cv[u % 3] = lds_load16(__builtin_amdgcn_perm(w, baseA, selGA[u & 1]));
-        rv[u % 3] = lds_load16(__builtin_amdgcn_perm(w, baseB, selGB[u & 1]));
+        cv[u % (AH + 1)] = lds_load16(__builtin_amdgcn_perm(w, baseA, selGA[u & 1]));
+        rv[u % (AH + 1)] = lds_load16(__builtin_amdgcn_perm(w, baseB, selGB[u & 1]));
       };
-      gather(0); gather(1);
+#pragma unroll
+      for (int u = 0; u < AH; ++u) gather(u);
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         __builtin_amdgcn_sched_barrier(0);
-        if (u + 2 < 8) gather(u + 2);
+        if (u + AH < 8) gather(u + AH);
         __builtin_amdgcn_sched_barrier(0);
-        const u32x4 c = cv[u % 3], rr = rv[u % 3];
+        const u32x4 c = cv[u % (AH + 1)], rr = rv[u % (AH + 1)];
         const u32x2 xo = u32x2{__builtin_amdgcn_perm(xq[u >> 1], 0u, selA[u & 1]), __builtin_amdgcn_perm(xq[u >> 1], 0u, selB[u & 1])};
         acc0 = F16::mfma4(xo, u32x2{c[0], c[1]}, acc0);
         acc1 = F16::mfma4(xo, u32x2{c[2], c[3]}, acc1);
@@ -138,10 +139,10 @@ __global__ __launch_bounds__(THREADS) void loop_kernel(float* out, unsigned long
   if (lane == 0) cyc[blockIdx.x * (THREADS / 64) + wave] = t1 - t0;
 }
 
-template <int MODE, int THREADS>
+template <int MODE, int THREADS, int AH = 2>
 static void run(const char* name, float* out, unsigned long long* cyc) {
   const int iters = 400, wgs = 256;
-  auto kern = loop_kernel<MODE, THREADS>;
+  auto kern = loop_kernel<MODE, THREADS, AH>;
   CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
   hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
   hipLaunchKernelGGL(kern, dim3(wgs), dim3(THREADS), 72 * 1024, 0, out, cyc, iters, 1u);
@@ -175,5 +176,16 @@ int main() {
   run<RD | MF | XR | AH2, 1024>("new loop, gathers two tile pairs ahead", out, cyc);
   run<RD | MF | XR, 512>("new loop, 2 waves / SIMD", out, cyc);
   run<OLD, 512>("old loop, 2 waves / SIMD", out, cyc);
+  // how the 4x4x4 loop depends on the gathers in flight per SIMD (waves x lookahead): latency or throughput?
+  run<OLD, 1024, 1>("old loop, 4 waves / SIMD, lookahead 1", out, cyc);
+  run<OLD, 1024, 3>("old loop, 4 waves / SIMD, lookahead 3", out, cyc);
+  run<OLD, 1024, 4>("old loop, 4 waves / SIMD, lookahead 4", out, cyc);
+  run<OLD, 512, 3>("old loop, 2 waves / SIMD, lookahead 3", out, cyc);
+  run<OLD, 512, 4>("old loop, 2 waves / SIMD, lookahead 4", out, cyc);
+  run<OLD, 512, 6>("old loop, 2 waves / SIMD, lookahead 6", out, cyc);
+  run<OLD, 256, 2>("old loop, 1 wave / SIMD, lookahead 2", out, cyc);
+  run<OLD, 256, 4>("old loop, 1 wave / SIMD, lookahead 4", out, cyc);
+  run<OLD, 256, 6>("old loop, 1 wave / SIMD, lookahead 6", out, cyc);
+  run<OLD, 256, 7>("old loop, 1 wave / SIMD, lookahead 7", out, cyc);
   return 0;
 }

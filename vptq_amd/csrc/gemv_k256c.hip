@@ -52,17 +52,47 @@
 
 namespace vptq {
 
-constexpr int kCThreads = 1024;
-constexpr int kCWaves = kCThreads / 64;
+// profiling build (tools/chain_prof.py): every wave adds up the shader-clock cycles it spends
+// waiting for its index words, consuming a sweep, requesting the next one and in the rare paths,
+// and stores them at P.sync[(workgroup * waves + wave) * kCProfWords ...] (non-dependent launches); 2: + a timeline
+#ifndef VPTQ_K256C_PROF
+#define VPTQ_K256C_PROF 0
+#endif
+// waves per workgroup (= per CU): 16 (4 per SIMD, 128 registers each) or 8 (2 per SIMD, 256 registers: room for 4 row
+// subgroups per sweep and a deeper gather lookahead; a step then covers twice the indices per wave)
+#ifndef VPTQ_K256C_WAVES
+#define VPTQ_K256C_WAVES 16
+#endif
+constexpr int kCWaves = VPTQ_K256C_WAVES;
+constexpr int kCThreads = 64 * kCWaves;
+static_assert(kCWaves == 16 || kCWaves == 8, "waves per workgroup");
 constexpr int kCBlockCols = 128;                     // columns of one wave per sweep
-constexpr int kCSweepCols = kCWaves * kCBlockCols;   // 2048
+// The waves of a workgroup as kCSplit row parts x kCColWaves column blocks: a sweep covers kCColWaves x 128 columns
+// of kCSplit x 8 vector-rows.  2 parts: a row group of an 8192-column layer is 8 sweeps instead of 4, so the sums
+// at the end of a row group (cross-lane reduction, deposit, hand-over: ~1500 clocks per wave) come half as often;
+// the sum over the waves is over 8 instead of 16 partial sums.
+#ifndef VPTQ_K256C_SPLIT
+#define VPTQ_K256C_SPLIT 1
+#endif
+constexpr int kCSplit = VPTQ_K256C_SPLIT;
+static_assert(kCSplit == 1 || kCSplit == 2 || kCSplit == 4, "row parts");
+constexpr int kCColWaves = kCWaves / kCSplit;
+static_assert(kCColWaves >= 4, "the sum over the waves is a tree of groups of 4");
+constexpr int kCSweepCols = kCColWaves * kCBlockCols;   // 2048
 #ifndef VPTQ_K256C_SUB
 #define VPTQ_K256C_SUB 2
 #endif
 constexpr int kCSub = VPTQ_K256C_SUB;                // row subgroups (4 vector-rows each) per row group
-constexpr int kCRows = 4 * kCSub;                    // vector-rows per row group
+constexpr int kCRowsW = 4 * kCSub;                   // vector-rows of one wave
+constexpr int kCOutW = 8 * kCRowsW;                  // outputs of one wave
+constexpr int kCRows = kCRowsW * kCSplit;            // vector-rows per row group
 constexpr int kCOut = 8 * kCRows;                    // outputs per row group
-static_assert(kCSub == 1 || kCSub == 2, "row subgroups per sweep");
+static_assert(kCSub == 1 || kCSub == 2 || kCSub == 4, "row subgroups per sweep");
+static_assert(kCSub != 1 || (kCWaves == 16 && kCSplit == 1), "1 subgroup: the 16-wave sum");
+// gathers requested ahead of the arithmetic, in units (one index of one subgroup)
+#ifndef VPTQ_K256C_AHEAD
+#define VPTQ_K256C_AHEAD 2
+#endif
 // sweeps in flight per wave: bandwidth x latency is ~48 KiB per CU
 #ifndef VPTQ_K256C_DEPTH
 #define VPTQ_K256C_DEPTH 3
@@ -74,9 +104,17 @@ constexpr uint32_t kCImgBytes = 65536;               // 256 rows x 16 units x 16
 constexpr uint32_t kCXsOff = 2 * kCImgBytes;         // wave-private activation slots
 constexpr uint32_t kCXsWave = 256;
 constexpr uint32_t kCRedOff = kCXsOff + kCWaves * kCXsWave;
-constexpr uint32_t kCRedBOff = kCRedOff + kCSlots * kCWaves * kCOut * 4;
+constexpr uint32_t kCRedBOff = kCRedOff + kCSlots * kCWaves * kCOutW * 4;
 constexpr uint32_t kCCntOff = kCRedBOff + kCSlots * kCWaves * 4;
+// profiling build 2: consume start / end stamps of kCTlSteps steps per wave (a timeline of who computes when)
+constexpr int kCTlFirst = 16, kCTlSteps = 32;
+constexpr uint32_t kCTlOff = kCCntOff + 64;
+#if VPTQ_K256C_PROF >= 2
+constexpr uint32_t kCLdsBytes = kCTlOff + kCWaves * kCTlSteps * 8;
+#else
 constexpr uint32_t kCLdsBytes = kCCntOff + 64;
+#endif
+constexpr int kCProfWords = 64;   // 8-byte words of profile output per wave
 static_assert(kCLdsBytes <= 163840, "LDS");
 constexpr int kCFlagStride = 256;   // DEP: arrival flags per layer (one per workgroup)
 
@@ -90,17 +128,14 @@ constexpr int kCFlagStride = 256;   // DEP: arrival flags per layer (one per wor
 #ifndef VPTQ_K256C_SPIN_LIMIT
 #define VPTQ_K256C_SPIN_LIMIT 0
 #endif
-// profiling build (tools/chain_prof.py): every wave adds up the shader-clock cycles it spends
-// waiting for its index words, consuming a sweep, requesting the next one and in the rare paths,
-// and stores them at P.sync[(workgroup * 16 + wave) * 8 ...] (non-dependent launches)
-#ifndef VPTQ_K256C_PROF
-#define VPTQ_K256C_PROF 0
-#endif
 #ifndef VPTQ_K256C_BALANCE
 #define VPTQ_K256C_BALANCE 1
 #endif
 // 1: everything outside the consume phase runs at issue priority 3: those instructions compete with the
 // other waves' MFMAs for the issue port and hold nothing another wave needs (measured: 4.91 -> 4.67 us)
+#ifndef VPTQ_K256C_LDS_FENCE
+#define VPTQ_K256C_LDS_FENCE 1
+#endif
 #ifndef VPTQ_K256C_STAGGER
 #define VPTQ_K256C_STAGGER 0
 #endif
@@ -237,6 +272,13 @@ __global__ __launch_bounds__(kCThreads) void gemv_k256c_kernel(const K256CParams
     typedef __attribute__((address_space(3))) unsigned char lds_u8_t;
     if ((uint32_t)(uintptr_t)(lds_u8_t*)smem != 0u) __builtin_trap();  // absolute LDS addressing
   }
+#if VPTQ_K256C_PROF
+  unsigned long long pf_entry, pf_pro[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pf_entry) :: "memory");
+#define PF_PRO(i) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pf_pro[i]) :: "memory")
+#else
+#define PF_PRO(i) ((void)0)
+#endif
   constexpr int D = kCDepth;
   const int n_layers = P.n_layers;
   const bool out_f32 = (P.tokens & kOutF32Bit) != 0;
@@ -316,8 +358,13 @@ __global__ __launch_bounds__(kCThreads) void gemv_k256c_kernel(const K256CParams
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : "v"(dep) : "memory");
     return t;
   };
+#if VPTQ_K256C_PROF >= 3   // light: only the consume start / end stamps of the timeline
+#define PF_START() ((void)0)
+#define PF_MARK(i) ((void)0)
+#else
 #define PF_START() (pf_last = now(0))
 #define PF_MARK(i) do { const unsigned long long t_ = now(0); pf_x[i] += t_ - pf_last; pf_last = t_; } while (0)
+#endif
 #else
 #define PF_START() ((void)0)
 #define PF_MARK(i) ((void)0)
@@ -334,7 +381,13 @@ __global__ __launch_bounds__(kCThreads) void gemv_k256c_kernel(const K256CParams
   {
     enter_layer(ci);
     if (ci.L >= n_layers) return;     // (whole workgroup: nothing to do)
+#if VPTQ_K256C_PROF
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pf_pro[0]) :: "memory");
+#endif
     const CLayerArgs L0 = c_load_layer(ci.L);
+#if VPTQ_K256C_PROF
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pf_pro[1]) :: "memory");
+#endif
     Li = c_issue_of(L0);
     Lc = c_cons_of(L0);
     Lf = CFillL{L0.cent, L0.rcent};
@@ -346,14 +399,14 @@ __global__ __launch_bounds__(kCThreads) void gemv_k256c_kernel(const K256CParams
   int i_left = 0;             // sweeps of the row group still to request
   int i_max8 = 0, i_max2 = 0;   // 2 (G - 8), 2 (G - 2): columns past G re-read the last ones
   auto issue_row_group = [&]() __attribute__((always_inline)) {
-    const int row0 = ci.rg * kCRows;
+    const int row0 = ci.rg * kCRows + (wave / kCColWaves) * kCRowsW;
 #pragma unroll
     for (int q = 0; q < kCSub; ++q) {
       const int want = row0 + 4 * q + (int)jrow;
       const int r = want < Li.N ? want : Li.N - 1;   // rows past N re-read the last row (not stored)
       i_rowoff[q] = (uint32_t)r * ((uint32_t)Li.row_words * 4u);
     }
-    i_col2 = wave * (kCBlockCols * 2);
+    i_col2 = (wave % kCColWaves) * (kCBlockCols * 2);
     i_left = ci.ns;
     i_max8 = (Li.G - 8) * 2;
     i_max2 = (Li.G - 2) * 2;
@@ -380,7 +433,7 @@ __global__ __launch_bounds__(kCThreads) void gemv_k256c_kernel(const K256CParams
   if (tid < 16) slot_cnt[tid] = 0u;
   __syncthreads();   // the only barrier: counters zeroed before anybody uses them
 
-  // ---- image fill by LDS-DMA: wave w brings rows 16 w .. 16 w + 15 (4 instructions of 4 rows;
+  // ---- image fill by LDS-DMA: wave w brings rows 16 w .. 16 w + 15 (4 instructions of 4 rows; 8 waves: 32 rows, 8;
   // lane l = unit l & 15 of row l >> 4: 16 bytes of entry (row) of table (unit >> 3)).  Invisible
   // loads can only make the compiler's counted waits stricter, never looser (vmcnt retires in order).
   auto fill_image = [&](const CFillL& F, uint32_t buf) __attribute__((always_inline)) {
@@ -389,10 +442,11 @@ __global__ __launch_bounds__(kCThreads) void gemv_k256c_kernel(const K256CParams
     // array in scratch memory and indexed it - a scratch load, waited for with vmcnt(0))
     const uint64_t tc = (uint64_t)(uintptr_t)F.cent, tr = (uint64_t)(uintptr_t)F.rcent;
     const uint64_t pick = (unit >> 3) ? ~0ull : 0ull;
-    const uint64_t va = tc + ((tr - tc) & pick) + (uint64_t)(((uint32_t)wave * 16u + r4) * 16u);
-    const uint32_t dst = buf * kCImgBytes + (uint32_t)wave * 16u * 256u;
+    constexpr uint32_t kRowsW = 256u / (uint32_t)kCWaves;   // image rows per wave
+    const uint64_t va = tc + ((tr - tc) & pick) + (uint64_t)(((uint32_t)wave * kRowsW + r4) * 16u);
+    const uint32_t dst = buf * kCImgBytes + (uint32_t)wave * kRowsW * 256u;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < (int)(kRowsW / 4u); ++i) {
       const uint32_t d = (uint32_t)__builtin_amdgcn_readfirstlane((int)(dst + (uint32_t)i * 1024u));
       const uint64_t v = va + (uint64_t)(i * 64);
       uint32_t keep_m0;   // (M0 belongs to the compiler: saved and restored inside the statement)
@@ -404,7 +458,14 @@ __global__ __launch_bounds__(kCThreads) void gemv_k256c_kernel(const K256CParams
   // order: fences restricted to the local address space.  An ordinary workgroup-scope release also
   // waits for every global load in flight (s_waitcnt vmcnt(0)) - here the whole queue of index
   // words requested ahead.
+  // (VPTQ_K256C_LDS_FENCE=0: the release is a compiler barrier only.  The fence makes the wave wait for its LDS
+  // writes to complete - one LDS round trip behind 16 waves' gathers - before it issues the counter update; the LDS
+  // executes one wave's operations in the order they were issued, so the update cannot overtake the writes.)
+#if VPTQ_K256C_LDS_FENCE
   auto lds_release = [&]() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); };
+#else
+  auto lds_release = [&]() { asm volatile("" ::: "memory"); };
+#endif
   auto lds_acquire = [&]() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); };
   auto lds_inc = [&](uint32_t* p) __attribute__((always_inline)) {
     lds_release();
@@ -473,7 +534,7 @@ __global__ __launch_bounds__(kCThreads) void gemv_k256c_kernel(const K256CParams
     for (int q = 0; q < kCSub; ++q) { acc[q][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[q][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     accb = 0.f;
   };
-  int c_col = wave * kCBlockCols;   // first column of the wave's block in the sweep being consumed
+  int c_col = (wave % kCColWaves) * kCBlockCols;   // first column of the wave's block in the sweep being consumed
   int c_left = cc.ns;               // sweeps of the row group still to consume
   bool done = false;
   uint32_t use = 0;            // how many layers this workgroup has entered before the current one
@@ -535,41 +596,50 @@ __global__ __launch_bounds__(kCThreads) void gemv_k256c_kernel(const K256CParams
     const int rg = fin_rg;
     {
       const int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-      const float* const pr = red + slot * (kCWaves * kCOut);
-      float sum;
-      int ol;   // output of the row group this lane stores
-      bool mine;
-      if constexpr (kCSub == 2) {
-        // 64 outputs: lane = output, 16 partials each, summed as a tree
-        ol = ln; mine = true;
-        float s[4];
+      const float* const pr0 = red + slot * (kCWaves * kCOutW);
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-          s[k] = (pr[(4 * k) * kCOut + ol] + pr[(4 * k + 1) * kCOut + ol]) + (pr[(4 * k + 2) * kCOut + ol] + pr[(4 * k + 3) * kCOut + ol]);
-        sum = (s[0] + s[1]) + (s[2] + s[3]);
-      } else {
-        // 32 outputs: lane (half, o) sums 8 of the 16 waves' partials, one lane swap joins the halves
-        const int half = ln >> 5;
-        ol = ln & 31; mine = ln < 32;
-        const float* const ps = pr + (half * 8) * kCOut + ol;
-        const float s0 = (ps[0] + ps[kCOut]) + (ps[2 * kCOut] + ps[3 * kCOut]);
-        const float s1 = (ps[4 * kCOut] + ps[5 * kCOut]) + (ps[6 * kCOut] + ps[7 * kCOut]);
-        const float hs = s0 + s1;
-        auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(hs), __float_as_uint(hs), false, false);
-        sum = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-      }
-      const int row = rg * kCRows + (ol >> 3);
-      const int o = row * 8 + (ol & 7);
-      const bool store = mine && row < Lc.N && o < Lc.O;
-      const float bdot = row16_allsum(red_b[slot * kCWaves + (ln & 15)]);
-      float bv = 0.f;
-      if (store && Lc.bias) bv = DT::to_float(as_global(Lc.bias)[o]);
-      const float total = sum + bdot;
-      if (store) {
-        if (out_f32) ((float*)as_global(Lc.y))[o] = total + bv;
-        else if (DEP)   // write-through at device scope (sc1): another workgroup reads it in this launch
-          __hip_atomic_store(as_global(Lc.y) + o, DT::from_float(total + bv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else as_global(Lc.y)[o] = DT::from_float(total + bv);
+      for (int fin_pass = 0; fin_pass < (kCOut + 63) / 64; ++fin_pass) {
+        const int part = (64 * fin_pass) / kCOutW;             // row part whose waves hold these outputs
+        const float* const pr = pr0 + part * (kCColWaves * kCOutW);
+        // sum b x: one term per wave of the part (every part forms the same sum; lanes past the wave count add 0)
+        const float bpart = (ln & 15) < kCColWaves ? red_b[slot * kCWaves + part * kCColWaves + (ln & 15) % kCColWaves] : 0.f;
+        const float bdot = row16_allsum(bpart);
+        float sum;
+        int ol;   // output (of this part of the row group) this lane stores
+        bool mine;
+        if constexpr (kCSub >= 2) {
+          // 64 outputs per pass: lane = output, one partial per wave, summed as a tree
+          ol = ln + (64 * fin_pass) % kCOutW; mine = true;
+          float s[kCColWaves / 4];
+#pragma unroll
+          for (int k = 0; k < kCColWaves / 4; ++k)
+            s[k] = (pr[(4 * k) * kCOutW + ol] + pr[(4 * k + 1) * kCOutW + ol]) + (pr[(4 * k + 2) * kCOutW + ol] + pr[(4 * k + 3) * kCOutW + ol]);
+          if constexpr (kCColWaves == 16) sum = (s[0] + s[1]) + (s[2] + s[3]);
+          else if constexpr (kCColWaves == 8) sum = s[0] + s[1];
+          else sum = s[0];
+        } else {
+          // 32 outputs: lane (half, o) sums 8 of the 16 waves' partials, one lane swap joins the halves
+          const int half = ln >> 5;
+          ol = ln & 31; mine = ln < 32;
+          const float* const ps = pr + (half * 8) * kCOutW + ol;
+          const float s0 = (ps[0] + ps[kCOutW]) + (ps[2 * kCOutW] + ps[3 * kCOutW]);
+          const float s1 = (ps[4 * kCOutW] + ps[5 * kCOutW]) + (ps[6 * kCOutW] + ps[7 * kCOutW]);
+          const float hs = s0 + s1;
+          auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(hs), __float_as_uint(hs), false, false);
+          sum = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+        }
+        const int row = rg * kCRows + part * kCRowsW + (ol >> 3);
+        const int o = row * 8 + (ol & 7);
+        const bool store = mine && row < Lc.N && o < Lc.O;
+        float bv = 0.f;
+        if (store && Lc.bias) bv = DT::to_float(as_global(Lc.bias)[o]);
+        const float total = sum + bdot;
+        if (store) {
+          if (out_f32) ((float*)as_global(Lc.y))[o] = total + bv;
+          else if (DEP)   // write-through at device scope (sc1): another workgroup reads it in this launch
+            __hip_atomic_store(as_global(Lc.y) + o, DT::from_float(total + bv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else as_global(Lc.y)[o] = DT::from_float(total + bv);
+        }
       }
       if (DEP) {
         // the write-through stores of this wave have reached memory (every storing wave drains)
@@ -603,7 +673,7 @@ __global__ __launch_bounds__(kCThreads) void gemv_k256c_kernel(const K256CParams
       const uint32_t need = q_done - (uint32_t)kCSlots + 1u;
       if (peeked(kCSlots + slot) < need) lds_wait_ge(&slot_done[slot], need);
     }
-    float* const rs = red + (slot * kCWaves + wave) * kCOut;
+    float* const rs = red + (slot * kCWaves + wave) * kCOutW;
 #pragma unroll
     for (int q = 0; q < kCSub; ++q) {
       float v[8];
@@ -634,7 +704,7 @@ __global__ __launch_bounds__(kCThreads) void gemv_k256c_kernel(const K256CParams
     // come back by now): the early ones yield
     const uint32_t before = (uint32_t)__builtin_amdgcn_readfirstlane((int)arrived_v);
 #if VPTQ_K256C_PRIO
-    bal = before < 5u ? 0 : before < 11u ? 1 : 2;
+    bal = before * (16u / (uint32_t)kCWaves) < 5u ? 0 : before * (16u / (uint32_t)kCWaves) < 11u ? 1 : 2;
 #else
     if (before < 4u) __builtin_amdgcn_s_setprio(0);
     else if (before < 8u) __builtin_amdgcn_s_setprio(1);
@@ -670,7 +740,7 @@ __global__ __launch_bounds__(kCThreads) void gemv_k256c_kernel(const K256CParams
       *(lds_u32_t*)(uintptr_t)st_addr = DT::mul2(xv, sr[S]);
     }
     const u32x4 xq = lds_load16(xq_addr);
-    constexpr int kUnits = 8 * kCSub, kAhead = 2, kNB = kAhead + 1;
+    constexpr int kUnits = 8 * kCSub, kAhead = VPTQ_K256C_AHEAD, kNB = kAhead + 1;
     u32x4 cv[kNB], rv[kNB];
     auto gather = [&](int t) {   // unit t = column t / kCSub of subgroup t % kCSub
       const int u = t / kCSub, q = t % kCSub;
@@ -755,17 +825,22 @@ __global__ __launch_bounds__(kCThreads) void gemv_k256c_kernel(const K256CParams
   };
 
   // ---- prologue: image of the first layer into buffer 0, first D sweeps requested
+  PF_PRO(2);
   fill_image(Lf, 0u);
   c_for_slots([&](auto slot_c) {
     issue(slot_c);
     __builtin_amdgcn_sched_barrier(0);   // (the slots in issue order: the counted waits of the loop rely on it)
   });
+  PF_PRO(3);
   wait_all_but(D);   // the 4 fill instructions are older than the loads above
+  PF_PRO(4);
   lds_inc(&ready_cnt[0]);
   plan_fill();
+  PF_PRO(5);
   zero_acc();
   if (DEP) dep_enter(cc.L);
   lds_wait_ge(&ready_cnt[0], (uint32_t)kCWaves);
+  PF_PRO(6);
 
   // ---- rare events, each behind one branch of the step
   // the next layer's image: requested as soon as its buffer is free (every wave has left the layer
@@ -792,7 +867,7 @@ __global__ __launch_bounds__(kCThreads) void gemv_k256c_kernel(const K256CParams
   auto row_group_done = [&]() __attribute__((always_inline)) {
     finish();
     zero_acc();
-    c_col = wave * kCBlockCols;
+    c_col = (wave % kCColWaves) * kCBlockCols;
     c_left = cc.ns;
     if (cc.rg + 1 < cc.re) { cc.rg += 1; return; }
     if (fin_pending) finalize();   // (the layer's arguments are about to change; DEP: its flag is due)
@@ -851,9 +926,12 @@ __global__ __launch_bounds__(kCThreads) void gemv_k256c_kernel(const K256CParams
   // ---- main loop: one step = wait for sweep k, consume it, request sweep k + D into its queue slot
   auto step = [&](auto slot_c) __attribute__((always_inline)) {
     __builtin_amdgcn_sched_barrier(0);
+#if VPTQ_K256C_PROF >= 3
+    const unsigned long long tb = now(0);   // (before the peek: the stamp waits for every LDS operation in flight)
+#endif
     peek_counters();
     __builtin_amdgcn_sched_barrier(0);
-#if VPTQ_K256C_PROF
+#if VPTQ_K256C_PROF && VPTQ_K256C_PROF < 3
     constexpr int SS = decltype(slot_c)::value;
     const unsigned long long ta = now(0);
     asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kLPS * (D - 1)) : "memory");
@@ -873,20 +951,28 @@ __global__ __launch_bounds__(kCThreads) void gemv_k256c_kernel(const K256CParams
 #if VPTQ_K256C_PROF
     const unsigned long long tc = now(__float_as_uint(acc[0][0][0] + acc[0][1][0]));
     pf_cons += tc - tb;
+#if VPTQ_K256C_PROF >= 2
+    if (lane == 0 && pf_steps >= (unsigned long long)kCTlFirst && pf_steps < (unsigned long long)(kCTlFirst + kCTlSteps)) {
+      uint32_t* const tl = (uint32_t*)(smem + kCTlOff) + ((uint32_t)wave * kCTlSteps + (uint32_t)(pf_steps - kCTlFirst)) * 2u;
+      tl[0] = (uint32_t)tb; tl[1] = (uint32_t)tc;
+    }
+#endif
 #endif
     if (fill_pending) fill_events_before_issue();
     __builtin_amdgcn_sched_barrier(0);
     issue(slot_c);
     __builtin_amdgcn_sched_barrier(0);
-#if VPTQ_K256C_PROF
+#if VPTQ_K256C_PROF && VPTQ_K256C_PROF < 3
     const unsigned long long td = now(0);
     pf_issue += td - tc;
 #endif
     if (land_steps > 0) fill_events_after_issue();
     c_col += kCSweepCols;
     if (--c_left == 0) row_group_done();
-#if VPTQ_K256C_PROF
+#if VPTQ_K256C_PROF && VPTQ_K256C_PROF < 3
     pf_cold += now(0) - td;
+#endif
+#if VPTQ_K256C_PROF
     ++pf_steps;
 #endif
   };
@@ -895,10 +981,25 @@ __global__ __launch_bounds__(kCThreads) void gemv_k256c_kernel(const K256CParams
   } while (!done);
 #if VPTQ_K256C_PROF
   if (!DEP && sync && lane == 0) {
-    unsigned long long* o = (unsigned long long*)sync + ((size_t)bid * kCWaves + wave) * 16;
+    unsigned long long* o = (unsigned long long*)sync + ((size_t)bid * kCWaves + wave) * kCProfWords;
 #pragma unroll
     for (int i = 0; i < 8; ++i) o[8 + i] = pf_x[i];
     o[0] = pf_wait; o[1] = pf_cons; o[2] = pf_issue; o[3] = pf_cold; o[4] = pf_steps; o[5] = now(0) - pf_t0;
+    o[6] = pf_t0 - pf_entry;   // kernel entry -> first step (prologue)
+    o[7] = pf_entry;           // absolute (s_memtime) entry stamp: spread of the workgroups' start
+#pragma unroll
+    for (int i = 0; i < 7; ++i) o[16 + i] = pf_pro[i] - pf_entry;   // prologue marks, clocks since kernel entry
+    {
+      uint32_t hw;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      o[23] = hw;   // wave 3:0, SIMD 5:4, CU 11:8, SH 12, SE 15:13
+    }
+#if VPTQ_K256C_PROF >= 2
+    {
+      const uint32_t* const tl = (const uint32_t*)(smem + kCTlOff) + (uint32_t)wave * kCTlSteps * 2u;
+      for (int i = 0; i < kCTlSteps; ++i) o[24 + i] = (unsigned long long)tl[2 * i] | ((unsigned long long)tl[2 * i + 1] << 32);
+    }
+#endif
   }
 #endif
 }
