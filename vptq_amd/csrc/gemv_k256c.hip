@@ -136,6 +136,9 @@ constexpr int kCFlagStride = 256;   // DEP: arrival flags per layer (one per wor
 #ifndef VPTQ_K256C_LDS_FENCE
 #define VPTQ_K256C_LDS_FENCE 1
 #endif
+#ifndef VPTQ_K256C_PREADD
+#define VPTQ_K256C_PREADD 0
+#endif
 #ifndef VPTQ_K256C_STAGGER
 #define VPTQ_K256C_STAGGER 0
 #endif
@@ -770,6 +773,13 @@ __global__ __launch_bounds__(kCThreads) void gemv_k256c_kernel(const K256CParams
       const u32x4 c = cv[t % kNB], r = rv[t % kNB];
       if constexpr ((VPTQ_K256C_ABLATE & 1) != 0) {
         asm volatile("" :: "v"(c), "v"(r), "v"(xo));
+      } else if constexpr (VPTQ_K256C_PREADD != 0 && std::is_same<DT, F16>::value) {
+        // (experiment) f16(c + r) first - the reference's own first rounding (csrc/kernels/quant_gemv.cuh) - then 2
+        // instead of 4 MFMAs per index: the MFMAs are the larger part of the energy, and the kernel runs at the
+        // package power limit
+        const u32x4 w = u32x4{DT::add2(c[0], r[0]), DT::add2(c[1], r[1]), DT::add2(c[2], r[2]), DT::add2(c[3], r[3])};
+        acc[q][0] = DT::mfma4(xo, u32x2{w[0], w[1]}, acc[q][0]);
+        acc[q][1] = DT::mfma4(xo, u32x2{w[2], w[3]}, acc[q][1]);
       } else {
         acc[q][0] = DT::mfma4(xo, u32x2{c[0], c[1]}, acc[q][0]);
         acc[q][1] = DT::mfma4(xo, u32x2{c[2], c[3]}, acc[q][1]);
