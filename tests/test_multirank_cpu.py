@@ -60,3 +60,26 @@ def test_layer_parallel_bookkeeping_world2():
 def test_alg_bytes_matches_survey():
     import bench
     assert bench.alg_bytes(4096) == 4235264 and bench.alg_bytes(8192) == 16850944
+
+
+def test_board_sampler_reads_the_card_of_this_device(tmp_path, monkeypatch):
+    """bench.py's clock / power sampler: the hwmon files of the card whose PCI address is the HIP device's (a box of the
+    pool shows every GPU of its node in /sys); nothing to read -> summaries are None, never an exception"""
+    import time
+    import bench
+    assert bench.sysfs_card_of_device(0) is None        # no GPU here
+    with bench.SclkSampler(0) as s:
+        time.sleep(0.05)
+    assert s.summary() is None and s.power_summary() is None
+    # a fake card: freq1_input in Hz, power1_input / power1_cap in microwatts
+    hw = tmp_path / "card7" / "device" / "hwmon" / "hwmon3"
+    hw.mkdir(parents=True)
+    (hw / "freq1_input").write_text("1620000000\n")
+    (hw / "power1_input").write_text("1399000000\n")
+    (hw / "power1_cap").write_text("1400000000\n")
+    monkeypatch.setattr(bench, "sysfs_card_of_device", lambda i=0: str(tmp_path / "card7" / "device"))
+    with bench.SclkSampler(0) as s:
+        time.sleep(0.1)
+    assert s.summary()["median_mhz"] == 1620.0
+    p = s.power_summary()
+    assert p["median_w"] == 1399.0 and p["cap_w"] == 1400.0
