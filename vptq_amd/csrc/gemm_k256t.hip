@@ -226,13 +226,14 @@ __global__ __launch_bounds__(kBTThreads) void gemm_k256t_kernel(const GemmK256TP
   int i_rg = bid, i_s = 0;
   uint32_t i_rowoff = 0;
   const uint32_t lane_chunk2 = (kg * 4u + src_e) * 16u;   // byte offset of this lane's 8 index elements in a block
-  const int i_max8 = (P.G - 8) * 2;
+  int i_max8 = (P.G - 8) * 2;
   // A operand: lane (kg, m = s16) supplies token m; token slots past the token count re-read the last token
   // (their rows of the result are never stored, and a row of D depends on its own row of A only).  (Loads
   // under a lane predicate instead: the compiler can no longer count them and every wait of the loop becomes
   // "all but 2".)
   const uint32_t tok = s16 < (uint32_t)P.tokens ? s16 : (uint32_t)P.tokens - 1u;
-  const uint32_t a_lane = kg * 256u + tok * 16u;
+  uint32_t a_lane = kg * 256u + tok * 16u;
+  uint32_t a_blk = 4096u;   // bytes of the activation operand per block of columns (0 past the end of the stream)
   auto issue_row_group = [&]() __attribute__((always_inline)) {
     const int want = i_rg * kBTRows + (int)src_c;
     const int r = want < P.N ? want : P.N - 1;   // rows past N re-read the last row (not stored)
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(kBTThreads) void gemm_k256t_kernel(const GemmK256TP
     const int want = blk * (kBTBlockCols * 2) + (int)lane_chunk2;
     const uint32_t coff = (uint32_t)(want < i_max8 ? want : i_max8);   // columns past G re-read the last ones (x' = 0 there)
     iw[S] = __builtin_nontemporal_load((const u32x4*)((const char*)idx + (i_rowoff + coff)));
-    const char* const ap = (const char*)xp + (a_lane + (uint32_t)blk * 4096u);
+    const char* const ap = (const char*)xp + (a_lane + (uint32_t)blk * a_blk);
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       if constexpr ((VPTQ_K256BT_ABLATE & 4) != 0) {
@@ -257,8 +258,14 @@ __global__ __launch_bounds__(kBTThreads) void gemm_k256t_kernel(const GemmK256TP
     }
     if (++i_s == ns) {
       i_s = 0;
-      if (i_rg + W < n_groups) i_rg += W;   // (past the end: the last row group is re-requested, harmless)
-      issue_row_group();
+      if (i_rg + W < n_groups) {
+        i_rg += W;
+        issue_row_group();
+      } else {
+        // past the end of the stream the steps still issue their loads (the waits stay counted): every lane reads
+        // the first bytes of the tensors - cached lines - instead of re-reading the last row group and its operands
+        i_rowoff = 0u; i_max8 = 0; a_lane = 0u; a_blk = 0u;
+      }
     }
   };
 
