@@ -138,6 +138,40 @@ def fuzz_adversarial(a, dev):
         print(f"  {k:22s} gated={int(w['gated'])} " + " ".join(f"{n}={v:.2e}" for n, v in w.items() if n != "gated"))
 
 
+def fuzz_tokens(a, dev):
+    """random canonical layers x 2 ... 40 tokens through the library's default route with the scratch buffer
+    (gemv_k256m for 2-4 tokens, gemm_k256t from 5: partial sweeps / row groups, perm, bias, launches of 16) against the
+    oracle; the same call twice - bit-identical"""
+    rng = np.random.default_rng(a.seed)
+    dt = a.dtype
+    tol = 1e-3 if dt == "f16" else 8e-3
+    worst = {}
+    for c in range(a.cases):
+        I = int(rng.choice([8 * int(rng.integers(16, 1800)), 2048 * int(rng.integers(1, 8)), 2048 * int(rng.integers(1, 8)) + 8]))
+        O = int(rng.choice([8 * int(rng.integers(1, 200)), 8 * int(rng.integers(200, 1400)) - int(rng.integers(0, 8))]))
+        O = max(O, 8)
+        if I * O > 16e6:
+            O = max(8, int(16e6 // I) // 8 * 8)
+        tokens = int(rng.choice([int(rng.integers(2, 5)), int(rng.integers(5, 17)), int(rng.integers(17, 41))]))
+        kw = dict(enable_perm=bool(rng.integers(0, 2)), bias=bool(rng.integers(0, 2)))
+        L = vo.make_layer(I, O, dist="llm", seed=3000 + c, dtype=dt, **kw)
+        x = vo.from_f32(rng.standard_normal((1, tokens, I)).astype(np.float32), dt)
+        m = spec_to_module(L, dev)
+        xt = bits_to_tensor(x, dt, dev).reshape(x.shape)
+        want = vo.forward(L, x)
+        name = kernel_name(m, min(tokens, 16))
+        got = gemv_abi(m, xt, 0)
+        torch.cuda.synchronize()
+        got2 = gemv_abi(m, xt, 0)
+        torch.cuda.synchronize()
+        assert torch.equal(got.view(torch.int16), got2.view(torch.int16)), (c, "not reproducible")
+        e = rel_err(tensor_to_bits(got), want, dt)
+        worst[name] = max(worst.get(name, 0.0), e)
+        print(f"case {c:3d} I={I:6d} O={O:6d} tokens={tokens:2d} perm={int(kw['enable_perm'])} bias={int(kw['bias'])} {name}: {e:.2e}", flush=True)
+        assert e <= tol, (c, I, O, tokens, name, e)
+    print("worst:", {k: f"{v:.2e}" for k, v in worst.items()})
+
+
 def fuzz_chains(a, dev):
     """random chains through the persistent launch (vptq_quant_gemv_chain / gemv_k256c_kernel): 2-14 layers of random
     shapes (partial sweeps / row groups, more or fewer row groups than workgroups, bias), independent and dependent,
@@ -245,10 +279,13 @@ def main():
     ap.add_argument("--formats", action="store_true", help="random index formats instead of the canonical one")
     ap.add_argument("--lds-tall", action="store_true", help="tall layers of the LDS-resident formats (gemv_lds_mfma_kernel)")
     ap.add_argument("--adversarial", action="store_true", help="families built against the folded arithmetic")
+    ap.add_argument("--tokens", action="store_true", help="random token counts 2 ... 40 through the default route")
     ap.add_argument("--chains", action="store_true", help="random chains through the persistent chain launch")
     ap.add_argument("--sliced", action="store_true", help="random k = 65536 layers over the sliced layout")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
+    if a.tokens:
+        return fuzz_tokens(a, dev)
     if a.chains:
         return fuzz_chains(a, dev)
     if a.sliced:
