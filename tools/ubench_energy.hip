@@ -8,7 +8,7 @@
 // modes: 0 v_mfma_f32_4x4x4_16B_f16   1 v_mfma_f32_16x16x16_f16   2 v_mfma_f32_16x16x32_f16   3 ds_read_b128 (conflict-free gather)
 //        4 v_perm_b32   5 v_dot2_f32_f16   6 v_pk_fma_f16   7 v_fma_mix_f32   8 v_pk_add_f16   9 s_nop (idle waves)
 //        10 4x4x4 MFMA with a one-hot A operand (x * e_j: what the kernel feeds it)
-// NOT RUN YET (written after the round's GPU budget was spent): next round's first measurement.
+// Modes 0, 10 and 3 were run once (profiles/r03/ubench_energy_first.txt); the others are next round's first measurement.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
