@@ -1,0 +1,106 @@
+"""The load-time derived layout of the k = 65536 formats (vptq_amd/utils/sliced.py:build_sliced_layout, consumed by
+gemv_sliced.hip) on CPU tensors: every element of every row appears exactly once, in the slice of its index, with its
+column, its index inside the slice and its residual index; lists are padded to blocks of 64 with (column = G, local 0);
+`blocks` / `first` describe the contiguous per-(slice, row) streams the kernel walks.
+Packed index format: vptq/utils/pack.py:26-89 (little-endian bit stream per row, element g at bits [T g, T g + T))."""
+import numpy as np
+import pytest
+import torch
+
+from vptq_amd.utils.sliced import build_sliced_layout, rows_per_wave_for
+
+
+def _pack(idx, ridx):
+    """idx [N, G] uint16 (+ ridx [N, G] uint8 or None) -> int32 [1, N, row_words]"""
+    N, G = idx.shape
+    nb = 2 if ridx is None else 3
+    by = np.zeros((N, G, nb), np.uint8)
+    by[:, :, 0] = idx & 0xff
+    by[:, :, 1] = idx >> 8
+    if ridx is not None:
+        by[:, :, 2] = ridx
+    flat = by.reshape(N, G * nb)
+    pad = (-flat.shape[1]) % 4
+    if pad:
+        flat = np.concatenate([flat, np.zeros((N, pad), np.uint8)], axis=1)
+    return torch.from_numpy(np.ascontiguousarray(flat).view(np.int32).reshape(1, N, -1).copy())
+
+
+@pytest.mark.parametrize("N,G,slices,residual,dist", [
+    (8, 64, 8, False, "uniform"),
+    (21, 520, 8, True, "uniform"),
+    (16, 2048, 16, True, "uniform"),
+    (5, 1000, 8, False, "one-slice"),      # every index in slice 3: the other slices' lists are empty
+    (7, 136, 16, True, "one-entry"),       # every element the same index: one class, one slice
+    (33, 72, 8, True, "uniform"),
+])
+def test_sliced_layout_holds_every_element_once(N, G, slices, residual, dist):
+    rng = np.random.default_rng(N * 1000 + G)
+    if dist == "uniform":
+        idx = rng.integers(0, 65536, (N, G), dtype=np.int64)
+    elif dist == "one-slice":
+        idx = 3 * (65536 // slices) + rng.integers(0, 65536 // slices, (N, G), dtype=np.int64)
+    else:
+        idx = np.full((N, G), 40000, np.int64)
+    idx = idx.astype(np.uint16)
+    ridx = rng.integers(0, 256, (N, G)).astype(np.uint8) if residual else None
+    elems, blocks, first, res = build_sliced_layout(_pack(idx, ridx), G, slices, residual)
+    assert elems.dtype == torch.int32 and blocks.shape == (slices, N) and first.shape == (slices, N)
+    assert (res is None) == (not residual)
+    e = elems.numpy().view(np.uint32)
+    blocks, first = blocks.numpy(), first.numpy()
+    slice_size = 65536 // slices
+    # `first` is the running total of `blocks` in (slice, row) order: one contiguous stream per workgroup's wave
+    flat_b = blocks.reshape(-1)
+    assert np.array_equal(first.reshape(-1), np.cumsum(flat_b) - flat_b)
+    assert e.size == max(int(flat_b.sum()), 1) * 64
+    if residual:
+        assert res.dtype == torch.uint8 and res.numel() == e.size
+        r = res.numpy()
+    for n in range(N):
+        seen = np.zeros(G, bool)
+        for s in range(slices):
+            lo, cnt = int(first[s, n]) * 64, int(blocks[s, n]) * 64
+            w = e[lo:lo + cnt]
+            col, local = w & 0xffff, w >> 16
+            real = col < G
+            # padding: (column G, local 0) only, and only at the end of the list, less than one block of it
+            assert np.all(col[~real] == G) and np.all(local[~real] == 0)
+            k = int(real.sum())
+            assert np.all(real[:k]) and cnt - k < 64 and (cnt == 0) == (k == 0)
+            c = col[:k].astype(np.int64)
+            assert not seen[c].any() and len(np.unique(c)) == k       # each column once
+            seen[c] = True
+            assert np.all(local[:k] < slice_size)
+            assert np.array_equal(s * slice_size + local[:k].astype(np.int64), idx[n, c].astype(np.int64))
+            if residual:
+                assert np.array_equal(r[lo:lo + k], ridx[n, c])
+        assert seen.all()
+
+
+def test_sliced_layout_spreads_lds_bank_groups():
+    """inside a (row, slice) list, 16 consecutive elements - one pass of the kernel's ds_read_b128 gather - should hit
+    different bank groups (entry & 15) as far as the list's classes allow: with uniform indices no class may appear
+    more than twice in a window of 16 (column order gives 3-way conflicts on average)"""
+    rng = np.random.default_rng(7)
+    N, G = 4, 8192
+    idx = rng.integers(0, 65536, (N, G)).astype(np.uint16)
+    elems, blocks, first, _ = build_sliced_layout(_pack(idx, None), G, 8, False)
+    e = elems.numpy().view(np.uint32)
+    worst = 0
+    for n in range(N):
+        for s in range(8):
+            lo, cnt = int(first[s, n]) * 64, int(blocks[s, n]) * 64
+            w = e[lo:lo + cnt]
+            w = w[(w & 0xffff) < G]
+            cls = (w >> 16) & 15
+            for i in range(0, len(cls) - 15 - 64, 16):   # (the tail of a list runs out of some classes)
+                worst = max(worst, int(np.bincount(cls[i:i + 16], minlength=16).max()))
+    assert worst <= 2
+
+
+def test_rows_per_wave():
+    assert rows_per_wave_for(1024, 8) == 2       # 8192 rows of 8 outputs: 8 slices x 32 row blocks = 256 workgroups
+    assert rows_per_wave_for(512, 8) == 1
+    assert rows_per_wave_for(3584, 16) == 14
+    assert rows_per_wave_for(10 ** 6, 8) == 64   # capped: block counts of a wave's rows sit in the lanes of one register
