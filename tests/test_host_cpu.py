@@ -230,6 +230,12 @@ def test_validation_errors_without_gpu():
     assert lib.vptq_quant_gemv(d, 16, 16, 99, 0, None, 0, None) == -5
     d.row_words = 3
     assert lib.vptq_quant_gemv(d, 16, 16, 1, 0, None, 0, None) == -2      # row too short
+    # 4 GiB or more of packed indices: the kernels' 32-bit byte offsets would wrap - refused, loudly
+    d.out_features, d.num_indices, d.row_words = 8 * (1 << 20), 1 << 20, 1024
+    assert lib.vptq_quant_gemv(d, 16, 16, 1, 0, None, 0, None) == -2 and b"4 GiB" in lib.vptq_last_error()
+    d.row_words = 1023                                                     # just under: accepted by the validation
+    assert lib.vptq_quant_gemv_kernel_name(d, 1, 0) is not None
+    d.out_features, d.num_indices = 64, 8
     d.row_words = 16
     d.perm = 16
     assert lib.vptq_dequant(d, 16, None) == -1                             # needs inv_perm

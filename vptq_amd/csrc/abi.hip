@@ -65,6 +65,11 @@ int validate_layer(const VptqLayerDesc* d) {
                 need_words);
   if (d->num_indices != (d->out_features + v - 1) / v)
     return fail(VPTQ_E_SHAPE, "num_indices %d != ceil(out_features/vector_len)", d->num_indices);
+  // the kernels address the packed indices with 32-bit byte offsets
+  if ((unsigned long long)d->num_codebooks * (unsigned long long)d->num_indices * (unsigned long long)d->row_words * 4ull >=
+      (1ull << 32))
+    return fail(VPTQ_E_SHAPE, "packed indices of %d x %d x %d words: 4 GiB or more are not supported", d->num_codebooks,
+                d->num_indices, d->row_words);
   if (d->outlier_size > 0) {
     if (!d->outlier_indices || !d->outlier_centroids)
       return fail(VPTQ_E_NULL, "outlier tensors required when outlier_size > 0");
