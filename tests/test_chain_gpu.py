@@ -9,7 +9,7 @@ import pytest
 import torch
 
 from oracle import vptq_oracle as vo
-from _cases import rel_err, big_names, load_big
+from _cases import rel_err, big_names, load_big, bit_identical_frac
 from _gpu_util import spec_to_module, bits_to_tensor, tensor_to_bits, gemv_abi
 
 pytestmark = pytest.mark.gpu
@@ -191,3 +191,64 @@ def test_chain_in_a_hipgraph_and_long_chains(dev):
         for i in (0, 17, 31, 32, 39):
             err = rel_err(tensor_to_bits(ys[i]), vo.forward(L, vals[i]), "f16")
             assert err <= 1e-3, (rep, i, err)
+
+
+def test_chain_with_the_reference_roundings(dev):
+    """VPTQ_GEMV_EXACT inside the chain launch (fp16, independent layers): every weight rebuilt with the reference
+    CPU path's three roundings (vptq/ops/quant_gemm.py:143-158), so the outputs are the oracle's up to the order of
+    the fp32 sums - over every edge shape of the stream; bf16 and dependent chains take the per-layer kernels."""
+    from vptq_amd.ops.chain import GemvChain
+    from vptq_amd import _backend as B
+    Ls, ms, xs = _build(SHAPES, "f16", dev)
+    chain = GemvChain(ms)
+    assert chain.kernel_name(1, CHAIN | B.GEMV_EXACT) == "gemv_k256c_kernel"
+    xt = [bits_to_tensor(x, "f16", dev).reshape(x.shape) for x in xs]
+    ys = chain(xt, flags=CHAIN | B.GEMV_EXACT)
+    torch.cuda.synchronize()
+    for L, m, x, xg, y in zip(Ls, ms, xs, xt, ys):
+        want = vo.forward(L, x)
+        assert rel_err(tensor_to_bits(y), want, "f16") <= 1e-3, f"{L.in_features}x{L.out_features}"
+        assert bit_identical_frac(tensor_to_bits(y), want) >= 0.95, f"{L.in_features}x{L.out_features}"
+        # the per-layer kernel with the same roundings: the same weights, another order of the sums
+        assert bit_identical_frac(tensor_to_bits(y), tensor_to_bits(gemv_abi(m, xg, B.GEMV_EXACT))) >= 0.95
+    y32 = chain(xt, flags=CHAIN | B.GEMV_EXACT | B.GEMV_OUT_F32)
+    for a, b in zip(ys, y32):
+        assert torch.equal(b.half().view(torch.int16), a.view(torch.int16))
+    Lb, mb, xb = _build(SHAPES[:2], "bf16", dev)
+    assert GemvChain(mb).kernel_name(1, CHAIN | B.GEMV_EXACT) == "per-layer"
+
+
+@pytest.mark.parametrize("exact", [False, True])
+def test_chain_of_32_distinct_8192_layers_every_output(exact, dev):
+    """>= 16 DISTINCT BASELINE-size layers through ONE launch, every layer's output checked (the ring of
+    `bench.py`): 32 procedural 8192 x 8192 layers (tests/golden/_proc.py:big_tensors, one seed each) against the C
+    oracle; default arithmetic within the bar, reference roundings >= 99 % bit-identical."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from _proc import big_tensors
+    from oracle import c_oracle as co
+    from vptq_amd.ops.chain import GemvChain
+    from vptq_amd import _backend as B
+    H, n = 8192, 32
+    Ls, ms, xs = [], [], []
+    for i in range(n):
+        t = big_tensors(H, H, 8, 256, 256, False, False, 1, "f16", "llm" if i % 4 else "ref-test", 9100 + i)
+        L = vo.LayerSpec(H, H, 8, 256, 256, 1, H, 0, -1, -1, "f16")
+        L.indices = t["indices"]
+        L.centroids, L.res_centroids = t["centroids"].reshape(1, 256, 8), t["res_centroids"].reshape(1, 256, 8)
+        L.weight_scale, L.weight_bias = t["weight_scale"], t["weight_bias"]
+        Ls.append(L); ms.append(spec_to_module(L, dev)); xs.append(t["x"].reshape(1, 1, H))
+    chain = GemvChain(ms)
+    flags = B.GEMV_EXACT if exact else 0
+    assert chain.kernel_name(1, flags) == "gemv_k256c_kernel"   # (fills the device by itself: no FORCE flag)
+    ys = chain([bits_to_tensor(x, "f16", dev).reshape(1, 1, H) for x in xs], flags=flags)
+    torch.cuda.synchronize()
+    worst = 0.0
+    for i, (L, x, y) in enumerate(zip(Ls, xs, ys)):
+        want = co.forward(L, x, quirk=False)
+        err = rel_err(tensor_to_bits(y), want, "f16")
+        worst = max(worst, err)
+        assert err <= 1e-3, f"layer {i}: {err:.3e}"
+        if exact:
+            assert bit_identical_frac(tensor_to_bits(y), want) >= 0.99, f"layer {i}"
+    print(f"32 distinct 8192^2 layers, exact={exact}: worst {worst:.2e}")

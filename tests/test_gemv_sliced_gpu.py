@@ -123,13 +123,13 @@ def test_sliced_layout_in_a_hipgraph(dev):
     sl = SlicedGemv(m)
     xs = torch.zeros(1, 1, 2048, dtype=torch.float16, device=dev)
     ys = torch.empty(1, 1, 1024, dtype=torch.float16, device=dev)
-    sl(xs, ys)
-    torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
     s = torch.cuda.Stream()
     with torch.cuda.stream(s):
+        sl(xs, ys)          # warm-up on the capture stream: the layer's workspace is per stream
+        torch.cuda.synchronize()
         with torch.cuda.graph(g, stream=s):
-            sl(xs, ys)
+            assert sl(xs, ys) is ys
     for rep in range(2):
         v = _x(2048, "f16", "llm", 50 + rep)
         xs.copy_(bits_to_tensor(v, "f16", dev).reshape(1, 1, 2048))
@@ -179,3 +179,52 @@ def test_module_forward_takes_the_sliced_layout_when_enabled(dev):
     assert rel_err(tensor_to_bits(m(xt)), vo.forward(L, x1), "f16") <= 1e-3
     m.enable_sliced_layout(False)
     assert m._sliced_gemv() is None
+
+
+def test_sliced_route_falls_back_instead_of_failing(dev):
+    """the sliced one-token route is on by default and sits in front of the regular routing, so whatever it
+    cannot take must fall through to it: an activation that is not 16-byte aligned, a capture on a stream the layer
+    has never run on (its workspace is per stream and is not allocated inside a capture), a first call inside a
+    capture (no layout is built there - and that "no" must not stick)."""
+    L = vo.make_layer(2048, 512, seed=31, dist="llm", num_centroids=65536, num_res_centroids=256)
+    m = spec_to_module(L, dev)
+    m.enable_sliced_layout()
+    x1 = _x(2048, "f16", "llm", 5)
+    want = vo.forward(L, x1)
+    buf = torch.zeros(2048 + 8, dtype=torch.float16, device=dev)
+    xm = buf[1:2049].view(1, 1, 2048)                 # contiguous, 2 bytes off a 16-byte boundary
+    xm.copy_(bits_to_tensor(x1, "f16", dev).reshape(1, 1, 2048))
+    assert xm.data_ptr() % 16 == 2
+    # a first call inside a capture: regular route, nothing remembered
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    xa = bits_to_tensor(x1, "f16", dev).reshape(1, 1, 2048)
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            yg = m(xa)
+    assert m.__dict__.get("_sliced") is None
+    g.replay()
+    torch.cuda.synchronize()
+    assert rel_err(tensor_to_bits(yg), want, "f16") <= 1e-3
+    ya = m(xa)                                        # builds the layout now
+    sl = m.__dict__["_sliced"][1]
+    assert sl is not None
+    assert rel_err(tensor_to_bits(ya), want, "f16") <= 1e-3
+    ym = m(xm)                                        # misaligned: the gather kernel
+    assert rel_err(tensor_to_bits(ym), want, "f16") <= 1e-3
+    assert sl(xm) is None
+    # capture on a stream this layer has not run on: no workspace is created inside the capture
+    g2 = torch.cuda.CUDAGraph()
+    s2 = torch.cuda.Stream()
+    with torch.cuda.stream(s2):
+        with torch.cuda.graph(g2, stream=s2):
+            assert sl(xa) is None
+            y2 = m(xa)
+    g2.replay()
+    torch.cuda.synchronize()
+    assert rel_err(tensor_to_bits(y2), want, "f16") <= 1e-3
+    # two streams: separate workspaces
+    with torch.cuda.stream(s2):
+        y3 = m(xa)
+    torch.cuda.synchronize()
+    assert len(sl._ws) >= 2 and torch.equal(y3.view(torch.int16), ya.view(torch.int16))

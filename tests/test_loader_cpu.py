@@ -71,6 +71,19 @@ def test_loader_device_map_is_honoured_or_refused(tmp_path):
     assert next(m.parameters()).device.type == "cpu"
     with pytest.raises(NotImplementedError):
         vptq_amd.AutoModelForCausalLM.from_pretrained(str(tmp_path), device_map={"model.layers.0": "cuda:0", "lm_head": "cuda:1"})
+    # HF's index forms: {"": 0} and a bare 1 are "cuda:0" / "cuda:1", never the invalid device string "0"
+    from vptq_amd.layers.model_base import _device_from_map
+    assert _device_from_map({"": 0}, None) == "cuda:0"
+    assert _device_from_map(1, None) == "cuda:1"
+    assert _device_from_map("1", None) == "cuda:1"
+    assert _device_from_map({"": torch.device("cuda", 2)}, None) == "cuda:2"
+    assert _device_from_map({"a": 0, "b": "cuda:0"}, None) == "cuda:0"
+    assert _device_from_map("auto", None) is None and _device_from_map(None, "cpu") == "cpu"
+    assert _device_from_map({"": 0}, "cpu") == "cpu"
+    with pytest.raises(NotImplementedError):
+        _device_from_map({"a": 0, "b": 1}, None)
+    with pytest.raises(TypeError):
+        _device_from_map(1.5, None)
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
         vptq_amd.AutoModelForCausalLM.from_pretrained(str(tmp_path), device="cpu", low_cpu_mem_usage=True)

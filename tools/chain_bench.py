@@ -5,6 +5,8 @@ replayed interleaved on the same box: us per layer for
   t1     : one launch of the chain kernel (gemv_k256c) per layer
   chainN : the ring as launches of N layers each (independent layers)
   dep    : the ring as ONE dependent chain (x of layer i + 1 is y of layer i)
+  a trailing x (singlex, chain32x): the reference's roundings (VPTQ_GEMV_EXACT)
+--soak S: every mode additionally replayed back to back for S seconds with package power / shader clock sampled
 python tools/chain_bench.py --hidden 8192 [--rows O] [--ring 32] [--reps 5] [--libs name=path,...]"""
 import argparse
 import json
@@ -26,6 +28,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--modes", default="single,t1,chain4,chain32,dep")
     ap.add_argument("--bf16", action="store_true")
+    ap.add_argument("--soak", type=float, default=0.0)
     ap.add_argument("--out", default="")
     a = ap.parse_args()
     import bench
@@ -46,14 +49,14 @@ def main():
     ys = [torch.empty(1, 1, O, dtype=dt, device=dev) for _ in range(R)]
     alg = bench.alg_bytes(I, O)
 
-    def run_single():
+    def run_single(fl=0):
         for m, y in zip(ring, ys):
             d = m._descriptor()
-            B.check(d[4](d[1], x.data_ptr(), y.data_ptr(), 1, 0, None, 0, B.current_stream_ptr(dev)), "gemv")
+            B.check(d[4](d[1], x.data_ptr(), y.data_ptr(), 1, fl, None, 0, B.current_stream_ptr(dev)), "gemv")
 
     chains = {}
 
-    def run_chain(n, dependent=False):
+    def run_chain(n, dependent=False, fl=0):
         key = (n, dependent)
         if key not in chains:
             if dependent:
@@ -62,20 +65,22 @@ def main():
             else:
                 chains[key] = [GemvChain(ring[i:i + n]) for i in range(0, R, n)]
         if dependent:
-            chains[key][0]([x], ys, flags=8)
+            chains[key][0]([x], ys, flags=8 | fl)
         else:
             for i, c in enumerate(chains[key]):
-                c(xs[i * n:(i + 1) * n], ys[i * n:(i + 1) * n], flags=8)
+                c(xs[i * n:(i + 1) * n], ys[i * n:(i + 1) * n], flags=8 | fl)
 
     modes = {}
     for name in a.modes.split(","):
-        if name == "single":
-            modes[name] = run_single
+        fl = B.GEMV_EXACT if name.endswith("x") else 0
+        base = name[:-1] if fl else name
+        if base == "single":
+            modes[name] = (lambda fl: (lambda: run_single(fl)))(fl)
         elif name == "t1":
             modes[name] = lambda: run_chain(1)
-        elif name.startswith("chain"):
-            n = int(name[5:])
-            modes[name] = (lambda n: (lambda: run_chain(n)))(n)
+        elif base.startswith("chain"):
+            n = int(base[5:])
+            modes[name] = (lambda n, fl: (lambda: run_chain(n, False, fl)))(n, fl)
         elif name == "dep":
             modes[name] = lambda: run_chain(R, True)
     graphs = {}
@@ -107,6 +112,21 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             res[name].append(e0.elapsed_time(e1) * 1e3 / (a.iters * R))
+    soak = {}
+    if a.soak > 0:
+        import time
+        for name, gr in graphs.items():
+            with bench.SclkSampler(0) as sm:
+                t0 = time.time()
+                n = 0
+                while time.time() - t0 < a.soak:
+                    for _ in range(50):
+                        gr.replay()
+                    n += 50
+                    torch.cuda.synchronize()
+                dt_s = time.time() - t0
+            ps, cs = sm.power_summary(), sm.summary()
+            soak[name] = {"us_per_layer": round(dt_s * 1e6 / (n * R), 3), "power_w": ps and ps["median_w"], "sclk_mhz": cs and cs["median_mhz"]}
     summary = {"hidden": I, "rows": O, "ring": R, "alg_bytes": alg, "dtype": str(dt)}
     for name, v in res.items():
         v = sorted(v)
@@ -114,8 +134,10 @@ def main():
         summary[name] = {"us_per_layer": round(med, 3), "min": round(v[0], 3), "max": round(v[-1], 3),
                          "GBps": round(alg / med / 1e3, 1), "frac_8TBps": round(alg / med / 1e3 / 8000, 3),
                          "parity_vs_first": parity.get(name)}
+        if name in soak:
+            summary[name]["soak"] = soak[name]
         print(f"{name:10s} {med:8.3f} us/layer  ({v[0]:.3f} .. {v[-1]:.3f})  {alg / med / 1e3:8.1f} GB/s  "
-              f"frac {alg / med / 1e3 / 8000:.3f}  parity {parity.get(name)}")
+              f"frac {alg / med / 1e3 / 8000:.3f}  parity {parity.get(name)}  soak {soak.get(name)}")
     if a.out:
         with open(a.out, "w") as f:
             json.dump(summary, f, indent=1)

@@ -290,9 +290,11 @@ int vptq_quant_gemv_grouped(const VptqLayerDesc* descs, int n, const void* const
 
 // ---- chain: one persistent launch per <= 32 layers (gemv_k256c.hip), else layer by layer ----
 static bool chain_one_kernel(const VptqLayerDesc* descs, int n, const void* const* x, int tokens, int flags) {
-  if (tokens != 1 || (flags & (VPTQ_GEMV_FORCE_GENERIC | VPTQ_GEMV_EXACT | VPTQ_GEMV_FORCE_VALU))) return false;
+  if (tokens != 1 || (flags & (VPTQ_GEMV_FORCE_GENERIC | VPTQ_GEMV_FORCE_VALU))) return false;
+  const bool exact = (flags & VPTQ_GEMV_EXACT) != 0, dep = (flags & VPTQ_GEMV_CHAIN_DEPENDENT) != 0;
   for (int i = 0; i < n; ++i) {
     if (descs[i].dtype != descs[0].dtype || !vptq::gemv_k256c_eligible(descs[i], tokens)) return false;
+    if (exact && !vptq::gemv_k256c_exact_ok(descs[i], dep)) return false;   // (bf16 / dependent: layer by layer)
     if (x && (((uintptr_t)x[i]) & 3) != 0) return false;
   }
   // a chain that cannot keep the workgroups busy (one small layer, q / k / v of a small model) is better

@@ -102,20 +102,23 @@ static_assert(kCDepth >= 2 && kCDepth <= 6, "queue depth");
 constexpr int kCSlots = 4;                           // cross-wave partial-sum slots
 constexpr uint32_t kCImgBytes = 65536;               // 256 rows x 16 units x 16 B
 constexpr uint32_t kCXsOff = 2 * kCImgBytes;         // wave-private activation slots
-constexpr uint32_t kCXsWave = 256;
-constexpr uint32_t kCRedOff = kCXsOff + kCWaves * kCXsWave;
-constexpr uint32_t kCRedBOff = kCRedOff + kCSlots * kCWaves * kCOutW * 4;
-constexpr uint32_t kCCntOff = kCRedBOff + kCSlots * kCWaves * 4;
+// folded form: 256 bytes per wave (f16(s x) of its 128 columns); reference roundings: x, scale, bias side by side
+constexpr uint32_t c_xs_wave(bool exact) { return exact ? 768u : 256u; }
+constexpr uint32_t c_red_off(bool exact) { return kCXsOff + kCWaves * c_xs_wave(exact); }
+constexpr uint32_t c_redb_off(bool exact) { return c_red_off(exact) + kCSlots * kCWaves * kCOutW * 4; }
+constexpr uint32_t c_cnt_off(bool exact) { return c_redb_off(exact) + kCSlots * kCWaves * 4; }
 // profiling build 2: consume start / end stamps of kCTlSteps steps per wave (a timeline of who computes when)
 constexpr int kCTlFirst = 16, kCTlSteps = 32;
-constexpr uint32_t kCTlOff = kCCntOff + 64;
+constexpr uint32_t c_tl_off(bool exact) { return c_cnt_off(exact) + 64; }
+constexpr uint32_t c_lds_bytes(bool exact) {
 #if VPTQ_K256C_PROF >= 2
-constexpr uint32_t kCLdsBytes = kCTlOff + kCWaves * kCTlSteps * 8;
+  return c_tl_off(exact) + kCWaves * kCTlSteps * 8;
 #else
-constexpr uint32_t kCLdsBytes = kCCntOff + 64;
+  return c_cnt_off(exact) + 64;
 #endif
+}
 constexpr int kCProfWords = 64;   // 8-byte words of profile output per wave
-static_assert(kCLdsBytes <= 163840, "LDS");
+static_assert(c_lds_bytes(false) <= 163840 && (VPTQ_K256C_PROF >= 2 || c_lds_bytes(true) <= 163840), "LDS");
 constexpr int kCFlagStride = 256;   // DEP: arrival flags per layer (one per workgroup)
 
 // timing-only ablations (results wrong): bit 0 no MFMAs, bit 1 no gathers, bit 2 no x / scale /
@@ -268,8 +271,17 @@ static __device__ __forceinline__ void c_for_slots(F&& f) {
   if constexpr (kCDepth > 5) f(std::integral_constant<int, (kCDepth > 5 ? 5 : 0)>{});
 }
 
-template <typename DT, bool DEP>
+// EXACT: every weight rebuilt with the reference CPU path's three roundings r16(r16(r16(c + r) s) + b)
+// (vptq/ops/quant_gemm.py:143-158; bit-identical to vptq_dequant), fp32 accumulation of x w by the same MFMAs
+// - VPTQ_GEMV_EXACT inside the chain launch (fp16, independent layers).
+template <typename DT, bool DEP, bool EXACT = false>
 __global__ __launch_bounds__(kCThreads) void gemv_k256c_kernel(const K256CParams P) {
+  static_assert(!EXACT || (std::is_same<DT, F16>::value && !DEP && kCSub == 2), "reference roundings: fp16, independent layers");
+  constexpr uint32_t kCXsWave = c_xs_wave(EXACT), kCRedOff = c_red_off(EXACT), kCRedBOff = c_redb_off(EXACT),
+                     kCCntOff = c_cnt_off(EXACT);
+#if VPTQ_K256C_PROF >= 2
+  constexpr uint32_t kCTlOff = c_tl_off(EXACT);
+#endif
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   {
     typedef __attribute__((address_space(3))) unsigned char lds_u8_t;
@@ -740,18 +752,28 @@ __global__ __launch_bounds__(kCThreads) void gemv_k256c_kernel(const K256CParams
   // shared by the subgroups.
   auto consume = [&](auto slot_c) __attribute__((always_inline)) {
     constexpr int S = decltype(slot_c)::value;
+    u32x4 sq = u32x4{0u, 0u, 0u, 0u}, bq = u32x4{0u, 0u, 0u, 0u};
     {
-      // activations: f16(s x) of this lane's two columns into the wave's slot, sum b x
       const uint32_t keep = c_col + 2 * lane < Lc.G ? 0xffffffffu : 0u;
       const uint32_t xv = xr[S] & keep;
-      accb = DT::dot2(xv, br[S], accb);
-      // (anchored here: left alone, the compiler sinks this towards its use in finish(), keeps the
-      // loaded register alive across the loop edge and copies it there - behind a wait for the
-      // loads the step has just issued)
-      asm volatile("" : "+v"(accb));
-      *(lds_u32_t*)(uintptr_t)st_addr = DT::mul2(xv, sr[S]);
+      if constexpr (EXACT) {
+        // x, scale and bias of this lane's two columns side by side in the wave's slot (no folding: the weights are
+        // rebuilt with the reference's roundings, so there is no sum b x either)
+        *(lds_u32_t*)(uintptr_t)st_addr = xv;
+        *(lds_u32_t*)(uintptr_t)(st_addr + 256u) = sr[S];
+        *(lds_u32_t*)(uintptr_t)(st_addr + 512u) = br[S];
+      } else {
+        // activations: f16(s x) of this lane's two columns into the wave's slot, sum b x
+        accb = DT::dot2(xv, br[S], accb);
+        // (anchored here: left alone, the compiler sinks this towards its use in finish(), keeps the
+        // loaded register alive across the loop edge and copies it there - behind a wait for the
+        // loads the step has just issued)
+        asm volatile("" : "+v"(accb));
+        *(lds_u32_t*)(uintptr_t)st_addr = DT::mul2(xv, sr[S]);
+      }
     }
     const u32x4 xq = lds_load16(xq_addr);
+    if constexpr (EXACT) { sq = lds_load16(xq_addr + 256u); bq = lds_load16(xq_addr + 512u); }
     constexpr int kUnits = 8 * kCSub, kAhead = VPTQ_K256C_AHEAD, kNB = kAhead + 1;
     u32x4 cv[kNB], rv[kNB];
     auto gather = [&](int t) {   // unit t = column t / kCSub of subgroup t % kCSub
@@ -780,7 +802,26 @@ __global__ __launch_bounds__(kCThreads) void gemv_k256c_kernel(const K256CParams
       if (q == 0)
         xo = u32x2{__builtin_amdgcn_perm(xq[u >> 1], 0u, selA[u & 1]), __builtin_amdgcn_perm(xq[u >> 1], 0u, selB[u & 1])};
       const u32x4 c = cv[t % kNB], r = rv[t % kNB];
-      if constexpr ((VPTQ_K256C_ABLATE & 1) != 0) {
+      if constexpr (EXACT) {
+        // both row subgroups of column u together, stage-major over 8 independent chains (dependent packed
+        // operations back to back cost wait states); the scale / bias half of the column is picked by op_sel
+        if (q == 0) {
+          const u32x4 c1 = cv[(t + 1) % kNB], r1 = rv[(t + 1) % kNB];
+          uint32_t w[8];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { w[k] = DT::add2(c[k], r[k]); w[4 + k] = DT::add2(c1[k], r1[k]); }
+          asm volatile("" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]));
+#pragma unroll
+          for (int k = 0; k < 8; ++k) w[k] = DT::mul2_bcast(w[k], sq[u >> 1], u & 1);
+          asm volatile("" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]));
+#pragma unroll
+          for (int k = 0; k < 8; ++k) w[k] = DT::add2_bcast(w[k], bq[u >> 1], u & 1);
+          acc[0][0] = DT::mfma4(xo, u32x2{w[0], w[1]}, acc[0][0]);
+          acc[0][1] = DT::mfma4(xo, u32x2{w[2], w[3]}, acc[0][1]);
+          acc[1][0] = DT::mfma4(xo, u32x2{w[4], w[5]}, acc[1][0]);
+          acc[1][1] = DT::mfma4(xo, u32x2{w[6], w[7]}, acc[1][1]);
+        }
+      } else if constexpr ((VPTQ_K256C_ABLATE & 1) != 0) {
         asm volatile("" :: "v"(c), "v"(r), "v"(xo));
       } else if constexpr (VPTQ_K256C_PREADD != 0 && std::is_same<DT, F16>::value) {
         // (experiment) f16(c + r) first - the reference's own first rounding (csrc/kernels/quant_gemv.cuh) - then 2
@@ -1092,20 +1133,25 @@ bool gemv_k256c_fills_device(const VptqLayerDesc* descs, int n, bool dependent) 
   return 4 * c_blocks(descs, n, cus, c_wide(descs, n, cus, dependent)) >= 3ll * cus;
 }
 
-template <typename DT, bool DEP>
+template <typename DT, bool DEP, bool EXACT = false>
 static hipError_t launch_c(const K256CParams& P, int grid, hipStream_t st) {
-  auto kern = gemv_k256c_kernel<DT, DEP>;
+  auto kern = gemv_k256c_kernel<DT, DEP, EXACT>;
+  constexpr uint32_t lds = c_lds_bytes(EXACT);
   static std::atomic<bool> attr_set[64];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
   if (!attr_set[dev]) {
-    const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                             (int)kCLdsBytes);
+    const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     attr_set[dev] = true;
   }
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(kCThreads), kCLdsBytes, st, P);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(kCThreads), lds, st, P);
   return hipGetLastError();
+}
+
+// the reference's roundings inside the chain launch: fp16, independent layers
+bool gemv_k256c_exact_ok(const VptqLayerDesc& d, bool dependent) {
+  return d.dtype == VPTQ_DTYPE_F16 && !dependent && VPTQ_K256C_PROF < 2;
 }
 
 // n <= kMaxGroup layers, all gemv_k256c_eligible and of one dtype; sync = kCFlagStride flags per
@@ -1149,6 +1195,14 @@ hipError_t launch_gemv_k256c(const VptqLayerDesc* descs, int n, const void* cons
     first = dependent ? 0 : first + (ng + rpw - 1) / rpw;
   }
   const bool f16 = descs[0].dtype == VPTQ_DTYPE_F16;
+  if (flags & VPTQ_GEMV_EXACT) {
+    if (!f16 || dependent) return hipErrorInvalidValue;   // (the caller routes those layer by layer)
+#if VPTQ_K256C_PROF < 2
+    return launch_c<F16, false, true>(P, grid, st);
+#else
+    return hipErrorInvalidValue;
+#endif
+  }
   if (dependent) return f16 ? launch_c<F16, true>(P, grid, st) : launch_c<BF16, true>(P, grid, st);
   return f16 ? launch_c<F16, false>(P, grid, st) : launch_c<BF16, false>(P, grid, st);
 }

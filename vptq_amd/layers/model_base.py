@@ -55,6 +55,40 @@ def _checkpoint_files(path: str):
     return files
 
 
+_PLACEMENTS = ("auto", "balanced", "sequential", "balanced_low_0")
+
+
+def _one_device(v) -> str:
+    """HF's forms of "this device": an index (0, "0"), a torch.device, "cuda:1", "cpu" """
+    if isinstance(v, torch.device):
+        return str(v)
+    if isinstance(v, bool):
+        raise ValueError(f"device_map value {v!r} names no device")
+    if isinstance(v, int) or (isinstance(v, str) and v.isdigit()):
+        return f"cuda:{int(v)}"
+    return str(v)
+
+
+def _device_from_map(dm, device: Optional[str]) -> Optional[str]:
+    """The ONE device a `device_map` asks for (an explicit `device` wins), None if it names none ("auto").
+    accelerate's layer placement over several GPUs (reference vptq/layers/model_base.py:165-194) is not carried
+    over: a map that asks for it is refused instead of being swallowed."""
+    if dm is None:
+        return device
+    if isinstance(dm, dict):
+        if len({_one_device(v) for v in dm.values()}) > 1:
+            raise NotImplementedError("device_map places the model on several devices: this loader puts a model on ONE "
+                                      "device (pass device=...); shard layers with vptq_amd.utils.shard for tensor parallelism")
+        return device if (device is not None or not dm) else _one_device(next(iter(dm.values())))
+    if isinstance(dm, str) and dm in _PLACEMENTS:
+        if dm != "auto" and torch.cuda.device_count() > 1:
+            raise NotImplementedError(f"device_map='{dm}' (multi-GPU placement by accelerate) is not supported: one device per model")
+        return device   # (= the one device chosen by the caller: what accelerate does when the model fits one GPU)
+    if isinstance(dm, (str, int, torch.device)) and not isinstance(dm, bool):
+        return device if device is not None else _one_device(dm)   # ("cuda:1", "cpu", 1, "1", torch.device(...))
+    raise TypeError(f"device_map of type {type(dm).__name__} is not understood")
+
+
 class AutoModelForCausalLM:
     """`vptq.AutoModelForCausalLM` (reference vptq/__init__.py:7-14)."""
 
@@ -66,18 +100,7 @@ class AutoModelForCausalLM:
         import transformers
         from safetensors.torch import load_file
 
-        # accelerate's layer placement over several GPUs (reference vptq/layers/model_base.py:165-194) is not
-        # carried over: a device_map that asks for it is refused instead of being swallowed by **kwargs
-        dm = kwargs.pop("device_map", None)
-        if isinstance(dm, dict) and len({str(v) for v in dm.values()}) > 1:
-            raise NotImplementedError("device_map places the model on several devices: this loader puts a model on ONE "
-                                      "device (pass device=...); shard layers with vptq_amd.utils.shard for tensor parallelism")
-        if isinstance(dm, dict) and dm and device is None:
-            device = str(next(iter(dm.values())))
-        if isinstance(dm, str) and dm not in ("auto", "balanced", "sequential", "balanced_low_0") and device is None:
-            device = dm   # ("cuda:1", "cpu", ...)
-        if isinstance(dm, str) and dm in ("balanced", "sequential", "balanced_low_0") and torch.cuda.device_count() > 1:
-            raise NotImplementedError(f"device_map='{dm}' (multi-GPU placement by accelerate) is not supported: one device per model")
+        device = _device_from_map(kwargs.pop("device_map", None), device)
         # ("auto" on this loader = the one device chosen below, what accelerate does when the model fits one GPU)
         if kwargs:
             import warnings

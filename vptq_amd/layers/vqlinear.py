@@ -414,10 +414,18 @@ class VQuantLinear(nn.Module):
         # (a rebuilt descriptor = other tensors; a bumped version counter = indices rewritten in place: rebuild)
         stamp = (cache[6], B.tensor_version(self._parameters["indices"]))
         if st is None or st[0] != stamp:
+            if torch.cuda.is_current_stream_capturing():
+                return None   # (no layout is built inside a capture - and the "no" is not remembered: a later call builds it)
             obj = None
             if not cache[9] and B.lib().vptq_sliced_layout_supported(cache[1]) and self._sliced_fits(cache, on):
                 from vptq_amd.utils.sliced import SlicedGemv
-                obj = SlicedGemv(self)
+                try:
+                    obj = SlicedGemv(self)
+                except (RuntimeError, MemoryError) as e:   # out of device memory while building: the regular route serves
+                    import warnings
+                    warnings.warn(f"sliced layout of a {self.in_features} x {self.out_features} layer not built "
+                                  f"({type(e).__name__}: {str(e)[:120]}); the layer keeps the gather kernel", stacklevel=3)
+                    obj = None
             st = (stamp, obj)
             self.__dict__["_sliced"] = st
         return st[1]
@@ -446,7 +454,9 @@ class VQuantLinear(nn.Module):
                     (not self.enable_residual or self.num_res_centroids == 256))
             sl = self._sliced_gemv() if self.__dict__["_sliced_cand"] else None
             if sl is not None and not (ops.quant_gemm_flags() & (B.GEMV_EXACT | B.GEMV_FORCE_GENERIC)):
-                return sl(x)
+                y = sl(x)
+                if y is not None:   # (None: misaligned activation, capture on a stream the layer has not run on, ...)
+                    return y
         group = self.__dict__.get("_siblings")
         if group is not None and tokens <= group.MAX_TOKENS:
             y = group.forward(self, x, tokens)

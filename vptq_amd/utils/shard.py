@@ -121,18 +121,28 @@ def forward_partial_f32(layer: VQuantLinear, x: torch.Tensor) -> torch.Tensor:
     # (vptq_quant_gemv_max_tokens answers 48 for them), 16 for every other layer; beyond that the partial
     # sum comes from the dense route: dequant + a matmul that accumulates and stays in fp32
     limit = B.GEMV_MAX_TOKENS if cache[5] >= 48 else 16
-    if tokens > limit:
+
+    def dense():
         W = layer.dequant().float()
         y = torch.matmul(xc.float(), W.t())
         if layer.bias is not None:
             y = y + layer.bias.float()
         return y
+
+    if tokens > limit:
+        return dense()
     y = torch.empty(xc.shape[:-1] + (layer.out_features,), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         sp = torch.cuda.current_stream(dev).cuda_stream
         ws, wsb = B.gemv_workspace(cache[8], sp, cache[10]) if tokens > 1 else (None, 0)
-        B.check(fn(desc, xc.data_ptr(), y.data_ptr(), tokens,
-                   ops.quant_gemm_flags() | B.GEMV_OUT_F32 | cache[9], ws, wsb, sp), "vptq_quant_gemv")
+        rc = fn(desc, xc.data_ptr(), y.data_ptr(), tokens,
+                ops.quant_gemm_flags() | B.GEMV_OUT_F32 | cache[9], ws, wsb, sp)
+    if rc == B.E_TOKENS and tokens > B.GEMV_ANY_FORMAT_TOKENS:
+        # the fused path takes 17+ tokens of this layer only under run-time conditions the descriptor cannot
+        # promise (a workspace - none is handed out inside a stream capture before one exists -, no exact-arithmetic
+        # flag, 16-byte aligned activations): the dense route, as VQuantLinear._gemv_cached does
+        return dense()
+    B.check(rc, "vptq_quant_gemv")
     return y
 
 

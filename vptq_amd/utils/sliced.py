@@ -100,16 +100,29 @@ class SlicedGemv:
                                      self.res.data_ptr() if residual else None,
                                      rows_per_wave or rows_per_wave_for(self.blocks.shape[1], self.slices), 1,
                                      self.slices, 0)
-        nb = B.lib().vptq_quant_gemv_sliced_workspace_bytes(self.desc)
-        self.ws = torch.zeros(nb, dtype=torch.uint8, device=self.dev)   # (arrival counters: zero once, every call leaves them zero)
+        self._ws_bytes = B.lib().vptq_quant_gemv_sliced_workspace_bytes(self.desc)
+        # partial sums + arrival counters, ONE PER STREAM (two streams - or a graph replay next to an eager call on
+        # another stream - running the same layer would race on a shared one); zeroed once, every call leaves the
+        # counters zero
+        self._ws = {}
         self._fn = B.lib().vptq_quant_gemv_sliced
         self._lay_ref = C.byref(self.layout)
-        self._ws_ptr, self._ws_bytes = self.ws.data_ptr(), self.ws.numel()
         self._dtype = cache[7]
         self._dev_index = cache[8]
         self.extra_bytes = self.elems.numel() * (5 if residual else 4) + self.blocks.numel() * 8
 
-    def __call__(self, x: torch.Tensor, out: torch.Tensor = None, flags: int = 0) -> torch.Tensor:
+    def _workspace(self, stream_ptr: int):
+        ws = self._ws.get(stream_ptr)
+        if ws is None:
+            if torch.cuda.is_current_stream_capturing():
+                return None   # (no allocation + memset inside a capture: warm the layer up on the capture stream first)
+            ws = torch.zeros(self._ws_bytes, dtype=torch.uint8, device=self.dev)
+            self._ws[stream_ptr] = ws
+        return ws
+
+    def __call__(self, x: torch.Tensor, out: torch.Tensor = None, flags: int = 0):
+        """y, or None where this call cannot take the sliced kernel (activation not 16-byte aligned, no workspace for a
+        capturing stream, the library says "unsupported"): the caller then takes the regular route."""
         lay = self.layer
         # (the checks of VQuantLinear._check_activation, against cached values: this is the per-token path)
         if x.shape[-1] != lay.in_features or x.numel() != lay.in_features:
@@ -118,16 +131,26 @@ class SlicedGemv:
             x = lay._check_activation(x)
         if not x.is_contiguous():
             x = x.contiguous()
-        if out is None:
-            out = torch.empty(x.shape[:-1] + (lay.out_features,), dtype=torch.float32 if (flags & B.GEMV_OUT_F32) else self._dtype,
-                              device=self.dev)
+        if x.data_ptr() & 15:
+            return None
         if torch.cuda.current_device() != self._dev_index:
             with torch.cuda.device(self.dev):
-                rc = self._fn(self.desc, self._lay_ref, x.data_ptr(), out.data_ptr(), flags, self._ws_ptr, self._ws_bytes,
-                              B.current_stream_ptr(self.dev))
-        else:
-            rc = self._fn(self.desc, self._lay_ref, x.data_ptr(), out.data_ptr(), flags, self._ws_ptr, self._ws_bytes,
-                          B.current_stream_ptr(self.dev))
+                return self._launch(x, out, flags)
+        return self._launch(x, out, flags)
+
+    def _launch(self, x, out, flags):
+        sp = B.current_stream_ptr(self.dev)
+        ws = self._workspace(sp)
+        if ws is None:
+            return None
+        if out is None:
+            out = torch.empty(x.shape[:-1] + (self.layer.out_features,),
+                              dtype=torch.float32 if (flags & B.GEMV_OUT_F32) else self._dtype, device=self.dev)
+        rc = self._fn(self.desc, self._lay_ref, x.data_ptr(), out.data_ptr(), flags, ws.data_ptr(), self._ws_bytes, sp)
+        if rc == B.E_UNSUPPORTED:
+            return None
         if rc:
+            # (a launch that did not happen or did not finish may have left arrival counters behind)
+            self._ws.pop(sp, None)
             B.check(rc, "vptq_quant_gemv_sliced")
         return out
