@@ -148,7 +148,7 @@ def test_chain_on_reference_goldens_at_baseline_sizes(name, dev):
 
 
 def test_chain_falls_back_layer_by_layer(dev):
-    """a chain the one-launch kernel does not take (another format in it, 2 tokens) is executed as
+    """a chain the one-launch kernel does not take (another format in it, 2 tokens) is executed as a grouped launch /
     single launches by the library: same results as the modules' forward"""
     from vptq_amd.ops.chain import GemvChain
     La = vo.make_layer(1024, 256, seed=3)
@@ -156,12 +156,12 @@ def test_chain_falls_back_layer_by_layer(dev):
     ma, mb = spec_to_module(La, dev), spec_to_module(Lb, dev)
     xa = bits_to_tensor(_x(1024, "f16", "ref-test", 1), "f16", dev).reshape(1, 1, 1024)
     chain = GemvChain([ma, mb])
-    assert chain.kernel_name(1, 0) == "per-layer"
+    assert chain.kernel_name(1, 0) == "grouped"      # (vptq_quant_gemv_grouped serves mixed members one by one)
     ya, yb = chain([xa, xa])
     assert torch.equal(ya, ma(xa)) and torch.equal(yb, mb(xa))
     x2 = bits_to_tensor(_x(1024, "f16", "ref-test", 2, tokens=2), "f16", dev).reshape(1, 2, 1024)
     c2 = GemvChain([ma, ma])
-    assert c2.kernel_name(2, 0) == "per-layer"
+    assert c2.kernel_name(2, 0) == "grouped"
     y2 = c2([x2, x2])
     assert torch.equal(y2[0], ma(x2)) and torch.equal(y2[1], ma(x2))
 
@@ -215,7 +215,7 @@ def test_chain_with_the_reference_roundings(dev):
     for a, b in zip(ys, y32):
         assert torch.equal(b.half().view(torch.int16), a.view(torch.int16))
     Lb, mb, xb = _build(SHAPES[:2], "bf16", dev)
-    assert GemvChain(mb).kernel_name(1, CHAIN | B.GEMV_EXACT) == "per-layer"
+    assert GemvChain(mb).kernel_name(1, CHAIN | B.GEMV_EXACT) == "grouped"   # (bf16: no reference roundings in the chain kernel)
 
 
 @pytest.mark.parametrize("exact", [False, True])

@@ -72,8 +72,8 @@ def test_one_pass_batched_decode_vs_oracle(I, O, kw, tokens, dt, dev):
     # the module's forward: the library's default route (it hands over the scratch buffer) - this kernel, same
     # bits, where it is the default; another kernel, same results within the bar, elsewhere
     ym = m(xt)
-    if default_route:
-        assert torch.equal(ym.view(torch.int16), got.view(torch.int16))
+    if default_route and not m._descriptor()[9]:   # (a layer the load-time gate serves with the reference's roundings - fewer
+        assert torch.equal(ym.view(torch.int16), got.view(torch.int16))   # than 32 vector-rows here - takes gemm_k256 instead)
     assert rel_err(tensor_to_bits(ym), want, dt) <= TOL[dt]
     # every token row against that token alone through the one-token kernels
     for t in {0, tokens - 1}:

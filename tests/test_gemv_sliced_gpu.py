@@ -112,8 +112,8 @@ def test_sliced_layout_small_reference_golden_and_rejections(dev):
     # the reference's roundings are not available here
     Lk = vo.make_layer(512, 128, seed=2, num_centroids=65536, num_res_centroids=0)
     sl = SlicedGemv(spec_to_module(Lk, dev))
-    with pytest.raises(RuntimeError):
-        sl(torch.zeros(1, 1, 512, dtype=torch.float16, device=dev), flags=EXACT)
+    # ("unsupported" from the library = None here: the caller takes the regular route, which has them)
+    assert sl(torch.zeros(1, 1, 512, dtype=torch.float16, device=dev), flags=EXACT) is None
 
 
 def test_sliced_layout_in_a_hipgraph(dev):
@@ -195,10 +195,13 @@ def test_sliced_route_falls_back_instead_of_failing(dev):
     xm = buf[1:2049].view(1, 1, 2048)                 # contiguous, 2 bytes off a 16-byte boundary
     xm.copy_(bits_to_tensor(x1, "f16", dev).reshape(1, 1, 2048))
     assert xm.data_ptr() % 16 == 2
-    # a first call inside a capture: regular route, nothing remembered
+    # a first ONE-TOKEN call inside a capture (the descriptor exists: a prompt went through the layer before - building it
+    # reads the load-time gate back from the device, which no capture allows): regular route, nothing remembered
     g = torch.cuda.CUDAGraph()
     s = torch.cuda.Stream()
     xa = bits_to_tensor(x1, "f16", dev).reshape(1, 1, 2048)
+    m(torch.cat([xa, xa], dim=1))
+    torch.cuda.synchronize()
     with torch.cuda.stream(s):
         with torch.cuda.graph(g, stream=s):
             yg = m(xa)

@@ -1520,7 +1520,9 @@ def test_adversarial_families_default_route(family, xkind, O, dev):
     m = spec_to_module(L, dev)
     xt = bits_to_tensor(x, "f16", dev).reshape(x.shape)
     gated = m._descriptor()[9] != 0
-    assert gated == (family in ("bias4", "bias16")), (family, gated)
+    # (round 4: the cyclic pattern with in_features a multiple of k makes every index row the same - 8 distinct
+    # outputs; layers with fewer than 32 distinct vector-rows are gated as well: tools/gpu_fuzz_count.py)
+    assert gated == (family in ("bias4", "bias16", "cyclic")), (family, gated)
     err = rel_err(tensor_to_bits(m(xt)), want, "f16")
     assert err <= 1e-3, f"module default route, {family}/{xkind}: {err:.2e}"
     # the chain API with the same layers (the gate routes bias-dominated ones to the per-layer exact path)
@@ -1539,7 +1541,7 @@ def test_adversarial_families_default_route(family, xkind, O, dev):
     # is folded arithmetic too) go through it as well
     import importlib
     qg = importlib.import_module("vptq_amd.ops.quant_gemm")   # (the package also exports a function of that name)
-    assert (qg._safe_flags(m.centroids.weight, m.res_centroids.weight, m.weight_scale, m.weight_bias) != 0) == gated
+    assert (qg._safe_flags(m.indices, m.centroids.weight, m.res_centroids.weight, m.weight_scale, m.weight_bias) != 0) == gated
     x6 = np.concatenate([x] * 6, axis=1)
     x6t = bits_to_tensor(x6, "f16", dev).reshape(x6.shape)
     y6 = m(x6t)

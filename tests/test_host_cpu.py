@@ -74,14 +74,25 @@ def test_chain_routing_without_gpu():
     assert name([big] * 32) == b"gemv_k256c_kernel"
     assert name([big] * 32, flags=B.GEMV_CHAIN_DEPENDENT) == b"gemv_k256c_kernel"
     assert name([small] * 32) == b"gemv_k256c_kernel"          # 64 row groups each: 8 layers side by side
-    assert name([big] * 2) == b"gemv_k256c_kernel"             # 2 x 128 row groups of 8 vector-rows
-    assert name([small]) == b"per-layer"                       # 64 row groups cannot fill 256 workgroups ...
+    assert name([big] * 9) == b"gemv_k256c_kernel"
+    # round 4: up to 8 independent layers = ONE grouped launch of the one-layer kernels (faster than the persistent
+    # launch there, profiles/r03/chain_vs_grouped_by_length.txt), also where the persistent kernel could not fill the device
+    assert name([big] * 2) == name([big] * 8) == b"grouped"
+    assert name([big] * 2, flags=B.GEMV_FORCE_MFMA) == b"gemv_k256c_kernel"   # (tests pin the persistent kernel)
+    assert name([big] * 2, flags=B.GEMV_CHAIN_DEPENDENT) == b"gemv_k256c_kernel"
+    assert name([_canonical_desc(8192, 1024)] * 3) == b"grouped"             # k / v sized projections
+    assert name([big] * 4, tokens=2) == b"grouped"
+    assert name([big] * 7 + [_canonical_desc(8192, 8192, perm=True)]) == b"grouped"
+    assert name([small]) == b"per-layer"                       # one layer: the one-layer kernels
     assert name([small], flags=B.GEMV_FORCE_MFMA) == b"gemv_k256c_kernel"    # ... unless asked for
-    assert name([_canonical_desc(8192, 1024)] * 3) == b"per-layer"           # k / v sized projections
-    assert name([big] * 32, tokens=2) == b"per-layer"
-    assert name([big] * 31 + [_canonical_desc(8192, 8192, perm=True)]) == b"per-layer"
-    assert name([big] * 31 + [_canonical_desc(8192, 8192, dtype=1)]) == b"per-layer"
-    assert name([big] * 32, flags=B.GEMV_EXACT) == b"per-layer"
+    assert name([big] * 32, tokens=2) == b"grouped"            # (any list of <= 64 layers the persistent kernel does not take)
+    assert name([big] * 31 + [_canonical_desc(8192, 8192, perm=True)]) == b"grouped"
+    assert name([big] * 31 + [_canonical_desc(8192, 8192, dtype=1)]) == b"per-layer"   # mixed dtypes
+    assert name([_canonical_desc(8192, 1024)] * 3, flags=B.GEMV_CHAIN_DEPENDENT) == b"per-layer"
+    # the reference's roundings inside the chain launch (round 4): fp16, independent layers
+    assert name([big] * 32, flags=B.GEMV_EXACT) == b"gemv_k256c_kernel"
+    assert name([big] * 32, flags=B.GEMV_EXACT | B.GEMV_CHAIN_DEPENDENT) == b"per-layer"
+    assert name([_canonical_desc(8192, 8192, dtype=1)] * 32, flags=B.GEMV_EXACT) == b"grouped"
     assert name([big] * 40) == b"gemv_k256c_kernel"            # two launches (32 + 8)
     assert lib.vptq_quant_gemv_chain_workspace_bytes(32, 0) == 0
     assert lib.vptq_quant_gemv_chain_workspace_bytes(32, B.GEMV_CHAIN_DEPENDENT) == 32 * 1024

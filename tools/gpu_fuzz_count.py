@@ -119,17 +119,23 @@ def main():
             ch = GemvChain(list(layers))
             outs = {}
             kn = ch.kernel_name(1, 0) or "?"
+            gated = any(m._descriptor()[9] for m in layers)
+            if gated:
+                kn += "+gate"
             outs["chain:" + kn] = (ch(list(xs), flags=0), ch(list(xs), flags=B.GEMV_OUT_F32))
             if a.dtype == "f16":   # the reference's roundings inside the chain launch
                 kx = ch.kernel_name(1, B.GEMV_EXACT) or "?"
                 outs["chain-exact:" + kx] = (ch(list(xs), flags=B.GEMV_EXACT), ch(list(xs), flags=B.GEMV_EXACT | B.GEMV_OUT_F32))
-            for tag, fl in (("mfma", B.GEMV_FORCE_MFMA), ("valu", B.GEMV_FORCE_VALU)):
+            # single launches with the kernel pinned; like every product route they carry the layer's load-time gate
+            # (VQuantLinear._descriptor()[9]); "ungated" = the folded form whatever the gate says (reported, not counted)
+            for tag, fl, gate in (("mfma", B.GEMV_FORCE_MFMA, True), ("valu", B.GEMV_FORCE_VALU, True), ("ungated-mfma", B.GEMV_FORCE_MFMA, False)):
                 y16, y32 = [], []
                 for m, x in zip(layers, xs):
                     d = m._descriptor()
-                    name = B.lib().vptq_quant_gemv_kernel_name(d[1], 1, fl)
+                    fg = fl | (d[9] if gate else 0)
+                    name = B.lib().vptq_quant_gemv_kernel_name(d[1], 1, fg)
                     names[tag] = name.decode() if name else "?"
-                    for out, f in ((y16, fl), (y32, fl | B.GEMV_OUT_F32)):
+                    for out, f in ((y16, fg), (y32, fg | B.GEMV_OUT_F32)):
                         y = torch.empty(1, 1, O, dtype=torch.float32 if f & B.GEMV_OUT_F32 else dt, device=dev)
                         B.check(B.lib().vptq_quant_gemv(d[1], x.data_ptr(), y.data_ptr(), 1, f, None, 0, B.current_stream_ptr(dev)), "gemv")
                         out.append(y)
@@ -169,9 +175,10 @@ def main():
         e = np.array([s[0] for s in st])
         u = np.array([s[1] for s in st])
         ex = int((e > bar).sum())
-        total_exceed += ex
+        if not key.startswith("ungated"):
+            total_exceed += ex
         print(f"{dist:12s} {key:60s} {len(e):6d} {e.max():9.2e} {np.quantile(e, 0.999):9.2e} {np.median(e):9.2e} {ex:6d} {np.nanmax(u) if np.isfinite(u).any() else float('nan'):26.2e}")
-    print(f"exceedances in all: {total_exceed}")
+    print(f"exceedances in all (product routes, i.e. with the load-time gate; the ungated rows are information): {total_exceed}")
     return 1 if total_exceed else 0
 
 

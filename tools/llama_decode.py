@@ -177,6 +177,41 @@ def run(args):
     except Exception as e:  # report, do not hide
         graph_tps = f"capture failed: {type(e).__name__}: {e}"
 
+    # ---- the VQuantLinear share of a decode step: the step's own VQuantLinear calls (same modules, same order, same
+    # activation objects - so sibling groups launch together as in the model), alone in a hipGraph of their own
+    vq_us = None
+    stage("VQuantLinear share")
+    try:
+        import vptq
+        calls, hooks = [], []
+        for m in qlayers:
+            hooks.append(m.register_forward_pre_hook(lambda mod, inp: calls.append((mod, inp[0]))))
+        step(tok, p)
+        for h in hooks:
+            h.remove()
+        torch.cuda.synchronize()
+        stream2 = torch.cuda.Stream()
+        with torch.cuda.stream(stream2):
+            def only_vq():
+                for mod, xin in calls:
+                    mod(xin)
+            for _ in range(2):
+                only_vq()
+            torch.cuda.synchronize()
+            g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g2, stream=stream2):
+                only_vq()
+            for _ in range(5):
+                g2.replay()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(50):
+                g2.replay()
+            torch.cuda.synchronize()
+            vq_us = (time.perf_counter() - t0) * 1e6 / 50
+    except Exception as e:  # report, do not hide
+        vq_us = f"failed: {type(e).__name__}: {e}"
+
     lm_head_bytes = cfg.vocab_size * cfg.hidden_size * 2
     res = dict(model=f"Llama-3-{args.model.upper()} shapes, {cfg.num_hidden_layers} layers, VQuantLinear v8-k{args.k}-{args.kr}" + (" (2-bit)" if (args.k, args.kr) == (256, 256) else "")
                      + (" +perm" if args.perm else ""),
@@ -186,6 +221,12 @@ def run(args):
                sibling_groups=fused)
     if isinstance(graph_tps, float):
         res["hipgraph_weight_GBps"] = (qbytes + lm_head_bytes) * graph_tps / 1e9
+    res["vqlinear_us_per_token"] = vq_us   # the step's VQuantLinear launches back to back in a graph of their own
+    if isinstance(vq_us, float):
+        res["vqlinear_calls_per_token"] = len(calls)
+        res["vqlinear_GBps"] = qbytes / vq_us / 1e3
+        if isinstance(graph_tps, float):
+            res["vqlinear_share_of_step"] = vq_us * 1e-6 * graph_tps
     print(json.dumps(res))
     if args.out:
         os.makedirs(os.path.dirname(args.out), exist_ok=True)

@@ -212,6 +212,56 @@ def _derived(owner: torch.Tensor, name: str, key, build):
     return hit[1]
 
 
+# ---- load-time gate of the default ("folded") decode arithmetic ---------------------------------------------------
+# The folded form  y = sum (c + r) * f16(s x) + sum b x  is as close to exact arithmetic as the reference CPU path
+# is: the reference rounds every weight three times (vptq/ops/quant_gemm.py:143-158), which puts ITS un-rounded sums
+# 1-6e-4 of max|y| away from exact math, and the parity bar (1e-3 of max|y|) has room for that distance
+# plus one rounding flip only while max|y| is a maximum over MANY independent outputs (max|y| / rms(y) ~ 4).  Two
+# kinds of layers break that and are served with the reference's roundings (VPTQ_GEMV_EXACT) instead:
+#  * bias-dominated ones (rms(b) > 2 rms(s) rms(c + r)): the reference's rounding of w s + b loses the low bits of
+#    w s, an activation for which sum b x cancels exposes it (1.6e-3 at |b| = 8 |w s|);
+#  * layers with fewer than FOLDED_MIN_DISTINCT_ROWS distinct vector-rows - tiny layers, and index tensors whose rows
+#    repeat, such as the reference test's cyclic arange(k) pattern with in_features a multiple of k
+#    (tests/test_quant_gemv.py:21-31: every row identical, 8 distinct outputs): counted over 2048 layers per dtype
+#    (tools/gpu_fuzz_count.py, profiles/r04/fuzz_count_*.txt) the folded form exceeds the bar on 2-6 % of those and on
+#    none of the layers with >= 128 distinct rows; numpy emulation (tools/fold_error_study.py): 1-2 % at 1-4 rows,
+#    0 of 150 from 16 rows on.
+FOLDED_MAX_BIAS_RATIO = 2.0
+FOLDED_MIN_DISTINCT_ROWS = 32
+_ROW_SAMPLE = 64
+
+
+def distinct_index_rows(indices: torch.Tensor) -> int:
+    """lower bound of the number of distinct packed index rows: min(rows, distinct among 64 evenly spaced rows)"""
+    rows = indices.reshape(-1, indices.shape[-1])[: indices.shape[-2]]   # (first codebook group)
+    n = rows.shape[0]
+    if n <= 1:
+        return n
+    pick = torch.linspace(0, n - 1, min(n, _ROW_SAMPLE), device=rows.device).round().long()
+    r = rows[pick].to(torch.int64)
+    w = torch.arange(1, r.shape[1] + 1, device=r.device, dtype=torch.int64) * 0x9E3779B1 + 1
+    h = (r * w).sum(1)   # (int64 arithmetic wraps: a position-weighted checksum per row)
+    return int(torch.unique(h).numel())
+
+
+def folded_form_is_safe(indices, centroids, res_centroids, weight_scale, weight_bias) -> bool:
+    """One device -> host read per call: call it once per set of tensors (descriptor build / functional-API cache)."""
+    if weight_scale is None or weight_bias is None or not weight_scale.is_cuda:
+        return True
+    with torch.no_grad():
+        w2 = centroids.float().pow(2).mean()
+        if res_centroids is not None:
+            w2 = w2 + res_centroids.float().pow(2).mean()
+        lhs = weight_bias.float().pow(2).mean()
+        rhs = (FOLDED_MAX_BIAS_RATIO ** 2) * weight_scale.float().pow(2).mean() * w2
+        if not bool((lhs <= rhs).item()):
+            return False
+        if indices is not None and indices.dim() == 3:
+            if indices.shape[1] < FOLDED_MIN_DISTINCT_ROWS or distinct_index_rows(indices) < FOLDED_MIN_DISTINCT_ROWS:
+                return False
+    return True
+
+
 def inverse_perm(perm: torch.Tensor) -> torch.Tensor:
     """argsort(perm) as int16 (uint16 bit pattern), cached per tensor version.
 

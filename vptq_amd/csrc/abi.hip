@@ -311,11 +311,36 @@ size_t vptq_quant_gemv_chain_workspace_bytes(int n, int flags) {
   return (flags & VPTQ_GEMV_CHAIN_DEPENDENT) && n > 0 ? (size_t)n * 1024 : 0;   // 256 arrival flags per layer
 }
 
+// How a chain call is executed.  The persistent launch pays its prologue (first codebook image, queue fill: ~7 us)
+// once per call and wins from ~16 independent layers on; up to 8 it loses to ONE grouped launch of the one-layer
+// kernels (layer = blockIdx.y; 8192^2, us per layer at 2 / 4 / 8 layers: 7.72 / 6.06 / 5.31 against 5.86 / 5.45 / 5.01,
+// profiles/r03/chain_vs_grouped_by_length.txt), and a list that cannot fill the device with the persistent kernel
+// (q / k / v of a small model) is still better served by one grouped launch than by one launch per layer.
+enum ChainRoute { kChainPersistent, kChainGrouped, kChainPerLayer };
+constexpr int kChainGroupedMax = 8;
+static ChainRoute chain_route(const VptqLayerDesc* descs, int n, const void* const* x, int tokens, int flags) {
+  const bool dependent = (flags & VPTQ_GEMV_CHAIN_DEPENDENT) != 0;
+  const bool persistent_ok = chain_one_kernel(descs, n, x, tokens, flags);
+  if (n == 1 && !(flags & VPTQ_GEMV_FORCE_MFMA)) return kChainPerLayer;   // (the one-layer kernels: arguments preloaded, short prologue)
+  if (persistent_ok && (dependent || n > kChainGroupedMax || (flags & VPTQ_GEMV_FORCE_MFMA))) return kChainPersistent;
+  if (!dependent && n >= 2 && n <= VPTQ_GROUP_MAX && tokens <= VPTQ_GEMV_MAX_TOKENS_ANY &&
+      (n <= kChainGroupedMax || !persistent_ok)) {
+    for (int i = 1; i < n; ++i)
+      if (descs[i].dtype != descs[0].dtype) return kChainPerLayer;
+    return kChainGrouped;
+  }
+  return persistent_ok ? kChainPersistent : kChainPerLayer;
+}
+
 const char* vptq_quant_gemv_chain_kernel_name(const VptqLayerDesc* descs, int n, int tokens, int flags) {
   if (!descs || n < 1 || n > VPTQ_CHAIN_MAX || tokens < 1 || tokens > VPTQ_GEMV_MAX_TOKENS) return nullptr;
   for (int i = 0; i < n; ++i)
     if (validate_layer(&descs[i]) != VPTQ_OK) return nullptr;
-  return chain_one_kernel(descs, n, nullptr, tokens, flags) ? "gemv_k256c_kernel" : "per-layer";
+  switch (chain_route(descs, n, nullptr, tokens, flags)) {
+    case kChainPersistent: return "gemv_k256c_kernel";
+    case kChainGrouped: return "grouped";
+    default: return "per-layer";
+  }
 }
 
 int vptq_quant_gemv_chain(const VptqLayerDesc* descs, int n, const void* const* x, void* const* y,
@@ -332,7 +357,10 @@ int vptq_quant_gemv_chain(const VptqLayerDesc* descs, int n, const void* const* 
   const bool dependent = (flags & VPTQ_GEMV_CHAIN_DEPENDENT) != 0;
   const int lflags = flags & ~VPTQ_GEMV_CHAIN_DEPENDENT;
   hipStream_t st = (hipStream_t)stream;
-  if (!chain_one_kernel(descs, n, x, tokens, flags)) {
+  const ChainRoute route = chain_route(descs, n, x, tokens, flags);
+  if (route == kChainGrouped)   // independent layers, one launch (it serves members it has no kernel for one by one)
+    return vptq_quant_gemv_grouped(descs, n, x, y, tokens, lflags & ~VPTQ_GEMV_FORCE_MFMA, stream);
+  if (route == kChainPerLayer) {
     // stream order is the dependency
     const int pflags = lflags & ~VPTQ_GEMV_FORCE_MFMA;
     for (int i = 0; i < n; ++i) {
@@ -348,11 +376,14 @@ int vptq_quant_gemv_chain(const VptqLayerDesc* descs, int n, const void* const* 
     const hipError_t e = hipMemsetAsync(workspace, 0, need, st);
     if (e != hipSuccess) return hip_fail(e, "chain workspace clear");
   }
+  // VPTQ_K256C_PROF builds write per-wave profile words to the workspace of a non-dependent launch: only when the
+  // caller handed over enough of it (256 workgroups x 16 waves x 64 words of 8 bytes)
+  const bool prof_ws = !dependent && getenv("VPTQ_K256C_PROF") && workspace && workspace_bytes >= (size_t)256 * 16 * 64 * 8;
   for (int i0 = 0; i0 < n; i0 += 32) {
     const int m = n - i0 < 32 ? n - i0 : 32;
     const hipError_t e = vptq::launch_gemv_k256c(descs + i0, m, x + i0, y + i0, lflags, dependent,
                                                  dependent ? (uint32_t*)workspace + (size_t)i0 * 256
-                                                           : (getenv("VPTQ_K256C_PROF") ? (uint32_t*)workspace : nullptr), st);
+                                                           : (prof_ws ? (uint32_t*)workspace : nullptr), st);
     if (e != hipSuccess) return hip_fail(e, "gemv_k256c launch");
   }
   return VPTQ_OK;

@@ -342,29 +342,11 @@ class VQuantLinear(nn.Module):
             self.__dict__["_desc_cache"] = cache
         return cache
 
-    # |weight_bias| against |weight_scale * (centroid + residual)|, RMS over the tensors, above which a layer
-    # is served in the reference's arithmetic even when the process default is the folded form
-    FOLDED_FORM_MAX_BIAS_RATIO = 2.0
-
     def _folded_form_is_safe(self, tensors) -> bool:
-        """Load-time gate of the library's default ("folded") decode arithmetic
-        y = sum (c + r) * f16(s x) + sum b x.  It is as close to exact math as the reference CPU path is
-        (each is ~4-8e-4 of max |y| from the other, inside the 1e-3 bar), EXCEPT for bias-dominated layers:
-        the reference rounds w s + b to 16 bits per weight, so with |b| >> |w s| its own result loses the
-        low bits of w s, and an activation for which sum b x cancels exposes that as > 1e-3 of what is
-        left (measured: 1.6e-3 at |b| = 8 |w s|, 2.8e-3 at 16; <= 8e-4 up to 4 - tests/test_hip_parity.py::
-        test_adversarial_families).  Such layers get VPTQ_GEMV_EXACT (the reference's three roundings per
-        weight).  One device -> host read per descriptor build, i.e. per layer load."""
-        scale, wbias = tensors[6], tensors[7]
-        if scale is None or wbias is None or not scale.is_cuda:
-            return True
-        with torch.no_grad():
-            w2 = tensors[1].float().pow(2).mean()
-            if tensors[2] is not None:
-                w2 = w2 + tensors[2].float().pow(2).mean()
-            lhs = wbias.float().pow(2).mean()
-            rhs = (self.FOLDED_FORM_MAX_BIAS_RATIO ** 2) * scale.float().pow(2).mean() * w2
-            return bool((lhs <= rhs).item())
+        """Load-time gate of the library's default ("folded") decode arithmetic (`_backend.folded_form_is_safe`):
+        bias-dominated layers and layers with fewer than 32 distinct vector-rows get VPTQ_GEMV_EXACT (the
+        reference's three roundings per weight).  One device -> host read per descriptor build, i.e. per layer load."""
+        return B.folded_form_is_safe(tensors[0], tensors[1], tensors[2], tensors[6], tensors[7])
 
     def _check_activation(self, x: torch.Tensor) -> torch.Tensor:
         if x.shape[-1] != self.in_features:

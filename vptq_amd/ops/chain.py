@@ -44,31 +44,41 @@ class GemvChain:
             dev = caches[0][3]
             if any(c[3] != dev for c in caches):
                 raise RuntimeError("the layers of a chain must share one device")
-            descs = (B.LayerDesc * n)(*[c[1] for c in caches])
             flags = B.GEMV_CHAIN_DEPENDENT if self.dependent else 0
+            # Layers the load-time gate serves with the reference's roundings (VQuantLinear._folded_form_is_safe:
+            # bias-dominated, fewer than 32 distinct vector-rows).  The arithmetic is a property of a LAUNCH, so
+            # independent layers are handed to the library as two lists - the gated ones with VPTQ_GEMV_EXACT - and one
+            # odd layer does not slow the others down; a dependent chain stays one list (the order is the
+            # dependency) and takes the reference's roundings as a whole.
+            gated = [i for i, c in enumerate(caches) if c[9]]
+            if self.dependent or not gated or len(gated) == n:
+                parts = [(list(range(n)), B.GEMV_EXACT if gated else 0)]
+            else:
+                parts = [([i for i in range(n) if not caches[i][9]], 0), (gated, B.GEMV_EXACT)]
+            subs = []
+            for idx, safe in parts:
+                m = len(idx)
+                subs.append((idx, (B.LayerDesc * m)(*[caches[i][1] for i in idx]), (C.c_void_p * m)(), (C.c_void_p * m)(), safe))
             nbytes = B.lib().vptq_quant_gemv_chain_workspace_bytes(n, flags)
             ws = torch.zeros(max(nbytes, 4) // 4, dtype=torch.int32, device=dev) if nbytes else None
-            safe = 0
-            for c in caches:
-                safe |= c[9]   # a bias-dominated layer (VQuantLinear._folded_form_is_safe): reference arithmetic
-            self._safe_flags = safe
-            self._state = (key, descs, (C.c_void_p * n)(), (C.c_void_p * n)(), ws, nbytes, dev,
-                           caches[0][7], [c[2] for c in caches])
+            self._state = (key, subs, ws, nbytes, dev, caches[0][7], [c[2] for c in caches])
         return self._state
 
     def kernel_name(self, tokens: int = 1, flags: Optional[int] = None) -> Optional[str]:
-        _, descs, _, _, _, _, _, _, _ = self._prepare()
-        f = (ops.quant_gemm_flags() if flags is None else flags) | self._safe_flags
+        """what the library runs for the (first, i.e. un-gated) list of this chain"""
+        _, subs, _, _, _, _, _ = self._prepare()
+        idx, descs, _, _, safe = subs[0]
+        f = (ops.quant_gemm_flags() if flags is None else flags) | safe
         if self.dependent:
             f |= B.GEMV_CHAIN_DEPENDENT
-        name = B.lib().vptq_quant_gemv_chain_kernel_name(descs, len(self.layers), tokens, f)
+        name = B.lib().vptq_quant_gemv_chain_kernel_name(descs, len(idx), tokens, f)
         return None if name is None else name.decode()
 
     def __call__(self, xs: Sequence[torch.Tensor], ys: Optional[Sequence[torch.Tensor]] = None,
                  flags: Optional[int] = None):
         """xs: one activation per layer (independent) or only the first layer's (dependent).
         ys: optional pre-allocated outputs.  Returns the list of outputs, one per layer."""
-        _, descs, xp, yp, ws, nbytes, dev, wdtype, _ = self._prepare()
+        _, subs, ws, nbytes, dev, wdtype, _ = self._prepare()
         n = len(self.layers)
         xs = list(xs)
         if self.dependent:
@@ -78,9 +88,9 @@ class GemvChain:
             raise ValueError(f"{n} layers need {n} activations")
         x0 = self.layers[0]._check_activation(xs[0])
         tokens = x0.numel() // x0.shape[-1]
-        f = (ops.quant_gemm_flags() if flags is None else flags) | self._safe_flags
-        out_dtype = torch.float32 if (f & B.GEMV_OUT_F32) else wdtype
-        if self.dependent and (f & B.GEMV_OUT_F32):
+        f0 = ops.quant_gemm_flags() if flags is None else flags
+        out_dtype = torch.float32 if (f0 & B.GEMV_OUT_F32) else wdtype
+        if self.dependent and (f0 & B.GEMV_OUT_F32):
             raise ValueError("a dependent chain feeds its outputs back in: no float32 outputs")
         if ys is None:
             ys = [torch.empty(x0.shape[:-1] + (m.out_features,), dtype=out_dtype, device=dev)
@@ -90,6 +100,7 @@ class GemvChain:
             if len(ys) != n:
                 raise ValueError(f"{n} layers need {n} outputs")
         keep = []
+        xin = []
         for i, m in enumerate(self.layers):
             xi = ys[i - 1] if (self.dependent and i > 0) else m._check_activation(xs[i])
             if xi.numel() // xi.shape[-1] != tokens:
@@ -98,16 +109,19 @@ class GemvChain:
                     ys[i].numel() != tokens * m.out_features:
                 raise ValueError(f"output {i}: wrong dtype / device / size")
             keep.append(xi)
-            xp[i] = xi.data_ptr()
-            yp[i] = ys[i].data_ptr()
+            xin.append(xi)
         if self.dependent:
-            f |= B.GEMV_CHAIN_DEPENDENT
+            f0 |= B.GEMV_CHAIN_DEPENDENT
         with torch.cuda.device(dev):
-            rc = B.lib().vptq_quant_gemv_chain(descs, n, xp, yp, tokens, f,
-                                               None if ws is None else ws.data_ptr(), nbytes,
-                                               B.current_stream_ptr(dev))
-        if rc:
-            B.check(rc, "vptq_quant_gemv_chain")
+            sp = B.current_stream_ptr(dev)
+            for idx, descs, xp, yp, safe in subs:
+                for j, i in enumerate(idx):
+                    xp[j] = xin[i].data_ptr()
+                    yp[j] = ys[i].data_ptr()
+                rc = B.lib().vptq_quant_gemv_chain(descs, len(idx), xp, yp, tokens, f0 | safe,
+                                                   None if ws is None else ws.data_ptr(), nbytes, sp)
+                if rc:
+                    B.check(rc, "vptq_quant_gemv_chain")
         self._keep = keep
         return ys
 

@@ -26,18 +26,17 @@ __all__ = ["dequant", "quant_gemm", "quant_gemv_v2"]
 # roundings (bit-identical weights) instead of the default folded fp32 form (<= 1e-3)
 _FLAGS = B.GEMV_EXACT if os.environ.get("VPTQ_EXACT", "0") == "1" else 0
 
-# The folded-form gate of VQuantLinear._folded_form_is_safe for the functional op: a bias-dominated layer
-# (rms(b)^2 > 4 rms(s)^2 (rms(c)^2 + rms(r)^2)) takes the reference's roundings.  Decided once per set of tensor
+# The folded-form gate (`_backend.folded_form_is_safe`) for the functional op: a bias-dominated layer, or one with
+# fewer than 32 distinct vector-rows, takes the reference's roundings.  Decided once per set of tensor
 # OBJECTS (weak references + version counters): one device -> host read, not one per call.
 _GATE_CACHE = {}
-_GATE_MAX_BIAS_RATIO = 2.0
 
 
-def _safe_flags(centroids, residual_centroids, weight_scale, weight_bias) -> int:
+def _safe_flags(indices, centroids, residual_centroids, weight_scale, weight_bias) -> int:
     if weight_scale is None or weight_bias is None or not weight_scale.is_cuda:
         return 0
     import weakref
-    tensors = (centroids, residual_centroids, weight_scale, weight_bias)
+    tensors = (indices, centroids, residual_centroids, weight_scale, weight_bias)
     key = tuple(id(t) for t in tensors)
     ent = _GATE_CACHE.get(key)
     if ent is not None:   # (the same OBJECTS, alive and unchanged: a recycled id or storage pointer must not hit)
@@ -45,13 +44,7 @@ def _safe_flags(centroids, residual_centroids, weight_scale, weight_bias) -> int
         if all((r is None and t is None) or (r is not None and r() is t) for r, t in zip(refs, tensors)) and \
                 vers == tuple(B.tensor_version(t) if t is not None else 0 for t in tensors):
             return hit
-    with torch.no_grad():
-        w2 = centroids.float().pow(2).mean()
-        if residual_centroids is not None:
-            w2 = w2 + residual_centroids.float().pow(2).mean()
-        lhs = weight_bias.float().pow(2).mean()
-        rhs = (_GATE_MAX_BIAS_RATIO ** 2) * weight_scale.float().pow(2).mean() * w2
-        hit = 0 if bool((lhs <= rhs).item()) else B.GEMV_EXACT
+    hit = 0 if B.folded_form_is_safe(indices, centroids, residual_centroids, weight_scale, weight_bias) else B.GEMV_EXACT
     if len(_GATE_CACHE) > 4096:
         _GATE_CACHE.clear()
     _GATE_CACHE[key] = (tuple(weakref.ref(t) if t is not None else None for t in tensors),
@@ -208,7 +201,7 @@ def quant_gemm(
             desc = None  # 9-16 tokens: only the canonical format's GEMV still beats dequant + GEMM
     if desc is not None:
         y = torch.empty(x.shape[:-1] + (out_features,), dtype=x.dtype, device=dev)
-        flags = _FLAGS | _safe_flags(centroids, residual_centroids if enable_residual else None, weight_scale, weight_bias)
+        flags = _FLAGS | _safe_flags(indices, centroids, residual_centroids if enable_residual else None, weight_scale, weight_bias)
         with torch.cuda.device(dev):
             sp = B.current_stream_ptr(dev)
             ws, wsb = (None, 0)
