@@ -284,10 +284,10 @@ def job_throughput_gbps(world, bytes_per_launch_layer, layers_per_rank, steps, w
     return world * bytes_per_launch_layer * layers_per_rank * steps / wall_s / 1e9
 
 
-def make_layer(I, O, dev, g, k=256, kr=256, dtype=torch.float16):
+def make_layer(I, O, dev, g, k=256, kr=256, dtype=torch.float16, v=8):
     import vptq_amd
     m = vptq_amd.VQuantLinear(
-        I, O, vector_lens=[-1, 8], num_centroids=[-1, k], num_res_centroids=[-1, kr if kr > 0 else -1],
+        I, O, vector_lens=[-1, v], num_centroids=[-1, k], num_res_centroids=[-1, kr if kr > 0 else -1],
         group_num=1, group_size=I, outlier_size=0, indices_as_float=False, enable_norm=True,
         enable_perm=False, is_indice_packed=True, bias=False, dtype=dtype,
         device=dev, enable_proxy_error=False)

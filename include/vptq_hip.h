@@ -230,10 +230,13 @@ VPTQ_API int vptq_quant_gemv_grouped(const VptqLayerDesc* descs, int n, const vo
  *   - VPTQ_GEMV_CHAIN_DEPENDENT: x[i + 1] may be y[i]; a device-scope arrival counter per layer
  *     orders them.  Needs workspace of vptq_quant_gemv_chain_workspace_bytes(n, flags) bytes (the
  *     call clears it on the stream).
- * Served by one launch per <= 32 layers when every layer is of the canonical v=8 / 256+256 format,
- * one dtype, without a permutation (absorb it first), tokens == 1
- * (vptq_quant_gemv_chain_kernel_name says "gemv_k256c_kernel"); anything else is executed as n
- * vptq_quant_gemv calls ("per-layer").  descs is a HOST array; x[i], y[i] device pointers.
+ * Served by one persistent launch per <= 32 layers when every layer is of the canonical v=8 / 256+256 format,
+ * one dtype, without a permutation (absorb it first), tokens == 1 and the list has more than 8 layers
+ * (vptq_quant_gemv_chain_kernel_name says "gemv_k256c_kernel"; with VPTQ_GEMV_EXACT: fp16, independent layers).
+ * Shorter lists of independent layers - and lists the persistent kernel does not take - go out as ONE
+ * vptq_quant_gemv_grouped launch ("grouped": faster than the persistent launch up to 8 layers; it serves members it
+ * has no common kernel for one by one); a single layer, mixed dtypes and dependent lists the persistent kernel does
+ * not take are executed as n vptq_quant_gemv calls ("per-layer").  descs is a HOST array; x[i], y[i] device pointers.
  */
 #define VPTQ_CHAIN_MAX 1024
 VPTQ_API int vptq_quant_gemv_chain(const VptqLayerDesc* descs, int n, const void* const* x,
@@ -258,11 +261,13 @@ VPTQ_API int vptq_quant_gemm(const VptqLayerDesc* desc, const void* x, void* y, 
                     void* workspace, size_t workspace_bytes, void* stream);
 
 /*
- * One token over a LOAD-TIME DERIVED LAYOUT of a large-codebook layer (v = 8, k = 65536, residual none or 256:
- * "v8-k65536-0" / "v8-k65536-256", the formats of most published checkpoints; ABI >= 6).  The reference gathers centroid rows from a 1 MiB codebook through the
- * caches (csrc/kernels/quant_gemv.cuh:11-186); here every row's elements are bucketed ONCE per layer by
- * the top 3 bits of their index, so that a workgroup holds its 8192-entry slice of the codebook in LDS:
- *   elems  : uint32, for slice s = 0..S-1 (S = 8 or 16; E = 65536 / S entries per slice), for row n = 0..N-1
+ * One token over a LOAD-TIME DERIVED LAYOUT of a large-codebook layer (k = 65536 main centroids; v = 8 with residual none,
+ * 256 or 65536: "v8-k65536-0" / "-256" / "-65536"; v = 16 with residual none or 65536: "v16-k65536-0" / "-65536" - the
+ * formats of most published checkpoints; ABI >= 6, the 65536-residual and v = 16 formats since round 4).  The reference
+ * gathers centroid rows from a 1 - 2 MiB codebook through the caches (csrc/kernels/quant_gemv.cuh:11-186); here every row's
+ * elements are bucketed ONCE per layer by the top bits of their index, so that a workgroup holds its slice of the codebook
+ * in LDS:
+ *   elems  : uint32, for slice s = 0..S-1 (E = 65536 / S entries per slice), for row n = 0..N-1
  *            (N = desc->num_indices): the elements of row n whose index / E == s, in any order, padded to a
  *            multiple of 64 with the word (column = group_size, local = 0);
  *            element word = column | (index mod E) << 16
@@ -270,11 +275,13 @@ VPTQ_API int vptq_quant_gemm(const VptqLayerDesc* desc, const void* x, void* y, 
  *            (prefix sum of `blocks` in (s, n) order)
  *   rows_per_wave : 1 .. 64 consecutive rows per wave (16 waves per workgroup); the layout does not
  *            depend on it
- * (vptq_amd/utils/sliced.py builds it with torch.)  It costs 2x the packed indices in device memory on
- * top of them; the state-dict tensors are untouched.  workspace: vptq_quant_gemv_sliced_workspace_bytes
- * (S x N x 8 floats of partial sums + arrival counters), 16-byte aligned, ZERO-FILLED ONCE by the caller before
- * its first use - every call leaves the counters zero; one workspace per layer call in flight (calls on one
- * stream may share it).  Folded arithmetic (parity bar, not bit-equivalent);
+ * (vptq_amd/utils/sliced.py builds it with torch.)  It costs 2x (residual 256: 1.7x) the packed indices in device memory on
+ * top of them; the state-dict tensors are untouched.  A layer with 65536 RESIDUAL centroids is served as two passes of the
+ * same kernel - (c + r) s x = c s x + r s x - and `layout` then points to TWO consecutive structs: [0] built from the main
+ * indices, [1] from the residual indices (`res` unused).  workspace: vptq_quant_gemv_sliced_workspace_bytes
+ * (S x N x v floats of partial sums + arrival counters + the first pass's sums), 16-byte aligned, ZERO-FILLED ONCE by the
+ * caller before its first use - every call leaves the counters zero; one workspace per layer and STREAM (two calls in
+ * flight on different streams must not share one).  Folded arithmetic (parity bar, not bit-equivalent);
  * Layers this path takes: group_size <= 32768; a permutation is applied while the activations are staged.
  */
 typedef struct VptqSlicedLayout {
@@ -284,11 +291,12 @@ typedef struct VptqSlicedLayout {
   const void* res;          /* uint8 per element (same order, padding = 0): residual index; NULL without residual */
   int32_t rows_per_wave;
   int32_t elems_per_lane;   /* 1 (or 0): a block = 64 elements */
-  int32_t n_slices;         /* 8 (or 0) / 16: what vptq_sliced_layout_supported() answers for the layer */
+  int32_t n_slices;         /* 8 (or 0) / 16 / 32: what vptq_sliced_layout_supported() answers for the layer */
   int32_t reserved;
 } VptqSlicedLayout;
-/* 0 = not a layer of this path; else the number of slices its layout must have: 8 slices of 8192 entries while
- * the activations fit in LDS beside them (group_size <= 14336, 14080 with a residual codebook), else 16 of 4096 */
+/* 0 = not a layer of this path; else the number of slices its layout(s) must have: v = 8: 8 slices of 8192 entries while
+ * the activations fit in LDS beside them (group_size <= 14336, 14080 with the 256-entry residual codebook), else 16 of
+ * 4096; v = 16 (32-byte entries): 16 slices of 4096 entries, beyond 14336 columns 32 of 2048 */
 VPTQ_API int vptq_sliced_layout_supported(const VptqLayerDesc* desc);
 VPTQ_API size_t vptq_quant_gemv_sliced_workspace_bytes(const VptqLayerDesc* desc);
 VPTQ_API int vptq_quant_gemv_sliced(const VptqLayerDesc* desc, const VptqSlicedLayout* layout, const void* x,

@@ -41,6 +41,13 @@ FMT_CASES = [
     # v8-k65536-256 (the format of most published checkpoints), one token
     ("t1_k65536_r256_4096x4096", 4096, 4096, 8, 65536, 256, False, True, "f16", 1, "llm"),
     ("t1_k65536_r256_bf16", 2048, 4096 + 8, 8, 65536, 256, False, False, "bf16", 1, "llm"),
+    # round 4: v8-k65536-65536 (T = 32, the "4 bit" format of every published model family), one token: two passes of the
+    # sliced kernel, one per table
+    ("t1_k65536_r65536_4096x4096", 4096, 4096, 8, 65536, 65536, False, True, "f16", 1, "llm"),
+    ("t1_k65536_r65536_bf16_perm", 2048, 2048 + 8, 8, 65536, 65536, True, False, "bf16", 1, "llm"),
+    # vector length 16: v16-k65536-65536 ("2 bits" of most model families) and v16-k65536-0
+    ("t1_v16_k65536_r65536_4096x4096", 4096, 4096, 16, 65536, 65536, False, True, "f16", 1, "llm"),
+    ("t1_v16_k65536_r0_bf16_perm", 2048, 2048 + 16, 16, 65536, 0, True, False, "bf16", 1, "llm"),
 ]
 
 

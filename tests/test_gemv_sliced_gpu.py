@@ -47,7 +47,7 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("kr", [0, 256])
+@pytest.mark.parametrize("kr", [0, 256, 65536])
 @pytest.mark.parametrize("dt", ["f16", "bf16"])
 @pytest.mark.parametrize("I,O,kw,rpw", CASES)
 def test_sliced_layout_gemv_vs_oracle(I, O, kw, rpw, dt, kr, dev):
@@ -66,7 +66,7 @@ def test_sliced_layout_gemv_vs_oracle(I, O, kw, rpw, dt, kr, dev):
     want = vo.forward(L, x)
     err = rel_err(tensor_to_bits(got), want, dt)
     assert err <= TOL[dt], f"{I}x{O} {dt}: {err:.3e}"
-    assert sl.slices == (8 if I <= (14080 if kr else 14336) else 16)
+    assert sl.slices == (8 if I <= (14080 if kr == 256 else 14336) else 16)   # (kr = 65536: one table per pass, nothing beside the slice)
     # against the library's own route for this layer (gather kernel, the reference's roundings)
     assert rel_err(tensor_to_bits(got), tensor_to_bits(gemv_abi(m, xt, 0)), dt) <= TOL[dt]
     # fp32 outputs: one rounding of the same sums; determinism
@@ -74,12 +74,14 @@ def test_sliced_layout_gemv_vs_oracle(I, O, kw, rpw, dt, kr, dev):
     assert y32.dtype == torch.float32 and torch.equal(y32.to(got.dtype).view(torch.int16), got.view(torch.int16))
     assert torch.equal(sl(xt).view(torch.int16), got.view(torch.int16))
     # memory: 4 bytes per element + padding, on top of the packed indices
-    assert sl.extra_bytes <= 2.0 * m.indices.numel() * 4 + 8 * 8 * m.indices.shape[1] + 8 * 64 * 5 * m.indices.shape[1]
+    # memory: 4 (5) bytes per element and layout + padding (< 64 elements per slice and row) + the block tables, on top of the packed indices
+    n_lay = 2 if kr == 65536 else 1
+    assert sl.extra_bytes <= 2.0 * m.indices.numel() * 4 + n_lay * sl.slices * (8 + 64 * 5) * m.indices.shape[1]
 
 
-@pytest.mark.parametrize("name", [n for n in fmt_names() if "k65536_r0" in n or "k65536_r256" in n])
+@pytest.mark.parametrize("name", [n for n in fmt_names() if "k65536_r0" in n or "k65536_r256" in n or "k65536_r65536" in n])
 def test_sliced_layout_gemv_on_reference_goldens(name, dev):
-    """v8-k65536-0 layers whose y comes from the real reference (tests/golden/gen_golden_fmt.py)"""
+    """v8-k65536-0 / -256 / -65536 layers whose y comes from the real reference (tests/golden/gen_golden_fmt.py)"""
     from vptq_amd.utils.sliced import SlicedGemv
     L, x, y, cfg, _ = load_fmt(name)
     dt = cfg["dtype"]
@@ -231,3 +233,56 @@ def test_sliced_route_falls_back_instead_of_failing(dev):
         y3 = m(xa)
     torch.cuda.synchronize()
     assert len(sl._ws) >= 2 and torch.equal(y3.view(torch.int16), ya.view(torch.int16))
+
+
+V16_CASES = [
+    (1024, 256, dict(), 0),
+    (2048, 1040, dict(bias=True), 3),
+    (4104, 272, dict(dist="llm"), 0),
+    (64, 72, dict(), 0),                                     # O not a multiple of 16: a padded last vector-row
+    (8192, 512, dict(dist="llm", bias=True), 1),
+    (2048, 528, dict(dist="llm", enable_perm=True, bias=True), 0),
+    (14352, 128, dict(dist="llm"), 0),                       # wider than 14336 columns: 32 slices of 2048 entries
+]
+
+
+@pytest.mark.parametrize("kr", [0, 65536])
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("I,O,kw,rpw", V16_CASES)
+def test_sliced_layout_gemv_vector_length_16(I, O, kw, rpw, dt, kr, dev):
+    """v16-k65536-0 and v16-k65536-65536 (the "2 bits" format of most published model families): 32-byte entries, 16 / 32
+    slices; the two-table format as two passes, one per table"""
+    from vptq_amd.utils.sliced import SlicedGemv
+    from vptq_amd import _backend as B
+    kw = dict(kw)
+    dist = kw.pop("dist", "ref-test")
+    L = vo.make_layer(I, O, dist=dist, seed=I + O + 16, dtype=dt, vector_len=16, num_centroids=65536, num_res_centroids=kr, **kw)
+    x = _x(I, dt, dist, I + 1)
+    m = spec_to_module(L, dev)
+    assert kernel_name(m, 1) == "gemv_gatherx_kernel"
+    sl = SlicedGemv(m, rows_per_wave=rpw)
+    assert sl.slices == (16 if I <= 14336 else 32) and len(sl.layout) == (2 if kr else 1)
+    xt = bits_to_tensor(x, dt, dev).reshape(x.shape)
+    got = sl(xt)
+    torch.cuda.synchronize()
+    want = vo.forward(L, x)
+    err = rel_err(tensor_to_bits(got), want, dt)
+    assert err <= TOL[dt], f"{I}x{O} {dt}: {err:.3e}"
+    assert rel_err(tensor_to_bits(got), tensor_to_bits(gemv_abi(m, xt, 0)), dt) <= TOL[dt]
+    y32 = sl(xt, flags=B.GEMV_OUT_F32)
+    assert y32.dtype == torch.float32 and torch.equal(y32.to(got.dtype).view(torch.int16), got.view(torch.int16))
+    assert torch.equal(sl(xt).view(torch.int16), got.view(torch.int16))
+    # the module's own one-token route takes it
+    m.enable_sliced_layout()
+    assert torch.equal(m(xt).view(torch.int16), got.view(torch.int16)) or rel_err(tensor_to_bits(m(xt)), want, dt) <= TOL[dt]
+
+
+@pytest.mark.parametrize("name", [n for n in fmt_names() if "v16_k65536" in n])
+def test_sliced_layout_vector_length_16_on_reference_goldens(name, dev):
+    from vptq_amd.utils.sliced import SlicedGemv
+    L, x, y, cfg, _ = load_fmt(name)
+    dt = cfg["dtype"]
+    m = spec_to_module(L, dev)
+    xt = bits_to_tensor(x, dt, dev).reshape(x.shape)
+    got = tensor_to_bits(SlicedGemv(m)(xt))
+    assert rel_err(got, y, dt) <= TOL[dt], name

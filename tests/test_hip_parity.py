@@ -802,7 +802,10 @@ FMT_KERNELS = {"t1_k8192_r256_8192x1024": "gemv_lds_mfma_kernel", "t1_k4096_r512
                # round 3: one-token fixtures of the k = 65536 formats (also served by gemv_sliced over the derived layout:
                # tests/test_gemv_sliced_gpu.py)
                "t1_k65536_r0_4096x4096": "gemv_gather_kernel", "t1_k65536_r0_bf16": "gemv_gather_kernel",
-               "t1_k65536_r256_4096x4096": "gemv_gather_kernel", "t1_k65536_r256_bf16": "gemv_gather_kernel"}
+               "t1_k65536_r256_4096x4096": "gemv_gather_kernel", "t1_k65536_r256_bf16": "gemv_gather_kernel",
+               # round 4: the two-table ("4 bit") format and vector length 16 (sliced: two passes / 32-byte entries)
+               "t1_k65536_r65536_4096x4096": "gemv_gather_kernel", "t1_k65536_r65536_bf16_perm": "gemv_gather_kernel",
+               "t1_v16_k65536_r65536_4096x4096": "gemv_gatherx_kernel", "t1_v16_k65536_r0_bf16_perm": "gemv_gatherx_kernel"}
 
 
 @pytest.mark.parametrize("name", fmt_names())
@@ -1242,6 +1245,7 @@ def test_gatherx_kernel_vs_oracle(I, O, kw, tokens, dev):
         else rng.standard_normal((1, tokens, I))
     x = vo.from_f32(xs.astype(np.float32), dt)
     m = spec_to_module(L, dev)
+    m.enable_sliced_layout(False)   # (this test is the gather kernel's: v16-k65536-0 / -65536 would take the sliced layout)
     assert kernel_name(m, tokens) == "gemv_gatherx_kernel", kernel_name(m, tokens)
     assert kernel_name(m, tokens, GENERIC) == "gemv_generic_kernel"
     xt = bits_to_tensor(x, dt, dev).reshape(x.shape)

@@ -104,3 +104,31 @@ def test_rows_per_wave():
     assert rows_per_wave_for(512, 8) == 1
     assert rows_per_wave_for(3584, 16) == 14
     assert rows_per_wave_for(10 ** 6, 8) == 64   # capped: block counts of a wave's rows sit in the lanes of one register
+
+
+def test_two_table_format_splits_into_two_index_streams():
+    """v8-k65536-65536 (T = 32): element g = (residual index << 16) | main index, one 32-bit word; the sliced path runs
+    one pass per table, each over a layout built from THAT table's index stream"""
+    from vptq_amd.utils.sliced import split_index_streams, layout_from_indices
+    rng = np.random.default_rng(5)
+    N, G = 9, 200
+    idx = rng.integers(0, 65536, (N, G), dtype=np.int64)
+    ridx = rng.integers(0, 65536, (N, G), dtype=np.int64)
+    words = ((ridx << 16) | idx).astype(np.uint32).view(np.int32).reshape(1, N, G)
+    a, b = split_index_streams(torch.from_numpy(words.copy()), G, 16)
+    assert np.array_equal(a.numpy(), idx) and np.array_equal(b.numpy(), ridx)
+    a8, b8 = split_index_streams(_pack(idx.astype(np.uint16), (ridx & 255).astype(np.uint8)), G, 8)
+    assert np.array_equal(a8.numpy(), idx) and np.array_equal(b8.numpy(), ridx & 255)
+    # the residual stream's layout holds every element once, in the slice of its RESIDUAL index
+    elems, blocks, first, res = layout_from_indices(b, 8)
+    assert res is None
+    e = elems.numpy().view(np.uint32)
+    for n in range(N):
+        got = {}
+        for s in range(8):
+            lo, cnt = int(first[s, n]) * 64, int(blocks[s, n]) * 64
+            w = e[lo:lo + cnt]
+            for col, local in zip(w & 0xffff, w >> 16):
+                if col < G:
+                    got[int(col)] = s * 8192 + int(local)
+        assert got == {g: int(ridx[n, g]) for g in range(G)}

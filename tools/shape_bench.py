@@ -13,8 +13,8 @@ SHAPES = {"8b": [(4096, 4096), (4096, 1024), (4096, 14336), (14336, 4096)],
           "70b": [(8192, 8192), (8192, 1024), (8192, 28672), (28672, 8192)]}
 
 
-def mk(I, O, dev, g, k=256, kr=256):
-    m = vptq_amd.VQuantLinear(I, O, vector_lens=[-1, 8], num_centroids=[-1, k], num_res_centroids=[-1, kr if kr > 0 else -1],
+def mk(I, O, dev, g, k=256, kr=256, v=8):
+    m = vptq_amd.VQuantLinear(I, O, vector_lens=[-1, v], num_centroids=[-1, k], num_res_centroids=[-1, kr if kr > 0 else -1],
                               group_num=1, group_size=I, outlier_size=0, indices_as_float=False, enable_norm=True,
                               enable_perm=False, is_indice_packed=True, bias=False, dtype=torch.float16, device=dev,
                               enable_proxy_error=False)

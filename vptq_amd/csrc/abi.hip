@@ -407,18 +407,20 @@ int vptq_quant_gemv_sliced(const VptqLayerDesc* d, const VptqSlicedLayout* layou
   if (rc) return rc;
   if (!x || !y || !layout) return fail(VPTQ_E_NULL, "x / y / layout is NULL");
   if (!vptq::gemv_sliced_eligible(*d))
-    return fail(VPTQ_E_UNSUPPORTED, "the sliced layout serves v8-k65536-0 / -256 layers, group_size <= 32768");
+    return fail(VPTQ_E_UNSUPPORTED, "the sliced layout serves v8-k65536-0 / -256 / -65536 layers, group_size <= 32768");
   if (flags & (VPTQ_GEMV_EXACT | VPTQ_GEMV_FORCE_GENERIC))
     return fail(VPTQ_E_UNSUPPORTED, "the sliced path has the folded arithmetic only: use vptq_quant_gemv");
   const size_t need = vptq::gemv_sliced_workspace_bytes(*d);
   if (!workspace || workspace_bytes < need || (((uintptr_t)workspace) & 15) != 0)
     return fail(VPTQ_E_WORKSPACE, "workspace of %zu bytes (16-byte aligned) needed", need);
-  if (layout->rows_per_wave < 1 || layout->rows_per_wave > 64 || !layout->elems || !layout->blocks || !layout->first ||
-      (layout->n_slices != 0 ? layout->n_slices : 8) != vptq::gemv_sliced_slices(*d))
-    return fail(VPTQ_E_UNSUPPORTED, "sliced layout: rows_per_wave in [1, 64], three tensors, n_slices = %d for this layer",
-                vptq::gemv_sliced_slices(*d));
+  const int n_layouts = d->num_res_centroids == 65536 ? 2 : 1;   // (two tables: one layout per table, consecutive structs)
+  for (int i = 0; i < n_layouts; ++i)
+    if (layout[i].rows_per_wave < 1 || layout[i].rows_per_wave > 64 || !layout[i].elems || !layout[i].blocks || !layout[i].first ||
+        (layout[i].n_slices != 0 ? layout[i].n_slices : 8) != vptq::gemv_sliced_slices(*d))
+      return fail(VPTQ_E_UNSUPPORTED, "sliced layout %d: rows_per_wave in [1, 64], three tensors, n_slices = %d for this layer",
+                  i, vptq::gemv_sliced_slices(*d));
   if ((((uintptr_t)x) & 15) != 0) return fail(VPTQ_E_UNSUPPORTED, "x must be 16-byte aligned");
-  const hipError_t e = vptq::launch_gemv_sliced(*d, *layout, x, y, flags, workspace, (hipStream_t)stream);
+  const hipError_t e = vptq::launch_gemv_sliced(*d, layout, x, y, flags, workspace, (hipStream_t)stream);
   return e == hipSuccess ? VPTQ_OK : hip_fail(e, "gemv_sliced launch");
 }
 

@@ -1,6 +1,7 @@
 // Fused dequant + GEMV for the large-codebook formats "v8-k65536-0" (v = 8, 65536 main centroids, no residual;
-// T = 16) and "v8-k65536-256" (+ 256 residual centroids, T = 24: most published checkpoints) over a LOAD-TIME
-// DERIVED LAYOUT that makes every centroid gather LDS-local.
+// T = 16), "v8-k65536-256" (+ 256 residual centroids, T = 24: most published checkpoints), "v8-k65536-65536" (T = 32,
+// the "4 bit" format: two passes, one per table) and "v16-k65536-0" / "v16-k65536-65536" (vector length 16: 32-byte
+// entries, 16 / 32 slices) over a LOAD-TIME DERIVED LAYOUT that makes every centroid gather LDS-local.
 // Same contract as gemv_gather.hip (reference: WqA16WithOutliers_PackIndice,
 // csrc/kernels/quant_gemv.cuh:11-186, dispatch csrc/quant_gemv.cu:54-132), one token.
 //
@@ -37,7 +38,7 @@ constexpr int kSLThreads = 1024;
 constexpr int kSLWaves = kSLThreads / 64;
 // 8 slices of 8192 entries (128 KiB of LDS) while the staged activations fit beside them, else 16 slices of 4096
 // (64 KiB): 8 slices hold f16(s x) of 14336 columns (14080 with the 4 KiB residual codebook), 16 slices of 32768
-constexpr int kSLMaxSlices = 16;
+constexpr int kSLMaxSlices = 32;
 constexpr int kSLMaxG8 = 14336, kSLMaxG8Res = 14080, kSLMaxG16 = 32768;
 constexpr uint32_t kSLLdsLimit = 163840;
 // element blocks in flight per wave.  Same-box A/B (profiles/r03/sliced_queue_ab.txt): depth 8 / 16 / 32 = 14.2 /
@@ -66,6 +67,7 @@ struct SlicedParams {
   const uint16_t* wbias;    // input-feature order
   const uint16_t* perm;     // column c of the quantised matrix multiplies input feature perm[c]; `scale` is then in column order
   const uint16_t* bias;
+  const float* addend;      // fp32 per output, added before the final rounding (second pass of the two-table format), or null
   float* partial;           // [slices][N * 8]
   uint32_t* arrived;        // [row blocks] workgroups of the row block that have stored their partial sums (0 between launches)
   void* y;
@@ -84,11 +86,12 @@ static __device__ __forceinline__ void sl_for_range(F&& f) {
 template <int Q, typename F>
 static __device__ __forceinline__ void sl_for_slots(F&& f) { sl_for_range<0, Q>(f); }
 
-template <typename DT, int NSL, bool RES>
+template <typename DT, int NSL, bool RES, int V = 8>
 __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedParams P) {
-  static_assert(NSL == 8 || NSL == 16, "slices");
+  static_assert(((V == 8 && (NSL == 8 || NSL == 16)) || (V == 16 && (NSL == 16 || NSL == 32))) && (V == 8 || !RES), "slices");
   constexpr int EPL = 1;   // element words per lane and block (2 and 4 - 8 / 16-byte loads - were measured: no difference)
-  constexpr uint32_t kSLTabBytes = (65536u / NSL) * 16u;   // this workgroup's slice of the codebook
+  constexpr uint32_t kEntry = V * 2u;                          // bytes of a codebook entry
+  constexpr uint32_t kSLTabBytes = (65536u / NSL) * kEntry;   // this workgroup's slice of the codebook
   constexpr uint32_t kSLXOff = kSLTabBytes;                // staged activations: (G + 64) halves
   typedef uint32_t evec_t __attribute__((ext_vector_type(EPL)));
   constexpr int kLoadsPerStep = RES ? 2 : 1;
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedPar
       if (q < chunks && !(VPTQ_SLICED_ABLATE & 4)) {
         // x in input-FEATURE order (sum b x needs nothing else: a permutation only reorders the sum)
         const u32x4 xv = *(const u32x4*)(as_global(P.x) + 8 * q);
-        if (s == 0) {
+        if (s == 0 && P.wbias != nullptr) {
           const u32x4 bv = *(const u32x4*)(as_global(P.wbias) + 8 * q);
 #pragma unroll
           for (int i = 0; i < 4; ++i) bd = DT::dot2(xv[i], bv[i], bd);
@@ -215,36 +218,38 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedPar
 #pragma unroll
     for (int i = 0; i < kSLWaves; ++i) bdot += bp[i];
   }
-  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float acc[V];
+#pragma unroll
+  for (int i = 0; i < V; ++i) acc[i] = 0.f;
   int row_i = 0;
   // rows without elements in this slice store zeros
   auto store_row = [&]() __attribute__((always_inline)) {
     // sum over the 64 lanes: swap-and-add halves the values carried (gemv_k256c.hip:finish), then DPP
-    float v[8];
+    float v[V];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = acc[i];
+    for (int i = 0; i < V; ++i) v[i] = acc[i];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 4]), false, false);
+    for (int i = 0; i < V / 2; ++i) {
+      auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(v[i + V / 2]), false, false);
       v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 2]), false, false);
+    for (int i = 0; i < V / 4; ++i) {
+      auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[i]), __float_as_uint(v[i + V / 4]), false, false);
       v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) v[i] = row16_allsum(v[i]);
-    // lane l (any of its row of 16) holds outputs 4 bit5 + 2 bit4 + {0, 1}
+    for (int i = 0; i < V / 4; ++i) v[i] = row16_allsum(v[i]);
+    // lane l (any of its row of 16) holds outputs (V / 2) bit5 + (V / 4) bit4 + {0 .. V / 4 - 1}
     if ((lane & 15) == 0) {
-      const int o8 = ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2;
+      const int o8 = ((lane >> 5) & 1) * (V / 2) + ((lane >> 4) & 1) * (V / 4);
       // write-through at device scope (sc1): the workgroup that sums the slices may sit on another XCD
-      float* const pp = as_global(P.partial) + ((size_t)s * N + (size_t)(row0 + row_i)) * 8 + o8;
-      __hip_atomic_store(pp, v[0] + bdot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(pp + 1, v[1] + bdot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      float* const pp = as_global(P.partial) + ((size_t)s * N + (size_t)(row0 + row_i)) * V + o8;
+#pragma unroll
+      for (int i = 0; i < V / 4; ++i) __hip_atomic_store(pp + i, v[i] + bdot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+    for (int i = 0; i < V; ++i) acc[i] = 0.f;
   };
   int left = 0x7fffffff;
   bool done = false;
@@ -268,13 +273,16 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedPar
       return;
     }
     typedef __attribute__((address_space(3))) uint16_t lds_h_t;
-    u32x4 ent[EPL];
+    constexpr int W4 = V / 8;   // 16-byte pieces of an entry
+    u32x4 ent[EPL][W4];
     u32x4 rent = {0u, 0u, 0u, 0u};
     uint16_t xh[EPL];
 #pragma unroll
     for (int k = 0; k < EPL; ++k) {
       const uint32_t e = ev[k];
-      ent[k] = lds_load16((e >> 16) << 4);
+      const uint32_t ea = (e >> 16) * kEntry;
+#pragma unroll
+      for (int w = 0; w < W4; ++w) ent[k][w] = lds_load16(ea + 16u * (uint32_t)w);
       xh[k] = *(const lds_h_t*)(uintptr_t)(kSLXOff + ((e & 0xffffu) << 1));
     }
     if constexpr (RES) rent = lds_load16(res_off + (rq[S] << 4));
@@ -285,13 +293,13 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedPar
         // fmaf of the converted values gives), halves picked by op_sel
         const uint32_t xw = xh[k];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < V / 2; ++i) {
           float lo = acc[2 * i], hi = acc[2 * i + 1];   // (an asm operand cannot name a captured array element)
-          const uint32_t ew = ent[k][i];
+          const uint32_t ew = ent[k][i / 4][i % 4];
           asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,1,0]" : "+v"(lo) : "v"(ew), "v"(xw));
           asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,0]" : "+v"(hi) : "v"(ew), "v"(xw));
           if constexpr (RES) {   // (c + r) x = c x + r x: the residual entry into the same sums
-            const uint32_t rw = rent[i];
+            const uint32_t rw = rent[i % 4];
             asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,1,0]" : "+v"(lo) : "v"(rw), "v"(xw));
             asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,0]" : "+v"(hi) : "v"(rw), "v"(xw));
           }
@@ -300,12 +308,13 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedPar
       } else {
         const float xf = DT::to_float(xh[k]);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          acc[2 * i] = __builtin_fmaf(DT::to_float((uint16_t)(ent[k][i] & 0xffffu)), xf, acc[2 * i]);
-          acc[2 * i + 1] = __builtin_fmaf(DT::to_float((uint16_t)(ent[k][i] >> 16)), xf, acc[2 * i + 1]);
+        for (int i = 0; i < V / 2; ++i) {
+          const uint32_t ew = ent[k][i / 4][i % 4];
+          acc[2 * i] = __builtin_fmaf(DT::to_float((uint16_t)(ew & 0xffffu)), xf, acc[2 * i]);
+          acc[2 * i + 1] = __builtin_fmaf(DT::to_float((uint16_t)(ew >> 16)), xf, acc[2 * i + 1]);
           if constexpr (RES) {
-            acc[2 * i] = __builtin_fmaf(DT::to_float((uint16_t)(rent[i] & 0xffffu)), xf, acc[2 * i]);
-            acc[2 * i + 1] = __builtin_fmaf(DT::to_float((uint16_t)(rent[i] >> 16)), xf, acc[2 * i + 1]);
+            acc[2 * i] = __builtin_fmaf(DT::to_float((uint16_t)(rent[i % 4] & 0xffffu)), xf, acc[2 * i]);
+            acc[2 * i + 1] = __builtin_fmaf(DT::to_float((uint16_t)(rent[i % 4] >> 16)), xf, acc[2 * i + 1]);
           }
         }
       }
@@ -360,19 +369,20 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedPar
   {
     const int rows_wg = kSLWaves * rpw;
     const int r_first = rb * rows_wg;
-    const int n_out = (N - r_first < rows_wg ? N - r_first : rows_wg) * 8;   // outputs of this row block
+    const int n_out = (N - r_first < rows_wg ? N - r_first : rows_wg) * V;   // outputs of this row block
     for (int k = tid; k < n_out; k += kSLThreads) {
-      const size_t o = (size_t)r_first * 8 + k;
+      const size_t o = (size_t)r_first * V + k;
       float p[NSL];
 #pragma unroll
       for (int sl = 0; sl < NSL; ++sl)
-        p[sl] = __hip_atomic_load(as_global(P.partial) + (size_t)sl * N * 8 + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        p[sl] = __hip_atomic_load(as_global(P.partial) + (size_t)sl * N * V + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
       for (int w = NSL / 2; w > 0; w >>= 1)   // (a fixed tree)
 #pragma unroll
         for (int i = 0; i < w; ++i) p[i] = p[2 * i] + p[2 * i + 1];
       float v = p[0];
       if ((int)o < P.O) {
+        if (P.addend) v += as_global(P.addend)[o];   // (written by the previous launch on this stream)
         if (P.bias) v += DT::to_float(as_global(P.bias)[o]);
         if (P.out_f32) ((float*)as_global(P.y))[o] = v;
         else ((uint16_t*)as_global(P.y))[o] = DT::from_float(v);
@@ -382,57 +392,72 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedPar
 }
 
 // ---- host side -------------------------------------------------------------------
-// v8-k65536-0 (T = 16) and v8-k65536-256 (T = 24: the format of most published checkpoints)
+// v8-k65536-0 (T = 16), v8-k65536-256 (T = 24: the format of most published checkpoints), v8-k65536-65536 (T = 32, two passes),
+// v16-k65536-0 and v16-k65536-65536 (vector length 16)
 bool gemv_sliced_eligible(const VptqLayerDesc& d) {
   const bool res = d.num_res_centroids == 256;
-  return d.vector_len == 8 && d.num_codebooks == 1 && d.outlier_size == 0 && d.num_centroids == 65536 &&
-         (d.num_res_centroids == 0 || res) && d.index_bits == 16 && (!res || d.res_bits == 8) &&
+  const bool two = d.num_res_centroids == 65536;   // T = 32: two passes, one per table
+  const bool v16 = d.vector_len == 16;
+  return (d.vector_len == 8 || v16) && d.num_codebooks == 1 && d.outlier_size == 0 && d.num_centroids == 65536 &&
+         (d.num_res_centroids == 0 || (res && !v16) || two) && d.index_bits == 16 && (!res || d.res_bits == 8) && (!two || d.res_bits == 16) &&
          d.weight_scale != nullptr && d.weight_bias != nullptr &&
          (d.perm == nullptr || d.scale_permuted != nullptr) && (d.group_size % 8) == 0 && d.group_size == d.in_features &&
          d.group_size <= kSLMaxG16 &&
-         (long long)d.row_words * 32 == (long long)d.group_size * (res ? 24 : 16) &&
+         (long long)d.row_words * 32 == (long long)d.group_size * (two ? 32 : res ? 24 : 16) &&
          (((uintptr_t)d.centroids | (uintptr_t)d.res_centroids | (uintptr_t)d.weight_scale | (uintptr_t)d.weight_bias |
            (uintptr_t)d.perm | (uintptr_t)d.scale_permuted) & 15) == 0;
 }
 
-// slices a layout of this layer must have
+// slices a layout of this layer must have: the slice (65536 / slices entries of 2 v bytes) + f16(s x) of every column
+// (+ the 4 KiB residual table) must fit the 160 KiB of LDS: v = 8: 8 slices of 8192 entries up to 14336 columns (14080 with
+// the residual table), else 16; v = 16: 16 slices of 4096 entries up to 14336 columns, else 32
 int gemv_sliced_slices(const VptqLayerDesc& d) {
-  static std::atomic<int> force16{-1};   // VPTQ_SLICED_SLICES=16: 16 slices for every layer (A/B)
+  static std::atomic<int> force16{-1};   // VPTQ_SLICED_SLICES=16: the larger slice count for every layer (A/B)
   if (force16 < 0) { const char* e = getenv("VPTQ_SLICED_SLICES"); force16 = (e && atoi(e) == 16) ? 1 : 0; }
-  if (force16 == 1) return 16;
-  return d.group_size <= (d.num_res_centroids == 256 ? kSLMaxG8Res : kSLMaxG8) ? 8 : 16;
+  const int small = d.vector_len == 16 ? 16 : 8;
+  if (force16 == 1) return 2 * small;
+  return d.group_size <= (d.num_res_centroids == 256 ? kSLMaxG8Res : kSLMaxG8) ? small : 2 * small;
 }
 
-// partial sums [slices][N x 8] floats + one arrival counter per block of 16 rows (the smallest row block), which must be
-// ZERO before the first launch; every launch leaves them zero
+// partial sums [slices][N x v] floats + one arrival counter per block of 16 rows (the smallest row block), which must be
+// ZERO before the first launch; every launch leaves them zero (the two passes of the two-table formats share them: the
+// second launch starts when the first has finished)
 static size_t sl_partial_bytes(const VptqLayerDesc& d) {
-  return ((size_t)gemv_sliced_slices(d) * d.num_indices * 8 * sizeof(float) + 255) / 256 * 256;
+  return ((size_t)gemv_sliced_slices(d) * d.num_indices * d.vector_len * sizeof(float) + 255) / 256 * 256;
 }
+static size_t sl_counter_bytes(const VptqLayerDesc& d) {
+  return (((size_t)(d.num_indices + kSLWaves - 1) / kSLWaves) * sizeof(uint32_t) + 255) / 256 * 256;
+}
+// + (two-table formats) the first pass's fp32 outputs
 size_t gemv_sliced_workspace_bytes(const VptqLayerDesc& d) {
-  return sl_partial_bytes(d) + ((size_t)(d.num_indices + kSLWaves - 1) / kSLWaves) * sizeof(uint32_t);
+  return sl_partial_bytes(d) + sl_counter_bytes(d) +
+         (d.num_res_centroids == 65536 ? (size_t)d.num_indices * d.vector_len * sizeof(float) : 0);
 }
 
-template <typename DT, int NSL>
-static hipError_t launch_sl(const SlicedParams& P, bool res, uint32_t lds, hipStream_t st) {
+template <typename DT, int NSL, bool RES, int V>
+static hipError_t launch_sl(const SlicedParams& P, uint32_t lds, hipStream_t st) {
+  auto kern = gemv_sliced_kernel<DT, NSL, RES, V>;
   static std::atomic<bool> attr_set[64];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
   if (!attr_set[dev]) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemv_sliced_kernel<DT, NSL, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSLLdsLimit);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute((const void*)gemv_sliced_kernel<DT, NSL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSLLdsLimit);
+    const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSLLdsLimit);
     if (e != hipSuccess) return e;
     attr_set[dev] = true;
   }
-  const dim3 grid(NSL * P.n_rowblocks), block(kSLThreads);
-  if (res) hipLaunchKernelGGL((gemv_sliced_kernel<DT, NSL, true>), grid, block, lds, st, P);
-  else hipLaunchKernelGGL((gemv_sliced_kernel<DT, NSL, false>), grid, block, lds, st, P);
+  hipLaunchKernelGGL(kern, dim3(NSL * P.n_rowblocks), dim3(kSLThreads), lds, st, P);
   return hipGetLastError();
 }
+template <typename DT>
+static hipError_t launch_sl_dt(const SlicedParams& P, int v, int nsl, bool res, uint32_t lds, hipStream_t st) {
+  if (v == 16) return nsl == 16 ? launch_sl<DT, 16, false, 16>(P, lds, st) : launch_sl<DT, 32, false, 16>(P, lds, st);
+  if (nsl == 8) return res ? launch_sl<DT, 8, true, 8>(P, lds, st) : launch_sl<DT, 8, false, 8>(P, lds, st);
+  return res ? launch_sl<DT, 16, true, 8>(P, lds, st) : launch_sl<DT, 16, false, 8>(P, lds, st);
+}
 
-hipError_t launch_gemv_sliced(const VptqLayerDesc& d, const VptqSlicedLayout& L, const void* x, void* y, int flags,
-                              void* ws, hipStream_t st) {
-  const bool res = d.num_res_centroids == 256;
+// one pass over one layout: cent = the table its elements index
+static hipError_t sl_pass(const VptqLayerDesc& d, const VptqSlicedLayout& L, const void* cent, bool res, const void* x, void* y,
+                          bool out_f32, bool with_wbias, const void* bias, const float* addend, void* ws, hipStream_t st) {
   const int nsl = gemv_sliced_slices(d);
   if ((L.n_slices != 0 ? L.n_slices : 8) != nsl || (L.elems_per_lane != 0 && L.elems_per_lane != 1) || (res && !L.res) ||
       L.rows_per_wave < 1 || L.rows_per_wave > kSLMaxRowsPerWave || !L.elems || !L.blocks || !L.first || !ws ||
@@ -444,12 +469,13 @@ hipError_t launch_gemv_sliced(const VptqLayerDesc& d, const VptqSlicedLayout& L,
   P.rcent = res ? (const uint32_t*)d.res_centroids : nullptr;
   P.blocks = (const int32_t*)L.blocks;
   P.first = (const int32_t*)L.first;
-  P.cent = (const uint32_t*)d.centroids;
+  P.cent = (const uint32_t*)cent;
   P.x = (const uint16_t*)x;
   P.scale = (const uint16_t*)(d.perm ? d.scale_permuted : d.weight_scale);
-  P.wbias = (const uint16_t*)d.weight_bias;
+  P.wbias = with_wbias ? (const uint16_t*)d.weight_bias : nullptr;
   P.perm = (const uint16_t*)d.perm;
-  P.bias = (const uint16_t*)d.bias;
+  P.bias = (const uint16_t*)bias;
+  P.addend = addend;
   P.partial = (float*)ws;
   P.arrived = (uint32_t*)((char*)ws + sl_partial_bytes(d));
   P.y = y;
@@ -457,12 +483,24 @@ hipError_t launch_gemv_sliced(const VptqLayerDesc& d, const VptqSlicedLayout& L,
   P.rows_per_wave = L.rows_per_wave;
   const int rows_per_wg = kSLWaves * L.rows_per_wave;
   P.n_rowblocks = (d.num_indices + rows_per_wg - 1) / rows_per_wg;
-  P.out_f32 = (flags & VPTQ_GEMV_OUT_F32) ? 1 : 0;
-  const uint32_t lds = (65536u / (uint32_t)nsl) * 16u + (uint32_t)(d.group_size + 64) * 2u + 64u + (res ? 4096u : 0u);
+  P.out_f32 = out_f32 ? 1 : 0;
+  const uint32_t lds = (65536u / (uint32_t)nsl) * (uint32_t)d.vector_len * 2u + (uint32_t)(d.group_size + 64) * 2u + 64u + (res ? 4096u : 0u);
   if (lds > kSLLdsLimit) return hipErrorInvalidValue;
-  const bool f16 = d.dtype == VPTQ_DTYPE_F16;
-  if (nsl == 8) return f16 ? launch_sl<F16, 8>(P, res, lds, st) : launch_sl<BF16, 8>(P, res, lds, st);
-  return f16 ? launch_sl<F16, 16>(P, res, lds, st) : launch_sl<BF16, 16>(P, res, lds, st);
+  return d.dtype == VPTQ_DTYPE_F16 ? launch_sl_dt<F16>(P, d.vector_len, nsl, res, lds, st)
+                                   : launch_sl_dt<BF16>(P, d.vector_len, nsl, res, lds, st);
+}
+
+// L: one layout (residual none / 256) or TWO consecutive ones (k65536 + 65536: [0] by main index, [1] by residual index)
+hipError_t launch_gemv_sliced(const VptqLayerDesc& d, const VptqSlicedLayout* L, const void* x, void* y, int flags,
+                              void* ws, hipStream_t st) {
+  const bool out_f32 = (flags & VPTQ_GEMV_OUT_F32) != 0;
+  if (d.num_res_centroids != 65536)
+    return sl_pass(d, L[0], d.centroids, d.num_res_centroids == 256, x, y, out_f32, true, d.bias, nullptr, ws, st);
+  // y = sum c[idx] f16(s x) + sum b x   (pass 1, fp32 into the workspace)   + sum r[ridx] f16(s x) + bias   (pass 2)
+  float* const first = (float*)((char*)ws + sl_partial_bytes(d) + sl_counter_bytes(d));
+  const hipError_t e = sl_pass(d, L[0], d.centroids, false, x, first, true, true, nullptr, nullptr, ws, st);
+  if (e != hipSuccess) return e;
+  return sl_pass(d, L[1], d.res_centroids, false, x, y, out_f32, false, d.bias, first, ws, st);
 }
 
 }  // namespace vptq

@@ -57,7 +57,7 @@ hipError_t launch_gemv_lds_v2(const VptqV2Desc& d, const void* x, void* y, int t
 bool gemv_sliced_eligible(const VptqLayerDesc& d);
 int gemv_sliced_slices(const VptqLayerDesc& d);
 size_t gemv_sliced_workspace_bytes(const VptqLayerDesc& d);
-hipError_t launch_gemv_sliced(const VptqLayerDesc& d, const VptqSlicedLayout& L, const void* x, void* y, int flags,
+hipError_t launch_gemv_sliced(const VptqLayerDesc& d, const VptqSlicedLayout* L, const void* x, void* y, int flags,
                               void* ws, hipStream_t st);
 // gemm_k256t.hip - canonical format, fp16 / bf16, up to 16 tokens in one pass over the indices (transposing
 // gather -> 16x16x32 MFMA with tokens as M; folded arithmetic; needs a workspace for the operand-ordered activations)

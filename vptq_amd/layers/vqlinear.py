@@ -399,7 +399,7 @@ class VQuantLinear(nn.Module):
             if torch.cuda.is_current_stream_capturing():
                 return None   # (no layout is built inside a capture - and the "no" is not remembered: a later call builds it)
             obj = None
-            if not cache[9] and B.lib().vptq_sliced_layout_supported(cache[1]) and self._sliced_fits(cache, on):
+            if not cache[9] and B.lib().vptq_sliced_layout_supported(cache[1]) and self._sliced_pays(on) and self._sliced_fits(cache, on):
                 from vptq_amd.utils.sliced import SlicedGemv
                 try:
                     obj = SlicedGemv(self)
@@ -412,6 +412,16 @@ class VQuantLinear(nn.Module):
             self.__dict__["_sliced"] = st
         return st[1]
 
+    def _sliced_pays(self, on) -> bool:
+        """auto mode: a layer with 65536 residual centroids is TWO passes (launches) over the derived layouts; below 2^21
+        elements per pass that is no faster than the one launch of the gather kernel (v16-k65536-65536 at 4096 x 4096:
+        20.5 against 19.1 us; v8 at 4096 x 4096: 17.8 against 21.8 - profiles/r04/sliced_*_r65536.json)"""
+        if on is True and "_sliced_on" in self.__dict__ or _SLICED_LAYOUT_MODE in ("1", "on", "true", "yes", "always"):
+            return True
+        if self.enable_residual and self.num_res_centroids == 65536:
+            return self.indices.shape[1] * self.group_size >= (1 << 21)
+        return True
+
     def _sliced_fits(self, cache, on) -> bool:
         """auto mode: build only while the layout (5 / 4 bytes per element + the builder's temporaries) leaves
         _SLICED_MIN_FREE_FRACTION of the device memory free, and never inside a stream capture"""
@@ -421,7 +431,8 @@ class VQuantLinear(nn.Module):
             return True
         free, total = torch.cuda.mem_get_info(cache[3])
         elems = self.indices.shape[1] * self.group_size
-        need = elems * 5 + elems * 8 * 12   # layout + int64 temporaries of build_sliced_layout
+        two = self.enable_residual and self.num_res_centroids == 65536   # (one layout per table)
+        need = elems * (8 if two else 5) + elems * 8 * 12   # layout + int64 temporaries of build_sliced_layout
         return free - need > _SLICED_MIN_FREE_FRACTION * total
 
     def _gemv_cached(self, x: torch.Tensor, tokens: int) -> torch.Tensor:
@@ -431,9 +442,10 @@ class VQuantLinear(nn.Module):
             if "_sliced_cand" not in self.__dict__:
                 # (static module configuration: decided once, so that every other layer pays one dict look-up per call)
                 self.__dict__["_sliced_cand"] = bool(
-                    self.num_centroids == 65536 and self.vector_len == 8 and self.num_codebooks == 1 and
+                    self.num_centroids == 65536 and self.vector_len in (8, 16) and self.num_codebooks == 1 and
                     not self.enable_outlier and self.enable_norm and   # (a permutation may still be absorbed later)
-                    (not self.enable_residual or self.num_res_centroids == 256))
+                    (not self.enable_residual or self.num_res_centroids == 65536 or
+                     (self.num_res_centroids == 256 and self.vector_len == 8)))
             sl = self._sliced_gemv() if self.__dict__["_sliced_cand"] else None
             if sl is not None and not (ops.quant_gemm_flags() & (B.GEMV_EXACT | B.GEMV_FORCE_GENERIC)):
                 y = sl(x)

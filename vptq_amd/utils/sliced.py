@@ -1,5 +1,5 @@
-"""Load-time derived layout for large-codebook layers (v = 8, k = 65536, residual none or 256: "v8-k65536-0",
-"v8-k65536-256"), the formats of most published VPTQ checkpoints, and the one-token GEMV over it
+"""Load-time derived layout for large-codebook layers (v = 8, k = 65536, residual none, 256 or 65536: "v8-k65536-0",
+"v8-k65536-256", "v8-k65536-65536"), the formats of most published VPTQ checkpoints, and the one-token GEMV over it
 (`vptq_quant_gemv_sliced`, vptq_amd/csrc/gemv_sliced.hip).
 
 The reference gathers centroid rows from the 1 MiB codebook through the caches for every index
@@ -23,21 +23,36 @@ from vptq_amd import _backend as B
 INDEX_BITS = 16   # 65536 main centroids
 
 
+def split_index_streams(indices: torch.Tensor, group_size: int, res_bits: int):
+    """the layer's packed int32 `indices` [1, N, row_words] -> (main index [N, G] int64, residual index [N, G] int64 or None):
+    a little-endian bit stream per row, element g at bits [T g, T g + T) with value (residual index << 16) | main index
+    (vptq/utils/pack.py:26-89); T = 16 without a residual codebook, 24 with 256, 32 with 65536 residual centroids."""
+    assert indices.dtype == torch.int32 and indices.dim() == 3 and indices.shape[0] == 1 and res_bits in (0, 8, 16)
+    N, G = indices.shape[1], group_size
+    nbytes = 2 + res_bits // 8
+    by = indices[0].contiguous().view(torch.uint8).reshape(N, -1)[:, :nbytes * G].reshape(N, G, nbytes).to(torch.int64)
+    idx = by[:, :, 0] | (by[:, :, 1] << 8)
+    ridx = None if res_bits == 0 else (by[:, :, 2] if res_bits == 8 else (by[:, :, 2] | (by[:, :, 3] << 8)))
+    return idx, ridx
+
+
 def build_sliced_layout(indices: torch.Tensor, group_size: int, slices: int = 8, residual: bool = False):
-    """indices: the layer's packed int32 `indices` [1, N, row_words]: a little-endian bit stream per row, element g
-    at bits [T g, T g + T) with value (residual index << 16) | main index (vptq/utils/pack.py:26-89); T = 16 without
-    a residual codebook, 24 with 256 residual centroids.  slices: 8 or 16 (vptq_sliced_layout_supported tells).
+    """indices: the layer's packed int32 `indices` [1, N, row_words] (T = 16 without a residual codebook, 24 with 256
+    residual centroids).  slices: 8 or 16 (vptq_sliced_layout_supported tells).
     Returns (elems uint32-as-int32 [blocks * 64], blocks int32 [slices, N], first int32 [slices, N], res uint8
     [like elems] or None) as described in include/vptq_hip.h (VptqSlicedLayout)."""
-    assert indices.dtype == torch.int32 and indices.dim() == 3 and indices.shape[0] == 1
-    assert slices in (8, 16)
-    SLICES, SLICE_BITS = slices, INDEX_BITS - (3 if slices == 8 else 4)
-    dev = indices.device
-    N, G = indices.shape[1], group_size
-    nbytes = 3 if residual else 2
-    by = indices[0].contiguous().view(torch.uint8).reshape(N, -1)[:, :nbytes * G].reshape(N, G, nbytes).to(torch.int64)
-    idx = by[:, :, 0] | (by[:, :, 1] << 8)                                    # [N, G] main index per column
-    ridx = by[:, :, 2] if residual else None
+    idx, ridx = split_index_streams(indices, group_size, 8 if residual else 0)
+    return layout_from_indices(idx, slices, ridx)
+
+
+def layout_from_indices(idx: torch.Tensor, slices: int = 8, ridx: torch.Tensor = None):
+    """idx [N, G] int64 (values < 65536): the index each element gathers with from the table this layout is for;
+    ridx: an 8-bit side index carried along per element (the 256-entry residual table), or None."""
+    assert slices in (8, 16, 32)
+    SLICES, SLICE_BITS = slices, INDEX_BITS - {8: 3, 16: 4, 32: 5}[slices]
+    dev = idx.device
+    N, G = idx.shape
+    residual = ridx is not None
     sl = idx >> SLICE_BITS
     col = torch.arange(G, device=dev, dtype=torch.int64)
     # Order inside a (row, slice) list is free (a sum): arrange it so that 16 CONSECUTIVE elements - the lanes one
@@ -92,24 +107,32 @@ class SlicedGemv:
         self.desc, self.dev = cache[1], cache[3]
         self.slices = B.lib().vptq_sliced_layout_supported(self.desc)
         if not self.slices:
-            raise ValueError("the sliced layout serves v8-k65536-0 / v8-k65536-256 layers, group_size <= 32768")
-        residual = bool(layer.enable_residual)
-        self.elems, self.blocks, self.first, self.res = build_sliced_layout(layer.indices.data, layer.group_size,
-                                                                            self.slices, residual)
-        self.layout = B.SlicedLayout(self.elems.data_ptr(), self.blocks.data_ptr(), self.first.data_ptr(),
-                                     self.res.data_ptr() if residual else None,
-                                     rows_per_wave or rows_per_wave_for(self.blocks.shape[1], self.slices), 1,
-                                     self.slices, 0)
+            raise ValueError("the sliced layout serves v8-k65536-0 / -256 / -65536 and v16-k65536-0 / -65536 layers, group_size <= 32768")
+        kr = layer.num_res_centroids if layer.enable_residual else 0
+        rpw = None
+        if kr == 65536:
+            # "v8-k65536-65536" (T = 32, the 4-bit format of the published checkpoints): (c + r) s x = c s x + r s x, so the
+            # layer is TWO passes of the one-table kernel, each over a layout bucketed by ITS table's index
+            idx, ridx = split_index_streams(layer.indices.data, layer.group_size, 16)
+            self._tensors = [layout_from_indices(idx, self.slices), layout_from_indices(ridx, self.slices)]
+            del idx, ridx
+        else:
+            self._tensors = [build_sliced_layout(layer.indices.data, layer.group_size, self.slices, kr == 256)]
+        self.elems, self.blocks, self.first, self.res = self._tensors[0]
+        rpw = rows_per_wave or rows_per_wave_for(self.blocks.shape[1], self.slices)
+        self.layout = (B.SlicedLayout * len(self._tensors))(*[
+            B.SlicedLayout(e.data_ptr(), b.data_ptr(), f.data_ptr(), r.data_ptr() if r is not None else None, rpw, 1, self.slices, 0)
+            for e, b, f, r in self._tensors])
         self._ws_bytes = B.lib().vptq_quant_gemv_sliced_workspace_bytes(self.desc)
         # partial sums + arrival counters, ONE PER STREAM (two streams - or a graph replay next to an eager call on
         # another stream - running the same layer would race on a shared one); zeroed once, every call leaves the
         # counters zero
         self._ws = {}
         self._fn = B.lib().vptq_quant_gemv_sliced
-        self._lay_ref = C.byref(self.layout)
+        self._lay_ref = self.layout   # (an array of 1 or 2 structs: passed as a pointer to the first)
         self._dtype = cache[7]
         self._dev_index = cache[8]
-        self.extra_bytes = self.elems.numel() * (5 if residual else 4) + self.blocks.numel() * 8
+        self.extra_bytes = sum(e.numel() * (5 if r is not None else 4) + b.numel() * 8 for e, b, f, r in self._tensors)
 
     def _workspace(self, stream_ptr: int):
         ws = self._ws.get(stream_ptr)
