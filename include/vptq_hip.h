@@ -276,10 +276,11 @@ VPTQ_API int vptq_quant_gemm(const VptqLayerDesc* desc, const void* x, void* y, 
  *   rows_per_wave : 1 .. 64 consecutive rows per wave (16 waves per workgroup); the layout does not
  *            depend on it
  * (vptq_amd/utils/sliced.py builds it with torch.)  It costs 2x (residual 256: 1.7x) the packed indices in device memory on
- * top of them; the state-dict tensors are untouched.  A layer with 65536 RESIDUAL centroids is served as two passes of the
- * same kernel - (c + r) s x = c s x + r s x - and `layout` then points to TWO consecutive structs: [0] built from the main
+ * top of them; the state-dict tensors are untouched.  A layer with 65536 RESIDUAL centroids is served table by table
+ * - (c + r) s x = c s x + r s x: the residual table's (slice, row block) workgroups run beside the main table's in the same
+ * launch - and `layout` then points to TWO consecutive structs with the same rows_per_wave: [0] built from the main
  * indices, [1] from the residual indices (`res` unused).  workspace: vptq_quant_gemv_sliced_workspace_bytes
- * (S x N x v floats of partial sums + arrival counters + the first pass's sums), 16-byte aligned, ZERO-FILLED ONCE by the
+ * ((2 x) S x N x v floats of partial sums + arrival counters), 16-byte aligned, ZERO-FILLED ONCE by the
  * caller before its first use - every call leaves the counters zero; one workspace per layer and STREAM (two calls in
  * flight on different streams must not share one).  Folded arithmetic (parity bar, not bit-equivalent);
  * Layers this path takes: group_size <= 32768; a permutation is applied while the activations are staged.

@@ -67,7 +67,13 @@ struct SlicedParams {
   const uint16_t* wbias;    // input-feature order
   const uint16_t* perm;     // column c of the quantised matrix multiplies input feature perm[c]; `scale` is then in column order
   const uint16_t* bias;
-  const float* addend;      // fp32 per output, added before the final rounding (second pass of the two-table format), or null
+  const float* addend;      // fp32 per output, added before the final rounding, or null
+  // TWO tables in one launch (65536 residual centroids): the residual table's layout and codebook; its workgroups are
+  // "slices" NSL .. 2 NSL - 1 of the same row blocks
+  const uint32_t* elems2;
+  const int32_t* blocks2;
+  const int32_t* first2;
+  const uint32_t* cent2;
   float* partial;           // [slices][N * 8]
   uint32_t* arrived;        // [row blocks] workgroups of the row block that have stored their partial sums (0 between launches)
   void* y;
@@ -86,9 +92,10 @@ static __device__ __forceinline__ void sl_for_range(F&& f) {
 template <int Q, typename F>
 static __device__ __forceinline__ void sl_for_slots(F&& f) { sl_for_range<0, Q>(f); }
 
-template <typename DT, int NSL, bool RES, int V = 8>
+template <typename DT, int NSL, bool RES, int V = 8, bool TWO = false>
 __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedParams P) {
-  static_assert(((V == 8 && (NSL == 8 || NSL == 16)) || (V == 16 && (NSL == 16 || NSL == 32))) && (V == 8 || !RES), "slices");
+  static_assert(((V == 8 && (NSL == 8 || NSL == 16)) || (V == 16 && (NSL == 16 || NSL == 32))) && (V == 8 || !RES) && !(TWO && RES), "slices");
+  constexpr int NSLT = TWO ? 2 * NSL : NSL;   // workgroups per row block: one per (table, slice)
   constexpr int EPL = 1;   // element words per lane and block (2 and 4 - 8 / 16-byte loads - were measured: no difference)
   constexpr uint32_t kEntry = V * 2u;                          // bytes of a codebook entry
   constexpr uint32_t kSLTabBytes = (65536u / NSL) * kEntry;   // this workgroup's slice of the codebook
@@ -103,7 +110,13 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedPar
   }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int s = (int)blockIdx.x & (NSL - 1), rb = (int)blockIdx.x / NSL;
+  const int sg = (int)blockIdx.x & (NSLT - 1), rb = (int)blockIdx.x / NSLT;
+  const int s = sg & (NSL - 1);
+  const bool second = TWO && sg >= NSL;   // (uniform over the workgroup) this workgroup gathers from the residual table
+  const uint32_t* const elems_t = second ? P.elems2 : P.elems;
+  const int32_t* const blocks_t = second ? P.blocks2 : P.blocks;
+  const int32_t* const first_t = second ? P.first2 : P.first;
+  const uint32_t* const cent_t = second ? P.cent2 : P.cent;
   const int N = P.N, G = P.G;
   const int rpw = P.rows_per_wave;
   const int row0 = (rb * kSLWaves + wave) * rpw;   // this wave's first row
@@ -112,9 +125,9 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedPar
   // ---- this wave's stream: the blocks of its rows are contiguous in `elems`
   int my_blocks = 0, total = 0, first_block = 0;
   if (n_rows > 0) {
-    const int32_t* const bp = as_global(P.blocks) + (size_t)s * N + row0;
+    const int32_t* const bp = as_global(blocks_t) + (size_t)s * N + row0;
     my_blocks = lane < n_rows ? bp[lane] : 0;           // lane i: blocks of row row0 + i
-    first_block = __builtin_amdgcn_readfirstlane(as_global(P.first)[(size_t)s * N + row0]);
+    first_block = __builtin_amdgcn_readfirstlane(as_global(first_t)[(size_t)s * N + row0]);
     int t = my_blocks;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
@@ -125,7 +138,7 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedPar
   // every load below, so the counted wait before the barrier covers it)
   {
     constexpr uint32_t kPerWave = kSLTabBytes / kSLWaves;
-    const uint64_t va = (uint64_t)(uintptr_t)as_global(P.cent) + (uint64_t)s * kSLTabBytes + (uint64_t)wave * kPerWave +
+    const uint64_t va = (uint64_t)(uintptr_t)as_global(cent_t) + (uint64_t)s * kSLTabBytes + (uint64_t)wave * kPerWave +
                         (uint64_t)lane * 16u;
 #pragma unroll
     for (int i = 0; i < ((VPTQ_SLICED_ABLATE & 2) ? 0 : (int)(kPerWave / 1024u)); ++i) {
@@ -159,7 +172,7 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedPar
       if (q < chunks && !(VPTQ_SLICED_ABLATE & 4)) {
         // x in input-FEATURE order (sum b x needs nothing else: a permutation only reorders the sum)
         const u32x4 xv = *(const u32x4*)(as_global(P.x) + 8 * q);
-        if (s == 0 && P.wbias != nullptr) {
+        if (sg == 0 && P.wbias != nullptr) {
           const u32x4 bv = *(const u32x4*)(as_global(P.wbias) + 8 * q);
 #pragma unroll
           for (int i = 0; i < 4; ++i) bd = DT::dot2(xv[i], bv[i], bd);
@@ -181,7 +194,7 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedPar
       }
       *(lds_q_t*)(uintptr_t)(kSLXOff + (uint32_t)q * 16u) = v;
     }
-    if (s == 0) {
+    if (sg == 0) {
       bd = wave_sum(bd);
       if (lane == 0) *(float*)(smem + bd_off + (uint32_t)wave * 4u) = bd;
     }
@@ -190,7 +203,7 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedPar
   // ---- element queue: block k of the stream -> slot k % kSLQueue
   evec_t eq[kSLQueue];
   uint32_t rq[RES ? kSLQueue : 1];
-  const evec_t* const ep = (const evec_t*)(as_global(P.elems) + (size_t)first_block * (64 * EPL)) + lane;
+  const evec_t* const ep = (const evec_t*)(as_global(elems_t) + (size_t)first_block * (64 * EPL)) + lane;
   const uint8_t* const rp = RES ? as_global(P.res) + (size_t)first_block * 64 + lane : nullptr;
   const int last = total > 0 ? total - 1 : 0;
   int i_next = 0;
@@ -213,7 +226,7 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedPar
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
   float bdot = 0.f;
-  if (s == 0) {   // (fixed order: the 16 waves' parts)
+  if (sg == 0) {   // (fixed order: the 16 waves' parts)
     const float* const bp = (const float*)(smem + bd_off);
 #pragma unroll
     for (int i = 0; i < kSLWaves; ++i) bdot += bp[i];
@@ -244,7 +257,7 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedPar
     if ((lane & 15) == 0) {
       const int o8 = ((lane >> 5) & 1) * (V / 2) + ((lane >> 4) & 1) * (V / 4);
       // write-through at device scope (sc1): the workgroup that sums the slices may sit on another XCD
-      float* const pp = as_global(P.partial) + ((size_t)s * N + (size_t)(row0 + row_i)) * V + o8;
+      float* const pp = as_global(P.partial) + ((size_t)sg * N + (size_t)(row0 + row_i)) * V + o8;
 #pragma unroll
       for (int i = 0; i < V / 4; ++i) __hip_atomic_store(pp + i, v[i] + bdot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -348,7 +361,7 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedPar
 
   // ---- the slices of a row block meet: the workgroup that stores its partial sums LAST adds them up.  Nobody
   // waits for anybody: every workgroup drains its write-through stores, counts itself in (device-scope atomic)
-  // and leaves unless it was the last of the row block's NSL; that one reads the NSL partial sums per output
+  // and leaves unless it was the last of the row block's NSLT; that one reads the NSLT partial sums per output
   // with device-coherent loads, adds them in a fixed tree (so the result does not depend on who was last), adds
   // the output bias and stores y.  A second launch for this step cost 4.3 us of the 14.2 (its reads were the
   // first touch of what other XCDs had just written, behind a kernel boundary).
@@ -358,7 +371,7 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedPar
   __builtin_amdgcn_s_barrier();
   if (tid == 0) {
     const uint32_t before = __hip_atomic_fetch_add(as_global(P.arrived) + rb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint32_t lastone = before == (uint32_t)NSL - 1u ? 1u : 0u;
+    const uint32_t lastone = before == (uint32_t)NSLT - 1u ? 1u : 0u;
     if (lastone) __hip_atomic_store(as_global(P.arrived) + rb, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
     *flag = lastone;
   }
@@ -372,12 +385,12 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedPar
     const int n_out = (N - r_first < rows_wg ? N - r_first : rows_wg) * V;   // outputs of this row block
     for (int k = tid; k < n_out; k += kSLThreads) {
       const size_t o = (size_t)r_first * V + k;
-      float p[NSL];
+      float p[NSLT];
 #pragma unroll
-      for (int sl = 0; sl < NSL; ++sl)
+      for (int sl = 0; sl < NSLT; ++sl)
         p[sl] = __hip_atomic_load(as_global(P.partial) + (size_t)sl * N * V + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-      for (int w = NSL / 2; w > 0; w >>= 1)   // (a fixed tree)
+      for (int w = NSLT / 2; w > 0; w >>= 1)   // (a fixed tree)
 #pragma unroll
         for (int i = 0; i < w; ++i) p[i] = p[2 * i] + p[2 * i + 1];
       float v = p[0];
@@ -419,24 +432,20 @@ int gemv_sliced_slices(const VptqLayerDesc& d) {
   return d.group_size <= (d.num_res_centroids == 256 ? kSLMaxG8Res : kSLMaxG8) ? small : 2 * small;
 }
 
-// partial sums [slices][N x v] floats + one arrival counter per block of 16 rows (the smallest row block), which must be
-// ZERO before the first launch; every launch leaves them zero (the two passes of the two-table formats share them: the
-// second launch starts when the first has finished)
+// partial sums [table x slices][N x v] floats + one arrival counter per block of 16 rows (the smallest row block), which
+// must be ZERO before the first launch; every launch leaves them zero
 static size_t sl_partial_bytes(const VptqLayerDesc& d) {
-  return ((size_t)gemv_sliced_slices(d) * d.num_indices * d.vector_len * sizeof(float) + 255) / 256 * 256;
+  const size_t parts = (size_t)gemv_sliced_slices(d) * (d.num_res_centroids == 65536 ? 2 : 1);
+  return (parts * d.num_indices * d.vector_len * sizeof(float) + 255) / 256 * 256;
 }
 static size_t sl_counter_bytes(const VptqLayerDesc& d) {
   return (((size_t)(d.num_indices + kSLWaves - 1) / kSLWaves) * sizeof(uint32_t) + 255) / 256 * 256;
 }
-// + (two-table formats) the first pass's fp32 outputs
-size_t gemv_sliced_workspace_bytes(const VptqLayerDesc& d) {
-  return sl_partial_bytes(d) + sl_counter_bytes(d) +
-         (d.num_res_centroids == 65536 ? (size_t)d.num_indices * d.vector_len * sizeof(float) : 0);
-}
+size_t gemv_sliced_workspace_bytes(const VptqLayerDesc& d) { return sl_partial_bytes(d) + sl_counter_bytes(d); }
 
-template <typename DT, int NSL, bool RES, int V>
+template <typename DT, int NSL, bool RES, int V, bool TWO>
 static hipError_t launch_sl(const SlicedParams& P, uint32_t lds, hipStream_t st) {
-  auto kern = gemv_sliced_kernel<DT, NSL, RES, V>;
+  auto kern = gemv_sliced_kernel<DT, NSL, RES, V, TWO>;
   static std::atomic<bool> attr_set[64];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
@@ -445,62 +454,68 @@ static hipError_t launch_sl(const SlicedParams& P, uint32_t lds, hipStream_t st)
     if (e != hipSuccess) return e;
     attr_set[dev] = true;
   }
-  hipLaunchKernelGGL(kern, dim3(NSL * P.n_rowblocks), dim3(kSLThreads), lds, st, P);
+  hipLaunchKernelGGL(kern, dim3((TWO ? 2 : 1) * NSL * P.n_rowblocks), dim3(kSLThreads), lds, st, P);
   return hipGetLastError();
 }
 template <typename DT>
-static hipError_t launch_sl_dt(const SlicedParams& P, int v, int nsl, bool res, uint32_t lds, hipStream_t st) {
-  if (v == 16) return nsl == 16 ? launch_sl<DT, 16, false, 16>(P, lds, st) : launch_sl<DT, 32, false, 16>(P, lds, st);
-  if (nsl == 8) return res ? launch_sl<DT, 8, true, 8>(P, lds, st) : launch_sl<DT, 8, false, 8>(P, lds, st);
-  return res ? launch_sl<DT, 16, true, 8>(P, lds, st) : launch_sl<DT, 16, false, 8>(P, lds, st);
+static hipError_t launch_sl_dt(const SlicedParams& P, int v, int nsl, bool res, bool two, uint32_t lds, hipStream_t st) {
+  if (v == 16) {
+    if (two) return nsl == 16 ? launch_sl<DT, 16, false, 16, true>(P, lds, st) : launch_sl<DT, 32, false, 16, true>(P, lds, st);
+    return nsl == 16 ? launch_sl<DT, 16, false, 16, false>(P, lds, st) : launch_sl<DT, 32, false, 16, false>(P, lds, st);
+  }
+  if (two) return nsl == 8 ? launch_sl<DT, 8, false, 8, true>(P, lds, st) : launch_sl<DT, 16, false, 8, true>(P, lds, st);
+  if (nsl == 8) return res ? launch_sl<DT, 8, true, 8, false>(P, lds, st) : launch_sl<DT, 8, false, 8, false>(P, lds, st);
+  return res ? launch_sl<DT, 16, true, 8, false>(P, lds, st) : launch_sl<DT, 16, false, 8, false>(P, lds, st);
 }
 
-// one pass over one layout: cent = the table its elements index
-static hipError_t sl_pass(const VptqLayerDesc& d, const VptqSlicedLayout& L, const void* cent, bool res, const void* x, void* y,
-                          bool out_f32, bool with_wbias, const void* bias, const float* addend, void* ws, hipStream_t st) {
+static bool sl_layout_ok(const VptqSlicedLayout& L, int nsl, bool res) {
+  return (L.n_slices != 0 ? L.n_slices : 8) == nsl && (L.elems_per_lane == 0 || L.elems_per_lane == 1) && (!res || L.res) &&
+         L.rows_per_wave >= 1 && L.rows_per_wave <= kSLMaxRowsPerWave && L.elems && L.blocks && L.first &&
+         (((uintptr_t)L.elems) & 3) == 0;
+}
+
+// L: one layout (residual none / 256) or TWO consecutive ones (65536 residual centroids: [0] bucketed by the main index,
+// [1] by the residual index).  (c + r) f16(s x) = c f16(s x) + r f16(s x): the residual table's (slice, row block)
+// workgroups run beside the main table's in the SAME launch and meet them in the cross-slice sum - two launches, one per
+// table, cost a second boundary, a second epilogue and half the workgroups in flight (8192^2: 27.2 us; 4096^2: 17.8)
+hipError_t launch_gemv_sliced(const VptqLayerDesc& d, const VptqSlicedLayout* L, const void* x, void* y, int flags,
+                              void* ws, hipStream_t st) {
+  const bool res = d.num_res_centroids == 256, two = d.num_res_centroids == 65536;
   const int nsl = gemv_sliced_slices(d);
-  if ((L.n_slices != 0 ? L.n_slices : 8) != nsl || (L.elems_per_lane != 0 && L.elems_per_lane != 1) || (res && !L.res) ||
-      L.rows_per_wave < 1 || L.rows_per_wave > kSLMaxRowsPerWave || !L.elems || !L.blocks || !L.first || !ws ||
-      (((uintptr_t)x) & 15) != 0 || (((uintptr_t)L.elems) & 3) != 0)
+  if (!sl_layout_ok(L[0], nsl, res) || (two && (!sl_layout_ok(L[1], nsl, false) || L[1].rows_per_wave != L[0].rows_per_wave)) ||
+      !ws || (((uintptr_t)x) & 15) != 0)
     return hipErrorInvalidValue;
   SlicedParams P = {};
-  P.elems = (const uint32_t*)L.elems;
-  P.res = res ? (const uint8_t*)L.res : nullptr;
+  P.elems = (const uint32_t*)L[0].elems;
+  P.res = res ? (const uint8_t*)L[0].res : nullptr;
   P.rcent = res ? (const uint32_t*)d.res_centroids : nullptr;
-  P.blocks = (const int32_t*)L.blocks;
-  P.first = (const int32_t*)L.first;
-  P.cent = (const uint32_t*)cent;
+  P.blocks = (const int32_t*)L[0].blocks;
+  P.first = (const int32_t*)L[0].first;
+  P.cent = (const uint32_t*)d.centroids;
+  if (two) {
+    P.elems2 = (const uint32_t*)L[1].elems;
+    P.blocks2 = (const int32_t*)L[1].blocks;
+    P.first2 = (const int32_t*)L[1].first;
+    P.cent2 = (const uint32_t*)d.res_centroids;
+  }
   P.x = (const uint16_t*)x;
   P.scale = (const uint16_t*)(d.perm ? d.scale_permuted : d.weight_scale);
-  P.wbias = with_wbias ? (const uint16_t*)d.weight_bias : nullptr;
+  P.wbias = (const uint16_t*)d.weight_bias;
   P.perm = (const uint16_t*)d.perm;
-  P.bias = (const uint16_t*)bias;
-  P.addend = addend;
+  P.bias = (const uint16_t*)d.bias;
+  P.addend = nullptr;
   P.partial = (float*)ws;
   P.arrived = (uint32_t*)((char*)ws + sl_partial_bytes(d));
   P.y = y;
   P.N = d.num_indices; P.G = d.group_size; P.O = d.out_features;
-  P.rows_per_wave = L.rows_per_wave;
-  const int rows_per_wg = kSLWaves * L.rows_per_wave;
+  P.rows_per_wave = L[0].rows_per_wave;
+  const int rows_per_wg = kSLWaves * L[0].rows_per_wave;
   P.n_rowblocks = (d.num_indices + rows_per_wg - 1) / rows_per_wg;
-  P.out_f32 = out_f32 ? 1 : 0;
+  P.out_f32 = (flags & VPTQ_GEMV_OUT_F32) ? 1 : 0;
   const uint32_t lds = (65536u / (uint32_t)nsl) * (uint32_t)d.vector_len * 2u + (uint32_t)(d.group_size + 64) * 2u + 64u + (res ? 4096u : 0u);
   if (lds > kSLLdsLimit) return hipErrorInvalidValue;
-  return d.dtype == VPTQ_DTYPE_F16 ? launch_sl_dt<F16>(P, d.vector_len, nsl, res, lds, st)
-                                   : launch_sl_dt<BF16>(P, d.vector_len, nsl, res, lds, st);
-}
-
-// L: one layout (residual none / 256) or TWO consecutive ones (k65536 + 65536: [0] by main index, [1] by residual index)
-hipError_t launch_gemv_sliced(const VptqLayerDesc& d, const VptqSlicedLayout* L, const void* x, void* y, int flags,
-                              void* ws, hipStream_t st) {
-  const bool out_f32 = (flags & VPTQ_GEMV_OUT_F32) != 0;
-  if (d.num_res_centroids != 65536)
-    return sl_pass(d, L[0], d.centroids, d.num_res_centroids == 256, x, y, out_f32, true, d.bias, nullptr, ws, st);
-  // y = sum c[idx] f16(s x) + sum b x   (pass 1, fp32 into the workspace)   + sum r[ridx] f16(s x) + bias   (pass 2)
-  float* const first = (float*)((char*)ws + sl_partial_bytes(d) + sl_counter_bytes(d));
-  const hipError_t e = sl_pass(d, L[0], d.centroids, false, x, first, true, true, nullptr, nullptr, ws, st);
-  if (e != hipSuccess) return e;
-  return sl_pass(d, L[1], d.res_centroids, false, x, y, out_f32, false, d.bias, first, ws, st);
+  return d.dtype == VPTQ_DTYPE_F16 ? launch_sl_dt<F16>(P, d.vector_len, nsl, res, two, lds, st)
+                                   : launch_sl_dt<BF16>(P, d.vector_len, nsl, res, two, lds, st);
 }
 
 }  // namespace vptq

@@ -399,7 +399,7 @@ class VQuantLinear(nn.Module):
             if torch.cuda.is_current_stream_capturing():
                 return None   # (no layout is built inside a capture - and the "no" is not remembered: a later call builds it)
             obj = None
-            if not cache[9] and B.lib().vptq_sliced_layout_supported(cache[1]) and self._sliced_pays(on) and self._sliced_fits(cache, on):
+            if not cache[9] and B.lib().vptq_sliced_layout_supported(cache[1]) and self._sliced_fits(cache, on):
                 from vptq_amd.utils.sliced import SlicedGemv
                 try:
                     obj = SlicedGemv(self)
@@ -411,16 +411,6 @@ class VQuantLinear(nn.Module):
             st = (stamp, obj)
             self.__dict__["_sliced"] = st
         return st[1]
-
-    def _sliced_pays(self, on) -> bool:
-        """auto mode: a layer with 65536 residual centroids is TWO passes (launches) over the derived layouts; below 2^21
-        elements per pass that is no faster than the one launch of the gather kernel (v16-k65536-65536 at 4096 x 4096:
-        20.5 against 19.1 us; v8 at 4096 x 4096: 17.8 against 21.8 - profiles/r04/sliced_*_r65536.json)"""
-        if on is True and "_sliced_on" in self.__dict__ or _SLICED_LAYOUT_MODE in ("1", "on", "true", "yes", "always"):
-            return True
-        if self.enable_residual and self.num_res_centroids == 65536:
-            return self.indices.shape[1] * self.group_size >= (1 << 21)
-        return True
 
     def _sliced_fits(self, cache, on) -> bool:
         """auto mode: build only while the layout (5 / 4 bytes per element + the builder's temporaries) leaves

@@ -119,7 +119,8 @@ class SlicedGemv:
         else:
             self._tensors = [build_sliced_layout(layer.indices.data, layer.group_size, self.slices, kr == 256)]
         self.elems, self.blocks, self.first, self.res = self._tensors[0]
-        rpw = rows_per_wave or rows_per_wave_for(self.blocks.shape[1], self.slices)
+        # (a two-table layer runs 2 x slices workgroups per row block in its one launch)
+        rpw = rows_per_wave or rows_per_wave_for(self.blocks.shape[1], self.slices * len(self._tensors))
         self.layout = (B.SlicedLayout * len(self._tensors))(*[
             B.SlicedLayout(e.data_ptr(), b.data_ptr(), f.data_ptr(), r.data_ptr() if r is not None else None, rpw, 1, self.slices, 0)
             for e, b, f, r in self._tensors])
