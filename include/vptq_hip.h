@@ -293,12 +293,16 @@ typedef struct VptqSlicedLayout {
   int32_t rows_per_wave;
   int32_t elems_per_lane;   /* 1 (or 0): a block = 64 elements */
   int32_t n_slices;         /* 8 (or 0) / 16 / 32: what vptq_sliced_layout_supported() answers for the layer */
-  int32_t reserved;
+  int32_t whole_table;      /* 0: element words carry the index INSIDE the slice (the workgroup holds its slice of the table);
+                             * 1: the full index (every workgroup of this table holds all of it: small residual tables) */
 } VptqSlicedLayout;
 /* 0 = not a layer of this path; else the number of slices its layout(s) must have: v = 8: 8 slices of 8192 entries while
  * the activations fit in LDS beside them (group_size <= 14336, 14080 with the 256-entry residual codebook), else 16 of
  * 4096; v = 16 (32-byte entries): 16 slices of 4096 entries, beyond 14336 columns 32 of 2048 */
 VPTQ_API int vptq_sliced_layout_supported(const VptqLayerDesc* desc);
+/* 0, or how many consecutive VptqSlicedLayout structs vptq_quant_gemv_sliced takes for this layer: 1 (no residual codebook;
+ * v = 8 with 256 residual centroids: `res` bytes), 2 (any other residual codebook: a second table with a layout of its own) */
+VPTQ_API int vptq_sliced_layout_tables(const VptqLayerDesc* desc);
 VPTQ_API size_t vptq_quant_gemv_sliced_workspace_bytes(const VptqLayerDesc* desc);
 VPTQ_API int vptq_quant_gemv_sliced(const VptqLayerDesc* desc, const VptqSlicedLayout* layout, const void* x,
                            void* y, int flags, void* workspace, size_t workspace_bytes, void* stream);

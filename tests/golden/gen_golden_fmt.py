@@ -48,6 +48,10 @@ FMT_CASES = [
     # vector length 16: v16-k65536-65536 ("2 bits" of most model families) and v16-k65536-0
     ("t1_v16_k65536_r65536_4096x4096", 4096, 4096, 16, 65536, 65536, False, True, "f16", 1, "llm"),
     ("t1_v16_k65536_r0_bf16_perm", 2048, 2048 + 16, 16, 65536, 0, True, False, "bf16", 1, "llm"),
+    # other published members of the family: small / mid residual tables as a second table, fewer main centroids
+    ("t1_v16_k65536_r1024_4096x4096", 4096, 4096, 16, 65536, 1024, False, False, "f16", 1, "llm"),
+    ("t1_v8_k65536_r4_bias", 2048, 2048, 8, 65536, 4, False, True, "f16", 1, "llm"),
+    ("t1_v8_k32768_r0_perm", 2048, 4096, 8, 32768, 0, True, False, "f16", 1, "llm"),
 ]
 
 

@@ -286,3 +286,49 @@ def test_sliced_layout_vector_length_16_on_reference_goldens(name, dev):
     xt = bits_to_tensor(x, dt, dev).reshape(x.shape)
     got = tensor_to_bits(SlicedGemv(m)(xt))
     assert rel_err(got, y, dt) <= TOL[dt], name
+
+
+# (vector length, main centroids, residual centroids): the other members of the family among the published checkpoints -
+# a residual codebook of any size is a second table in the same launch (small ones held whole by their workgroups), main
+# codebooks of 16384 / 32768 entries give smaller slices
+FAMILY = [(8, 65536, 4), (8, 65536, 1024), (8, 65536, 4096), (8, 32768, 0), (8, 16384, 0), (16, 65536, 64), (16, 65536, 256),
+          (16, 65536, 1024), (16, 65536, 16384), (16, 32768, 32768)]
+FAMILY_SHAPES = [(2048, 528, dict(dist="llm", enable_perm=True, bias=True)), (4104, 272, dict(dist="llm")), (72, 1040, dict()),
+                 (8192, 512, dict(dist="llm", bias=True))]
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("v,k,kr", FAMILY)
+@pytest.mark.parametrize("I,O,kw", FAMILY_SHAPES)
+def test_sliced_layout_family(I, O, kw, v, k, kr, dt, dev):
+    from vptq_amd.utils.sliced import SlicedGemv
+    from vptq_amd import _backend as B
+    kw = dict(kw)
+    dist = kw.pop("dist", "ref-test")
+    L = vo.make_layer(I, O, dist=dist, seed=I + O + v + kr, dtype=dt, vector_len=v, num_centroids=k, num_res_centroids=kr, **kw)
+    x = _x(I, dt, dist, I + 2)
+    m = spec_to_module(L, dev)
+    sl = SlicedGemv(m)
+    assert len(sl.layout) == (2 if kr else 1)
+    xt = bits_to_tensor(x, dt, dev).reshape(x.shape)
+    got = sl(xt)
+    torch.cuda.synchronize()
+    want = vo.forward(L, x)
+    err = rel_err(tensor_to_bits(got), want, dt)
+    assert err <= TOL[dt], f"v{v}-k{k}-{kr} {I}x{O} {dt}: {err:.3e}"
+    m.enable_sliced_layout(False)
+    assert rel_err(tensor_to_bits(got), tensor_to_bits(m(xt)), dt) <= TOL[dt]     # the gather kernels
+    y32 = sl(xt, flags=B.GEMV_OUT_F32)
+    assert torch.equal(y32.to(got.dtype).view(torch.int16), got.view(torch.int16))
+    assert torch.equal(sl(xt).view(torch.int16), got.view(torch.int16))
+
+
+@pytest.mark.parametrize("name", ["t1_v16_k65536_r1024_4096x4096", "t1_v8_k65536_r4_bias", "t1_v8_k32768_r0_perm"])
+def test_sliced_layout_family_on_reference_goldens(name, dev):
+    from vptq_amd.utils.sliced import SlicedGemv
+    L, x, y, cfg, _ = load_fmt(name)
+    dt = cfg["dtype"]
+    m = spec_to_module(L, dev)
+    xt = bits_to_tensor(x, dt, dev).reshape(x.shape)
+    assert rel_err(tensor_to_bits(SlicedGemv(m)(xt)), y, dt) <= TOL[dt], name
+    assert rel_err(tensor_to_bits(m(xt)), y, dt) <= TOL[dt], name      # the module's own one-token route (auto: sliced)

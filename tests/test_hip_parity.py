@@ -805,7 +805,9 @@ FMT_KERNELS = {"t1_k8192_r256_8192x1024": "gemv_lds_mfma_kernel", "t1_k4096_r512
                "t1_k65536_r256_4096x4096": "gemv_gather_kernel", "t1_k65536_r256_bf16": "gemv_gather_kernel",
                # round 4: the two-table ("4 bit") format and vector length 16 (sliced: two passes / 32-byte entries)
                "t1_k65536_r65536_4096x4096": "gemv_gather_kernel", "t1_k65536_r65536_bf16_perm": "gemv_gather_kernel",
-               "t1_v16_k65536_r65536_4096x4096": "gemv_gatherx_kernel", "t1_v16_k65536_r0_bf16_perm": "gemv_gatherx_kernel"}
+               "t1_v16_k65536_r65536_4096x4096": "gemv_gatherx_kernel", "t1_v16_k65536_r0_bf16_perm": "gemv_gatherx_kernel",
+               "t1_v16_k65536_r1024_4096x4096": "gemv_gatherx_kernel", "t1_v8_k65536_r4_bias": "gemv_gatherx_kernel",
+               "t1_v8_k32768_r0_perm": "gemv_gatherx_kernel"}
 
 
 @pytest.mark.parametrize("name", fmt_names())

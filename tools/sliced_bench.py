@@ -16,6 +16,7 @@ ap.add_argument("--shapes", default="8192,8192;4096,4096")
 ap.add_argument("--ring", type=int, default=8)
 ap.add_argument("--rpw", type=int, default=0)
 ap.add_argument("--kr", type=int, default=0, help="residual centroids: 0 (v8-k65536-0) or 256 (v8-k65536-256)")
+ap.add_argument("--k", type=int, default=65536, help="main centroids: 16384 / 32768 / 65536")
 ap.add_argument("--v", type=int, default=8, help="vector length: 8 or 16 (v16-k65536-0 / -65536)")
 ap.add_argument("--bf16", action="store_true")
 ap.add_argument("--out", default="")
@@ -25,7 +26,7 @@ dt = torch.bfloat16 if a.bf16 else torch.float16
 res = []
 for I, O in [tuple(int(v) for v in p.split(',')) for p in a.shapes.split(';')]:
     R = a.ring
-    layers = [mk(I, O, dev, g, k=65536, kr=a.kr, v=a.v) for _ in range(R)]
+    layers = [mk(I, O, dev, g, k=a.k, kr=a.kr, v=a.v) for _ in range(R)]
     if a.bf16:
         layers = [m.to(torch.bfloat16) for m in layers]
     descs = [module_desc(m) for m in layers]
@@ -47,7 +48,7 @@ for I, O in [tuple(int(v) for v in p.split(',')) for p in a.shapes.split(';')]:
     us_d = time_graph(run_default, 10) / R
     us_s = time_graph(run_sliced, 10) / R
     idx_bytes = layers[0].indices.numel() * 4
-    r = dict(I=I, O=O, kr=a.kr, dtype="bf16" if a.bf16 else "f16", default_us=us_d, default_kernel=lib.vptq_quant_gemv_kernel_name(descs[0][0], 1, 0).decode(),
+    r = dict(I=I, O=O, v=a.v, k=a.k, kr=a.kr, dtype="bf16" if a.bf16 else "f16", default_us=us_d, default_kernel=lib.vptq_quant_gemv_kernel_name(descs[0][0], 1, 0).decode(),
              sliced_us=us_s, speedup=us_d / us_s, rel_diff=err, packed_index_MiB=idx_bytes / 2**20,
              layout_MiB=sls[0].extra_bytes / 2**20, rows_per_wave=sls[0].layout[0].rows_per_wave, slices=sls[0].slices,
              sliced_GBps_of_packed_bytes=idx_bytes / us_s / 1e3, sliced_GBps_of_layout_bytes=sls[0].extra_bytes / us_s / 1e3)

@@ -397,6 +397,10 @@ int vptq_sliced_layout_supported(const VptqLayerDesc* d) {
   return validate_layer(d) == VPTQ_OK && vptq::gemv_sliced_eligible(*d) ? vptq::gemv_sliced_slices(*d) : 0;
 }
 
+int vptq_sliced_layout_tables(const VptqLayerDesc* d) {
+  return validate_layer(d) == VPTQ_OK && vptq::gemv_sliced_eligible(*d) ? vptq::gemv_sliced_tables(*d) : 0;
+}
+
 size_t vptq_quant_gemv_sliced_workspace_bytes(const VptqLayerDesc* d) {
   return validate_layer(d) == VPTQ_OK && vptq::gemv_sliced_eligible(*d) ? vptq::gemv_sliced_workspace_bytes(*d) : 0;
 }
@@ -407,13 +411,13 @@ int vptq_quant_gemv_sliced(const VptqLayerDesc* d, const VptqSlicedLayout* layou
   if (rc) return rc;
   if (!x || !y || !layout) return fail(VPTQ_E_NULL, "x / y / layout is NULL");
   if (!vptq::gemv_sliced_eligible(*d))
-    return fail(VPTQ_E_UNSUPPORTED, "the sliced layout serves v8-k65536-0 / -256 / -65536 layers, group_size <= 32768");
+    return fail(VPTQ_E_UNSUPPORTED, "the sliced layout serves v = 8 / 16 layers with 16384 ... 65536 main centroids, group_size <= 32768");
   if (flags & (VPTQ_GEMV_EXACT | VPTQ_GEMV_FORCE_GENERIC))
     return fail(VPTQ_E_UNSUPPORTED, "the sliced path has the folded arithmetic only: use vptq_quant_gemv");
   const size_t need = vptq::gemv_sliced_workspace_bytes(*d);
   if (!workspace || workspace_bytes < need || (((uintptr_t)workspace) & 15) != 0)
     return fail(VPTQ_E_WORKSPACE, "workspace of %zu bytes (16-byte aligned) needed", need);
-  const int n_layouts = d->num_res_centroids == 65536 ? 2 : 1;   // (two tables: one layout per table, consecutive structs)
+  const int n_layouts = vptq::gemv_sliced_tables(*d);   // (two tables: one layout per table, consecutive structs)
   for (int i = 0; i < n_layouts; ++i)
     if (layout[i].rows_per_wave < 1 || layout[i].rows_per_wave > 64 || !layout[i].elems || !layout[i].blocks || !layout[i].first ||
         (layout[i].n_slices != 0 ? layout[i].n_slices : 8) != vptq::gemv_sliced_slices(*d))

@@ -74,6 +74,10 @@ struct SlicedParams {
   const int32_t* blocks2;
   const int32_t* first2;
   const uint32_t* cent2;
+  // what a workgroup of table t copies into LDS: tab_t bytes from cent + slice x stride_t (stride = tab: its slice of
+  // the table, element words carry the index inside the slice; stride = 0: the WHOLE table - small residual tables -,
+  // element words carry the full index); the staged activations start at x_off >= max(tab)
+  uint32_t tab0, tab1, stride0, stride1, x_off;
   float* partial;           // [slices][N * 8]
   uint32_t* arrived;        // [row blocks] workgroups of the row block that have stored their partial sums (0 between launches)
   void* y;
@@ -98,8 +102,7 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedPar
   constexpr int NSLT = TWO ? 2 * NSL : NSL;   // workgroups per row block: one per (table, slice)
   constexpr int EPL = 1;   // element words per lane and block (2 and 4 - 8 / 16-byte loads - were measured: no difference)
   constexpr uint32_t kEntry = V * 2u;                          // bytes of a codebook entry
-  constexpr uint32_t kSLTabBytes = (65536u / NSL) * kEntry;   // this workgroup's slice of the codebook
-  constexpr uint32_t kSLXOff = kSLTabBytes;                // staged activations: (G + 64) halves
+  const uint32_t kSLXOff = P.x_off;                          // staged activations: (G + 64) halves, behind the table
   typedef uint32_t evec_t __attribute__((ext_vector_type(EPL)));
   constexpr int kLoadsPerStep = RES ? 2 : 1;
   constexpr int kSLQueue = kSLQueueWords / EPL < 2 ? 2 : kSLQueueWords / EPL;   // blocks in flight per wave
@@ -134,19 +137,19 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedPar
     total = __builtin_amdgcn_readfirstlane(t);
   }
 
-  // ---- codebook slice into LDS by LDS-DMA: 1 KiB per instruction, 8 (4) per wave (no registers; older than
-  // every load below, so the counted wait before the barrier covers it)
+  // ---- this workgroup's part of its table into LDS by LDS-DMA: 1 KiB per instruction and wave (no registers; older
+  // than every load below, so the counted wait before the barrier covers it); the last piece of a small table is partial
   {
-    constexpr uint32_t kPerWave = kSLTabBytes / kSLWaves;
-    const uint64_t va = (uint64_t)(uintptr_t)as_global(cent_t) + (uint64_t)s * kSLTabBytes + (uint64_t)wave * kPerWave +
-                        (uint64_t)lane * 16u;
-#pragma unroll
-    for (int i = 0; i < ((VPTQ_SLICED_ABLATE & 2) ? 0 : (int)(kPerWave / 1024u)); ++i) {
-      const uint32_t d = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)wave * kPerWave + (uint32_t)i * 1024u));
-      const uint64_t v = va + (uint64_t)(i * 1024);
-      uint32_t keep_m0;   // (M0 belongs to the compiler: saved and restored inside the statement)
-      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                   : "=&s"(keep_m0) : "v"(v), "s"(d) : "memory");
+    const uint32_t tab = second ? P.tab1 : P.tab0;   // (scalar fields: a run-time index into the by-value argument makes the compiler copy it to scratch)
+    const uint64_t va = (uint64_t)(uintptr_t)as_global(cent_t) + (uint64_t)s * (second ? P.stride1 : P.stride0) + (uint64_t)lane * 16u;
+    for (uint32_t off = (uint32_t)wave * 1024u; off < ((VPTQ_SLICED_ABLATE & 2) ? 0u : tab); off += kSLWaves * 1024u) {
+      const uint32_t d = (uint32_t)__builtin_amdgcn_readfirstlane((int)off);
+      if (off + (uint32_t)lane * 16u < tab) {
+        const uint64_t v = va + (uint64_t)off;
+        uint32_t keep_m0;   // (M0 belongs to the compiler: saved and restored inside the statement)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep_m0) : "v"(v), "s"(d) : "memory");
+      }
     }
   }
   // residual codebook (256 entries = 4 KiB) behind the activations: waves 0-3 bring 1 KiB each
@@ -405,37 +408,45 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedPar
 }
 
 // ---- host side -------------------------------------------------------------------
-// v8-k65536-0 (T = 16), v8-k65536-256 (T = 24: the format of most published checkpoints), v8-k65536-65536 (T = 32, two passes),
-// v16-k65536-0 and v16-k65536-65536 (vector length 16)
+// Large-codebook layers: v = 8 or 16, 16384 ... 65536 main centroids, one codebook group, no outlier columns, norm on.
+// Residual codebook: none; v = 8 with 256 entries (one launch, the table beside the slice, a byte per element); any other
+// size (2 ... 65536 entries) as a SECOND TABLE with a layout of its own in the same launch.
+static bool sl_pow2(int k) { return k > 0 && (k & (k - 1)) == 0; }
+static bool sl_res256(const VptqLayerDesc& d) { return d.vector_len == 8 && d.num_res_centroids == 256; }
+static bool sl_two(const VptqLayerDesc& d) { return d.num_res_centroids > 0 && !sl_res256(d); }
+int gemv_sliced_tables(const VptqLayerDesc& d) { return sl_two(d) ? 2 : 1; }
 bool gemv_sliced_eligible(const VptqLayerDesc& d) {
-  const bool res = d.num_res_centroids == 256;
-  const bool two = d.num_res_centroids == 65536;   // T = 32: two passes, one per table
-  const bool v16 = d.vector_len == 16;
-  return (d.vector_len == 8 || v16) && d.num_codebooks == 1 && d.outlier_size == 0 && d.num_centroids == 65536 &&
-         (d.num_res_centroids == 0 || (res && !v16) || two) && d.index_bits == 16 && (!res || d.res_bits == 8) && (!two || d.res_bits == 16) &&
+  const int T = d.index_bits + d.res_bits;
+  return (d.vector_len == 8 || d.vector_len == 16) && d.num_codebooks == 1 && d.outlier_size == 0 &&
+         d.num_centroids >= 16384 && d.num_centroids <= 65536 && sl_pow2(d.num_centroids) && (1 << d.index_bits) == d.num_centroids &&
+         (d.num_res_centroids == 0 || (d.num_res_centroids >= 2 && d.num_res_centroids <= 65536 && sl_pow2(d.num_res_centroids) &&
+                                       (1 << d.res_bits) == d.num_res_centroids)) &&
          d.weight_scale != nullptr && d.weight_bias != nullptr &&
          (d.perm == nullptr || d.scale_permuted != nullptr) && (d.group_size % 8) == 0 && d.group_size == d.in_features &&
-         d.group_size <= kSLMaxG16 &&
-         (long long)d.row_words * 32 == (long long)d.group_size * (two ? 32 : res ? 24 : 16) &&
+         d.group_size <= kSLMaxG16 && T <= 32 && (long long)d.row_words * 32 >= (long long)d.group_size * T &&
          (((uintptr_t)d.centroids | (uintptr_t)d.res_centroids | (uintptr_t)d.weight_scale | (uintptr_t)d.weight_bias |
            (uintptr_t)d.perm | (uintptr_t)d.scale_permuted) & 15) == 0;
 }
 
-// slices a layout of this layer must have: the slice (65536 / slices entries of 2 v bytes) + f16(s x) of every column
-// (+ the 4 KiB residual table) must fit the 160 KiB of LDS: v = 8: 8 slices of 8192 entries up to 14336 columns (14080 with
-// the residual table), else 16; v = 16: 16 slices of 4096 entries up to 14336 columns, else 32
+// slices a layout of this layer must have: the slice (table entries / slices, 2 v bytes each) + f16(s x) of every column
+// (+ the 4 KiB residual table of the 256-entry path) must fit the 160 KiB of LDS: v = 8: 8 slices up to 14336 columns
+// (14080 with that table), else 16; v = 16: 16 slices up to 14336 columns, else 32
 int gemv_sliced_slices(const VptqLayerDesc& d) {
   static std::atomic<int> force16{-1};   // VPTQ_SLICED_SLICES=16: the larger slice count for every layer (A/B)
   if (force16 < 0) { const char* e = getenv("VPTQ_SLICED_SLICES"); force16 = (e && atoi(e) == 16) ? 1 : 0; }
   const int small = d.vector_len == 16 ? 16 : 8;
   if (force16 == 1) return 2 * small;
-  return d.group_size <= (d.num_res_centroids == 256 ? kSLMaxG8Res : kSLMaxG8) ? small : 2 * small;
+  return d.group_size <= (sl_res256(d) ? kSLMaxG8Res : kSLMaxG8) ? small : 2 * small;
+}
+// bytes a workgroup of a table with k entries holds: its slice, or (whole != 0) the whole table
+static uint32_t sl_tab_bytes(const VptqLayerDesc& d, int k, int whole) {
+  return (uint32_t)(whole ? k : k / gemv_sliced_slices(d)) * (uint32_t)d.vector_len * 2u;
 }
 
 // partial sums [table x slices][N x v] floats + one arrival counter per block of 16 rows (the smallest row block), which
 // must be ZERO before the first launch; every launch leaves them zero
 static size_t sl_partial_bytes(const VptqLayerDesc& d) {
-  const size_t parts = (size_t)gemv_sliced_slices(d) * (d.num_res_centroids == 65536 ? 2 : 1);
+  const size_t parts = (size_t)gemv_sliced_slices(d) * (sl_two(d) ? 2 : 1);
   return (parts * d.num_indices * d.vector_len * sizeof(float) + 255) / 256 * 256;
 }
 static size_t sl_counter_bytes(const VptqLayerDesc& d) {
@@ -468,21 +479,25 @@ static hipError_t launch_sl_dt(const SlicedParams& P, int v, int nsl, bool res, 
   return res ? launch_sl<DT, 16, true, 8, false>(P, lds, st) : launch_sl<DT, 16, false, 8, false>(P, lds, st);
 }
 
-static bool sl_layout_ok(const VptqSlicedLayout& L, int nsl, bool res) {
+static bool sl_layout_ok(const VptqLayerDesc& d, const VptqSlicedLayout& L, int nsl, bool res, int k) {
+  // (a sliced table needs at least one entry per slice; whole = every workgroup of the table holds all of it)
   return (L.n_slices != 0 ? L.n_slices : 8) == nsl && (L.elems_per_lane == 0 || L.elems_per_lane == 1) && (!res || L.res) &&
          L.rows_per_wave >= 1 && L.rows_per_wave <= kSLMaxRowsPerWave && L.elems && L.blocks && L.first &&
-         (((uintptr_t)L.elems) & 3) == 0;
+         (((uintptr_t)L.elems) & 3) == 0 && (L.whole_table == 0 || L.whole_table == 1) && (L.whole_table || k >= nsl) &&
+         sl_tab_bytes(d, k, L.whole_table) <= 131072u;
 }
 
-// L: one layout (residual none / 256) or TWO consecutive ones (65536 residual centroids: [0] bucketed by the main index,
-// [1] by the residual index).  (c + r) f16(s x) = c f16(s x) + r f16(s x): the residual table's (slice, row block)
-// workgroups run beside the main table's in the SAME launch and meet them in the cross-slice sum - two launches, one per
-// table, cost a second boundary, a second epilogue and half the workgroups in flight (8192^2: 27.2 us; 4096^2: 17.8)
+// L: one layout (residual none / the 256-entry path of v = 8) or TWO consecutive ones (any other residual codebook: [0]
+// bucketed by the main index, [1] by the residual index).  (c + r) f16(s x) = c f16(s x) + r f16(s x): the residual table's
+// (slice, row block) workgroups run beside the main table's in the SAME launch and meet them in the cross-slice sum - two
+// launches, one per table, cost a second boundary, a second epilogue and half the workgroups in flight (8192^2: 27.2 us
+// against 21.2; 4096^2: 17.8 against 12.0)
 hipError_t launch_gemv_sliced(const VptqLayerDesc& d, const VptqSlicedLayout* L, const void* x, void* y, int flags,
                               void* ws, hipStream_t st) {
-  const bool res = d.num_res_centroids == 256, two = d.num_res_centroids == 65536;
+  const bool res = sl_res256(d), two = sl_two(d);
   const int nsl = gemv_sliced_slices(d);
-  if (!sl_layout_ok(L[0], nsl, res) || (two && (!sl_layout_ok(L[1], nsl, false) || L[1].rows_per_wave != L[0].rows_per_wave)) ||
+  if (!sl_layout_ok(d, L[0], nsl, res, d.num_centroids) ||
+      (two && (!sl_layout_ok(d, L[1], nsl, false, d.num_res_centroids) || L[1].rows_per_wave != L[0].rows_per_wave)) ||
       !ws || (((uintptr_t)x) & 15) != 0)
     return hipErrorInvalidValue;
   SlicedParams P = {};
@@ -492,12 +507,17 @@ hipError_t launch_gemv_sliced(const VptqLayerDesc& d, const VptqSlicedLayout* L,
   P.blocks = (const int32_t*)L[0].blocks;
   P.first = (const int32_t*)L[0].first;
   P.cent = (const uint32_t*)d.centroids;
+  P.tab0 = sl_tab_bytes(d, d.num_centroids, L[0].whole_table);
+  P.stride0 = L[0].whole_table ? 0u : P.tab0;
   if (two) {
     P.elems2 = (const uint32_t*)L[1].elems;
     P.blocks2 = (const int32_t*)L[1].blocks;
     P.first2 = (const int32_t*)L[1].first;
     P.cent2 = (const uint32_t*)d.res_centroids;
+    P.tab1 = sl_tab_bytes(d, d.num_res_centroids, L[1].whole_table);
+    P.stride1 = L[1].whole_table ? 0u : P.tab1;
   }
+  P.x_off = ((P.tab0 > P.tab1 ? P.tab0 : P.tab1) + 15u) & ~15u;
   P.x = (const uint16_t*)x;
   P.scale = (const uint16_t*)(d.perm ? d.scale_permuted : d.weight_scale);
   P.wbias = (const uint16_t*)d.weight_bias;
@@ -512,7 +532,7 @@ hipError_t launch_gemv_sliced(const VptqLayerDesc& d, const VptqSlicedLayout* L,
   const int rows_per_wg = kSLWaves * L[0].rows_per_wave;
   P.n_rowblocks = (d.num_indices + rows_per_wg - 1) / rows_per_wg;
   P.out_f32 = (flags & VPTQ_GEMV_OUT_F32) ? 1 : 0;
-  const uint32_t lds = (65536u / (uint32_t)nsl) * (uint32_t)d.vector_len * 2u + (uint32_t)(d.group_size + 64) * 2u + 64u + (res ? 4096u : 0u);
+  const uint32_t lds = P.x_off + (uint32_t)(d.group_size + 64) * 2u + 64u + (res ? 4096u : 0u);
   if (lds > kSLLdsLimit) return hipErrorInvalidValue;
   return d.dtype == VPTQ_DTYPE_F16 ? launch_sl_dt<F16>(P, d.vector_len, nsl, res, two, lds, st)
                                    : launch_sl_dt<BF16>(P, d.vector_len, nsl, res, two, lds, st);

@@ -421,7 +421,7 @@ class VQuantLinear(nn.Module):
             return True
         free, total = torch.cuda.mem_get_info(cache[3])
         elems = self.indices.shape[1] * self.group_size
-        two = self.enable_residual and self.num_res_centroids == 65536   # (one layout per table)
+        two = B.lib().vptq_sliced_layout_tables(cache[1]) == 2   # (one layout per table)
         need = elems * (8 if two else 5) + elems * 8 * 12   # layout + int64 temporaries of build_sliced_layout
         return free - need > _SLICED_MIN_FREE_FRACTION * total
 
@@ -432,10 +432,9 @@ class VQuantLinear(nn.Module):
             if "_sliced_cand" not in self.__dict__:
                 # (static module configuration: decided once, so that every other layer pays one dict look-up per call)
                 self.__dict__["_sliced_cand"] = bool(
-                    self.num_centroids == 65536 and self.vector_len in (8, 16) and self.num_codebooks == 1 and
-                    not self.enable_outlier and self.enable_norm and   # (a permutation may still be absorbed later)
-                    (not self.enable_residual or self.num_res_centroids == 65536 or
-                     (self.num_res_centroids == 256 and self.vector_len == 8)))
+                    self.num_centroids >= 16384 and self.vector_len in (8, 16) and self.num_codebooks == 1 and
+                    not self.enable_outlier and self.enable_norm)   # (a permutation may still be absorbed later; the library
+                    # decides: vptq_sliced_layout_supported)
             sl = self._sliced_gemv() if self.__dict__["_sliced_cand"] else None
             if sl is not None and not (ops.quant_gemm_flags() & (B.GEMV_EXACT | B.GEMV_FORCE_GENERIC)):
                 y = sl(x)

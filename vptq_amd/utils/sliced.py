@@ -23,17 +23,14 @@ from vptq_amd import _backend as B
 INDEX_BITS = 16   # 65536 main centroids
 
 
-def split_index_streams(indices: torch.Tensor, group_size: int, res_bits: int):
+def split_index_streams(indices: torch.Tensor, group_size: int, res_bits: int, index_bits: int = INDEX_BITS):
     """the layer's packed int32 `indices` [1, N, row_words] -> (main index [N, G] int64, residual index [N, G] int64 or None):
-    a little-endian bit stream per row, element g at bits [T g, T g + T) with value (residual index << 16) | main index
-    (vptq/utils/pack.py:26-89); T = 16 without a residual codebook, 24 with 256, 32 with 65536 residual centroids."""
-    assert indices.dtype == torch.int32 and indices.dim() == 3 and indices.shape[0] == 1 and res_bits in (0, 8, 16)
-    N, G = indices.shape[1], group_size
-    nbytes = 2 + res_bits // 8
-    by = indices[0].contiguous().view(torch.uint8).reshape(N, -1)[:, :nbytes * G].reshape(N, G, nbytes).to(torch.int64)
-    idx = by[:, :, 0] | (by[:, :, 1] << 8)
-    ridx = None if res_bits == 0 else (by[:, :, 2] if res_bits == 8 else (by[:, :, 2] | (by[:, :, 3] << 8)))
-    return idx, ridx
+    a little-endian bit stream per row, element g at bits [T g, T g + T) with value (residual index << index_bits) | main
+    index, T = index_bits + res_bits (vptq/utils/pack.py:26-89)."""
+    assert indices.dtype == torch.int32 and indices.dim() == 3 and indices.shape[0] == 1
+    from vptq_amd.utils.pack import unpack_index_tensor
+    idx, ridx = unpack_index_tensor(indices, index_bits, group_size, res_bits, group_size, res_mask_bits=res_bits)
+    return idx[0], (None if ridx is None else ridx[0])
 
 
 def build_sliced_layout(indices: torch.Tensor, group_size: int, slices: int = 8, residual: bool = False):
@@ -45,21 +42,31 @@ def build_sliced_layout(indices: torch.Tensor, group_size: int, slices: int = 8,
     return layout_from_indices(idx, slices, ridx)
 
 
-def layout_from_indices(idx: torch.Tensor, slices: int = 8, ridx: torch.Tensor = None):
-    """idx [N, G] int64 (values < 65536): the index each element gathers with from the table this layout is for;
-    ridx: an 8-bit side index carried along per element (the 256-entry residual table), or None."""
-    assert slices in (8, 16, 32)
-    SLICES, SLICE_BITS = slices, INDEX_BITS - {8: 3, 16: 4, 32: 5}[slices]
+def layout_from_indices(idx: torch.Tensor, slices: int = 8, ridx: torch.Tensor = None, index_bits: int = INDEX_BITS,
+                        whole_table: bool = False):
+    """idx [N, G] int64 (values < 2^index_bits): the index each element gathers with from the table this layout is for;
+    ridx: an 8-bit side index carried along per element (the 256-entry residual table of v = 8), or None.  Elements are
+    bucketed by the top log2(slices) bits of idx and the element word carries idx inside its slice; or - whole_table:
+    every workgroup of the table holds the whole (small) table - split into equal column ranges, the word carrying idx itself."""
+    assert slices in (8, 16, 32) and 1 <= index_bits <= 16
+    SLICES = slices
+    lg = {8: 3, 16: 4, 32: 5}[slices]
+    SLICE_BITS = max(index_bits - lg, 0)
     dev = idx.device
     N, G = idx.shape
     residual = ridx is not None
-    sl = idx >> SLICE_BITS
     col = torch.arange(G, device=dev, dtype=torch.int64)
+    if whole_table:
+        # every workgroup of the table holds all of it, so ANY split of a row's elements is valid: equal column ranges
+        # (bucketing a 4- or 64-entry table by its index would leave most of the slices - workgroups - empty)
+        sl = (col * SLICES // G)[None, :].expand(N, G).contiguous()
+    else:
+        sl = idx >> SLICE_BITS
     # Order inside a (row, slice) list is free (a sum): arrange it so that 16 CONSECUTIVE elements - the lanes one
     # pass of the kernel's ds_read_b128 gather serves - hit 16 different LDS bank groups (entry & 15): elements are
     # ranked inside their (slice, entry & 15) class and laid out rank-major, i.e. one element of every class in turn.
     # (Column order gave 3-way conflicts on average: SQ_LDS_BANK_CONFLICT = 60 % of the LDS cycles.)
-    local = idx & ((1 << SLICE_BITS) - 1)
+    local = idx if whole_table else idx & ((1 << SLICE_BITS) - 1)
     cls = local & 15
     order1 = torch.argsort((sl * 16 + cls) * G + col[None, :], dim=1)
     seg1 = torch.gather(sl * 16 + cls, 1, order1)                                       # sorted (slice, class) id
@@ -107,23 +114,28 @@ class SlicedGemv:
         self.desc, self.dev = cache[1], cache[3]
         self.slices = B.lib().vptq_sliced_layout_supported(self.desc)
         if not self.slices:
-            raise ValueError("the sliced layout serves v8-k65536-0 / -256 / -65536 and v16-k65536-0 / -65536 layers, group_size <= 32768")
+            raise ValueError("the sliced layout serves v = 8 / 16 layers with 16384 ... 65536 main centroids, group_size <= 32768")
         kr = layer.num_res_centroids if layer.enable_residual else 0
-        rpw = None
-        if kr == 65536:
-            # "v8-k65536-65536" (T = 32, the 4-bit format of the published checkpoints): (c + r) s x = c s x + r s x, so the
-            # layer is TWO passes of the one-table kernel, each over a layout bucketed by ITS table's index
-            idx, ridx = split_index_streams(layer.indices.data, layer.group_size, 16)
-            self._tensors = [layout_from_indices(idx, self.slices), layout_from_indices(ridx, self.slices)]
-            del idx, ridx
+        ib = int(layer.num_centroids).bit_length() - 1
+        rb = int(kr).bit_length() - 1 if kr else 0
+        n_tables = B.lib().vptq_sliced_layout_tables(self.desc)
+        entry = 2 * layer.vector_len
+        # a table whose slice would be under 16 KiB is held WHOLE by each of its workgroups (small residual tables)
+        whole = [False, n_tables == 2 and (kr // self.slices) * entry < 16384]
+        idx, ridx = split_index_streams(layer.indices.data, layer.group_size, rb, ib)
+        if n_tables == 2:
+            # (c + r) s x = c s x + r s x: the residual codebook is a second table with a layout bucketed by ITS index
+            self._tensors = [layout_from_indices(idx, self.slices, None, ib), layout_from_indices(ridx, self.slices, None, rb, whole[1])]
         else:
-            self._tensors = [build_sliced_layout(layer.indices.data, layer.group_size, self.slices, kr == 256)]
+            self._tensors = [layout_from_indices(idx, self.slices, ridx if kr else None, ib)]
+        del idx, ridx
+        self._whole = whole[:len(self._tensors)]
         self.elems, self.blocks, self.first, self.res = self._tensors[0]
         # (a two-table layer runs 2 x slices workgroups per row block in its one launch)
         rpw = rows_per_wave or rows_per_wave_for(self.blocks.shape[1], self.slices * len(self._tensors))
         self.layout = (B.SlicedLayout * len(self._tensors))(*[
-            B.SlicedLayout(e.data_ptr(), b.data_ptr(), f.data_ptr(), r.data_ptr() if r is not None else None, rpw, 1, self.slices, 0)
-            for e, b, f, r in self._tensors])
+            B.SlicedLayout(e.data_ptr(), b.data_ptr(), f.data_ptr(), r.data_ptr() if r is not None else None, rpw, 1, self.slices, int(w))
+            for (e, b, f, r), w in zip(self._tensors, self._whole)])
         self._ws_bytes = B.lib().vptq_quant_gemv_sliced_workspace_bytes(self.desc)
         # partial sums + arrival counters, ONE PER STREAM (two streams - or a graph replay next to an eager call on
         # another stream - running the same layer would race on a shared one); zeroed once, every call leaves the
