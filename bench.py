@@ -131,12 +131,13 @@ def prefill_extra(dev, tokens=8192):
     return out
 
 
-def k65536_extra(lib, B, dev, H, steps, warmup, regions, R=8):
+def k65536_extra(lib, B, dev, H, steps, warmup, regions, R=8, kr=256, v=8):
     """v8-k65536-256 (T = 24 bits, the format of most published checkpoints), H x H, one token: the library's default
     route (gemv_gather_kernel: centroid gathers through the caches) and the one-token GEMV over the load-time derived
     sliced layout (gemv_sliced.hip, VQuantLinear.enable_sliced_layout) on the same ring of R distinct layers."""
     from vptq_amd.utils.sliced import SlicedGemv
-    layers = make_ring(H, R, dev, seed=4321, k=65536, kr=256)
+    g = torch.Generator(device=dev).manual_seed(4321)
+    layers = [make_layer(H, H, dev, g, 65536, kr, v=v) for _ in range(R)]
     x = torch.randn(1, 1, H, device=dev, generator=torch.Generator(device=dev).manual_seed(7)).half()
     ys = [torch.empty(1, 1, H, device=dev, dtype=torch.float16) for _ in range(R)]
     descs = [layer_desc(m) for m in layers]
@@ -151,9 +152,10 @@ def k65536_extra(lib, B, dev, H, steps, warmup, regions, R=8):
     def sliced_pass():
         for i in range(R):
             sls[i](x, ys[i])
-    ab = alg_bytes(H, H, 65536, 256, 1)
-    out = {"what": f"VQuantLinear {H}x{H} v=8 k=65536+256 (3-bit, T = 24), ring of {R} layers; GB/s of the PACKED format's "
-                   "algorithmic bytes for both routes (the sliced layout reads 5 instead of 3 bytes per element)"}
+    T = 16 + (int(np.log2(kr)) if kr else 0)
+    ab = (H // v) * ((H * T + 31) // 32) * 4 + (65536 + kr) * v * 2 + 2 * H + 4 * H + 2 * H
+    out = {"what": f"VQuantLinear {H}x{H} v={v} k=65536+{kr} (T = {T} bits per index), ring of {R} layers; GB/s of the PACKED format's "
+                   "algorithmic bytes for both routes (the sliced layouts read 4 bytes per element and table, 5 for k65536+256)"}
     for key, fn in (("default", default_pass), ("sliced_layout", sliced_pass)):
         t = Timer(dev).run(fn, steps, warmup, regions)
         us = t["event_ms"] * 1e3 / (steps * R)
@@ -207,6 +209,10 @@ class SclkSampler:
         self.power_path = pw[0] if pw else None
         self.power_samples = []
         self.power_cap_w = None
+        # memory clock (hwmon freq2_input, Hz) where offered: boxes of the pool differ in what the memory system delivers
+        mc = sorted(glob.glob(os.path.join(self.card, "hwmon", "hwmon*", "freq2_input"))) if self.card else []
+        self.mclk_path = mc[0] if mc else None
+        self.mclk_samples = []
         if pw:
             try:
                 self.power_cap_w = float(open(os.path.join(os.path.dirname(pw[0]), "power1_cap")).read().strip()) / 1e6
@@ -238,6 +244,11 @@ class SclkSampler:
                             self.power_samples.append(float(open(self.power_path).read().strip()) / 1e6)
                         except Exception:
                             pass
+                    if self.mclk_path is not None:
+                        try:
+                            self.mclk_samples.append(float(open(self.mclk_path).read().strip()) / 1e6)
+                        except Exception:
+                            pass
                     time.sleep(0.02)
             self._thread = threading.Thread(target=loop, daemon=True)
             self._thread.start()
@@ -255,6 +266,10 @@ class SclkSampler:
         return {"samples": len(s), "min_mhz": s[0], "median_mhz": s[len(s) // 2], "max_mhz": s[-1],
                 "source": f"{self.kind} of the card whose PCI address is this HIP device's, every 20 ms (before round 3's "
                           "last session the first card of /sys was read - on a box of the pool that is another GPU of the node)"}
+
+    def mclk_mhz(self):
+        s = sorted(self.mclk_samples)
+        return s[len(s) // 2] if s else None
 
     def power_summary(self):
         if not self.power_samples:
@@ -872,7 +887,7 @@ def main():
             us_replay = timer.soak(1.5)
         if sk.power_summary() is not None or sk.summary() is not None:
             soak = {"what": "the timed workload replayed back to back for 1.5 s (after the timed regions), hwmon of this GPU sampled every 20 ms",
-                    "us_per_step": us_replay, "power": sk.power_summary(), "sclk": sk.summary()}
+                    "us_per_step": us_replay, "power": sk.power_summary(), "sclk": sk.summary(), "mclk_mhz": sk.mclk_mhz()}
     chain_mode = mode in ("chain", "chain_dep")
     mode_name = (f"chain{min(a.chain, 32, r['ring'])}" if mode == "chain" else mode)
     out = {
@@ -911,7 +926,11 @@ def main():
                      "sclk_mhz_during_timed_regions": (sclk.summary() or {}).get("median_mhz"),
                      "soak": None if soak is None else {"us_per_step": soak["us_per_step"],
                                                         "power_w": (soak["power"] or {}).get("median_w"),
-                                                        "sclk_mhz": (soak["sclk"] or {}).get("median_mhz")},
+                                                        "sclk_mhz": (soak["sclk"] or {}).get("median_mhz"),
+                                                        "mclk_mhz": soak.get("mclk_mhz"),
+                                                        "reading": "at the 1400 W cap with the shader clock pulled down = the energy-bound state of DESIGN 4.9; "
+                                                                   "well under the cap at a high shader clock = this box's memory system is the limit (boxes of the pool: "
+                                                                   "143 us per step at 1400 W / 1.66 GHz on most, 237 us at 1020 W / 2.1 GHz on one)"},
                      "note": ("one launch = the whole ring (32 layers): bytes_per_launch = 32 x the algorithmic bytes of a "
                               "layer (SURVEY 8d), us_per_launch = HIP-event time over the (median) timed region / launches; "
                               "what bounds it: the 1400 W package power limit - this kernel draws the cap and the shader clock "
@@ -996,6 +1015,8 @@ def main():
                                        "tokens = M; + its pre-pass); round 2: 4 launches of 4 tokens, 39 us")
         ex["k8192_r256"]["what"] = "k = 8192 + 256 (T = 21 bits), LDS-resident codebooks"
         ex["k65536_r256"] = k65536_extra(lib, B, dev, H, st, wu, rg)
+        ex["k65536_r65536"] = k65536_extra(lib, B, dev, H, st, wu, rg, kr=65536)            # the "4 bits" format of every published family
+        ex["v16_k65536_r65536"] = k65536_extra(lib, B, dev, H, st, wu, rg, kr=65536, v=16)   # "2 bits" of most families
         tr = bench_tp_row(lib, B, dev, Timer(dev), 0, 1, a.tp_layers, 0, st, wu, rg)
         ex["tp_row_n1"] = {"what": f"Llama-3-70B shaped decoder layers (x{a.tp_layers}, the ring of --gpus N) on ONE GPU "
                                    "through the row-parallel code path (world size 1): the strong-scaling baseline of --gpus N",

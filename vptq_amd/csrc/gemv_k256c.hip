@@ -1145,6 +1145,21 @@ static hipError_t launch_c(const K256CParams& P, int grid, hipStream_t st) {
     if (e != hipSuccess) return e;
     attr_set[dev] = true;
   }
+  if (DEP) {
+    // A dependent chain's workgroups wait for each other INSIDE the launch (arrival flags per layer): every one of them
+    // must be resident at once, or the waiting ones starve the rest.  The grid is one workgroup per CU; refuse it unless
+    // the runtime confirms that this kernel (1024 threads, this much LDS) fits a CU and the grid does not exceed the
+    // CUs it reports.  (A device shared with another CU-pinning kernel, a CU mask or a partition mode the runtime does
+    // not reflect here can still break the assumption: the library's advice for dependent layers is one launch per
+    // layer)
+    static std::atomic<int> resident[64];
+    if (!resident[dev]) {
+      int per_cu = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, kCThreads, lds) != hipSuccess) per_cu = 0;
+      resident[dev] = per_cu > 0 ? per_cu * c_device_cus() : -1;
+    }
+    if (resident[dev] < grid) return hipErrorCooperativeLaunchTooLarge;
+  }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(kCThreads), lds, st, P);
   return hipGetLastError();
 }
