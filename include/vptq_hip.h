@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define VPTQ_ABI_VERSION 6
+#define VPTQ_ABI_VERSION 7
 
 #if defined(__GNUC__)
 #define VPTQ_API __attribute__((visibility("default")))

@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # VPTQ_HIP_LIB: load another build of the library (A/B runs of tools/)
 LIB_PATH = os.environ.get("VPTQ_HIP_LIB") or os.path.join(_HERE, "libvptq_hip.so")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 DTYPE_F16, DTYPE_BF16 = 0, 1
 GEMV_FAST_MATH = 1 << 0
 GEMV_FORCE_GENERIC = 1 << 1
