@@ -303,6 +303,8 @@ VPTQ_API int vptq_sliced_layout_supported(const VptqLayerDesc* desc);
 /* 0, or how many consecutive VptqSlicedLayout structs vptq_quant_gemv_sliced takes for this layer: 1 (no residual codebook;
  * v = 8 with 256 residual centroids: `res` bytes), 2 (any other residual codebook: a second table with a layout of its own) */
 VPTQ_API int vptq_sliced_layout_tables(const VptqLayerDesc* desc);
+/* the `whole_table` value the layout of table 0 / 1 must be built with (1: a small residual table every workgroup holds whole) */
+VPTQ_API int vptq_sliced_layout_whole_table(const VptqLayerDesc* desc, int table);
 VPTQ_API size_t vptq_quant_gemv_sliced_workspace_bytes(const VptqLayerDesc* desc);
 VPTQ_API int vptq_quant_gemv_sliced(const VptqLayerDesc* desc, const VptqSlicedLayout* layout, const void* x,
                            void* y, int flags, void* workspace, size_t workspace_bytes, void* stream);

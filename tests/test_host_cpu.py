@@ -557,3 +557,35 @@ def test_module_copies_and_pickles_without_its_derived_state():
     m3 = pickle.loads(pickle.dumps(m))
     assert "_desc_cache" not in m3.__dict__ and "_sliced" not in m3.__dict__
     assert sorted(m3.state_dict()) == sorted(m.state_dict())
+
+
+def _family_desc(I, O, v, k, kr):
+    """descriptor of a large-codebook layer (fake aligned pointers, never dereferenced)"""
+    d = B.LayerDesc()
+    ib, rb = k.bit_length() - 1, (kr.bit_length() - 1 if kr else 0)
+    d.in_features, d.out_features, d.vector_len, d.num_codebooks, d.group_size = I, O, v, 1, I
+    d.num_centroids, d.num_res_centroids, d.index_bits, d.res_bits = k, kr, ib, rb
+    d.row_words, d.num_indices, d.dtype = (I * (ib + rb) + 31) // 32, (O + v - 1) // v, 0
+    d.indices, d.centroids, d.res_centroids = 1 << 20, 2 << 20, (3 << 20 if kr else None)
+    d.weight_scale, d.weight_bias = 4 << 20, 5 << 20
+    return d
+
+
+def test_sliced_layout_routing_without_gpu():
+    """which layers get sliced layouts, how many tables, which slice counts, whole-table mode: host logic"""
+    lib = B.lib()
+    sup, tabs, whole = lib.vptq_sliced_layout_supported, lib.vptq_sliced_layout_tables, lib.vptq_sliced_layout_whole_table
+    assert sup(_family_desc(8192, 8192, 8, 65536, 0)) == 8 and tabs(_family_desc(8192, 8192, 8, 65536, 0)) == 1
+    assert sup(_family_desc(8192, 8192, 8, 65536, 256)) == 8 and tabs(_family_desc(8192, 8192, 8, 65536, 256)) == 1   # byte side stream
+    assert sup(_family_desc(14336, 4096, 8, 65536, 256)) == 16                     # the 4 KiB table no longer fits beside 8 slices
+    assert sup(_family_desc(28672, 8192, 8, 65536, 65536)) == 16 and tabs(_family_desc(28672, 8192, 8, 65536, 65536)) == 2
+    assert sup(_family_desc(8192, 8192, 16, 65536, 65536)) == 16 and sup(_family_desc(28672, 8192, 16, 65536, 0)) == 32
+    assert tabs(_family_desc(8192, 8192, 16, 65536, 256)) == 2                     # v = 16 has no byte side stream
+    assert sup(_family_desc(8192, 8192, 8, 32768, 0)) == 8 and sup(_family_desc(8192, 8192, 8, 8192, 0)) == 0   # (k <= 8192: gemv_lds)
+    assert sup(_family_desc(8192, 8192, 12, 65536, 0)) == 0 and sup(_family_desc(40000, 8192, 8, 65536, 0)) == 0
+    # a small second table is held whole ... while it fits beside the activations
+    assert whole(_family_desc(8192, 8192, 16, 65536, 1024), 1) == 1 and whole(_family_desc(8192, 8192, 16, 65536, 1024), 0) == 0
+    assert whole(_family_desc(8192, 8192, 16, 65536, 65536), 1) == 0               # 128 KiB slices
+    assert whole(_family_desc(8192, 8192, 8, 65536, 4), 1) == 1
+    assert whole(_family_desc(25704, 768, 16, 65536, 4096), 1) == 0                # 128 KiB of table + 51 KiB of activations: sliced
+    assert sup(_family_desc(25704, 768, 16, 65536, 4096)) == 32

@@ -219,39 +219,43 @@ def fuzz_chains(a, dev):
 
 
 def fuzz_sliced(a, dev):
-    """random v8-k65536-0 / -256 layers, one token, over the sliced layout (gemv_sliced_kernel - the module's default
-    one-token route for these formats): against the oracle and the gather kernel, twice (reproducible bits), with
-    random rows-per-wave; skewed index distributions (most elements in one slice, empty slices) included"""
+    """random layers of the k >= 16384 family (v = 8 / 16; 16384 ... 65536 main centroids; residual codebook none, 256 or any
+    power of two up to 65536), one token, over the sliced layout(s) (gemv_sliced_kernel - the module's default one-token route
+    for these formats): against the oracle and the gather kernels, twice (reproducible bits), with random rows-per-wave;
+    skewed index distributions (most elements in one slice, empty slices - of the main AND the residual table) included"""
     from vptq_amd.utils.sliced import SlicedGemv
+    from vptq_amd.utils.pack import pack_index
     rng = np.random.default_rng(a.seed)
     dt = a.dtype
     tol = 1e-3 if dt == "f16" else 8e-3
     worst = 0.0
     for c in range(a.cases):
-        kr = int(rng.choice([0, 256]))
+        v = int(rng.choice([8, 8, 16]))
+        k = int(rng.choice([65536, 65536, 65536, 32768, 16384]))
+        kr = int(rng.choice([0, 256, 65536, 4, 64, 1024, 4096, 16384, 32768, 2]))
         I = int(rng.choice([8 * int(rng.integers(8, 1800)), 2048 * int(rng.integers(1, 8)), 8 * int(rng.integers(1800, 3600))]))
-        O = int(rng.choice([8 * int(rng.integers(1, 64)), 8 * int(rng.integers(64, 700)) - int(rng.integers(0, 8))]))
-        O = max(O, 8)
-        L = vo.make_layer(I, O, dist="llm", seed=9000 + c, dtype=dt, num_centroids=65536, num_res_centroids=kr,
+        O = int(rng.choice([v * int(rng.integers(33, 80)), v * int(rng.integers(64, 700)) - int(rng.integers(0, v))]))
+        L = vo.make_layer(I, O, dist="llm", seed=9000 + c, dtype=dt, vector_len=v, num_centroids=k, num_res_centroids=kr,
                           bias=bool(rng.integers(0, 2)), enable_perm=bool(rng.integers(0, 3) == 0))
         skew = int(rng.integers(0, 4))
-        if skew:   # rewrite the main indices: 1 = one slice only, 2 = two slices, 3 = 90 % in slice 5
+        if skew:   # rewrite the indices: 1 = one slice only, 2 = two slices, 3 = 90 % in one slice (main and residual alike)
             N = L.indices.shape[1]
-            idx = rng.integers(0, 65536, size=(N, I), dtype=np.int64)
-            if skew == 1:
-                idx = (idx & 8191) | (3 << 13)
-            elif skew == 2:
-                idx = (idx & 8191) | (rng.integers(0, 2, size=(N, I)) * 7 << 13)
-            else:
-                idx = np.where(rng.random((N, I)) < 0.9, (idx & 8191) | (5 << 13), idx)
-            ridx = rng.integers(0, 256, size=(N, I), dtype=np.int64) if kr else np.zeros((N, I), dtype=np.int64)
-            val = idx | (ridx << 16)
-            nb = 3 if kr else 2
-            by = np.stack([(val >> (8 * k)) & 255 for k in range(nb)], axis=2).astype(np.uint8).reshape(N, I * nb)
-            words = L.indices.shape[2]
-            buf = np.zeros((N, words * 4), dtype=np.uint8)
-            buf[:, :I * nb] = by
-            L.indices = buf.view(np.int32).reshape(1, N, words)
+            ib, rb = L.index_bits, L.res_bits
+
+            def skewed(bits):
+                if bits == 0:
+                    return None
+                idx = rng.integers(0, 1 << bits, size=(1, N, I), dtype=np.int64)
+                top = max(bits - 3, 0)
+                low = (1 << top) - 1
+                if skew == 1:
+                    idx = (idx & low) | ((3 % (1 << (bits - top))) << top)
+                elif skew == 2:
+                    idx = (idx & low) | ((rng.integers(0, 2, size=idx.shape) * (7 % (1 << (bits - top)))) << top)
+                else:
+                    idx = np.where(rng.random(idx.shape) < 0.9, (idx & low) | ((5 % (1 << (bits - top))) << top), idx)
+                return idx
+            L.indices = vo.pack_indices(skewed(ib), ib, skewed(rb), rb)
         x = vo.from_f32(rng.standard_normal((1, 1, I)).astype(np.float32), dt)
         m = spec_to_module(L, dev)
         m.enable_sliced_layout(False)
@@ -262,11 +266,14 @@ def fuzz_sliced(a, dev):
         torch.cuda.synchronize()
         again = sl(xt)
         assert torch.equal(got.view(torch.int16), again.view(torch.int16)), (c, "not reproducible")
-        want = vo.forward(L, x)
+        # (residual indices masked with res_bits as the reference's CUDA kernel does, quant_gemv.cuh:120-121: the Python
+        # path's mask differs where res_bits > index_bits, e.g. k16384 + 32768 - DESIGN.md section 3)
+        want = vo.gemv(vo.dequant(L, ref_residual_mask_quirk=False), x, dt, L.bias)
         e = rel_err(tensor_to_bits(got), want, dt)
         e2 = rel_err(tensor_to_bits(got), tensor_to_bits(gemv_abi(m, xt, 0)), dt)
         worst = max(worst, e)
-        print(f"case {c:3d} I={I:6d} O={O:5d} kr={kr:3d} skew={skew} slices={sl.slices} rpw={sl.layout.rows_per_wave}: oracle {e:.2e} gather {e2:.2e}", flush=True)
+        print(f"case {c:3d} v{v}-k{k}-{kr} I={I:6d} O={O:5d} skew={skew} slices={sl.slices} tables={len(sl.layout)} "
+              f"whole={sl._whole} rpw={sl.layout[0].rows_per_wave}: oracle {e:.2e} gather {e2:.2e}", flush=True)
         assert e <= tol and e2 <= tol, (c, e, e2)
     print(f"worst: {worst:.2e}")
 

@@ -82,6 +82,7 @@ EXPORTS = {
     "vptq_dequant": (C.c_int, [C.POINTER(LayerDesc), _vp, _vp]),
     "vptq_sliced_layout_supported": (C.c_int, [C.POINTER(LayerDesc)]),
     "vptq_sliced_layout_tables": (C.c_int, [C.POINTER(LayerDesc)]),
+    "vptq_sliced_layout_whole_table": (C.c_int, [C.POINTER(LayerDesc), C.c_int]),
     "vptq_quant_gemv_sliced_workspace_bytes": (C.c_size_t, [C.POINTER(LayerDesc)]),
     "vptq_quant_gemv_sliced": (C.c_int, [C.POINTER(LayerDesc), C.POINTER(SlicedLayout), _vp, _vp, C.c_int, _vp,
                                          C.c_size_t, _vp]),

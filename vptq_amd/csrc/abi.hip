@@ -401,6 +401,10 @@ int vptq_sliced_layout_tables(const VptqLayerDesc* d) {
   return validate_layer(d) == VPTQ_OK && vptq::gemv_sliced_eligible(*d) ? vptq::gemv_sliced_tables(*d) : 0;
 }
 
+int vptq_sliced_layout_whole_table(const VptqLayerDesc* d, int table) {
+  return validate_layer(d) == VPTQ_OK && vptq::gemv_sliced_eligible(*d) ? vptq::gemv_sliced_whole_table(*d, table) : 0;
+}
+
 size_t vptq_quant_gemv_sliced_workspace_bytes(const VptqLayerDesc* d) {
   return validate_layer(d) == VPTQ_OK && vptq::gemv_sliced_eligible(*d) ? vptq::gemv_sliced_workspace_bytes(*d) : 0;
 }

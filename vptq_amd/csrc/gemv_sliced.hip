@@ -1,7 +1,8 @@
-// Fused dequant + GEMV for the large-codebook formats "v8-k65536-0" (v = 8, 65536 main centroids, no residual;
-// T = 16), "v8-k65536-256" (+ 256 residual centroids, T = 24: most published checkpoints), "v8-k65536-65536" (T = 32,
-// the "4 bit" format: two passes, one per table) and "v16-k65536-0" / "v16-k65536-65536" (vector length 16: 32-byte
-// entries, 16 / 32 slices) over a LOAD-TIME DERIVED LAYOUT that makes every centroid gather LDS-local.
+// Fused dequant + GEMV for the large-codebook formats of the published checkpoints - vector length 8 or 16, 16384 ...
+// 65536 main centroids, any residual codebook: "v8-k65536-0" (T = 16), "v8-k65536-256" (T = 24: most checkpoints),
+// "v8-k65536-65536" (T = 32, the "4 bit" format), "v16-k65536-65536", "v16-k65536-1024", "v8-k32768-0", ... - over LOAD-TIME
+// DERIVED LAYOUTS that make every centroid gather LDS-local.  A residual codebook other than v8's 256-entry one is a second
+// table with a layout of its own, served by its own workgroups in the same launch: (c + r) s x = c s x + r s x.
 // Same contract as gemv_gather.hip (reference: WqA16WithOutliers_PackIndice,
 // csrc/kernels/quant_gemv.cuh:11-186, dispatch csrc/quant_gemv.cu:54-132), one token.
 //
@@ -38,7 +39,6 @@ constexpr int kSLThreads = 1024;
 constexpr int kSLWaves = kSLThreads / 64;
 // 8 slices of 8192 entries (128 KiB of LDS) while the staged activations fit beside them, else 16 slices of 4096
 // (64 KiB): 8 slices hold f16(s x) of 14336 columns (14080 with the 4 KiB residual codebook), 16 slices of 32768
-constexpr int kSLMaxSlices = 32;
 constexpr int kSLMaxG8 = 14336, kSLMaxG8Res = 14080, kSLMaxG16 = 32768;
 constexpr uint32_t kSLLdsLimit = 163840;
 // element blocks in flight per wave.  Same-box A/B (profiles/r03/sliced_queue_ab.txt): depth 8 / 16 / 32 = 14.2 /
@@ -67,7 +67,6 @@ struct SlicedParams {
   const uint16_t* wbias;    // input-feature order
   const uint16_t* perm;     // column c of the quantised matrix multiplies input feature perm[c]; `scale` is then in column order
   const uint16_t* bias;
-  const float* addend;      // fp32 per output, added before the final rounding, or null
   // TWO tables in one launch (65536 residual centroids): the residual table's layout and codebook; its workgroups are
   // "slices" NSL .. 2 NSL - 1 of the same row blocks
   const uint32_t* elems2;
@@ -280,7 +279,6 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedPar
       left = __builtin_amdgcn_readlane(my_blocks, row_i);
     }
   }
-  int c_next = 0;
   auto consume = [&](auto slot_c) __attribute__((always_inline)) {
     constexpr int S = decltype(slot_c)::value;
     const evec_t ev = eq[S];
@@ -344,7 +342,6 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedPar
     __builtin_amdgcn_sched_barrier(0);
     issue(slot_c);
     __builtin_amdgcn_sched_barrier(0);
-    ++c_next;
     if (--left == 0) {
       if (!done) store_row();
       ++row_i;
@@ -398,7 +395,6 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedPar
         for (int i = 0; i < w; ++i) p[i] = p[2 * i] + p[2 * i + 1];
       float v = p[0];
       if ((int)o < P.O) {
-        if (P.addend) v += as_global(P.addend)[o];   // (written by the previous launch on this stream)
         if (P.bias) v += DT::to_float(as_global(P.bias)[o]);
         if (P.out_f32) ((float*)as_global(P.y))[o] = v;
         else ((uint16_t*)as_global(P.y))[o] = DT::from_float(v);
@@ -415,9 +411,10 @@ static bool sl_pow2(int k) { return k > 0 && (k & (k - 1)) == 0; }
 static bool sl_res256(const VptqLayerDesc& d) { return d.vector_len == 8 && d.num_res_centroids == 256; }
 static bool sl_two(const VptqLayerDesc& d) { return d.num_res_centroids > 0 && !sl_res256(d); }
 int gemv_sliced_tables(const VptqLayerDesc& d) { return sl_two(d) ? 2 : 1; }
+static bool sl_shape_ok(const VptqLayerDesc& d);
 bool gemv_sliced_eligible(const VptqLayerDesc& d) {
   const int T = d.index_bits + d.res_bits;
-  return (d.vector_len == 8 || d.vector_len == 16) && d.num_codebooks == 1 && d.outlier_size == 0 &&
+  return sl_shape_ok(d) && (d.vector_len == 8 || d.vector_len == 16) && d.num_codebooks == 1 && d.outlier_size == 0 &&
          d.num_centroids >= 16384 && d.num_centroids <= 65536 && sl_pow2(d.num_centroids) && (1 << d.index_bits) == d.num_centroids &&
          (d.num_res_centroids == 0 || (d.num_res_centroids >= 2 && d.num_res_centroids <= 65536 && sl_pow2(d.num_res_centroids) &&
                                        (1 << d.res_bits) == d.num_res_centroids)) &&
@@ -441,6 +438,29 @@ int gemv_sliced_slices(const VptqLayerDesc& d) {
 // bytes a workgroup of a table with k entries holds: its slice, or (whole != 0) the whole table
 static uint32_t sl_tab_bytes(const VptqLayerDesc& d, int k, int whole) {
   return (uint32_t)(whole ? k : k / gemv_sliced_slices(d)) * (uint32_t)d.vector_len * 2u;
+}
+// Does every workgroup of table t (0 main, 1 residual-as-second-table) hold the WHOLE table (element words then carry the
+// full index and a row's elements are split into column ranges)?  Only a second table whose slice would be under 16 KiB -
+// copied in 1 KiB pieces by 16 waves, a smaller slice is mostly partial pieces and its lists are short - and only while the
+// whole table still fits beside the staged activations.
+int gemv_sliced_whole_table(const VptqLayerDesc& d, int t) {
+  if (t != 1 || !sl_two(d)) return 0;
+  const uint32_t slice = sl_tab_bytes(d, d.num_res_centroids, 0), whole = sl_tab_bytes(d, d.num_res_centroids, 1);
+  const uint32_t main_slice = sl_tab_bytes(d, d.num_centroids, 0);
+  const uint32_t x_bytes = (uint32_t)(d.group_size + 64) * 2u + 64u;
+  if (d.num_res_centroids < gemv_sliced_slices(d)) return 1;   // (fewer entries than slices: no other way)
+  return slice < 16384u && ((whole > main_slice ? whole : main_slice) + 15u) / 16u * 16u + x_bytes <= kSLLdsLimit ? 1 : 0;
+}
+
+// the tables' parts + the staged activations (+ the 4 KiB table of the 256-entry path) fit the LDS
+static bool sl_shape_ok(const VptqLayerDesc& d) {
+  if (!(d.vector_len == 8 || d.vector_len == 16) || d.group_size <= 0 || d.group_size > kSLMaxG16 || d.num_centroids < 16384) return false;
+  uint32_t tab = sl_tab_bytes(d, d.num_centroids, 0);
+  if (sl_two(d)) {
+    const uint32_t t1 = sl_tab_bytes(d, d.num_res_centroids, gemv_sliced_whole_table(d, 1));
+    tab = t1 > tab ? t1 : tab;
+  }
+  return (tab + 15u) / 16u * 16u + (uint32_t)(d.group_size + 64) * 2u + 64u + (sl_res256(d) ? 4096u : 0u) <= kSLLdsLimit;
 }
 
 // partial sums [table x slices][N x v] floats + one arrival counter per block of 16 rows (the smallest row block), which
@@ -483,8 +503,7 @@ static bool sl_layout_ok(const VptqLayerDesc& d, const VptqSlicedLayout& L, int 
   // (a sliced table needs at least one entry per slice; whole = every workgroup of the table holds all of it)
   return (L.n_slices != 0 ? L.n_slices : 8) == nsl && (L.elems_per_lane == 0 || L.elems_per_lane == 1) && (!res || L.res) &&
          L.rows_per_wave >= 1 && L.rows_per_wave <= kSLMaxRowsPerWave && L.elems && L.blocks && L.first &&
-         (((uintptr_t)L.elems) & 3) == 0 && (L.whole_table == 0 || L.whole_table == 1) && (L.whole_table || k >= nsl) &&
-         sl_tab_bytes(d, k, L.whole_table) <= 131072u;
+         (((uintptr_t)L.elems) & 3) == 0 && (L.whole_table == 0 || L.whole_table == 1) && (L.whole_table || k >= nsl);
 }
 
 // L: one layout (residual none / the 256-entry path of v = 8) or TWO consecutive ones (any other residual codebook: [0]
@@ -496,8 +515,9 @@ hipError_t launch_gemv_sliced(const VptqLayerDesc& d, const VptqSlicedLayout* L,
                               void* ws, hipStream_t st) {
   const bool res = sl_res256(d), two = sl_two(d);
   const int nsl = gemv_sliced_slices(d);
-  if (!sl_layout_ok(d, L[0], nsl, res, d.num_centroids) ||
-      (two && (!sl_layout_ok(d, L[1], nsl, false, d.num_res_centroids) || L[1].rows_per_wave != L[0].rows_per_wave)) ||
+  if (!sl_layout_ok(d, L[0], nsl, res, d.num_centroids) || L[0].whole_table != 0 ||
+      (two && (!sl_layout_ok(d, L[1], nsl, false, d.num_res_centroids) || L[1].rows_per_wave != L[0].rows_per_wave ||
+               L[1].whole_table != gemv_sliced_whole_table(d, 1))) ||
       !ws || (((uintptr_t)x) & 15) != 0)
     return hipErrorInvalidValue;
   SlicedParams P = {};
@@ -523,7 +543,6 @@ hipError_t launch_gemv_sliced(const VptqLayerDesc& d, const VptqSlicedLayout* L,
   P.wbias = (const uint16_t*)d.weight_bias;
   P.perm = (const uint16_t*)d.perm;
   P.bias = (const uint16_t*)d.bias;
-  P.addend = nullptr;
   P.partial = (float*)ws;
   P.arrived = (uint32_t*)((char*)ws + sl_partial_bytes(d));
   P.y = y;

@@ -56,7 +56,8 @@ hipError_t launch_gemv_lds_v2(const VptqV2Desc& d, const void* x, void* y, int t
 // gemv_sliced.hip - v8-k65536-0, one token, over the load-time derived sliced layout (LDS-local gathers)
 bool gemv_sliced_eligible(const VptqLayerDesc& d);
 int gemv_sliced_slices(const VptqLayerDesc& d);
-int gemv_sliced_tables(const VptqLayerDesc& d);   // layouts the layer needs: 1, or 2 (a residual codebook served as a second table)
+int gemv_sliced_tables(const VptqLayerDesc& d);
+int gemv_sliced_whole_table(const VptqLayerDesc& d, int table);   // VptqSlicedLayout::whole_table the layout of `table` must have   // layouts the layer needs: 1, or 2 (a residual codebook served as a second table)
 size_t gemv_sliced_workspace_bytes(const VptqLayerDesc& d);
 hipError_t launch_gemv_sliced(const VptqLayerDesc& d, const VptqSlicedLayout* L, const void* x, void* y, int flags,
                               void* ws, hipStream_t st);

@@ -119,9 +119,9 @@ class SlicedGemv:
         ib = int(layer.num_centroids).bit_length() - 1
         rb = int(kr).bit_length() - 1 if kr else 0
         n_tables = B.lib().vptq_sliced_layout_tables(self.desc)
-        entry = 2 * layer.vector_len
-        # a table whose slice would be under 16 KiB is held WHOLE by each of its workgroups (small residual tables)
-        whole = [False, n_tables == 2 and (kr // self.slices) * entry < 16384]
+        # a second table whose slice would be under 16 KiB is held WHOLE by each of its workgroups while it fits (the
+        # library decides: the kernel's LDS budget)
+        whole = [False, n_tables == 2 and bool(B.lib().vptq_sliced_layout_whole_table(self.desc, 1))]
         idx, ridx = split_index_streams(layer.indices.data, layer.group_size, rb, ib)
         if n_tables == 2:
             # (c + r) s x = c s x + r s x: the residual codebook is a second table with a layout bucketed by ITS index
