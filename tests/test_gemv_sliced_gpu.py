@@ -202,7 +202,7 @@ def test_sliced_route_falls_back_instead_of_failing(dev):
     g = torch.cuda.CUDAGraph()
     s = torch.cuda.Stream()
     xa = bits_to_tensor(x1, "f16", dev).reshape(1, 1, 2048)
-    m(torch.cat([xa, xa], dim=1))
+    m(torch.cat([xa] * 4, dim=1))          # (4 tokens: the gather kernel; 1 - 3 tokens would build the layout here)
     torch.cuda.synchronize()
     with torch.cuda.stream(s):
         with torch.cuda.graph(g, stream=s):
@@ -332,3 +332,42 @@ def test_sliced_layout_family_on_reference_goldens(name, dev):
     xt = bits_to_tensor(x, dt, dev).reshape(x.shape)
     assert rel_err(tensor_to_bits(SlicedGemv(m)(xt)), y, dt) <= TOL[dt], name
     assert rel_err(tensor_to_bits(m(xt)), y, dt) <= TOL[dt], name      # the module's own one-token route (auto: sliced)
+
+
+def test_two_and_three_tokens_as_sliced_launches_per_token(dev, monkeypatch):
+    """2 tokens of a LARGE large-codebook layer (the 4-bit format: 3) are served as one sliced launch per token
+    (VQuantLinear._sliced_token_limit: the gather kernels cost as much for one token as for four, the sliced kernel a
+    third to a half of that per token); smaller layers and more tokens keep the gather kernels"""
+    import vptq_amd.layers.vqlinear as vq
+    from oracle import c_oracle as co
+    L = vo.make_layer(8192, 6200, dist="llm", seed=41, num_centroids=65536, num_res_centroids=0)
+    m = spec_to_module(L, dev)
+    m.enable_sliced_layout()
+    x = _x(8192, "f16", "llm", 7)
+    x2 = np.concatenate([x, _x(8192, "f16", "llm", 8)], axis=1)
+    xt = bits_to_tensor(x2, "f16", dev).reshape(x2.shape)
+    y = m(xt)
+    sl = m.__dict__["_sliced"][1]
+    assert sl is not None and m._sliced_token_limit(sl) == 2
+    for t in range(2):
+        assert torch.equal(y[:, t].view(torch.int16), sl(xt[:, t:t + 1].contiguous()).view(torch.int16)[0])
+        assert rel_err(tensor_to_bits(y[:, t:t + 1]), co.forward(L, x2[:, t:t + 1], quirk=False), "f16") <= 1e-3
+    x3 = torch.cat([xt, xt[:, :1]], dim=1)
+    y3 = m(x3)                                   # 3 tokens: the gather kernel
+    m.enable_sliced_layout(False)
+    assert torch.equal(y3.view(torch.int16), m(x3).view(torch.int16))
+    # a small two-table layer: limit 1 by the rule; with the override 3 tokens go through the layouts
+    Ls = vo.make_layer(1024, 512, dist="llm", seed=42, num_centroids=65536, num_res_centroids=65536)
+    ms = spec_to_module(Ls, dev)
+    ms.enable_sliced_layout()
+    xs = np.concatenate([_x(1024, "f16", "llm", 9 + i) for i in range(3)], axis=1)
+    xst = bits_to_tensor(xs, "f16", dev).reshape(xs.shape)
+    ms(xst[:, :1].contiguous())
+    sls = ms.__dict__["_sliced"][1]
+    assert ms._sliced_token_limit(sls) == 1
+    monkeypatch.setattr(vq, "_SLICED_TOKENS_ENV", (3, 3))
+    sls.__dict__.pop("_token_limit")
+    ys = ms(xst)
+    for t in range(3):
+        assert torch.equal(ys[:, t].view(torch.int16), sls(xst[:, t:t + 1].contiguous()).view(torch.int16)[0])
+    assert rel_err(tensor_to_bits(ys), vo.forward(Ls, xs), "f16") <= 1e-3

@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""2-4 tokens of the large-codebook formats: the gather kernels (one launch for all tokens) against one sliced launch PER TOKEN
+(VQuantLinear._gemv_cached, VPTQ_SLICED_TOKENS), ring of distinct layers in a hipGraph; us per layer.
+    python tools/sliced_tokens_bench.py --v 8 --kr 65536 --shapes "8192,8192;4096,4096" """
+import argparse, json, os, sys, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tools"))
+os.environ["VPTQ_SLICED_TOKENS"] = "4,4"   # (the route under test is chosen per call below)
+from microbench import time_graph  # noqa
+from shape_bench import mk  # noqa
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--shapes", default="8192,8192;4096,4096")
+ap.add_argument("--ring", type=int, default=8)
+ap.add_argument("--k", type=int, default=65536)
+ap.add_argument("--kr", type=int, default=0)
+ap.add_argument("--v", type=int, default=8)
+a = ap.parse_args()
+dev = torch.device("cuda", 0); g = torch.Generator(device=dev).manual_seed(0)
+for I, O in [tuple(int(v) for v in p.split(',')) for p in a.shapes.split(';')]:
+    layers = [mk(I, O, dev, g, k=a.k, kr=a.kr, v=a.v) for _ in range(a.ring)]
+    row = dict(I=I, O=O, v=a.v, k=a.k, kr=a.kr)
+    for T in (1, 2, 3, 4):
+        x = torch.randn(1, T, I, device=dev).half()
+        for m in layers:
+            m.enable_sliced_layout(True)
+        ys = [m(x) for m in layers]           # builds the layouts
+        us_s = time_graph(lambda: [m(x) for m in layers], 10) / a.ring
+        for m in layers:
+            m.enable_sliced_layout(False)
+        yg = layers[0](x)
+        us_g = time_graph(lambda: [m(x) for m in layers], 10) / a.ring
+        err = ((ys[0].float() - yg.float()).abs().max() / yg.float().abs().max()).item()
+        row[f"t{T}"] = dict(gather_us=round(us_g, 2), sliced_per_token_us=round(us_s, 2), rel_diff=err)
+    print(json.dumps(row), flush=True)

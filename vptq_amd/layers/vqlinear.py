@@ -55,6 +55,10 @@ def _raw_stream(device_index: int) -> int:
 _SLICED_LAYOUT_MODE = os.environ.get("VPTQ_SLICED_LAYOUT", "auto").strip().lower() or "auto"
 _SLICED_LAYOUT_ENV = _SLICED_LAYOUT_MODE not in ("0", "off", "false", "no")
 _SLICED_MIN_FREE_FRACTION = 0.25
+# most tokens served as one sliced launch PER TOKEN: decided per layer (VQuantLinear._sliced_token_limit);
+# VPTQ_SLICED_TOKENS="one-table,two-table" overrides it (tools/sliced_tokens_bench.py)
+_SLICED_TOKENS_ENV = tuple(int(v) for v in os.environ["VPTQ_SLICED_TOKENS"].split(",")) if os.environ.get("VPTQ_SLICED_TOKENS") else None
+_SLICED_MAX_TOKENS = max(_SLICED_TOKENS_ENV) if _SLICED_TOKENS_ENV else 3
 
 
 class SiblingGroup:
@@ -412,6 +416,27 @@ class VQuantLinear(nn.Module):
             self.__dict__["_sliced"] = st
         return st[1]
 
+    def _sliced_token_limit(self, sl) -> int:
+        """most tokens served as one sliced launch per token (measured, profiles/r04/sliced_tokens.txt: 8192^2 / 4096 x 14336 /
+        4096^2, us per layer, gather kernel against T sliced launches - v8-k65536-0: 2 tokens 39.6 / 36.2 / 13.2 against 26.4 /
+        27.1 / 17.0; v8-k65536-256: 41.4 / 36.7 / 13.4 against 34.0 / 34.5 / 19.5; v8-k65536-65536: 2 tokens 78.6 / 66.6 / 22.0
+        against 42.1 / 41.3 / 23.5, 3 tokens 80.9 / 69.1 against 62.2 / 61.7; v16-k65536-65536: 2 tokens 52.9 / 52.0 / 19.6
+        against 40.2 / 44.0 / 24.1; small residual tables of v = 16: never)"""
+        lim = sl.__dict__.get("_token_limit")
+        if lim is None:
+            if _SLICED_TOKENS_ENV is not None:
+                lim = _SLICED_TOKENS_ENV[1 if len(sl.layout) == 2 else 0]
+            else:
+                n_el = self.indices.shape[1] * self.group_size      # elements per table
+                kr = self.num_res_centroids if self.enable_residual else 0
+                lim = 1
+                if self.vector_len == 8 and kr in (0, 256) and n_el >= 6 << 20:
+                    lim = 2
+                elif kr >= 16384 and n_el >= 3 << 20:
+                    lim = 3 if (self.vector_len == 8 and kr == 65536 and n_el >= 6 << 20) else 2
+            sl.__dict__["_token_limit"] = lim
+        return lim
+
     def _sliced_fits(self, cache, on) -> bool:
         """auto mode: build only while the layout (5 / 4 bytes per element + the builder's temporaries) leaves
         _SLICED_MIN_FREE_FRACTION of the device memory free, and never inside a stream capture"""
@@ -428,7 +453,7 @@ class VQuantLinear(nn.Module):
     def _gemv_cached(self, x: torch.Tensor, tokens: int) -> torch.Tensor:
         """Decode fast path: identical to `ops.quant_gemm` for 1..8 (canonical format: 16) tokens with a cached
         descriptor; layers linked by `link_siblings` share one grouped launch."""
-        if tokens == 1 and self.__dict__.get("_sliced_cand", True) and (_SLICED_LAYOUT_ENV or "_sliced_on" in self.__dict__):
+        if tokens <= _SLICED_MAX_TOKENS and self.__dict__.get("_sliced_cand", True) and (_SLICED_LAYOUT_ENV or "_sliced_on" in self.__dict__):
             if "_sliced_cand" not in self.__dict__:
                 # (static module configuration: decided once, so that every other layer pays one dict look-up per call)
                 self.__dict__["_sliced_cand"] = bool(
@@ -437,9 +462,24 @@ class VQuantLinear(nn.Module):
                     # decides: vptq_sliced_layout_supported)
             sl = self._sliced_gemv() if self.__dict__["_sliced_cand"] else None
             if sl is not None and not (ops.quant_gemm_flags() & (B.GEMV_EXACT | B.GEMV_FORCE_GENERIC)):
-                y = sl(x)
-                if y is not None:   # (None: misaligned activation, capture on a stream the layer has not run on, ...)
-                    return y
+                if tokens == 1:
+                    y = sl(x)
+                    if y is not None:   # (None: misaligned activation, capture on a stream the layer has not run on, ...)
+                        return y
+                elif tokens <= self._sliced_token_limit(sl) and x.is_contiguous() and (self.in_features * x.element_size()) % 16 == 0:
+                    # 2 (the 4-bit format: 3) tokens of a LARGE layer = one launch per token over the layouts: the gather
+                    # kernels cost about as much for one token as for four (they are bound by the table gathers, not by
+                    # the FMAs), the sliced kernel a third to a half of that per token (profiles/r04/sliced_tokens.txt)
+                    x2 = x.reshape(tokens, self.in_features)
+                    y = torch.empty(x.shape[:-1] + (self.out_features,), dtype=x.dtype, device=x.device)
+                    y2 = y.view(tokens, self.out_features)
+                    ok = True
+                    for t in range(tokens):
+                        if sl(x2[t], y2[t]) is None:
+                            ok = False
+                            break
+                    if ok:
+                        return y
         group = self.__dict__.get("_siblings")
         if group is not None and tokens <= group.MAX_TOKENS:
             y = group.forward(self, x, tokens)
