@@ -902,7 +902,12 @@ def main():
                                + (f" = {r['launches_per_step']} persistent launch(es) walking "
                                   f"{'dependent' if mode == 'chain_dep' else 'independent'} layers one after the other"
                                   if chain_mode else ""),
-                   "hidden": H, "ring": r["ring"], "mode": mode_name, "launches_per_step": r["launches_per_step"],
+                   "hidden": H, "ring": r["ring"], "mode": mode_name,
+                   "mode_note": ("throughput mode: the ring's layers are INDEPENDENT (each its own x and y), which is what lets one persistent "
+                                 "launch walk 32 of them; the layers of a decoder depend on each other and run at the rate of "
+                                 "extras.single_launch_per_layer (the reference's operator granularity), sibling projections at "
+                                 "extras.grouped_x4") if mode == "chain" else None,
+                   "launches_per_step": r["launches_per_step"],
                    "us_per_layer": r["us_per_layer"],
                    "kernel": r["kernel"], "arithmetic": arithmetic,
                    "read_ahead_next_layer": bool(a.prefetch), "hipgraph": r["hipgraph"],
