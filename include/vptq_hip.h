@@ -309,6 +309,15 @@ VPTQ_API size_t vptq_quant_gemv_sliced_workspace_bytes(const VptqLayerDesc* desc
 VPTQ_API int vptq_quant_gemv_sliced(const VptqLayerDesc* desc, const VptqSlicedLayout* layout, const void* x,
                            void* y, int flags, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Up to 3 layers of ONE format, dtype and input width that read the SAME activation (q / k / v, gate / up) in one launch
+ * (ABI >= 7): layouts = the layers' structs one after the other (vptq_sliced_layout_tables() each; give every struct the
+ * group's rows_per_wave - one round of workgroups over ALL layers), y / workspaces / workspace_bytes one per layer.  The
+ * fixed part of a sliced launch (boundary, slice copy, staging, cross-slice hand-over: ~7 of the 10 us of a 4096 x 4096
+ * layer) is paid once. */
+VPTQ_API int vptq_quant_gemv_sliced_grouped(const VptqLayerDesc* descs, const VptqSlicedLayout* layouts, int n,
+                                   const void* x, void* const* y, int flags, void* const* workspaces,
+                                   const size_t* workspace_bytes, void* stream);
+
 /* W[O, I] dense, row-major, desc->dtype: the reference CPU path's bits. */
 VPTQ_API int vptq_dequant(const VptqLayerDesc* desc, void* W, void* stream);
 

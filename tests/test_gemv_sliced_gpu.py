@@ -371,3 +371,50 @@ def test_two_and_three_tokens_as_sliced_launches_per_token(dev, monkeypatch):
     for t in range(3):
         assert torch.equal(ys[:, t].view(torch.int16), sls(xst[:, t:t + 1].contiguous()).view(torch.int16)[0])
     assert rel_err(tensor_to_bits(ys), vo.forward(Ls, xs), "f16") <= 1e-3
+
+
+@pytest.mark.parametrize("v,kr", [(8, 256), (8, 0), (8, 65536), (16, 65536), (16, 1024)])
+def test_sibling_layers_share_one_sliced_launch(v, kr, dev):
+    """q / k / v (gate / up) of a large-codebook model read the same activation: one launch of the sliced kernel for the
+    group (`vptq_quant_gemv_sliced_grouped` via `SiblingGroup.forward_sliced`), bit-identical to the layers' own launches
+    (a row's sums are formed by one wave in the same order whatever the rows per wave; the cross-slice sum is a fixed tree)"""
+    from vptq_amd.layers.vqlinear import SiblingGroup
+    from vptq_amd.utils.sliced import SlicedGemv, SlicedGroupGemv
+    I = 2048
+    outs = (1024, 33 * v, 512)     # (33 vector-rows: the load-time gate serves layers with fewer than 32 by the exact kernels)
+    Ls = [vo.make_layer(I, O, dist="llm", seed=70 + i + kr % 7, vector_len=v, num_centroids=65536, num_res_centroids=kr,
+                        bias=(i == 1), enable_perm=(i == 2)) for i, O in enumerate(outs)]
+    ms = [spec_to_module(L, dev) for L in Ls]
+    x = _x(I, "f16", "llm", 11)
+    xt = bits_to_tensor(x, "f16", dev).reshape(x.shape)
+    for m in ms:
+        m.enable_sliced_layout()
+    alone = [SlicedGemv(m)(xt) for m in ms]
+    group = SiblingGroup(ms)
+    for m in ms:
+        object.__setattr__(m, "_siblings", group)
+    ys = [m(xt) for m in ms]                       # the first call launches all three
+    torch.cuda.synchronize()
+    assert isinstance(group.__dict__.get("_sgroup"), tuple) and isinstance(group._sgroup[1], SlicedGroupGemv)
+    for L, y, a in zip(Ls, ys, alone):
+        assert torch.equal(y.view(torch.int16), a.view(torch.int16))
+        assert rel_err(tensor_to_bits(y), vo.forward(L, x), "f16") <= 1e-3
+    # a new activation object: a new launch; the same object with other contents (version bumped): also
+    x2 = bits_to_tensor(_x(I, "f16", "llm", 12), "f16", dev).reshape(x.shape)
+    y2 = [m(x2) for m in ms]
+    assert rel_err(tensor_to_bits(y2[1]), vo.forward(Ls[1], tensor_to_bits(x2)), "f16") <= 1e-3
+    x2.copy_(xt)
+    y3 = [m(x2) for m in ms]
+    for y, a in zip(y3, alone):
+        assert torch.equal(y.view(torch.int16), a.view(torch.int16))
+    # in a hipGraph (warm-up on the capture stream)
+    g, s = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        [m(xt) for m in ms]
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=s):
+            yg = [m(xt) for m in ms]
+    g.replay()
+    torch.cuda.synchronize()
+    for y, a in zip(yg, alone):
+        assert torch.equal(y.view(torch.int16), a.view(torch.int16))

@@ -432,6 +432,37 @@ int vptq_quant_gemv_sliced(const VptqLayerDesc* d, const VptqSlicedLayout* layou
   return e == hipSuccess ? VPTQ_OK : hip_fail(e, "gemv_sliced launch");
 }
 
+int vptq_quant_gemv_sliced_grouped(const VptqLayerDesc* descs, const VptqSlicedLayout* layouts, int n, const void* x,
+                                   void* const* y, int flags, void* const* workspaces, const size_t* workspace_bytes, void* stream) {
+  if (!descs || !layouts || !x || !y || !workspaces || !workspace_bytes) return fail(VPTQ_E_NULL, "descs / layouts / x / y / workspaces is NULL");
+  if (n < 1 || n > 3) return fail(VPTQ_E_SHAPE, "n %d outside [1, 3]", n);
+  for (int i = 0; i < n; ++i) {
+    const int rc = validate_layer(&descs[i]);
+    if (rc) return rc;
+    if (!y[i]) return fail(VPTQ_E_NULL, "y[%d] is NULL", i);
+  }
+  if (!vptq::gemv_sliced_groupable(descs, n))
+    return fail(VPTQ_E_UNSUPPORTED, "a sliced group takes layers of ONE format, dtype and input width that vptq_sliced_layout_supported() accepts");
+  if (flags & (VPTQ_GEMV_EXACT | VPTQ_GEMV_FORCE_GENERIC))
+    return fail(VPTQ_E_UNSUPPORTED, "the sliced path has the folded arithmetic only: use vptq_quant_gemv");
+  if ((((uintptr_t)x) & 15) != 0) return fail(VPTQ_E_UNSUPPORTED, "x must be 16-byte aligned");
+  const int tables = vptq::gemv_sliced_tables(descs[0]);
+  for (int i = 0; i < n; ++i) {
+    const size_t need = vptq::gemv_sliced_workspace_bytes(descs[i]);
+    if (!workspaces[i] || workspace_bytes[i] < need || (((uintptr_t)workspaces[i]) & 15) != 0)
+      return fail(VPTQ_E_WORKSPACE, "layer %d: workspace of %zu bytes (16-byte aligned) needed", i, need);
+    for (int t = 0; t < tables; ++t) {
+      const VptqSlicedLayout& L = layouts[(size_t)i * tables + t];
+      if (L.rows_per_wave < 1 || L.rows_per_wave > 64 || !L.elems || !L.blocks || !L.first ||
+          (L.n_slices != 0 ? L.n_slices : 8) != vptq::gemv_sliced_slices(descs[i]))
+        return fail(VPTQ_E_UNSUPPORTED, "layer %d, sliced layout %d: rows_per_wave in [1, 64], three tensors, n_slices = %d", i, t,
+                    vptq::gemv_sliced_slices(descs[i]));
+    }
+  }
+  const hipError_t e = vptq::launch_gemv_sliced_group(descs, layouts, n, x, y, flags, workspaces, (hipStream_t)stream);
+  return e == hipSuccess ? VPTQ_OK : hip_fail(e, "gemv_sliced grouped launch");
+}
+
 size_t vptq_quant_gemm_workspace_bytes(const VptqLayerDesc* d, int tokens) {
   if (validate_layer(d) != VPTQ_OK || tokens < 1) return 0;
   return vptq::gemm_fused_workspace_bytes(*d, tokens);

@@ -83,6 +83,16 @@ struct SlicedParams {
   int N, G, O, rows_per_wave, n_rowblocks, out_f32;
 };
 
+// Up to kSLMaxGroup layers that read the SAME activation (q / k / v, gate / up) in one launch: layer l owns the workgroups
+// [start[l], start[l + 1]).  One launch instead of n: the fixed part of a launch (boundary, slice copy, staging, the
+// cross-slice hand-over: ~7 of the 10 us of a 4096 x 4096 layer) is paid once.
+constexpr int kSLMaxGroup = 3;
+struct SlicedGroupParams {
+  int n;
+  int start[kSLMaxGroup + 1];
+  SlicedParams p[kSLMaxGroup];
+};
+
 // f(slot 0), ... f(slot kSLQueue - 1) with the slot as a compile-time constant
 template <int I0, int I1, typename F>
 static __device__ __forceinline__ void sl_for_range(F&& f) {
@@ -96,7 +106,22 @@ template <int Q, typename F>
 static __device__ __forceinline__ void sl_for_slots(F&& f) { sl_for_range<0, Q>(f); }
 
 template <typename DT, int NSL, bool RES, int V = 8, bool TWO = false>
-__global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedParams P) {
+__global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGroupParams GP) {
+  // this workgroup's layer; its parameters come out of the kernel-argument segment through the scalar cache (a run-time
+  // index into the by-value argument would make the compiler copy it to scratch memory)
+  int layer = 0;
+  if (GP.n > 1 && (int)blockIdx.x >= GP.start[1]) layer = 1;
+  if (GP.n > 2 && (int)blockIdx.x >= GP.start[2]) layer = 2;
+  layer = __builtin_amdgcn_readfirstlane(layer);
+  const int bx = (int)blockIdx.x - (layer == 0 ? 0 : layer == 1 ? GP.start[1] : GP.start[2]);
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef const char __attribute__((address_space(4)))* sl_kernarg_t;
+  typedef const SlicedParams __attribute__((address_space(4)))* sl_params_t;
+  const SlicedParams P = *(sl_params_t)((sl_kernarg_t)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(SlicedGroupParams, p) +
+                                         (size_t)layer * sizeof(SlicedParams));
+#else
+  const SlicedParams P = GP.p[0];   // (host pass of the compiler: never executed)
+#endif
   static_assert(((V == 8 && (NSL == 8 || NSL == 16)) || (V == 16 && (NSL == 16 || NSL == 32))) && (V == 8 || !RES) && !(TWO && RES), "slices");
   constexpr int NSLT = TWO ? 2 * NSL : NSL;   // workgroups per row block: one per (table, slice)
   constexpr int EPL = 1;   // element words per lane and block (2 and 4 - 8 / 16-byte loads - were measured: no difference)
@@ -112,7 +137,7 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedPar
   }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int sg = (int)blockIdx.x & (NSLT - 1), rb = (int)blockIdx.x / NSLT;
+  const int sg = bx & (NSLT - 1), rb = bx / NSLT;
   const int s = sg & (NSL - 1);
   const bool second = TWO && sg >= NSL;   // (uniform over the workgroup) this workgroup gathers from the residual table
   const uint32_t* const elems_t = second ? P.elems2 : P.elems;
@@ -475,7 +500,7 @@ static size_t sl_counter_bytes(const VptqLayerDesc& d) {
 size_t gemv_sliced_workspace_bytes(const VptqLayerDesc& d) { return sl_partial_bytes(d) + sl_counter_bytes(d); }
 
 template <typename DT, int NSL, bool RES, int V, bool TWO>
-static hipError_t launch_sl(const SlicedParams& P, uint32_t lds, hipStream_t st) {
+static hipError_t launch_sl(const SlicedGroupParams& P, uint32_t lds, hipStream_t st) {
   auto kern = gemv_sliced_kernel<DT, NSL, RES, V, TWO>;
   static std::atomic<bool> attr_set[64];
   int dev = 0;
@@ -485,11 +510,11 @@ static hipError_t launch_sl(const SlicedParams& P, uint32_t lds, hipStream_t st)
     if (e != hipSuccess) return e;
     attr_set[dev] = true;
   }
-  hipLaunchKernelGGL(kern, dim3((TWO ? 2 : 1) * NSL * P.n_rowblocks), dim3(kSLThreads), lds, st, P);
+  hipLaunchKernelGGL(kern, dim3(P.start[P.n]), dim3(kSLThreads), lds, st, P);
   return hipGetLastError();
 }
 template <typename DT>
-static hipError_t launch_sl_dt(const SlicedParams& P, int v, int nsl, bool res, bool two, uint32_t lds, hipStream_t st) {
+static hipError_t launch_sl_dt(const SlicedGroupParams& P, int v, int nsl, bool res, bool two, uint32_t lds, hipStream_t st) {
   if (v == 16) {
     if (two) return nsl == 16 ? launch_sl<DT, 16, false, 16, true>(P, lds, st) : launch_sl<DT, 32, false, 16, true>(P, lds, st);
     return nsl == 16 ? launch_sl<DT, 16, false, 16, false>(P, lds, st) : launch_sl<DT, 32, false, 16, false>(P, lds, st);
@@ -511,8 +536,8 @@ static bool sl_layout_ok(const VptqLayerDesc& d, const VptqSlicedLayout& L, int 
 // (slice, row block) workgroups run beside the main table's in the SAME launch and meet them in the cross-slice sum - two
 // launches, one per table, cost a second boundary, a second epilogue and half the workgroups in flight (8192^2: 27.2 us
 // against 21.2; 4096^2: 17.8 against 12.0)
-hipError_t launch_gemv_sliced(const VptqLayerDesc& d, const VptqSlicedLayout* L, const void* x, void* y, int flags,
-                              void* ws, hipStream_t st) {
+static hipError_t sl_fill(const VptqLayerDesc& d, const VptqSlicedLayout* L, const void* x, void* y, int flags, void* ws,
+                          SlicedParams& P, uint32_t& lds) {
   const bool res = sl_res256(d), two = sl_two(d);
   const int nsl = gemv_sliced_slices(d);
   if (!sl_layout_ok(d, L[0], nsl, res, d.num_centroids) || L[0].whole_table != 0 ||
@@ -520,7 +545,7 @@ hipError_t launch_gemv_sliced(const VptqLayerDesc& d, const VptqSlicedLayout* L,
                L[1].whole_table != gemv_sliced_whole_table(d, 1))) ||
       !ws || (((uintptr_t)x) & 15) != 0)
     return hipErrorInvalidValue;
-  SlicedParams P = {};
+  P = SlicedParams{};
   P.elems = (const uint32_t*)L[0].elems;
   P.res = res ? (const uint8_t*)L[0].res : nullptr;
   P.rcent = res ? (const uint32_t*)d.res_centroids : nullptr;
@@ -551,10 +576,47 @@ hipError_t launch_gemv_sliced(const VptqLayerDesc& d, const VptqSlicedLayout* L,
   const int rows_per_wg = kSLWaves * L[0].rows_per_wave;
   P.n_rowblocks = (d.num_indices + rows_per_wg - 1) / rows_per_wg;
   P.out_f32 = (flags & VPTQ_GEMV_OUT_F32) ? 1 : 0;
-  const uint32_t lds = P.x_off + (uint32_t)(d.group_size + 64) * 2u + 64u + (res ? 4096u : 0u);
-  if (lds > kSLLdsLimit) return hipErrorInvalidValue;
-  return d.dtype == VPTQ_DTYPE_F16 ? launch_sl_dt<F16>(P, d.vector_len, nsl, res, two, lds, st)
-                                   : launch_sl_dt<BF16>(P, d.vector_len, nsl, res, two, lds, st);
+  lds = P.x_off + (uint32_t)(d.group_size + 64) * 2u + 64u + (res ? 4096u : 0u);
+  return lds > kSLLdsLimit ? hipErrorInvalidValue : hipSuccess;
+}
+
+// n <= kSLMaxGroup layers of ONE format (vector length, slices, residual kind, dtype) and one input width reading the same x:
+// layouts = the layers' layout structs one after the other (1 or 2 each); one launch
+bool gemv_sliced_groupable(const VptqLayerDesc* d, int n) {
+  if (n < 1 || n > kSLMaxGroup) return false;
+  for (int i = 0; i < n; ++i) {
+    if (!gemv_sliced_eligible(d[i])) return false;
+    if (d[i].dtype != d[0].dtype || d[i].vector_len != d[0].vector_len || d[i].group_size != d[0].group_size ||
+        gemv_sliced_slices(d[i]) != gemv_sliced_slices(d[0]) || sl_res256(d[i]) != sl_res256(d[0]) || sl_two(d[i]) != sl_two(d[0]))
+      return false;
+  }
+  return true;
+}
+hipError_t launch_gemv_sliced_group(const VptqLayerDesc* d, const VptqSlicedLayout* L, int n, const void* x, void* const* y,
+                                    int flags, void* const* ws, hipStream_t st) {
+  if (!gemv_sliced_groupable(d, n)) return hipErrorInvalidValue;
+  SlicedGroupParams GP = {};
+  GP.n = n;
+  uint32_t lds = 0;
+  const int tables = gemv_sliced_tables(d[0]);
+  const int nslt = gemv_sliced_slices(d[0]) * tables;
+  for (int i = 0; i < n; ++i) {
+    uint32_t l = 0;
+    const hipError_t e = sl_fill(d[i], L + (size_t)i * tables, x, y[i], flags, ws[i], GP.p[i], l);
+    if (e != hipSuccess) return e;
+    lds = l > lds ? l : lds;
+    GP.start[i + 1] = GP.start[i] + nslt * GP.p[i].n_rowblocks;
+  }
+  for (int i = n; i < kSLMaxGroup; ++i) GP.start[i + 1] = GP.start[n];
+  return d[0].dtype == VPTQ_DTYPE_F16
+             ? launch_sl_dt<F16>(GP, d[0].vector_len, gemv_sliced_slices(d[0]), sl_res256(d[0]), sl_two(d[0]), lds, st)
+             : launch_sl_dt<BF16>(GP, d[0].vector_len, gemv_sliced_slices(d[0]), sl_res256(d[0]), sl_two(d[0]), lds, st);
+}
+hipError_t launch_gemv_sliced(const VptqLayerDesc& d, const VptqSlicedLayout* L, const void* x, void* y, int flags,
+                              void* ws, hipStream_t st) {
+  void* const ys[1] = {y};
+  void* const wss[1] = {ws};
+  return launch_gemv_sliced_group(&d, L, 1, x, ys, flags, wss, st);
 }
 
 }  // namespace vptq

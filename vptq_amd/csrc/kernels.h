@@ -61,6 +61,10 @@ int gemv_sliced_whole_table(const VptqLayerDesc& d, int table);   // VptqSlicedL
 size_t gemv_sliced_workspace_bytes(const VptqLayerDesc& d);
 hipError_t launch_gemv_sliced(const VptqLayerDesc& d, const VptqSlicedLayout* L, const void* x, void* y, int flags,
                               void* ws, hipStream_t st);
+// up to 3 layers of one format reading the same x (q / k / v, gate / up) in one launch
+bool gemv_sliced_groupable(const VptqLayerDesc* d, int n);
+hipError_t launch_gemv_sliced_group(const VptqLayerDesc* d, const VptqSlicedLayout* L, int n, const void* x, void* const* y,
+                                    int flags, void* const* ws, hipStream_t st);
 // gemm_k256t.hip - canonical format, fp16 / bf16, up to 16 tokens in one pass over the indices (transposing
 // gather -> 16x16x32 MFMA with tokens as M; folded arithmetic; needs a workspace for the operand-ordered activations)
 bool gemm_k256t_eligible(const VptqLayerDesc& d, int tokens, int flags);

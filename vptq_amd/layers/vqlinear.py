@@ -77,6 +77,39 @@ class SiblingGroup:
         self._out = {}
         self._arrays = None
 
+    def forward_sliced(self, layer, x):
+        """one token of large-codebook siblings over their sliced layouts: ONE launch for the group
+        (`vptq_amd/utils/sliced.py:SlicedGroupGemv`); same protocol as `forward` - the first member called launches, the
+        others pick their output up when they are called with the very same tensor.  None = not this group's route (a
+        member without a layout, mixed formats, a tensor without version counter, ...): the caller goes on alone."""
+        ver = B.tensor_version(x)
+        if ver >= 0 and self.__dict__.get("_sx") is x and ver == self._sversion and id(layer) in self._sout:
+            y = self._sout.pop(id(layer))
+            if not self._sout:
+                self._sx = None
+            return y
+        if ver < 0 or self.__dict__.get("_sgroup") is False:
+            return None
+        sls = [m._sliced_gemv() for m in self.members]
+        if any(sl is None for sl in sls):
+            return None
+        key = tuple(id(sl) for sl in sls)
+        sg = self.__dict__.get("_sgroup")
+        if sg is None or sg[0] != key:
+            from vptq_amd.utils.sliced import SlicedGroupGemv
+            try:
+                sg = (key, SlicedGroupGemv(sls))
+            except ValueError:
+                self._sgroup = False      # (mixed formats: every member launches for itself)
+                return None
+            self._sgroup = sg
+        ys = sg[1](x)
+        if ys is None:
+            return None
+        self._sx, self._sversion, self._keep_sx = x, ver, x
+        self._sout = {id(m): y for m, y in zip(self.members, ys) if m is not layer}
+        return ys[self.members.index(layer)]
+
     def forward(self, layer, x, tokens):
         # Tensors made under inference_mode track no version (-1): whether x was rewritten in place since the
         # leader's launch cannot be told then, so sibling outputs are not reused at all - every layer launches
@@ -463,6 +496,11 @@ class VQuantLinear(nn.Module):
             sl = self._sliced_gemv() if self.__dict__["_sliced_cand"] else None
             if sl is not None and not (ops.quant_gemm_flags() & (B.GEMV_EXACT | B.GEMV_FORCE_GENERIC)):
                 if tokens == 1:
+                    sib = self.__dict__.get("_siblings")
+                    if sib is not None:      # q / k / v, gate / up: one sliced launch for the group
+                        y = sib.forward_sliced(self, x)
+                        if y is not None:
+                            return y
                     y = sl(x)
                     if y is not None:   # (None: misaligned activation, capture on a stream the layer has not run on, ...)
                         return y

@@ -190,3 +190,62 @@ class SlicedGemv:
             self._ws.pop(sp, None)
             B.check(rc, "vptq_quant_gemv_sliced")
         return out
+
+
+class SlicedGroupGemv:
+    """One token through up to 3 sibling layers (q / k / v, gate / up: one format, one input width, the SAME activation)
+    in ONE launch of the sliced kernel (`vptq_quant_gemv_sliced_grouped`): the fixed part of a sliced launch - boundary,
+    slice copy, staging, the cross-slice hand-over: ~7 of the 10 us of a 4096 x 4096 layer - is paid once.  `members`:
+    the layers' `SlicedGemv` objects (their tensors are shared, only the rows per wave are the group's)."""
+
+    def __init__(self, members):
+        self.members = list(members)
+        n = len(self.members)
+        m0 = self.members[0]
+        tables = len(m0.layout)
+        if not 1 <= n <= 3 or any(len(m.layout) != tables or m.slices != m0.slices or m._dtype != m0._dtype or m.dev != m0.dev or
+                                  m.layer.in_features != m0.layer.in_features for m in self.members):
+            raise ValueError("a sliced group takes 1..3 layers of one format, dtype, device and input width")
+        rpw = rows_per_wave_for(sum(m.blocks.shape[1] for m in self.members), m0.slices * tables)   # one round of workgroups over ALL layers
+        structs = [B.SlicedLayout(e.data_ptr(), b.data_ptr(), f.data_ptr(), r.data_ptr() if r is not None else None, rpw, 1, m.slices, int(w))
+                   for m in self.members for (e, b, f, r), w in zip(m._tensors, m._whole)]
+        self.layouts = (B.SlicedLayout * len(structs))(*structs)
+        self.descs = (B.LayerDesc * n)(*[m.desc for m in self.members])
+        self._yp, self._wp = (C.c_void_p * n)(), (C.c_void_p * n)()
+        self._wb = (C.c_size_t * n)(*[m._ws_bytes for m in self.members])
+        self._fn = B.lib().vptq_quant_gemv_sliced_grouped
+        self.dev, self._dtype, self._dev_index = m0.dev, m0._dtype, m0._dev_index
+
+    def __call__(self, x: torch.Tensor):
+        """list of outputs (one per member), or None where the call cannot take the sliced kernel (as SlicedGemv.__call__)"""
+        lay = self.members[0].layer
+        if x.shape[-1] != lay.in_features or x.numel() != lay.in_features:
+            raise ValueError("the sliced path takes one token of in_features values")
+        if x.dtype != self._dtype or x.device != self.dev:
+            x = lay._check_activation(x)
+        if not x.is_contiguous():
+            x = x.contiguous()
+        if x.data_ptr() & 15:
+            return None
+        if torch.cuda.current_device() != self._dev_index:
+            with torch.cuda.device(self.dev):
+                return self._launch(x)
+        return self._launch(x)
+
+    def _launch(self, x):
+        sp = B.current_stream_ptr(self.dev)
+        wss = [m._workspace(sp) for m in self.members]
+        if any(w is None for w in wss):
+            return None
+        ys = [torch.empty(x.shape[:-1] + (m.layer.out_features,), dtype=self._dtype, device=self.dev) for m in self.members]
+        for i, (y, w) in enumerate(zip(ys, wss)):
+            self._yp[i] = y.data_ptr()
+            self._wp[i] = w.data_ptr()
+        rc = self._fn(self.descs, self.layouts, len(ys), x.data_ptr(), self._yp, 0, self._wp, self._wb, sp)
+        if rc == B.E_UNSUPPORTED:
+            return None
+        if rc:
+            for m in self.members:
+                m._ws.pop(sp, None)
+            B.check(rc, "vptq_quant_gemv_sliced_grouped")
+        return ys
