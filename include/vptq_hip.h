@@ -243,6 +243,10 @@ VPTQ_API int vptq_quant_gemv_chain(const VptqLayerDesc* descs, int n, const void
                           void* const* y, int tokens, int flags, void* workspace,
                           size_t workspace_bytes, void* stream);
 VPTQ_API size_t vptq_quant_gemv_chain_workspace_bytes(int n, int flags);
+/* the same + (independent lists, ABI >= 7) room for x[perm] of every layer with an input permutation: with that much
+ * 256-byte aligned workspace such layers stay in the persistent launch (x is gathered by one small launch in front of
+ * it); with less they are served by grouped / single launches, which apply permutations themselves */
+VPTQ_API size_t vptq_quant_gemv_chain_workspace_bytes_for(const VptqLayerDesc* descs, int n, int flags);
 VPTQ_API const char* vptq_quant_gemv_chain_kernel_name(const VptqLayerDesc* descs, int n, int tokens,
                                               int flags);
 

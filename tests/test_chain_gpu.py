@@ -252,3 +252,47 @@ def test_chain_of_32_distinct_8192_layers_every_output(exact, dev):
         if exact:
             assert bit_identical_frac(tensor_to_bits(y), want) >= 0.99, f"layer {i}"
     print(f"32 distinct 8192^2 layers, exact={exact}: worst {worst:.2e}")
+
+
+def test_chain_takes_layers_with_an_input_permutation(dev):
+    """un-absorbed permutations must not drop a list to one launch per layer.  With the workspace
+    `vptq_quant_gemv_chain_workspace_bytes_for` asks for (GemvChain provides it) x[perm] is gathered by one small launch in
+    front of the persistent launch, which then runs on (x[perm], scale_permuted, bias_permuted); results = the layers' own
+    forward.  Incl. one token of the reference's golden with perm + bias at hidden 4096."""
+    from vptq_amd.ops.chain import GemvChain
+    shapes = [(1024, 512, dict(dist="llm", enable_perm=True)), (4096, 264, dict(enable_perm=True, bias=True)),
+              (2048, 2048, dict(dist="llm")), (4104, 64, dict(enable_perm=True)), (512, 1000, dict(dist="llm", enable_perm=True, bias=True))]
+    Ls, ms, xs = _build(shapes, "f16", dev)
+    chain = GemvChain(ms)
+    assert chain.kernel_name(1, CHAIN) == "gemv_k256c_kernel"
+    xt = [bits_to_tensor(x, "f16", dev).reshape(x.shape) for x in xs]
+    ys = chain(xt, flags=CHAIN)
+    torch.cuda.synchronize()
+    for L, m, x, xg, y in zip(Ls, ms, xs, xt, ys):
+        assert rel_err(tensor_to_bits(y), vo.forward(L, x), "f16") <= 1e-3, f"{L.in_features}x{L.out_features}"
+        assert rel_err(tensor_to_bits(y), tensor_to_bits(gemv_abi(m, xg, 0)), "f16") <= 1e-3
+    ys2 = chain(xt, flags=CHAIN)      # (the workspace is reused: same bits)
+    for a, b in zip(ys, ys2):
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+    # the reference's golden with perm + bias (2 tokens in the fixture: one of them here), 8 times in one launch
+    L, x, y, cfg, _ = load_big("h4096_f16_llm_perm_bias_t2")
+    m = spec_to_module(L, dev)
+    x0 = bits_to_tensor(x[:, :1], "f16", dev).reshape(1, 1, -1)
+    c8 = GemvChain([m] * 9)
+    assert c8.kernel_name(1, 0) == "gemv_k256c_kernel"     # (9 layers of 4096^2 fill the device: no FORCE flag)
+    out = c8([x0] * 9)
+    torch.cuda.synchronize()
+    assert rel_err(tensor_to_bits(out[0]), y[:, :1], "f16") <= 1e-3
+    for o in out[1:]:
+        assert torch.equal(o.view(torch.int16), out[0].view(torch.int16))
+    # in a hipGraph
+    g, s = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        chain(xt, flags=CHAIN)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=s):
+            yg = chain(xt, flags=CHAIN)
+    g.replay()
+    torch.cuda.synchronize()
+    for a, b in zip(ys, yg):
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16))

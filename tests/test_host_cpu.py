@@ -86,7 +86,12 @@ def test_chain_routing_without_gpu():
     assert name([small]) == b"per-layer"                       # one layer: the one-layer kernels
     assert name([small], flags=B.GEMV_FORCE_MFMA) == b"gemv_k256c_kernel"    # ... unless asked for
     assert name([big] * 32, tokens=2) == b"grouped"            # (any list of <= 64 layers the persistent kernel does not take)
-    assert name([big] * 31 + [_canonical_desc(8192, 8192, perm=True)]) == b"grouped"
+    # (round 4: a layer with an input permutation stays in the persistent launch - x[perm] is gathered into the workspace
+    # vptq_quant_gemv_chain_workspace_bytes_for asks for by a small launch in front of it)
+    assert name([big] * 31 + [_canonical_desc(8192, 8192, perm=True)]) == b"gemv_k256c_kernel"
+    assert lib.vptq_quant_gemv_chain_workspace_bytes_for((B.LayerDesc * 2)(big, _canonical_desc(8192, 8192, perm=True)), 2, 0) == 16384
+    assert lib.vptq_quant_gemv_chain_workspace_bytes_for((B.LayerDesc * 2)(big, big), 2, 0) == 0
+    assert name([big] * 31 + [_canonical_desc(8192, 8192, perm=True)], flags=B.GEMV_CHAIN_DEPENDENT) == b"per-layer"
     assert name([big] * 31 + [_canonical_desc(8192, 8192, dtype=1)]) == b"per-layer"   # mixed dtypes
     assert name([_canonical_desc(8192, 1024)] * 3, flags=B.GEMV_CHAIN_DEPENDENT) == b"per-layer"
     # the reference's roundings inside the chain launch (round 4): fp16, independent layers

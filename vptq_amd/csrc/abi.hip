@@ -1,5 +1,6 @@
 // C ABI of libvptq_hip.so (declared in include/vptq_hip.h): argument validation,
 // kernel selection, launch.  No allocation, no synchronisation, no torch.
+#include <vector>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -310,6 +311,14 @@ static bool chain_one_kernel(const VptqLayerDesc* descs, int n, const void* cons
 size_t vptq_quant_gemv_chain_workspace_bytes(int n, int flags) {
   return (flags & VPTQ_GEMV_CHAIN_DEPENDENT) && n > 0 ? (size_t)n * 1024 : 0;   // 256 arrival flags per layer
 }
+// ... and, for an INDEPENDENT list, room for x[perm] of every layer that has an input permutation (optional: without it
+// such a list is served by grouped / single launches, which take permutations themselves)
+size_t vptq_quant_gemv_chain_workspace_bytes_for(const VptqLayerDesc* descs, int n, int flags) {
+  size_t b = vptq_quant_gemv_chain_workspace_bytes(n, flags);
+  if (!descs || n < 1 || (flags & VPTQ_GEMV_CHAIN_DEPENDENT)) return b;
+  for (int i = 0; i < n; ++i) b += vptq::gemv_k256c_perm_bytes(descs[i]);
+  return b;
+}
 
 // How a chain call is executed.  The persistent launch pays its prologue (first codebook image, queue fill: ~7 us)
 // once per call and wins from ~16 independent layers on; up to 8 it loses to ONE grouped launch of the one-layer
@@ -336,6 +345,21 @@ const char* vptq_quant_gemv_chain_kernel_name(const VptqLayerDesc* descs, int n,
   if (!descs || n < 1 || n > VPTQ_CHAIN_MAX || tokens < 1 || tokens > VPTQ_GEMV_MAX_TOKENS) return nullptr;
   for (int i = 0; i < n; ++i)
     if (validate_layer(&descs[i]) != VPTQ_OK) return nullptr;
+  if (!(flags & VPTQ_GEMV_CHAIN_DEPENDENT) && tokens == 1) {
+    // (as vptq_quant_gemv_kernel_name: assuming the caller hands over the workspace ..._workspace_bytes_for asks for -
+    // layers with an input permutation then stay in the persistent launch)
+    bool any = false, ok = true;
+    std::vector<VptqLayerDesc> dd(descs, descs + n);
+    for (int i = 0; i < n; ++i) {
+      if (!dd[i].perm) continue;
+      any = true;
+      ok = ok && dd[i].scale_permuted && dd[i].bias_permuted && (dd[i].in_features % 8) == 0 && (((uintptr_t)dd[i].perm) & 15) == 0;
+      dd[i].weight_scale = dd[i].scale_permuted;
+      dd[i].weight_bias = dd[i].bias_permuted;
+      dd[i].perm = nullptr; dd[i].inv_perm = nullptr; dd[i].scale_permuted = nullptr; dd[i].bias_permuted = nullptr;
+    }
+    if (any && ok && chain_route(dd.data(), n, nullptr, tokens, flags) == kChainPersistent) return "gemv_k256c_kernel";
+  }
   switch (chain_route(descs, n, nullptr, tokens, flags)) {
     case kChainPersistent: return "gemv_k256c_kernel";
     case kChainGrouped: return "grouped";
@@ -357,6 +381,39 @@ int vptq_quant_gemv_chain(const VptqLayerDesc* descs, int n, const void* const* 
   const bool dependent = (flags & VPTQ_GEMV_CHAIN_DEPENDENT) != 0;
   const int lflags = flags & ~VPTQ_GEMV_CHAIN_DEPENDENT;
   hipStream_t st = (hipStream_t)stream;
+  // Layers with an input permutation in an independent list: with enough workspace for x[perm] the list still runs in the
+  // persistent launch - on (x[perm], scale_permuted, bias_permuted), gathered by one small launch in front of it.
+  if (!dependent && tokens == 1) {
+    size_t need = 0;
+    for (int i = 0; i < n; ++i) need += vptq::gemv_k256c_perm_bytes(descs[i]);
+    if (need > 0 && workspace && workspace_bytes >= need && (((uintptr_t)workspace) & 255) == 0) {
+      std::vector<VptqLayerDesc> dd(descs, descs + n);
+      std::vector<const void*> xx(x, x + n);
+      std::vector<void*> xp(n, nullptr);
+      char* w = (char*)workspace;
+      bool ok = true;
+      for (int i = 0; i < n; ++i) {
+        if (!dd[i].perm) continue;
+        ok = ok && dd[i].scale_permuted && dd[i].bias_permuted && (dd[i].in_features % 8) == 0 && (((uintptr_t)dd[i].perm) & 15) == 0;
+        xp[i] = w;
+        xx[i] = w;
+        w += vptq::gemv_k256c_perm_bytes(dd[i]);
+        dd[i].weight_scale = dd[i].scale_permuted;
+        dd[i].weight_bias = dd[i].bias_permuted;
+        dd[i].perm = nullptr; dd[i].inv_perm = nullptr; dd[i].scale_permuted = nullptr; dd[i].bias_permuted = nullptr;
+      }
+      if (ok && chain_route(dd.data(), n, xx.data(), tokens, flags) == kChainPersistent) {
+        for (int i0 = 0; i0 < n; i0 += 32) {
+          const int m = n - i0 < 32 ? n - i0 : 32;
+          hipError_t e = vptq::launch_permute_x(descs + i0, m, x + i0, xp.data() + i0, st);
+          if (e != hipSuccess) return hip_fail(e, "permute_x launch");
+          e = vptq::launch_gemv_k256c(dd.data() + i0, m, xx.data() + i0, y + i0, lflags, false, nullptr, st);
+          if (e != hipSuccess) return hip_fail(e, "gemv_k256c launch");
+        }
+        return VPTQ_OK;
+      }
+    }
+  }
   const ChainRoute route = chain_route(descs, n, x, tokens, flags);
   if (route == kChainGrouped)   // independent layers, one launch (it serves members it has no kernel for one by one)
     return vptq_quant_gemv_grouped(descs, n, x, y, tokens, lflags & ~VPTQ_GEMV_FORCE_MFMA, stream);

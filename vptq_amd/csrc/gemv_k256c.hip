@@ -1169,6 +1169,66 @@ bool gemv_k256c_exact_ok(const VptqLayerDesc& d, bool dependent) {
   return d.dtype == VPTQ_DTYPE_F16 && !dependent && VPTQ_K256C_PROF < 2;
 }
 
+// ---- layers with an input permutation: x is gathered ONCE into the caller's workspace (xp[c] = x[perm[c]]) by a small
+// launch in front of the chain launch, which then runs on (xp, scale_permuted, bias_permuted) without a permutation: the
+// chain kernel's LDS is full (two 64 KiB codebook images), and a gather inside its load queue would put a dependent load -
+// perm, then x - in front of every sweep.  (The reference applies `perm` inline, csrc/kernels/quant_gemv.cuh:53-54.)
+struct PermXParams {
+  int n;
+  int start[kMaxGroup + 1];          // first workgroup of layer l
+  const uint16_t* x[kMaxGroup];
+  const uint16_t* perm[kMaxGroup];
+  uint16_t* out[kMaxGroup];
+  int I[kMaxGroup];
+};
+__global__ __launch_bounds__(256) void permute_x_kernel(const PermXParams P) {
+  int l = 0;
+  for (int i = 1; i < P.n; ++i)
+    if ((int)blockIdx.x >= P.start[i]) l = i;
+  l = __builtin_amdgcn_readfirstlane(l);
+  // (layer fields through the scalar cache: constant-address-space loads with a uniform index)
+  typedef const char __attribute__((address_space(4)))* ka_t;
+#if defined(__HIP_DEVICE_COMPILE__)
+  const ka_t base = (ka_t)__builtin_amdgcn_kernarg_segment_ptr();
+  const uint16_t* const x = *(const uint16_t* const __attribute__((address_space(4)))*)(base + offsetof(PermXParams, x) + (size_t)l * 8);
+  const uint16_t* const perm = *(const uint16_t* const __attribute__((address_space(4)))*)(base + offsetof(PermXParams, perm) + (size_t)l * 8);
+  uint16_t* const out = *(uint16_t* const __attribute__((address_space(4)))*)(base + offsetof(PermXParams, out) + (size_t)l * 8);
+  const int I = *(const int __attribute__((address_space(4)))*)(base + offsetof(PermXParams, I) + (size_t)l * 4);
+  const int b0 = *(const int __attribute__((address_space(4)))*)(base + offsetof(PermXParams, start) + (size_t)l * 4);
+#else
+  const uint16_t* const x = P.x[0]; const uint16_t* const perm = P.perm[0]; uint16_t* const out = P.out[0];
+  const int I = P.I[0], b0 = P.start[0];
+#endif
+  const int c0 = (((int)blockIdx.x - b0) * 256 + (int)threadIdx.x) * 8;
+  if (c0 >= I) return;   // (I is a multiple of 8: whole groups of 8 columns)
+  const u32x4 pv = *(const u32x4*)(as_global(perm) + c0);
+  u32x4 r;
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    r[q] = (uint32_t)as_global(x)[pv[q] & 0xffffu] | ((uint32_t)as_global(x)[pv[q] >> 16] << 16);
+  *(u32x4*)(as_global(out) + c0) = r;
+}
+size_t gemv_k256c_perm_bytes(const VptqLayerDesc& d) { return d.perm ? ((size_t)d.in_features * 2 + 255) / 256 * 256 : 0; }
+hipError_t launch_permute_x(const VptqLayerDesc* descs, int n, const void* const* x, void* const* out, hipStream_t st) {
+  PermXParams P = {};
+  int blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!descs[i].perm) continue;
+    if (P.n == kMaxGroup) return hipErrorInvalidValue;
+    P.start[P.n] = blocks;
+    P.x[P.n] = (const uint16_t*)x[i];
+    P.perm[P.n] = (const uint16_t*)descs[i].perm;
+    P.out[P.n] = (uint16_t*)out[i];
+    P.I[P.n] = descs[i].in_features;
+    blocks += (descs[i].in_features / 8 + 255) / 256;
+    ++P.n;
+  }
+  if (P.n == 0) return hipSuccess;
+  for (int i = P.n; i <= kMaxGroup; ++i) P.start[i] = blocks;
+  hipLaunchKernelGGL(permute_x_kernel, dim3(blocks), dim3(256), 0, st, P);
+  return hipGetLastError();
+}
+
 // n <= kMaxGroup layers, all gemv_k256c_eligible and of one dtype; sync = kCFlagStride flags per
 // layer (zeroed by the caller's memset node) when dependent
 hipError_t launch_gemv_k256c(const VptqLayerDesc* descs, int n, const void* const* x, void* const* y,

@@ -58,16 +58,18 @@ class GemvChain:
             subs = []
             for idx, safe in parts:
                 m = len(idx)
-                subs.append((idx, (B.LayerDesc * m)(*[caches[i][1] for i in idx]), (C.c_void_p * m)(), (C.c_void_p * m)(), safe))
-            nbytes = B.lib().vptq_quant_gemv_chain_workspace_bytes(n, flags)
-            ws = torch.zeros(max(nbytes, 4) // 4, dtype=torch.int32, device=dev) if nbytes else None
-            self._state = (key, subs, ws, nbytes, dev, caches[0][7], [c[2] for c in caches])
+                descs = (B.LayerDesc * m)(*[caches[i][1] for i in idx])
+                # arrival flags of a dependent chain / x[perm] of independent layers that have an input permutation
+                nbytes = B.lib().vptq_quant_gemv_chain_workspace_bytes_for(descs, m, flags)
+                ws = torch.zeros(max(nbytes, 4) // 4, dtype=torch.int32, device=dev) if nbytes else None
+                subs.append((idx, descs, (C.c_void_p * m)(), (C.c_void_p * m)(), safe, ws, nbytes))
+            self._state = (key, subs, dev, caches[0][7], [c[2] for c in caches])
         return self._state
 
     def kernel_name(self, tokens: int = 1, flags: Optional[int] = None) -> Optional[str]:
         """what the library runs for the (first, i.e. un-gated) list of this chain"""
-        _, subs, _, _, _, _, _ = self._prepare()
-        idx, descs, _, _, safe = subs[0]
+        _, subs, _, _, _ = self._prepare()
+        idx, descs, _, _, safe, _, _ = subs[0]
         f = (ops.quant_gemm_flags() if flags is None else flags) | safe
         if self.dependent:
             f |= B.GEMV_CHAIN_DEPENDENT
@@ -78,7 +80,7 @@ class GemvChain:
                  flags: Optional[int] = None):
         """xs: one activation per layer (independent) or only the first layer's (dependent).
         ys: optional pre-allocated outputs.  Returns the list of outputs, one per layer."""
-        _, subs, ws, nbytes, dev, wdtype, _ = self._prepare()
+        _, subs, dev, wdtype, _ = self._prepare()
         n = len(self.layers)
         xs = list(xs)
         if self.dependent:
@@ -114,7 +116,7 @@ class GemvChain:
             f0 |= B.GEMV_CHAIN_DEPENDENT
         with torch.cuda.device(dev):
             sp = B.current_stream_ptr(dev)
-            for idx, descs, xp, yp, safe in subs:
+            for idx, descs, xp, yp, safe, ws, nbytes in subs:
                 for j, i in enumerate(idx):
                     xp[j] = xin[i].data_ptr()
                     yp[j] = ys[i].data_ptr()
