@@ -487,7 +487,7 @@ def test_command_line_options_match_the_reference():
     assert ns.model == "m" and ns.chat and ns.chat_system_prompt == "s" and ns.tokenizer == ""
     with pytest.raises(SystemExit):
         app.define_basic_args().parse_args([])      # --model is required
-    for fn in ("define_basic_args", "eval_prompt", "chat_loop", "get_chat_loop_generator", "get_valid_args", "main"):
+    for fn in ("define_basic_args", "eval_prompt", "chat_loop", "get_valid_args", "main"):
         assert callable(getattr(app, fn))
 
 

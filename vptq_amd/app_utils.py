@@ -3,14 +3,13 @@
 Mirror of the reference's command-line entry (vptq/app_utils.py:17-189, vptq/__main__.py): same
 options, same defaults (100 new tokens for a prompt, 500 sampled tokens per chat turn,
 pad_token_id 2), same public helpers (`define_basic_args`, `eval_prompt`, `chat_loop`,
-`get_chat_loop_generator`, `main`).  The model comes from this package's loader, so every quantised
+`main`; the UI callback generator of app_utils.py:114-163 is out of this path's scope).  The model comes from this package's loader, so every quantised
 linear runs on the HIP kernels; there is no hub access in this build, `--model` is a local directory.
 """
 from __future__ import annotations
 
 import argparse
 import os
-from threading import Thread
 
 PAD_TOKEN_ID = 2   # what the reference passes to generate() for every model
 BANNER = "=" * 28 + "chat with the model" + "=" * 28
@@ -72,31 +71,6 @@ def chat_loop(model, tokenizer, args, read=input):
                              do_sample=True)
         reply = tokenizer.batch_decode(out[:, ids.shape[-1]:], skip_special_tokens=True)[0]
         history.append({"role": "assistant", "content": reply})
-
-
-def get_chat_loop_generator(model_id):
-    """For a UI callback (reference app_utils.py:114-163): returns `gen(messages, max_tokens, stream,
-    temperature, top_p)` that yields the reply piece by piece while `generate` runs on a thread."""
-    import transformers
-    from vptq_amd.layers.model_base import AutoModelForCausalLM
-    model = AutoModelForCausalLM.from_pretrained(model_id, device_map="auto", **_hub_kwargs()).half()
-    tokenizer = transformers.AutoTokenizer.from_pretrained(model_id, **_hub_kwargs())
-    if getattr(tokenizer, "chat_template", None) is None:
-        raise Exception("this tokenizer has no chat_template")
-
-    def chat_loop_generator(messages, max_tokens: int, stream: bool = True, temperature: float = 1.0,
-                            top_p: float = 1.0):
-        streamer = transformers.TextIteratorStreamer(tokenizer, skip_prompt=True, skip_special_tokens=True)
-        enc = tokenizer.apply_chat_template(messages, add_generation_prompt=True, return_tensors="pt",
-                                            return_dict=True).to(model.device)
-        worker = Thread(target=model.generate,
-                        kwargs=dict(enc, streamer=streamer, max_new_tokens=max_tokens, pad_token_id=PAD_TOKEN_ID,
-                                    do_sample=True, temperature=temperature, top_p=top_p))
-        worker.start()
-        yield from streamer
-        worker.join()
-
-    return chat_loop_generator
 
 
 def get_valid_args(parser):

@@ -108,7 +108,7 @@ constexpr uint32_t c_red_off(bool exact) { return kCXsOff + kCWaves * c_xs_wave(
 constexpr uint32_t c_redb_off(bool exact) { return c_red_off(exact) + kCSlots * kCWaves * kCOutW * 4; }
 constexpr uint32_t c_cnt_off(bool exact) { return c_redb_off(exact) + kCSlots * kCWaves * 4; }
 // profiling build 2: consume start / end stamps of kCTlSteps steps per wave (a timeline of who computes when)
-constexpr int kCTlFirst = 16, kCTlSteps = 32;
+[[maybe_unused]] constexpr int kCTlFirst = 16, kCTlSteps = 32;
 constexpr uint32_t c_tl_off(bool exact) { return c_cnt_off(exact) + 64; }
 constexpr uint32_t c_lds_bytes(bool exact) {
 #if VPTQ_K256C_PROF >= 2
@@ -117,7 +117,7 @@ constexpr uint32_t c_lds_bytes(bool exact) {
   return c_cnt_off(exact) + 64;
 #endif
 }
-constexpr int kCProfWords = 64;   // 8-byte words of profile output per wave
+[[maybe_unused]] constexpr int kCProfWords = 64;   // 8-byte words of profile output per wave
 static_assert(c_lds_bytes(false) <= 163840 && (VPTQ_K256C_PROF >= 2 || c_lds_bytes(true) <= 163840), "LDS");
 constexpr int kCFlagStride = 256;   // DEP: arrival flags per layer (one per workgroup)
 
@@ -1187,8 +1187,8 @@ __global__ __launch_bounds__(256) void permute_x_kernel(const PermXParams P) {
     if ((int)blockIdx.x >= P.start[i]) l = i;
   l = __builtin_amdgcn_readfirstlane(l);
   // (layer fields through the scalar cache: constant-address-space loads with a uniform index)
-  typedef const char __attribute__((address_space(4)))* ka_t;
 #if defined(__HIP_DEVICE_COMPILE__)
+  typedef const char __attribute__((address_space(4)))* ka_t;
   const ka_t base = (ka_t)__builtin_amdgcn_kernarg_segment_ptr();
   const uint16_t* const x = *(const uint16_t* const __attribute__((address_space(4)))*)(base + offsetof(PermXParams, x) + (size_t)l * 8);
   const uint16_t* const perm = *(const uint16_t* const __attribute__((address_space(4)))*)(base + offsetof(PermXParams, perm) + (size_t)l * 8);
