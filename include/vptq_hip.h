@@ -299,7 +299,13 @@ typedef struct VptqSlicedLayout {
   int32_t n_slices;         /* 8 (or 0) / 16 / 32: what vptq_sliced_layout_supported() answers for the layer */
   int32_t whole_table;      /* 0: element words carry the index INSIDE the slice (the workgroup holds its slice of the table);
                              * 1: the full index (every workgroup of this table holds all of it: small residual tables) */
+  const void* wstart;       /* int32 [S][N][VPTQ_SLICED_WINDOWS + 1], or NULL (one token only): every (s, n) list is ordered by
+                             * COLUMN WINDOW - window w = columns [w C, (w + 1) C), C = group_size / 4 rounded up to a multiple
+                             * of 8, the last window taking what is left - and wstart[s][n][w] is the position inside the list
+                             * at which window w begins, [VPTQ_SLICED_WINDOWS] the list's length without padding.  What
+                             * vptq_quant_gemv_sliced_tokens walks; one token ignores it */
 } VptqSlicedLayout;
+#define VPTQ_SLICED_WINDOWS 4
 /* 0 = not a layer of this path; else the number of slices its layout(s) must have: v = 8: 8 slices of 8192 entries while
  * the activations fit in LDS beside them (group_size <= 14336, 14080 with the 256-entry residual codebook), else 16 of
  * 4096; v = 16 (32-byte entries): 16 slices of 4096 entries, beyond 14336 columns 32 of 2048 */
@@ -312,6 +318,18 @@ VPTQ_API int vptq_sliced_layout_whole_table(const VptqLayerDesc* desc, int table
 VPTQ_API size_t vptq_quant_gemv_sliced_workspace_bytes(const VptqLayerDesc* desc);
 VPTQ_API int vptq_quant_gemv_sliced(const VptqLayerDesc* desc, const VptqSlicedLayout* layout, const void* x,
                            void* y, int flags, void* workspace, size_t workspace_bytes, void* stream);
+
+/* 2 - 4 tokens over the same layouts (ABI >= 7; needs `wstart`): x [tokens][in_features], y [tokens][out_features]
+ * (float32 with VPTQ_GEMV_OUT_F32), one launch.  The activations of T tokens do not fit beside a slice, so the kernel takes
+ * the columns in 1, 2 or 4 phases (as few as the LDS allows: 4096-column layers need one for 2 - 3 tokens) and walks the
+ * phase's column windows of every list.  workspace: vptq_quant_gemv_sliced_tokens_workspace_bytes(desc, tokens), zero-filled
+ * once, one per layer and stream, not shared with the one-token call.  VPTQ_E_UNSUPPORTED where the layer, the layout
+ * (no wstart) or the token count is not served: take vptq_quant_gemv.  Replaces the same reference kernel for
+ * 1 < tokens < 16 (vptq/ops/quant_gemm.py:213, csrc/kernels/quant_gemv.cuh:11-186). */
+VPTQ_API int vptq_quant_gemv_sliced_tokens_supported(const VptqLayerDesc* desc, const VptqSlicedLayout* layout, int tokens);
+VPTQ_API size_t vptq_quant_gemv_sliced_tokens_workspace_bytes(const VptqLayerDesc* desc, int tokens);
+VPTQ_API int vptq_quant_gemv_sliced_tokens(const VptqLayerDesc* desc, const VptqSlicedLayout* layout, const void* x, void* y,
+                                  int tokens, int flags, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Up to 3 layers of ONE format, dtype and input width that read the SAME activation (q / k / v, gate / up) in one launch
  * (ABI >= 7): layouts = the layers' structs one after the other (vptq_sliced_layout_tables() each; give every struct the

@@ -52,6 +52,11 @@ FMT_CASES = [
     ("t1_v16_k65536_r1024_4096x4096", 4096, 4096, 16, 65536, 1024, False, False, "f16", 1, "llm"),
     ("t1_v8_k65536_r4_bias", 2048, 2048, 8, 65536, 4, False, True, "f16", 1, "llm"),
     ("t1_v8_k32768_r0_perm", 2048, 4096, 8, 32768, 0, True, False, "f16", 1, "llm"),
+    # 2 - 4 tokens of large-codebook layers: one launch over the sliced layouts, 1 / 4 / 2 / 1 column phases (gemv_sliced_tok.hip)
+    ("t2_k65536_r256_4096x4096", 4096, 4096, 8, 65536, 256, False, True, "f16", 2, "llm"),
+    ("t4_k65536_r0_8192x2048_perm", 8192, 2048, 8, 65536, 0, True, False, "f16", 4, "llm"),
+    ("t3_k65536_r65536_bf16", 4096, 2048 + 8, 8, 65536, 65536, False, True, "bf16", 3, "llm"),
+    ("t2_v16_k65536_r65536_4096x2048", 4096, 2048, 16, 65536, 65536, False, False, "f16", 2, "llm"),
 ]
 
 

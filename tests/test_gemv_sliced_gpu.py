@@ -202,7 +202,7 @@ def test_sliced_route_falls_back_instead_of_failing(dev):
     g = torch.cuda.CUDAGraph()
     s = torch.cuda.Stream()
     xa = bits_to_tensor(x1, "f16", dev).reshape(1, 1, 2048)
-    m(torch.cat([xa] * 4, dim=1))          # (4 tokens: the gather kernel; 1 - 3 tokens would build the layout here)
+    m(torch.cat([xa] * 5, dim=1))          # (5 tokens: the gather kernel; 1 - 4 tokens would build the layout here)
     torch.cuda.synchronize()
     with torch.cuda.stream(s):
         with torch.cuda.graph(g, stream=s):
@@ -277,7 +277,7 @@ def test_sliced_layout_gemv_vector_length_16(I, O, kw, rpw, dt, kr, dev):
     assert torch.equal(m(xt).view(torch.int16), got.view(torch.int16)) or rel_err(tensor_to_bits(m(xt)), want, dt) <= TOL[dt]
 
 
-@pytest.mark.parametrize("name", [n for n in fmt_names() if "v16_k65536" in n])
+@pytest.mark.parametrize("name", [n for n in fmt_names() if "v16_k65536" in n and n.startswith("t1_")])
 def test_sliced_layout_vector_length_16_on_reference_goldens(name, dev):
     from vptq_amd.utils.sliced import SlicedGemv
     L, x, y, cfg, _ = load_fmt(name)
@@ -340,6 +340,7 @@ def test_two_and_three_tokens_as_sliced_launches_per_token(dev, monkeypatch):
     third to a half of that per token); smaller layers and more tokens keep the gather kernels"""
     import vptq_amd.layers.vqlinear as vq
     from oracle import c_oracle as co
+    monkeypatch.setattr(vq, "_SLICED_ONE_LAUNCH", "0")    # (the route of this test: one launch PER token)
     L = vo.make_layer(8192, 6200, dist="llm", seed=41, num_centroids=65536, num_res_centroids=0)
     m = spec_to_module(L, dev)
     m.enable_sliced_layout()
@@ -418,3 +419,130 @@ def test_sibling_layers_share_one_sliced_launch(v, kr, dev):
     torch.cuda.synchronize()
     for y, a in zip(yg, alone):
         assert torch.equal(y.view(torch.int16), a.view(torch.int16))
+
+
+# ---------------------------------------------------------------- 2 - 4 tokens in one launch (gemv_sliced_tok.hip)
+TOK_FORMATS = [(8, 65536, 0), (8, 65536, 256), (8, 65536, 65536), (8, 65536, 1024), (8, 32768, 0), (16, 65536, 0), (16, 65536, 65536),
+               (16, 65536, 256)]
+# one phase (the tokens' activations fit beside the slice) / 2 - 4 phases / a column count that is no multiple of 32 / 16
+# (v = 16: 32) slices / a tiny layer (most windows of most lists empty)
+TOK_SHAPES = [(2048, 528, dict(dist="llm", enable_perm=True, bias=True)), (8192, 512, dict(dist="llm", bias=True)), (4104, 272, dict(dist="llm")),
+              (14336, 136, dict(dist="llm")), (16392, 72, dict(dist="llm", enable_perm=True)), (72, 1040, dict())]
+
+
+def _xt(I, T, dt, dist, seed):
+    rng = np.random.default_rng(seed)
+    xs = (0.02 + 0.5 * rng.standard_normal((1, T, I))) if dist == "ref-test" else rng.standard_normal((1, T, I))
+    return vo.from_f32(xs.astype(np.float32), dt)
+
+
+@pytest.mark.parametrize("tokens,dt", [(2, "f16"), (3, "bf16"), (4, "f16"), (4, "bf16")])
+@pytest.mark.parametrize("v,k,kr", TOK_FORMATS)
+@pytest.mark.parametrize("I,O,kw", TOK_SHAPES)
+def test_sliced_tokens_one_launch(I, O, kw, v, k, kr, tokens, dt, dev):
+    """2 - 4 tokens over the sliced layouts in ONE launch (column phases): against the oracle, against one sliced launch per
+    token, float32 outputs, repeatable"""
+    from vptq_amd.utils.sliced import SlicedGemv
+    from vptq_amd import _backend as B
+    kw = dict(kw)
+    dist = kw.pop("dist", "ref-test")
+    L = vo.make_layer(I, O, dist=dist, seed=I + O + v + kr + tokens, dtype=dt, vector_len=v, num_centroids=k, num_res_centroids=kr, **kw)
+    x = _xt(I, tokens, dt, dist, I + 3)
+    m = spec_to_module(L, dev)
+    sl = SlicedGemv(m)
+    xt = bits_to_tensor(x, dt, dev).reshape(x.shape)
+    if not sl.tokens_supported(tokens):
+        assert sl.forward_tokens(xt) is None
+        pytest.skip("the activations of this many tokens do not fit beside the slice")
+    got = sl.forward_tokens(xt)
+    torch.cuda.synchronize()
+    assert got.shape == (1, tokens, O)
+    want = vo.forward(L, x)
+    err = rel_err(tensor_to_bits(got), want, dt)
+    assert err <= TOL[dt], f"v{v}-k{k}-{kr} {I}x{O} {tokens} tokens {dt}: {err:.3e}"
+    for t in range(tokens):     # the one-token kernel over the same layouts (other summation order: the bar, not bits)
+        one = sl(xt[:, t:t + 1].contiguous())
+        assert rel_err(tensor_to_bits(got[:, t:t + 1]), tensor_to_bits(one), dt) <= TOL[dt]
+    y32 = sl.forward_tokens(xt, flags=B.GEMV_OUT_F32)
+    assert y32.dtype == torch.float32 and torch.equal(y32.to(got.dtype).view(torch.int16), got.view(torch.int16))
+    assert torch.equal(sl.forward_tokens(xt).view(torch.int16), got.view(torch.int16))
+
+
+@pytest.mark.parametrize("name,parts", [("t8_k65536_r256", [(0, 4), (4, 8), (2, 4), (5, 8)]), ("t5_k65536_r65536_perm", [(0, 2), (2, 5), (1, 5)]),
+                                        ("t2_k65536_r256_4096x4096", [(0, 2)]), ("t4_k65536_r0_8192x2048_perm", [(0, 4), (1, 4), (2, 4)]),
+                                        ("t3_k65536_r65536_bf16", [(0, 3), (1, 3)]), ("t2_v16_k65536_r65536_4096x2048", [(0, 2)])])
+def test_sliced_tokens_on_reference_goldens(name, parts, dev):
+    """the real reference's outputs for 5 / 8 tokens of k = 65536 layers, 2 - 4 tokens at a time"""
+    from vptq_amd.utils.sliced import SlicedGemv
+    L, x, y, cfg, _ = load_fmt(name)
+    dt = cfg["dtype"]
+    m = spec_to_module(L, dev)
+    sl = SlicedGemv(m)
+    xt = bits_to_tensor(x, dt, dev).reshape(x.shape)
+    for a, b in parts:
+        got = sl.forward_tokens(xt[:, a:b].contiguous())
+        assert got is not None
+        assert rel_err(tensor_to_bits(got), y[:, a:b], dt) <= TOL[dt], (name, a, b)
+
+
+def test_sliced_tokens_rejections(dev):
+    from vptq_amd.utils.sliced import SlicedGemv
+    from vptq_amd import _backend as B
+    L = vo.make_layer(2048, 512, dist="llm", seed=51, num_centroids=65536, num_res_centroids=256)
+    m = spec_to_module(L, dev)
+    sl = SlicedGemv(m)
+    x = torch.randn(1, 3, 2048, device=dev, dtype=torch.float16)
+    assert sl.tokens_supported(2) and sl.tokens_supported(4) and not sl.tokens_supported(5) and not sl.tokens_supported(1)
+    y = torch.empty(1, 3, 512, device=dev, dtype=torch.float16)
+    lib = B.lib()
+    need = lib.vptq_quant_gemv_sliced_tokens_workspace_bytes(sl.desc, 3)
+    ws = torch.zeros(need, dtype=torch.uint8, device=dev)
+    sp = B.current_stream_ptr(dev)
+    assert lib.vptq_quant_gemv_sliced_tokens(sl.desc, sl.layout, x.data_ptr(), y.data_ptr(), 3, 0, ws.data_ptr(), need - 1, sp) == B.E_WORKSPACE
+    assert lib.vptq_quant_gemv_sliced_tokens(sl.desc, sl.layout, x.data_ptr(), y.data_ptr(), 5, 0, ws.data_ptr(), need, sp) == B.E_UNSUPPORTED
+    assert lib.vptq_quant_gemv_sliced_tokens(sl.desc, sl.layout, x.data_ptr(), y.data_ptr(), 3, EXACT, ws.data_ptr(), need, sp) == B.E_UNSUPPORTED
+    assert lib.vptq_quant_gemv_sliced_tokens(sl.desc, sl.layout, x.data_ptr(), y.data_ptr(), 3, 0, ws.data_ptr(), need, sp) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(y, sl.forward_tokens(x))
+    # a layout without the column windows' table serves one token only
+    lay = B.SlicedLayout.from_buffer_copy(sl.layout[0])
+    lay.wstart = None
+    assert not lib.vptq_quant_gemv_sliced_tokens_supported(sl.desc, lay, 3)
+    assert sl(x[:, :1].contiguous()) is not None
+
+
+def test_module_route_for_two_to_four_tokens_in_one_launch(dev, monkeypatch):
+    """the module's forward: 2 tokens of a large-codebook layer = ONE launch over the layouts (VQuantLinear._sliced_one_launch);
+    3 - 4 tokens only where that was measured faster (large v = 8 layers without / with a large residual table); switched off:
+    the other routes"""
+    import vptq_amd.layers.vqlinear as vq
+    L = vo.make_layer(4096, 1024, dist="llm", seed=61, num_centroids=65536, num_res_centroids=256, bias=True)
+    m = spec_to_module(L, dev)
+    m.enable_sliced_layout()
+    xs = np.concatenate([_x(4096, "f16", "llm", 20 + i) for i in range(4)], axis=1)
+    xt = bits_to_tensor(xs, "f16", dev).reshape(xs.shape)
+    m(xt[:, :1].contiguous())
+    sl = m.__dict__["_sliced"][1]
+    assert sl is not None and m._sliced_one_launch(sl, 2) and not m._sliced_one_launch(sl, 3) and not m._sliced_one_launch(sl, 4)
+    y2 = m(xt[:, :2].contiguous())
+    assert torch.equal(y2.view(torch.int16), sl.forward_tokens(xt[:, :2].contiguous()).view(torch.int16))
+    assert rel_err(tensor_to_bits(y2), vo.forward(L, xs[:, :2]), "f16") <= 1e-3
+    y4 = m(xt)                                     # 4 tokens of this layer: the gather kernel
+    assert rel_err(tensor_to_bits(y4), vo.forward(L, xs), "f16") <= 1e-3
+    monkeypatch.setattr(vq, "_SLICED_ONE_LAUNCH", "1")
+    sl.__dict__.pop(("_one_launch", 4))
+    y4b = m(xt)
+    assert torch.equal(y4b.view(torch.int16), sl.forward_tokens(xt).view(torch.int16))
+    assert rel_err(tensor_to_bits(y4b), vo.forward(L, xs), "f16") <= 1e-3
+    # inside a stream capture: the workspace exists (the calls above ran on this stream), the launch is captured
+    g = torch.cuda.CUDAGraph()
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        m(xt[:, :2].contiguous())
+        torch.cuda.synchronize()
+        x2 = xt[:, :2].contiguous()
+        with torch.cuda.graph(g, stream=st):
+            yg = m(x2)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(yg.view(torch.int16), y2.view(torch.int16))

@@ -808,7 +808,11 @@ FMT_KERNELS = {"t1_k8192_r256_8192x1024": "gemv_lds_mfma_kernel", "t1_k4096_r512
                "t1_k65536_r65536_4096x4096": "gemv_gather_kernel", "t1_k65536_r65536_bf16_perm": "gemv_gather_kernel",
                "t1_v16_k65536_r65536_4096x4096": "gemv_gatherx_kernel", "t1_v16_k65536_r0_bf16_perm": "gemv_gatherx_kernel",
                "t1_v16_k65536_r1024_4096x4096": "gemv_gatherx_kernel", "t1_v8_k65536_r4_bias": "gemv_gatherx_kernel",
-               "t1_v8_k32768_r0_perm": "gemv_gatherx_kernel"}
+               "t1_v8_k32768_r0_perm": "gemv_gatherx_kernel",
+               # 2 - 4 tokens of large-codebook layers (the module's route: one launch over the sliced layouts where that was
+               # measured faster, tests/test_gemv_sliced_gpu.py; through vptq_quant_gemv: the gather kernels)
+               "t2_k65536_r256_4096x4096": "gemv_gather_kernel", "t4_k65536_r0_8192x2048_perm": "gemv_gather_kernel",
+               "t3_k65536_r65536_bf16": "gemv_gather_kernel", "t2_v16_k65536_r65536_4096x2048": "gemv_gatherx_kernel"}
 
 
 @pytest.mark.parametrize("name", fmt_names())

@@ -594,3 +594,29 @@ def test_sliced_layout_routing_without_gpu():
     assert whole(_family_desc(8192, 8192, 8, 65536, 4), 1) == 1
     assert whole(_family_desc(25704, 768, 16, 65536, 4096), 1) == 0                # 128 KiB of table + 51 KiB of activations: sliced
     assert sup(_family_desc(25704, 768, 16, 65536, 4096)) == 32
+
+
+def test_sliced_tokens_plan_without_gpu():
+    """2 - 4 tokens over the sliced layouts (gemv_sliced_tok.hip): which layers the library takes - the activations of the
+    tokens must fit the LDS beside the slice in at most 4 column phases - and the workspace it asks for: host logic"""
+    import ctypes as C
+    lib = B.lib()
+    sup, wsb = lib.vptq_quant_gemv_sliced_tokens_supported, lib.vptq_quant_gemv_sliced_tokens_workspace_bytes
+    buf = (C.c_char * 64)()   # (never dereferenced here)
+    p = C.addressof(buf)
+
+    def layouts(d, wstart=True):
+        n = lib.vptq_sliced_layout_tables(d)
+        return (B.SlicedLayout * n)(*[B.SlicedLayout(p, p, p, p, 2, 1, lib.vptq_sliced_layout_supported(d),
+                                                     lib.vptq_sliced_layout_whole_table(d, t), p if wstart else None) for t in range(n)])
+    d = _family_desc(8192, 8192, 8, 65536, 0)
+    assert [sup(d, layouts(d), t) for t in (1, 2, 3, 4, 5)] == [0, 1, 1, 1, 0]
+    assert sup(d, layouts(d, wstart=False), 2) == 0                       # layouts without the column windows' table: one token only
+    # partial sums [tokens][slices x tables][N x v] floats (256-byte multiple) + the arrival counters (one per 16 rows)
+    assert wsb(d, 2) == 2 * 8 * 8192 * 4 + 256 and wsb(d, 4) == 4 * 8 * 8192 * 4 + 256 and wsb(d, 5) == 0 and wsb(d, 1) == 0
+    d2 = _family_desc(8192, 8192, 8, 65536, 65536)
+    assert sup(d2, layouts(d2), 4) == 1 and wsb(d2, 3) == 3 * 16 * 8192 * 4 + 256
+    assert sup(_family_desc(28672, 8192, 8, 65536, 0), layouts(_family_desc(28672, 8192, 8, 65536, 0)), 4) == 1   # 16 slices of 64 KiB
+    dv = _family_desc(8192, 8192, 16, 65536, 65536)
+    assert sup(dv, layouts(dv), 2) == 1
+    assert sup(_family_desc(8192, 8192, 12, 65536, 0), layouts(d), 2) == 0   # not a layer of the sliced path at all

@@ -44,7 +44,11 @@ def test_sliced_layout_holds_every_element_once(N, G, slices, residual, dist):
         idx = np.full((N, G), 40000, np.int64)
     idx = idx.astype(np.uint16)
     ridx = rng.integers(0, 256, (N, G)).astype(np.uint8) if residual else None
-    elems, blocks, first, res = build_sliced_layout(_pack(idx, ridx), G, slices, residual)
+    elems, blocks, first, res, wstart = build_sliced_layout(_pack(idx, ridx), G, slices, residual)
+    from vptq_amd.utils.sliced import WINDOWS, window_cols
+    assert wstart.dtype == torch.int32 and wstart.shape == (slices, N, WINDOWS + 1)
+    wstart, wc = wstart.numpy(), window_cols(G)
+    assert wc % 8 == 0 and wc * WINDOWS >= G
     assert elems.dtype == torch.int32 and blocks.shape == (slices, N) and first.shape == (slices, N)
     assert (res is None) == (not residual)
     e = elems.numpy().view(np.uint32)
@@ -75,28 +79,43 @@ def test_sliced_layout_holds_every_element_once(N, G, slices, residual, dist):
             assert np.array_equal(s * slice_size + local[:k].astype(np.int64), idx[n, c].astype(np.int64))
             if residual:
                 assert np.array_equal(r[lo:lo + k], ridx[n, c])
+            # ordered by column window; wstart[s, n, w] = where window w begins, [WINDOWS] = the list's length
+            ws = wstart[s, n]
+            assert ws[0] == 0 and ws[WINDOWS] == k and np.all(np.diff(ws) >= 0)
+            assert np.array_equal(np.minimum(c // wc, WINDOWS - 1), np.repeat(np.arange(WINDOWS), np.diff(ws)))
         assert seen.all()
 
 
 def test_sliced_layout_spreads_lds_bank_groups():
-    """inside a (row, slice) list, 16 consecutive elements - one pass of the kernel's ds_read_b128 gather - should hit
-    different bank groups (entry & 15) as far as the list's classes allow: with uniform indices no class may appear
-    more than twice in a window of 16 (column order gives 3-way conflicts on average)"""
+    """inside a (row, slice, column window) list, 16 consecutive elements - one pass of the kernel's ds_read_b128 gather -
+    should hit different bank groups (entry & 15) as far as the list's classes allow: while every class still has an
+    element left (rank-major order: the first min-class-count rows of 16) a group of 16 holds 16 different classes, and
+    overall the mean multiplicity stays well under column order's (3-way conflicts on average)"""
+    from vptq_amd.utils.sliced import WINDOWS
     rng = np.random.default_rng(7)
     N, G = 4, 8192
     idx = rng.integers(0, 65536, (N, G)).astype(np.uint16)
-    elems, blocks, first, _ = build_sliced_layout(_pack(idx, None), G, 8, False)
+    elems, blocks, first, _, wstart = build_sliced_layout(_pack(idx, None), G, 8, False)
     e = elems.numpy().view(np.uint32)
-    worst = 0
+    wstart = wstart.numpy()
+    mult, groups, free = 0, 0, 0
     for n in range(N):
         for s in range(8):
-            lo, cnt = int(first[s, n]) * 64, int(blocks[s, n]) * 64
-            w = e[lo:lo + cnt]
-            w = w[(w & 0xffff) < G]
-            cls = (w >> 16) & 15
-            for i in range(0, len(cls) - 15 - 64, 16):   # (the tail of a list runs out of some classes)
-                worst = max(worst, int(np.bincount(cls[i:i + 16], minlength=16).max()))
-    assert worst <= 2
+            lo = int(first[s, n]) * 64
+            for w in range(WINDOWS):
+                a, b = int(wstart[s, n, w]), int(wstart[s, n, w + 1])
+                cls = (e[lo + a:lo + b] >> 16) & 15
+                full = int(np.bincount(cls, minlength=16).min())      # rows of 16 that hold every class
+                assert full >= 4
+                for r in range(full):
+                    assert len(np.unique(cls[16 * r:16 * r + 16])) == 16
+                free += full * 16
+            k = int(wstart[s, n, WINDOWS])
+            cls = (e[lo:lo + k] >> 16) & 15
+            for i in range(0, k - 15, 16):   # (the kernel's groups of 16 lanes are aligned to the list, not to its windows)
+                mult += int(np.bincount(cls[i:i + 16], minlength=16).max())
+                groups += 1
+    assert free >= 0.5 * N * G and mult / groups <= 1.8, (free / (N * G), mult / groups)
 
 
 def test_rows_per_wave():
@@ -120,7 +139,7 @@ def test_two_table_format_splits_into_two_index_streams():
     a8, b8 = split_index_streams(_pack(idx.astype(np.uint16), (ridx & 255).astype(np.uint8)), G, 8)
     assert np.array_equal(a8.numpy(), idx) and np.array_equal(b8.numpy(), ridx & 255)
     # the residual stream's layout holds every element once, in the slice of its RESIDUAL index
-    elems, blocks, first, res = layout_from_indices(b, 8)
+    elems, blocks, first, res, _ = layout_from_indices(b, 8)
     assert res is None
     e = elems.numpy().view(np.uint32)
     for n in range(N):

@@ -272,9 +272,20 @@ def fuzz_sliced(a, dev):
         e = rel_err(tensor_to_bits(got), want, dt)
         e2 = rel_err(tensor_to_bits(got), tensor_to_bits(gemv_abi(m, xt, 0)), dt)
         worst = max(worst, e)
+        # 2 - 4 tokens in one launch over the same layouts (gemv_sliced_tok.hip: column phases), where the library takes it
+        T = int(rng.integers(2, 5))
+        et = -1.0
+        if sl.tokens_supported(T):
+            xT = vo.from_f32(rng.standard_normal((1, T, I)).astype(np.float32), dt)
+            xTt = bits_to_tensor(xT, dt, dev).reshape(xT.shape)
+            gotT = sl.forward_tokens(xTt)
+            torch.cuda.synchronize()
+            assert torch.equal(gotT.view(torch.int16), sl.forward_tokens(xTt).view(torch.int16)), (c, "tokens: not reproducible")
+            et = rel_err(tensor_to_bits(gotT), vo.gemv(vo.dequant(L, ref_residual_mask_quirk=False), xT, dt, L.bias), dt)
+            worst = max(worst, et)
         print(f"case {c:3d} v{v}-k{k}-{kr} I={I:6d} O={O:5d} skew={skew} slices={sl.slices} tables={len(sl.layout)} "
-              f"whole={sl._whole} rpw={sl.layout[0].rows_per_wave}: oracle {e:.2e} gather {e2:.2e}", flush=True)
-        assert e <= tol and e2 <= tol, (c, e, e2)
+              f"whole={sl._whole} rpw={sl.layout[0].rows_per_wave}: oracle {e:.2e} gather {e2:.2e} | {T} tokens {et:.2e}", flush=True)
+        assert e <= tol and e2 <= tol and et <= tol, (c, e, e2, et)
     print(f"worst: {worst:.2e}")
 
 

@@ -41,7 +41,8 @@ _vp = C.c_void_p
 class SlicedLayout(C.Structure):
     """Mirror of `VptqSlicedLayout` (include/vptq_hip.h)."""
     _fields_ = [("elems", C.c_void_p), ("blocks", C.c_void_p), ("first", C.c_void_p), ("res", C.c_void_p),
-                ("rows_per_wave", C.c_int32), ("elems_per_lane", C.c_int32), ("n_slices", C.c_int32), ("whole_table", C.c_int32)]
+                ("rows_per_wave", C.c_int32), ("elems_per_lane", C.c_int32), ("n_slices", C.c_int32), ("whole_table", C.c_int32),
+                ("wstart", C.c_void_p)]
 
 
 class LayerDesc(C.Structure):
@@ -87,6 +88,10 @@ EXPORTS = {
     "vptq_quant_gemv_sliced_workspace_bytes": (C.c_size_t, [C.POINTER(LayerDesc)]),
     "vptq_quant_gemv_sliced": (C.c_int, [C.POINTER(LayerDesc), C.POINTER(SlicedLayout), _vp, _vp, C.c_int, _vp,
                                          C.c_size_t, _vp]),
+    "vptq_quant_gemv_sliced_tokens_supported": (C.c_int, [C.POINTER(LayerDesc), C.POINTER(SlicedLayout), C.c_int]),
+    "vptq_quant_gemv_sliced_tokens_workspace_bytes": (C.c_size_t, [C.POINTER(LayerDesc), C.c_int]),
+    "vptq_quant_gemv_sliced_tokens": (C.c_int, [C.POINTER(LayerDesc), C.POINTER(SlicedLayout), _vp, _vp, C.c_int, C.c_int, _vp,
+                                                C.c_size_t, _vp]),
     "vptq_quant_gemv_sliced_grouped": (C.c_int, [C.POINTER(LayerDesc), C.POINTER(SlicedLayout), C.c_int, _vp, C.POINTER(_vp), C.c_int,
                                                  C.POINTER(_vp), C.POINTER(C.c_size_t), _vp]),
     "vptq_quant_gemm_supported": (C.c_int, [C.POINTER(LayerDesc)]),

@@ -489,6 +489,31 @@ int vptq_quant_gemv_sliced(const VptqLayerDesc* d, const VptqSlicedLayout* layou
   return e == hipSuccess ? VPTQ_OK : hip_fail(e, "gemv_sliced launch");
 }
 
+int vptq_quant_gemv_sliced_tokens_supported(const VptqLayerDesc* d, const VptqSlicedLayout* layout, int tokens) {
+  return validate_layer(d) == VPTQ_OK && layout && vptq::gemv_sliced_tok_eligible(*d, layout, tokens) ? 1 : 0;
+}
+
+size_t vptq_quant_gemv_sliced_tokens_workspace_bytes(const VptqLayerDesc* d, int tokens) {
+  return validate_layer(d) == VPTQ_OK && vptq::gemv_sliced_eligible(*d) && tokens >= 2 && tokens <= 4
+             ? vptq::gemv_sliced_tok_workspace_bytes(*d, tokens) : 0;
+}
+
+int vptq_quant_gemv_sliced_tokens(const VptqLayerDesc* d, const VptqSlicedLayout* layout, const void* x, void* y, int tokens,
+                                  int flags, void* workspace, size_t workspace_bytes, void* stream) {
+  if (int rc = validate_layer(d)) return rc;
+  if (!layout || !x || !y) return fail(VPTQ_E_NULL, "layout, x and y must be set");
+  if (flags & VPTQ_GEMV_EXACT)
+    return fail(VPTQ_E_UNSUPPORTED, "the sliced path has the folded arithmetic only: use vptq_quant_gemv");
+  if (!vptq::gemv_sliced_eligible(*d) || !vptq::gemv_sliced_tok_eligible(*d, layout, tokens))
+    return fail(VPTQ_E_UNSUPPORTED, "sliced layouts with column windows (wstart), 2 - 4 tokens, and activations that fit the LDS beside the slice");
+  const size_t need = vptq::gemv_sliced_tok_workspace_bytes(*d, tokens);
+  if (!workspace || workspace_bytes < need || (((uintptr_t)workspace) & 15) != 0)
+    return fail(VPTQ_E_WORKSPACE, "the sliced path for %d tokens needs %zu bytes of 16-byte aligned, zero-initialised workspace", tokens, need);
+  if ((((uintptr_t)x) & 15) != 0) return fail(VPTQ_E_UNSUPPORTED, "x must be 16-byte aligned");
+  const hipError_t e = vptq::launch_gemv_sliced_tok(*d, layout, x, y, tokens, flags, workspace, (hipStream_t)stream);
+  return e == hipSuccess ? VPTQ_OK : hip_fail(e, "gemv_sliced_tok launch");
+}
+
 int vptq_quant_gemv_sliced_grouped(const VptqLayerDesc* descs, const VptqSlicedLayout* layouts, int n, const void* x,
                                    void* const* y, int flags, void* const* workspaces, const size_t* workspace_bytes, void* stream) {
   if (!descs || !layouts || !x || !y || !workspaces || !workspace_bytes) return fail(VPTQ_E_NULL, "descs / layouts / x / y / workspaces is NULL");

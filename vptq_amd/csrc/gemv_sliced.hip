@@ -28,19 +28,10 @@
 // go to the caller's workspace; the workgroup of a row block that stores them last adds the slices in a fixed
 // order and the output bias (sum b x rides in slice 0's partial sums).  Folded arithmetic (gemv_k256m.hip):
 // y = sum c[idx] * f16(s x) + sum b x + bias.
-#include <type_traits>
-
-#include "common.h"
-#include "kernels.h"
+#include "sliced.h"
 
 namespace vptq {
 
-constexpr int kSLThreads = 1024;
-constexpr int kSLWaves = kSLThreads / 64;
-// 8 slices of 8192 entries (128 KiB of LDS) while the staged activations fit beside them, else 16 slices of 4096
-// (64 KiB): 8 slices hold f16(s x) of 14336 columns (14080 with the 4 KiB residual codebook), 16 slices of 32768
-constexpr int kSLMaxG8 = 14336, kSLMaxG8Res = 14080, kSLMaxG16 = 32768;
-constexpr uint32_t kSLLdsLimit = 163840;
 // element blocks in flight per wave.  Same-box A/B (profiles/r03/sliced_queue_ab.txt): depth 8 / 16 / 32 = 14.2 /
 // 16.2 / 21.2 us per 8192^2 layer - the unrolled loop runs ceil(blocks / depth) * depth steps, and a wave's stream is
 // only ~34 blocks long: the steps past its end cost as much as real ones (8- and 16-byte loads per lane made no
@@ -53,36 +44,6 @@ constexpr int kSLQueueWords = VPTQ_SLICED_QUEUE;
 #ifndef VPTQ_SLICED_ABLATE
 #define VPTQ_SLICED_ABLATE 0
 #endif
-constexpr int kSLMaxRowsPerWave = 64;                    // (their block counts sit in the lanes of one register)
-
-struct SlicedParams {
-  const uint32_t* elems;
-  const uint8_t* res;       // residual index per element (same order and padding), or null
-  const uint32_t* rcent;    // [256][8] halves, or null
-  const int32_t* blocks;    // [8][N]
-  const int32_t* first;     // [8][N]
-  const uint32_t* cent;     // [65536][8] halves
-  const uint16_t* x;
-  const uint16_t* scale;
-  const uint16_t* wbias;    // input-feature order
-  const uint16_t* perm;     // column c of the quantised matrix multiplies input feature perm[c]; `scale` is then in column order
-  const uint16_t* bias;
-  // TWO tables in one launch (65536 residual centroids): the residual table's layout and codebook; its workgroups are
-  // "slices" NSL .. 2 NSL - 1 of the same row blocks
-  const uint32_t* elems2;
-  const int32_t* blocks2;
-  const int32_t* first2;
-  const uint32_t* cent2;
-  // what a workgroup of table t copies into LDS: tab_t bytes from cent + slice x stride_t (stride = tab: its slice of
-  // the table, element words carry the index inside the slice; stride = 0: the WHOLE table - small residual tables -,
-  // element words carry the full index); the staged activations start at x_off >= max(tab)
-  uint32_t tab0, tab1, stride0, stride1, x_off;
-  float* partial;           // [slices][N * 8]
-  uint32_t* arrived;        // [row blocks] workgroups of the row block that have stored their partial sums (0 between launches)
-  void* y;
-  int N, G, O, rows_per_wave, n_rowblocks, out_f32;
-};
-
 // Up to kSLMaxGroup layers that read the SAME activation (q / k / v, gate / up) in one launch: layer l owns the workgroups
 // [start[l], start[l + 1]).  One launch instead of n: the fixed part of a launch (boundary, slice copy, staging, the
 // cross-slice hand-over: ~7 of the 10 us of a 4096 x 4096 layer) is paid once.
@@ -92,18 +53,6 @@ struct SlicedGroupParams {
   int start[kSLMaxGroup + 1];
   SlicedParams p[kSLMaxGroup];
 };
-
-// f(slot 0), ... f(slot kSLQueue - 1) with the slot as a compile-time constant
-template <int I0, int I1, typename F>
-static __device__ __forceinline__ void sl_for_range(F&& f) {
-  if constexpr (I1 - I0 == 1) f(std::integral_constant<int, I0>{});
-  else {
-    sl_for_range<I0, (I0 + I1) / 2>(f);
-    sl_for_range<(I0 + I1) / 2, I1>(f);
-  }
-}
-template <int Q, typename F>
-static __device__ __forceinline__ void sl_for_slots(F&& f) { sl_for_range<0, Q>(f); }
 
 template <typename DT, int NSL, bool RES, int V = 8, bool TWO = false>
 __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGroupParams GP) {
@@ -433,8 +382,8 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
 // Residual codebook: none; v = 8 with 256 entries (one launch, the table beside the slice, a byte per element); any other
 // size (2 ... 65536 entries) as a SECOND TABLE with a layout of its own in the same launch.
 static bool sl_pow2(int k) { return k > 0 && (k & (k - 1)) == 0; }
-static bool sl_res256(const VptqLayerDesc& d) { return d.vector_len == 8 && d.num_res_centroids == 256; }
-static bool sl_two(const VptqLayerDesc& d) { return d.num_res_centroids > 0 && !sl_res256(d); }
+bool sl_res256(const VptqLayerDesc& d) { return d.vector_len == 8 && d.num_res_centroids == 256; }
+bool sl_two(const VptqLayerDesc& d) { return d.num_res_centroids > 0 && !sl_res256(d); }
 int gemv_sliced_tables(const VptqLayerDesc& d) { return sl_two(d) ? 2 : 1; }
 static bool sl_shape_ok(const VptqLayerDesc& d);
 bool gemv_sliced_eligible(const VptqLayerDesc& d) {
@@ -461,7 +410,7 @@ int gemv_sliced_slices(const VptqLayerDesc& d) {
   return d.group_size <= (sl_res256(d) ? kSLMaxG8Res : kSLMaxG8) ? small : 2 * small;
 }
 // bytes a workgroup of a table with k entries holds: its slice, or (whole != 0) the whole table
-static uint32_t sl_tab_bytes(const VptqLayerDesc& d, int k, int whole) {
+uint32_t sl_tab_bytes(const VptqLayerDesc& d, int k, int whole) {
   return (uint32_t)(whole ? k : k / gemv_sliced_slices(d)) * (uint32_t)d.vector_len * 2u;
 }
 // Does every workgroup of table t (0 main, 1 residual-as-second-table) hold the WHOLE table (element words then carry the
@@ -524,7 +473,7 @@ static hipError_t launch_sl_dt(const SlicedGroupParams& P, int v, int nsl, bool 
   return res ? launch_sl<DT, 16, true, 8, false>(P, lds, st) : launch_sl<DT, 16, false, 8, false>(P, lds, st);
 }
 
-static bool sl_layout_ok(const VptqLayerDesc& d, const VptqSlicedLayout& L, int nsl, bool res, int k) {
+bool sl_layout_ok(const VptqLayerDesc& d, const VptqSlicedLayout& L, int nsl, bool res, int k) {
   // (a sliced table needs at least one entry per slice; whole = every workgroup of the table holds all of it)
   return (L.n_slices != 0 ? L.n_slices : 8) == nsl && (L.elems_per_lane == 0 || L.elems_per_lane == 1) && (!res || L.res) &&
          L.rows_per_wave >= 1 && L.rows_per_wave <= kSLMaxRowsPerWave && L.elems && L.blocks && L.first &&

@@ -1,0 +1,606 @@
+// Fused dequant + GEMV for 2 - 4 TOKENS over the load-time derived sliced layouts of gemv_sliced.hip (large-codebook
+// formats: v = 8 / 16, 16384 ... 65536 main centroids, any residual codebook; reference: WqA16WithOutliers_PackIndice,
+// csrc/kernels/quant_gemv.cuh:11-186, which serves these token counts - vptq/ops/quant_gemm.py:213 - by gathering every
+// centroid row from the 1 - 2 MiB codebook through the caches once per token batch).
+//
+// One token fills the LDS: a workgroup's slice of the table (128 KiB) + f16(scale x) of every column (2 G bytes).  T tokens
+// need T x 2 G bytes of activations, so the columns are taken in PHASES: the layout orders every (slice, row) list by column
+// window (VPTQ_SLICED_WINDOWS = 4 equal column ranges, `wstart` = where each begins inside the list), a phase stages the T
+// tokens of 4 / phases windows - [column][token] halves, what one token of all columns takes - and every wave walks that
+// part of its rows' lists: per element one ds_read_b128 (entry), one ds_read_b32 / b64 (the element's column for all tokens),
+// 8 T FMAs.  Blocks of 64 elements do not end where windows do: a block that straddles two phases is walked in both, its
+// elements outside the phase's columns read a zero (so do the padding elements); with 4 phases a list of 16 blocks costs
+// about 3 more.  As many phases as the LDS asks for: 4096-column layers take 2 - 3 tokens in ONE.  At the end of a
+// (row, phase) part the 64 lanes' sums are reduce-scattered (common.h:WaveReduce) and added to the row's sums in LDS (owned by
+// the wave: no atomics, a fixed order); after the last phase they go out as partial sums per (table, slice) and meet as in
+// gemv_sliced.hip: the last workgroup of the row block adds them in a fixed order.  Folded arithmetic (gemv_k256m.hip):
+// y[t] = sum c[idx] f16(s x[t]) + sum b x[t] + bias.
+#include "sliced.h"
+
+namespace vptq {
+
+constexpr int kSTWindows = VPTQ_SLICED_WINDOWS;
+// element blocks in flight per wave (4 where a lane carries 64 sums: v = 16 with 4 tokens would spill at 8)
+#ifndef VPTQ_ST_QUEUE
+#define VPTQ_ST_QUEUE 8
+#endif
+template <int NV> constexpr int st_queue() { return NV >= 64 ? 4 : VPTQ_ST_QUEUE; }
+
+// timing-only ablations (results wrong): bit 0 no FMAs, bit 1 no reduction at the end of a (row, phase) part, bit 2 no LDS gathers,
+// bit 3 no staging of a later phase's activations (its barriers stay), bit 4 none of a later phase's barriers either
+#ifndef VPTQ_ST_ABLATE
+#define VPTQ_ST_ABLATE 0
+#endif
+
+struct SlicedTokParams {
+  SlicedParams p;            // as for one token; x / y: token 0, rows_per_wave / n_rowblocks: this launch's
+  const int32_t* wstart;     // [slices][N][kSTWindows + 1]
+  const int32_t* wstart2;    // second table
+  int tokens;                // 2 .. TOK
+  int phases;                // 1, 2 or 4
+  int wcols;                 // columns per layout window
+  int x_stride, y_stride;    // elements between two tokens of x / y
+  uint32_t bd_off, res_off, sum_off;   // LDS: sum b x parts [TOK][16 waves] floats; 256-entry residual table; row sums
+};
+
+template <typename DT, int NSL, bool RES, int V, bool TWO, int TOK>
+__global__ __launch_bounds__(kSLThreads) void gemv_sliced_tok_kernel(const SlicedTokParams TP) {
+  static_assert(((V == 8 && (NSL == 8 || NSL == 16)) || (V == 16 && (NSL == 16 || NSL == 32))) && (V == 8 || !RES) && !(TWO && RES) &&
+                (TOK == 2 || TOK == 4), "instantiation");
+  const SlicedParams& P = TP.p;
+  constexpr int NSLT = TWO ? 2 * NSL : NSL;
+  constexpr uint32_t kEntry = V * 2u;
+  constexpr uint32_t kXStride = TOK * 2u;    // bytes per staged column
+  constexpr int NV = TOK * V;                // sums per lane
+  constexpr int kSTQueue = st_queue<NV>();
+  const uint32_t kXOff = P.x_off;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  {
+    typedef __attribute__((address_space(3))) unsigned char lds_u8_t;
+    if ((uint32_t)(uintptr_t)(lds_u8_t*)smem != 0u) __builtin_trap();  // absolute LDS addressing
+  }
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int bx = (int)blockIdx.x;
+  const int sg = bx & (NSLT - 1), rb = bx / NSLT;
+  const int s = sg & (NSL - 1);
+  const bool second = TWO && sg >= NSL;
+  const uint32_t* const elems_t = second ? P.elems2 : P.elems;
+  const int32_t* const first_t = second ? P.first2 : P.first;
+  const uint32_t* const cent_t = second ? P.cent2 : P.cent;
+  const int32_t* const wstart_t = second ? TP.wstart2 : TP.wstart;
+  const int N = P.N, G = P.G, tokens = TP.tokens;
+  const int rpw = P.rows_per_wave;
+  const int row0 = (rb * kSLWaves + wave) * rpw;
+  const int n_rows = row0 >= N ? 0 : (N - row0 < rpw ? N - row0 : rpw);
+
+  // ---- lane i: the list of row row0 + i in this slice - its first block and where the column windows begin
+  int list_first = 0;
+  int wofs[kSTWindows + 1];
+#pragma unroll
+  for (int j = 0; j <= kSTWindows; ++j) wofs[j] = 0;
+  if (lane < n_rows) {
+    const size_t li = (size_t)s * N + row0 + lane;
+    list_first = as_global(first_t)[li];
+#pragma unroll
+    for (int j = 0; j <= kSTWindows; ++j) wofs[j] = as_global(wstart_t)[li * (kSTWindows + 1) + j];
+  }
+
+  // ---- this workgroup's part of its table into LDS by LDS-DMA (gemv_sliced.hip)
+  {
+    const uint32_t tab = second ? P.tab1 : P.tab0;
+    const uint64_t va = (uint64_t)(uintptr_t)as_global(cent_t) + (uint64_t)s * (second ? P.stride1 : P.stride0) + (uint64_t)lane * 16u;
+    for (uint32_t off = (uint32_t)wave * 1024u; off < tab; off += kSLWaves * 1024u) {
+      const uint32_t d = (uint32_t)__builtin_amdgcn_readfirstlane((int)off);
+      if (off + (uint32_t)lane * 16u < tab) {
+        const uint64_t v = va + (uint64_t)off;
+        uint32_t keep_m0;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep_m0) : "v"(v), "s"(d) : "memory");
+      }
+    }
+  }
+  if constexpr (RES) {
+    if (wave < 4) {
+      const uint64_t v = (uint64_t)(uintptr_t)as_global(P.rcent) + (uint64_t)wave * 1024u + (uint64_t)lane * 16u;
+      const uint32_t d = (uint32_t)__builtin_amdgcn_readfirstlane((int)(TP.res_off + (uint32_t)wave * 1024u));
+      uint32_t keep_m0;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep_m0) : "v"(v), "s"(d) : "memory");
+    }
+  }
+  // ---- sum b x per token (the workgroups of slice 0: it rides in their partial sums), x in input-feature order
+  if (sg == 0) {
+    float bd[TOK];
+#pragma unroll
+    for (int t = 0; t < TOK; ++t) bd[t] = 0.f;
+    if (P.wbias != nullptr) {
+      for (int q = tid; q < (G >> 3); q += kSLThreads) {
+        const u32x4 bv = *(const u32x4*)(as_global(P.wbias) + 8 * q);
+#pragma unroll
+        for (int t = 0; t < TOK; ++t) {
+          if (t < tokens) {
+            const u32x4 xv = *(const u32x4*)(as_global(P.x) + (size_t)t * TP.x_stride + 8 * q);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bd[t] = DT::dot2(xv[i], bv[i], bd[t]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < TOK; ++t) {
+      const float v = wave_sum(bd[t]);
+      if (lane == 0) *(float*)(smem + TP.bd_off + (uint32_t)(t * kSLWaves + wave) * 4u) = v;
+    }
+  }
+  // ---- the rows' sums start at zero
+  {
+    typedef __attribute__((address_space(3))) u32x4 lds_q_t;
+    const int n16 = kSLWaves * rpw * NV / 4;
+    for (int q = tid; q < n16; q += kSLThreads) *(lds_q_t*)(uintptr_t)(TP.sum_off + (uint32_t)q * 16u) = u32x4{0u, 0u, 0u, 0u};
+  }
+
+  // ---- a phase's columns [c0, c0 + wlen): its windows of every list
+  const int wpp = kSTWindows / TP.phases;   // layout windows per phase
+  auto phase_c0 = [&](int ph) { const int c = ph * wpp * TP.wcols; return c < G ? c : G; };
+  auto phase_c1 = [&](int ph) { const int c = (ph + 1) * wpp * TP.wcols; return (ph == TP.phases - 1 || c > G) ? G : c; };
+  // the 8 columns q of phase ph for every token, scaled: registers now, LDS after the barrier
+  struct Chunk { u32x4 v[TOK]; };
+  auto load_chunk = [&](int c0, int q) __attribute__((always_inline)) {
+    Chunk ch;
+    const int c = c0 + 8 * q;
+    const u32x4 sv = *(const u32x4*)(as_global(P.scale) + c);
+    u32x4 pv = {0u, 0u, 0u, 0u};
+    if (P.perm != nullptr) pv = *(const u32x4*)(as_global(P.perm) + c);
+#pragma unroll
+    for (int t = 0; t < TOK; ++t) {
+      u32x4 xc = {0u, 0u, 0u, 0u};
+      if (t < tokens) {
+        const uint16_t* const xt = as_global(P.x) + (size_t)t * TP.x_stride;
+        if (P.perm != nullptr) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) xc[i] = (uint32_t)xt[pv[i] & 0xffffu] | ((uint32_t)xt[pv[i] >> 16] << 16);
+        } else {
+          xc = *(const u32x4*)(xt + c);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xc[i] = DT::mul2(xc[i], sv[i]);
+      }
+      ch.v[t] = xc;
+    }
+    return ch;
+  };
+  // [column][token] halves: column 2 i of the chunk = the low halves of v[t][i], column 2 i + 1 the high halves
+  auto store_chunk = [&](const Chunk& ch, int q) __attribute__((always_inline)) {
+    const uint32_t base = kXOff + (uint32_t)q * 8u * kXStride;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if constexpr (TOK == 2) {
+        const uint32_t lo = (ch.v[0][i] & 0xffffu) | (ch.v[1][i] << 16);
+        const uint32_t hi = (ch.v[0][i] >> 16) | (ch.v[1][i] & 0xffff0000u);
+        *(__attribute__((address_space(3))) u32x2*)(uintptr_t)(base + (uint32_t)i * 8u) = u32x2{lo, hi};
+      } else {
+        const uint32_t lo01 = (ch.v[0][i] & 0xffffu) | (ch.v[1][i] << 16), lo23 = (ch.v[2][i] & 0xffffu) | (ch.v[3][i] << 16);
+        const uint32_t hi01 = (ch.v[0][i] >> 16) | (ch.v[1][i] & 0xffff0000u), hi23 = (ch.v[2][i] >> 16) | (ch.v[3][i] & 0xffff0000u);
+        lds_store16(base + (uint32_t)i * 16u, u32x4{lo01, lo23, hi01, hi23});
+      }
+    }
+  };
+
+  // ---- element queue.  The stream of a wave = phase by phase, row by row, the phase's part of the row's list; the ISSUE side
+  // walks it ahead of the CONSUME side by kSTQueue blocks and does not stop at a phase's end (a first version started every
+  // phase's stream behind its barriers: one exposed memory latency per phase, 2.5 - 3 us each)
+  uint32_t eq[kSTQueue];
+  uint32_t rq[RES ? kSTQueue : 1];
+  const uint32_t* const ep = as_global(elems_t) + lane;
+  const uint8_t* const rp = RES ? as_global(P.res) + lane : nullptr;
+  // lane i: the blocks [first, first + cnt) of row row0 + i that hold the phase's windows (a block that holds a window's edge
+  // is walked in both phases)
+  auto seg_of = [&](int ph, int& first, int& cnt) __attribute__((always_inline)) {
+    int ws = wofs[0], we = wofs[kSTWindows];
+#pragma unroll
+    for (int j = 0; j <= kSTWindows; ++j) {
+      if (j == ph * wpp) ws = wofs[j];
+      if (j == (ph + 1) * wpp) we = wofs[j];
+    }
+    cnt = we > ws ? ((we + 63) >> 6) - (ws >> 6) : 0;
+    first = list_first + (ws >> 6);
+  };
+  int iseg_first = 0, iseg_cnt = 0, cseg_cnt = 0, unused_first = 0;
+  int iq_ph = 0, iq_row = 0, iq_left = 0, iq_blk = 0, iq_last = 0;   // issue side: phase, row inside the wave, blocks left, next block
+  int cq_ph = 0, cq_row = 0, cq_left = 0;                             // consume side
+  bool iq_end = false, done = false;
+  seg_of(0, iseg_first, iseg_cnt);
+  cseg_cnt = iseg_cnt;
+  // the next (phase, row) that has blocks
+  auto iq_advance = [&]() __attribute__((always_inline)) {
+    for (;;) {
+      while (iq_row < n_rows) {
+        const int c = __builtin_amdgcn_readlane(iseg_cnt, iq_row);
+        if (c != 0) { iq_left = c; iq_blk = __builtin_amdgcn_readlane(iseg_first, iq_row); return; }
+        ++iq_row;
+      }
+      if (iq_ph + 1 >= TP.phases) { iq_end = true; iq_left = 0; return; }
+      ++iq_ph;
+      seg_of(iq_ph, iseg_first, iseg_cnt);
+      iq_row = 0;
+    }
+  };
+  auto issue = [&](auto slot_c) __attribute__((always_inline)) {
+    constexpr int S = decltype(slot_c)::value;
+    // (past the end of the stream the last block again: every step the same instructions)
+    const int b = iq_end ? iq_last : iq_blk;
+    eq[S] = __builtin_nontemporal_load(ep + (size_t)b * 64);
+    if constexpr (RES) rq[S] = rp[(size_t)b * 64];
+    if (!iq_end) {
+      iq_last = b;
+      ++iq_blk;
+      if (--iq_left == 0) { ++iq_row; iq_advance(); }
+    }
+  };
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  f32x2_t acc2[TOK][V / 2];
+#pragma unroll
+  for (int t = 0; t < TOK; ++t)
+#pragma unroll
+    for (int i = 0; i < V / 2; ++i) acc2[t][i] = f32x2_t{0.f, 0.f};
+  uint32_t c0 = 0, wlen = 0;   // the consume side's phase: its columns
+  // a (row, phase) part ends: the 64 lanes' sums -> the row's sums in LDS (this wave owns them)
+  auto row_end = [&]() __attribute__((always_inline)) {
+    float acc[NV];
+#pragma unroll
+    for (int t = 0; t < TOK; ++t)
+#pragma unroll
+      for (int i = 0; i < V / 2; ++i) { acc[t * V + 2 * i] = acc2[t][i][0]; acc[t * V + 2 * i + 1] = acc2[t][i][1]; }
+    if constexpr ((VPTQ_ST_ABLATE & 2) == 0) WaveReduce<NV>::run(acc, lane);
+    constexpr int kShift = WaveReduce<NV>::kShift;
+    if ((lane & ((1 << kShift) - 1)) == 0) {
+      typedef __attribute__((address_space(3))) float lds_f_t;
+      lds_f_t* const sp = (lds_f_t*)(uintptr_t)(TP.sum_off + (uint32_t)(((wave * rpw + cq_row) * NV) + (lane >> kShift)) * 4u);
+      *sp = *sp + acc[0];
+    }
+#pragma unroll
+    for (int t = 0; t < TOK; ++t)
+#pragma unroll
+      for (int i = 0; i < V / 2; ++i) acc2[t][i] = f32x2_t{0.f, 0.f};
+  };
+  auto consume = [&](auto slot_c) __attribute__((always_inline)) {
+    constexpr int S = decltype(slot_c)::value;
+    const uint32_t e = eq[S];
+    if constexpr ((VPTQ_ST_ABLATE & 4) != 0) { acc2[0][0][0] += __uint_as_float(e); return; }
+    constexpr int W4 = V / 8;
+    u32x4 ent[W4];
+    const uint32_t ea = (e >> 16) * kEntry;
+#pragma unroll
+    for (int w = 0; w < W4; ++w) ent[w] = lds_load16(ea + 16u * (uint32_t)w);
+    // the element's column inside the phase, or the zero column behind it (other phases' elements, padding)
+    uint32_t ci = (e & 0xffffu) - c0;
+    ci = ci < wlen ? ci : wlen;
+    uint32_t xw[TOK / 2];
+    if constexpr (TOK == 2) {
+      xw[0] = *(const __attribute__((address_space(3))) uint32_t*)(uintptr_t)(kXOff + ci * kXStride);
+    } else {
+      const u32x2 t = *(const __attribute__((address_space(3))) u32x2*)(uintptr_t)(kXOff + ci * kXStride);
+      xw[0] = t[0]; xw[1] = t[1];
+    }
+    u32x4 rent = {0u, 0u, 0u, 0u};
+    if constexpr (RES) rent = lds_load16(TP.res_off + (rq[S] << 4));
+    if constexpr ((VPTQ_ST_ABLATE & 1) != 0) {
+      acc2[0][0][0] += __uint_as_float(ent[0][0] ^ xw[0] ^ rent[0]);
+      return;
+    }
+    // the entry (+ its residual entry: c + r once, in fp32) as fp32 pairs, the tokens' activations as fp32 pairs, then one
+    // packed FMA per (token, pair of outputs): v_pk_fma_f32 takes the activation from either half of its pair (op_sel)
+    f32x2_t ef[V / 2], xf[TOK / 2];
+#pragma unroll
+    for (int i = 0; i < V / 2; ++i) {
+      const uint32_t ew = ent[i / 4][i % 4];
+      if constexpr (std::is_same<DT, F16>::value) {
+        if constexpr (RES) {
+          const uint32_t rw = rent[i % 4];
+          float lo, hi;
+          asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(lo) : "v"(ew), "v"(rw));
+          asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(hi) : "v"(ew), "v"(rw));
+          ef[i] = f32x2_t{lo, hi};
+        } else {
+          ef[i] = f32x2_t{DT::lo(ew), DT::hi(ew)};
+        }
+      } else {
+        ef[i] = f32x2_t{DT::to_float((uint16_t)(ew & 0xffffu)), DT::to_float((uint16_t)(ew >> 16))};
+        if constexpr (RES) {
+          const uint32_t rw = rent[i % 4];
+          ef[i] += f32x2_t{DT::to_float((uint16_t)(rw & 0xffffu)), DT::to_float((uint16_t)(rw >> 16))};
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < TOK / 2; ++t)
+      xf[t] = f32x2_t{DT::to_float((uint16_t)(xw[t] & 0xffffu)), DT::to_float((uint16_t)(xw[t] >> 16))};
+#pragma unroll
+    for (int t = 0; t < TOK; ++t) {
+#pragma unroll
+      for (int i = 0; i < V / 2; ++i) {
+        f32x2_t a = acc2[t][i];   // (an asm operand cannot name a captured array element)
+        const f32x2_t ev = ef[i], xv = xf[t / 2];
+        if (t % 2 == 0) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "+v"(a) : "v"(ev), "v"(xv));
+        else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(a) : "v"(ev), "v"(xv));
+        acc2[t][i] = a;
+      }
+    }
+  };
+  // the consume side enters phase ph: everybody has left the previous phase's activations (barrier), this thread's chunk of the
+  // new ones - loaded a phase ago - goes to LDS, barrier, the chunk after it sets out
+  Chunk pre = {};
+  if (tid * 8 < phase_c1(0) - phase_c0(0)) pre = load_chunk(phase_c0(0), tid);
+  auto enter_phase = [&](int ph) __attribute__((always_inline)) {
+    if ((VPTQ_ST_ABLATE & 8) && ph > 0) {
+      c0 = (uint32_t)phase_c0(ph);
+      wlen = (uint32_t)phase_c1(ph) - c0;
+      if (!(VPTQ_ST_ABLATE & 16)) {
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();
+      }
+      return;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    c0 = (uint32_t)phase_c0(ph);
+    wlen = (uint32_t)phase_c1(ph) - c0;
+    const int chunks = (int)(wlen >> 3);
+    if (tid < chunks) store_chunk(pre, tid);
+    for (int q = tid + kSLThreads; q < chunks; q += kSLThreads) store_chunk(load_chunk((int)c0, q), q);
+    if (tid == 0) {   // the zero column
+      if constexpr (TOK == 2) *(__attribute__((address_space(3))) uint32_t*)(uintptr_t)(kXOff + wlen * kXStride) = 0u;
+      else *(__attribute__((address_space(3))) u32x2*)(uintptr_t)(kXOff + wlen * kXStride) = u32x2{0u, 0u};
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    if (!(VPTQ_ST_ABLATE & 8) && ph + 1 < TP.phases && tid * 8 < phase_c1(ph + 1) - phase_c0(ph + 1)) pre = load_chunk(phase_c0(ph + 1), tid);
+  };
+  // the consume side's next row with blocks; at the end of a phase's rows the next phase is entered (EVERY wave enters every
+  // phase: the barriers), at the end of the last one the wave is done
+  auto cq_advance = [&]() __attribute__((always_inline)) {
+    for (;;) {
+      while (cq_row < n_rows) {
+        cq_left = __builtin_amdgcn_readlane(cseg_cnt, cq_row);
+        if (cq_left != 0) return;
+        ++cq_row;
+      }
+      if (cq_ph + 1 >= TP.phases) { done = true; return; }
+      ++cq_ph;
+      seg_of(cq_ph, unused_first, cseg_cnt);
+      cq_row = 0;
+      enter_phase(cq_ph);
+    }
+  };
+  auto step = [&](auto slot_c) __attribute__((always_inline)) {
+    __builtin_amdgcn_sched_barrier(0);
+    if (!done) {
+      consume(slot_c);
+      __builtin_amdgcn_sched_barrier(0);
+      issue(slot_c);
+      __builtin_amdgcn_sched_barrier(0);
+      if (--cq_left == 0) {
+        row_end();
+        ++cq_row;
+        cq_advance();
+      }
+    }
+  };
+
+  iq_advance();
+  sl_for_slots<kSTQueue>([&](auto slot_c) { issue(slot_c); __builtin_amdgcn_sched_barrier(0); });
+  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kSTQueue * (RES ? 2 : 1)) : "memory");   // the DMA'd table: older than the queue's loads
+  enter_phase(0);
+  cq_advance();
+  while (!done) sl_for_slots<kSTQueue>(step);
+
+  // ---- partial sums of this (table, slice): [token][NSLT][N x V]; sum b x rides with slice 0
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+  const int rows_wg = kSLWaves * rpw;
+  const int r_first = rb * rows_wg;
+  const int n_rows_wg = N - r_first < rows_wg ? N - r_first : rows_wg;
+  {
+    float bdot[TOK];
+#pragma unroll
+    for (int t = 0; t < TOK; ++t) {
+      bdot[t] = 0.f;
+      if (sg == 0) {
+        const float* const bp = (const float*)(smem + TP.bd_off) + t * kSLWaves;
+#pragma unroll
+        for (int i = 0; i < kSLWaves; ++i) bdot[t] += bp[i];
+      }
+    }
+    for (int k = tid; k < n_rows_wg * NV; k += kSLThreads) {
+      const int r = k / NV, e = k % NV, t = e / V, o = e % V;
+      if (t < tokens) {
+        float v = *(const float*)(smem + TP.sum_off + (uint32_t)k * 4u);
+#pragma unroll
+        for (int tt = 0; tt < TOK; ++tt) v += tt == t ? bdot[tt] : 0.f;
+        float* const pp = as_global(P.partial) + (((size_t)t * NSLT + sg) * N + (size_t)(r_first + r)) * V + o;
+        __hip_atomic_store(pp, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // write-through (sc1): read on another XCD
+      }
+    }
+  }
+  // ---- the last workgroup of the row block adds the slices (gemv_sliced.hip)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  uint32_t* const flag = (uint32_t*)(smem + TP.bd_off);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  if (tid == 0) {
+    const uint32_t before = __hip_atomic_fetch_add(as_global(P.arrived) + rb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t lastone = before == (uint32_t)NSLT - 1u ? 1u : 0u;
+    if (lastone) __hip_atomic_store(as_global(P.arrived) + rb, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *flag = lastone;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+  if (*flag == 0u) return;
+  const int n_out = n_rows_wg * V;
+  for (int k = tid; k < n_out * tokens; k += kSLThreads) {
+    const int t = k / n_out;
+    const size_t o = (size_t)r_first * V + (size_t)(k - t * n_out);
+    float p[NSLT];
+#pragma unroll
+    for (int sl = 0; sl < NSLT; ++sl)
+      p[sl] = __hip_atomic_load(as_global(P.partial) + ((size_t)t * NSLT + sl) * N * V + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int w = NSLT / 2; w > 0; w >>= 1)
+#pragma unroll
+      for (int i = 0; i < w; ++i) p[i] = p[2 * i] + p[2 * i + 1];
+    float v = p[0];
+    if ((int)o < P.O) {
+      if (P.bias) v += DT::to_float(as_global(P.bias)[o]);
+      if (P.out_f32) ((float*)as_global(P.y))[(size_t)t * TP.y_stride + o] = v;
+      else ((uint16_t*)as_global(P.y))[(size_t)t * TP.y_stride + o] = DT::from_float(v);
+    }
+  }
+}
+
+// ---- host side -------------------------------------------------------------------
+static size_t st_partial_bytes(const VptqLayerDesc& d, int tokens) {
+  const size_t parts = (size_t)gemv_sliced_slices(d) * (sl_two(d) ? 2 : 1);
+  return ((size_t)tokens * parts * d.num_indices * d.vector_len * sizeof(float) + 255) / 256 * 256;
+}
+static size_t st_counter_bytes(const VptqLayerDesc& d) {
+  return (((size_t)(d.num_indices + kSLWaves - 1) / kSLWaves) * sizeof(uint32_t) + 255) / 256 * 256;
+}
+size_t gemv_sliced_tok_workspace_bytes(const VptqLayerDesc& d, int tokens) {
+  return st_partial_bytes(d, tokens) + st_counter_bytes(d);
+}
+
+// rows per wave: one round of workgroups (slices x tables x row blocks of 16 waves ~ the CUs)
+static int st_rows_per_wave(const VptqLayerDesc& d) {
+  const long long nslt = (long long)gemv_sliced_slices(d) * (sl_two(d) ? 2 : 1);
+  long long r = ((long long)d.num_indices * nslt + kSLWaves * 256 - 1) / (kSLWaves * 256);
+  return (int)(r < 1 ? 1 : r > kSLMaxRowsPerWave ? kSLMaxRowsPerWave : r);
+}
+
+struct StPlan { int tok, phases, rpw; uint32_t x_off, bd_off, res_off, sum_off, lds; };
+// the template's token count (2 or 4), the fewest phases whose activations fit beside the table, and the LDS map
+static bool st_plan(const VptqLayerDesc& d, const VptqSlicedLayout* L, int tokens, StPlan& pl) {
+  if (tokens < 2 || tokens > 4) return false;
+  const bool res = sl_res256(d), two = sl_two(d);
+  pl.tok = tokens == 2 ? 2 : 4;
+  pl.rpw = st_rows_per_wave(d);
+  uint32_t tab = sl_tab_bytes(d, d.num_centroids, 0);
+  if (two) {
+    const uint32_t t1 = sl_tab_bytes(d, d.num_res_centroids, L[1].whole_table);
+    tab = t1 > tab ? t1 : tab;
+  }
+  pl.x_off = (tab + 15u) & ~15u;
+  const int G = d.group_size;
+  const int wcols = (G + kSTWindows * 8 - 1) / (kSTWindows * 8) * 8;
+  static std::atomic<int> min_phases{-1};   // VPTQ_SLICED_MIN_PHASES=2 / 4: more phases than the LDS asks for (A/B runs)
+  if (min_phases < 0) { const char* e = getenv("VPTQ_SLICED_MIN_PHASES"); const int v = e ? atoi(e) : 1; min_phases = (v == 2 || v == 4) ? v : 1; }
+  for (int phases = min_phases; phases <= kSTWindows; phases *= 2) {
+    const int wmax = (kSTWindows / phases) * wcols < G ? (kSTWindows / phases) * wcols : G;   // columns of the widest phase
+    uint32_t o = pl.x_off + (uint32_t)(wmax + 8) * (uint32_t)pl.tok * 2u;
+    o = (o + 15u) & ~15u;
+    pl.bd_off = o; o += (uint32_t)pl.tok * kSLWaves * 4u;
+    pl.res_off = o; o += res ? 4096u : 0u;
+    pl.sum_off = o; o += (uint32_t)kSLWaves * (uint32_t)pl.rpw * (uint32_t)(pl.tok * d.vector_len) * 4u;
+    if (o <= kSLLdsLimit) { pl.phases = phases; pl.lds = o; return true; }
+  }
+  return false;
+}
+
+bool gemv_sliced_tok_eligible(const VptqLayerDesc& d, const VptqSlicedLayout* L, int tokens) {
+  StPlan pl;
+  if (!gemv_sliced_eligible(d) || !L) return false;
+  const int n = gemv_sliced_tables(d);
+  for (int i = 0; i < n; ++i)
+    if (!L[i].wstart) return false;
+  return st_plan(d, L, tokens, pl);
+}
+
+template <typename DT, int NSL, bool RES, int V, bool TWO, int TOK>
+static hipError_t launch_st(const SlicedTokParams& P, int grid, uint32_t lds, hipStream_t st) {
+  auto kern = gemv_sliced_tok_kernel<DT, NSL, RES, V, TWO, TOK>;
+  static std::atomic<bool> attr_set[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (!attr_set[dev]) {
+    const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSLLdsLimit);
+    if (e != hipSuccess) return e;
+    attr_set[dev] = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(kSLThreads), lds, st, P);
+  return hipGetLastError();
+}
+template <typename DT, int TOK>
+static hipError_t launch_st_dt(const SlicedTokParams& P, int grid, int v, int nsl, bool res, bool two, uint32_t lds, hipStream_t st) {
+  if (v == 16) {
+    if (two) return nsl == 16 ? launch_st<DT, 16, false, 16, true, TOK>(P, grid, lds, st) : launch_st<DT, 32, false, 16, true, TOK>(P, grid, lds, st);
+    return nsl == 16 ? launch_st<DT, 16, false, 16, false, TOK>(P, grid, lds, st) : launch_st<DT, 32, false, 16, false, TOK>(P, grid, lds, st);
+  }
+  if (two) return nsl == 8 ? launch_st<DT, 8, false, 8, true, TOK>(P, grid, lds, st) : launch_st<DT, 16, false, 8, true, TOK>(P, grid, lds, st);
+  if (nsl == 8) return res ? launch_st<DT, 8, true, 8, false, TOK>(P, grid, lds, st) : launch_st<DT, 8, false, 8, false, TOK>(P, grid, lds, st);
+  return res ? launch_st<DT, 16, true, 8, false, TOK>(P, grid, lds, st) : launch_st<DT, 16, false, 8, false, TOK>(P, grid, lds, st);
+}
+
+// x: [tokens][in_features], y: [tokens][out_features] (fp32 with VPTQ_GEMV_OUT_F32); ws: gemv_sliced_tok_workspace_bytes,
+// zero before its first use (every launch leaves the counters zero)
+hipError_t launch_gemv_sliced_tok(const VptqLayerDesc& d, const VptqSlicedLayout* L, const void* x, void* y, int tokens, int flags,
+                                  void* ws, hipStream_t st) {
+  StPlan pl;
+  if (!gemv_sliced_tok_eligible(d, L, tokens) || !st_plan(d, L, tokens, pl)) return hipErrorInvalidValue;
+  const bool res = sl_res256(d), two = sl_two(d);
+  const int nsl = gemv_sliced_slices(d);
+  if (!sl_layout_ok(d, L[0], nsl, res, d.num_centroids) || L[0].whole_table != 0 ||
+      (two && (!sl_layout_ok(d, L[1], nsl, false, d.num_res_centroids) || L[1].whole_table != gemv_sliced_whole_table(d, 1))) ||
+      !ws || (((uintptr_t)x) & 15) != 0 || (d.in_features % 8) != 0)
+    return hipErrorInvalidValue;
+  SlicedTokParams TP = {};
+  SlicedParams& P = TP.p;
+  P.elems = (const uint32_t*)L[0].elems;
+  P.res = res ? (const uint8_t*)L[0].res : nullptr;
+  P.rcent = res ? (const uint32_t*)d.res_centroids : nullptr;
+  P.blocks = (const int32_t*)L[0].blocks;
+  P.first = (const int32_t*)L[0].first;
+  P.cent = (const uint32_t*)d.centroids;
+  P.tab0 = sl_tab_bytes(d, d.num_centroids, 0);
+  P.stride0 = P.tab0;
+  TP.wstart = (const int32_t*)L[0].wstart;
+  if (two) {
+    P.elems2 = (const uint32_t*)L[1].elems;
+    P.blocks2 = (const int32_t*)L[1].blocks;
+    P.first2 = (const int32_t*)L[1].first;
+    P.cent2 = (const uint32_t*)d.res_centroids;
+    P.tab1 = sl_tab_bytes(d, d.num_res_centroids, L[1].whole_table);
+    P.stride1 = L[1].whole_table ? 0u : P.tab1;
+    TP.wstart2 = (const int32_t*)L[1].wstart;
+  }
+  P.x_off = pl.x_off;
+  P.x = (const uint16_t*)x;
+  P.scale = (const uint16_t*)(d.perm ? d.scale_permuted : d.weight_scale);
+  P.wbias = (const uint16_t*)d.weight_bias;
+  P.perm = (const uint16_t*)d.perm;
+  P.bias = (const uint16_t*)d.bias;
+  P.partial = (float*)ws;
+  P.arrived = (uint32_t*)((char*)ws + st_partial_bytes(d, tokens));
+  P.y = y;
+  P.N = d.num_indices; P.G = d.group_size; P.O = d.out_features;
+  P.rows_per_wave = pl.rpw;
+  const int rows_per_wg = kSLWaves * pl.rpw;
+  P.n_rowblocks = (d.num_indices + rows_per_wg - 1) / rows_per_wg;
+  P.out_f32 = (flags & VPTQ_GEMV_OUT_F32) ? 1 : 0;
+  TP.tokens = tokens;
+  TP.phases = pl.phases;
+  TP.wcols = (d.group_size + kSTWindows * 8 - 1) / (kSTWindows * 8) * 8;
+  TP.x_stride = d.in_features;
+  TP.y_stride = d.out_features;
+  TP.bd_off = pl.bd_off; TP.res_off = pl.res_off; TP.sum_off = pl.sum_off;
+  const int grid = gemv_sliced_slices(d) * (two ? 2 : 1) * P.n_rowblocks;
+  if (d.dtype == VPTQ_DTYPE_F16)
+    return pl.tok == 2 ? launch_st_dt<F16, 2>(TP, grid, d.vector_len, nsl, res, two, pl.lds, st)
+                       : launch_st_dt<F16, 4>(TP, grid, d.vector_len, nsl, res, two, pl.lds, st);
+  return pl.tok == 2 ? launch_st_dt<BF16, 2>(TP, grid, d.vector_len, nsl, res, two, pl.lds, st)
+                     : launch_st_dt<BF16, 4>(TP, grid, d.vector_len, nsl, res, two, pl.lds, st);
+}
+
+}  // namespace vptq

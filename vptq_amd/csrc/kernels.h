@@ -65,6 +65,11 @@ size_t gemv_sliced_workspace_bytes(const VptqLayerDesc& d);
 hipError_t launch_gemv_sliced(const VptqLayerDesc& d, const VptqSlicedLayout* L, const void* x, void* y, int flags,
                               void* ws, hipStream_t st);
 // up to 3 layers of one format reading the same x (q / k / v, gate / up) in one launch
+// gemv_sliced_tok.hip - 2 - 4 tokens over the same layouts (column windows of every list, phase by phase)
+bool gemv_sliced_tok_eligible(const VptqLayerDesc& d, const VptqSlicedLayout* L, int tokens);
+size_t gemv_sliced_tok_workspace_bytes(const VptqLayerDesc& d, int tokens);
+hipError_t launch_gemv_sliced_tok(const VptqLayerDesc& d, const VptqSlicedLayout* L, const void* x, void* y, int tokens, int flags,
+                                  void* ws, hipStream_t st);
 bool gemv_sliced_groupable(const VptqLayerDesc* d, int n);
 hipError_t launch_gemv_sliced_group(const VptqLayerDesc* d, const VptqSlicedLayout* L, int n, const void* x, void* const* y,
                                     int flags, void* const* ws, hipStream_t st);

@@ -58,7 +58,11 @@ _SLICED_MIN_FREE_FRACTION = 0.25
 # most tokens served as one sliced launch PER TOKEN: decided per layer (VQuantLinear._sliced_token_limit);
 # VPTQ_SLICED_TOKENS="one-table,two-table" overrides it (tools/sliced_tokens_bench.py)
 _SLICED_TOKENS_ENV = tuple(int(v) for v in os.environ["VPTQ_SLICED_TOKENS"].split(",")) if os.environ.get("VPTQ_SLICED_TOKENS") else None
-_SLICED_MAX_TOKENS = max(_SLICED_TOKENS_ENV) if _SLICED_TOKENS_ENV else 3
+_SLICED_MAX_TOKENS = max(max(_SLICED_TOKENS_ENV) if _SLICED_TOKENS_ENV else 3, 4)
+# 2 - 4 tokens in ONE sliced launch (gemv_sliced_tok.hip): "auto" (default) = per layer where it was measured faster than the
+# gather kernels and than one sliced launch per token (VQuantLinear._sliced_one_launch); "1" = wherever the library takes the
+# layer; "0" = never
+_SLICED_ONE_LAUNCH = os.environ.get("VPTQ_SLICED_ONE_LAUNCH", "auto").strip().lower() or "auto"
 
 
 class SiblingGroup:
@@ -470,6 +474,37 @@ class VQuantLinear(nn.Module):
             sl.__dict__["_token_limit"] = lim
         return lim
 
+    def _sliced_one_launch(self, sl, tokens: int) -> bool:
+        """2 - 4 tokens in ONE launch over the layouts (column phases, gemv_sliced_tok.hip)?  Measured against the gather kernels
+        (profiles/r04/sliced_tokens_one_launch.txt; us per 8192^2 / 4096^2 / 14336 x 4096 layer, gather -> one launch):
+        2 tokens: v8-k65536-0 39.8 / 13.2 / 35.7 -> 22.3 / 11.5 / 20.6, -256 40.1 / 13.4 / 36.2 -> 29.3 / 12.8 / 25.2, -65536
+        76.5 / 21.8 / 66.9 -> 36.1 / 15.9 / 30.9, v16-k65536-65536 52.4 / 19.5 / 53.3 -> 38.4 / 17.7 / 37.6, v16-k65536-0 27.3 / 13.5 /
+        33.2 -> 23.8 / 12.9 / 20.4: every layer from 4096 x 1024 on.  3 - 4 tokens run the 4-token kernel in 4 phases; it is bound
+        by instruction issue (the FMAs of 4 tokens, a 64-lane reduction per row and phase) and by the shorter runs of the element
+        stream: worth it on v = 8 layers from 8192^2 / 4096 x 14336 on - no residual table 40.7 / 35.8 -> 36.0 / 30.0, a second table
+        79.0 / 67.5 -> 60.3 / 53.8, the 256-entry table from 8192 columns on 43.0 / 42.4 -> 41.9 / 34.8 - not at 4096^2 (13.3 -> 16.3)
+        and not for v = 16 (64 sums per lane: 30.6 -> 48.2)."""
+        key = ("_one_launch", tokens)
+        ok = sl.__dict__.get(key)
+        if ok is None:
+            if _SLICED_ONE_LAUNCH in ("0", "off", "false", "no") or not sl.tokens_supported(tokens):
+                ok = False
+            elif _SLICED_ONE_LAUNCH in ("1", "on", "true", "yes", "always"):
+                ok = True
+            else:
+                n_el = self.indices.shape[1] * self.group_size      # index elements per table
+                kr = self.num_res_centroids if self.enable_residual else 0
+                if tokens == 2:    # (smaller layers are launch-bound on every route and were not measured)
+                    ok = n_el >= 1 << 19
+                elif self.vector_len != 8:
+                    ok = False
+                elif kr not in (0, 256):
+                    ok = n_el >= 4 << 20
+                else:
+                    ok = n_el >= 6 << 20 and (kr == 0 or self.group_size >= 8192)
+            sl.__dict__[key] = ok
+        return ok
+
     def _sliced_fits(self, cache, on) -> bool:
         """auto mode: build only while the layout (5 / 4 bytes per element + the builder's temporaries) leaves
         _SLICED_MIN_FREE_FRACTION of the device memory free, and never inside a stream capture"""
@@ -503,6 +538,10 @@ class VQuantLinear(nn.Module):
                             return y
                     y = sl(x)
                     if y is not None:   # (None: misaligned activation, capture on a stream the layer has not run on, ...)
+                        return y
+                elif tokens <= 4 and self._sliced_one_launch(sl, tokens) and x.is_contiguous():
+                    y = sl.forward_tokens(x)
+                    if y is not None:   # (None: misaligned activation, capture on a stream without a workspace yet)
                         return y
                 elif tokens <= self._sliced_token_limit(sl) and x.is_contiguous() and (self.in_features * x.element_size()) % 16 == 0:
                     # 2 (the 4-bit format: 3) tokens of a LARGE layer = one launch per token over the layouts: the gather

@@ -21,6 +21,12 @@ import torch
 from vptq_amd import _backend as B
 
 INDEX_BITS = 16   # 65536 main centroids
+WINDOWS = 4       # column windows the lists are ordered by (VPTQ_SLICED_WINDOWS in include/vptq_hip.h)
+
+
+def window_cols(G: int) -> int:
+    """columns per window: G / WINDOWS rounded up to a multiple of 8 (the last window takes what is left)"""
+    return (G + WINDOWS * 8 - 1) // (WINDOWS * 8) * 8
 
 
 def split_index_streams(indices: torch.Tensor, group_size: int, res_bits: int, index_bits: int = INDEX_BITS):
@@ -37,7 +43,7 @@ def build_sliced_layout(indices: torch.Tensor, group_size: int, slices: int = 8,
     """indices: the layer's packed int32 `indices` [1, N, row_words] (T = 16 without a residual codebook, 24 with 256
     residual centroids).  slices: 8 or 16 (vptq_sliced_layout_supported tells).
     Returns (elems uint32-as-int32 [blocks * 64], blocks int32 [slices, N], first int32 [slices, N], res uint8
-    [like elems] or None) as described in include/vptq_hip.h (VptqSlicedLayout)."""
+    [like elems] or None, wstart int32 [slices, N, WINDOWS + 1]) as described in include/vptq_hip.h (VptqSlicedLayout)."""
     idx, ridx = split_index_streams(indices, group_size, 8 if residual else 0)
     return layout_from_indices(idx, slices, ridx)
 
@@ -68,12 +74,28 @@ def layout_from_indices(idx: torch.Tensor, slices: int = 8, ridx: torch.Tensor =
     # (Column order gave 3-way conflicts on average: SQ_LDS_BANK_CONFLICT = 60 % of the LDS cycles.)
     local = idx if whole_table else idx & ((1 << SLICE_BITS) - 1)
     cls = local & 15
-    order1 = torch.argsort((sl * 16 + cls) * G + col[None, :], dim=1)
-    seg1 = torch.gather(sl * 16 + cls, 1, order1)                                       # sorted (slice, class) id
-    cnt1 = torch.zeros(N, SLICES * 16, dtype=torch.int64, device=dev)
+    # ... and, before that, by COLUMN WINDOW (WINDOWS equal ranges of window_cols(G) columns): the kernel for 2 - 4 tokens
+    # (gemv_sliced_tok.hip) stages one window of the activations at a time - T tokens of G / T columns fill the room one token of
+    # G columns has - and walks the window's part of every list; `wstart` tells where it begins.  One token ignores it.
+    wcols = window_cols(G)
+    win = torch.clamp(col // wcols, max=WINDOWS - 1)[None, :].expand(N, G)
+    sw = sl * WINDOWS + win
+    order1 = torch.argsort((sw * 16 + cls) * G + col[None, :], dim=1)
+    seg1 = torch.gather(sw * 16 + cls, 1, order1)                                       # sorted (slice, window, class) id
+    cnt1 = torch.zeros(N, SLICES * WINDOWS * 16, dtype=torch.int64, device=dev)
     cnt1.scatter_add_(1, seg1, torch.ones_like(seg1))
     rank1 = col[None, :] - torch.gather(torch.cumsum(cnt1, 1) - cnt1, 1, seg1)          # rank inside the class
-    order2 = torch.argsort(((seg1 >> 4) * G + rank1) * 16 + (seg1 & 15), dim=1)         # (slice, rank, class)
+    # rank-major while every class still has an element (rows of 16 different classes); what is left over - the surplus of
+    # the classes that have more than the smallest one - is spread evenly over the rest of the (slice, window) list (an
+    # element's place = (its rank + 1/2) / its class's surplus of the way through), not bunched class by class at its end
+    cnt3 = cnt1.reshape(N, SLICES * WINDOWS, 16)
+    full = cnt3.min(2).values                                                               # complete rows per (slice, window)
+    rest = cnt3.sum(2) - 16 * full
+    b1 = seg1 >> 4
+    full_e, rest_e, cnt_e = torch.gather(full, 1, b1), torch.gather(rest, 1, b1), torch.gather(cnt1, 1, seg1)
+    spread = 16 * full_e + ((rank1 - full_e).double() + 0.5) * rest_e.double() / (cnt_e - full_e).clamp(min=1).double()
+    place = torch.where(rank1 < full_e, (rank1 * 16 + (seg1 & 15)).double(), spread)
+    order2 = torch.argsort((b1 * (2 * G)).double() + place + (seg1 & 15).double() / 64.0, dim=1)   # (slice, window, place)
     order = torch.gather(order1, 1, order2)
     s_sorted = torch.gather(sl, 1, order)
     word = order | (torch.gather(local, 1, order) << 16)                                # column | local << 16
@@ -96,7 +118,14 @@ def layout_from_indices(idx: torch.Tensor, slices: int = 8, ridx: torch.Tensor =
     if residual:
         res = torch.zeros(elems.numel(), dtype=torch.uint8, device=dev)
         res[dest.reshape(-1)] = torch.gather(ridx, 1, order).reshape(-1).to(torch.uint8)
-    return elems32, blocks_sn.to(torch.int32).contiguous(), first_sn.to(torch.int32).contiguous(), res
+    # wstart [slices][N][WINDOWS + 1]: position inside the (s, n) list at which window w begins; [WINDOWS] = the list's length
+    cntw = torch.zeros(N, SLICES * WINDOWS, dtype=torch.int64, device=dev)
+    cntw.scatter_add_(1, sw, torch.ones_like(sw))
+    cntw = cntw.reshape(N, SLICES, WINDOWS)
+    wstart = torch.zeros(N, SLICES, WINDOWS + 1, dtype=torch.int64, device=dev)
+    wstart[:, :, 1:] = torch.cumsum(cntw, 2)
+    wstart = wstart.permute(1, 0, 2).to(torch.int32).contiguous()
+    return elems32, blocks_sn.to(torch.int32).contiguous(), first_sn.to(torch.int32).contiguous(), res, wstart
 
 
 def rows_per_wave_for(n_rows: int, slices: int = 8, workgroups: int = 256) -> int:
@@ -130,22 +159,24 @@ class SlicedGemv:
             self._tensors = [layout_from_indices(idx, self.slices, ridx if kr else None, ib)]
         del idx, ridx
         self._whole = whole[:len(self._tensors)]
-        self.elems, self.blocks, self.first, self.res = self._tensors[0]
+        self.elems, self.blocks, self.first, self.res, self.wstart = self._tensors[0]
         # (a two-table layer runs 2 x slices workgroups per row block in its one launch)
         rpw = rows_per_wave or rows_per_wave_for(self.blocks.shape[1], self.slices * len(self._tensors))
         self.layout = (B.SlicedLayout * len(self._tensors))(*[
-            B.SlicedLayout(e.data_ptr(), b.data_ptr(), f.data_ptr(), r.data_ptr() if r is not None else None, rpw, 1, self.slices, int(w))
-            for (e, b, f, r), w in zip(self._tensors, self._whole)])
+            B.SlicedLayout(e.data_ptr(), b.data_ptr(), f.data_ptr(), r.data_ptr() if r is not None else None, rpw, 1, self.slices, int(w),
+                           ws.data_ptr())
+            for (e, b, f, r, ws), w in zip(self._tensors, self._whole)])
         self._ws_bytes = B.lib().vptq_quant_gemv_sliced_workspace_bytes(self.desc)
         # partial sums + arrival counters, ONE PER STREAM (two streams - or a graph replay next to an eager call on
         # another stream - running the same layer would race on a shared one); zeroed once, every call leaves the
         # counters zero
         self._ws = {}
+        self._ws_tok = {}   # (stream, tokens) -> workspace of the 2 - 4 token kernel
         self._fn = B.lib().vptq_quant_gemv_sliced
         self._lay_ref = self.layout   # (an array of 1 or 2 structs: passed as a pointer to the first)
         self._dtype = cache[7]
         self._dev_index = cache[8]
-        self.extra_bytes = sum(e.numel() * (5 if r is not None else 4) + b.numel() * 8 for e, b, f, r in self._tensors)
+        self.extra_bytes = sum(e.numel() * (5 if r is not None else 4) + b.numel() * 8 for e, b, f, r, _ in self._tensors)
 
     def _workspace(self, stream_ptr: int):
         ws = self._ws.get(stream_ptr)
@@ -173,6 +204,49 @@ class SlicedGemv:
             with torch.cuda.device(self.dev):
                 return self._launch(x, out, flags)
         return self._launch(x, out, flags)
+
+    def tokens_supported(self, tokens: int) -> bool:
+        """does the library's kernel for 2 - 4 tokens over these layouts take this layer (its activations must fit the LDS
+        beside the slice in at most 4 column phases)?"""
+        return bool(B.lib().vptq_quant_gemv_sliced_tokens_supported(self.desc, self._lay_ref, int(tokens)))
+
+    def forward_tokens(self, x: torch.Tensor, out: torch.Tensor = None, flags: int = 0):
+        """2 - 4 tokens in ONE launch (`vptq_quant_gemv_sliced_tokens`, gemv_sliced_tok.hip): x [..., in_features] with 2 - 4
+        rows, contiguous.  Returns y, or None where the call cannot be served (the caller takes the regular route)."""
+        lay = self.layer
+        tokens = x.numel() // lay.in_features
+        if x.shape[-1] != lay.in_features or not 2 <= tokens <= 4:
+            raise ValueError("forward_tokens takes 2 - 4 tokens of in_features values")
+        if x.dtype != self._dtype or x.device != self.dev:
+            x = lay._check_activation(x)
+        if not x.is_contiguous():
+            x = x.contiguous()
+        if x.data_ptr() & 15 or (lay.in_features * x.element_size()) & 15:
+            return None
+        sp = B.current_stream_ptr(self.dev)
+        key = (sp, tokens)
+        ws = self._ws_tok.get(key)
+        if ws is None:
+            if torch.cuda.is_current_stream_capturing():
+                return None
+            nbytes = B.lib().vptq_quant_gemv_sliced_tokens_workspace_bytes(self.desc, tokens)
+            if not nbytes:
+                return None
+            with torch.cuda.device(self.dev):
+                ws = torch.zeros(nbytes, dtype=torch.uint8, device=self.dev)
+            self._ws_tok[key] = ws
+        if out is None:
+            out = torch.empty(x.shape[:-1] + (lay.out_features,),
+                              dtype=torch.float32 if (flags & B.GEMV_OUT_F32) else self._dtype, device=self.dev)
+        with torch.cuda.device(self.dev):
+            rc = B.lib().vptq_quant_gemv_sliced_tokens(self.desc, self._lay_ref, x.data_ptr(), out.data_ptr(), tokens, flags,
+                                                       ws.data_ptr(), ws.numel(), sp)
+        if rc == B.E_UNSUPPORTED:
+            return None
+        if rc:
+            self._ws_tok.pop(key, None)
+            B.check(rc, "vptq_quant_gemv_sliced_tokens")
+        return out
 
     def _launch(self, x, out, flags):
         sp = B.current_stream_ptr(self.dev)
@@ -207,8 +281,9 @@ class SlicedGroupGemv:
                                   m.layer.in_features != m0.layer.in_features for m in self.members):
             raise ValueError("a sliced group takes 1..3 layers of one format, dtype, device and input width")
         rpw = rows_per_wave_for(sum(m.blocks.shape[1] for m in self.members), m0.slices * tables)   # one round of workgroups over ALL layers
-        structs = [B.SlicedLayout(e.data_ptr(), b.data_ptr(), f.data_ptr(), r.data_ptr() if r is not None else None, rpw, 1, m.slices, int(w))
-                   for m in self.members for (e, b, f, r), w in zip(m._tensors, m._whole)]
+        structs = [B.SlicedLayout(e.data_ptr(), b.data_ptr(), f.data_ptr(), r.data_ptr() if r is not None else None, rpw, 1, m.slices, int(w),
+                                  ws.data_ptr())
+                   for m in self.members for (e, b, f, r, ws), w in zip(m._tensors, m._whole)]
         self.layouts = (B.SlicedLayout * len(structs))(*structs)
         self.descs = (B.LayerDesc * n)(*[m.desc for m in self.members])
         self._yp, self._wp = (C.c_void_p * n)(), (C.c_void_p * n)()
