@@ -512,28 +512,40 @@ def test_sliced_tokens_rejections(dev):
 
 
 def test_module_route_for_two_to_four_tokens_in_one_launch(dev, monkeypatch):
-    """the module's forward: 2 tokens of a large-codebook layer = ONE launch over the layouts (VQuantLinear._sliced_one_launch);
-    3 - 4 tokens only where that was measured faster (large v = 8 layers without / with a large residual table); switched off:
-    the other routes"""
+    """the module's forward: 2 - 4 tokens of a large-codebook layer = ONE launch over the layouts (VQuantLinear._sliced_one_launch:
+    where that was measured faster - not v = 16 with a small residual table, not tiny layers); switched off: the other routes"""
     import vptq_amd.layers.vqlinear as vq
     L = vo.make_layer(4096, 1024, dist="llm", seed=61, num_centroids=65536, num_res_centroids=256, bias=True)
     m = spec_to_module(L, dev)
     m.enable_sliced_layout()
-    xs = np.concatenate([_x(4096, "f16", "llm", 20 + i) for i in range(4)], axis=1)
+    xs = np.concatenate([_x(4096, "f16", "llm", 20 + i) for i in range(5)], axis=1)
     xt = bits_to_tensor(xs, "f16", dev).reshape(xs.shape)
     m(xt[:, :1].contiguous())
     sl = m.__dict__["_sliced"][1]
-    assert sl is not None and m._sliced_one_launch(sl, 2) and not m._sliced_one_launch(sl, 3) and not m._sliced_one_launch(sl, 4)
+    assert sl is not None and all(m._sliced_one_launch(sl, t) for t in (2, 3, 4))
+    for T in (2, 3, 4):
+        x = xt[:, :T].contiguous()
+        y = m(x)
+        assert torch.equal(y.view(torch.int16), sl.forward_tokens(x).view(torch.int16))
+        assert rel_err(tensor_to_bits(y), vo.forward(L, xs[:, :T]), "f16") <= 1e-3
+    y5 = m(xt)                                     # 5 tokens: the gather kernel
+    assert rel_err(tensor_to_bits(y5), vo.forward(L, xs), "f16") <= 1e-3
     y2 = m(xt[:, :2].contiguous())
-    assert torch.equal(y2.view(torch.int16), sl.forward_tokens(xt[:, :2].contiguous()).view(torch.int16))
-    assert rel_err(tensor_to_bits(y2), vo.forward(L, xs[:, :2]), "f16") <= 1e-3
-    y4 = m(xt)                                     # 4 tokens of this layer: the gather kernel
-    assert rel_err(tensor_to_bits(y4), vo.forward(L, xs), "f16") <= 1e-3
-    monkeypatch.setattr(vq, "_SLICED_ONE_LAUNCH", "1")
-    sl.__dict__.pop(("_one_launch", 4))
-    y4b = m(xt)
-    assert torch.equal(y4b.view(torch.int16), sl.forward_tokens(xt).view(torch.int16))
-    assert rel_err(tensor_to_bits(y4b), vo.forward(L, xs), "f16") <= 1e-3
+    monkeypatch.setattr(vq, "_SLICED_ONE_LAUNCH", "0")
+    for T in (2, 3, 4):
+        sl.__dict__.pop(("_one_launch", T), None)
+    y2g = m(xt[:, :2].contiguous())                # the gather kernel (this layer is too small for a launch per token)
+    assert rel_err(tensor_to_bits(y2g), vo.forward(L, xs[:, :2]), "f16") <= 1e-3
+    monkeypatch.setattr(vq, "_SLICED_ONE_LAUNCH", "auto")
+    for T in (2, 3, 4):
+        sl.__dict__.pop(("_one_launch", T), None)
+    # v = 16 with a 1024-entry residual table: the gather kernel holds that table in LDS and is the faster one
+    L16 = vo.make_layer(4096, 2048, dist="llm", seed=62, vector_len=16, num_centroids=65536, num_res_centroids=1024)
+    m16 = spec_to_module(L16, dev)
+    m16.enable_sliced_layout()
+    m16(xt[:, :1].contiguous())
+    sl16 = m16.__dict__["_sliced"][1]
+    assert sl16 is not None and sl16.tokens_supported(2) and not m16._sliced_one_launch(sl16, 2)
     # inside a stream capture: the workspace exists (the calls above ran on this stream), the launch is captured
     g = torch.cuda.CUDAGraph()
     st = torch.cuda.Stream()

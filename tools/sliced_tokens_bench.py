@@ -17,6 +17,7 @@ ap.add_argument("--ring", type=int, default=8)
 ap.add_argument("--k", type=int, default=65536)
 ap.add_argument("--kr", type=int, default=0)
 ap.add_argument("--v", type=int, default=8)
+ap.add_argument("--no-eight", action="store_true")
 ap.add_argument("--only-one-launch", action="store_true", help="time only the one-launch kernel (ablation builds: results are wrong)")
 a = ap.parse_args()
 dev = torch.device("cuda", 0); g = torch.Generator(device=dev).manual_seed(0)
@@ -48,4 +49,21 @@ for I, O in [tuple(int(v) for v in p.split(',')) for p in a.shapes.split(';')]:
         if us_t is not None:
             row[f"t{T}"]["sliced_one_launch_us"] = round(us_t, 2)
             row[f"t{T}"]["one_launch_rel_diff"] = ((yt[0].float() - yg.float()).abs().max() / yg.float().abs().max()).item()
+    if not a.only_one_launch and not a.no_eight:
+        # 5 - 8 tokens: the gather kernels (one launch for v = 8, two for v = 16) against TWO launches over the layouts (4 + the rest)
+        for T in (6, 8):
+            x = torch.randn(1, T, I, device=dev).half()
+            for m in layers:
+                m.enable_sliced_layout(True)
+            sls = [m._sliced_gemv() for m in layers]
+            us_t = None
+            if all(sl is not None and sl.tokens_supported(4) and sl.tokens_supported(T - 4) for sl in sls):
+                xa, xb = x[:, :4].contiguous(), x[:, 4:].contiguous()
+                [(sl.forward_tokens(xa), sl.forward_tokens(xb)) for sl in sls]
+                us_t = time_graph(lambda: [(sl.forward_tokens(xa), sl.forward_tokens(xb)) for sl in sls], 10) / a.ring
+            for m in layers:
+                m.enable_sliced_layout(False)
+            layers[0](x)
+            us_g = time_graph(lambda: [m(x) for m in layers], 10) / a.ring
+            row[f"t{T}"] = dict(gather_us=round(us_g, 2), sliced_two_launches_us=None if us_t is None else round(us_t, 2))
     print(json.dumps(row), flush=True)

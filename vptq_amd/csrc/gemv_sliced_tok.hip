@@ -7,14 +7,22 @@
 // need T x 2 G bytes of activations, so the columns are taken in PHASES: the layout orders every (slice, row) list by column
 // window (VPTQ_SLICED_WINDOWS = 4 equal column ranges, `wstart` = where each begins inside the list), a phase stages the T
 // tokens of 4 / phases windows - [column][token] halves, what one token of all columns takes - and every wave walks that
-// part of its rows' lists: per element one ds_read_b128 (entry), one ds_read_b32 / b64 (the element's column for all tokens),
-// 8 T FMAs.  Blocks of 64 elements do not end where windows do: a block that straddles two phases is walked in both, its
-// elements outside the phase's columns read a zero (so do the padding elements); with 4 phases a list of 16 blocks costs
-// about 3 more.  As many phases as the LDS asks for: 4096-column layers take 2 - 3 tokens in ONE.  At the end of a
-// (row, phase) part the 64 lanes' sums are reduce-scattered (common.h:WaveReduce) and added to the row's sums in LDS (owned by
-// the wave: no atomics, a fixed order); after the last phase they go out as partial sums per (table, slice) and meet as in
-// gemv_sliced.hip: the last workgroup of the row block adds them in a fixed order.  Folded arithmetic (gemv_k256m.hip):
-// y[t] = sum c[idx] f16(s x[t]) + sum b x[t] + bias.
+// part of its rows' lists.  Blocks of 64 elements do not end where windows do: a block that straddles two phases is walked in
+// both, its elements outside the phase's columns read a zero column (so do the padding elements); with 4 phases a list of 16
+// blocks costs about 3 more.  As many phases as the LDS asks for: 4096-column layers take 2 - 3 tokens in ONE.
+//   * 2 tokens: per element one ds_read_b128 (entry), one ds_read_b32 (the column's two tokens), the entry converted to fp32
+//     pairs once (+ the 256-entry residual entry: c + r in fp32) and one v_pk_fma_f32 per (token, pair of outputs); at the end of
+//     a (row, phase) part the 64 lanes' sums are reduce-scattered (common.h:WaveReduce) into the row's sums in LDS.
+//   * 3 - 4 tokens: the contraction over a block's 64 elements runs on the MATRIX PIPE - transposing gathers
+//     (ds_read_b64_tr_b16) deliver entries and activations in the operand layout of v_mfma_f32_16x16x32, see `MF` below: a third
+//     of the vector instructions, 4 sums per lane, no reduction (8192^2, 4 tokens: 35.5 -> 26.5 us; two tables 59.0 -> 40.4).
+// The rows' sums live in LDS (owned by the wave: no atomics, a fixed order); after the last phase they go out as partial sums
+// per (table, slice) and meet as in gemv_sliced.hip: the last workgroup of the row block adds them in a fixed order.  Folded
+// arithmetic (gemv_k256m.hip): y[t] = sum c[idx] f16(s x[t]) + sum b x[t] + bias.
+// What the stream loop must NOT contain (found the hard way, profiles/r04/sliced_tokens_*.txt): a load the compiler can see
+// (it then waits for vmcnt(0) in every step - the activations of a phase are loaded by ONE asm statement with its own wait,
+// a layer's permutation is applied by a pre-pass), a load that is issued on some paths only (the waits then shrink down the
+// unrolled round), 64-bit booleans and index -> address arithmetic in the scalar bookkeeping.
 #include "sliced.h"
 
 namespace vptq {
@@ -32,14 +40,29 @@ template <int NV> constexpr int st_queue() { return NV >= 64 ? 4 : VPTQ_ST_QUEUE
 #define VPTQ_ST_ABLATE 0
 #endif
 
+typedef _Float16 st_h8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 st_b8_t __attribute__((ext_vector_type(8)));
+template <typename DT>
+static __device__ __forceinline__ f32x4 st_mfma(u32x4 a, u32x4 b, f32x4 c) {
+  if constexpr (std::is_same<DT, F16>::value)
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(st_h8_t, a), __builtin_bit_cast(st_h8_t, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(st_b8_t, a), __builtin_bit_cast(st_b8_t, b), c, 0, 0, 0);
+}
+static __device__ __forceinline__ u32x2 st_lds_tr8(uint32_t byte_addr) {   // ds_read_b64_tr_b16
+  typedef __attribute__((address_space(3))) s4_t lds_s4_t;
+  return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t*)(uintptr_t)byte_addr));
+}
+
 struct SlicedTokParams {
   SlicedParams p;            // as for one token; x / y: token 0, rows_per_wave / n_rowblocks: this launch's
   const int32_t* wstart;     // [slices][N][kSTWindows + 1]
   const int32_t* wstart2;    // second table
+  const uint16_t* xs;        // the activations in COLUMN order: p.x, or the pre-pass's x[perm] (p.scale is in column order too)
   int tokens;                // 2 .. TOK
   int phases;                // 1, 2 or 4
   int wcols;                 // columns per layout window
-  int x_stride, y_stride;    // elements between two tokens of x / y
+  int x_stride, x_in_stride, y_stride;    // elements between two tokens of xs / p.x / y
   uint32_t bd_off, res_off, sum_off;   // LDS: sum b x parts [TOK][16 waves] floats; 256-entry residual table; row sums
 };
 
@@ -52,7 +75,7 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_tok_kernel(const Slice
   constexpr uint32_t kEntry = V * 2u;
   constexpr uint32_t kXStride = TOK * 2u;    // bytes per staged column
   constexpr int NV = TOK * V;                // sums per lane
-  constexpr int kSTQueue = st_queue<NV>();
+  constexpr int kSTQueue = (TOK == 4 && !(VPTQ_ST_ABLATE & 32)) ? 8 : st_queue<NV>();   // (MFMA mode: 4 sums per lane)
   const uint32_t kXOff = P.x_off;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   {
@@ -120,7 +143,7 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_tok_kernel(const Slice
 #pragma unroll
         for (int t = 0; t < TOK; ++t) {
           if (t < tokens) {
-            const u32x4 xv = *(const u32x4*)(as_global(P.x) + (size_t)t * TP.x_stride + 8 * q);
+            const u32x4 xv = *(const u32x4*)(as_global(P.x) + (size_t)t * TP.x_in_stride + 8 * q);
 #pragma unroll
             for (int i = 0; i < 4; ++i) bd[t] = DT::dot2(xv[i], bv[i], bd[t]);
           }
@@ -144,29 +167,37 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_tok_kernel(const Slice
   const int wpp = kSTWindows / TP.phases;   // layout windows per phase
   auto phase_c0 = [&](int ph) { const int c = ph * wpp * TP.wcols; return c < G ? c : G; };
   auto phase_c1 = [&](int ph) { const int c = (ph + 1) * wpp * TP.wcols; return (ph == TP.phases - 1 || c > G) ? G : c; };
-  // the 8 columns q of phase ph for every token, scaled: registers now, LDS after the barrier
+  // the 8 columns q of a phase for every token, scaled.  The loads AND their wait are one asm statement: a load the compiler
+  // could see inside the stream loop makes it lose count of the queue's loads (every step then waits for vmcnt(0): the first
+  // versions ran with NO load in flight across a step - 25 of 37 us for 4 tokens at 8192^2).  The statement's wait drains the
+  // queue once per phase; the steps keep their counted waits.  (x is in column order here: a layer's permutation is applied
+  // by a pre-pass, launch_gemv_sliced_tok.)
   struct Chunk { u32x4 v[TOK]; };
   auto load_chunk = [&](int c0, int q) __attribute__((always_inline)) {
     Chunk ch;
     const int c = c0 + 8 * q;
-    const u32x4 sv = *(const u32x4*)(as_global(P.scale) + c);
-    u32x4 pv = {0u, 0u, 0u, 0u};
-    if (P.perm != nullptr) pv = *(const u32x4*)(as_global(P.perm) + c);
+    const uint16_t* const ps = as_global(P.scale) + c;
+    const uint16_t* px[TOK];
+#pragma unroll
+    for (int t = 0; t < TOK; ++t) px[t] = as_global(TP.xs) + (size_t)(t < tokens ? t : 0) * TP.x_stride + c;
+    u32x4 sv;
+    if constexpr (TOK == 2) {
+      u32x4 a, b;
+      asm volatile("global_load_dwordx4 %0, %3, off\n\tglobal_load_dwordx4 %1, %4, off\n\tglobal_load_dwordx4 %2, %5, off\n\ts_waitcnt vmcnt(0)"
+                   : "=&v"(a), "=&v"(b), "=&v"(sv) : "v"(px[0]), "v"(px[1]), "v"(ps) : "memory");
+      ch.v[0] = a; ch.v[1] = b;
+    } else {
+      u32x4 a, b, c2, d;
+      asm volatile("global_load_dwordx4 %0, %5, off\n\tglobal_load_dwordx4 %1, %6, off\n\tglobal_load_dwordx4 %2, %7, off\n\t"
+                   "global_load_dwordx4 %3, %8, off\n\tglobal_load_dwordx4 %4, %9, off\n\ts_waitcnt vmcnt(0)"
+                   : "=&v"(a), "=&v"(b), "=&v"(c2), "=&v"(d), "=&v"(sv)
+                   : "v"(px[0]), "v"(px[1]), "v"(px[2]), "v"(px[3]), "v"(ps) : "memory");
+      ch.v[0] = a; ch.v[1] = b; ch.v[2] = c2; ch.v[3] = d;
+    }
 #pragma unroll
     for (int t = 0; t < TOK; ++t) {
-      u32x4 xc = {0u, 0u, 0u, 0u};
-      if (t < tokens) {
-        const uint16_t* const xt = as_global(P.x) + (size_t)t * TP.x_stride;
-        if (P.perm != nullptr) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) xc[i] = (uint32_t)xt[pv[i] & 0xffffu] | ((uint32_t)xt[pv[i] >> 16] << 16);
-        } else {
-          xc = *(const u32x4*)(xt + c);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) xc[i] = DT::mul2(xc[i], sv[i]);
-      }
-      ch.v[t] = xc;
+      for (int i = 0; i < 4; ++i) ch.v[t][i] = t < tokens ? DT::mul2(ch.v[t][i], sv[i]) : 0u;
     }
     return ch;
   };
@@ -190,10 +221,26 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_tok_kernel(const Slice
   // ---- element queue.  The stream of a wave = phase by phase, row by row, the phase's part of the row's list; the ISSUE side
   // walks it ahead of the CONSUME side by kSTQueue blocks and does not stop at a phase's end (a first version started every
   // phase's stream behind its barriers: one exposed memory latency per phase, 2.5 - 3 us each)
-  uint32_t eq[kSTQueue];
-  uint32_t rq[RES ? kSTQueue : 1];
-  const uint32_t* const ep = as_global(elems_t) + lane;
-  const uint8_t* const rp = RES ? as_global(P.res) + lane : nullptr;
+  // MF (v = 8, 4 token slots): the contraction over a block's 64 elements runs on the matrix pipe.  ds_read_b64_tr_b16 hands a
+  // lane component m of FOUR elements' entries (gemm_k256t.hip: inside 16 lanes, source lane 4 e + c supplies an 8-byte chunk's
+  // address, result lane 4 c' + m receives half m of the chunks of source lanes 4 e' + c', e' = 0..3) - the operand layout of
+  // v_mfma_f32_16x16x32 (lane 16 g + j: row / column j, K = 8 g .. 8 g + 7).  Source lane (g, e, c) of read i = 0, 1 takes
+  // the element at position 32 i + 8 g + 2 e + (c >> 1) of the block and chunk c & 1 of its entry, so a result lane's column
+  // is 8 h + component, h = c' >> 1 the element SET; the activations go through the same read - chunk = the column's 4 tokens
+  // (c & 1 = 0) or the zero column - so a row is 8 h + token.  D[8 h + token][8 h' + component] is the sum over the block's
+  // K = (g, i, e) for h = h' (the two diagonal blocks; the others mix sets and are dropped): lanes 0 - 7 hold set 0, lanes
+  // 40 - 47 set 1, 4 registers = 4 tokens.  Per block 4 (6 with the 256-entry residual table) gathers + 1 (2) MFMAs instead of
+  // 2 gathers + 12 conversions + 16 packed FMAs, and the end of a (row, phase) part is a lane swap and an add instead of a
+  // 64-lane reduce-scatter of 32 sums.  Every lane loads TWO element words per block (a pair of lanes the same ones).
+  // v = 16: an entry is FOUR chunks, so the 16 columns are the 16 components of ONE set, source lane (g, e, c) of read i = 0..3
+  // takes the element at position 16 i + 4 g + e and chunk c of its entry (activations: c = 0 the tokens, else the zero column),
+  // reads 0, 1 feed one MFMA, reads 2, 3 a second one; lanes 0 - 15 hold the sums, four element words per lane and block.
+  constexpr bool MF = TOK == 4 && !(VPTQ_ST_ABLATE & 32);
+  constexpr int EW = MF ? (V == 8 ? 2 : 4) : 1;
+  constexpr int EPR = 64 / EW;                   // elements per read of the block
+  uint32_t eq[kSTQueue][EW];
+  uint32_t rq[RES ? kSTQueue : 1][EW];
+  const int epos = MF ? (V == 8 ? (lane >> 1) : (lane >> 2)) : lane;      // this lane's (first) element of a block
   // lane i: the blocks [first, first + cnt) of row row0 + i that hold the phase's windows (a block that holds a window's edge
   // is walked in both phases)
   auto seg_of = [&](int ph, int& first, int& cnt) __attribute__((always_inline)) {
@@ -206,10 +253,17 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_tok_kernel(const Slice
     cnt = we > ws ? ((we + 63) >> 6) - (ws >> 6) : 0;
     first = list_first + (ws >> 6);
   };
+  // The bookkeeping of a step is SCALAR work, and a SIMD issues one scalar instruction per 4 cycles for its 4 waves just as it
+  // issues one vector instruction: ~30 scalar instructions per step (64-bit booleans, block index -> address, two flags per side)
+  // were as much of the walk as the vector work.  Now: a running scalar pointer per side, one count-down, one stride that
+  // turns 0 at the end of the stream.
   int iseg_first = 0, iseg_cnt = 0, cseg_cnt = 0, unused_first = 0;
-  int iq_ph = 0, iq_row = 0, iq_left = 0, iq_blk = 0, iq_last = 0;   // issue side: phase, row inside the wave, blocks left, next block
-  int cq_ph = 0, cq_row = 0, cq_left = 0;                             // consume side
-  bool iq_end = false, done = false;
+  int iq_ph = 0, iq_row = 0, iq_left = 0;        // issue side: phase, row inside the wave, blocks left in its part
+  int cq_ph = 0, cq_row = 0, cq_left = 0;        // consume side
+  int done = 0;
+  const uint32_t* iq_ptr = as_global(elems_t);   // the next block (wave-uniform)
+  const uint8_t* iq_rptr = RES ? as_global(P.res) : nullptr;
+  int iq_stride = 64;                            // elements to the next block: 0 once the stream has ended (its last block again)
   seg_of(0, iseg_first, iseg_cnt);
   cseg_cnt = iseg_cnt;
   // the next (phase, row) that has blocks
@@ -217,10 +271,16 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_tok_kernel(const Slice
     for (;;) {
       while (iq_row < n_rows) {
         const int c = __builtin_amdgcn_readlane(iseg_cnt, iq_row);
-        if (c != 0) { iq_left = c; iq_blk = __builtin_amdgcn_readlane(iseg_first, iq_row); return; }
+        if (c != 0) {
+          iq_left = c;
+          const size_t b = (size_t)__builtin_amdgcn_readlane(iseg_first, iq_row) * 64;
+          iq_ptr = as_global(elems_t) + b;
+          if constexpr (RES) iq_rptr = as_global(P.res) + b;
+          return;
+        }
         ++iq_row;
       }
-      if (iq_ph + 1 >= TP.phases) { iq_end = true; iq_left = 0; return; }
+      if (iq_ph + 1 >= TP.phases) { iq_stride = 0; iq_left = 0x7fffffff; return; }   // (the pointers stay on the last block)
       ++iq_ph;
       seg_of(iq_ph, iseg_first, iseg_cnt);
       iq_row = 0;
@@ -228,14 +288,17 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_tok_kernel(const Slice
   };
   auto issue = [&](auto slot_c) __attribute__((always_inline)) {
     constexpr int S = decltype(slot_c)::value;
-    // (past the end of the stream the last block again: every step the same instructions)
-    const int b = iq_end ? iq_last : iq_blk;
-    eq[S] = __builtin_nontemporal_load(ep + (size_t)b * 64);
-    if constexpr (RES) rq[S] = rp[(size_t)b * 64];
-    if (!iq_end) {
-      iq_last = b;
-      ++iq_blk;
-      if (--iq_left == 0) { ++iq_row; iq_advance(); }
+#pragma unroll
+    for (int i = 0; i < EW; ++i) {
+      eq[S][i] = __builtin_nontemporal_load(iq_ptr + epos + EPR * i);
+      if constexpr (RES) rq[S][i] = iq_rptr[epos + EPR * i];
+    }
+    if (--iq_left != 0) {
+      iq_ptr += iq_stride;
+      if constexpr (RES) iq_rptr += iq_stride;
+    } else {
+      ++iq_row;
+      iq_advance();
     }
   };
   typedef float f32x2_t __attribute__((ext_vector_type(2)));
@@ -244,9 +307,30 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_tok_kernel(const Slice
   for (int t = 0; t < TOK; ++t)
 #pragma unroll
     for (int i = 0; i < V / 2; ++i) acc2[t][i] = f32x2_t{0.f, 0.f};
+  f32x4 accm = {0.f, 0.f, 0.f, 0.f};   // MF: D of the MFMA (rows = 4 (lane / 16) + r, column = lane % 16)
   uint32_t c0 = 0, wlen = 0;   // the consume side's phase: its columns
   // a (row, phase) part ends: the 64 lanes' sums -> the row's sums in LDS (this wave owns them)
   auto row_end = [&]() __attribute__((always_inline)) {
+    if constexpr (MF) {
+      // v = 8: lanes 0 - 7: set 0's sums of component `lane` for tokens r = 0..3; lanes 40 - 47: set 1's.  Lane 8 + j gets lane
+      // 40 + j's by the 32-lane swap, lane j lane 8 + j's by a rotation inside the row of 16.  v = 16: lanes 0 - 15 have them.
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = accm[r];
+        if constexpr (V == 8) {
+          auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(accm[r]), __float_as_uint(accm[r]), false, false);
+          const float hi = __uint_as_float(sw[1]);   // (lanes 0 - 31: the value of lane + 32)
+          v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(hi), 0x128 /* row_ror:8 */, 0xf, 0xf, false));
+        }
+        if (lane < V) {
+          typedef __attribute__((address_space(3))) float lds_f_t;
+          lds_f_t* const sp = (lds_f_t*)(uintptr_t)(TP.sum_off + (uint32_t)(((wave * rpw + cq_row) * NV) + r * V + lane) * 4u);
+          *sp = *sp + v;
+        }
+      }
+      accm = f32x4{0.f, 0.f, 0.f, 0.f};
+      return;
+    }
     float acc[NV];
 #pragma unroll
     for (int t = 0; t < TOK; ++t)
@@ -266,7 +350,30 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_tok_kernel(const Slice
   };
   auto consume = [&](auto slot_c) __attribute__((always_inline)) {
     constexpr int S = decltype(slot_c)::value;
-    const uint32_t e = eq[S];
+    if constexpr (MF) {
+      if constexpr ((VPTQ_ST_ABLATE & 4) != 0) { accm[0] += __uint_as_float(eq[S][0] ^ eq[S][EW - 1]); return; }
+      constexpr uint32_t kChunks = V / 4;                                    // 8-byte chunks of an entry
+      const uint32_t q8 = (uint32_t)(lane & (kChunks - 1)) * 8u;             // this lane's chunk
+      const uint32_t qmask = (lane & (kChunks - 1)) ? 0xffffffffu : 0u;      // chunk 0's lanes bring the tokens, the others the zero column
+      u32x2 at[EW], bt[EW], rt[RES ? EW : 1];
+#pragma unroll
+      for (int i = 0; i < EW; ++i) {
+        const uint32_t e = eq[S][i];
+        bt[i] = st_lds_tr8((e >> 16) * kEntry + q8);
+        uint32_t ci = ((e & 0xffffu) - c0) | qmask;
+        ci = ci < wlen ? ci : wlen;
+        at[i] = st_lds_tr8(kXOff + ci * kXStride);
+        if constexpr (RES) rt[i] = st_lds_tr8(TP.res_off + (rq[S][i] << 4) + q8);
+      }
+#pragma unroll
+      for (int i = 0; i < EW; i += 2) {
+        const u32x4 A = {at[i][0], at[i][1], at[i + 1][0], at[i + 1][1]};
+        accm = st_mfma<DT>(A, u32x4{bt[i][0], bt[i][1], bt[i + 1][0], bt[i + 1][1]}, accm);
+        if constexpr (RES) accm = st_mfma<DT>(A, u32x4{rt[i][0], rt[i][1], rt[i + 1][0], rt[i + 1][1]}, accm);
+      }
+      return;
+    }
+    const uint32_t e = eq[S][0];
     if constexpr ((VPTQ_ST_ABLATE & 4) != 0) { acc2[0][0][0] += __uint_as_float(e); return; }
     constexpr int W4 = V / 8;
     u32x4 ent[W4];
@@ -284,7 +391,7 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_tok_kernel(const Slice
       xw[0] = t[0]; xw[1] = t[1];
     }
     u32x4 rent = {0u, 0u, 0u, 0u};
-    if constexpr (RES) rent = lds_load16(TP.res_off + (rq[S] << 4));
+    if constexpr (RES) rent = lds_load16(TP.res_off + (rq[S][0] << 4));
     if constexpr ((VPTQ_ST_ABLATE & 1) != 0) {
       acc2[0][0][0] += __uint_as_float(ent[0][0] ^ xw[0] ^ rent[0]);
       return;
@@ -328,10 +435,8 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_tok_kernel(const Slice
       }
     }
   };
-  // the consume side enters phase ph: everybody has left the previous phase's activations (barrier), this thread's chunk of the
-  // new ones - loaded a phase ago - goes to LDS, barrier, the chunk after it sets out
-  Chunk pre = {};
-  if (tid * 8 < phase_c1(0) - phase_c0(0)) pre = load_chunk(phase_c0(0), tid);
+  // the consume side enters phase ph: everybody has left the previous phase's activations (barrier), this thread's chunks of
+  // the new ones go to LDS, barrier
   auto enter_phase = [&](int ph) __attribute__((always_inline)) {
     if ((VPTQ_ST_ABLATE & 8) && ph > 0) {
       c0 = (uint32_t)phase_c0(ph);
@@ -347,8 +452,7 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_tok_kernel(const Slice
     c0 = (uint32_t)phase_c0(ph);
     wlen = (uint32_t)phase_c1(ph) - c0;
     const int chunks = (int)(wlen >> 3);
-    if (tid < chunks) store_chunk(pre, tid);
-    for (int q = tid + kSLThreads; q < chunks; q += kSLThreads) store_chunk(load_chunk((int)c0, q), q);
+    for (int q = tid; q < chunks; q += kSLThreads) store_chunk(load_chunk((int)c0, q), q);
     if (tid == 0) {   // the zero column
       if constexpr (TOK == 2) *(__attribute__((address_space(3))) uint32_t*)(uintptr_t)(kXOff + wlen * kXStride) = 0u;
       else *(__attribute__((address_space(3))) u32x2*)(uintptr_t)(kXOff + wlen * kXStride) = u32x2{0u, 0u};
@@ -356,7 +460,6 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_tok_kernel(const Slice
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-    if (!(VPTQ_ST_ABLATE & 8) && ph + 1 < TP.phases && tid * 8 < phase_c1(ph + 1) - phase_c0(ph + 1)) pre = load_chunk(phase_c0(ph + 1), tid);
   };
   // the consume side's next row with blocks; at the end of a phase's rows the next phase is entered (EVERY wave enters every
   // phase: the barriers), at the end of the last one the wave is done
@@ -367,7 +470,7 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_tok_kernel(const Slice
         if (cq_left != 0) return;
         ++cq_row;
       }
-      if (cq_ph + 1 >= TP.phases) { done = true; return; }
+      if (cq_ph + 1 >= TP.phases) { done = 1; cq_left = 0x7fffffff; return; }
       ++cq_ph;
       seg_of(cq_ph, unused_first, cseg_cnt);
       cq_row = 0;
@@ -376,25 +479,26 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_tok_kernel(const Slice
   };
   auto step = [&](auto slot_c) __attribute__((always_inline)) {
     __builtin_amdgcn_sched_barrier(0);
-    if (!done) {
-      consume(slot_c);
-      __builtin_amdgcn_sched_barrier(0);
-      issue(slot_c);
-      __builtin_amdgcn_sched_barrier(0);
-      if (--cq_left == 0) {
-        row_end();
-        ++cq_row;
-        cq_advance();
-      }
+    // (after the wave's last block the steps of the round still issue their load - the last block again -: ONE load per
+    // step on every path is what lets the compiler count: vmcnt(queue - 1) before every consume.  With the load under
+    // `if (!done)` it waited for vmcnt(7), 6, ... 0 down the round: half the queue on average, drained once per round.)
+    if (done == 0) consume(slot_c);
+    __builtin_amdgcn_sched_barrier(0);
+    issue(slot_c);
+    __builtin_amdgcn_sched_barrier(0);
+    if (--cq_left == 0) {   // (a wave that is done counts down from 2^31)
+      row_end();
+      ++cq_row;
+      cq_advance();
     }
   };
 
   iq_advance();
   sl_for_slots<kSTQueue>([&](auto slot_c) { issue(slot_c); __builtin_amdgcn_sched_barrier(0); });
-  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kSTQueue * (RES ? 2 : 1)) : "memory");   // the DMA'd table: older than the queue's loads
+  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kSTQueue * (RES ? 2 : 1) * EW) : "memory");   // the DMA'd table: older than the queue's loads
   enter_phase(0);
   cq_advance();
-  while (!done) sl_for_slots<kSTQueue>(step);
+  while (done == 0) sl_for_slots<kSTQueue>(step);
 
   // ---- partial sums of this (table, slice): [token][NSLT][N x V]; sum b x rides with slice 0
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
@@ -469,8 +573,12 @@ static size_t st_partial_bytes(const VptqLayerDesc& d, int tokens) {
 static size_t st_counter_bytes(const VptqLayerDesc& d) {
   return (((size_t)(d.num_indices + kSLWaves - 1) / kSLWaves) * sizeof(uint32_t) + 255) / 256 * 256;
 }
+// ... + (a layer with an input permutation) x[perm] of every token: the kernel stages activations in COLUMN order and a load
+// the compiler can see inside its stream loop costs it the counted waits, so the gather is a pre-pass (gemv_k256c.hip:
+// permute_x_kernel, one workgroup per 2048 columns and token)
+static size_t st_perm_bytes(const VptqLayerDesc& d, int tokens) { return (size_t)tokens * gemv_k256c_perm_bytes(d); }
 size_t gemv_sliced_tok_workspace_bytes(const VptqLayerDesc& d, int tokens) {
-  return st_partial_bytes(d, tokens) + st_counter_bytes(d);
+  return st_partial_bytes(d, tokens) + st_counter_bytes(d) + st_perm_bytes(d, tokens);
 }
 
 // rows per wave: one round of workgroups (slices x tables x row blocks of 16 waves ~ the CUs)
@@ -481,12 +589,13 @@ static int st_rows_per_wave(const VptqLayerDesc& d) {
 }
 
 struct StPlan { int tok, phases, rpw; uint32_t x_off, bd_off, res_off, sum_off, lds; };
-// the template's token count (2 or 4), the fewest phases whose activations fit beside the table, and the LDS map
+// the template's token count (2 or 4), the fewest phases whose activations fit beside the table, and the LDS map.  The rows'
+// sums (16 waves x rows per wave x tokens x v floats) must fit too: where one round of workgroups does not leave room for
+// them even with 4 phases (v = 16 with two tables: 64 floats per row), fewer rows per wave - more workgroups - do.
 static bool st_plan(const VptqLayerDesc& d, const VptqSlicedLayout* L, int tokens, StPlan& pl) {
   if (tokens < 2 || tokens > 4) return false;
   const bool res = sl_res256(d), two = sl_two(d);
   pl.tok = tokens == 2 ? 2 : 4;
-  pl.rpw = st_rows_per_wave(d);
   uint32_t tab = sl_tab_bytes(d, d.num_centroids, 0);
   if (two) {
     const uint32_t t1 = sl_tab_bytes(d, d.num_res_centroids, L[1].whole_table);
@@ -497,14 +606,16 @@ static bool st_plan(const VptqLayerDesc& d, const VptqSlicedLayout* L, int token
   const int wcols = (G + kSTWindows * 8 - 1) / (kSTWindows * 8) * 8;
   static std::atomic<int> min_phases{-1};   // VPTQ_SLICED_MIN_PHASES=2 / 4: more phases than the LDS asks for (A/B runs)
   if (min_phases < 0) { const char* e = getenv("VPTQ_SLICED_MIN_PHASES"); const int v = e ? atoi(e) : 1; min_phases = (v == 2 || v == 4) ? v : 1; }
-  for (int phases = min_phases; phases <= kSTWindows; phases *= 2) {
-    const int wmax = (kSTWindows / phases) * wcols < G ? (kSTWindows / phases) * wcols : G;   // columns of the widest phase
-    uint32_t o = pl.x_off + (uint32_t)(wmax + 8) * (uint32_t)pl.tok * 2u;
-    o = (o + 15u) & ~15u;
-    pl.bd_off = o; o += (uint32_t)pl.tok * kSLWaves * 4u;
-    pl.res_off = o; o += res ? 4096u : 0u;
-    pl.sum_off = o; o += (uint32_t)kSLWaves * (uint32_t)pl.rpw * (uint32_t)(pl.tok * d.vector_len) * 4u;
-    if (o <= kSLLdsLimit) { pl.phases = phases; pl.lds = o; return true; }
+  for (int rpw = st_rows_per_wave(d); rpw >= 1; rpw = rpw > 1 ? (rpw + 1) / 2 : 0) {
+    for (int phases = min_phases; phases <= kSTWindows; phases *= 2) {
+      const int wmax = (kSTWindows / phases) * wcols < G ? (kSTWindows / phases) * wcols : G;   // columns of the widest phase
+      uint32_t o = pl.x_off + (uint32_t)(wmax + 8) * (uint32_t)pl.tok * 2u;
+      o = (o + 15u) & ~15u;
+      pl.bd_off = o; o += (uint32_t)pl.tok * kSLWaves * 4u;
+      pl.res_off = o; o += res ? 4096u : 0u;
+      pl.sum_off = o; o += (uint32_t)kSLWaves * (uint32_t)rpw * (uint32_t)(pl.tok * d.vector_len) * 4u;
+      if (o <= kSLLdsLimit) { pl.phases = phases; pl.rpw = rpw; pl.lds = o; return true; }
+    }
   }
   return false;
 }
@@ -579,7 +690,24 @@ hipError_t launch_gemv_sliced_tok(const VptqLayerDesc& d, const VptqSlicedLayout
   P.x = (const uint16_t*)x;
   P.scale = (const uint16_t*)(d.perm ? d.scale_permuted : d.weight_scale);
   P.wbias = (const uint16_t*)d.weight_bias;
-  P.perm = (const uint16_t*)d.perm;
+  P.perm = nullptr;
+  TP.xs = (const uint16_t*)x;
+  TP.x_stride = d.in_features;
+  if (d.perm) {
+    VptqLayerDesc dd[4];
+    const void* xin[4];
+    void* xout[4];
+    char* const base = (char*)ws + st_partial_bytes(d, tokens) + st_counter_bytes(d);
+    for (int t = 0; t < tokens; ++t) {
+      dd[t] = d;
+      xin[t] = (const uint16_t*)x + (size_t)t * d.in_features;
+      xout[t] = base + (size_t)t * gemv_k256c_perm_bytes(d);
+    }
+    const hipError_t e = launch_permute_x(dd, tokens, xin, xout, st);
+    if (e != hipSuccess) return e;
+    TP.xs = (const uint16_t*)base;
+    TP.x_stride = (int)(gemv_k256c_perm_bytes(d) / 2);
+  }
   P.bias = (const uint16_t*)d.bias;
   P.partial = (float*)ws;
   P.arrived = (uint32_t*)((char*)ws + st_partial_bytes(d, tokens));
@@ -592,7 +720,7 @@ hipError_t launch_gemv_sliced_tok(const VptqLayerDesc& d, const VptqSlicedLayout
   TP.tokens = tokens;
   TP.phases = pl.phases;
   TP.wcols = (d.group_size + kSTWindows * 8 - 1) / (kSTWindows * 8) * 8;
-  TP.x_stride = d.in_features;
+  TP.x_in_stride = d.in_features;
   TP.y_stride = d.out_features;
   TP.bd_off = pl.bd_off; TP.res_off = pl.res_off; TP.sum_off = pl.sum_off;
   const int grid = gemv_sliced_slices(d) * (two ? 2 : 1) * P.n_rowblocks;

@@ -475,15 +475,15 @@ class VQuantLinear(nn.Module):
         return lim
 
     def _sliced_one_launch(self, sl, tokens: int) -> bool:
-        """2 - 4 tokens in ONE launch over the layouts (column phases, gemv_sliced_tok.hip)?  Measured against the gather kernels
-        (profiles/r04/sliced_tokens_one_launch.txt; us per 8192^2 / 4096^2 / 14336 x 4096 layer, gather -> one launch):
-        2 tokens: v8-k65536-0 39.8 / 13.2 / 35.7 -> 22.3 / 11.5 / 20.6, -256 40.1 / 13.4 / 36.2 -> 29.3 / 12.8 / 25.2, -65536
-        76.5 / 21.8 / 66.9 -> 36.1 / 15.9 / 30.9, v16-k65536-65536 52.4 / 19.5 / 53.3 -> 38.4 / 17.7 / 37.6, v16-k65536-0 27.3 / 13.5 /
-        33.2 -> 23.8 / 12.9 / 20.4: every layer from 4096 x 1024 on.  3 - 4 tokens run the 4-token kernel in 4 phases; it is bound
-        by instruction issue (the FMAs of 4 tokens, a 64-lane reduction per row and phase) and by the shorter runs of the element
-        stream: worth it on v = 8 layers from 8192^2 / 4096 x 14336 on - no residual table 40.7 / 35.8 -> 36.0 / 30.0, a second table
-        79.0 / 67.5 -> 60.3 / 53.8, the 256-entry table from 8192 columns on 43.0 / 42.4 -> 41.9 / 34.8 - not at 4096^2 (13.3 -> 16.3)
-        and not for v = 16 (64 sums per lane: 30.6 -> 48.2)."""
+        """2 - 4 tokens in ONE launch over the layouts (column phases; 3 - 4 tokens: the contraction on the matrix pipe -
+        gemv_sliced_tok.hip)?  Measured against the gather kernels (profiles/r04/sliced_tokens_one_launch.txt; us per 8192^2 /
+        4096^2 / 14336 x 4096 layer, gather -> one launch): v8-k65536-0: 2 tokens 40.8 / 12.9 / 36.6 -> 21.4 / 11.5 / 19.0, 4 tokens
+        41.1 / 13.4 / 36.9 -> 26.0 / 13.5 / 22.8; -256: 40.9 / 13.2 / 36.8 -> 23.7 / 12.4 / 20.4 and 44.0 / 16.0 / 42.9 -> 29.4 / 14.8 / 23.9;
+        -65536: 78.2 / 21.5 / 68.8 -> 33.7 / 15.9 / 28.5 and 80.0 / 23.6 / 72.0 -> 39.8 / 18.5 / 43.6; v16-k65536-0: 27.7 / 13.7 / 33.5 ->
+        23.4 / 12.8 / 19.5 and 31.1 / 15.2 -> 25.6 / 14.4; v16-k65536-65536: 53.0 / 19.6 / 53.9 -> 37.7 / 17.8 / 36.1 and 55.8 / 21.0 ->
+        51.7 / 20.5 (64 sums per row and token set: two rounds of workgroups at 8192^2; 4096 x 14336: 57.2 -> 65.5, not taken).
+        v = 16 with a residual table of <= 1024 entries stays on the gather kernel, which holds that table in LDS (v16-k65536-1024,
+        2 tokens: 28.3 -> 36.1)."""
         key = ("_one_launch", tokens)
         ok = sl.__dict__.get(key)
         if ok is None:
@@ -494,14 +494,14 @@ class VQuantLinear(nn.Module):
             else:
                 n_el = self.indices.shape[1] * self.group_size      # index elements per table
                 kr = self.num_res_centroids if self.enable_residual else 0
-                if tokens == 2:    # (smaller layers are launch-bound on every route and were not measured)
-                    ok = n_el >= 1 << 19
-                elif self.vector_len != 8:
+                if n_el < 1 << 19:       # (smaller layers are launch-bound on every route and were not measured)
                     ok = False
-                elif kr not in (0, 256):
-                    ok = n_el >= 4 << 20
+                elif self.vector_len == 8 or kr == 0:
+                    ok = True
+                elif kr <= 1024:
+                    ok = False
                 else:
-                    ok = n_el >= 6 << 20 and (kr == 0 or self.group_size >= 8192)
+                    ok = tokens == 2 or self.out_features <= 8192
             sl.__dict__[key] = ok
         return ok
 
