@@ -169,6 +169,35 @@ def k65536_extra(lib, B, dev, H, steps, warmup, regions, R=8, kr=256, v=8):
     layers[-1].enable_sliced_layout(False)   # (reference = the gather kernel, not the module's default one-token route)
     ref = layers[-1](x)
     out["sliced_vs_default_rel_diff"] = ((ys[-1].float() - ref.float()).abs().max() / ref.float().abs().max()).item()
+    # 2 and 4 tokens: the gather kernel (vptq_quant_gemv) against ONE launch over the same layouts (gemv_sliced_tok.hip:
+    # column phases; 4 tokens contract on the matrix pipe), where the library takes the layer
+    for tokens in (2, 4):
+        if not all(sl.tokens_supported(tokens) for sl in sls):
+            continue
+        xt = torch.randn(1, tokens, H, device=dev, generator=torch.Generator(device=dev).manual_seed(8)).half()
+        yt = [torch.empty(1, tokens, H, device=dev, dtype=torch.float16) for _ in range(R)]
+
+        def gather_pass():
+            sp = torch.cuda.current_stream().cuda_stream
+            for i in range(R):
+                rc = lib.vptq_quant_gemv(descs[i][0], xt.data_ptr(), yt[i].data_ptr(), tokens, 0, None, 0, sp)
+                assert rc == 0, lib.vptq_last_error()
+
+        def tokens_pass():
+            for i in range(R):
+                assert sls[i].forward_tokens(xt, yt[i]) is not None
+        tokens_pass()
+        torch.cuda.synchronize()
+        got = yt[-1].clone()
+        row = {}
+        for key, fn in (("default", gather_pass), ("sliced_one_launch", tokens_pass)):
+            t = Timer(dev).run(fn, steps, warmup, regions)
+            row[key + "_us_per_layer"] = t["event_ms"] * 1e3 / (steps * R)
+        gather_pass()
+        torch.cuda.synchronize()
+        row["rel_diff"] = ((got.float() - yt[-1].float()).abs().max() / yt[-1].float().abs().max()).item()
+        assert row["rel_diff"] <= 2e-3, row     # (both within 1e-3 of the reference)
+        out[f"tokens{tokens}"] = row
     del layers, sls
     torch.cuda.empty_cache()
     return out
