@@ -28,6 +28,7 @@
 namespace vptq {
 
 constexpr int kSTWindows = VPTQ_SLICED_WINDOWS;
+constexpr int kSTRegRows = 4;   // rows per wave whose sums (4 registers each in matrix-pipe mode) are kept in registers
 // element blocks in flight per wave (4 where a lane carries 64 sums: v = 16 with 4 tokens would spill at 8)
 #ifndef VPTQ_ST_QUEUE
 #define VPTQ_ST_QUEUE 8
@@ -64,6 +65,7 @@ struct SlicedTokParams {
   int wcols;                 // columns per layout window
   int x_stride, x_in_stride, y_stride;    // elements between two tokens of xs / p.x / y
   uint32_t bd_off, res_off, sum_off;   // LDS: sum b x parts [TOK][16 waves] floats; 256-entry residual table; row sums
+  int reg_sums;              // (matrix-pipe mode, <= kSTRegRows rows per wave) the rows' sums stay in registers: no LDS for them
 };
 
 template <typename DT, int NSL, bool RES, int V, bool TWO, int TOK>
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_tok_kernel(const Slice
   // ---- the rows' sums start at zero
   {
     typedef __attribute__((address_space(3))) u32x4 lds_q_t;
-    const int n16 = kSLWaves * rpw * NV / 4;
+    const int n16 = TP.reg_sums ? 0 : kSLWaves * rpw * NV / 4;
     for (int q = tid; q < n16; q += kSLThreads) *(lds_q_t*)(uintptr_t)(TP.sum_off + (uint32_t)q * 16u) = u32x4{0u, 0u, 0u, 0u};
   }
 
@@ -308,10 +310,20 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_tok_kernel(const Slice
 #pragma unroll
     for (int i = 0; i < V / 2; ++i) acc2[t][i] = f32x2_t{0.f, 0.f};
   f32x4 accm = {0.f, 0.f, 0.f, 0.f};   // MF: D of the MFMA (rows = 4 (lane / 16) + r, column = lane % 16)
+  f32x4 saved[MF ? kSTRegRows : 1];    // MF, reg_sums: the sums of the wave's rows over the phases
+#pragma unroll
+  for (int k = 0; k < (MF ? kSTRegRows : 1); ++k) saved[k] = f32x4{0.f, 0.f, 0.f, 0.f};
   uint32_t c0 = 0, wlen = 0;   // the consume side's phase: its columns
   // a (row, phase) part ends: the 64 lanes' sums -> the row's sums in LDS (this wave owns them)
   auto row_end = [&]() __attribute__((always_inline)) {
     if constexpr (MF) {
+      if (TP.reg_sums) {   // D as it is (v = 8: both sets' lanes) into the row's registers; the sets meet once, at the end
+#pragma unroll
+        for (int k = 0; k < kSTRegRows; ++k)
+          if (cq_row == k) saved[k] += accm;
+        accm = f32x4{0.f, 0.f, 0.f, 0.f};
+        return;
+      }
       // v = 8: lanes 0 - 7: set 0's sums of component `lane` for tokens r = 0..3; lanes 40 - 47: set 1's.  Lane 8 + j gets lane
       // 40 + j's by the 32-lane swap, lane j lane 8 + j's by a rotation inside the row of 16.  v = 16: lanes 0 - 15 have them.
 #pragma unroll
@@ -518,7 +530,28 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_tok_kernel(const Slice
         for (int i = 0; i < kSLWaves; ++i) bdot[t] += bp[i];
       }
     }
-    for (int k = tid; k < n_rows_wg * NV; k += kSLThreads) {
+    if constexpr (MF) {
+      if (TP.reg_sums) {   // every wave stores its rows' sums itself: lanes 0 .. v - 1 = the outputs, 4 registers = the tokens
+#pragma unroll
+        for (int k = 0; k < kSTRegRows; ++k) {
+          if (k < n_rows) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float v = saved[k][r];
+              if constexpr (V == 8) {
+                auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+                v += __int_as_float(__builtin_amdgcn_update_dpp(0, (int)sw[1], 0x128 /* row_ror:8 */, 0xf, 0xf, false));
+              }
+              if (lane < V && r < tokens) {
+                float* const pp = as_global(P.partial) + (((size_t)r * NSLT + sg) * N + (size_t)(row0 + k)) * V + lane;
+                __hip_atomic_store(pp, v + bdot[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              }
+            }
+          }
+        }
+      }
+    }
+    for (int k = tid; k < (TP.reg_sums ? 0 : n_rows_wg * NV); k += kSLThreads) {
       const int r = k / NV, e = k % NV, t = e / V, o = e % V;
       if (t < tokens) {
         float v = *(const float*)(smem + TP.sum_off + (uint32_t)k * 4u);
@@ -588,7 +621,7 @@ static int st_rows_per_wave(const VptqLayerDesc& d) {
   return (int)(r < 1 ? 1 : r > kSLMaxRowsPerWave ? kSLMaxRowsPerWave : r);
 }
 
-struct StPlan { int tok, phases, rpw; uint32_t x_off, bd_off, res_off, sum_off, lds; };
+struct StPlan { int tok, phases, rpw, reg_sums; uint32_t x_off, bd_off, res_off, sum_off, lds; };
 // the template's token count (2 or 4), the fewest phases whose activations fit beside the table, and the LDS map.  The rows'
 // sums (16 waves x rows per wave x tokens x v floats) must fit too: where one round of workgroups does not leave room for
 // them even with 4 phases (v = 16 with two tables: 64 floats per row), fewer rows per wave - more workgroups - do.
@@ -606,6 +639,8 @@ static bool st_plan(const VptqLayerDesc& d, const VptqSlicedLayout* L, int token
   const int wcols = (G + kSTWindows * 8 - 1) / (kSTWindows * 8) * 8;
   static std::atomic<int> min_phases{-1};   // VPTQ_SLICED_MIN_PHASES=2 / 4: more phases than the LDS asks for (A/B runs)
   if (min_phases < 0) { const char* e = getenv("VPTQ_SLICED_MIN_PHASES"); const int v = e ? atoi(e) : 1; min_phases = (v == 2 || v == 4) ? v : 1; }
+  static std::atomic<int> no_reg_sums{-1};  // VPTQ_SLICED_LDS_SUMS=1: the rows' sums in LDS in every mode (A/B runs)
+  if (no_reg_sums < 0) { const char* e = getenv("VPTQ_SLICED_LDS_SUMS"); no_reg_sums = (e && atoi(e) == 1) ? 1 : 0; }
   for (int rpw = st_rows_per_wave(d); rpw >= 1; rpw = rpw > 1 ? (rpw + 1) / 2 : 0) {
     for (int phases = min_phases; phases <= kSTWindows; phases *= 2) {
       const int wmax = (kSTWindows / phases) * wcols < G ? (kSTWindows / phases) * wcols : G;   // columns of the widest phase
@@ -613,8 +648,9 @@ static bool st_plan(const VptqLayerDesc& d, const VptqSlicedLayout* L, int token
       o = (o + 15u) & ~15u;
       pl.bd_off = o; o += (uint32_t)pl.tok * kSLWaves * 4u;
       pl.res_off = o; o += res ? 4096u : 0u;
-      pl.sum_off = o; o += (uint32_t)kSLWaves * (uint32_t)rpw * (uint32_t)(pl.tok * d.vector_len) * 4u;
-      if (o <= kSLLdsLimit) { pl.phases = phases; pl.rpw = rpw; pl.lds = o; return true; }
+      const int reg_sums = pl.tok == 4 && rpw <= kSTRegRows && !no_reg_sums;   // (matrix-pipe mode: 4 registers per row)
+      pl.sum_off = o; o += reg_sums ? 0u : (uint32_t)kSLWaves * (uint32_t)rpw * (uint32_t)(pl.tok * d.vector_len) * 4u;
+      if (o <= kSLLdsLimit) { pl.phases = phases; pl.rpw = rpw; pl.reg_sums = reg_sums; pl.lds = o; return true; }
     }
   }
   return false;
@@ -723,6 +759,7 @@ hipError_t launch_gemv_sliced_tok(const VptqLayerDesc& d, const VptqSlicedLayout
   TP.x_in_stride = d.in_features;
   TP.y_stride = d.out_features;
   TP.bd_off = pl.bd_off; TP.res_off = pl.res_off; TP.sum_off = pl.sum_off;
+  TP.reg_sums = pl.reg_sums;
   const int grid = gemv_sliced_slices(d) * (two ? 2 : 1) * P.n_rowblocks;
   if (d.dtype == VPTQ_DTYPE_F16)
     return pl.tok == 2 ? launch_st_dt<F16, 2>(TP, grid, d.vector_len, nsl, res, two, pl.lds, st)

@@ -481,7 +481,7 @@ class VQuantLinear(nn.Module):
         41.1 / 13.4 / 36.9 -> 26.0 / 13.5 / 22.8; -256: 40.9 / 13.2 / 36.8 -> 23.7 / 12.4 / 20.4 and 44.0 / 16.0 / 42.9 -> 29.4 / 14.8 / 23.9;
         -65536: 78.2 / 21.5 / 68.8 -> 33.7 / 15.9 / 28.5 and 80.0 / 23.6 / 72.0 -> 39.8 / 18.5 / 43.6; v16-k65536-0: 27.7 / 13.7 / 33.5 ->
         23.4 / 12.8 / 19.5 and 31.1 / 15.2 -> 25.6 / 14.4; v16-k65536-65536: 53.0 / 19.6 / 53.9 -> 37.7 / 17.8 / 36.1 and 55.8 / 21.0 ->
-        51.7 / 20.5 (64 sums per row and token set: two rounds of workgroups at 8192^2; 4096 x 14336: 57.2 -> 65.5, not taken).
+        46.0 / 20.5 (4096 x 14336: 7 rows per wave - their sums in LDS, two rounds of workgroups: 57.2 -> 58.0, not taken).
         v = 16 with a residual table of <= 1024 entries stays on the gather kernel, which holds that table in LDS (v16-k65536-1024,
         2 tokens: 28.3 -> 36.1)."""
         key = ("_one_launch", tokens)
