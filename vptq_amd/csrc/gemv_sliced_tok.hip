@@ -628,7 +628,9 @@ struct StPlan { int tok, phases, rpw, reg_sums; uint32_t x_off, bd_off, res_off,
 static bool st_plan(const VptqLayerDesc& d, const VptqSlicedLayout* L, int tokens, StPlan& pl) {
   if (tokens < 2 || tokens > 4) return false;
   const bool res = sl_res256(d), two = sl_two(d);
-  pl.tok = tokens == 2 ? 2 : 4;
+  static std::atomic<int> tok4{-1};   // VPTQ_SLICED_TOK4=1: 2 tokens through the 4-slot (matrix-pipe) kernel too (A/B runs)
+  if (tok4 < 0) { const char* e = getenv("VPTQ_SLICED_TOK4"); tok4 = (e && atoi(e) == 1) ? 1 : 0; }
+  pl.tok = (tokens == 2 && !tok4) ? 2 : 4;
   uint32_t tab = sl_tab_bytes(d, d.num_centroids, 0);
   if (two) {
     const uint32_t t1 = sl_tab_bytes(d, d.num_res_centroids, L[1].whole_table);
