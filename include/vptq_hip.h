@@ -331,6 +331,13 @@ VPTQ_API size_t vptq_quant_gemv_sliced_tokens_workspace_bytes(const VptqLayerDes
 VPTQ_API int vptq_quant_gemv_sliced_tokens(const VptqLayerDesc* desc, const VptqSlicedLayout* layout, const void* x, void* y,
                                   int tokens, int flags, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ... and for up to 3 sibling layers (one format, dtype and input width, the SAME x [tokens][in_features]) in one launch, as
+ * vptq_quant_gemv_sliced_grouped does for one token: y / workspaces / workspace_bytes one per layer
+ * (vptq_quant_gemv_sliced_tokens_workspace_bytes each) */
+VPTQ_API int vptq_quant_gemv_sliced_tokens_grouped(const VptqLayerDesc* descs, const VptqSlicedLayout* layouts, int n, const void* x,
+                                          void* const* y, int tokens, int flags, void* const* workspaces,
+                                          const size_t* workspace_bytes, void* stream);
+
 /* Up to 3 layers of ONE format, dtype and input width that read the SAME activation (q / k / v, gate / up) in one launch
  * (ABI >= 7): layouts = the layers' structs one after the other (vptq_sliced_layout_tables() each; give every struct the
  * group's rows_per_wave - one round of workgroups over ALL layers), y / workspaces / workspace_bytes one per layer.  The

@@ -558,3 +558,40 @@ def test_module_route_for_two_to_four_tokens_in_one_launch(dev, monkeypatch):
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(yg.view(torch.int16), y2.view(torch.int16))
+
+
+@pytest.mark.parametrize("tokens", [2, 3, 4])
+@pytest.mark.parametrize("v,kr,dt", [(8, 256, "f16"), (8, 0, "bf16"), (8, 65536, "f16"), (16, 65536, "f16"), (16, 0, "bf16")])
+def test_sibling_layers_share_one_launch_for_two_to_four_tokens(v, kr, dt, tokens, dev, monkeypatch):
+    """q / k / v of a large-codebook model, 2 - 4 tokens: ONE launch of the token kernel for the group
+    (`vptq_quant_gemv_sliced_tokens_grouped` via `SiblingGroup.forward_sliced`): bit-identical to the layers' own launches where the
+    rows per wave do not change the order of a row's sums (they do not: a row is summed by one wave, phase by phase), one
+    member with a permutation (its own pre-pass), one with an output bias"""
+    import vptq_amd.layers.vqlinear as vq
+    from vptq_amd.layers.vqlinear import SiblingGroup
+    from vptq_amd.utils.sliced import SlicedGemv
+    monkeypatch.setattr(vq, "_SLICED_ONE_LAUNCH", "1")       # (small test layers: below the auto rule's size)
+    I = 2048
+    outs = (1024, 33 * v, 512)
+    Ls = [vo.make_layer(I, O, dist="llm", seed=170 + i + kr % 7 + tokens, dtype=dt, vector_len=v, num_centroids=65536, num_res_centroids=kr,
+                        bias=(i == 1), enable_perm=(i == 2)) for i, O in enumerate(outs)]
+    ms = [spec_to_module(L, dev) for L in Ls]
+    x = _xt(I, tokens, dt, "llm", 31)
+    xt = bits_to_tensor(x, dt, dev).reshape(x.shape)
+    for m in ms:
+        m.enable_sliced_layout()
+    alone = [SlicedGemv(m).forward_tokens(xt) for m in ms]
+    assert all(a is not None for a in alone)
+    group = SiblingGroup(ms)
+    for m in ms:
+        object.__setattr__(m, "_siblings", group)
+    [m(xt[:, :1].contiguous()) for m in ms]        # (one token first: builds the layouts and the group)
+    ys = [m(xt) for m in ms]                       # the first call launches all three
+    torch.cuda.synchronize()
+    assert len(group._sout) == 0                   # every member picked its output up
+    for L, y, a in zip(Ls, ys, alone):
+        assert torch.equal(y.view(torch.int16), a.view(torch.int16))
+        assert rel_err(tensor_to_bits(y), vo.forward(L, x), dt) <= TOL[dt]
+    x2 = bits_to_tensor(_xt(I, tokens, dt, "llm", 32), dt, dev).reshape(x.shape)
+    y2 = [m(x2) for m in ms]
+    assert rel_err(tensor_to_bits(y2[2]), vo.forward(Ls[2], tensor_to_bits(x2)), dt) <= TOL[dt]

@@ -18,9 +18,34 @@ ap.add_argument("--k", type=int, default=65536)
 ap.add_argument("--kr", type=int, default=0)
 ap.add_argument("--v", type=int, default=8)
 ap.add_argument("--no-eight", action="store_true")
+ap.add_argument("--siblings", default="", help="O1,O2,O3 with --shapes I,*: q / k / v as three launches against one grouped launch, 1 - 4 tokens")
 ap.add_argument("--only-one-launch", action="store_true", help="time only the one-launch kernel (ablation builds: results are wrong)")
 a = ap.parse_args()
 dev = torch.device("cuda", 0); g = torch.Generator(device=dev).manual_seed(0)
+if a.siblings:
+    from vptq_amd.utils.sliced import SlicedGemv, SlicedGroupGemv
+    I = int(a.shapes.split(';')[0].split(',')[0])
+    outs = [int(o) for o in a.siblings.split(',')]
+    groups = []
+    for _ in range(a.ring):
+        ms = [mk(I, O, dev, g, k=a.k, kr=a.kr, v=a.v) for O in outs]
+        sls = [SlicedGemv(m) for m in ms]
+        groups.append((ms, sls, SlicedGroupGemv(sls)))
+    row = dict(I=I, outs=outs, v=a.v, k=a.k, kr=a.kr)
+    for T in (1, 2, 3, 4):
+        x = torch.randn(1, T, I, device=dev).half()
+        if T == 1:
+            f_alone = lambda: [[sl(x) for sl in sls] for _, sls, _ in groups]
+            f_group = lambda: [sg(x) for _, _, sg in groups]
+        else:
+            if not all(sg.tokens_supported(T) for _, _, sg in groups):
+                continue
+            f_alone = lambda: [[sl.forward_tokens(x) for sl in sls] for _, sls, _ in groups]
+            f_group = lambda: [sg.forward_tokens(x) for _, _, sg in groups]
+        f_alone(); f_group()
+        row[f"t{T}"] = dict(three_launches_us=round(time_graph(f_alone, 10) / a.ring, 2), one_launch_us=round(time_graph(f_group, 10) / a.ring, 2))
+    print(json.dumps(row), flush=True)
+    sys.exit(0)
 for I, O in [tuple(int(v) for v in p.split(',')) for p in a.shapes.split(';')]:
     layers = [mk(I, O, dev, g, k=a.k, kr=a.kr, v=a.v) for _ in range(a.ring)]
     row = dict(I=I, O=O, v=a.v, k=a.k, kr=a.kr)

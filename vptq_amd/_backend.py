@@ -92,6 +92,8 @@ EXPORTS = {
     "vptq_quant_gemv_sliced_tokens_workspace_bytes": (C.c_size_t, [C.POINTER(LayerDesc), C.c_int]),
     "vptq_quant_gemv_sliced_tokens": (C.c_int, [C.POINTER(LayerDesc), C.POINTER(SlicedLayout), _vp, _vp, C.c_int, C.c_int, _vp,
                                                 C.c_size_t, _vp]),
+    "vptq_quant_gemv_sliced_tokens_grouped": (C.c_int, [C.POINTER(LayerDesc), C.POINTER(SlicedLayout), C.c_int, _vp, C.POINTER(_vp), C.c_int, C.c_int,
+                                                        C.POINTER(_vp), C.POINTER(C.c_size_t), _vp]),
     "vptq_quant_gemv_sliced_grouped": (C.c_int, [C.POINTER(LayerDesc), C.POINTER(SlicedLayout), C.c_int, _vp, C.POINTER(_vp), C.c_int,
                                                  C.POINTER(_vp), C.POINTER(C.c_size_t), _vp]),
     "vptq_quant_gemm_supported": (C.c_int, [C.POINTER(LayerDesc)]),

@@ -545,6 +545,29 @@ int vptq_quant_gemv_sliced_grouped(const VptqLayerDesc* descs, const VptqSlicedL
   return e == hipSuccess ? VPTQ_OK : hip_fail(e, "gemv_sliced grouped launch");
 }
 
+int vptq_quant_gemv_sliced_tokens_grouped(const VptqLayerDesc* descs, const VptqSlicedLayout* layouts, int n, const void* x,
+                                          void* const* y, int tokens, int flags, void* const* workspaces, const size_t* workspace_bytes,
+                                          void* stream) {
+  if (!descs || !layouts || !x || !y || !workspaces || !workspace_bytes) return fail(VPTQ_E_NULL, "descs / layouts / x / y / workspaces is NULL");
+  if (n < 1 || n > 3) return fail(VPTQ_E_UNSUPPORTED, "a sliced group takes 1 .. 3 layers");
+  for (int i = 0; i < n; ++i) {
+    if (int rc = validate_layer(descs + i)) return rc;
+    if (!y[i]) return fail(VPTQ_E_NULL, "y[%d] is NULL", i);
+  }
+  if (flags & (VPTQ_GEMV_EXACT | VPTQ_GEMV_FORCE_GENERIC))
+    return fail(VPTQ_E_UNSUPPORTED, "the sliced path has the folded arithmetic only: use vptq_quant_gemv");
+  if (!vptq::gemv_sliced_tok_groupable(descs, layouts, n, tokens))
+    return fail(VPTQ_E_UNSUPPORTED, "a sliced group of 2 - 4 tokens takes layers of ONE format, dtype and input width whose layouts carry wstart");
+  if ((((uintptr_t)x) & 15) != 0) return fail(VPTQ_E_UNSUPPORTED, "x must be 16-byte aligned");
+  for (int i = 0; i < n; ++i) {
+    const size_t need = vptq::gemv_sliced_tok_workspace_bytes(descs[i], tokens);
+    if (!workspaces[i] || workspace_bytes[i] < need || (((uintptr_t)workspaces[i]) & 15) != 0)
+      return fail(VPTQ_E_WORKSPACE, "layer %d: workspace of %zu bytes (16-byte aligned, zero-initialised) needed for %d tokens", i, need, tokens);
+  }
+  const hipError_t e = vptq::launch_gemv_sliced_tok_group(descs, layouts, n, x, y, tokens, flags, workspaces, (hipStream_t)stream);
+  return e == hipSuccess ? VPTQ_OK : hip_fail(e, "gemv_sliced_tok grouped launch");
+}
+
 size_t vptq_quant_gemm_workspace_bytes(const VptqLayerDesc* d, int tokens) {
   if (validate_layer(d) != VPTQ_OK || tokens < 1) return 0;
   return vptq::gemm_fused_workspace_bytes(*d, tokens);

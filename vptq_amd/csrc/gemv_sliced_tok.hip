@@ -68,8 +68,30 @@ struct SlicedTokParams {
   int reg_sums;              // (matrix-pipe mode, <= kSTRegRows rows per wave) the rows' sums stay in registers: no LDS for them
 };
 
+// Up to kSTMaxGroup layers that read the SAME activations (q / k / v, gate / up) in one launch, as in gemv_sliced.hip: layer l
+// owns the workgroups [start[l], start[l + 1]); the fixed part of a launch is paid once.
+constexpr int kSTMaxGroup = 3;
+struct SlicedTokGroupParams {
+  int n;
+  int start[kSTMaxGroup + 1];
+  SlicedTokParams p[kSTMaxGroup];
+};
+
 template <typename DT, int NSL, bool RES, int V, bool TWO, int TOK>
-__global__ __launch_bounds__(kSLThreads) void gemv_sliced_tok_kernel(const SlicedTokParams TP) {
+__global__ __launch_bounds__(kSLThreads) void gemv_sliced_tok_kernel(const SlicedTokGroupParams GP) {
+  // this workgroup's layer; its parameters come out of the kernel-argument segment through the scalar cache (gemv_sliced.hip)
+  int layer = 0;
+  if (GP.n > 1 && (int)blockIdx.x >= GP.start[1]) layer = 1;
+  if (GP.n > 2 && (int)blockIdx.x >= GP.start[2]) layer = 2;
+  layer = __builtin_amdgcn_readfirstlane(layer);
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef const char __attribute__((address_space(4)))* st_kernarg_t;
+  typedef const SlicedTokParams __attribute__((address_space(4)))* st_params_t;
+  const SlicedTokParams TP = *(st_params_t)((st_kernarg_t)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(SlicedTokGroupParams, p) +
+                                            (size_t)layer * sizeof(SlicedTokParams));
+#else
+  const SlicedTokParams TP = GP.p[0];   // (host pass of the compiler: never executed)
+#endif
   static_assert(((V == 8 && (NSL == 8 || NSL == 16)) || (V == 16 && (NSL == 16 || NSL == 32))) && (V == 8 || !RES) && !(TWO && RES) &&
                 (TOK == 2 || TOK == 4), "instantiation");
   const SlicedParams& P = TP.p;
@@ -86,7 +108,7 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_tok_kernel(const Slice
   }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int bx = (int)blockIdx.x;
+  const int bx = (int)blockIdx.x - (layer == 0 ? 0 : layer == 1 ? GP.start[1] : GP.start[2]);
   const int sg = bx & (NSLT - 1), rb = bx / NSLT;
   const int s = sg & (NSL - 1);
   const bool second = TWO && sg >= NSL;
@@ -625,7 +647,7 @@ struct StPlan { int tok, phases, rpw, reg_sums; uint32_t x_off, bd_off, res_off,
 // the template's token count (2 or 4), the fewest phases whose activations fit beside the table, and the LDS map.  The rows'
 // sums (16 waves x rows per wave x tokens x v floats) must fit too: where one round of workgroups does not leave room for
 // them even with 4 phases (v = 16 with two tables: 64 floats per row), fewer rows per wave - more workgroups - do.
-static bool st_plan(const VptqLayerDesc& d, const VptqSlicedLayout* L, int tokens, StPlan& pl) {
+static bool st_plan(const VptqLayerDesc& d, const VptqSlicedLayout* L, int tokens, StPlan& pl, int rpw0 = 0) {
   if (tokens < 2 || tokens > 4) return false;
   const bool res = sl_res256(d), two = sl_two(d);
   static std::atomic<int> tok4{-1};   // VPTQ_SLICED_TOK4=1: 2 tokens through the 4-slot (matrix-pipe) kernel too (A/B runs)
@@ -643,7 +665,7 @@ static bool st_plan(const VptqLayerDesc& d, const VptqSlicedLayout* L, int token
   if (min_phases < 0) { const char* e = getenv("VPTQ_SLICED_MIN_PHASES"); const int v = e ? atoi(e) : 1; min_phases = (v == 2 || v == 4) ? v : 1; }
   static std::atomic<int> no_reg_sums{-1};  // VPTQ_SLICED_LDS_SUMS=1: the rows' sums in LDS in every mode (A/B runs)
   if (no_reg_sums < 0) { const char* e = getenv("VPTQ_SLICED_LDS_SUMS"); no_reg_sums = (e && atoi(e) == 1) ? 1 : 0; }
-  for (int rpw = st_rows_per_wave(d); rpw >= 1; rpw = rpw > 1 ? (rpw + 1) / 2 : 0) {
+  for (int rpw = rpw0 > 0 ? rpw0 : st_rows_per_wave(d); rpw >= 1; rpw = rpw > 1 ? (rpw + 1) / 2 : 0) {
     for (int phases = min_phases; phases <= kSTWindows; phases *= 2) {
       const int wmax = (kSTWindows / phases) * wcols < G ? (kSTWindows / phases) * wcols : G;   // columns of the widest phase
       uint32_t o = pl.x_off + (uint32_t)(wmax + 8) * (uint32_t)pl.tok * 2u;
@@ -668,7 +690,7 @@ bool gemv_sliced_tok_eligible(const VptqLayerDesc& d, const VptqSlicedLayout* L,
 }
 
 template <typename DT, int NSL, bool RES, int V, bool TWO, int TOK>
-static hipError_t launch_st(const SlicedTokParams& P, int grid, uint32_t lds, hipStream_t st) {
+static hipError_t launch_st(const SlicedTokGroupParams& P, int grid, uint32_t lds, hipStream_t st) {
   auto kern = gemv_sliced_tok_kernel<DT, NSL, RES, V, TWO, TOK>;
   static std::atomic<bool> attr_set[64];
   int dev = 0;
@@ -682,7 +704,7 @@ static hipError_t launch_st(const SlicedTokParams& P, int grid, uint32_t lds, hi
   return hipGetLastError();
 }
 template <typename DT, int TOK>
-static hipError_t launch_st_dt(const SlicedTokParams& P, int grid, int v, int nsl, bool res, bool two, uint32_t lds, hipStream_t st) {
+static hipError_t launch_st_dt(const SlicedTokGroupParams& P, int grid, int v, int nsl, bool res, bool two, uint32_t lds, hipStream_t st) {
   if (v == 16) {
     if (two) return nsl == 16 ? launch_st<DT, 16, false, 16, true, TOK>(P, grid, lds, st) : launch_st<DT, 32, false, 16, true, TOK>(P, grid, lds, st);
     return nsl == 16 ? launch_st<DT, 16, false, 16, false, TOK>(P, grid, lds, st) : launch_st<DT, 32, false, 16, false, TOK>(P, grid, lds, st);
@@ -692,19 +714,18 @@ static hipError_t launch_st_dt(const SlicedTokParams& P, int grid, int v, int ns
   return res ? launch_st<DT, 16, true, 8, false, TOK>(P, grid, lds, st) : launch_st<DT, 16, false, 8, false, TOK>(P, grid, lds, st);
 }
 
-// x: [tokens][in_features], y: [tokens][out_features] (fp32 with VPTQ_GEMV_OUT_F32); ws: gemv_sliced_tok_workspace_bytes,
-// zero before its first use (every launch leaves the counters zero)
-hipError_t launch_gemv_sliced_tok(const VptqLayerDesc& d, const VptqSlicedLayout* L, const void* x, void* y, int tokens, int flags,
-                                  void* ws, hipStream_t st) {
-  StPlan pl;
-  if (!gemv_sliced_tok_eligible(d, L, tokens) || !st_plan(d, L, tokens, pl)) return hipErrorInvalidValue;
+// one layer's parameter block (its permutation pre-pass is queued into perm_*: one launch for the whole group)
+struct StPermJobs { VptqLayerDesc d[4 * kSTMaxGroup]; const void* xin[4 * kSTMaxGroup]; void* xout[4 * kSTMaxGroup]; int n; };
+static hipError_t st_fill(const VptqLayerDesc& d, const VptqSlicedLayout* L, const void* x, void* y, int tokens, int flags, void* ws,
+                          int rpw0, SlicedTokParams& TP, StPlan& pl, StPermJobs& jobs) {
+  if (!gemv_sliced_tok_eligible(d, L, tokens) || !st_plan(d, L, tokens, pl, rpw0)) return hipErrorInvalidValue;
   const bool res = sl_res256(d), two = sl_two(d);
   const int nsl = gemv_sliced_slices(d);
   if (!sl_layout_ok(d, L[0], nsl, res, d.num_centroids) || L[0].whole_table != 0 ||
       (two && (!sl_layout_ok(d, L[1], nsl, false, d.num_res_centroids) || L[1].whole_table != gemv_sliced_whole_table(d, 1))) ||
       !ws || (((uintptr_t)x) & 15) != 0 || (d.in_features % 8) != 0)
     return hipErrorInvalidValue;
-  SlicedTokParams TP = {};
+  TP = SlicedTokParams{};
   SlicedParams& P = TP.p;
   P.elems = (const uint32_t*)L[0].elems;
   P.res = res ? (const uint8_t*)L[0].res : nullptr;
@@ -732,17 +753,13 @@ hipError_t launch_gemv_sliced_tok(const VptqLayerDesc& d, const VptqSlicedLayout
   TP.xs = (const uint16_t*)x;
   TP.x_stride = d.in_features;
   if (d.perm) {
-    VptqLayerDesc dd[4];
-    const void* xin[4];
-    void* xout[4];
     char* const base = (char*)ws + st_partial_bytes(d, tokens) + st_counter_bytes(d);
     for (int t = 0; t < tokens; ++t) {
-      dd[t] = d;
-      xin[t] = (const uint16_t*)x + (size_t)t * d.in_features;
-      xout[t] = base + (size_t)t * gemv_k256c_perm_bytes(d);
+      jobs.d[jobs.n] = d;
+      jobs.xin[jobs.n] = (const uint16_t*)x + (size_t)t * d.in_features;
+      jobs.xout[jobs.n] = base + (size_t)t * gemv_k256c_perm_bytes(d);
+      ++jobs.n;
     }
-    const hipError_t e = launch_permute_x(dd, tokens, xin, xout, st);
-    if (e != hipSuccess) return e;
     TP.xs = (const uint16_t*)base;
     TP.x_stride = (int)(gemv_k256c_perm_bytes(d) / 2);
   }
@@ -762,12 +779,66 @@ hipError_t launch_gemv_sliced_tok(const VptqLayerDesc& d, const VptqSlicedLayout
   TP.y_stride = d.out_features;
   TP.bd_off = pl.bd_off; TP.res_off = pl.res_off; TP.sum_off = pl.sum_off;
   TP.reg_sums = pl.reg_sums;
-  const int grid = gemv_sliced_slices(d) * (two ? 2 : 1) * P.n_rowblocks;
-  if (d.dtype == VPTQ_DTYPE_F16)
-    return pl.tok == 2 ? launch_st_dt<F16, 2>(TP, grid, d.vector_len, nsl, res, two, pl.lds, st)
-                       : launch_st_dt<F16, 4>(TP, grid, d.vector_len, nsl, res, two, pl.lds, st);
-  return pl.tok == 2 ? launch_st_dt<BF16, 2>(TP, grid, d.vector_len, nsl, res, two, pl.lds, st)
-                     : launch_st_dt<BF16, 4>(TP, grid, d.vector_len, nsl, res, two, pl.lds, st);
+  return hipSuccess;
+}
+
+// n <= kSTMaxGroup layers of ONE format (vector length, slices, residual kind, dtype) and one input width reading the same x
+bool gemv_sliced_tok_groupable(const VptqLayerDesc* d, const VptqSlicedLayout* L, int n, int tokens) {
+  if (n < 1 || n > kSTMaxGroup || !gemv_sliced_groupable(d, n)) return false;
+  const int tables = gemv_sliced_tables(d[0]);
+  for (int i = 0; i < n; ++i)
+    if (!gemv_sliced_tok_eligible(d[i], L + (size_t)i * tables, tokens)) return false;
+  return true;
+}
+
+// x: [tokens][in_features], y[i]: [tokens][out_features of layer i] (fp32 with VPTQ_GEMV_OUT_F32); ws[i]:
+// gemv_sliced_tok_workspace_bytes of layer i, zero before its first use (every launch leaves the counters zero)
+hipError_t launch_gemv_sliced_tok_group(const VptqLayerDesc* d, const VptqSlicedLayout* L, int n, const void* x, void* const* y,
+                                        int tokens, int flags, void* const* ws, hipStream_t st) {
+  if (!gemv_sliced_tok_groupable(d, L, n, tokens)) return hipErrorInvalidValue;
+  SlicedTokGroupParams GP = {};
+  GP.n = n;
+  StPermJobs jobs = {};
+  const int tables = gemv_sliced_tables(d[0]);
+  const int nslt = gemv_sliced_slices(d[0]) * tables;
+  // rows per wave: one round of workgroups over ALL members
+  long long rows = 0;
+  for (int i = 0; i < n; ++i) rows += d[i].num_indices;
+  long long r0 = (rows * nslt + kSLWaves * 256 - 1) / (kSLWaves * 256);
+  int rpw0 = n == 1 ? 0 : (int)(r0 < 1 ? 1 : r0 > kSLMaxRowsPerWave ? kSLMaxRowsPerWave : r0);
+  // (3 - 4 tokens: rather a second round of workgroups than the rows' sums out of the registers - gate / up of an 8B model,
+  // 2 x 14336 outputs, v8-k65536-256: 7 rows per wave 55.5 us, 4 rows per wave 52.3 - but not a third and fourth round: the
+  // two-table format of the same layers, 14 rows per wave 72.9 us, 4 rows per wave 90.9)
+  if (tokens > 2 && rpw0 > kSTRegRows && rpw0 <= 2 * kSTRegRows) rpw0 = kSTRegRows;
+  uint32_t lds = 0;
+  int tok = 0;
+  for (int i = 0; i < n; ++i) {
+    StPlan pl;
+    const hipError_t e = st_fill(d[i], L + (size_t)i * tables, x, y[i], tokens, flags, ws[i], rpw0, GP.p[i], pl, jobs);
+    if (e != hipSuccess) return e;
+    lds = pl.lds > lds ? pl.lds : lds;
+    tok = pl.tok;
+    GP.start[i + 1] = GP.start[i] + nslt * GP.p[i].p.n_rowblocks;
+  }
+  for (int i = n; i < kSTMaxGroup; ++i) GP.start[i + 1] = GP.start[n];
+  if (jobs.n > 0) {
+    const hipError_t e = launch_permute_x(jobs.d, jobs.n, jobs.xin, jobs.xout, st);
+    if (e != hipSuccess) return e;
+  }
+  const int grid = GP.start[n];
+  const bool res = sl_res256(d[0]), two = sl_two(d[0]);
+  const int nsl = gemv_sliced_slices(d[0]);
+  if (d[0].dtype == VPTQ_DTYPE_F16)
+    return tok == 2 ? launch_st_dt<F16, 2>(GP, grid, d[0].vector_len, nsl, res, two, lds, st)
+                    : launch_st_dt<F16, 4>(GP, grid, d[0].vector_len, nsl, res, two, lds, st);
+  return tok == 2 ? launch_st_dt<BF16, 2>(GP, grid, d[0].vector_len, nsl, res, two, lds, st)
+                  : launch_st_dt<BF16, 4>(GP, grid, d[0].vector_len, nsl, res, two, lds, st);
+}
+hipError_t launch_gemv_sliced_tok(const VptqLayerDesc& d, const VptqSlicedLayout* L, const void* x, void* y, int tokens, int flags,
+                                  void* ws, hipStream_t st) {
+  void* const ys[1] = {y};
+  void* const wss[1] = {ws};
+  return launch_gemv_sliced_tok_group(&d, L, 1, x, ys, tokens, flags, wss, st);
 }
 
 }  // namespace vptq

@@ -70,6 +70,9 @@ bool gemv_sliced_tok_eligible(const VptqLayerDesc& d, const VptqSlicedLayout* L,
 size_t gemv_sliced_tok_workspace_bytes(const VptqLayerDesc& d, int tokens);
 hipError_t launch_gemv_sliced_tok(const VptqLayerDesc& d, const VptqSlicedLayout* L, const void* x, void* y, int tokens, int flags,
                                   void* ws, hipStream_t st);
+bool gemv_sliced_tok_groupable(const VptqLayerDesc* d, const VptqSlicedLayout* L, int n, int tokens);
+hipError_t launch_gemv_sliced_tok_group(const VptqLayerDesc* d, const VptqSlicedLayout* L, int n, const void* x, void* const* y,
+                                        int tokens, int flags, void* const* ws, hipStream_t st);
 bool gemv_sliced_groupable(const VptqLayerDesc* d, int n);
 hipError_t launch_gemv_sliced_group(const VptqLayerDesc* d, const VptqSlicedLayout* L, int n, const void* x, void* const* y,
                                     int flags, void* const* ws, hipStream_t st);

@@ -81,8 +81,8 @@ class SiblingGroup:
         self._out = {}
         self._arrays = None
 
-    def forward_sliced(self, layer, x):
-        """one token of large-codebook siblings over their sliced layouts: ONE launch for the group
+    def forward_sliced(self, layer, x, tokens=1):
+        """one token (2 - 4: `SlicedGroupGemv.forward_tokens`) of large-codebook siblings over their sliced layouts: ONE launch for the group
         (`vptq_amd/utils/sliced.py:SlicedGroupGemv`); same protocol as `forward` - the first member called launches, the
         others pick their output up when they are called with the very same tensor.  None = not this group's route (a
         member without a layout, mixed formats, a tensor without version counter, ...): the caller goes on alone."""
@@ -107,7 +107,12 @@ class SiblingGroup:
                 self._sgroup = False      # (mixed formats: every member launches for itself)
                 return None
             self._sgroup = sg
-        ys = sg[1](x)
+        if tokens == 1:
+            ys = sg[1](x)
+        else:   # (every member must be a layer this route was measured faster for: VQuantLinear._sliced_one_launch)
+            if not all(m._sliced_one_launch(sl, tokens) for m, sl in zip(self.members, sls)):
+                return None
+            ys = sg[1].forward_tokens(x)
         if ys is None:
             return None
         self._sx, self._sversion, self._keep_sx = x, ver, x
@@ -540,6 +545,11 @@ class VQuantLinear(nn.Module):
                     if y is not None:   # (None: misaligned activation, capture on a stream the layer has not run on, ...)
                         return y
                 elif tokens <= 4 and self._sliced_one_launch(sl, tokens) and x.is_contiguous():
+                    sib = self.__dict__.get("_siblings")
+                    if sib is not None:      # q / k / v, gate / up: one launch for the group
+                        y = sib.forward_sliced(self, x, tokens)
+                        if y is not None:
+                            return y
                     y = sl.forward_tokens(x)
                     if y is not None:   # (None: misaligned activation, capture on a stream without a workspace yet)
                         return y

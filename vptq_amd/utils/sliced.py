@@ -173,6 +173,7 @@ class SlicedGemv:
         self._ws = {}
         self._ws_tok = {}   # (stream, tokens) -> workspace of the 2 - 4 token kernel
         self._fn = B.lib().vptq_quant_gemv_sliced
+        self._fn_tok = B.lib().vptq_quant_gemv_sliced_tokens
         self._lay_ref = self.layout   # (an array of 1 or 2 structs: passed as a pointer to the first)
         self._dtype = cache[7]
         self._dev_index = cache[8]
@@ -223,6 +224,13 @@ class SlicedGemv:
             x = x.contiguous()
         if x.data_ptr() & 15 or (lay.in_features * x.element_size()) & 15:
             return None
+        if torch.cuda.current_device() != self._dev_index:
+            with torch.cuda.device(self.dev):
+                return self._launch_tokens(x, out, flags, tokens)
+        return self._launch_tokens(x, out, flags, tokens)
+
+    def _launch_tokens(self, x, out, flags, tokens):
+        lay = self.layer
         sp = B.current_stream_ptr(self.dev)
         key = (sp, tokens)
         ws = self._ws_tok.get(key)
@@ -232,15 +240,12 @@ class SlicedGemv:
             nbytes = B.lib().vptq_quant_gemv_sliced_tokens_workspace_bytes(self.desc, tokens)
             if not nbytes:
                 return None
-            with torch.cuda.device(self.dev):
-                ws = torch.zeros(nbytes, dtype=torch.uint8, device=self.dev)
+            ws = torch.zeros(nbytes, dtype=torch.uint8, device=self.dev)
             self._ws_tok[key] = ws
         if out is None:
             out = torch.empty(x.shape[:-1] + (lay.out_features,),
                               dtype=torch.float32 if (flags & B.GEMV_OUT_F32) else self._dtype, device=self.dev)
-        with torch.cuda.device(self.dev):
-            rc = B.lib().vptq_quant_gemv_sliced_tokens(self.desc, self._lay_ref, x.data_ptr(), out.data_ptr(), tokens, flags,
-                                                       ws.data_ptr(), ws.numel(), sp)
+        rc = self._fn_tok(self.desc, self._lay_ref, x.data_ptr(), out.data_ptr(), tokens, flags, ws.data_ptr(), ws.numel(), sp)
         if rc == B.E_UNSUPPORTED:
             return None
         if rc:
@@ -306,6 +311,57 @@ class SlicedGroupGemv:
             with torch.cuda.device(self.dev):
                 return self._launch(x)
         return self._launch(x)
+
+    def tokens_supported(self, tokens: int) -> bool:
+        return all(m.tokens_supported(tokens) for m in self.members)
+
+    def forward_tokens(self, x: torch.Tensor):
+        """2 - 4 tokens through every member in ONE launch (`vptq_quant_gemv_sliced_tokens_grouped`): list of outputs, or None
+        where the call cannot be served (as SlicedGemv.forward_tokens)"""
+        lay = self.members[0].layer
+        tokens = x.numel() // lay.in_features
+        if x.shape[-1] != lay.in_features or not 2 <= tokens <= 4:
+            raise ValueError("forward_tokens takes 2 - 4 tokens of in_features values")
+        if x.dtype != self._dtype or x.device != self.dev:
+            x = lay._check_activation(x)
+        if not x.is_contiguous():
+            x = x.contiguous()
+        if x.data_ptr() & 15 or (lay.in_features * x.element_size()) & 15:
+            return None
+        if torch.cuda.current_device() != self._dev_index:
+            with torch.cuda.device(self.dev):
+                return self._launch_tokens(x, tokens)
+        return self._launch_tokens(x, tokens)
+
+    def _launch_tokens(self, x, tokens):
+        sp = B.current_stream_ptr(self.dev)
+        n = len(self.members)
+        wss = []
+        for m in self.members:
+            key = (sp, tokens)
+            ws = m._ws_tok.get(key)
+            if ws is None:
+                if torch.cuda.is_current_stream_capturing():
+                    return None
+                nbytes = B.lib().vptq_quant_gemv_sliced_tokens_workspace_bytes(m.desc, tokens)
+                if not nbytes:
+                    return None
+                ws = torch.zeros(nbytes, dtype=torch.uint8, device=self.dev)
+                m._ws_tok[key] = ws
+            wss.append(ws)
+        ys = [torch.empty(x.shape[:-1] + (m.layer.out_features,), dtype=self._dtype, device=self.dev) for m in self.members]
+        wb = (C.c_size_t * n)(*[w.numel() for w in wss])
+        for i, (y, w) in enumerate(zip(ys, wss)):
+            self._yp[i] = y.data_ptr()
+            self._wp[i] = w.data_ptr()
+        rc = B.lib().vptq_quant_gemv_sliced_tokens_grouped(self.descs, self.layouts, n, x.data_ptr(), self._yp, tokens, 0, self._wp, wb, sp)
+        if rc == B.E_UNSUPPORTED:
+            return None
+        if rc:
+            for m in self.members:
+                m._ws_tok.pop((sp, tokens), None)
+            B.check(rc, "vptq_quant_gemv_sliced_tokens_grouped")
+        return ys
 
     def _launch(self, x):
         sp = B.current_stream_ptr(self.dev)
