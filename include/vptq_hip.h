@@ -323,7 +323,8 @@ VPTQ_API int vptq_quant_gemv_sliced(const VptqLayerDesc* desc, const VptqSlicedL
  * (float32 with VPTQ_GEMV_OUT_F32), one launch.  The activations of T tokens do not fit beside a slice, so the kernel takes
  * the columns in 1, 2 or 4 phases (as few as the LDS allows: 4096-column layers need one for 2 - 3 tokens) and walks the
  * phase's column windows of every list.  workspace: vptq_quant_gemv_sliced_tokens_workspace_bytes(desc, tokens), zero-filled
- * once, one per layer and stream, not shared with the one-token call.  VPTQ_E_UNSUPPORTED where the layer, the layout
+ * once, one per layer and stream, not shared with the one-token call; a workspace for T tokens serves fewer as well (the
+ * arrival counters sit in front).  VPTQ_E_UNSUPPORTED where the layer, the layout
  * (no wstart) or the token count is not served: take vptq_quant_gemv.  Replaces the same reference kernel for
  * 1 < tokens < 16 (vptq/ops/quant_gemm.py:213, csrc/kernels/quant_gemv.cuh:11-186). */
 VPTQ_API int vptq_quant_gemv_sliced_tokens_supported(const VptqLayerDesc* desc, const VptqSlicedLayout* layout, int tokens);

@@ -753,7 +753,7 @@ static hipError_t st_fill(const VptqLayerDesc& d, const VptqSlicedLayout* L, con
   TP.xs = (const uint16_t*)x;
   TP.x_stride = d.in_features;
   if (d.perm) {
-    char* const base = (char*)ws + st_partial_bytes(d, tokens) + st_counter_bytes(d);
+    char* const base = (char*)ws + st_counter_bytes(d) + st_partial_bytes(d, tokens);
     for (int t = 0; t < tokens; ++t) {
       jobs.d[jobs.n] = d;
       jobs.xin[jobs.n] = (const uint16_t*)x + (size_t)t * d.in_features;
@@ -764,8 +764,9 @@ static hipError_t st_fill(const VptqLayerDesc& d, const VptqSlicedLayout* L, con
     TP.x_stride = (int)(gemv_k256c_perm_bytes(d) / 2);
   }
   P.bias = (const uint16_t*)d.bias;
-  P.partial = (float*)ws;
-  P.arrived = (uint32_t*)((char*)ws + st_partial_bytes(d, tokens));
+  // (the arrival counters FIRST: a workspace sized - and zeroed once - for 4 tokens serves 2 and 3 as well)
+  P.arrived = (uint32_t*)ws;
+  P.partial = (float*)((char*)ws + st_counter_bytes(d));
   P.y = y;
   P.N = d.num_indices; P.G = d.group_size; P.O = d.out_features;
   P.rows_per_wave = pl.rpw;

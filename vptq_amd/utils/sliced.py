@@ -171,7 +171,7 @@ class SlicedGemv:
         # another stream - running the same layer would race on a shared one); zeroed once, every call leaves the
         # counters zero
         self._ws = {}
-        self._ws_tok = {}   # (stream, tokens) -> workspace of the 2 - 4 token kernel
+        self._ws_tok = {}   # stream -> workspace of the 2 - 4 token kernel
         self._fn = B.lib().vptq_quant_gemv_sliced
         self._fn_tok = B.lib().vptq_quant_gemv_sliced_tokens
         self._lay_ref = self.layout   # (an array of 1 or 2 structs: passed as a pointer to the first)
@@ -229,19 +229,27 @@ class SlicedGemv:
                 return self._launch_tokens(x, out, flags, tokens)
         return self._launch_tokens(x, out, flags, tokens)
 
-    def _launch_tokens(self, x, out, flags, tokens):
-        lay = self.layer
-        sp = B.current_stream_ptr(self.dev)
-        key = (sp, tokens)
-        ws = self._ws_tok.get(key)
+    def _tokens_workspace(self, stream_ptr: int):
+        """the workspace of the 2 - 4 token kernel for this stream (sized for 4 tokens: it serves 2 and 3 as well), or None
+        inside a capture on a stream the layer has not run on"""
+        ws = self._ws_tok.get(stream_ptr)
         if ws is None:
             if torch.cuda.is_current_stream_capturing():
                 return None
-            nbytes = B.lib().vptq_quant_gemv_sliced_tokens_workspace_bytes(self.desc, tokens)
+            nbytes = B.lib().vptq_quant_gemv_sliced_tokens_workspace_bytes(self.desc, 4)
             if not nbytes:
                 return None
             ws = torch.zeros(nbytes, dtype=torch.uint8, device=self.dev)
-            self._ws_tok[key] = ws
+            self._ws_tok[stream_ptr] = ws
+        return ws
+
+    def _launch_tokens(self, x, out, flags, tokens):
+        lay = self.layer
+        sp = B.current_stream_ptr(self.dev)
+        key = sp
+        ws = self._tokens_workspace(sp)
+        if ws is None:
+            return None
         if out is None:
             out = torch.empty(x.shape[:-1] + (lay.out_features,),
                               dtype=torch.float32 if (flags & B.GEMV_OUT_F32) else self._dtype, device=self.dev)
@@ -338,16 +346,9 @@ class SlicedGroupGemv:
         n = len(self.members)
         wss = []
         for m in self.members:
-            key = (sp, tokens)
-            ws = m._ws_tok.get(key)
+            ws = m._tokens_workspace(sp)
             if ws is None:
-                if torch.cuda.is_current_stream_capturing():
-                    return None
-                nbytes = B.lib().vptq_quant_gemv_sliced_tokens_workspace_bytes(m.desc, tokens)
-                if not nbytes:
-                    return None
-                ws = torch.zeros(nbytes, dtype=torch.uint8, device=self.dev)
-                m._ws_tok[key] = ws
+                return None
             wss.append(ws)
         ys = [torch.empty(x.shape[:-1] + (m.layer.out_features,), dtype=self._dtype, device=self.dev) for m in self.members]
         wb = (C.c_size_t * n)(*[w.numel() for w in wss])
@@ -359,7 +360,7 @@ class SlicedGroupGemv:
             return None
         if rc:
             for m in self.members:
-                m._ws_tok.pop((sp, tokens), None)
+                m._ws_tok.pop(sp, None)
             B.check(rc, "vptq_quant_gemv_sliced_tokens_grouped")
         return ys
 
