@@ -502,7 +502,7 @@ int vptq_quant_gemv_sliced_tokens(const VptqLayerDesc* d, const VptqSlicedLayout
                                   int flags, void* workspace, size_t workspace_bytes, void* stream) {
   if (int rc = validate_layer(d)) return rc;
   if (!layout || !x || !y) return fail(VPTQ_E_NULL, "layout, x and y must be set");
-  if (flags & VPTQ_GEMV_EXACT)
+  if (flags & (VPTQ_GEMV_EXACT | VPTQ_GEMV_FORCE_GENERIC))
     return fail(VPTQ_E_UNSUPPORTED, "the sliced path has the folded arithmetic only: use vptq_quant_gemv");
   if (!vptq::gemv_sliced_eligible(*d) || !vptq::gemv_sliced_tok_eligible(*d, layout, tokens))
     return fail(VPTQ_E_UNSUPPORTED, "sliced layouts with column windows (wstart), 2 - 4 tokens, and activations that fit the LDS beside the slice");
