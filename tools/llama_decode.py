@@ -116,7 +116,7 @@ def run(args):
     stage("built")
     qbytes = sum(m.indices.numel() * 4 for m in qlayers)
     maxlen = args.prompt + 2 * args.new + 80   # eager steps + captured replays share one cache
-    prompt = torch.randint(0, cfg.vocab_size, (1, args.prompt), device=dev)
+    prompt = torch.randint(0, cfg.vocab_size, (args.batch, args.prompt), device=dev)
 
     def fresh_cache():
         return StaticCache(config=cfg, max_cache_len=maxlen)
@@ -150,7 +150,7 @@ def run(args):
     for _ in range(n_eager):
         tok = step(tok, p); p += 1
     torch.cuda.synchronize()
-    eager_tps = n_eager / (time.perf_counter() - t0)
+    eager_tps = n_eager * args.batch / (time.perf_counter() - t0)
 
     # ---- hipGraph decode: one captured step, replayed ----
     graph_tps = None
@@ -173,7 +173,7 @@ def run(args):
                 s_tok.copy_(s_out)
                 s_pos += 1
             torch.cuda.synchronize()
-            graph_tps = args.new / (time.perf_counter() - t0)
+            graph_tps = args.new * args.batch / (time.perf_counter() - t0)
     except Exception as e:  # report, do not hide
         graph_tps = f"capture failed: {type(e).__name__}: {e}"
 
@@ -218,15 +218,15 @@ def run(args):
                quantized_linears=len(qlayers), packed_index_GB=qbytes / 1e9,
                lm_head_GB=lm_head_bytes / 1e9, prompt=args.prompt, new_tokens=args.new,
                ttft_ms=ttft * 1e3, decode_tok_s_eager=eager_tps, decode_tok_s_hipgraph=graph_tps,
-               sibling_groups=fused)
+               sibling_groups=fused, batch=args.batch)
     if isinstance(graph_tps, float):
-        res["hipgraph_weight_GBps"] = (qbytes + lm_head_bytes) * graph_tps / 1e9
-    res["vqlinear_us_per_token"] = vq_us   # the step's VQuantLinear launches back to back in a graph of their own
+        res["hipgraph_weight_GBps"] = (qbytes + lm_head_bytes) * graph_tps / args.batch / 1e9   # (a step reads the weights once for the whole batch)
+    res["vqlinear_us_per_token"] = vq_us   # the step's VQuantLinear launches back to back in a graph of their own (batch > 1: per STEP)
     if isinstance(vq_us, float):
         res["vqlinear_calls_per_token"] = len(calls)
         res["vqlinear_GBps"] = qbytes / vq_us / 1e3
         if isinstance(graph_tps, float):
-            res["vqlinear_share_of_step"] = vq_us * 1e-6 * graph_tps
+            res["vqlinear_share_of_step"] = vq_us * 1e-6 * graph_tps / args.batch
     print(json.dumps(res))
     if args.out:
         os.makedirs(os.path.dirname(args.out), exist_ok=True)
@@ -243,5 +243,6 @@ if __name__ == "__main__":
     ap.add_argument("--k", type=int, default=256, help="main codebook entries (v = 8): 256 = the 2-bit format, 65536 = the published 3-bit ones")
     ap.add_argument("--kr", type=int, default=256, help="residual codebook entries")
     ap.add_argument("--fuse", action="store_true", help="link_siblings: q/k/v and gate/up share one grouped launch")
+    ap.add_argument("--batch", type=int, default=1, help="sequences decoded together: every VQuantLinear call of a step sees that many tokens")
     ap.add_argument("--out", default="")
     run(ap.parse_args())
