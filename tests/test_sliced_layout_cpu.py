@@ -151,3 +151,55 @@ def test_two_table_format_splits_into_two_index_streams():
                 if col < G:
                     got[int(col)] = s * 8192 + int(local)
         assert got == {g: int(ridx[n, g]) for g in range(G)}
+
+
+@pytest.mark.parametrize("V", [8, 16])
+def test_matrix_pipe_operand_mapping_emulated(V):
+    """gemv_sliced_tok.hip, 3 - 4 tokens: the contraction over a block's 64 elements on the matrix pipe.  numpy emulation of
+    what the kernel relies on - ds_read_b64_tr_b16 (inside 16 lanes, source lane 4 e + c supplies an 8-byte chunk, result lane
+    4 c' + m receives half m of the chunks of source lanes 4 e' + c', e' = 0..3) and the operand layout of v_mfma_f32_16x16x32
+    (lane 16 g + j: row / column j, K = 8 g .. 8 g + 7; D: lane 16 g + j holds rows 4 g .. 4 g + 3 of column j) - with the
+    kernel's choice of element and chunk per source lane: the sums land where row_end() reads them."""
+    rng = np.random.default_rng(V)
+    E = rng.standard_normal((64, V))           # the block's entries
+    X = rng.standard_normal((64, 4))           # its activations, 4 tokens
+    reads = 2 if V == 8 else 4
+    per_read = 64 // reads                     # elements a read covers
+    chunks = V // 4                            # 8-byte chunks of an entry
+
+    def source(lane, i):                       # (element position in the block, chunk) of source lane `lane` in read i
+        pos = per_read * i + (lane >> 1 if V == 8 else lane >> 2)
+        return pos, lane & (chunks - 1)
+
+    def tr_read(chunk_of_lane):                # chunk_of_lane[lane] = 4 values -> result[lane] = 4 values
+        out = np.zeros((64, 4))
+        for g in range(4):
+            for c in range(4):
+                for m in range(4):
+                    out[16 * g + 4 * c + m] = [chunk_of_lane[16 * g + 4 * e + c][m] for e in range(4)]
+        return out
+    A = np.zeros((16, 32 * (reads // 2)))      # rows: 8 h + token (v = 16: token), K = (MFMA, lane group, read, e')
+    Bm = np.zeros((32 * (reads // 2), 16))     # columns: 8 h + component (v = 16: component)
+    for i in range(reads):
+        ent, act = [], []
+        for lane in range(64):
+            pos, q = source(lane, i)
+            ent.append(E[pos, 4 * q:4 * q + 4])
+            act.append(X[pos] if q == 0 else np.zeros(4))       # chunk 0's lanes bring the tokens, the others the zero column
+        bt, at = tr_read(ent), tr_read(act)
+        for lane in range(64):
+            g, j = lane >> 4, lane & 15
+            for e in range(4):
+                k = 32 * (i // 2) + 8 * g + 4 * (i % 2) + e     # reads 2 m, 2 m + 1 feed MFMA m
+                A[j, k] = at[lane][e]
+                Bm[k, j] = bt[lane][e]
+    D = A @ Bm                                  # (v = 16: the two MFMAs accumulate into the same D)
+    want = E.T @ X                              # [component][token]
+    if V == 8:    # lanes 0 - 7 hold set 0 (rows 0 - 3 = tokens), lanes 40 - 47 set 1 (rows 8 - 11, columns 8 - 15)
+        got = np.array([[D[t, comp] + D[8 + t, 8 + comp] for t in range(4)] for comp in range(8)])
+    else:         # lanes 0 - 15: rows 0 - 3 = tokens, column = component
+        got = np.array([[D[t, comp] for t in range(4)] for comp in range(16)])
+    assert np.allclose(got, want)
+    # every element is taken exactly once per chunk
+    seen = sorted(source(lane, i) for i in range(reads) for lane in range(64))
+    assert seen == sorted((p, q) for p in range(64) for q in range(chunks))
