@@ -520,7 +520,7 @@ class VQuantLinear(nn.Module):
         free, total = torch.cuda.mem_get_info(cache[3])
         elems = self.indices.shape[1] * self.group_size
         two = B.lib().vptq_sliced_layout_tables(cache[1]) == 2   # (one layout per table)
-        need = elems * (8 if two else 5) + elems * 8 * 12   # layout + int64 temporaries of build_sliced_layout
+        need = elems * (8 if two else 5) + elems * 8 * 20   # layout + int64 / float64 temporaries of build_sliced_layout (window order: more of them)
         return free - need > _SLICED_MIN_FREE_FRACTION * total
 
     def _gemv_cached(self, x: torch.Tensor, tokens: int) -> torch.Tensor:
