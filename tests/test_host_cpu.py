@@ -620,3 +620,27 @@ def test_sliced_tokens_plan_without_gpu():
     dv = _family_desc(8192, 8192, 16, 65536, 65536)
     assert sup(dv, layouts(dv), 2) == 1
     assert sup(_family_desc(8192, 8192, 12, 65536, 0), layouts(d), 2) == 0   # not a layer of the sliced path at all
+
+
+def test_one_launch_rule_for_two_to_four_tokens():
+    """VQuantLinear._sliced_one_launch: which layers send 2 - 4 tokens through the token kernel over the sliced layouts (the
+    measured table of profiles/r04/sliced_tokens_one_launch.txt as a rule) - host logic, no GPU"""
+    import types
+    import torch
+    from vptq_amd.layers.vqlinear import VQuantLinear
+
+    def layer(I, O, v, kr):
+        return types.SimpleNamespace(indices=torch.empty(1, O // v, 1), group_size=I, vector_len=v, out_features=O,
+                                     num_res_centroids=kr, enable_residual=kr > 0)
+
+    def rule(I, O, v, kr, tokens, supported=True):
+        class SL:       # (stands in for vptq_amd.utils.sliced.SlicedGemv: what the library answers + the per-layout cache)
+            def tokens_supported(self, t):
+                return supported
+        return VQuantLinear._sliced_one_launch(layer(I, O, v, kr), SL(), tokens)
+    for t in (2, 3, 4):
+        assert rule(8192, 8192, 8, 0, t) and rule(4096, 4096, 8, 256, t) and rule(4096, 14336, 8, 65536, t) and rule(8192, 8192, 16, 0, t)
+        assert not rule(2048, 512, 8, 256, t)                     # tiny: launch-bound on every route
+        assert not rule(8192, 8192, 16, 1024, t)                  # v = 16 with a small residual table: the gather kernel holds it in LDS
+        assert not rule(8192, 8192, 8, 0, t, supported=False)     # the library does not take it (no wstart, no room in LDS)
+    assert rule(4096, 14336, 16, 65536, 2) and not rule(4096, 14336, 16, 65536, 4) and rule(8192, 8192, 16, 65536, 4)
