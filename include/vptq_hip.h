@@ -319,7 +319,8 @@ VPTQ_API size_t vptq_quant_gemv_sliced_workspace_bytes(const VptqLayerDesc* desc
 VPTQ_API int vptq_quant_gemv_sliced(const VptqLayerDesc* desc, const VptqSlicedLayout* layout, const void* x,
                            void* y, int flags, void* workspace, size_t workspace_bytes, void* stream);
 
-/* 2 - 4 tokens over the same layouts (ABI >= 7; needs `wstart`): x [tokens][in_features], y [tokens][out_features]
+/* 2 - 4 tokens (5 - 8 where 16 bytes of activations per column still fit the LDS in 4 phases: layers of up to ~4600 columns)
+ * over the same layouts (ABI >= 7; needs `wstart`): x [tokens][in_features], y [tokens][out_features]
  * (float32 with VPTQ_GEMV_OUT_F32), one launch.  The activations of T tokens do not fit beside a slice, so the kernel takes
  * the columns in 1, 2 or 4 phases (as few as the LDS allows: 4096-column layers need one for 2 - 3 tokens) and walks the
  * phase's column windows of every list.  workspace: vptq_quant_gemv_sliced_tokens_workspace_bytes(desc, tokens), zero-filled

@@ -492,14 +492,14 @@ def test_sliced_tokens_rejections(dev):
     m = spec_to_module(L, dev)
     sl = SlicedGemv(m)
     x = torch.randn(1, 3, 2048, device=dev, dtype=torch.float16)
-    assert sl.tokens_supported(2) and sl.tokens_supported(4) and not sl.tokens_supported(5) and not sl.tokens_supported(1)
+    assert sl.tokens_supported(2) and sl.tokens_supported(4) and sl.tokens_supported(8) and not sl.tokens_supported(9) and not sl.tokens_supported(1)
     y = torch.empty(1, 3, 512, device=dev, dtype=torch.float16)
     lib = B.lib()
     need = lib.vptq_quant_gemv_sliced_tokens_workspace_bytes(sl.desc, 3)
     ws = torch.zeros(need, dtype=torch.uint8, device=dev)
     sp = B.current_stream_ptr(dev)
     assert lib.vptq_quant_gemv_sliced_tokens(sl.desc, sl.layout, x.data_ptr(), y.data_ptr(), 3, 0, ws.data_ptr(), need - 1, sp) == B.E_WORKSPACE
-    assert lib.vptq_quant_gemv_sliced_tokens(sl.desc, sl.layout, x.data_ptr(), y.data_ptr(), 5, 0, ws.data_ptr(), need, sp) == B.E_UNSUPPORTED
+    assert lib.vptq_quant_gemv_sliced_tokens(sl.desc, sl.layout, x.data_ptr(), y.data_ptr(), 9, 0, ws.data_ptr(), need, sp) == B.E_UNSUPPORTED
     assert lib.vptq_quant_gemv_sliced_tokens(sl.desc, sl.layout, x.data_ptr(), y.data_ptr(), 3, EXACT, ws.data_ptr(), need, sp) == B.E_UNSUPPORTED
     assert lib.vptq_quant_gemv_sliced_tokens(sl.desc, sl.layout, x.data_ptr(), y.data_ptr(), 3, 0, ws.data_ptr(), need, sp) == 0
     torch.cuda.synchronize()
@@ -595,3 +595,40 @@ def test_sibling_layers_share_one_launch_for_two_to_four_tokens(v, kr, dt, token
     x2 = bits_to_tensor(_xt(I, tokens, dt, "llm", 32), dt, dev).reshape(x.shape)
     y2 = [m(x2) for m in ms]
     assert rel_err(tensor_to_bits(y2[2]), vo.forward(Ls[2], tensor_to_bits(x2)), dt) <= TOL[dt]
+
+
+@pytest.mark.parametrize("tokens,dt", [(5, "f16"), (8, "f16"), (6, "bf16"), (8, "bf16")])
+@pytest.mark.parametrize("v,k,kr", [(8, 65536, 0), (8, 65536, 256), (8, 65536, 65536), (16, 65536, 65536), (16, 65536, 0), (8, 65536, 1024)])
+@pytest.mark.parametrize("I,O,kw", [(2048, 528, dict(dist="llm", enable_perm=True, bias=True)), (4096, 272, dict(dist="llm", bias=True)),
+                                    (4104, 136, dict(dist="llm")), (72, 1040, dict())])
+def test_sliced_tokens_five_to_eight(I, O, kw, v, k, kr, tokens, dt, dev):
+    """5 - 8 tokens in one launch: 8 token slots on the matrix pipe (16 bytes of activations per column: layers of up to ~4600
+    columns), against the oracle; float32 outputs; repeatable"""
+    from vptq_amd.utils.sliced import SlicedGemv
+    from vptq_amd import _backend as B
+    kw = dict(kw)
+    dist = kw.pop("dist", "ref-test")
+    L = vo.make_layer(I, O, dist=dist, seed=I + O + v + kr + tokens, dtype=dt, vector_len=v, num_centroids=k, num_res_centroids=kr, **kw)
+    x = _xt(I, tokens, dt, dist, I + 5)
+    m = spec_to_module(L, dev)
+    sl = SlicedGemv(m)
+    xt = bits_to_tensor(x, dt, dev).reshape(x.shape)
+    assert sl.tokens_supported(tokens)
+    got = sl.forward_tokens(xt)
+    torch.cuda.synchronize()
+    assert got.shape == (1, tokens, O)
+    err = rel_err(tensor_to_bits(got), vo.forward(L, x), dt)
+    assert err <= TOL[dt], f"v{v}-k{k}-{kr} {I}x{O} {tokens} tokens {dt}: {err:.3e}"
+    y32 = sl.forward_tokens(xt, flags=B.GEMV_OUT_F32)
+    assert torch.equal(y32.to(got.dtype).view(torch.int16), got.view(torch.int16))
+    assert torch.equal(sl.forward_tokens(xt).view(torch.int16), got.view(torch.int16))
+    # the 4-token workspace was replaced by the larger one: fewer tokens still run in it
+    assert rel_err(tensor_to_bits(sl.forward_tokens(xt[:, :3].contiguous())), vo.forward(L, x[:, :3]), dt) <= TOL[dt]
+
+
+def test_sliced_tokens_five_to_eight_need_narrow_layers(dev):
+    from vptq_amd.utils.sliced import SlicedGemv
+    L = vo.make_layer(8192, 64, dist="llm", seed=91, num_centroids=65536, num_res_centroids=0)
+    sl = SlicedGemv(spec_to_module(L, dev))
+    assert sl.tokens_supported(4) and not sl.tokens_supported(5) and not sl.tokens_supported(9)
+    assert sl.forward_tokens(torch.randn(1, 6, 8192, device=dev, dtype=torch.float16)) is None

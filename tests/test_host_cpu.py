@@ -613,7 +613,9 @@ def test_sliced_tokens_plan_without_gpu():
     assert [sup(d, layouts(d), t) for t in (1, 2, 3, 4, 5)] == [0, 1, 1, 1, 0]
     assert sup(d, layouts(d, wstart=False), 2) == 0                       # layouts without the column windows' table: one token only
     # partial sums [tokens][slices x tables][N x v] floats (256-byte multiple) + the arrival counters (one per 16 rows)
-    assert wsb(d, 2) == 2 * 8 * 8192 * 4 + 256 and wsb(d, 4) == 4 * 8 * 8192 * 4 + 256 and wsb(d, 5) == 0 and wsb(d, 1) == 0
+    assert wsb(d, 2) == 2 * 8 * 8192 * 4 + 256 and wsb(d, 4) == 4 * 8 * 8192 * 4 + 256 and wsb(d, 9) == 0 and wsb(d, 1) == 0
+    d4 = _family_desc(4096, 4096, 8, 65536, 256)      # 5 - 8 tokens: 16 bytes of activations per column must fit in 4 phases
+    assert [sup(d4, layouts(d4), t) for t in (5, 8, 9)] == [1, 1, 0] and wsb(d4, 8) == 8 * 8 * 4096 * 4 + 256
     d2 = _family_desc(8192, 8192, 8, 65536, 65536)
     assert sup(d2, layouts(d2), 4) == 1 and wsb(d2, 3) == 3 * 16 * 8192 * 4 + 256
     assert sup(_family_desc(28672, 8192, 8, 65536, 0), layouts(_family_desc(28672, 8192, 8, 65536, 0)), 4) == 1   # 16 slices of 64 KiB

@@ -32,7 +32,7 @@ if a.siblings:
         sls = [SlicedGemv(m) for m in ms]
         groups.append((ms, sls, SlicedGroupGemv(sls)))
     row = dict(I=I, outs=outs, v=a.v, k=a.k, kr=a.kr)
-    for T in (1, 2, 3, 4):
+    for T in (1, 2, 3, 4, 6, 8):
         x = torch.randn(1, T, I, device=dev).half()
         if T == 1:
             f_alone = lambda: [[sl(x) for sl in sls] for _, sls, _ in groups]
@@ -49,7 +49,7 @@ if a.siblings:
 for I, O in [tuple(int(v) for v in p.split(',')) for p in a.shapes.split(';')]:
     layers = [mk(I, O, dev, g, k=a.k, kr=a.kr, v=a.v) for _ in range(a.ring)]
     row = dict(I=I, O=O, v=a.v, k=a.k, kr=a.kr)
-    for T in (1, 2, 3, 4):
+    for T in ((1, 2, 3, 4, 6, 8) if a.only_one_launch else (1, 2, 3, 4)):
         x = torch.randn(1, T, I, device=dev).half()
         for m in layers:
             m.enable_sliced_layout(True)

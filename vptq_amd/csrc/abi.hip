@@ -494,7 +494,7 @@ int vptq_quant_gemv_sliced_tokens_supported(const VptqLayerDesc* d, const VptqSl
 }
 
 size_t vptq_quant_gemv_sliced_tokens_workspace_bytes(const VptqLayerDesc* d, int tokens) {
-  return validate_layer(d) == VPTQ_OK && vptq::gemv_sliced_eligible(*d) && tokens >= 2 && tokens <= 4
+  return validate_layer(d) == VPTQ_OK && vptq::gemv_sliced_eligible(*d) && tokens >= 2 && tokens <= 8
              ? vptq::gemv_sliced_tok_workspace_bytes(*d, tokens) : 0;
 }
 
@@ -505,7 +505,7 @@ int vptq_quant_gemv_sliced_tokens(const VptqLayerDesc* d, const VptqSlicedLayout
   if (flags & (VPTQ_GEMV_EXACT | VPTQ_GEMV_FORCE_GENERIC))
     return fail(VPTQ_E_UNSUPPORTED, "the sliced path has the folded arithmetic only: use vptq_quant_gemv");
   if (!vptq::gemv_sliced_eligible(*d) || !vptq::gemv_sliced_tok_eligible(*d, layout, tokens))
-    return fail(VPTQ_E_UNSUPPORTED, "sliced layouts with column windows (wstart), 2 - 4 tokens, and activations that fit the LDS beside the slice");
+    return fail(VPTQ_E_UNSUPPORTED, "sliced layouts with column windows (wstart), 2 - 8 tokens, and activations that fit the LDS beside the slice");
   const size_t need = vptq::gemv_sliced_tok_workspace_bytes(*d, tokens);
   if (!workspace || workspace_bytes < need || (((uintptr_t)workspace) & 15) != 0)
     return fail(VPTQ_E_WORKSPACE, "the sliced path for %d tokens needs %zu bytes of 16-byte aligned, zero-initialised workspace", tokens, need);

@@ -93,13 +93,13 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_tok_kernel(const Slice
   const SlicedTokParams TP = GP.p[0];   // (host pass of the compiler: never executed)
 #endif
   static_assert(((V == 8 && (NSL == 8 || NSL == 16)) || (V == 16 && (NSL == 16 || NSL == 32))) && (V == 8 || !RES) && !(TWO && RES) &&
-                (TOK == 2 || TOK == 4), "instantiation");
+                (TOK == 2 || TOK == 4 || TOK == 8), "instantiation");
   const SlicedParams& P = TP.p;
   constexpr int NSLT = TWO ? 2 * NSL : NSL;
   constexpr uint32_t kEntry = V * 2u;
   constexpr uint32_t kXStride = TOK * 2u;    // bytes per staged column
   constexpr int NV = TOK * V;                // sums per lane
-  constexpr int kSTQueue = (TOK == 4 && !(VPTQ_ST_ABLATE & 32)) ? 8 : st_queue<NV>();   // (MFMA mode: 4 sums per lane)
+  constexpr int kSTQueue = (TOK >= 4 && !(VPTQ_ST_ABLATE & 32)) ? 8 : st_queue<(NV > 64 ? 64 : NV)>();   // (MFMA mode: 4 sums per lane)
   const uint32_t kXOff = P.x_off;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   {
@@ -217,6 +217,14 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_tok_kernel(const Slice
                    : "=&v"(a), "=&v"(b), "=&v"(c2), "=&v"(d), "=&v"(sv)
                    : "v"(px[0]), "v"(px[1]), "v"(px[2]), "v"(px[3]), "v"(ps) : "memory");
       ch.v[0] = a; ch.v[1] = b; ch.v[2] = c2; ch.v[3] = d;
+      if constexpr (TOK == 8) {   // (tokens 4 - 7: a second statement)
+        u32x4 e2, f2, g2, h2;
+        asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %5, off\n\tglobal_load_dwordx4 %2, %6, off\n\t"
+                     "global_load_dwordx4 %3, %7, off\n\ts_waitcnt vmcnt(0)"
+                     : "=&v"(e2), "=&v"(f2), "=&v"(g2), "=&v"(h2)
+                     : "v"(px[TOK - 4]), "v"(px[TOK - 3]), "v"(px[TOK - 2]), "v"(px[TOK - 1]) : "memory");
+        ch.v[TOK - 4] = e2; ch.v[TOK - 3] = f2; ch.v[TOK - 2] = g2; ch.v[TOK - 1] = h2;
+      }
     }
 #pragma unroll
     for (int t = 0; t < TOK; ++t) {
@@ -234,10 +242,19 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_tok_kernel(const Slice
         const uint32_t lo = (ch.v[0][i] & 0xffffu) | (ch.v[1][i] << 16);
         const uint32_t hi = (ch.v[0][i] >> 16) | (ch.v[1][i] & 0xffff0000u);
         *(__attribute__((address_space(3))) u32x2*)(uintptr_t)(base + (uint32_t)i * 8u) = u32x2{lo, hi};
-      } else {
+      } else if constexpr (TOK == 4) {
         const uint32_t lo01 = (ch.v[0][i] & 0xffffu) | (ch.v[1][i] << 16), lo23 = (ch.v[2][i] & 0xffffu) | (ch.v[3][i] << 16);
         const uint32_t hi01 = (ch.v[0][i] >> 16) | (ch.v[1][i] & 0xffff0000u), hi23 = (ch.v[2][i] >> 16) | (ch.v[3][i] & 0xffff0000u);
         lds_store16(base + (uint32_t)i * 16u, u32x4{lo01, lo23, hi01, hi23});
+      } else {   // 8 tokens: 16 bytes per column
+        u32x4 lo, hi;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          lo[p] = (ch.v[(2 * p) % TOK][i] & 0xffffu) | (ch.v[(2 * p + 1) % TOK][i] << 16);
+          hi[p] = (ch.v[(2 * p) % TOK][i] >> 16) | (ch.v[(2 * p + 1) % TOK][i] & 0xffff0000u);
+        }
+        lds_store16(base + (uint32_t)(2 * i) * 16u, lo);
+        lds_store16(base + (uint32_t)(2 * i + 1) * 16u, hi);
       }
     }
   };
@@ -259,7 +276,7 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_tok_kernel(const Slice
   // v = 16: an entry is FOUR chunks, so the 16 columns are the 16 components of ONE set, source lane (g, e, c) of read i = 0..3
   // takes the element at position 16 i + 4 g + e and chunk c of its entry (activations: c = 0 the tokens, else the zero column),
   // reads 0, 1 feed one MFMA, reads 2, 3 a second one; lanes 0 - 15 hold the sums, four element words per lane and block.
-  constexpr bool MF = TOK == 4 && !(VPTQ_ST_ABLATE & 32);
+  constexpr bool MF = (TOK >= 4 && !(VPTQ_ST_ABLATE & 32)) || TOK == 8;   // (8 token slots exist on the matrix pipe only)
   constexpr int EW = MF ? (V == 8 ? 2 : 4) : 1;
   constexpr int EPR = 64 / EW;                   // elements per read of the block
   uint32_t eq[kSTQueue][EW];
@@ -356,15 +373,16 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_tok_kernel(const Slice
           const float hi = __uint_as_float(sw[1]);   // (lanes 0 - 31: the value of lane + 32)
           v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(hi), 0x128 /* row_ror:8 */, 0xf, 0xf, false));
         }
-        if (lane < V) {
+        // (8 token slots: lanes 16 .. 16 + v - 1 hold tokens 4 - 7 of the same outputs)
+        if ((lane & 15) < V && lane < (TOK == 8 ? 32 : 16)) {
           typedef __attribute__((address_space(3))) float lds_f_t;
-          lds_f_t* const sp = (lds_f_t*)(uintptr_t)(TP.sum_off + (uint32_t)(((wave * rpw + cq_row) * NV) + r * V + lane) * 4u);
+          lds_f_t* const sp = (lds_f_t*)(uintptr_t)(TP.sum_off + (uint32_t)(((wave * rpw + cq_row) * NV) + (4 * (lane >> 4) + r) * V + (lane & 15)) * 4u);
           *sp = *sp + v;
         }
       }
       accm = f32x4{0.f, 0.f, 0.f, 0.f};
       return;
-    }
+    } else {
     float acc[NV];
 #pragma unroll
     for (int t = 0; t < TOK; ++t)
@@ -381,6 +399,7 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_tok_kernel(const Slice
     for (int t = 0; t < TOK; ++t)
 #pragma unroll
       for (int i = 0; i < V / 2; ++i) acc2[t][i] = f32x2_t{0.f, 0.f};
+    }
   };
   auto consume = [&](auto slot_c) __attribute__((always_inline)) {
     constexpr int S = decltype(slot_c)::value;
@@ -388,7 +407,9 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_tok_kernel(const Slice
       if constexpr ((VPTQ_ST_ABLATE & 4) != 0) { accm[0] += __uint_as_float(eq[S][0] ^ eq[S][EW - 1]); return; }
       constexpr uint32_t kChunks = V / 4;                                    // 8-byte chunks of an entry
       const uint32_t q8 = (uint32_t)(lane & (kChunks - 1)) * 8u;             // this lane's chunk
-      const uint32_t qmask = (lane & (kChunks - 1)) ? 0xffffffffu : 0u;      // chunk 0's lanes bring the tokens, the others the zero column
+      // chunk 0's lanes bring tokens 0 - 3 (with 8 token slots chunk 1's lanes tokens 4 - 7), the others the zero column
+      const uint32_t xq = TOK == 8 ? (uint32_t)(lane & 1) * 8u : 0u;
+      const uint32_t qmask = (lane & (kChunks - 1)) >= (TOK == 8 ? 2u : 1u) ? 0xffffffffu : 0u;
       u32x2 at[EW], bt[EW], rt[RES ? EW : 1];
 #pragma unroll
       for (int i = 0; i < EW; ++i) {
@@ -396,7 +417,7 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_tok_kernel(const Slice
         bt[i] = st_lds_tr8((e >> 16) * kEntry + q8);
         uint32_t ci = ((e & 0xffffu) - c0) | qmask;
         ci = ci < wlen ? ci : wlen;
-        at[i] = st_lds_tr8(kXOff + ci * kXStride);
+        at[i] = st_lds_tr8(kXOff + ci * kXStride + xq);
         if constexpr (RES) rt[i] = st_lds_tr8(TP.res_off + (rq[S][i] << 4) + q8);
       }
 #pragma unroll
@@ -489,7 +510,8 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_tok_kernel(const Slice
     for (int q = tid; q < chunks; q += kSLThreads) store_chunk(load_chunk((int)c0, q), q);
     if (tid == 0) {   // the zero column
       if constexpr (TOK == 2) *(__attribute__((address_space(3))) uint32_t*)(uintptr_t)(kXOff + wlen * kXStride) = 0u;
-      else *(__attribute__((address_space(3))) u32x2*)(uintptr_t)(kXOff + wlen * kXStride) = u32x2{0u, 0u};
+      else if constexpr (TOK == 4) *(__attribute__((address_space(3))) u32x2*)(uintptr_t)(kXOff + wlen * kXStride) = u32x2{0u, 0u};
+      else lds_store16(kXOff + wlen * kXStride, u32x4{0u, 0u, 0u, 0u});
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     __builtin_amdgcn_s_barrier();
@@ -564,9 +586,12 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_tok_kernel(const Slice
                 auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
                 v += __int_as_float(__builtin_amdgcn_update_dpp(0, (int)sw[1], 0x128 /* row_ror:8 */, 0xf, 0xf, false));
               }
-              if (lane < V && r < tokens) {
-                float* const pp = as_global(P.partial) + (((size_t)r * NSLT + sg) * N + (size_t)(row0 + k)) * V + lane;
-                __hip_atomic_store(pp, v + bdot[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              const int tk = 4 * (lane >> 4) + r;     // (8 token slots: lanes 16 .. hold tokens 4 - 7)
+              if ((lane & 15) < V && lane < (TOK == 8 ? 32 : 16) && tk < tokens) {
+                float bt = bdot[r];
+                if constexpr (TOK == 8) bt = (lane >> 4) ? bdot[(4 + r) % TOK] : bdot[r];
+                float* const pp = as_global(P.partial) + (((size_t)tk * NSLT + sg) * N + (size_t)(row0 + k)) * V + (lane & 15);
+                __hip_atomic_store(pp, v + bt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
               }
             }
           }
@@ -648,11 +673,11 @@ struct StPlan { int tok, phases, rpw, reg_sums; uint32_t x_off, bd_off, res_off,
 // sums (16 waves x rows per wave x tokens x v floats) must fit too: where one round of workgroups does not leave room for
 // them even with 4 phases (v = 16 with two tables: 64 floats per row), fewer rows per wave - more workgroups - do.
 static bool st_plan(const VptqLayerDesc& d, const VptqSlicedLayout* L, int tokens, StPlan& pl, int rpw0 = 0) {
-  if (tokens < 2 || tokens > 4) return false;
+  if (tokens < 2 || tokens > 8) return false;
   const bool res = sl_res256(d), two = sl_two(d);
   static std::atomic<int> tok4{-1};   // VPTQ_SLICED_TOK4=1: 2 tokens through the 4-slot (matrix-pipe) kernel too (A/B runs)
   if (tok4 < 0) { const char* e = getenv("VPTQ_SLICED_TOK4"); tok4 = (e && atoi(e) == 1) ? 1 : 0; }
-  pl.tok = (tokens == 2 && !tok4) ? 2 : 4;
+  pl.tok = tokens > 4 ? 8 : (tokens == 2 && !tok4) ? 2 : 4;
   uint32_t tab = sl_tab_bytes(d, d.num_centroids, 0);
   if (two) {
     const uint32_t t1 = sl_tab_bytes(d, d.num_res_centroids, L[1].whole_table);
@@ -672,7 +697,7 @@ static bool st_plan(const VptqLayerDesc& d, const VptqSlicedLayout* L, int token
       o = (o + 15u) & ~15u;
       pl.bd_off = o; o += (uint32_t)pl.tok * kSLWaves * 4u;
       pl.res_off = o; o += res ? 4096u : 0u;
-      const int reg_sums = pl.tok == 4 && rpw <= kSTRegRows && !no_reg_sums;   // (matrix-pipe mode: 4 registers per row)
+      const int reg_sums = pl.tok >= 4 && rpw <= kSTRegRows && !no_reg_sums;   // (matrix-pipe mode: 4 registers per row)
       pl.sum_off = o; o += reg_sums ? 0u : (uint32_t)kSLWaves * (uint32_t)rpw * (uint32_t)(pl.tok * d.vector_len) * 4u;
       if (o <= kSLLdsLimit) { pl.phases = phases; pl.rpw = rpw; pl.reg_sums = reg_sums; pl.lds = o; return true; }
     }
@@ -715,7 +740,7 @@ static hipError_t launch_st_dt(const SlicedTokGroupParams& P, int grid, int v, i
 }
 
 // one layer's parameter block (its permutation pre-pass is queued into perm_*: one launch for the whole group)
-struct StPermJobs { VptqLayerDesc d[4 * kSTMaxGroup]; const void* xin[4 * kSTMaxGroup]; void* xout[4 * kSTMaxGroup]; int n; };
+struct StPermJobs { VptqLayerDesc d[8 * kSTMaxGroup]; const void* xin[8 * kSTMaxGroup]; void* xout[8 * kSTMaxGroup]; int n; };
 static hipError_t st_fill(const VptqLayerDesc& d, const VptqSlicedLayout* L, const void* x, void* y, int tokens, int flags, void* ws,
                           int rpw0, SlicedTokParams& TP, StPlan& pl, StPermJobs& jobs) {
   if (!gemv_sliced_tok_eligible(d, L, tokens) || !st_plan(d, L, tokens, pl, rpw0)) return hipErrorInvalidValue;
@@ -830,10 +855,12 @@ hipError_t launch_gemv_sliced_tok_group(const VptqLayerDesc* d, const VptqSliced
   const bool res = sl_res256(d[0]), two = sl_two(d[0]);
   const int nsl = gemv_sliced_slices(d[0]);
   if (d[0].dtype == VPTQ_DTYPE_F16)
-    return tok == 2 ? launch_st_dt<F16, 2>(GP, grid, d[0].vector_len, nsl, res, two, lds, st)
-                    : launch_st_dt<F16, 4>(GP, grid, d[0].vector_len, nsl, res, two, lds, st);
-  return tok == 2 ? launch_st_dt<BF16, 2>(GP, grid, d[0].vector_len, nsl, res, two, lds, st)
-                  : launch_st_dt<BF16, 4>(GP, grid, d[0].vector_len, nsl, res, two, lds, st);
+    return tok == 2   ? launch_st_dt<F16, 2>(GP, grid, d[0].vector_len, nsl, res, two, lds, st)
+           : tok == 4 ? launch_st_dt<F16, 4>(GP, grid, d[0].vector_len, nsl, res, two, lds, st)
+                      : launch_st_dt<F16, 8>(GP, grid, d[0].vector_len, nsl, res, two, lds, st);
+  return tok == 2   ? launch_st_dt<BF16, 2>(GP, grid, d[0].vector_len, nsl, res, two, lds, st)
+         : tok == 4 ? launch_st_dt<BF16, 4>(GP, grid, d[0].vector_len, nsl, res, two, lds, st)
+                    : launch_st_dt<BF16, 8>(GP, grid, d[0].vector_len, nsl, res, two, lds, st);
 }
 hipError_t launch_gemv_sliced_tok(const VptqLayerDesc& d, const VptqSlicedLayout* L, const void* x, void* y, int tokens, int flags,
                                   void* ws, hipStream_t st) {

@@ -216,8 +216,8 @@ class SlicedGemv:
         rows, contiguous.  Returns y, or None where the call cannot be served (the caller takes the regular route)."""
         lay = self.layer
         tokens = x.numel() // lay.in_features
-        if x.shape[-1] != lay.in_features or not 2 <= tokens <= 4:
-            raise ValueError("forward_tokens takes 2 - 4 tokens of in_features values")
+        if x.shape[-1] != lay.in_features or not 2 <= tokens <= 8:
+            raise ValueError("forward_tokens takes 2 - 8 tokens of in_features values")
         if x.dtype != self._dtype or x.device != self.dev:
             x = lay._check_activation(x)
         if not x.is_contiguous():
@@ -229,25 +229,26 @@ class SlicedGemv:
                 return self._launch_tokens(x, out, flags, tokens)
         return self._launch_tokens(x, out, flags, tokens)
 
-    def _tokens_workspace(self, stream_ptr: int):
-        """the workspace of the 2 - 4 token kernel for this stream (sized for 4 tokens: it serves 2 and 3 as well), or None
-        inside a capture on a stream the layer has not run on"""
+    def _tokens_workspace(self, stream_ptr: int, tokens: int = 4):
+        """the workspace of the token kernel for this stream (sized for 4 tokens - it serves 2 and 3 as well -, for 8 once more
+        than 4 have been asked for), or None inside a capture on a stream the layer has not run on with that many tokens"""
         ws = self._ws_tok.get(stream_ptr)
-        if ws is None:
+        need = 8 if tokens > 4 else 4
+        if ws is None or ws[1] < need:
             if torch.cuda.is_current_stream_capturing():
                 return None
-            nbytes = B.lib().vptq_quant_gemv_sliced_tokens_workspace_bytes(self.desc, 4)
+            nbytes = B.lib().vptq_quant_gemv_sliced_tokens_workspace_bytes(self.desc, need)
             if not nbytes:
                 return None
-            ws = torch.zeros(nbytes, dtype=torch.uint8, device=self.dev)
+            ws = (torch.zeros(nbytes, dtype=torch.uint8, device=self.dev), need)
             self._ws_tok[stream_ptr] = ws
-        return ws
+        return ws[0]
 
     def _launch_tokens(self, x, out, flags, tokens):
         lay = self.layer
         sp = B.current_stream_ptr(self.dev)
         key = sp
-        ws = self._tokens_workspace(sp)
+        ws = self._tokens_workspace(sp, tokens)
         if ws is None:
             return None
         if out is None:
@@ -328,8 +329,8 @@ class SlicedGroupGemv:
         where the call cannot be served (as SlicedGemv.forward_tokens)"""
         lay = self.members[0].layer
         tokens = x.numel() // lay.in_features
-        if x.shape[-1] != lay.in_features or not 2 <= tokens <= 4:
-            raise ValueError("forward_tokens takes 2 - 4 tokens of in_features values")
+        if x.shape[-1] != lay.in_features or not 2 <= tokens <= 8:
+            raise ValueError("forward_tokens takes 2 - 8 tokens of in_features values")
         if x.dtype != self._dtype or x.device != self.dev:
             x = lay._check_activation(x)
         if not x.is_contiguous():
@@ -346,7 +347,7 @@ class SlicedGroupGemv:
         n = len(self.members)
         wss = []
         for m in self.members:
-            ws = m._tokens_workspace(sp)
+            ws = m._tokens_workspace(sp, tokens)
             if ws is None:
                 return None
             wss.append(ws)
