@@ -645,6 +645,41 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_tok_kernel(const Slice
   }
 }
 
+// ---- launchers (both parts of the build: the file is compiled twice, VPTQ_ST_PART = 1: 2 and 4 token slots + the host side,
+// 2: the 8-slot instantiations - two minutes of compile time as one translation unit)
+template <typename DT, int NSL, bool RES, int V, bool TWO, int TOK>
+static hipError_t launch_st(const SlicedTokGroupParams& P, int grid, uint32_t lds, hipStream_t st) {
+  auto kern = gemv_sliced_tok_kernel<DT, NSL, RES, V, TWO, TOK>;
+  static std::atomic<bool> attr_set[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (!attr_set[dev]) {
+    const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSLLdsLimit);
+    if (e != hipSuccess) return e;
+    attr_set[dev] = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(kSLThreads), lds, st, P);
+  return hipGetLastError();
+}
+template <typename DT, int TOK>
+static hipError_t launch_st_dt(const SlicedTokGroupParams& P, int grid, int v, int nsl, bool res, bool two, uint32_t lds, hipStream_t st) {
+  if (v == 16) {
+    if (two) return nsl == 16 ? launch_st<DT, 16, false, 16, true, TOK>(P, grid, lds, st) : launch_st<DT, 32, false, 16, true, TOK>(P, grid, lds, st);
+    return nsl == 16 ? launch_st<DT, 16, false, 16, false, TOK>(P, grid, lds, st) : launch_st<DT, 32, false, 16, false, TOK>(P, grid, lds, st);
+  }
+  if (two) return nsl == 8 ? launch_st<DT, 8, false, 8, true, TOK>(P, grid, lds, st) : launch_st<DT, 16, false, 8, true, TOK>(P, grid, lds, st);
+  if (nsl == 8) return res ? launch_st<DT, 8, true, 8, false, TOK>(P, grid, lds, st) : launch_st<DT, 8, false, 8, false, TOK>(P, grid, lds, st);
+  return res ? launch_st<DT, 16, true, 8, false, TOK>(P, grid, lds, st) : launch_st<DT, 16, false, 8, false, TOK>(P, grid, lds, st);
+}
+
+hipError_t launch_st_tok8(int dtype, const SlicedTokGroupParams& P, int grid, int v, int nsl, bool res, bool two, uint32_t lds, hipStream_t st);
+#if !defined(VPTQ_ST_PART) || VPTQ_ST_PART == 2
+hipError_t launch_st_tok8(int dtype, const SlicedTokGroupParams& P, int grid, int v, int nsl, bool res, bool two, uint32_t lds, hipStream_t st) {
+  return dtype == VPTQ_DTYPE_F16 ? launch_st_dt<F16, 8>(P, grid, v, nsl, res, two, lds, st) : launch_st_dt<BF16, 8>(P, grid, v, nsl, res, two, lds, st);
+}
+#endif
+
+#if !defined(VPTQ_ST_PART) || VPTQ_ST_PART == 1
 // ---- host side -------------------------------------------------------------------
 static size_t st_partial_bytes(const VptqLayerDesc& d, int tokens) {
   const size_t parts = (size_t)gemv_sliced_slices(d) * (sl_two(d) ? 2 : 1);
@@ -712,31 +747,6 @@ bool gemv_sliced_tok_eligible(const VptqLayerDesc& d, const VptqSlicedLayout* L,
   for (int i = 0; i < n; ++i)
     if (!L[i].wstart) return false;
   return st_plan(d, L, tokens, pl);
-}
-
-template <typename DT, int NSL, bool RES, int V, bool TWO, int TOK>
-static hipError_t launch_st(const SlicedTokGroupParams& P, int grid, uint32_t lds, hipStream_t st) {
-  auto kern = gemv_sliced_tok_kernel<DT, NSL, RES, V, TWO, TOK>;
-  static std::atomic<bool> attr_set[64];
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-  if (!attr_set[dev]) {
-    const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSLLdsLimit);
-    if (e != hipSuccess) return e;
-    attr_set[dev] = true;
-  }
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(kSLThreads), lds, st, P);
-  return hipGetLastError();
-}
-template <typename DT, int TOK>
-static hipError_t launch_st_dt(const SlicedTokGroupParams& P, int grid, int v, int nsl, bool res, bool two, uint32_t lds, hipStream_t st) {
-  if (v == 16) {
-    if (two) return nsl == 16 ? launch_st<DT, 16, false, 16, true, TOK>(P, grid, lds, st) : launch_st<DT, 32, false, 16, true, TOK>(P, grid, lds, st);
-    return nsl == 16 ? launch_st<DT, 16, false, 16, false, TOK>(P, grid, lds, st) : launch_st<DT, 32, false, 16, false, TOK>(P, grid, lds, st);
-  }
-  if (two) return nsl == 8 ? launch_st<DT, 8, false, 8, true, TOK>(P, grid, lds, st) : launch_st<DT, 16, false, 8, true, TOK>(P, grid, lds, st);
-  if (nsl == 8) return res ? launch_st<DT, 8, true, 8, false, TOK>(P, grid, lds, st) : launch_st<DT, 8, false, 8, false, TOK>(P, grid, lds, st);
-  return res ? launch_st<DT, 16, true, 8, false, TOK>(P, grid, lds, st) : launch_st<DT, 16, false, 8, false, TOK>(P, grid, lds, st);
 }
 
 // one layer's parameter block (its permutation pre-pass is queued into perm_*: one launch for the whole group)
@@ -854,13 +864,12 @@ hipError_t launch_gemv_sliced_tok_group(const VptqLayerDesc* d, const VptqSliced
   const int grid = GP.start[n];
   const bool res = sl_res256(d[0]), two = sl_two(d[0]);
   const int nsl = gemv_sliced_slices(d[0]);
+  if (tok == 8) return launch_st_tok8(d[0].dtype, GP, grid, d[0].vector_len, nsl, res, two, lds, st);
   if (d[0].dtype == VPTQ_DTYPE_F16)
-    return tok == 2   ? launch_st_dt<F16, 2>(GP, grid, d[0].vector_len, nsl, res, two, lds, st)
-           : tok == 4 ? launch_st_dt<F16, 4>(GP, grid, d[0].vector_len, nsl, res, two, lds, st)
-                      : launch_st_dt<F16, 8>(GP, grid, d[0].vector_len, nsl, res, two, lds, st);
-  return tok == 2   ? launch_st_dt<BF16, 2>(GP, grid, d[0].vector_len, nsl, res, two, lds, st)
-         : tok == 4 ? launch_st_dt<BF16, 4>(GP, grid, d[0].vector_len, nsl, res, two, lds, st)
-                    : launch_st_dt<BF16, 8>(GP, grid, d[0].vector_len, nsl, res, two, lds, st);
+    return tok == 2 ? launch_st_dt<F16, 2>(GP, grid, d[0].vector_len, nsl, res, two, lds, st)
+                    : launch_st_dt<F16, 4>(GP, grid, d[0].vector_len, nsl, res, two, lds, st);
+  return tok == 2 ? launch_st_dt<BF16, 2>(GP, grid, d[0].vector_len, nsl, res, two, lds, st)
+                  : launch_st_dt<BF16, 4>(GP, grid, d[0].vector_len, nsl, res, two, lds, st);
 }
 hipError_t launch_gemv_sliced_tok(const VptqLayerDesc& d, const VptqSlicedLayout* L, const void* x, void* y, int tokens, int flags,
                                   void* ws, hipStream_t st) {
@@ -868,5 +877,7 @@ hipError_t launch_gemv_sliced_tok(const VptqLayerDesc& d, const VptqSlicedLayout
   void* const wss[1] = {ws};
   return launch_gemv_sliced_tok_group(&d, L, 1, x, ys, tokens, flags, wss, st);
 }
+
+#endif   // part 1
 
 }  // namespace vptq
