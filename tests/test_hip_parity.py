@@ -1536,7 +1536,11 @@ def test_adversarial_families_default_route(family, xkind, O, dev):
     gated = m._descriptor()[9] != 0
     # (round 4: the cyclic pattern with in_features a multiple of k makes every index row the same - 8 distinct
     # outputs; layers with fewer than 32 distinct vector-rows are gated as well: tools/gpu_fuzz_count.py)
-    assert gated == (family in ("plain", "bias4", "bias16", "cyclic")), (family, gated)
+    # round 5: the gate MEASURES the folded form against the reference's roundings on probe activations (float32 outputs):
+    # bias-dominated layers and the cyclic pattern sit far above its line, LLM-like tensors and bias0.7 far below; the
+    # reference test's own distribution ("plain": bias as large as the scaled weights) sits near it and may go either way
+    if family != "plain":
+        assert gated == (family in ("bias4", "bias16", "cyclic")), (family, gated)
     err = rel_err(tensor_to_bits(m(xt)), want, "f16")
     assert err <= 1e-3, f"module default route, {family}/{xkind}: {err:.2e}"
     # the chain API with the same layers (the gate routes bias-dominated ones to the per-layer exact path)
@@ -1555,7 +1559,8 @@ def test_adversarial_families_default_route(family, xkind, O, dev):
     # is folded arithmetic too) go through it as well
     import importlib
     qg = importlib.import_module("vptq_amd.ops.quant_gemm")   # (the package also exports a function of that name)
-    assert (qg._safe_flags(m.indices, m.centroids.weight, m.res_centroids.weight, m.weight_scale, m.weight_bias) != 0) == gated
+    assert (qg._safe_flags(m.indices, m.centroids.weight, m.res_centroids.weight, m.weight_scale, m.weight_bias,
+                           m._descriptor()[1], I, O) != 0) == gated
     x6 = np.concatenate([x] * 6, axis=1)
     x6t = bits_to_tensor(x6, "f16", dev).reshape(x6.shape)
     y6 = m(x6t)

@@ -1,0 +1,163 @@
+#!/usr/bin/env python3
+"""Counting fuzz of the measured folded-form gate (vptq_amd/_backend.py:folded_form_is_safe, round 5) THROUGH THE PRODUCT
+ROUTE - `VQuantLinear.forward` - on tensor families the gate was not tuned on: checkpoint-like
+statistics instead of the four synthetic distributions of tools/gpu_fuzz_count.py.
+
+    python tools/gpu_gate_count.py [--layers 4096] [--dtype f16|bf16] [--seed 0]
+
+Families (weights as VPTQ stores them: centroids of column-NORMALISED weights, weight_scale = column std, weight_bias =
+column mean - vptq/layers/vqlinear.py:214-240 of the reference):
+  ckpt          centroids N(0, 1), residual N(0, 0.25), scale 0.02 lognormal(0.3), bias N(0, 0.002)
+  heavy-scale   ckpt with scale 0.02 lognormal(1.0) (heavy-tailed column norms)
+  outlier-cols  ckpt with 0.5 % of the columns' scale x 10 ... 50 (outlier channels)
+  zero-bias     ckpt with bias exactly 0 / 1e-5 N
+  t-centroids   centroids / residual Student-t (3 degrees of freedom)
+  sorted-idx    ckpt values, every row's index stream sorted along the columns (clustered, low-entropy indices)
+  low-entropy   ckpt values, indices drawn from 16 of the 256 entries (perm-clustered codebook use)
+  big-bias      bias N(0, 0.05): column means as large as 2.5 column stds (an un-centred weight matrix)
+  ref-test      the reference test's normal(0.02, 0.5) for every tensor (bias as large as the scaled weights); llm-r4: the
+                "llm" distribution of rounds 1 - 4 (centroids N(0, 0.02), residual N(0, 0.005), scale 1 + 0.1 N, bias 0.01 N)
+Activations rotate per layer: N(0, 1); N(0, 1) with 0.5 % of the channels x 50 (massive activations); |N(0, 1)| (post-ReLU
+like, large mean); 90 % zeros; N(0, 1) projected orthogonal to the bias.
+
+Reference on the GPU as in tools/gpu_fuzz_count.py: `vptq_dequant` (bit-identical to the reference CPU path's dequant:
+sha256 of W on every golden in tests/test_hip_parity.py) and a float64 product rounded once.  Per family: layers, how
+many the gate sent to the reference's roundings, worst / p99.9 / median of max|dy| / max|y_ref| through the product
+route, count above the bar (1e-3 fp16, 8e-3 bf16); for information the folded form WITHOUT the gate and the un-rounded
+distance the gate measured on its probes (median / max)."""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import vptq_amd  # noqa: E402
+from vptq_amd import _backend as B  # noqa: E402
+
+SHAPES = [(4096, 4096), (4096, 4096), (4096, 1024), (8192, 8192), (4096, 14336), (14336, 4096), (5120, 5120), (2048, 8192),
+          (8192, 1024), (1024, 4096)]   # (in, out)
+FAMILIES = ("ckpt", "heavy-scale", "outlier-cols", "zero-bias", "t-centroids", "sorted-idx", "low-entropy", "big-bias", "ref-test", "llm-r4")
+XKINDS = ("normal", "massive", "relu", "sparse", "bias-orth")
+
+
+def make(I, O, fam, dt, dev, g, k=256, kr=256):
+    m = vptq_amd.VQuantLinear(I, O, vector_lens=[-1, 8], num_centroids=[-1, k], num_res_centroids=[-1, kr],
+                              group_num=1, group_size=I, outlier_size=0, indices_as_float=False, enable_norm=True,
+                              enable_perm=False, is_indice_packed=True, bias=False, dtype=dt, device=dev,
+                              enable_proxy_error=False)
+    rn = lambda *s: torch.randn(*s, generator=g, device=dev)  # noqa: E731
+    cw, rw = m.centroids.weight.shape, m.res_centroids.weight.shape
+    if fam == "t-centroids":
+        t3 = lambda *s: rn(*s) / torch.sqrt((rn(3, *s) ** 2).mean(0))  # noqa: E731
+        c, r = t3(*cw), 0.25 * t3(*rw)
+    else:
+        c, r = rn(*cw), 0.25 * rn(*rw)
+    sig = {"heavy-scale": 1.0}.get(fam, 0.3)
+    scale = 0.02 * torch.exp(sig * rn(I))
+    if fam == "outlier-cols":
+        hot = torch.randperm(I, generator=g, device=dev)[: max(1, I // 200)]
+        scale[hot] *= 10 + 40 * torch.rand(hot.numel(), generator=g, device=dev)
+    bias = 0.002 * rn(I)
+    if fam == "zero-bias":
+        bias = bias * (0.0 if int(torch.randint(0, 2, (1,), generator=g, device=dev)) else 5e-3)
+    if fam == "big-bias":
+        bias = 0.05 * rn(I)
+    if fam == "ref-test":
+        c, r, scale, bias = 0.02 + 0.5 * rn(*cw), 0.02 + 0.5 * rn(*rw), 0.02 + 0.5 * rn(I), 0.02 + 0.5 * rn(I)
+    if fam == "llm-r4":
+        c, r, scale, bias = 0.02 * rn(*cw), 0.005 * rn(*rw), 1 + 0.1 * rn(I), 0.01 * rn(I)
+    m.centroids.weight.data = c.to(dt)
+    m.res_centroids.weight.data = r.to(dt)
+    m.weight_scale.data = scale.to(dt)
+    m.weight_bias.data = bias.to(dt)
+    N = m.indices.shape[1]
+    if fam in ("sorted-idx", "low-entropy"):
+        hi = 16 if fam == "low-entropy" else k
+        e = torch.randint(0, hi, (N, I), generator=g, device=dev, dtype=torch.int64)
+        er = torch.randint(0, kr, (N, I), generator=g, device=dev, dtype=torch.int64)
+        if fam == "sorted-idx":
+            e = torch.sort(e, dim=1).values
+        w16 = e | (er << 8)
+        m.indices.data = (w16[:, 0::2] | (w16[:, 1::2] << 16)).to(torch.int32).view(m.indices.shape)
+    else:
+        m.indices.data = torch.randint(-2**31, 2**31 - 1, m.indices.shape, generator=g, device=dev, dtype=torch.int64).to(torch.int32)
+    return m.eval()
+
+
+def make_x(m, kind, dt, dev, g):
+    I = m.in_features
+    x = torch.randn(I, generator=g, device=dev)
+    if kind == "massive":
+        hot = torch.randperm(I, generator=g, device=dev)[: max(1, I // 200)]
+        x[hot] *= 50
+    elif kind == "relu":
+        x = x.abs()
+    elif kind == "sparse":
+        x = x * (torch.rand(I, generator=g, device=dev) < 0.1)
+    elif kind == "bias-orth":
+        b = m.weight_bias.data.float()
+        bb = (b * b).sum()
+        if float(bb) > 0:
+            x = x - (x * b).sum() / bb * b
+    return x.to(dt).view(1, 1, I)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--layers", type=int, default=4096)
+    ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--max-elems", type=float, default=70e6, help="largest in x out drawn (time)")
+    a = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    dt = torch.float16 if a.dtype == "f16" else torch.bfloat16
+    bar = 1e-3 if a.dtype == "f16" else 8e-3
+    g = torch.Generator(device=dev).manual_seed(7000 + a.seed)
+    rng = np.random.default_rng(a.seed)
+    shapes = [s for s in SHAPES if s[0] * s[1] <= a.max_elems]
+    stats = {}
+    t0 = time.time()
+    per = (a.layers + len(FAMILIES) - 1) // len(FAMILIES)
+    done = 0
+    for fam in FAMILIES:
+        st = stats.setdefault(fam, dict(err=[], raw=[], gated=0, probe=[]))
+        for i in range(per):
+            I, O = shapes[int(rng.integers(0, len(shapes)))]
+            m = make(I, O, fam, dt, dev, g)
+            x = make_x(m, XKINDS[(done + i) % len(XKINDS)], dt, dev, g)
+            d = m._descriptor()
+            gated = bool(d[9])
+            st["gated"] += int(gated)
+            W = m.dequant()
+            s64 = W.double() @ x.reshape(-1).double()
+            r16 = s64.to(dt)
+            den = r16.double().abs().max().clamp_min(1e-30)
+            y = m(x)                                                  # the product route (with the gate)
+            st["err"].append(float((y.reshape(-1).double() - r16.double()).abs().max() / den))
+            yr = torch.empty(1, 1, O, dtype=dt, device=dev)          # the folded form whatever the gate says (information)
+            B.check(B.lib().vptq_quant_gemv(d[1], x.data_ptr(), yr.data_ptr(), 1, 0, None, 0, B.current_stream_ptr(dev)), "gemv")
+            st["raw"].append(float((yr.reshape(-1).double() - r16.double()).abs().max() / den))
+            st["probe"].append(float(B.folded_probe_distance(d[1], I, O, m.weight_bias.data, dt, dev)))
+            del m, W
+        done += per
+        print(f"# {fam}: {per} layers done after {time.time() - t0:.0f} s", flush=True)
+    print(f"dtype {a.dtype}, bar {bar:g}, {done} layers, seed {a.seed}, gate line {B.FOLDED_MAX_PROBE_DISTANCE[dt]:g} (un-rounded distance on the probes)")
+    print(f"{'family':14s} {'layers':>6s} {'gated':>6s} | product route: {'worst':>9s} {'p99.9':>9s} {'median':>9s} {'> bar':>6s} | "
+          f"folded, no gate: {'worst':>9s} {'> bar':>6s} | probe distance: {'median':>9s} {'max':>9s}")
+    total = 0
+    for fam, st in stats.items():
+        e, r, p = np.array(st["err"]), np.array(st["raw"]), np.array(st["probe"])
+        ex = int((e > bar).sum())
+        total += ex
+        print(f"{fam:14s} {len(e):6d} {st['gated']:6d} | {'':14s} {e.max():9.2e} {np.quantile(e, 0.999):9.2e} {np.median(e):9.2e} {ex:6d} | "
+              f"{'':16s} {r.max():9.2e} {int((r > bar).sum()):6d} | {'':15s} {np.median(p):9.2e} {p.max():9.2e}")
+    print(f"exceedances through the product route: {total}")
+    return 1 if total else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -226,25 +226,28 @@ def _derived(owner: torch.Tensor, name: str, key, build):
 
 # ---- load-time gate of the default ("folded") decode arithmetic ---------------------------------------------------
 # The folded form  y = sum (c + r) * f16(s x) + sum b x  is as close to exact arithmetic as the reference CPU path
-# is: the reference rounds every weight three times (vptq/ops/quant_gemm.py:143-158), which puts ITS un-rounded sums
-# 1-6e-4 of max|y| away from exact math, and the parity bar (1e-3 of max|y|) has room for that distance
-# plus one rounding flip only while max|y| is a maximum over MANY independent outputs (max|y| / rms(y) ~ 4).  Two
-# kinds of layers break that and are served with the reference's roundings (VPTQ_GEMV_EXACT) instead:
-#  * layers whose weight bias is at least as large as the scaled weights (rms(b) > rms(s) rms(c + r)): the reference's
-#    rounding of w s + b loses low bits of w s, an activation for which sum b x cancels exposes it (1.6e-3 at |b| = 8 |w s|).
-#    Round 3 drew the line at 2; the count over 8192 + 4096 layers (profiles/r04/fuzz_count_f16_8192.txt) found ONE layer
-#    in 2048 at ratio 1.4 (the reference test's normal(0.02, 0.5) for every tensor) at 1.11e-3 (bf16: one in 1024 at
-#    8.7e-3), none in 4096 at ratio 0.5 (LLM-like tensors; real checkpoints: the bias is a column mean, far below the
-#    column's scale): the line is 1 now;
-#  * layers with fewer than FOLDED_MIN_DISTINCT_ROWS distinct vector-rows - tiny layers, and index tensors whose rows
-#    repeat, such as the reference test's cyclic arange(k) pattern with in_features a multiple of k
-#    (tests/test_quant_gemv.py:21-31: every row identical, 8 distinct outputs): counted over 2048 layers per dtype
-#    (tools/gpu_fuzz_count.py, profiles/r04/fuzz_count_*.txt) the folded form exceeds the bar on 2-6 % of those and on
-#    none of the layers with >= 128 distinct rows; numpy emulation (tools/fold_error_study.py): 1-2 % at 1-4 rows,
-#    0 of 150 from 16 rows on.
-FOLDED_MAX_BIAS_RATIO = 1.0
-FOLDED_MIN_DISTINCT_ROWS = 32
+# is: the reference rounds every weight three times (vptq/ops/quant_gemm.py:121,155-156), which puts ITS un-rounded
+# sums 2-7e-4 of max|y| away from exact math.  What the parity bar (1e-3 of max|y|) has room for:
+# a rounded output differs from the reference's by n ulps where n <= |un-rounded distance| / ulp + 1, one fp16 ulp of
+# the top binade is 2^-10 * 2^k with max|y| = m 2^k, 1 <= m < 2, so ONE flip costs 9.77e-4 / m <= 1e-3 and TWO exceed
+# the bar while m < 1.95: a layer is safe while its un-rounded distance stays under one top-binade ulp, i.e. under
+# 9.77e-4 / m of max|y|.
+#
+# Round 5: the gate MEASURES that distance on the layer's own tensors instead of predicting it from tensor statistics
+# (rounds 3-4: rms(b) against rms(s) rms(c + r) and a count of distinct index rows - tuned on four synthetic
+# distributions).  At descriptor build the layer runs both forms through the library - folded and
+# VPTQ_GEMV_EXACT (the reference's three roundings: >= 99 % bit-identical, un-rounded distance ~1e-6), float32
+# outputs - on PROBE activations: N(0, 1); N(0, 1) with 8 channels x 40 (outlier channels); |N(0, 1)| (a large mean:
+# sum b x as large as it gets); N(0, 1) projected orthogonal to the weight bias (sum b x cancels: what exposes a
+# bias-dominated layer).  The layer keeps the folded form while max|y_folded - y_exact| / max|y_exact| stays under
+# FOLDED_MAX_PROBE_DISTANCE on every probe.  Bias-dominated layers (1.6e-3 at |b| = 8 |w s|) and layers with few distinct
+# outputs (the reference test's cyclic index pattern: max|y| is a maximum over 8 values, not thousands) land far
+# above the line; random layers of the LLM-like and the reference-test distributions at 2-7e-4 (tools/gate_probe_study.py,
+# profiles/r05/gate_probe_study_*.txt).  One device -> host read per descriptor build, i.e. per layer load.
+FOLDED_MAX_PROBE_DISTANCE = {torch.float16: 7.5e-4, torch.bfloat16: 6.0e-3}   # (bf16: 8 mantissa bits fewer... 3: x 8)
+FOLDED_MIN_DISTINCT_ROWS = 32   # (kept as a cheap pre-filter: tiny layers and repeating index rows never take the folded form)
 _ROW_SAMPLE = 64
+_PROBE_SEED = 0x5eed
 
 
 def distinct_index_rows(indices: torch.Tensor) -> int:
@@ -260,22 +263,67 @@ def distinct_index_rows(indices: torch.Tensor) -> int:
     return int(torch.unique(h).numel())
 
 
-def folded_form_is_safe(indices, centroids, res_centroids, weight_scale, weight_bias) -> bool:
-    """One device -> host read per call: call it once per set of tensors (descriptor build / functional-API cache)."""
+def probe_activations(in_features: int, weight_bias: Optional[torch.Tensor], dtype, dev) -> torch.Tensor:
+    """[4, in_features] probe activations of the folded-form gate (deterministic: the same layer gets the same answer)"""
+    g = torch.Generator(device=dev).manual_seed(_PROBE_SEED + in_features)
+    r = torch.randn(4, in_features, generator=g, device=dev, dtype=torch.float32)
+    hot = torch.randint(0, in_features, (8,), generator=g, device=dev)
+    r[1, hot] *= 40.0
+    r[2] = r[2].abs()
+    if weight_bias is not None:
+        b = weight_bias.detach().float().reshape(-1)
+        bb = (b * b).sum()
+        r[3] = torch.where(bb > 0, r[3] - ((r[3] * b).sum() / bb.clamp_min(1e-30)) * b, r[3])
+    return r.to(dtype).contiguous()
+
+
+def folded_probe_distance(desc, in_features: int, out_features: int, weight_bias, dtype, dev, folded=None) -> torch.Tensor:
+    """max over the probes of max|y_folded - y_exact| / max|y_exact| on float32 outputs (a 0-dim device tensor).
+    `folded(x_row, y_f32) -> bool`: another folded route than the library's default one (the sliced layouts)."""
+    fn = lib().vptq_quant_gemv
+    xs = probe_activations(in_features, weight_bias, dtype, dev)
+    ya = torch.empty(xs.shape[0], out_features, dtype=torch.float32, device=dev)
+    yb = torch.empty_like(ya)
+    with torch.cuda.device(dev):
+        sp = current_stream_ptr(dev)
+        for i in range(xs.shape[0]):
+            if folded is not None:
+                if not folded(xs[i], ya[i]):
+                    return torch.full((), float("inf"), device=dev)
+            else:
+                check(fn(desc, xs[i].data_ptr(), ya[i].data_ptr(), 1, GEMV_OUT_F32, None, 0, sp), "vptq_quant_gemv")
+            check(fn(desc, xs[i].data_ptr(), yb[i].data_ptr(), 1, GEMV_OUT_F32 | GEMV_EXACT, None, 0, sp), "vptq_quant_gemv")
+    den = yb.abs().amax(1).clamp_min(1e-30)
+    d = ((ya - yb).abs().amax(1) / den)
+    # (a probe whose exact output is not finite says nothing about the arithmetic: inf / nan weights are the caller's)
+    d = torch.where(torch.isfinite(d), d, torch.zeros_like(d))
+    return d.amax()
+
+
+def folded_form_is_safe(indices, centroids, res_centroids, weight_scale, weight_bias, desc=None,
+                        in_features: int = 0, out_features: int = 0) -> bool:
+    """One device -> host read per call: call it once per set of tensors (descriptor build / functional-API cache).
+    With `desc` (the layer's descriptor): the measured gate; without: only the pre-filter."""
     if weight_scale is None or weight_bias is None or not weight_scale.is_cuda:
         return True
     with torch.no_grad():
-        w2 = centroids.float().pow(2).mean()
-        if res_centroids is not None:
-            w2 = w2 + res_centroids.float().pow(2).mean()
-        lhs = weight_bias.float().pow(2).mean()
-        rhs = (FOLDED_MAX_BIAS_RATIO ** 2) * weight_scale.float().pow(2).mean() * w2
-        if not bool((lhs <= rhs).item()):
-            return False
         if indices is not None and indices.dim() == 3:
             if indices.shape[1] < FOLDED_MIN_DISTINCT_ROWS or distinct_index_rows(indices) < FOLDED_MIN_DISTINCT_ROWS:
                 return False
-    return True
+        if desc is None or torch.cuda.is_current_stream_capturing():
+            return desc is None   # (no launch + read-back inside a capture: the reference's roundings serve until a rebuild)
+        lim = FOLDED_MAX_PROBE_DISTANCE.get(centroids.dtype)
+        if lim is None:
+            return True
+        name = lib().vptq_quant_gemv_kernel_name(desc, 1, 0)
+        name_x = lib().vptq_quant_gemv_kernel_name(desc, 1, GEMV_EXACT)
+        if name is not None and name == name_x:
+            return True   # (one kernel either way: this layer's default route IS the reference's roundings - nothing to gate)
+        try:
+            d = folded_probe_distance(desc, in_features, out_features, weight_bias, centroids.dtype, weight_scale.device)
+        except VptqBackendError:
+            return True   # (a layer the library refuses shows that at its first real call, with the library's message)
+        return bool((d <= lim).item())
 
 
 def inverse_perm(perm: torch.Tensor) -> torch.Tensor:

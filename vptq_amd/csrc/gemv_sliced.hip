@@ -48,6 +48,36 @@ constexpr int kSLQueueWords = VPTQ_SLICED_QUEUE;
 // [start[l], start[l + 1]).  One launch instead of n: the fixed part of a launch (boundary, slice copy, staging, the
 // cross-slice hand-over: ~7 of the 10 us of a 4096 x 4096 layer) is paid once.
 constexpr int kSLMaxGroup = 3;
+// how the slices of a row meet.  1 (default): ONE hop - every (slice, output) partial sum becomes a 64-bit fixed-point word
+// (count | value) added to the output's accumulator with a returning device-scope atomic; integer adds commute, so the sum
+// does not depend on the order, and the lane whose add completes the count holds the total.  0: the round-3/4 hand-over
+// (write-through partial sums, arrival counter per row block, the last workgroup reads them back: three dependent trips).
+#ifndef VPTQ_SLICED_EPI
+#define VPTQ_SLICED_EPI 1
+#endif
+// phase time stamps (tools/sliced_trace.py): every wave writes s_memrealtime at entry / after the prologue barrier / at the
+// end of its stream / at its exit behind the accumulator words of the workspace (8192^2-sized layers only: the room the
+// round-4 partial sums had)
+#ifndef VPTQ_SLICED_TRACE
+#define VPTQ_SLICED_TRACE 0
+#endif
+// accumulator word of one output: bits [0, 7) arrivals, [7, 14) arrivals whose partial sum was NaN, [14, 64) the sum in
+// units of 2^-24 (50 bits signed: +-3.3e7; a partial sum beyond that - or an infinite one - saturates, which still rounds to
+// the 16-bit formats' infinity)
+constexpr int kSLFixFrac = 24, kSLFixShift = 14;
+static __device__ __forceinline__ unsigned long long sl_to_fixed(float v) {
+  const bool nan = v != v;
+  const float lim = 33554430.f;   // 2^25 - 2: the product below stays under 2^49
+  float c = __builtin_fminf(__builtin_fmaxf(v, -lim), lim);
+  if (nan) c = 0.f;
+  const long long q = (long long)(c * (float)(1 << kSLFixFrac));   // exact product (a power of two), truncated to an integer
+  return ((unsigned long long)q << kSLFixShift) + (nan ? 129ull : 1ull);
+}
+static __device__ __forceinline__ float sl_from_fixed(unsigned long long w) {
+  if ((w >> 7) & 127ull) return __builtin_nanf("");
+  const long long q = (long long)w >> kSLFixShift;
+  return (float)((double)q * (1.0 / (double)(1 << kSLFixFrac)));   // |q| < 2^50: exact in fp64, ONE rounding to fp32
+}
 struct SlicedGroupParams {
   int n;
   int start[kSLMaxGroup + 1];
@@ -98,6 +128,10 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
   const int row0 = (rb * kSLWaves + wave) * rpw;   // this wave's first row
   const int n_rows = row0 >= N ? 0 : (N - row0 < rpw ? N - row0 : rpw);
 
+#if VPTQ_SLICED_TRACE
+  unsigned long long* const trace = (unsigned long long*)as_global(P.partial) + (size_t)N * V + ((size_t)blockIdx.x * kSLWaves + wave) * 4;
+  if (lane == 0) trace[0] = __builtin_amdgcn_s_memrealtime();
+#endif
   // ---- this wave's stream: the blocks of its rows are contiguous in `elems`
   int my_blocks = 0, total = 0, first_block = 0;
   if (n_rows > 0) {
@@ -201,6 +235,9 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+#if VPTQ_SLICED_TRACE
+  if (lane == 0) trace[1] = __builtin_amdgcn_s_memrealtime();
+#endif
   float bdot = 0.f;
   if (sg == 0) {   // (fixed order: the 16 waves' parts)
     const float* const bp = (const float*)(smem + bd_off);
@@ -211,6 +248,32 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
 #pragma unroll
   for (int i = 0; i < V; ++i) acc[i] = 0.f;
   int row_i = 0;
+#if VPTQ_SLICED_EPI
+  // ---- the slices of a row meet in the output's accumulator word (caller's workspace, zero between launches): the lane
+  // whose add brings the arrivals to NSLT has old + its own = the sum of all slices (+ sum b x, which rides with slice 0),
+  // exact in fixed point and therefore the same whoever comes last; it rounds ONCE, adds the output bias, stores y and
+  // puts the word back to zero.  One returning atomic is the whole hand-over: nobody waits for anybody, nothing is read back.
+  int pend_o = -1;
+  unsigned long long pend_old[V / 4], pend_mine[V / 4];
+  auto finish_rows = [&]() __attribute__((always_inline)) {
+    if (pend_o >= 0) {
+#pragma unroll
+      for (int i = 0; i < V / 4; ++i) {
+        if ((pend_old[i] & 127ull) == (unsigned long long)(NSLT - 1)) {
+          const int o = pend_o + i;
+          float r = sl_from_fixed(pend_old[i] + pend_mine[i]);
+          if (o < P.O) {
+            if (P.bias) r += DT::to_float(as_global(P.bias)[o]);
+            if (P.out_f32) ((float*)as_global(P.y))[o] = r;
+            else ((uint16_t*)as_global(P.y))[o] = DT::from_float(r);
+          }
+          __hip_atomic_store((unsigned long long*)as_global(P.partial) + o, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      pend_o = -1;
+    }
+  };
+#endif
   // rows without elements in this slice store zeros
   auto store_row = [&]() __attribute__((always_inline)) {
     // sum over the 64 lanes: swap-and-add halves the values carried (gemv_k256c.hip:finish), then DPP
@@ -230,6 +293,20 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
 #pragma unroll
     for (int i = 0; i < V / 4; ++i) v[i] = row16_allsum(v[i]);
     // lane l (any of its row of 16) holds outputs (V / 2) bit5 + (V / 4) bit4 + {0 .. V / 4 - 1}
+#if VPTQ_SLICED_EPI
+    // row i of the wave is handed over by lanes (i & 15) + {0, 16, 32, 48}: up to 16 rows' returned words wait in the
+    // registers of different lanes until the stream is through (no wait inside the loop)
+    if ((row_i & 15) == 0 && row_i > 0) finish_rows();   // (more than 16 rows per wave: the lanes come round again)
+    if ((lane & 15) == (row_i & 15)) {
+      pend_o = (row0 + row_i) * V + ((lane >> 5) & 1) * (V / 2) + ((lane >> 4) & 1) * (V / 4);
+      unsigned long long* const ap = (unsigned long long*)as_global(P.partial) + pend_o;
+#pragma unroll
+      for (int i = 0; i < V / 4; ++i) {
+        pend_mine[i] = sl_to_fixed(v[i] + bdot);
+        pend_old[i] = __hip_atomic_fetch_add(ap + i, pend_mine[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+#else
     if ((lane & 15) == 0) {
       const int o8 = ((lane >> 5) & 1) * (V / 2) + ((lane >> 4) & 1) * (V / 4);
       // write-through at device scope (sc1): the workgroup that sums the slices may sit on another XCD
@@ -237,6 +314,7 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
 #pragma unroll
       for (int i = 0; i < V / 4; ++i) __hip_atomic_store(pp + i, v[i] + bdot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+#endif
 #pragma unroll
     for (int i = 0; i < V; ++i) acc[i] = 0.f;
   };
@@ -339,6 +417,17 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
   // with device-coherent loads, adds them in a fixed tree (so the result does not depend on who was last), adds
   // the output bias and stores y.  A second launch for this step cost 4.3 us of the 14.2 (its reads were the
   // first touch of what other XCDs had just written, behind a kernel boundary).
+#if VPTQ_SLICED_TRACE
+  if (lane == 0) trace[2] = __builtin_amdgcn_s_memrealtime();
+#endif
+#if VPTQ_SLICED_EPI
+  finish_rows();
+#if VPTQ_SLICED_TRACE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (lane == 0) trace[3] = __builtin_amdgcn_s_memrealtime();
+#endif
+  return;
+#endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's partial sums have reached memory
   uint32_t* const flag = (uint32_t*)(smem + bd_off);   // (the sum b x parts are dead by now)
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
@@ -352,6 +441,9 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+#if VPTQ_SLICED_TRACE
+  if (lane == 0) trace[3] = __builtin_amdgcn_s_memrealtime();
+#endif
   if (*flag == 0u) return;
   {
     const int rows_wg = kSLWaves * rpw;
@@ -375,6 +467,10 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
       }
     }
   }
+#if VPTQ_SLICED_TRACE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (lane == 0) trace[3] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // ---- host side -------------------------------------------------------------------

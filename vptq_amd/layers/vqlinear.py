@@ -383,16 +383,19 @@ class VQuantLinear(nn.Module):
             cache = (key, desc, keep, dev, B.lib().vptq_quant_gemv,
                      B.lib().vptq_quant_gemv_max_tokens(desc), VQuantLinear._desc_generation,
                      tensors[1].dtype, dev.index if dev.index is not None else torch.cuda.current_device(),
-                     0 if self._folded_form_is_safe(tensors) else B.GEMV_EXACT,
+                     0 if self._folded_form_is_safe(tensors, desc) else B.GEMV_EXACT,
                      B.lib().vptq_quant_gemv_workspace_bytes(desc, 16, 0))   # [10]: scratch bytes of the batched-decode kernel
             self.__dict__["_desc_cache"] = cache
         return cache
 
-    def _folded_form_is_safe(self, tensors) -> bool:
-        """Load-time gate of the library's default ("folded") decode arithmetic (`_backend.folded_form_is_safe`):
-        bias-dominated layers and layers with fewer than 32 distinct vector-rows get VPTQ_GEMV_EXACT (the
-        reference's three roundings per weight).  One device -> host read per descriptor build, i.e. per layer load."""
-        return B.folded_form_is_safe(tensors[0], tensors[1], tensors[2], tensors[6], tensors[7])
+    def _folded_form_is_safe(self, tensors, desc=None) -> bool:
+        """Load-time gate of the library's default ("folded") decode arithmetic (`_backend.folded_form_is_safe`): the layer
+        runs both forms on probe activations and keeps the folded one while their un-rounded outputs stay within
+        `FOLDED_MAX_PROBE_DISTANCE` of max|y|; bias-dominated layers and layers with few distinct vector-rows get
+        VPTQ_GEMV_EXACT (the reference's three roundings per weight).  One device -> host read per descriptor build, i.e.
+        per layer load."""
+        return B.folded_form_is_safe(tensors[0], tensors[1], tensors[2], tensors[6], tensors[7], desc,
+                                     self.in_features, self.out_features)
 
     def _check_activation(self, x: torch.Tensor) -> torch.Tensor:
         if x.shape[-1] != self.in_features:
@@ -449,11 +452,27 @@ class VQuantLinear(nn.Module):
                 from vptq_amd.utils.sliced import SlicedGemv
                 try:
                     obj = SlicedGemv(self)
-                except (RuntimeError, MemoryError) as e:   # out of device memory while building: the regular route serves
+                except torch.cuda.OutOfMemoryError as e:
+                    # out of device memory while building: the regular route serves THIS call; nothing is remembered, so a
+                    # later call (memory freed meanwhile) tries again.  Any other error is a bug and propagates.
                     import warnings
+                    torch.cuda.empty_cache()
                     warnings.warn(f"sliced layout of a {self.in_features} x {self.out_features} layer not built "
-                                  f"({type(e).__name__}: {str(e)[:120]}); the layer keeps the gather kernel", stacklevel=3)
-                    obj = None
+                                  f"({str(e)[:120]}); the layer keeps the gather kernel for now", stacklevel=3)
+                    return None
+                # the kernel over the layouts evaluates the folded form: the same measured gate as every folded route
+                # (_backend.folded_form_is_safe) - its float32 outputs against the gather kernel's (the reference's roundings)
+                # on the probe activations
+                lim = B.FOLDED_MAX_PROBE_DISTANCE.get(cache[7])
+                if lim is not None and self._parameters.get("weight_bias") is not None:
+                    run = obj
+
+                    def folded(xr, yr):
+                        return run(xr.view(1, 1, -1), yr.view(1, 1, -1), flags=B.GEMV_OUT_F32) is not None
+                    d = B.folded_probe_distance(cache[1], self.in_features, self.out_features, self._parameters["weight_bias"],
+                                                cache[7], cache[3], folded=folded)
+                    if not bool((d <= lim).item()):
+                        obj = None
             st = (stamp, obj)
             self.__dict__["_sliced"] = st
         return st[1]

@@ -32,7 +32,7 @@ _FLAGS = B.GEMV_EXACT if os.environ.get("VPTQ_EXACT", "0") == "1" else 0
 _GATE_CACHE = {}
 
 
-def _safe_flags(indices, centroids, residual_centroids, weight_scale, weight_bias) -> int:
+def _safe_flags(indices, centroids, residual_centroids, weight_scale, weight_bias, desc=None, in_features=0, out_features=0) -> int:
     if weight_scale is None or weight_bias is None or not weight_scale.is_cuda:
         return 0
     import weakref
@@ -44,7 +44,8 @@ def _safe_flags(indices, centroids, residual_centroids, weight_scale, weight_bia
         if all((r is None and t is None) or (r is not None and r() is t) for r, t in zip(refs, tensors)) and \
                 vers == tuple(B.tensor_version(t) if t is not None else 0 for t in tensors):
             return hit
-    hit = 0 if B.folded_form_is_safe(indices, centroids, residual_centroids, weight_scale, weight_bias) else B.GEMV_EXACT
+    hit = 0 if B.folded_form_is_safe(indices, centroids, residual_centroids, weight_scale, weight_bias, desc,
+                                     in_features, out_features) else B.GEMV_EXACT
     if len(_GATE_CACHE) > 4096:
         _GATE_CACHE.clear()
     _GATE_CACHE[key] = (tuple(weakref.ref(t) if t is not None else None for t in tensors),
@@ -201,7 +202,8 @@ def quant_gemm(
             desc = None  # 9-16 tokens: only the canonical format's GEMV still beats dequant + GEMM
     if desc is not None:
         y = torch.empty(x.shape[:-1] + (out_features,), dtype=x.dtype, device=dev)
-        flags = _FLAGS | _safe_flags(indices, centroids, residual_centroids if enable_residual else None, weight_scale, weight_bias)
+        flags = _FLAGS | _safe_flags(indices, centroids, residual_centroids if enable_residual else None, weight_scale, weight_bias,
+                                     desc, in_features, out_features)
         with torch.cuda.device(dev):
             sp = B.current_stream_ptr(dev)
             ws, wsb = (None, 0)
