@@ -487,7 +487,7 @@ def test_command_line_options_match_the_reference():
     assert ns.model == "m" and ns.chat and ns.chat_system_prompt == "s" and ns.tokenizer == ""
     with pytest.raises(SystemExit):
         app.define_basic_args().parse_args([])      # --model is required
-    for fn in ("define_basic_args", "eval_prompt", "chat_loop", "get_valid_args", "main"):
+    for fn in ("define_basic_args", "eval_prompt", "chat_loop", "get_chat_loop_generator", "get_valid_args", "main"):
         assert callable(getattr(app, fn))
 
 
@@ -541,6 +541,51 @@ def test_command_line_chat_loop_logic_without_gpu(capsys):
     tok.chat_template = None
     out = app.chat_loop(model, tok, args)
     assert out.shape == (1, 6) and "no chat_template" in capsys.readouterr().out
+
+
+def test_chat_generator_streams_from_a_worker_thread(capsys):
+    """the UI callback (reference vptq/app_utils.py:109-165, imported by vptq/app.py:17): generate() runs on a worker
+    thread and the reply arrives piece by piece through a TextIteratorStreamer; sampling options are passed on; a
+    tokenizer without a chat template is refused with the reference's error"""
+    import threading
+    import vptq_amd.app_utils as app
+
+    class Enc(dict):
+        def to(self, dev):
+            return self
+
+    class Tok:
+        chat_template = "x"
+
+        def apply_chat_template(self, messages, add_generation_prompt=True, return_tensors=None, return_dict=False):
+            assert return_dict and add_generation_prompt
+            return Enc(input_ids=torch.tensor([[5, 6]]), attention_mask=torch.ones(1, 2, dtype=torch.long))
+
+        def decode(self, ids, **kw):
+            return "".join("w%d " % int(i) for i in ids)
+
+    class Model:
+        device = torch.device("cpu")
+
+        def generate(self, input_ids=None, streamer=None, **kw):
+            self.kw, self.thread = kw, threading.current_thread()
+            streamer.put(input_ids)                      # the prompt (skipped by the streamer)
+            for t in (7, 8, 9):
+                streamer.put(torch.tensor([t]))
+            streamer.end()
+
+    model = Model()
+    gen = app.chat_generator(model, Tok())
+    pieces = list(gen([{"role": "user", "content": "hi"}], 12, temperature=0.5, top_p=0.9))
+    assert "".join(pieces).split() == ["w7", "w8", "w9"]
+    assert model.thread is not threading.current_thread()
+    assert model.kw["max_new_tokens"] == 12 and model.kw["do_sample"] is True and model.kw["pad_token_id"] == 2
+    assert model.kw["temperature"] == 0.5 and model.kw["top_p"] == 0.9 and "attention_mask" in model.kw
+    assert "Press 'exit' to quit" in capsys.readouterr().out
+    tok = Tok()
+    tok.chat_template = None
+    with pytest.raises(Exception, match="chat_template"):
+        app.chat_generator(model, tok)
 
 
 def test_module_copies_and_pickles_without_its_derived_state():

@@ -3,7 +3,7 @@
 Mirror of the reference's command-line entry (vptq/app_utils.py:17-189, vptq/__main__.py): same
 options, same defaults (100 new tokens for a prompt, 500 sampled tokens per chat turn,
 pad_token_id 2), same public helpers (`define_basic_args`, `eval_prompt`, `chat_loop`,
-`main`; the UI callback generator of app_utils.py:114-163 is out of this path's scope).  The model comes from this package's loader, so every quantised
+`get_chat_loop_generator`, `main`).  The model comes from this package's loader, so every quantised
 linear runs on the HIP kernels; there is no hub access in this build, `--model` is a local directory.
 """
 from __future__ import annotations
@@ -71,6 +71,43 @@ def chat_loop(model, tokenizer, args, read=input):
                              do_sample=True)
         reply = tokenizer.batch_decode(out[:, ids.shape[-1]:], skip_special_tokens=True)[0]
         history.append({"role": "assistant", "content": reply})
+
+
+def chat_generator(model, tokenizer):
+    """The streaming callback a UI drives: `gen(messages, max_tokens, stream=True, temperature=1.0, top_p=1.0)` yields
+    the reply piece by piece while `model.generate` runs on a worker thread (reference app_utils.py:127-163)."""
+    import threading
+    import transformers
+    if getattr(tokenizer, "chat_template", None) is None:
+        raise Exception("warning: this tokenizer didn't provide chat_template.!!!")   # (the reference's error and wording)
+
+    def chat_loop_generator(messages, max_tokens: int, stream: bool = True, temperature: float = 1.0, top_p: float = 1.0):
+        print(BANNER)
+        print("Press 'exit' to quit")
+        streamer = transformers.TextIteratorStreamer(tokenizer, skip_prompt=True, skip_special_tokens=True)
+        enc = tokenizer.apply_chat_template(messages, add_generation_prompt=True, return_tensors="pt", return_dict=True)
+        enc = enc.to(model.device)
+        worker = threading.Thread(target=model.generate, kwargs=dict(
+            enc, streamer=streamer, max_new_tokens=max_tokens, pad_token_id=PAD_TOKEN_ID, do_sample=True,
+            temperature=temperature, top_p=top_p))
+        worker.start()
+        try:
+            for piece in streamer:
+                yield piece
+        finally:
+            worker.join()
+
+    return chat_loop_generator
+
+
+def get_chat_loop_generator(model_id):
+    """Load `model_id` (a local checkpoint directory in this build) in fp16 and return its streaming chat callback
+    (reference app_utils.py:109-165, what vptq/app.py:17 imports for the Gradio UI)."""
+    import transformers
+    from vptq_amd.layers.model_base import AutoModelForCausalLM
+    model = AutoModelForCausalLM.from_pretrained(model_id, device_map="auto", **_hub_kwargs()).half()
+    tokenizer = transformers.AutoTokenizer.from_pretrained(model_id, **_hub_kwargs())
+    return chat_generator(model, tokenizer)
 
 
 def get_valid_args(parser):

@@ -441,6 +441,17 @@ int vptq_quant_gemv_chain(const VptqLayerDesc* descs, int n, const void* const* 
     const hipError_t e = vptq::launch_gemv_k256c(descs + i0, m, x + i0, y + i0, lflags, dependent,
                                                  dependent ? (uint32_t*)workspace + (size_t)i0 * 256
                                                            : (prof_ws ? (uint32_t*)workspace : nullptr), st);
+    if (dependent && e == hipErrorCooperativeLaunchTooLarge) {
+      // the runtime does not confirm that every workgroup of the dependent chain is resident at once (gemv_k256c.hip:launch_c):
+      // one launch per layer, stream order is the dependency - slower, never wrong (layers already walked are walked again)
+      (void)hipGetLastError();
+      const int pflags = lflags & ~VPTQ_GEMV_FORCE_MFMA;
+      for (int i = 0; i < n; ++i) {
+        const int rc = vptq_quant_gemv(&descs[i], x[i], y[i], tokens, pflags, nullptr, 0, stream);
+        if (rc) return rc;
+      }
+      return VPTQ_OK;
+    }
     if (e != hipSuccess) return hip_fail(e, "gemv_k256c launch");
   }
   return VPTQ_OK;
@@ -479,11 +490,15 @@ int vptq_quant_gemv_sliced(const VptqLayerDesc* d, const VptqSlicedLayout* layou
   if (!workspace || workspace_bytes < need || (((uintptr_t)workspace) & 15) != 0)
     return fail(VPTQ_E_WORKSPACE, "workspace of %zu bytes (16-byte aligned) needed", need);
   const int n_layouts = vptq::gemv_sliced_tables(*d);   // (two tables: one layout per table, consecutive structs)
-  for (int i = 0; i < n_layouts; ++i)
+  for (int i = 0; i < n_layouts; ++i) {
     if (layout[i].rows_per_wave < 1 || layout[i].rows_per_wave > 64 || !layout[i].elems || !layout[i].blocks || !layout[i].first ||
         (layout[i].n_slices != 0 ? layout[i].n_slices : 8) != vptq::gemv_sliced_slices(*d))
       return fail(VPTQ_E_UNSUPPORTED, "sliced layout %d: rows_per_wave in [1, 64], three tensors, n_slices = %d for this layer",
                   i, vptq::gemv_sliced_slices(*d));
+    if (layout[i].whole_table != vptq::gemv_sliced_whole_table(*d, i) || layout[i].rows_per_wave != layout[0].rows_per_wave)
+      return fail(VPTQ_E_UNSUPPORTED, "sliced layout %d: whole_table must be %d (vptq_sliced_layout_whole_table) and rows_per_wave the "
+                  "same for both tables", i, vptq::gemv_sliced_whole_table(*d, i));
+  }
   if ((((uintptr_t)x) & 15) != 0) return fail(VPTQ_E_UNSUPPORTED, "x must be 16-byte aligned");
   const hipError_t e = vptq::launch_gemv_sliced(*d, layout, x, y, flags, workspace, (hipStream_t)stream);
   return e == hipSuccess ? VPTQ_OK : hip_fail(e, "gemv_sliced launch");
@@ -539,6 +554,9 @@ int vptq_quant_gemv_sliced_grouped(const VptqLayerDesc* descs, const VptqSlicedL
           (L.n_slices != 0 ? L.n_slices : 8) != vptq::gemv_sliced_slices(descs[i]))
         return fail(VPTQ_E_UNSUPPORTED, "layer %d, sliced layout %d: rows_per_wave in [1, 64], three tensors, n_slices = %d", i, t,
                     vptq::gemv_sliced_slices(descs[i]));
+      if (L.whole_table != vptq::gemv_sliced_whole_table(descs[i], t) || L.rows_per_wave != layouts[0].rows_per_wave)
+        return fail(VPTQ_E_UNSUPPORTED, "layer %d, sliced layout %d: whole_table must be %d and rows_per_wave the group's", i, t,
+                    vptq::gemv_sliced_whole_table(descs[i], t));
     }
   }
   const hipError_t e = vptq::launch_gemv_sliced_group(descs, layouts, n, x, y, flags, workspaces, (hipStream_t)stream);

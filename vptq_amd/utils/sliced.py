@@ -171,7 +171,8 @@ class SlicedGemv:
         # another stream - running the same layer would race on a shared one); zeroed once, every call leaves the
         # counters zero
         self._ws = {}
-        self._ws_tok = {}   # stream -> workspace of the 2 - 4 token kernel
+        self._ws_tok = {}   # stream -> workspace of the 2 - 8 token kernel
+        self._retired = []  # workspaces that were ever handed to a launch stay alive as long as the layer does
         self._fn = B.lib().vptq_quant_gemv_sliced
         self._fn_tok = B.lib().vptq_quant_gemv_sliced_tokens
         self._lay_ref = self.layout   # (an array of 1 or 2 structs: passed as a pointer to the first)
@@ -230,24 +231,30 @@ class SlicedGemv:
         return self._launch_tokens(x, out, flags, tokens)
 
     def _tokens_workspace(self, stream_ptr: int, tokens: int = 4):
-        """the workspace of the token kernel for this stream (sized for 4 tokens - it serves 2 and 3 as well -, for 8 once more
-        than 4 have been asked for), or None inside a capture on a stream the layer has not run on with that many tokens"""
+        """the workspace of the token kernel for this stream, or None inside a capture on a stream the layer has not run on.
+        Sized ONCE for the most tokens the library serves for this layer (8, else 4 - a workspace for T tokens serves fewer)
+        and never replaced or freed afterwards: a hipGraph captured on this stream holds its address (one workspace per
+        stream = per capture; a graph replayed on another stream than the one it was captured on races with eager calls on
+        the first - replay where you captured)."""
         ws = self._ws_tok.get(stream_ptr)
         need = 8 if tokens > 4 else 4
         if ws is None or ws[1] < need:
             if torch.cuda.is_current_stream_capturing():
                 return None
-            nbytes = B.lib().vptq_quant_gemv_sliced_tokens_workspace_bytes(self.desc, need)
+            size, nbytes = 8, B.lib().vptq_quant_gemv_sliced_tokens_workspace_bytes(self.desc, 8)
             if not nbytes:
+                size, nbytes = 4, B.lib().vptq_quant_gemv_sliced_tokens_workspace_bytes(self.desc, 4)
+            if not nbytes or size < need:
                 return None
-            ws = (torch.zeros(nbytes, dtype=torch.uint8, device=self.dev), need)
+            if ws is not None:
+                self._retired.append(ws[0])   # (cannot happen with the sizing above; kept alive if it ever does)
+            ws = (torch.zeros(nbytes, dtype=torch.uint8, device=self.dev), size)
             self._ws_tok[stream_ptr] = ws
         return ws[0]
 
     def _launch_tokens(self, x, out, flags, tokens):
         lay = self.layer
         sp = B.current_stream_ptr(self.dev)
-        key = sp
         ws = self._tokens_workspace(sp, tokens)
         if ws is None:
             return None
@@ -258,8 +265,8 @@ class SlicedGemv:
         if rc == B.E_UNSUPPORTED:
             return None
         if rc:
-            self._ws_tok.pop(key, None)
-            B.check(rc, "vptq_quant_gemv_sliced_tokens")
+            ws.zero_()   # (a launch that did not happen or did not finish may have left arrival counters behind; the buffer
+            B.check(rc, "vptq_quant_gemv_sliced_tokens")   # itself stays: a captured graph may hold its address)
         return out
 
     def _launch(self, x, out, flags):
@@ -274,8 +281,9 @@ class SlicedGemv:
         if rc == B.E_UNSUPPORTED:
             return None
         if rc:
-            # (a launch that did not happen or did not finish may have left arrival counters behind)
-            self._ws.pop(sp, None)
+            # (a launch that did not happen or did not finish may have left accumulator words behind; the buffer itself
+            # stays: a captured graph may hold its address)
+            ws.zero_()
             B.check(rc, "vptq_quant_gemv_sliced")
         return out
 
@@ -291,9 +299,11 @@ class SlicedGroupGemv:
         n = len(self.members)
         m0 = self.members[0]
         tables = len(m0.layout)
+        kind = lambda m: (m.layer.vector_len, m.layer.num_centroids,   # noqa: E731
+                          m.layer.num_res_centroids if m.layer.enable_residual else 0, tuple(m._whole))
         if not 1 <= n <= 3 or any(len(m.layout) != tables or m.slices != m0.slices or m._dtype != m0._dtype or m.dev != m0.dev or
-                                  m.layer.in_features != m0.layer.in_features for m in self.members):
-            raise ValueError("a sliced group takes 1..3 layers of one format, dtype, device and input width")
+                                  m.layer.in_features != m0.layer.in_features or kind(m) != kind(m0) for m in self.members):
+            raise ValueError("a sliced group takes 1..3 layers of one format (vector length, codebook sizes), dtype, device and input width")
         rpw = rows_per_wave_for(sum(m.blocks.shape[1] for m in self.members), m0.slices * tables)   # one round of workgroups over ALL layers
         structs = [B.SlicedLayout(e.data_ptr(), b.data_ptr(), f.data_ptr(), r.data_ptr() if r is not None else None, rpw, 1, m.slices, int(w),
                                   ws.data_ptr())
@@ -360,8 +370,8 @@ class SlicedGroupGemv:
         if rc == B.E_UNSUPPORTED:
             return None
         if rc:
-            for m in self.members:
-                m._ws_tok.pop(sp, None)
+            for w in wss:
+                w.zero_()
             B.check(rc, "vptq_quant_gemv_sliced_tokens_grouped")
         return ys
 
@@ -378,7 +388,7 @@ class SlicedGroupGemv:
         if rc == B.E_UNSUPPORTED:
             return None
         if rc:
-            for m in self.members:
-                m._ws.pop(sp, None)
+            for w in wss:
+                w.zero_()
             B.check(rc, "vptq_quant_gemv_sliced_grouped")
         return ys
