@@ -62,7 +62,7 @@ def alg_bytes(I, O=None, k=256, kr=256, tokens=1):
     return (O // 8) * ((I * T + 31) // 32) * 4 + (k + max(kr, 0)) * 8 * 2 + tokens * 2 * I + 4 * I + tokens * 2 * O
 
 
-def model_decode_extra(timeout_s=240):
+def model_decode_extra(timeout_s=240, arithmetic="reference"):
     """BASELINE configs[2]: the Llama-3-8B shaped decode loop of tools/llama_decode.py (all 32 decoder
     layers, every nn.Linear a 2-bit VQuantLinear through HF Transformers' VPTQ route, sibling projections
     in grouped launches, decode step replayed from a hipGraph) in a process of its own, after the timed
@@ -71,10 +71,10 @@ def model_decode_extra(timeout_s=240):
     import subprocess
     try:
         p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "llama_decode.py"), "--fuse", "--new", "256"],
-                           capture_output=True, text=True, timeout=timeout_s)
+                           capture_output=True, text=True, timeout=timeout_s, env=dict(os.environ, VPTQ_ARITHMETIC=arithmetic))
         line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
         d = json.loads(line)
-        return {"what": d["model"] + ", prompt 128, 256 new tokens, batch 1, one GPU; tools/llama_decode.py --fuse",
+        return {"what": d["model"] + f", prompt 128, 256 new tokens, batch 1, one GPU; tools/llama_decode.py --fuse; arithmetic: {arithmetic}",
                 "tokens_per_s": d["decode_tok_s_hipgraph"], "tokens_per_s_eager": d["decode_tok_s_eager"],
                 "ttft_ms": d["ttft_ms"], "packed_index_GB": d["packed_index_GB"],
                 "weight_GBps": d.get("hipgraph_weight_GBps"),
@@ -819,11 +819,11 @@ def main():
     ap.add_argument("--group", type=int, default=4)
     ap.add_argument("--tp-layers", type=int, default=20,
                     help="tp_row: Llama-3-70B decoder layers in the ring (20 = 4.3 GB of packed indices)")
-    ap.add_argument("--exact", action="store_true",
-                    help="VPTQ_GEMV_EXACT: rebuild every weight with the reference CPU path's three "
-                         "16-bit roundings (bit-identical weights) instead of the default folded "
-                         "fp32 form (both are inside the 1e-3 parity bar, checked below)")
-    ap.add_argument("--fast-math", action="store_true", help="accepted, no effect: the default")
+    ap.add_argument("--folded", "--fast-math", dest="folded", action="store_true",
+                    help="the opt-in folded fp32 form sum (c+r)*f16(s*x) + sum b*x (vptq_amd.set_arithmetic('folded')) "
+                         "instead of the default: every weight rebuilt with the reference CPU path's three 16-bit "
+                         "roundings (VPTQ_GEMV_EXACT, bit-identical weights)")
+    ap.add_argument("--exact", action="store_true", help="accepted, no effect: the default since round 5")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--prefetch", action="store_true")
@@ -858,8 +858,14 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # one process per GPU: LOCAL_RANK is the device (every launch, allocation and the process group's device below)
+    assert torch.cuda.current_device() == local_rank and dev.index == local_rank, (torch.cuda.current_device(), local_rank)
     dist = None
-    if world > 1:
+    # VPTQ_BENCH_FORCE_DIST=1 (test knob, tests/test_bench_dist_gpu.py): initialise the process group at world size 1 too, so
+    # that a one-GPU box runs the N > 1 code path through the REAL backend - RCCL init, the all-reduce inside the step, its
+    # hipGraph capture (or the eager fallback) - before the first multi-GPU run ever happens
+    force_dist = os.environ.get("VPTQ_BENCH_FORCE_DIST") == "1"
+    if world > 1 or force_dist:
         import torch.distributed as dist
         if same_gpu:
             dist.init_process_group("gloo")
@@ -867,19 +873,23 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
     mode = a.mode
     if mode == "auto":
-        mode = "chain" if world == 1 else "tp_row"
+        mode = "chain" if (world == 1 and not force_dist) else "tp_row"
     if mode == "rings":
         mode = "single"
 
     from vptq_amd import _backend as B
     lib = B.lib()
     H = a.hidden
+    a.exact = not a.folded
     flags = B.GEMV_EXACT if a.exact else 0
+    B.set_arithmetic("reference" if a.exact else "folded")   # (module routes inside the extras follow the same mode)
     timer = Timer(dev, dist, allow_eager=mode in ("tp", "tp_row", "tp_pair"))
-    arithmetic = ("reference roundings per weight (VPTQ_GEMV_EXACT), fp32 accumulate" if a.exact else
-                  "folded fp32 (default): sum (c+r)*f16(s*x) + sum b*x - inside the 1e-3 max-normalised "
-                  "parity bar (measured 5-6e-4), not bit-equivalent; see extras.exact for the "
-                  "bit-equivalent form")
+    arithmetic = ("reference roundings per weight (VPTQ_GEMV_EXACT, the product default since round 5): w = f16(f16(f16(c+r)*s)+b) "
+                  "as the reference CPU path rounds it, fp32 accumulate, one rounding of y - bit-identical weights, >= 99 % of "
+                  "the outputs bit-identical" if a.exact else
+                  "folded fp32 (opt-in, --folded / VPTQ_ARITHMETIC=folded): sum (c+r)*f16(s*x) + sum b*x - inside the 1e-3 "
+                  "max-normalised parity bar for dense activations (measured 5-6e-4), not bit-equivalent, above the bar on 3 of 1000 "
+                  "checkpoint-like layers with massive-channel / sparse activations (profiles/r05/gate_count_*)")
 
     if mode in ("tp_row", "tp_pair"):
         r = bench_tp_row(lib, B, dev, timer, rank, world, a.tp_layers, flags, a.steps, a.warmup, a.regions,
@@ -903,6 +913,8 @@ def main():
                          "frac": r["value"] / world / HBM_PEAK_GBPS, "traffic": None,
                          "note": "per GPU: whole-job algorithmic bytes / N / time, collectives included"},
             "tp_row": {k: v for k, v in r.items() if k != "regions_ms_per_step"},
+            "process": {"rank": rank, "local_rank": local_rank, "world": world, "device": torch.cuda.current_device(),
+                        "collective_backend": None if dist is None else dist.get_backend()},
         }
         if world > 1 and not a.no_extras and mode == "tp_row":
             # the Megatron pairing (2 all-reduces per decoder layer instead of 4) on the same layers
@@ -985,7 +997,13 @@ def main():
                                                         "reading": "at the 1400 W cap with the shader clock pulled down = the energy-bound state of DESIGN 4.9; "
                                                                    "well under the cap at a high shader clock = this box's memory system is the limit (boxes of the pool: "
                                                                    "143 us per step at 1400 W / 1.66 GHz on most, 237 us at 1020 W / 2.1 GHz on one)"},
-                     "note": ("one launch = the whole ring (32 layers): bytes_per_launch = 32 x the algorithmic bytes of a "
+                     "note": ("one launch = the whole ring (32 layers): bytes_per_launch = 32 x the algorithmic bytes of a layer (SURVEY 8d), "
+                              "us_per_launch = HIP-event time over the (median) timed region / launches.  Reference roundings: 12 packed-f16 "
+                              "instructions per index rebuild the 8 weights as the reference rounds them (add, multiply by the column's scale, add "
+                              "its bias: three roundings) + 2 MFMA 4x4x4 for the products - the launch is bound by VECTOR ISSUE, not by HBM "
+                              "(DESIGN.md 4.9: the same loop with the folded arithmetic - 4 v_perm + 4 MFMA per index - runs at the package "
+                              "power limit, extras.folded_chain)") if (chain_mode and a.exact) else
+                             ("one launch = the whole ring (32 layers): bytes_per_launch = 32 x the algorithmic bytes of a "
                               "layer (SURVEY 8d), us_per_launch = HIP-event time over the (median) timed region / launches; "
                               "what bounds it: the 1400 W package power limit - this kernel draws the cap and the shader clock "
                               "settles at ~1.65 of 2.4 GHz (`soak` in this object).  Energy roofline (profiles/r04/"
@@ -1004,8 +1022,8 @@ def main():
     # the newest round's PMC summary of this configuration
     rounds = sorted(d for d in os.listdir(os.path.join(ROOT, "profiles")) if d[:1] == "r" and d[1:].isdigit())
     for rd in reversed(rounds):
-        cand = os.path.join(ROOT, "profiles", rd, f"bench_h{H}_{'chain' if chain_mode else mode}_pmc_summary.json")
-        if os.path.exists(cand) and not a.exact and not a.prefetch:
+        cand = os.path.join(ROOT, "profiles", rd, f"bench_h{H}_{'chain' if chain_mode else mode}{'_exact' if a.exact else ''}_pmc_summary.json")
+        if os.path.exists(cand) and not a.prefetch:
             # HBM bytes per launch from a separate rocprofv3 --pmc run of this same command
             # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); see the file's _note
             out["roofline"]["traffic"] = json.load(open(cand)).get("hbm_bytes_corrected")
@@ -1031,25 +1049,40 @@ def main():
                     assert checked[i] <= 1e-3, f"layer {i}: GPU result differs from the CPU oracle: {checked[i]}"
         out["parity_checked_on"] = {"layers_of_the_ring": sorted(checked), "rel_err_vs_cpu_oracle": [checked[i] for i in sorted(checked)],
                                     "bar": 1e-3, "every_layer": "tests/test_chain_gpu.py::test_chain_of_32_distinct_8192_layers_every_output"}
-    if world == 1 and not a.no_extras and mode in ("single", "chain") and not a.exact:
+    if world == 1 and not a.no_extras and mode in ("single", "chain") and a.exact:
         del layers, ys, keeps
         torch.cuda.empty_cache()
         ex = {}
         st, wu, rg = max(10, a.steps // 4), 5, 3
+        EX = B.GEMV_EXACT
 
         def short(res, nbytes=None):
             return {"GBps": res["achieved"], "frac_of_8TBps": res["achieved"] / HBM_PEAK_GBPS,
                     "us_per_launch": res["us_per_launch"], "kernel": res["kernel"]}
-        for key, kw in (("single_launch_per_layer", dict(H=H, mode="single", flags=0)),
-                        ("chain_dependent", dict(H=H, mode="chain_dep", flags=0)),
-                        ("h4096_chain", dict(H=4096, mode="chain", flags=0)),
-                        ("h4096", dict(H=4096, mode="single", flags=0)),
-                        ("exact", dict(H=H, mode="single", flags=B.GEMV_EXACT)),
-                        ("exact_chain", dict(H=H, mode="chain", flags=B.GEMV_EXACT)),
-                        ("grouped_x4", dict(H=H, mode="grouped", flags=0)),
-                        ("tokens16", dict(H=H, mode="single", flags=0, tokens=16)),
-                        ("tokens16_bf16", dict(H=H, mode="single", flags=0, tokens=16, dtype=torch.bfloat16)),
-                        ("k8192_r256", dict(H=H, mode="single", flags=0, k=8192, kr=256))):
+        # (name, arguments, what) - the product default (reference roundings) first, the opt-in folded form of the same
+        # workloads as folded_*
+        table = (
+            ("single_launch_per_layer", dict(H=H, mode="single", flags=EX),
+             "the same ring, one vptq_quant_gemv launch per layer - what VQuantLinear.forward issues (the reference's operator granularity)"),
+            ("h4096_chain", dict(H=4096, mode="chain", flags=EX), "VQuantLinear 4096x4096 (BASELINE configs[0]/[1] shape), ring of 128 layers as 4 chain launches"),
+            ("h4096", dict(H=4096, mode="single", flags=EX), "VQuantLinear 4096x4096 (BASELINE configs[0]/[1] shape), single launch per layer"),
+            ("grouped_x4", dict(H=H, mode="grouped", flags=EX), "4 independent layers per launch (vptq_quant_gemv_grouped), us per LAYER = us_per_launch / 4"),
+            ("folded_chain", dict(H=H, mode="chain", flags=0),
+             "OPT-IN folded arithmetic (vptq_amd.set_arithmetic('folded')), the headline workload: 32 layers per persistent launch (the headline of rounds 3-4)"),
+            ("folded_single_launch_per_layer", dict(H=H, mode="single", flags=0), "opt-in folded arithmetic, one launch per layer"),
+            ("folded_h4096", dict(H=4096, mode="single", flags=0), "opt-in folded arithmetic, 4096x4096, one launch per layer"),
+            ("folded_h4096_chain", dict(H=4096, mode="chain", flags=0), "opt-in folded arithmetic, 4096x4096, chains of 32"),
+            ("chain_dependent", dict(H=H, mode="chain_dep", flags=0),
+             "the same ring as ONE dependent chain (x of layer i + 1 = y of layer i; folded arithmetic only): device-scope hand-over per layer "
+             "inside the launch; us_per_launch is the whole chain"),
+            ("tokens16", dict(H=H, mode="single", flags=EX, tokens=16), "16 tokens per launch (batched decode, reference roundings), bytes incl. 16 x and y rows"),
+            ("folded_tokens16", dict(H=H, mode="single", flags=0, tokens=16), "16 tokens in ONE pass over the indices (gemm_k256t, folded arithmetic only)"),
+            ("folded_tokens16_bf16", dict(H=H, mode="single", flags=0, tokens=16, dtype=torch.bfloat16),
+             "16 bf16 tokens in one pass over the indices (gemm_k256t: transposing gathers -> 16x16x32 MFMA, tokens = M; + its pre-pass)"),
+            ("k8192_r256", dict(H=H, mode="single", flags=EX, k=8192, kr=256), "k = 8192 + 256 (T = 21 bits), LDS-resident codebooks, reference roundings"),
+            ("folded_k8192_r256", dict(H=H, mode="single", flags=0, k=8192, kr=256), "k = 8192 + 256, opt-in folded arithmetic (MFMA accumulate)"),
+        )
+        for key, kw, what in table:
             kw = dict(kw)
             try:   # (the headline line must not depend on an extra)
                 rr, *_ = bench_ring(lib, B, dev, Timer(dev), kw.pop("H"), kw.pop("mode"), kw.pop("flags"), st, wu, rg, **kw)
@@ -1057,23 +1090,8 @@ def main():
                 ex[key]["us_per_layer"] = rr["us_per_layer"]
             except Exception as e:
                 ex[key] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            ex[key]["what"] = what
             torch.cuda.empty_cache()
-        for k_ in list(ex):
-            ex[k_].setdefault("what", "")
-        ex["single_launch_per_layer"]["what"] = ("the same ring, one vptq_quant_gemv launch per layer (the reference's operator "
-                                                  "granularity; the round-1 / round-2 headline)")
-        ex["chain_dependent"]["what"] = ("the same ring as ONE dependent chain (x of layer i + 1 = y of layer i): device-scope "
-                                         "hand-over per layer inside the launch; us_per_launch is the whole chain")
-        ex["h4096_chain"]["what"] = "VQuantLinear 4096x4096 (BASELINE configs[0]/[1] shape), ring of 128 layers as 4 chain launches"
-        ex["h4096"]["what"] = "VQuantLinear 4096x4096 (BASELINE configs[0]/[1] shape), single launch per layer"
-        ex["exact"]["what"] = "VPTQ_GEMV_EXACT: the reference's three roundings per weight (bit-equivalent form), one launch per layer"
-        ex["exact_chain"]["what"] = ("VPTQ_GEMV_EXACT inside the chain launch (round 4): the same ring, 32 layers per persistent launch, "
-                                     "every weight rebuilt with the reference's three roundings; us_per_launch is the whole ring")
-        ex["grouped_x4"]["what"] = "4 independent layers per launch (vptq_quant_gemv_grouped), us per LAYER = us_per_launch / 4"
-        ex["tokens16"]["what"] = "16 tokens per launch (batched-decode kernel), bytes incl. 16 x and y rows"
-        ex["tokens16_bf16"]["what"] = ("16 bf16 tokens in one pass over the indices (gemm_k256t: transposing gathers -> 16x16x32 MFMA, "
-                                       "tokens = M; + its pre-pass); round 2: 4 launches of 4 tokens, 39 us")
-        ex["k8192_r256"]["what"] = "k = 8192 + 256 (T = 21 bits), LDS-resident codebooks"
         for key, kw in (("k65536_r256", {}), ("k65536_r65536", dict(kr=65536)),     # ... the "4 bits" format of every published family
                         ("v16_k65536_r65536", dict(kr=65536, v=16))):              # "2 bits" of most families
             try:   # (the headline line must not depend on an extra)
@@ -1082,7 +1100,7 @@ def main():
                 ex[key] = {"error": f"{type(e).__name__}: {e}"[:300]}
                 torch.cuda.empty_cache()
         try:
-            tr = bench_tp_row(lib, B, dev, Timer(dev), 0, 1, a.tp_layers, 0, st, wu, rg)
+            tr = bench_tp_row(lib, B, dev, Timer(dev), 0, 1, a.tp_layers, EX, st, wu, rg)
             ex["tp_row_n1"] = {"what": f"Llama-3-70B shaped decoder layers (x{a.tp_layers}, the ring of --gpus N) on ONE GPU "
                                        "through the row-parallel code path (world size 1): the strong-scaling baseline of --gpus N",
                                "GBps": tr["value"], "us_per_decoder_layer": tr["us_per_decoder_layer"],
@@ -1094,28 +1112,37 @@ def main():
             ex["prefill"] = prefill_extra(dev)
         except Exception as e:   # the headline line must not depend on it
             ex["prefill"] = {"error": f"{type(e).__name__}: {e}"[:300]}
-        try:
-            ex["llama3_8b_decode"] = model_decode_extra()
-        except Exception as e:
-            ex["llama3_8b_decode"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        for key, mode_ in (("llama3_8b_decode", "reference"), ("folded_llama3_8b_decode", "folded")):
+            try:
+                ex[key] = model_decode_extra(arithmetic=mode_)
+            except Exception as e:
+                ex[key] = {"error": f"{type(e).__name__}: {e}"[:300]}
         out["extras"] = ex
         # what the drop-in module delivers (VQuantLinear.forward -> ops.quant_gemm -> ONE vptq_quant_gemv launch per layer, the
         # reference's operator granularity, vptq/ops/quant_gemm.py:213-228), beside the throughput-mode headline: the driver
         # keeps the `roofline` object whole, `extras` only in part
         mp = {}
-        for key, name in (("single_launch_per_layer", f"h{H}"), ("h4096", "h4096"), ("exact", f"h{H}_reference_roundings")):
+        for key, name in (("single_launch_per_layer", f"h{H}"), ("h4096", "h4096"), ("folded_single_launch_per_layer", f"h{H}_folded_opt_in"),
+                          ("folded_h4096", "h4096_folded_opt_in")):
             e = ex.get(key) or {}
             if "us_per_launch" in e:
                 mp[name] = {"us_per_layer": e["us_per_launch"], "GBps": e["GBps"], "frac": e["frac_of_8TBps"], "kernel": e["kernel"]}
         for key in ("k65536_r256", "k65536_r65536", "v16_k65536_r65536"):
             e = ex.get(key) or {}
             sl = e.get("sliced_layout") or {}
-            if "us_per_layer" in sl:
-                mp[key] = {"us_per_layer": sl["us_per_layer"], "GBps_of_packed_bytes": sl.get("GBps"), "frac": sl.get("frac_of_8TBps"),
-                           "kernel": sl.get("kernel", "gemv_sliced_kernel")}
+            df = e.get("default") or {}
+            if "us_per_layer" in df:     # the product default for the large-codebook formats: centroid gathers through the caches
+                mp[key] = {"us_per_layer": df["us_per_layer"], "GBps_of_packed_bytes": df.get("GBps"), "frac": df.get("frac_of_8TBps"),
+                           "kernel": df.get("kernel")}
+            if "us_per_layer" in sl:     # ... and the opt-in folded arithmetic over the load-time derived sliced layouts
+                mp[key + "_folded_opt_in"] = {"us_per_layer": sl["us_per_layer"], "GBps_of_packed_bytes": sl.get("GBps"),
+                                              "frac": sl.get("frac_of_8TBps"), "kernel": sl.get("kernel", "gemv_sliced_kernel")}
         dec = ex.get("llama3_8b_decode") or {}
         if "vqlinear_us_per_token" in dec:
             mp["llama3_8b_decode_step"] = {k_: dec.get(k_) for k_ in ("tokens_per_s", "vqlinear_us_per_token", "vqlinear_GBps")}
+        dec = ex.get("folded_llama3_8b_decode") or {}
+        if "vqlinear_us_per_token" in dec:
+            mp["llama3_8b_decode_step_folded_opt_in"] = {k_: dec.get(k_) for k_ in ("tokens_per_s", "vqlinear_us_per_token", "vqlinear_GBps")}
         out["roofline"]["module_path"] = mp
     if rank == 0:
         emit(out)

@@ -34,3 +34,15 @@ def _seeded():
     import torch
     torch.manual_seed(20260924)
     yield
+
+
+@pytest.fixture
+def folded_arithmetic():
+    """The opt-in fast arithmetic for the duration of a test (`vptq_amd.set_arithmetic("folded")`): tests of the routes that
+    exist in that mode only - the sliced layouts of the large-codebook formats, the one-pass batched-decode kernel, the
+    folded forms of the canonical kernels through the MODULE.  The product default is the reference's roundings."""
+    import vptq_amd
+    before = vptq_amd.arithmetic()
+    vptq_amd.set_arithmetic("folded")
+    yield
+    vptq_amd.set_arithmetic(before)

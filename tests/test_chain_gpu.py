@@ -95,9 +95,11 @@ def test_chain_float32_outputs(dev):
 
 
 @pytest.mark.parametrize("dt", ["f16", "bf16"])
-def test_dependent_chain(dt, dev):
+def test_dependent_chain(dt, dev, folded_arithmetic):
     """x of layer i + 1 is y of layer i: every layer against the oracle applied to the GPU's own
-    previous output (so the per-layer bar applies), and against the same layers launched one by one."""
+    previous output (so the per-layer bar applies), and against the same layers launched one by one.  (The persistent
+    dependent walk exists for the opt-in folded arithmetic only; with the default arithmetic a dependent chain is one launch
+    per layer: test_dependent_chain_reference_arithmetic.)"""
     from vptq_amd.ops.chain import GemvChain
     dims = [1024, 2048, 512, 4096, 264, 1032, 1024]
     shapes = [(dims[i], dims[i + 1], dict(dist="llm", bias=(i % 3 == 1))) for i in range(len(dims) - 1)]
@@ -123,8 +125,28 @@ def test_dependent_chain(dt, dev):
         xi = y1
 
 
+def test_dependent_chain_reference_arithmetic(dev):
+    """the product default: a dependent chain of layers in the reference's roundings = one launch per layer in stream
+    order, the same bits as the modules called one after the other"""
+    from vptq_amd.ops.chain import GemvChain
+    dims = [1024, 2048, 512, 1024]
+    shapes = [(dims[i], dims[i + 1], dict(dist="llm", bias=(i == 1))) for i in range(len(dims) - 1)]
+    Ls, ms, _ = _build(shapes, "f16", dev)
+    x0 = _x(dims[0], "f16", "llm", 5)
+    xt = bits_to_tensor(x0, "f16", dev).reshape(x0.shape)
+    chain = GemvChain(ms, dependent=True)
+    assert chain.kernel_name(1) != "gemv_k256c_kernel"
+    ys = chain([xt])
+    xi, xin = xt, x0
+    for L, m, y in zip(Ls, ms, ys):
+        assert torch.equal(m(xi).view(torch.int16), y.view(torch.int16))
+        assert rel_err(tensor_to_bits(y), vo.forward(L, xin), "f16") <= TOL["f16"]
+        xi, xin = y, tensor_to_bits(y).reshape(1, 1, -1)
+
+
+@pytest.mark.parametrize("arith", ["reference", "folded"])
 @pytest.mark.parametrize("name", big_names())
-def test_chain_on_reference_goldens_at_baseline_sizes(name, dev):
+def test_chain_on_reference_goldens_at_baseline_sizes(name, arith, dev, request):
     """hidden 4096 / 8192 layers whose y comes from the real reference (tests/golden/gen_golden_big.py):
     one-token, permutation-free cases through the chain launch, alone and 6 times in a row."""
     from vptq_amd.ops.chain import GemvChain
@@ -132,10 +154,13 @@ def test_chain_on_reference_goldens_at_baseline_sizes(name, dev):
     if cfg["tokens"] != 1 or cfg["perm"]:
         pytest.skip("the chain kernel takes one token, no permutation")
     dt = cfg["dtype"]
+    if arith == "folded":
+        request.getfixturevalue("folded_arithmetic")
     m = spec_to_module(L, dev)
     xt = bits_to_tensor(x, dt, dev).reshape(x.shape)
     chain = GemvChain([m] * 6)
-    assert chain.kernel_name(1, CHAIN) == "gemv_k256c_kernel"
+    # (the reference's roundings run inside the chain launch for fp16; bf16 layers go out one launch per layer)
+    assert (chain.kernel_name(1, CHAIN) == "gemv_k256c_kernel") == (arith == "folded" or dt == "f16")
     ys = chain([xt] * 6, flags=CHAIN)
     torch.cuda.synchronize()
     err = rel_err(tensor_to_bits(ys[0]), y, dt)

@@ -140,7 +140,7 @@ def test_sliced_layout_in_a_hipgraph(dev):
         assert rel_err(tensor_to_bits(ys), vo.forward(L, v), "f16") <= 1e-3
 
 
-def test_module_forward_takes_the_sliced_layout_when_enabled(dev):
+def test_module_forward_takes_the_sliced_layout_when_enabled(dev, folded_arithmetic):
     """VQuantLinear.enable_sliced_layout() - the default (VPTQ_SLICED_LAYOUT=auto) while the layout leaves a quarter
     of the device memory free: one-token calls go through the derived layout, everything else (several tokens,
     dequant) through the state-dict tensors as before; an in-place change of the indices rebuilds it"""
@@ -183,7 +183,7 @@ def test_module_forward_takes_the_sliced_layout_when_enabled(dev):
     assert m._sliced_gemv() is None
 
 
-def test_sliced_route_falls_back_instead_of_failing(dev):
+def test_sliced_route_falls_back_instead_of_failing(dev, folded_arithmetic):
     """the sliced one-token route is on by default and sits in front of the regular routing, so whatever it
     cannot take must fall through to it: an activation that is not 16-byte aligned, a capture on a stream the layer
     has never run on (its workspace is per stream and is not allocated inside a capture), a first call inside a
@@ -334,7 +334,7 @@ def test_sliced_layout_family_on_reference_goldens(name, dev):
     assert rel_err(tensor_to_bits(m(xt)), y, dt) <= TOL[dt], name      # the module's own one-token route (auto: sliced)
 
 
-def test_two_and_three_tokens_as_sliced_launches_per_token(dev, monkeypatch):
+def test_two_and_three_tokens_as_sliced_launches_per_token(dev, monkeypatch, folded_arithmetic):
     """2 tokens of a LARGE large-codebook layer (the 4-bit format: 3) are served as one sliced launch per token
     (VQuantLinear._sliced_token_limit: the gather kernels cost as much for one token as for four, the sliced kernel a
     third to a half of that per token); smaller layers and more tokens keep the gather kernels"""
@@ -375,7 +375,7 @@ def test_two_and_three_tokens_as_sliced_launches_per_token(dev, monkeypatch):
 
 
 @pytest.mark.parametrize("v,kr", [(8, 256), (8, 0), (8, 65536), (16, 65536), (16, 1024)])
-def test_sibling_layers_share_one_sliced_launch(v, kr, dev):
+def test_sibling_layers_share_one_sliced_launch(v, kr, dev, folded_arithmetic):
     """q / k / v (gate / up) of a large-codebook model read the same activation: one launch of the sliced kernel for the
     group (`vptq_quant_gemv_sliced_grouped` via `SiblingGroup.forward_sliced`), bit-identical to the layers' own launches
     (a row's sums are formed by one wave in the same order whatever the rows per wave; the cross-slice sum is a fixed tree)"""
@@ -511,7 +511,7 @@ def test_sliced_tokens_rejections(dev):
     assert sl(x[:, :1].contiguous()) is not None
 
 
-def test_module_route_for_two_to_four_tokens_in_one_launch(dev, monkeypatch):
+def test_module_route_for_two_to_four_tokens_in_one_launch(dev, monkeypatch, folded_arithmetic):
     """the module's forward: 2 - 4 tokens of a large-codebook layer = ONE launch over the layouts (VQuantLinear._sliced_one_launch:
     where that was measured faster - not v = 16 with a small residual table, not tiny layers); switched off: the other routes"""
     import vptq_amd.layers.vqlinear as vq
@@ -562,7 +562,7 @@ def test_module_route_for_two_to_four_tokens_in_one_launch(dev, monkeypatch):
 
 @pytest.mark.parametrize("tokens", [2, 3, 4])
 @pytest.mark.parametrize("v,kr,dt", [(8, 256, "f16"), (8, 0, "bf16"), (8, 65536, "f16"), (16, 65536, "f16"), (16, 0, "bf16")])
-def test_sibling_layers_share_one_launch_for_two_to_four_tokens(v, kr, dt, tokens, dev, monkeypatch):
+def test_sibling_layers_share_one_launch_for_two_to_four_tokens(v, kr, dt, tokens, dev, monkeypatch, folded_arithmetic):
     """q / k / v of a large-codebook model, 2 - 4 tokens: ONE launch of the token kernel for the group
     (`vptq_quant_gemv_sliced_tokens_grouped` via `SiblingGroup.forward_sliced`): bit-identical to the layers' own launches where the
     rows per wave do not change the order of a row's sums (they do not: a row is summed by one wave, phase by phase), one

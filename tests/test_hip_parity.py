@@ -23,10 +23,12 @@ FAST, GENERIC, EXACT, MFMA, VALU = 1, 2, 4, 8, 16
 
 
 def module_flags():
-    """the flags the module forward passes to the library (VPTQ_EXACT=1 in the environment
-    switches the whole process to the reference's roundings)"""
+    """the flags the module forward passes to the library for a layer with norm tensors: the reference's roundings
+    (VPTQ_GEMV_EXACT) unless the folded arithmetic is opted in (vptq_amd.set_arithmetic("folded"); the `folded_arithmetic`
+    fixture) - and then still for the layers its measured gate turns down; VPTQ_EXACT=1 in the environment forces them"""
+    import vptq_amd
     from vptq_amd import ops
-    return ops.quant_gemm_flags()
+    return ops.quant_gemm_flags() | (EXACT if vptq_amd.arithmetic() == "reference" else 0)
 
 
 def expect_kernel(m, tokens, flags, name):
@@ -1522,10 +1524,29 @@ ADVERSARIAL = [("plain", "normal"), ("plain", "large_mean"), ("llm", "normal"), 
 
 @pytest.mark.parametrize("family,xkind", ADVERSARIAL)
 @pytest.mark.parametrize("O", [512, 4608])   # the VALU kernel / the persistent MFMA kernel (144 row groups)
-def test_adversarial_families_default_route(family, xkind, O, dev):
-    """The module's default route must stay inside the 1e-3 bar on inputs built against the folded form:
-    bias-dominated layers are recognised at load time (VQuantLinear._folded_form_is_safe) and served in the
-    reference's arithmetic; everything else takes the folded form and must pass as it is."""
+def test_adversarial_families_reference_default(family, xkind, O, dev):
+    """The product default (the reference's roundings for every layer) on inputs built against the folded form:
+    inside the bar by a wide margin, module forward = the C ABI with VPTQ_GEMV_EXACT bit for bit."""
+    import vptq_amd
+    assert vptq_amd.arithmetic() == "reference"
+    L = _adversarial_layer(4096, O, family, seed=77 + O)
+    x = _adversarial_x(L, xkind, seed=5)
+    want = vo.forward(L, x)
+    m = spec_to_module(L, dev)
+    xt = bits_to_tensor(x, "f16", dev).reshape(x.shape)
+    assert m._descriptor()[9] == EXACT
+    y = m(xt)
+    assert torch.equal(y.view(torch.int16), gemv_abi(m, xt, EXACT).view(torch.int16))
+    assert rel_err(tensor_to_bits(y), want, "f16") <= 1e-3      # (at most the flip of one last bit: 2^-10 of max|y|)
+    assert bit_identical_frac(tensor_to_bits(y), want) >= 0.95
+
+
+@pytest.mark.parametrize("family,xkind", ADVERSARIAL)
+@pytest.mark.parametrize("O", [512, 4608])   # the VALU kernel / the persistent MFMA kernel (144 row groups)
+def test_adversarial_families_default_route(family, xkind, O, dev, folded_arithmetic):
+    """The OPT-IN folded arithmetic through the module must stay inside the 1e-3 bar on inputs built against it:
+    bias-dominated layers are recognised at load time (VQuantLinear._folded_form_is_safe: both forms on probe
+    activations) and served in the reference's arithmetic; everything else takes the folded form and must pass as it is."""
     from vptq_amd.ops.chain import GemvChain
     I = 4096
     L = _adversarial_layer(I, O, family, seed=77 + O)

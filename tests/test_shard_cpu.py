@@ -115,3 +115,52 @@ def test_tp_exchange_world2_gloo():
         assert p.exitcode == 0
     for rank, col_exact, row_err in res:
         assert col_exact and row_err <= 1e-3
+
+
+def _worker_rpf(rank, world, port, q):
+    """`row_parallel_forward` ITSELF on this rank's shard (the function bench.py's multi-GPU step is built from), with a
+    CPU stand-in for the one GPU call inside it (`forward_partial_f32`: the fused GEMV with float32 output)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import vptq_amd.utils.shard as shard_mod
+
+    def partial_f32_on_cpu(layer, x):     # what the kernel computes: fp32 sums of this shard's columns (+ bias on rank 0)
+        Ls = module_to_spec(layer)
+        W = vo.to_f32(vo.dequant(Ls), "f16").astype(np.float64)
+        xb = x.contiguous().view(torch.int16).numpy().view(np.uint16)
+        part = vo.to_f32(xb, "f16").astype(np.float64) @ W.T
+        if Ls.bias is not None:
+            part = part + vo.to_f32(Ls.bias, "f16")
+        return torch.from_numpy(part.astype(np.float32))
+
+    shard_mod.forward_partial_f32 = partial_f32_on_cpu
+    L = _layer()
+    m = spec_to_module(L, "cpu")
+    xb = vo.from_f32(np.random.default_rng(3).standard_normal((1, 2, 512)).astype(np.float32), "f16")
+    x = torch.from_numpy(xb.view(np.int16).copy()).view(torch.float16)
+    si = shard_in_features(m, rank, world)
+    assert (si.bias is not None) == (rank == 0 and m.bias is not None)     # the output bias rides on rank 0 only
+    y = shard_mod.row_parallel_forward(si, x)                               # slice x, partial sums, all-reduce, ONE rounding
+    want = vo.forward(L, xb)
+    got = y.contiguous().view(torch.int16).numpy().view(np.uint16)
+    ident = float((got.reshape(-1) == np.asarray(want).reshape(-1)).mean())
+    err = float(np.abs(vo.to_f32(got, "f16") - vo.to_f32(want, "f16")).max() / np.abs(vo.to_f32(want, "f16")).max())
+    q.put((rank, y.dtype == torch.float16 and tuple(y.shape) == (1, 2, m.out_features), ident, err))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_row_parallel_forward_world_gloo(world):
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker_rpf, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, shape_ok, ident, err in res:
+        # every rank holds the SAME reduced result; fp32 partial sums + one rounding = the reference's F.linear model
+        assert shape_ok and ident >= 0.98 and err <= 1e-3, (rank, ident, err)

@@ -16,6 +16,7 @@ ap.add_argument("--k", type=int, default=65536)
 ap.add_argument("--v", type=int, default=8)
 ap.add_argument("--ring", type=int, default=6)
 ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--raw", default="", help="save the last run's stamps [workgroups, 16 waves, 4] (us from the first entry) as .npy")
 a = ap.parse_args()
 dev = torch.device("cuda", 0); g = torch.Generator(device=dev).manual_seed(0)
 I, O = (int(v) for v in a.shape.split(","))
@@ -42,6 +43,9 @@ for rep in range(a.reps):
     q = lambda t: [round(float(v), 2) for v in (t.min(), t.median(), t.max())]
     res.append(dict(workgroups=int(live.sum()), entry=q(us[:, :, 0]), prologue_done=q(us[:, :, 1]), stream_done=q(us[:, :, 2]),
                     exit=q(us[:, :, 3]), stream_len=q(us[:, :, 2] - us[:, :, 1]), tail=q(us[:, :, 3] - us[:, :, 2])))
+    if a.raw and rep == a.reps - 1:
+        import numpy as np
+        np.save(a.raw, us.numpy())
     words[N * a.v:].zero_()
 print(json.dumps(dict(shape=[I, O], v=a.v, k=a.k, kr=a.kr, lib=os.environ.get("VPTQ_HIP_LIB", "default"),
                       note="min / median / max over waves, us from the first wave's entry", runs=res), indent=1))

@@ -224,7 +224,7 @@ def _derived(owner: torch.Tensor, name: str, key, build):
     return hit[1]
 
 
-# ---- load-time gate of the default ("folded") decode arithmetic ---------------------------------------------------
+# ---- load-time gate of the opt-in "folded" decode arithmetic -------------------------------------------------------
 # The folded form  y = sum (c + r) * f16(s x) + sum b x  is as close to exact arithmetic as the reference CPU path
 # is: the reference rounds every weight three times (vptq/ops/quant_gemm.py:121,155-156), which puts ITS un-rounded
 # sums 2-7e-4 of max|y| away from exact math.  What the parity bar (1e-3 of max|y|) has room for:
@@ -244,6 +244,41 @@ def _derived(owner: torch.Tensor, name: str, key, build):
 # outputs (the reference test's cyclic index pattern: max|y| is a maximum over 8 values, not thousands) land far
 # above the line; random layers of the LLM-like and the reference-test distributions at 2-7e-4 (tools/gate_probe_study.py,
 # profiles/r05/gate_probe_study_*.txt).  One device -> host read per descriptor build, i.e. per layer load.
+# ---- which arithmetic the decode GEMV evaluates by default ----------------------------------------------------------
+# "reference" (the default since round 5): every weight is rebuilt with the reference CPU path's three 16-bit roundings
+# (VPTQ_GEMV_EXACT: w = f16(f16(f16(c + r) * s) + b), vptq/ops/quant_gemm.py:121,155-156; un-rounded sums ~1e-6 of max|y|
+# from the reference's, >= 99 % of the outputs bit-identical, the rest one flip of the last bit) - the form SURVEY 7.2(5)
+# specified as the default and the only one that stays inside the 1e-3 bar for EVERY activation.
+# "folded" (opt-in: VPTQ_ARITHMETIC=folded, set_arithmetic("folded")): y = sum (c + r) f16(s x) + sum b x in fp32 - 25-35 %
+# faster on the canonical format and the only arithmetic of the sliced layouts of the large-codebook formats.  It is as
+# close to exact math as the reference is, but it does not repeat the reference's rounding errors: with dense
+# activations those average out over the columns (0 of 12 288 layers above the bar, profiles/r04/fuzz_count_*), with
+# activations dominated by a few channels - massive-activation channels, 90 % sparse inputs - they do not: 3 of 1000
+# checkpoint-like fp16 layers at 1.05 - 1.26e-3 and 1 of 500 bf16 layers at 9.8e-3 against bars of 1e-3 / 8e-3
+# (tools/gpu_gate_count.py, profiles/r05/gate_count_*_folded_default.txt).  No load-time gate can see that coming - it
+# depends on the activation - so the bar-safe form is the default and the fast one is the user's decision.
+_ARITH = {"folded": os.environ.get("VPTQ_ARITHMETIC", "reference").strip().lower() in ("folded", "fast") or
+          os.environ.get("VPTQ_FOLDED", "0") == "1", "generation": 0}
+
+
+def set_arithmetic(mode: str) -> None:
+    """"reference" (default) or "folded"; layers rebuild their descriptors (and drop or build their sliced layouts) at their
+    next call.  Not inside a stream capture."""
+    mode = mode.strip().lower()
+    if mode not in ("reference", "exact", "folded", "fast"):
+        raise ValueError("arithmetic is 'reference' or 'folded'")
+    _ARITH["folded"] = mode in ("folded", "fast")
+    _ARITH["generation"] += 1
+
+
+def arithmetic() -> str:
+    return "folded" if _ARITH["folded"] else "reference"
+
+
+def arithmetic_generation() -> int:
+    return _ARITH["generation"]
+
+
 FOLDED_MAX_PROBE_DISTANCE = {torch.float16: 7.5e-4, torch.bfloat16: 6.0e-3}   # (bf16: 8 mantissa bits fewer... 3: x 8)
 FOLDED_MIN_DISTINCT_ROWS = 32   # (kept as a cheap pre-filter: tiny layers and repeating index rows never take the folded form)
 _ROW_SAMPLE = 64
@@ -306,6 +341,8 @@ def folded_form_is_safe(indices, centroids, res_centroids, weight_scale, weight_
     With `desc` (the layer's descriptor): the measured gate; without: only the pre-filter."""
     if weight_scale is None or weight_bias is None or not weight_scale.is_cuda:
         return True
+    if not _ARITH["folded"]:
+        return False   # the default: the reference's roundings for every layer
     with torch.no_grad():
         if indices is not None and indices.dim() == 3:
             if indices.shape[1] < FOLDED_MIN_DISTINCT_ROWS or distinct_index_rows(indices) < FOLDED_MIN_DISTINCT_ROWS:

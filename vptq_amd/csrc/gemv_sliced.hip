@@ -61,6 +61,11 @@ constexpr int kSLMaxGroup = 3;
 #ifndef VPTQ_SLICED_TRACE
 #define VPTQ_SLICED_TRACE 0
 #endif
+// A/B: issue priority by wave age (the phase stamps show the 4 waves of a SIMD finishing 1.3 us apart, oldest first):
+// 1 = the youngest wave of a SIMD gets the highest priority, 2 = the oldest
+#ifndef VPTQ_SLICED_PRIO
+#define VPTQ_SLICED_PRIO 0
+#endif
 // accumulator word of one output: bits [0, 7) arrivals, [7, 14) arrivals whose partial sum was NaN, [14, 64) the sum in
 // units of 2^-24 (50 bits signed: +-3.3e7; a partial sum beyond that - or an infinite one - saturates, which still rounds to
 // the 16-bit formats' infinity)
@@ -132,20 +137,16 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
   unsigned long long* const trace = (unsigned long long*)as_global(P.partial) + (size_t)N * V + ((size_t)blockIdx.x * kSLWaves + wave) * 4;
   if (lane == 0) trace[0] = __builtin_amdgcn_s_memrealtime();
 #endif
-  // ---- this wave's stream: the blocks of its rows are contiguous in `elems`
-  int my_blocks = 0, total = 0, first_block = 0;
-  if (n_rows > 0) {
-    const int32_t* const bp = as_global(blocks_t) + (size_t)s * N + row0;
-    my_blocks = lane < n_rows ? bp[lane] : 0;           // lane i: blocks of row row0 + i
-    first_block = __builtin_amdgcn_readfirstlane(as_global(first_t)[(size_t)s * N + row0]);
-    int t = my_blocks;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
-    total = __builtin_amdgcn_readfirstlane(t);
-  }
-
-  // ---- this workgroup's part of its table into LDS by LDS-DMA: 1 KiB per instruction and wave (no registers; older
-  // than every load below, so the counted wait before the barrier covers it); the last piece of a small table is partial
+  // ---- prologue, ordered by what has to be in flight first (round 5; phase stamps of the round-4 order - profiles/r05/
+  // sliced_trace_*.txt: the barrier fell at 3.1 us of a 12.6 us launch, the first element words arrived after it: every wave
+  // first WAITED ~1 us for its two index words from cold memory, then issued the table copy, waited for it before it staged
+  // the activations and only then asked for elements).  vmcnt returns in order, so a wait for a load also waits for everything
+  // issued before it: (1) the table copy (LDS-DMA: needs kernel arguments only) goes out first; (2) the staging loads and the
+  // rows' block counts follow, nobody waits for them yet; (3) where the wave's stream starts and how long it is come through
+  // the SCALAR cache (lgkmcnt, not vmcnt: waiting for them waits for nothing else); (4) the element queue is requested;
+  // (5) only then the staging arithmetic, whose wait is "all but the element words" and covers the table copy.
+  // (1) this workgroup's part of its table into LDS by LDS-DMA: 1 KiB per instruction and wave (no registers); the last
+  // piece of a small table is partial
   {
     const uint32_t tab = second ? P.tab1 : P.tab0;   // (scalar fields: a run-time index into the by-value argument makes the compiler copy it to scratch)
     const uint64_t va = (uint64_t)(uintptr_t)as_global(cent_t) + (uint64_t)s * (second ? P.stride1 : P.stride0) + (uint64_t)lane * 16u;
@@ -170,47 +171,86 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
                    : "=&s"(keep_m0) : "v"(v), "s"(d) : "memory");
     }
   }
-  // ---- activations: f16(scale * x) of every column, zero for the padding column G; the workgroups of slice 0
-  // also form sum b x (it rides in their partial sums: the second kernel then reads nothing but partial sums)
-  const uint32_t bd_off = kSLXOff + (uint32_t)(G + 64) * 2u;   // 16 floats behind the staged activations
-  {
-    typedef __attribute__((address_space(3))) u32x4 lds_q_t;
-    const int chunks = G >> 3;
-    float bd = 0.f;
-    for (int q = tid; q < chunks + 8; q += kSLThreads) {
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (q < chunks && !(VPTQ_SLICED_ABLATE & 4)) {
-        // x in input-FEATURE order (sum b x needs nothing else: a permutation only reorders the sum)
-        const u32x4 xv = *(const u32x4*)(as_global(P.x) + 8 * q);
-        if (sg == 0 && P.wbias != nullptr) {
-          const u32x4 bv = *(const u32x4*)(as_global(P.wbias) + 8 * q);
+  // (2) staging loads of the first kSLPre rounds of the staging loop (16376 columns: every layer of the published
+  // families); a permutation makes the activation loads depend on its own load (layers that keep one pay that wait here)
+  const int chunks = G >> 3;
+  constexpr int kSLPre = 2;
+  u32x4 st_x[kSLPre], st_s[kSLPre], st_b[kSLPre];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) bd = DT::dot2(xv[i], bv[i], bd);
-        }
-        // the staged operand is in COLUMN order: column c multiplies feature perm[c] (scale in column order comes
-        // with the descriptor: scale_permuted)
-        u32x4 xc = xv;
-        if (P.perm != nullptr) {
-          const u32x4 pv = *(const u32x4*)(as_global(P.perm) + 8 * q);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const uint32_t lo = as_global(P.x)[pv[i] & 0xffffu], hi = as_global(P.x)[pv[i] >> 16];
-            xc[i] = lo | (hi << 16);
-          }
-        }
-        const u32x4 sv = *(const u32x4*)(as_global(P.scale) + 8 * q);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = DT::mul2(xc[i], sv[i]);
-      }
-      *(lds_q_t*)(uintptr_t)(kSLXOff + (uint32_t)q * 16u) = v;
+  for (int r = 0; r < kSLPre; ++r) {
+    const int q = tid + r * kSLThreads;
+    st_x[r] = st_s[r] = st_b[r] = u32x4{0u, 0u, 0u, 0u};
+    if (q < chunks && !(VPTQ_SLICED_ABLATE & 4)) {
+      st_s[r] = *(const u32x4*)(as_global(P.scale) + 8 * q);
+      if (P.perm == nullptr) st_x[r] = *(const u32x4*)(as_global(P.x) + 8 * q);
+      else st_x[r] = *(const u32x4*)(as_global(P.perm) + 8 * q);   // (the permutation's words: resolved in (5))
+      if (sg == 0 && P.wbias != nullptr) st_b[r] = *(const u32x4*)(as_global(P.wbias) + 8 * q);
     }
-    if (sg == 0) {
-      bd = wave_sum(bd);
-      if (lane == 0) *(float*)(smem + bd_off + (uint32_t)wave * 4u) = bd;
+  }
+  // ... and the rows' block counts (lane i: blocks of row row0 + i; read after the barrier)
+  int my_blocks = 0;
+  if (n_rows > 0 && lane < n_rows) my_blocks = (as_global(blocks_t) + (size_t)s * N + row0)[lane];
+  // activations: f16(scale * x) of every column, zero for the padding column G; the workgroups of slice 0 also form
+  // sum b x (it rides in their partial sums)
+  const uint32_t bd_off = kSLXOff + (uint32_t)(G + 64) * 2u;   // 16 floats behind the staged activations
+  typedef __attribute__((address_space(3))) u32x4 lds_q_t;
+  float bd = 0.f;
+  auto stage = [&](int q, u32x4 xv, const u32x4 sv, const u32x4 bv, bool have_perm_words) __attribute__((always_inline)) {
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (q < chunks && !(VPTQ_SLICED_ABLATE & 4)) {
+      // the staged operand is in COLUMN order: column c multiplies feature perm[c] (scale in column order comes
+      // with the descriptor: scale_permuted); sum b x is taken in input-FEATURE order (a permutation only reorders it)
+      u32x4 xc = xv;
+      if (have_perm_words) {
+        const u32x4 pv = xv;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const uint32_t lo = as_global(P.x)[pv[i] & 0xffffu], hi = as_global(P.x)[pv[i] >> 16];
+          xc[i] = lo | (hi << 16);
+        }
+        xv = *(const u32x4*)(as_global(P.x) + 8 * q);
+      }
+      if (sg == 0 && P.wbias != nullptr) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bd = DT::dot2(xv[i], bv[i], bd);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = DT::mul2(xc[i], sv[i]);
+    }
+    *(lds_q_t*)(uintptr_t)(kSLXOff + (uint32_t)q * 16u) = v;
+  };
+  // layers of more than 16376 columns: the staging rounds behind the first kSLPre, done HERE - in front of the element
+  // queue (a load issued behind it would make every later wait drain the queue; the compiler did exactly that for the
+  // slice-0 workgroups' LDS read behind the barrier, found in the ISA)
+  for (int q = tid + kSLPre * kSLThreads; q < chunks + 8; q += kSLThreads) {
+    u32x4 xv = {0u, 0u, 0u, 0u}, sv = xv, bv = xv;
+    if (q < chunks && !(VPTQ_SLICED_ABLATE & 4)) {
+      sv = *(const u32x4*)(as_global(P.scale) + 8 * q);
+      xv = *(const u32x4*)(as_global(P.perm != nullptr ? P.perm : P.x) + 8 * q);
+      if (sg == 0 && P.wbias != nullptr) bv = *(const u32x4*)(as_global(P.wbias) + 8 * q);
+    }
+    stage(q, xv, sv, bv, P.perm != nullptr);
+  }
+  // (3) this wave's stream: the blocks of its rows are contiguous in `elems`; `first` is a running sum over (slice, row),
+  // so its next entry behind the wave's rows ends the stream (the last wave of the last slice has no such entry: it adds its
+  // block counts up)
+  int total = 0, first_block = 0;
+  if (n_rows > 0) {
+    typedef const int32_t __attribute__((address_space(4)))* sl_const_i32_t;   // uniform + constant address space = scalar loads
+    const size_t at = (size_t)s * N + row0;
+    const sl_const_i32_t fp = (sl_const_i32_t)(uintptr_t)as_global(first_t);
+    first_block = fp[at];
+    if (at + (size_t)n_rows < (size_t)NSL * N) {
+      total = fp[at + n_rows] - first_block;
+    } else {
+      int t = my_blocks;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+      total = __builtin_amdgcn_readfirstlane(t);
     }
   }
 
-  // ---- element queue: block k of the stream -> slot k % kSLQueue
+  // (4) element queue: block k of the stream -> slot k % kSLQueue
   evec_t eq[kSLQueue];
   uint32_t rq[RES ? kSLQueue : 1];
   const evec_t* const ep = (const evec_t*)(as_global(elems_t) + (size_t)first_block * (64 * EPL)) + lane;
@@ -230,8 +270,24 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
     issue(slot_c);
     __builtin_amdgcn_sched_barrier(0);
   });
+
+  // (5) the hoisted staging rounds: arithmetic + LDS stores (their loads are older than the element words)
+  {
+#pragma unroll
+    for (int r = 0; r < kSLPre; ++r) {
+      const int q = tid + r * kSLThreads;
+      if (q < chunks + 8) stage(q, st_x[r], st_s[r], st_b[r], P.perm != nullptr);
+    }
+    if (sg == 0) {
+      bd = wave_sum(bd);
+      if (lane == 0) *(float*)(smem + bd_off + (uint32_t)wave * 4u) = bd;
+    }
+  }
   // the DMA and the staging loads are done before anybody reads LDS (the queue loads stay in flight)
-  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kSLQueue * kLoadsPerStep) : "memory");
+  {   // (as a builtin: the compiler sees it and keeps counting from here)
+    constexpr int kN = kSLQueue * kLoadsPerStep;
+    __builtin_amdgcn_s_waitcnt(0x0F70 | (kN & 15) | ((kN >> 4) << 14));   // vmcnt(kN), nothing else
+  }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
@@ -240,10 +296,33 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
 #endif
   float bdot = 0.f;
   if (sg == 0) {   // (fixed order: the 16 waves' parts)
-    const float* const bp = (const float*)(smem + bd_off);
+    // read by hand: in front of a compiler-generated LDS read here the compiler drained vmcnt - the element queue of
+    // every slice-0 workgroup, one memory latency (found in the ISA; the phase stamps had slice 0 finishing last)
+    static_assert(kSLWaves == 16, "sum b x: 16 parts");
+    u32x4 q0, q1, q2, q3;
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:32\n\t"
+                 "ds_read_b128 %3, %4 offset:48\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3) : "v"(bd_off) : "memory");
 #pragma unroll
-    for (int i = 0; i < kSLWaves; ++i) bdot += bp[i];
+    for (int i = 0; i < 4; ++i) bdot += __uint_as_float(q0[i]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bdot += __uint_as_float(q1[i]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bdot += __uint_as_float(q2[i]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bdot += __uint_as_float(q3[i]);
   }
+#if VPTQ_SLICED_PRIO == 1
+  __builtin_amdgcn_s_setprio(3);   // (A/B, round 5) constants only: the instruction takes an immediate
+  if (wave < 12) __builtin_amdgcn_s_setprio(2);
+  if (wave < 8) __builtin_amdgcn_s_setprio(1);
+  if (wave < 4) __builtin_amdgcn_s_setprio(0);
+#elif VPTQ_SLICED_PRIO == 2
+  __builtin_amdgcn_s_setprio(0);
+  if (wave < 12) __builtin_amdgcn_s_setprio(1);
+  if (wave < 8) __builtin_amdgcn_s_setprio(2);
+  if (wave < 4) __builtin_amdgcn_s_setprio(3);
+#endif
   float acc[V];
 #pragma unroll
   for (int i = 0; i < V; ++i) acc[i] = 0.f;
@@ -361,14 +440,13 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
 #pragma unroll
         for (int i = 0; i < V / 2; ++i) {
           float lo = acc[2 * i], hi = acc[2 * i + 1];   // (an asm operand cannot name a captured array element)
-          const uint32_t ew = ent[k][i / 4][i % 4];
+          uint32_t ew = ent[k][i / 4][i % 4];
+          // 256-entry residual table: f16(c + r) first - the reference's own first rounding (vptq/ops/quant_gemm.py:121) -
+          // as ONE packed add per pair of outputs instead of a second pair of multiply-adds (round 5: the phase stamps
+          // showed this format's stream bound by vector issue, 25 instructions per block)
+          if constexpr (RES) ew = DT::add2(ew, rent[i % 4]);
           asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,1,0]" : "+v"(lo) : "v"(ew), "v"(xw));
           asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,0]" : "+v"(hi) : "v"(ew), "v"(xw));
-          if constexpr (RES) {   // (c + r) x = c x + r x: the residual entry into the same sums
-            const uint32_t rw = rent[i % 4];
-            asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,1,0]" : "+v"(lo) : "v"(rw), "v"(xw));
-            asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,0]" : "+v"(hi) : "v"(rw), "v"(xw));
-          }
           acc[2 * i] = lo; acc[2 * i + 1] = hi;
         }
       } else {

@@ -361,7 +361,7 @@ class VQuantLinear(nn.Module):
         # storage pointers of everything; version counters of the tensors the descriptor holds DERIVED
         # copies of (scale / bias in column order for `perm` layers), which an in-place update of the
         # parameters (load_state_dict's copy_, an optimizer step) must invalidate
-        key = tuple(0 if t is None else t.data_ptr() for t in tensors)
+        key = tuple(0 if t is None else t.data_ptr() for t in tensors) + (B.arithmetic_generation(),)
         if perm is not None:
             key += (B.tensor_version(perm), B.tensor_version(tensors[6]), B.tensor_version(tensors[7]))
         cache = self.__dict__.get("_desc_cache")

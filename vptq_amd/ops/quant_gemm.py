@@ -22,12 +22,12 @@ from vptq_amd import _backend as B
 
 __all__ = ["dequant", "quant_gemm", "quant_gemv_v2"]
 
-# env knob: VPTQ_EXACT=1 rebuilds every weight with the reference CPU path's three 16-bit
-# roundings (bit-identical weights) instead of the default folded fp32 form (<= 1e-3)
+# env knob: VPTQ_EXACT=1 forces the reference CPU path's three 16-bit roundings per weight whatever the arithmetic mode
+# says (`_backend.set_arithmetic`: "reference" is the default since round 5, "folded" the opt-in fast form)
 _FLAGS = B.GEMV_EXACT if os.environ.get("VPTQ_EXACT", "0") == "1" else 0
 
-# The folded-form gate (`_backend.folded_form_is_safe`) for the functional op: a bias-dominated layer, or one with
-# fewer than 32 distinct vector-rows, takes the reference's roundings.  Decided once per set of tensor
+# The arithmetic of the functional op (`_backend.folded_form_is_safe`): the reference's roundings unless the folded form is
+# opted in AND the layer passes its measured gate.  Decided once per set of tensor
 # OBJECTS (weak references + version counters): one device -> host read, not one per call.
 _GATE_CACHE = {}
 
@@ -37,7 +37,7 @@ def _safe_flags(indices, centroids, residual_centroids, weight_scale, weight_bia
         return 0
     import weakref
     tensors = (indices, centroids, residual_centroids, weight_scale, weight_bias)
-    key = tuple(id(t) for t in tensors)
+    key = tuple(id(t) for t in tensors) + (B.arithmetic_generation(),)
     ent = _GATE_CACHE.get(key)
     if ent is not None:   # (the same OBJECTS, alive and unchanged: a recycled id or storage pointer must not hit)
         refs, vers, hit = ent
