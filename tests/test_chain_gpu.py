@@ -63,7 +63,9 @@ def test_independent_chain_every_layer_vs_oracle(dt, dev):
     from vptq_amd.ops.chain import GemvChain
     Ls, ms, xs = _build(SHAPES, dt, dev)
     chain = GemvChain(ms)
-    assert chain.kernel_name(1, CHAIN) == "gemv_k256c_kernel"
+    # (the default arithmetic - the reference's roundings - runs inside the chain launch for fp16; bf16 layers go out as
+    # grouped launches of the widened VALU kernel: test_independent_chain_folded covers the bf16 chain launch)
+    assert chain.kernel_name(1, CHAIN) == ("gemv_k256c_kernel" if dt == "f16" else "grouped")
     xt = [bits_to_tensor(x, dt, dev).reshape(x.shape) for x in xs]
     ys = chain(xt, flags=CHAIN)
     torch.cuda.synchronize()
@@ -80,6 +82,20 @@ def test_independent_chain_every_layer_vs_oracle(dt, dev):
     for i in (0, 2, 5):
         y1 = GemvChain([ms[i]])([xt[i]], flags=CHAIN)[0]
         assert torch.equal(y1.view(torch.int16), ys[i].view(torch.int16))
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+def test_independent_chain_folded(dt, dev, folded_arithmetic):
+    """the opt-in folded arithmetic through the chain launch, both dtypes: every layer against the oracle"""
+    from vptq_amd.ops.chain import GemvChain
+    Ls, ms, xs = _build(SHAPES, dt, dev)
+    chain = GemvChain(ms)
+    assert chain.kernel_name(1, CHAIN) == "gemv_k256c_kernel"
+    xt = [bits_to_tensor(x, dt, dev).reshape(x.shape) for x in xs]
+    ys = chain(xt, flags=CHAIN)
+    for L, x, y in zip(Ls, xs, ys):
+        err = rel_err(tensor_to_bits(y), vo.forward(L, x), dt)
+        assert err <= TOL[dt], f"{L.in_features}x{L.out_features}: {err:.3e}"
 
 
 def test_chain_float32_outputs(dev):
