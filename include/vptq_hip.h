@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define VPTQ_ABI_VERSION 7
+#define VPTQ_ABI_VERSION 8
 
 #if defined(__GNUC__)
 #define VPTQ_API __attribute__((visibility("default")))
@@ -283,10 +283,13 @@ VPTQ_API int vptq_quant_gemm(const VptqLayerDesc* desc, const void* x, void* y, 
  * top of them; the state-dict tensors are untouched.  A layer with 65536 RESIDUAL centroids is served table by table
  * - (c + r) s x = c s x + r s x: the residual table's (slice, row block) workgroups run beside the main table's in the same
  * launch - and `layout` then points to TWO consecutive structs with the same rows_per_wave: [0] built from the main
- * indices, [1] from the residual indices (`res` unused).  workspace: vptq_quant_gemv_sliced_workspace_bytes
- * ((2 x) S x N x v floats of partial sums + arrival counters), 16-byte aligned, ZERO-FILLED ONCE by the
- * caller before its first use - every call leaves the counters zero; one workspace per layer and STREAM (two calls in
- * flight on different streams must not share one).  Folded arithmetic (parity bar, not bit-equivalent);
+ * indices, [1] from the residual indices (`res` unused).  workspace: vptq_quant_gemv_sliced_workspace_bytes, 16-byte aligned,
+ * ZERO-FILLED ONCE by the caller before its first use - one 64-bit accumulator word per output (fixed-point sum | arrivals)
+ * that the slices' partial sums are added to with returning atomics; the last arriver of an output rounds, stores y and
+ * puts the word back to zero: every call leaves the workspace zero.  One workspace per layer and STREAM (two calls in flight
+ * on different streams must not share one).  Arithmetic: flags = 0 the folded form (parity bar for dense activations, not
+ * bit-equivalent); VPTQ_GEMV_EXACT (ABI >= 8) the reference's roundings per weight over a layout with the slice count
+ * vptq_sliced_layout_supported_for(desc, VPTQ_GEMV_EXACT) answers.
  * Layers this path takes: group_size <= 32768; a permutation is applied while the activations are staged.
  */
 typedef struct VptqSlicedLayout {
@@ -310,6 +313,13 @@ typedef struct VptqSlicedLayout {
  * the activations fit in LDS beside them (group_size <= 14336, 14080 with the 256-entry residual codebook), else 16 of
  * 4096; v = 16 (32-byte entries): 16 slices of 4096 entries, beyond 14336 columns 32 of 2048 */
 VPTQ_API int vptq_sliced_layout_supported(const VptqLayerDesc* desc);
+/* ... and for the arithmetic a call will ask for (ABI >= 8): flags = 0 as above; VPTQ_GEMV_EXACT - the reference's roundings per
+ * weight, w = f16(f16(f16(c + r) * s) + b) (vptq/ops/quant_gemm.py:121,155-156), what gemv_gather computes through the caches -
+ * takes layers without a residual codebook or with the 256-entry one of v = 8 (c and r must meet in one lane: one table) and
+ * stages scale, bias and x of every column beside the slice, 6 instead of 2 bytes of LDS per column: v = 8: 8 slices up to
+ * 5376 columns (4704 with the residual table), 16 up to 16288 (15616); v = 16: 16 / 32; wider layers: 0.  A layout built with
+ * THAT slice count serves vptq_quant_gemv_sliced(..., flags | VPTQ_GEMV_EXACT, ...); one token only. */
+VPTQ_API int vptq_sliced_layout_supported_for(const VptqLayerDesc* desc, int flags);
 /* 0, or how many consecutive VptqSlicedLayout structs vptq_quant_gemv_sliced takes for this layer: 1 (no residual codebook;
  * v = 8 with 256 residual centroids: `res` bytes), 2 (any other residual codebook: a second table with a layout of its own) */
 VPTQ_API int vptq_sliced_layout_tables(const VptqLayerDesc* desc);

@@ -79,6 +79,117 @@ def test_sliced_layout_gemv_vs_oracle(I, O, kw, rpw, dt, kr, dev):
     assert sl.extra_bytes <= 2.0 * m.indices.numel() * 4 + n_lay * sl.slices * (8 + 64 * 5) * m.indices.shape[1]
 
 
+# ---- the reference's roundings over the layouts (VPTQ_GEMV_EXACT, the product default arithmetic; round 5)
+EXACT_CASES = [
+    (1024, 256, dict(), 0),                                            # 8 slices
+    (2048, 1032, dict(bias=True), 3),
+    (4104, 264, dict(dist="llm"), 0),                                  # 8 slices without, 8 with the residual table (4704)
+    (4712, 136, dict(dist="llm"), 0),                                  # 8 slices without the residual table, 16 with it
+    (64, 72, dict(), 0),
+    (8192, 512, dict(dist="llm", bias=True), 0),                       # 16 slices (scale, bias and x of 8192 columns: 48 KiB)
+    (2048, 520, dict(dist="llm", enable_perm=True, bias=True), 0),     # a permutation: x gathered, scale / bias in column order
+    (6152, 264, dict(enable_perm=True), 2),
+    (14336, 128, dict(dist="llm"), 0),                                 # 16 slices, two staging rounds
+    (16392, 72, dict(dist="llm"), 0),                                  # too wide for the reference's roundings in LDS: not served
+]
+
+
+@pytest.mark.parametrize("v,kr", [(8, 0), (8, 256), (16, 0)])
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("I,O,kw,rpw", EXACT_CASES)
+def test_sliced_layout_reference_roundings(I, O, kw, rpw, dt, v, kr, dev):
+    """w = f16(f16(f16(c + r) * s) + b) per weight, as the reference CPU path rounds it, with LDS-local gathers: against the
+    oracle (almost every output bit-identical, the rest one flip of the last bit) and against the gather kernel, which
+    evaluates the same form through the caches"""
+    from vptq_amd.utils.sliced import SlicedGemv
+    from vptq_amd import _backend as B
+    kw = dict(kw)
+    dist = kw.pop("dist", "ref-test")
+    L = vo.make_layer(I, O, dist=dist, seed=I + O + v, dtype=dt, vector_len=v, num_centroids=65536, num_res_centroids=kr, **kw)
+    x = _x(I, dt, dist, I + 1)
+    m = spec_to_module(L, dev)
+    desc = m._descriptor()[1]
+    want_slices = B.lib().vptq_sliced_layout_supported_for(desc, EXACT)
+    small = 8 if v == 8 else 16
+    lds = lambda nsl: (65536 // nsl) * v * 2 + (I + 64) * 6 + 64 + (4096 if kr == 256 else 0)   # noqa: E731
+    assert want_slices == (small if lds(small) <= 163840 else (2 * small if lds(2 * small) <= 163840 else 0))
+    if not want_slices:
+        with pytest.raises(ValueError):
+            SlicedGemv(m, exact=True)
+        return
+    sl = SlicedGemv(m, rows_per_wave=rpw, exact=True)
+    assert sl.slices == want_slices and sl.exact
+    xt = bits_to_tensor(x, dt, dev).reshape(x.shape)
+    got = sl(xt)
+    torch.cuda.synchronize()
+    want = vo.forward(L, x)
+    gb = tensor_to_bits(got)
+    assert rel_err(gb, want, dt) <= TOL[dt], f"{I}x{O} {dt}: {rel_err(gb, want, dt):.3e}"
+    ident = float((gb.reshape(-1) == np.asarray(want).reshape(-1)).mean())
+    assert ident >= 0.95, ident
+    ref = tensor_to_bits(gemv_abi(m, xt, EXACT))                      # gather kernel: the same weights, another summation order
+    assert float((gb.reshape(-1) == ref.reshape(-1)).mean()) >= 0.95
+    # fp32 outputs: one rounding of the same sums; determinism; several tokens are not this object's business
+    y32 = sl(xt, flags=B.GEMV_OUT_F32)
+    assert y32.dtype == torch.float32 and torch.equal(y32.to(got.dtype).view(torch.int16), got.view(torch.int16))
+    assert torch.equal(sl(xt).view(torch.int16), got.view(torch.int16))
+    assert not sl.tokens_supported(2) and sl.forward_tokens(torch.cat([xt, xt], dim=1)) is None
+
+
+def test_module_default_route_takes_the_exact_sliced_kernel(dev):
+    """the product default (reference roundings): one-token calls of v8-k65536-0 / -256 layers go over an EXACT sliced layout,
+    two-table formats and several tokens keep the gather kernel; siblings share one launch"""
+    import vptq_amd
+    from vptq_amd.layers.vqlinear import SiblingGroup
+    assert vptq_amd.arithmetic() == "reference"
+    L = vo.make_layer(2048, 512, seed=31, dist="llm", num_centroids=65536, num_res_centroids=256, bias=True)
+    m = spec_to_module(L, dev)
+    x1 = _x(2048, "f16", "llm", 3)
+    xt = bits_to_tensor(x1, "f16", dev).reshape(x1.shape)
+    y = m(xt)
+    sl = m.__dict__["_sliced"][1]
+    assert sl is not None and sl.exact and sl.slices == 8
+    want = vo.forward(L, x1)
+    assert rel_err(tensor_to_bits(y), want, "f16") <= 1e-3
+    assert float((tensor_to_bits(y).reshape(-1) == np.asarray(want).reshape(-1)).mean()) >= 0.95
+    x3 = torch.cat([xt, xt, xt], dim=1)
+    y3 = m(x3)                                                          # three tokens: the gather kernel (same arithmetic)
+    assert torch.equal(y3.view(torch.int16), gemv_abi(m, x3, EXACT).view(torch.int16))
+    # a two-table format keeps the gather kernel in this arithmetic
+    L2 = vo.make_layer(2048, 512, seed=32, dist="llm", num_centroids=65536, num_res_centroids=65536)
+    m2 = spec_to_module(L2, dev)
+    y2 = m2(xt)
+    assert m2.__dict__["_sliced"][1] is None
+    assert torch.equal(y2.view(torch.int16), gemv_abi(m2, xt, EXACT).view(torch.int16))
+    # siblings (q / k / v): one launch of the exact kernel, the members' own bits
+    Ls = [vo.make_layer(2048, O, seed=40 + i, dist="llm", num_centroids=65536, num_res_centroids=256, bias=(i == 1)) for i, O in enumerate((1024, 264, 512))]
+    ms = [spec_to_module(Li, dev) for Li in Ls]
+    alone = [mm(xt) for mm in ms]
+    group = SiblingGroup(ms)
+    for mm in ms:
+        object.__setattr__(mm, "_siblings", group)
+    ys = [mm(xt) for mm in ms]
+    assert isinstance(group.__dict__.get("_sgroup"), tuple) and group._sgroup[1].exact
+    for a, b, Li in zip(alone, ys, Ls):
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+        assert rel_err(tensor_to_bits(b), vo.forward(Li, x1), "f16") <= 1e-3
+
+
+@pytest.mark.parametrize("name", [n for n in fmt_names() if ("k65536_r0" in n or "k65536_r256" in n) and n.startswith("t1_") and "v16" not in n])
+def test_sliced_layout_reference_roundings_on_reference_goldens(name, dev):
+    """one-token goldens of the real reference through the exact sliced kernel: the reference's own outputs, bit for bit
+    on almost every element"""
+    from vptq_amd.utils.sliced import SlicedGemv
+    L, x, y, cfg, _ = load_fmt(name)
+    dt = cfg["dtype"]
+    m = spec_to_module(L, dev)
+    xt = bits_to_tensor(x, dt, dev).reshape(x.shape)
+    sl = SlicedGemv(m, exact=True)
+    got = tensor_to_bits(sl(xt[:, :1].contiguous()))
+    assert rel_err(got, y[:, :1], dt) <= TOL[dt]
+    assert float((got.reshape(-1) == np.asarray(y[:, :1]).reshape(-1)).mean()) >= 0.95
+
+
 @pytest.mark.parametrize("name", [n for n in fmt_names() if "k65536_r0" in n or "k65536_r256" in n or "k65536_r65536" in n])
 def test_sliced_layout_gemv_on_reference_goldens(name, dev):
     """v8-k65536-0 / -256 / -65536 layers whose y comes from the real reference (tests/golden/gen_golden_fmt.py)"""

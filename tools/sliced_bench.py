@@ -19,6 +19,7 @@ ap.add_argument("--kr", type=int, default=0, help="residual centroids: 0 (v8-k65
 ap.add_argument("--k", type=int, default=65536, help="main centroids: 16384 / 32768 / 65536")
 ap.add_argument("--v", type=int, default=8, help="vector length: 8 or 16 (v16-k65536-0 / -65536)")
 ap.add_argument("--bf16", action="store_true")
+ap.add_argument("--exact", action="store_true", help="the reference's roundings (VPTQ_GEMV_EXACT): gather kernel against the exact sliced kernel")
 ap.add_argument("--out", default="")
 a = ap.parse_args()
 dev = torch.device("cuda", 0); g = torch.Generator(device=dev).manual_seed(0); lib = B.lib()
@@ -30,7 +31,7 @@ for I, O in [tuple(int(v) for v in p.split(',')) for p in a.shapes.split(';')]:
     if a.bf16:
         layers = [m.to(torch.bfloat16) for m in layers]
     descs = [module_desc(m) for m in layers]
-    sls = [SlicedGemv(m, rows_per_wave=a.rpw) for m in layers]
+    sls = [SlicedGemv(m, rows_per_wave=a.rpw, exact=a.exact) for m in layers]
     x = torch.randn(1, 1, I, device=dev).to(dt)
     y = torch.empty(1, 1, O, device=dev, dtype=dt)
     layers[0].enable_sliced_layout(False)   # (the module's own one-token route would be the sliced one)
@@ -40,7 +41,7 @@ for I, O in [tuple(int(v) for v in p.split(',')) for p in a.shapes.split(';')]:
 
     def run_default():
         for d, _ in descs:
-            B.check(lib.vptq_quant_gemv(d, x.data_ptr(), y.data_ptr(), 1, 0, None, 0, torch.cuda.current_stream().cuda_stream), "gemv")
+            B.check(lib.vptq_quant_gemv(d, x.data_ptr(), y.data_ptr(), 1, B.GEMV_EXACT if a.exact else 0, None, 0, torch.cuda.current_stream().cuda_stream), "gemv")
 
     def run_sliced():
         for s in sls:
@@ -48,7 +49,7 @@ for I, O in [tuple(int(v) for v in p.split(',')) for p in a.shapes.split(';')]:
     us_d = time_graph(run_default, 10) / R
     us_s = time_graph(run_sliced, 10) / R
     idx_bytes = layers[0].indices.numel() * 4
-    r = dict(I=I, O=O, v=a.v, k=a.k, kr=a.kr, dtype="bf16" if a.bf16 else "f16", default_us=us_d, default_kernel=lib.vptq_quant_gemv_kernel_name(descs[0][0], 1, 0).decode(),
+    r = dict(I=I, O=O, v=a.v, k=a.k, kr=a.kr, arithmetic="reference roundings" if a.exact else "folded", dtype="bf16" if a.bf16 else "f16", default_us=us_d, default_kernel=lib.vptq_quant_gemv_kernel_name(descs[0][0], 1, 0).decode(),
              sliced_us=us_s, speedup=us_d / us_s, rel_diff=err, packed_index_MiB=idx_bytes / 2**20,
              layout_MiB=sls[0].extra_bytes / 2**20, rows_per_wave=sls[0].layout[0].rows_per_wave, slices=sls[0].slices,
              sliced_GBps_of_packed_bytes=idx_bytes / us_s / 1e3, sliced_GBps_of_layout_bytes=sls[0].extra_bytes / us_s / 1e3)

@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # VPTQ_HIP_LIB: load another build of the library (A/B runs of tools/)
 LIB_PATH = os.environ.get("VPTQ_HIP_LIB") or os.path.join(_HERE, "libvptq_hip.so")
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 DTYPE_F16, DTYPE_BF16 = 0, 1
 GEMV_FAST_MATH = 1 << 0
 GEMV_FORCE_GENERIC = 1 << 1
@@ -101,6 +101,7 @@ EXPORTS = {
     "vptq_quant_gemm": (C.c_int, [C.POINTER(LayerDesc), _vp, _vp, C.c_int, C.c_int, _vp, C.c_size_t, _vp]),
     "vptq_quant_gemv_v2": (C.c_int, [C.POINTER(V2Desc), _vp, _vp, C.c_int, C.c_int, _vp]),
     "vptq_quant_gemv_kernel_name": (C.c_char_p, [C.POINTER(LayerDesc), C.c_int, C.c_int]),
+    "vptq_sliced_layout_supported_for": (C.c_int, [C.POINTER(LayerDesc), C.c_int]),
     "vptq_quant_gemv_grouped_kernel_name": (C.c_char_p, [C.POINTER(LayerDesc), C.c_int, C.c_int, C.c_int]),
 }
 

@@ -465,6 +465,12 @@ int vptq_sliced_layout_supported(const VptqLayerDesc* d) {
   return validate_layer(d) == VPTQ_OK && vptq::gemv_sliced_eligible(*d) ? vptq::gemv_sliced_slices(*d) : 0;
 }
 
+int vptq_sliced_layout_supported_for(const VptqLayerDesc* d, int flags) {
+  const bool exact = (flags & VPTQ_GEMV_EXACT) != 0;
+  if (flags & VPTQ_GEMV_FORCE_GENERIC) return 0;
+  return validate_layer(d) == VPTQ_OK && vptq::gemv_sliced_eligible(*d, exact) ? vptq::gemv_sliced_slices(*d, exact) : 0;
+}
+
 int vptq_sliced_layout_tables(const VptqLayerDesc* d) {
   return validate_layer(d) == VPTQ_OK && vptq::gemv_sliced_eligible(*d) ? vptq::gemv_sliced_tables(*d) : 0;
 }
@@ -482,19 +488,22 @@ int vptq_quant_gemv_sliced(const VptqLayerDesc* d, const VptqSlicedLayout* layou
   int rc = validate_layer(d);
   if (rc) return rc;
   if (!x || !y || !layout) return fail(VPTQ_E_NULL, "x / y / layout is NULL");
-  if (!vptq::gemv_sliced_eligible(*d))
-    return fail(VPTQ_E_UNSUPPORTED, "the sliced layout serves v = 8 / 16 layers with 16384 ... 65536 main centroids, group_size <= 32768");
-  if (flags & (VPTQ_GEMV_EXACT | VPTQ_GEMV_FORCE_GENERIC))
-    return fail(VPTQ_E_UNSUPPORTED, "the sliced path has the folded arithmetic only: use vptq_quant_gemv");
+  const bool exact = (flags & VPTQ_GEMV_EXACT) != 0;
+  if (flags & VPTQ_GEMV_FORCE_GENERIC) return fail(VPTQ_E_UNSUPPORTED, "VPTQ_GEMV_FORCE_GENERIC: use vptq_quant_gemv");
+  if (!vptq::gemv_sliced_eligible(*d, exact))
+    return fail(VPTQ_E_UNSUPPORTED, exact ? "VPTQ_GEMV_EXACT over a sliced layout: v = 8 / 16, 16384 ... 65536 main centroids, no residual "
+                                            "codebook or the 256-entry one of v = 8, scale / bias / x of every column beside a slice in LDS "
+                                            "(vptq_sliced_layout_supported_for)"
+                                          : "the sliced layout serves v = 8 / 16 layers with 16384 ... 65536 main centroids, group_size <= 32768");
   const size_t need = vptq::gemv_sliced_workspace_bytes(*d);
   if (!workspace || workspace_bytes < need || (((uintptr_t)workspace) & 15) != 0)
     return fail(VPTQ_E_WORKSPACE, "workspace of %zu bytes (16-byte aligned) needed", need);
   const int n_layouts = vptq::gemv_sliced_tables(*d);   // (two tables: one layout per table, consecutive structs)
   for (int i = 0; i < n_layouts; ++i) {
     if (layout[i].rows_per_wave < 1 || layout[i].rows_per_wave > 64 || !layout[i].elems || !layout[i].blocks || !layout[i].first ||
-        (layout[i].n_slices != 0 ? layout[i].n_slices : 8) != vptq::gemv_sliced_slices(*d))
-      return fail(VPTQ_E_UNSUPPORTED, "sliced layout %d: rows_per_wave in [1, 64], three tensors, n_slices = %d for this layer",
-                  i, vptq::gemv_sliced_slices(*d));
+        (layout[i].n_slices != 0 ? layout[i].n_slices : 8) != vptq::gemv_sliced_slices(*d, exact))
+      return fail(VPTQ_E_UNSUPPORTED, "sliced layout %d: rows_per_wave in [1, 64], three tensors, n_slices = %d for this layer and arithmetic",
+                  i, vptq::gemv_sliced_slices(*d, exact));
     if (layout[i].whole_table != vptq::gemv_sliced_whole_table(*d, i) || layout[i].rows_per_wave != layout[0].rows_per_wave)
       return fail(VPTQ_E_UNSUPPORTED, "sliced layout %d: whole_table must be %d (vptq_sliced_layout_whole_table) and rows_per_wave the "
                   "same for both tables", i, vptq::gemv_sliced_whole_table(*d, i));
@@ -538,10 +547,10 @@ int vptq_quant_gemv_sliced_grouped(const VptqLayerDesc* descs, const VptqSlicedL
     if (rc) return rc;
     if (!y[i]) return fail(VPTQ_E_NULL, "y[%d] is NULL", i);
   }
-  if (!vptq::gemv_sliced_groupable(descs, n))
-    return fail(VPTQ_E_UNSUPPORTED, "a sliced group takes layers of ONE format, dtype and input width that vptq_sliced_layout_supported() accepts");
-  if (flags & (VPTQ_GEMV_EXACT | VPTQ_GEMV_FORCE_GENERIC))
-    return fail(VPTQ_E_UNSUPPORTED, "the sliced path has the folded arithmetic only: use vptq_quant_gemv");
+  const bool exact = (flags & VPTQ_GEMV_EXACT) != 0;
+  if (flags & VPTQ_GEMV_FORCE_GENERIC) return fail(VPTQ_E_UNSUPPORTED, "VPTQ_GEMV_FORCE_GENERIC: use vptq_quant_gemv");
+  if (!vptq::gemv_sliced_groupable(descs, n, exact))
+    return fail(VPTQ_E_UNSUPPORTED, "a sliced group takes layers of ONE format, dtype and input width that vptq_sliced_layout_supported_for() accepts");
   if ((((uintptr_t)x) & 15) != 0) return fail(VPTQ_E_UNSUPPORTED, "x must be 16-byte aligned");
   const int tables = vptq::gemv_sliced_tables(descs[0]);
   for (int i = 0; i < n; ++i) {
@@ -551,9 +560,9 @@ int vptq_quant_gemv_sliced_grouped(const VptqLayerDesc* descs, const VptqSlicedL
     for (int t = 0; t < tables; ++t) {
       const VptqSlicedLayout& L = layouts[(size_t)i * tables + t];
       if (L.rows_per_wave < 1 || L.rows_per_wave > 64 || !L.elems || !L.blocks || !L.first ||
-          (L.n_slices != 0 ? L.n_slices : 8) != vptq::gemv_sliced_slices(descs[i]))
+          (L.n_slices != 0 ? L.n_slices : 8) != vptq::gemv_sliced_slices(descs[i], exact))
         return fail(VPTQ_E_UNSUPPORTED, "layer %d, sliced layout %d: rows_per_wave in [1, 64], three tensors, n_slices = %d", i, t,
-                    vptq::gemv_sliced_slices(descs[i]));
+                    vptq::gemv_sliced_slices(descs[i], exact));
       if (L.whole_table != vptq::gemv_sliced_whole_table(descs[i], t) || L.rows_per_wave != layouts[0].rows_per_wave)
         return fail(VPTQ_E_UNSUPPORTED, "layer %d, sliced layout %d: whole_table must be %d and rows_per_wave the group's", i, t,
                     vptq::gemv_sliced_whole_table(descs[i], t));

@@ -24,10 +24,13 @@
 // 2.06x / 1.72x the packed indices in memory on top of them and in HBM traffic per token.  A workgroup owns
 // (slice, block of rows): it copies its slice (LDS-DMA) and f16(scale * x) of all columns into LDS, then each wave
 // streams the CONTIGUOUS element blocks of its consecutive rows through a register queue; per element one
-// ds_read_b128 (entry) + one ds_read_u16 (activation) + 8 FMAs in fp32.  Partial sums per (slice, output)
-// go to the caller's workspace; the workgroup of a row block that stores them last adds the slices in a fixed
-// order and the output bias (sum b x rides in slice 0's partial sums).  Folded arithmetic (gemv_k256m.hip):
-// y = sum c[idx] * f16(s x) + sum b x + bias.
+// ds_read_b128 (entry) + one ds_read_u16 (activation) + 8 FMAs in fp32.  A row's partial sum per slice is added to the
+// output's 64-bit accumulator word in the caller's workspace (fixed point + arrival count, one returning atomic); the lane
+// whose add completes the count rounds the total once, adds the output bias and stores y.  Two arithmetics:
+//   folded (flags = 0):   y = sum (c + r)[idx] * f16(s x) + sum b x + bias   (sum b x rides with slice 0; two-table formats:
+//                         c f16(s x) and r f16(s x) from different workgroups)
+//   reference roundings (VPTQ_GEMV_EXACT, template EX): w = f16(f16(f16(c + r) * s) + b) per weight, y = sum w x + bias -
+//                         the product default since round 5; one table only (none or the 256-entry residual codebook)
 #include "sliced.h"
 
 namespace vptq {
@@ -48,13 +51,13 @@ constexpr int kSLQueueWords = VPTQ_SLICED_QUEUE;
 // [start[l], start[l + 1]).  One launch instead of n: the fixed part of a launch (boundary, slice copy, staging, the
 // cross-slice hand-over: ~7 of the 10 us of a 4096 x 4096 layer) is paid once.
 constexpr int kSLMaxGroup = 3;
-// how the slices of a row meet.  1 (default): ONE hop - every (slice, output) partial sum becomes a 64-bit fixed-point word
-// (count | value) added to the output's accumulator with a returning device-scope atomic; integer adds commute, so the sum
-// does not depend on the order, and the lane whose add completes the count holds the total.  0: the round-3/4 hand-over
-// (write-through partial sums, arrival counter per row block, the last workgroup reads them back: three dependent trips).
-#ifndef VPTQ_SLICED_EPI
-#define VPTQ_SLICED_EPI 1
-#endif
+// How the slices of a row meet (round 5): ONE hop.  Every (slice, output) partial sum becomes a 64-bit fixed-point word
+// (count | value) that is added to the output's accumulator word with a returning device-scope atomic; integer adds commute, so
+// the sum does not depend on the order, and the lane whose add completes the count holds the total, rounds it once and stores y.
+// (Rounds 3-4: write-through partial sums, an arrival counter per row block and a read-back by the last workgroup - three
+// dependent trips through memory, ~4 us measured as a launch of its own; the phase stamps of round 5 show that in ONE launch
+// the stragglers of the stream hid most of it: the two forms time the same, profiles/r05/sliced_epilogue_ab.txt.  The one-hop
+// form stays: no counters, no barriers, no read-back, half the workspace.)
 // phase time stamps (tools/sliced_trace.py): every wave writes s_memrealtime at entry / after the prologue barrier / at the
 // end of its stream / at its exit behind the accumulator words of the workspace (8192^2-sized layers only: the room the
 // round-4 partial sums had)
@@ -89,7 +92,11 @@ struct SlicedGroupParams {
   SlicedParams p[kSLMaxGroup];
 };
 
-template <typename DT, int NSL, bool RES, int V = 8, bool TWO = false>
+// EX (round 5): the reference's roundings per weight instead of the folded form - w = f16(f16(f16(c + r) * s) + b)
+// (vptq/ops/quant_gemm.py:121,155-156), y = sum w x in fp32: what gemv_gather computes, here with LDS-local gathers.  The
+// column's scale and bias are staged as a word per column beside the raw activations (6 instead of 2 bytes per column: the
+// host picks 16 slices where 8 no longer fit); one table only - c and r must meet in one lane.
+template <typename DT, int NSL, bool RES, int V = 8, bool TWO = false, bool EX = false>
 __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGroupParams GP) {
   // this workgroup's layer; its parameters come out of the kernel-argument segment through the scalar cache (a run-time
   // index into the by-value argument would make the compiler copy it to scratch memory)
@@ -106,7 +113,8 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
 #else
   const SlicedParams P = GP.p[0];   // (host pass of the compiler: never executed)
 #endif
-  static_assert(((V == 8 && (NSL == 8 || NSL == 16)) || (V == 16 && (NSL == 16 || NSL == 32))) && (V == 8 || !RES) && !(TWO && RES), "slices");
+  static_assert(((V == 8 && (NSL == 8 || NSL == 16)) || (V == 16 && (NSL == 16 || NSL == 32))) && (V == 8 || !RES) && !(TWO && RES) &&
+                !(EX && TWO), "slices");
   constexpr int NSLT = TWO ? 2 * NSL : NSL;   // workgroups per row block: one per (table, slice)
   constexpr int EPL = 1;   // element words per lane and block (2 and 4 - 8 / 16-byte loads - were measured: no difference)
   constexpr uint32_t kEntry = V * 2u;                          // bytes of a codebook entry
@@ -161,7 +169,10 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
     }
   }
   // residual codebook (256 entries = 4 KiB) behind the activations: waves 0-3 bring 1 KiB each
-  const uint32_t res_off = kSLXOff + (uint32_t)(G + 64) * 2u + 64u;
+  // LDS behind the table: [G + 64 halves: f16(s x), EX: x] [EX: G + 64 words {s, b}] [16 floats: sum b x parts] [RES: 4 KiB]
+  const uint32_t sb_off = kSLXOff + (uint32_t)(G + 64) * 2u;                     // (EX) scale | bias << 16 per column
+  const uint32_t bd_off = sb_off + (EX ? (uint32_t)(G + 64) * 4u : 0u);          // 16 floats behind the staged operands
+  const uint32_t res_off = bd_off + 64u;
   if constexpr (RES) {
     if (wave < 4) {
       const uint64_t v = (uint64_t)(uintptr_t)as_global(P.rcent) + (uint64_t)wave * 1024u + (uint64_t)lane * 16u;
@@ -184,7 +195,8 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
       st_s[r] = *(const u32x4*)(as_global(P.scale) + 8 * q);
       if (P.perm == nullptr) st_x[r] = *(const u32x4*)(as_global(P.x) + 8 * q);
       else st_x[r] = *(const u32x4*)(as_global(P.perm) + 8 * q);   // (the permutation's words: resolved in (5))
-      if (sg == 0 && P.wbias != nullptr) st_b[r] = *(const u32x4*)(as_global(P.wbias) + 8 * q);
+      if constexpr (EX) st_b[r] = *(const u32x4*)(as_global(P.cbias) + 8 * q);
+      else if (sg == 0 && P.wbias != nullptr) st_b[r] = *(const u32x4*)(as_global(P.wbias) + 8 * q);
     }
   }
   // ... and the rows' block counts (lane i: blocks of row row0 + i; read after the barrier)
@@ -192,7 +204,6 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
   if (n_rows > 0 && lane < n_rows) my_blocks = (as_global(blocks_t) + (size_t)s * N + row0)[lane];
   // activations: f16(scale * x) of every column, zero for the padding column G; the workgroups of slice 0 also form
   // sum b x (it rides in their partial sums)
-  const uint32_t bd_off = kSLXOff + (uint32_t)(G + 64) * 2u;   // 16 floats behind the staged activations
   typedef __attribute__((address_space(3))) u32x4 lds_q_t;
   float bd = 0.f;
   auto stage = [&](int q, u32x4 xv, const u32x4 sv, const u32x4 bv, bool have_perm_words) __attribute__((always_inline)) {
@@ -210,12 +221,30 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
         }
         xv = *(const u32x4*)(as_global(P.x) + 8 * q);
       }
-      if (sg == 0 && P.wbias != nullptr) {
+      if constexpr (EX) {
+        v = xc;   // raw activations; the column's scale and bias as one word: {s, b}
+        u32x4 w0, w1;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) bd = DT::dot2(xv[i], bv[i], bd);
+        for (int i = 0; i < 2; ++i) {
+          w0[2 * i] = (sv[i] & 0xffffu) | (bv[i] << 16);
+          w0[2 * i + 1] = (sv[i] >> 16) | (bv[i] & 0xffff0000u);
+          w1[2 * i] = (sv[2 + i] & 0xffffu) | (bv[2 + i] << 16);
+          w1[2 * i + 1] = (sv[2 + i] >> 16) | (bv[2 + i] & 0xffff0000u);
+        }
+        *(lds_q_t*)(uintptr_t)(sb_off + (uint32_t)q * 32u) = w0;
+        *(lds_q_t*)(uintptr_t)(sb_off + (uint32_t)q * 32u + 16u) = w1;
+      } else {
+        if (sg == 0 && P.wbias != nullptr) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) bd = DT::dot2(xv[i], bv[i], bd);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = DT::mul2(xc[i], sv[i]);
       }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) v[i] = DT::mul2(xc[i], sv[i]);
+    } else if constexpr (EX) {   // the padding column: scale = bias = 0 (and x = 0: w x = 0)
+      const u32x4 z = {0u, 0u, 0u, 0u};
+      *(lds_q_t*)(uintptr_t)(sb_off + (uint32_t)q * 32u) = z;
+      *(lds_q_t*)(uintptr_t)(sb_off + (uint32_t)q * 32u + 16u) = z;
     }
     *(lds_q_t*)(uintptr_t)(kSLXOff + (uint32_t)q * 16u) = v;
   };
@@ -227,7 +256,8 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
     if (q < chunks && !(VPTQ_SLICED_ABLATE & 4)) {
       sv = *(const u32x4*)(as_global(P.scale) + 8 * q);
       xv = *(const u32x4*)(as_global(P.perm != nullptr ? P.perm : P.x) + 8 * q);
-      if (sg == 0 && P.wbias != nullptr) bv = *(const u32x4*)(as_global(P.wbias) + 8 * q);
+      if constexpr (EX) bv = *(const u32x4*)(as_global(P.cbias) + 8 * q);
+      else if (sg == 0 && P.wbias != nullptr) bv = *(const u32x4*)(as_global(P.wbias) + 8 * q);
     }
     stage(q, xv, sv, bv, P.perm != nullptr);
   }
@@ -278,7 +308,7 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
       const int q = tid + r * kSLThreads;
       if (q < chunks + 8) stage(q, st_x[r], st_s[r], st_b[r], P.perm != nullptr);
     }
-    if (sg == 0) {
+    if (!EX && sg == 0) {
       bd = wave_sum(bd);
       if (lane == 0) *(float*)(smem + bd_off + (uint32_t)wave * 4u) = bd;
     }
@@ -295,7 +325,7 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
   if (lane == 0) trace[1] = __builtin_amdgcn_s_memrealtime();
 #endif
   float bdot = 0.f;
-  if (sg == 0) {   // (fixed order: the 16 waves' parts)
+  if (!EX && sg == 0) {   // (fixed order: the 16 waves' parts)
     // read by hand: in front of a compiler-generated LDS read here the compiler drained vmcnt - the element queue of
     // every slice-0 workgroup, one memory latency (found in the ISA; the phase stamps had slice 0 finishing last)
     static_assert(kSLWaves == 16, "sum b x: 16 parts");
@@ -327,7 +357,6 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
 #pragma unroll
   for (int i = 0; i < V; ++i) acc[i] = 0.f;
   int row_i = 0;
-#if VPTQ_SLICED_EPI
   // ---- the slices of a row meet in the output's accumulator word (caller's workspace, zero between launches): the lane
   // whose add brings the arrivals to NSLT has old + its own = the sum of all slices (+ sum b x, which rides with slice 0),
   // exact in fixed point and therefore the same whoever comes last; it rounds ONCE, adds the output bias, stores y and
@@ -352,7 +381,6 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
       pend_o = -1;
     }
   };
-#endif
   // rows without elements in this slice store zeros
   auto store_row = [&]() __attribute__((always_inline)) {
     // sum over the 64 lanes: swap-and-add halves the values carried (gemv_k256c.hip:finish), then DPP
@@ -372,7 +400,6 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
 #pragma unroll
     for (int i = 0; i < V / 4; ++i) v[i] = row16_allsum(v[i]);
     // lane l (any of its row of 16) holds outputs (V / 2) bit5 + (V / 4) bit4 + {0 .. V / 4 - 1}
-#if VPTQ_SLICED_EPI
     // row i of the wave is handed over by lanes (i & 15) + {0, 16, 32, 48}: up to 16 rows' returned words wait in the
     // registers of different lanes until the stream is through (no wait inside the loop)
     if ((row_i & 15) == 0 && row_i > 0) finish_rows();   // (more than 16 rows per wave: the lanes come round again)
@@ -385,15 +412,6 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
         pend_old[i] = __hip_atomic_fetch_add(ap + i, pend_mine[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
-#else
-    if ((lane & 15) == 0) {
-      const int o8 = ((lane >> 5) & 1) * (V / 2) + ((lane >> 4) & 1) * (V / 4);
-      // write-through at device scope (sc1): the workgroup that sums the slices may sit on another XCD
-      float* const pp = as_global(P.partial) + ((size_t)sg * N + (size_t)(row0 + row_i)) * V + o8;
-#pragma unroll
-      for (int i = 0; i < V / 4; ++i) __hip_atomic_store(pp + i, v[i] + bdot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-#endif
 #pragma unroll
     for (int i = 0; i < V; ++i) acc[i] = 0.f;
   };
@@ -431,6 +449,22 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
       xh[k] = *(const lds_h_t*)(uintptr_t)(kSLXOff + ((e & 0xffffu) << 1));
     }
     if constexpr (RES) rent = lds_load16(res_off + (rq[S] << 4));
+    [[maybe_unused]] uint32_t sb[EPL];
+    if constexpr (EX) {
+      typedef __attribute__((address_space(3))) uint32_t lds_w_t;
+#pragma unroll
+      for (int k = 0; k < EPL; ++k) sb[k] = *(const lds_w_t*)(uintptr_t)(sb_off + ((ev[k] & 0xffffu) << 2));
+    }
+    // EX: the weight as the reference rounds it - u = f16(c + r), t = f16(u * s), w = f16(t + b): three packed instructions per
+    // pair of outputs, scale and bias broadcast out of the column's word by op_sel - then w x in fp32
+    auto weight = [&](uint32_t ew, uint32_t rw, uint32_t sbw) __attribute__((always_inline)) -> uint32_t {
+      if constexpr (RES) ew = DT::add2(ew, rw);
+      if constexpr (EX) {
+        ew = DT::mul2_bcast(ew, sbw, 0);
+        ew = DT::add2_bcast(ew, sbw, 1);
+      }
+      return ew;
+    };
 #pragma unroll
     for (int k = 0; k < EPL; ++k) {
       if constexpr (std::is_same<DT, F16>::value) {
@@ -440,11 +474,10 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
 #pragma unroll
         for (int i = 0; i < V / 2; ++i) {
           float lo = acc[2 * i], hi = acc[2 * i + 1];   // (an asm operand cannot name a captured array element)
-          uint32_t ew = ent[k][i / 4][i % 4];
           // 256-entry residual table: f16(c + r) first - the reference's own first rounding (vptq/ops/quant_gemm.py:121) -
           // as ONE packed add per pair of outputs instead of a second pair of multiply-adds (round 5: the phase stamps
           // showed this format's stream bound by vector issue, 25 instructions per block)
-          if constexpr (RES) ew = DT::add2(ew, rent[i % 4]);
+          const uint32_t ew = weight(ent[k][i / 4][i % 4], rent[i % 4], EX ? sb[k] : 0u);
           asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,1,0]" : "+v"(lo) : "v"(ew), "v"(xw));
           asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,0]" : "+v"(hi) : "v"(ew), "v"(xw));
           acc[2 * i] = lo; acc[2 * i + 1] = hi;
@@ -453,10 +486,11 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
         const float xf = DT::to_float(xh[k]);
 #pragma unroll
         for (int i = 0; i < V / 2; ++i) {
-          const uint32_t ew = ent[k][i / 4][i % 4];
+          // (folded bf16: c x + r x, two pairs of multiply-adds - a widened add would cost more than it saves)
+          const uint32_t ew = EX ? weight(ent[k][i / 4][i % 4], rent[i % 4], sb[k]) : ent[k][i / 4][i % 4];
           acc[2 * i] = __builtin_fmaf(DT::to_float((uint16_t)(ew & 0xffffu)), xf, acc[2 * i]);
           acc[2 * i + 1] = __builtin_fmaf(DT::to_float((uint16_t)(ew >> 16)), xf, acc[2 * i + 1]);
-          if constexpr (RES) {
+          if constexpr (RES && !EX) {
             acc[2 * i] = __builtin_fmaf(DT::to_float((uint16_t)(rent[i % 4] & 0xffffu)), xf, acc[2 * i]);
             acc[2 * i + 1] = __builtin_fmaf(DT::to_float((uint16_t)(rent[i % 4] >> 16)), xf, acc[2 * i + 1]);
           }
@@ -489,62 +523,11 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
     sl_for_slots<kSLQueue>(step);
   }
 
-  // ---- the slices of a row block meet: the workgroup that stores its partial sums LAST adds them up.  Nobody
-  // waits for anybody: every workgroup drains its write-through stores, counts itself in (device-scope atomic)
-  // and leaves unless it was the last of the row block's NSLT; that one reads the NSLT partial sums per output
-  // with device-coherent loads, adds them in a fixed tree (so the result does not depend on who was last), adds
-  // the output bias and stores y.  A second launch for this step cost 4.3 us of the 14.2 (its reads were the
-  // first touch of what other XCDs had just written, behind a kernel boundary).
+  // ---- the rows whose words are still on their way: the last arriver of every output rounds and stores it
 #if VPTQ_SLICED_TRACE
   if (lane == 0) trace[2] = __builtin_amdgcn_s_memrealtime();
 #endif
-#if VPTQ_SLICED_EPI
   finish_rows();
-#if VPTQ_SLICED_TRACE
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (lane == 0) trace[3] = __builtin_amdgcn_s_memrealtime();
-#endif
-  return;
-#endif
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's partial sums have reached memory
-  uint32_t* const flag = (uint32_t*)(smem + bd_off);   // (the sum b x parts are dead by now)
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-  __builtin_amdgcn_s_barrier();
-  if (tid == 0) {
-    const uint32_t before = __hip_atomic_fetch_add(as_global(P.arrived) + rb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint32_t lastone = before == (uint32_t)NSLT - 1u ? 1u : 0u;
-    if (lastone) __hip_atomic_store(as_global(P.arrived) + rb, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
-    *flag = lastone;
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-  __builtin_amdgcn_s_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-#if VPTQ_SLICED_TRACE
-  if (lane == 0) trace[3] = __builtin_amdgcn_s_memrealtime();
-#endif
-  if (*flag == 0u) return;
-  {
-    const int rows_wg = kSLWaves * rpw;
-    const int r_first = rb * rows_wg;
-    const int n_out = (N - r_first < rows_wg ? N - r_first : rows_wg) * V;   // outputs of this row block
-    for (int k = tid; k < n_out; k += kSLThreads) {
-      const size_t o = (size_t)r_first * V + k;
-      float p[NSLT];
-#pragma unroll
-      for (int sl = 0; sl < NSLT; ++sl)
-        p[sl] = __hip_atomic_load(as_global(P.partial) + (size_t)sl * N * V + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-      for (int w = NSLT / 2; w > 0; w >>= 1)   // (a fixed tree)
-#pragma unroll
-        for (int i = 0; i < w; ++i) p[i] = p[2 * i] + p[2 * i + 1];
-      float v = p[0];
-      if ((int)o < P.O) {
-        if (P.bias) v += DT::to_float(as_global(P.bias)[o]);
-        if (P.out_f32) ((float*)as_global(P.y))[o] = v;
-        else ((uint16_t*)as_global(P.y))[o] = DT::from_float(v);
-      }
-    }
-  }
 #if VPTQ_SLICED_TRACE
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (lane == 0) trace[3] = __builtin_amdgcn_s_memrealtime();
@@ -559,10 +542,12 @@ static bool sl_pow2(int k) { return k > 0 && (k & (k - 1)) == 0; }
 bool sl_res256(const VptqLayerDesc& d) { return d.vector_len == 8 && d.num_res_centroids == 256; }
 bool sl_two(const VptqLayerDesc& d) { return d.num_res_centroids > 0 && !sl_res256(d); }
 int gemv_sliced_tables(const VptqLayerDesc& d) { return sl_two(d) ? 2 : 1; }
-static bool sl_shape_ok(const VptqLayerDesc& d);
-bool gemv_sliced_eligible(const VptqLayerDesc& d) {
+static bool sl_shape_ok(const VptqLayerDesc& d, bool exact);
+bool gemv_sliced_eligible(const VptqLayerDesc& d, bool exact) {
   const int T = d.index_bits + d.res_bits;
-  return sl_shape_ok(d) && (d.vector_len == 8 || d.vector_len == 16) && d.num_codebooks == 1 && d.outlier_size == 0 &&
+  // the reference's roundings: c and r must meet in one lane (one table), bias in column order
+  if (exact && (sl_two(d) || (d.perm != nullptr && (d.bias_permuted == nullptr || (((uintptr_t)d.bias_permuted) & 15) != 0)))) return false;
+  return sl_shape_ok(d, exact) && (d.vector_len == 8 || d.vector_len == 16) && d.num_codebooks == 1 && d.outlier_size == 0 &&
          d.num_centroids >= 16384 && d.num_centroids <= 65536 && sl_pow2(d.num_centroids) && (1 << d.index_bits) == d.num_centroids &&
          (d.num_res_centroids == 0 || (d.num_res_centroids >= 2 && d.num_res_centroids <= 65536 && sl_pow2(d.num_res_centroids) &&
                                        (1 << d.res_bits) == d.num_res_centroids)) &&
@@ -573,19 +558,34 @@ bool gemv_sliced_eligible(const VptqLayerDesc& d) {
            (uintptr_t)d.perm | (uintptr_t)d.scale_permuted) & 15) == 0;
 }
 
-// slices a layout of this layer must have: the slice (table entries / slices, 2 v bytes each) + f16(s x) of every column
-// (+ the 4 KiB residual table of the 256-entry path) must fit the 160 KiB of LDS: v = 8: 8 slices up to 14336 columns
-// (14080 with that table), else 16; v = 16: 16 slices up to 14336 columns, else 32
-int gemv_sliced_slices(const VptqLayerDesc& d) {
+// bytes of LDS behind the table: f16(s x) of every column (+ 64 padding columns) + 16 floats; the reference's roundings
+// stage x and a word {scale, bias} per column instead: 6 bytes per column; + the 4 KiB residual table of the 256-entry path
+static uint32_t sl_operand_bytes(const VptqLayerDesc& d, bool exact) {
+  return (uint32_t)(d.group_size + 64) * (exact ? 6u : 2u) + 64u + (sl_res256(d) ? 4096u : 0u);
+}
+// slices a layout of this layer must have: the slice (table entries / slices, 2 v bytes each) + the staged operands must fit
+// the 160 KiB of LDS.  Folded arithmetic: v = 8: 8 slices up to 14336 columns (14080 with the 256-entry table), else 16;
+// v = 16: 16 slices up to 14336 columns, else 32.  Reference roundings (6 bytes per column): v = 8: 8 slices up to 5376 columns
+// (4704), 16 up to 16288 (15616); v = 16: 16 / 32 at the same widths; wider layers: 0 (not served: gemv_gather)
+int gemv_sliced_slices(const VptqLayerDesc& d, bool exact) {
   static std::atomic<int> force16{-1};   // VPTQ_SLICED_SLICES=16: the larger slice count for every layer (A/B)
   if (force16 < 0) { const char* e = getenv("VPTQ_SLICED_SLICES"); force16 = (e && atoi(e) == 16) ? 1 : 0; }
   const int small = d.vector_len == 16 ? 16 : 8;
-  if (force16 == 1) return 2 * small;
-  return d.group_size <= (sl_res256(d) ? kSLMaxG8Res : kSLMaxG8) ? small : 2 * small;
+  if (!exact) {
+    if (force16 == 1) return 2 * small;
+    return d.group_size <= (sl_res256(d) ? kSLMaxG8Res : kSLMaxG8) ? small : 2 * small;
+  }
+  if (d.num_centroids <= 0 || d.vector_len <= 0) return 0;
+  for (int nsl = (force16 == 1 ? 2 * small : small); nsl <= 2 * small; nsl *= 2) {
+    const uint32_t tab = (uint32_t)(d.num_centroids / nsl) * (uint32_t)d.vector_len * 2u;
+    if ((tab + 15u) / 16u * 16u + sl_operand_bytes(d, true) <= kSLLdsLimit) return nsl;
+  }
+  return 0;
 }
 // bytes a workgroup of a table with k entries holds: its slice, or (whole != 0) the whole table
-uint32_t sl_tab_bytes(const VptqLayerDesc& d, int k, int whole) {
-  return (uint32_t)(whole ? k : k / gemv_sliced_slices(d)) * (uint32_t)d.vector_len * 2u;
+uint32_t sl_tab_bytes(const VptqLayerDesc& d, int k, int whole, bool exact) {
+  const int nsl = gemv_sliced_slices(d, exact);
+  return (uint32_t)(whole || nsl == 0 ? k : k / nsl) * (uint32_t)d.vector_len * 2u;
 }
 // Does every workgroup of table t (0 main, 1 residual-as-second-table) hold the WHOLE table (element words then carry the
 // full index and a row's elements are split into column ranges)?  Only a second table whose slice would be under 16 KiB -
@@ -600,31 +600,31 @@ int gemv_sliced_whole_table(const VptqLayerDesc& d, int t) {
   return slice < 16384u && ((whole > main_slice ? whole : main_slice) + 15u) / 16u * 16u + x_bytes <= kSLLdsLimit ? 1 : 0;
 }
 
-// the tables' parts + the staged activations (+ the 4 KiB table of the 256-entry path) fit the LDS
-static bool sl_shape_ok(const VptqLayerDesc& d) {
+// the tables' parts + the staged operands fit the LDS
+static bool sl_shape_ok(const VptqLayerDesc& d, bool exact) {
   if (!(d.vector_len == 8 || d.vector_len == 16) || d.group_size <= 0 || d.group_size > kSLMaxG16 || d.num_centroids < 16384) return false;
+  if (exact) return gemv_sliced_slices(d, true) != 0;
   uint32_t tab = sl_tab_bytes(d, d.num_centroids, 0);
   if (sl_two(d)) {
     const uint32_t t1 = sl_tab_bytes(d, d.num_res_centroids, gemv_sliced_whole_table(d, 1));
     tab = t1 > tab ? t1 : tab;
   }
-  return (tab + 15u) / 16u * 16u + (uint32_t)(d.group_size + 64) * 2u + 64u + (sl_res256(d) ? 4096u : 0u) <= kSLLdsLimit;
+  return (tab + 15u) / 16u * 16u + sl_operand_bytes(d, false) <= kSLLdsLimit;
 }
 
-// partial sums [table x slices][N x v] floats + one arrival counter per block of 16 rows (the smallest row block), which
-// must be ZERO before the first launch; every launch leaves them zero
-static size_t sl_partial_bytes(const VptqLayerDesc& d) {
+// one 64-bit accumulator word per output (N x v of them), which must be ZERO before the first launch; every launch leaves
+// them zero.  (Rounds 3-4 kept [tables x slices][N x v] float partial sums + arrival counters here; the size the ABI asks for
+// is still that one - callers' buffers stay valid, tools/sliced_trace.py stamps into the rest.)
+size_t gemv_sliced_workspace_bytes(const VptqLayerDesc& d) {
   const size_t parts = (size_t)gemv_sliced_slices(d) * (sl_two(d) ? 2 : 1);
-  return (parts * d.num_indices * d.vector_len * sizeof(float) + 255) / 256 * 256;
+  const size_t partial = (parts * d.num_indices * d.vector_len * sizeof(float) + 255) / 256 * 256;
+  const size_t counters = (((size_t)(d.num_indices + kSLWaves - 1) / kSLWaves) * sizeof(uint32_t) + 255) / 256 * 256;
+  return partial + counters;
 }
-static size_t sl_counter_bytes(const VptqLayerDesc& d) {
-  return (((size_t)(d.num_indices + kSLWaves - 1) / kSLWaves) * sizeof(uint32_t) + 255) / 256 * 256;
-}
-size_t gemv_sliced_workspace_bytes(const VptqLayerDesc& d) { return sl_partial_bytes(d) + sl_counter_bytes(d); }
 
-template <typename DT, int NSL, bool RES, int V, bool TWO>
+template <typename DT, int NSL, bool RES, int V, bool TWO, bool EX = false>
 static hipError_t launch_sl(const SlicedGroupParams& P, uint32_t lds, hipStream_t st) {
-  auto kern = gemv_sliced_kernel<DT, NSL, RES, V, TWO>;
+  auto kern = gemv_sliced_kernel<DT, NSL, RES, V, TWO, EX>;
   static std::atomic<bool> attr_set[64];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
@@ -637,7 +637,13 @@ static hipError_t launch_sl(const SlicedGroupParams& P, uint32_t lds, hipStream_
   return hipGetLastError();
 }
 template <typename DT>
-static hipError_t launch_sl_dt(const SlicedGroupParams& P, int v, int nsl, bool res, bool two, uint32_t lds, hipStream_t st) {
+static hipError_t launch_sl_dt(const SlicedGroupParams& P, int v, int nsl, bool res, bool two, bool exact, uint32_t lds, hipStream_t st) {
+  if (exact) {   // the reference's roundings: one table
+    if (two) return hipErrorInvalidValue;
+    if (v == 16) return nsl == 16 ? launch_sl<DT, 16, false, 16, false, true>(P, lds, st) : launch_sl<DT, 32, false, 16, false, true>(P, lds, st);
+    if (nsl == 8) return res ? launch_sl<DT, 8, true, 8, false, true>(P, lds, st) : launch_sl<DT, 8, false, 8, false, true>(P, lds, st);
+    return res ? launch_sl<DT, 16, true, 8, false, true>(P, lds, st) : launch_sl<DT, 16, false, 8, false, true>(P, lds, st);
+  }
   if (v == 16) {
     if (two) return nsl == 16 ? launch_sl<DT, 16, false, 16, true>(P, lds, st) : launch_sl<DT, 32, false, 16, true>(P, lds, st);
     return nsl == 16 ? launch_sl<DT, 16, false, 16, false>(P, lds, st) : launch_sl<DT, 32, false, 16, false>(P, lds, st);
@@ -656,14 +662,15 @@ bool sl_layout_ok(const VptqLayerDesc& d, const VptqSlicedLayout& L, int nsl, bo
 
 // L: one layout (residual none / the 256-entry path of v = 8) or TWO consecutive ones (any other residual codebook: [0]
 // bucketed by the main index, [1] by the residual index).  (c + r) f16(s x) = c f16(s x) + r f16(s x): the residual table's
-// (slice, row block) workgroups run beside the main table's in the SAME launch and meet them in the cross-slice sum - two
-// launches, one per table, cost a second boundary, a second epilogue and half the workgroups in flight (8192^2: 27.2 us
+// (slice, row block) workgroups run beside the main table's in the SAME launch and meet them in the output's accumulator
+// word - two launches, one per table, cost a second boundary, a second epilogue and half the workgroups in flight (8192^2: 27.2 us
 // against 21.2; 4096^2: 17.8 against 12.0)
 static hipError_t sl_fill(const VptqLayerDesc& d, const VptqSlicedLayout* L, const void* x, void* y, int flags, void* ws,
                           SlicedParams& P, uint32_t& lds) {
+  const bool exact = (flags & VPTQ_GEMV_EXACT) != 0;
   const bool res = sl_res256(d), two = sl_two(d);
-  const int nsl = gemv_sliced_slices(d);
-  if (!sl_layout_ok(d, L[0], nsl, res, d.num_centroids) || L[0].whole_table != 0 ||
+  const int nsl = gemv_sliced_slices(d, exact);
+  if (nsl == 0 || !sl_layout_ok(d, L[0], nsl, res, d.num_centroids) || L[0].whole_table != 0 ||
       (two && (!sl_layout_ok(d, L[1], nsl, false, d.num_res_centroids) || L[1].rows_per_wave != L[0].rows_per_wave ||
                L[1].whole_table != gemv_sliced_whole_table(d, 1))) ||
       !ws || (((uintptr_t)x) & 15) != 0)
@@ -675,7 +682,7 @@ static hipError_t sl_fill(const VptqLayerDesc& d, const VptqSlicedLayout* L, con
   P.blocks = (const int32_t*)L[0].blocks;
   P.first = (const int32_t*)L[0].first;
   P.cent = (const uint32_t*)d.centroids;
-  P.tab0 = sl_tab_bytes(d, d.num_centroids, L[0].whole_table);
+  P.tab0 = sl_tab_bytes(d, d.num_centroids, L[0].whole_table, exact);
   P.stride0 = L[0].whole_table ? 0u : P.tab0;
   if (two) {
     P.elems2 = (const uint32_t*)L[1].elems;
@@ -689,40 +696,42 @@ static hipError_t sl_fill(const VptqLayerDesc& d, const VptqSlicedLayout* L, con
   P.x = (const uint16_t*)x;
   P.scale = (const uint16_t*)(d.perm ? d.scale_permuted : d.weight_scale);
   P.wbias = (const uint16_t*)d.weight_bias;
+  P.cbias = (const uint16_t*)(d.perm ? d.bias_permuted : d.weight_bias);
   P.perm = (const uint16_t*)d.perm;
   P.bias = (const uint16_t*)d.bias;
   P.partial = (float*)ws;
-  P.arrived = (uint32_t*)((char*)ws + sl_partial_bytes(d));
   P.y = y;
   P.N = d.num_indices; P.G = d.group_size; P.O = d.out_features;
   P.rows_per_wave = L[0].rows_per_wave;
   const int rows_per_wg = kSLWaves * L[0].rows_per_wave;
   P.n_rowblocks = (d.num_indices + rows_per_wg - 1) / rows_per_wg;
   P.out_f32 = (flags & VPTQ_GEMV_OUT_F32) ? 1 : 0;
-  lds = P.x_off + (uint32_t)(d.group_size + 64) * 2u + 64u + (res ? 4096u : 0u);
+  lds = P.x_off + sl_operand_bytes(d, exact);
   return lds > kSLLdsLimit ? hipErrorInvalidValue : hipSuccess;
 }
 
 // n <= kSLMaxGroup layers of ONE format (vector length, slices, residual kind, dtype) and one input width reading the same x:
 // layouts = the layers' layout structs one after the other (1 or 2 each); one launch
-bool gemv_sliced_groupable(const VptqLayerDesc* d, int n) {
+bool gemv_sliced_groupable(const VptqLayerDesc* d, int n, bool exact) {
   if (n < 1 || n > kSLMaxGroup) return false;
   for (int i = 0; i < n; ++i) {
-    if (!gemv_sliced_eligible(d[i])) return false;
+    if (!gemv_sliced_eligible(d[i], exact)) return false;
     if (d[i].dtype != d[0].dtype || d[i].vector_len != d[0].vector_len || d[i].group_size != d[0].group_size ||
-        gemv_sliced_slices(d[i]) != gemv_sliced_slices(d[0]) || sl_res256(d[i]) != sl_res256(d[0]) || sl_two(d[i]) != sl_two(d[0]))
+        gemv_sliced_slices(d[i], exact) != gemv_sliced_slices(d[0], exact) || sl_res256(d[i]) != sl_res256(d[0]) || sl_two(d[i]) != sl_two(d[0]))
       return false;
   }
   return true;
 }
 hipError_t launch_gemv_sliced_group(const VptqLayerDesc* d, const VptqSlicedLayout* L, int n, const void* x, void* const* y,
                                     int flags, void* const* ws, hipStream_t st) {
-  if (!gemv_sliced_groupable(d, n)) return hipErrorInvalidValue;
+  const bool exact = (flags & VPTQ_GEMV_EXACT) != 0;
+  if (!gemv_sliced_groupable(d, n, exact)) return hipErrorInvalidValue;
   SlicedGroupParams GP = {};
   GP.n = n;
   uint32_t lds = 0;
   const int tables = gemv_sliced_tables(d[0]);
-  const int nslt = gemv_sliced_slices(d[0]) * tables;
+  const int nsl = gemv_sliced_slices(d[0], exact);
+  const int nslt = nsl * tables;
   for (int i = 0; i < n; ++i) {
     uint32_t l = 0;
     const hipError_t e = sl_fill(d[i], L + (size_t)i * tables, x, y[i], flags, ws[i], GP.p[i], l);
@@ -732,8 +741,8 @@ hipError_t launch_gemv_sliced_group(const VptqLayerDesc* d, const VptqSlicedLayo
   }
   for (int i = n; i < kSLMaxGroup; ++i) GP.start[i + 1] = GP.start[n];
   return d[0].dtype == VPTQ_DTYPE_F16
-             ? launch_sl_dt<F16>(GP, d[0].vector_len, gemv_sliced_slices(d[0]), sl_res256(d[0]), sl_two(d[0]), lds, st)
-             : launch_sl_dt<BF16>(GP, d[0].vector_len, gemv_sliced_slices(d[0]), sl_res256(d[0]), sl_two(d[0]), lds, st);
+             ? launch_sl_dt<F16>(GP, d[0].vector_len, nsl, sl_res256(d[0]), sl_two(d[0]), exact, lds, st)
+             : launch_sl_dt<BF16>(GP, d[0].vector_len, nsl, sl_res256(d[0]), sl_two(d[0]), exact, lds, st);
 }
 hipError_t launch_gemv_sliced(const VptqLayerDesc& d, const VptqSlicedLayout* L, const void* x, void* y, int flags,
                               void* ws, hipStream_t st) {

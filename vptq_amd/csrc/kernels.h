@@ -57,8 +57,10 @@ hipError_t launch_gemv_lds_v2(const VptqV2Desc& d, const void* x, void* y, int t
                               int flags, hipStream_t st);
 
 // gemv_sliced.hip - v8-k65536-0, one token, over the load-time derived sliced layout (LDS-local gathers)
-bool gemv_sliced_eligible(const VptqLayerDesc& d);
-int gemv_sliced_slices(const VptqLayerDesc& d);
+// exact: the reference's roundings per weight (VPTQ_GEMV_EXACT) - scale and bias staged per column beside the activations
+// (6 instead of 2 bytes of LDS per column: more slices for wide layers), one table only
+bool gemv_sliced_eligible(const VptqLayerDesc& d, bool exact = false);
+int gemv_sliced_slices(const VptqLayerDesc& d, bool exact = false);
 int gemv_sliced_tables(const VptqLayerDesc& d);
 int gemv_sliced_whole_table(const VptqLayerDesc& d, int table);   // VptqSlicedLayout::whole_table the layout of `table` must have   // layouts the layer needs: 1, or 2 (a residual codebook served as a second table)
 size_t gemv_sliced_workspace_bytes(const VptqLayerDesc& d);
@@ -73,7 +75,7 @@ hipError_t launch_gemv_sliced_tok(const VptqLayerDesc& d, const VptqSlicedLayout
 bool gemv_sliced_tok_groupable(const VptqLayerDesc* d, const VptqSlicedLayout* L, int n, int tokens);
 hipError_t launch_gemv_sliced_tok_group(const VptqLayerDesc* d, const VptqSlicedLayout* L, int n, const void* x, void* const* y,
                                         int tokens, int flags, void* const* ws, hipStream_t st);
-bool gemv_sliced_groupable(const VptqLayerDesc* d, int n);
+bool gemv_sliced_groupable(const VptqLayerDesc* d, int n, bool exact = false);
 hipError_t launch_gemv_sliced_group(const VptqLayerDesc* d, const VptqSlicedLayout* L, int n, const void* x, void* const* y,
                                     int flags, void* const* ws, hipStream_t st);
 // gemm_k256t.hip - canonical format, fp16 / bf16, up to 16 tokens in one pass over the indices (transposing

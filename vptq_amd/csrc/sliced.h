@@ -25,7 +25,8 @@ struct SlicedParams {
   const uint32_t* cent;     // [65536][8] halves
   const uint16_t* x;
   const uint16_t* scale;
-  const uint16_t* wbias;    // input-feature order
+  const uint16_t* wbias;    // input-feature order (folded arithmetic: sum b x)
+  const uint16_t* cbias;    // COLUMN order (reference roundings: w = f16(f16(u * s) + b) per weight): bias_permuted or weight_bias
   const uint16_t* perm;     // column c of the quantised matrix multiplies input feature perm[c]; `scale` is then in column order
   const uint16_t* bias;
   // TWO tables in one launch (65536 residual centroids): the residual table's layout and codebook; its workgroups are
@@ -59,7 +60,7 @@ static __device__ __forceinline__ void sl_for_slots(F&& f) { sl_for_range<0, Q>(
 // ---- host side (gemv_sliced.hip)
 bool sl_res256(const VptqLayerDesc& d);   // v = 8 with the 256-entry residual table: a byte per element beside the main layout
 bool sl_two(const VptqLayerDesc& d);      // any other residual table: a second table with a layout of its own
-uint32_t sl_tab_bytes(const VptqLayerDesc& d, int k, int whole);   // bytes a workgroup of a k-entry table holds
+uint32_t sl_tab_bytes(const VptqLayerDesc& d, int k, int whole, bool exact = false);   // bytes a workgroup of a k-entry table holds
 bool sl_layout_ok(const VptqLayerDesc& d, const VptqSlicedLayout& L, int nsl, bool res, int k);
 
 }  // namespace vptq

@@ -448,10 +448,14 @@ class VQuantLinear(nn.Module):
             if torch.cuda.is_current_stream_capturing():
                 return None   # (no layout is built inside a capture - and the "no" is not remembered: a later call builds it)
             obj = None
-            if not cache[9] and B.lib().vptq_sliced_layout_supported(cache[1]) and self._sliced_fits(cache, on):
+            # the layer's arithmetic (cache[9]): the reference's roundings (the default) take the EXACT sliced kernel where it
+            # serves the layer - no residual codebook or the 256-entry one of v = 8, up to ~16000 columns; the others keep the
+            # gather kernel -, the opt-in folded form the folded one
+            exact = bool(cache[9] & B.GEMV_EXACT)
+            if B.lib().vptq_sliced_layout_supported_for(cache[1], B.GEMV_EXACT if exact else 0) and self._sliced_fits(cache, on):
                 from vptq_amd.utils.sliced import SlicedGemv
                 try:
-                    obj = SlicedGemv(self)
+                    obj = SlicedGemv(self, exact=exact)
                 except torch.cuda.OutOfMemoryError as e:
                     # out of device memory while building: the regular route serves THIS call; nothing is remembered, so a
                     # later call (memory freed meanwhile) tries again.  Any other error is a bug and propagates.
@@ -463,7 +467,7 @@ class VQuantLinear(nn.Module):
                 # the kernel over the layouts evaluates the folded form: the same measured gate as every folded route
                 # (_backend.folded_form_is_safe) - its float32 outputs against the gather kernel's (the reference's roundings)
                 # on the probe activations
-                lim = B.FOLDED_MAX_PROBE_DISTANCE.get(cache[7])
+                lim = None if exact else B.FOLDED_MAX_PROBE_DISTANCE.get(cache[7])
                 if lim is not None and self._parameters.get("weight_bias") is not None:
                     run = obj
 
@@ -485,7 +489,9 @@ class VQuantLinear(nn.Module):
         against 40.2 / 44.0 / 24.1; small residual tables of v = 16: never)"""
         lim = sl.__dict__.get("_token_limit")
         if lim is None:
-            if _SLICED_TOKENS_ENV is not None:
+            if sl.exact:      # (the reference's roundings over a layout: one token; the gather kernels take 2 - 8 for the price of one)
+                lim = 1
+            elif _SLICED_TOKENS_ENV is not None:
                 lim = _SLICED_TOKENS_ENV[1 if len(sl.layout) == 2 else 0]
             else:
                 n_el = self.indices.shape[1] * self.group_size      # elements per table
@@ -553,7 +559,8 @@ class VQuantLinear(nn.Module):
                     not self.enable_outlier and self.enable_norm)   # (a permutation may still be absorbed later; the library
                     # decides: vptq_sliced_layout_supported)
             sl = self._sliced_gemv() if self.__dict__["_sliced_cand"] else None
-            if sl is not None and not (ops.quant_gemm_flags() & (B.GEMV_EXACT | B.GEMV_FORCE_GENERIC)):
+            gf = ops.quant_gemm_flags()
+            if sl is not None and not (gf & B.GEMV_FORCE_GENERIC) and (sl.exact or not (gf & B.GEMV_EXACT)):
                 if tokens == 1:
                     sib = self.__dict__.get("_siblings")
                     if sib is not None:      # q / k / v, gate / up: one sliced launch for the group

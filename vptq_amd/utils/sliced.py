@@ -137,13 +137,19 @@ def rows_per_wave_for(n_rows: int, slices: int = 8, workgroups: int = 256) -> in
 class SlicedGemv:
     """One-token forward of a v8-k65536-0 `VQuantLinear` over its sliced layout."""
 
-    def __init__(self, layer, rows_per_wave: int = 0):
+    def __init__(self, layer, rows_per_wave: int = 0, exact: bool = False):
+        """exact: the reference's roundings per weight (`VPTQ_GEMV_EXACT`, the product default arithmetic) instead of the
+        folded form - layers without a residual codebook or with the 256-entry one of v = 8; the layout then has the slice
+        count that arithmetic needs (scale, bias and x of every column sit beside the slice in LDS)."""
         self.layer = layer
+        self.exact = bool(exact)
+        self._flags = B.GEMV_EXACT if self.exact else 0
         cache = layer._descriptor()
         self.desc, self.dev = cache[1], cache[3]
-        self.slices = B.lib().vptq_sliced_layout_supported(self.desc)
+        self.slices = B.lib().vptq_sliced_layout_supported_for(self.desc, self._flags)
         if not self.slices:
-            raise ValueError("the sliced layout serves v = 8 / 16 layers with 16384 ... 65536 main centroids, group_size <= 32768")
+            raise ValueError("the sliced layout serves v = 8 / 16 layers with 16384 ... 65536 main centroids, group_size <= 32768"
+                             " (reference roundings: one table, up to ~16000 columns)")
         kr = layer.num_res_centroids if layer.enable_residual else 0
         ib = int(layer.num_centroids).bit_length() - 1
         rb = int(kr).bit_length() - 1 if kr else 0
@@ -210,6 +216,8 @@ class SlicedGemv:
     def tokens_supported(self, tokens: int) -> bool:
         """does the library's kernel for 2 - 4 tokens over these layouts take this layer (its activations must fit the LDS
         beside the slice in at most 4 column phases)?"""
+        if self.exact:      # (the token kernel has the folded arithmetic only, and its layouts another slice count)
+            return False
         return bool(B.lib().vptq_quant_gemv_sliced_tokens_supported(self.desc, self._lay_ref, int(tokens)))
 
     def forward_tokens(self, x: torch.Tensor, out: torch.Tensor = None, flags: int = 0):
@@ -219,6 +227,8 @@ class SlicedGemv:
         tokens = x.numel() // lay.in_features
         if x.shape[-1] != lay.in_features or not 2 <= tokens <= 8:
             raise ValueError("forward_tokens takes 2 - 8 tokens of in_features values")
+        if self.exact:
+            return None
         if x.dtype != self._dtype or x.device != self.dev:
             x = lay._check_activation(x)
         if not x.is_contiguous():
@@ -277,7 +287,7 @@ class SlicedGemv:
         if out is None:
             out = torch.empty(x.shape[:-1] + (self.layer.out_features,),
                               dtype=torch.float32 if (flags & B.GEMV_OUT_F32) else self._dtype, device=self.dev)
-        rc = self._fn(self.desc, self._lay_ref, x.data_ptr(), out.data_ptr(), flags, ws.data_ptr(), self._ws_bytes, sp)
+        rc = self._fn(self.desc, self._lay_ref, x.data_ptr(), out.data_ptr(), flags | self._flags, ws.data_ptr(), self._ws_bytes, sp)
         if rc == B.E_UNSUPPORTED:
             return None
         if rc:
@@ -300,7 +310,7 @@ class SlicedGroupGemv:
         m0 = self.members[0]
         tables = len(m0.layout)
         kind = lambda m: (m.layer.vector_len, m.layer.num_centroids,   # noqa: E731
-                          m.layer.num_res_centroids if m.layer.enable_residual else 0, tuple(m._whole))
+                          m.layer.num_res_centroids if m.layer.enable_residual else 0, tuple(m._whole), m.exact)
         if not 1 <= n <= 3 or any(len(m.layout) != tables or m.slices != m0.slices or m._dtype != m0._dtype or m.dev != m0.dev or
                                   m.layer.in_features != m0.layer.in_features or kind(m) != kind(m0) for m in self.members):
             raise ValueError("a sliced group takes 1..3 layers of one format (vector length, codebook sizes), dtype, device and input width")
@@ -314,6 +324,7 @@ class SlicedGroupGemv:
         self._wb = (C.c_size_t * n)(*[m._ws_bytes for m in self.members])
         self._fn = B.lib().vptq_quant_gemv_sliced_grouped
         self.dev, self._dtype, self._dev_index = m0.dev, m0._dtype, m0._dev_index
+        self.exact, self._flags = m0.exact, m0._flags
 
     def __call__(self, x: torch.Tensor):
         """list of outputs (one per member), or None where the call cannot take the sliced kernel (as SlicedGemv.__call__)"""
@@ -332,7 +343,7 @@ class SlicedGroupGemv:
         return self._launch(x)
 
     def tokens_supported(self, tokens: int) -> bool:
-        return all(m.tokens_supported(tokens) for m in self.members)
+        return not self.exact and all(m.tokens_supported(tokens) for m in self.members)
 
     def forward_tokens(self, x: torch.Tensor):
         """2 - 4 tokens through every member in ONE launch (`vptq_quant_gemv_sliced_tokens_grouped`): list of outputs, or None
@@ -341,6 +352,8 @@ class SlicedGroupGemv:
         tokens = x.numel() // lay.in_features
         if x.shape[-1] != lay.in_features or not 2 <= tokens <= 8:
             raise ValueError("forward_tokens takes 2 - 8 tokens of in_features values")
+        if self.exact:
+            return None
         if x.dtype != self._dtype or x.device != self.dev:
             x = lay._check_activation(x)
         if not x.is_contiguous():
@@ -384,7 +397,7 @@ class SlicedGroupGemv:
         for i, (y, w) in enumerate(zip(ys, wss)):
             self._yp[i] = y.data_ptr()
             self._wp[i] = w.data_ptr()
-        rc = self._fn(self.descs, self.layouts, len(ys), x.data_ptr(), self._yp, 0, self._wp, self._wb, sp)
+        rc = self._fn(self.descs, self.layouts, len(ys), x.data_ptr(), self._yp, self._flags, self._wp, self._wb, sp)
         if rc == B.E_UNSUPPORTED:
             return None
         if rc:
