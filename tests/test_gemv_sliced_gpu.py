@@ -146,6 +146,9 @@ def test_module_default_route_takes_the_exact_sliced_kernel(dev):
     m = spec_to_module(L, dev)
     x1 = _x(2048, "f16", "llm", 3)
     xt = bits_to_tensor(x1, "f16", dev).reshape(x1.shape)
+    y0 = m(xt)                                # a layer this small stays on the gather kernel by itself (under 1 M index elements)
+    assert m.__dict__["_sliced"][1] is None and torch.equal(y0.view(torch.int16), gemv_abi(m, xt, EXACT).view(torch.int16))
+    m.enable_sliced_layout()
     y = m(xt)
     sl = m.__dict__["_sliced"][1]
     assert sl is not None and sl.exact and sl.slices == 8
@@ -158,12 +161,15 @@ def test_module_default_route_takes_the_exact_sliced_kernel(dev):
     # a two-table format keeps the gather kernel in this arithmetic
     L2 = vo.make_layer(2048, 512, seed=32, dist="llm", num_centroids=65536, num_res_centroids=65536)
     m2 = spec_to_module(L2, dev)
+    m2.enable_sliced_layout()
     y2 = m2(xt)
     assert m2.__dict__["_sliced"][1] is None
     assert torch.equal(y2.view(torch.int16), gemv_abi(m2, xt, EXACT).view(torch.int16))
     # siblings (q / k / v): one launch of the exact kernel, the members' own bits
     Ls = [vo.make_layer(2048, O, seed=40 + i, dist="llm", num_centroids=65536, num_res_centroids=256, bias=(i == 1)) for i, O in enumerate((1024, 264, 512))]
     ms = [spec_to_module(Li, dev) for Li in Ls]
+    for mm in ms:
+        mm.enable_sliced_layout()
     alone = [mm(xt) for mm in ms]
     group = SiblingGroup(ms)
     for mm in ms:
@@ -222,11 +228,19 @@ def test_sliced_layout_small_reference_golden_and_rejections(dev):
     # a canonical 256 + 256 layer is not a sliced-layout layer
     with pytest.raises(ValueError):
         SlicedGemv(spec_to_module(vo.make_layer(256, 64, seed=1), dev))
-    # the reference's roundings are not available here
-    Lk = vo.make_layer(512, 128, seed=2, num_centroids=65536, num_res_centroids=0)
-    sl = SlicedGemv(spec_to_module(Lk, dev))
+    # the reference's roundings (ABI 8) need c and r in one lane - a two-table layer is not served - and a layout with the
+    # slice count THAT arithmetic wants: an 8-slice folded layout of an 8192-column layer is turned down
     # ("unsupported" from the library = None here: the caller takes the regular route, which has them)
-    assert sl(torch.zeros(1, 1, 512, dtype=torch.float16, device=dev), flags=EXACT) is None
+    L2 = vo.make_layer(512, 128, seed=2, num_centroids=65536, num_res_centroids=65536)
+    sl2 = SlicedGemv(spec_to_module(L2, dev))
+    assert sl2(torch.zeros(1, 1, 512, dtype=torch.float16, device=dev), flags=EXACT) is None
+    with pytest.raises(ValueError):
+        SlicedGemv(spec_to_module(L2, dev), exact=True)
+    Lw = vo.make_layer(8192, 64, seed=3, num_centroids=65536, num_res_centroids=0)
+    mw = spec_to_module(Lw, dev)
+    slw = SlicedGemv(mw)
+    assert slw.slices == 8 and B.lib().vptq_sliced_layout_supported_for(mw._descriptor()[1], EXACT) == 16
+    assert slw(torch.zeros(1, 1, 8192, dtype=torch.float16, device=dev), flags=EXACT) is None
 
 
 def test_sliced_layout_in_a_hipgraph(dev):

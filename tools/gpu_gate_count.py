@@ -145,7 +145,8 @@ def main():
             del m, W
         done += per
         print(f"# {fam}: {per} layers done after {time.time() - t0:.0f} s", flush=True)
-    print(f"dtype {a.dtype}, bar {bar:g}, {done} layers, seed {a.seed}, gate line {B.FOLDED_MAX_PROBE_DISTANCE[dt]:g} (un-rounded distance on the probes)")
+    print(f"dtype {a.dtype}, bar {bar:g}, {done} layers, seed {a.seed}, arithmetic of the product route: {vptq_amd.arithmetic()}"
+          f" (gate line of the folded form: {B.FOLDED_MAX_PROBE_DISTANCE[dt]:g}, un-rounded distance on the probes)")
     print(f"{'family':14s} {'layers':>6s} {'gated':>6s} | product route: {'worst':>9s} {'p99.9':>9s} {'median':>9s} {'> bar':>6s} | "
           f"folded, no gate: {'worst':>9s} {'> bar':>6s} | probe distance: {'median':>9s} {'max':>9s}")
     total = 0

@@ -55,6 +55,7 @@ def _raw_stream(device_index: int) -> int:
 _SLICED_LAYOUT_MODE = os.environ.get("VPTQ_SLICED_LAYOUT", "auto").strip().lower() or "auto"
 _SLICED_LAYOUT_ENV = _SLICED_LAYOUT_MODE not in ("0", "off", "false", "no")
 _SLICED_MIN_FREE_FRACTION = 0.25
+_SLICED_EXACT_MIN_ELEMENTS = 1 << 20   # vector-rows x columns from which the exact sliced kernel beats the gather kernel
 # most tokens served as one sliced launch PER TOKEN: decided per layer (VQuantLinear._sliced_token_limit);
 # VPTQ_SLICED_TOKENS="one-table,two-table" overrides it (tools/sliced_tokens_bench.py)
 _SLICED_TOKENS_ENV = tuple(int(v) for v in os.environ["VPTQ_SLICED_TOKENS"].split(",")) if os.environ.get("VPTQ_SLICED_TOKENS") else None
@@ -452,7 +453,12 @@ class VQuantLinear(nn.Module):
             # serves the layer - no residual codebook or the 256-entry one of v = 8, up to ~16000 columns; the others keep the
             # gather kernel -, the opt-in folded form the folded one
             exact = bool(cache[9] & B.GEMV_EXACT)
-            if B.lib().vptq_sliced_layout_supported_for(cache[1], B.GEMV_EXACT if exact else 0) and self._sliced_fits(cache, on):
+            # (reference roundings, us per layer, gather -> exact sliced, profiles/r05/sliced_exact.txt: 8192^2 39.4 -> 17.2,
+            # 4096 x 14336 34.5 -> 17.0, 14336 x 4096 34.9 -> 14.7, 4096^2 12.6 -> 9.0, 4096 x 1024 7.8 -> 8.3: from 1 M index elements -
+            # 8 M weights - on; enable_sliced_layout() asks for it on any layer)
+            big = self.indices.shape[1] * self.group_size >= _SLICED_EXACT_MIN_ELEMENTS or "_sliced_on" in self.__dict__
+            if (big or not exact) and B.lib().vptq_sliced_layout_supported_for(cache[1], B.GEMV_EXACT if exact else 0) and \
+                    self._sliced_fits(cache, on):
                 from vptq_amd.utils.sliced import SlicedGemv
                 try:
                     obj = SlicedGemv(self, exact=exact)
