@@ -142,6 +142,10 @@ def k65536_extra(lib, B, dev, H, steps, warmup, regions, R=8, kr=256, v=8):
     ys = [torch.empty(1, 1, H, device=dev, dtype=torch.float16) for _ in range(R)]
     descs = [layer_desc(m) for m in layers]
     sls = [SlicedGemv(m) for m in layers]
+    # the reference's roundings over a layout (round 5; no residual codebook or the 256-entry one): what VQuantLinear.forward
+    # takes for these layers in the default arithmetic
+    exact_ok = bool(lib.vptq_sliced_layout_supported_for(descs[0][0], B.GEMV_EXACT))
+    sxs = [SlicedGemv(m, exact=True) for m in layers] if exact_ok else []
 
     def default_pass():
         sp = torch.cuda.current_stream().cuda_stream
@@ -152,16 +156,30 @@ def k65536_extra(lib, B, dev, H, steps, warmup, regions, R=8, kr=256, v=8):
     def sliced_pass():
         for i in range(R):
             sls[i](x, ys[i])
+
+    def exact_sliced_pass():
+        for i in range(R):
+            sxs[i](x, ys[i])
     T = 16 + (int(np.log2(kr)) if kr else 0)
     ab = (H // v) * ((H * T + 31) // 32) * 4 + (65536 + kr) * v * 2 + 2 * H + 4 * H + 2 * H
     out = {"what": f"VQuantLinear {H}x{H} v={v} k=65536+{kr} (T = {T} bits per index), ring of {R} layers; GB/s of the PACKED format's "
                    "algorithmic bytes for both routes (the sliced layouts read 4 bytes per element and table, 5 for k65536+256)"}
-    for key, fn in (("default", default_pass), ("sliced_layout", sliced_pass)):
+    for key, fn in (("default", default_pass), ("sliced_layout", sliced_pass)) + ((("exact_sliced_layout", exact_sliced_pass),) if exact_ok else ()):
         t = Timer(dev).run(fn, steps, warmup, regions)
         us = t["event_ms"] * 1e3 / (steps * R)
         out[key] = {"us_per_layer": us, "GBps": ab / us / 1e3, "frac_of_8TBps": ab / us / 1e3 / 8000.0}
     out["default"]["kernel"] = lib.vptq_quant_gemv_kernel_name(descs[0][0], 1, 0).decode()
+    out["default"]["what"] = "vptq_quant_gemv: centroid gathers through the caches (reference roundings); the module's route for layers the exact sliced kernel does not take"
     out["sliced_layout"]["kernel"] = "gemv_sliced_kernel"
+    out["sliced_layout"]["what"] = "OPT-IN folded arithmetic over the load-time derived layouts"
+    if exact_ok:
+        out["exact_sliced_layout"]["kernel"] = "gemv_sliced_kernel<EX>"
+        out["exact_sliced_layout"]["what"] = ("the reference's roundings over a load-time derived layout (LDS-local gathers): the module's one-token route "
+                                              "for this format in the default arithmetic")
+        out["exact_sliced_layout"]["slices"] = sxs[0].slices
+        exact_sliced_pass()
+        torch.cuda.synchronize()
+        got_x = ys[-1].clone()
     out["sliced_layout"]["layout_MiB_per_layer"] = sls[0].extra_bytes / 2**20
     out["sliced_layout"]["packed_index_MiB_per_layer"] = layers[0].indices.numel() * 4 / 2**20
     sliced_pass()
@@ -169,6 +187,9 @@ def k65536_extra(lib, B, dev, H, steps, warmup, regions, R=8, kr=256, v=8):
     layers[-1].enable_sliced_layout(False)   # (reference = the gather kernel, not the module's default one-token route)
     ref = layers[-1](x)
     out["sliced_vs_default_rel_diff"] = ((ys[-1].float() - ref.float()).abs().max() / ref.float().abs().max()).item()
+    if exact_ok:
+        out["exact_sliced_vs_default_bit_identical"] = float((got_x.view(torch.int16) == ref.view(torch.int16)).float().mean())
+        assert out["exact_sliced_vs_default_bit_identical"] >= 0.95, out
     # 2 and 4 tokens: the gather kernel (vptq_quant_gemv) against ONE launch over the same layouts (gemv_sliced_tok.hip:
     # column phases; 4 tokens contract on the matrix pipe), where the library takes the layer
     for tokens in (2, 4):
@@ -1130,8 +1151,8 @@ def main():
         for key in ("k65536_r256", "k65536_r65536", "v16_k65536_r65536"):
             e = ex.get(key) or {}
             sl = e.get("sliced_layout") or {}
-            df = e.get("default") or {}
-            if "us_per_layer" in df:     # the product default for the large-codebook formats: centroid gathers through the caches
+            df = e.get("exact_sliced_layout") or e.get("default") or {}
+            if "us_per_layer" in df:     # the product default: the exact sliced kernel where it serves the format, else centroid gathers through the caches
                 mp[key] = {"us_per_layer": df["us_per_layer"], "GBps_of_packed_bytes": df.get("GBps"), "frac": df.get("frac_of_8TBps"),
                            "kernel": df.get("kernel")}
             if "us_per_layer" in sl:     # ... and the opt-in folded arithmetic over the load-time derived sliced layouts
