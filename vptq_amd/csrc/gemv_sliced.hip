@@ -69,6 +69,10 @@ constexpr int kSLMaxGroup = 3;
 #ifndef VPTQ_SLICED_PRIO
 #define VPTQ_SLICED_PRIO 0
 #endif
+// 1: a block's LDS gathers are issued one step ahead of its arithmetic (two register sets); 0: gather, wait, compute per step
+#ifndef VPTQ_SLICED_PIPE
+#define VPTQ_SLICED_PIPE 1
+#endif
 // accumulator word of one output: bits [0, 7) arrivals, [7, 14) arrivals whose partial sum was NaN, [14, 64) the sum in
 // units of 2^-24 (50 bits signed: +-3.3e7; a partial sum beyond that - or an infinite one - saturates, which still rounds to
 // the 16-bit formats' infinity)
@@ -428,33 +432,34 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
       left = __builtin_amdgcn_readlane(my_blocks, row_i);
     }
   }
-  auto consume = [&](auto slot_c) __attribute__((always_inline)) {
-    constexpr int S = decltype(slot_c)::value;
-    const evec_t ev = eq[S];
-    if constexpr ((VPTQ_SLICED_ABLATE & 1) != 0) {
-      acc[0] += __uint_as_float(ev[0]);
-      return;
-    }
-    typedef __attribute__((address_space(3))) uint16_t lds_h_t;
-    constexpr int W4 = V / 8;   // 16-byte pieces of an entry
-    u32x4 ent[EPL][W4];
-    u32x4 rent = {0u, 0u, 0u, 0u};
-    uint16_t xh[EPL];
+  // ---- a block's work in two halves: FETCH (its element word -> LDS addresses -> the gathers go out) and MATH (on what a fetch
+  // brought).  VPTQ_SLICED_PIPE (round 5): block k's gathers are issued BEFORE block k - 1's arithmetic, into the other of two
+  // register sets - a wave then covers its own LDS latency instead of leaving that to the 3 other waves of its SIMD (the
+  // phase stamps showed the SIMD's issue bandwidth half idle: 100 cycles per step for 52 cycles of vector work).
+  typedef __attribute__((address_space(3))) uint16_t lds_h_t;
+  typedef __attribute__((address_space(3))) uint32_t lds_w_t;
+  constexpr int W4 = V / 8;   // 16-byte pieces of an entry
+  // (measured, profiles/r05/sliced_pipe_ab.txt: -1 ... -3 % without the 256-entry residual table, + 4 % with it - its third
+  // gather per block and 8 more live registers: those instantiations keep gather, wait, compute)
+  constexpr bool kPipe = VPTQ_SLICED_PIPE != 0 && !RES;
+  constexpr int kBufs = kPipe ? 2 : 1;
+  u32x4 g_ent[kBufs][W4];
+  u32x4 g_rent[kBufs];
+  uint32_t g_x[kBufs], g_sb[kBufs];
+  auto fetch = [&](auto slot_c, auto buf_c) __attribute__((always_inline)) {
+    constexpr int S = decltype(slot_c)::value, Bf = decltype(buf_c)::value;
+    const uint32_t e = eq[S][0];
+    if constexpr ((VPTQ_SLICED_ABLATE & 1) != 0) { g_x[Bf] = e; return; }
+    const uint32_t ea = (e >> 16) * kEntry;
 #pragma unroll
-    for (int k = 0; k < EPL; ++k) {
-      const uint32_t e = ev[k];
-      const uint32_t ea = (e >> 16) * kEntry;
-#pragma unroll
-      for (int w = 0; w < W4; ++w) ent[k][w] = lds_load16(ea + 16u * (uint32_t)w);
-      xh[k] = *(const lds_h_t*)(uintptr_t)(kSLXOff + ((e & 0xffffu) << 1));
-    }
-    if constexpr (RES) rent = lds_load16(res_off + (rq[S] << 4));
-    [[maybe_unused]] uint32_t sb[EPL];
-    if constexpr (EX) {
-      typedef __attribute__((address_space(3))) uint32_t lds_w_t;
-#pragma unroll
-      for (int k = 0; k < EPL; ++k) sb[k] = *(const lds_w_t*)(uintptr_t)(sb_off + ((ev[k] & 0xffffu) << 2));
-    }
+    for (int w = 0; w < W4; ++w) g_ent[Bf][w] = lds_load16(ea + 16u * (uint32_t)w);
+    g_x[Bf] = *(const lds_h_t*)(uintptr_t)(kSLXOff + ((e & 0xffffu) << 1));
+    if constexpr (RES) g_rent[Bf] = lds_load16(res_off + (rq[S] << 4));
+    if constexpr (EX) g_sb[Bf] = *(const lds_w_t*)(uintptr_t)(sb_off + ((e & 0xffffu) << 2));
+  };
+  auto math = [&](auto buf_c) __attribute__((always_inline)) {
+    constexpr int Bf = decltype(buf_c)::value;
+    if constexpr ((VPTQ_SLICED_ABLATE & 1) != 0) { acc[0] += __uint_as_float(g_x[Bf]); return; }
     // EX: the weight as the reference rounds it - u = f16(c + r), t = f16(u * s), w = f16(t + b): three packed instructions per
     // pair of outputs, scale and bias broadcast out of the column's word by op_sel - then w x in fp32
     auto weight = [&](uint32_t ew, uint32_t rw, uint32_t sbw) __attribute__((always_inline)) -> uint32_t {
@@ -465,52 +470,45 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
       }
       return ew;
     };
+    if constexpr (std::is_same<DT, F16>::value) {
+      // v_fma_mix_f32: fp16 x fp16 + fp32 -> fp32 in one instruction (exact product, one rounding: what
+      // fmaf of the converted values gives), halves picked by op_sel
+      const uint32_t xw = g_x[Bf];
 #pragma unroll
-    for (int k = 0; k < EPL; ++k) {
-      if constexpr (std::is_same<DT, F16>::value) {
-        // v_fma_mix_f32: fp16 x fp16 + fp32 -> fp32 in one instruction (exact product, one rounding: what
-        // fmaf of the converted values gives), halves picked by op_sel
-        const uint32_t xw = xh[k];
+      for (int i = 0; i < V / 2; ++i) {
+        float lo = acc[2 * i], hi = acc[2 * i + 1];   // (an asm operand cannot name a captured array element)
+        // 256-entry residual table: f16(c + r) first - the reference's own first rounding (vptq/ops/quant_gemm.py:121) -
+        // as ONE packed add per pair of outputs instead of a second pair of multiply-adds (round 5: the phase stamps
+        // showed this format's stream bound by vector issue, 25 instructions per block)
+        const uint32_t ew = weight(g_ent[Bf][i / 4][i % 4], RES ? g_rent[Bf][i % 4] : 0u, EX ? g_sb[Bf] : 0u);
+        asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,1,0]" : "+v"(lo) : "v"(ew), "v"(xw));
+        asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,0]" : "+v"(hi) : "v"(ew), "v"(xw));
+        acc[2 * i] = lo; acc[2 * i + 1] = hi;
+      }
+    } else {
+      const float xf = DT::to_float((uint16_t)g_x[Bf]);
 #pragma unroll
-        for (int i = 0; i < V / 2; ++i) {
-          float lo = acc[2 * i], hi = acc[2 * i + 1];   // (an asm operand cannot name a captured array element)
-          // 256-entry residual table: f16(c + r) first - the reference's own first rounding (vptq/ops/quant_gemm.py:121) -
-          // as ONE packed add per pair of outputs instead of a second pair of multiply-adds (round 5: the phase stamps
-          // showed this format's stream bound by vector issue, 25 instructions per block)
-          const uint32_t ew = weight(ent[k][i / 4][i % 4], rent[i % 4], EX ? sb[k] : 0u);
-          asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,1,0]" : "+v"(lo) : "v"(ew), "v"(xw));
-          asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,0]" : "+v"(hi) : "v"(ew), "v"(xw));
-          acc[2 * i] = lo; acc[2 * i + 1] = hi;
-        }
-      } else {
-        const float xf = DT::to_float(xh[k]);
-#pragma unroll
-        for (int i = 0; i < V / 2; ++i) {
-          // (folded bf16: c x + r x, two pairs of multiply-adds - a widened add would cost more than it saves)
-          const uint32_t ew = EX ? weight(ent[k][i / 4][i % 4], rent[i % 4], sb[k]) : ent[k][i / 4][i % 4];
-          acc[2 * i] = __builtin_fmaf(DT::to_float((uint16_t)(ew & 0xffffu)), xf, acc[2 * i]);
-          acc[2 * i + 1] = __builtin_fmaf(DT::to_float((uint16_t)(ew >> 16)), xf, acc[2 * i + 1]);
-          if constexpr (RES && !EX) {
-            acc[2 * i] = __builtin_fmaf(DT::to_float((uint16_t)(rent[i % 4] & 0xffffu)), xf, acc[2 * i]);
-            acc[2 * i + 1] = __builtin_fmaf(DT::to_float((uint16_t)(rent[i % 4] >> 16)), xf, acc[2 * i + 1]);
-          }
+      for (int i = 0; i < V / 2; ++i) {
+        // (folded bf16: c x + r x, two pairs of multiply-adds - a widened add would cost more than it saves)
+        const uint32_t c0 = g_ent[Bf][i / 4][i % 4];
+        const uint32_t ew = EX ? weight(c0, RES ? g_rent[Bf][i % 4] : 0u, g_sb[Bf]) : c0;
+        acc[2 * i] = __builtin_fmaf(DT::to_float((uint16_t)(ew & 0xffffu)), xf, acc[2 * i]);
+        acc[2 * i + 1] = __builtin_fmaf(DT::to_float((uint16_t)(ew >> 16)), xf, acc[2 * i + 1]);
+        if constexpr (RES && !EX) {
+          const uint32_t rw = g_rent[Bf][i % 4];
+          acc[2 * i] = __builtin_fmaf(DT::to_float((uint16_t)(rw & 0xffffu)), xf, acc[2 * i]);
+          acc[2 * i + 1] = __builtin_fmaf(DT::to_float((uint16_t)(rw >> 16)), xf, acc[2 * i + 1]);
         }
       }
     }
   };
-  auto step = [&](auto slot_c) __attribute__((always_inline)) {
-    __builtin_amdgcn_sched_barrier(0);
-    // (past the end of the wave's stream the steps of the last round only keep the loads counted: a stream is
-    // ~34 blocks long, so up to depth - 1 idle steps were 15 % of the launch while they still gathered and added)
-    if (!done) consume(slot_c);
-    __builtin_amdgcn_sched_barrier(0);
-    issue(slot_c);
-    __builtin_amdgcn_sched_barrier(0);
+  // the end of a row: `left` counts the blocks of the current row whose arithmetic is still to come
+  auto row_step = [&]() __attribute__((always_inline)) {
     if (--left == 0) {
       if (!done) store_row();
       ++row_i;
-      // next row with elements; after the last one the remaining steps of this loop iteration consume
-      // re-read blocks into sums nobody stores (ONE loop exit, at the end: gemv_k256c.hip)
+      // next row with elements; after the last one the remaining steps of this loop iteration only keep the loads
+      // counted (ONE loop exit, at the end: gemv_k256c.hip)
       left = 0;
       while (row_i < n_rows && left == 0) {
         left = __builtin_amdgcn_readlane(my_blocks, row_i);
@@ -518,6 +516,36 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
       }
       if (row_i >= n_rows) { done = true; left = 0x7fffffff; }
     }
+  };
+  static_assert(kSLQueue % 2 == 0 && EPL == 1, "two register sets alternate over an even number of slots");
+  // pipelined: block 0's gathers go out in front of the loop; the loop's step for slot S fetches THAT slot's block and then
+  // does the arithmetic of the block before it (slot S - 1): slots are walked 1, 2, ... Q - 1, 0
+  if constexpr (kPipe) {
+    if (!done) {
+      fetch(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+      __builtin_amdgcn_sched_barrier(0);
+      issue(std::integral_constant<int, 0>{});
+    }
+  }
+  auto step = [&](auto slot_c) __attribute__((always_inline)) {
+    constexpr int S = kPipe ? (decltype(slot_c)::value + 1) % kSLQueue : decltype(slot_c)::value;
+    __builtin_amdgcn_sched_barrier(0);
+    // (past the end of the wave's stream the steps of the last round only keep the loads counted: a stream is
+    // ~34 blocks long, so up to depth - 1 idle steps were 15 % of the launch while they still gathered and added)
+    if (!done) {
+      if constexpr (kPipe) {
+        fetch(std::integral_constant<int, S>{}, std::integral_constant<int, S & 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        math(std::integral_constant<int, (S & 1) ^ 1>{});
+      } else {
+        fetch(std::integral_constant<int, S>{}, std::integral_constant<int, 0>{});
+        math(std::integral_constant<int, 0>{});
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    issue(std::integral_constant<int, S>{});
+    __builtin_amdgcn_sched_barrier(0);
+    row_step();
   };
   while (!done) {   // (waves without elements skip it; ONE exit for the others)
     sl_for_slots<kSLQueue>(step);
