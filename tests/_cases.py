@@ -113,7 +113,7 @@ def load_big(name, directory=None):
         L.bias = t["bias"]
     # y rows the fixture keeps (gen_golden_big.py:stored_rows): all up to 64 tokens, every 8th + the last beyond
     T = cfg["tokens"]
-    cfg["y_rows"] = list(range(T)) if T <= 64 else sorted(set(range(0, T, 8)) | {T - 1})
+    cfg["y_rows"] = list(range(T)) if T <= 64 else sorted(set(range(0, T, 8 if T <= 1024 else 256)) | {T - 1})
     return L, t["x"].reshape(1, cfg["tokens"], I), z["y"], cfg, z["W_head"]
 
 

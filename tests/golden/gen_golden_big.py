@@ -43,14 +43,17 @@ BIG_CASES = [
     ("h4096_bf16_llm_t64", 4096, 4096, False, False, "bf16", 64, "llm"),
     ("h4096_f16_llm_t256", 4096, 4096, False, False, "f16", 256, "llm"),
     ("h4096_bf16_llm_t256", 4096, 4096, False, False, "bf16", 256, "llm"),
+    # round 5: BASELINE configs[3]'s real token count (batch 4 x seq 2048 = 8192 tokens, bf16); every 256th token row of y
+    # is stored (+ the last one): 33 rows
+    ("h4096_bf16_llm_t8192", 4096, 4096, False, False, "bf16", 8192, "llm"),
 ]
 
 
 def stored_rows(tokens):
-    """token rows of y a fixture keeps: all of them up to 64 tokens, every 8th + the last beyond"""
+    """token rows of y a fixture keeps: all of them up to 64 tokens, every 8th + the last up to 1024, every 256th + the last beyond"""
     if tokens <= 64:
         return list(range(tokens))
-    return sorted(set(range(0, tokens, 8)) | {tokens - 1})
+    return sorted(set(range(0, tokens, 8 if tokens <= 1024 else 256)) | {tokens - 1})
 
 
 def main():

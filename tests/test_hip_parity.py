@@ -767,9 +767,9 @@ def test_baseline_size_goldens_every_kernel_and_form(name, dev):
     print(name, seen)
 
 
-@pytest.mark.parametrize("name", [n for n in big_names() if n.endswith(("_t64", "_t256"))])
+@pytest.mark.parametrize("name", [n for n in big_names() if n.endswith(("_t64", "_t256", "_t8192"))])
 def test_many_token_routes_vs_reference_goldens(name, dev):
-    """64 and 256 tokens through a 4096^2 layer against the REAL reference's prefill branch (dequant +
+    """64, 256 and 8192 (BASELINE configs[3]: batch 4 x seq 2048, bf16) tokens through a 4096^2 layer against the REAL reference's prefill branch (dequant +
     F.linear, /root/reference/vptq/ops/quant_gemm.py:231-274; fixtures: tests/golden/gen_golden_big.py):
     the module's own route, the cached dense route, the fused dequant-tile GEMM, and - 64 tokens, fp16 -
     the batched-decode kernel (4 launches of 16 tokens)."""

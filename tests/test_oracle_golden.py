@@ -110,7 +110,8 @@ def test_c_oracle_vs_reference_at_baseline_sizes(name):
     W = co.dequant(L)
     assert (W[:2] == W_head).all()
     assert hashlib.sha256(W.tobytes()).hexdigest() == cfg["W_sha256"]
-    out = stored_rows(co.forward(L, x), cfg)
+    # (thousands of tokens: only the token rows the fixture stores go through the oracle - rows are independent)
+    out = co.forward(L, np.ascontiguousarray(x[:, cfg["y_rows"]])) if cfg["tokens"] > 1024 else stored_rows(co.forward(L, x), cfg)
     assert rel_err(out, y, cfg["dtype"]) <= Y_TOL[cfg["dtype"]]
     assert bit_identical_frac(out, y) >= 0.98
 
@@ -120,7 +121,7 @@ def test_numpy_oracle_vs_reference_at_hidden_4096(name):
     L, x, y, cfg, W_head = load_big(name)
     W = vo.dequant(L)
     assert hashlib.sha256(W.tobytes()).hexdigest() == cfg["W_sha256"]
-    out = stored_rows(vo.forward(L, x), cfg)
+    out = vo.forward(L, np.ascontiguousarray(x[:, cfg["y_rows"]])) if cfg["tokens"] > 1024 else stored_rows(vo.forward(L, x), cfg)
     assert rel_err(out, y, cfg["dtype"]) <= Y_TOL[cfg["dtype"]]
     assert bit_identical_frac(out, y) >= 0.98
 
