@@ -296,7 +296,9 @@ typedef struct VptqSlicedLayout {
   const void* elems;
   const void* blocks;
   const void* first;
-  const void* res;          /* uint8 per element (same order, padding = 0): residual index; NULL without residual */
+  const void* res;          /* uint8 per element (same order, padding = 0): residual index of v = 8's 256-entry table; NULL without
+                             * residual codebook.  VPTQ_GEMV_EXACT layouts (ABI >= 8) of layers with ANY OTHER residual codebook:
+                             * uint16 per element - the residual entry is gathered from the codebook in device memory */
   int32_t rows_per_wave;
   int32_t elems_per_lane;   /* 1 (or 0): a block = 64 elements */
   int32_t n_slices;         /* 8 (or 0) / 16 / 32: what vptq_sliced_layout_supported() answers for the layer */
@@ -315,10 +317,12 @@ typedef struct VptqSlicedLayout {
 VPTQ_API int vptq_sliced_layout_supported(const VptqLayerDesc* desc);
 /* ... and for the arithmetic a call will ask for (ABI >= 8): flags = 0 as above; VPTQ_GEMV_EXACT - the reference's roundings per
  * weight, w = f16(f16(f16(c + r) * s) + b) (vptq/ops/quant_gemm.py:121,155-156), what gemv_gather computes through the caches -
- * takes layers without a residual codebook or with the 256-entry one of v = 8 (c and r must meet in one lane: one table) and
- * stages scale, bias and x of every column beside the slice, 6 instead of 2 bytes of LDS per column: v = 8: 8 slices up to
- * 5376 columns (4704 with the residual table), 16 up to 16288 (15616); v = 16: 16 / 32; wider layers: 0.  A layout built with
- * THAT slice count serves vptq_quant_gemv_sliced(..., flags | VPTQ_GEMV_EXACT, ...); one token only. */
+ * needs c and r in one lane, so it always takes ONE layout, bucketed by the main index (vptq_sliced_layout_tables() is the folded
+ * form's answer): no residual codebook; v = 8 with 256 residual centroids (`res` bytes, table in LDS); any other residual
+ * codebook: `res` = uint16 residual indices, the entry gathered from device memory (one of the gather kernel's two cache
+ * gathers per element).  Scale, bias and x of every column sit beside the slice, 6 instead of 2 bytes of LDS per column:
+ * v = 8: 8 slices up to 5376 columns (4704 with the 256-entry table), 16 up to 16288 (15616); v = 16: 16 / 32; wider layers: 0.
+ * A layout built with THAT slice count serves vptq_quant_gemv_sliced(..., flags | VPTQ_GEMV_EXACT, ...); one token only. */
 VPTQ_API int vptq_sliced_layout_supported_for(const VptqLayerDesc* desc, int flags);
 /* 0, or how many consecutive VptqSlicedLayout structs vptq_quant_gemv_sliced takes for this layer: 1 (no residual codebook;
  * v = 8 with 256 residual centroids: `res` bytes), 2 (any other residual codebook: a second table with a layout of its own) */

@@ -498,13 +498,17 @@ int vptq_quant_gemv_sliced(const VptqLayerDesc* d, const VptqSlicedLayout* layou
   const size_t need = vptq::gemv_sliced_workspace_bytes(*d);
   if (!workspace || workspace_bytes < need || (((uintptr_t)workspace) & 15) != 0)
     return fail(VPTQ_E_WORKSPACE, "workspace of %zu bytes (16-byte aligned) needed", need);
-  const int n_layouts = vptq::gemv_sliced_tables(*d);   // (two tables: one layout per table, consecutive structs)
+  // (folded, two tables: one layout per table, consecutive structs; the reference's roundings: always ONE layout)
+  const int n_layouts = exact ? 1 : vptq::gemv_sliced_tables(*d);
   for (int i = 0; i < n_layouts; ++i) {
     if (layout[i].rows_per_wave < 1 || layout[i].rows_per_wave > 64 || !layout[i].elems || !layout[i].blocks || !layout[i].first ||
         (layout[i].n_slices != 0 ? layout[i].n_slices : 8) != vptq::gemv_sliced_slices(*d, exact))
       return fail(VPTQ_E_UNSUPPORTED, "sliced layout %d: rows_per_wave in [1, 64], three tensors, n_slices = %d for this layer and arithmetic",
                   i, vptq::gemv_sliced_slices(*d, exact));
-    if (layout[i].whole_table != vptq::gemv_sliced_whole_table(*d, i) || layout[i].rows_per_wave != layout[0].rows_per_wave)
+    if (exact && d->num_res_centroids > 0 && (!layout[i].res || (((uintptr_t)layout[i].res) & 1) != 0))
+      return fail(VPTQ_E_UNSUPPORTED, "VPTQ_GEMV_EXACT over a sliced layout of a layer with a residual codebook needs the layout's `res` "
+                  "side stream (uint8 for v = 8 with 256 residual centroids, else uint16)");
+    if (layout[i].whole_table != (exact ? 0 : vptq::gemv_sliced_whole_table(*d, i)) || layout[i].rows_per_wave != layout[0].rows_per_wave)
       return fail(VPTQ_E_UNSUPPORTED, "sliced layout %d: whole_table must be %d (vptq_sliced_layout_whole_table) and rows_per_wave the "
                   "same for both tables", i, vptq::gemv_sliced_whole_table(*d, i));
   }
@@ -552,7 +556,7 @@ int vptq_quant_gemv_sliced_grouped(const VptqLayerDesc* descs, const VptqSlicedL
   if (!vptq::gemv_sliced_groupable(descs, n, exact))
     return fail(VPTQ_E_UNSUPPORTED, "a sliced group takes layers of ONE format, dtype and input width that vptq_sliced_layout_supported_for() accepts");
   if ((((uintptr_t)x) & 15) != 0) return fail(VPTQ_E_UNSUPPORTED, "x must be 16-byte aligned");
-  const int tables = vptq::gemv_sliced_tables(descs[0]);
+  const int tables = exact ? 1 : vptq::gemv_sliced_tables(descs[0]);
   for (int i = 0; i < n; ++i) {
     const size_t need = vptq::gemv_sliced_workspace_bytes(descs[i]);
     if (!workspaces[i] || workspace_bytes[i] < need || (((uintptr_t)workspaces[i]) & 15) != 0)
@@ -563,7 +567,9 @@ int vptq_quant_gemv_sliced_grouped(const VptqLayerDesc* descs, const VptqSlicedL
           (L.n_slices != 0 ? L.n_slices : 8) != vptq::gemv_sliced_slices(descs[i], exact))
         return fail(VPTQ_E_UNSUPPORTED, "layer %d, sliced layout %d: rows_per_wave in [1, 64], three tensors, n_slices = %d", i, t,
                     vptq::gemv_sliced_slices(descs[i], exact));
-      if (L.whole_table != vptq::gemv_sliced_whole_table(descs[i], t) || L.rows_per_wave != layouts[0].rows_per_wave)
+      if (exact && descs[i].num_res_centroids > 0 && (!L.res || (((uintptr_t)L.res) & 1) != 0))
+        return fail(VPTQ_E_UNSUPPORTED, "layer %d: VPTQ_GEMV_EXACT needs the layout's `res` side stream", i);
+      if (L.whole_table != (exact ? 0 : vptq::gemv_sliced_whole_table(descs[i], t)) || L.rows_per_wave != layouts[0].rows_per_wave)
         return fail(VPTQ_E_UNSUPPORTED, "layer %d, sliced layout %d: whole_table must be %d and rows_per_wave the group's", i, t,
                     vptq::gemv_sliced_whole_table(descs[i], t));
     }

@@ -100,7 +100,11 @@ struct SlicedGroupParams {
 // (vptq/ops/quant_gemm.py:121,155-156), y = sum w x in fp32: what gemv_gather computes, here with LDS-local gathers.  The
 // column's scale and bias are staged as a word per column beside the raw activations (6 instead of 2 bytes per column: the
 // host picks 16 slices where 8 no longer fit); one table only - c and r must meet in one lane.
-template <typename DT, int NSL, bool RES, int V = 8, bool TWO = false, bool EX = false>
+// RG (EX only): any OTHER residual codebook (2 ... 65536 entries: the "4 bit" v8-k65536-65536, the "2 bit" v16-k65536-65536, ...) in
+// the reference's roundings - c and r must meet in one lane, and a second 1 - 2 MiB table cannot sit in LDS as well: the main
+// entry comes out of the LDS slice, the residual entry is GATHERED FROM L2 by its index (a uint16 side stream of the layout), a
+// second queue stage ahead of the arithmetic.  One of the gather kernel's two cache gathers per element instead of both.
+template <typename DT, int NSL, bool RES, int V = 8, bool TWO = false, bool EX = false, bool RG = false>
 __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGroupParams GP) {
   // this workgroup's layer; its parameters come out of the kernel-argument segment through the scalar cache (a run-time
   // index into the by-value argument would make the compiler copy it to scratch memory)
@@ -118,14 +122,16 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
   const SlicedParams P = GP.p[0];   // (host pass of the compiler: never executed)
 #endif
   static_assert(((V == 8 && (NSL == 8 || NSL == 16)) || (V == 16 && (NSL == 16 || NSL == 32))) && (V == 8 || !RES) && !(TWO && RES) &&
-                !(EX && TWO), "slices");
+                !(EX && TWO) && (!RG || (EX && !RES && !TWO)), "slices");
   constexpr int NSLT = TWO ? 2 * NSL : NSL;   // workgroups per row block: one per (table, slice)
   constexpr int EPL = 1;   // element words per lane and block (2 and 4 - 8 / 16-byte loads - were measured: no difference)
   constexpr uint32_t kEntry = V * 2u;                          // bytes of a codebook entry
   const uint32_t kSLXOff = P.x_off;                          // staged activations: (G + 64) halves, behind the table
   typedef uint32_t evec_t __attribute__((ext_vector_type(EPL)));
-  constexpr int kLoadsPerStep = RES ? 2 : 1;
-  constexpr int kSLQueue = kSLQueueWords / EPL < 2 ? 2 : kSLQueueWords / EPL;   // blocks in flight per wave
+  constexpr int kLoadsPerStep = (RES || RG) ? 2 : 1;
+  // blocks in flight per wave (RG, v = 16: 4 - the gathered residual entries of the second stage are 8 registers each)
+  constexpr int kSLQueue = (RG && V == 16) ? 4 : (kSLQueueWords / EPL < 2 ? 2 : kSLQueueWords / EPL);
+  constexpr int W4 = V / 8;   // 16-byte pieces of an entry
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   {
     typedef __attribute__((address_space(3))) unsigned char lds_u8_t;
@@ -286,9 +292,10 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
 
   // (4) element queue: block k of the stream -> slot k % kSLQueue
   evec_t eq[kSLQueue];
-  uint32_t rq[RES ? kSLQueue : 1];
+  uint32_t rq[(RES || RG) ? kSLQueue : 1];
   const evec_t* const ep = (const evec_t*)(as_global(elems_t) + (size_t)first_block * (64 * EPL)) + lane;
   const uint8_t* const rp = RES ? as_global(P.res) + (size_t)first_block * 64 + lane : nullptr;
+  const uint16_t* const rp16 = RG ? (const uint16_t*)as_global(P.res) + (size_t)first_block * 64 + lane : nullptr;
   const int last = total > 0 ? total - 1 : 0;
   int i_next = 0;
   // (past the end of the stream a step still issues its load - every step the same instructions, so the waits
@@ -298,6 +305,7 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
     const size_t b64 = (size_t)(i_next < last ? i_next : last) * 64;
     eq[S] = __builtin_nontemporal_load(ep + b64);
     if constexpr (RES) rq[S] = rp[b64];
+    if constexpr (RG) rq[S] = rp16[b64];
     ++i_next;
   };
   sl_for_slots<kSLQueue>([&](auto slot_c) {
@@ -317,9 +325,29 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
       if (lane == 0) *(float*)(smem + bd_off + (uint32_t)wave * 4u) = bd;
     }
   }
+  // RG: the second queue stage.  Slot S keeps the element word of the block whose residual entry is on its way (ew) and that
+  // entry (rgq); `gather` moves the slot's freshly arrived (element word, residual index) there and asks for the entry.  Primed
+  // here: blocks 0 .. Q - 1 go to the second stage, blocks Q .. 2 Q - 1 are requested behind them.
+  [[maybe_unused]] uint32_t ew[RG ? kSLQueue : 1];
+  [[maybe_unused]] u32x4 rgq[RG ? kSLQueue : 1][W4];
+  [[maybe_unused]] auto gather = [&](auto slot_c) __attribute__((always_inline)) {
+    constexpr int S = decltype(slot_c)::value;
+    ew[S] = eq[S][0];
+    const char* const ra = (const char*)as_global(P.rcent) + (size_t)rq[S] * kEntry;
+#pragma unroll
+    for (int w = 0; w < W4; ++w) rgq[S][w] = *(const u32x4*)(ra + 16 * w);
+  };
+  if constexpr (RG) {
+    sl_for_slots<kSLQueue>([&](auto slot_c) {
+      gather(slot_c);
+      __builtin_amdgcn_sched_barrier(0);
+      issue(slot_c);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  }
   // the DMA and the staging loads are done before anybody reads LDS (the queue loads stay in flight)
   {   // (as a builtin: the compiler sees it and keeps counting from here)
-    constexpr int kN = kSLQueue * kLoadsPerStep;
+    constexpr int kN = RG ? kSLQueue * (W4 + 2) : kSLQueue * kLoadsPerStep;
     __builtin_amdgcn_s_waitcnt(0x0F70 | (kN & 15) | ((kN >> 4) << 14));   // vmcnt(kN), nothing else
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
@@ -438,17 +466,16 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
   // phase stamps showed the SIMD's issue bandwidth half idle: 100 cycles per step for 52 cycles of vector work).
   typedef __attribute__((address_space(3))) uint16_t lds_h_t;
   typedef __attribute__((address_space(3))) uint32_t lds_w_t;
-  constexpr int W4 = V / 8;   // 16-byte pieces of an entry
   // (measured, profiles/r05/sliced_pipe_ab.txt: -1 ... -3 % without the 256-entry residual table, + 4 % with it - its third
   // gather per block and 8 more live registers: those instantiations keep gather, wait, compute)
-  constexpr bool kPipe = VPTQ_SLICED_PIPE != 0 && !RES;
+  constexpr bool kPipe = VPTQ_SLICED_PIPE != 0 && !RES && !RG;
   constexpr int kBufs = kPipe ? 2 : 1;
   u32x4 g_ent[kBufs][W4];
   u32x4 g_rent[kBufs];
   uint32_t g_x[kBufs], g_sb[kBufs];
   auto fetch = [&](auto slot_c, auto buf_c) __attribute__((always_inline)) {
     constexpr int S = decltype(slot_c)::value, Bf = decltype(buf_c)::value;
-    const uint32_t e = eq[S][0];
+    const uint32_t e = RG ? ew[S] : eq[S][0];
     if constexpr ((VPTQ_SLICED_ABLATE & 1) != 0) { g_x[Bf] = e; return; }
     const uint32_t ea = (e >> 16) * kEntry;
 #pragma unroll
@@ -457,13 +484,14 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
     if constexpr (RES) g_rent[Bf] = lds_load16(res_off + (rq[S] << 4));
     if constexpr (EX) g_sb[Bf] = *(const lds_w_t*)(uintptr_t)(sb_off + ((e & 0xffffu) << 2));
   };
-  auto math = [&](auto buf_c) __attribute__((always_inline)) {
+  auto math = [&](auto buf_c, auto slot_c) __attribute__((always_inline)) {
     constexpr int Bf = decltype(buf_c)::value;
+    [[maybe_unused]] constexpr int S = decltype(slot_c)::value;   // (RG: the residual entry sits in the slot's second stage)
     if constexpr ((VPTQ_SLICED_ABLATE & 1) != 0) { acc[0] += __uint_as_float(g_x[Bf]); return; }
     // EX: the weight as the reference rounds it - u = f16(c + r), t = f16(u * s), w = f16(t + b): three packed instructions per
     // pair of outputs, scale and bias broadcast out of the column's word by op_sel - then w x in fp32
     auto weight = [&](uint32_t ew, uint32_t rw, uint32_t sbw) __attribute__((always_inline)) -> uint32_t {
-      if constexpr (RES) ew = DT::add2(ew, rw);
+      if constexpr (RES || RG) ew = DT::add2(ew, rw);
       if constexpr (EX) {
         ew = DT::mul2_bcast(ew, sbw, 0);
         ew = DT::add2_bcast(ew, sbw, 1);
@@ -480,7 +508,7 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
         // 256-entry residual table: f16(c + r) first - the reference's own first rounding (vptq/ops/quant_gemm.py:121) -
         // as ONE packed add per pair of outputs instead of a second pair of multiply-adds (round 5: the phase stamps
         // showed this format's stream bound by vector issue, 25 instructions per block)
-        const uint32_t ew = weight(g_ent[Bf][i / 4][i % 4], RES ? g_rent[Bf][i % 4] : 0u, EX ? g_sb[Bf] : 0u);
+        const uint32_t ew = weight(g_ent[Bf][i / 4][i % 4], RES ? g_rent[Bf][i % 4] : (RG ? rgq[RG ? S : 0][i / 4][i % 4] : 0u), EX ? g_sb[Bf] : 0u);
         asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,1,0]" : "+v"(lo) : "v"(ew), "v"(xw));
         asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,0]" : "+v"(hi) : "v"(ew), "v"(xw));
         acc[2 * i] = lo; acc[2 * i + 1] = hi;
@@ -491,7 +519,7 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
       for (int i = 0; i < V / 2; ++i) {
         // (folded bf16: c x + r x, two pairs of multiply-adds - a widened add would cost more than it saves)
         const uint32_t c0 = g_ent[Bf][i / 4][i % 4];
-        const uint32_t ew = EX ? weight(c0, RES ? g_rent[Bf][i % 4] : 0u, g_sb[Bf]) : c0;
+        const uint32_t ew = EX ? weight(c0, RES ? g_rent[Bf][i % 4] : (RG ? rgq[RG ? S : 0][i / 4][i % 4] : 0u), g_sb[Bf]) : c0;
         acc[2 * i] = __builtin_fmaf(DT::to_float((uint16_t)(ew & 0xffffu)), xf, acc[2 * i]);
         acc[2 * i + 1] = __builtin_fmaf(DT::to_float((uint16_t)(ew >> 16)), xf, acc[2 * i + 1]);
         if constexpr (RES && !EX) {
@@ -536,13 +564,17 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
       if constexpr (kPipe) {
         fetch(std::integral_constant<int, S>{}, std::integral_constant<int, S & 1>{});
         __builtin_amdgcn_sched_barrier(0);
-        math(std::integral_constant<int, (S & 1) ^ 1>{});
+        math(std::integral_constant<int, (S & 1) ^ 1>{}, std::integral_constant<int, 0>{});
       } else {
         fetch(std::integral_constant<int, S>{}, std::integral_constant<int, 0>{});
-        math(std::integral_constant<int, 0>{});
+        math(std::integral_constant<int, 0>{}, std::integral_constant<int, S>{});
       }
     }
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (RG) {   // the slot's (element word, residual index) - requested a round ago - move to the second stage
+      gather(std::integral_constant<int, S>{});
+      __builtin_amdgcn_sched_barrier(0);
+    }
     issue(std::integral_constant<int, S>{});
     __builtin_amdgcn_sched_barrier(0);
     row_step();
@@ -573,8 +605,9 @@ int gemv_sliced_tables(const VptqLayerDesc& d) { return sl_two(d) ? 2 : 1; }
 static bool sl_shape_ok(const VptqLayerDesc& d, bool exact);
 bool gemv_sliced_eligible(const VptqLayerDesc& d, bool exact) {
   const int T = d.index_bits + d.res_bits;
-  // the reference's roundings: c and r must meet in one lane (one table), bias in column order
-  if (exact && (sl_two(d) || (d.perm != nullptr && (d.bias_permuted == nullptr || (((uintptr_t)d.bias_permuted) & 15) != 0)))) return false;
+  // the reference's roundings: bias in column order (c and r meet in one lane: a residual codebook other than v8's 256-entry
+  // one is gathered from L2 by a side stream of 16-bit indices - ONE layout, bucketed by the main index)
+  if (exact && d.perm != nullptr && (d.bias_permuted == nullptr || (((uintptr_t)d.bias_permuted) & 15) != 0)) return false;
   return sl_shape_ok(d, exact) && (d.vector_len == 8 || d.vector_len == 16) && d.num_codebooks == 1 && d.outlier_size == 0 &&
          d.num_centroids >= 16384 && d.num_centroids <= 65536 && sl_pow2(d.num_centroids) && (1 << d.index_bits) == d.num_centroids &&
          (d.num_res_centroids == 0 || (d.num_res_centroids >= 2 && d.num_res_centroids <= 65536 && sl_pow2(d.num_res_centroids) &&
@@ -650,9 +683,9 @@ size_t gemv_sliced_workspace_bytes(const VptqLayerDesc& d) {
   return partial + counters;
 }
 
-template <typename DT, int NSL, bool RES, int V, bool TWO, bool EX = false>
+template <typename DT, int NSL, bool RES, int V, bool TWO, bool EX = false, bool RG = false>
 static hipError_t launch_sl(const SlicedGroupParams& P, uint32_t lds, hipStream_t st) {
-  auto kern = gemv_sliced_kernel<DT, NSL, RES, V, TWO, EX>;
+  auto kern = gemv_sliced_kernel<DT, NSL, RES, V, TWO, EX, RG>;
   static std::atomic<bool> attr_set[64];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
@@ -666,8 +699,11 @@ static hipError_t launch_sl(const SlicedGroupParams& P, uint32_t lds, hipStream_
 }
 template <typename DT>
 static hipError_t launch_sl_dt(const SlicedGroupParams& P, int v, int nsl, bool res, bool two, bool exact, uint32_t lds, hipStream_t st) {
-  if (exact) {   // the reference's roundings: one table
-    if (two) return hipErrorInvalidValue;
+  if (exact) {   // the reference's roundings: one layout; another residual codebook than the 256-entry one comes from L2 (RG)
+    if (two) {
+      if (v == 16) return nsl == 16 ? launch_sl<DT, 16, false, 16, false, true, true>(P, lds, st) : launch_sl<DT, 32, false, 16, false, true, true>(P, lds, st);
+      return nsl == 8 ? launch_sl<DT, 8, false, 8, false, true, true>(P, lds, st) : launch_sl<DT, 16, false, 8, false, true, true>(P, lds, st);
+    }
     if (v == 16) return nsl == 16 ? launch_sl<DT, 16, false, 16, false, true>(P, lds, st) : launch_sl<DT, 32, false, 16, false, true>(P, lds, st);
     if (nsl == 8) return res ? launch_sl<DT, 8, true, 8, false, true>(P, lds, st) : launch_sl<DT, 8, false, 8, false, true>(P, lds, st);
     return res ? launch_sl<DT, 16, true, 8, false, true>(P, lds, st) : launch_sl<DT, 16, false, 8, false, true>(P, lds, st);
@@ -696,17 +732,18 @@ bool sl_layout_ok(const VptqLayerDesc& d, const VptqSlicedLayout& L, int nsl, bo
 static hipError_t sl_fill(const VptqLayerDesc& d, const VptqSlicedLayout* L, const void* x, void* y, int flags, void* ws,
                           SlicedParams& P, uint32_t& lds) {
   const bool exact = (flags & VPTQ_GEMV_EXACT) != 0;
-  const bool res = sl_res256(d), two = sl_two(d);
+  const bool res = sl_res256(d), rg = exact && sl_two(d), two = sl_two(d) && !exact;
   const int nsl = gemv_sliced_slices(d, exact);
-  if (nsl == 0 || !sl_layout_ok(d, L[0], nsl, res, d.num_centroids) || L[0].whole_table != 0 ||
+  if (nsl == 0 || !sl_layout_ok(d, L[0], nsl, res || rg, d.num_centroids) || L[0].whole_table != 0 ||
+      (rg && (((uintptr_t)L[0].res) & 1) != 0) ||
       (two && (!sl_layout_ok(d, L[1], nsl, false, d.num_res_centroids) || L[1].rows_per_wave != L[0].rows_per_wave ||
                L[1].whole_table != gemv_sliced_whole_table(d, 1))) ||
       !ws || (((uintptr_t)x) & 15) != 0)
     return hipErrorInvalidValue;
   P = SlicedParams{};
   P.elems = (const uint32_t*)L[0].elems;
-  P.res = res ? (const uint8_t*)L[0].res : nullptr;
-  P.rcent = res ? (const uint32_t*)d.res_centroids : nullptr;
+  P.res = (res || rg) ? (const uint8_t*)L[0].res : nullptr;   // (rg: uint16 per element)
+  P.rcent = (res || rg) ? (const uint32_t*)d.res_centroids : nullptr;
   P.blocks = (const int32_t*)L[0].blocks;
   P.first = (const int32_t*)L[0].first;
   P.cent = (const uint32_t*)d.centroids;
@@ -757,7 +794,7 @@ hipError_t launch_gemv_sliced_group(const VptqLayerDesc* d, const VptqSlicedLayo
   SlicedGroupParams GP = {};
   GP.n = n;
   uint32_t lds = 0;
-  const int tables = gemv_sliced_tables(d[0]);
+  const int tables = exact ? 1 : gemv_sliced_tables(d[0]);
   const int nsl = gemv_sliced_slices(d[0], exact);
   const int nslt = nsl * tables;
   for (int i = 0; i < n; ++i) {
@@ -770,7 +807,7 @@ hipError_t launch_gemv_sliced_group(const VptqLayerDesc* d, const VptqSlicedLayo
   for (int i = n; i < kSLMaxGroup; ++i) GP.start[i + 1] = GP.start[n];
   return d[0].dtype == VPTQ_DTYPE_F16
              ? launch_sl_dt<F16>(GP, d[0].vector_len, nsl, sl_res256(d[0]), sl_two(d[0]), exact, lds, st)
-             : launch_sl_dt<BF16>(GP, d[0].vector_len, nsl, sl_res256(d[0]), sl_two(d[0]), exact, lds, st);
+             : launch_sl_dt<BF16>(GP, d[0].vector_len, nsl, sl_res256(d[0]), sl_two(d[0]), exact, lds, st);   // (exact && two = RG)
 }
 hipError_t launch_gemv_sliced(const VptqLayerDesc& d, const VptqSlicedLayout* L, const void* x, void* y, int flags,
                               void* ws, hipStream_t st) {

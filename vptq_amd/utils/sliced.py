@@ -49,9 +49,11 @@ def build_sliced_layout(indices: torch.Tensor, group_size: int, slices: int = 8,
 
 
 def layout_from_indices(idx: torch.Tensor, slices: int = 8, ridx: torch.Tensor = None, index_bits: int = INDEX_BITS,
-                        whole_table: bool = False):
+                        whole_table: bool = False, side_dtype=torch.uint8):
     """idx [N, G] int64 (values < 2^index_bits): the index each element gathers with from the table this layout is for;
-    ridx: an 8-bit side index carried along per element (the 256-entry residual table of v = 8), or None.  Elements are
+    ridx: a side index carried along per element, or None - 8 bits (the 256-entry residual table of v = 8, held in LDS) or, for
+    the reference's roundings with any other residual codebook, 16 bits as int16 bit patterns (`side_dtype=torch.int16`: the
+    residual entry is gathered from device memory).  Elements are
     bucketed by the top log2(slices) bits of idx and the element word carries idx inside its slice; or - whole_table:
     every workgroup of the table holds the whole (small) table - split into equal column ranges, the word carrying idx itself."""
     assert slices in (8, 16, 32) and 1 <= index_bits <= 16
@@ -116,8 +118,11 @@ def layout_from_indices(idx: torch.Tensor, slices: int = 8, ridx: torch.Tensor =
     elems32 = torch.where(elems32 >= (1 << 31), elems32 - (1 << 32), elems32).to(torch.int32)
     res = None
     if residual:
-        res = torch.zeros(elems.numel(), dtype=torch.uint8, device=dev)
-        res[dest.reshape(-1)] = torch.gather(ridx, 1, order).reshape(-1).to(torch.uint8)
+        res = torch.zeros(elems.numel(), dtype=side_dtype, device=dev)
+        rv = torch.gather(ridx, 1, order).reshape(-1)
+        if side_dtype == torch.int16:       # (uint16 bit patterns)
+            rv = torch.where(rv >= 32768, rv - 65536, rv)
+        res[dest.reshape(-1)] = rv.to(side_dtype)
     # wstart [slices][N][WINDOWS + 1]: position inside the (s, n) list at which window w begins; [WINDOWS] = the list's length
     cntw = torch.zeros(N, SLICES * WINDOWS, dtype=torch.int64, device=dev)
     cntw.scatter_add_(1, sw, torch.ones_like(sw))
@@ -153,7 +158,10 @@ class SlicedGemv:
         kr = layer.num_res_centroids if layer.enable_residual else 0
         ib = int(layer.num_centroids).bit_length() - 1
         rb = int(kr).bit_length() - 1 if kr else 0
-        n_tables = B.lib().vptq_sliced_layout_tables(self.desc)
+        # (the reference's roundings need c and r in one lane: always ONE layout, bucketed by the main index; a residual codebook
+        # other than v8's 256-entry one rides along as a 16-bit side stream and its entries are gathered from device memory)
+        n_tables = 1 if self.exact else B.lib().vptq_sliced_layout_tables(self.desc)
+        side16 = self.exact and kr > 0 and not (layer.vector_len == 8 and kr == 256)
         # a second table whose slice would be under 16 KiB is held WHOLE by each of its workgroups while it fits (the
         # library decides: the kernel's LDS budget)
         whole = [False, n_tables == 2 and bool(B.lib().vptq_sliced_layout_whole_table(self.desc, 1))]
@@ -162,7 +170,8 @@ class SlicedGemv:
             # (c + r) s x = c s x + r s x: the residual codebook is a second table with a layout bucketed by ITS index
             self._tensors = [layout_from_indices(idx, self.slices, None, ib), layout_from_indices(ridx, self.slices, None, rb, whole[1])]
         else:
-            self._tensors = [layout_from_indices(idx, self.slices, ridx if kr else None, ib)]
+            self._tensors = [layout_from_indices(idx, self.slices, ridx if kr else None, ib,
+                                                 side_dtype=torch.int16 if side16 else torch.uint8)]
         del idx, ridx
         self._whole = whole[:len(self._tensors)]
         self.elems, self.blocks, self.first, self.res, self.wstart = self._tensors[0]
@@ -184,7 +193,7 @@ class SlicedGemv:
         self._lay_ref = self.layout   # (an array of 1 or 2 structs: passed as a pointer to the first)
         self._dtype = cache[7]
         self._dev_index = cache[8]
-        self.extra_bytes = sum(e.numel() * (5 if r is not None else 4) + b.numel() * 8 for e, b, f, r, _ in self._tensors)
+        self.extra_bytes = sum(e.numel() * (4 + (r.element_size() if r is not None else 0)) + b.numel() * 8 for e, b, f, r, _ in self._tensors)
 
     def _workspace(self, stream_ptr: int):
         ws = self._ws.get(stream_ptr)
