@@ -136,6 +136,31 @@ def test_sliced_layout_reference_roundings(I, O, kw, rpw, dt, v, kr, dev):
     assert not sl.tokens_supported(2) and sl.forward_tokens(torch.cat([xt, xt], dim=1)) is None
 
 
+@pytest.mark.parametrize("v,kr", [(8, 2), (8, 64), (16, 4), (8, 0), (8, 256)])
+def test_sliced_layouts_with_every_element_in_one_slice(v, kr, dev):
+    """all main indices in ONE slice (the others' lists are empty: their waves have no stream at all) and a tiny residual
+    table: a wave without blocks must not read behind the last list - the residual index it would pick up there sends the
+    exact kernel's L2 gather anywhere (a memory fault found by tools/gpu_fuzz.py --sliced in round 5)"""
+    from vptq_amd.utils.sliced import SlicedGemv
+    I, O = 3384, 4684 // v * v
+    L = vo.make_layer(I, O, dist="llm", seed=91 + kr, vector_len=v, num_centroids=65536, num_res_centroids=kr)
+    N = L.indices.shape[1]
+    rng = np.random.default_rng(kr)
+    idx = (rng.integers(0, 8192, size=(1, N, I), dtype=np.int64)) | (3 << 13)
+    ridx = None if kr == 0 else np.full((1, N, I), kr - 1, dtype=np.int64)
+    L.indices = vo.pack_indices(idx, L.index_bits, ridx, L.res_bits)
+    m = spec_to_module(L, dev)
+    x = _x(I, "f16", "llm", 17)
+    xt = bits_to_tensor(x, "f16", dev).reshape(x.shape)
+    want = vo.forward(L, x)
+    for exact in (False, True):
+        for rpw in (0, 5):
+            sl = SlicedGemv(m, rows_per_wave=rpw, exact=exact)
+            got = sl(xt)
+            torch.cuda.synchronize()
+            assert rel_err(tensor_to_bits(got), want, "f16") <= 1e-3, (exact, rpw)
+
+
 def test_module_default_route_takes_the_exact_sliced_kernel(dev):
     """the product default (reference roundings): one-token calls of v8-k65536-0 / -256 layers go over an EXACT sliced layout,
     two-table formats and several tokens keep the gather kernel; siblings share one launch"""

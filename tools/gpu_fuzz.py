@@ -258,6 +258,7 @@ def fuzz_sliced(a, dev):
                 return idx
             L.indices = vo.pack_indices(skewed(ib), ib, skewed(rb), rb)
         x = vo.from_f32(rng.standard_normal((1, 1, I)).astype(np.float32), dt)
+        print(f"case {c:3d} start: v{v}-k{k}-{kr} I={I} O={O} skew={skew} perm={L.perm is not None} bias={L.bias is not None}", flush=True)
         m = spec_to_module(L, dev)
         m.enable_sliced_layout(False)
         xt = bits_to_tensor(x, dt, dev).reshape(x.shape)
@@ -265,6 +266,7 @@ def fuzz_sliced(a, dev):
         sl = SlicedGemv(m, rows_per_wave=rpw)
         got = sl(xt)
         torch.cuda.synchronize()
+        print(f"  folded ok (rpw {rpw}, slices {sl.slices})", flush=True)
         again = sl(xt)
         assert torch.equal(got.view(torch.int16), again.view(torch.int16)), (c, "not reproducible")
         # (residual indices masked with res_bits as the reference's CUDA kernel does, quant_gemv.cuh:120-121: the Python
@@ -278,7 +280,9 @@ def fuzz_sliced(a, dev):
         ex = -1.0
         if B_.lib().vptq_sliced_layout_supported_for(m._descriptor()[1], 4):
             sx = SlicedGemv(m, rows_per_wave=rpw, exact=True)
+            print(f"  exact layout built (slices {sx.slices})", flush=True)
             gx = sx(xt)
+            torch.cuda.synchronize()
             assert torch.equal(gx.view(torch.int16), sx(xt).view(torch.int16)), (c, "exact: not reproducible")
             ex = rel_err(tensor_to_bits(gx), want, dt)
             ident = float((tensor_to_bits(gx).reshape(-1) == np.asarray(want).reshape(-1)).mean())

@@ -293,9 +293,13 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
   // (4) element queue: block k of the stream -> slot k % kSLQueue
   evec_t eq[kSLQueue];
   uint32_t rq[(RES || RG) ? kSLQueue : 1];
-  const evec_t* const ep = (const evec_t*)(as_global(elems_t) + (size_t)first_block * (64 * EPL)) + lane;
-  const uint8_t* const rp = RES ? as_global(P.res) + (size_t)first_block * 64 + lane : nullptr;
-  const uint16_t* const rp16 = RG ? (const uint16_t*)as_global(P.res) + (size_t)first_block * 64 + lane : nullptr;
+  // (a wave without blocks still issues its counted loads: of block 0 of the layout, which always exists - behind the last
+  // list there is nothing to read, and a residual index picked up there would send the second stage's gather anywhere:
+  // found by tools/gpu_fuzz.py --sliced with every element in one slice, round 5)
+  const size_t fb = total > 0 ? (size_t)first_block : 0;
+  const evec_t* const ep = (const evec_t*)(as_global(elems_t) + fb * (64 * EPL)) + lane;
+  const uint8_t* const rp = RES ? as_global(P.res) + fb * 64 + lane : nullptr;
+  const uint16_t* const rp16 = RG ? (const uint16_t*)as_global(P.res) + fb * 64 + lane : nullptr;
   const int last = total > 0 ? total - 1 : 0;
   int i_next = 0;
   // (past the end of the stream a step still issues its load - every step the same instructions, so the waits
