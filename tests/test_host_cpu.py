@@ -641,6 +641,43 @@ def test_sliced_layout_routing_without_gpu():
     assert sup(_family_desc(25704, 768, 16, 65536, 4096)) == 32
 
 
+def test_exact_sliced_layout_routing_without_gpu():
+    """ABI 8: the slice count a layout needs for the reference's roundings (scale, bias and x of every column beside the slice: 6
+    bytes of LDS per column), which layers that arithmetic serves over a layout, and what the entry point turns down: host logic"""
+    import ctypes as C
+    lib = B.lib()
+    EX = B.GEMV_EXACT
+    supf = lib.vptq_sliced_layout_supported_for
+
+    def want(I, v, k, kr):       # the LDS budget restated: 160 KiB = table slice + 6 (I + 64) + 64 (+ 4 KiB for v8's 256-entry table)
+        small = 8 if v == 8 else 16
+        for nsl in (small, 2 * small):
+            if (k // nsl) * v * 2 + (I + 64) * 6 + 64 + (4096 if (v == 8 and kr == 256) else 0) <= 163840:
+                return nsl
+        return 0
+    for (I, v, k, kr) in ((4096, 8, 65536, 0), (4096, 8, 65536, 256), (4704, 8, 65536, 256), (4712, 8, 65536, 256), (5376, 8, 65536, 0),
+                          (5384, 8, 65536, 0), (8192, 8, 65536, 256), (14336, 8, 65536, 256), (16288, 8, 65536, 0), (16296, 8, 65536, 0),
+                          (28672, 8, 65536, 0), (8192, 16, 65536, 0), (4096, 16, 65536, 0), (14336, 8, 16384, 64), (8192, 8, 65536, 65536),
+                          (8192, 16, 65536, 65536), (8192, 8, 65536, 4096)):
+        d = _family_desc(I, 4096, v, k, kr)
+        assert supf(d, EX) == want(I, v, k, kr), (I, v, k, kr, supf(d, EX))
+        assert supf(d, 0) == lib.vptq_sliced_layout_supported(d)
+        assert supf(d, EX | B.GEMV_FORCE_GENERIC) == 0
+    assert supf(_family_desc(8192, 8192, 8, 8192, 0), EX) == 0 and supf(_family_desc(8192, 8192, 12, 65536, 0), EX) == 0
+    # the entry point: a layout with the folded form's slice count, or without the residual side stream, is "unsupported"
+    buf = (C.c_char * 64)()
+    p = C.addressof(buf)
+    d = _family_desc(8192, 8192, 8, 65536, 256)
+    lay8 = (B.SlicedLayout * 1)(B.SlicedLayout(p, p, p, p, 2, 1, 8, 0, None))
+    lay16 = (B.SlicedLayout * 1)(B.SlicedLayout(p, p, p, None, 2, 1, 16, 0, None))
+    x = (C.c_char * 64)()
+    xa = (C.addressof(x) + 15) & ~15
+    ws = 1 << 24   # (never dereferenced: the call is turned down before any launch)
+    assert lib.vptq_quant_gemv_sliced(d, lay8, xa, xa, EX, xa, ws, None) == B.E_UNSUPPORTED      # 8 slices: the folded layout
+    assert lib.vptq_quant_gemv_sliced(d, lay16, xa, xa, EX, xa, ws, None) == B.E_UNSUPPORTED     # no residual side stream
+    assert b"res" in lib.vptq_last_error()
+
+
 def test_sliced_tokens_plan_without_gpu():
     """2 - 4 tokens over the sliced layouts (gemv_sliced_tok.hip): which layers the library takes - the activations of the
     tokens must fit the LDS beside the slice in at most 4 column phases - and the workspace it asks for: host logic"""
