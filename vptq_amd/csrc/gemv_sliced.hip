@@ -70,6 +70,15 @@ constexpr int kSLMaxGroup = 3;
 #define VPTQ_SLICED_PRIO 0
 #endif
 // 1: a block's LDS gathers are issued one step ahead of its arithmetic (two register sets); 0: gather, wait, compute per step
+// RG: blocks per queue stage (A/B)
+// (measured, profiles/r05/sliced_exact_two_table_queue_ab.txt: 8 / 4 / 2 blocks = 65.8 / 61.2 / 60.1 us at 8192^2 v8-k65536-65536 - the
+// L1 miss path of a CU is the limit, more gathers in flight only queue up in front of the element words)
+#ifndef VPTQ_SLICED_RGQ
+#define VPTQ_SLICED_RGQ 2
+#endif
+#ifndef VPTQ_SLICED_RGNT
+#define VPTQ_SLICED_RGNT 0
+#endif
 #ifndef VPTQ_SLICED_PIPE
 #define VPTQ_SLICED_PIPE 1
 #endif
@@ -78,12 +87,23 @@ constexpr int kSLMaxGroup = 3;
 // the 16-bit formats' infinity)
 constexpr int kSLFixFrac = 24, kSLFixShift = 14;
 static __device__ __forceinline__ unsigned long long sl_to_fixed(float v) {
+  // floor(v * 2^24) as a 64-bit integer out of two 32-bit conversions (the compiler's float -> int64 is ~25 instructions, and a
+  // wave pays it at the end of every row: a third of the exact kernel's vector instructions went there - PMC, round 5):
+  // v = a + f with a = floor(v) (|a| <= 2^25: an int32) and f in [0, 1) exact; Q = a 2^24 + floor(f 2^24), no carry between them
   const bool nan = v != v;
-  const float lim = 33554430.f;   // 2^25 - 2: the product below stays under 2^49
+  const float lim = 33554430.f;   // 2^25 - 2: Q stays inside 50 bits
   float c = __builtin_fminf(__builtin_fmaxf(v, -lim), lim);
   if (nan) c = 0.f;
-  const long long q = (long long)(c * (float)(1 << kSLFixFrac));   // exact product (a power of two), truncated to an integer
-  return ((unsigned long long)q << kSLFixShift) + (nan ? 129ull : 1ull);
+  const float a = __builtin_floorf(c);
+  const int32_t ai = (int32_t)a;
+  // (c - a rounds up to 1.0 for tiny negative c: capped one unit below - 2^-24 of error, as everywhere)
+  const uint32_t f0 = (uint32_t)((c - a) * (float)(1 << kSLFixFrac));
+  const uint32_t fi = f0 < (1u << kSLFixFrac) ? f0 : (1u << kSLFixFrac) - 1u;
+  const uint32_t lo = ((uint32_t)ai << kSLFixFrac) | fi;      // low word of Q
+  const int32_t hi = ai >> (32 - kSLFixFrac);                 // high word of Q (sign-extending)
+  const uint32_t wlo = (lo << kSLFixShift) | (nan ? 129u : 1u);
+  const uint32_t whi = ((uint32_t)hi << kSLFixShift) | (lo >> (32 - kSLFixShift));
+  return ((unsigned long long)whi << 32) | wlo;
 }
 static __device__ __forceinline__ float sl_from_fixed(unsigned long long w) {
   if ((w >> 7) & 127ull) return __builtin_nanf("");
@@ -130,7 +150,7 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
   typedef uint32_t evec_t __attribute__((ext_vector_type(EPL)));
   constexpr int kLoadsPerStep = (RES || RG) ? 2 : 1;
   // blocks in flight per wave (RG, v = 16: 4 - the gathered residual entries of the second stage are 8 registers each)
-  constexpr int kSLQueue = (RG && V == 16) ? 4 : (kSLQueueWords / EPL < 2 ? 2 : kSLQueueWords / EPL);
+  constexpr int kSLQueue = RG ? (V == 16 && VPTQ_SLICED_RGQ > 4 ? 4 : VPTQ_SLICED_RGQ) : (kSLQueueWords / EPL < 2 ? 2 : kSLQueueWords / EPL);
   constexpr int W4 = V / 8;   // 16-byte pieces of an entry
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   {
@@ -297,9 +317,10 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
   // list there is nothing to read, and a residual index picked up there would send the second stage's gather anywhere:
   // found by tools/gpu_fuzz.py --sliced with every element in one slice, round 5)
   const size_t fb = total > 0 ? (size_t)first_block : 0;
-  const evec_t* const ep = (const evec_t*)(as_global(elems_t) + fb * (64 * EPL)) + lane;
-  const uint8_t* const rp = RES ? as_global(P.res) + fb * 64 + lane : nullptr;
-  const uint16_t* const rp16 = RG ? (const uint16_t*)as_global(P.res) + fb * 64 + lane : nullptr;
+  // (wave-uniform base + the lane's 32-bit byte offset: the scalar-base addressing form - no 64-bit vector add per load)
+  const char* const ep = (const char*)(as_global(elems_t) + fb * (64 * EPL));
+  const char* const rp = (RES || RG) ? (const char*)as_global(P.res) + fb * 64 * (RG ? 2 : 1) : nullptr;
+  const uint32_t lane4 = (uint32_t)lane * 4u * EPL, lane_r = (uint32_t)lane * (RG ? 2u : 1u);
   const int last = total > 0 ? total - 1 : 0;
   int i_next = 0;
   // (past the end of the stream a step still issues its load - every step the same instructions, so the waits
@@ -307,9 +328,9 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
   auto issue = [&](auto slot_c) __attribute__((always_inline)) {
     constexpr int S = decltype(slot_c)::value;
     const size_t b64 = (size_t)(i_next < last ? i_next : last) * 64;
-    eq[S] = __builtin_nontemporal_load(ep + b64);
-    if constexpr (RES) rq[S] = rp[b64];
-    if constexpr (RG) rq[S] = rp16[b64];
+    eq[S] = __builtin_nontemporal_load((const evec_t*)(ep + b64 * (4 * EPL) + (size_t)lane4));
+    if constexpr (RES) rq[S] = *(const uint8_t*)(rp + b64 + (size_t)lane_r);
+    if constexpr (RG) rq[S] = *(const uint16_t*)(rp + b64 * 2 + (size_t)lane_r);
     ++i_next;
   };
   sl_for_slots<kSLQueue>([&](auto slot_c) {
@@ -339,7 +360,13 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
     ew[S] = eq[S][0];
     const char* const ra = (const char*)as_global(P.rcent) + (size_t)rq[S] * kEntry;
 #pragma unroll
-    for (int w = 0; w < W4; ++w) rgq[S][w] = *(const u32x4*)(ra + 16 * w);
+    for (int w = 0; w < W4; ++w) {
+#if VPTQ_SLICED_RGNT
+      rgq[S][w] = __builtin_nontemporal_load((const u32x4*)(ra + 16 * w));
+#else
+      rgq[S][w] = *(const u32x4*)(ra + 16 * w);
+#endif
+    }
   };
   if constexpr (RG) {
     sl_for_slots<kSLQueue>([&](auto slot_c) {

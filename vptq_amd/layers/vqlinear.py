@@ -56,7 +56,7 @@ _SLICED_LAYOUT_MODE = os.environ.get("VPTQ_SLICED_LAYOUT", "auto").strip().lower
 _SLICED_LAYOUT_ENV = _SLICED_LAYOUT_MODE not in ("0", "off", "false", "no")
 _SLICED_MIN_FREE_FRACTION = 0.25
 _SLICED_EXACT_MIN_ELEMENTS = 1 << 20   # vector-rows x columns from which the exact sliced kernel beats the gather kernel
-_SLICED_EXACT_RG_MIN_ELEMENTS = 6 << 20   # ... with the residual entries gathered from L2 (two-table formats)
+_SLICED_EXACT_RG_MIN_ELEMENTS = 2 << 20   # ... with the residual entries gathered from L2 (two-table formats)
 # most tokens served as one sliced launch PER TOKEN: decided per layer (VQuantLinear._sliced_token_limit);
 # VPTQ_SLICED_TOKENS="one-table,two-table" overrides it (tools/sliced_tokens_bench.py)
 _SLICED_TOKENS_ENV = tuple(int(v) for v in os.environ["VPTQ_SLICED_TOKENS"].split(",")) if os.environ.get("VPTQ_SLICED_TOKENS") else None
@@ -460,10 +460,11 @@ class VQuantLinear(nn.Module):
             n_el = self.indices.shape[1] * self.group_size
             kr_ = self.num_res_centroids if self.enable_residual else 0
             if exact and kr_ > 0 and not (self.vector_len == 8 and kr_ == 256):
-                # any other residual codebook: its entries are gathered from L2 behind the LDS-local main gathers - 10-20 % ahead
-                # of the gather kernels on 70B-sized layers with a large residual table, behind them elsewhere (us per layer, gather
-                # -> sliced, profiles/r05/sliced_exact_two_table.txt: v8-k65536-65536 8192^2 77.2 -> 65.6, 14336 x 4096 67.3 -> 56.1,
-                # 4096^2 21.6 -> 24.6; v16-k65536-65536 54.0 -> 49.3 / 52.4 -> 42.1 / 19.1 -> 19.6; v16-k65536-1024 28.4 -> 32.7)
+                # any other residual codebook: its entries are gathered from L2 behind the LDS-local main gathers (2 blocks per
+                # queue stage: the CU's L1 miss path is the limit) - us per layer, gather kernels -> sliced, profiles/r05/
+                # sliced_exact_two_table_queue_ab.txt: v8-k65536-65536 8192^2 78.0 -> 59.9, 14336 x 4096 68.5 -> 52.2, 4096^2 21.6 ->
+                # 21.2; v8-k65536-4096 69.9 -> 50.6 / 59.8 -> 44.3 / 20.5 -> 18.4; v16-k65536-65536 53.9 -> 46.7 / 52.3 -> 40.9 / 19.2 ->
+                # 18.3; small residual tables (v16-k65536-1024: the gather kernel holds them in LDS) stay there
                 big = (kr_ >= 4096 and n_el >= _SLICED_EXACT_RG_MIN_ELEMENTS) or "_sliced_on" in self.__dict__
             else:
                 big = n_el >= _SLICED_EXACT_MIN_ELEMENTS or "_sliced_on" in self.__dict__
