@@ -1133,7 +1133,8 @@ def main():
             ex["prefill"] = prefill_extra(dev)
         except Exception as e:   # the headline line must not depend on it
             ex["prefill"] = {"error": f"{type(e).__name__}: {e}"[:300]}
-        for key, mode_ in (("llama3_8b_decode", "reference"), ("folded_llama3_8b_decode", "folded")):
+        # (the opt-in folded arithmetic of the same loop: VPTQ_BENCH_FOLDED_DECODE=1 - 25 s more; profiles/r05/bench_h8192_chain.json has it)
+        for key, mode_ in (("llama3_8b_decode", "reference"),) + ((("folded_llama3_8b_decode", "folded"),) if os.environ.get("VPTQ_BENCH_FOLDED_DECODE") == "1" else ()):
             try:
                 ex[key] = model_decode_extra(arithmetic=mode_)
             except Exception as e:

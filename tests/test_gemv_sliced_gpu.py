@@ -38,6 +38,7 @@ CASES = [
     (2048, 1032, dict(bias=True), 3),
     (4104, 264, dict(dist="llm"), 0),
     (512, 4096, dict(dist="llm"), 2),
+    (1024, 4608, dict(dist="llm", bias=True), 18),   # more than 16 rows per wave: the lanes that hold the rows' words come round again
     (64, 72, dict(), 0),
     (8192, 512, dict(dist="llm", bias=True), 1),
     (2048, 520, dict(dist="llm", enable_perm=True, bias=True), 0),   # a permutation: applied while the activations are staged
@@ -83,6 +84,7 @@ def test_sliced_layout_gemv_vs_oracle(I, O, kw, rpw, dt, kr, dev):
 EXACT_CASES = [
     (1024, 256, dict(), 0),                                            # 8 slices
     (2048, 1032, dict(bias=True), 3),
+    (1024, 4608, dict(dist="llm", bias=True), 18),                     # more than 16 rows per wave
     (4104, 264, dict(dist="llm"), 0),                                  # 8 slices without, 8 with the residual table (4704)
     (4712, 136, dict(dist="llm"), 0),                                  # 8 slices without the residual table, 16 with it
     (64, 72, dict(), 0),
