@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define VPTQ_ABI_VERSION 8
+#define VPTQ_ABI_VERSION 9
 
 #if defined(__GNUC__)
 #define VPTQ_API __attribute__((visibility("default")))
@@ -322,7 +322,8 @@ VPTQ_API int vptq_sliced_layout_supported(const VptqLayerDesc* desc);
  * codebook: `res` = uint16 residual indices, the entry gathered from device memory (one of the gather kernel's two cache
  * gathers per element).  Scale, bias and x of every column sit beside the slice, 6 instead of 2 bytes of LDS per column:
  * v = 8: 8 slices up to 5376 columns (4704 with the 256-entry table), 16 up to 16288 (15616); v = 16: 16 / 32; wider layers: 0.
- * A layout built with THAT slice count serves vptq_quant_gemv_sliced(..., flags | VPTQ_GEMV_EXACT, ...); one token only. */
+ * A layout built with THAT slice count serves vptq_quant_gemv_sliced(..., flags | VPTQ_GEMV_EXACT, ...) and - one-table formats,
+ * ABI >= 9 - vptq_quant_gemv_sliced_tokens(..., flags | VPTQ_GEMV_EXACT, ...). */
 VPTQ_API int vptq_sliced_layout_supported_for(const VptqLayerDesc* desc, int flags);
 /* 0, or how many consecutive VptqSlicedLayout structs vptq_quant_gemv_sliced takes for this layer: 1 (no residual codebook;
  * v = 8 with 256 residual centroids: `res` bytes), 2 (any other residual codebook: a second table with a layout of its own) */
@@ -341,8 +342,14 @@ VPTQ_API int vptq_quant_gemv_sliced(const VptqLayerDesc* desc, const VptqSlicedL
  * once, one per layer and stream, not shared with the one-token call; a workspace for T tokens serves fewer as well (the
  * arrival counters sit in front).  VPTQ_E_UNSUPPORTED where the layer, the layout
  * (no wstart) or the token count is not served: take vptq_quant_gemv.  Replaces the same reference kernel for
- * 1 < tokens < 16 (vptq/ops/quant_gemm.py:213, csrc/kernels/quant_gemv.cuh:11-186). */
+ * 1 < tokens < 16 (vptq/ops/quant_gemm.py:213, csrc/kernels/quant_gemv.cuh:11-186).
+ * flags | VPTQ_GEMV_EXACT (ABI >= 9): the reference's roundings per weight over an EXACT layout (vptq_sliced_layout_supported_for(desc,
+ * VPTQ_GEMV_EXACT) slices) of a one-table format (no residual codebook; v = 8 with 256 residual centroids): scale and bias of a
+ * column are staged beside its activations (8 more bytes of LDS per column and phase), every weight is rebuilt as
+ * f16(f16(f16(c + r) s) + b) in the matrix pipe's operand layout; vptq_quant_gemv_sliced_tokens_supported_for says whether the
+ * layer's columns fit (4 phases x (2 x token slots + 8) bytes beside the slice: 5 - 8 tokens up to ~16000 columns). */
 VPTQ_API int vptq_quant_gemv_sliced_tokens_supported(const VptqLayerDesc* desc, const VptqSlicedLayout* layout, int tokens);
+VPTQ_API int vptq_quant_gemv_sliced_tokens_supported_for(const VptqLayerDesc* desc, const VptqSlicedLayout* layout, int tokens, int flags);
 VPTQ_API size_t vptq_quant_gemv_sliced_tokens_workspace_bytes(const VptqLayerDesc* desc, int tokens);
 VPTQ_API int vptq_quant_gemv_sliced_tokens(const VptqLayerDesc* desc, const VptqSlicedLayout* layout, const void* x, void* y,
                                   int tokens, int flags, void* workspace, size_t workspace_bytes, void* stream);

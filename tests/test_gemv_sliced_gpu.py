@@ -135,7 +135,64 @@ def test_sliced_layout_reference_roundings(I, O, kw, rpw, dt, v, kr, dev):
     y32 = sl(xt, flags=B.GEMV_OUT_F32)
     assert y32.dtype == torch.float32 and torch.equal(y32.to(got.dtype).view(torch.int16), got.view(torch.int16))
     assert torch.equal(sl(xt).view(torch.int16), got.view(torch.int16))
-    assert not sl.tokens_supported(2) and sl.forward_tokens(torch.cat([xt, xt], dim=1)) is None
+    if kr not in (0, 256) or (v == 16 and kr):   # two tables in the reference's roundings: one token only
+        assert not sl.tokens_supported(2) and sl.forward_tokens(torch.cat([xt, xt], dim=1)) is None
+
+
+EXACT_TOK_SHAPES = [(2048, 528, dict(dist="llm", enable_perm=True, bias=True)), (8192, 512, dict(dist="llm", bias=True)), (4104, 272, dict(dist="llm")),
+                    (14336, 136, dict(dist="llm")), (72, 1040, dict()), (4096, 2056, dict(dist="llm", enable_perm=True))]
+
+
+@pytest.mark.parametrize("tokens,dt", [(2, "f16"), (3, "bf16"), (4, "f16"), (4, "bf16"), (5, "f16"), (7, "bf16"), (8, "f16"), (8, "bf16")])
+@pytest.mark.parametrize("v,k,kr", [(8, 65536, 0), (8, 65536, 256), (16, 65536, 0), (8, 16384, 256)])
+@pytest.mark.parametrize("I,O,kw", EXACT_TOK_SHAPES)
+def test_sliced_tokens_reference_roundings(I, O, kw, v, k, kr, tokens, dt, dev):
+    """2 - 8 tokens in ONE launch over the exact sliced layout, every weight rebuilt as f16(f16(f16(c + r) s) + b) in the matrix
+    pipe's operand layout: against the oracle (almost every output bit-identical), against the gather kernel in the same
+    arithmetic, against the one-token exact sliced kernel; float32 outputs; repeatable"""
+    from vptq_amd.utils.sliced import SlicedGemv
+    from vptq_amd import _backend as B
+    kw = dict(kw)
+    dist = kw.pop("dist", "ref-test")
+    L = vo.make_layer(I, O, dist=dist, seed=I + O + v + kr + tokens, dtype=dt, vector_len=v, num_centroids=k, num_res_centroids=kr, **kw)
+    x = _xt(I, tokens, dt, dist, I + 7)
+    m = spec_to_module(L, dev)
+    sl = SlicedGemv(m, exact=True)
+    xt = bits_to_tensor(x, dt, dev).reshape(x.shape)
+    assert sl.tokens_supported(tokens)    # (8 + 2 x token slots bytes per column and phase: every width of these cases fits)
+    got = sl.forward_tokens(xt)
+    torch.cuda.synchronize()
+    assert got.shape == (1, tokens, O)
+    want = vo.forward(L, x)
+    gb = tensor_to_bits(got)
+    err = rel_err(gb, want, dt)
+    assert err <= TOL[dt], f"v{v}-k{k}-{kr} {I}x{O} {tokens} tokens {dt}: {err:.3e}"
+    assert float((gb.reshape(-1) == np.asarray(want).reshape(-1)).mean()) >= 0.95
+    ref = tensor_to_bits(gemv_abi(m, xt, EXACT))
+    assert float((gb.reshape(-1) == ref.reshape(-1)).mean()) >= 0.95
+    for t in (0, tokens - 1):
+        one = sl(xt[:, t:t + 1].contiguous())
+        assert float((tensor_to_bits(got[:, t:t + 1]).reshape(-1) == tensor_to_bits(one).reshape(-1)).mean()) >= 0.95
+    y32 = sl.forward_tokens(xt, flags=B.GEMV_OUT_F32)
+    assert y32.dtype == torch.float32 and torch.equal(y32.to(got.dtype).view(torch.int16), got.view(torch.int16))
+    assert torch.equal(sl.forward_tokens(xt).view(torch.int16), got.view(torch.int16))
+
+
+@pytest.mark.parametrize("name,parts", [("t8_k65536_r256", [(0, 4), (0, 8), (2, 4), (3, 8)]), ("t2_k65536_r256_4096x4096", [(0, 2)]),
+                                        ("t4_k65536_r0_8192x2048_perm", [(0, 4), (1, 4), (2, 4)])])
+def test_sliced_tokens_reference_roundings_on_reference_goldens(name, parts, dev):
+    """the real reference's outputs for 2 - 8 tokens of one-table k = 65536 layers"""
+    from vptq_amd.utils.sliced import SlicedGemv
+    L, x, y, cfg, _ = load_fmt(name)
+    dt = cfg["dtype"]
+    sl = SlicedGemv(spec_to_module(L, dev), exact=True)
+    xt = bits_to_tensor(x, dt, dev).reshape(x.shape)
+    for a, b in parts:
+        got = sl.forward_tokens(xt[:, a:b].contiguous())
+        assert got is not None, (name, a, b)
+        gb = tensor_to_bits(got)
+        assert rel_err(gb, y[:, a:b], dt) <= TOL[dt], (name, a, b)
+        assert float((gb.reshape(-1) == np.asarray(y[:, a:b]).reshape(-1)).mean()) >= 0.95, (name, a, b)
 
 
 @pytest.mark.parametrize("v,kr", [(8, 2), (8, 64), (16, 4), (8, 0), (8, 256)])
@@ -656,10 +713,24 @@ def test_sliced_tokens_rejections(dev):
     sp = B.current_stream_ptr(dev)
     assert lib.vptq_quant_gemv_sliced_tokens(sl.desc, sl.layout, x.data_ptr(), y.data_ptr(), 3, 0, ws.data_ptr(), need - 1, sp) == B.E_WORKSPACE
     assert lib.vptq_quant_gemv_sliced_tokens(sl.desc, sl.layout, x.data_ptr(), y.data_ptr(), 9, 0, ws.data_ptr(), need, sp) == B.E_UNSUPPORTED
-    assert lib.vptq_quant_gemv_sliced_tokens(sl.desc, sl.layout, x.data_ptr(), y.data_ptr(), 3, EXACT, ws.data_ptr(), need, sp) == B.E_UNSUPPORTED
+    assert lib.vptq_quant_gemv_sliced_tokens(sl.desc, sl.layout, x.data_ptr(), y.data_ptr(), 3, B.GEMV_FORCE_GENERIC, ws.data_ptr(), need, sp) == B.E_UNSUPPORTED
     assert lib.vptq_quant_gemv_sliced_tokens(sl.desc, sl.layout, x.data_ptr(), y.data_ptr(), 3, 0, ws.data_ptr(), need, sp) == 0
     torch.cuda.synchronize()
     assert torch.equal(y, sl.forward_tokens(x))
+    # one-table formats: the layout of the folded form IS the exact one where the slice counts agree (they do at 2048 columns) ...
+    assert lib.vptq_sliced_layout_supported_for(sl.desc, EXACT) == sl.slices
+    assert lib.vptq_quant_gemv_sliced_tokens_supported_for(sl.desc, sl.layout, 3, EXACT)
+    assert lib.vptq_quant_gemv_sliced_tokens(sl.desc, sl.layout, x.data_ptr(), y.data_ptr(), 3, EXACT, ws.data_ptr(), need, sp) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(y, SlicedGemv(m, exact=True).forward_tokens(x))
+    # ... two-table formats have no exact token kernel
+    L2 = vo.make_layer(2048, 512, dist="llm", seed=52, num_centroids=65536, num_res_centroids=65536)
+    sl2 = SlicedGemv(spec_to_module(L2, dev))
+    assert lib.vptq_quant_gemv_sliced_tokens_supported_for(sl2.desc, sl2.layout, 3, 0)
+    assert not lib.vptq_quant_gemv_sliced_tokens_supported_for(sl2.desc, sl2.layout, 3, EXACT)
+    need2 = lib.vptq_quant_gemv_sliced_tokens_workspace_bytes(sl2.desc, 3)
+    ws2 = torch.zeros(need2, dtype=torch.uint8, device=dev)
+    assert lib.vptq_quant_gemv_sliced_tokens(sl2.desc, sl2.layout, x.data_ptr(), y.data_ptr(), 3, EXACT, ws2.data_ptr(), need2, sp) == B.E_UNSUPPORTED
     # a layout without the column windows' table serves one token only
     lay = B.SlicedLayout.from_buffer_copy(sl.layout[0])
     lay.wstart = None
@@ -714,6 +785,66 @@ def test_module_route_for_two_to_four_tokens_in_one_launch(dev, monkeypatch, fol
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(yg.view(torch.int16), y2.view(torch.int16))
+
+
+def test_module_default_route_for_two_to_four_tokens_of_wide_layers(dev, monkeypatch):
+    """the product default (reference roundings): 2 - 4 tokens of a LARGE v = 8 one-table layer whose exact layout has 16 slices go
+    through the exact token kernel in one launch (VQuantLinear._sliced_one_launch: where it was measured faster than the gather
+    kernel); everything else keeps the gather kernel; siblings share the launch"""
+    import vptq_amd
+    import vptq_amd.layers.vqlinear as vq
+    from vptq_amd.layers.vqlinear import SiblingGroup
+    assert vptq_amd.arithmetic() == "reference"
+    L = vo.make_layer(8192, 6144, dist="llm", seed=71, num_centroids=65536, num_res_centroids=256, bias=True)
+    m = spec_to_module(L, dev)
+    xs = np.concatenate([_x(8192, "f16", "llm", 30 + i) for i in range(5)], axis=1)
+    xt = bits_to_tensor(xs, "f16", dev).reshape(xs.shape)
+    m(xt[:, :1].contiguous())
+    sl = m.__dict__["_sliced"][1]
+    assert sl is not None and sl.exact and sl.slices == 16 and all(m._sliced_one_launch(sl, t) for t in (3, 4))
+    assert not m._sliced_one_launch(sl, 5) and not m._sliced_one_launch(sl, 2) and m._sliced_token_limit(sl) == 2
+    want = vo.forward(L, xs)
+    for T in (2, 3, 4):
+        x = xt[:, :T].contiguous()
+        y = m(x)
+        if T == 2:   # two launches of the one-token kernel
+            assert all(torch.equal(y[:, t].reshape(-1).view(torch.int16), sl(x[:, t:t + 1].contiguous()).reshape(-1).view(torch.int16)) for t in range(2))
+        else:
+            assert torch.equal(y.view(torch.int16), sl.forward_tokens(x).view(torch.int16))
+        yb = tensor_to_bits(y)
+        assert rel_err(yb, want[:, :T], "f16") <= 1e-3
+        assert float((yb.reshape(-1) == np.asarray(want[:, :T]).reshape(-1)).mean()) >= 0.95
+    y5 = m(xt)                                     # 5 tokens: the gather kernel, the same arithmetic
+    assert torch.equal(y5.view(torch.int16), gemv_abi(m, xt, EXACT).view(torch.int16))
+    # a narrow layer (8 slices of 128 KiB: four column phases) and a small one stay on the gather kernel
+    for (I, O) in ((4096, 2048), (8192, 512)):
+        Ls = vo.make_layer(I, O, dist="llm", seed=72, num_centroids=65536, num_res_centroids=0)
+        ms = spec_to_module(Ls, dev)
+        ms.enable_sliced_layout()
+        x2 = bits_to_tensor(np.concatenate([_x(I, "f16", "llm", 40 + i) for i in range(2)], axis=1), "f16", dev).reshape(1, 2, I)
+        ms(x2[:, :1].contiguous())
+        s2 = ms.__dict__["_sliced"][1]
+        assert s2 is not None and s2.exact and s2.tokens_supported(3) and not ms._sliced_one_launch(s2, 3) and ms._sliced_token_limit(s2) == 1
+        assert torch.equal(ms(x2).view(torch.int16), gemv_abi(ms, x2, EXACT).view(torch.int16))
+    # switched on for every layer the library takes ("1"): siblings of one format share one launch, each member's own bits
+    monkeypatch.setattr(vq, "_SLICED_ONE_LAUNCH", "1")
+    Lq = [vo.make_layer(8192, O, seed=80 + i, dist="llm", num_centroids=65536, num_res_centroids=256, bias=(i == 1)) for i, O in enumerate((1024, 264, 512))]
+    mq = [spec_to_module(Li, dev) for Li in Lq]
+    for mm in mq:
+        mm.enable_sliced_layout()
+    x3 = xt[:, :3].contiguous()
+    alone = [mm(x3) for mm in mq]
+    for mm in mq:
+        assert mm.__dict__["_sliced"][1].exact and mm._sliced_one_launch(mm.__dict__["_sliced"][1], 3)
+    group = SiblingGroup(mq)
+    for mm in mq:
+        object.__setattr__(mm, "_siblings", group)
+    x3b = x3.clone()
+    ys = [mm(x3b) for mm in mq]
+    assert isinstance(group.__dict__.get("_sgroup"), tuple) and group._sgroup[1].exact
+    for a, b, Li in zip(alone, ys, Lq):
+        assert rel_err(tensor_to_bits(b), vo.forward(Li, xs[:, :3]), "f16") <= 1e-3
+        assert float((a.view(torch.int16) == b.view(torch.int16)).float().mean()) >= 0.95   # (the group's rows per wave: another order of sums)
 
 
 @pytest.mark.parametrize("tokens", [2, 3, 4])

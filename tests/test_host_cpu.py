@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, s), f"{s} declared in include/vptq_hip.h but not exported"
     assert sorted(B.EXPORTS) == syms, "python binding table out of sync with the header"
     lib.vptq_abi_version.restype = ctypes.c_int
-    assert lib.vptq_abi_version() == B.ABI_VERSION == 8
+    assert lib.vptq_abi_version() == B.ABI_VERSION == 9
 
 
 def test_ctypes_struct_layout_matches_header():
@@ -695,11 +695,28 @@ def test_sliced_tokens_plan_without_gpu():
     assert [sup(d, layouts(d), t) for t in (1, 2, 3, 4, 5)] == [0, 1, 1, 1, 0]
     assert sup(d, layouts(d, wstart=False), 2) == 0                       # layouts without the column windows' table: one token only
     # partial sums [tokens][slices x tables][N x v] floats (256-byte multiple) + the arrival counters (one per 16 rows)
-    assert wsb(d, 2) == 2 * 8 * 8192 * 4 + 256 and wsb(d, 4) == 4 * 8 * 8192 * 4 + 256 and wsb(d, 9) == 0 and wsb(d, 1) == 0
+    # (ONE size for both arithmetics: the exact layout of an 8192-column layer has 16 slices)
+    assert wsb(d, 2) == 2 * 16 * 8192 * 4 + 256 and wsb(d, 4) == 4 * 16 * 8192 * 4 + 256 and wsb(d, 9) == 0 and wsb(d, 1) == 0
     d4 = _family_desc(4096, 4096, 8, 65536, 256)      # 5 - 8 tokens: 16 bytes of activations per column must fit in 4 phases
     assert [sup(d4, layouts(d4), t) for t in (5, 8, 9)] == [1, 1, 0] and wsb(d4, 8) == 8 * 8 * 4096 * 4 + 256
     d2 = _family_desc(8192, 8192, 8, 65536, 65536)
     assert sup(d2, layouts(d2), 4) == 1 and wsb(d2, 3) == 3 * 16 * 8192 * 4 + 256
+    # ABI 9: the reference's roundings (one-table formats, an exact layout: its slice count), 8 + 2 x token slots bytes per column and phase
+    EX = B.GEMV_EXACT
+    supf = lib.vptq_quant_gemv_sliced_tokens_supported_for
+
+    def exact_layout(dd, wstart=True):
+        return (B.SlicedLayout * 1)(B.SlicedLayout(p, p, p, p, 2, 1, lib.vptq_sliced_layout_supported_for(dd, EX), 0, p if wstart else None))
+    for (I, v, kr, want) in ((4096, 8, 256, [0, 1, 1, 1, 1, 0]), (8192, 8, 256, [0, 1, 1, 1, 1, 0]), (14336, 8, 0, [0, 1, 1, 1, 1, 0]),
+                             (5376, 8, 0, [0, 1, 1, 0, 0, 0]), (16288, 8, 0, [0, 1, 1, 0, 0, 0]), (8192, 16, 0, [0, 1, 1, 1, 1, 0]),
+                             (8192, 8, 65536, [0] * 6), (8192, 16, 65536, [0] * 6), (8192, 8, 4096, [0] * 6)):
+        dd = _family_desc(I, 4096, v, 65536, kr)
+        assert [supf(dd, exact_layout(dd), t, EX) for t in (1, 2, 4, 5, 8, 9)] == want, (I, v, kr)
+        assert supf(dd, exact_layout(dd), 2, EX | B.GEMV_FORCE_GENERIC) == 0
+    assert supf(d, exact_layout(d, wstart=False), 2, EX) == 0
+    assert supf(d, layouts(d), 2, EX) == 0                 # the folded form's 8 slices: not the exact layout of an 8192-column layer
+    assert supf(d4, layouts(d4), 8, EX) == 1               # 4096 columns: the same 8 slices, the same layout
+    assert supf(d, layouts(d), 4, 0) == sup(d, layouts(d), 4) == 1
     assert sup(_family_desc(28672, 8192, 8, 65536, 0), layouts(_family_desc(28672, 8192, 8, 65536, 0)), 4) == 1   # 16 slices of 64 KiB
     dv = _family_desc(8192, 8192, 16, 65536, 65536)
     assert sup(dv, layouts(dv), 2) == 1
@@ -717,14 +734,23 @@ def test_one_launch_rule_for_two_to_four_tokens():
         return types.SimpleNamespace(indices=torch.empty(1, O // v, 1), group_size=I, vector_len=v, out_features=O,
                                      num_res_centroids=kr, enable_residual=kr > 0)
 
-    def rule(I, O, v, kr, tokens, supported=True):
+    def rule(I, O, v, kr, tokens, supported=True, exact=False, slices=8):
         class SL:       # (stands in for vptq_amd.utils.sliced.SlicedGemv: what the library answers + the per-layout cache)
             def tokens_supported(self, t):
                 return supported
-        return VQuantLinear._sliced_one_launch(layer(I, O, v, kr), SL(), tokens)
+        sl = SL()
+        sl.exact, sl.slices = exact, slices
+        return VQuantLinear._sliced_one_launch(layer(I, O, v, kr), sl, tokens)
     for t in (2, 3, 4):
         assert rule(8192, 8192, 8, 0, t) and rule(4096, 4096, 8, 256, t) and rule(4096, 14336, 8, 65536, t) and rule(8192, 8192, 16, 0, t)
         assert not rule(2048, 512, 8, 256, t)                     # tiny: launch-bound on every route
         assert not rule(8192, 8192, 16, 1024, t)                  # v = 16 with a small residual table: the gather kernel holds it in LDS
         assert not rule(8192, 8192, 8, 0, t, supported=False)     # the library does not take it (no wstart, no room in LDS)
     assert rule(4096, 14336, 16, 65536, 2) and not rule(4096, 14336, 16, 65536, 4) and rule(8192, 8192, 16, 65536, 4)
+    # the reference's roundings (profiles/r05/sliced_tokens_exact.txt): large v = 8 layers whose exact layout has 16 slices
+    assert not rule(8192, 8192, 8, 256, 2, exact=True, slices=16)      # 2 tokens: two launches of the one-token kernel instead
+    for t in (3, 4):
+        assert rule(8192, 8192, 8, 256, t, exact=True, slices=16) and rule(14336, 4096, 8, 0, t, exact=True, slices=16)
+        assert not rule(4096, 14336, 8, 256, t, exact=True, slices=8) and not rule(4096, 4096, 8, 0, t, exact=True, slices=8)
+        assert not rule(8192, 8192, 16, 0, t, exact=True, slices=32) and not rule(8192, 2048, 8, 0, t, exact=True, slices=16)
+        assert not rule(8192, 8192, 8, 256, t, exact=True, slices=16, supported=False)

@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # VPTQ_HIP_LIB: load another build of the library (A/B runs of tools/)
 LIB_PATH = os.environ.get("VPTQ_HIP_LIB") or os.path.join(_HERE, "libvptq_hip.so")
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 DTYPE_F16, DTYPE_BF16 = 0, 1
 GEMV_FAST_MATH = 1 << 0
 GEMV_FORCE_GENERIC = 1 << 1
@@ -89,6 +89,7 @@ EXPORTS = {
     "vptq_quant_gemv_sliced": (C.c_int, [C.POINTER(LayerDesc), C.POINTER(SlicedLayout), _vp, _vp, C.c_int, _vp,
                                          C.c_size_t, _vp]),
     "vptq_quant_gemv_sliced_tokens_supported": (C.c_int, [C.POINTER(LayerDesc), C.POINTER(SlicedLayout), C.c_int]),
+    "vptq_quant_gemv_sliced_tokens_supported_for": (C.c_int, [C.POINTER(LayerDesc), C.POINTER(SlicedLayout), C.c_int, C.c_int]),
     "vptq_quant_gemv_sliced_tokens_workspace_bytes": (C.c_size_t, [C.POINTER(LayerDesc), C.c_int]),
     "vptq_quant_gemv_sliced_tokens": (C.c_int, [C.POINTER(LayerDesc), C.POINTER(SlicedLayout), _vp, _vp, C.c_int, C.c_int, _vp,
                                                 C.c_size_t, _vp]),

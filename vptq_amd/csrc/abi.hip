@@ -518,11 +518,15 @@ int vptq_quant_gemv_sliced(const VptqLayerDesc* d, const VptqSlicedLayout* layou
 }
 
 int vptq_quant_gemv_sliced_tokens_supported(const VptqLayerDesc* d, const VptqSlicedLayout* layout, int tokens) {
-  return validate_layer(d) == VPTQ_OK && layout && vptq::gemv_sliced_tok_eligible(*d, layout, tokens) ? 1 : 0;
+  return vptq_quant_gemv_sliced_tokens_supported_for(d, layout, tokens, 0);
+}
+int vptq_quant_gemv_sliced_tokens_supported_for(const VptqLayerDesc* d, const VptqSlicedLayout* layout, int tokens, int flags) {
+  if (flags & ~(VPTQ_GEMV_EXACT | VPTQ_GEMV_OUT_F32)) return 0;
+  return validate_layer(d) == VPTQ_OK && layout && vptq::gemv_sliced_tok_eligible(*d, layout, tokens, (flags & VPTQ_GEMV_EXACT) != 0) ? 1 : 0;
 }
 
 size_t vptq_quant_gemv_sliced_tokens_workspace_bytes(const VptqLayerDesc* d, int tokens) {
-  return validate_layer(d) == VPTQ_OK && vptq::gemv_sliced_eligible(*d) && tokens >= 2 && tokens <= 8
+  return validate_layer(d) == VPTQ_OK && (vptq::gemv_sliced_eligible(*d) || vptq::gemv_sliced_eligible(*d, true)) && tokens >= 2 && tokens <= 8
              ? vptq::gemv_sliced_tok_workspace_bytes(*d, tokens) : 0;
 }
 
@@ -530,10 +534,11 @@ int vptq_quant_gemv_sliced_tokens(const VptqLayerDesc* d, const VptqSlicedLayout
                                   int flags, void* workspace, size_t workspace_bytes, void* stream) {
   if (int rc = validate_layer(d)) return rc;
   if (!layout || !x || !y) return fail(VPTQ_E_NULL, "layout, x and y must be set");
-  if (flags & (VPTQ_GEMV_EXACT | VPTQ_GEMV_FORCE_GENERIC))
-    return fail(VPTQ_E_UNSUPPORTED, "the sliced path has the folded arithmetic only: use vptq_quant_gemv");
-  if (!vptq::gemv_sliced_eligible(*d) || !vptq::gemv_sliced_tok_eligible(*d, layout, tokens))
-    return fail(VPTQ_E_UNSUPPORTED, "sliced layouts with column windows (wstart), 2 - 8 tokens, and activations that fit the LDS beside the slice");
+  if (flags & VPTQ_GEMV_FORCE_GENERIC) return fail(VPTQ_E_UNSUPPORTED, "the sliced path is not the generic kernel: use vptq_quant_gemv");
+  const bool exact = (flags & VPTQ_GEMV_EXACT) != 0;
+  if (!vptq::gemv_sliced_eligible(*d, exact) || !vptq::gemv_sliced_tok_eligible(*d, layout, tokens, exact))
+    return fail(VPTQ_E_UNSUPPORTED, "sliced layouts with column windows (wstart), 2 - 8 tokens, and activations that fit the LDS beside the slice"
+                                    " (VPTQ_GEMV_EXACT: one-table formats, a layout of vptq_sliced_layout_supported_for(desc, VPTQ_GEMV_EXACT) slices)");
   const size_t need = vptq::gemv_sliced_tok_workspace_bytes(*d, tokens);
   if (!workspace || workspace_bytes < need || (((uintptr_t)workspace) & 15) != 0)
     return fail(VPTQ_E_WORKSPACE, "the sliced path for %d tokens needs %zu bytes of 16-byte aligned, zero-initialised workspace", tokens, need);
@@ -587,9 +592,8 @@ int vptq_quant_gemv_sliced_tokens_grouped(const VptqLayerDesc* descs, const Vptq
     if (int rc = validate_layer(descs + i)) return rc;
     if (!y[i]) return fail(VPTQ_E_NULL, "y[%d] is NULL", i);
   }
-  if (flags & (VPTQ_GEMV_EXACT | VPTQ_GEMV_FORCE_GENERIC))
-    return fail(VPTQ_E_UNSUPPORTED, "the sliced path has the folded arithmetic only: use vptq_quant_gemv");
-  if (!vptq::gemv_sliced_tok_groupable(descs, layouts, n, tokens))
+  if (flags & VPTQ_GEMV_FORCE_GENERIC) return fail(VPTQ_E_UNSUPPORTED, "the sliced path is not the generic kernel: use vptq_quant_gemv");
+  if (!vptq::gemv_sliced_tok_groupable(descs, layouts, n, tokens, (flags & VPTQ_GEMV_EXACT) != 0))
     return fail(VPTQ_E_UNSUPPORTED, "a sliced group of 2 - 4 tokens takes layers of ONE format, dtype and input width whose layouts carry wstart");
   if ((((uintptr_t)x) & 15) != 0) return fail(VPTQ_E_UNSUPPORTED, "x must be 16-byte aligned");
   for (int i = 0; i < n; ++i) {

@@ -1,4 +1,4 @@
-// Fused dequant + GEMV for 2 - 4 TOKENS over the load-time derived sliced layouts of gemv_sliced.hip (large-codebook
+// Fused dequant + GEMV for 2 - 8 TOKENS over the load-time derived sliced layouts of gemv_sliced.hip (large-codebook
 // formats: v = 8 / 16, 16384 ... 65536 main centroids, any residual codebook; reference: WqA16WithOutliers_PackIndice,
 // csrc/kernels/quant_gemv.cuh:11-186, which serves these token counts - vptq/ops/quant_gemm.py:213 - by gathering every
 // centroid row from the 1 - 2 MiB codebook through the caches once per token batch).
@@ -17,8 +17,9 @@
 //     (ds_read_b64_tr_b16) deliver entries and activations in the operand layout of v_mfma_f32_16x16x32, see `MF` below: a third
 //     of the vector instructions, 4 sums per lane, no reduction (8192^2, 4 tokens: 35.5 -> 26.5 us; two tables 59.0 -> 40.4).
 // The rows' sums live in LDS (owned by the wave: no atomics, a fixed order); after the last phase they go out as partial sums
-// per (table, slice) and meet as in gemv_sliced.hip: the last workgroup of the row block adds them in a fixed order.  Folded
-// arithmetic (gemv_k256m.hip): y[t] = sum c[idx] f16(s x[t]) + sum b x[t] + bias.
+// per (table, slice) and meet at the last workgroup of the row block, which adds them in a fixed order.  Folded arithmetic
+// (gemv_k256m.hip): y[t] = sum c[idx] f16(s x[t]) + sum b x[t] + bias; EX (round 5): the reference's roundings per weight, see the
+// kernel's comment.
 // What the stream loop must NOT contain (found the hard way, profiles/r04/sliced_tokens_*.txt): a load the compiler can see
 // (it then waits for vmcnt(0) in every step - the activations of a phase are loaded by ONE asm statement with its own wait,
 // a layer's permutation is applied by a pre-pass), a load that is issued on some paths only (the waits then shrink down the
@@ -65,6 +66,7 @@ struct SlicedTokParams {
   int wcols;                 // columns per layout window
   int x_stride, x_in_stride, y_stride;    // elements between two tokens of xs / p.x / y
   uint32_t bd_off, res_off, sum_off;   // LDS: sum b x parts [TOK][16 waves] floats; 256-entry residual table; row sums
+  uint32_t sb_off;           // EX: LDS, per staged column 8 bytes {s, b, s, b} (and the zero column's zeros)
   int reg_sums;              // (matrix-pipe mode, <= kSTRegRows rows per wave) the rows' sums stay in registers: no LDS for them
 };
 
@@ -77,7 +79,13 @@ struct SlicedTokGroupParams {
   SlicedTokParams p[kSTMaxGroup];
 };
 
-template <typename DT, int NSL, bool RES, int V, bool TWO, int TOK>
+// EX: the reference's roundings (vptq/ops/quant_gemm.py:121,155-156): every weight rebuilt as f16(f16(f16(c + r) s) + b) before it
+// meets the RAW activations - matrix-pipe mode only (4 / 8 token slots), one table (+ the 256-entry residual table): the
+// transposing gather that hands a lane component m of four elements' entries hands it the four elements' scales (m even) or biases
+// (m odd) the same way - 8 bytes {s, b, s, b} per staged column; lanes m and m ^ 1 hold the same four elements, a swap inside
+// the pair gives each both - so the rebuild is 2 packed ops per operand register (+ 1 for c + r, which takes the place of the
+// second MFMA).  No sum b x part.
+template <typename DT, int NSL, bool RES, int V, bool TWO, int TOK, bool EX = false>
 __global__ __launch_bounds__(kSLThreads) void gemv_sliced_tok_kernel(const SlicedTokGroupParams GP) {
   // this workgroup's layer; its parameters come out of the kernel-argument segment through the scalar cache (gemv_sliced.hip)
   int layer = 0;
@@ -93,7 +101,7 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_tok_kernel(const Slice
   const SlicedTokParams TP = GP.p[0];   // (host pass of the compiler: never executed)
 #endif
   static_assert(((V == 8 && (NSL == 8 || NSL == 16)) || (V == 16 && (NSL == 16 || NSL == 32))) && (V == 8 || !RES) && !(TWO && RES) &&
-                (TOK == 2 || TOK == 4 || TOK == 8), "instantiation");
+                (TOK == 2 || TOK == 4 || TOK == 8) && (!EX || (TOK >= 4 && !TWO)), "instantiation");
   const SlicedParams& P = TP.p;
   constexpr int NSLT = TWO ? 2 * NSL : NSL;
   constexpr uint32_t kEntry = V * 2u;
@@ -157,7 +165,7 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_tok_kernel(const Slice
     }
   }
   // ---- sum b x per token (the workgroups of slice 0: it rides in their partial sums), x in input-feature order
-  if (sg == 0) {
+  if (sg == 0 && !EX) {
     float bd[TOK];
 #pragma unroll
     for (int t = 0; t < TOK; ++t) bd[t] = 0.f;
@@ -196,7 +204,7 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_tok_kernel(const Slice
   // versions ran with NO load in flight across a step - 25 of 37 us for 4 tokens at 8192^2).  The statement's wait drains the
   // queue once per phase; the steps keep their counted waits.  (x is in column order here: a layer's permutation is applied
   // by a pre-pass, launch_gemv_sliced_tok.)
-  struct Chunk { u32x4 v[TOK]; };
+  struct Chunk { u32x4 v[TOK]; u32x4 s, b; };
   auto load_chunk = [&](int c0, int q) __attribute__((always_inline)) {
     Chunk ch;
     const int c = c0 + 8 * q;
@@ -205,26 +213,57 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_tok_kernel(const Slice
 #pragma unroll
     for (int t = 0; t < TOK; ++t) px[t] = as_global(TP.xs) + (size_t)(t < tokens ? t : 0) * TP.x_stride + c;
     u32x4 sv;
+    // EX: the column-order bias rides in the same statement (ONE exposed wait per chunk; without a bias: the scales again, dropped)
+    [[maybe_unused]] u32x4 bv = {0u, 0u, 0u, 0u};
+    [[maybe_unused]] const uint16_t* const pb = (EX && P.cbias != nullptr) ? as_global(P.cbias) + c : ps;
     if constexpr (TOK == 2) {
       u32x4 a, b;
       asm volatile("global_load_dwordx4 %0, %3, off\n\tglobal_load_dwordx4 %1, %4, off\n\tglobal_load_dwordx4 %2, %5, off\n\ts_waitcnt vmcnt(0)"
                    : "=&v"(a), "=&v"(b), "=&v"(sv) : "v"(px[0]), "v"(px[1]), "v"(ps) : "memory");
       ch.v[0] = a; ch.v[1] = b;
-    } else {
+    } else if constexpr (TOK == 4) {
       u32x4 a, b, c2, d;
+      if constexpr (EX)
+        asm volatile("global_load_dwordx4 %0, %6, off\n\tglobal_load_dwordx4 %1, %7, off\n\tglobal_load_dwordx4 %2, %8, off\n\t"
+                     "global_load_dwordx4 %3, %9, off\n\tglobal_load_dwordx4 %4, %10, off\n\tglobal_load_dwordx4 %5, %11, off\n\t"
+                     "s_waitcnt vmcnt(0)"
+                     : "=&v"(a), "=&v"(b), "=&v"(c2), "=&v"(d), "=&v"(sv), "=&v"(bv)
+                     : "v"(px[0]), "v"(px[1]), "v"(px[2]), "v"(px[3]), "v"(ps), "v"(pb) : "memory");
+      else
+        asm volatile("global_load_dwordx4 %0, %5, off\n\tglobal_load_dwordx4 %1, %6, off\n\tglobal_load_dwordx4 %2, %7, off\n\t"
+                     "global_load_dwordx4 %3, %8, off\n\tglobal_load_dwordx4 %4, %9, off\n\ts_waitcnt vmcnt(0)"
+                     : "=&v"(a), "=&v"(b), "=&v"(c2), "=&v"(d), "=&v"(sv)
+                     : "v"(px[0]), "v"(px[1]), "v"(px[2]), "v"(px[3]), "v"(ps) : "memory");
+      ch.v[0] = a; ch.v[1] = b; ch.v[2] = c2; ch.v[3] = d;
+    } else {   // 8 token slots: two statements (ONE with ten loads - 40 result registers live across the wait - was measured at
+      // 95 instead of 55 us per 8192^2 layer: profiles/r05/sliced_tokens_exact.txt); the bias rides in the second
+      u32x4 a, b, c2, d, e2, f2, g2, h2;
       asm volatile("global_load_dwordx4 %0, %5, off\n\tglobal_load_dwordx4 %1, %6, off\n\tglobal_load_dwordx4 %2, %7, off\n\t"
                    "global_load_dwordx4 %3, %8, off\n\tglobal_load_dwordx4 %4, %9, off\n\ts_waitcnt vmcnt(0)"
                    : "=&v"(a), "=&v"(b), "=&v"(c2), "=&v"(d), "=&v"(sv)
                    : "v"(px[0]), "v"(px[1]), "v"(px[2]), "v"(px[3]), "v"(ps) : "memory");
       ch.v[0] = a; ch.v[1] = b; ch.v[2] = c2; ch.v[3] = d;
-      if constexpr (TOK == 8) {   // (tokens 4 - 7: a second statement)
-        u32x4 e2, f2, g2, h2;
+      if constexpr (EX)
+        asm volatile("global_load_dwordx4 %0, %5, off\n\tglobal_load_dwordx4 %1, %6, off\n\tglobal_load_dwordx4 %2, %7, off\n\t"
+                     "global_load_dwordx4 %3, %8, off\n\tglobal_load_dwordx4 %4, %9, off\n\ts_waitcnt vmcnt(0)"
+                     : "=&v"(e2), "=&v"(f2), "=&v"(g2), "=&v"(h2), "=&v"(bv)
+                     : "v"(px[TOK - 4]), "v"(px[TOK - 3]), "v"(px[TOK - 2]), "v"(px[TOK - 1]), "v"(pb) : "memory");
+      else
         asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %5, off\n\tglobal_load_dwordx4 %2, %6, off\n\t"
                      "global_load_dwordx4 %3, %7, off\n\ts_waitcnt vmcnt(0)"
                      : "=&v"(e2), "=&v"(f2), "=&v"(g2), "=&v"(h2)
                      : "v"(px[TOK - 4]), "v"(px[TOK - 3]), "v"(px[TOK - 2]), "v"(px[TOK - 1]) : "memory");
-        ch.v[TOK - 4] = e2; ch.v[TOK - 3] = f2; ch.v[TOK - 2] = g2; ch.v[TOK - 1] = h2;
+      ch.v[TOK - 4] = e2; ch.v[TOK - 3] = f2; ch.v[TOK - 2] = g2; ch.v[TOK - 1] = h2;
+    }
+    if constexpr (EX) {   // the activations stay raw; scale and bias (column order) are staged per column
+      if (P.cbias == nullptr) bv = u32x4{0u, 0u, 0u, 0u};
+      ch.s = sv; ch.b = bv;
+#pragma unroll
+      for (int t = 0; t < TOK; ++t) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ch.v[t][i] = t < tokens ? ch.v[t][i] : 0u;
       }
+      return ch;
     }
 #pragma unroll
     for (int t = 0; t < TOK; ++t) {
@@ -236,6 +275,15 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_tok_kernel(const Slice
   // [column][token] halves: column 2 i of the chunk = the low halves of v[t][i], column 2 i + 1 the high halves
   auto store_chunk = [&](const Chunk& ch, int q) __attribute__((always_inline)) {
     const uint32_t base = kXOff + (uint32_t)q * 8u * kXStride;
+    if constexpr (EX) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const uint32_t sw = (j & 1) ? (ch.s[j / 2] >> 16) : (ch.s[j / 2] & 0xffffu);
+        const uint32_t bw = (j & 1) ? (ch.b[j / 2] >> 16) : (ch.b[j / 2] & 0xffffu);
+        const uint32_t sb = sw | (bw << 16);
+        *(__attribute__((address_space(3))) u32x2*)(uintptr_t)(TP.sb_off + (uint32_t)(q * 8 + j) * 8u) = u32x2{sb, sb};
+      }
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       if constexpr (TOK == 2) {
@@ -255,6 +303,51 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_tok_kernel(const Slice
         }
         lds_store16(base + (uint32_t)(2 * i) * 16u, lo);
         lds_store16(base + (uint32_t)(2 * i + 1) * 16u, hi);
+      }
+    }
+  };
+
+  // 8 token slots: a chunk is staged in two HALVES of four tokens (8 of a column's 16 bytes each).  All eight tokens (+ scale
+  // + bias: 40 result registers and 10 addresses across one wait, next to the queue's registers) spilled into the stream loop:
+  // the 256-entry-table variants ran at 90 instead of 55 us per 8192^2 layer (profiles/r05/sliced_tokens_exact.txt)
+  [[maybe_unused]] auto stage8 = [&](int c0, int q) __attribute__((always_inline)) {
+    const int c = c0 + 8 * q;
+    const uint16_t* const ps = as_global(P.scale) + c;
+    const uint16_t* const pb = (EX && P.cbias != nullptr) ? as_global(P.cbias) + c : ps;
+    const uint32_t base = kXOff + (uint32_t)q * 8u * kXStride;
+    u32x4 sv = {0u, 0u, 0u, 0u}, bv = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      const uint16_t* px[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) px[t] = as_global(TP.xs) + (size_t)(4 * hf + t < tokens ? 4 * hf + t : 0) * TP.x_stride + c;
+      u32x4 v[4], w;
+      asm volatile("global_load_dwordx4 %0, %5, off\n\tglobal_load_dwordx4 %1, %6, off\n\tglobal_load_dwordx4 %2, %7, off\n\t"
+                   "global_load_dwordx4 %3, %8, off\n\tglobal_load_dwordx4 %4, %9, off\n\ts_waitcnt vmcnt(0)"
+                   : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(w)
+                   : "v"(px[0]), "v"(px[1]), "v"(px[2]), "v"(px[3]), "v"(hf == 0 ? ps : pb) : "memory");
+      if (hf == 0) sv = w; else bv = w;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[t][i] = 4 * hf + t < tokens ? (EX ? v[t][i] : DT::mul2(v[t][i], sv[i])) : 0u;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {   // columns 2 i (low halves) and 2 i + 1 (high halves): tokens 4 hf .. 4 hf + 3 = bytes 8 hf .. of the 16
+        const uint32_t lo01 = (v[0][i] & 0xffffu) | (v[1][i] << 16), lo23 = (v[2][i] & 0xffffu) | (v[3][i] << 16);
+        const uint32_t hi01 = (v[0][i] >> 16) | (v[1][i] & 0xffff0000u), hi23 = (v[2][i] >> 16) | (v[3][i] & 0xffff0000u);
+        *(__attribute__((address_space(3))) u32x2*)(uintptr_t)(base + (uint32_t)(2 * i) * 16u + 8u * (uint32_t)hf) = u32x2{lo01, lo23};
+        *(__attribute__((address_space(3))) u32x2*)(uintptr_t)(base + (uint32_t)(2 * i + 1) * 16u + 8u * (uint32_t)hf) = u32x2{hi01, hi23};
+      }
+    }
+    if constexpr (EX) {
+      if (P.cbias == nullptr) bv = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const uint32_t sw = (j & 1) ? (sv[j / 2] >> 16) : (sv[j / 2] & 0xffffu);
+        const uint32_t bw = (j & 1) ? (bv[j / 2] >> 16) : (bv[j / 2] & 0xffffu);
+        const uint32_t sb = sw | (bw << 16);
+        *(__attribute__((address_space(3))) u32x2*)(uintptr_t)(TP.sb_off + (uint32_t)(q * 8 + j) * 8u) = u32x2{sb, sb};
       }
     }
   };
@@ -411,20 +504,43 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_tok_kernel(const Slice
       const uint32_t xq = TOK == 8 ? (uint32_t)(lane & 1) * 8u : 0u;
       const uint32_t qmask = (lane & (kChunks - 1)) >= (TOK == 8 ? 2u : 1u) ? 0xffffffffu : 0u;
       u32x2 at[EW], bt[EW], rt[RES ? EW : 1];
+      [[maybe_unused]] u32x2 sc[EX ? EW : 1], bi[EX ? EW : 1];
 #pragma unroll
       for (int i = 0; i < EW; ++i) {
         const uint32_t e = eq[S][i];
         bt[i] = st_lds_tr8((e >> 16) * kEntry + q8);
-        uint32_t ci = ((e & 0xffffu) - c0) | qmask;
+        const uint32_t cc = (e & 0xffffu) - c0;
+        uint32_t ci = cc | qmask;
         ci = ci < wlen ? ci : wlen;
         at[i] = st_lds_tr8(kXOff + ci * kXStride + xq);
         if constexpr (RES) rt[i] = st_lds_tr8(TP.res_off + (rq[S][i] << 4) + q8);
+        if constexpr (EX) {   // EVERY chunk's lanes bring their element's scale and bias (the zero column's: 0, 0)
+          // lanes with m = lane & 3 even receive the four elements' scales, odd ones their biases; the neighbour has the other
+          const u32x2 t = st_lds_tr8(TP.sb_off + (cc < wlen ? cc : wlen) * 8u);
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t[h], 0xB1 /* quad_perm [1, 0, 3, 2] */, 0xf, 0xf, true);
+            sc[i][h] = (lane & 1) ? o : t[h];
+            bi[i][h] = (lane & 1) ? t[h] : o;
+          }
+        }
+      }
+      if constexpr (EX) {
+#pragma unroll
+        for (int i = 0; i < EW; ++i) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            uint32_t w = bt[i][h];
+            if constexpr (RES) w = DT::add2(w, rt[i][h]);
+            bt[i][h] = DT::add2(DT::mul2(w, sc[i][h]), bi[i][h]);
+          }
+        }
       }
 #pragma unroll
       for (int i = 0; i < EW; i += 2) {
         const u32x4 A = {at[i][0], at[i][1], at[i + 1][0], at[i + 1][1]};
         accm = st_mfma<DT>(A, u32x4{bt[i][0], bt[i][1], bt[i + 1][0], bt[i + 1][1]}, accm);
-        if constexpr (RES) accm = st_mfma<DT>(A, u32x4{rt[i][0], rt[i][1], rt[i + 1][0], rt[i + 1][1]}, accm);
+        if constexpr (RES && !EX) accm = st_mfma<DT>(A, u32x4{rt[i][0], rt[i][1], rt[i + 1][0], rt[i + 1][1]}, accm);
       }
       return;
     }
@@ -507,11 +623,15 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_tok_kernel(const Slice
     c0 = (uint32_t)phase_c0(ph);
     wlen = (uint32_t)phase_c1(ph) - c0;
     const int chunks = (int)(wlen >> 3);
-    for (int q = tid; q < chunks; q += kSLThreads) store_chunk(load_chunk((int)c0, q), q);
+    for (int q = tid; q < chunks; q += kSLThreads) {
+      if constexpr (TOK == 8) stage8((int)c0, q);
+      else store_chunk(load_chunk((int)c0, q), q);
+    }
     if (tid == 0) {   // the zero column
       if constexpr (TOK == 2) *(__attribute__((address_space(3))) uint32_t*)(uintptr_t)(kXOff + wlen * kXStride) = 0u;
       else if constexpr (TOK == 4) *(__attribute__((address_space(3))) u32x2*)(uintptr_t)(kXOff + wlen * kXStride) = u32x2{0u, 0u};
       else lds_store16(kXOff + wlen * kXStride, u32x4{0u, 0u, 0u, 0u});
+      if constexpr (EX) *(__attribute__((address_space(3))) u32x2*)(uintptr_t)(TP.sb_off + wlen * 8u) = u32x2{0u, 0u};   // (scale 0, bias 0: a weight of 0)
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     __builtin_amdgcn_s_barrier();
@@ -568,7 +688,7 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_tok_kernel(const Slice
 #pragma unroll
     for (int t = 0; t < TOK; ++t) {
       bdot[t] = 0.f;
-      if (sg == 0) {
+      if (sg == 0 && !EX) {
         const float* const bp = (const float*)(smem + TP.bd_off) + t * kSLWaves;
 #pragma unroll
         for (int i = 0; i < kSLWaves; ++i) bdot[t] += bp[i];
@@ -645,11 +765,12 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_tok_kernel(const Slice
   }
 }
 
-// ---- launchers (both parts of the build: the file is compiled twice, VPTQ_ST_PART = 1: 2 and 4 token slots + the host side,
-// 2: the 8-slot instantiations - two minutes of compile time as one translation unit)
-template <typename DT, int NSL, bool RES, int V, bool TWO, int TOK>
+// ---- launchers (every part of the build: the file is compiled four times, VPTQ_ST_PART = 1: 2 and 4 token slots + the host
+// side, 2: the 8-slot instantiations, 3 / 4: 4 / 8 slots with the reference's roundings - minutes of compile time as one
+// translation unit)
+template <typename DT, int NSL, bool RES, int V, bool TWO, int TOK, bool EX = false>
 static hipError_t launch_st(const SlicedTokGroupParams& P, int grid, uint32_t lds, hipStream_t st) {
-  auto kern = gemv_sliced_tok_kernel<DT, NSL, RES, V, TWO, TOK>;
+  auto kern = gemv_sliced_tok_kernel<DT, NSL, RES, V, TWO, TOK, EX>;
   static std::atomic<bool> attr_set[64];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
@@ -672,6 +793,25 @@ static hipError_t launch_st_dt(const SlicedTokGroupParams& P, int grid, int v, i
   return res ? launch_st<DT, 16, true, 8, false, TOK>(P, grid, lds, st) : launch_st<DT, 16, false, 8, false, TOK>(P, grid, lds, st);
 }
 
+template <typename DT, int TOK>
+static hipError_t launch_st_ex(const SlicedTokGroupParams& P, int grid, int v, int nsl, bool res, uint32_t lds, hipStream_t st) {
+  if (v == 16) return nsl == 16 ? launch_st<DT, 16, false, 16, false, TOK, true>(P, grid, lds, st) : launch_st<DT, 32, false, 16, false, TOK, true>(P, grid, lds, st);
+  if (nsl == 8) return res ? launch_st<DT, 8, true, 8, false, TOK, true>(P, grid, lds, st) : launch_st<DT, 8, false, 8, false, TOK, true>(P, grid, lds, st);
+  return res ? launch_st<DT, 16, true, 8, false, TOK, true>(P, grid, lds, st) : launch_st<DT, 16, false, 8, false, TOK, true>(P, grid, lds, st);
+}
+hipError_t launch_st_ex4(int dtype, const SlicedTokGroupParams& P, int grid, int v, int nsl, bool res, uint32_t lds, hipStream_t st);
+hipError_t launch_st_ex8(int dtype, const SlicedTokGroupParams& P, int grid, int v, int nsl, bool res, uint32_t lds, hipStream_t st);
+#if !defined(VPTQ_ST_PART) || VPTQ_ST_PART == 3
+hipError_t launch_st_ex4(int dtype, const SlicedTokGroupParams& P, int grid, int v, int nsl, bool res, uint32_t lds, hipStream_t st) {
+  return dtype == VPTQ_DTYPE_F16 ? launch_st_ex<F16, 4>(P, grid, v, nsl, res, lds, st) : launch_st_ex<BF16, 4>(P, grid, v, nsl, res, lds, st);
+}
+#endif
+#if !defined(VPTQ_ST_PART) || VPTQ_ST_PART == 4
+hipError_t launch_st_ex8(int dtype, const SlicedTokGroupParams& P, int grid, int v, int nsl, bool res, uint32_t lds, hipStream_t st) {
+  return dtype == VPTQ_DTYPE_F16 ? launch_st_ex<F16, 8>(P, grid, v, nsl, res, lds, st) : launch_st_ex<BF16, 8>(P, grid, v, nsl, res, lds, st);
+}
+#endif
+
 hipError_t launch_st_tok8(int dtype, const SlicedTokGroupParams& P, int grid, int v, int nsl, bool res, bool two, uint32_t lds, hipStream_t st);
 #if !defined(VPTQ_ST_PART) || VPTQ_ST_PART == 2
 hipError_t launch_st_tok8(int dtype, const SlicedTokGroupParams& P, int grid, int v, int nsl, bool res, bool two, uint32_t lds, hipStream_t st) {
@@ -681,8 +821,9 @@ hipError_t launch_st_tok8(int dtype, const SlicedTokGroupParams& P, int grid, in
 
 #if !defined(VPTQ_ST_PART) || VPTQ_ST_PART == 1
 // ---- host side -------------------------------------------------------------------
-static size_t st_partial_bytes(const VptqLayerDesc& d, int tokens) {
-  const size_t parts = (size_t)gemv_sliced_slices(d) * (sl_two(d) ? 2 : 1);
+static bool st_exact_ok(const VptqLayerDesc& d) { return !sl_two(d) && gemv_sliced_eligible(d, true); }
+static size_t st_partial_bytes(const VptqLayerDesc& d, int tokens, bool exact) {
+  const size_t parts = exact ? (size_t)gemv_sliced_slices(d, true) : (size_t)gemv_sliced_slices(d) * (sl_two(d) ? 2 : 1);
   return ((size_t)tokens * parts * d.num_indices * d.vector_len * sizeof(float) + 255) / 256 * 256;
 }
 static size_t st_counter_bytes(const VptqLayerDesc& d) {
@@ -692,28 +833,34 @@ static size_t st_counter_bytes(const VptqLayerDesc& d) {
 // the compiler can see inside its stream loop costs it the counted waits, so the gather is a pre-pass (gemv_k256c.hip:
 // permute_x_kernel, one workgroup per 2048 columns and token)
 static size_t st_perm_bytes(const VptqLayerDesc& d, int tokens) { return (size_t)tokens * gemv_k256c_perm_bytes(d); }
+// (one size for both arithmetics: the exact layouts may have twice the slices)
+static size_t st_partial_bytes_max(const VptqLayerDesc& d, int tokens) {
+  const size_t a = gemv_sliced_eligible(d) ? st_partial_bytes(d, tokens, false) : 0, b = st_exact_ok(d) ? st_partial_bytes(d, tokens, true) : 0;
+  return a > b ? a : b;
+}
 size_t gemv_sliced_tok_workspace_bytes(const VptqLayerDesc& d, int tokens) {
-  return st_partial_bytes(d, tokens) + st_counter_bytes(d) + st_perm_bytes(d, tokens);
+  return st_partial_bytes_max(d, tokens) + st_counter_bytes(d) + st_perm_bytes(d, tokens);
 }
 
 // rows per wave: one round of workgroups (slices x tables x row blocks of 16 waves ~ the CUs)
-static int st_rows_per_wave(const VptqLayerDesc& d) {
-  const long long nslt = (long long)gemv_sliced_slices(d) * (sl_two(d) ? 2 : 1);
+static int st_rows_per_wave(const VptqLayerDesc& d, bool exact) {
+  const long long nslt = exact ? (long long)gemv_sliced_slices(d, true) : (long long)gemv_sliced_slices(d) * (sl_two(d) ? 2 : 1);
   long long r = ((long long)d.num_indices * nslt + kSLWaves * 256 - 1) / (kSLWaves * 256);
   return (int)(r < 1 ? 1 : r > kSLMaxRowsPerWave ? kSLMaxRowsPerWave : r);
 }
 
-struct StPlan { int tok, phases, rpw, reg_sums; uint32_t x_off, bd_off, res_off, sum_off, lds; };
+struct StPlan { int tok, phases, rpw, reg_sums; uint32_t x_off, bd_off, res_off, sum_off, sb_off, lds; };
 // the template's token count (2 or 4), the fewest phases whose activations fit beside the table, and the LDS map.  The rows'
 // sums (16 waves x rows per wave x tokens x v floats) must fit too: where one round of workgroups does not leave room for
 // them even with 4 phases (v = 16 with two tables: 64 floats per row), fewer rows per wave - more workgroups - do.
-static bool st_plan(const VptqLayerDesc& d, const VptqSlicedLayout* L, int tokens, StPlan& pl, int rpw0 = 0) {
+static bool st_plan(const VptqLayerDesc& d, const VptqSlicedLayout* L, int tokens, bool exact, StPlan& pl, int rpw0 = 0) {
   if (tokens < 2 || tokens > 8) return false;
   const bool res = sl_res256(d), two = sl_two(d);
+  if (exact && !st_exact_ok(d)) return false;
   static std::atomic<int> tok4{-1};   // VPTQ_SLICED_TOK4=1: 2 tokens through the 4-slot (matrix-pipe) kernel too (A/B runs)
   if (tok4 < 0) { const char* e = getenv("VPTQ_SLICED_TOK4"); tok4 = (e && atoi(e) == 1) ? 1 : 0; }
-  pl.tok = tokens > 4 ? 8 : (tokens == 2 && !tok4) ? 2 : 4;
-  uint32_t tab = sl_tab_bytes(d, d.num_centroids, 0);
+  pl.tok = tokens > 4 ? 8 : (tokens == 2 && !tok4 && !exact) ? 2 : 4;   // (the reference's roundings: matrix-pipe mode only)
+  uint32_t tab = sl_tab_bytes(d, d.num_centroids, 0, exact);
   if (two) {
     const uint32_t t1 = sl_tab_bytes(d, d.num_res_centroids, L[1].whole_table);
     tab = t1 > tab ? t1 : tab;
@@ -725,11 +872,12 @@ static bool st_plan(const VptqLayerDesc& d, const VptqSlicedLayout* L, int token
   if (min_phases < 0) { const char* e = getenv("VPTQ_SLICED_MIN_PHASES"); const int v = e ? atoi(e) : 1; min_phases = (v == 2 || v == 4) ? v : 1; }
   static std::atomic<int> no_reg_sums{-1};  // VPTQ_SLICED_LDS_SUMS=1: the rows' sums in LDS in every mode (A/B runs)
   if (no_reg_sums < 0) { const char* e = getenv("VPTQ_SLICED_LDS_SUMS"); no_reg_sums = (e && atoi(e) == 1) ? 1 : 0; }
-  for (int rpw = rpw0 > 0 ? rpw0 : st_rows_per_wave(d); rpw >= 1; rpw = rpw > 1 ? (rpw + 1) / 2 : 0) {
+  for (int rpw = rpw0 > 0 ? rpw0 : st_rows_per_wave(d, exact); rpw >= 1; rpw = rpw > 1 ? (rpw + 1) / 2 : 0) {
     for (int phases = min_phases; phases <= kSTWindows; phases *= 2) {
       const int wmax = (kSTWindows / phases) * wcols < G ? (kSTWindows / phases) * wcols : G;   // columns of the widest phase
       uint32_t o = pl.x_off + (uint32_t)(wmax + 8) * (uint32_t)pl.tok * 2u;
       o = (o + 15u) & ~15u;
+      pl.sb_off = o; o += exact ? (uint32_t)(wmax + 8) * 8u : 0u;
       pl.bd_off = o; o += (uint32_t)pl.tok * kSLWaves * 4u;
       pl.res_off = o; o += res ? 4096u : 0u;
       const int reg_sums = pl.tok >= 4 && rpw <= kSTRegRows && !no_reg_sums;   // (matrix-pipe mode: 4 registers per row)
@@ -740,22 +888,23 @@ static bool st_plan(const VptqLayerDesc& d, const VptqSlicedLayout* L, int token
   return false;
 }
 
-bool gemv_sliced_tok_eligible(const VptqLayerDesc& d, const VptqSlicedLayout* L, int tokens) {
+bool gemv_sliced_tok_eligible(const VptqLayerDesc& d, const VptqSlicedLayout* L, int tokens, bool exact) {
   StPlan pl;
-  if (!gemv_sliced_eligible(d) || !L) return false;
-  const int n = gemv_sliced_tables(d);
+  if (!(exact ? st_exact_ok(d) : gemv_sliced_eligible(d)) || !L) return false;
+  const int n = exact ? 1 : gemv_sliced_tables(d);
   for (int i = 0; i < n; ++i)
-    if (!L[i].wstart) return false;
-  return st_plan(d, L, tokens, pl);
+    if (!L[i].wstart || L[i].n_slices != gemv_sliced_slices(d, exact)) return false;   // (the arithmetic's own slice count)
+  return st_plan(d, L, tokens, exact, pl);
 }
 
 // one layer's parameter block (its permutation pre-pass is queued into perm_*: one launch for the whole group)
 struct StPermJobs { VptqLayerDesc d[8 * kSTMaxGroup]; const void* xin[8 * kSTMaxGroup]; void* xout[8 * kSTMaxGroup]; int n; };
 static hipError_t st_fill(const VptqLayerDesc& d, const VptqSlicedLayout* L, const void* x, void* y, int tokens, int flags, void* ws,
                           int rpw0, SlicedTokParams& TP, StPlan& pl, StPermJobs& jobs) {
-  if (!gemv_sliced_tok_eligible(d, L, tokens) || !st_plan(d, L, tokens, pl, rpw0)) return hipErrorInvalidValue;
+  const bool exact = (flags & VPTQ_GEMV_EXACT) != 0;
+  if (!gemv_sliced_tok_eligible(d, L, tokens, exact) || !st_plan(d, L, tokens, exact, pl, rpw0)) return hipErrorInvalidValue;
   const bool res = sl_res256(d), two = sl_two(d);
-  const int nsl = gemv_sliced_slices(d);
+  const int nsl = gemv_sliced_slices(d, exact);
   if (!sl_layout_ok(d, L[0], nsl, res, d.num_centroids) || L[0].whole_table != 0 ||
       (two && (!sl_layout_ok(d, L[1], nsl, false, d.num_res_centroids) || L[1].whole_table != gemv_sliced_whole_table(d, 1))) ||
       !ws || (((uintptr_t)x) & 15) != 0 || (d.in_features % 8) != 0)
@@ -768,7 +917,7 @@ static hipError_t st_fill(const VptqLayerDesc& d, const VptqSlicedLayout* L, con
   P.blocks = (const int32_t*)L[0].blocks;
   P.first = (const int32_t*)L[0].first;
   P.cent = (const uint32_t*)d.centroids;
-  P.tab0 = sl_tab_bytes(d, d.num_centroids, 0);
+  P.tab0 = sl_tab_bytes(d, d.num_centroids, 0, exact);
   P.stride0 = P.tab0;
   TP.wstart = (const int32_t*)L[0].wstart;
   if (two) {
@@ -784,11 +933,12 @@ static hipError_t st_fill(const VptqLayerDesc& d, const VptqSlicedLayout* L, con
   P.x = (const uint16_t*)x;
   P.scale = (const uint16_t*)(d.perm ? d.scale_permuted : d.weight_scale);
   P.wbias = (const uint16_t*)d.weight_bias;
+  P.cbias = (const uint16_t*)(d.perm ? d.bias_permuted : d.weight_bias);
   P.perm = nullptr;
   TP.xs = (const uint16_t*)x;
   TP.x_stride = d.in_features;
   if (d.perm) {
-    char* const base = (char*)ws + st_counter_bytes(d) + st_partial_bytes(d, tokens);
+    char* const base = (char*)ws + st_counter_bytes(d) + st_partial_bytes_max(d, tokens);
     for (int t = 0; t < tokens; ++t) {
       jobs.d[jobs.n] = d;
       jobs.xin[jobs.n] = (const uint16_t*)x + (size_t)t * d.in_features;
@@ -813,17 +963,17 @@ static hipError_t st_fill(const VptqLayerDesc& d, const VptqSlicedLayout* L, con
   TP.wcols = (d.group_size + kSTWindows * 8 - 1) / (kSTWindows * 8) * 8;
   TP.x_in_stride = d.in_features;
   TP.y_stride = d.out_features;
-  TP.bd_off = pl.bd_off; TP.res_off = pl.res_off; TP.sum_off = pl.sum_off;
+  TP.bd_off = pl.bd_off; TP.res_off = pl.res_off; TP.sum_off = pl.sum_off; TP.sb_off = pl.sb_off;
   TP.reg_sums = pl.reg_sums;
   return hipSuccess;
 }
 
 // n <= kSTMaxGroup layers of ONE format (vector length, slices, residual kind, dtype) and one input width reading the same x
-bool gemv_sliced_tok_groupable(const VptqLayerDesc* d, const VptqSlicedLayout* L, int n, int tokens) {
-  if (n < 1 || n > kSTMaxGroup || !gemv_sliced_groupable(d, n)) return false;
-  const int tables = gemv_sliced_tables(d[0]);
+bool gemv_sliced_tok_groupable(const VptqLayerDesc* d, const VptqSlicedLayout* L, int n, int tokens, bool exact) {
+  if (n < 1 || n > kSTMaxGroup || !gemv_sliced_groupable(d, n, exact)) return false;
+  const int tables = exact ? 1 : gemv_sliced_tables(d[0]);
   for (int i = 0; i < n; ++i)
-    if (!gemv_sliced_tok_eligible(d[i], L + (size_t)i * tables, tokens)) return false;
+    if (!gemv_sliced_tok_eligible(d[i], L + (size_t)i * tables, tokens, exact)) return false;
   return true;
 }
 
@@ -831,12 +981,13 @@ bool gemv_sliced_tok_groupable(const VptqLayerDesc* d, const VptqSlicedLayout* L
 // gemv_sliced_tok_workspace_bytes of layer i, zero before its first use (every launch leaves the counters zero)
 hipError_t launch_gemv_sliced_tok_group(const VptqLayerDesc* d, const VptqSlicedLayout* L, int n, const void* x, void* const* y,
                                         int tokens, int flags, void* const* ws, hipStream_t st) {
-  if (!gemv_sliced_tok_groupable(d, L, n, tokens)) return hipErrorInvalidValue;
+  const bool exact = (flags & VPTQ_GEMV_EXACT) != 0;
+  if (!gemv_sliced_tok_groupable(d, L, n, tokens, exact)) return hipErrorInvalidValue;
   SlicedTokGroupParams GP = {};
   GP.n = n;
   StPermJobs jobs = {};
-  const int tables = gemv_sliced_tables(d[0]);
-  const int nslt = gemv_sliced_slices(d[0]) * tables;
+  const int tables = exact ? 1 : gemv_sliced_tables(d[0]);
+  const int nslt = gemv_sliced_slices(d[0], exact) * tables;
   // rows per wave: one round of workgroups over ALL members
   long long rows = 0;
   for (int i = 0; i < n; ++i) rows += d[i].num_indices;
@@ -863,7 +1014,10 @@ hipError_t launch_gemv_sliced_tok_group(const VptqLayerDesc* d, const VptqSliced
   }
   const int grid = GP.start[n];
   const bool res = sl_res256(d[0]), two = sl_two(d[0]);
-  const int nsl = gemv_sliced_slices(d[0]);
+  const int nsl = gemv_sliced_slices(d[0], exact);
+  if (exact)
+    return tok == 8 ? launch_st_ex8(d[0].dtype, GP, grid, d[0].vector_len, nsl, res, lds, st)
+                    : launch_st_ex4(d[0].dtype, GP, grid, d[0].vector_len, nsl, res, lds, st);
   if (tok == 8) return launch_st_tok8(d[0].dtype, GP, grid, d[0].vector_len, nsl, res, two, lds, st);
   if (d[0].dtype == VPTQ_DTYPE_F16)
     return tok == 2 ? launch_st_dt<F16, 2>(GP, grid, d[0].vector_len, nsl, res, two, lds, st)

@@ -68,11 +68,11 @@ hipError_t launch_gemv_sliced(const VptqLayerDesc& d, const VptqSlicedLayout* L,
                               void* ws, hipStream_t st);
 // up to 3 layers of one format reading the same x (q / k / v, gate / up) in one launch
 // gemv_sliced_tok.hip - 2 - 4 tokens over the same layouts (column windows of every list, phase by phase)
-bool gemv_sliced_tok_eligible(const VptqLayerDesc& d, const VptqSlicedLayout* L, int tokens);
+bool gemv_sliced_tok_eligible(const VptqLayerDesc& d, const VptqSlicedLayout* L, int tokens, bool exact = false);
 size_t gemv_sliced_tok_workspace_bytes(const VptqLayerDesc& d, int tokens);
 hipError_t launch_gemv_sliced_tok(const VptqLayerDesc& d, const VptqSlicedLayout* L, const void* x, void* y, int tokens, int flags,
                                   void* ws, hipStream_t st);
-bool gemv_sliced_tok_groupable(const VptqLayerDesc* d, const VptqSlicedLayout* L, int n, int tokens);
+bool gemv_sliced_tok_groupable(const VptqLayerDesc* d, const VptqSlicedLayout* L, int n, int tokens, bool exact = false);
 hipError_t launch_gemv_sliced_tok_group(const VptqLayerDesc* d, const VptqSlicedLayout* L, int n, const void* x, void* const* y,
                                         int tokens, int flags, void* const* ws, hipStream_t st);
 bool gemv_sliced_groupable(const VptqLayerDesc* d, int n, bool exact = false);

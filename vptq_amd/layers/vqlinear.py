@@ -506,8 +506,14 @@ class VQuantLinear(nn.Module):
         against 40.2 / 44.0 / 24.1; small residual tables of v = 16: never)"""
         lim = sl.__dict__.get("_token_limit")
         if lim is None:
-            if sl.exact:      # (the reference's roundings over a layout: one token; the gather kernels take 2 - 8 for the price of one)
-                lim = 1
+            if sl.exact:
+                # the reference's roundings: the gather kernels take 2 - 8 tokens for the price of one; TWO exact sliced launches beat
+                # them on large v = 8 one-table layers only (profiles/r05/sliced_tokens_exact.txt, gather -> 2 launches, v8-k65536-256 /
+                # -0: 8192^2 41.8 -> 40.0 / 41.4 -> 32.9; 14336 x 4096 37.0 -> 32.6 / 37.1 -> 27.9; 8192 x 28672 148.7 -> 94.8 / 135.1 ->
+                # 80.9; but 4096 x 14336 36.7 -> 37.4, 4096^2 13.5 -> 19.5)
+                n_el = self.indices.shape[1] * self.group_size
+                kr = self.num_res_centroids if self.enable_residual else 0
+                lim = 2 if (self.vector_len == 8 and kr in (0, 256) and sl.slices >= 16 and n_el >= 6 << 20) else 1
             elif _SLICED_TOKENS_ENV is not None:
                 lim = _SLICED_TOKENS_ENV[1 if len(sl.layout) == 2 else 0]
             else:
@@ -522,8 +528,8 @@ class VQuantLinear(nn.Module):
         return lim
 
     def _sliced_one_launch(self, sl, tokens: int) -> bool:
-        """2 - 4 tokens in ONE launch over the layouts (column phases; 3 - 4 tokens: the contraction on the matrix pipe -
-        gemv_sliced_tok.hip)?  Measured against the gather kernels (profiles/r04/sliced_tokens_one_launch.txt; us per 8192^2 /
+        """2 - 4 tokens in ONE launch over the layouts (column phases; 3 - 4 tokens - in the reference's roundings: 2 - 4 - the
+        contraction on the matrix pipe - gemv_sliced_tok.hip)?  Measured against the gather kernels (profiles/r04/sliced_tokens_one_launch.txt; us per 8192^2 /
         4096^2 / 14336 x 4096 layer, gather -> one launch): v8-k65536-0: 2 tokens 40.8 / 12.9 / 36.6 -> 21.4 / 11.5 / 19.0, 4 tokens
         41.1 / 13.4 / 36.9 -> 26.0 / 13.5 / 22.8; -256: 40.9 / 13.2 / 36.8 -> 23.7 / 12.4 / 20.4 and 44.0 / 16.0 / 42.9 -> 29.4 / 14.8 / 23.9;
         -65536: 78.2 / 21.5 / 68.8 -> 33.7 / 15.9 / 28.5 and 80.0 / 23.6 / 72.0 -> 39.8 / 18.5 / 43.6; v16-k65536-0: 27.7 / 13.7 / 33.5 ->
@@ -538,6 +544,15 @@ class VQuantLinear(nn.Module):
                 ok = False
             elif _SLICED_ONE_LAUNCH in ("1", "on", "true", "yes", "always"):
                 ok = True
+            elif sl.exact:
+                # the reference's roundings (gemv_sliced_tok.hip, EX; profiles/r05/sliced_tokens_exact.txt, gather -> one launch, us per
+                # layer, v8-k65536-256): 8192^2: 2 / 3 / 4 tokens 41.5 / 43.7 / 42.0 -> 37.5 / 36.0 / 36.8; 14336 x 4096: 36.7 / 41.0 / 41.3 ->
+                # 37.4 / 37.5 / 38.0; 8192 x 28672: 148.7 / 146.6 / 147.9 -> 122.0 / 124.5 / 127.0 (-0: 135 -> 82 - 86); but 4096^2: 13.5 / 15.8 / 15.7 -> 20.9 / 20.7 / 20.8 and 4096 x 14336: 36.7 / 36.8 / 37.0 -> 41.1 / 41.3 /
+                # 41.9 (8 slices of 128 KiB leave room for a quarter of the columns: 4 phases); v = 16: 28.5 -> 36.0.  5 - 8 tokens: never
+                # (8192^2: 44 - 46 -> 54 - 55)
+                # 2 tokens: two launches of the one-token kernel are as fast or faster (_sliced_token_limit)
+                n_el = self.indices.shape[1] * self.group_size
+                ok = 3 <= tokens <= 4 and self.vector_len == 8 and sl.slices >= 16 and n_el >= 6 << 20
             else:
                 n_el = self.indices.shape[1] * self.group_size      # index elements per table
                 kr = self.num_res_centroids if self.enable_residual else 0

@@ -162,6 +162,7 @@ class SlicedGemv:
         # other than v8's 256-entry one rides along as a 16-bit side stream and its entries are gathered from device memory)
         n_tables = 1 if self.exact else B.lib().vptq_sliced_layout_tables(self.desc)
         side16 = self.exact and kr > 0 and not (layer.vector_len == 8 and kr == 256)
+        self._side16 = side16
         # a second table whose slice would be under 16 KiB is held WHOLE by each of its workgroups while it fits (the
         # library decides: the kernel's LDS budget)
         whole = [False, n_tables == 2 and bool(B.lib().vptq_sliced_layout_whole_table(self.desc, 1))]
@@ -225,9 +226,9 @@ class SlicedGemv:
     def tokens_supported(self, tokens: int) -> bool:
         """does the library's kernel for 2 - 4 tokens over these layouts take this layer (its activations must fit the LDS
         beside the slice in at most 4 column phases)?"""
-        if self.exact:      # (the token kernel has the folded arithmetic only, and its layouts another slice count)
+        if self.exact and self._side16:   # (the reference's roundings over two-table formats: one token only)
             return False
-        return bool(B.lib().vptq_quant_gemv_sliced_tokens_supported(self.desc, self._lay_ref, int(tokens)))
+        return bool(B.lib().vptq_quant_gemv_sliced_tokens_supported_for(self.desc, self._lay_ref, int(tokens), self._flags))
 
     def forward_tokens(self, x: torch.Tensor, out: torch.Tensor = None, flags: int = 0):
         """2 - 4 tokens in ONE launch (`vptq_quant_gemv_sliced_tokens`, gemv_sliced_tok.hip): x [..., in_features] with 2 - 4
@@ -236,7 +237,7 @@ class SlicedGemv:
         tokens = x.numel() // lay.in_features
         if x.shape[-1] != lay.in_features or not 2 <= tokens <= 8:
             raise ValueError("forward_tokens takes 2 - 8 tokens of in_features values")
-        if self.exact:
+        if self.exact and self._side16:
             return None
         if x.dtype != self._dtype or x.device != self.dev:
             x = lay._check_activation(x)
@@ -280,7 +281,7 @@ class SlicedGemv:
         if out is None:
             out = torch.empty(x.shape[:-1] + (lay.out_features,),
                               dtype=torch.float32 if (flags & B.GEMV_OUT_F32) else self._dtype, device=self.dev)
-        rc = self._fn_tok(self.desc, self._lay_ref, x.data_ptr(), out.data_ptr(), tokens, flags, ws.data_ptr(), ws.numel(), sp)
+        rc = self._fn_tok(self.desc, self._lay_ref, x.data_ptr(), out.data_ptr(), tokens, flags | self._flags, ws.data_ptr(), ws.numel(), sp)
         if rc == B.E_UNSUPPORTED:
             return None
         if rc:
@@ -333,7 +334,7 @@ class SlicedGroupGemv:
         self._wb = (C.c_size_t * n)(*[m._ws_bytes for m in self.members])
         self._fn = B.lib().vptq_quant_gemv_sliced_grouped
         self.dev, self._dtype, self._dev_index = m0.dev, m0._dtype, m0._dev_index
-        self.exact, self._flags = m0.exact, m0._flags
+        self.exact, self._flags, self._side16 = m0.exact, m0._flags, m0._side16
 
     def __call__(self, x: torch.Tensor):
         """list of outputs (one per member), or None where the call cannot take the sliced kernel (as SlicedGemv.__call__)"""
@@ -352,7 +353,7 @@ class SlicedGroupGemv:
         return self._launch(x)
 
     def tokens_supported(self, tokens: int) -> bool:
-        return not self.exact and all(m.tokens_supported(tokens) for m in self.members)
+        return all(m.tokens_supported(tokens) for m in self.members)
 
     def forward_tokens(self, x: torch.Tensor):
         """2 - 4 tokens through every member in ONE launch (`vptq_quant_gemv_sliced_tokens_grouped`): list of outputs, or None
@@ -361,7 +362,7 @@ class SlicedGroupGemv:
         tokens = x.numel() // lay.in_features
         if x.shape[-1] != lay.in_features or not 2 <= tokens <= 8:
             raise ValueError("forward_tokens takes 2 - 8 tokens of in_features values")
-        if self.exact:
+        if self.exact and self._side16:
             return None
         if x.dtype != self._dtype or x.device != self.dev:
             x = lay._check_activation(x)
@@ -388,7 +389,7 @@ class SlicedGroupGemv:
         for i, (y, w) in enumerate(zip(ys, wss)):
             self._yp[i] = y.data_ptr()
             self._wp[i] = w.data_ptr()
-        rc = B.lib().vptq_quant_gemv_sliced_tokens_grouped(self.descs, self.layouts, n, x.data_ptr(), self._yp, tokens, 0, self._wp, wb, sp)
+        rc = B.lib().vptq_quant_gemv_sliced_tokens_grouped(self.descs, self.layouts, n, x.data_ptr(), self._yp, tokens, self._flags, self._wp, wb, sp)
         if rc == B.E_UNSUPPORTED:
             return None
         if rc:
