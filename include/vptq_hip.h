@@ -347,7 +347,9 @@ VPTQ_API int vptq_quant_gemv_sliced(const VptqLayerDesc* desc, const VptqSlicedL
  * VPTQ_GEMV_EXACT) slices) of a one-table format (no residual codebook; v = 8 with 256 residual centroids): scale and bias of a
  * column are staged beside its activations (8 more bytes of LDS per column and phase), every weight is rebuilt as
  * f16(f16(f16(c + r) s) + b) in the matrix pipe's operand layout; vptq_quant_gemv_sliced_tokens_supported_for says whether the
- * layer's columns fit (4 phases x (2 x token slots + 8) bytes beside the slice: 5 - 8 tokens up to ~16000 columns). */
+ * layer's columns fit (4 phases x (2 x token slots + 8) bytes beside the slice: 5 - 8 tokens up to ~16000 columns).  2 / 3 tokens (v = 16:
+ * 2) of a layer whose slice leaves room for 2 x tokens + 4 bytes per column take ONE PASS of the one-token kernel instead (no `wstart`
+ * needed; accumulator words behind the arrival counters of the same workspace). */
 VPTQ_API int vptq_quant_gemv_sliced_tokens_supported(const VptqLayerDesc* desc, const VptqSlicedLayout* layout, int tokens);
 VPTQ_API int vptq_quant_gemv_sliced_tokens_supported_for(const VptqLayerDesc* desc, const VptqSlicedLayout* layout, int tokens, int flags);
 VPTQ_API size_t vptq_quant_gemv_sliced_tokens_workspace_bytes(const VptqLayerDesc* desc, int tokens);

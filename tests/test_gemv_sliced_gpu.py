@@ -176,6 +176,24 @@ def test_sliced_tokens_reference_roundings(I, O, kw, v, k, kr, tokens, dt, dev):
     y32 = sl.forward_tokens(xt, flags=B.GEMV_OUT_F32)
     assert y32.dtype == torch.float32 and torch.equal(y32.to(got.dtype).view(torch.int16), got.view(torch.int16))
     assert torch.equal(sl.forward_tokens(xt).view(torch.int16), got.view(torch.int16))
+    # 2 / 3 tokens where the slice + (2 tokens + 4) bytes per column fit the LDS: ONE pass of the one-token kernel (TOK) - it needs
+    # no column windows; everything else walks them in phases
+    lib = B.lib()
+    lay = B.SlicedLayout.from_buffer_copy(sl.layout[0])
+    lay.wstart = None
+    tab = (k // sl.slices) * v * 2
+    one_pass = tokens <= (3 if v == 8 else 2) and tab + (I + 64) * (4 + 2 * tokens) + 64 + (4096 if kr == 256 else 0) <= 163840
+    assert bool(lib.vptq_quant_gemv_sliced_tokens_supported_for(sl.desc, lay, tokens, EXACT)) == one_pass
+    if one_pass:
+        need = lib.vptq_quant_gemv_sliced_tokens_workspace_bytes(sl.desc, tokens)
+        ws = torch.zeros(need, dtype=torch.uint8, device=dev)
+        y = torch.empty_like(got)
+        assert lib.vptq_quant_gemv_sliced_tokens(sl.desc, lay, xt.data_ptr(), y.data_ptr(), tokens, EXACT, ws.data_ptr(), need, B.current_stream_ptr(dev)) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(y.view(torch.int16), got.view(torch.int16))
+        nrows = (O + v - 1) // v
+        cnt = ((nrows + 15) // 16 * 4 + 255) // 256 * 256
+        assert int(ws[cnt:cnt + 3 * nrows * v * 8].count_nonzero().item()) == 0
 
 
 @pytest.mark.parametrize("name,parts", [("t8_k65536_r256", [(0, 4), (0, 8), (2, 4), (3, 8)]), ("t2_k65536_r256_4096x4096", [(0, 2)]),
@@ -788,9 +806,10 @@ def test_module_route_for_two_to_four_tokens_in_one_launch(dev, monkeypatch, fol
 
 
 def test_module_default_route_for_two_to_four_tokens_of_wide_layers(dev, monkeypatch):
-    """the product default (reference roundings): 2 - 4 tokens of a LARGE v = 8 one-table layer whose exact layout has 16 slices go
-    through the exact token kernel in one launch (VQuantLinear._sliced_one_launch: where it was measured faster than the gather
-    kernel); everything else keeps the gather kernel; siblings share the launch"""
+    """the product default (reference roundings), 2 - 4 tokens of v = 8 one-table layers whose exact layout has 16 slices: 2 / 3 tokens
+    in ONE PASS of the one-token kernel where the operands fit its LDS (8192 columns), else - large layers - two launches (2 tokens)
+    or the column-phase kernel (3 - 4 tokens) (VQuantLinear._sliced_one_launch / _sliced_token_limit: where each was measured
+    faster than the gather kernel); everything else keeps the gather kernel; siblings share the launch"""
     import vptq_amd
     import vptq_amd.layers.vqlinear as vq
     from vptq_amd.layers.vqlinear import SiblingGroup
@@ -801,31 +820,42 @@ def test_module_default_route_for_two_to_four_tokens_of_wide_layers(dev, monkeyp
     xt = bits_to_tensor(xs, "f16", dev).reshape(xs.shape)
     m(xt[:, :1].contiguous())
     sl = m.__dict__["_sliced"][1]
-    assert sl is not None and sl.exact and sl.slices == 16 and all(m._sliced_one_launch(sl, t) for t in (3, 4))
-    assert not m._sliced_one_launch(sl, 5) and not m._sliced_one_launch(sl, 2) and m._sliced_token_limit(sl) == 2
+    assert sl is not None and sl.exact and sl.slices == 16 and all(m._sliced_one_launch(sl, t) for t in (2, 3, 4))
+    assert sl.tokens_one_pass(2) and sl.tokens_one_pass(3) and not sl.tokens_one_pass(4) and not m._sliced_one_launch(sl, 5)
     want = vo.forward(L, xs)
     for T in (2, 3, 4):
         x = xt[:, :T].contiguous()
         y = m(x)
-        if T == 2:   # two launches of the one-token kernel
-            assert all(torch.equal(y[:, t].reshape(-1).view(torch.int16), sl(x[:, t:t + 1].contiguous()).reshape(-1).view(torch.int16)) for t in range(2))
-        else:
-            assert torch.equal(y.view(torch.int16), sl.forward_tokens(x).view(torch.int16))
+        assert torch.equal(y.view(torch.int16), sl.forward_tokens(x).view(torch.int16))
         yb = tensor_to_bits(y)
         assert rel_err(yb, want[:, :T], "f16") <= 1e-3
         assert float((yb.reshape(-1) == np.asarray(want[:, :T]).reshape(-1)).mean()) >= 0.95
     y5 = m(xt)                                     # 5 tokens: the gather kernel, the same arithmetic
     assert torch.equal(y5.view(torch.int16), gemv_abi(m, xt, EXACT).view(torch.int16))
-    # a narrow layer (8 slices of 128 KiB: four column phases) and a small one stay on the gather kernel
-    for (I, O) in ((4096, 2048), (8192, 512)):
+    # a small 8192-column layer takes the one pass as well; a narrow layer (8 slices of 128 KiB) and a small 14336-column one (no room
+    # for two tokens beside the slice, too small for the column-phase kernel to pay) stay on the gather kernel
+    for (I, O, one) in ((8192, 512, True), (4096, 2048, False), (14336, 512, False)):
         Ls = vo.make_layer(I, O, dist="llm", seed=72, num_centroids=65536, num_res_centroids=0)
         ms = spec_to_module(Ls, dev)
         ms.enable_sliced_layout()
         x2 = bits_to_tensor(np.concatenate([_x(I, "f16", "llm", 40 + i) for i in range(2)], axis=1), "f16", dev).reshape(1, 2, I)
         ms(x2[:, :1].contiguous())
         s2 = ms.__dict__["_sliced"][1]
-        assert s2 is not None and s2.exact and s2.tokens_supported(3) and not ms._sliced_one_launch(s2, 3) and ms._sliced_token_limit(s2) == 1
-        assert torch.equal(ms(x2).view(torch.int16), gemv_abi(ms, x2, EXACT).view(torch.int16))
+        assert s2 is not None and s2.exact and s2.tokens_supported(3) and ms._sliced_one_launch(s2, 2) == one and ms._sliced_token_limit(s2) == 1
+        assert torch.equal(ms(x2).view(torch.int16), (s2.forward_tokens(x2) if one else gemv_abi(ms, x2, EXACT)).view(torch.int16))
+        assert rel_err(tensor_to_bits(ms(x2)), vo.forward(Ls, tensor_to_bits(x2)), "f16") <= 1e-3
+    # a LARGE 14336-column layer: 2 tokens = two launches of the one-token kernel, 3 tokens = the column-phase kernel
+    Lw = vo.make_layer(14336, 3584, dist="llm", seed=73, num_centroids=65536, num_res_centroids=256)
+    mw = spec_to_module(Lw, dev)
+    xw = bits_to_tensor(np.concatenate([_x(14336, "f16", "llm", 50 + i) for i in range(3)], axis=1), "f16", dev).reshape(1, 3, 14336)
+    mw(xw[:, :1].contiguous())
+    sw = mw.__dict__["_sliced"][1]
+    assert sw is not None and sw.exact and not sw.tokens_one_pass(2) and mw._sliced_token_limit(sw) == 2
+    assert not mw._sliced_one_launch(sw, 2) and mw._sliced_one_launch(sw, 3)
+    yw = mw(xw[:, :2].contiguous())
+    assert all(torch.equal(yw[:, t].reshape(-1).view(torch.int16), sw(xw[:, t:t + 1].contiguous()).reshape(-1).view(torch.int16)) for t in range(2))
+    assert torch.equal(mw(xw).view(torch.int16), sw.forward_tokens(xw).view(torch.int16))
+    assert rel_err(tensor_to_bits(mw(xw)), vo.forward(Lw, tensor_to_bits(xw)), "f16") <= 1e-3
     # switched on for every layer the library takes ("1"): siblings of one format share one launch, each member's own bits
     monkeypatch.setattr(vq, "_SLICED_ONE_LAUNCH", "1")
     Lq = [vo.make_layer(8192, O, seed=80 + i, dist="llm", num_centroids=65536, num_res_centroids=256, bias=(i == 1)) for i, O in enumerate((1024, 264, 512))]

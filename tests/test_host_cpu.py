@@ -695,10 +695,12 @@ def test_sliced_tokens_plan_without_gpu():
     assert [sup(d, layouts(d), t) for t in (1, 2, 3, 4, 5)] == [0, 1, 1, 1, 0]
     assert sup(d, layouts(d, wstart=False), 2) == 0                       # layouts without the column windows' table: one token only
     # partial sums [tokens][slices x tables][N x v] floats (256-byte multiple) + the arrival counters (one per 16 rows)
-    # (ONE size for both arithmetics: the exact layout of an 8192-column layer has 16 slices)
-    assert wsb(d, 2) == 2 * 16 * 8192 * 4 + 256 and wsb(d, 4) == 4 * 16 * 8192 * 4 + 256 and wsb(d, 9) == 0 and wsb(d, 1) == 0
+    # (ONE size for both arithmetics: the exact layout of an 8192-column layer has 16 slices; one-table formats: + 3 x N x v
+    # 64-bit accumulator words of the one-pass route for 2 / 3 exact tokens, behind the counters)
+    acc = 3 * 8192 * 8
+    assert wsb(d, 2) == 2 * 16 * 8192 * 4 + 256 + acc and wsb(d, 4) == 4 * 16 * 8192 * 4 + 256 + acc and wsb(d, 9) == 0 and wsb(d, 1) == 0
     d4 = _family_desc(4096, 4096, 8, 65536, 256)      # 5 - 8 tokens: 16 bytes of activations per column must fit in 4 phases
-    assert [sup(d4, layouts(d4), t) for t in (5, 8, 9)] == [1, 1, 0] and wsb(d4, 8) == 8 * 8 * 4096 * 4 + 256
+    assert [sup(d4, layouts(d4), t) for t in (5, 8, 9)] == [1, 1, 0] and wsb(d4, 8) == 8 * 8 * 4096 * 4 + 256 + 3 * 4096 * 8
     d2 = _family_desc(8192, 8192, 8, 65536, 65536)
     assert sup(d2, layouts(d2), 4) == 1 and wsb(d2, 3) == 3 * 16 * 8192 * 4 + 256
     # ABI 9: the reference's roundings (one-table formats, an exact layout: its slice count), 8 + 2 x token slots bytes per column and phase
@@ -713,7 +715,14 @@ def test_sliced_tokens_plan_without_gpu():
         dd = _family_desc(I, 4096, v, 65536, kr)
         assert [supf(dd, exact_layout(dd), t, EX) for t in (1, 2, 4, 5, 8, 9)] == want, (I, v, kr)
         assert supf(dd, exact_layout(dd), 2, EX | B.GEMV_FORCE_GENERIC) == 0
-    assert supf(d, exact_layout(d, wstart=False), 2, EX) == 0
+    # 2 / 3 tokens of a layer whose exact layout has 16 slices (+ 2 tokens + 4 bytes per column fit beside the 64 KiB slice): ONE pass
+    # of the one-token kernel - no column windows needed; 4 tokens and narrow layers (8 slices of 128 KiB): the column-phase kernel
+    assert [supf(d, exact_layout(d, wstart=False), t, EX) for t in (2, 3, 4)] == [1, 1, 0]
+    assert [supf(d4, exact_layout(d4, wstart=False), t, EX) for t in (2, 3, 4)] == [0, 0, 0]
+    d14 = _family_desc(14336, 4096, 8, 65536, 256)
+    assert [supf(d14, exact_layout(d14, wstart=False), t, EX) for t in (2, 3)] == [0, 0] and supf(d14, exact_layout(d14), 2, EX) == 1
+    d16 = _family_desc(8192, 4096, 16, 65536, 0)
+    assert [supf(d16, exact_layout(d16, wstart=False), t, EX) for t in (2, 3)] == [1, 0]
     assert supf(d, layouts(d), 2, EX) == 0                 # the folded form's 8 slices: not the exact layout of an 8192-column layer
     assert supf(d4, layouts(d4), 8, EX) == 1               # 4096 columns: the same 8 slices, the same layout
     assert supf(d, layouts(d), 4, 0) == sup(d, layouts(d), 4) == 1
@@ -734,12 +743,13 @@ def test_one_launch_rule_for_two_to_four_tokens():
         return types.SimpleNamespace(indices=torch.empty(1, O // v, 1), group_size=I, vector_len=v, out_features=O,
                                      num_res_centroids=kr, enable_residual=kr > 0)
 
-    def rule(I, O, v, kr, tokens, supported=True, exact=False, slices=8):
+    def rule(I, O, v, kr, tokens, supported=True, exact=False, slices=8, one_pass=False):
         class SL:       # (stands in for vptq_amd.utils.sliced.SlicedGemv: what the library answers + the per-layout cache)
             def tokens_supported(self, t):
                 return supported
         sl = SL()
         sl.exact, sl.slices = exact, slices
+        sl.tokens_one_pass = lambda t: one_pass
         return VQuantLinear._sliced_one_launch(layer(I, O, v, kr), sl, tokens)
     for t in (2, 3, 4):
         assert rule(8192, 8192, 8, 0, t) and rule(4096, 4096, 8, 256, t) and rule(4096, 14336, 8, 65536, t) and rule(8192, 8192, 16, 0, t)
@@ -754,3 +764,7 @@ def test_one_launch_rule_for_two_to_four_tokens():
         assert not rule(4096, 14336, 8, 256, t, exact=True, slices=8) and not rule(4096, 4096, 8, 0, t, exact=True, slices=8)
         assert not rule(8192, 8192, 16, 0, t, exact=True, slices=32) and not rule(8192, 2048, 8, 0, t, exact=True, slices=16)
         assert not rule(8192, 8192, 8, 256, t, exact=True, slices=16, supported=False)
+    # ... and 2 / 3 tokens in ONE PASS of the one-token kernel wherever the library takes that (16-slice layouts, any size)
+    for t in (2, 3):
+        assert rule(8192, 8192, 8, 256, t, exact=True, slices=16, one_pass=True) and rule(8192, 1024, 8, 0, t, exact=True, slices=16, one_pass=True)
+        assert not rule(2048, 8192, 8, 0, t, exact=True, slices=8, one_pass=True) and not rule(8192, 8192, 16, 0, t, exact=True, slices=32, one_pass=True)

@@ -278,6 +278,7 @@ def fuzz_sliced(a, dev):
         # the reference's roundings over a layout of their own (round 5: ONE layout; any residual codebook but v8's 256-entry
         # one gathered from device memory), where the library serves the layer: almost every output bit-identical
         ex = -1.0
+        sx = None
         if B_.lib().vptq_sliced_layout_supported_for(m._descriptor()[1], 4):
             sx = SlicedGemv(m, rows_per_wave=rpw, exact=True)
             print(f"  exact layout built (slices {sx.slices})", flush=True)
@@ -299,8 +300,23 @@ def fuzz_sliced(a, dev):
             assert torch.equal(gotT.view(torch.int16), sl.forward_tokens(xTt).view(torch.int16)), (c, "tokens: not reproducible")
             et = rel_err(tensor_to_bits(gotT), vo.gemv(vo.dequant(L, ref_residual_mask_quirk=False), xT, dt, L.bias), dt)
             worst = max(worst, et)
+        # ... and 2 - 8 tokens in the reference's roundings over the exact layout (gemv_sliced_tok.hip, EX: one-table formats)
+        TX = int(rng.integers(2, 9))
+        etx = -1.0
+        if sx is not None and sx.tokens_supported(TX):
+            xT = vo.from_f32(rng.standard_normal((1, TX, I)).astype(np.float32), dt)
+            xTt = bits_to_tensor(xT, dt, dev).reshape(xT.shape)
+            gX = sx.forward_tokens(xTt)
+            torch.cuda.synchronize()
+            assert torch.equal(gX.view(torch.int16), sx.forward_tokens(xTt).view(torch.int16)), (c, "exact tokens: not reproducible")
+            wX = vo.gemv(vo.dequant(L, ref_residual_mask_quirk=False), xT, dt, L.bias)
+            etx = rel_err(tensor_to_bits(gX), wX, dt)
+            identx = float((tensor_to_bits(gX).reshape(-1) == np.asarray(wX).reshape(-1)).mean())
+            assert etx <= tol and identx >= 0.9, (c, v, k, kr, I, O, TX, etx, identx)
+            worst = max(worst, etx)
         print(f"case {c:3d} v{v}-k{k}-{kr} I={I:6d} O={O:5d} skew={skew} slices={sl.slices} tables={len(sl.layout)} "
-              f"whole={sl._whole} rpw={sl.layout[0].rows_per_wave}: oracle {e:.2e} gather {e2:.2e} | {T} tokens {et:.2e} | reference roundings {ex:.2e}", flush=True)
+              f"whole={sl._whole} rpw={sl.layout[0].rows_per_wave}: oracle {e:.2e} gather {e2:.2e} | {T} tokens {et:.2e} | reference roundings {ex:.2e}"
+              f" | {TX} tokens in them {etx:.2e}", flush=True)
         assert e <= tol and e2 <= tol and et <= tol, (c, e, e2, et)
     print(f"worst: {worst:.2e}")
 

@@ -124,7 +124,12 @@ struct SlicedGroupParams {
 // the reference's roundings - c and r must meet in one lane, and a second 1 - 2 MiB table cannot sit in LDS as well: the main
 // entry comes out of the LDS slice, the residual entry is GATHERED FROM L2 by its index (a uint16 side stream of the layout), a
 // second queue stage ahead of the arithmetic.  One of the gather kernel's two cache gathers per element instead of both.
-template <typename DT, int NSL, bool RES, int V = 8, bool TWO = false, bool EX = false, bool RG = false>
+// TOK = 2 / 3 (EX, one table): that many TOKENS in one pass over the layout - the weight is rebuilt once per element and meets
+// every token's activation (2 / 4 more multiply-adds per pair of outputs; the stream, the gathers and the three roundings are
+// paid once).  x [TOK][x_stride], y [TOK][y_stride], accumulator words [TOK][acc_stride]; LDS: tokens 0 and 1 interleaved per
+// column (one 32-bit gather), token 2 a plane of its own: 2 TOK + 4 bytes per column - layers whose exact layout has 16 (v = 16:
+// 32) slices, up to ~12000 (2 tokens) / ~9700 (3) columns.  More tokens: gemv_sliced_tok.hip (column phases, matrix pipe).
+template <typename DT, int NSL, bool RES, int V = 8, bool TWO = false, bool EX = false, bool RG = false, int TOK = 1>
 __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGroupParams GP) {
   // this workgroup's layer; its parameters come out of the kernel-argument segment through the scalar cache (a run-time
   // index into the by-value argument would make the compiler copy it to scratch memory)
@@ -142,7 +147,7 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
   const SlicedParams P = GP.p[0];   // (host pass of the compiler: never executed)
 #endif
   static_assert(((V == 8 && (NSL == 8 || NSL == 16)) || (V == 16 && (NSL == 16 || NSL == 32))) && (V == 8 || !RES) && !(TWO && RES) &&
-                !(EX && TWO) && (!RG || (EX && !RES && !TWO)), "slices");
+                !(EX && TWO) && (!RG || (EX && !RES && !TWO)) && (TOK == 1 || ((TOK == 2 || TOK == 3) && EX && !RG)), "slices");
   constexpr int NSLT = TWO ? 2 * NSL : NSL;   // workgroups per row block: one per (table, slice)
   constexpr int EPL = 1;   // element words per lane and block (2 and 4 - 8 / 16-byte loads - were measured: no difference)
   constexpr uint32_t kEntry = V * 2u;                          // bytes of a codebook entry
@@ -200,7 +205,9 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
   }
   // residual codebook (256 entries = 4 KiB) behind the activations: waves 0-3 bring 1 KiB each
   // LDS behind the table: [G + 64 halves: f16(s x), EX: x] [EX: G + 64 words {s, b}] [16 floats: sum b x parts] [RES: 4 KiB]
-  const uint32_t sb_off = kSLXOff + (uint32_t)(G + 64) * 2u;                     // (EX) scale | bias << 16 per column
+  // (TOK > 1: [G + 64 words: tokens 0 | 1] [TOK = 3: G + 64 halves: token 2] in front of the {s, b} words)
+  [[maybe_unused]] const uint32_t x2_off = kSLXOff + (uint32_t)(G + 64) * 4u;
+  const uint32_t sb_off = kSLXOff + (uint32_t)(G + 64) * 2u * (uint32_t)TOK;     // (EX) scale | bias << 16 per column
   const uint32_t bd_off = sb_off + (EX ? (uint32_t)(G + 64) * 4u : 0u);          // 16 floats behind the staged operands
   const uint32_t res_off = bd_off + 64u;
   if constexpr (RES) {
@@ -216,15 +223,22 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
   // families); a permutation makes the activation loads depend on its own load (layers that keep one pay that wait here)
   const int chunks = G >> 3;
   constexpr int kSLPre = 2;
-  u32x4 st_x[kSLPre], st_s[kSLPre], st_b[kSLPre];
+  struct XT { u32x4 v[TOK]; };   // a chunk's activations, one vector per token ([0] = the permutation's words where there is one)
+  XT st_x[kSLPre];
+  u32x4 st_s[kSLPre], st_b[kSLPre];
 #pragma unroll
   for (int r = 0; r < kSLPre; ++r) {
     const int q = tid + r * kSLThreads;
-    st_x[r] = st_s[r] = st_b[r] = u32x4{0u, 0u, 0u, 0u};
+    st_s[r] = st_b[r] = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int t = 0; t < TOK; ++t) st_x[r].v[t] = u32x4{0u, 0u, 0u, 0u};
     if (q < chunks && !(VPTQ_SLICED_ABLATE & 4)) {
       st_s[r] = *(const u32x4*)(as_global(P.scale) + 8 * q);
-      if (P.perm == nullptr) st_x[r] = *(const u32x4*)(as_global(P.x) + 8 * q);
-      else st_x[r] = *(const u32x4*)(as_global(P.perm) + 8 * q);   // (the permutation's words: resolved in (5))
+      if (P.perm == nullptr) {
+#pragma unroll
+        for (int t = 0; t < TOK; ++t) st_x[r].v[t] = *(const u32x4*)(as_global(P.x) + (size_t)t * P.x_stride + 8 * q);
+      }
+      else st_x[r].v[0] = *(const u32x4*)(as_global(P.perm) + 8 * q);   // (the permutation's words: resolved in (5))
       if constexpr (EX) st_b[r] = *(const u32x4*)(as_global(P.cbias) + 8 * q);
       else if (sg == 0 && P.wbias != nullptr) st_b[r] = *(const u32x4*)(as_global(P.wbias) + 8 * q);
     }
@@ -236,11 +250,15 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
   // sum b x (it rides in their partial sums)
   typedef __attribute__((address_space(3))) u32x4 lds_q_t;
   float bd = 0.f;
-  auto stage = [&](int q, u32x4 xv, const u32x4 sv, const u32x4 bv, bool have_perm_words) __attribute__((always_inline)) {
+  auto stage = [&](int q, const XT xin, const u32x4 sv, const u32x4 bv, bool have_perm_words) __attribute__((always_inline)) {
     u32x4 v = {0u, 0u, 0u, 0u};
+    [[maybe_unused]] u32x4 vt[TOK > 1 ? TOK : 1];   // (TOK > 1) tokens 1 ..: v is token 0
+#pragma unroll
+    for (int t = 0; t < (TOK > 1 ? TOK : 1); ++t) vt[t] = u32x4{0u, 0u, 0u, 0u};
     if (q < chunks && !(VPTQ_SLICED_ABLATE & 4)) {
       // the staged operand is in COLUMN order: column c multiplies feature perm[c] (scale in column order comes
       // with the descriptor: scale_permuted); sum b x is taken in input-FEATURE order (a permutation only reorders it)
+      u32x4 xv = xin.v[0];
       u32x4 xc = xv;
       if (have_perm_words) {
         const u32x4 pv = xv;
@@ -249,7 +267,21 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
           const uint32_t lo = as_global(P.x)[pv[i] & 0xffffu], hi = as_global(P.x)[pv[i] >> 16];
           xc[i] = lo | (hi << 16);
         }
-        xv = *(const u32x4*)(as_global(P.x) + 8 * q);
+        if constexpr (TOK > 1) {
+#pragma unroll
+          for (int t = 1; t < TOK; ++t) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const uint32_t lo = (as_global(P.x) + (size_t)t * P.x_stride)[pv[i] & 0xffffu], hi = (as_global(P.x) + (size_t)t * P.x_stride)[pv[i] >> 16];
+              vt[t][i] = lo | (hi << 16);
+            }
+          }
+        } else {
+          xv = *(const u32x4*)(as_global(P.x) + 8 * q);
+        }
+      } else if constexpr (TOK > 1) {
+#pragma unroll
+        for (int t = 1; t < TOK; ++t) vt[t] = xin.v[t];
       }
       if constexpr (EX) {
         v = xc;   // raw activations; the column's scale and bias as one word: {s, b}
@@ -276,16 +308,39 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
       *(lds_q_t*)(uintptr_t)(sb_off + (uint32_t)q * 32u) = z;
       *(lds_q_t*)(uintptr_t)(sb_off + (uint32_t)q * 32u + 16u) = z;
     }
-    *(lds_q_t*)(uintptr_t)(kSLXOff + (uint32_t)q * 16u) = v;
+    if constexpr (TOK == 1) {
+      *(lds_q_t*)(uintptr_t)(kSLXOff + (uint32_t)q * 16u) = v;
+    } else {   // column j of the chunk: {token 0, token 1} in one word; token 2 in its plane
+      u32x4 w0, w1;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        w0[2 * i] = (v[i] & 0xffffu) | (vt[1][i] << 16);
+        w0[2 * i + 1] = (v[i] >> 16) | (vt[1][i] & 0xffff0000u);
+        w1[2 * i] = (v[2 + i] & 0xffffu) | (vt[1][2 + i] << 16);
+        w1[2 * i + 1] = (v[2 + i] >> 16) | (vt[1][2 + i] & 0xffff0000u);
+      }
+      *(lds_q_t*)(uintptr_t)(kSLXOff + (uint32_t)q * 32u) = w0;
+      *(lds_q_t*)(uintptr_t)(kSLXOff + (uint32_t)q * 32u + 16u) = w1;
+      if constexpr (TOK == 3) *(lds_q_t*)(uintptr_t)(x2_off + (uint32_t)q * 16u) = vt[2];
+    }
   };
   // layers of more than 16376 columns: the staging rounds behind the first kSLPre, done HERE - in front of the element
   // queue (a load issued behind it would make every later wait drain the queue; the compiler did exactly that for the
   // slice-0 workgroups' LDS read behind the barrier, found in the ISA)
   for (int q = tid + kSLPre * kSLThreads; q < chunks + 8; q += kSLThreads) {
-    u32x4 xv = {0u, 0u, 0u, 0u}, sv = xv, bv = xv;
+    u32x4 sv = {0u, 0u, 0u, 0u}, bv = sv;
+    XT xv;
+#pragma unroll
+    for (int t = 0; t < TOK; ++t) xv.v[t] = u32x4{0u, 0u, 0u, 0u};
     if (q < chunks && !(VPTQ_SLICED_ABLATE & 4)) {
       sv = *(const u32x4*)(as_global(P.scale) + 8 * q);
-      xv = *(const u32x4*)(as_global(P.perm != nullptr ? P.perm : P.x) + 8 * q);
+      xv.v[0] = *(const u32x4*)(as_global(P.perm != nullptr ? P.perm : P.x) + 8 * q);
+      if constexpr (TOK > 1) {
+        if (P.perm == nullptr) {
+#pragma unroll
+          for (int t = 1; t < TOK; ++t) xv.v[t] = *(const u32x4*)(as_global(P.x) + (size_t)t * P.x_stride + 8 * q);
+        }
+      }
       if constexpr (EX) bv = *(const u32x4*)(as_global(P.cbias) + 8 * q);
       else if (sg == 0 && P.wbias != nullptr) bv = *(const u32x4*)(as_global(P.wbias) + 8 * q);
     }
@@ -416,29 +471,36 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
   if (wave < 8) __builtin_amdgcn_s_setprio(2);
   if (wave < 4) __builtin_amdgcn_s_setprio(3);
 #endif
-  float acc[V];
+  float acc[TOK][V];
 #pragma unroll
-  for (int i = 0; i < V; ++i) acc[i] = 0.f;
+  for (int t = 0; t < TOK; ++t)
+#pragma unroll
+    for (int i = 0; i < V; ++i) acc[t][i] = 0.f;
   int row_i = 0;
   // ---- the slices of a row meet in the output's accumulator word (caller's workspace, zero between launches): the lane
   // whose add brings the arrivals to NSLT has old + its own = the sum of all slices (+ sum b x, which rides with slice 0),
   // exact in fixed point and therefore the same whoever comes last; it rounds ONCE, adds the output bias, stores y and
   // puts the word back to zero.  One returning atomic is the whole hand-over: nobody waits for anybody, nothing is read back.
   int pend_o = -1;
-  unsigned long long pend_old[V / 4], pend_mine[V / 4];
+  unsigned long long pend_old[TOK][V / 4], pend_mine[TOK][V / 4];
   auto finish_rows = [&]() __attribute__((always_inline)) {
     if (pend_o >= 0) {
 #pragma unroll
-      for (int i = 0; i < V / 4; ++i) {
-        if ((pend_old[i] & 127ull) == (unsigned long long)(NSLT - 1)) {
-          const int o = pend_o + i;
-          float r = sl_from_fixed(pend_old[i] + pend_mine[i]);
-          if (o < P.O) {
-            if (P.bias) r += DT::to_float(as_global(P.bias)[o]);
-            if (P.out_f32) ((float*)as_global(P.y))[o] = r;
-            else ((uint16_t*)as_global(P.y))[o] = DT::from_float(r);
+      for (int t = 0; t < TOK; ++t) {
+#pragma unroll
+        for (int i = 0; i < V / 4; ++i) {
+          if ((pend_old[t][i] & 127ull) == (unsigned long long)(NSLT - 1)) {
+            const int o = pend_o + i;
+            float r = sl_from_fixed(pend_old[t][i] + pend_mine[t][i]);
+            if (o < P.O) {
+              if (P.bias) r += DT::to_float(as_global(P.bias)[o]);
+              const size_t yo = (TOK > 1 ? (size_t)t * P.y_stride : 0) + (size_t)o;
+              if (P.out_f32) ((float*)as_global(P.y))[yo] = r;
+              else ((uint16_t*)as_global(P.y))[yo] = DT::from_float(r);
+            }
+            __hip_atomic_store((unsigned long long*)as_global(P.partial) + (TOK > 1 ? (size_t)t * P.acc_stride : 0) + o, 0ull, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
           }
-          __hip_atomic_store((unsigned long long*)as_global(P.partial) + o, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
       pend_o = -1;
@@ -447,36 +509,44 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
   // rows without elements in this slice store zeros
   auto store_row = [&]() __attribute__((always_inline)) {
     // sum over the 64 lanes: swap-and-add halves the values carried (gemv_k256c.hip:finish), then DPP
-    float v[V];
+    float v[TOK][V];
 #pragma unroll
-    for (int i = 0; i < V; ++i) v[i] = acc[i];
+    for (int t = 0; t < TOK; ++t) {
 #pragma unroll
-    for (int i = 0; i < V / 2; ++i) {
-      auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(v[i + V / 2]), false, false);
-      v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+      for (int i = 0; i < V; ++i) v[t][i] = acc[t][i];
+#pragma unroll
+      for (int i = 0; i < V / 2; ++i) {
+        auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[t][i]), __float_as_uint(v[t][i + V / 2]), false, false);
+        v[t][i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+      }
+#pragma unroll
+      for (int i = 0; i < V / 4; ++i) {
+        auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[t][i]), __float_as_uint(v[t][i + V / 4]), false, false);
+        v[t][i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+      }
+#pragma unroll
+      for (int i = 0; i < V / 4; ++i) v[t][i] = row16_allsum(v[t][i]);
     }
-#pragma unroll
-    for (int i = 0; i < V / 4; ++i) {
-      auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[i]), __float_as_uint(v[i + V / 4]), false, false);
-      v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-    }
-#pragma unroll
-    for (int i = 0; i < V / 4; ++i) v[i] = row16_allsum(v[i]);
     // lane l (any of its row of 16) holds outputs (V / 2) bit5 + (V / 4) bit4 + {0 .. V / 4 - 1}
     // row i of the wave is handed over by lanes (i & 15) + {0, 16, 32, 48}: up to 16 rows' returned words wait in the
     // registers of different lanes until the stream is through (no wait inside the loop)
     if ((row_i & 15) == 0 && row_i > 0) finish_rows();   // (more than 16 rows per wave: the lanes come round again)
     if ((lane & 15) == (row_i & 15)) {
       pend_o = (row0 + row_i) * V + ((lane >> 5) & 1) * (V / 2) + ((lane >> 4) & 1) * (V / 4);
-      unsigned long long* const ap = (unsigned long long*)as_global(P.partial) + pend_o;
 #pragma unroll
-      for (int i = 0; i < V / 4; ++i) {
-        pend_mine[i] = sl_to_fixed(v[i] + bdot);
-        pend_old[i] = __hip_atomic_fetch_add(ap + i, pend_mine[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int t = 0; t < TOK; ++t) {
+        unsigned long long* const ap = (unsigned long long*)as_global(P.partial) + (TOK > 1 ? (size_t)t * P.acc_stride : 0) + pend_o;
+#pragma unroll
+        for (int i = 0; i < V / 4; ++i) {
+          pend_mine[t][i] = sl_to_fixed(v[t][i] + bdot);
+          pend_old[t][i] = __hip_atomic_fetch_add(ap + i, pend_mine[t][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
       }
     }
 #pragma unroll
-    for (int i = 0; i < V; ++i) acc[i] = 0.f;
+    for (int t = 0; t < TOK; ++t)
+#pragma unroll
+      for (int i = 0; i < V; ++i) acc[t][i] = 0.f;
   };
   int left = 0x7fffffff;
   bool done = false;
@@ -504,6 +574,7 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
   u32x4 g_ent[kBufs][W4];
   u32x4 g_rent[kBufs];
   uint32_t g_x[kBufs], g_sb[kBufs];
+  [[maybe_unused]] uint32_t g_x2[kBufs];   // (TOK = 3) token 2
   auto fetch = [&](auto slot_c, auto buf_c) __attribute__((always_inline)) {
     constexpr int S = decltype(slot_c)::value, Bf = decltype(buf_c)::value;
     const uint32_t e = RG ? ew[S] : eq[S][0];
@@ -511,14 +582,16 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
     const uint32_t ea = (e >> 16) * kEntry;
 #pragma unroll
     for (int w = 0; w < W4; ++w) g_ent[Bf][w] = lds_load16(ea + 16u * (uint32_t)w);
-    g_x[Bf] = *(const lds_h_t*)(uintptr_t)(kSLXOff + ((e & 0xffffu) << 1));
+    if constexpr (TOK == 1) g_x[Bf] = *(const lds_h_t*)(uintptr_t)(kSLXOff + ((e & 0xffffu) << 1));
+    else g_x[Bf] = *(const lds_w_t*)(uintptr_t)(kSLXOff + ((e & 0xffffu) << 2));   // tokens 0 | 1
+    if constexpr (TOK == 3) g_x2[Bf] = *(const lds_h_t*)(uintptr_t)(x2_off + ((e & 0xffffu) << 1));
     if constexpr (RES) g_rent[Bf] = lds_load16(res_off + (rq[S] << 4));
     if constexpr (EX) g_sb[Bf] = *(const lds_w_t*)(uintptr_t)(sb_off + ((e & 0xffffu) << 2));
   };
   auto math = [&](auto buf_c, auto slot_c) __attribute__((always_inline)) {
     constexpr int Bf = decltype(buf_c)::value;
     [[maybe_unused]] constexpr int S = decltype(slot_c)::value;   // (RG: the residual entry sits in the slot's second stage)
-    if constexpr ((VPTQ_SLICED_ABLATE & 1) != 0) { acc[0] += __uint_as_float(g_x[Bf]); return; }
+    if constexpr ((VPTQ_SLICED_ABLATE & 1) != 0) { acc[0][0] += __uint_as_float(g_x[Bf]); return; }
     // EX: the weight as the reference rounds it - u = f16(c + r), t = f16(u * s), w = f16(t + b): three packed instructions per
     // pair of outputs, scale and bias broadcast out of the column's word by op_sel - then w x in fp32
     auto weight = [&](uint32_t ew, uint32_t rw, uint32_t sbw) __attribute__((always_inline)) -> uint32_t {
@@ -535,28 +608,48 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
       const uint32_t xw = g_x[Bf];
 #pragma unroll
       for (int i = 0; i < V / 2; ++i) {
-        float lo = acc[2 * i], hi = acc[2 * i + 1];   // (an asm operand cannot name a captured array element)
+        float lo = acc[0][2 * i], hi = acc[0][2 * i + 1];   // (an asm operand cannot name a captured array element)
         // 256-entry residual table: f16(c + r) first - the reference's own first rounding (vptq/ops/quant_gemm.py:121) -
         // as ONE packed add per pair of outputs instead of a second pair of multiply-adds (round 5: the phase stamps
         // showed this format's stream bound by vector issue, 25 instructions per block)
         const uint32_t ew = weight(g_ent[Bf][i / 4][i % 4], RES ? g_rent[Bf][i % 4] : (RG ? rgq[RG ? S : 0][i / 4][i % 4] : 0u), EX ? g_sb[Bf] : 0u);
         asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,1,0]" : "+v"(lo) : "v"(ew), "v"(xw));
         asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,0]" : "+v"(hi) : "v"(ew), "v"(xw));
-        acc[2 * i] = lo; acc[2 * i + 1] = hi;
+        acc[0][2 * i] = lo; acc[0][2 * i + 1] = hi;
+        if constexpr (TOK >= 2) {   // token 1: the high half of the same word
+          float lo1 = acc[1][2 * i], hi1 = acc[1][2 * i + 1];
+          asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,0]" : "+v"(lo1) : "v"(ew), "v"(xw));
+          asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,1,0]" : "+v"(hi1) : "v"(ew), "v"(xw));
+          acc[1][2 * i] = lo1; acc[1][2 * i + 1] = hi1;
+        }
+        if constexpr (TOK == 3) {
+          const uint32_t xw2 = g_x2[Bf];
+          float lo2 = acc[2][2 * i], hi2 = acc[2][2 * i + 1];
+          asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,1,0]" : "+v"(lo2) : "v"(ew), "v"(xw2));
+          asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,0]" : "+v"(hi2) : "v"(ew), "v"(xw2));
+          acc[2][2 * i] = lo2; acc[2][2 * i + 1] = hi2;
+        }
       }
     } else {
-      const float xf = DT::to_float((uint16_t)g_x[Bf]);
+      float xf[TOK];
+      xf[0] = DT::to_float((uint16_t)g_x[Bf]);
+      if constexpr (TOK >= 2) xf[1] = DT::to_float((uint16_t)(g_x[Bf] >> 16));
+      if constexpr (TOK == 3) xf[2] = DT::to_float((uint16_t)g_x2[Bf]);
 #pragma unroll
       for (int i = 0; i < V / 2; ++i) {
         // (folded bf16: c x + r x, two pairs of multiply-adds - a widened add would cost more than it saves)
         const uint32_t c0 = g_ent[Bf][i / 4][i % 4];
         const uint32_t ew = EX ? weight(c0, RES ? g_rent[Bf][i % 4] : (RG ? rgq[RG ? S : 0][i / 4][i % 4] : 0u), g_sb[Bf]) : c0;
-        acc[2 * i] = __builtin_fmaf(DT::to_float((uint16_t)(ew & 0xffffu)), xf, acc[2 * i]);
-        acc[2 * i + 1] = __builtin_fmaf(DT::to_float((uint16_t)(ew >> 16)), xf, acc[2 * i + 1]);
+        const float wl = DT::to_float((uint16_t)(ew & 0xffffu)), wh = DT::to_float((uint16_t)(ew >> 16));
+#pragma unroll
+        for (int t = 0; t < TOK; ++t) {
+          acc[t][2 * i] = __builtin_fmaf(wl, xf[t], acc[t][2 * i]);
+          acc[t][2 * i + 1] = __builtin_fmaf(wh, xf[t], acc[t][2 * i + 1]);
+        }
         if constexpr (RES && !EX) {
           const uint32_t rw = g_rent[Bf][i % 4];
-          acc[2 * i] = __builtin_fmaf(DT::to_float((uint16_t)(rw & 0xffffu)), xf, acc[2 * i]);
-          acc[2 * i + 1] = __builtin_fmaf(DT::to_float((uint16_t)(rw >> 16)), xf, acc[2 * i + 1]);
+          acc[0][2 * i] = __builtin_fmaf(DT::to_float((uint16_t)(rw & 0xffffu)), xf[0], acc[0][2 * i]);
+          acc[0][2 * i + 1] = __builtin_fmaf(DT::to_float((uint16_t)(rw >> 16)), xf[0], acc[0][2 * i + 1]);
         }
       }
     }
@@ -625,6 +718,41 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
 #endif
 }
 
+// ---- launchers (both parts of the build: the file is compiled twice, VPTQ_SL_PART = 1: the one-token instantiations + the host
+// side, 2: the 2 / 3-token instantiations of the reference's roundings)
+template <typename DT, int NSL, bool RES, int V, bool TWO, bool EX = false, bool RG = false, int TOK = 1>
+static hipError_t launch_sl(const SlicedGroupParams& P, uint32_t lds, hipStream_t st) {
+  auto kern = gemv_sliced_kernel<DT, NSL, RES, V, TWO, EX, RG, TOK>;
+  static std::atomic<bool> attr_set[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (!attr_set[dev]) {
+    const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSLLdsLimit);
+    if (e != hipSuccess) return e;
+    attr_set[dev] = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(P.start[P.n]), dim3(kSLThreads), lds, st, P);
+  return hipGetLastError();
+}
+hipError_t launch_sl_tokens(int dtype, const SlicedGroupParams& P, int v, int nsl, bool res, int tokens, uint32_t lds, hipStream_t st);
+#if !defined(VPTQ_SL_PART) || VPTQ_SL_PART == 2
+template <typename DT, int TOK>
+static hipError_t launch_sl_tok(const SlicedGroupParams& P, int v, int nsl, bool res, uint32_t lds, hipStream_t st) {
+  if (v == 16) {   // (3 tokens of 16 outputs: 48 sums + 12 returned words per lane spill - 2 tokens only)
+    if constexpr (TOK == 2) return nsl == 16 ? launch_sl<DT, 16, false, 16, false, true, false, TOK>(P, lds, st) : launch_sl<DT, 32, false, 16, false, true, false, TOK>(P, lds, st);
+    else return hipErrorInvalidValue;
+  }
+  if (nsl == 8) return res ? launch_sl<DT, 8, true, 8, false, true, false, TOK>(P, lds, st) : launch_sl<DT, 8, false, 8, false, true, false, TOK>(P, lds, st);
+  return res ? launch_sl<DT, 16, true, 8, false, true, false, TOK>(P, lds, st) : launch_sl<DT, 16, false, 8, false, true, false, TOK>(P, lds, st);
+}
+hipError_t launch_sl_tokens(int dtype, const SlicedGroupParams& P, int v, int nsl, bool res, int tokens, uint32_t lds, hipStream_t st) {
+  if (tokens == 2) return dtype == VPTQ_DTYPE_F16 ? launch_sl_tok<F16, 2>(P, v, nsl, res, lds, st) : launch_sl_tok<BF16, 2>(P, v, nsl, res, lds, st);
+  if (tokens == 3) return dtype == VPTQ_DTYPE_F16 ? launch_sl_tok<F16, 3>(P, v, nsl, res, lds, st) : launch_sl_tok<BF16, 3>(P, v, nsl, res, lds, st);
+  return hipErrorInvalidValue;
+}
+#endif
+
+#if !defined(VPTQ_SL_PART) || VPTQ_SL_PART == 1
 // ---- host side -------------------------------------------------------------------
 // Large-codebook layers: v = 8 or 16, 16384 ... 65536 main centroids, one codebook group, no outlier columns, norm on.
 // Residual codebook: none; v = 8 with 256 entries (one launch, the table beside the slice, a byte per element); any other
@@ -652,8 +780,8 @@ bool gemv_sliced_eligible(const VptqLayerDesc& d, bool exact) {
 
 // bytes of LDS behind the table: f16(s x) of every column (+ 64 padding columns) + 16 floats; the reference's roundings
 // stage x and a word {scale, bias} per column instead: 6 bytes per column; + the 4 KiB residual table of the 256-entry path
-static uint32_t sl_operand_bytes(const VptqLayerDesc& d, bool exact) {
-  return (uint32_t)(d.group_size + 64) * (exact ? 6u : 2u) + 64u + (sl_res256(d) ? 4096u : 0u);
+static uint32_t sl_operand_bytes(const VptqLayerDesc& d, bool exact, int tokens = 1) {
+  return (uint32_t)(d.group_size + 64) * (exact ? 4u + 2u * (uint32_t)tokens : 2u) + 64u + (sl_res256(d) ? 4096u : 0u);
 }
 // slices a layout of this layer must have: the slice (table entries / slices, 2 v bytes each) + the staged operands must fit
 // the 160 KiB of LDS.  Folded arithmetic: v = 8: 8 slices up to 14336 columns (14080 with the 256-entry table), else 16;
@@ -714,20 +842,6 @@ size_t gemv_sliced_workspace_bytes(const VptqLayerDesc& d) {
   return partial + counters;
 }
 
-template <typename DT, int NSL, bool RES, int V, bool TWO, bool EX = false, bool RG = false>
-static hipError_t launch_sl(const SlicedGroupParams& P, uint32_t lds, hipStream_t st) {
-  auto kern = gemv_sliced_kernel<DT, NSL, RES, V, TWO, EX, RG>;
-  static std::atomic<bool> attr_set[64];
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-  if (!attr_set[dev]) {
-    const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSLLdsLimit);
-    if (e != hipSuccess) return e;
-    attr_set[dev] = true;
-  }
-  hipLaunchKernelGGL(kern, dim3(P.start[P.n]), dim3(kSLThreads), lds, st, P);
-  return hipGetLastError();
-}
 template <typename DT>
 static hipError_t launch_sl_dt(const SlicedGroupParams& P, int v, int nsl, bool res, bool two, bool exact, uint32_t lds, hipStream_t st) {
   if (exact) {   // the reference's roundings: one layout; another residual codebook than the 256-entry one comes from L2 (RG)
@@ -761,8 +875,9 @@ bool sl_layout_ok(const VptqLayerDesc& d, const VptqSlicedLayout& L, int nsl, bo
 // word - two launches, one per table, cost a second boundary, a second epilogue and half the workgroups in flight (8192^2: 27.2 us
 // against 21.2; 4096^2: 17.8 against 12.0)
 static hipError_t sl_fill(const VptqLayerDesc& d, const VptqSlicedLayout* L, const void* x, void* y, int flags, void* ws,
-                          SlicedParams& P, uint32_t& lds) {
+                          SlicedParams& P, uint32_t& lds, int tokens = 1) {
   const bool exact = (flags & VPTQ_GEMV_EXACT) != 0;
+  if (tokens != 1 && !gemv_sliced_exact_tokens_ok(d, tokens)) return hipErrorInvalidValue;
   const bool res = sl_res256(d), rg = exact && sl_two(d), two = sl_two(d) && !exact;
   const int nsl = gemv_sliced_slices(d, exact);
   if (nsl == 0 || !sl_layout_ok(d, L[0], nsl, res || rg, d.num_centroids) || L[0].whole_table != 0 ||
@@ -802,7 +917,8 @@ static hipError_t sl_fill(const VptqLayerDesc& d, const VptqSlicedLayout* L, con
   const int rows_per_wg = kSLWaves * L[0].rows_per_wave;
   P.n_rowblocks = (d.num_indices + rows_per_wg - 1) / rows_per_wg;
   P.out_f32 = (flags & VPTQ_GEMV_OUT_F32) ? 1 : 0;
-  lds = P.x_off + sl_operand_bytes(d, exact);
+  P.x_stride = d.in_features; P.y_stride = d.out_features; P.acc_stride = d.num_indices * d.vector_len;
+  lds = P.x_off + sl_operand_bytes(d, exact, tokens);
   return lds > kSLLdsLimit ? hipErrorInvalidValue : hipSuccess;
 }
 
@@ -818,10 +934,22 @@ bool gemv_sliced_groupable(const VptqLayerDesc* d, int n, bool exact) {
   }
   return true;
 }
+// 2 / 3 tokens in one pass of the exact kernel (TOK): one-table formats whose slice + (2 tokens + 4) bytes per column fit the LDS.
+// Measured (profiles/r05/sliced_exact_tokens_one_pass.txt) where the 16 (v = 16: 32) slice layouts are: wider than ~5000 columns.
+bool gemv_sliced_exact_tokens_ok(const VptqLayerDesc& d, int tokens) {
+  if (tokens < 2 || tokens > (d.vector_len == 16 ? 2 : 3) || !gemv_sliced_eligible(d, true) || sl_two(d)) return false;
+  const int nsl = gemv_sliced_slices(d, true);
+  if (nsl == 0) return false;
+  return (sl_tab_bytes(d, d.num_centroids, 0, true) + 15u) / 16u * 16u + sl_operand_bytes(d, true, tokens) <= kSLLdsLimit;
+}
+// accumulator words of such a launch: [tokens][N x v], zero before the first launch, left zero by every launch
+size_t gemv_sliced_exact_tokens_workspace_bytes(const VptqLayerDesc& d, int tokens) {
+  return ((size_t)tokens * d.num_indices * d.vector_len * sizeof(unsigned long long) + 255) / 256 * 256;
+}
 hipError_t launch_gemv_sliced_group(const VptqLayerDesc* d, const VptqSlicedLayout* L, int n, const void* x, void* const* y,
-                                    int flags, void* const* ws, hipStream_t st) {
+                                    int flags, void* const* ws, hipStream_t st, int tokens) {
   const bool exact = (flags & VPTQ_GEMV_EXACT) != 0;
-  if (!gemv_sliced_groupable(d, n, exact)) return hipErrorInvalidValue;
+  if (!gemv_sliced_groupable(d, n, exact) || (tokens != 1 && !exact)) return hipErrorInvalidValue;
   SlicedGroupParams GP = {};
   GP.n = n;
   uint32_t lds = 0;
@@ -830,12 +958,13 @@ hipError_t launch_gemv_sliced_group(const VptqLayerDesc* d, const VptqSlicedLayo
   const int nslt = nsl * tables;
   for (int i = 0; i < n; ++i) {
     uint32_t l = 0;
-    const hipError_t e = sl_fill(d[i], L + (size_t)i * tables, x, y[i], flags, ws[i], GP.p[i], l);
+    const hipError_t e = sl_fill(d[i], L + (size_t)i * tables, x, y[i], flags, ws[i], GP.p[i], l, tokens);
     if (e != hipSuccess) return e;
     lds = l > lds ? l : lds;
     GP.start[i + 1] = GP.start[i] + nslt * GP.p[i].n_rowblocks;
   }
   for (int i = n; i < kSLMaxGroup; ++i) GP.start[i + 1] = GP.start[n];
+  if (tokens != 1) return launch_sl_tokens(d[0].dtype, GP, d[0].vector_len, nsl, sl_res256(d[0]), tokens, lds, st);
   return d[0].dtype == VPTQ_DTYPE_F16
              ? launch_sl_dt<F16>(GP, d[0].vector_len, nsl, sl_res256(d[0]), sl_two(d[0]), exact, lds, st)
              : launch_sl_dt<BF16>(GP, d[0].vector_len, nsl, sl_res256(d[0]), sl_two(d[0]), exact, lds, st);   // (exact && two = RG)
@@ -846,5 +975,6 @@ hipError_t launch_gemv_sliced(const VptqLayerDesc& d, const VptqSlicedLayout* L,
   void* const wss[1] = {ws};
   return launch_gemv_sliced_group(&d, L, 1, x, ys, flags, wss, st);
 }
+#endif   // part 1
 
 }  // namespace vptq

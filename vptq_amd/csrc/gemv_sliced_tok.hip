@@ -838,8 +838,17 @@ static size_t st_partial_bytes_max(const VptqLayerDesc& d, int tokens) {
   const size_t a = gemv_sliced_eligible(d) ? st_partial_bytes(d, tokens, false) : 0, b = st_exact_ok(d) ? st_partial_bytes(d, tokens, true) : 0;
   return a > b ? a : b;
 }
+// ... and, in front of the partial sums (a fixed place whatever the token count), the accumulator words of the ONE-PASS route:
+// 2 / 3 tokens in the reference's roundings through the one-token kernel (gemv_sliced.hip, TOK), zero between launches
+static size_t st_acc_bytes(const VptqLayerDesc& d) { return st_exact_ok(d) ? gemv_sliced_exact_tokens_workspace_bytes(d, 3) : 0; }
 size_t gemv_sliced_tok_workspace_bytes(const VptqLayerDesc& d, int tokens) {
-  return st_partial_bytes_max(d, tokens) + st_counter_bytes(d) + st_perm_bytes(d, tokens);
+  return st_counter_bytes(d) + st_acc_bytes(d) + st_partial_bytes_max(d, tokens) + st_perm_bytes(d, tokens);
+}
+// VPTQ_SLICED_ONE_PASS=0: 2 / 3 exact tokens through the column-phase kernel as well (A/B runs)
+static bool st_one_pass(const VptqLayerDesc& d, int tokens, bool exact) {
+  static std::atomic<int> on{-1};
+  if (on < 0) { const char* e = getenv("VPTQ_SLICED_ONE_PASS"); on = (e && atoi(e) == 0 && e[0] == '0') ? 0 : 1; }
+  return exact && on == 1 && gemv_sliced_exact_tokens_ok(d, tokens);
 }
 
 // rows per wave: one round of workgroups (slices x tables x row blocks of 16 waves ~ the CUs)
@@ -892,6 +901,7 @@ bool gemv_sliced_tok_eligible(const VptqLayerDesc& d, const VptqSlicedLayout* L,
   StPlan pl;
   if (!(exact ? st_exact_ok(d) : gemv_sliced_eligible(d)) || !L) return false;
   const int n = exact ? 1 : gemv_sliced_tables(d);
+  if (st_one_pass(d, tokens, exact)) return L[0].n_slices == gemv_sliced_slices(d, true);   // (no column windows needed)
   for (int i = 0; i < n; ++i)
     if (!L[i].wstart || L[i].n_slices != gemv_sliced_slices(d, exact)) return false;   // (the arithmetic's own slice count)
   return st_plan(d, L, tokens, exact, pl);
@@ -938,7 +948,7 @@ static hipError_t st_fill(const VptqLayerDesc& d, const VptqSlicedLayout* L, con
   TP.xs = (const uint16_t*)x;
   TP.x_stride = d.in_features;
   if (d.perm) {
-    char* const base = (char*)ws + st_counter_bytes(d) + st_partial_bytes_max(d, tokens);
+    char* const base = (char*)ws + st_counter_bytes(d) + st_acc_bytes(d) + st_partial_bytes_max(d, tokens);
     for (int t = 0; t < tokens; ++t) {
       jobs.d[jobs.n] = d;
       jobs.xin[jobs.n] = (const uint16_t*)x + (size_t)t * d.in_features;
@@ -951,7 +961,7 @@ static hipError_t st_fill(const VptqLayerDesc& d, const VptqSlicedLayout* L, con
   P.bias = (const uint16_t*)d.bias;
   // (the arrival counters FIRST: a workspace sized - and zeroed once - for 4 tokens serves 2 and 3 as well)
   P.arrived = (uint32_t*)ws;
-  P.partial = (float*)((char*)ws + st_counter_bytes(d));
+  P.partial = (float*)((char*)ws + st_counter_bytes(d) + st_acc_bytes(d));
   P.y = y;
   P.N = d.num_indices; P.G = d.group_size; P.O = d.out_features;
   P.rows_per_wave = pl.rpw;
@@ -983,6 +993,15 @@ hipError_t launch_gemv_sliced_tok_group(const VptqLayerDesc* d, const VptqSliced
                                         int tokens, int flags, void* const* ws, hipStream_t st) {
   const bool exact = (flags & VPTQ_GEMV_EXACT) != 0;
   if (!gemv_sliced_tok_groupable(d, L, n, tokens, exact)) return hipErrorInvalidValue;
+  {   // 2 / 3 tokens in the reference's roundings: ONE pass of the one-token kernel where every member's operands fit its LDS
+    bool one_pass = true;
+    for (int i = 0; i < n; ++i) one_pass = one_pass && st_one_pass(d[i], tokens, exact);
+    if (one_pass) {
+      void* acc[kSTMaxGroup];
+      for (int i = 0; i < n; ++i) acc[i] = (char*)ws[i] + st_counter_bytes(d[i]);
+      return launch_gemv_sliced_group(d, L, n, x, y, flags, acc, st, tokens);
+    }
+  }
   SlicedTokGroupParams GP = {};
   GP.n = n;
   StPermJobs jobs = {};

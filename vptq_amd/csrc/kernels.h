@@ -77,7 +77,10 @@ hipError_t launch_gemv_sliced_tok_group(const VptqLayerDesc* d, const VptqSliced
                                         int tokens, int flags, void* const* ws, hipStream_t st);
 bool gemv_sliced_groupable(const VptqLayerDesc* d, int n, bool exact = false);
 hipError_t launch_gemv_sliced_group(const VptqLayerDesc* d, const VptqSlicedLayout* L, int n, const void* x, void* const* y,
-                                    int flags, void* const* ws, hipStream_t st);
+                                    int flags, void* const* ws, hipStream_t st, int tokens = 1);
+// (VPTQ_GEMV_EXACT) 2 / 3 tokens in ONE pass of the one-token kernel: x [tokens][in], y[i] [tokens][out], ws[i]: accumulator words
+bool gemv_sliced_exact_tokens_ok(const VptqLayerDesc& d, int tokens);
+size_t gemv_sliced_exact_tokens_workspace_bytes(const VptqLayerDesc& d, int tokens);
 // gemm_k256t.hip - canonical format, fp16 / bf16, up to 16 tokens in one pass over the indices (transposing
 // gather -> 16x16x32 MFMA with tokens as M; folded arithmetic; needs a workspace for the operand-ordered activations)
 bool gemm_k256t_eligible(const VptqLayerDesc& d, int tokens, int flags);

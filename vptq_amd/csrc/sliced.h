@@ -43,6 +43,8 @@ struct SlicedParams {
   uint32_t* arrived;        // [row blocks] workgroups of the row block that have stored their partial sums (0 between launches)
   void* y;
   int N, G, O, rows_per_wave, n_rowblocks, out_f32;
+  // several tokens in one pass (gemv_sliced.hip, TOK > 1): elements between two tokens of x / y, words between their accumulators
+  int x_stride, y_stride, acc_stride;
 };
 
 // f(slot 0), ... f(slot kSLQueue - 1) with the slot as a compile-time constant

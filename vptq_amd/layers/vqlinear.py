@@ -550,9 +550,19 @@ class VQuantLinear(nn.Module):
                 # 37.4 / 37.5 / 38.0; 8192 x 28672: 148.7 / 146.6 / 147.9 -> 122.0 / 124.5 / 127.0 (-0: 135 -> 82 - 86); but 4096^2: 13.5 / 15.8 / 15.7 -> 20.9 / 20.7 / 20.8 and 4096 x 14336: 36.7 / 36.8 / 37.0 -> 41.1 / 41.3 /
                 # 41.9 (8 slices of 128 KiB leave room for a quarter of the columns: 4 phases); v = 16: 28.5 -> 36.0.  5 - 8 tokens: never
                 # (8192^2: 44 - 46 -> 54 - 55)
-                # 2 tokens: two launches of the one-token kernel are as fast or faster (_sliced_token_limit)
+                # 2 tokens there: two launches of the one-token kernel are as fast or faster (_sliced_token_limit).
+                # 2 / 3 tokens of layers whose slice leaves room for (2 tokens + 4) bytes per column - 16-slice layouts up to ~12000 /
+                # ~9700 columns - take ONE PASS of the one-token kernel (gemv_sliced.hip, TOK; profiles/r05/sliced_exact_tokens_one_pass.txt,
+                # gather -> one pass, 2 / 3 tokens): 8192^2 42.1 / 44.9 -> 25.1 / 28.3; 8192 x 28672 149 / 147 -> 62 / 76; 8192 x 1024 13.0 / 18.0
+                # -> 11.0 / 12.9 (k65536-0: 41.3 / 42.2 -> 22.2 / 25.9, 134 / 135 -> 53 / 66); narrow layers that fit with 8 slices: parity
+                # (2048 x 8192: 13.5 / 16.0 -> 13.5 / 15.5), v = 16: slower (8192^2 28.6 -> 30.3) - both stay on the gather kernel
                 n_el = self.indices.shape[1] * self.group_size
-                ok = 3 <= tokens <= 4 and self.vector_len == 8 and sl.slices >= 16 and n_el >= 6 << 20
+                if self.vector_len != 8 or sl.slices < 16:
+                    ok = False
+                elif tokens <= 3 and sl.tokens_one_pass(tokens):
+                    ok = True
+                else:
+                    ok = 3 <= tokens <= 4 and n_el >= 6 << 20
             else:
                 n_el = self.indices.shape[1] * self.group_size      # index elements per table
                 kr = self.num_res_centroids if self.enable_residual else 0

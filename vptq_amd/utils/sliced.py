@@ -230,6 +230,20 @@ class SlicedGemv:
             return False
         return bool(B.lib().vptq_quant_gemv_sliced_tokens_supported_for(self.desc, self._lay_ref, int(tokens), self._flags))
 
+    def tokens_one_pass(self, tokens: int) -> bool:
+        """(reference roundings) does the library take these 2 / 3 tokens in ONE PASS of the one-token kernel (gemv_sliced.hip, TOK:
+        slice + (2 tokens + 4) bytes per column fit the LDS) - the route that needs no column windows?"""
+        if not self.exact or self._side16 or not 2 <= tokens <= 3:
+            return False
+        key = ("_one_pass", tokens)
+        ok = self.__dict__.get(key)
+        if ok is None:
+            lay = B.SlicedLayout.from_buffer_copy(self.layout[0])
+            lay.wstart = None
+            ok = bool(B.lib().vptq_quant_gemv_sliced_tokens_supported_for(self.desc, lay, int(tokens), self._flags))
+            self.__dict__[key] = ok
+        return ok
+
     def forward_tokens(self, x: torch.Tensor, out: torch.Tensor = None, flags: int = 0):
         """2 - 4 tokens in ONE launch (`vptq_quant_gemv_sliced_tokens`, gemv_sliced_tok.hip): x [..., in_features] with 2 - 4
         rows, contiguous.  Returns y, or None where the call cannot be served (the caller takes the regular route)."""
