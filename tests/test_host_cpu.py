@@ -678,6 +678,27 @@ def test_exact_sliced_layout_routing_without_gpu():
     assert b"res" in lib.vptq_last_error()
 
 
+def test_exact_slice_rule_opt_in_for_two_tokens():
+    """VPTQ_SLICED_SLICES=room2 (read once per process: a subprocess): the exact layouts of v = 8 layers take the smaller slice count only
+    where TWO tokens' operands fit beside the slice - 4096-column layers then have 16 slices and their 2 / 3 tokens one pass"""
+    import os
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "from vptq_amd import _backend as B\nfrom test_host_cpu import _family_desc\n"
+            "f = B.lib().vptq_sliced_layout_supported_for\n"
+            "print([f(_family_desc(I, 4096, v, 65536, kr), B.GEMV_EXACT) for (I, v, kr) in "
+            "((4096, 8, 0), (4024, 8, 0), (4032, 8, 0), (3512, 8, 256), (3520, 8, 256), (8192, 8, 256), (4096, 16, 0), (5376, 16, 0))],"
+            " [f(_family_desc(4096, 4096, 8, 65536, 256), 0)])") % (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden"))
+    env = dict(os.environ, VPTQ_SLICED_SLICES="room2")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.strip().splitlines()[-1] == "[16, 8, 16, 8, 16, 16, 16, 16] [8]", out.stdout
+    env.pop("VPTQ_SLICED_SLICES")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().splitlines()[-1] == "[8, 8, 8, 8, 8, 16, 16, 16] [8]", out.stdout + out.stderr[-1000:]
+
+
 def test_sliced_tokens_plan_without_gpu():
     """2 - 4 tokens over the sliced layouts (gemv_sliced_tok.hip): which layers the library takes - the activations of the
     tokens must fit the LDS beside the slice in at most 4 column phases - and the workspace it asks for: host logic"""

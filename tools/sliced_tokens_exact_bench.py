@@ -39,6 +39,7 @@ for I, O in [tuple(int(v) for v in p.split(',')) for p in a.shapes.split(';')]:
                 B.check(lib.vptq_quant_gemv(d, x.data_ptr(), y.data_ptr(), T, B.GEMV_EXACT, None, 0, torch.cuda.current_stream().cuda_stream), "gemv")
         B.check(lib.vptq_quant_gemv(descs[0][0], x.data_ptr(), y.data_ptr(), T, B.GEMV_EXACT, None, 0, torch.cuda.current_stream().cuda_stream), "gemv")
         ref = y.clone()
+        torch.cuda.synchronize()   # (time_graph works on a stream of its own: its warm-up would overwrite y while the clone still reads it)
         r = dict(gather_us=round(time_graph(run_gather, 10) / a.ring, 2))
         xs = [x[:, t:t + 1].contiguous() for t in range(T)]
         ys = [y[:, t:t + 1] for t in range(T)]
@@ -47,6 +48,13 @@ for I, O in [tuple(int(v) for v in p.split(',')) for p in a.shapes.split(';')]:
             got = sls[0].forward_tokens(x)
             torch.cuda.synchronize()
             r["rel_diff"] = ((got.float() - ref.float()).abs().max() / ref.float().abs().max()).item()
+            if r["rel_diff"] > 1e-3:    # which of the two is off?  (the gather kernel again, one launch per token)
+                B.check(lib.vptq_quant_gemv(descs[0][0], x.data_ptr(), y.data_ptr(), T, B.GEMV_EXACT, None, 0, torch.cuda.current_stream().cuda_stream), "gemv")
+                per = torch.cat([sls[0](xs[t]) for t in range(T)], dim=1)
+                torch.cuda.synchronize()
+                f = lambda a, b: ((a.float() - b.float()).abs().max() / b.float().abs().max()).item()  # noqa: E731
+                r["diag"] = dict(gather_again_vs_first=f(y, ref), one_launch_vs_gather_again=f(got, y), per_token_vs_gather_again=f(per, y),
+                                 one_launch_again_vs_first=f(sls[0].forward_tokens(x), got))
             r["identical"] = round((got.view(torch.int16) == ref.view(torch.int16)).float().mean().item(), 4)
             r["one_launch_us"] = round(time_graph(lambda: [s.forward_tokens(x) for s in sls], 10) / a.ring, 2)
         row[f"t{T}"] = r

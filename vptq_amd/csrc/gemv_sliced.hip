@@ -31,6 +31,8 @@
 //                         c f16(s x) and r f16(s x) from different workgroups)
 //   reference roundings (VPTQ_GEMV_EXACT, template EX): w = f16(f16(f16(c + r) * s) + b) per weight, y = sum w x + bias -
 //                         the product default since round 5; one table only (none or the 256-entry residual codebook)
+#include <cstring>
+
 #include "sliced.h"
 
 namespace vptq {
@@ -796,9 +798,16 @@ int gemv_sliced_slices(const VptqLayerDesc& d, bool exact) {
     return d.group_size <= (sl_res256(d) ? kSLMaxG8Res : kSLMaxG8) ? small : 2 * small;
   }
   if (d.num_centroids <= 0 || d.vector_len <= 0) return 0;
+  // VPTQ_SLICED_SLICES=room2 (process-wide opt-in, v = 8): the smaller count only where the slice leaves room for TWO tokens'
+  // operands, so that 2 / 3 tokens take one pass of the one-token kernel (TOK) on 4096-column layers too - they miss that by 0.5 KiB
+  // with 128 KiB slices.  Measured on the Llama-3-8B shapes in v8-k65536-256 (profiles/r05/sliced_exact_slices_16_for_narrow_layers.txt):
+  // 2 sequences 198.6 -> 210.7 tokens/s, 3: 270.6 -> 277.3, ONE: 127.1 -> 125.4 (the layers' own time +5 %) - one token is the
+  // default's business, so the default stays "8 slices wherever one token fits".
+  static std::atomic<int> room2{-1};
+  if (room2 < 0) { const char* e = getenv("VPTQ_SLICED_SLICES"); room2 = (e && strcmp(e, "room2") == 0) ? 1 : 0; }
   for (int nsl = (force16 == 1 ? 2 * small : small); nsl <= 2 * small; nsl *= 2) {
     const uint32_t tab = (uint32_t)(d.num_centroids / nsl) * (uint32_t)d.vector_len * 2u;
-    if ((tab + 15u) / 16u * 16u + sl_operand_bytes(d, true) <= kSLLdsLimit) return nsl;
+    if ((tab + 15u) / 16u * 16u + sl_operand_bytes(d, true, (nsl == small && room2 == 1 && d.vector_len == 8) ? 2 : 1) <= kSLLdsLimit) return nsl;
   }
   return 0;
 }
