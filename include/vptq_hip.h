@@ -95,7 +95,9 @@ enum {
   /* take the one-pass batched-decode kernel (gemm_k256t: canonical format, 1-16 tokens per launch,
    * needs the workspace) wherever it is eligible, not only where it is the fastest (bf16, 5+
    * tokens): testing / A-B */
-  VPTQ_GEMV_FORCE_BATCHED = 1 << 7
+  VPTQ_GEMV_FORCE_BATCHED = 1 << 7,
+  /* vptq_quant_gemv_sliced_grouped (ABI >= 9): the n descriptors are COLUMN PARTS of one layer - see there */
+  VPTQ_GEMV_COLUMN_PARTS = 1 << 8
 };
 
 /* most tokens vptq_quant_gemv accepts (fp16 layers of the canonical format; every other layer:
@@ -367,7 +369,13 @@ VPTQ_API int vptq_quant_gemv_sliced_tokens_grouped(const VptqLayerDesc* descs, c
  * (ABI >= 7): layouts = the layers' structs one after the other (vptq_sliced_layout_tables() each; give every struct the
  * group's rows_per_wave - one round of workgroups over ALL layers), y / workspaces / workspace_bytes one per layer.  The
  * fixed part of a sliced launch (boundary, slice copy, staging, cross-slice hand-over: ~7 of the 10 us of a 4096 x 4096
- * layer) is paid once. */
+ * layer) is paid once.
+ * flags | VPTQ_GEMV_EXACT | VPTQ_GEMV_COLUMN_PARTS (ABI >= 9): the n descriptors are the COLUMN RANGES [i G / n, (i + 1) G / n) of ONE
+ * layer that is too wide for the reference's roundings in one piece (6 bytes of LDS per column: 28672-column layers) - copies of
+ * the layer's descriptor with in_features = group_size = G / n (a multiple of 8) and weight_scale / weight_bias / perm /
+ * scale_permuted / bias_permuted advanced to the part's first column, a layout per part built from those columns of the index
+ * matrix (columns counted from the part's first); x = the WHOLE activation, y[i] = y[0], workspaces[i] = workspaces[0]: the parts
+ * meet in the output's accumulator word (n x slices arrivals; at most 127). */
 VPTQ_API int vptq_quant_gemv_sliced_grouped(const VptqLayerDesc* descs, const VptqSlicedLayout* layouts, int n,
                                    const void* x, void* const* y, int flags, void* const* workspaces,
                                    const size_t* workspace_bytes, void* stream);

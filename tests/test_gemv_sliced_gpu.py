@@ -92,7 +92,10 @@ EXACT_CASES = [
     (2048, 520, dict(dist="llm", enable_perm=True, bias=True), 0),     # a permutation: x gathered, scale / bias in column order
     (6152, 264, dict(enable_perm=True), 2),
     (14336, 128, dict(dist="llm"), 0),                                 # 16 slices, two staging rounds
-    (16392, 72, dict(dist="llm"), 0),                                  # too wide for the reference's roundings in LDS: not served
+    (16392, 72, dict(dist="llm"), 0),                                  # too wide for the reference's roundings in one piece: 3 column parts
+    (28672, 136, dict(dist="llm", bias=True), 0),                      # 2 column parts of 14336 (the down projection of the 70B class)
+    (24576, 72, dict(dist="llm", enable_perm=True), 2),                # 2 x 12288, each part its slice of the permutation
+    (32768, 72, dict(dist="llm"), 0),                                  # 2 x 16384: a part is still too wide; 3 do not divide it: not served
 ]
 
 
@@ -115,12 +118,15 @@ def test_sliced_layout_reference_roundings(I, O, kw, rpw, dt, v, kr, dev):
     small = 8 if v == 8 else 16
     lds = lambda nsl: (65536 // nsl) * v * 2 + (I + 64) * 6 + 64 + (4096 if kr == 256 else 0)   # noqa: E731
     assert want_slices == (small if lds(small) <= 163840 else (2 * small if lds(2 * small) <= 163840 else 0))
-    if not want_slices:
+    from vptq_amd.utils.sliced import exact_column_parts
+    parts, pslices = exact_column_parts(desc, I)
+    if not parts:
         with pytest.raises(ValueError):
             SlicedGemv(m, exact=True)
         return
     sl = SlicedGemv(m, rows_per_wave=rpw, exact=True)
-    assert sl.slices == want_slices and sl.exact
+    # (too wide for 6 bytes of LDS per column in one piece: equal column parts of a multiple of 8 columns - 16392 = 3 x 5464)
+    assert sl.exact and sl.parts == parts == (1 if want_slices else 3 if I == 16392 else 2) and sl.slices == (want_slices or pslices)
     xt = bits_to_tensor(x, dt, dev).reshape(x.shape)
     got = sl(xt)
     torch.cuda.synchronize()
@@ -135,7 +141,7 @@ def test_sliced_layout_reference_roundings(I, O, kw, rpw, dt, v, kr, dev):
     y32 = sl(xt, flags=B.GEMV_OUT_F32)
     assert y32.dtype == torch.float32 and torch.equal(y32.to(got.dtype).view(torch.int16), got.view(torch.int16))
     assert torch.equal(sl(xt).view(torch.int16), got.view(torch.int16))
-    if kr not in (0, 256) or (v == 16 and kr):   # two tables in the reference's roundings: one token only
+    if kr not in (0, 256) or (v == 16 and kr) or sl.parts > 1:   # two tables / column parts in the reference's roundings: one token only
         assert not sl.tokens_supported(2) and sl.forward_tokens(torch.cat([xt, xt], dim=1)) is None
 
 

@@ -678,6 +678,20 @@ def test_exact_sliced_layout_routing_without_gpu():
     assert b"res" in lib.vptq_last_error()
 
 
+def test_exact_column_parts_without_gpu():
+    """layers too wide for the reference's roundings in one piece (6 bytes of LDS per column beside the slice) are served as 2 or 3
+    equal column parts of a multiple of 8 columns (VPTQ_GEMV_COLUMN_PARTS): which layers, which descriptors - host logic"""
+    from vptq_amd.utils.sliced import exact_column_parts, part_desc
+    for (I, v, kr, want) in ((8192, 8, 256, (1, 16)), (4096, 8, 0, (1, 8)), (28672, 8, 256, (2, 16)), (28672, 8, 0, (2, 16)), (24576, 8, 65536, (2, 16)),
+                             (16392, 8, 0, (3, 16)), (32768, 8, 0, (0, 0)), (28672, 16, 0, (2, 32)), (16304, 8, 0, (1, 16)), (16312, 8, 0, (0, 0)), (16320, 8, 0, (2, 16))):
+        assert exact_column_parts(_family_desc(I, 4096, v, 65536, kr), I) == want, (I, v, kr)
+    d = _family_desc(28672, 4096, 8, 65536, 256)
+    p = part_desc(d, 14336, 28672)
+    assert (p.in_features, p.group_size, p.out_features, p.num_indices) == (14336, 14336, d.out_features, d.num_indices)
+    assert p.weight_scale == d.weight_scale + 2 * 14336 and p.weight_bias == d.weight_bias + 2 * 14336 and p.centroids == d.centroids
+    assert p.indices == d.indices and p.bias == d.bias and not p.perm
+
+
 def test_exact_slice_rule_opt_in_for_two_tokens():
     """VPTQ_SLICED_SLICES=room2 (read once per process: a subprocess): the exact layouts of v = 8 layers take the smaller slice count only
     where TWO tokens' operands fit beside the slice - 4096-column layers then have 16 slices and their 2 / 3 tokens one pass"""

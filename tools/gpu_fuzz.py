@@ -234,7 +234,7 @@ def fuzz_sliced(a, dev):
         v = int(rng.choice([8, 8, 16]))
         k = int(rng.choice([65536, 65536, 65536, 32768, 16384]))
         kr = int(rng.choice([0, 256, 65536, 4, 64, 1024, 4096, 16384, 32768, 2]))
-        I = int(rng.choice([8 * int(rng.integers(8, 1800)), 2048 * int(rng.integers(1, 8)), 8 * int(rng.integers(1800, 3600))]))
+        I = int(rng.choice([8 * int(rng.integers(8, 1800)), 2048 * int(rng.integers(1, 8)), 8 * int(rng.integers(1800, 3600)), 48 * int(rng.integers(340, 600))]))
         O = int(rng.choice([v * int(rng.integers(33, 80)), v * int(rng.integers(64, 700)) - int(rng.integers(0, v))]))
         L = vo.make_layer(I, O, dist="llm", seed=9000 + c, dtype=dt, vector_len=v, num_centroids=k, num_res_centroids=kr,
                           bias=bool(rng.integers(0, 2)), enable_perm=bool(rng.integers(0, 3) == 0))
@@ -279,9 +279,10 @@ def fuzz_sliced(a, dev):
         # one gathered from device memory), where the library serves the layer: almost every output bit-identical
         ex = -1.0
         sx = None
-        if B_.lib().vptq_sliced_layout_supported_for(m._descriptor()[1], 4):
+        from vptq_amd.utils.sliced import exact_column_parts
+        if exact_column_parts(m._descriptor()[1], I)[0]:    # (in one piece, or - layers wider than ~16300 columns - as 2 / 3 column parts)
             sx = SlicedGemv(m, rows_per_wave=rpw, exact=True)
-            print(f"  exact layout built (slices {sx.slices})", flush=True)
+            print(f"  exact layout built (slices {sx.slices}, column parts {sx.parts})", flush=True)
             gx = sx(xt)
             torch.cuda.synchronize()
             assert torch.equal(gx.view(torch.int16), sx(xt).view(torch.int16)), (c, "exact: not reproducible")

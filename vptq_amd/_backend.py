@@ -30,6 +30,7 @@ GEMV_MAX_TOKENS = 64       # most vptq_quant_gemv accepts (any layer: 16); per l
 GEMV_ANY_FORMAT_TOKENS = 8  # the fused GEMV is the faster path for every format up to here
 GEMV_CHAIN_DEPENDENT = 1 << 6  # vptq_quant_gemv_chain: layer i + 1 reads what layer i wrote
 GEMV_FORCE_BATCHED = 1 << 7    # the one-pass batched-decode kernel wherever eligible (tests, A/B)
+GEMV_COLUMN_PARTS = 1 << 8     # vptq_quant_gemv_sliced_grouped: the descriptors are column ranges of ONE layer (shared y / workspace)
 # return codes (include/vptq_hip.h)
 E_NULL, E_SHAPE, E_UNSUPPORTED, E_ALIGN, E_TOKENS, E_WORKSPACE = -1, -2, -3, -4, -5, -6
 GROUP_MAX = 64

@@ -558,6 +558,13 @@ int vptq_quant_gemv_sliced_grouped(const VptqLayerDesc* descs, const VptqSlicedL
   }
   const bool exact = (flags & VPTQ_GEMV_EXACT) != 0;
   if (flags & VPTQ_GEMV_FORCE_GENERIC) return fail(VPTQ_E_UNSUPPORTED, "VPTQ_GEMV_FORCE_GENERIC: use vptq_quant_gemv");
+  if (flags & VPTQ_GEMV_COLUMN_PARTS) {
+    if (!exact) return fail(VPTQ_E_UNSUPPORTED, "VPTQ_GEMV_COLUMN_PARTS goes with VPTQ_GEMV_EXACT (the folded form stages 32768 columns in one piece)");
+    for (int i = 1; i < n; ++i)
+      if (y[i] != y[0] || workspaces[i] != workspaces[0] || descs[i].out_features != descs[0].out_features ||
+          descs[i].num_indices != descs[0].num_indices || descs[i].bias != descs[0].bias || descs[i].in_features != descs[0].in_features)
+        return fail(VPTQ_E_UNSUPPORTED, "column parts share y, the workspace, the output bias and have one width");
+  }
   if (!vptq::gemv_sliced_groupable(descs, n, exact))
     return fail(VPTQ_E_UNSUPPORTED, "a sliced group takes layers of ONE format, dtype and input width that vptq_sliced_layout_supported_for() accepts");
   if ((((uintptr_t)x) & 15) != 0) return fail(VPTQ_E_UNSUPPORTED, "x must be 16-byte aligned");

@@ -114,6 +114,7 @@ static __device__ __forceinline__ float sl_from_fixed(unsigned long long w) {
 }
 struct SlicedGroupParams {
   int n;
+  int arrivals;   // workgroups that add into an output's accumulator word: (tables x) slices - x n where the "layers" are COLUMN PARTS of one
   int start[kSLMaxGroup + 1];
   SlicedParams p[kSLMaxGroup];
 };
@@ -491,7 +492,7 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
       for (int t = 0; t < TOK; ++t) {
 #pragma unroll
         for (int i = 0; i < V / 4; ++i) {
-          if ((pend_old[t][i] & 127ull) == (unsigned long long)(NSLT - 1)) {
+          if ((pend_old[t][i] & 127ull) == (unsigned long long)(GP.arrivals - 1)) {
             const int o = pend_o + i;
             float r = sl_from_fixed(pend_old[t][i] + pend_mine[t][i]);
             if (o < P.O) {
@@ -955,10 +956,22 @@ bool gemv_sliced_exact_tokens_ok(const VptqLayerDesc& d, int tokens) {
 size_t gemv_sliced_exact_tokens_workspace_bytes(const VptqLayerDesc& d, int tokens) {
   return ((size_t)tokens * d.num_indices * d.vector_len * sizeof(unsigned long long) + 255) / 256 * 256;
 }
+// VPTQ_GEMV_COLUMN_PARTS: the n "layers" are the column ranges [i G / n, (i + 1) G / n) of ONE layer too wide for the LDS (28672
+// columns in the reference's roundings: 6 bytes per column) - descriptors with in_features = group_size = G / n and the column
+// order tensors (scale, bias, permutation) advanced to the part's first column, a layout per part built from those columns of
+// the index matrix; x is the WHOLE activation (part i reads it from column i G / n on, or through its slice of the permutation),
+// y and the accumulator words are shared: an output is complete after n x slices arrivals.
 hipError_t launch_gemv_sliced_group(const VptqLayerDesc* d, const VptqSlicedLayout* L, int n, const void* x, void* const* y,
                                     int flags, void* const* ws, hipStream_t st, int tokens) {
   const bool exact = (flags & VPTQ_GEMV_EXACT) != 0;
+  const bool parts = (flags & VPTQ_GEMV_COLUMN_PARTS) != 0;
   if (!gemv_sliced_groupable(d, n, exact) || (tokens != 1 && !exact)) return hipErrorInvalidValue;
+  if (parts) {
+    for (int i = 1; i < n; ++i)
+      if (y[i] != y[0] || ws[i] != ws[0] || d[i].out_features != d[0].out_features || d[i].num_indices != d[0].num_indices || d[i].bias != d[0].bias)
+        return hipErrorInvalidValue;
+    if (tokens != 1 || !exact) return hipErrorInvalidValue;   // (the folded form stages 32768 columns in one piece: no parts needed)
+  }
   SlicedGroupParams GP = {};
   GP.n = n;
   uint32_t lds = 0;
@@ -967,12 +980,16 @@ hipError_t launch_gemv_sliced_group(const VptqLayerDesc* d, const VptqSlicedLayo
   const int nslt = nsl * tables;
   for (int i = 0; i < n; ++i) {
     uint32_t l = 0;
-    const hipError_t e = sl_fill(d[i], L + (size_t)i * tables, x, y[i], flags, ws[i], GP.p[i], l, tokens);
+    // (a part without a permutation reads its own columns of x; with one, its slice of `perm` indexes the whole activation)
+    const void* const xi = (parts && d[i].perm == nullptr) ? (const void*)((const uint16_t*)x + (size_t)i * d[i].in_features) : x;
+    const hipError_t e = sl_fill(d[i], L + (size_t)i * tables, xi, y[i], flags, ws[i], GP.p[i], l, tokens);
     if (e != hipSuccess) return e;
     lds = l > lds ? l : lds;
     GP.start[i + 1] = GP.start[i] + nslt * GP.p[i].n_rowblocks;
   }
   for (int i = n; i < kSLMaxGroup; ++i) GP.start[i + 1] = GP.start[n];
+  GP.arrivals = nslt * (parts ? n : 1);
+  if (GP.arrivals > 127) return hipErrorInvalidValue;   // (7 bits of the accumulator word count them)
   if (tokens != 1) return launch_sl_tokens(d[0].dtype, GP, d[0].vector_len, nsl, sl_res256(d[0]), tokens, lds, st);
   return d[0].dtype == VPTQ_DTYPE_F16
              ? launch_sl_dt<F16>(GP, d[0].vector_len, nsl, sl_res256(d[0]), sl_two(d[0]), exact, lds, st)

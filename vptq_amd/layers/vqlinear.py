@@ -468,9 +468,10 @@ class VQuantLinear(nn.Module):
                 big = (kr_ >= 4096 and n_el >= _SLICED_EXACT_RG_MIN_ELEMENTS) or "_sliced_on" in self.__dict__
             else:
                 big = n_el >= _SLICED_EXACT_MIN_ELEMENTS or "_sliced_on" in self.__dict__
-            if (big or not exact) and B.lib().vptq_sliced_layout_supported_for(cache[1], B.GEMV_EXACT if exact else 0) and \
-                    self._sliced_fits(cache, on):
-                from vptq_amd.utils.sliced import SlicedGemv
+            from vptq_amd.utils.sliced import SlicedGemv, exact_column_parts
+            # (reference roundings: layers too wide for the LDS in one piece - 28672 columns - are served as equal column parts)
+            served = exact_column_parts(cache[1], self.group_size)[0] if exact else B.lib().vptq_sliced_layout_supported_for(cache[1], 0)
+            if (big or not exact) and served and self._sliced_fits(cache, on):
                 try:
                     obj = SlicedGemv(self, exact=exact)
                 except torch.cuda.OutOfMemoryError as e:

@@ -139,6 +139,32 @@ def rows_per_wave_for(n_rows: int, slices: int = 8, workgroups: int = 256) -> in
     return min(r, 64)
 
 
+def part_desc(desc, c0: int, c1: int):
+    """copy of a layer's descriptor that stands for its columns [c0, c1) alone (`VPTQ_GEMV_COLUMN_PARTS`, include/vptq_hip.h): widths
+    and the column-order tensors advanced to c0 (16-bit elements).  The tensors stay owned by the layer's own descriptor."""
+    d = B.LayerDesc.from_buffer_copy(desc)
+    d.in_features = d.group_size = c1 - c0
+    for f in ("weight_scale", "weight_bias", "perm", "scale_permuted", "bias_permuted"):
+        p = getattr(desc, f)
+        if p:
+            setattr(d, f, p + 2 * c0)
+    return d
+
+
+def exact_column_parts(desc, group_size: int):
+    """(parts, slices) with which the reference's roundings are served over sliced layouts: (1, n) where the layer fits in one
+    piece, (2 or 3, n) where equal column parts of a multiple of 8 columns do (28672-column layers: 2 x 14336), (0, 0) else"""
+    n = B.lib().vptq_sliced_layout_supported_for(desc, B.GEMV_EXACT)
+    if n:
+        return 1, n
+    for parts in (2, 3):
+        if group_size % (8 * parts) == 0:
+            n = B.lib().vptq_sliced_layout_supported_for(part_desc(desc, 0, group_size // parts), B.GEMV_EXACT)
+            if n and n * parts <= 127:
+                return parts, n
+    return 0, 0
+
+
 class SlicedGemv:
     """One-token forward of a v8-k65536-0 `VQuantLinear` over its sliced layout."""
 
@@ -151,7 +177,11 @@ class SlicedGemv:
         self._flags = B.GEMV_EXACT if self.exact else 0
         cache = layer._descriptor()
         self.desc, self.dev = cache[1], cache[3]
-        self.slices = B.lib().vptq_sliced_layout_supported_for(self.desc, self._flags)
+        self.parts = 1
+        if self.exact:   # (a layer too wide for 6 bytes of LDS per column in one piece: equal column parts, one layout each)
+            self.parts, self.slices = exact_column_parts(self.desc, layer.group_size)
+        else:
+            self.slices = B.lib().vptq_sliced_layout_supported_for(self.desc, self._flags)
         if not self.slices:
             raise ValueError("the sliced layout serves v = 8 / 16 layers with 16384 ... 65536 main centroids, group_size <= 32768"
                              " (reference roundings: one table, up to ~16000 columns)")
@@ -167,7 +197,14 @@ class SlicedGemv:
         # library decides: the kernel's LDS budget)
         whole = [False, n_tables == 2 and bool(B.lib().vptq_sliced_layout_whole_table(self.desc, 1))]
         idx, ridx = split_index_streams(layer.indices.data, layer.group_size, rb, ib)
-        if n_tables == 2:
+        if self.parts > 1:
+            w = layer.group_size // self.parts
+            self._tensors = [layout_from_indices(idx[:, p * w:(p + 1) * w].contiguous(), self.slices,
+                                                 ridx[:, p * w:(p + 1) * w].contiguous() if kr else None, ib,
+                                                 side_dtype=torch.int16 if side16 else torch.uint8) for p in range(self.parts)]
+            self._part_descs = (B.LayerDesc * self.parts)(*[part_desc(self.desc, p * w, (p + 1) * w) for p in range(self.parts)])
+            whole = [False] * self.parts
+        elif n_tables == 2:
             # (c + r) s x = c s x + r s x: the residual codebook is a second table with a layout bucketed by ITS index
             self._tensors = [layout_from_indices(idx, self.slices, None, ib), layout_from_indices(ridx, self.slices, None, rb, whole[1])]
         else:
@@ -182,7 +219,9 @@ class SlicedGemv:
             B.SlicedLayout(e.data_ptr(), b.data_ptr(), f.data_ptr(), r.data_ptr() if r is not None else None, rpw, 1, self.slices, int(w),
                            ws.data_ptr())
             for (e, b, f, r, ws), w in zip(self._tensors, self._whole)])
-        self._ws_bytes = B.lib().vptq_quant_gemv_sliced_workspace_bytes(self.desc)
+        self._ws_bytes = B.lib().vptq_quant_gemv_sliced_workspace_bytes(self._part_descs[0] if self.parts > 1 else self.desc)
+        if self.parts > 1:
+            self._pp = ((C.c_void_p * self.parts)(), (C.c_void_p * self.parts)(), (C.c_size_t * self.parts)(*([self._ws_bytes] * self.parts)))
         # partial sums + arrival counters, ONE PER STREAM (two streams - or a graph replay next to an eager call on
         # another stream - running the same layer would race on a shared one); zeroed once, every call leaves the
         # counters zero
@@ -226,14 +265,14 @@ class SlicedGemv:
     def tokens_supported(self, tokens: int) -> bool:
         """does the library's kernel for 2 - 4 tokens over these layouts take this layer (its activations must fit the LDS
         beside the slice in at most 4 column phases)?"""
-        if self.exact and self._side16:   # (the reference's roundings over two-table formats: one token only)
+        if self.exact and (self._side16 or self.parts > 1):   # (the reference's roundings over two-table formats / column parts: one token only)
             return False
         return bool(B.lib().vptq_quant_gemv_sliced_tokens_supported_for(self.desc, self._lay_ref, int(tokens), self._flags))
 
     def tokens_one_pass(self, tokens: int) -> bool:
         """(reference roundings) does the library take these 2 / 3 tokens in ONE PASS of the one-token kernel (gemv_sliced.hip, TOK:
         slice + (2 tokens + 4) bytes per column fit the LDS) - the route that needs no column windows?"""
-        if not self.exact or self._side16 or not 2 <= tokens <= 3:
+        if not self.exact or self._side16 or self.parts > 1 or not 2 <= tokens <= 3:
             return False
         key = ("_one_pass", tokens)
         ok = self.__dict__.get(key)
@@ -251,7 +290,7 @@ class SlicedGemv:
         tokens = x.numel() // lay.in_features
         if x.shape[-1] != lay.in_features or not 2 <= tokens <= 8:
             raise ValueError("forward_tokens takes 2 - 8 tokens of in_features values")
-        if self.exact and self._side16:
+        if self.exact and (self._side16 or self.parts > 1):
             return None
         if x.dtype != self._dtype or x.device != self.dev:
             x = lay._check_activation(x)
@@ -311,7 +350,15 @@ class SlicedGemv:
         if out is None:
             out = torch.empty(x.shape[:-1] + (self.layer.out_features,),
                               dtype=torch.float32 if (flags & B.GEMV_OUT_F32) else self._dtype, device=self.dev)
-        rc = self._fn(self.desc, self._lay_ref, x.data_ptr(), out.data_ptr(), flags | self._flags, ws.data_ptr(), self._ws_bytes, sp)
+        if self.parts > 1:   # column parts of one layer: one grouped launch, shared output and accumulator words
+            yp, wp, wb = self._pp
+            for i in range(self.parts):
+                yp[i] = out.data_ptr()
+                wp[i] = ws.data_ptr()
+            rc = B.lib().vptq_quant_gemv_sliced_grouped(self._part_descs, self._lay_ref, self.parts, x.data_ptr(), yp,
+                                                        flags | self._flags | B.GEMV_COLUMN_PARTS, wp, wb, sp)
+        else:
+            rc = self._fn(self.desc, self._lay_ref, x.data_ptr(), out.data_ptr(), flags | self._flags, ws.data_ptr(), self._ws_bytes, sp)
         if rc == B.E_UNSUPPORTED:
             return None
         if rc:
@@ -335,7 +382,7 @@ class SlicedGroupGemv:
         tables = len(m0.layout)
         kind = lambda m: (m.layer.vector_len, m.layer.num_centroids,   # noqa: E731
                           m.layer.num_res_centroids if m.layer.enable_residual else 0, tuple(m._whole), m.exact)
-        if not 1 <= n <= 3 or any(len(m.layout) != tables or m.slices != m0.slices or m._dtype != m0._dtype or m.dev != m0.dev or
+        if not 1 <= n <= 3 or any(m.parts > 1 for m in self.members) or any(len(m.layout) != tables or m.slices != m0.slices or m._dtype != m0._dtype or m.dev != m0.dev or
                                   m.layer.in_features != m0.layer.in_features or kind(m) != kind(m0) for m in self.members):
             raise ValueError("a sliced group takes 1..3 layers of one format (vector length, codebook sizes), dtype, device and input width")
         rpw = rows_per_wave_for(sum(m.blocks.shape[1] for m in self.members), m0.slices * tables)   # one round of workgroups over ALL layers
