@@ -154,14 +154,21 @@ def part_desc(desc, c0: int, c1: int):
 def exact_column_parts(desc, group_size: int):
     """(parts, slices) with which the reference's roundings are served over sliced layouts: (1, n) where the layer fits in one
     piece, (2 or 3, n) where equal column parts of a multiple of 8 columns do (28672-column layers: 2 x 14336), (0, 0) else"""
+    import os
+    least = int(os.environ.get("VPTQ_SLICED_PARTS", "1") or 1)     # (A/B: at least this many parts where the columns divide)
     n = B.lib().vptq_sliced_layout_supported_for(desc, B.GEMV_EXACT)
-    if n:
+    if n and least <= 1:
         return 1, n
     for parts in (2, 3):
+        if parts < least:
+            continue
         if group_size % (8 * parts) == 0:
             n = B.lib().vptq_sliced_layout_supported_for(part_desc(desc, 0, group_size // parts), B.GEMV_EXACT)
             if n and n * parts <= 127:
                 return parts, n
+    if least > 1:
+        n = B.lib().vptq_sliced_layout_supported_for(desc, B.GEMV_EXACT)
+        return (1, n) if n else (0, 0)
     return 0, 0
 
 
