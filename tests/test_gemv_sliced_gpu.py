@@ -141,7 +141,8 @@ def test_sliced_layout_reference_roundings(I, O, kw, rpw, dt, v, kr, dev):
     y32 = sl(xt, flags=B.GEMV_OUT_F32)
     assert y32.dtype == torch.float32 and torch.equal(y32.to(got.dtype).view(torch.int16), got.view(torch.int16))
     assert torch.equal(sl(xt).view(torch.int16), got.view(torch.int16))
-    if kr not in (0, 256) or (v == 16 and kr) or sl.parts > 1:   # two tables / column parts in the reference's roundings: one token only
+    # column parts, two tables of v = 16, two tables of v = 8 whose operands of two tokens do not fit beside the slice: one token only
+    if sl.parts > 1 or (v == 16 and kr) or (kr not in (0, 256) and not sl.tokens_one_pass(2)):
         assert not sl.tokens_supported(2) and sl.forward_tokens(torch.cat([xt, xt], dim=1)) is None
 
 
@@ -150,7 +151,7 @@ EXACT_TOK_SHAPES = [(2048, 528, dict(dist="llm", enable_perm=True, bias=True)), 
 
 
 @pytest.mark.parametrize("tokens,dt", [(2, "f16"), (3, "bf16"), (4, "f16"), (4, "bf16"), (5, "f16"), (7, "bf16"), (8, "f16"), (8, "bf16")])
-@pytest.mark.parametrize("v,k,kr", [(8, 65536, 0), (8, 65536, 256), (16, 65536, 0), (8, 16384, 256)])
+@pytest.mark.parametrize("v,k,kr", [(8, 65536, 0), (8, 65536, 256), (16, 65536, 0), (8, 16384, 256), (8, 65536, 65536), (8, 65536, 1024)])
 @pytest.mark.parametrize("I,O,kw", EXACT_TOK_SHAPES)
 def test_sliced_tokens_reference_roundings(I, O, kw, v, k, kr, tokens, dt, dev):
     """2 - 8 tokens in ONE launch over the exact sliced layout, every weight rebuilt as f16(f16(f16(c + r) s) + b) in the matrix
@@ -165,6 +166,11 @@ def test_sliced_tokens_reference_roundings(I, O, kw, v, k, kr, tokens, dt, dev):
     m = spec_to_module(L, dev)
     sl = SlicedGemv(m, exact=True)
     xt = bits_to_tensor(x, dt, dev).reshape(x.shape)
+    if kr not in (0, 256) and not sl.tokens_one_pass(tokens):   # two tables: 2 / 3 tokens in one pass (residual entries gathered once), else none
+        assert not sl.tokens_supported(tokens) and sl.forward_tokens(xt) is None
+        # (what one pass needs: the slice + (2 tokens + 4) bytes per column within 160 KiB, at most 3 tokens)
+        assert tokens > 3 or (k // sl.slices) * v * 2 + (I + 64) * (4 + 2 * tokens) + 64 > 163840, (I, tokens)
+        return
     assert sl.tokens_supported(tokens)    # (8 + 2 x token slots bytes per column and phase: every width of these cases fits)
     got = sl.forward_tokens(xt)
     torch.cuda.synchronize()
@@ -862,6 +868,21 @@ def test_module_default_route_for_two_to_four_tokens_of_wide_layers(dev, monkeyp
     assert all(torch.equal(yw[:, t].reshape(-1).view(torch.int16), sw(xw[:, t:t + 1].contiguous()).reshape(-1).view(torch.int16)) for t in range(2))
     assert torch.equal(mw(xw).view(torch.int16), sw.forward_tokens(xw).view(torch.int16))
     assert rel_err(tensor_to_bits(mw(xw)), vo.forward(Lw, tensor_to_bits(xw)), "f16") <= 1e-3
+    # a two-table format of v = 8 ("4 bit"): 2 / 3 tokens in one pass as well - the residual entries are gathered from L2 once
+    L4 = vo.make_layer(8192, 2048, dist="llm", seed=74, num_centroids=65536, num_res_centroids=65536)
+    m4 = spec_to_module(L4, dev)
+    m4(xt[:, :1].contiguous())
+    s4 = m4.__dict__["_sliced"][1]
+    assert s4 is not None and s4.exact and s4.res.dtype == torch.int16 and s4.tokens_one_pass(3) and not s4.tokens_supported(4)
+    assert m4._sliced_one_launch(s4, 2) and m4._sliced_one_launch(s4, 3) and not m4._sliced_one_launch(s4, 4)
+    for T in (2, 3):
+        x = xt[:, :T].contiguous()
+        y = m4(x)
+        assert torch.equal(y.view(torch.int16), s4.forward_tokens(x).view(torch.int16))
+        yb = tensor_to_bits(y)
+        w4 = vo.forward(L4, xs[:, :T])
+        assert rel_err(yb, w4, "f16") <= 1e-3 and float((yb.reshape(-1) == np.asarray(w4).reshape(-1)).mean()) >= 0.95
+    assert torch.equal(m4(xt[:, :4].contiguous()).view(torch.int16), gemv_abi(m4, xt[:, :4].contiguous(), EXACT).view(torch.int16))
     # switched on for every layer the library takes ("1"): siblings of one format share one launch, each member's own bits
     monkeypatch.setattr(vq, "_SLICED_ONE_LAUNCH", "1")
     Lq = [vo.make_layer(8192, O, seed=80 + i, dist="llm", num_centroids=65536, num_res_centroids=256, bias=(i == 1)) for i, O in enumerate((1024, 264, 512))]

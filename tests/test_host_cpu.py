@@ -737,7 +737,7 @@ def test_sliced_tokens_plan_without_gpu():
     d4 = _family_desc(4096, 4096, 8, 65536, 256)      # 5 - 8 tokens: 16 bytes of activations per column must fit in 4 phases
     assert [sup(d4, layouts(d4), t) for t in (5, 8, 9)] == [1, 1, 0] and wsb(d4, 8) == 8 * 8 * 4096 * 4 + 256 + 3 * 4096 * 8
     d2 = _family_desc(8192, 8192, 8, 65536, 65536)
-    assert sup(d2, layouts(d2), 4) == 1 and wsb(d2, 3) == 3 * 16 * 8192 * 4 + 256
+    assert sup(d2, layouts(d2), 4) == 1 and wsb(d2, 3) == 3 * 16 * 8192 * 4 + 256 + acc   # (two tables of v = 8 have the one-pass route too)
     # ABI 9: the reference's roundings (one-table formats, an exact layout: its slice count), 8 + 2 x token slots bytes per column and phase
     EX = B.GEMV_EXACT
     supf = lib.vptq_quant_gemv_sliced_tokens_supported_for
@@ -746,7 +746,7 @@ def test_sliced_tokens_plan_without_gpu():
         return (B.SlicedLayout * 1)(B.SlicedLayout(p, p, p, p, 2, 1, lib.vptq_sliced_layout_supported_for(dd, EX), 0, p if wstart else None))
     for (I, v, kr, want) in ((4096, 8, 256, [0, 1, 1, 1, 1, 0]), (8192, 8, 256, [0, 1, 1, 1, 1, 0]), (14336, 8, 0, [0, 1, 1, 1, 1, 0]),
                              (5376, 8, 0, [0, 1, 1, 0, 0, 0]), (16288, 8, 0, [0, 1, 1, 0, 0, 0]), (8192, 16, 0, [0, 1, 1, 1, 1, 0]),
-                             (8192, 8, 65536, [0] * 6), (8192, 16, 65536, [0] * 6), (8192, 8, 4096, [0] * 6)):
+                             (8192, 8, 65536, [0, 1, 0, 0, 0, 0]), (8192, 16, 65536, [0] * 6), (8192, 8, 4096, [0, 1, 0, 0, 0, 0]), (14336, 8, 65536, [0] * 6)):   # (two tables, v = 8: 2 / 3 tokens in one pass where they fit)
         dd = _family_desc(I, 4096, v, 65536, kr)
         assert [supf(dd, exact_layout(dd), t, EX) for t in (1, 2, 4, 5, 8, 9)] == want, (I, v, kr)
         assert supf(dd, exact_layout(dd), 2, EX | B.GEMV_FORCE_GENERIC) == 0
@@ -803,3 +803,8 @@ def test_one_launch_rule_for_two_to_four_tokens():
     for t in (2, 3):
         assert rule(8192, 8192, 8, 256, t, exact=True, slices=16, one_pass=True) and rule(8192, 1024, 8, 0, t, exact=True, slices=16, one_pass=True)
         assert not rule(2048, 8192, 8, 0, t, exact=True, slices=8, one_pass=True) and not rule(8192, 8192, 16, 0, t, exact=True, slices=32, one_pass=True)
+        # two tables of v = 8: large layers with >= 4096 residual centroids (the one-token rule's sizes)
+        assert rule(8192, 8192, 8, 65536, t, exact=True, slices=16, one_pass=True) and rule(8192, 8192, 8, 4096, t, exact=True, slices=16, one_pass=True)
+        assert not rule(8192, 1024, 8, 65536, t, exact=True, slices=16, one_pass=True) and not rule(8192, 8192, 8, 1024, t, exact=True, slices=16, one_pass=True)
+        assert not rule(8192, 8192, 8, 65536, t, exact=True, slices=16, one_pass=False)
+    assert not rule(8192, 8192, 8, 65536, 4, exact=True, slices=16, one_pass=True)

@@ -150,7 +150,7 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
   const SlicedParams P = GP.p[0];   // (host pass of the compiler: never executed)
 #endif
   static_assert(((V == 8 && (NSL == 8 || NSL == 16)) || (V == 16 && (NSL == 16 || NSL == 32))) && (V == 8 || !RES) && !(TWO && RES) &&
-                !(EX && TWO) && (!RG || (EX && !RES && !TWO)) && (TOK == 1 || ((TOK == 2 || TOK == 3) && EX && !RG)), "slices");
+                !(EX && TWO) && (!RG || (EX && !RES && !TWO)) && (TOK == 1 || ((TOK == 2 || TOK == 3) && EX)), "slices");
   constexpr int NSLT = TWO ? 2 * NSL : NSL;   // workgroups per row block: one per (table, slice)
   constexpr int EPL = 1;   // element words per lane and block (2 and 4 - 8 / 16-byte loads - were measured: no difference)
   constexpr uint32_t kEntry = V * 2u;                          // bytes of a codebook entry
@@ -737,10 +737,14 @@ static hipError_t launch_sl(const SlicedGroupParams& P, uint32_t lds, hipStream_
   hipLaunchKernelGGL(kern, dim3(P.start[P.n]), dim3(kSLThreads), lds, st, P);
   return hipGetLastError();
 }
-hipError_t launch_sl_tokens(int dtype, const SlicedGroupParams& P, int v, int nsl, bool res, int tokens, uint32_t lds, hipStream_t st);
+hipError_t launch_sl_tokens(int dtype, const SlicedGroupParams& P, int v, int nsl, bool res, bool rg, int tokens, uint32_t lds, hipStream_t st);
 #if !defined(VPTQ_SL_PART) || VPTQ_SL_PART == 2
 template <typename DT, int TOK>
-static hipError_t launch_sl_tok(const SlicedGroupParams& P, int v, int nsl, bool res, uint32_t lds, hipStream_t st) {
+static hipError_t launch_sl_tok(const SlicedGroupParams& P, int v, int nsl, bool res, bool rg, uint32_t lds, hipStream_t st) {
+  if (rg) {   // (v = 8 only: the gathered residual entries of v = 16 on top of two tokens' sums spill)
+    if (v != 8) return hipErrorInvalidValue;
+    return nsl == 8 ? launch_sl<DT, 8, false, 8, false, true, true, TOK>(P, lds, st) : launch_sl<DT, 16, false, 8, false, true, true, TOK>(P, lds, st);
+  }
   if (v == 16) {   // (3 tokens of 16 outputs: 48 sums + 12 returned words per lane spill - 2 tokens only)
     if constexpr (TOK == 2) return nsl == 16 ? launch_sl<DT, 16, false, 16, false, true, false, TOK>(P, lds, st) : launch_sl<DT, 32, false, 16, false, true, false, TOK>(P, lds, st);
     else return hipErrorInvalidValue;
@@ -748,9 +752,9 @@ static hipError_t launch_sl_tok(const SlicedGroupParams& P, int v, int nsl, bool
   if (nsl == 8) return res ? launch_sl<DT, 8, true, 8, false, true, false, TOK>(P, lds, st) : launch_sl<DT, 8, false, 8, false, true, false, TOK>(P, lds, st);
   return res ? launch_sl<DT, 16, true, 8, false, true, false, TOK>(P, lds, st) : launch_sl<DT, 16, false, 8, false, true, false, TOK>(P, lds, st);
 }
-hipError_t launch_sl_tokens(int dtype, const SlicedGroupParams& P, int v, int nsl, bool res, int tokens, uint32_t lds, hipStream_t st) {
-  if (tokens == 2) return dtype == VPTQ_DTYPE_F16 ? launch_sl_tok<F16, 2>(P, v, nsl, res, lds, st) : launch_sl_tok<BF16, 2>(P, v, nsl, res, lds, st);
-  if (tokens == 3) return dtype == VPTQ_DTYPE_F16 ? launch_sl_tok<F16, 3>(P, v, nsl, res, lds, st) : launch_sl_tok<BF16, 3>(P, v, nsl, res, lds, st);
+hipError_t launch_sl_tokens(int dtype, const SlicedGroupParams& P, int v, int nsl, bool res, bool rg, int tokens, uint32_t lds, hipStream_t st) {
+  if (tokens == 2) return dtype == VPTQ_DTYPE_F16 ? launch_sl_tok<F16, 2>(P, v, nsl, res, rg, lds, st) : launch_sl_tok<BF16, 2>(P, v, nsl, res, rg, lds, st);
+  if (tokens == 3) return dtype == VPTQ_DTYPE_F16 ? launch_sl_tok<F16, 3>(P, v, nsl, res, rg, lds, st) : launch_sl_tok<BF16, 3>(P, v, nsl, res, rg, lds, st);
   return hipErrorInvalidValue;
 }
 #endif
@@ -947,7 +951,7 @@ bool gemv_sliced_groupable(const VptqLayerDesc* d, int n, bool exact) {
 // 2 / 3 tokens in one pass of the exact kernel (TOK): one-table formats whose slice + (2 tokens + 4) bytes per column fit the LDS.
 // Measured (profiles/r05/sliced_exact_tokens_one_pass.txt) where the 16 (v = 16: 32) slice layouts are: wider than ~5000 columns.
 bool gemv_sliced_exact_tokens_ok(const VptqLayerDesc& d, int tokens) {
-  if (tokens < 2 || tokens > (d.vector_len == 16 ? 2 : 3) || !gemv_sliced_eligible(d, true) || sl_two(d)) return false;
+  if (tokens < 2 || tokens > (d.vector_len == 16 ? 2 : 3) || !gemv_sliced_eligible(d, true) || (sl_two(d) && d.vector_len != 8)) return false;
   const int nsl = gemv_sliced_slices(d, true);
   if (nsl == 0) return false;
   return (sl_tab_bytes(d, d.num_centroids, 0, true) + 15u) / 16u * 16u + sl_operand_bytes(d, true, tokens) <= kSLLdsLimit;
@@ -990,7 +994,7 @@ hipError_t launch_gemv_sliced_group(const VptqLayerDesc* d, const VptqSlicedLayo
   for (int i = n; i < kSLMaxGroup; ++i) GP.start[i + 1] = GP.start[n];
   GP.arrivals = nslt * (parts ? n : 1);
   if (GP.arrivals > 127) return hipErrorInvalidValue;   // (7 bits of the accumulator word count them)
-  if (tokens != 1) return launch_sl_tokens(d[0].dtype, GP, d[0].vector_len, nsl, sl_res256(d[0]), tokens, lds, st);
+  if (tokens != 1) return launch_sl_tokens(d[0].dtype, GP, d[0].vector_len, nsl, sl_res256(d[0]), sl_two(d[0]), tokens, lds, st);
   return d[0].dtype == VPTQ_DTYPE_F16
              ? launch_sl_dt<F16>(GP, d[0].vector_len, nsl, sl_res256(d[0]), sl_two(d[0]), exact, lds, st)
              : launch_sl_dt<BF16>(GP, d[0].vector_len, nsl, sl_res256(d[0]), sl_two(d[0]), exact, lds, st);   // (exact && two = RG)

@@ -840,7 +840,7 @@ static size_t st_partial_bytes_max(const VptqLayerDesc& d, int tokens) {
 }
 // ... and, in front of the partial sums (a fixed place whatever the token count), the accumulator words of the ONE-PASS route:
 // 2 / 3 tokens in the reference's roundings through the one-token kernel (gemv_sliced.hip, TOK), zero between launches
-static size_t st_acc_bytes(const VptqLayerDesc& d) { return st_exact_ok(d) ? gemv_sliced_exact_tokens_workspace_bytes(d, 3) : 0; }
+static size_t st_acc_bytes(const VptqLayerDesc& d) { return gemv_sliced_eligible(d, true) ? gemv_sliced_exact_tokens_workspace_bytes(d, 3) : 0; }
 size_t gemv_sliced_tok_workspace_bytes(const VptqLayerDesc& d, int tokens) {
   return st_counter_bytes(d) + st_acc_bytes(d) + st_partial_bytes_max(d, tokens) + st_perm_bytes(d, tokens);
 }
@@ -899,9 +899,11 @@ static bool st_plan(const VptqLayerDesc& d, const VptqSlicedLayout* L, int token
 
 bool gemv_sliced_tok_eligible(const VptqLayerDesc& d, const VptqSlicedLayout* L, int tokens, bool exact) {
   StPlan pl;
-  if (!(exact ? st_exact_ok(d) : gemv_sliced_eligible(d)) || !L) return false;
+  if (!L) return false;
+  // (ONE pass of the one-token kernel: also the two-table formats of v = 8, their residual entries gathered once for all tokens)
+  if (st_one_pass(d, tokens, exact)) return L[0].n_slices == gemv_sliced_slices(d, true) && (!sl_two(d) || L[0].res);   // (no column windows needed)
+  if (!(exact ? st_exact_ok(d) : gemv_sliced_eligible(d))) return false;
   const int n = exact ? 1 : gemv_sliced_tables(d);
-  if (st_one_pass(d, tokens, exact)) return L[0].n_slices == gemv_sliced_slices(d, true);   // (no column windows needed)
   for (int i = 0; i < n; ++i)
     if (!L[i].wstart || L[i].n_slices != gemv_sliced_slices(d, exact)) return false;   // (the arithmetic's own slice count)
   return st_plan(d, L, tokens, exact, pl);

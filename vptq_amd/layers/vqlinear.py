@@ -557,9 +557,15 @@ class VQuantLinear(nn.Module):
                 # gather -> one pass, 2 / 3 tokens): 8192^2 42.1 / 44.9 -> 25.1 / 28.3; 8192 x 28672 149 / 147 -> 62 / 76; 8192 x 1024 13.0 / 18.0
                 # -> 11.0 / 12.9 (k65536-0: 41.3 / 42.2 -> 22.2 / 25.9, 134 / 135 -> 53 / 66); narrow layers that fit with 8 slices: parity
                 # (2048 x 8192: 13.5 / 16.0 -> 13.5 / 15.5), v = 16: slower (8192^2 28.6 -> 30.3) - both stay on the gather kernel
+                # two tables (v8-k65536-65536, -4096: the residual entries gathered from L2 ONCE for all tokens; profiles/r05/
+                # sliced_exact_tokens_one_pass.txt): 8192^2 77.8 -> 61.5 / 63.4, 8192 x 28672 255 -> 202 / 206, kr = 4096: 68 -> 53 / 54; small
+                # layers lose (8192 x 1024: 18.8 -> 21.1): the one-token rule's sizes
                 n_el = self.indices.shape[1] * self.group_size
+                kr = self.num_res_centroids if self.enable_residual else 0
                 if self.vector_len != 8 or sl.slices < 16:
                     ok = False
+                elif kr not in (0, 256):
+                    ok = tokens <= 3 and kr >= 4096 and n_el >= _SLICED_EXACT_RG_MIN_ELEMENTS and sl.tokens_one_pass(tokens)
                 elif tokens <= 3 and sl.tokens_one_pass(tokens):
                     ok = True
                 else:

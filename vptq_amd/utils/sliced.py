@@ -272,14 +272,16 @@ class SlicedGemv:
     def tokens_supported(self, tokens: int) -> bool:
         """does the library's kernel for 2 - 4 tokens over these layouts take this layer (its activations must fit the LDS
         beside the slice in at most 4 column phases)?"""
-        if self.exact and (self._side16 or self.parts > 1):   # (the reference's roundings over two-table formats / column parts: one token only)
+        if self.exact and self.parts > 1:    # (column parts: one token only)
             return False
+        if self.exact and self._side16:      # (the reference's roundings over two-table formats: 2 / 3 tokens in one pass, nothing else)
+            return self.tokens_one_pass(tokens)
         return bool(B.lib().vptq_quant_gemv_sliced_tokens_supported_for(self.desc, self._lay_ref, int(tokens), self._flags))
 
     def tokens_one_pass(self, tokens: int) -> bool:
         """(reference roundings) does the library take these 2 / 3 tokens in ONE PASS of the one-token kernel (gemv_sliced.hip, TOK:
         slice + (2 tokens + 4) bytes per column fit the LDS) - the route that needs no column windows?"""
-        if not self.exact or self._side16 or self.parts > 1 or not 2 <= tokens <= 3:
+        if not self.exact or self.parts > 1 or not 2 <= tokens <= 3:
             return False
         key = ("_one_pass", tokens)
         ok = self.__dict__.get(key)
@@ -297,7 +299,7 @@ class SlicedGemv:
         tokens = x.numel() // lay.in_features
         if x.shape[-1] != lay.in_features or not 2 <= tokens <= 8:
             raise ValueError("forward_tokens takes 2 - 8 tokens of in_features values")
-        if self.exact and (self._side16 or self.parts > 1):
+        if self.exact and (self.parts > 1 or (self._side16 and not self.tokens_one_pass(tokens))):
             return None
         if x.dtype != self._dtype or x.device != self.dev:
             x = lay._check_activation(x)
@@ -430,7 +432,7 @@ class SlicedGroupGemv:
         tokens = x.numel() // lay.in_features
         if x.shape[-1] != lay.in_features or not 2 <= tokens <= 8:
             raise ValueError("forward_tokens takes 2 - 8 tokens of in_features values")
-        if self.exact and self._side16:
+        if self.exact and self._side16 and not all(m.tokens_one_pass(tokens) for m in self.members):
             return None
         if x.dtype != self._dtype or x.device != self.dev:
             x = lay._check_activation(x)
