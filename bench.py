@@ -219,7 +219,83 @@ def k65536_extra(lib, B, dev, H, steps, warmup, regions, R=8, kr=256, v=8):
         row["rel_diff"] = ((got.float() - yt[-1].float()).abs().max() / yt[-1].float().abs().max()).item()
         assert row["rel_diff"] <= 2e-3, row     # (both within 1e-3 of the reference)
         out[f"tokens{tokens}"] = row
-    del layers, sls
+    # round 5: 2 and 3 tokens in the reference's roundings - the gather kernel (VPTQ_GEMV_EXACT) against ONE PASS of the exact sliced
+    # kernel over the exact layout (gemv_sliced<EX, TOK>: every token's activations beside the slice, the weight rebuilt once; two
+    # tables of v = 8: the residual entries gathered once) - what VQuantLinear.forward takes for these layers in the default arithmetic
+    try:
+        for tokens in (2, 3):
+            if not sxs or not all(sx.tokens_one_pass(tokens) for sx in sxs):
+                continue
+            xt = torch.randn(1, tokens, H, device=dev, generator=torch.Generator(device=dev).manual_seed(9)).half()
+            yt = [torch.empty(1, tokens, H, device=dev, dtype=torch.float16) for _ in range(R)]
+
+            def gather_exact_pass():
+                sp = torch.cuda.current_stream().cuda_stream
+                for i in range(R):
+                    rc = lib.vptq_quant_gemv(descs[i][0], xt.data_ptr(), yt[i].data_ptr(), tokens, B.GEMV_EXACT, None, 0, sp)
+                    assert rc == 0, lib.vptq_last_error()
+
+            def one_pass():
+                for i in range(R):
+                    assert sxs[i].forward_tokens(xt, yt[i]) is not None
+            one_pass()
+            torch.cuda.synchronize()
+            got = yt[-1].clone()
+            row = {"kernel": f"gemv_sliced_kernel<EX, TOK = {tokens}>"}
+            for key, fn in (("default", gather_exact_pass), ("exact_sliced_one_pass", one_pass)):
+                t = Timer(dev).run(fn, steps, warmup, regions)
+                row[key + "_us_per_layer"] = t["event_ms"] * 1e3 / (steps * R)
+            gather_exact_pass()
+            torch.cuda.synchronize()
+            row["bit_identical_to_default"] = float((got.view(torch.int16) == yt[-1].view(torch.int16)).float().mean())
+            assert row["bit_identical_to_default"] >= 0.95, row
+            out[f"exact_tokens{tokens}"] = row
+    except Exception as e:   # (an extra of an extra)
+        out["exact_tokens_error"] = f"{type(e).__name__}: {e}"[:300]
+    del layers, sls, sxs
+    torch.cuda.empty_cache()
+    return out
+
+
+def wide_layer_extra(lib, B, dev, steps, warmup, regions, I=28672, O=8192, R=4, kr=256):
+    """a layer too wide for the reference's roundings in one piece (28672 columns: the down projections of the 70B class), one
+    token: the gather kernel against the exact sliced kernel over COLUMN PARTS (2 x 14336 columns, one grouped launch, shared
+    accumulator words: VPTQ_GEMV_COLUMN_PARTS) - what VQuantLinear.forward takes for it in the default arithmetic (round 5)"""
+    from vptq_amd.utils.sliced import SlicedGemv
+    g = torch.Generator(device=dev).manual_seed(4322)
+    layers = [make_layer(I, O, dev, g, 65536, kr) for _ in range(R)]
+    x = torch.randn(1, 1, I, device=dev, generator=torch.Generator(device=dev).manual_seed(10)).half()
+    ys = [torch.empty(1, 1, O, device=dev, dtype=torch.float16) for _ in range(R)]
+    descs = [layer_desc(m) for m in layers]
+    sxs = [SlicedGemv(m, exact=True) for m in layers]
+
+    def default_pass():
+        sp = torch.cuda.current_stream().cuda_stream
+        for i in range(R):
+            rc = lib.vptq_quant_gemv(descs[i][0], x.data_ptr(), ys[i].data_ptr(), 1, B.GEMV_EXACT, None, 0, sp)
+            assert rc == 0, lib.vptq_last_error()
+
+    def parts_pass():
+        for i in range(R):
+            assert sxs[i](x, ys[i]) is not None
+    T = 16 + (int(np.log2(kr)) if kr else 0)
+    ab = (O // 8) * ((I * T + 31) // 32) * 4 + (65536 + kr) * 8 * 2 + 2 * I + 4 * I + 2 * O
+    out = {"what": f"VQuantLinear {I}x{O} v=8 k=65536+{kr}, ring of {R} layers, one token, reference roundings; GB/s of the PACKED format's algorithmic bytes",
+           "column_parts": sxs[0].parts, "slices": sxs[0].slices}
+    parts_pass()
+    torch.cuda.synchronize()
+    got = ys[-1].clone()
+    for key, fn in (("default", default_pass), ("exact_sliced_column_parts", parts_pass)):
+        t = Timer(dev).run(fn, steps, warmup, regions)
+        us = t["event_ms"] * 1e3 / (steps * R)
+        out[key] = {"us_per_layer": us, "GBps": ab / us / 1e3, "frac_of_8TBps": ab / us / 1e3 / 8000.0}
+    out["default"]["kernel"] = lib.vptq_quant_gemv_kernel_name(descs[0][0], 1, B.GEMV_EXACT).decode()
+    out["exact_sliced_column_parts"]["kernel"] = "gemv_sliced_kernel<EX>"
+    default_pass()
+    torch.cuda.synchronize()
+    out["bit_identical_to_default"] = float((got.view(torch.int16) == ys[-1].view(torch.int16)).float().mean())
+    assert out["bit_identical_to_default"] >= 0.95, out
+    del layers, sxs
     torch.cuda.empty_cache()
     return out
 
@@ -1120,6 +1196,11 @@ def main():
             except Exception as e:
                 ex[key] = {"error": f"{type(e).__name__}: {e}"[:300]}
                 torch.cuda.empty_cache()
+        try:   # (the headline line must not depend on an extra)
+            ex["k65536_r256_28672x8192"] = wide_layer_extra(lib, B, dev, st, wu, rg)
+        except Exception as e:
+            ex["k65536_r256_28672x8192"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            torch.cuda.empty_cache()
         try:
             tr = bench_tp_row(lib, B, dev, Timer(dev), 0, 1, a.tp_layers, EX, st, wu, rg)
             ex["tp_row_n1"] = {"what": f"Llama-3-70B shaped decoder layers (x{a.tp_layers}, the ring of --gpus N) on ONE GPU "
