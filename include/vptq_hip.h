@@ -354,6 +354,11 @@ VPTQ_API int vptq_quant_gemv_sliced(const VptqLayerDesc* desc, const VptqSlicedL
  * needed; accumulator words behind the arrival counters of the same workspace). */
 VPTQ_API int vptq_quant_gemv_sliced_tokens_supported(const VptqLayerDesc* desc, const VptqSlicedLayout* layout, int tokens);
 VPTQ_API int vptq_quant_gemv_sliced_tokens_supported_for(const VptqLayerDesc* desc, const VptqSlicedLayout* layout, int tokens, int flags);
+/* 0, or in how many WINDOW PARTS vptq_quant_gemv_sliced_tokens(..., flags) takes these tokens in ONE PASS of the one-token kernel (ABI >= 9,
+ * flags | VPTQ_GEMV_EXACT, 2 / 3 tokens): 1 = every column's operands fit beside the slice (no `wstart` needed); 2 / 4 = v = 8 one-table layers
+ * whose slice leaves room for half / a quarter of the columns (4096 columns beside a 128 KiB slice, 14336 beside 64 KiB): that many workgroups
+ * per (slice, row block), each staging its column windows alone and walking their part of every list (`wstart` needed) */
+VPTQ_API int vptq_quant_gemv_sliced_tokens_one_pass(const VptqLayerDesc* desc, int tokens, int flags);
 VPTQ_API size_t vptq_quant_gemv_sliced_tokens_workspace_bytes(const VptqLayerDesc* desc, int tokens);
 VPTQ_API int vptq_quant_gemv_sliced_tokens(const VptqLayerDesc* desc, const VptqSlicedLayout* layout, const void* x, void* y,
                                   int tokens, int flags, void* workspace, size_t workspace_bytes, void* stream);

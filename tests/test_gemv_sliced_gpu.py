@@ -854,20 +854,40 @@ def test_module_default_route_for_two_to_four_tokens_of_wide_layers(dev, monkeyp
         ms(x2[:, :1].contiguous())
         s2 = ms.__dict__["_sliced"][1]
         assert s2 is not None and s2.exact and s2.tokens_supported(3) and ms._sliced_one_launch(s2, 2) == one and ms._sliced_token_limit(s2) == 1
+        assert s2.tokens_window_parts(2) == (1 if I in (8192, 2048) else 2)
         assert torch.equal(ms(x2).view(torch.int16), (s2.forward_tokens(x2) if one else gemv_abi(ms, x2, EXACT)).view(torch.int16))
         assert rel_err(tensor_to_bits(ms(x2)), vo.forward(Ls, tensor_to_bits(x2)), "f16") <= 1e-3
-    # a LARGE 14336-column layer: 2 tokens = two launches of the one-token kernel, 3 tokens = the column-phase kernel
+    # a LARGE 14336-column layer: 2 / 3 tokens in one pass in two WINDOW PARTS (half of the columns' operands fit beside the slice);
+    # 4 tokens: the column-phase kernel.  With the window parts switched off in the rule's eyes: two launches for 2 tokens
     Lw = vo.make_layer(14336, 3584, dist="llm", seed=73, num_centroids=65536, num_res_centroids=256)
     mw = spec_to_module(Lw, dev)
-    xw = bits_to_tensor(np.concatenate([_x(14336, "f16", "llm", 50 + i) for i in range(3)], axis=1), "f16", dev).reshape(1, 3, 14336)
+    xw = bits_to_tensor(np.concatenate([_x(14336, "f16", "llm", 50 + i) for i in range(4)], axis=1), "f16", dev).reshape(1, 4, 14336)
     mw(xw[:, :1].contiguous())
     sw = mw.__dict__["_sliced"][1]
-    assert sw is not None and sw.exact and not sw.tokens_one_pass(2) and mw._sliced_token_limit(sw) == 2
-    assert not mw._sliced_one_launch(sw, 2) and mw._sliced_one_launch(sw, 3)
-    yw = mw(xw[:, :2].contiguous())
-    assert all(torch.equal(yw[:, t].reshape(-1).view(torch.int16), sw(xw[:, t:t + 1].contiguous()).reshape(-1).view(torch.int16)) for t in range(2))
-    assert torch.equal(mw(xw).view(torch.int16), sw.forward_tokens(xw).view(torch.int16))
-    assert rel_err(tensor_to_bits(mw(xw)), vo.forward(Lw, tensor_to_bits(xw)), "f16") <= 1e-3
+    assert sw is not None and sw.exact and sw.tokens_window_parts(2) == 2 and sw.tokens_window_parts(3) == 2 and mw._sliced_token_limit(sw) == 2
+    assert mw._sliced_one_launch(sw, 2) and mw._sliced_one_launch(sw, 3) and mw._sliced_one_launch(sw, 4)
+    ww = vo.forward(Lw, tensor_to_bits(xw))
+    for T in (2, 3, 4):
+        x = xw[:, :T].contiguous()
+        y = mw(x)
+        assert torch.equal(y.view(torch.int16), sw.forward_tokens(x).view(torch.int16))
+        yb = tensor_to_bits(y)
+        assert rel_err(yb, ww[:, :T], "f16") <= 1e-3 and float((yb.reshape(-1) == np.asarray(ww[:, :T]).reshape(-1)).mean()) >= 0.95
+    for T in (2, 3):   # (the one-token kernel over the same layout: the same weights; a row's sum is formed in two parts here)
+        y = mw(xw[:, :T].contiguous())
+        assert all(float((y[:, t].reshape(-1).view(torch.int16) == sw(xw[:, t:t + 1].contiguous()).reshape(-1).view(torch.int16)).float().mean()) >= 0.95
+                   for t in range(T))
+    # a 4096-column layer of that size (8 slices of 128 KiB): window parts too; a small one: the gather kernel
+    Lg = vo.make_layer(4096, 12288, dist="llm", seed=75, num_centroids=65536, num_res_centroids=0, enable_perm=True)
+    mg = spec_to_module(Lg, dev)
+    xg = bits_to_tensor(np.concatenate([_x(4096, "f16", "llm", 60 + i) for i in range(3)], axis=1), "f16", dev).reshape(1, 3, 4096)
+    mg(xg[:, :1].contiguous())
+    sg = mg.__dict__["_sliced"][1]
+    assert sg is not None and sg.exact and sg.slices == 8 and sg.tokens_window_parts(3) == 2 and mg._sliced_one_launch(sg, 3)
+    yg = mg(xg)
+    assert torch.equal(yg.view(torch.int16), sg.forward_tokens(xg).view(torch.int16))
+    wg = vo.forward(Lg, tensor_to_bits(xg))
+    assert rel_err(tensor_to_bits(yg), wg, "f16") <= 1e-3 and float((tensor_to_bits(yg).reshape(-1) == np.asarray(wg).reshape(-1)).mean()) >= 0.95
     # a two-table format of v = 8 ("4 bit"): 2 / 3 tokens in one pass as well - the residual entries are gathered from L2 once
     L4 = vo.make_layer(8192, 2048, dist="llm", seed=74, num_centroids=65536, num_res_centroids=65536)
     m4 = spec_to_module(L4, dev)

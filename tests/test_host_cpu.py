@@ -784,7 +784,8 @@ def test_one_launch_rule_for_two_to_four_tokens():
                 return supported
         sl = SL()
         sl.exact, sl.slices = exact, slices
-        sl.tokens_one_pass = lambda t: one_pass
+        sl.tokens_one_pass = lambda t: bool(one_pass)
+        sl.tokens_window_parts = lambda t: int(one_pass)
         return VQuantLinear._sliced_one_launch(layer(I, O, v, kr), sl, tokens)
     for t in (2, 3, 4):
         assert rule(8192, 8192, 8, 0, t) and rule(4096, 4096, 8, 256, t) and rule(4096, 14336, 8, 65536, t) and rule(8192, 8192, 16, 0, t)
@@ -808,3 +809,7 @@ def test_one_launch_rule_for_two_to_four_tokens():
         assert not rule(8192, 1024, 8, 65536, t, exact=True, slices=16, one_pass=True) and not rule(8192, 8192, 8, 1024, t, exact=True, slices=16, one_pass=True)
         assert not rule(8192, 8192, 8, 65536, t, exact=True, slices=16, one_pass=False)
     assert not rule(8192, 8192, 8, 65536, 4, exact=True, slices=16, one_pass=True)
+    # ... and in WINDOW PARTS (the library's answer 2 / 4: half / a quarter of the columns staged per workgroup) on layers of >= 6 M index elements
+    for t in (2, 3):
+        assert rule(14336, 4096, 8, 256, t, exact=True, slices=16, one_pass=2) and rule(4096, 14336, 8, 0, t, exact=True, slices=8, one_pass=2)
+        assert not rule(4096, 4096, 8, 0, t, exact=True, slices=8, one_pass=2) and not rule(14336, 512, 8, 0, t, exact=True, slices=16, one_pass=2)

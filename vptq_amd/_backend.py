@@ -91,6 +91,7 @@ EXPORTS = {
                                          C.c_size_t, _vp]),
     "vptq_quant_gemv_sliced_tokens_supported": (C.c_int, [C.POINTER(LayerDesc), C.POINTER(SlicedLayout), C.c_int]),
     "vptq_quant_gemv_sliced_tokens_supported_for": (C.c_int, [C.POINTER(LayerDesc), C.POINTER(SlicedLayout), C.c_int, C.c_int]),
+    "vptq_quant_gemv_sliced_tokens_one_pass": (C.c_int, [C.POINTER(LayerDesc), C.c_int, C.c_int]),
     "vptq_quant_gemv_sliced_tokens_workspace_bytes": (C.c_size_t, [C.POINTER(LayerDesc), C.c_int]),
     "vptq_quant_gemv_sliced_tokens": (C.c_int, [C.POINTER(LayerDesc), C.POINTER(SlicedLayout), _vp, _vp, C.c_int, C.c_int, _vp,
                                                 C.c_size_t, _vp]),

@@ -525,6 +525,11 @@ int vptq_quant_gemv_sliced_tokens_supported_for(const VptqLayerDesc* d, const Vp
   return validate_layer(d) == VPTQ_OK && layout && vptq::gemv_sliced_tok_eligible(*d, layout, tokens, (flags & VPTQ_GEMV_EXACT) != 0) ? 1 : 0;
 }
 
+int vptq_quant_gemv_sliced_tokens_one_pass(const VptqLayerDesc* d, int tokens, int flags) {
+  if (validate_layer(d) != VPTQ_OK || (flags & ~(VPTQ_GEMV_EXACT | VPTQ_GEMV_OUT_F32))) return 0;
+  return vptq::gemv_sliced_tok_one_pass_parts(*d, tokens, (flags & VPTQ_GEMV_EXACT) != 0);
+}
+
 size_t vptq_quant_gemv_sliced_tokens_workspace_bytes(const VptqLayerDesc* d, int tokens) {
   return validate_layer(d) == VPTQ_OK && (vptq::gemv_sliced_eligible(*d) || vptq::gemv_sliced_eligible(*d, true)) && tokens >= 2 && tokens <= 8
              ? vptq::gemv_sliced_tok_workspace_bytes(*d, tokens) : 0;

@@ -132,7 +132,12 @@ struct SlicedGroupParams {
 // paid once).  x [TOK][x_stride], y [TOK][y_stride], accumulator words [TOK][acc_stride]; LDS: tokens 0 and 1 interleaved per
 // column (one 32-bit gather), token 2 a plane of its own: 2 TOK + 4 bytes per column - layers whose exact layout has 16 (v = 16:
 // 32) slices, up to ~12000 (2 tokens) / ~9700 (3) columns.  More tokens: gemv_sliced_tok.hip (column phases, matrix pipe).
-template <typename DT, int NSL, bool RES, int V = 8, bool TWO = false, bool EX = false, bool RG = false, int TOK = 1>
+// WPT (TOK > 1): WINDOW PARTS - where the slice leaves no room for (2 tokens + 4) bytes of EVERY column (4096 columns beside a 128 KiB
+// slice, 14336 beside 64 KiB), a workgroup takes only some of the layout's four column windows (P.wparts = 2 or 4 workgroups per
+// (slice, row block)): it stages those columns alone and walks, row by row, the blocks that hold its windows' part of the list
+// (`wstart`; blocks do not end where windows do - an element of another window reads the zero column, as the padding does).  The
+// parts meet in the outputs' accumulator words like slices do: slices x parts arrivals.
+template <typename DT, int NSL, bool RES, int V = 8, bool TWO = false, bool EX = false, bool RG = false, int TOK = 1, bool WPT = false>
 __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGroupParams GP) {
   // this workgroup's layer; its parameters come out of the kernel-argument segment through the scalar cache (a run-time
   // index into the by-value argument would make the compiler copy it to scratch memory)
@@ -150,7 +155,7 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
   const SlicedParams P = GP.p[0];   // (host pass of the compiler: never executed)
 #endif
   static_assert(((V == 8 && (NSL == 8 || NSL == 16)) || (V == 16 && (NSL == 16 || NSL == 32))) && (V == 8 || !RES) && !(TWO && RES) &&
-                !(EX && TWO) && (!RG || (EX && !RES && !TWO)) && (TOK == 1 || ((TOK == 2 || TOK == 3) && EX)), "slices");
+                !(EX && TWO) && (!RG || (EX && !RES && !TWO)) && (TOK == 1 || ((TOK == 2 || TOK == 3) && EX)) && (!WPT || (TOK > 1 && !RG)), "slices");
   constexpr int NSLT = TWO ? 2 * NSL : NSL;   // workgroups per row block: one per (table, slice)
   constexpr int EPL = 1;   // element words per lane and block (2 and 4 - 8 / 16-byte loads - were measured: no difference)
   constexpr uint32_t kEntry = V * 2u;                          // bytes of a codebook entry
@@ -167,14 +172,24 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
   }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int sg = bx & (NSLT - 1), rb = bx / NSLT;
+  // (WPT: the window part varies fastest, then the slice)
+  const int wparts = WPT ? P.wparts : 1;
+  const int wp = WPT ? bx & (wparts - 1) : 0;
+  const int bxs = WPT ? bx / wparts : bx;
+  const int sg = bxs & (NSLT - 1), rb = bxs / NSLT;
   const int s = sg & (NSL - 1);
   const bool second = TWO && sg >= NSL;   // (uniform over the workgroup) this workgroup gathers from the residual table
   const uint32_t* const elems_t = second ? P.elems2 : P.elems;
   const int32_t* const blocks_t = second ? P.blocks2 : P.blocks;
   const int32_t* const first_t = second ? P.first2 : P.first;
   const uint32_t* const cent_t = second ? P.cent2 : P.cent;
-  const int N = P.N, G = P.G;
+  const int N = P.N;
+  // WPT: this workgroup's columns [c0, c0 + G) = its windows; G = what is staged (the other kernels: all columns, c0 = 0)
+  const int wper = WPT ? kSLWindows / wparts : 0;                                 // layout windows per part
+  const int c0 = WPT ? (wp * wper * P.wcols < P.G ? wp * wper * P.wcols : P.G) : 0;
+  const int c1 = WPT ? ((wp == wparts - 1 || (wp + 1) * wper * P.wcols > P.G) ? P.G : (wp + 1) * wper * P.wcols) : P.G;
+  const int G = c1 - c0;
+  const int GS = WPT ? P.wstage : P.G;                                            // columns the LDS map is laid out for
   const int rpw = P.rows_per_wave;
   const int row0 = (rb * kSLWaves + wave) * rpw;   // this wave's first row
   const int n_rows = row0 >= N ? 0 : (N - row0 < rpw ? N - row0 : rpw);
@@ -209,9 +224,9 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
   // residual codebook (256 entries = 4 KiB) behind the activations: waves 0-3 bring 1 KiB each
   // LDS behind the table: [G + 64 halves: f16(s x), EX: x] [EX: G + 64 words {s, b}] [16 floats: sum b x parts] [RES: 4 KiB]
   // (TOK > 1: [G + 64 words: tokens 0 | 1] [TOK = 3: G + 64 halves: token 2] in front of the {s, b} words)
-  [[maybe_unused]] const uint32_t x2_off = kSLXOff + (uint32_t)(G + 64) * 4u;
-  const uint32_t sb_off = kSLXOff + (uint32_t)(G + 64) * 2u * (uint32_t)TOK;     // (EX) scale | bias << 16 per column
-  const uint32_t bd_off = sb_off + (EX ? (uint32_t)(G + 64) * 4u : 0u);          // 16 floats behind the staged operands
+  [[maybe_unused]] const uint32_t x2_off = kSLXOff + (uint32_t)(GS + 64) * 4u;
+  const uint32_t sb_off = kSLXOff + (uint32_t)(GS + 64) * 2u * (uint32_t)TOK;    // (EX) scale | bias << 16 per column
+  const uint32_t bd_off = sb_off + (EX ? (uint32_t)(GS + 64) * 4u : 0u);         // 16 floats behind the staged operands
   const uint32_t res_off = bd_off + 64u;
   if constexpr (RES) {
     if (wave < 4) {
@@ -225,6 +240,11 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
   // (2) staging loads of the first kSLPre rounds of the staging loop (16376 columns: every layer of the published
   // families); a permutation makes the activation loads depend on its own load (layers that keep one pay that wait here)
   const int chunks = G >> 3;
+  // (column-order tensors from this workgroup's first column on: c0 = 0 unless WPT)
+  const uint16_t* const scale_c = as_global(P.scale) + c0;
+  const uint16_t* const xcol = as_global(P.x) + c0;
+  const uint16_t* const perm_c = P.perm != nullptr ? as_global(P.perm) + c0 : nullptr;
+  const uint16_t* const cbias_c = EX ? as_global(P.cbias) + c0 : nullptr;
   constexpr int kSLPre = 2;
   struct XT { u32x4 v[TOK]; };   // a chunk's activations, one vector per token ([0] = the permutation's words where there is one)
   XT st_x[kSLPre];
@@ -236,19 +256,31 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
 #pragma unroll
     for (int t = 0; t < TOK; ++t) st_x[r].v[t] = u32x4{0u, 0u, 0u, 0u};
     if (q < chunks && !(VPTQ_SLICED_ABLATE & 4)) {
-      st_s[r] = *(const u32x4*)(as_global(P.scale) + 8 * q);
+      st_s[r] = *(const u32x4*)(scale_c + 8 * q);
       if (P.perm == nullptr) {
 #pragma unroll
-        for (int t = 0; t < TOK; ++t) st_x[r].v[t] = *(const u32x4*)(as_global(P.x) + (size_t)t * P.x_stride + 8 * q);
+        for (int t = 0; t < TOK; ++t) st_x[r].v[t] = *(const u32x4*)(xcol + (size_t)t * P.x_stride + 8 * q);
       }
-      else st_x[r].v[0] = *(const u32x4*)(as_global(P.perm) + 8 * q);   // (the permutation's words: resolved in (5))
-      if constexpr (EX) st_b[r] = *(const u32x4*)(as_global(P.cbias) + 8 * q);
+      else st_x[r].v[0] = *(const u32x4*)(perm_c + 8 * q);   // (the permutation's words: resolved in (5))
+      if constexpr (EX) st_b[r] = *(const u32x4*)(cbias_c + 8 * q);
       else if (sg == 0 && P.wbias != nullptr) st_b[r] = *(const u32x4*)(as_global(P.wbias) + 8 * q);
     }
   }
   // ... and the rows' block counts (lane i: blocks of row row0 + i; read after the barrier)
   int my_blocks = 0;
-  if (n_rows > 0 && lane < n_rows) my_blocks = (as_global(blocks_t) + (size_t)s * N + row0)[lane];
+  [[maybe_unused]] int seg_first = 0;   // (WPT) lane i: the first block of row row0 + i that holds elements of this workgroup's windows
+  if constexpr (WPT) {
+    // the windows' part of a (slice, row) list = positions [wstart[w0], wstart[w1]) of it: the blocks that overlap them
+    if (n_rows > 0 && lane < n_rows) {
+      const size_t li = (size_t)s * N + row0 + lane;
+      const int32_t* const wsp = as_global(P.wstart) + li * (kSLWindows + 1);
+      const int ws = wsp[wp * wper], we = wsp[(wp + 1) * wper];
+      my_blocks = we > ws ? ((we + 63) >> 6) - (ws >> 6) : 0;
+      seg_first = as_global(first_t)[li] + (ws >> 6);
+    }
+  } else {
+    if (n_rows > 0 && lane < n_rows) my_blocks = (as_global(blocks_t) + (size_t)s * N + row0)[lane];
+  }
   // activations: f16(scale * x) of every column, zero for the padding column G; the workgroups of slice 0 also form
   // sum b x (it rides in their partial sums)
   typedef __attribute__((address_space(3))) u32x4 lds_q_t;
@@ -336,15 +368,15 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
 #pragma unroll
     for (int t = 0; t < TOK; ++t) xv.v[t] = u32x4{0u, 0u, 0u, 0u};
     if (q < chunks && !(VPTQ_SLICED_ABLATE & 4)) {
-      sv = *(const u32x4*)(as_global(P.scale) + 8 * q);
-      xv.v[0] = *(const u32x4*)(as_global(P.perm != nullptr ? P.perm : P.x) + 8 * q);
+      sv = *(const u32x4*)(scale_c + 8 * q);
+      xv.v[0] = *(const u32x4*)((P.perm != nullptr ? perm_c : xcol) + 8 * q);
       if constexpr (TOK > 1) {
         if (P.perm == nullptr) {
 #pragma unroll
-          for (int t = 1; t < TOK; ++t) xv.v[t] = *(const u32x4*)(as_global(P.x) + (size_t)t * P.x_stride + 8 * q);
+          for (int t = 1; t < TOK; ++t) xv.v[t] = *(const u32x4*)(xcol + (size_t)t * P.x_stride + 8 * q);
         }
       }
-      if constexpr (EX) bv = *(const u32x4*)(as_global(P.cbias) + 8 * q);
+      if constexpr (EX) bv = *(const u32x4*)(cbias_c + 8 * q);
       else if (sg == 0 && P.wbias != nullptr) bv = *(const u32x4*)(as_global(P.wbias) + 8 * q);
     }
     stage(q, xv, sv, bv, P.perm != nullptr);
@@ -353,7 +385,12 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
   // so its next entry behind the wave's rows ends the stream (the last wave of the last slice has no such entry: it adds its
   // block counts up)
   int total = 0, first_block = 0;
-  if (n_rows > 0) {
+  if constexpr (WPT) {   // (the rows' parts are not contiguous: the stream is walked row by row, its length is the sum)
+    int t = my_blocks;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+    total = __builtin_amdgcn_readfirstlane(t);
+  } else if (n_rows > 0) {
     typedef const int32_t __attribute__((address_space(4)))* sl_const_i32_t;   // uniform + constant address space = scalar loads
     const size_t at = (size_t)s * N + row0;
     const sl_const_i32_t fp = (sl_const_i32_t)(uintptr_t)as_global(first_t);
@@ -374,7 +411,7 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
   // (a wave without blocks still issues its counted loads: of block 0 of the layout, which always exists - behind the last
   // list there is nothing to read, and a residual index picked up there would send the second stage's gather anywhere:
   // found by tools/gpu_fuzz.py --sliced with every element in one slice, round 5)
-  const size_t fb = total > 0 ? (size_t)first_block : 0;
+  const size_t fb = (!WPT && total > 0) ? (size_t)first_block : 0;   // (WPT: absolute block indices)
   // (wave-uniform base + the lane's 32-bit byte offset: the scalar-base addressing form - no 64-bit vector add per load)
   const char* const ep = (const char*)(as_global(elems_t) + fb * (64 * EPL));
   const char* const rp = (RES || RG) ? (const char*)as_global(P.res) + fb * 64 * (RG ? 2 : 1) : nullptr;
@@ -383,8 +420,38 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
   int i_next = 0;
   // (past the end of the stream a step still issues its load - every step the same instructions, so the waits
   // stay counted - of the last block again; one cached word for all lanes instead was measured slower)
+  // WPT: the issue side's place in the stream - row, blocks left in its part, block (x 64) - as scalars; past the end the last block
+  // again (stride 0), as above
+  [[maybe_unused]] int iq_row = 0, iq_left = 0x7fffffff, iq_stride = 0;
+  [[maybe_unused]] size_t iq_b64 = 0;
+  [[maybe_unused]] auto iq_find = [&]() __attribute__((always_inline)) {   // the next row (from iq_row on) with blocks
+    while (iq_row < n_rows) {
+      const int c = __builtin_amdgcn_readlane(my_blocks, iq_row);
+      if (c != 0) {
+        iq_left = c;
+        iq_b64 = (size_t)__builtin_amdgcn_readlane(seg_first, iq_row) * 64;
+        iq_stride = 64;
+        return;
+      }
+      ++iq_row;
+    }
+    iq_left = 0x7fffffff;
+    iq_stride = 0;
+  };
+  if constexpr (WPT) iq_find();
   auto issue = [&](auto slot_c) __attribute__((always_inline)) {
     constexpr int S = decltype(slot_c)::value;
+    if constexpr (WPT) {
+      eq[S] = __builtin_nontemporal_load((const evec_t*)(ep + iq_b64 * (4 * EPL) + (size_t)lane4));
+      if constexpr (RES) rq[S] = *(const uint8_t*)(rp + iq_b64 + (size_t)lane_r);
+      if (--iq_left == 0) {
+        ++iq_row;
+        iq_find();
+      } else {
+        iq_b64 += (size_t)iq_stride;
+      }
+      return;
+    }
     const size_t b64 = (size_t)(i_next < last ? i_next : last) * 64;
     eq[S] = __builtin_nontemporal_load((const evec_t*)(ep + b64 * (4 * EPL) + (size_t)lane4));
     if constexpr (RES) rq[S] = *(const uint8_t*)(rp + b64 + (size_t)lane_r);
@@ -583,13 +650,19 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
     const uint32_t e = RG ? ew[S] : eq[S][0];
     if constexpr ((VPTQ_SLICED_ABLATE & 1) != 0) { g_x[Bf] = e; return; }
     const uint32_t ea = (e >> 16) * kEntry;
+    // the element's staged column (WPT: inside this workgroup's windows, else - other windows' elements, padding - the zero column)
+    uint32_t col = e & 0xffffu;
+    if constexpr (WPT) {
+      col -= (uint32_t)c0;
+      col = col < (uint32_t)G ? col : (uint32_t)G;
+    }
 #pragma unroll
     for (int w = 0; w < W4; ++w) g_ent[Bf][w] = lds_load16(ea + 16u * (uint32_t)w);
-    if constexpr (TOK == 1) g_x[Bf] = *(const lds_h_t*)(uintptr_t)(kSLXOff + ((e & 0xffffu) << 1));
-    else g_x[Bf] = *(const lds_w_t*)(uintptr_t)(kSLXOff + ((e & 0xffffu) << 2));   // tokens 0 | 1
-    if constexpr (TOK == 3) g_x2[Bf] = *(const lds_h_t*)(uintptr_t)(x2_off + ((e & 0xffffu) << 1));
+    if constexpr (TOK == 1) g_x[Bf] = *(const lds_h_t*)(uintptr_t)(kSLXOff + (col << 1));
+    else g_x[Bf] = *(const lds_w_t*)(uintptr_t)(kSLXOff + (col << 2));   // tokens 0 | 1
+    if constexpr (TOK == 3) g_x2[Bf] = *(const lds_h_t*)(uintptr_t)(x2_off + (col << 1));
     if constexpr (RES) g_rent[Bf] = lds_load16(res_off + (rq[S] << 4));
-    if constexpr (EX) g_sb[Bf] = *(const lds_w_t*)(uintptr_t)(sb_off + ((e & 0xffffu) << 2));
+    if constexpr (EX) g_sb[Bf] = *(const lds_w_t*)(uintptr_t)(sb_off + (col << 2));
   };
   auto math = [&](auto buf_c, auto slot_c) __attribute__((always_inline)) {
     constexpr int Bf = decltype(buf_c)::value;
@@ -723,9 +796,9 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
 
 // ---- launchers (both parts of the build: the file is compiled twice, VPTQ_SL_PART = 1: the one-token instantiations + the host
 // side, 2: the 2 / 3-token instantiations of the reference's roundings)
-template <typename DT, int NSL, bool RES, int V, bool TWO, bool EX = false, bool RG = false, int TOK = 1>
+template <typename DT, int NSL, bool RES, int V, bool TWO, bool EX = false, bool RG = false, int TOK = 1, bool WPT = false>
 static hipError_t launch_sl(const SlicedGroupParams& P, uint32_t lds, hipStream_t st) {
-  auto kern = gemv_sliced_kernel<DT, NSL, RES, V, TWO, EX, RG, TOK>;
+  auto kern = gemv_sliced_kernel<DT, NSL, RES, V, TWO, EX, RG, TOK, WPT>;
   static std::atomic<bool> attr_set[64];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
@@ -738,6 +811,20 @@ static hipError_t launch_sl(const SlicedGroupParams& P, uint32_t lds, hipStream_
   return hipGetLastError();
 }
 hipError_t launch_sl_tokens(int dtype, const SlicedGroupParams& P, int v, int nsl, bool res, bool rg, int tokens, uint32_t lds, hipStream_t st);
+hipError_t launch_sl_tokens_wpt(int dtype, const SlicedGroupParams& P, int nsl, bool res, int tokens, uint32_t lds, hipStream_t st);
+#if !defined(VPTQ_SL_PART) || VPTQ_SL_PART == 3
+// (window parts: v = 8, one table)
+template <typename DT, int TOK>
+static hipError_t launch_sl_tok_wpt(const SlicedGroupParams& P, int nsl, bool res, uint32_t lds, hipStream_t st) {
+  if (nsl == 8) return res ? launch_sl<DT, 8, true, 8, false, true, false, TOK, true>(P, lds, st) : launch_sl<DT, 8, false, 8, false, true, false, TOK, true>(P, lds, st);
+  return res ? launch_sl<DT, 16, true, 8, false, true, false, TOK, true>(P, lds, st) : launch_sl<DT, 16, false, 8, false, true, false, TOK, true>(P, lds, st);
+}
+hipError_t launch_sl_tokens_wpt(int dtype, const SlicedGroupParams& P, int nsl, bool res, int tokens, uint32_t lds, hipStream_t st) {
+  if (tokens == 2) return dtype == VPTQ_DTYPE_F16 ? launch_sl_tok_wpt<F16, 2>(P, nsl, res, lds, st) : launch_sl_tok_wpt<BF16, 2>(P, nsl, res, lds, st);
+  if (tokens == 3) return dtype == VPTQ_DTYPE_F16 ? launch_sl_tok_wpt<F16, 3>(P, nsl, res, lds, st) : launch_sl_tok_wpt<BF16, 3>(P, nsl, res, lds, st);
+  return hipErrorInvalidValue;
+}
+#endif
 #if !defined(VPTQ_SL_PART) || VPTQ_SL_PART == 2
 template <typename DT, int TOK>
 static hipError_t launch_sl_tok(const SlicedGroupParams& P, int v, int nsl, bool res, bool rg, uint32_t lds, hipStream_t st) {
@@ -787,8 +874,9 @@ bool gemv_sliced_eligible(const VptqLayerDesc& d, bool exact) {
 
 // bytes of LDS behind the table: f16(s x) of every column (+ 64 padding columns) + 16 floats; the reference's roundings
 // stage x and a word {scale, bias} per column instead: 6 bytes per column; + the 4 KiB residual table of the 256-entry path
-static uint32_t sl_operand_bytes(const VptqLayerDesc& d, bool exact, int tokens = 1) {
-  return (uint32_t)(d.group_size + 64) * (exact ? 4u + 2u * (uint32_t)tokens : 2u) + 64u + (sl_res256(d) ? 4096u : 0u);
+static int sl_window_cols(const VptqLayerDesc& d) { return (d.group_size + kSLWindows * 8 - 1) / (kSLWindows * 8) * 8; }   // (the layout's window width)
+static uint32_t sl_operand_bytes(const VptqLayerDesc& d, bool exact, int tokens = 1, int columns = 0) {
+  return (uint32_t)((columns ? columns : d.group_size) + 64) * (exact ? 4u + 2u * (uint32_t)tokens : 2u) + 64u + (sl_res256(d) ? 4096u : 0u);
 }
 // slices a layout of this layer must have: the slice (table entries / slices, 2 v bytes each) + the staged operands must fit
 // the 160 KiB of LDS.  Folded arithmetic: v = 8: 8 slices up to 14336 columns (14080 with the 256-entry table), else 16;
@@ -932,7 +1020,22 @@ static hipError_t sl_fill(const VptqLayerDesc& d, const VptqSlicedLayout* L, con
   P.n_rowblocks = (d.num_indices + rows_per_wg - 1) / rows_per_wg;
   P.out_f32 = (flags & VPTQ_GEMV_OUT_F32) ? 1 : 0;
   P.x_stride = d.in_features; P.y_stride = d.out_features; P.acc_stride = d.num_indices * d.vector_len;
-  lds = P.x_off + sl_operand_bytes(d, exact, tokens);
+  P.wparts = 1;
+  if (tokens != 1) {
+    P.wparts = gemv_sliced_exact_tokens_parts(d, tokens);
+    if (P.wparts > 1) {
+      if (!L[0].wstart) return hipErrorInvalidValue;
+      P.wstart = (const int32_t*)L[0].wstart;
+      P.wcols = sl_window_cols(d);
+      P.wstage = (kSLWindows / P.wparts) * P.wcols < d.group_size ? (kSLWindows / P.wparts) * P.wcols : d.group_size;
+      // (one round of workgroups: the rows per wave grow with the parts)
+      const int rpw = L[0].rows_per_wave * P.wparts;
+      P.rows_per_wave = rpw > kSLMaxRowsPerWave ? kSLMaxRowsPerWave : rpw;
+      const int rows_per_wg2 = kSLWaves * P.rows_per_wave;
+      P.n_rowblocks = (d.num_indices + rows_per_wg2 - 1) / rows_per_wg2;
+    }
+  }
+  lds = P.x_off + sl_operand_bytes(d, exact, tokens, P.wparts > 1 ? P.wstage : 0);
   return lds > kSLLdsLimit ? hipErrorInvalidValue : hipSuccess;
 }
 
@@ -950,12 +1053,25 @@ bool gemv_sliced_groupable(const VptqLayerDesc* d, int n, bool exact) {
 }
 // 2 / 3 tokens in one pass of the exact kernel (TOK): one-table formats whose slice + (2 tokens + 4) bytes per column fit the LDS.
 // Measured (profiles/r05/sliced_exact_tokens_one_pass.txt) where the 16 (v = 16: 32) slice layouts are: wider than ~5000 columns.
-bool gemv_sliced_exact_tokens_ok(const VptqLayerDesc& d, int tokens) {
-  if (tokens < 2 || tokens > (d.vector_len == 16 ? 2 : 3) || !gemv_sliced_eligible(d, true) || (sl_two(d) && d.vector_len != 8)) return false;
+// ... in how many WINDOW PARTS (workgroups per (slice, row block), each staging its column windows alone): 1 where all columns
+// fit, else - v = 8, one table; the layout must carry `wstart` - 2 or 4; 0 = not served.  VPTQ_SLICED_WINDOW_PARTS=0: never more than 1 (A/B)
+int gemv_sliced_exact_tokens_parts(const VptqLayerDesc& d, int tokens) {
+  if (tokens < 2 || tokens > (d.vector_len == 16 ? 2 : 3) || !gemv_sliced_eligible(d, true) || (sl_two(d) && d.vector_len != 8)) return 0;
   const int nsl = gemv_sliced_slices(d, true);
-  if (nsl == 0) return false;
-  return (sl_tab_bytes(d, d.num_centroids, 0, true) + 15u) / 16u * 16u + sl_operand_bytes(d, true, tokens) <= kSLLdsLimit;
+  if (nsl == 0) return 0;
+  const uint32_t tab = (sl_tab_bytes(d, d.num_centroids, 0, true) + 15u) / 16u * 16u;
+  if (tab + sl_operand_bytes(d, true, tokens) <= kSLLdsLimit) return 1;
+  static std::atomic<int> on{-1};
+  if (on < 0) { const char* e = getenv("VPTQ_SLICED_WINDOW_PARTS"); on = (e && e[0] == '0') ? 0 : 1; }
+  if (!on || d.vector_len != 8 || sl_two(d)) return 0;
+  const int wc = sl_window_cols(d);
+  for (int wparts = 2; wparts <= kSLWindows; wparts *= 2) {
+    const int wmax = (kSLWindows / wparts) * wc < d.group_size ? (kSLWindows / wparts) * wc : d.group_size;
+    if (tab + sl_operand_bytes(d, true, tokens, wmax) <= kSLLdsLimit && nsl * wparts <= 127) return wparts;
+  }
+  return 0;
 }
+bool gemv_sliced_exact_tokens_ok(const VptqLayerDesc& d, int tokens) { return gemv_sliced_exact_tokens_parts(d, tokens) >= 1; }
 // accumulator words of such a launch: [tokens][N x v], zero before the first launch, left zero by every launch
 size_t gemv_sliced_exact_tokens_workspace_bytes(const VptqLayerDesc& d, int tokens) {
   return ((size_t)tokens * d.num_indices * d.vector_len * sizeof(unsigned long long) + 255) / 256 * 256;
@@ -989,11 +1105,13 @@ hipError_t launch_gemv_sliced_group(const VptqLayerDesc* d, const VptqSlicedLayo
     const hipError_t e = sl_fill(d[i], L + (size_t)i * tables, xi, y[i], flags, ws[i], GP.p[i], l, tokens);
     if (e != hipSuccess) return e;
     lds = l > lds ? l : lds;
-    GP.start[i + 1] = GP.start[i] + nslt * GP.p[i].n_rowblocks;
+    GP.start[i + 1] = GP.start[i] + nslt * GP.p[i].wparts * GP.p[i].n_rowblocks;
+    if (GP.p[i].wparts != GP.p[0].wparts) return hipErrorInvalidValue;   // (one input width: one answer)
   }
   for (int i = n; i < kSLMaxGroup; ++i) GP.start[i + 1] = GP.start[n];
-  GP.arrivals = nslt * (parts ? n : 1);
+  GP.arrivals = nslt * (parts ? n : 1) * GP.p[0].wparts;
   if (GP.arrivals > 127) return hipErrorInvalidValue;   // (7 bits of the accumulator word count them)
+  if (tokens != 1 && GP.p[0].wparts > 1) return launch_sl_tokens_wpt(d[0].dtype, GP, nsl, sl_res256(d[0]), tokens, lds, st);
   if (tokens != 1) return launch_sl_tokens(d[0].dtype, GP, d[0].vector_len, nsl, sl_res256(d[0]), sl_two(d[0]), tokens, lds, st);
   return d[0].dtype == VPTQ_DTYPE_F16
              ? launch_sl_dt<F16>(GP, d[0].vector_len, nsl, sl_res256(d[0]), sl_two(d[0]), exact, lds, st)

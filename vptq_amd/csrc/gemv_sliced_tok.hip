@@ -897,11 +897,14 @@ static bool st_plan(const VptqLayerDesc& d, const VptqSlicedLayout* L, int token
   return false;
 }
 
+int gemv_sliced_tok_one_pass_parts(const VptqLayerDesc& d, int tokens, bool exact) { return st_one_pass(d, tokens, exact) ? gemv_sliced_exact_tokens_parts(d, tokens) : 0; }
 bool gemv_sliced_tok_eligible(const VptqLayerDesc& d, const VptqSlicedLayout* L, int tokens, bool exact) {
   StPlan pl;
   if (!L) return false;
   // (ONE pass of the one-token kernel: also the two-table formats of v = 8, their residual entries gathered once for all tokens)
-  if (st_one_pass(d, tokens, exact)) return L[0].n_slices == gemv_sliced_slices(d, true) && (!sl_two(d) || L[0].res);   // (no column windows needed)
+  // (no column windows needed - unless the columns are taken in window parts)
+  if (st_one_pass(d, tokens, exact))
+    return L[0].n_slices == gemv_sliced_slices(d, true) && (!sl_two(d) || L[0].res) && (gemv_sliced_exact_tokens_parts(d, tokens) == 1 || L[0].wstart);
   if (!(exact ? st_exact_ok(d) : gemv_sliced_eligible(d))) return false;
   const int n = exact ? 1 : gemv_sliced_tables(d);
   for (int i = 0; i < n; ++i)

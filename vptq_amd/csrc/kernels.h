@@ -69,6 +69,7 @@ hipError_t launch_gemv_sliced(const VptqLayerDesc& d, const VptqSlicedLayout* L,
 // up to 3 layers of one format reading the same x (q / k / v, gate / up) in one launch
 // gemv_sliced_tok.hip - 2 - 4 tokens over the same layouts (column windows of every list, phase by phase)
 bool gemv_sliced_tok_eligible(const VptqLayerDesc& d, const VptqSlicedLayout* L, int tokens, bool exact = false);
+int gemv_sliced_tok_one_pass_parts(const VptqLayerDesc& d, int tokens, bool exact);   // 0: column phases / not served; 1, 2, 4: one pass, that many window parts
 size_t gemv_sliced_tok_workspace_bytes(const VptqLayerDesc& d, int tokens);
 hipError_t launch_gemv_sliced_tok(const VptqLayerDesc& d, const VptqSlicedLayout* L, const void* x, void* y, int tokens, int flags,
                                   void* ws, hipStream_t st);
@@ -80,6 +81,7 @@ hipError_t launch_gemv_sliced_group(const VptqLayerDesc* d, const VptqSlicedLayo
                                     int flags, void* const* ws, hipStream_t st, int tokens = 1);
 // (VPTQ_GEMV_EXACT) 2 / 3 tokens in ONE pass of the one-token kernel: x [tokens][in], y[i] [tokens][out], ws[i]: accumulator words
 bool gemv_sliced_exact_tokens_ok(const VptqLayerDesc& d, int tokens);
+int gemv_sliced_exact_tokens_parts(const VptqLayerDesc& d, int tokens);   // 0: not served; 1: all columns staged; 2 / 4: window parts (needs wstart)
 size_t gemv_sliced_exact_tokens_workspace_bytes(const VptqLayerDesc& d, int tokens);
 // gemm_k256t.hip - canonical format, fp16 / bf16, up to 16 tokens in one pass over the indices (transposing
 // gather -> 16x16x32 MFMA with tokens as M; folded arithmetic; needs a workspace for the operand-ordered activations)

@@ -45,7 +45,12 @@ struct SlicedParams {
   int N, G, O, rows_per_wave, n_rowblocks, out_f32;
   // several tokens in one pass (gemv_sliced.hip, TOK > 1): elements between two tokens of x / y, words between their accumulators
   int x_stride, y_stride, acc_stride;
+  // ... in WINDOW PARTS (WPT): the layout's window table [slices][N][windows + 1], workgroups per (slice, row block) (2 or 4), columns
+  // per layout window, columns the LDS map is laid out for (the widest part)
+  const int32_t* wstart;
+  int wparts, wcols, wstage;
 };
+constexpr int kSLWindows = VPTQ_SLICED_WINDOWS;
 
 // f(slot 0), ... f(slot kSLQueue - 1) with the slot as a compile-time constant
 template <int I0, int I1, typename F>

@@ -562,14 +562,22 @@ class VQuantLinear(nn.Module):
                 # layers lose (8192 x 1024: 18.8 -> 21.1): the one-token rule's sizes
                 n_el = self.indices.shape[1] * self.group_size
                 kr = self.num_res_centroids if self.enable_residual else 0
-                if self.vector_len != 8 or sl.slices < 16:
+                # ... in WINDOW PARTS where only half of the columns' operands fit beside the slice (WPT; profiles/r05/
+                # sliced_exact_tokens_window_parts.txt, gather -> one pass, 2 / 3 tokens, k65536-256 / -0): 14336 x 4096 37.0 / 42.6 -> 24.9 / 28.4
+                # and 36.9 / 35.3 -> 21.7 / 26.2; 4096 x 14336 37.1 / 38.2 -> 31.5 / 37.1 and 36.2 / 35.0 -> 27.9 / 34.2; smaller layers lose
+                # (4096^2 13.6 / 16.2 -> 14.8 / 16.7): from 6 M index elements on
+                if self.vector_len != 8:
                     ok = False
                 elif kr not in (0, 256):
-                    ok = tokens <= 3 and kr >= 4096 and n_el >= _SLICED_EXACT_RG_MIN_ELEMENTS and sl.tokens_one_pass(tokens)
-                elif tokens <= 3 and sl.tokens_one_pass(tokens):
-                    ok = True
+                    ok = sl.slices >= 16 and tokens <= 3 and kr >= 4096 and n_el >= _SLICED_EXACT_RG_MIN_ELEMENTS and sl.tokens_one_pass(tokens)
                 else:
-                    ok = 3 <= tokens <= 4 and n_el >= 6 << 20
+                    wparts = sl.tokens_window_parts(tokens) if tokens <= 3 else 0
+                    if wparts == 1:
+                        ok = sl.slices >= 16
+                    elif wparts > 1:
+                        ok = n_el >= 6 << 20
+                    else:
+                        ok = sl.slices >= 16 and 3 <= tokens <= 4 and n_el >= 6 << 20
             else:
                 n_el = self.indices.shape[1] * self.group_size      # index elements per table
                 kr = self.num_res_centroids if self.enable_residual else 0

@@ -283,14 +283,21 @@ class SlicedGemv:
         slice + (2 tokens + 4) bytes per column fit the LDS) - the route that needs no column windows?"""
         if not self.exact or self.parts > 1 or not 2 <= tokens <= 3:
             return False
+        return self.tokens_window_parts(tokens) >= 1
+
+    def tokens_window_parts(self, tokens: int) -> int:
+        """0, or in how many window parts the library takes these tokens in one pass: 1 = every column staged beside the slice; 2 / 4 =
+        that many workgroups per (slice, row block), each with its column windows (`vptq_quant_gemv_sliced_tokens_one_pass`)"""
+        if not self.exact or self.parts > 1 or not 2 <= tokens <= 3:
+            return 0
         key = ("_one_pass", tokens)
-        ok = self.__dict__.get(key)
-        if ok is None:
-            lay = B.SlicedLayout.from_buffer_copy(self.layout[0])
-            lay.wstart = None
-            ok = bool(B.lib().vptq_quant_gemv_sliced_tokens_supported_for(self.desc, lay, int(tokens), self._flags))
-            self.__dict__[key] = ok
-        return ok
+        n = self.__dict__.get(key)
+        if n is None:
+            n = int(B.lib().vptq_quant_gemv_sliced_tokens_one_pass(self.desc, int(tokens), self._flags))
+            if n and not B.lib().vptq_quant_gemv_sliced_tokens_supported_for(self.desc, self._lay_ref, int(tokens), self._flags):
+                n = 0
+            self.__dict__[key] = n
+        return n
 
     def forward_tokens(self, x: torch.Tensor, out: torch.Tensor = None, flags: int = 0):
         """2 - 4 tokens in ONE launch (`vptq_quant_gemv_sliced_tokens`, gemv_sliced_tok.hip): x [..., in_features] with 2 - 4
