@@ -380,7 +380,8 @@ VPTQ_API int vptq_quant_gemv_sliced_tokens_grouped(const VptqLayerDesc* descs, c
  * the layer's descriptor with in_features = group_size = G / n (a multiple of 8) and weight_scale / weight_bias / perm /
  * scale_permuted / bias_permuted advanced to the part's first column, a layout per part built from those columns of the index
  * matrix (columns counted from the part's first); x = the WHOLE activation, y[i] = y[0], workspaces[i] = workspaces[0]: the parts
- * meet in the output's accumulator word (n x slices arrivals; at most 127). */
+ * meet in the output's accumulator word (n x slices arrivals; at most 127).  vptq_quant_gemv_sliced_tokens_grouped takes the same flags for
+ * 2 / 3 tokens where every part takes them in one pass (vptq_quant_gemv_sliced_tokens_one_pass(part, tokens, flags) != 0): x [tokens][G]. */
 VPTQ_API int vptq_quant_gemv_sliced_grouped(const VptqLayerDesc* descs, const VptqSlicedLayout* layouts, int n,
                                    const void* x, void* const* y, int flags, void* const* workspaces,
                                    const size_t* workspace_bytes, void* stream);

@@ -141,9 +141,20 @@ def test_sliced_layout_reference_roundings(I, O, kw, rpw, dt, v, kr, dev):
     y32 = sl(xt, flags=B.GEMV_OUT_F32)
     assert y32.dtype == torch.float32 and torch.equal(y32.to(got.dtype).view(torch.int16), got.view(torch.int16))
     assert torch.equal(sl(xt).view(torch.int16), got.view(torch.int16))
-    # column parts, two tables of v = 16, two tables of v = 8 whose operands of two tokens do not fit beside the slice: one token only
-    if sl.parts > 1 or (v == 16 and kr) or (kr not in (0, 256) and not sl.tokens_one_pass(2)):
+    # two tables of v = 16, two tables of v = 8 whose operands of two tokens do not fit beside the slice: one token only; column parts:
+    # 2 / 3 tokens where every part takes them in one pass (whole or in window parts), nothing else
+    if (v == 16 and kr) or (kr not in (0, 256) and not sl.tokens_one_pass(2)) or (sl.parts > 1 and not sl.tokens_one_pass(2)):
         assert not sl.tokens_supported(2) and sl.forward_tokens(torch.cat([xt, xt], dim=1)) is None
+    elif sl.parts > 1:
+        assert sl.tokens_supported(2) and not sl.tokens_supported(4)
+        x2 = _xt(I, 2, dt, dist, I + 9)
+        got2 = sl.forward_tokens(bits_to_tensor(x2, dt, dev).reshape(x2.shape))
+        torch.cuda.synchronize()
+        want2 = vo.forward(L, x2)
+        g2 = tensor_to_bits(got2)
+        assert got2.shape == (1, 2, O) and rel_err(g2, want2, dt) <= TOL[dt], f"{I}x{O} {dt} 2 tokens over {sl.parts} column parts: {rel_err(g2, want2, dt):.3e}"
+        assert float((g2.reshape(-1) == np.asarray(want2).reshape(-1)).mean()) >= 0.95
+        assert sl.forward_tokens(torch.cat([xt] * 4, dim=1)) is None
 
 
 EXACT_TOK_SHAPES = [(2048, 528, dict(dist="llm", enable_perm=True, bias=True)), (8192, 512, dict(dist="llm", bias=True)), (4104, 272, dict(dist="llm")),
@@ -922,6 +933,29 @@ def test_module_default_route_for_two_to_four_tokens_of_wide_layers(dev, monkeyp
     for a, b, Li in zip(alone, ys, Lq):
         assert rel_err(tensor_to_bits(b), vo.forward(Li, xs[:, :3]), "f16") <= 1e-3
         assert float((a.view(torch.int16) == b.view(torch.int16)).float().mean()) >= 0.95   # (the group's rows per wave: another order of sums)
+
+
+def test_module_route_for_two_and_three_tokens_over_column_parts(dev):
+    """the product default: a 28672-column layer (two column parts of 14336) takes 2 / 3 tokens in one pass as well - every part in two
+    window parts, 2 x 2 x 16 workgroups per row block meeting in the accumulator words; 4 tokens: the gather kernel"""
+    L = vo.make_layer(28672, 2048, dist="llm", seed=76, num_centroids=65536, num_res_centroids=256, bias=True)
+    m = spec_to_module(L, dev)
+    xs = np.concatenate([_x(28672, "f16", "llm", 70 + i) for i in range(4)], axis=1)
+    xt = bits_to_tensor(xs, "f16", dev).reshape(xs.shape)
+    m(xt[:, :1].contiguous())
+    sl = m.__dict__["_sliced"][1]
+    assert sl is not None and sl.exact and sl.parts == 2 and sl.slices == 16 and sl.tokens_window_parts(2) == 2 and sl.tokens_window_parts(3) == 2
+    assert m._sliced_one_launch(sl, 2) and m._sliced_one_launch(sl, 3) and not m._sliced_one_launch(sl, 4)
+    want = vo.forward(L, xs)
+    for T in (1, 2, 3):
+        x = xt[:, :T].contiguous()
+        y = m(x)
+        if T > 1:
+            assert torch.equal(y.view(torch.int16), sl.forward_tokens(x).view(torch.int16))
+        yb = tensor_to_bits(y)
+        assert rel_err(yb, want[:, :T], "f16") <= 1e-3, (T, rel_err(yb, want[:, :T], "f16"))
+        assert float((yb.reshape(-1) == np.asarray(want[:, :T]).reshape(-1)).mean()) >= 0.95
+    assert torch.equal(m(xt).view(torch.int16), gemv_abi(m, xt, EXACT).view(torch.int16))
 
 
 @pytest.mark.parametrize("tokens", [2, 3, 4])

@@ -605,6 +605,13 @@ int vptq_quant_gemv_sliced_tokens_grouped(const VptqLayerDesc* descs, const Vptq
     if (!y[i]) return fail(VPTQ_E_NULL, "y[%d] is NULL", i);
   }
   if (flags & VPTQ_GEMV_FORCE_GENERIC) return fail(VPTQ_E_UNSUPPORTED, "the sliced path is not the generic kernel: use vptq_quant_gemv");
+  if (flags & VPTQ_GEMV_COLUMN_PARTS) {   // (as vptq_quant_gemv_sliced_grouped: parts of ONE layer; 2 / 3 tokens, where every part takes them in one pass)
+    if (!(flags & VPTQ_GEMV_EXACT)) return fail(VPTQ_E_UNSUPPORTED, "VPTQ_GEMV_COLUMN_PARTS goes with VPTQ_GEMV_EXACT");
+    for (int i = 0; i < n; ++i)
+      if (y[i] != y[0] || workspaces[i] != workspaces[0] || descs[i].out_features != descs[0].out_features || descs[i].num_indices != descs[0].num_indices ||
+          descs[i].bias != descs[0].bias || descs[i].in_features != descs[0].in_features || !vptq::gemv_sliced_tok_one_pass_parts(descs[i], tokens, true))
+        return fail(VPTQ_E_UNSUPPORTED, "column parts share y, the workspace, the output bias, have one width and take the tokens in one pass");
+  }
   if (!vptq::gemv_sliced_tok_groupable(descs, layouts, n, tokens, (flags & VPTQ_GEMV_EXACT) != 0))
     return fail(VPTQ_E_UNSUPPORTED, "a sliced group of 2 - 4 tokens takes layers of ONE format, dtype and input width whose layouts carry wstart");
   if ((((uintptr_t)x) & 15) != 0) return fail(VPTQ_E_UNSUPPORTED, "x must be 16-byte aligned");

@@ -1090,7 +1090,7 @@ hipError_t launch_gemv_sliced_group(const VptqLayerDesc* d, const VptqSlicedLayo
     for (int i = 1; i < n; ++i)
       if (y[i] != y[0] || ws[i] != ws[0] || d[i].out_features != d[0].out_features || d[i].num_indices != d[0].num_indices || d[i].bias != d[0].bias)
         return hipErrorInvalidValue;
-    if (tokens != 1 || !exact) return hipErrorInvalidValue;   // (the folded form stages 32768 columns in one piece: no parts needed)
+    if (!exact) return hipErrorInvalidValue;   // (the folded form stages 32768 columns in one piece: no parts needed)
   }
   SlicedGroupParams GP = {};
   GP.n = n;
@@ -1104,6 +1104,7 @@ hipError_t launch_gemv_sliced_group(const VptqLayerDesc* d, const VptqSlicedLayo
     const void* const xi = (parts && d[i].perm == nullptr) ? (const void*)((const uint16_t*)x + (size_t)i * d[i].in_features) : x;
     const hipError_t e = sl_fill(d[i], L + (size_t)i * tables, xi, y[i], flags, ws[i], GP.p[i], l, tokens);
     if (e != hipSuccess) return e;
+    if (parts) GP.p[i].x_stride = n * d[i].in_features;   // (tokens of the WHOLE activation: a part's columns lie one row of all parts apart)
     lds = l > lds ? l : lds;
     GP.start[i + 1] = GP.start[i] + nslt * GP.p[i].wparts * GP.p[i].n_rowblocks;
     if (GP.p[i].wparts != GP.p[0].wparts) return hipErrorInvalidValue;   // (one input width: one answer)

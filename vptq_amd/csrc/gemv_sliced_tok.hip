@@ -1006,6 +1006,9 @@ hipError_t launch_gemv_sliced_tok_group(const VptqLayerDesc* d, const VptqSliced
       for (int i = 0; i < n; ++i) acc[i] = (char*)ws[i] + st_counter_bytes(d[i]);
       return launch_gemv_sliced_group(d, L, n, x, y, flags, acc, st, tokens);
     }
+    // (column parts of one layer share their output and accumulator words: the one pass only - the column-phase kernel below keeps
+    // partial sums and counters per layer)
+    if (flags & VPTQ_GEMV_COLUMN_PARTS) return hipErrorInvalidValue;
   }
   SlicedTokGroupParams GP = {};
   GP.n = n;

@@ -272,8 +272,8 @@ class SlicedGemv:
     def tokens_supported(self, tokens: int) -> bool:
         """does the library's kernel for 2 - 4 tokens over these layouts take this layer (its activations must fit the LDS
         beside the slice in at most 4 column phases)?"""
-        if self.exact and self.parts > 1:    # (column parts: one token only)
-            return False
+        if self.exact and self.parts > 1:    # (column parts: 2 / 3 tokens where every part takes them in one pass, nothing else)
+            return self.tokens_one_pass(tokens)
         if self.exact and self._side16:      # (the reference's roundings over two-table formats: 2 / 3 tokens in one pass, nothing else)
             return self.tokens_one_pass(tokens)
         return bool(B.lib().vptq_quant_gemv_sliced_tokens_supported_for(self.desc, self._lay_ref, int(tokens), self._flags))
@@ -281,20 +281,21 @@ class SlicedGemv:
     def tokens_one_pass(self, tokens: int) -> bool:
         """(reference roundings) does the library take these 2 / 3 tokens in ONE PASS of the one-token kernel (gemv_sliced.hip, TOK:
         slice + (2 tokens + 4) bytes per column fit the LDS) - the route that needs no column windows?"""
-        if not self.exact or self.parts > 1 or not 2 <= tokens <= 3:
+        if not self.exact or not 2 <= tokens <= 3:
             return False
         return self.tokens_window_parts(tokens) >= 1
 
     def tokens_window_parts(self, tokens: int) -> int:
         """0, or in how many window parts the library takes these tokens in one pass: 1 = every column staged beside the slice; 2 / 4 =
         that many workgroups per (slice, row block), each with its column windows (`vptq_quant_gemv_sliced_tokens_one_pass`)"""
-        if not self.exact or self.parts > 1 or not 2 <= tokens <= 3:
+        if not self.exact or not 2 <= tokens <= 3:
             return 0
         key = ("_one_pass", tokens)
         n = self.__dict__.get(key)
         if n is None:
-            n = int(B.lib().vptq_quant_gemv_sliced_tokens_one_pass(self.desc, int(tokens), self._flags))
-            if n and not B.lib().vptq_quant_gemv_sliced_tokens_supported_for(self.desc, self._lay_ref, int(tokens), self._flags):
+            d = self._part_descs[0] if self.parts > 1 else self.desc     # (column parts: every part is asked - they have one width)
+            n = int(B.lib().vptq_quant_gemv_sliced_tokens_one_pass(d, int(tokens), self._flags))
+            if n and not B.lib().vptq_quant_gemv_sliced_tokens_supported_for(d, self._lay_ref, int(tokens), self._flags):
                 n = 0
             self.__dict__[key] = n
         return n
@@ -306,7 +307,7 @@ class SlicedGemv:
         tokens = x.numel() // lay.in_features
         if x.shape[-1] != lay.in_features or not 2 <= tokens <= 8:
             raise ValueError("forward_tokens takes 2 - 8 tokens of in_features values")
-        if self.exact and (self.parts > 1 or (self._side16 and not self.tokens_one_pass(tokens))):
+        if self.exact and (self.parts > 1 or self._side16) and not self.tokens_one_pass(tokens):
             return None
         if x.dtype != self._dtype or x.device != self.dev:
             x = lay._check_activation(x)
@@ -330,9 +331,10 @@ class SlicedGemv:
         if ws is None or ws[1] < need:
             if torch.cuda.is_current_stream_capturing():
                 return None
-            size, nbytes = 8, B.lib().vptq_quant_gemv_sliced_tokens_workspace_bytes(self.desc, 8)
+            wd = self._part_descs[0] if self.parts > 1 else self.desc
+            size, nbytes = 8, B.lib().vptq_quant_gemv_sliced_tokens_workspace_bytes(wd, 8)
             if not nbytes:
-                size, nbytes = 4, B.lib().vptq_quant_gemv_sliced_tokens_workspace_bytes(self.desc, 4)
+                size, nbytes = 4, B.lib().vptq_quant_gemv_sliced_tokens_workspace_bytes(wd, 4)
             if not nbytes or size < need:
                 return None
             if ws is not None:
@@ -350,7 +352,16 @@ class SlicedGemv:
         if out is None:
             out = torch.empty(x.shape[:-1] + (lay.out_features,),
                               dtype=torch.float32 if (flags & B.GEMV_OUT_F32) else self._dtype, device=self.dev)
-        rc = self._fn_tok(self.desc, self._lay_ref, x.data_ptr(), out.data_ptr(), tokens, flags | self._flags, ws.data_ptr(), ws.numel(), sp)
+        if self.parts > 1:   # column parts of one layer: one grouped launch, shared output and workspace
+            yp, wp, _ = self._pp
+            for i in range(self.parts):
+                yp[i] = out.data_ptr()
+                wp[i] = ws.data_ptr()
+            wb = (C.c_size_t * self.parts)(*([ws.numel()] * self.parts))
+            rc = B.lib().vptq_quant_gemv_sliced_tokens_grouped(self._part_descs, self._lay_ref, self.parts, x.data_ptr(), yp, tokens,
+                                                               flags | self._flags | B.GEMV_COLUMN_PARTS, wp, wb, sp)
+        else:
+            rc = self._fn_tok(self.desc, self._lay_ref, x.data_ptr(), out.data_ptr(), tokens, flags | self._flags, ws.data_ptr(), ws.numel(), sp)
         if rc == B.E_UNSUPPORTED:
             return None
         if rc:
