@@ -11,6 +11,12 @@ the contract, and the many-token / dequant paths keep using them); the derived t
 
     sl = SlicedGemv(layer)          # builds the layout (torch, on the layer's device)
     y = sl(x)                       # one token; same result as layer(x) within the parity bar
+
+Round 5: `SlicedGemv(layer, exact=True)` - the reference's roundings per weight (the product default) over ONE layout bucketed by
+the main index (a residual codebook other than v8's 256-entry one rides along as 16-bit indices, its entries gathered from L2);
+layers too wide for that arithmetic's 6 bytes of LDS per column in one piece (28672 columns) as 2 - 3 COLUMN PARTS with a layout
+each (`exact_column_parts`, `part_desc`); `forward_tokens` for 2 - 8 tokens: 2 / 3 in one pass of the one-token kernel where the
+operands fit - whole (`tokens_window_parts` = 1) or in window parts (2 / 4) -, else column phases on the matrix pipe.
 """
 from __future__ import annotations
 
