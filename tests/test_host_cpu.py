@@ -692,6 +692,59 @@ def test_exact_column_parts_without_gpu():
     assert p.indices == d.indices and p.bias == d.bias and not p.perm
 
 
+def test_one_pass_plan_for_two_and_three_tokens_without_gpu():
+    """vptq_quant_gemv_sliced_tokens_one_pass: in how many window parts 2 / 3 tokens take one pass of the one-token kernel in the reference's
+    roundings - 1 where the slice leaves room for (2 tokens + 4) bytes of every column, 2 / 4 where for half / a quarter of them (v = 8, one
+    table), 0 else (column phases or the gather kernel); the same question per column part; the flags it answers for - host logic"""
+    import ctypes as C
+    from vptq_amd.utils.sliced import part_desc
+    lib = B.lib()
+    EX = B.GEMV_EXACT
+    one = lib.vptq_quant_gemv_sliced_tokens_one_pass
+
+    def want(I, v, kr, tokens):      # the LDS budget restated
+        if tokens > (3 if v == 8 else 2) or (kr not in (0, 256) and v != 8) or (v == 16 and kr):
+            return 0
+        slices = lib.vptq_sliced_layout_supported_for(_family_desc(I, 4096, v, 65536, kr), EX)
+        if not slices:
+            return 0
+        tab = 65536 // slices * v * 2
+        res = 4096 if (v == 8 and kr == 256) else 0
+        if tab + (I + 64) * (4 + 2 * tokens) + 64 + res <= 163840:
+            return 1
+        if v != 8 or kr not in (0, 256):
+            return 0
+        wc = (I + 31) // 32 * 8
+        for parts in (2, 4):
+            if tab + (min(4 // parts * wc, I) + 64) * (4 + 2 * tokens) + 64 + res <= 163840:
+                return parts
+        return 0
+    for (I, v, kr) in ((2048, 8, 256), (4096, 8, 0), (4096, 8, 256), (5376, 8, 0), (8192, 8, 256), (12288, 8, 0), (14336, 8, 256), (16288, 8, 0),
+                       (8192, 16, 0), (14336, 16, 0), (8192, 8, 65536), (14336, 8, 65536), (4096, 8, 65536), (8192, 8, 4096), (8192, 16, 65536)):
+        d = _family_desc(I, 4096, v, 65536, kr)
+        got = [one(d, t, EX) for t in (1, 2, 3, 4)]
+        assert got == [0] + [want(I, v, kr, t) for t in (2, 3, 4)], (I, v, kr, got)
+        assert one(d, 2, 0) == 0 and one(d, 2, EX | B.GEMV_FORCE_GENERIC) == 0        # (the folded form: column phases only)
+    assert [one(_family_desc(4096, 4096, 8, 65536, 256), t, EX) for t in (2, 3)] == [2, 2]
+    assert [one(_family_desc(14336, 4096, 8, 65536, 0), t, EX) for t in (2, 3)] == [2, 2]
+    assert [one(_family_desc(8192, 4096, 8, 65536, 256), t, EX) for t in (2, 3)] == [1, 1]
+    # window parts need the layout's window table, the whole-column pass does not
+    buf = (C.c_char * 64)()
+    p = C.addressof(buf)
+    supf = lib.vptq_quant_gemv_sliced_tokens_supported_for
+
+    def layout(dd, wstart):
+        return (B.SlicedLayout * 1)(B.SlicedLayout(p, p, p, p, 2, 1, lib.vptq_sliced_layout_supported_for(dd, EX), 0, p if wstart else None))
+    d4, d8 = _family_desc(4096, 4096, 8, 65536, 0), _family_desc(8192, 4096, 8, 65536, 0)
+    assert supf(d4, layout(d4, True), 2, EX) == 1 and supf(d4, layout(d4, False), 2, EX) == 0
+    assert supf(d8, layout(d8, True), 2, EX) == 1 and supf(d8, layout(d8, False), 2, EX) == 1
+    # a 28672-column layer: not in one piece; each of its two column parts in two window parts
+    dw = _family_desc(28672, 4096, 8, 65536, 256)
+    assert [one(dw, t, EX) for t in (2, 3)] == [0, 0]
+    pd = part_desc(dw, 0, 14336)
+    assert [one(pd, t, EX) for t in (2, 3, 4)] == [2, 2, 0] and supf(pd, layout(pd, True), 3, EX) == 1
+
+
 def test_exact_slice_rule_opt_in_for_two_tokens():
     """VPTQ_SLICED_SLICES=room2 (read once per process: a subprocess): the exact layouts of v = 8 layers take the smaller slice count only
     where TWO tokens' operands fit beside the slice - 4096-column layers then have 16 slices and their 2 / 3 tokens one pass"""
