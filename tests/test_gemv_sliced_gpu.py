@@ -935,6 +935,36 @@ def test_module_default_route_for_two_to_four_tokens_of_wide_layers(dev, monkeyp
         assert float((a.view(torch.int16) == b.view(torch.int16)).float().mean()) >= 0.95   # (the group's rows per wave: another order of sums)
 
 
+def test_sibling_layers_share_one_pass_in_window_parts(dev, monkeypatch):
+    """q / k / v of a 4096-wide model, 3 tokens, reference roundings: ONE grouped launch of the one-pass kernel in two window parts
+    (every member: half of the columns staged per workgroup), each member's result as from its own launch"""
+    import vptq_amd
+    import vptq_amd.layers.vqlinear as vq
+    from vptq_amd.layers.vqlinear import SiblingGroup
+    assert vptq_amd.arithmetic() == "reference"
+    monkeypatch.setattr(vq, "_SLICED_ONE_LAUNCH", "1")       # (small test layers: below the auto rule's size)
+    xs = np.concatenate([_x(4096, "f16", "llm", 90 + i) for i in range(3)], axis=1)
+    x3 = bits_to_tensor(xs, "f16", dev).reshape(xs.shape)
+    Lq = [vo.make_layer(4096, O, seed=95 + i, dist="llm", num_centroids=65536, num_res_centroids=256, bias=(i == 1)) for i, O in enumerate((1024, 264, 512))]
+    mq = [spec_to_module(Li, dev) for Li in Lq]
+    for mm in mq:
+        mm.enable_sliced_layout()
+    alone = [mm(x3) for mm in mq]
+    for mm in mq:
+        sq = mm.__dict__["_sliced"][1]
+        assert sq.exact and sq.slices == 8 and sq.tokens_window_parts(3) == 2 and mm._sliced_one_launch(sq, 3)
+    group = SiblingGroup(mq)
+    for mm in mq:
+        object.__setattr__(mm, "_siblings", group)
+    x3b = x3.clone()
+    ys = [mm(x3b) for mm in mq]
+    assert isinstance(group.__dict__.get("_sgroup"), tuple) and group._sgroup[1].exact
+    for a, b, Li in zip(alone, ys, Lq):
+        assert rel_err(tensor_to_bits(a), vo.forward(Li, xs), "f16") <= 1e-3
+        assert rel_err(tensor_to_bits(b), vo.forward(Li, xs), "f16") <= 1e-3
+        assert float((a.view(torch.int16) == b.view(torch.int16)).float().mean()) >= 0.95   # (the group's rows per wave: another order of sums)
+
+
 def test_module_route_for_two_and_three_tokens_over_column_parts(dev):
     """the product default: a 28672-column layer (two column parts of 14336) takes 2 / 3 tokens in one pass as well - every part in two
     window parts, 2 x 2 x 16 workgroups per row block meeting in the accumulator words; 4 tokens: the gather kernel"""
