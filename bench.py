@@ -131,7 +131,7 @@ def prefill_extra(dev, tokens=8192):
     return out
 
 
-def k65536_extra(lib, B, dev, H, steps, warmup, regions, R=8, kr=256, v=8):
+def k65536_extra(lib, B, dev, H, steps, warmup, regions, R=8, kr=256, v=8, light=False):
     """v8-k65536-256 (T = 24 bits, the format of most published checkpoints), H x H, one token: the library's default
     route (gemv_gather_kernel: centroid gathers through the caches) and the one-token GEMV over the load-time derived
     sliced layout (gemv_sliced.hip, VQuantLinear.enable_sliced_layout) on the same ring of R distinct layers."""
@@ -141,7 +141,8 @@ def k65536_extra(lib, B, dev, H, steps, warmup, regions, R=8, kr=256, v=8):
     x = torch.randn(1, 1, H, device=dev, generator=torch.Generator(device=dev).manual_seed(7)).half()
     ys = [torch.empty(1, 1, H, device=dev, dtype=torch.float16) for _ in range(R)]
     descs = [layer_desc(m) for m in layers]
-    sls = [SlicedGemv(m) for m in layers]
+    # (light: only the product's default route - the exact sliced kernel where it serves the format, else the gather kernel)
+    sls = [] if light else [SlicedGemv(m) for m in layers]
     # the reference's roundings over a layout (round 5; no residual codebook or the 256-entry one): what VQuantLinear.forward
     # takes for these layers in the default arithmetic
     exact_ok = bool(lib.vptq_sliced_layout_supported_for(descs[0][0], B.GEMV_EXACT))
@@ -164,14 +165,19 @@ def k65536_extra(lib, B, dev, H, steps, warmup, regions, R=8, kr=256, v=8):
     ab = (H // v) * ((H * T + 31) // 32) * 4 + (65536 + kr) * v * 2 + 2 * H + 4 * H + 2 * H
     out = {"what": f"VQuantLinear {H}x{H} v={v} k=65536+{kr} (T = {T} bits per index), ring of {R} layers; GB/s of the PACKED format's "
                    "algorithmic bytes for both routes (the sliced layouts read 4 bytes per element and table, 5 for k65536+256)"}
-    for key, fn in (("default", default_pass), ("sliced_layout", sliced_pass)) + ((("exact_sliced_layout", exact_sliced_pass),) if exact_ok else ()):
+    routes = (("default", default_pass), ("sliced_layout", sliced_pass)) + ((("exact_sliced_layout", exact_sliced_pass),) if exact_ok else ())
+    if light:
+        routes = routes[2:] if exact_ok else routes[:1]
+    for key, fn in routes:
         t = Timer(dev).run(fn, steps, warmup, regions)
         us = t["event_ms"] * 1e3 / (steps * R)
         out[key] = {"us_per_layer": us, "GBps": ab / us / 1e3, "frac_of_8TBps": ab / us / 1e3 / 8000.0}
-    out["default"]["kernel"] = lib.vptq_quant_gemv_kernel_name(descs[0][0], 1, 0).decode()
-    out["default"]["what"] = "vptq_quant_gemv: centroid gathers through the caches (reference roundings); the module's route for layers the exact sliced kernel does not take"
-    out["sliced_layout"]["kernel"] = "gemv_sliced_kernel"
-    out["sliced_layout"]["what"] = "OPT-IN folded arithmetic over the load-time derived layouts"
+    if "default" in out:
+        out["default"]["kernel"] = lib.vptq_quant_gemv_kernel_name(descs[0][0], 1, 0).decode()
+        out["default"]["what"] = "vptq_quant_gemv: centroid gathers through the caches (reference roundings); the module's route for layers the exact sliced kernel does not take"
+    if "sliced_layout" in out:
+        out["sliced_layout"]["kernel"] = "gemv_sliced_kernel"
+        out["sliced_layout"]["what"] = "OPT-IN folded arithmetic over the load-time derived layouts"
     if exact_ok:
         out["exact_sliced_layout"]["kernel"] = "gemv_sliced_kernel<EX>"
         out["exact_sliced_layout"]["what"] = ("the reference's roundings over a load-time derived layout (LDS-local gathers): the module's one-token route "
@@ -180,16 +186,22 @@ def k65536_extra(lib, B, dev, H, steps, warmup, regions, R=8, kr=256, v=8):
         exact_sliced_pass()
         torch.cuda.synchronize()
         got_x = ys[-1].clone()
-    out["sliced_layout"]["layout_MiB_per_layer"] = sls[0].extra_bytes / 2**20
-    out["sliced_layout"]["packed_index_MiB_per_layer"] = layers[0].indices.numel() * 4 / 2**20
-    sliced_pass()
-    torch.cuda.synchronize()
+    if not light:
+        out["sliced_layout"]["layout_MiB_per_layer"] = sls[0].extra_bytes / 2**20
+        out["sliced_layout"]["packed_index_MiB_per_layer"] = layers[0].indices.numel() * 4 / 2**20
+        sliced_pass()
+        torch.cuda.synchronize()
     layers[-1].enable_sliced_layout(False)   # (reference = the gather kernel, not the module's default one-token route)
     ref = layers[-1](x)
-    out["sliced_vs_default_rel_diff"] = ((ys[-1].float() - ref.float()).abs().max() / ref.float().abs().max()).item()
+    if not light:
+        out["sliced_vs_default_rel_diff"] = ((ys[-1].float() - ref.float()).abs().max() / ref.float().abs().max()).item()
     if exact_ok:
         out["exact_sliced_vs_default_bit_identical"] = float((got_x.view(torch.int16) == ref.view(torch.int16)).float().mean())
         assert out["exact_sliced_vs_default_bit_identical"] >= 0.95, out
+    if light:
+        del layers, sxs
+        torch.cuda.empty_cache()
+        return out
     # 2 and 4 tokens: the gather kernel (vptq_quant_gemv) against ONE launch over the same layouts (gemv_sliced_tok.hip:
     # column phases; 4 tokens contract on the matrix pipe), where the library takes the layer
     for tokens in (2, 4):
@@ -903,6 +915,85 @@ def bench_tp_row(lib, B, dev, timer, rank, world, n_layers, flags, steps, warmup
     return res
 
 
+COMPACT_LIMIT = 4096   # bytes: the driver keeps an 8 KB stdout tail; round 5's 21.5 KB line did not parse (BENCH_r05.parsed = null)
+
+
+def _short_sample(s, n=160):
+    s = str(s)
+    return s if len(s) <= n else s[:n - 3] + "..."
+
+
+def compact_line(out):
+    """The ONE stdout line: the contract's keys + `roofline` + `cpu_baseline`, nothing verbose.  Everything else
+    (`extras`, soak, clocks, notes) goes to gpurun_out/bench_full.json and stderr (write_full).  Pure function of the
+    full result dict, tested on CPU (tests/test_bench_line_cpu.py): < COMPACT_LIMIT bytes, json round trip."""
+    cfg = out.get("config") or {}
+    rf = out.get("roofline") or {}
+    c = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                 "scaling", "vs_baseline", "dtype", "data")}
+    arith = cfg.get("arithmetic") or ""
+    c["config"] = {"workload": _short_sample(cfg.get("workload", ""), 260)}
+    for k in ("hidden", "ring", "mode", "decoder_layers", "launches_per_step", "us_per_layer", "kernel", "hipgraph"):
+        if cfg.get(k) is not None:
+            c["config"][k] = cfg[k]
+    c["config"]["arithmetic"] = "reference" if arith.startswith("reference") else ("folded" if arith.startswith("folded") else arith[:40])
+    c["config"]["parallelism"] = _short_sample(cfg.get("parallelism", ""), 120)
+    r = {k: rf.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
+    for k in ("traffic_source", "traffic_from_committed_profile", "bytes_per_launch", "us_per_launch", "ms_per_step_one_step_per_graph",
+              "power_w_during_timed_regions", "sclk_mhz_during_timed_regions"):
+        if rf.get(k) is not None:
+            r[k] = rf[k]
+    mp = {}
+    for name, e in (rf.get("module_path") or {}).items():
+        row = {}
+        for k_src, k_dst in (("us_per_layer", "us"), ("frac", "frac"), ("tokens_per_s", "tok_s"), ("vqlinear_us_per_token", "vq_us_tok")):
+            if e.get(k_src) is not None:
+                row[k_dst] = round(float(e[k_src]), 4)
+        if e.get("kernel"):
+            row["kernel"] = str(e["kernel"])[:40]
+        mp[name] = row
+    if mp:
+        r["module_path"] = mp
+    c["roofline"] = r
+    cb = out.get("cpu_baseline")
+    if cb:
+        c["cpu_baseline"] = {"value": cb.get("value"), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
+                             "sample": _short_sample(cb.get("sample", ""), 200)}
+    for k in ("parity_rel_err_vs_cpu_oracle", "full"):
+        if out.get(k) is not None:
+            c[k] = out[k]
+    tp = out.get("tp_row")
+    if tp:
+        c["tp_row"] = {k: tp.get(k) for k in ("us_per_decoder_layer", "allreduce_per_decoder_layer", "parity_rel_err_vs_cpu_oracle") if tp.get(k) is not None}
+    ws = out.get("weak_scaling")
+    if ws:
+        c["weak_scaling"] = {k: ws.get(k) for k in ("value", "unit", "us_per_launch", "scaling")}
+    line = json.dumps(c, separators=(",", ":"))
+    if len(line) >= COMPACT_LIMIT:     # never let verbosity cost the record: drop the optional parts, in this order
+        for victim in (("roofline", "module_path"), ("config", "workload"), ("cpu_baseline", "sample")):
+            obj = c.get(victim[0]) or {}
+            if victim[1] in obj:
+                obj[victim[1]] = None if victim[1] == "module_path" else _short_sample(obj[victim[1]], 60)
+            line = json.dumps(c, separators=(",", ":"))
+            if len(line) < COMPACT_LIMIT:
+                break
+    return line
+
+
+def write_full(out, path=None):
+    """The whole result (extras, soak, clocks, notes): gpurun_out/bench_full.json (merged back by gpurun) + stderr."""
+    path = path or os.path.join(ROOT, "gpurun_out", "bench_full.json")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(out, f, indent=1)
+        rel = os.path.relpath(path, ROOT)
+    except OSError:
+        rel = None
+    print("[bench] full result: " + json.dumps(out), file=sys.stderr, flush=True)
+    return rel
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -923,6 +1014,10 @@ def main():
     ap.add_argument("--exact", action="store_true", help="accepted, no effect: the default since round 5")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--extras", action="store_true",
+                    help="measure every other route too (folded opt-in, grouped, tokens, k8192, wide layers, tp_row on one GPU, prefill, the "
+                         "Llama-3-8B-shaped decode loop: ~60 s more).  Default: only the module-path rows of the compact line "
+                         "(one launch per layer at 8192^2 and 4096^2, the large-codebook formats' default route)")
     ap.add_argument("--prefetch", action="store_true")
     ap.add_argument("--steps-per-graph", type=int, default=0,
                     help="steps captured per hipGraph (0 = as many as divide K, up to 10; 1 = the rounds 1 - 3 methodology: "
@@ -938,8 +1033,11 @@ def main():
     os.dup2(2, 1)
 
     def emit(obj):
+        # the full result to gpurun_out/bench_full.json + stderr, the compact line (LAST thing on stdout) to the driver
+        obj["full"] = write_full(obj)
         sys.stdout.flush()
-        os.write(json_fd, (json.dumps(obj) + "\n").encode())
+        sys.stderr.flush()
+        os.write(json_fd, (compact_line(obj) + "\n").encode())
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -1179,7 +1277,10 @@ def main():
             ("k8192_r256", dict(H=H, mode="single", flags=EX, k=8192, kr=256), "k = 8192 + 256 (T = 21 bits), LDS-resident codebooks, reference roundings"),
             ("folded_k8192_r256", dict(H=H, mode="single", flags=0, k=8192, kr=256), "k = 8192 + 256, opt-in folded arithmetic (MFMA accumulate)"),
         )
+        core = ("single_launch_per_layer", "h4096")     # the compact line's roofline.module_path rows
         for key, kw, what in table:
+            if not a.extras and key not in core:
+                continue
             kw = dict(kw)
             try:   # (the headline line must not depend on an extra)
                 rr, *_ = bench_ring(lib, B, dev, Timer(dev), kw.pop("H"), kw.pop("mode"), kw.pop("flags"), st, wu, rg, **kw)
@@ -1192,30 +1293,36 @@ def main():
         for key, kw in (("k65536_r256", {}), ("k65536_r65536", dict(kr=65536)),     # ... the "4 bits" format of every published family
                         ("v16_k65536_r65536", dict(kr=65536, v=16))):              # "2 bits" of most families
             try:   # (the headline line must not depend on an extra)
-                ex[key] = k65536_extra(lib, B, dev, H, st, wu, rg, **kw)
+                ex[key] = k65536_extra(lib, B, dev, H, st, wu, rg, light=not a.extras, R=8 if a.extras else 4, **kw)
             except Exception as e:
                 ex[key] = {"error": f"{type(e).__name__}: {e}"[:300]}
                 torch.cuda.empty_cache()
         try:   # (the headline line must not depend on an extra)
-            ex["k65536_r256_28672x8192"] = wide_layer_extra(lib, B, dev, st, wu, rg)
+            if a.extras:
+                ex["k65536_r256_28672x8192"] = wide_layer_extra(lib, B, dev, st, wu, rg)
         except Exception as e:
             ex["k65536_r256_28672x8192"] = {"error": f"{type(e).__name__}: {e}"[:300]}
             torch.cuda.empty_cache()
         try:
+            if not a.extras:
+                raise StopIteration
             tr = bench_tp_row(lib, B, dev, Timer(dev), 0, 1, a.tp_layers, EX, st, wu, rg)
             ex["tp_row_n1"] = {"what": f"Llama-3-70B shaped decoder layers (x{a.tp_layers}, the ring of --gpus N) on ONE GPU "
                                        "through the row-parallel code path (world size 1): the strong-scaling baseline of --gpus N",
                                "GBps": tr["value"], "us_per_decoder_layer": tr["us_per_decoder_layer"],
                                "parity_rel_err_vs_cpu_oracle": tr.get("parity_rel_err_vs_cpu_oracle"),
                                "parity_per_projection": tr.get("parity_per_projection")}
+        except StopIteration:
+            pass
         except Exception as e:
             ex["tp_row_n1"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         try:
-            ex["prefill"] = prefill_extra(dev)
+            if a.extras:
+                ex["prefill"] = prefill_extra(dev)
         except Exception as e:   # the headline line must not depend on it
             ex["prefill"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         # (the opt-in folded arithmetic of the same loop: VPTQ_BENCH_FOLDED_DECODE=1 - 25 s more; profiles/r05/bench_h8192_chain.json has it)
-        for key, mode_ in (("llama3_8b_decode", "reference"),) + ((("folded_llama3_8b_decode", "folded"),) if os.environ.get("VPTQ_BENCH_FOLDED_DECODE") == "1" else ()):
+        for key, mode_ in ((("llama3_8b_decode", "reference"),) if a.extras else ()) + ((("folded_llama3_8b_decode", "folded"),) if os.environ.get("VPTQ_BENCH_FOLDED_DECODE") == "1" else ()):
             try:
                 ex[key] = model_decode_extra(arithmetic=mode_)
             except Exception as e:
