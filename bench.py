@@ -752,8 +752,6 @@ def bench_ring(lib, B, dev, timer, H, mode, flags, steps, warmup, regions, rank=
         # i + 1 reads layer i's output
         dep = mode == "chain_dep"
         cflags = flags | (B.GEMV_CHAIN_DEPENDENT if dep else 0)
-        wsb = lib.vptq_quant_gemv_chain_workspace_bytes(R, cflags)
-        ws = torch.zeros(max(wsb, 4) // 4, dtype=torch.int32, device=dev) if wsb else None
         per = R if dep else min(chain, 32, R)      # layers per call (a dependent chain is ONE call; the
         chunks = []                                # library cuts calls of more than 32 layers itself)
         for i0 in range(0, R, per):
@@ -761,6 +759,10 @@ def bench_ring(lib, B, dev, timer, H, mode, flags, steps, warmup, regions, rank=
             chunks.append((m, (B.LayerDesc * m)(*descs[i0:i0 + m]),
                            (C.c_void_p * m)(*[(ys[i - 1] if dep and i > 0 else x).data_ptr() for i in range(i0, i0 + m)]),
                            (C.c_void_p * m)(*[t.data_ptr() for t in ys[i0:i0 + m]])))
+        # arrival flags of a dependent chain / thresholds + corrections of VPTQ_GEMV_SELECTIVE; the calls follow each other on
+        # one stream and share the buffer
+        wsb = max(lib.vptq_quant_gemv_chain_workspace_bytes_for(arr, m, cflags) for m, arr, *_ in chunks)
+        ws = torch.zeros(max(wsb, 4) // 4, dtype=torch.int32, device=dev) if wsb else None
         launches = sum((m + 31) // 32 for m, *_ in chunks)
         kname = lib.vptq_quant_gemv_chain_kernel_name(chunks[0][1], chunks[0][0], tokens, cflags).decode()
         keeps.append((chunks, ws))
@@ -954,6 +956,9 @@ def compact_line(out):
         mp[name] = row
     if mp:
         r["module_path"] = mp
+    oi = rf.get("opt_in_arithmetic") or {}
+    if oi:
+        r["opt_in_arithmetic"] = {k: {kk: round(float(vv), 4) for kk, vv in v.items()} for k, v in oi.items()}
     c["roofline"] = r
     cb = out.get("cpu_baseline")
     if cb:
@@ -970,10 +975,10 @@ def compact_line(out):
         c["weak_scaling"] = {k: ws.get(k) for k in ("value", "unit", "us_per_launch", "scaling")}
     line = json.dumps(c, separators=(",", ":"))
     if len(line) >= COMPACT_LIMIT:     # never let verbosity cost the record: drop the optional parts, in this order
-        for victim in (("roofline", "module_path"), ("config", "workload"), ("cpu_baseline", "sample")):
+        for victim in (("roofline", "opt_in_arithmetic"), ("roofline", "module_path"), ("config", "workload"), ("cpu_baseline", "sample")):
             obj = c.get(victim[0]) or {}
             if victim[1] in obj:
-                obj[victim[1]] = None if victim[1] == "module_path" else _short_sample(obj[victim[1]], 60)
+                obj[victim[1]] = None if victim[1] in ("module_path", "opt_in_arithmetic") else _short_sample(obj[victim[1]], 60)
             line = json.dumps(c, separators=(",", ":"))
             if len(line) < COMPACT_LIMIT:
                 break
@@ -1261,6 +1266,10 @@ def main():
              "the same ring, one vptq_quant_gemv launch per layer - what VQuantLinear.forward issues (the reference's operator granularity)"),
             ("h4096_chain", dict(H=4096, mode="chain", flags=EX), "VQuantLinear 4096x4096 (BASELINE configs[0]/[1] shape), ring of 128 layers as 4 chain launches"),
             ("h4096", dict(H=4096, mode="single", flags=EX), "VQuantLinear 4096x4096 (BASELINE configs[0]/[1] shape), single launch per layer"),
+            ("selective_chain", dict(H=H, mode="chain", flags=B.GEMV_SELECTIVE),
+             "OPT-IN selective arithmetic (vptq_amd.set_arithmetic('selective'), round 6), the headline workload: the folded form with the "
+             "reference's roundings on the 128-column blocks an activation dominates (|f16(s x)| >= 6 rms) - 2 of 12 300 checkpoint-like layers "
+             "above the bar at 1.00e-3 / 1.09e-3 against 30 of 4100 for the folded form, profiles/r06/count_chain_*.txt"),
             ("grouped_x4", dict(H=H, mode="grouped", flags=EX), "4 independent layers per launch (vptq_quant_gemv_grouped), us per LAYER = us_per_launch / 4"),
             ("folded_chain", dict(H=H, mode="chain", flags=0),
              "OPT-IN folded arithmetic (vptq_amd.set_arithmetic('folded')), the headline workload: 32 layers per persistent launch (the headline of rounds 3-4)"),
@@ -1277,7 +1286,7 @@ def main():
             ("k8192_r256", dict(H=H, mode="single", flags=EX, k=8192, kr=256), "k = 8192 + 256 (T = 21 bits), LDS-resident codebooks, reference roundings"),
             ("folded_k8192_r256", dict(H=H, mode="single", flags=0, k=8192, kr=256), "k = 8192 + 256, opt-in folded arithmetic (MFMA accumulate)"),
         )
-        core = ("single_launch_per_layer", "h4096")     # the compact line's roofline.module_path rows
+        core = ("single_launch_per_layer", "h4096", "selective_chain")     # the compact line's roofline.module_path / opt_in rows
         for key, kw, what in table:
             if not a.extras and key not in core:
                 continue
@@ -1354,6 +1363,13 @@ def main():
         if "vqlinear_us_per_token" in dec:
             mp["llama3_8b_decode_step_folded_opt_in"] = {k_: dec.get(k_) for k_ in ("tokens_per_s", "vqlinear_us_per_token", "vqlinear_GBps")}
         out["roofline"]["module_path"] = mp
+        # the opt-in arithmetics on the headline workload (never `value`): selective (round 6) and, with --extras, folded
+        oi = {}
+        for key, name in (("selective_chain", "selective"), ("folded_chain", "folded")):
+            e = ex.get(key) or {}
+            if "us_per_layer" in e:
+                oi[name] = {"GBps": e["GBps"], "frac": e["frac_of_8TBps"], "us_per_layer": e["us_per_layer"]}
+        out["roofline"]["opt_in_arithmetic"] = oi
     if rank == 0:
         emit(out)
     if dist is not None:

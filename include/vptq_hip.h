@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define VPTQ_ABI_VERSION 9
+#define VPTQ_ABI_VERSION 10
 
 #if defined(__GNUC__)
 #define VPTQ_API __attribute__((visibility("default")))
@@ -97,7 +97,16 @@ enum {
    * tokens): testing / A-B */
   VPTQ_GEMV_FORCE_BATCHED = 1 << 7,
   /* vptq_quant_gemv_sliced_grouped (ABI >= 9): the n descriptors are COLUMN PARTS of one layer - see there */
-  VPTQ_GEMV_COLUMN_PARTS = 1 << 8
+  VPTQ_GEMV_COLUMN_PARTS = 1 << 8,
+  /* SELECTIVE roundings (ABI >= 10): the folded form, with the reference's three roundings per weight (VPTQ_GEMV_EXACT's
+   * arithmetic) on the activation columns that dominate the token - |f16(scale_g x_g)| >= 6 x the rms of f16(scale x) over the
+   * layer's columns.  The folded form's distance to the reference is a sum of per-column rounding errors that average out over
+   * thousands of columns when the activations are dense and do not when a handful of channels carry the token (massive
+   * activations): those columns are rebuilt bit-exactly, the rest stays folded.  Kernels that implement it: the persistent
+   * chain launch (fp16, independent layers; needs vptq_quant_gemv_chain_workspace_bytes(n, flags) of workspace for the
+   * thresholds) and the persistent MFMA kernel (fp16, 1 token); every other kernel / layer takes VPTQ_GEMV_EXACT
+   * instead (always at least as close to the reference).  With VPTQ_GEMV_EXACT set as well, EXACT wins. */
+  VPTQ_GEMV_SELECTIVE = 1 << 9
 };
 
 /* most tokens vptq_quant_gemv accepts (fp16 layers of the canonical format; every other layer:

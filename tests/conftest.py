@@ -46,3 +46,15 @@ def folded_arithmetic():
     vptq_amd.set_arithmetic("folded")
     yield
     vptq_amd.set_arithmetic(before)
+
+
+@pytest.fixture
+def selective_arithmetic():
+    """`vptq_amd.set_arithmetic("selective")` for the duration of a test (round 6): the folded form with the reference's roundings on
+    the blocks of columns an activation dominates - VPTQ_GEMV_SELECTIVE where a kernel implements it (the persistent chain launch),
+    the reference's roundings everywhere else."""
+    import vptq_amd
+    before = vptq_amd.arithmetic()
+    vptq_amd.set_arithmetic("selective")
+    yield
+    vptq_amd.set_arithmetic(before)

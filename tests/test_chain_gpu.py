@@ -337,3 +337,117 @@ def test_chain_takes_layers_with_an_input_permutation(dev):
     torch.cuda.synchronize()
     for a, b in zip(ys, yg):
         assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+
+
+# ---- VPTQ_GEMV_SELECTIVE (round 6): folded form + the reference's roundings on the blocks of columns an activation dominates ----
+def _spiky(x_bits, dt, cols, gain):
+    """activation bits with `cols` columns multiplied by `gain` (massive-activation channels)"""
+    x = vo.to_f32(x_bits, dt).copy()
+    x[..., cols] *= gain
+    return vo.from_f32(x.astype(np.float32), dt)
+
+
+def test_selective_chain_vs_oracle(dev, selective_arithmetic):
+    """every edge shape of the stream in the selective arithmetic, dense activations and activations with massive channels
+    (which the folded form alone does not survive: profiles/r05/gate_count_*_folded_opt_in.txt): within the bar of the oracle"""
+    from vptq_amd.ops.chain import GemvChain
+    from vptq_amd import _backend as B
+    Ls, ms, xs = _build(SHAPES, "f16", dev)
+    chain = GemvChain(ms)
+    assert chain.kernel_name(1, CHAIN) == "gemv_k256c_kernel"
+    for variant in ("dense", "massive"):
+        xv = xs if variant == "dense" else [_spiky(x, "f16", [3, x.shape[-1] // 2 + 5, x.shape[-1] - 1], 40.0) for x in xs]
+        xt = [bits_to_tensor(x, "f16", dev).reshape(x.shape) for x in xv]
+        ys = chain(xt, flags=CHAIN)
+        torch.cuda.synchronize()
+        for L, m, x, y in zip(Ls, ms, xv, ys):
+            flag = m._descriptor()[9]
+            assert flag in (B.GEMV_SELECTIVE, B.GEMV_EXACT)   # (EXACT: the load-time gate refused the layer)
+            err = rel_err(tensor_to_bits(y), vo.forward(L, x), "f16")
+            assert err <= 1e-3, f"{variant} {L.in_features}x{L.out_features}: {err:.3e}"
+
+
+def test_selective_hot_blocks_take_the_reference_roundings(dev, folded_arithmetic):
+    """activations that are ZERO outside a few massive columns: every column that contributes sits in a hot block, so the
+    selective launch must reproduce the launch with VPTQ_GEMV_EXACT (same weights bit for bit; fp32 sums of <= 3 terms in another
+    order) - and the folded launch of the same inputs must NOT (else the test proves nothing)"""
+    from vptq_amd.ops.chain import GemvChain
+    from vptq_amd import _backend as B
+    Ls, ms, xs = _build(SHAPES[:6], "f16", dev)
+    xt = []
+    for x in xs:
+        I = x.shape[-1]
+        xf = np.zeros((1, 1, I), dtype=np.float32)
+        for c, v in ((1, 23.5), (I // 3, -17.25), (I - 2, 9.125)):
+            xf[0, 0, c] = v
+        xt.append(bits_to_tensor(vo.from_f32(xf, "f16"), "f16", dev).reshape(1, 1, I))
+    chain = GemvChain(ms)
+    y_sel = chain(xt, flags=CHAIN | B.GEMV_SELECTIVE | B.GEMV_OUT_F32)
+    y_ex = chain(xt, flags=CHAIN | B.GEMV_EXACT | B.GEMV_OUT_F32)
+    y_fo = chain(xt, flags=CHAIN | B.GEMV_OUT_F32)
+    torch.cuda.synchronize()
+    differs = 0
+    for L, a, b, c in zip(Ls, y_sel, y_ex, y_fo):
+        den = float(b.abs().max())
+        assert float((a - b).abs().max()) <= 2e-6 * den, f"{L.in_features}x{L.out_features}"   # (fp32 summation order only)
+        differs += int(float((c - b).abs().max()) > 1e-5 * den)
+    assert differs >= 4, differs
+    # ... and rounded: bit-identical to the exact launch
+    for a, b in zip(chain(xt, flags=CHAIN | B.GEMV_SELECTIVE), chain(xt, flags=CHAIN | B.GEMV_EXACT)):
+        assert float((a.view(torch.int16) == b.view(torch.int16)).float().mean()) >= 0.999
+
+
+def test_selective_dense_activations_run_the_folded_loop(dev, folded_arithmetic):
+    """without a dominant column nothing is hot: the selective launch IS the folded launch, bit for bit"""
+    from vptq_amd.ops.chain import GemvChain
+    from vptq_amd import _backend as B
+    Ls, ms, _ = _build(SHAPES[:6], "f16", dev)
+    # +-1 activations: |f16(s x)| = |s|, and the layers' scales stay far below 6 x their rms
+    xt = []
+    for i, L in enumerate(Ls):
+        rng = np.random.default_rng(77 + i)
+        xf = np.where(rng.random((1, 1, L.in_features)) < 0.5, -1.0, 1.0).astype(np.float32)
+        xt.append(bits_to_tensor(vo.from_f32(xf, "f16"), "f16", dev).reshape(xf.shape))
+    for m in ms:
+        s = m.weight_scale.float().abs()
+        assert float(s.max()) < 5.5 * float(s.pow(2).mean().sqrt()), "pick another seed: a scale outlier makes a column hot"
+    chain = GemvChain(ms)
+    for a, b in zip(chain(xt, flags=CHAIN | B.GEMV_SELECTIVE), chain(xt, flags=CHAIN)):
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+
+
+def test_selective_without_workspace_or_kernel_is_exact(dev, folded_arithmetic):
+    """VPTQ_GEMV_SELECTIVE where nothing implements it - no workspace for the chain's thresholds, the one-layer entry point, bf16 -
+    is VPTQ_GEMV_EXACT (always at least as close to the reference); EXACT wins when both are set"""
+    from vptq_amd import _backend as B
+    Ls, ms, xs = _build(SHAPES[:3], "f16", dev)
+    xt = [bits_to_tensor(x, "f16", dev).reshape(x.shape) for x in xs]
+    n = len(ms)
+    descs = (B.LayerDesc * n)(*[m._descriptor()[1] for m in ms])
+    xp, yp = (C.c_void_p * n)(), (C.c_void_p * n)()
+
+    def run(flags, ws=None):
+        ys = [torch.empty(1, 1, m.out_features, dtype=torch.float16, device=dev) for m in ms]
+        for i in range(n):
+            xp[i], yp[i] = xt[i].data_ptr(), ys[i].data_ptr()
+        rc = B.lib().vptq_quant_gemv_chain(descs, n, xp, yp, 1, flags, None if ws is None else ws.data_ptr(),
+                                           0 if ws is None else ws.numel(), B.current_stream_ptr(dev))
+        assert rc == 0, B.lib().vptq_last_error()
+        torch.cuda.synchronize()
+        return ys
+    want = run(CHAIN | B.GEMV_EXACT)
+    for got in (run(CHAIN | B.GEMV_SELECTIVE), run(CHAIN | B.GEMV_SELECTIVE | B.GEMV_EXACT)):
+        for a, b in zip(got, want):
+            assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+    need = B.lib().vptq_quant_gemv_chain_workspace_bytes_for(descs, n, B.GEMV_SELECTIVE)
+    assert need >= 256 + sum(4 * 8 * ((m.out_features + 7) // 8) for m in ms)
+    assert B.lib().vptq_quant_gemv_chain_workspace_bytes_for(descs, n, B.GEMV_SELECTIVE | B.GEMV_EXACT) == 0
+    ws = torch.zeros(need, dtype=torch.uint8, device=dev)
+    sel = run(CHAIN | B.GEMV_SELECTIVE, ws)
+    for L, x, y in zip(Ls, xs, sel):
+        assert rel_err(tensor_to_bits(y), vo.forward(L, x), "f16") <= 1e-3
+    # the one-layer entry point
+    for m, x, w in zip(ms, xt, want):
+        a = gemv_abi(m, x, B.GEMV_SELECTIVE)
+        b = gemv_abi(m, x, B.GEMV_EXACT)
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16))

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, s), f"{s} declared in include/vptq_hip.h but not exported"
     assert sorted(B.EXPORTS) == syms, "python binding table out of sync with the header"
     lib.vptq_abi_version.restype = ctypes.c_int
-    assert lib.vptq_abi_version() == B.ABI_VERSION == 9
+    assert lib.vptq_abi_version() == B.ABI_VERSION == 10
 
 
 def test_ctypes_struct_layout_matches_header():

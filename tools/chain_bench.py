@@ -5,7 +5,7 @@ replayed interleaved on the same box: us per layer for
   t1     : one launch of the chain kernel (gemv_k256c) per layer
   chainN : the ring as launches of N layers each (independent layers)
   dep    : the ring as ONE dependent chain (x of layer i + 1 is y of layer i)
-  a trailing x (singlex, chain32x): the reference's roundings (VPTQ_GEMV_EXACT)
+  a trailing x (singlex, chain32x): the reference's roundings (VPTQ_GEMV_EXACT); chain32s: VPTQ_GEMV_SELECTIVE
 --soak S: every mode additionally replayed back to back for S seconds with package power / shader clock sampled
 python tools/chain_bench.py --hidden 8192 [--rows O] [--ring 32] [--reps 5] [--libs name=path,...]"""
 import argparse
@@ -72,7 +72,7 @@ def main():
 
     modes = {}
     for name in a.modes.split(","):
-        fl = B.GEMV_EXACT if name.endswith("x") else 0
+        fl = B.GEMV_EXACT if name.endswith("x") else (B.GEMV_SELECTIVE if name.startswith("chain") and name.endswith("s") else 0)
         base = name[:-1] if fl else name
         if base == "single":
             modes[name] = (lambda fl: (lambda: run_single(fl)))(fl)

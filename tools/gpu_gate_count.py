@@ -106,13 +106,80 @@ def make_x(m, kind, dt, dev, g):
     return x.to(dt).view(1, 1, I)
 
 
+def main_chain(a):
+    """the same families and activation kinds through the persistent chain launch, one arithmetic per run"""
+    from vptq_amd.ops.chain import GemvChain
+    dev = torch.device("cuda", 0)
+    assert a.dtype == "f16", "the chain kernel takes the reference's roundings (whole or selective) for fp16 only"
+    dt, bar = torch.float16, 1e-3
+    B.set_arithmetic("folded")          # (descriptor flags: the call's flags decide, not the load-time gate's EXACT)
+    fl = {"chain-selective": B.GEMV_SELECTIVE, "chain-folded": 0, "chain-exact": B.GEMV_EXACT}[a.route] | B.GEMV_FORCE_MFMA
+    g = torch.Generator(device=dev).manual_seed(7000 + a.seed)
+    rng = np.random.default_rng(a.seed)
+    shapes = [s for s in SHAPES if s[0] * s[1] <= a.max_elems]
+    per = (a.layers + len(FAMILIES) - 1) // len(FAMILIES)
+    t0 = time.time()
+    total, done = 0, 0
+    rows = []
+    for fam in FAMILIES:
+        errs, bitid, gated, probes = [], [], 0, []
+        i = 0
+        while i < per:
+            nb = min(8, per - i)
+            ms, xs = [], []
+            for j in range(nb):
+                I, O = shapes[int(rng.integers(0, len(shapes)))]
+                m = make(I, O, fam, dt, dev, g)
+                ms.append(m)
+                xs.append(make_x(m, XKINDS[(done + i + j) % len(XKINDS)], dt, dev, g))
+            ch = GemvChain(ms)
+            name = ch.kernel_name(flags=fl)
+            assert name == "gemv_k256c_kernel", name
+            gated += sum(int(bool(m._descriptor()[9])) for m in ms)
+            if a.probe:
+                probes += [float(B.folded_probe_distance(m._descriptor()[1], m.in_features, m.out_features, m.weight_bias.data, dt, dev)) for m in ms]
+            ys = ch(xs, flags=fl)
+            for m, x, y in zip(ms, xs, ys):
+                W = m.dequant()
+                r16 = (W.double() @ x.reshape(-1).double()).to(dt)
+                den = r16.double().abs().max().clamp_min(1e-30)
+                errs.append(float((y.reshape(-1).double() - r16.double()).abs().max() / den))
+                bitid.append(float((y.reshape(-1).view(torch.int16) == r16.view(torch.int16)).float().mean()))
+                del W
+            del ms, xs, ch, ys
+            i += nb
+        done += per
+        e = np.array(errs)
+        ex = int((e > bar).sum())
+        total += ex
+        rows.append((fam, len(e), gated, e.max(), np.quantile(e, 0.999), np.median(e), ex, float(np.median(bitid)), float(np.min(bitid))))
+        if a.probe:
+            pr = np.array(probes)
+            print(f"# {fam}: probe distance quantiles 50/90/99/max = {np.quantile(pr, 0.5):.2e} {np.quantile(pr, 0.9):.2e} {np.quantile(pr, 0.99):.2e} {pr.max():.2e}; "
+                  f"share above 5e-4 / 5.5e-4 / 6e-4 / 6.5e-4 / 7e-4: " + " ".join(f"{float((pr > t).mean()):.3f}" for t in (5e-4, 5.5e-4, 6e-4, 6.5e-4, 7e-4))
+                  + "; layers above the bar (error, probe distance): " + str([(f"{e[k]:.2e}", f"{pr[k]:.2e}") for k in np.nonzero(e > bar)[0]]), flush=True)
+        print(f"# {fam}: {per} layers done after {time.time() - t0:.0f} s", flush=True)
+    print(f"route {a.route} (one persistent launch per 8 layers), dtype {a.dtype}, bar {bar:g}, {done} layers, seed {a.seed}")
+    print(f"{'family':14s} {'layers':>6s} {'gated':>6s} {'worst':>9s} {'p99.9':>9s} {'median':>9s} {'> bar':>6s} {'bit-identical: median':>22s} {'min':>6s}")
+    for r in rows:
+        print(f"{r[0]:14s} {r[1]:6d} {r[2]:6d} {r[3]:9.2e} {r[4]:9.2e} {r[5]:9.2e} {r[6]:6d} {r[7]:22.4f} {r[8]:6.4f}")
+    print(f"exceedances: {total}")
+    return 1 if total else 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--layers", type=int, default=4096)
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--max-elems", type=float, default=70e6, help="largest in x out drawn (time)")
+    ap.add_argument("--route", default="module", choices=["module", "chain-selective", "chain-folded", "chain-exact"],
+                    help="module: VQuantLinear.forward in the process's arithmetic; chain-*: batches of 8 layers through ONE persistent "
+                         "launch (vptq_quant_gemv_chain, FORCE_MFMA) with VPTQ_GEMV_SELECTIVE / no flag / VPTQ_GEMV_EXACT (round 6)")
+    ap.add_argument("--probe", action="store_true", help="chain routes: also the load-time gate's probe distance of every layer")
     a = ap.parse_args()
+    if a.route != "module":
+        return main_chain(a)
     dev = torch.device("cuda", 0)
     dt = torch.float16 if a.dtype == "f16" else torch.bfloat16
     bar = 1e-3 if a.dtype == "f16" else 8e-3

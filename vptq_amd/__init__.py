@@ -8,6 +8,6 @@ __version__ = "0.0.5.post1"
 
 from vptq_amd import ops  # noqa: E402
 from vptq_amd.layers import AutoModelForCausalLM, VQuantLinear  # noqa: E402
-from vptq_amd._backend import arithmetic, set_arithmetic  # noqa: E402  ("reference" by default, "folded" = the fast form)
+from vptq_amd._backend import arithmetic, set_arithmetic  # noqa: E402  ("reference" by default; "selective" / "folded" = the opt-in fast forms)
 
 __all__ = ["AutoModelForCausalLM", "VQuantLinear", "ops", "arithmetic", "set_arithmetic", "__version__"]

@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # VPTQ_HIP_LIB: load another build of the library (A/B runs of tools/)
 LIB_PATH = os.environ.get("VPTQ_HIP_LIB") or os.path.join(_HERE, "libvptq_hip.so")
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 DTYPE_F16, DTYPE_BF16 = 0, 1
 GEMV_FAST_MATH = 1 << 0
 GEMV_FORCE_GENERIC = 1 << 1
@@ -31,6 +31,7 @@ GEMV_ANY_FORMAT_TOKENS = 8  # the fused GEMV is the faster path for every format
 GEMV_CHAIN_DEPENDENT = 1 << 6  # vptq_quant_gemv_chain: layer i + 1 reads what layer i wrote
 GEMV_FORCE_BATCHED = 1 << 7    # the one-pass batched-decode kernel wherever eligible (tests, A/B)
 GEMV_COLUMN_PARTS = 1 << 8     # vptq_quant_gemv_sliced_grouped: the descriptors are column ranges of ONE layer (shared y / workspace)
+GEMV_SELECTIVE = 1 << 9        # folded form + the reference's roundings on the activation columns that dominate the token (ABI 10)
 # return codes (include/vptq_hip.h)
 E_NULL, E_SHAPE, E_UNSUPPORTED, E_ALIGN, E_TOKENS, E_WORKSPACE = -1, -2, -3, -4, -5, -6
 GROUP_MAX = 64
@@ -261,22 +262,40 @@ def _derived(owner: torch.Tensor, name: str, key, build):
 # checkpoint-like fp16 layers at 1.05 - 1.26e-3 and 1 of 500 bf16 layers at 9.8e-3 against bars of 1e-3 / 8e-3
 # (tools/gpu_gate_count.py, profiles/r05/gate_count_*_folded_default.txt).  No load-time gate can see that coming - it
 # depends on the activation - so the bar-safe form is the default and the fast one is the user's decision.
+# "selective" (opt-in, round 6: VPTQ_ARITHMETIC=selective, set_arithmetic("selective")): the reference's roundings wherever an
+# activation column dominates the token (|f16(s x)| >= 6 x the rms over the layer's columns: blocks of 128 columns that hold such
+# a column are rebuilt bit-exactly), the folded form on the rest - VPTQ_GEMV_SELECTIVE, where a kernel implements it (the
+# persistent chain launch, fp16); every other route takes the reference's roundings, as do the layers the load-time gate below
+# refuses.  It removes the folded form's activation-dependent failures (chain route, same ten families x five activation
+# kinds: 30 of 4100 layers above the bar folded, 2 of 12 300 selective at 1.00e-3 / 1.09e-3 - both dense-activation tail
+# events no run-time test can see; profiles/r06/count_chain_*.txt) at 95 % of its speed, and is still not bit-equivalent:
+# ~55 - 65 % of the outputs bit-identical, worst ~9.8e-4 = one flip of the last bit at the top binade.
 _ARITH = {"folded": os.environ.get("VPTQ_ARITHMETIC", "reference").strip().lower() in ("folded", "fast") or
-          os.environ.get("VPTQ_FOLDED", "0") == "1", "generation": 0}
+          os.environ.get("VPTQ_FOLDED", "0") == "1",
+          "selective": os.environ.get("VPTQ_ARITHMETIC", "reference").strip().lower() == "selective", "generation": 0}
 
 
 def set_arithmetic(mode: str) -> None:
-    """"reference" (default) or "folded"; layers rebuild their descriptors (and drop or build their sliced layouts) at their
-    next call.  Not inside a stream capture."""
+    """"reference" (default), "selective" or "folded"; layers rebuild their descriptors (and drop or build their sliced
+    layouts) at their next call.  Not inside a stream capture."""
     mode = mode.strip().lower()
-    if mode not in ("reference", "exact", "folded", "fast"):
-        raise ValueError("arithmetic is 'reference' or 'folded'")
+    if mode not in ("reference", "exact", "selective", "folded", "fast"):
+        raise ValueError("arithmetic is 'reference', 'selective' or 'folded'")
     _ARITH["folded"] = mode in ("folded", "fast")
+    _ARITH["selective"] = mode == "selective"
     _ARITH["generation"] += 1
 
 
 def arithmetic() -> str:
-    return "folded" if _ARITH["folded"] else "reference"
+    return "folded" if _ARITH["folded"] else ("selective" if _ARITH["selective"] else "reference")
+
+
+def layer_arithmetic_flags(gate_passed: bool) -> int:
+    """flags of a layer's launches in the process's arithmetic: VPTQ_GEMV_EXACT (reference; any layer the load-time gate refuses),
+    VPTQ_GEMV_SELECTIVE (selective) or 0 (folded)"""
+    if not gate_passed:
+        return GEMV_EXACT
+    return 0 if _ARITH["folded"] else (GEMV_SELECTIVE if _ARITH["selective"] else GEMV_EXACT)
 
 
 def arithmetic_generation() -> int:
@@ -343,10 +362,10 @@ def folded_form_is_safe(indices, centroids, res_centroids, weight_scale, weight_
                         in_features: int = 0, out_features: int = 0) -> bool:
     """One device -> host read per call: call it once per set of tensors (descriptor build / functional-API cache).
     With `desc` (the layer's descriptor): the measured gate; without: only the pre-filter."""
+    if not (_ARITH["folded"] or _ARITH["selective"]):
+        return False   # the default: the reference's roundings for EVERY layer (layers without scale / bias too: f16(c + r) is a rounding)
     if weight_scale is None or weight_bias is None or not weight_scale.is_cuda:
         return True
-    if not _ARITH["folded"]:
-        return False   # the default: the reference's roundings for every layer
     with torch.no_grad():
         if indices is not None and indices.dim() == 3:
             if indices.shape[1] < FOLDED_MIN_DISTINCT_ROWS or distinct_index_rows(indices) < FOLDED_MIN_DISTINCT_ROWS:

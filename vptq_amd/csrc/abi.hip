@@ -90,6 +90,15 @@ int validate_layer(const VptqLayerDesc* d) {
   return VPTQ_OK;
 }
 
+// VPTQ_GEMV_SELECTIVE where a kernel does not implement it = VPTQ_GEMV_EXACT (always at least as close to the reference);
+// EXACT wins when both are set
+int selective_as_exact(int flags) {
+  return (flags & VPTQ_GEMV_SELECTIVE) ? ((flags & ~VPTQ_GEMV_SELECTIVE) | VPTQ_GEMV_EXACT) : flags;
+}
+int drop_redundant_selective(int flags) {
+  return (flags & VPTQ_GEMV_EXACT) ? (flags & ~VPTQ_GEMV_SELECTIVE) : flags;
+}
+
 }  // namespace
 
 extern "C" {
@@ -193,6 +202,7 @@ int vptq_quant_gemv(const VptqLayerDesc* d, const void* x, void* y, int tokens, 
                     void* workspace, size_t workspace_bytes, void* stream) {
   int rc = validate_layer(d);
   if (rc) return rc;
+  flags = selective_as_exact(flags);
   if (!x || !y) return fail(VPTQ_E_NULL, "x / y is NULL");
   // (a workspace is never required: without it the call takes the kernels that need none)
   const bool have_ws = workspace && (((uintptr_t)workspace) & 15) == 0 &&
@@ -253,6 +263,7 @@ int vptq_quant_gemv_grouped(const VptqLayerDesc* descs, int n, const void* const
   if (n < 1 || n > VPTQ_GROUP_MAX) return fail(VPTQ_E_SHAPE, "n %d outside [1, %d]", n, VPTQ_GROUP_MAX);
   if (tokens < 1 || tokens > VPTQ_GEMV_MAX_TOKENS_ANY)
     return fail(VPTQ_E_TOKENS, "tokens %d outside [1, %d]", tokens, VPTQ_GEMV_MAX_TOKENS_ANY);
+  flags = selective_as_exact(flags);
   bool all_fast = !(flags & VPTQ_GEMV_FORCE_GENERIC);
   bool same_perm = true;  // one instantiation serves the whole group
   for (int i = 0; i < n; ++i) {
@@ -293,9 +304,11 @@ int vptq_quant_gemv_grouped(const VptqLayerDesc* descs, int n, const void* const
 static bool chain_one_kernel(const VptqLayerDesc* descs, int n, const void* const* x, int tokens, int flags) {
   if (tokens != 1 || (flags & (VPTQ_GEMV_FORCE_GENERIC | VPTQ_GEMV_FORCE_VALU))) return false;
   const bool exact = (flags & VPTQ_GEMV_EXACT) != 0, dep = (flags & VPTQ_GEMV_CHAIN_DEPENDENT) != 0;
+  const bool sel = !exact && (flags & VPTQ_GEMV_SELECTIVE) != 0;
   for (int i = 0; i < n; ++i) {
     if (descs[i].dtype != descs[0].dtype || !vptq::gemv_k256c_eligible(descs[i], tokens)) return false;
     if (exact && !vptq::gemv_k256c_exact_ok(descs[i], dep)) return false;   // (bf16 / dependent: layer by layer)
+    if (sel && !vptq::gemv_k256c_selective_ok(descs[i], dep)) return false;
     if (x && (((uintptr_t)x[i]) & 3) != 0) return false;
   }
   // a chain that cannot keep the workgroups busy (one small layer, q / k / v of a small model) is better
@@ -308,6 +321,15 @@ static bool chain_one_kernel(const VptqLayerDesc* descs, int n, const void* cons
   return true;
 }
 
+// SELECTIVE (independent lists): per launch of <= 32 layers a header + one float per output (gemv_k256c.hip), in front of
+// everything else
+static size_t chain_sel_bytes(const VptqLayerDesc* descs, int n, int flags) {
+  flags = drop_redundant_selective(flags);
+  if (!(flags & VPTQ_GEMV_SELECTIVE) || (flags & VPTQ_GEMV_CHAIN_DEPENDENT) || !descs || n < 1) return 0;
+  size_t b = 0;
+  for (int i0 = 0; i0 < n; i0 += 32) b += vptq::gemv_k256c_selective_bytes(descs + i0, n - i0 < 32 ? n - i0 : 32);
+  return b;
+}
 size_t vptq_quant_gemv_chain_workspace_bytes(int n, int flags) {
   return (flags & VPTQ_GEMV_CHAIN_DEPENDENT) && n > 0 ? (size_t)n * 1024 : 0;   // 256 arrival flags per layer
 }
@@ -316,6 +338,7 @@ size_t vptq_quant_gemv_chain_workspace_bytes(int n, int flags) {
 size_t vptq_quant_gemv_chain_workspace_bytes_for(const VptqLayerDesc* descs, int n, int flags) {
   size_t b = vptq_quant_gemv_chain_workspace_bytes(n, flags);
   if (!descs || n < 1 || (flags & VPTQ_GEMV_CHAIN_DEPENDENT)) return b;
+  b += chain_sel_bytes(descs, n, flags);
   for (int i = 0; i < n; ++i) b += vptq::gemv_k256c_perm_bytes(descs[i]);
   return b;
 }
@@ -379,6 +402,22 @@ int vptq_quant_gemv_chain(const VptqLayerDesc* descs, int n, const void* const* 
     if (!x[i] || !y[i]) return fail(VPTQ_E_NULL, "x[%d] / y[%d] is NULL", i, i);
   }
   const bool dependent = (flags & VPTQ_GEMV_CHAIN_DEPENDENT) != 0;
+  flags = drop_redundant_selective(flags);
+  // SELECTIVE: the thresholds live in the first chain_thr_bytes of the workspace; without it (or for a dependent list) the
+  // call takes the reference's roundings everywhere
+  char* thr_ws = nullptr;
+  {
+    const size_t tb = chain_sel_bytes(descs, n, flags);
+    if (flags & VPTQ_GEMV_SELECTIVE) {
+      if (tb > 0 && workspace && workspace_bytes >= tb && (((uintptr_t)workspace) & 255) == 0) {
+        thr_ws = (char*)workspace;
+        workspace = (char*)workspace + tb;
+        workspace_bytes -= tb;
+      } else {
+        flags = selective_as_exact(flags);
+      }
+    }
+  }
   const int lflags = flags & ~VPTQ_GEMV_CHAIN_DEPENDENT;
   hipStream_t st = (hipStream_t)stream;
   // Layers with an input permutation in an independent list: with enough workspace for x[perm] the list still runs in the
@@ -407,7 +446,8 @@ int vptq_quant_gemv_chain(const VptqLayerDesc* descs, int n, const void* const* 
           const int m = n - i0 < 32 ? n - i0 : 32;
           hipError_t e = vptq::launch_permute_x(descs + i0, m, x + i0, xp.data() + i0, st);
           if (e != hipSuccess) return hip_fail(e, "permute_x launch");
-          e = vptq::launch_gemv_k256c(dd.data() + i0, m, xx.data() + i0, y + i0, lflags, false, nullptr, st);
+          e = vptq::launch_gemv_k256c(dd.data() + i0, m, xx.data() + i0, y + i0, lflags, false, (uint32_t*)thr_ws, st);
+          if (thr_ws) thr_ws += vptq::gemv_k256c_selective_bytes(dd.data() + i0, m);
           if (e != hipSuccess) return hip_fail(e, "gemv_k256c launch");
         }
         return VPTQ_OK;
@@ -440,7 +480,9 @@ int vptq_quant_gemv_chain(const VptqLayerDesc* descs, int n, const void* const* 
     const int m = n - i0 < 32 ? n - i0 : 32;
     const hipError_t e = vptq::launch_gemv_k256c(descs + i0, m, x + i0, y + i0, lflags, dependent,
                                                  dependent ? (uint32_t*)workspace + (size_t)i0 * 256
+                                                           : thr_ws ? (uint32_t*)thr_ws
                                                            : (prof_ws ? (uint32_t*)workspace : nullptr), st);
+    if (thr_ws) thr_ws += vptq::gemv_k256c_selective_bytes(descs + i0, m);
     if (dependent && e == hipErrorCooperativeLaunchTooLarge) {
       // the runtime does not confirm that every workgroup of the dependent chain is resident at once (gemv_k256c.hip:launch_c):
       // one launch per layer, stream order is the dependency - slower, never wrong (layers already walked are walked again)

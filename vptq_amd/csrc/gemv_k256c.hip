@@ -102,23 +102,26 @@ static_assert(kCDepth >= 2 && kCDepth <= 6, "queue depth");
 constexpr int kCSlots = 4;                           // cross-wave partial-sum slots
 constexpr uint32_t kCImgBytes = 65536;               // 256 rows x 16 units x 16 B
 constexpr uint32_t kCXsOff = 2 * kCImgBytes;         // wave-private activation slots
-// folded form: 256 bytes per wave (f16(s x) of its 128 columns); reference roundings: x, scale, bias side by side
-constexpr uint32_t c_xs_wave(bool exact) { return exact ? 768u : 256u; }
-constexpr uint32_t c_red_off(bool exact) { return kCXsOff + kCWaves * c_xs_wave(exact); }
-constexpr uint32_t c_redb_off(bool exact) { return c_red_off(exact) + kCSlots * kCWaves * kCOutW * 4; }
-constexpr uint32_t c_cnt_off(bool exact) { return c_redb_off(exact) + kCSlots * kCWaves * 4; }
+// arithmetic of a launch: folded (sum (c + r) f16(s x) + sum b x), the reference's roundings per weight, or SELECTIVE:
+// the folded form, with the reference's roundings wherever an activation column dominates (kCModeSel below)
+constexpr int kCModeFolded = 0, kCModeExact = 1, kCModeSel = 2;
+// folded form (and selective): 256 bytes per wave (f16(s x) of its 128 columns); reference roundings: x, scale, bias side by side
+constexpr uint32_t c_xs_wave(int mode) { return mode == kCModeExact ? 768u : 256u; }
+constexpr uint32_t c_red_off(int mode) { return kCXsOff + kCWaves * c_xs_wave(mode); }
+constexpr uint32_t c_redb_off(int mode) { return c_red_off(mode) + kCSlots * kCWaves * kCOutW * 4; }
+constexpr uint32_t c_cnt_off(int mode) { return c_redb_off(mode) + kCSlots * kCWaves * 4; }
 // profiling build 2: consume start / end stamps of kCTlSteps steps per wave (a timeline of who computes when)
 [[maybe_unused]] constexpr int kCTlFirst = 16, kCTlSteps = 32;
-constexpr uint32_t c_tl_off(bool exact) { return c_cnt_off(exact) + 64; }
-constexpr uint32_t c_lds_bytes(bool exact) {
+constexpr uint32_t c_tl_off(int mode) { return c_cnt_off(mode) + 64; }
+constexpr uint32_t c_lds_bytes(int mode) {
 #if VPTQ_K256C_PROF >= 2
-  return c_tl_off(exact) + kCWaves * kCTlSteps * 8;
+  return c_tl_off(mode) + kCWaves * kCTlSteps * 8;
 #else
-  return c_cnt_off(exact) + 64;
+  return c_cnt_off(mode) + 64;
 #endif
 }
 [[maybe_unused]] constexpr int kCProfWords = 64;   // 8-byte words of profile output per wave
-static_assert(c_lds_bytes(false) <= 163840 && (VPTQ_K256C_PROF >= 2 || c_lds_bytes(true) <= 163840), "LDS");
+static_assert(c_lds_bytes(kCModeFolded) <= 163840 && (VPTQ_K256C_PROF >= 2 || c_lds_bytes(kCModeExact) <= 163840), "LDS");
 constexpr int kCFlagStride = 256;   // DEP: arrival flags per layer (one per workgroup)
 
 // timing-only ablations (results wrong): bit 0 no MFMAs, bit 1 no gathers, bit 2 no x / scale /
@@ -274,13 +277,27 @@ static __device__ __forceinline__ void c_for_slots(F&& f) {
 // EXACT: every weight rebuilt with the reference CPU path's three roundings r16(r16(r16(c + r) s) + b)
 // (vptq/ops/quant_gemm.py:143-158; bit-identical to vptq_dequant), fp32 accumulation of x w by the same MFMAs
 // - VPTQ_GEMV_EXACT inside the chain launch (fp16, independent layers).
-template <typename DT, bool DEP, bool EXACT = false>
+//
+// SEL (MODE = kCModeSel, VPTQ_GEMV_SELECTIVE; round 6): the folded form, EXCEPT where an activation column dominates the layer's -
+// |f16(s x)| >= thr, thr = kappa x rms of f16(s x) over the layer's columns.  The folded form's distance to the reference is a sum
+// of per-column rounding errors; with dense activations they average out over thousands of columns, a handful of dominant ones
+// do not (profiles/r05/gate_count_*_folded_opt_in.txt).  Granularity = a wave's sweep block: 128 consecutive columns.  A block
+// that holds a hot column contributes NOTHING in this kernel (its staged activations are zeroed: one ballot + two selects per
+// sweep); k256c_hot_kernel, launched in front of this one, has rebuilt those blocks' weights with the reference's roundings and
+// left their products in `corr` (float32 per output), which finalize() adds before the one rounding.  [Built first: the decision
+// inside this kernel - a scalar branch per column, then per sweep in front of the EXACT and the folded loop body.  Either way the
+// register allocator (128 registers, 4 waves per SIMD) spills - reloads are scratch loads, i.e. s_waitcnt vmcnt(0) in a loop
+// whose waits must stay counted: 5.3 - 7.9 us per layer against 4.4 folded.]
+// P.sync = per layer 4 words {thr, hot blocks, byte offset of the layer's corr from P.sync, 0}, written by k256c_hot_kernel.
+template <typename DT, bool DEP, int MODE = kCModeFolded>
 __global__ __launch_bounds__(kCThreads) void gemv_k256c_kernel(const K256CParams P) {
-  static_assert(!EXACT || (std::is_same<DT, F16>::value && !DEP && kCSub == 2), "reference roundings: fp16, independent layers");
-  constexpr uint32_t kCXsWave = c_xs_wave(EXACT), kCRedOff = c_red_off(EXACT), kCRedBOff = c_redb_off(EXACT),
-                     kCCntOff = c_cnt_off(EXACT);
+  constexpr bool EXACT = MODE == kCModeExact, SEL = MODE == kCModeSel;
+  static_assert(MODE == kCModeFolded || (std::is_same<DT, F16>::value && !DEP && kCSub >= 2), "reference roundings: fp16, independent layers");
+  static_assert(!SEL || VPTQ_K256C_PROF == 0, "selective: P.sync carries the thresholds");
+  constexpr uint32_t kCXsWave = c_xs_wave(MODE), kCRedOff = c_red_off(MODE), kCRedBOff = c_redb_off(MODE),
+                     kCCntOff = c_cnt_off(MODE);
 #if VPTQ_K256C_PROF >= 2
-  constexpr uint32_t kCTlOff = c_tl_off(EXACT);
+  constexpr uint32_t kCTlOff = c_tl_off(MODE);
 #endif
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   {
@@ -407,6 +424,24 @@ __global__ __launch_bounds__(kCThreads) void gemv_k256c_kernel(const K256CParams
     Lc = c_cons_of(L0);
     Lf = CFillL{L0.cent, L0.rcent};
   }
+  // SEL: the layer's threshold (magnitude bits of the 16-bit type) and where its corrections are (null: no hot block),
+  // through the scalar cache
+  const float* corr = nullptr;
+  auto load_thr = [&](int L) __attribute__((always_inline)) -> uint32_t {
+    uint32_t t = 0x7fffu;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (SEL) {
+      typedef int i4_t __attribute__((ext_vector_type(4)));
+      const uint32_t* const tp = sync + 4 * __builtin_amdgcn_readfirstlane(L);
+      i4_t h;
+      asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(h) : "s"(tp) : "memory");
+      t = (uint32_t)h[0];
+      corr = h[1] != 0 ? (const float*)((const char*)sync + (uint32_t)h[2]) : nullptr;
+    }
+#endif
+    return t;
+  };
+  uint32_t thr = load_thr(ci.L);
   CCursor cc = ci;             // row group being consumed
   const uint32_t lane_chunk2 = ((uint32_t)lane >> 2) * 16u;   // byte offset of this lane's 8 index elements in a block
   uint32_t i_rowoff[kCSub];   // per lane: byte offset of its vector-row (subgroup q) in the layer's index tensor
@@ -657,7 +692,10 @@ __global__ __launch_bounds__(kCThreads) void gemv_k256c_kernel(const K256CParams
         const bool store = mine && row < Lc.N && o < Lc.O;
         float bv = 0.f;
         if (store && Lc.bias) bv = DT::to_float(as_global(Lc.bias)[o]);
-        const float total = sum + bdot;
+        float total = sum + bdot;
+        if constexpr (SEL) {
+          if (corr != nullptr && store) total += corr[o];   // (the hot blocks' columns, reference roundings)
+        }
         if (store) {
           if (out_f32) ((float*)as_global(Lc.y))[o] = total + bv;
           else if (DEP)   // write-through at device scope (sc1): another workgroup reads it in this launch
@@ -762,6 +800,17 @@ __global__ __launch_bounds__(kCThreads) void gemv_k256c_kernel(const K256CParams
         *(lds_u32_t*)(uintptr_t)st_addr = xv;
         *(lds_u32_t*)(uintptr_t)(st_addr + 256u) = sr[S];
         *(lds_u32_t*)(uintptr_t)(st_addr + 512u) = br[S];
+      } else if constexpr (SEL) {
+        // the folded form; a sweep that holds a HOT column (|f16(s x)| >= thr; NaN / inf compare as large) contributes nothing
+        // here - its 128 columns x the layer's rows come in through `corr`, rebuilt with the reference's roundings by
+        // k256c_hot_kernel in front of this launch
+        const uint32_t xp = DT::mul2(xv, sr[S]);
+        const uint32_t m16 = (xp & 0x7fffu) > ((xp >> 16) & 0x7fffu) ? (xp & 0x7fffu) : ((xp >> 16) & 0x7fffu);
+        const bool hot = __builtin_amdgcn_ballot_w64(m16 >= thr) != 0ull;   // (wave-uniform)
+        const uint32_t xe = hot ? 0u : xv;
+        accb = DT::dot2(xe, br[S], accb);
+        asm volatile("" : "+v"(accb));
+        *(lds_u32_t*)(uintptr_t)st_addr = hot ? 0u : xp;
       } else {
         // activations: f16(s x) of this lane's two columns into the wave's slot, sum b x
         accb = DT::dot2(xv, br[S], accb);
@@ -805,7 +854,7 @@ __global__ __launch_bounds__(kCThreads) void gemv_k256c_kernel(const K256CParams
       if constexpr (EXACT) {
         // both row subgroups of column u together, stage-major over 8 independent chains (dependent packed
         // operations back to back cost wait states); the scale / bias half of the column is picked by op_sel
-        if (q == 0) {
+        if ((q & 1) == 0) {   // (row subgroups q, q + 1)
           const u32x4 c1 = cv[(t + 1) % kNB], r1 = rv[(t + 1) % kNB];
           uint32_t w[8];
 #pragma unroll
@@ -816,10 +865,10 @@ __global__ __launch_bounds__(kCThreads) void gemv_k256c_kernel(const K256CParams
           asm volatile("" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]));
 #pragma unroll
           for (int k = 0; k < 8; ++k) w[k] = DT::add2_bcast(w[k], bq[u >> 1], u & 1);
-          acc[0][0] = DT::mfma4(xo, u32x2{w[0], w[1]}, acc[0][0]);
-          acc[0][1] = DT::mfma4(xo, u32x2{w[2], w[3]}, acc[0][1]);
-          acc[1][0] = DT::mfma4(xo, u32x2{w[4], w[5]}, acc[1][0]);
-          acc[1][1] = DT::mfma4(xo, u32x2{w[6], w[7]}, acc[1][1]);
+          acc[q][0] = DT::mfma4(xo, u32x2{w[0], w[1]}, acc[q][0]);
+          acc[q][1] = DT::mfma4(xo, u32x2{w[2], w[3]}, acc[q][1]);
+          acc[q + 1][0] = DT::mfma4(xo, u32x2{w[4], w[5]}, acc[q + 1][0]);
+          acc[q + 1][1] = DT::mfma4(xo, u32x2{w[6], w[7]}, acc[q + 1][1]);
         }
       } else if constexpr ((VPTQ_K256C_ABLATE & 1) != 0) {
         asm volatile("" :: "v"(c), "v"(r), "v"(xo));
@@ -962,6 +1011,7 @@ __global__ __launch_bounds__(kCThreads) void gemv_k256c_kernel(const K256CParams
     baseB ^= 0x10000u;
     cc = cf;
     Lc = c_cons_of(c_load_layer(cc.L));
+    if constexpr (SEL) thr = load_thr(cc.L);
     c_left = cc.ns;
     PF_MARK(4);
     if (DEP) dep_enter(cc.L);
@@ -1066,6 +1116,116 @@ __global__ __launch_bounds__(kCThreads) void gemv_k256c_kernel(const K256CParams
 #endif
 }
 
+// ---- SEL: thresholds and corrections of a launch's layers (gemv_k256c_kernel<.., kCModeSel>).  grid = (row chunks, layers),
+// 256 threads.  Every workgroup of a layer finds the layer's threshold and hot blocks itself (two passes over x and scale: 48 KiB
+// out of the L2): thr = magnitude bits (16-bit type) of kappa x rms of f16(s x), a block of 128 columns is hot when one of its
+// columns is at or above it.  Chunk 0 writes the layer's header; without a hot block that is all (dense activations: kappa = 6
+// puts one Gaussian column in 5 x 10^8 above the line).  Otherwise the workgroup rebuilds the hot blocks' weights of ITS kHotRows
+// vector-rows as the reference rounds them - w = f16(f16(f16(c + r) s) + b), vptq/ops/quant_gemm.py:121,155-156 - and stores
+// sum w x (fp32) of those columns as the rows' corrections.  kappa: VPTQ_SELECTIVE_KAPPA; the study behind the 6:
+// tools/hybrid_error_study.py, profiles/r06/selective_*.txt.
+constexpr int kHotRows = 16;          // vector-rows per workgroup: 16 lanes per row, 8 columns per lane and hot block
+constexpr int kHotMaxBlocks = 256;    // 32768 columns
+struct CHotArgs {
+  uint32_t corr_off[kMaxGroup];   // byte offset of layer l's corrections from P.sync
+  float kappa;
+};
+template <typename DT>
+__global__ __launch_bounds__(256) void k256c_hot_kernel(const K256CParams P, const CHotArgs H) {
+  __shared__ float part[4];
+  __shared__ uint32_t mask[kHotMaxBlocks / 32];
+  __shared__ __attribute__((aligned(16))) uint32_t cb[2][256 * 4];   // both codebooks, 16 bytes per entry
+  const int L = (int)blockIdx.y, tid = (int)threadIdx.x;
+  const CLayerArgs Ly = c_load_layer(L);
+  uint32_t* const hdr = as_global(P.sync) + 4 * L;
+  if (tid < kHotMaxBlocks / 32) mask[tid] = 0u;
+  float ss = 0.f;
+  for (int c = 2 * tid; c < Ly.G; c += 512) {
+    const uint32_t xp = DT::mul2(*(const uint32_t*)(Ly.x + c), *(const uint32_t*)(Ly.scale + c));
+    const float a = DT::lo(xp), b = DT::hi(xp);
+    ss = __builtin_fmaf(a, a, __builtin_fmaf(b, b, ss));
+  }
+  ss = wave_sum(ss);
+  if ((tid & 63) == 0) part[tid >> 6] = ss;
+  __syncthreads();
+  uint32_t thr = 0x7c00u;                          // inf / NaN sums: only inf / NaN columns are hot
+  {
+    const float tot = (part[0] + part[1]) + (part[2] + part[3]);
+    const float t = H.kappa * __builtin_sqrtf(tot / (float)Ly.G);
+    if (t < 65504.f) {
+      thr = (uint32_t)DT::from_float(t) & 0x7fffu;
+      if (DT::to_float((uint16_t)thr) < t) thr += 1u;   // (rounded up: at or above the threshold)
+    }
+    if (thr == 0u) thr = 1u;                       // (all-zero activations: nothing is hot)
+  }
+  for (int c = 2 * tid; c < Ly.G; c += 512) {
+    const uint32_t xp = DT::mul2(*(const uint32_t*)(Ly.x + c), *(const uint32_t*)(Ly.scale + c));
+    if ((xp & 0x7fffu) >= thr || ((xp >> 16) & 0x7fffu) >= thr) atomicOr(&mask[c >> 12], 1u << ((c >> 7) & 31));
+  }
+  __syncthreads();
+  int nhot = 0;
+#pragma unroll
+  for (int i = 0; i < kHotMaxBlocks / 32; ++i) nhot += __builtin_popcount(mask[i]);
+  if (blockIdx.x == 0 && tid == 0) {
+    hdr[0] = thr; hdr[1] = (uint32_t)nhot; hdr[2] = H.corr_off[L]; hdr[3] = 0u;
+  }
+  const int row = (int)blockIdx.x * kHotRows + (tid >> 4);
+  if (nhot == 0 || (int)blockIdx.x * kHotRows >= Ly.N) return;
+  // both codebooks: thread t copies entry t of each (16 bytes)
+  *(u32x4*)&cb[0][tid * 4] = *(const u32x4*)(Ly.cent + tid * 4);
+  *(u32x4*)&cb[1][tid * 4] = *(const u32x4*)(Ly.rcent + tid * 4);
+  __syncthreads();
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const int sub = tid & 15;                        // 8 columns of the block
+  const int rr = row < Ly.N ? row : Ly.N - 1;
+  const char* const irow = (const char*)Ly.idx + (size_t)rr * ((size_t)Ly.row_words * 4);
+  for (int wd = 0; wd < kHotMaxBlocks / 32; ++wd) {
+    uint32_t m = mask[wd];
+    while (m) {
+      const int bit = __builtin_ctz(m);
+      m &= m - 1u;
+      const int c0 = (wd * 32 + bit) * kCBlockCols + sub * 8;
+      if (c0 >= Ly.G) continue;                    // (G is a multiple of 8)
+      const u32x4 iw = *(const u32x4*)(irow + (size_t)c0 * 2);
+      const u32x4 xq = *(const u32x4*)(Ly.x + c0), sq = *(const u32x4*)(Ly.scale + c0), bq = *(const u32x4*)(Ly.wbias + c0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const uint32_t e = (iw[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+        const u32x4 c = *(const u32x4*)&cb[0][(e & 255u) * 4], r = *(const u32x4*)&cb[1][(e >> 8) * 4];
+        const float xf = DT::half_of(xq[j >> 1], j & 1);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          uint32_t w = DT::add2(c[k], r[k]);
+          w = DT::mul2_bcast(w, sq[j >> 1], j & 1);
+          w = DT::add2_bcast(w, bq[j >> 1], j & 1);
+          acc[2 * k] = DT::fma_lo(w, xf, acc[2 * k]);
+          acc[2 * k + 1] = DT::fma_hi(w, xf, acc[2 * k + 1]);
+        }
+      }
+    }
+  }
+  // the 16 lanes of a row
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = row16_allsum(acc[k]);
+  if (sub == 0 && row < Ly.N) {
+    float* const co = (float*)((char*)as_global(P.sync) + H.corr_off[L]) + (size_t)row * 8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (row * 8 + k < Ly.O) co[k] = acc[k];
+  }
+}
+// bytes of a SEL launch's workspace: 16 per layer, then 4 per output
+size_t gemv_k256c_selective_bytes(const VptqLayerDesc* descs, int n) {
+  size_t b = ((size_t)n * 16 + 255) / 256 * 256;
+  for (int i = 0; i < n; ++i) b += ((size_t)descs[i].num_indices * 8 * 4 + 255) / 256 * 256;
+  return b;
+}
+static float c_kappa() {
+  static std::atomic<int> milli{-1};
+  if (milli < 0) { const char* e = getenv("VPTQ_SELECTIVE_KAPPA"); const double v = e ? atof(e) : 0.0; milli = v > 0.0 ? (int)(v * 1000.0) : 6000; }
+  return (float)milli.load() * 1e-3f;
+}
+
 // ---- host side -------------------------------------------------------------------
 bool gemv_k256c_eligible(const VptqLayerDesc& d, int tokens) {
   return tokens == 1 && d.perm == nullptr && gemv_k256_eligible(d, 1) &&
@@ -1133,10 +1293,10 @@ bool gemv_k256c_fills_device(const VptqLayerDesc* descs, int n, bool dependent) 
   return 4 * c_blocks(descs, n, cus, c_wide(descs, n, cus, dependent)) >= 3ll * cus;
 }
 
-template <typename DT, bool DEP, bool EXACT = false>
+template <typename DT, bool DEP, int MODE = kCModeFolded>
 static hipError_t launch_c(const K256CParams& P, int grid, hipStream_t st) {
-  auto kern = gemv_k256c_kernel<DT, DEP, EXACT>;
-  constexpr uint32_t lds = c_lds_bytes(EXACT);
+  auto kern = gemv_k256c_kernel<DT, DEP, MODE>;
+  constexpr uint32_t lds = c_lds_bytes(MODE);
   static std::atomic<bool> attr_set[64];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
@@ -1167,6 +1327,10 @@ static hipError_t launch_c(const K256CParams& P, int grid, hipStream_t st) {
 // the reference's roundings inside the chain launch: fp16, independent layers
 bool gemv_k256c_exact_ok(const VptqLayerDesc& d, bool dependent) {
   return d.dtype == VPTQ_DTYPE_F16 && !dependent && VPTQ_K256C_PROF < 2;
+}
+// ... and where an activation column dominates only (VPTQ_GEMV_SELECTIVE): the same, + workspace (gemv_k256c_selective_bytes)
+bool gemv_k256c_selective_ok(const VptqLayerDesc& d, bool dependent) {
+  return d.dtype == VPTQ_DTYPE_F16 && !dependent && VPTQ_K256C_PROF == 0 && d.group_size <= kHotMaxBlocks * kCBlockCols;
 }
 
 // ---- layers with an input permutation: x is gathered ONCE into the caller's workspace (xp[c] = x[perm[c]]) by a small
@@ -1270,10 +1434,32 @@ hipError_t launch_gemv_k256c(const VptqLayerDesc* descs, int n, const void* cons
     first = dependent ? 0 : first + (ng + rpw - 1) / rpw;
   }
   const bool f16 = descs[0].dtype == VPTQ_DTYPE_F16;
+  if ((flags & VPTQ_GEMV_SELECTIVE) && !(flags & VPTQ_GEMV_EXACT)) {
+    // sync = n thresholds, written by the launch in front of the chain launch (same stream)
+    if (!f16 || dependent || !sync) return hipErrorInvalidValue;   // (the caller routes those layer by layer / asks for EXACT)
+#if VPTQ_K256C_PROF == 0
+    CHotArgs H = {};
+    size_t off = ((size_t)n * 16 + 255) / 256 * 256;
+    int max_rows = 1;
+    for (int i = 0; i < n; ++i) {
+      if (descs[i].group_size > kHotMaxBlocks * kCBlockCols || off > 0xffffffffull) return hipErrorInvalidValue;
+      H.corr_off[i] = (uint32_t)off;
+      off += ((size_t)descs[i].num_indices * 8 * 4 + 255) / 256 * 256;
+      max_rows = descs[i].num_indices > max_rows ? descs[i].num_indices : max_rows;
+    }
+    H.kappa = c_kappa();
+    hipLaunchKernelGGL(k256c_hot_kernel<F16>, dim3((max_rows + kHotRows - 1) / kHotRows, n), dim3(256), 0, st, P, H);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    return launch_c<F16, false, kCModeSel>(P, grid, st);
+#else
+    return hipErrorInvalidValue;
+#endif
+  }
   if (flags & VPTQ_GEMV_EXACT) {
     if (!f16 || dependent) return hipErrorInvalidValue;   // (the caller routes those layer by layer)
 #if VPTQ_K256C_PROF < 2
-    return launch_c<F16, false, true>(P, grid, st);
+    return launch_c<F16, false, kCModeExact>(P, grid, st);
 #else
     return hipErrorInvalidValue;
 #endif

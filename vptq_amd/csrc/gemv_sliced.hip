@@ -84,33 +84,37 @@ constexpr int kSLMaxGroup = 3;
 #ifndef VPTQ_SLICED_PIPE
 #define VPTQ_SLICED_PIPE 1
 #endif
-// accumulator word of one output: bits [0, 7) arrivals, [7, 14) arrivals whose partial sum was NaN, [14, 64) the sum in
-// units of 2^-24 (50 bits signed: +-3.3e7; a partial sum beyond that - or an infinite one - saturates, which still rounds to
-// the 16-bit formats' infinity)
-constexpr int kSLFixFrac = 24, kSLFixShift = 14;
+// accumulator word of one output: bits [0, 7) arrivals, [7, 14) arrivals whose partial sum could not be represented (NaN, infinite,
+// beyond the field), [14, 64) the sum in units of 2^-F as a 50-bit two's-complement number.  F = 30 for fp16 layers: partial sums up
+// to 2^17 (twice the type's range), resolution 9.3e-10 - a 16-bit output of magnitude 1e-4 still gets its sum to 1e-5 relative per
+// arrival; F = 24 for bf16 layers: partial sums up to 2^25.  Truncation is towards zero (magnitude first, then the sign): no bias.
+// Integer adds commute and wrap: the result is the same whoever arrives last, and a transient overflow of the field does not
+// matter as long as the final sum fits it (a final sum beyond +-2^19 / 2^25 is beyond what the output types of this library hold
+// anyway).  A partial sum that cannot be represented makes the OUTPUT NaN - loud - instead of saturating to a finite value.
+// [Round 5: units of 2^-24 for every type, floor (a bias of up to 6e-8 per arrival, always downwards: 16 - 96 arrivals moved
+// outputs of magnitude 1e-3 by several fp16 ulps), clamp to +-3.3e7 - a finite bf16 value.  ADVICE r5.]
+constexpr int kSLFixShift = 14;
+template <typename DT> constexpr int sl_frac() { return std::is_same<DT, F16>::value ? 30 : 24; }
+template <int F>
 static __device__ __forceinline__ unsigned long long sl_to_fixed(float v) {
-  // floor(v * 2^24) as a 64-bit integer out of two 32-bit conversions (the compiler's float -> int64 is ~25 instructions, and a
-  // wave pays it at the end of every row: a third of the exact kernel's vector instructions went there - PMC, round 5):
-  // v = a + f with a = floor(v) (|a| <= 2^25: an int32) and f in [0, 1) exact; Q = a 2^24 + floor(f 2^24), no carry between them
-  const bool nan = v != v;
-  const float lim = 33554430.f;   // 2^25 - 2: Q stays inside 50 bits
-  float c = __builtin_fminf(__builtin_fmaxf(v, -lim), lim);
-  if (nan) c = 0.f;
+  // |v| 2^F as a 64-bit integer out of two 32-bit conversions (the compiler's float -> int64 is ~25 instructions, and a wave pays
+  // it at the end of every row): |v| = a + f with a = floor(|v|) < 2^25 and f = |v| - a in [0, 1), exact in fp32
+  constexpr float lim = (float)(1u << (49 - F - (F == 30 ? 2 : 0)));   // fp16: 2^17; bf16: 2^25
+  const float m = __builtin_fabsf(v);
+  const bool bad = !(m < lim);                       // NaN, infinite, beyond the field
+  const float c = bad ? 0.f : m;
   const float a = __builtin_floorf(c);
-  const int32_t ai = (int32_t)a;
-  // (c - a rounds up to 1.0 for tiny negative c: capped one unit below - 2^-24 of error, as everywhere)
-  const uint32_t f0 = (uint32_t)((c - a) * (float)(1 << kSLFixFrac));
-  const uint32_t fi = f0 < (1u << kSLFixFrac) ? f0 : (1u << kSLFixFrac) - 1u;
-  const uint32_t lo = ((uint32_t)ai << kSLFixFrac) | fi;      // low word of Q
-  const int32_t hi = ai >> (32 - kSLFixFrac);                 // high word of Q (sign-extending)
-  const uint32_t wlo = (lo << kSLFixShift) | (nan ? 129u : 1u);
-  const uint32_t whi = ((uint32_t)hi << kSLFixShift) | (lo >> (32 - kSLFixShift));
-  return ((unsigned long long)whi << 32) | wlo;
+  const uint32_t ai = (uint32_t)a;
+  const uint32_t fi = (uint32_t)((c - a) * (float)(1u << F));   // < 2^F: f <= 1 - 2^-24
+  unsigned long long q = ((unsigned long long)ai << F) + (unsigned long long)fi;
+  if (v < 0.f) q = 0ull - q;
+  return (q << kSLFixShift) + (bad ? 129ull : 1ull);
 }
+template <int F>
 static __device__ __forceinline__ float sl_from_fixed(unsigned long long w) {
   if ((w >> 7) & 127ull) return __builtin_nanf("");
   const long long q = (long long)w >> kSLFixShift;
-  return (float)((double)q * (1.0 / (double)(1 << kSLFixFrac)));   // |q| < 2^50: exact in fp64, ONE rounding to fp32
+  return (float)((double)q * (1.0 / (double)(1ull << F)));   // |q| < 2^49: exact in fp64, ONE rounding to fp32
 }
 struct SlicedGroupParams {
   int n;
@@ -561,7 +565,7 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
         for (int i = 0; i < V / 4; ++i) {
           if ((pend_old[t][i] & 127ull) == (unsigned long long)(GP.arrivals - 1)) {
             const int o = pend_o + i;
-            float r = sl_from_fixed(pend_old[t][i] + pend_mine[t][i]);
+            float r = sl_from_fixed<sl_frac<DT>()>(pend_old[t][i] + pend_mine[t][i]);
             if (o < P.O) {
               if (P.bias) r += DT::to_float(as_global(P.bias)[o]);
               const size_t yo = (TOK > 1 ? (size_t)t * P.y_stride : 0) + (size_t)o;
@@ -608,7 +612,7 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
         unsigned long long* const ap = (unsigned long long*)as_global(P.partial) + (TOK > 1 ? (size_t)t * P.acc_stride : 0) + pend_o;
 #pragma unroll
         for (int i = 0; i < V / 4; ++i) {
-          pend_mine[t][i] = sl_to_fixed(v[t][i] + bdot);
+          pend_mine[t][i] = sl_to_fixed<sl_frac<DT>()>(v[t][i] + bdot);
           pend_old[t][i] = __hip_atomic_fetch_add(ap + i, pend_mine[t][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }

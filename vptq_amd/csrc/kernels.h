@@ -25,6 +25,8 @@ hipError_t launch_gemv_k256(const VptqLayerDesc* descs, int n, const void* const
 bool gemv_k256c_eligible(const VptqLayerDesc& d, int tokens);
 bool gemv_k256c_fills_device(const VptqLayerDesc* descs, int n, bool dependent);
 bool gemv_k256c_exact_ok(const VptqLayerDesc& d, bool dependent);
+bool gemv_k256c_selective_ok(const VptqLayerDesc& d, bool dependent);
+size_t gemv_k256c_selective_bytes(const VptqLayerDesc* descs, int n);
 // layers with an input permutation in an independent chain: x[perm] gathered into a workspace in front of the launch
 size_t gemv_k256c_perm_bytes(const VptqLayerDesc& d);
 hipError_t launch_permute_x(const VptqLayerDesc* descs, int n, const void* const* x, void* const* out, hipStream_t st);   // VPTQ_GEMV_EXACT inside the chain launch

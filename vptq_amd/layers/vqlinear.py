@@ -67,6 +67,9 @@ _SLICED_MAX_TOKENS = max(max(_SLICED_TOKENS_ENV) if _SLICED_TOKENS_ENV else 3, 4
 _SLICED_ONE_LAUNCH = os.environ.get("VPTQ_SLICED_ONE_LAUNCH", "auto").strip().lower() or "auto"
 
 
+_SLICED_OOM_RETRY_CALLS = 256   # calls of a layer before a sliced-layout build that ran out of memory is tried again
+
+
 class SiblingGroup:
     """Layers that are applied to the SAME activation one after the other (q / k / v, gate / up).
     The first member called with a tensor launches all members in one grouped kernel
@@ -94,7 +97,7 @@ class SiblingGroup:
             if not self._sout:
                 self._sx = None
             return y
-        if ver < 0 or self.__dict__.get("_sgroup") is False:
+        if ver < 0:
             return None
         sls = [m._sliced_gemv() for m in self.members]
         if any(sl is None for sl in sls):
@@ -106,9 +109,12 @@ class SiblingGroup:
             try:
                 sg = (key, SlicedGroupGemv(sls))
             except ValueError:
-                self._sgroup = False      # (mixed formats: every member launches for itself)
-                return None
+                # mixed formats / arithmetics: every member launches for itself - remembered for THESE layouts only (the key):
+                # a rebuilt layout or another arithmetic (set_arithmetic) makes new objects and the group is looked at again
+                sg = (key, None)
             self._sgroup = sg
+        if sg[1] is None:
+            return None
         if tokens == 1:
             ys = sg[1](x)
         else:   # (every member must be a layer this route was measured faster for: VQuantLinear._sliced_one_launch)
@@ -385,7 +391,7 @@ class VQuantLinear(nn.Module):
             cache = (key, desc, keep, dev, B.lib().vptq_quant_gemv,
                      B.lib().vptq_quant_gemv_max_tokens(desc), VQuantLinear._desc_generation,
                      tensors[1].dtype, dev.index if dev.index is not None else torch.cuda.current_device(),
-                     0 if self._folded_form_is_safe(tensors, desc) else B.GEMV_EXACT,
+                     B.layer_arithmetic_flags(self._folded_form_is_safe(tensors, desc)),
                      B.lib().vptq_quant_gemv_workspace_bytes(desc, 16, 0))   # [10]: scratch bytes of the batched-decode kernel
             self.__dict__["_desc_cache"] = cache
         return cache
@@ -453,7 +459,7 @@ class VQuantLinear(nn.Module):
             # the layer's arithmetic (cache[9]): the reference's roundings (the default) take the EXACT sliced kernel where it
             # serves the layer - no residual codebook or the 256-entry one of v = 8, up to ~16000 columns; the others keep the
             # gather kernel -, the opt-in folded form the folded one
-            exact = bool(cache[9] & B.GEMV_EXACT)
+            exact = bool(cache[9] & (B.GEMV_EXACT | B.GEMV_SELECTIVE))   # (selective: the sliced routes take the reference's roundings)
             # (reference roundings, us per layer, gather -> exact sliced, profiles/r05/sliced_exact.txt: 8192^2 39.4 -> 17.2,
             # 4096 x 14336 34.5 -> 17.0, 14336 x 4096 34.9 -> 14.7, 4096^2 12.6 -> 9.0, 4096 x 1024 7.8 -> 8.3: from 1 M index elements -
             # 8 M weights - on; enable_sliced_layout() asks for it on any layer)
@@ -472,15 +478,26 @@ class VQuantLinear(nn.Module):
             # (reference roundings: layers too wide for the LDS in one piece - 28672 columns - are served as equal column parts)
             served = exact_column_parts(cache[1], self.group_size)[0] if exact else B.lib().vptq_sliced_layout_supported_for(cache[1], 0)
             if (big or not exact) and served and self._sliced_fits(cache, on):
+                # (a build that ran out of device memory is retried only after a back-off: every attempt costs int64 / float64
+                # temporaries of ~160 bytes per element, an empty_cache() and a warning - per decode call, while memory stays tight)
+                oom = self.__dict__.get("_sliced_oom")
+                if oom is not None:
+                    oom[0] -= 1
+                    free = torch.cuda.mem_get_info(cache[3])[0] if oom[0] > 0 else 0
+                    if oom[0] > 0 and free < oom[1]:
+                        return None
                 try:
                     obj = SlicedGemv(self, exact=exact)
+                    self.__dict__.pop("_sliced_oom", None)
                 except torch.cuda.OutOfMemoryError as e:
-                    # out of device memory while building: the regular route serves THIS call; nothing is remembered, so a
-                    # later call (memory freed meanwhile) tries again.  Any other error is a bug and propagates.
+                    # out of device memory while building: the regular route serves the calls until _SLICED_OOM_RETRY_CALLS further
+                    # ones have passed or the device reports twice the free bytes it had now.  Any other error is a bug and propagates.
                     import warnings
                     torch.cuda.empty_cache()
-                    warnings.warn(f"sliced layout of a {self.in_features} x {self.out_features} layer not built "
-                                  f"({str(e)[:120]}); the layer keeps the gather kernel for now", stacklevel=3)
+                    if oom is None:   # (warn once per layer)
+                        warnings.warn(f"sliced layout of a {self.in_features} x {self.out_features} layer not built "
+                                      f"({str(e)[:120]}); the layer keeps the gather kernel for now", stacklevel=3)
+                    self.__dict__["_sliced_oom"] = [_SLICED_OOM_RETRY_CALLS, 2 * torch.cuda.mem_get_info(cache[3])[0] + (n_el * 160)]
                     return None
                 # the kernel over the layouts evaluates the folded form: the same measured gate as every folded route
                 # (_backend.folded_form_is_safe) - its float32 outputs against the gather kernel's (the reference's roundings)

@@ -50,17 +50,21 @@ class GemvChain:
             # independent layers are handed to the library as two lists - the gated ones with VPTQ_GEMV_EXACT - and one
             # odd layer does not slow the others down; a dependent chain stays one list (the order is the
             # dependency) and takes the reference's roundings as a whole.
-            gated = [i for i, c in enumerate(caches) if c[9]]
+            gated = [i for i, c in enumerate(caches) if c[9] & B.GEMV_EXACT]
+            rest = 0
+            for c in caches:
+                rest |= c[9] & B.GEMV_SELECTIVE      # (selective arithmetic: the un-gated layers' launch asks for it)
             if self.dependent or not gated or len(gated) == n:
-                parts = [(list(range(n)), B.GEMV_EXACT if gated else 0)]
+                parts = [(list(range(n)), B.GEMV_EXACT if gated else rest)]
             else:
-                parts = [([i for i in range(n) if not caches[i][9]], 0), (gated, B.GEMV_EXACT)]
+                parts = [([i for i in range(n) if not caches[i][9] & B.GEMV_EXACT], rest), (gated, B.GEMV_EXACT)]
             subs = []
             for idx, safe in parts:
                 m = len(idx)
                 descs = (B.LayerDesc * m)(*[caches[i][1] for i in idx])
-                # arrival flags of a dependent chain / x[perm] of independent layers that have an input permutation
-                nbytes = B.lib().vptq_quant_gemv_chain_workspace_bytes_for(descs, m, flags)
+                # arrival flags of a dependent chain / x[perm] of independent layers that have an input permutation / the
+                # thresholds of a call with VPTQ_GEMV_SELECTIVE (one word per layer)
+                nbytes = B.lib().vptq_quant_gemv_chain_workspace_bytes_for(descs, m, flags | (0 if self.dependent else B.GEMV_SELECTIVE))
                 ws = torch.zeros(max(nbytes, 4) // 4, dtype=torch.int32, device=dev) if nbytes else None
                 subs.append((idx, descs, (C.c_void_p * m)(), (C.c_void_p * m)(), safe, ws, nbytes))
             self._state = (key, subs, dev, caches[0][7], [c[2] for c in caches])

@@ -44,8 +44,8 @@ def _safe_flags(indices, centroids, residual_centroids, weight_scale, weight_bia
         if all((r is None and t is None) or (r is not None and r() is t) for r, t in zip(refs, tensors)) and \
                 vers == tuple(B.tensor_version(t) if t is not None else 0 for t in tensors):
             return hit
-    hit = 0 if B.folded_form_is_safe(indices, centroids, residual_centroids, weight_scale, weight_bias, desc,
-                                     in_features, out_features) else B.GEMV_EXACT
+    hit = B.layer_arithmetic_flags(B.folded_form_is_safe(indices, centroids, residual_centroids, weight_scale, weight_bias, desc,
+                                                         in_features, out_features))
     if len(_GATE_CACHE) > 4096:
         _GATE_CACHE.clear()
     _GATE_CACHE[key] = (tuple(weakref.ref(t) if t is not None else None for t in tensors),
