@@ -157,6 +157,40 @@ def test_sliced_layout_reference_roundings(I, O, kw, rpw, dt, v, kr, dev):
         assert sl.forward_tokens(torch.cat([xt] * 4, dim=1)) is None
 
 
+@pytest.mark.parametrize("scale", [1e-3, 1e-4])
+@pytest.mark.parametrize("v,kr", [(8, 0), (8, 256), (8, 65536)])
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+def test_sliced_reference_roundings_small_outputs(dt, v, kr, scale, dev):
+    """the slices' partial sums meet in fixed-point accumulator words.  Round 5's unit was 2^-24 with floor - an absolute
+    error of up to arrivals x 6e-8, always downwards, whatever |y| is: outputs of magnitude 1e-3 and below lost the >= 95 %
+    bit-identity of the exact route (and a float32 output its low bits).  Activations scaled by 1e-3 / 1e-4 (outputs ~1e-2 ... 1e-4):
+    the same bars as at magnitude 1."""
+    from vptq_amd.utils.sliced import SlicedGemv
+    from vptq_amd import _backend as B
+    I, O = 8192, 520
+    L = vo.make_layer(I, O, dist="llm", seed=77 + v + kr, dtype=dt, vector_len=v, num_centroids=65536, num_res_centroids=kr)
+    x = vo.from_f32((vo.to_f32(_x(I, dt, "llm", 5), dt) * scale).astype(np.float32), dt)
+    m = spec_to_module(L, dev)
+    sl = SlicedGemv(m, exact=True)
+    xt = bits_to_tensor(x, dt, dev).reshape(x.shape)
+    got = sl(xt)
+    torch.cuda.synchronize()
+    want = vo.forward(L, x)
+    gb = tensor_to_bits(got)
+    assert float(np.abs(vo.to_f32(np.asarray(want), dt)).max()) < 60 * scale      # (the outputs ARE small)
+    assert rel_err(gb, want, dt) <= TOL[dt]
+    ident = float((gb.reshape(-1) == np.asarray(want).reshape(-1)).mean())
+    assert ident >= 0.95, f"{dt} v{v} kr{kr} x{scale:g}: {ident:.4f} bit-identical"
+    ref = tensor_to_bits(gemv_abi(m, xt, EXACT))                      # gather kernel: float partial sums, no fixed point
+    assert float((gb.reshape(-1) == ref.reshape(-1)).mean()) >= 0.95
+    # float32 outputs: against the gather kernel's un-rounded sums, relative to the outputs' OWN magnitude
+    y32 = sl(xt, flags=B.GEMV_OUT_F32).reshape(-1).double()
+    r32 = gemv_abi(m, xt, EXACT, out_f32=True).reshape(-1).double()
+    # (the words' resolution: 2^-30 per arrival for fp16 layers - up to 32 arrivals here -, 2^-28 for bf16 layers)
+    res = 32 * (2.0 ** -30 if dt == "f16" else 2.0 ** -28)
+    assert float((y32 - r32).abs().max()) <= max(2e-6 * float(r32.abs().max()), res)
+
+
 EXACT_TOK_SHAPES = [(2048, 528, dict(dist="llm", enable_perm=True, bias=True)), (8192, 512, dict(dist="llm", bias=True)), (4104, 272, dict(dist="llm")),
                     (14336, 136, dict(dist="llm")), (72, 1040, dict()), (4096, 2056, dict(dist="llm", enable_perm=True))]
 

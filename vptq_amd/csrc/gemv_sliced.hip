@@ -87,19 +87,20 @@ constexpr int kSLMaxGroup = 3;
 // accumulator word of one output: bits [0, 7) arrivals, [7, 14) arrivals whose partial sum could not be represented (NaN, infinite,
 // beyond the field), [14, 64) the sum in units of 2^-F as a 50-bit two's-complement number.  F = 30 for fp16 layers: partial sums up
 // to 2^17 (twice the type's range), resolution 9.3e-10 - a 16-bit output of magnitude 1e-4 still gets its sum to 1e-5 relative per
-// arrival; F = 24 for bf16 layers: partial sums up to 2^25.  Truncation is towards zero (magnitude first, then the sign): no bias.
-// Integer adds commute and wrap: the result is the same whoever arrives last, and a transient overflow of the field does not
-// matter as long as the final sum fits it (a final sum beyond +-2^19 / 2^25 is beyond what the output types of this library hold
-// anyway).  A partial sum that cannot be represented makes the OUTPUT NaN - loud - instead of saturating to a finite value.
+// arrival; F = 28 for bf16 layers: partial sums up to 2^19 = 5.2e5 (no activation of a language model comes near; the type itself
+// goes to 3e38), resolution 3.7e-9 against an ulp of 4.8e-7 at 1e-4.  Truncation is towards zero (magnitude first, then the sign):
+// no bias.  Integer adds commute and wrap: the result is the same whoever arrives last, and a transient overflow of the field does
+// not matter as long as the final sum fits it (2 bits above the partial sums' limit).  A partial sum that cannot be represented
+// makes the OUTPUT NaN - loud - instead of saturating to a finite value.
 // [Round 5: units of 2^-24 for every type, floor (a bias of up to 6e-8 per arrival, always downwards: 16 - 96 arrivals moved
 // outputs of magnitude 1e-3 by several fp16 ulps), clamp to +-3.3e7 - a finite bf16 value.  ADVICE r5.]
 constexpr int kSLFixShift = 14;
-template <typename DT> constexpr int sl_frac() { return std::is_same<DT, F16>::value ? 30 : 24; }
+template <typename DT> constexpr int sl_frac() { return std::is_same<DT, F16>::value ? 30 : 28; }
 template <int F>
 static __device__ __forceinline__ unsigned long long sl_to_fixed(float v) {
   // |v| 2^F as a 64-bit integer out of two 32-bit conversions (the compiler's float -> int64 is ~25 instructions, and a wave pays
   // it at the end of every row): |v| = a + f with a = floor(|v|) < 2^25 and f = |v| - a in [0, 1), exact in fp32
-  constexpr float lim = (float)(1u << (49 - F - (F == 30 ? 2 : 0)));   // fp16: 2^17; bf16: 2^25
+  constexpr float lim = (float)(1u << (49 - F - 2));   // fp16: 2^17; bf16: 2^19
   const float m = __builtin_fabsf(v);
   const bool bad = !(m < lim);                       // NaN, infinite, beyond the field
   const float c = bad ? 0.f : m;
