@@ -1266,6 +1266,9 @@ def main():
              "the same ring, one vptq_quant_gemv launch per layer - what VQuantLinear.forward issues (the reference's operator granularity)"),
             ("h4096_chain", dict(H=4096, mode="chain", flags=EX), "VQuantLinear 4096x4096 (BASELINE configs[0]/[1] shape), ring of 128 layers as 4 chain launches"),
             ("h4096", dict(H=4096, mode="single", flags=EX), "VQuantLinear 4096x4096 (BASELINE configs[0]/[1] shape), single launch per layer"),
+            ("selective_single_launch_per_layer", dict(H=H, mode="single", flags=B.GEMV_SELECTIVE),
+             "OPT-IN selective arithmetic, one launch per layer (what VQuantLinear.forward issues after vptq_amd.set_arithmetic('selective')): "
+             "gemv_k256m_kernel<selective> - hot blocks found, zeroed and corrected inside the launch"),
             ("selective_chain", dict(H=H, mode="chain", flags=B.GEMV_SELECTIVE),
              "OPT-IN selective arithmetic (vptq_amd.set_arithmetic('selective'), round 6), the headline workload: the folded form with the "
              "reference's roundings on the 128-column blocks an activation dominates (|f16(s x)| >= 6 rms) - 2 of 12 300 checkpoint-like layers "
@@ -1286,7 +1289,7 @@ def main():
             ("k8192_r256", dict(H=H, mode="single", flags=EX, k=8192, kr=256), "k = 8192 + 256 (T = 21 bits), LDS-resident codebooks, reference roundings"),
             ("folded_k8192_r256", dict(H=H, mode="single", flags=0, k=8192, kr=256), "k = 8192 + 256, opt-in folded arithmetic (MFMA accumulate)"),
         )
-        core = ("single_launch_per_layer", "h4096", "selective_chain")     # the compact line's roofline.module_path / opt_in rows
+        core = ("single_launch_per_layer", "h4096", "selective_chain", "selective_single_launch_per_layer")   # the compact line's roofline.module_path / opt_in rows
         for key, kw, what in table:
             if not a.extras and key not in core:
                 continue
@@ -1341,8 +1344,8 @@ def main():
         # reference's operator granularity, vptq/ops/quant_gemm.py:213-228), beside the throughput-mode headline: the driver
         # keeps the `roofline` object whole, `extras` only in part
         mp = {}
-        for key, name in (("single_launch_per_layer", f"h{H}"), ("h4096", "h4096"), ("folded_single_launch_per_layer", f"h{H}_folded_opt_in"),
-                          ("folded_h4096", "h4096_folded_opt_in")):
+        for key, name in (("single_launch_per_layer", f"h{H}"), ("h4096", "h4096"), ("selective_single_launch_per_layer", f"h{H}_selective_opt_in"),
+                          ("folded_single_launch_per_layer", f"h{H}_folded_opt_in"), ("folded_h4096", "h4096_folded_opt_in")):
             e = ex.get(key) or {}
             if "us_per_launch" in e:
                 mp[name] = {"us_per_layer": e["us_per_launch"], "GBps": e["GBps"], "frac": e["frac_of_8TBps"], "kernel": e["kernel"]}

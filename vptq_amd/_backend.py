@@ -303,6 +303,10 @@ def arithmetic_generation() -> int:
 
 
 FOLDED_MAX_PROBE_DISTANCE = {torch.float16: 7.5e-4, torch.bfloat16: 6.0e-3}   # (bf16: 8 mantissa bits fewer... 3: x 8)
+# the selective arithmetic's gate sits lower: what is left of its failures are LAYER properties (a bias-dominated layer at a probe
+# distance of 7.3e-4 went 1.09e-3 above the bar on a dense activation, profiles/r06/count_chain_selective_seed0_probe.txt); 6.5e-4
+# sends 4 - 9 % of checkpoint-like layers (a third of the un-centred "big-bias" family) to the reference's roundings
+SELECTIVE_MAX_PROBE_DISTANCE = {torch.float16: 6.5e-4}
 FOLDED_MIN_DISTINCT_ROWS = 32   # (kept as a cheap pre-filter: tiny layers and repeating index rows never take the folded form)
 _ROW_SAMPLE = 64
 _PROBE_SEED = 0x5eed
@@ -372,7 +376,9 @@ def folded_form_is_safe(indices, centroids, res_centroids, weight_scale, weight_
                 return False
         if desc is None or torch.cuda.is_current_stream_capturing():
             return desc is None   # (no launch + read-back inside a capture: the reference's roundings serve until a rebuild)
-        lim = FOLDED_MAX_PROBE_DISTANCE.get(centroids.dtype)
+        lim = (SELECTIVE_MAX_PROBE_DISTANCE if _ARITH["selective"] else FOLDED_MAX_PROBE_DISTANCE).get(centroids.dtype)
+        if lim is None and _ARITH["selective"]:
+            return False   # (selective roundings exist for fp16: every other dtype takes the reference's)
         if lim is None:
             return True
         name = lib().vptq_quant_gemv_kernel_name(desc, 1, 0)

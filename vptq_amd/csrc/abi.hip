@@ -168,15 +168,18 @@ static Route route_gemv(const VptqLayerDesc& d, int tokens, int flags, const voi
 
 size_t vptq_quant_gemv_workspace_bytes(const VptqLayerDesc* d, int tokens, int flags) {
   if (validate_layer(d) != VPTQ_OK || tokens < 1 || tokens > VPTQ_GEMV_MAX_TOKENS) return 0;
+  flags = selective_as_exact(flags);
   return route_gemv(*d, tokens, flags, nullptr, true) == kRouteGemmK256T ? vptq::gemm_k256t_workspace_bytes(*d) : 0;
 }
 
 const char* vptq_quant_gemv_kernel_name(const VptqLayerDesc* d, int tokens, int flags) {
   if (validate_layer(d) != VPTQ_OK || tokens < 1 || tokens > VPTQ_GEMV_MAX_TOKENS) return nullptr;
+  const int kflags = drop_redundant_selective(flags);
+  flags = selective_as_exact(flags);
   switch (route_gemv(*d, tokens, flags, nullptr, true)) {
     case kRouteGemmK256T: return "gemm_k256t_kernel";
     case kRouteGemmK256: return "gemm_k256_kernel";
-    case kRouteK256: return vptq::gemv_k256_name(*d, tokens, flags);
+    case kRouteK256: return vptq::gemv_k256_name(*d, tokens, tokens == 1 ? kflags : flags);
     case kRouteGather: return "gemv_gather_kernel";
     case kRouteLds: return vptq::gemv_lds_name(*d, tokens, flags);
     case kRouteGatherX: return "gemv_gatherx_kernel";
@@ -202,6 +205,9 @@ int vptq_quant_gemv(const VptqLayerDesc* d, const void* x, void* y, int tokens, 
                     void* workspace, size_t workspace_bytes, void* stream) {
   int rc = validate_layer(d);
   if (rc) return rc;
+  // SELECTIVE: the canonical format's kernels decide (gemv_k256.hip:choose_kernel - the persistent MFMA kernel at one token, else
+  // the reference's roundings); every other route takes the reference's roundings
+  const int kflags = drop_redundant_selective(flags);
   flags = selective_as_exact(flags);
   if (!x || !y) return fail(VPTQ_E_NULL, "x / y is NULL");
   // (a workspace is never required: without it the call takes the kernels that need none)
@@ -235,7 +241,7 @@ int vptq_quant_gemv(const VptqLayerDesc* d, const void* x, void* y, int tokens, 
         return vptq::launch_gemm_k256(*d, xc, yc, m, out_f32, st); });
     case kRouteK256:
       return chunks(4, "gemv_k256 launch", [&](const void* xc, void* yc, int m) {
-        return vptq::launch_gemv_k256(d, 1, &xc, &yc, m, flags, st); });
+        return vptq::launch_gemv_k256(d, 1, &xc, &yc, m, tokens == 1 ? kflags : flags, st); });
     case kRouteGather:     // up to 8 tokens per pass over the indices
       return chunks(8, "gemv_gather launch", [&](const void* xc, void* yc, int m) {
         return vptq::launch_gemv_gather(*d, xc, yc, m, out_f32, st); });
@@ -263,7 +269,7 @@ int vptq_quant_gemv_grouped(const VptqLayerDesc* descs, int n, const void* const
   if (n < 1 || n > VPTQ_GROUP_MAX) return fail(VPTQ_E_SHAPE, "n %d outside [1, %d]", n, VPTQ_GROUP_MAX);
   if (tokens < 1 || tokens > VPTQ_GEMV_MAX_TOKENS_ANY)
     return fail(VPTQ_E_TOKENS, "tokens %d outside [1, %d]", tokens, VPTQ_GEMV_MAX_TOKENS_ANY);
-  flags = selective_as_exact(flags);
+  flags = tokens == 1 ? drop_redundant_selective(flags) : selective_as_exact(flags);   // (one token: gemv_k256.hip:choose_kernel decides)
   bool all_fast = !(flags & VPTQ_GEMV_FORCE_GENERIC);
   bool same_perm = true;  // one instantiation serves the whole group
   for (int i = 0; i < n; ++i) {

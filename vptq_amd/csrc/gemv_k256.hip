@@ -437,6 +437,7 @@ static hipError_t dispatch(const K256Params& P, int grid, int rows, int tok, boo
 struct K256Choice {
   bool mfma;  // persistent MFMA kernel (else the VALU kernel)
   bool fast;  // folded arithmetic (else the reference's per-weight roundings)
+  bool sel;   // VPTQ_GEMV_SELECTIVE inside the persistent MFMA kernel: folded + the reference's roundings on the hot blocks
 };
 
 static K256Choice choose_kernel(const VptqLayerDesc* descs, int n, int tokens, int flags) {
@@ -447,19 +448,31 @@ static K256Choice choose_kernel(const VptqLayerDesc* descs, int n, int tokens, i
   }
   const int tok = tokens > 2 ? 4 : tokens;
   const bool f16 = descs[0].dtype == VPTQ_DTYPE_F16;
-  const bool exact = (flags & VPTQ_GEMV_EXACT) != 0;
+  // SELECTIVE without a kernel that implements it = the reference's roundings (EXACT wins when both are set)
+  const bool want_sel = (flags & VPTQ_GEMV_SELECTIVE) != 0 && !(flags & VPTQ_GEMV_EXACT);
+  bool exact = (flags & VPTQ_GEMV_EXACT) != 0 || want_sel;
   int max_cols = 0;
   bool same_cols = true, perm = false;
   long long row_groups = 0;
+  int n_rows[kMaxGroup];
   for (int i = 0; i < n; ++i) {
     max_cols = descs[i].group_size > max_cols ? descs[i].group_size : max_cols;
     // the persistent MFMA kernel is instantiated per column count: one count per launch
     same_cols = same_cols && descs[i].group_size == descs[0].group_size;
     perm = perm || descs[i].perm != nullptr;
     row_groups += gemv_k256m_row_groups(descs[i].num_indices);
+    n_rows[i < kMaxGroup ? i : 0] = descs[i].num_indices;
+  }
+  {
+    // selective: where the persistent MFMA kernel would be taken in the folded arithmetic and can carry the corrections
+    const long long threshold = f16 ? 144 : 32;
+    const bool mfma_ok = same_cols && forced != 1 && !(flags & VPTQ_GEMV_FORCE_VALU) &&
+                         (forced == 2 || (flags & VPTQ_GEMV_FORCE_MFMA) || row_groups >= threshold);
+    if (want_sel && n <= kMaxGroup && mfma_ok && gemv_k256m_selective_ok(n_rows, n, f16, tok, max_cols, perm))
+      return {true, true, true};
   }
   // VALU kernel: its folded-arithmetic instantiations exist for fp16, 1-2 tokens
-  K256Choice c = {false, f16 && tok <= 2 && !exact};
+  K256Choice c = {false, f16 && tok <= 2 && !exact, false};
   if (same_cols && forced != 1 && !(flags & VPTQ_GEMV_FORCE_VALU) &&
       gemv_k256m_supported(tok, f16, !exact, max_cols, perm)) {
     // fp16: from 144 row groups on (where the VALU kernel needs a second round of workgroups;
@@ -467,12 +480,13 @@ static K256Choice choose_kernel(const VptqLayerDesc* descs, int n, int tokens, i
     // kernel runs widened arithmetic, the MFMA kernel's folded form is dtype agnostic.
     const long long threshold = f16 ? 144 : 32;
     if (forced == 2 || (flags & VPTQ_GEMV_FORCE_MFMA) || row_groups >= threshold)
-      c = {true, !exact};
+      c = {true, !exact, false};
   }
   return c;
 }
 
 static const char* choice_name(K256Choice c) {
+  if (c.sel) return "gemv_k256m_kernel<selective>";
   if (c.mfma) return c.fast ? "gemv_k256m_kernel<fast>" : "gemv_k256m_kernel";
   return c.fast ? "gemv_k256_kernel<fast>" : "gemv_k256_kernel";
 }
@@ -544,7 +558,7 @@ hipError_t launch_gemv_k256(const VptqLayerDesc* descs, int n, const void* const
   // must agree on it, checked by the caller)
   // two sweeps per iteration keep more loads in flight, but the 4-token instantiation
   // only stays spill-free with one
-  if (mfma) return launch_gemv_k256m(P, tok, f16, fast, maxG, perm, st);
+  if (mfma) return launch_gemv_k256m(P, tok, f16, fast, maxG, perm, st, choice.sel);
   const int sw = (maxG > kSweepCols && tok != 4) ? 2 : 1;
   return f16 ? dispatch<F16, true>(P, grid, rows, tok, fast, sw, perm, st)
              : dispatch<BF16, false>(P, grid, rows, tok, false, sw, perm, st);

@@ -57,6 +57,17 @@ constexpr int kMMaxLds = 163840;   // 160 KiB per CU
 constexpr int kMMaxCols = 14336;   // staged activations must fit beside the image
 constexpr int kMRedSlot = kMWaves * 32 * 4;   // one row group's cross-wave partials, per token
 constexpr int kMMaxSlots = 4;
+// VPTQ_GEMV_SELECTIVE (round 6; one token, fp16, folded instantiations; K256Layer::slots bit 8): the folded form, with the reference's
+// roundings on the blocks of 128 columns an activation dominates - see gemv_k256c.hip.  Here everything happens inside the launch:
+// while a wave stages its 512 columns it takes the rms of ITS f16(s x), marks the blocks that hold a column at or above
+// kMSelKappa x that rms (one flag byte per block), and stages zeros for them (so the folded loop adds nothing there, and sum b x
+// leaves them out); behind the prologue barrier the workgroup rebuilds the hot blocks' weights of its own row groups as the
+// reference rounds them and leaves sum w x in `corr` (LDS), which finish() adds before the one rounding.  Nothing in the loop changes.
+constexpr float kMSelKappa = 6.0f;
+constexpr int kMSelBit = 0x100;            // K256Layer::slots: selective roundings
+constexpr int kMSelMaxBlocks = 128;        // 16384 columns (staged: <= 14336)
+constexpr int kMSelRowGroups = 4;          // row groups per workgroup the corrections cover (16 waves = 4 x 4 rows)
+constexpr int kMSelBytes = kMSelMaxBlocks + kMSelRowGroups * 32 * 4;   // flags + corr
 // VPTQ_K256M_XDUP: one token - the staged activations are kept as DUPLICATED pairs (x, x), one
 // dword per column, so that the MFMA x operand (x * e_j) is two v_and_b32 with per-lane
 // constant masks instead of two v_perm_b32 (a three-source VOP3: ~5.5 vs ~3.3 cycles per
@@ -204,8 +215,14 @@ static __device__ __forceinline__ void gemv_k256m_body(const K256Layer& Ly, cons
   float* const red_b = (float*)(smem + red_off);        // [TOK][kMWaves]: sum b * x per wave
   uint32_t* const slot_cnt = (uint32_t*)(red_b + TOK * kMWaves);  // [kMMaxSlots] waves that have arrived
   uint32_t* const slot_done = slot_cnt + kMMaxSlots;         // [kMMaxSlots] row groups finished + 1
-  float* const red = (float*)(slot_done + kMMaxSlots + 8);   // [K][TOK][kMWaves][32]
-  const int K = Ly.slots;  // partial-sum slots that fit into LDS (1..kMMaxSlots, host)
+  // one token: hot-block flags and corrections of the selective arithmetic in front of the slots
+  uint8_t* const hot_flag = (uint8_t*)(slot_done + kMMaxSlots + 8);     // [kMSelMaxBlocks]
+  float* const corr = (float*)(hot_flag + kMSelMaxBlocks);              // [kMSelRowGroups][32]
+  float* const red = (float*)(slot_done + kMMaxSlots + 8) + (TOK == 1 ? kMSelBytes / 4 : 0);   // [K][TOK][kMWaves][32]
+  const int K = Ly.slots & 0xff;  // partial-sum slots that fit into LDS (1..kMMaxSlots, host)
+  constexpr bool kSelOk = FAST && (NST > 0) && TOK == 1 && std::is_same<DT, F16>::value;
+  const bool sel = kSelOk && (Ly.slots & kMSelBit) != 0;   // (wave-uniform)
+  bool sel_any = false;                                     // ... and a block is hot: finish() adds the corrections
 
   // ---- 2. the index queue: slot s holds sweep s (2048 columns x 4 rows, 16 bytes per lane)
   u32x4 iw[NS], s_raw[NQ], b_raw[NQ];
@@ -333,6 +350,7 @@ static __device__ __forceinline__ void gemv_k256m_body(const K256Layer& Ly, cons
     float accb[TOK];
 #pragma unroll
     for (int t = 0; t < TOK; ++t) accb[t] = 0.f;
+    u32x4 sel_xp[kSelOk ? kSt : 1];   // selective: this thread's staged f16(s x)
     K256_STAMP(kMWaves, 6, st_x[0][0][0]);  // (trace build) the activations have arrived
 #pragma unroll
     for (int k = 0; k < NST; ++k) {
@@ -352,6 +370,7 @@ static __device__ __forceinline__ void gemv_k256m_body(const K256Layer& Ly, cons
             if (!kLateB) accb[t] = DT::dot2(v[q], st_b[k][q], accb[t]);  // sum b * x
             v[q] = DT::mul2(v[q], st_s[k][q]);                           // f16(s * x)
           }
+          if constexpr (kSelOk) sel_xp[k] = v;
         }
         if constexpr (kXDup) {
           // (x_c, x_c) per column: 32 bytes per thread
@@ -363,6 +382,54 @@ static __device__ __forceinline__ void gemv_k256m_body(const K256Layer& Ly, cons
                                        __builtin_amdgcn_perm(v[3], v[3], 0x01000100u), __builtin_amdgcn_perm(v[3], v[3], 0x03020302u)});
         } else {
           lds_store16(xs_off + t * xs_stride + (uint32_t)(valid ? want : G + 8) * 2u, v);
+        }
+      }
+    }
+    if constexpr (kSelOk) {
+      if (sel) {
+        // hot blocks: threshold = kMSelKappa x rms of f16(s x) over the 512 NST columns THIS WAVE stages (no barrier needed).
+        // Columns past G count as zeros: a wave with a handful of valid columns gets a LOW threshold (its columns turn hot
+        // sooner), never a useless one (a lone column is only sqrt(n) x the rms of n columns).
+        float ss = 0.f;
+        constexpr int cnt = 512 * (NST > 0 ? NST : 1);
+#pragma unroll
+        for (int k = 0; k < NST; ++k) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float a = DT::lo(sel_xp[k][q]), b = DT::hi(sel_xp[k][q]);
+            ss = __builtin_fmaf(a, a, __builtin_fmaf(b, b, ss));
+          }
+        }
+        ss = wave_sum(ss);
+        uint32_t thr = 0x7c00u;                       // inf / NaN sums: only inf / NaN columns are hot
+        {
+          const float tq = kMSelKappa * __builtin_sqrtf(ss / (float)cnt);
+          if (tq < 65504.f) {
+            thr = (uint32_t)DT::from_float(tq) & 0x7fffu;
+            if (DT::to_float((uint16_t)thr) < tq) thr += 1u;
+          }
+          if (thr == 0u) thr = 1u;                    // (all-zero activations: nothing is hot)
+        }
+#pragma unroll
+        for (int k = 0; k < NST; ++k) {
+          const int want = k * kStageCols + tid * 8;
+          const bool valid = want < G;
+          uint32_t mg = 0u;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const uint32_t lo = sel_xp[k][q] & 0x7fffu, hi = (sel_xp[k][q] >> 16) & 0x7fffu;
+            mg = mg > lo ? mg : lo;
+            mg = mg > hi ? mg : hi;
+          }
+          // the 16 threads of a block of 128 columns are 16 consecutive lanes
+          const unsigned long long bal = __builtin_amdgcn_ballot_w64(valid && mg >= thr);
+          const bool hot = ((uint32_t)(bal >> (lane & 48)) & 0xffffu) != 0u;
+          if (valid && (lane & 15) == 0) hot_flag[want >> 7] = hot ? 1 : 0;   // one writer per block: no init, no atomics
+          if (hot && valid) {
+            lds_store16(xs_off + (uint32_t)want * kXB, u32x4{0u, 0u, 0u, 0u});   // (same thread, same address: behind its own store)
+            if constexpr (kXDup) lds_store16(xs_off + (uint32_t)want * kXB + 16u, u32x4{0u, 0u, 0u, 0u});
+            late_x[k] = u32x4{0u, 0u, 0u, 0u};                                  // ... and out of sum b x
+          }
         }
       }
     }
@@ -413,6 +480,67 @@ static __device__ __forceinline__ void gemv_k256m_body(const K256Layer& Ly, cons
   // past the barrier the queue is filled to its steady-state depth
 #pragma unroll
   for (int s = DS; s < D; ++s) issue_sweep(s, bid, 0);
+  if constexpr (kSelOk) {
+    if (sel) {
+      const int nblk = (G + 127) >> 7;
+      const unsigned long long m0 = __builtin_amdgcn_ballot_w64(lane < nblk && hot_flag[lane] != 0);
+      const unsigned long long m1 = __builtin_amdgcn_ballot_w64(lane + 64 < nblk && hot_flag[lane + 64] != 0);
+      sel_any = (m0 | m1) != 0ull;   // (every wave reads the same flags: uniform over the workgroup)
+      if (sel_any) {
+        // wave w = (row group qi = w >> 2 of this workgroup, vector-row j = w & 3): the hot blocks' columns of that row, two per
+        // lane, with the reference's roundings - w = f16(f16(f16(c + r) s) + b), vptq/ops/quant_gemm.py:121,155-156 - entries out of
+        // the image (any replica: slot lane & 7), fp32 multiply-adds, one DPP sum per output.  Rare, short, not tuned.
+        const int qi = wave >> 2, jr = wave & 3;
+        const int rgq = bid + qi * step;
+        if (rgq < n_groups) {
+          const int rowq = rgq * kMRows + jr;
+          const char* const irow = (const char*)Ly.idx + (size_t)(rowq < N ? rowq : N - 1) * row_bytes;
+          float ac[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+          for (int half = 0; half < 2; ++half) {
+            unsigned long long m = half ? m1 : m0;
+            while (m) {
+              const int bit = __builtin_ctzll(m);
+              m &= m - 1ull;
+              const int c = (half * 64 + bit) * 128 + 2 * lane;
+              if (c >= G) continue;                 // (G is a multiple of 8: whole pairs)
+              const uint32_t iwd = *(const uint32_t*)as_global(irow + (size_t)c * 2);
+              uint32_t xw;
+              if (PERM) {
+                const uint32_t pv = *(const uint32_t*)as_global(Ly.perm + c);
+                xw = (uint32_t)as_global(Ly.x)[pv & 0xffffu] | ((uint32_t)as_global(Ly.x)[pv >> 16] << 16);
+              } else {
+                xw = *(const uint32_t*)as_global(Ly.x + c);
+              }
+              const uint32_t sw = *(const uint32_t*)as_global(sp + c), bw = *(const uint32_t*)as_global(bp + c);
+#pragma unroll
+              for (int h = 0; h < 2; ++h) {
+                const uint32_t e = (iwd >> (16 * h)) & 0xffffu;
+                const u32x4 ce = lds_load16((e & 255u) * 256u + ((uint32_t)lane & 7u) * 16u);
+                const u32x4 re = lds_load16((e >> 8) * 256u + (8u + ((uint32_t)lane & 7u)) * 16u);
+                const float xf = DT::half_of(xw, h);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                  uint32_t w = DT::add2(ce[k], re[k]);
+                  w = DT::mul2_bcast(w, sw, h);
+                  w = DT::add2_bcast(w, bw, h);
+                  ac[2 * k] = DT::fma_lo(w, xf, ac[2 * k]);
+                  ac[2 * k + 1] = DT::fma_hi(w, xf, ac[2 * k + 1]);
+                }
+              }
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < 8; ++k) ac[k] = wave_sum(ac[k]);
+          if (lane == 0 && qi < kMSelRowGroups) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) corr[qi * 32 + jr * 8 + k] = ac[k];
+          }
+        }
+        __syncthreads();   // (uniform: every wave took this branch)
+      }
+    }
+  }
 
   // ---- 4. row groups ----
   // one sweep: 8 indices per lane (2 gathers each, kAhead indices ahead of the arithmetic)
@@ -686,7 +814,10 @@ static __device__ __forceinline__ void gemv_k256m_body(const K256Layer& Ly, cons
 #pragma unroll
       for (int t = 0; t < TOK; ++t) {
         auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(sum[t]), __float_as_uint(sum[t]), false, false);
-        const float total = (__uint_as_float(r[0]) + __uint_as_float(r[1])) + bdot[t];
+        float total = (__uint_as_float(r[0]) + __uint_as_float(r[1])) + bdot[t];
+        if constexpr (kSelOk) {
+          if (sel_any) total += corr[(q < kMSelRowGroups ? q : 0) * 32 + ol];   // (the hot blocks' columns, reference roundings)
+        }
         if (store && t < tokens) {
           if (out_f32) ((float*)as_global(Ly.y))[(size_t)t * O + o] = total + bv;
           else as_global(Ly.y)[(size_t)t * O + o] = DT::from_float(total + bv);
@@ -820,13 +951,13 @@ static int device_cus() {
 // unstaged) and the per-wave sum b * x + slot counters
 static int lds_fixed_bytes(int staged_cols, int tok) {
   const int xb = tok == 1 ? kMXBytes1 : 2;
-  return kMTableBytes + (staged_cols > 0 ? tok * (staged_cols * xb + 32) : 0) + tok * kMWaves * 4 + 64;
+  return kMTableBytes + (staged_cols > 0 ? tok * (staged_cols * xb + 32) : 0) + tok * kMWaves * 4 + 64 + (tok == 1 ? kMSelBytes : 0);
 }
 
 template <typename DT, int NS, int NST, bool PERM, bool FAST, int TOK>
 static hipError_t launch_m(const K256Params& P, int gx, int max_cols, hipStream_t st) {
   const int fixed = lds_fixed_bytes(NST > 0 ? max_cols : 0, TOK);
-  const int slots = P.layer[0].slots;  // set by launch_gemv_k256m
+  const int slots = P.layer[0].slots & 0xff;  // set by launch_gemv_k256m (bit 8: selective roundings)
   if (slots < 1 || slots > kMMaxSlots) return hipErrorInvalidValue;
   const int lds = fixed + slots * kMRedSlot * TOK;
   if (lds > kMMaxLds) return hipErrorInvalidValue;
@@ -938,9 +1069,35 @@ int gemv_k256m_row_groups(int n_rows) { return (n_rows + kMRows - 1) / kMRows; }
 // All layers of a grouped launch must have the same number of columns (checked by the
 // caller, launch_gemv_k256).  Fills in K256Layer::wgs: one workgroup per CU, shared out
 // between the layers in proportion to their row groups.
+// how many row groups a workgroup of layer `n_rows` walks at most when the launch has `total` row groups on `cus` CUs
+static int m_groups_per_wg(int groups, long long total, int cus) {
+  long long share = total > cus ? ((long long)groups * cus + total - 1) / total : groups;
+  if (share < 1) share = 1;
+  if (share > groups) share = groups;
+  return (int)((groups + share - 1) / share);
+}
+static int m_cus() {
+  static std::atomic<int> forced_wgs{-1};  // VPTQ_K256M_WGS: tuning override of the CU count
+  if (forced_wgs < 0) { const char* e = getenv("VPTQ_K256M_WGS"); forced_wgs = e ? atoi(e) : 0; }
+  const int fw = forced_wgs.load();
+  return fw > 0 ? fw : device_cus();
+}
+// VPTQ_GEMV_SELECTIVE in this kernel: one token, fp16, staged activations, the folded instantiation; every workgroup's row groups
+// must fit the corrections' LDS (kMSelRowGroups)
+bool gemv_k256m_selective_ok(const int* n_rows, int n, bool f16, int tok, int max_cols, bool perm) {
+  if (!f16 || tok != 1 || max_cols > kMMaxCols || max_cols > kMSelMaxBlocks * 128 || !gemv_k256m_supported(1, true, true, max_cols, perm)) return false;
+  long long total = 0;
+  for (int i = 0; i < n; ++i) total += gemv_k256m_row_groups(n_rows[i]);
+  const int cus = m_cus();
+  for (int i = 0; i < n; ++i)
+    if (m_groups_per_wg(gemv_k256m_row_groups(n_rows[i]), total, cus) > kMSelRowGroups) return false;
+  return true;
+}
+
 hipError_t launch_gemv_k256m(K256Params& P, int tok, bool f16, bool fast, int max_cols, bool perm,
-                             hipStream_t st) {
+                             hipStream_t st, bool selective) {
   if (!gemv_k256m_supported(tok, f16, fast, max_cols, perm)) return hipErrorInvalidValue;
+  if (selective && !(fast && f16 && tok == 1 && max_cols <= kMMaxCols)) return hipErrorInvalidValue;
   static std::atomic<int> forced_wgs{-1};  // VPTQ_K256M_WGS: tuning override of the CU count
   if (forced_wgs < 0) { const char* e = getenv("VPTQ_K256M_WGS"); forced_wgs = e ? atoi(e) : 0; }
   const int fw = forced_wgs.load();
@@ -954,7 +1111,7 @@ hipError_t launch_gemv_k256m(K256Params& P, int tok, bool f16, bool fast, int ma
     if (share < 1) share = 1;
     if (share > groups) share = groups;
     P.layer[i].wgs = (int)share;
-    P.layer[i].slots = lds_slots(tok, max_cols);
+    P.layer[i].slots = lds_slots(tok, max_cols) | (selective ? kMSelBit : 0);
     gx = (int)share > gx ? (int)share : gx;
   }
   if (tok != 1)

@@ -28,7 +28,7 @@ struct K256Layer {
   int wgs;       // gemv_k256m: persistent workgroups walking this layer's row groups
   int pf_chunk;  // read-ahead stride per workgroup in bytes (multiple of 128)
   int pf_len;    // bytes actually touched per workgroup (<= pf_chunk)
-  int slots;      // gemv_k256m: cross-wave partial-sum slots in LDS
+  int slots;      // gemv_k256m: cross-wave partial-sum slots in LDS (bits 0-7) | bit 8: VPTQ_GEMV_SELECTIVE
 };
 
 // K256Params::tokens: token count in the low 16 bits; kOutF32Bit set = y is float32
@@ -103,6 +103,7 @@ constexpr int kMRows = 4;  // vector-rows per workgroup of the MFMA kernel
 bool gemv_k256m_supported(int tok, bool f16, bool fast, int max_cols, bool perm);
 int gemv_k256m_row_groups(int n_rows);
 hipError_t launch_gemv_k256m(K256Params& P, int tok, bool f16, bool fast, int max_cols, bool perm,
-                             hipStream_t st);
+                             hipStream_t st, bool selective = false);
+bool gemv_k256m_selective_ok(const int* n_rows, int n, bool f16, int tok, int max_cols, bool perm);
 
 }  // namespace vptq
