@@ -938,7 +938,7 @@ def compact_line(out):
     for k in ("hidden", "ring", "mode", "decoder_layers", "launches_per_step", "us_per_layer", "kernel", "hipgraph"):
         if cfg.get(k) is not None:
             c["config"][k] = cfg[k]
-    c["config"]["arithmetic"] = "reference" if arith.startswith("reference") else ("folded" if arith.startswith("folded") else arith[:40])
+    c["config"]["arithmetic"] = next((m for m in ("reference", "selective", "folded") if arith.startswith(m)), arith[:40])
     c["config"]["parallelism"] = _short_sample(cfg.get("parallelism", ""), 120)
     r = {k: rf.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
     for k in ("traffic_source", "traffic_from_committed_profile", "bytes_per_launch", "us_per_launch", "ms_per_step_one_step_per_graph",
@@ -964,7 +964,7 @@ def compact_line(out):
     if cb:
         c["cpu_baseline"] = {"value": cb.get("value"), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
                              "sample": _short_sample(cb.get("sample", ""), 200)}
-    for k in ("parity_rel_err_vs_cpu_oracle", "full"):
+    for k in ("parity_rel_err_vs_cpu_oracle", "process", "full"):
         if out.get(k) is not None:
             c[k] = out[k]
     tp = out.get("tp_row")
@@ -1017,6 +1017,9 @@ def main():
                          "instead of the default: every weight rebuilt with the reference CPU path's three 16-bit "
                          "roundings (VPTQ_GEMV_EXACT, bit-identical weights)")
     ap.add_argument("--exact", action="store_true", help="accepted, no effect: the default since round 5")
+    ap.add_argument("--arithmetic", choices=["reference", "selective", "folded"], default=None,
+                    help="the headline's arithmetic (default: reference = the product default; selective / folded = the opt-in forms, "
+                         "vptq_amd.set_arithmetic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--extras", action="store_true",
@@ -1080,13 +1083,19 @@ def main():
     from vptq_amd import _backend as B
     lib = B.lib()
     H = a.hidden
-    a.exact = not a.folded
-    flags = B.GEMV_EXACT if a.exact else 0
-    B.set_arithmetic("reference" if a.exact else "folded")   # (module routes inside the extras follow the same mode)
+    if a.arithmetic is None:
+        a.arithmetic = "folded" if a.folded else "reference"
+    a.folded = a.arithmetic == "folded"
+    a.exact = a.arithmetic == "reference"
+    flags = {"reference": B.GEMV_EXACT, "selective": B.GEMV_SELECTIVE, "folded": 0}[a.arithmetic]
+    B.set_arithmetic(a.arithmetic)   # (module routes inside the extras follow the same mode)
     timer = Timer(dev, dist, allow_eager=mode in ("tp", "tp_row", "tp_pair"))
     arithmetic = ("reference roundings per weight (VPTQ_GEMV_EXACT, the product default since round 5): w = f16(f16(f16(c+r)*s)+b) "
                   "as the reference CPU path rounds it, fp32 accumulate, one rounding of y - bit-identical weights, >= 99 % of "
                   "the outputs bit-identical" if a.exact else
+                  "selective (opt-in, --arithmetic selective / VPTQ_ARITHMETIC=selective, round 6): the folded form with the reference's roundings "
+                  "on the 128-column blocks an activation dominates (|f16(s x)| >= 6 rms); 2 of 12 300 checkpoint-like layers above the bar at "
+                  "1.00e-3 / 1.09e-3 through the chain route (folded: 30 of 4100), profiles/r06/count_chain_*.txt" if a.arithmetic == "selective" else
                   "folded fp32 (opt-in, --folded / VPTQ_ARITHMETIC=folded): sum (c+r)*f16(s*x) + sum b*x - inside the 1e-3 "
                   "max-normalised parity bar for dense activations (measured 5-6e-4), not bit-equivalent, above the bar on 3 of 1000 "
                   "checkpoint-like layers with massive-channel / sparse activations (profiles/r05/gate_count_*)")
@@ -1222,7 +1231,8 @@ def main():
     # the newest round's PMC summary of this configuration
     rounds = sorted(d for d in os.listdir(os.path.join(ROOT, "profiles")) if d[:1] == "r" and d[1:].isdigit())
     for rd in reversed(rounds):
-        cand = os.path.join(ROOT, "profiles", rd, f"bench_h{H}_{'chain' if chain_mode else mode}{'_exact' if a.exact else ''}_pmc_summary.json")
+        cand = os.path.join(ROOT, "profiles", rd, f"bench_h{H}_{'chain' if chain_mode else mode}"
+                            f"{'_exact' if a.exact else '_selective' if a.arithmetic == 'selective' else ''}_pmc_summary.json")
         if os.path.exists(cand) and not a.prefetch:
             # HBM bytes per launch from a separate rocprofv3 --pmc run of this same command
             # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); see the file's _note

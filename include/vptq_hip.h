@@ -102,10 +102,15 @@ enum {
    * arithmetic) on the activation columns that dominate the token - |f16(scale_g x_g)| >= 6 x the rms of f16(scale x) over the
    * layer's columns.  The folded form's distance to the reference is a sum of per-column rounding errors that average out over
    * thousands of columns when the activations are dense and do not when a handful of channels carry the token (massive
-   * activations): those columns are rebuilt bit-exactly, the rest stays folded.  Kernels that implement it: the persistent
-   * chain launch (fp16, independent layers; needs vptq_quant_gemv_chain_workspace_bytes(n, flags) of workspace for the
-   * thresholds) and the persistent MFMA kernel (fp16, 1 token); every other kernel / layer takes VPTQ_GEMV_EXACT
-   * instead (always at least as close to the reference).  With VPTQ_GEMV_EXACT set as well, EXACT wins. */
+   * activations): the blocks of 128 columns that hold such a column are rebuilt bit-exactly, the rest stays folded.  Kernels
+   * that implement it: the persistent chain launch (fp16, independent layers; needs the workspace
+   * vptq_quant_gemv_chain_workspace_bytes_for(descs, n, flags) asks for - 16 bytes per layer + 4 per output: thresholds and
+   * the hot blocks' exact products) and the persistent MFMA kernel of one-layer / grouped launches (fp16, 1 token, up to
+   * 14336 columns, at most 4 row groups per workgroup; the threshold there is taken over the 512 columns a wave stages);
+   * every other kernel / layer / token count takes VPTQ_GEMV_EXACT instead (always at least as close to the reference).
+   * With VPTQ_GEMV_EXACT set as well, EXACT wins.  Not bit-equivalent (55 - 65 % of the outputs bit-identical); counted on
+   * checkpoint-like layers: 2 of 12 300 above the 1e-3 bar at 1.00e-3 / 1.09e-3 through the chain launch (folded form: 30
+   * of 4100; the reference's roundings: 0 by construction) - an opt-in, not the default. */
   VPTQ_GEMV_SELECTIVE = 1 << 9
 };
 
@@ -256,7 +261,9 @@ VPTQ_API int vptq_quant_gemv_chain(const VptqLayerDesc* descs, int n, const void
 VPTQ_API size_t vptq_quant_gemv_chain_workspace_bytes(int n, int flags);
 /* the same + (independent lists, ABI >= 7) room for x[perm] of every layer with an input permutation: with that much
  * 256-byte aligned workspace such layers stay in the persistent launch (x is gathered by one small launch in front of
- * it); with less they are served by grouped / single launches, which apply permutations themselves */
+ * it); with less they are served by grouped / single launches, which apply permutations themselves.
+ * flags | VPTQ_GEMV_SELECTIVE (ABI >= 10): + per launch of <= 32 layers 16 bytes per layer and 4 per output, in front of the
+ * rest; with less (or NULL) the call takes VPTQ_GEMV_EXACT for every layer */
 VPTQ_API size_t vptq_quant_gemv_chain_workspace_bytes_for(const VptqLayerDesc* descs, int n, int flags);
 VPTQ_API const char* vptq_quant_gemv_chain_kernel_name(const VptqLayerDesc* descs, int n, int tokens,
                                               int flags);

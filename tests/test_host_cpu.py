@@ -757,7 +757,7 @@ def test_exact_slice_rule_opt_in_for_two_tokens():
             "print([f(_family_desc(I, 4096, v, 65536, kr), B.GEMV_EXACT) for (I, v, kr) in "
             "((4096, 8, 0), (4024, 8, 0), (4032, 8, 0), (3512, 8, 256), (3520, 8, 256), (8192, 8, 256), (4096, 16, 0), (5376, 16, 0))],"
             " [f(_family_desc(4096, 4096, 8, 65536, 256), 0)])") % (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden"))
-    env = dict(os.environ, VPTQ_SLICED_SLICES="room2")
+    env = dict(os.environ, VPTQ_SLICED_SLICES="room2", VPTQ_TUNING="1")   # (tuning knobs are read only with VPTQ_TUNING=1)
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.strip().splitlines()[-1] == "[16, 8, 16, 8, 16, 16, 16, 16] [8]", out.stdout

@@ -112,7 +112,9 @@ def main_chain(a):
     dev = torch.device("cuda", 0)
     assert a.dtype == "f16", "the chain kernel takes the reference's roundings (whole or selective) for fp16 only"
     dt, bar = torch.float16, 1e-3
-    B.set_arithmetic("folded")          # (descriptor flags: the call's flags decide, not the load-time gate's EXACT)
+    # (descriptor flags: the call's flags decide on top of the load-time gate's EXACT - the gate of the arithmetic under test:
+    # 6.5e-4 of probe distance for the selective form, 7.5e-4 for the folded one; chain-exact: no gate needed)
+    B.set_arithmetic("selective" if a.route == "chain-selective" else "folded")
     fl = {"chain-selective": B.GEMV_SELECTIVE, "chain-folded": 0, "chain-exact": B.GEMV_EXACT}[a.route] | B.GEMV_FORCE_MFMA
     g = torch.Generator(device=dev).manual_seed(7000 + a.seed)
     rng = np.random.default_rng(a.seed)
@@ -135,7 +137,7 @@ def main_chain(a):
             ch = GemvChain(ms)
             name = ch.kernel_name(flags=fl)
             assert name == "gemv_k256c_kernel", name
-            gated += sum(int(bool(m._descriptor()[9])) for m in ms)
+            gated += sum(int(bool(m._descriptor()[9] & B.GEMV_EXACT)) for m in ms)
             if a.probe:
                 probes += [float(B.folded_probe_distance(m._descriptor()[1], m.in_features, m.out_features, m.weight_bias.data, dt, dev)) for m in ms]
             ys = ch(xs, flags=fl)
@@ -197,7 +199,7 @@ def main():
             m = make(I, O, fam, dt, dev, g)
             x = make_x(m, XKINDS[(done + i) % len(XKINDS)], dt, dev, g)
             d = m._descriptor()
-            gated = bool(d[9])
+            gated = bool(d[9] & B.GEMV_EXACT) if vptq_amd.arithmetic() != "reference" else False   # (sent to the reference roundings by the load-time gate)
             st["gated"] += int(gated)
             W = m.dequant()
             s64 = W.double() @ x.reshape(-1).double()

@@ -6,6 +6,7 @@ layers in a hipGraph; us per layer.
 import argparse, json, os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tools"))
+os.environ["VPTQ_TUNING"] = "1"          # (tuning knobs are read only with it)
 os.environ["VPTQ_SLICED_TOKENS"] = "4,4"   # (the route under test is chosen per call below)
 os.environ["VPTQ_SLICED_ONE_LAUNCH"] = "0"  # (the module's forward = one sliced launch PER token here; the one-launch kernel is called directly)
 from microbench import time_graph  # noqa

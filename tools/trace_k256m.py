@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--out", default="")
     a = ap.parse_args()
     os.environ["VPTQ_K256_KERNEL"] = a.kernel
+    os.environ["VPTQ_TUNING"] = "1"   # (tuning knobs are read only with it)
     dev = torch.device("cuda", 0)
     H = a.hidden
     lib = C.CDLL(os.environ.get("VPTQ_TRACE_LIB") or os.path.join(ROOT, "tools", "_build", "libvptq_hip_trace.so"))

@@ -18,6 +18,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # VPTQ_HIP_LIB: load another build of the library (A/B runs of tools/)
 LIB_PATH = os.environ.get("VPTQ_HIP_LIB") or os.path.join(_HERE, "libvptq_hip.so")
 
+
+def tune_env(name: str, default=None):
+    """Tuning / A-B knobs (tools/README.md lists them) are read only when VPTQ_TUNING=1 is set - here and in the library
+    (csrc/common.h:tune_env): the package's behaviour does not depend on stray environment variables.  The four PRODUCT
+    knobs are read unconditionally: VPTQ_ARITHMETIC (reference | selective | folded), VPTQ_SLICED_LAYOUT (auto | 0 | 1),
+    VPTQ_FUSED_GEMM_MAX_TOKENS, VPTQ_HIP_LIB (another build of the library)."""
+    return os.environ.get(name, default) if os.environ.get("VPTQ_TUNING") == "1" else default
+
 ABI_VERSION = 10
 DTYPE_F16, DTYPE_BF16 = 0, 1
 GEMV_FAST_MATH = 1 << 0
@@ -271,7 +279,7 @@ def _derived(owner: torch.Tensor, name: str, key, build):
 # events no run-time test can see; profiles/r06/count_chain_*.txt) at 95 % of its speed, and is still not bit-equivalent:
 # ~55 - 65 % of the outputs bit-identical, worst ~9.8e-4 = one flip of the last bit at the top binade.
 _ARITH = {"folded": os.environ.get("VPTQ_ARITHMETIC", "reference").strip().lower() in ("folded", "fast") or
-          os.environ.get("VPTQ_FOLDED", "0") == "1",
+          tune_env("VPTQ_FOLDED", "0") == "1",
           "selective": os.environ.get("VPTQ_ARITHMETIC", "reference").strip().lower() == "selective", "generation": 0}
 
 

@@ -122,7 +122,7 @@ enum Route { kRouteNone, kRouteGemmK256T, kRouteGemmK256, kRouteK256, kRouteGath
 static int batch_min_tokens() {
   static std::atomic<int> v{-1};  // VPTQ_GEMM_MIN_TOKENS: smallest token count that takes the batched-decode kernel
   // (at most 16: vptq_quant_gemv_max_tokens promises the batched kernel for 17+ tokens of such layers)
-  if (v < 0) { const char* ev = getenv("VPTQ_GEMM_MIN_TOKENS"); const int w = ev ? atoi(ev) : 5; v = w > 16 ? 16 : (w < 1 ? 1 : w); }
+  if (v < 0) { const char* ev = vptq::tune_env("VPTQ_GEMM_MIN_TOKENS"); const int w = ev ? atoi(ev) : 5; v = w > 16 ? 16 : (w < 1 ? 1 : w); }
   return v;
 }
 
@@ -135,7 +135,7 @@ static int batch_t_min_tokens(int dtype) {
   static std::atomic<int> vf{-1}, vb{-1};
   std::atomic<int>& v = dtype == VPTQ_DTYPE_F16 ? vf : vb;
   if (v < 0) {
-    const char* ev = getenv(dtype == VPTQ_DTYPE_F16 ? "VPTQ_GEMMT_MIN_TOKENS_F16" : "VPTQ_GEMMT_MIN_TOKENS_BF16");
+    const char* ev = vptq::tune_env(dtype == VPTQ_DTYPE_F16 ? "VPTQ_GEMMT_MIN_TOKENS_F16" : "VPTQ_GEMMT_MIN_TOKENS_BF16");
     const int w = ev ? atoi(ev) : 5;
     v = w < 1 ? 1 : w;
   }
@@ -481,7 +481,7 @@ int vptq_quant_gemv_chain(const VptqLayerDesc* descs, int n, const void* const* 
   }
   // VPTQ_K256C_PROF builds write per-wave profile words to the workspace of a non-dependent launch: only when the
   // caller handed over enough of it (256 workgroups x 16 waves x 64 words of 8 bytes)
-  const bool prof_ws = !dependent && getenv("VPTQ_K256C_PROF") && workspace && workspace_bytes >= (size_t)256 * 16 * 64 * 8;
+  const bool prof_ws = !dependent && vptq::tune_env("VPTQ_K256C_PROF") && workspace && workspace_bytes >= (size_t)256 * 16 * 64 * 8;
   for (int i0 = 0; i0 < n; i0 += 32) {
     const int m = n - i0 < 32 ? n - i0 : 32;
     const hipError_t e = vptq::launch_gemv_k256c(descs + i0, m, x + i0, y + i0, lflags, dependent,

@@ -1,15 +1,19 @@
 // Device-side helpers shared by the gfx950 kernels (wave64, CDNA4).
 #pragma once
+#include <stdlib.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "../../include/vptq_hip.h"
+#include "tune_env.h"
 
 // The 16-bit arithmetic below must round after EVERY op (that is what the
 // reference CPU path does); never let the compiler fuse a*b+c into one fma.
 #pragma clang fp contract(off)
 
 namespace vptq {
+
+
 
 typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));

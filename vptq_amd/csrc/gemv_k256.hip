@@ -359,7 +359,7 @@ bool gemv_k256_eligible(const VptqLayerDesc& d, int tokens) {
 // the instantiation stays spill-free under the 128-VGPR budget (f16, one token).
 static int pick_rows(int n_rows_total, int tok, bool f16) {
   static std::atomic<int> forced{-1};  // VPTQ_K256_ROWS=1|2: tuning override
-  if (forced < 0) { const char* e = getenv("VPTQ_K256_ROWS"); forced = e ? atoi(e) : 0; }
+  if (forced < 0) { const char* e = vptq::tune_env("VPTQ_K256_ROWS"); forced = e ? atoi(e) : 0; }
   if (forced == 2 && f16 && tok == 1) return 2;
   if (forced == 1) return 1;
   return (f16 && tok == 1 && (n_rows_total + 1) / 2 >= 512) ? 2 : 1;
@@ -443,7 +443,7 @@ struct K256Choice {
 static K256Choice choose_kernel(const VptqLayerDesc* descs, int n, int tokens, int flags) {
   static std::atomic<int> forced{-1};
   if (forced < 0) {
-    const char* e = getenv("VPTQ_K256_KERNEL");
+    const char* e = vptq::tune_env("VPTQ_K256_KERNEL");
     forced = !e ? 0 : (e[0] == 'v' ? 1 : e[0] == 'm' ? 2 : 0);
   }
   const int tok = tokens > 2 ? 4 : tokens;
@@ -545,7 +545,7 @@ hipError_t launch_gemv_k256(const VptqLayerDesc* descs, int n, const void* const
     chunk = (chunk + 127) / 128 * 128;
     Ly.pf_chunk = (int)chunk;
     static std::atomic<int> pf_cap{-1};  // VPTQ_PF_BYTES: cap on the bytes each workgroup reads ahead
-    if (pf_cap < 0) { const char* e = getenv("VPTQ_PF_BYTES"); pf_cap = e ? atoi(e) : 1 << 30; }
+    if (pf_cap < 0) { const char* e = vptq::tune_env("VPTQ_PF_BYTES"); pf_cap = e ? atoi(e) : 1 << 30; }
     const long long cap = pf_cap.load();
     long long len = chunk < cap ? chunk : cap;
     if (len > wg_threads * 128) len = wg_threads * 128;  // one line per thread

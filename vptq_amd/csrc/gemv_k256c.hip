@@ -1124,7 +1124,9 @@ __global__ __launch_bounds__(kCThreads) void gemv_k256c_kernel(const K256CParams
 // vector-rows as the reference rounds them - w = f16(f16(f16(c + r) s) + b), vptq/ops/quant_gemm.py:121,155-156 - and stores
 // sum w x (fp32) of those columns as the rows' corrections.  kappa: VPTQ_SELECTIVE_KAPPA; the study behind the 6:
 // tools/hybrid_error_study.py, profiles/r06/selective_*.txt.
-constexpr int kHotRows = 16;          // vector-rows per workgroup: 16 lanes per row, 8 columns per lane and hot block
+constexpr int kHotRows = 64;          // vector-rows per workgroup: 4 rounds of 16 (16 lanes per row, 8 columns per lane and hot block);
+                                      // every workgroup repeats the threshold / hot-block search (64 KiB out of the L2): 16 rows per
+                                      // workgroup made that search 10 us per launch of 32 layers (rocprofv3, round 6), 64: a quarter
 constexpr int kHotMaxBlocks = 256;    // 32768 columns
 struct CHotArgs {
   uint32_t corr_off[kMaxGroup];   // byte offset of layer l's corrections from P.sync
@@ -1139,11 +1141,27 @@ __global__ __launch_bounds__(256) void k256c_hot_kernel(const K256CParams P, con
   const CLayerArgs Ly = c_load_layer(L);
   uint32_t* const hdr = as_global(P.sync) + 4 * L;
   if (tid < kHotMaxBlocks / 32) mask[tid] = 0u;
+  // the columns in batches of 8192 per workgroup: a thread's 16 pairs of a batch are requested together (one latency per batch, not
+  // per pair: 32 dependent trips to the L2 made this search 7 us per launch); the first batch stays in registers for the second pass
+  constexpr int kPer = 16;
+  uint32_t xp0[kPer];
   float ss = 0.f;
-  for (int c = 2 * tid; c < Ly.G; c += 512) {
-    const uint32_t xp = DT::mul2(*(const uint32_t*)(Ly.x + c), *(const uint32_t*)(Ly.scale + c));
-    const float a = DT::lo(xp), b = DT::hi(xp);
-    ss = __builtin_fmaf(a, a, __builtin_fmaf(b, b, ss));
+  for (int base = 0; base < Ly.G; base += 512 * kPer) {
+    uint32_t xv[kPer], sv[kPer];
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) {
+      const int c = base + i * 512 + 2 * tid;
+      const int cc = c < Ly.G ? c : 0;
+      xv[i] = *(const uint32_t*)(Ly.x + cc);
+      sv[i] = *(const uint32_t*)(Ly.scale + cc);
+    }
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) {
+      const uint32_t xp = base + i * 512 + 2 * tid < Ly.G ? DT::mul2(xv[i], sv[i]) : 0u;
+      if (base == 0) xp0[i] = xp;
+      const float a = DT::lo(xp), b = DT::hi(xp);
+      ss = __builtin_fmaf(a, a, __builtin_fmaf(b, b, ss));
+    }
   }
   ss = wave_sum(ss);
   if ((tid & 63) == 0) part[tid >> 6] = ss;
@@ -1158,9 +1176,28 @@ __global__ __launch_bounds__(256) void k256c_hot_kernel(const K256CParams P, con
     }
     if (thr == 0u) thr = 1u;                       // (all-zero activations: nothing is hot)
   }
-  for (int c = 2 * tid; c < Ly.G; c += 512) {
-    const uint32_t xp = DT::mul2(*(const uint32_t*)(Ly.x + c), *(const uint32_t*)(Ly.scale + c));
-    if ((xp & 0x7fffu) >= thr || ((xp >> 16) & 0x7fffu) >= thr) atomicOr(&mask[c >> 12], 1u << ((c >> 7) & 31));
+  for (int base = 0; base < Ly.G; base += 512 * kPer) {
+    uint32_t xq[kPer];
+    if (base == 0) {
+#pragma unroll
+      for (int i = 0; i < kPer; ++i) xq[i] = xp0[i];
+    } else {
+      uint32_t xv[kPer], sv[kPer];
+#pragma unroll
+      for (int i = 0; i < kPer; ++i) {
+        const int c = base + i * 512 + 2 * tid;
+        const int cc = c < Ly.G ? c : 0;
+        xv[i] = *(const uint32_t*)(Ly.x + cc);
+        sv[i] = *(const uint32_t*)(Ly.scale + cc);
+      }
+#pragma unroll
+      for (int i = 0; i < kPer; ++i) xq[i] = base + i * 512 + 2 * tid < Ly.G ? DT::mul2(xv[i], sv[i]) : 0u;
+    }
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) {
+      const int c = base + i * 512 + 2 * tid;
+      if ((xq[i] & 0x7fffu) >= thr || ((xq[i] >> 16) & 0x7fffu) >= thr) atomicOr(&mask[c >> 12], 1u << ((c >> 7) & 31));
+    }
   }
   __syncthreads();
   int nhot = 0;
@@ -1169,14 +1206,16 @@ __global__ __launch_bounds__(256) void k256c_hot_kernel(const K256CParams P, con
   if (blockIdx.x == 0 && tid == 0) {
     hdr[0] = thr; hdr[1] = (uint32_t)nhot; hdr[2] = H.corr_off[L]; hdr[3] = 0u;
   }
-  const int row = (int)blockIdx.x * kHotRows + (tid >> 4);
   if (nhot == 0 || (int)blockIdx.x * kHotRows >= Ly.N) return;
   // both codebooks: thread t copies entry t of each (16 bytes)
   *(u32x4*)&cb[0][tid * 4] = *(const u32x4*)(Ly.cent + tid * 4);
   *(u32x4*)&cb[1][tid * 4] = *(const u32x4*)(Ly.rcent + tid * 4);
   __syncthreads();
-  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const int sub = tid & 15;                        // 8 columns of the block
+#pragma unroll 1
+  for (int round = 0; round < kHotRows / 16; ++round) {
+  const int row = (int)blockIdx.x * kHotRows + round * 16 + (tid >> 4);
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const int rr = row < Ly.N ? row : Ly.N - 1;
   const char* const irow = (const char*)Ly.idx + (size_t)rr * ((size_t)Ly.row_words * 4);
   for (int wd = 0; wd < kHotMaxBlocks / 32; ++wd) {
@@ -1213,6 +1252,7 @@ __global__ __launch_bounds__(256) void k256c_hot_kernel(const K256CParams P, con
     for (int k = 0; k < 8; ++k)
       if (row * 8 + k < Ly.O) co[k] = acc[k];
   }
+  }   // round
 }
 // bytes of a SEL launch's workspace: 16 per layer, then 4 per output
 size_t gemv_k256c_selective_bytes(const VptqLayerDesc* descs, int n) {
@@ -1222,7 +1262,7 @@ size_t gemv_k256c_selective_bytes(const VptqLayerDesc* descs, int n) {
 }
 static float c_kappa() {
   static std::atomic<int> milli{-1};
-  if (milli < 0) { const char* e = getenv("VPTQ_SELECTIVE_KAPPA"); const double v = e ? atof(e) : 0.0; milli = v > 0.0 ? (int)(v * 1000.0) : 6000; }
+  if (milli < 0) { const char* e = vptq::tune_env("VPTQ_SELECTIVE_KAPPA"); const double v = e ? atof(e) : 0.0; milli = v > 0.0 ? (int)(v * 1000.0) : 6000; }
   return (float)milli.load() * 1e-3f;
 }
 
@@ -1276,7 +1316,7 @@ static int c_device_cus() {
 
 static int c_workgroups(bool dependent) {
   static std::atomic<int> forced_wgs{-1};  // VPTQ_K256C_WGS: tuning override of the workgroup count
-  if (forced_wgs < 0) { const char* e = getenv("VPTQ_K256C_WGS"); forced_wgs = e ? atoi(e) : 0; }
+  if (forced_wgs < 0) { const char* e = vptq::tune_env("VPTQ_K256C_WGS"); forced_wgs = e ? atoi(e) : 0; }
   const int fw = forced_wgs.load();
   const int cus = fw > 0 ? fw : c_device_cus();
   return dependent && cus > kCFlagStride ? kCFlagStride : cus;

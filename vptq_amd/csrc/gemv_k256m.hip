@@ -1078,7 +1078,7 @@ static int m_groups_per_wg(int groups, long long total, int cus) {
 }
 static int m_cus() {
   static std::atomic<int> forced_wgs{-1};  // VPTQ_K256M_WGS: tuning override of the CU count
-  if (forced_wgs < 0) { const char* e = getenv("VPTQ_K256M_WGS"); forced_wgs = e ? atoi(e) : 0; }
+  if (forced_wgs < 0) { const char* e = vptq::tune_env("VPTQ_K256M_WGS"); forced_wgs = e ? atoi(e) : 0; }
   const int fw = forced_wgs.load();
   return fw > 0 ? fw : device_cus();
 }
@@ -1099,7 +1099,7 @@ hipError_t launch_gemv_k256m(K256Params& P, int tok, bool f16, bool fast, int ma
   if (!gemv_k256m_supported(tok, f16, fast, max_cols, perm)) return hipErrorInvalidValue;
   if (selective && !(fast && f16 && tok == 1 && max_cols <= kMMaxCols)) return hipErrorInvalidValue;
   static std::atomic<int> forced_wgs{-1};  // VPTQ_K256M_WGS: tuning override of the CU count
-  if (forced_wgs < 0) { const char* e = getenv("VPTQ_K256M_WGS"); forced_wgs = e ? atoi(e) : 0; }
+  if (forced_wgs < 0) { const char* e = vptq::tune_env("VPTQ_K256M_WGS"); forced_wgs = e ? atoi(e) : 0; }
   const int fw = forced_wgs.load();
   const int cus = fw > 0 ? fw : device_cus();
   long long total = 0;

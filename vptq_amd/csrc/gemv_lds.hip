@@ -767,7 +767,7 @@ static hipError_t launch_lds_mfma_dt(const LdsParams& P, int fmt, int grid, int 
 static bool lds_use_mfma(const LdsParams& P, int RW, bool exact) {
   static std::atomic<int> force{-1};   // VPTQ_LDS_KERNEL=valu|mfma (A/B runs)
   if (force < 0) {
-    const char* ev = getenv("VPTQ_LDS_KERNEL");
+    const char* ev = vptq::tune_env("VPTQ_LDS_KERNEL");
     force = ev && ev[0] == 'v' ? 1 : 0;
   }
   return force != 1 && P.tokens == 1 && !exact && RW >= 4 && P.G <= kLMStageIt * kLThreads * 8 &&

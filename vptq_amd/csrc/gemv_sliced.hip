@@ -889,7 +889,7 @@ static uint32_t sl_operand_bytes(const VptqLayerDesc& d, bool exact, int tokens 
 // (4704), 16 up to 16288 (15616); v = 16: 16 / 32 at the same widths; wider layers: 0 (not served: gemv_gather)
 int gemv_sliced_slices(const VptqLayerDesc& d, bool exact) {
   static std::atomic<int> force16{-1};   // VPTQ_SLICED_SLICES=16: the larger slice count for every layer (A/B)
-  if (force16 < 0) { const char* e = getenv("VPTQ_SLICED_SLICES"); force16 = (e && atoi(e) == 16) ? 1 : 0; }
+  if (force16 < 0) { const char* e = vptq::tune_env("VPTQ_SLICED_SLICES"); force16 = (e && atoi(e) == 16) ? 1 : 0; }
   const int small = d.vector_len == 16 ? 16 : 8;
   if (!exact) {
     if (force16 == 1) return 2 * small;
@@ -902,7 +902,7 @@ int gemv_sliced_slices(const VptqLayerDesc& d, bool exact) {
   // 2 sequences 198.6 -> 210.7 tokens/s, 3: 270.6 -> 277.3, ONE: 127.1 -> 125.4 (the layers' own time +5 %) - one token is the
   // default's business, so the default stays "8 slices wherever one token fits".
   static std::atomic<int> room2{-1};
-  if (room2 < 0) { const char* e = getenv("VPTQ_SLICED_SLICES"); room2 = (e && strcmp(e, "room2") == 0) ? 1 : 0; }
+  if (room2 < 0) { const char* e = vptq::tune_env("VPTQ_SLICED_SLICES"); room2 = (e && strcmp(e, "room2") == 0) ? 1 : 0; }
   for (int nsl = (force16 == 1 ? 2 * small : small); nsl <= 2 * small; nsl *= 2) {
     const uint32_t tab = (uint32_t)(d.num_centroids / nsl) * (uint32_t)d.vector_len * 2u;
     if ((tab + 15u) / 16u * 16u + sl_operand_bytes(d, true, (nsl == small && room2 == 1 && d.vector_len == 8) ? 2 : 1) <= kSLLdsLimit) return nsl;
@@ -1067,7 +1067,7 @@ int gemv_sliced_exact_tokens_parts(const VptqLayerDesc& d, int tokens) {
   const uint32_t tab = (sl_tab_bytes(d, d.num_centroids, 0, true) + 15u) / 16u * 16u;
   if (tab + sl_operand_bytes(d, true, tokens) <= kSLLdsLimit) return 1;
   static std::atomic<int> on{-1};
-  if (on < 0) { const char* e = getenv("VPTQ_SLICED_WINDOW_PARTS"); on = (e && e[0] == '0') ? 0 : 1; }
+  if (on < 0) { const char* e = vptq::tune_env("VPTQ_SLICED_WINDOW_PARTS"); on = (e && e[0] == '0') ? 0 : 1; }
   if (!on || d.vector_len != 8 || sl_two(d)) return 0;
   const int wc = sl_window_cols(d);
   for (int wparts = 2; wparts <= kSLWindows; wparts *= 2) {

@@ -847,7 +847,7 @@ size_t gemv_sliced_tok_workspace_bytes(const VptqLayerDesc& d, int tokens) {
 // VPTQ_SLICED_ONE_PASS=0: 2 / 3 exact tokens through the column-phase kernel as well (A/B runs)
 static bool st_one_pass(const VptqLayerDesc& d, int tokens, bool exact) {
   static std::atomic<int> on{-1};
-  if (on < 0) { const char* e = getenv("VPTQ_SLICED_ONE_PASS"); on = (e && atoi(e) == 0 && e[0] == '0') ? 0 : 1; }
+  if (on < 0) { const char* e = vptq::tune_env("VPTQ_SLICED_ONE_PASS"); on = (e && atoi(e) == 0 && e[0] == '0') ? 0 : 1; }
   return exact && on == 1 && gemv_sliced_exact_tokens_ok(d, tokens);
 }
 
@@ -867,7 +867,7 @@ static bool st_plan(const VptqLayerDesc& d, const VptqSlicedLayout* L, int token
   const bool res = sl_res256(d), two = sl_two(d);
   if (exact && !st_exact_ok(d)) return false;
   static std::atomic<int> tok4{-1};   // VPTQ_SLICED_TOK4=1: 2 tokens through the 4-slot (matrix-pipe) kernel too (A/B runs)
-  if (tok4 < 0) { const char* e = getenv("VPTQ_SLICED_TOK4"); tok4 = (e && atoi(e) == 1) ? 1 : 0; }
+  if (tok4 < 0) { const char* e = vptq::tune_env("VPTQ_SLICED_TOK4"); tok4 = (e && atoi(e) == 1) ? 1 : 0; }
   pl.tok = tokens > 4 ? 8 : (tokens == 2 && !tok4 && !exact) ? 2 : 4;   // (the reference's roundings: matrix-pipe mode only)
   uint32_t tab = sl_tab_bytes(d, d.num_centroids, 0, exact);
   if (two) {
@@ -878,9 +878,9 @@ static bool st_plan(const VptqLayerDesc& d, const VptqSlicedLayout* L, int token
   const int G = d.group_size;
   const int wcols = (G + kSTWindows * 8 - 1) / (kSTWindows * 8) * 8;
   static std::atomic<int> min_phases{-1};   // VPTQ_SLICED_MIN_PHASES=2 / 4: more phases than the LDS asks for (A/B runs)
-  if (min_phases < 0) { const char* e = getenv("VPTQ_SLICED_MIN_PHASES"); const int v = e ? atoi(e) : 1; min_phases = (v == 2 || v == 4) ? v : 1; }
+  if (min_phases < 0) { const char* e = vptq::tune_env("VPTQ_SLICED_MIN_PHASES"); const int v = e ? atoi(e) : 1; min_phases = (v == 2 || v == 4) ? v : 1; }
   static std::atomic<int> no_reg_sums{-1};  // VPTQ_SLICED_LDS_SUMS=1: the rows' sums in LDS in every mode (A/B runs)
-  if (no_reg_sums < 0) { const char* e = getenv("VPTQ_SLICED_LDS_SUMS"); no_reg_sums = (e && atoi(e) == 1) ? 1 : 0; }
+  if (no_reg_sums < 0) { const char* e = vptq::tune_env("VPTQ_SLICED_LDS_SUMS"); no_reg_sums = (e && atoi(e) == 1) ? 1 : 0; }
   for (int rpw = rpw0 > 0 ? rpw0 : st_rows_per_wave(d, exact); rpw >= 1; rpw = rpw > 1 ? (rpw + 1) / 2 : 0) {
     for (int phases = min_phases; phases <= kSTWindows; phases *= 2) {
       const int wmax = (kSTWindows / phases) * wcols < G ? (kSTWindows / phases) * wcols : G;   // columns of the widest phase

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/vptq_hip.h"
+#include "tune_env.h"
 
 namespace vptq {
 

@@ -59,12 +59,12 @@ _SLICED_EXACT_MIN_ELEMENTS = 1 << 20   # vector-rows x columns from which the ex
 _SLICED_EXACT_RG_MIN_ELEMENTS = 2 << 20   # ... with the residual entries gathered from L2 (two-table formats)
 # most tokens served as one sliced launch PER TOKEN: decided per layer (VQuantLinear._sliced_token_limit);
 # VPTQ_SLICED_TOKENS="one-table,two-table" overrides it (tools/sliced_tokens_bench.py)
-_SLICED_TOKENS_ENV = tuple(int(v) for v in os.environ["VPTQ_SLICED_TOKENS"].split(",")) if os.environ.get("VPTQ_SLICED_TOKENS") else None
+_SLICED_TOKENS_ENV = tuple(int(v) for v in B.tune_env("VPTQ_SLICED_TOKENS").split(",")) if B.tune_env("VPTQ_SLICED_TOKENS") else None
 _SLICED_MAX_TOKENS = max(max(_SLICED_TOKENS_ENV) if _SLICED_TOKENS_ENV else 3, 4)
 # 2 - 4 tokens in ONE sliced launch (gemv_sliced_tok.hip): "auto" (default) = per layer where it was measured faster than the
 # gather kernels and than one sliced launch per token (VQuantLinear._sliced_one_launch); "1" = wherever the library takes the
 # layer; "0" = never
-_SLICED_ONE_LAUNCH = os.environ.get("VPTQ_SLICED_ONE_LAUNCH", "auto").strip().lower() or "auto"
+_SLICED_ONE_LAUNCH = B.tune_env("VPTQ_SLICED_ONE_LAUNCH", "auto").strip().lower() or "auto"
 
 
 _SLICED_OOM_RETRY_CALLS = 256   # calls of a layer before a sliced-layout build that ran out of memory is tried again

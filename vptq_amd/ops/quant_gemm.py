@@ -24,7 +24,7 @@ __all__ = ["dequant", "quant_gemm", "quant_gemv_v2"]
 
 # env knob: VPTQ_EXACT=1 forces the reference CPU path's three 16-bit roundings per weight whatever the arithmetic mode
 # says (`_backend.set_arithmetic`: "reference" is the default since round 5, "folded" the opt-in fast form)
-_FLAGS = B.GEMV_EXACT if os.environ.get("VPTQ_EXACT", "0") == "1" else 0
+_FLAGS = B.GEMV_EXACT if B.tune_env("VPTQ_EXACT", "0") == "1" else 0
 
 # The arithmetic of the functional op (`_backend.folded_form_is_safe`): the reference's roundings unless the folded form is
 # opted in AND the layer passes its measured gate.  Decided once per set of tensor

@@ -161,7 +161,7 @@ def exact_column_parts(desc, group_size: int):
     """(parts, slices) with which the reference's roundings are served over sliced layouts: (1, n) where the layer fits in one
     piece, (2 or 3, n) where equal column parts of a multiple of 8 columns do (28672-column layers: 2 x 14336), (0, 0) else"""
     import os
-    least = int(os.environ.get("VPTQ_SLICED_PARTS", "1") or 1)     # (A/B: at least this many parts where the columns divide)
+    least = int(B.tune_env("VPTQ_SLICED_PARTS", "1") or 1)     # (A/B: at least this many parts where the columns divide)
     n = B.lib().vptq_sliced_layout_supported_for(desc, B.GEMV_EXACT)
     if n and least <= 1:
         return 1, n
