@@ -147,6 +147,9 @@ def k65536_extra(lib, B, dev, H, steps, warmup, regions, R=8, kr=256, v=8, light
     # takes for these layers in the default arithmetic
     exact_ok = bool(lib.vptq_sliced_layout_supported_for(descs[0][0], B.GEMV_EXACT))
     sxs = [SlicedGemv(m, exact=True) for m in layers] if exact_ok else []
+    # round 6, opt-in selective arithmetic: the two-table formats over the FOLDED layouts with VPTQ_GEMV_SELECTIVE (gemv_hot.hip pre-pass)
+    sel_ok = kr >= 4096 and bool(lib.vptq_quant_gemv_sliced_selective_supported(descs[0][0]))
+    ssel = [SlicedGemv(m, selective=True) for m in layers] if sel_ok else []
 
     def default_pass():
         sp = torch.cuda.current_stream().cuda_stream
@@ -161,6 +164,10 @@ def k65536_extra(lib, B, dev, H, steps, warmup, regions, R=8, kr=256, v=8, light
     def exact_sliced_pass():
         for i in range(R):
             sxs[i](x, ys[i])
+
+    def selective_sliced_pass():
+        for i in range(R):
+            ssel[i](x, ys[i])
     T = 16 + (int(np.log2(kr)) if kr else 0)
     ab = (H // v) * ((H * T + 31) // 32) * 4 + (65536 + kr) * v * 2 + 2 * H + 4 * H + 2 * H
     out = {"what": f"VQuantLinear {H}x{H} v={v} k=65536+{kr} (T = {T} bits per index), ring of {R} layers; GB/s of the PACKED format's "
@@ -168,6 +175,8 @@ def k65536_extra(lib, B, dev, H, steps, warmup, regions, R=8, kr=256, v=8, light
     routes = (("default", default_pass), ("sliced_layout", sliced_pass)) + ((("exact_sliced_layout", exact_sliced_pass),) if exact_ok else ())
     if light:
         routes = routes[2:] if exact_ok else routes[:1]
+    if sel_ok:
+        routes = routes + (("selective_sliced_layout", selective_sliced_pass),)
     for key, fn in routes:
         t = Timer(dev).run(fn, steps, warmup, regions)
         us = t["event_ms"] * 1e3 / (steps * R)
@@ -178,6 +187,11 @@ def k65536_extra(lib, B, dev, H, steps, warmup, regions, R=8, kr=256, v=8, light
     if "sliced_layout" in out:
         out["sliced_layout"]["kernel"] = "gemv_sliced_kernel"
         out["sliced_layout"]["what"] = "OPT-IN folded arithmetic over the load-time derived layouts"
+    if sel_ok:
+        out["selective_sliced_layout"]["kernel"] = "gemv_hot_kernel + gemv_sliced_kernel"
+        out["selective_sliced_layout"]["what"] = ("OPT-IN selective arithmetic (round 6): pre-pass (threshold, hot blocks zeroed, their exact products) + the "
+                                                  "folded launch over the layouts - what VQuantLinear.forward takes for two-table formats after "
+                                                  "vptq_amd.set_arithmetic('selective')")
     if exact_ok:
         out["exact_sliced_layout"]["kernel"] = "gemv_sliced_kernel<EX>"
         out["exact_sliced_layout"]["what"] = ("the reference's roundings over a load-time derived layout (LDS-local gathers): the module's one-token route "
@@ -199,7 +213,7 @@ def k65536_extra(lib, B, dev, H, steps, warmup, regions, R=8, kr=256, v=8, light
         out["exact_sliced_vs_default_bit_identical"] = float((got_x.view(torch.int16) == ref.view(torch.int16)).float().mean())
         assert out["exact_sliced_vs_default_bit_identical"] >= 0.95, out
     if light:
-        del layers, sxs
+        del layers, sxs, ssel
         torch.cuda.empty_cache()
         return out
     # 2 and 4 tokens: the gather kernel (vptq_quant_gemv) against ONE launch over the same layouts (gemv_sliced_tok.hip:
@@ -264,7 +278,7 @@ def k65536_extra(lib, B, dev, H, steps, warmup, regions, R=8, kr=256, v=8, light
             out[f"exact_tokens{tokens}"] = row
     except Exception as e:   # (an extra of an extra)
         out["exact_tokens_error"] = f"{type(e).__name__}: {e}"[:300]
-    del layers, sls, sxs
+    del layers, sls, sxs, ssel
     torch.cuda.empty_cache()
     return out
 
@@ -1366,6 +1380,10 @@ def main():
             if "us_per_layer" in df:     # the product default: the exact sliced kernel where it serves the format, else centroid gathers through the caches
                 mp[key] = {"us_per_layer": df["us_per_layer"], "GBps_of_packed_bytes": df.get("GBps"), "frac": df.get("frac_of_8TBps"),
                            "kernel": df.get("kernel")}
+            ss = e.get("selective_sliced_layout") or {}
+            if "us_per_layer" in ss:     # ... the opt-in selective arithmetic (round 6)
+                mp[key + "_selective_opt_in"] = {"us_per_layer": ss["us_per_layer"], "GBps_of_packed_bytes": ss.get("GBps"),
+                                                 "frac": ss.get("frac_of_8TBps"), "kernel": "gemv_hot + gemv_sliced"}
             if "us_per_layer" in sl:     # ... and the opt-in folded arithmetic over the load-time derived sliced layouts
                 mp[key + "_folded_opt_in"] = {"us_per_layer": sl["us_per_layer"], "GBps_of_packed_bytes": sl.get("GBps"),
                                               "frac": sl.get("frac_of_8TBps"), "kernel": sl.get("kernel", "gemv_sliced_kernel")}

@@ -351,6 +351,16 @@ VPTQ_API int vptq_sliced_layout_whole_table(const VptqLayerDesc* desc, int table
 VPTQ_API size_t vptq_quant_gemv_sliced_workspace_bytes(const VptqLayerDesc* desc);
 VPTQ_API int vptq_quant_gemv_sliced(const VptqLayerDesc* desc, const VptqSlicedLayout* layout, const void* x,
                            void* y, int flags, void* workspace, size_t workspace_bytes, void* stream);
+/* flags | VPTQ_GEMV_SELECTIVE (ABI >= 10; the FOLDED layouts, i.e. without VPTQ_GEMV_EXACT): the folded form over the layouts, with the
+ * reference's roundings on the blocks of 128 columns an activation dominates.  A small launch in front (gemv_hot.hip) finds the
+ * threshold, writes the activation with those blocks' input features zeroed - what the folded launch then reads - and the blocks'
+ * exact products per output (entries gathered from the codebooks in device memory: few columns), which the folded launch adds before
+ * its one rounding.  fp16 layers with scale and bias (vptq_quant_gemv_sliced_selective_supported); workspace:
+ * vptq_quant_gemv_sliced_workspace_bytes_for(desc, flags) bytes, 256-byte aligned, zero-filled once (the accumulator words come first).
+ * What it buys: the two-table formats (v8-k65536-65536, v16-k65536-65536) at the folded form's speed - 8192^2: 59 / 46 us in the
+ * reference's roundings, ~21 / ~22 here - without the folded form's activation-dependent failures; opt-in, like every use of the flag. */
+VPTQ_API int vptq_quant_gemv_sliced_selective_supported(const VptqLayerDesc* desc);
+VPTQ_API size_t vptq_quant_gemv_sliced_workspace_bytes_for(const VptqLayerDesc* desc, int flags);
 
 /* 2 - 4 tokens (5 - 8 where 16 bytes of activations per column still fit the LDS in 4 phases: layers of up to ~4600 columns)
  * over the same layouts (ABI >= 7; needs `wstart`): x [tokens][in_features], y [tokens][out_features]

@@ -29,6 +29,12 @@ def _x(I, seed, dist="llm"):
     return xs.astype(np.float32)
 
 
+def _col_scale(L):
+    """weight_scale in COLUMN order (column c of the quantised matrix multiplies input feature perm[c])"""
+    s = vo.to_f32(np.asarray(L.weight_scale), "f16").reshape(-1)
+    return s
+
+
 # (I, O, kwargs): one to seven sweeps, partial sweeps and row groups, several row groups per workgroup, bias, permutation
 SHAPES = [
     (2048, 4608, dict(dist="llm")),                       # 144 row groups: the kernel's own threshold
@@ -57,8 +63,9 @@ def test_selective_one_layer_vs_oracle_and_pure_arithmetics(I, O, kw, dev):
     hot_cols = [1, I // 3, I - 2]
     xm[..., hot_cols] *= 40.0
     xo = np.zeros_like(xd)
+    sc = _col_scale(L)
     for c, v in zip(hot_cols, (23.5, -17.25, 9.125)):
-        xo[..., c] = v
+        xo[..., c] = v / max(abs(float(sc[c])), 1e-3)     # (|s x| of comparable size: all three columns are hot whatever their scales)
     for name, xf in (("dense", xd), ("massive", xm), ("only-massive", xo)):
         xb = vo.from_f32(xf, "f16")
         xt = bits_to_tensor(xb, "f16", dev).reshape(1, 1, I)
@@ -156,3 +163,89 @@ def test_module_forward_in_the_selective_arithmetic(dev, selective_arithmetic):
     want2 = vo.forward(L2, x2)
     assert rel_err(tensor_to_bits(y2), want2, "f16") <= 1e-3
     assert float((tensor_to_bits(y2).reshape(-1) == np.asarray(want2).reshape(-1)).mean()) >= 0.95   # (the reference's roundings)
+
+
+# ---- the large-codebook formats: VPTQ_GEMV_SELECTIVE over the FOLDED sliced layouts (gemv_hot.hip + gemv_sliced.hip) ----
+SLICED_CASES = [
+    # (I, O, v, kr, kwargs)
+    (4096, 1024, 8, 65536, dict(dist="llm")),
+    (8192, 520, 8, 65536, dict(dist="llm", bias=True)),
+    (2048, 1032, 8, 4096, dict(dist="llm", enable_perm=True)),
+    (4104, 264, 8, 65536, dict()),
+    (4096, 1024, 16, 65536, dict(dist="llm")),
+    (2048, 528, 16, 65536, dict(dist="llm", enable_perm=True, bias=True)),
+    (4096, 512, 8, 256, dict(dist="llm")),          # one table + the 256-entry residual (24-bit elements)
+    (4096, 512, 8, 0, dict(dist="llm")),            # no residual codebook
+]
+
+
+@pytest.mark.parametrize("I,O,v,kr,kw", SLICED_CASES)
+def test_selective_over_sliced_layouts(I, O, v, kr, kw, dev):
+    from vptq_amd.utils.sliced import SlicedGemv
+    from vptq_amd import _backend as B
+    kw = dict(kw)
+    dist = kw.pop("dist", "ref-test")
+    L = vo.make_layer(I, O, dist=dist, seed=I + O + v + kr, dtype="f16", vector_len=v, num_centroids=65536, num_res_centroids=kr, **kw)
+    m = spec_to_module(L, dev)
+    assert B.lib().vptq_quant_gemv_sliced_selective_supported(m._descriptor()[1]) == 1
+    sl = SlicedGemv(m, selective=True)
+    fo = SlicedGemv(m)
+    assert sl.selective and not sl.exact and not sl.tokens_supported(2)
+    xd = _x(I, I + 7, dist)
+    xm = xd.copy()
+    hot_cols = [2, I // 2 + 1, I - 3]
+    xm[..., hot_cols] *= 40.0
+    xo = np.zeros_like(xd)
+    sc = _col_scale(L)
+    for c, val in zip(hot_cols, (21.5, -13.25, 7.125)):
+        xo[..., c] = val / max(abs(float(sc[c])), 1e-3)   # (|s x| of comparable size: all three columns are hot whatever their scales)
+    for name, xf in (("dense", xd), ("massive", xm), ("only-massive", xo)):
+        xb = vo.from_f32(xf, "f16")
+        xt = bits_to_tensor(xb, "f16", dev).reshape(1, 1, I)
+        y = sl(xt)
+        assert y is not None
+        torch.cuda.synchronize()
+        err = rel_err(tensor_to_bits(y), vo.forward(L, xb), "f16")
+        assert err <= 1e-3, f"{name} {I}x{O} v{v} kr{kr}: {err:.3e}"
+        ys = sl(xt, flags=B.GEMV_OUT_F32)
+        ye = gemv_abi(m, xt, B.GEMV_EXACT, out_f32=True)         # the gather kernels: the reference's roundings
+        yf = fo(xt, flags=B.GEMV_OUT_F32)
+        den = float(ye.abs().max())
+        if name == "only-massive":
+            assert float((ys - ye).abs().max()) <= 3e-6 * den, f"{I}x{O} v{v} kr{kr}"
+        if name == "massive":
+            assert float((ys - ye).abs().max()) <= float((yf - ye).abs().max()) + 1e-6 * den
+        assert torch.equal(sl(xt).view(torch.int16), y.view(torch.int16))     # deterministic; the workspace is left clean
+    # without a hot block: the folded launch, bit for bit (+-1 activations against scales without outliers)
+    s = m.weight_scale.float().abs()
+    if float(s.max()) < 5.5 * float(s.pow(2).mean().sqrt()):
+        rng = np.random.default_rng(3)
+        xf = np.where(rng.random((1, 1, I)) < 0.5, -1.0, 1.0).astype(np.float32)
+        xt = bits_to_tensor(vo.from_f32(xf, "f16"), "f16", dev).reshape(1, 1, I)
+        assert torch.equal(sl(xt).view(torch.int16), fo(xt).view(torch.int16))
+
+
+def test_module_takes_the_selective_sliced_route_for_two_table_formats(dev, selective_arithmetic):
+    """set_arithmetic("selective"): a two-table large-codebook layer big enough for the sliced routes runs the folded layouts with the
+    pre-pass; one-table formats keep the reference's roundings over their exact layouts"""
+    from vptq_amd import _backend as B
+    L = vo.make_layer(4096, 4096, dist="llm", seed=21, dtype="f16", num_centroids=65536, num_res_centroids=65536)
+    m = spec_to_module(L, dev)
+    xf = _x(4096, 22)
+    xf[..., [9, 3000]] *= 45.0
+    xb = vo.from_f32(xf, "f16")
+    y = m(bits_to_tensor(xb, "f16", dev).reshape(1, 1, 4096))
+    torch.cuda.synchronize()
+    assert rel_err(tensor_to_bits(y), vo.forward(L, xb), "f16") <= 1e-3
+    sl = m.__dict__.get("_sliced")
+    assert sl is not None and sl[1] is not None
+    if m._descriptor()[9] == B.GEMV_SELECTIVE:
+        assert sl[1].selective or sl[1].exact        # (exact: the load-time gate refused the selective form of this layer)
+    L1 = vo.make_layer(4096, 2048, dist="llm", seed=23, dtype="f16", num_centroids=65536, num_res_centroids=256)
+    m1 = spec_to_module(L1, dev)
+    x1 = vo.from_f32(_x(4096, 24), "f16")
+    y1 = m1(bits_to_tensor(x1, "f16", dev).reshape(1, 1, 4096))
+    w1 = vo.forward(L1, x1)
+    assert rel_err(tensor_to_bits(y1), w1, "f16") <= 1e-3
+    s1 = m1.__dict__.get("_sliced")
+    assert s1 is not None and s1[1] is not None and s1[1].exact

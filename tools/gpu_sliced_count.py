@@ -30,6 +30,8 @@ def main():
     ap.add_argument("--layers", type=int, default=160)
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--tokens", type=int, default=3, help="token counts drawn from 1 .. this")
+    ap.add_argument("--formats", default="0,256,65536", help="residual codebook sizes drawn (v = 8, 65536 main centroids)")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     dt = torch.float16 if a.dtype == "f16" else torch.bfloat16
@@ -38,10 +40,12 @@ def main():
     rng = np.random.default_rng(a.seed)
     stats = {}
     t0 = time.time()
-    assert vptq_amd.arithmetic() == "reference"
+    # (round 6: VPTQ_ARITHMETIC=selective counts the selective routes - the two-table formats over the folded layouts with the pre-pass)
+    assert vptq_amd.arithmetic() in ("reference", "selective")
+    krs = tuple(int(v) for v in a.formats.split(","))
     for n in range(a.layers):
         fam = FAMILIES[n % len(FAMILIES)]
-        kr = (0, 256, 65536)[int(rng.integers(0, 3))]
+        kr = krs[int(rng.integers(0, len(krs)))]
         I, O = SHAPES[int(rng.integers(0, len(SHAPES)))]
         m = make(I, O, fam, dt, dev, g, k=65536, kr=max(kr, 1)) if kr else None
         if m is None:     # (no residual codebook: the module is built without one)
@@ -54,7 +58,7 @@ def main():
             m.indices.data = torch.randint(-2**31, 2**31 - 1, m.indices.shape, generator=g, device=dev, dtype=torch.int64).to(torch.int32)
             m = m.eval()
         m.enable_sliced_layout()      # (every layer over its layout, small ones too: the kernels are what is counted)
-        T = int(rng.integers(1, 4))
+        T = int(rng.integers(1, a.tokens + 1))
         x = torch.cat([make_x(m, XKINDS[(n + t) % len(XKINDS)], dt, dev, g) for t in range(T)], dim=1)
         W = m.dequant()
         r16 = (x.reshape(T, I).double() @ W.double().t()).to(dt)
@@ -63,7 +67,7 @@ def main():
         if sl is None:
             route = "gather"
         elif T == 1:
-            route = "sliced, %d column part(s)%s" % (sl.parts, ", RG" if sl._side16 else "")
+            route = "selective: pre-pass + folded sliced" if getattr(sl, "selective", False) else "sliced, %d column part(s)%s" % (sl.parts, ", RG" if sl._side16 else "")
         else:
             route = ("one pass" if (m._sliced_one_launch(sl, T) and sl.tokens_one_pass(T)) else "column phases" if m._sliced_one_launch(sl, T)
                      else "launch per token" if T <= m._sliced_token_limit(sl) else "gather")

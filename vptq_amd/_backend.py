@@ -96,6 +96,8 @@ EXPORTS = {
     "vptq_sliced_layout_tables": (C.c_int, [C.POINTER(LayerDesc)]),
     "vptq_sliced_layout_whole_table": (C.c_int, [C.POINTER(LayerDesc), C.c_int]),
     "vptq_quant_gemv_sliced_workspace_bytes": (C.c_size_t, [C.POINTER(LayerDesc)]),
+    "vptq_quant_gemv_sliced_workspace_bytes_for": (C.c_size_t, [C.POINTER(LayerDesc), C.c_int]),
+    "vptq_quant_gemv_sliced_selective_supported": (C.c_int, [C.POINTER(LayerDesc)]),
     "vptq_quant_gemv_sliced": (C.c_int, [C.POINTER(LayerDesc), C.POINTER(SlicedLayout), _vp, _vp, C.c_int, _vp,
                                          C.c_size_t, _vp]),
     "vptq_quant_gemv_sliced_tokens_supported": (C.c_int, [C.POINTER(LayerDesc), C.POINTER(SlicedLayout), C.c_int]),

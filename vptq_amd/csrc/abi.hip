@@ -536,16 +536,22 @@ int vptq_quant_gemv_sliced(const VptqLayerDesc* d, const VptqSlicedLayout* layou
   int rc = validate_layer(d);
   if (rc) return rc;
   if (!x || !y || !layout) return fail(VPTQ_E_NULL, "x / y / layout is NULL");
+  flags = drop_redundant_selective(flags);
   const bool exact = (flags & VPTQ_GEMV_EXACT) != 0;
+  const bool sel = (flags & VPTQ_GEMV_SELECTIVE) != 0;
   if (flags & VPTQ_GEMV_FORCE_GENERIC) return fail(VPTQ_E_UNSUPPORTED, "VPTQ_GEMV_FORCE_GENERIC: use vptq_quant_gemv");
+  if (sel && !vptq::gemv_hot_eligible(*d))
+    return fail(VPTQ_E_UNSUPPORTED, "VPTQ_GEMV_SELECTIVE over a sliced layout: fp16 layers the folded sliced kernel serves, with scale and bias "
+                                    "(vptq_quant_gemv_sliced_selective_supported); ask for VPTQ_GEMV_EXACT over an exact layout instead");
   if (!vptq::gemv_sliced_eligible(*d, exact))
     return fail(VPTQ_E_UNSUPPORTED, exact ? "VPTQ_GEMV_EXACT over a sliced layout: v = 8 / 16, 16384 ... 65536 main centroids, no residual "
                                             "codebook or the 256-entry one of v = 8, scale / bias / x of every column beside a slice in LDS "
                                             "(vptq_sliced_layout_supported_for)"
                                           : "the sliced layout serves v = 8 / 16 layers with 16384 ... 65536 main centroids, group_size <= 32768");
-  const size_t need = vptq::gemv_sliced_workspace_bytes(*d);
-  if (!workspace || workspace_bytes < need || (((uintptr_t)workspace) & 15) != 0)
-    return fail(VPTQ_E_WORKSPACE, "workspace of %zu bytes (16-byte aligned) needed", need);
+  const size_t acc_bytes = (vptq::gemv_sliced_workspace_bytes(*d) + 255) / 256 * 256;
+  const size_t need = sel ? acc_bytes + vptq::gemv_hot_bytes(*d) : vptq::gemv_sliced_workspace_bytes(*d);
+  if (!workspace || workspace_bytes < need || (((uintptr_t)workspace) & (sel ? 255 : 15)) != 0)
+    return fail(VPTQ_E_WORKSPACE, "workspace of %zu bytes (%d-byte aligned) needed", need, sel ? 256 : 16);
   // (folded, two tables: one layout per table, consecutive structs; the reference's roundings: always ONE layout)
   const int n_layouts = exact ? 1 : vptq::gemv_sliced_tables(*d);
   for (int i = 0; i < n_layouts; ++i) {
@@ -561,8 +567,28 @@ int vptq_quant_gemv_sliced(const VptqLayerDesc* d, const VptqSlicedLayout* layou
                   "same for both tables", i, vptq::gemv_sliced_whole_table(*d, i));
   }
   if ((((uintptr_t)x) & 15) != 0) return fail(VPTQ_E_UNSUPPORTED, "x must be 16-byte aligned");
+  if (sel) {
+    // the pre-pass (gemv_hot.hip): threshold, x with the hot blocks' features zeroed, the hot blocks' exact products - behind the
+    // accumulator words of the same workspace; then the folded launch over x_masked, which adds the products before its rounding
+    const void* xm = nullptr;
+    const float* corr = nullptr;
+    hipError_t e = vptq::launch_gemv_hot(*d, x, (char*)workspace + acc_bytes, &xm, &corr, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "gemv_hot launch");
+    e = vptq::launch_gemv_sliced(*d, layout, xm, y, flags & ~VPTQ_GEMV_SELECTIVE, workspace, (hipStream_t)stream, corr);
+    return e == hipSuccess ? VPTQ_OK : hip_fail(e, "gemv_sliced launch");
+  }
   const hipError_t e = vptq::launch_gemv_sliced(*d, layout, x, y, flags, workspace, (hipStream_t)stream);
   return e == hipSuccess ? VPTQ_OK : hip_fail(e, "gemv_sliced launch");
+}
+
+int vptq_quant_gemv_sliced_selective_supported(const VptqLayerDesc* d) {
+  return validate_layer(d) == VPTQ_OK && vptq::gemv_hot_eligible(*d) ? 1 : 0;
+}
+size_t vptq_quant_gemv_sliced_workspace_bytes_for(const VptqLayerDesc* d, int flags) {
+  if (validate_layer(d) != VPTQ_OK || !vptq::gemv_sliced_eligible(*d, (flags & VPTQ_GEMV_EXACT) != 0)) return 0;
+  flags = drop_redundant_selective(flags);
+  if (!(flags & VPTQ_GEMV_SELECTIVE)) return vptq::gemv_sliced_workspace_bytes(*d);
+  return vptq::gemv_hot_eligible(*d) ? (vptq::gemv_sliced_workspace_bytes(*d) + 255) / 256 * 256 + vptq::gemv_hot_bytes(*d) : 0;
 }
 
 int vptq_quant_gemv_sliced_tokens_supported(const VptqLayerDesc* d, const VptqSlicedLayout* layout, int tokens) {

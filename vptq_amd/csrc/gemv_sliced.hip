@@ -568,6 +568,7 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
             const int o = pend_o + i;
             float r = sl_from_fixed<sl_frac<DT>()>(pend_old[t][i] + pend_mine[t][i]);
             if (o < P.O) {
+              if (P.corr) r += as_global(P.corr)[o];
               if (P.bias) r += DT::to_float(as_global(P.bias)[o]);
               const size_t yo = (TOK > 1 ? (size_t)t * P.y_stride : 0) + (size_t)o;
               if (P.out_f32) ((float*)as_global(P.y))[yo] = r;
@@ -1087,7 +1088,7 @@ size_t gemv_sliced_exact_tokens_workspace_bytes(const VptqLayerDesc& d, int toke
 // the index matrix; x is the WHOLE activation (part i reads it from column i G / n on, or through its slice of the permutation),
 // y and the accumulator words are shared: an output is complete after n x slices arrivals.
 hipError_t launch_gemv_sliced_group(const VptqLayerDesc* d, const VptqSlicedLayout* L, int n, const void* x, void* const* y,
-                                    int flags, void* const* ws, hipStream_t st, int tokens) {
+                                    int flags, void* const* ws, hipStream_t st, int tokens, const float* corr) {
   const bool exact = (flags & VPTQ_GEMV_EXACT) != 0;
   const bool parts = (flags & VPTQ_GEMV_COLUMN_PARTS) != 0;
   if (!gemv_sliced_groupable(d, n, exact) || (tokens != 1 && !exact)) return hipErrorInvalidValue;
@@ -1110,6 +1111,7 @@ hipError_t launch_gemv_sliced_group(const VptqLayerDesc* d, const VptqSlicedLayo
     const hipError_t e = sl_fill(d[i], L + (size_t)i * tables, xi, y[i], flags, ws[i], GP.p[i], l, tokens);
     if (e != hipSuccess) return e;
     if (parts) GP.p[i].x_stride = n * d[i].in_features;   // (tokens of the WHOLE activation: a part's columns lie one row of all parts apart)
+    GP.p[i].corr = (n == 1 && tokens == 1 && !exact) ? corr : nullptr;   // (selective roundings: one layer, one token, folded form)
     lds = l > lds ? l : lds;
     GP.start[i + 1] = GP.start[i] + nslt * GP.p[i].wparts * GP.p[i].n_rowblocks;
     if (GP.p[i].wparts != GP.p[0].wparts) return hipErrorInvalidValue;   // (one input width: one answer)
@@ -1124,10 +1126,10 @@ hipError_t launch_gemv_sliced_group(const VptqLayerDesc* d, const VptqSlicedLayo
              : launch_sl_dt<BF16>(GP, d[0].vector_len, nsl, sl_res256(d[0]), sl_two(d[0]), exact, lds, st);   // (exact && two = RG)
 }
 hipError_t launch_gemv_sliced(const VptqLayerDesc& d, const VptqSlicedLayout* L, const void* x, void* y, int flags,
-                              void* ws, hipStream_t st) {
+                              void* ws, hipStream_t st, const float* corr) {
   void* const ys[1] = {y};
   void* const wss[1] = {ws};
-  return launch_gemv_sliced_group(&d, L, 1, x, ys, flags, wss, st);
+  return launch_gemv_sliced_group(&d, L, 1, x, ys, flags, wss, st, 1, corr);
 }
 #endif   // part 1
 

@@ -67,8 +67,12 @@ int gemv_sliced_slices(const VptqLayerDesc& d, bool exact = false);
 int gemv_sliced_tables(const VptqLayerDesc& d);
 int gemv_sliced_whole_table(const VptqLayerDesc& d, int table);   // VptqSlicedLayout::whole_table the layout of `table` must have   // layouts the layer needs: 1, or 2 (a residual codebook served as a second table)
 size_t gemv_sliced_workspace_bytes(const VptqLayerDesc& d);
+// gemv_hot.hip - VPTQ_GEMV_SELECTIVE over the sliced layouts: thresholds, x with the hot blocks zeroed, the hot blocks' exact products
+bool gemv_hot_eligible(const VptqLayerDesc& d);
+size_t gemv_hot_bytes(const VptqLayerDesc& d);
+hipError_t launch_gemv_hot(const VptqLayerDesc& d, const void* x, void* extra, const void** x_masked, const float** corr, hipStream_t st);
 hipError_t launch_gemv_sliced(const VptqLayerDesc& d, const VptqSlicedLayout* L, const void* x, void* y, int flags,
-                              void* ws, hipStream_t st);
+                              void* ws, hipStream_t st, const float* corr = nullptr);
 // up to 3 layers of one format reading the same x (q / k / v, gate / up) in one launch
 // gemv_sliced_tok.hip - 2 - 4 tokens over the same layouts (column windows of every list, phase by phase)
 bool gemv_sliced_tok_eligible(const VptqLayerDesc& d, const VptqSlicedLayout* L, int tokens, bool exact = false);
@@ -81,7 +85,7 @@ hipError_t launch_gemv_sliced_tok_group(const VptqLayerDesc* d, const VptqSliced
                                         int tokens, int flags, void* const* ws, hipStream_t st);
 bool gemv_sliced_groupable(const VptqLayerDesc* d, int n, bool exact = false);
 hipError_t launch_gemv_sliced_group(const VptqLayerDesc* d, const VptqSlicedLayout* L, int n, const void* x, void* const* y,
-                                    int flags, void* const* ws, hipStream_t st, int tokens = 1);
+                                    int flags, void* const* ws, hipStream_t st, int tokens = 1, const float* corr = nullptr);
 // (VPTQ_GEMV_EXACT) 2 / 3 tokens in ONE pass of the one-token kernel: x [tokens][in], y[i] [tokens][out], ws[i]: accumulator words
 bool gemv_sliced_exact_tokens_ok(const VptqLayerDesc& d, int tokens);
 int gemv_sliced_exact_tokens_parts(const VptqLayerDesc& d, int tokens);   // 0: not served; 1: all columns staged; 2 / 4: window parts (needs wstart)

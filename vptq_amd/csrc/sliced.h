@@ -29,6 +29,8 @@ struct SlicedParams {
   const uint16_t* cbias;    // COLUMN order (reference roundings: w = f16(f16(u * s) + b) per weight): bias_permuted or weight_bias
   const uint16_t* perm;     // column c of the quantised matrix multiplies input feature perm[c]; `scale` is then in column order
   const uint16_t* bias;
+  const float* corr;        // [N x v] float32 added to the sums before the one rounding, or null: the hot blocks' exact products of
+                            // VPTQ_GEMV_SELECTIVE (gemv_hot.hip), whose activations this launch reads as zeros
   // TWO tables in one launch (65536 residual centroids): the residual table's layout and codebook; its workgroups are
   // "slices" NSL .. 2 NSL - 1 of the same row blocks
   const uint32_t* elems2;

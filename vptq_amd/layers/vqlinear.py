@@ -459,7 +459,15 @@ class VQuantLinear(nn.Module):
             # the layer's arithmetic (cache[9]): the reference's roundings (the default) take the EXACT sliced kernel where it
             # serves the layer - no residual codebook or the 256-entry one of v = 8, up to ~16000 columns; the others keep the
             # gather kernel -, the opt-in folded form the folded one
-            exact = bool(cache[9] & (B.GEMV_EXACT | B.GEMV_SELECTIVE))   # (selective: the sliced routes take the reference's roundings)
+            exact = bool(cache[9] & (B.GEMV_EXACT | B.GEMV_SELECTIVE))   # (selective: the one-table formats take the reference's roundings)
+            # ... the two-table ones (v8-k65536-65536, v16-k65536-65536, ...: 59 / 46 us in the reference's roundings, the residual entry an
+            # L2 gather per element) the FOLDED layouts with VPTQ_GEMV_SELECTIVE - a pre-pass zeroes the blocks an activation dominates and
+            # hands their exact products to the folded launch (gemv_hot.hip): ~21 us
+            kr0 = self.num_res_centroids if self.enable_residual else 0
+            selective = bool(cache[9] & B.GEMV_SELECTIVE) and not (cache[9] & B.GEMV_EXACT) and kr0 >= 4096 and \
+                bool(B.lib().vptq_quant_gemv_sliced_selective_supported(cache[1])) and bool(B.lib().vptq_sliced_layout_supported_for(cache[1], 0))
+            if selective:
+                exact = False
             # (reference roundings, us per layer, gather -> exact sliced, profiles/r05/sliced_exact.txt: 8192^2 39.4 -> 17.2,
             # 4096 x 14336 34.5 -> 17.0, 14336 x 4096 34.9 -> 14.7, 4096^2 12.6 -> 9.0, 4096 x 1024 7.8 -> 8.3: from 1 M index elements -
             # 8 M weights - on; enable_sliced_layout() asks for it on any layer)
@@ -477,7 +485,9 @@ class VQuantLinear(nn.Module):
             from vptq_amd.utils.sliced import SlicedGemv, exact_column_parts
             # (reference roundings: layers too wide for the LDS in one piece - 28672 columns - are served as equal column parts)
             served = exact_column_parts(cache[1], self.group_size)[0] if exact else B.lib().vptq_sliced_layout_supported_for(cache[1], 0)
-            if (big or not exact) and served and self._sliced_fits(cache, on):
+            if selective:
+                big = self.indices.shape[1] * self.group_size >= _SLICED_EXACT_RG_MIN_ELEMENTS or "_sliced_on" in self.__dict__
+            if (big or not (exact or selective)) and served and self._sliced_fits(cache, on):
                 # (a build that ran out of device memory is retried only after a back-off: every attempt costs int64 / float64
                 # temporaries of ~160 bytes per element, an empty_cache() and a warning - per decode call, while memory stays tight)
                 oom = self.__dict__.get("_sliced_oom")
@@ -487,7 +497,7 @@ class VQuantLinear(nn.Module):
                     if oom[0] > 0 and free < oom[1]:
                         return None
                 try:
-                    obj = SlicedGemv(self, exact=exact)
+                    obj = SlicedGemv(self, exact=exact, selective=selective)
                     self.__dict__.pop("_sliced_oom", None)
                 except torch.cuda.OutOfMemoryError as e:
                     # out of device memory while building: the regular route serves the calls until _SLICED_OOM_RETRY_CALLS further
@@ -502,7 +512,7 @@ class VQuantLinear(nn.Module):
                 # the kernel over the layouts evaluates the folded form: the same measured gate as every folded route
                 # (_backend.folded_form_is_safe) - its float32 outputs against the gather kernel's (the reference's roundings)
                 # on the probe activations
-                lim = None if exact else B.FOLDED_MAX_PROBE_DISTANCE.get(cache[7])
+                lim = None if exact else (B.SELECTIVE_MAX_PROBE_DISTANCE if selective else B.FOLDED_MAX_PROBE_DISTANCE).get(cache[7])
                 if lim is not None and self._parameters.get("weight_bias") is not None:
                     run = obj
 
@@ -512,6 +522,14 @@ class VQuantLinear(nn.Module):
                                                 cache[7], cache[3], folded=folded)
                     if not bool((d <= lim).item()):
                         obj = None
+                        if selective:
+                            # the gate refused the selective form of this layer: the reference's roundings over an exact layout
+                            # (main entry from LDS, residual entry from L2), where that route serves it
+                            if exact_column_parts(cache[1], self.group_size)[0] and self._sliced_fits(cache, on):
+                                try:
+                                    obj = SlicedGemv(self, exact=True)
+                                except (torch.cuda.OutOfMemoryError, ValueError):
+                                    obj = None
             st = (stamp, obj)
             self.__dict__["_sliced"] = st
         return st[1]

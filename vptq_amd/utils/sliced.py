@@ -181,20 +181,25 @@ def exact_column_parts(desc, group_size: int):
 class SlicedGemv:
     """One-token forward of a v8-k65536-0 `VQuantLinear` over its sliced layout."""
 
-    def __init__(self, layer, rows_per_wave: int = 0, exact: bool = False):
+    def __init__(self, layer, rows_per_wave: int = 0, exact: bool = False, selective: bool = False):
         """exact: the reference's roundings per weight (`VPTQ_GEMV_EXACT`, the product default arithmetic) instead of the
         folded form - layers without a residual codebook or with the 256-entry one of v = 8; the layout then has the slice
-        count that arithmetic needs (scale, bias and x of every column sit beside the slice in LDS)."""
+        count that arithmetic needs (scale, bias and x of every column sit beside the slice in LDS).
+        selective (round 6, one token): the FOLDED layouts with `VPTQ_GEMV_SELECTIVE` - a pre-pass finds the blocks of 128 columns an
+        activation dominates, the folded launch reads them as zeros and adds their exact products (gemv_hot.hip)."""
         self.layer = layer
         self.exact = bool(exact)
-        self._flags = B.GEMV_EXACT if self.exact else 0
+        self.selective = bool(selective) and not self.exact
+        self._flags = B.GEMV_EXACT if self.exact else (B.GEMV_SELECTIVE if self.selective else 0)
+        if self.selective and not B.lib().vptq_quant_gemv_sliced_selective_supported(layer._descriptor()[1]):
+            raise ValueError("selective roundings over the sliced layouts: fp16 layers with scale and bias")
         cache = layer._descriptor()
         self.desc, self.dev = cache[1], cache[3]
         self.parts = 1
         if self.exact:   # (a layer too wide for 6 bytes of LDS per column in one piece: equal column parts, one layout each)
             self.parts, self.slices = exact_column_parts(self.desc, layer.group_size)
         else:
-            self.slices = B.lib().vptq_sliced_layout_supported_for(self.desc, self._flags)
+            self.slices = B.lib().vptq_sliced_layout_supported_for(self.desc, 0)
         if not self.slices:
             raise ValueError("the sliced layout serves v = 8 / 16 layers with 16384 ... 65536 main centroids, group_size <= 32768"
                              " (reference roundings: one table, up to ~16000 columns)")
@@ -233,6 +238,8 @@ class SlicedGemv:
                            ws.data_ptr())
             for (e, b, f, r, ws), w in zip(self._tensors, self._whole)])
         self._ws_bytes = B.lib().vptq_quant_gemv_sliced_workspace_bytes(self._part_descs[0] if self.parts > 1 else self.desc)
+        if self.selective:   # (+ header, x with the hot blocks zeroed, the hot blocks' exact products)
+            self._ws_bytes = B.lib().vptq_quant_gemv_sliced_workspace_bytes_for(self.desc, self._flags)
         if self.parts > 1:
             self._pp = ((C.c_void_p * self.parts)(), (C.c_void_p * self.parts)(), (C.c_size_t * self.parts)(*([self._ws_bytes] * self.parts)))
         # partial sums + arrival counters, ONE PER STREAM (two streams - or a graph replay next to an eager call on
@@ -282,6 +289,8 @@ class SlicedGemv:
             return self.tokens_one_pass(tokens)
         if self.exact and self._side16:      # (the reference's roundings over two-table formats: 2 / 3 tokens in one pass, nothing else)
             return self.tokens_one_pass(tokens)
+        if self.selective:                   # (one token: several tokens of such a layer take the module's regular route)
+            return False
         return bool(B.lib().vptq_quant_gemv_sliced_tokens_supported_for(self.desc, self._lay_ref, int(tokens), self._flags))
 
     def tokens_one_pass(self, tokens: int) -> bool:
@@ -313,7 +322,7 @@ class SlicedGemv:
         tokens = x.numel() // lay.in_features
         if x.shape[-1] != lay.in_features or not 2 <= tokens <= 8:
             raise ValueError("forward_tokens takes 2 - 8 tokens of in_features values")
-        if self.exact and (self.parts > 1 or self._side16) and not self.tokens_one_pass(tokens):
+        if self.selective or (self.exact and (self.parts > 1 or self._side16) and not self.tokens_one_pass(tokens)):
             return None
         if x.dtype != self._dtype or x.device != self.dev:
             x = lay._check_activation(x)
@@ -415,7 +424,7 @@ class SlicedGroupGemv:
         tables = len(m0.layout)
         kind = lambda m: (m.layer.vector_len, m.layer.num_centroids,   # noqa: E731
                           m.layer.num_res_centroids if m.layer.enable_residual else 0, tuple(m._whole), m.exact)
-        if not 1 <= n <= 3 or any(m.parts > 1 for m in self.members) or any(len(m.layout) != tables or m.slices != m0.slices or m._dtype != m0._dtype or m.dev != m0.dev or
+        if not 1 <= n <= 3 or any(m.parts > 1 or getattr(m, "selective", False) for m in self.members) or any(len(m.layout) != tables or m.slices != m0.slices or m._dtype != m0._dtype or m.dev != m0.dev or
                                   m.layer.in_features != m0.layer.in_features or kind(m) != kind(m0) for m in self.members):
             raise ValueError("a sliced group takes 1..3 layers of one format (vector length, codebook sizes), dtype, device and input width")
         rpw = rows_per_wave_for(sum(m.blocks.shape[1] for m in self.members), m0.slices * tables)   # one round of workgroups over ALL layers
