@@ -19,7 +19,11 @@
 
 namespace vptq {
 
-constexpr int kGHRows = 64;            // vector-rows per workgroup: 4 rounds of 16 (16 lanes per row, 8 columns per lane and hot block)
+constexpr int kGHRows = 16;            // vector-rows per workgroup (16 lanes per row, 8 columns per lane and hot block): the exact products are
+                                       // latency-bound gathers out of the L2 - as many workgroups as the rows give (64 rows per workgroup:
+                                       // 16 workgroups on 256 CUs, 130 us per call inside a decoder with a handful of hot blocks per layer)
+constexpr int kGHMaxHot = 16;          // hot blocks the corrections cover: with more, the threshold is raised until the 16 most dominant
+                                       // remain (a token with dozens of "dominant" blocks is a dense one: the folded form's regime)
 constexpr int kGHMaxBlocks = 256;      // 32768 columns
 
 struct HotParams {
@@ -104,6 +108,27 @@ __global__ __launch_bounds__(256) void gemv_hot_kernel(const HotParams P) {
   int nhot = 0;
 #pragma unroll
   for (int i = 0; i < kGHMaxBlocks / 32; ++i) nhot += __builtin_popcount(mask[i]);
+  // too many: raise the threshold by a quarter (magnitude bits of a 16-bit float: + 1/4 of an octave per 256 / 32 ... simply scale
+  // the float) and look again - every workgroup walks the same sequence
+  for (int it = 0; it < 24 && nhot > kGHMaxHot; ++it) {
+    __syncthreads();
+    if (tid < kGHMaxBlocks / 32) mask[tid] = 0u;
+    __syncthreads();
+    const float tf = DT::to_float((uint16_t)thr) * 1.25f;
+    thr = tf < 65504.f ? ((uint32_t)DT::from_float(tf) & 0x7fffu) + 1u : 0x7c00u;
+    for (int base = 0; base < P.G; base += 512 * kPer) {
+#pragma unroll
+      for (int i = 0; i < kPer; ++i) {
+        const int c = base + i * 512 + 2 * tid;
+        const uint32_t xq = base == 0 ? xp0[i] : (c < P.G ? staged(c) : 0u);
+        if ((xq & 0x7fffu) >= thr || ((xq >> 16) & 0x7fffu) >= thr) atomicOr(&mask[c >> 12], 1u << ((c >> 7) & 31));
+      }
+    }
+    __syncthreads();
+    nhot = 0;
+#pragma unroll
+    for (int i = 0; i < kGHMaxBlocks / 32; ++i) nhot += __builtin_popcount(mask[i]);
+  }
   if (blockIdx.x == 0 && tid == 0) { as_global(P.hdr)[0] = thr; as_global(P.hdr)[1] = (uint32_t)nhot; }
   {
     // x_masked, shared out over ALL workgroups in chunks of 8 columns (one workgroup writing it alone was 32 dependent round trips:
@@ -150,7 +175,7 @@ __global__ __launch_bounds__(256) void gemv_hot_kernel(const HotParams P) {
           m &= m - 1u;
           const int c0 = (wd * 32 + bit) * 128 + sub * 8;
           if (c0 >= P.G) continue;                 // (G is a multiple of 8)
-#pragma unroll 2
+#pragma unroll
           for (int j = 0; j < 8; j += 2) {
             const int c = c0 + j;
             const uint32_t sp = *(const uint32_t*)(sc + c), bp = *(const uint32_t*)(cb + c);

@@ -67,6 +67,7 @@ _SLICED_MAX_TOKENS = max(max(_SLICED_TOKENS_ENV) if _SLICED_TOKENS_ENV else 3, 4
 _SLICED_ONE_LAUNCH = B.tune_env("VPTQ_SLICED_ONE_LAUNCH", "auto").strip().lower() or "auto"
 
 
+_SLICED_SELECTIVE_MIN_ELEMENTS = 6 << 20   # selective roundings over the folded sliced layouts (two-table formats): from 6 M index elements on
 _SLICED_OOM_RETRY_CALLS = 256   # calls of a layer before a sliced-layout build that ran out of memory is tried again
 
 
@@ -464,7 +465,10 @@ class VQuantLinear(nn.Module):
             # L2 gather per element) the FOLDED layouts with VPTQ_GEMV_SELECTIVE - a pre-pass zeroes the blocks an activation dominates and
             # hands their exact products to the folded launch (gemv_hot.hip): ~21 us
             kr0 = self.num_res_centroids if self.enable_residual else 0
+            # (the pre-pass is a launch of its own, ~9 us at 8192^2: it pays on the large layers - from 6 M index elements on - where the
+            # reference's roundings cost 46 - 59 us; smaller two-table layers keep the exact layouts)
             selective = bool(cache[9] & B.GEMV_SELECTIVE) and not (cache[9] & B.GEMV_EXACT) and kr0 >= 4096 and \
+                (self.indices.shape[1] * self.group_size >= _SLICED_SELECTIVE_MIN_ELEMENTS or "_sliced_on" in self.__dict__) and \
                 bool(B.lib().vptq_quant_gemv_sliced_selective_supported(cache[1])) and bool(B.lib().vptq_sliced_layout_supported_for(cache[1], 0))
             if selective:
                 exact = False
@@ -486,7 +490,7 @@ class VQuantLinear(nn.Module):
             # (reference roundings: layers too wide for the LDS in one piece - 28672 columns - are served as equal column parts)
             served = exact_column_parts(cache[1], self.group_size)[0] if exact else B.lib().vptq_sliced_layout_supported_for(cache[1], 0)
             if selective:
-                big = self.indices.shape[1] * self.group_size >= _SLICED_EXACT_RG_MIN_ELEMENTS or "_sliced_on" in self.__dict__
+                big = True
             if (big or not (exact or selective)) and served and self._sliced_fits(cache, on):
                 # (a build that ran out of device memory is retried only after a back-off: every attempt costs int64 / float64
                 # temporaries of ~160 bytes per element, an empty_cache() and a warning - per decode call, while memory stays tight)
