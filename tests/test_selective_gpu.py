@@ -127,9 +127,8 @@ def test_selective_grouped_siblings_and_the_fallbacks(dev):
         assert rel_err(tensor_to_bits(y), vo.forward(L, xb), "f16") <= 1e-3
         # the same layer alone: the same arithmetic (its own launch: another share of the CUs, the same sums)
         assert torch.equal(gemv_abi(m, xt, B.GEMV_SELECTIVE | MFMA).view(torch.int16), y.view(torch.int16))
-    # bf16, the small-layer VALU kernel and layers whose workgroups walk more than 4 row groups: the reference's roundings
-    Lb = vo.make_layer(2048, 4608, dist="llm", seed=1, dtype="bf16")
-    assert kernel_name(spec_to_module(Lb, dev), 1, B.GEMV_SELECTIVE) != "gemv_k256m_kernel<selective>"
+    # the small-layer VALU kernel and layers whose workgroups walk more than 4 row groups: the reference's roundings
+    # (bf16 layers take the selective form like fp16 ones: test_selective_bf16_one_layer_and_chain)
     Lsmall = vo.make_layer(1024, 256, dist="llm", seed=2, dtype="f16")
     msmall = spec_to_module(Lsmall, dev)
     assert kernel_name(msmall, 1, B.GEMV_SELECTIVE) == "gemv_k256_kernel"
@@ -249,3 +248,57 @@ def test_module_takes_the_selective_sliced_route_for_two_table_formats(dev, sele
     assert rel_err(tensor_to_bits(y1), w1, "f16") <= 1e-3
     s1 = m1.__dict__.get("_sliced")
     assert s1 is not None and s1[1] is not None and s1[1].exact
+
+
+# ---- bf16 (the dtype of most published checkpoints): the default arithmetic runs the widened VALU kernel there (21.5 us per 8192^2
+# layer); the selective form = the dtype-agnostic folded MFMA loop + corrections in widened arithmetic on the hot blocks only
+@pytest.mark.parametrize("I,O,kw", [SHAPES[0], SHAPES[1], SHAPES[4]])
+def test_selective_bf16_one_layer_and_chain(I, O, kw, dev):
+    from vptq_amd import _backend as B
+    from vptq_amd.ops.chain import GemvChain
+    import vptq_amd
+    kw = dict(kw)
+    dist = kw.pop("dist", "ref-test")
+    L = vo.make_layer(I, O, dist=dist, seed=5 * I + O, dtype="bf16", **kw)
+    m = spec_to_module(L, dev)
+    assert kernel_name(m, 1, B.GEMV_SELECTIVE | MFMA) == "gemv_k256m_kernel<selective>"
+    xd = _x(I, I + 2, dist)
+    xm = xd.copy()
+    xm[..., [1, I // 3, I - 2]] *= 40.0
+    before = vptq_amd.arithmetic()
+    vptq_amd.set_arithmetic("folded")      # (descriptor flags 0: the call's flags decide inside GemvChain)
+    try:
+        for name, xf in (("dense", xd), ("massive", xm)):
+            xb = vo.from_f32(xf, "bf16")
+            xt = bits_to_tensor(xb, "bf16", dev).reshape(1, 1, I)
+            want = vo.forward(L, xb)
+            y = gemv_abi(m, xt, B.GEMV_SELECTIVE | MFMA)
+            torch.cuda.synchronize()
+            assert rel_err(tensor_to_bits(y), want, "bf16") <= 8e-3, f"{name} {I}x{O}"
+            if not kw.get("enable_perm"):
+                ch = GemvChain([m, m])
+                assert ch.kernel_name(1, B.GEMV_SELECTIVE | MFMA) == "gemv_k256c_kernel"
+                for yc in ch([xt, xt], flags=B.GEMV_SELECTIVE | MFMA):
+                    assert rel_err(tensor_to_bits(yc), want, "bf16") <= 8e-3, f"chain {name} {I}x{O}"
+            if name == "massive":
+                ys = gemv_abi(m, xt, B.GEMV_SELECTIVE | MFMA, out_f32=True)
+                ye = gemv_abi(m, xt, B.GEMV_EXACT, out_f32=True)       # (bf16: the widened VALU kernel)
+                yf = gemv_abi(m, xt, MFMA, out_f32=True)
+                assert float((ys - ye).abs().max()) <= float((yf - ye).abs().max()) + 1e-6 * float(ye.abs().max())
+    finally:
+        vptq_amd.set_arithmetic(before)
+
+
+def test_selective_bf16_over_sliced_layouts(dev):
+    from vptq_amd.utils.sliced import SlicedGemv
+    from vptq_amd import _backend as B
+    for (I, O, v) in ((4096, 1024, 8), (2048, 528, 16)):
+        L = vo.make_layer(I, O, dist="llm", seed=I + v, dtype="bf16", vector_len=v, num_centroids=65536, num_res_centroids=65536)
+        m = spec_to_module(L, dev)
+        sl = SlicedGemv(m, selective=True)
+        xf = _x(I, 3)
+        xf[..., [4, I // 2, I - 1]] *= 40.0
+        xb = vo.from_f32(xf, "bf16")
+        y = sl(bits_to_tensor(xb, "bf16", dev).reshape(1, 1, I))
+        torch.cuda.synchronize()
+        assert rel_err(tensor_to_bits(y), vo.forward(L, xb), "bf16") <= 8e-3

@@ -316,7 +316,7 @@ FOLDED_MAX_PROBE_DISTANCE = {torch.float16: 7.5e-4, torch.bfloat16: 6.0e-3}   # 
 # the selective arithmetic's gate sits lower: what is left of its failures are LAYER properties (a bias-dominated layer at a probe
 # distance of 7.3e-4 went 1.09e-3 above the bar on a dense activation, profiles/r06/count_chain_selective_seed0_probe.txt); 6.5e-4
 # sends 4 - 9 % of checkpoint-like layers (a third of the un-centred "big-bias" family) to the reference's roundings
-SELECTIVE_MAX_PROBE_DISTANCE = {torch.float16: 6.5e-4}
+SELECTIVE_MAX_PROBE_DISTANCE = {torch.float16: 6.5e-4, torch.bfloat16: 5.2e-3}   # (bf16: x 8, as above)
 FOLDED_MIN_DISTINCT_ROWS = 32   # (kept as a cheap pre-filter: tiny layers and repeating index rows never take the folded form)
 _ROW_SAMPLE = 64
 _PROBE_SEED = 0x5eed

@@ -27,6 +27,8 @@ constexpr int kWave = 64;
 // ---- 16-bit element types: a "pair" is two elements in one 32-bit register ----
 struct F16 {
   static constexpr int kDtype = VPTQ_DTYPE_F16;
+  static constexpr uint32_t kInfBits = 0x7c00u;      // magnitude bits of infinity; anything above: NaN
+  static constexpr float kMaxFinite = 65504.f;
   // packed pair ops: one VALU instruction each (v_pk_add_f16 / v_pk_mul_f16)
   static __device__ __forceinline__ uint32_t add2(uint32_t a, uint32_t b) {
     h2_t r = __builtin_bit_cast(h2_t, a) + __builtin_bit_cast(h2_t, b);
@@ -95,6 +97,8 @@ struct F16 {
 
 struct BF16 {
   static constexpr int kDtype = VPTQ_DTYPE_BF16;
+  static constexpr uint32_t kInfBits = 0x7f80u;
+  static constexpr float kMaxFinite = 3.3895314e38f;
   static __device__ __forceinline__ float lo(uint32_t p) { return __uint_as_float(p << 16); }
   static __device__ __forceinline__ float hi(uint32_t p) {
     return __uint_as_float(p & 0xffff0000u);

@@ -81,11 +81,11 @@ __global__ __launch_bounds__(256) void gemv_hot_kernel(const HotParams P) {
   ss = wave_sum(ss);
   if ((tid & 63) == 0) part[tid >> 6] = ss;
   __syncthreads();
-  uint32_t thr = 0x7c00u;                          // inf / NaN sums: only inf / NaN columns are hot
+  uint32_t thr = DT::kInfBits;                     // inf / NaN sums: only inf / NaN columns are hot
   {
     const float tot = (part[0] + part[1]) + (part[2] + part[3]);
     const float t = P.kappa * __builtin_sqrtf(tot / (float)P.G);
-    if (t < 65504.f) {
+    if (t < DT::kMaxFinite) {
       thr = (uint32_t)DT::from_float(t) & 0x7fffu;
       if (DT::to_float((uint16_t)thr) < t) thr += 1u;
     }
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void gemv_hot_kernel(const HotParams P) {
     if (tid < kGHMaxBlocks / 32) mask[tid] = 0u;
     __syncthreads();
     const float tf = DT::to_float((uint16_t)thr) * 1.25f;
-    thr = tf < 65504.f ? ((uint32_t)DT::from_float(tf) & 0x7fffu) + 1u : 0x7c00u;
+    thr = tf < DT::kMaxFinite ? ((uint32_t)DT::from_float(tf) & 0x7fffu) + 1u : DT::kInfBits;
     for (int base = 0; base < P.G; base += 512 * kPer) {
 #pragma unroll
       for (int i = 0; i < kPer; ++i) {
@@ -225,9 +225,9 @@ __global__ __launch_bounds__(256) void gemv_hot_kernel(const HotParams P) {
 }
 
 // ---- host side -------------------------------------------------------------------
-// layers the pre-pass serves: what the folded sliced kernel serves, fp16, with scale and bias, element words of <= 32 bits
+// layers the pre-pass serves: what the folded sliced kernel serves, with scale and bias, element words of <= 32 bits
 bool gemv_hot_eligible(const VptqLayerDesc& d) {
-  return d.dtype == VPTQ_DTYPE_F16 && gemv_sliced_eligible(d, false) && d.weight_scale && d.weight_bias &&
+  return gemv_sliced_eligible(d, false) && d.weight_scale && d.weight_bias &&
          d.num_codebooks == 1 && d.outlier_size == 0 && d.index_bits == 16 && d.index_bits + d.res_bits <= 32 &&
          (d.vector_len == 8 || d.vector_len == 16) && d.group_size <= kGHMaxBlocks * 128 && (d.group_size % 8) == 0 &&
          (d.perm == nullptr || (d.scale_permuted && d.bias_permuted));
@@ -260,8 +260,14 @@ hipError_t launch_gemv_hot(const VptqLayerDesc& d, const void* x, void* extra, c
   P.kappa = gh_kappa();
   if ((((uintptr_t)P.cent | (uintptr_t)P.rcent) & 15) != 0) return hipErrorInvalidValue;
   const int grid = (d.num_indices + kGHRows - 1) / kGHRows;
-  if (d.vector_len == 8) hipLaunchKernelGGL((gemv_hot_kernel<F16, 8>), dim3(grid), dim3(256), 0, st, P);
-  else hipLaunchKernelGGL((gemv_hot_kernel<F16, 16>), dim3(grid), dim3(256), 0, st, P);
+  const bool f16 = d.dtype == VPTQ_DTYPE_F16;
+  if (d.vector_len == 8) {
+    if (f16) hipLaunchKernelGGL((gemv_hot_kernel<F16, 8>), dim3(grid), dim3(256), 0, st, P);
+    else hipLaunchKernelGGL((gemv_hot_kernel<BF16, 8>), dim3(grid), dim3(256), 0, st, P);
+  } else {
+    if (f16) hipLaunchKernelGGL((gemv_hot_kernel<F16, 16>), dim3(grid), dim3(256), 0, st, P);
+    else hipLaunchKernelGGL((gemv_hot_kernel<BF16, 16>), dim3(grid), dim3(256), 0, st, P);
+  }
   *x_masked = P.xm;
   *corr = P.corr;
   return hipGetLastError();

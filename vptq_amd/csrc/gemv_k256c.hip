@@ -292,7 +292,8 @@ static __device__ __forceinline__ void c_for_slots(F&& f) {
 template <typename DT, bool DEP, int MODE = kCModeFolded>
 __global__ __launch_bounds__(kCThreads) void gemv_k256c_kernel(const K256CParams P) {
   constexpr bool EXACT = MODE == kCModeExact, SEL = MODE == kCModeSel;
-  static_assert(MODE == kCModeFolded || (std::is_same<DT, F16>::value && !DEP && kCSub >= 2), "reference roundings: fp16, independent layers");
+  static_assert(MODE != kCModeExact || (std::is_same<DT, F16>::value && kCSub >= 2), "reference roundings in this loop: fp16");
+  static_assert(MODE == kCModeFolded || !DEP, "reference / selective roundings: independent layers");
   static_assert(!SEL || VPTQ_K256C_PROF == 0, "selective: P.sync carries the thresholds");
   constexpr uint32_t kCXsWave = c_xs_wave(MODE), kCRedOff = c_red_off(MODE), kCRedBOff = c_redb_off(MODE),
                      kCCntOff = c_cnt_off(MODE);
@@ -1166,11 +1167,11 @@ __global__ __launch_bounds__(256) void k256c_hot_kernel(const K256CParams P, con
   ss = wave_sum(ss);
   if ((tid & 63) == 0) part[tid >> 6] = ss;
   __syncthreads();
-  uint32_t thr = 0x7c00u;                          // inf / NaN sums: only inf / NaN columns are hot
+  uint32_t thr = DT::kInfBits;                     // inf / NaN sums: only inf / NaN columns are hot
   {
     const float tot = (part[0] + part[1]) + (part[2] + part[3]);
     const float t = H.kappa * __builtin_sqrtf(tot / (float)Ly.G);
-    if (t < 65504.f) {
+    if (t < DT::kMaxFinite) {
       thr = (uint32_t)DT::from_float(t) & 0x7fffu;
       if (DT::to_float((uint16_t)thr) < t) thr += 1u;   // (rounded up: at or above the threshold)
     }
@@ -1370,7 +1371,7 @@ bool gemv_k256c_exact_ok(const VptqLayerDesc& d, bool dependent) {
 }
 // ... and where an activation column dominates only (VPTQ_GEMV_SELECTIVE): the same, + workspace (gemv_k256c_selective_bytes)
 bool gemv_k256c_selective_ok(const VptqLayerDesc& d, bool dependent) {
-  return d.dtype == VPTQ_DTYPE_F16 && !dependent && VPTQ_K256C_PROF == 0 && d.group_size <= kHotMaxBlocks * kCBlockCols;
+  return !dependent && VPTQ_K256C_PROF == 0 && d.group_size <= kHotMaxBlocks * kCBlockCols;   // (fp16 and bf16: the corrections are VALU arithmetic)
 }
 
 // ---- layers with an input permutation: x is gathered ONCE into the caller's workspace (xp[c] = x[perm[c]]) by a small
@@ -1476,7 +1477,7 @@ hipError_t launch_gemv_k256c(const VptqLayerDesc* descs, int n, const void* cons
   const bool f16 = descs[0].dtype == VPTQ_DTYPE_F16;
   if ((flags & VPTQ_GEMV_SELECTIVE) && !(flags & VPTQ_GEMV_EXACT)) {
     // sync = n thresholds, written by the launch in front of the chain launch (same stream)
-    if (!f16 || dependent || !sync) return hipErrorInvalidValue;   // (the caller routes those layer by layer / asks for EXACT)
+    if (dependent || !sync) return hipErrorInvalidValue;   // (the caller routes those layer by layer / asks for EXACT)
 #if VPTQ_K256C_PROF == 0
     CHotArgs H = {};
     size_t off = ((size_t)n * 16 + 255) / 256 * 256;
@@ -1488,10 +1489,11 @@ hipError_t launch_gemv_k256c(const VptqLayerDesc* descs, int n, const void* cons
       max_rows = descs[i].num_indices > max_rows ? descs[i].num_indices : max_rows;
     }
     H.kappa = c_kappa();
-    hipLaunchKernelGGL(k256c_hot_kernel<F16>, dim3((max_rows + kHotRows - 1) / kHotRows, n), dim3(256), 0, st, P, H);
+    if (f16) hipLaunchKernelGGL(k256c_hot_kernel<F16>, dim3((max_rows + kHotRows - 1) / kHotRows, n), dim3(256), 0, st, P, H);
+    else hipLaunchKernelGGL(k256c_hot_kernel<BF16>, dim3((max_rows + kHotRows - 1) / kHotRows, n), dim3(256), 0, st, P, H);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    return launch_c<F16, false, kCModeSel>(P, grid, st);
+    return f16 ? launch_c<F16, false, kCModeSel>(P, grid, st) : launch_c<BF16, false, kCModeSel>(P, grid, st);
 #else
     return hipErrorInvalidValue;
 #endif

@@ -220,7 +220,7 @@ static __device__ __forceinline__ void gemv_k256m_body(const K256Layer& Ly, cons
   float* const corr = (float*)(hot_flag + kMSelMaxBlocks);              // [kMSelRowGroups][32]
   float* const red = (float*)(slot_done + kMMaxSlots + 8) + (TOK == 1 ? kMSelBytes / 4 : 0);   // [K][TOK][kMWaves][32]
   const int K = Ly.slots & 0xff;  // partial-sum slots that fit into LDS (1..kMMaxSlots, host)
-  constexpr bool kSelOk = FAST && (NST > 0) && TOK == 1 && std::is_same<DT, F16>::value;
+  constexpr bool kSelOk = FAST && (NST > 0) && TOK == 1;   // (fp16 and bf16: the corrections are VALU arithmetic in either type)
   const bool sel = kSelOk && (Ly.slots & kMSelBit) != 0;   // (wave-uniform)
   bool sel_any = false;                                     // ... and a block is hot: finish() adds the corrections
 
@@ -401,10 +401,10 @@ static __device__ __forceinline__ void gemv_k256m_body(const K256Layer& Ly, cons
           }
         }
         ss = wave_sum(ss);
-        uint32_t thr = 0x7c00u;                       // inf / NaN sums: only inf / NaN columns are hot
+        uint32_t thr = DT::kInfBits;                  // inf / NaN sums: only inf / NaN columns are hot
         {
           const float tq = kMSelKappa * __builtin_sqrtf(ss / (float)cnt);
-          if (tq < 65504.f) {
+          if (tq < DT::kMaxFinite) {
             thr = (uint32_t)DT::from_float(tq) & 0x7fffu;
             if (DT::to_float((uint16_t)thr) < tq) thr += 1u;
           }
@@ -1085,7 +1085,7 @@ static int m_cus() {
 // VPTQ_GEMV_SELECTIVE in this kernel: one token, fp16, staged activations, the folded instantiation; every workgroup's row groups
 // must fit the corrections' LDS (kMSelRowGroups)
 bool gemv_k256m_selective_ok(const int* n_rows, int n, bool f16, int tok, int max_cols, bool perm) {
-  if (!f16 || tok != 1 || max_cols > kMMaxCols || max_cols > kMSelMaxBlocks * 128 || !gemv_k256m_supported(1, true, true, max_cols, perm)) return false;
+  if (tok != 1 || max_cols > kMMaxCols || max_cols > kMSelMaxBlocks * 128 || !gemv_k256m_supported(1, f16, true, max_cols, perm)) return false;
   long long total = 0;
   for (int i = 0; i < n; ++i) total += gemv_k256m_row_groups(n_rows[i]);
   const int cus = m_cus();
@@ -1097,7 +1097,7 @@ bool gemv_k256m_selective_ok(const int* n_rows, int n, bool f16, int tok, int ma
 hipError_t launch_gemv_k256m(K256Params& P, int tok, bool f16, bool fast, int max_cols, bool perm,
                              hipStream_t st, bool selective) {
   if (!gemv_k256m_supported(tok, f16, fast, max_cols, perm)) return hipErrorInvalidValue;
-  if (selective && !(fast && f16 && tok == 1 && max_cols <= kMMaxCols)) return hipErrorInvalidValue;
+  if (selective && !(fast && tok == 1 && max_cols <= kMMaxCols)) return hipErrorInvalidValue;
   static std::atomic<int> forced_wgs{-1};  // VPTQ_K256M_WGS: tuning override of the CU count
   if (forced_wgs < 0) { const char* e = vptq::tune_env("VPTQ_K256M_WGS"); forced_wgs = e ? atoi(e) : 0; }
   const int fw = forced_wgs.load();
