@@ -103,9 +103,9 @@ enum {
    * layer's columns.  The folded form's distance to the reference is a sum of per-column rounding errors that average out over
    * thousands of columns when the activations are dense and do not when a handful of channels carry the token (massive
    * activations): the blocks of 128 columns that hold such a column are rebuilt bit-exactly, the rest stays folded.  Kernels
-   * that implement it: the persistent chain launch (fp16, independent layers; needs the workspace
+   * that implement it (fp16 and bf16): the persistent chain launch (independent layers; needs the workspace
    * vptq_quant_gemv_chain_workspace_bytes_for(descs, n, flags) asks for - 16 bytes per layer + 4 per output: thresholds and
-   * the hot blocks' exact products) and the persistent MFMA kernel of one-layer / grouped launches (fp16, 1 token, up to
+   * the hot blocks' exact products) and the persistent MFMA kernel of one-layer / grouped launches (1 token, up to
    * 14336 columns, at most 4 row groups per workgroup; the threshold there is taken over the 512 columns a wave stages);
    * every other kernel / layer / token count takes VPTQ_GEMV_EXACT instead (always at least as close to the reference).
    * With VPTQ_GEMV_EXACT set as well, EXACT wins.  Not bit-equivalent (55 - 65 % of the outputs bit-identical); counted on
