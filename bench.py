@@ -1293,6 +1293,11 @@ def main():
             ("selective_single_launch_per_layer", dict(H=H, mode="single", flags=B.GEMV_SELECTIVE),
              "OPT-IN selective arithmetic, one launch per layer (what VQuantLinear.forward issues after vptq_amd.set_arithmetic('selective')): "
              "gemv_k256m_kernel<selective> - hot blocks found, zeroed and corrected inside the launch"),
+            ("bf16_single_launch_per_layer", dict(H=H, mode="single", flags=EX, dtype=torch.bfloat16),
+             "bf16 layers (the dtype of most published checkpoints), one launch per layer, the default arithmetic: the reference's roundings are widened "
+             "VALU arithmetic there (gemv_k256_kernel)"),
+            ("selective_bf16_single_launch_per_layer", dict(H=H, mode="single", flags=B.GEMV_SELECTIVE, dtype=torch.bfloat16),
+             "bf16 layers, OPT-IN selective arithmetic: the dtype-agnostic folded MFMA loop + widened corrections on the hot blocks only"),
             ("selective_chain", dict(H=H, mode="chain", flags=B.GEMV_SELECTIVE),
              "OPT-IN selective arithmetic (vptq_amd.set_arithmetic('selective'), round 6), the headline workload: the folded form with the "
              "reference's roundings on the 128-column blocks an activation dominates (|f16(s x)| >= 6 rms) - 2 of 12 300 checkpoint-like layers "
@@ -1313,7 +1318,8 @@ def main():
             ("k8192_r256", dict(H=H, mode="single", flags=EX, k=8192, kr=256), "k = 8192 + 256 (T = 21 bits), LDS-resident codebooks, reference roundings"),
             ("folded_k8192_r256", dict(H=H, mode="single", flags=0, k=8192, kr=256), "k = 8192 + 256, opt-in folded arithmetic (MFMA accumulate)"),
         )
-        core = ("single_launch_per_layer", "h4096", "selective_chain", "selective_single_launch_per_layer")   # the compact line's roofline.module_path / opt_in rows
+        core = ("single_launch_per_layer", "h4096", "selective_chain", "selective_single_launch_per_layer",
+                "bf16_single_launch_per_layer", "selective_bf16_single_launch_per_layer")   # the compact line's roofline.module_path / opt_in rows
         for key, kw, what in table:
             if not a.extras and key not in core:
                 continue
@@ -1369,6 +1375,7 @@ def main():
         # keeps the `roofline` object whole, `extras` only in part
         mp = {}
         for key, name in (("single_launch_per_layer", f"h{H}"), ("h4096", "h4096"), ("selective_single_launch_per_layer", f"h{H}_selective_opt_in"),
+                          ("bf16_single_launch_per_layer", f"h{H}_bf16"), ("selective_bf16_single_launch_per_layer", f"h{H}_bf16_selective_opt_in"),
                           ("folded_single_launch_per_layer", f"h{H}_folded_opt_in"), ("folded_h4096", "h4096_folded_opt_in")):
             e = ex.get(key) or {}
             if "us_per_launch" in e:
