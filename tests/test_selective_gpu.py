@@ -134,8 +134,15 @@ def test_selective_grouped_siblings_and_the_fallbacks(dev):
     assert kernel_name(msmall, 1, B.GEMV_SELECTIVE) == "gemv_k256_kernel"
     xs = bits_to_tensor(vo.from_f32(_x(1024, 3), "f16"), "f16", dev).reshape(1, 1, 1024)
     assert torch.equal(gemv_abi(msmall, xs, B.GEMV_SELECTIVE).view(torch.int16), gemv_abi(msmall, xs, B.GEMV_EXACT).view(torch.int16))
-    Ltall = vo.make_layer(512, 8192 * 5, dist="llm", seed=4, dtype="f16")     # 1280 row groups: 5 per workgroup, the corrections hold 4
-    assert kernel_name(spec_to_module(Ltall, dev), 1, B.GEMV_SELECTIVE) == "gemv_k256m_kernel"
+    # 1280 row groups: 5 per workgroup - the corrections are built in two rounds of 4 row groups (they hold 16)
+    Ltall = vo.make_layer(512, 8192 * 5, dist="llm", seed=4, dtype="f16")
+    mtall = spec_to_module(Ltall, dev)
+    assert kernel_name(mtall, 1, B.GEMV_SELECTIVE) == "gemv_k256m_kernel<selective>"
+    xtl = _x(512, 6)
+    xtl[..., [3, 300]] *= 40.0
+    xtb = vo.from_f32(xtl, "f16")
+    ytl = gemv_abi(mtall, bits_to_tensor(xtb, "f16", dev).reshape(1, 1, 512), B.GEMV_SELECTIVE)
+    assert rel_err(tensor_to_bits(ytl), vo.forward(Ltall, xtb), "f16") <= 1e-3
 
 
 def test_module_forward_in_the_selective_arithmetic(dev, selective_arithmetic):

@@ -27,7 +27,7 @@ SIZES = {"8b": dict(hidden_size=4096, intermediate_size=14336, num_attention_hea
          "70b": dict(hidden_size=8192, intermediate_size=28672, num_attention_heads=64, layers=80)}
 
 
-def build_model(layers, dev, k=256, kr=256, perm=False, size="8b"):
+def build_model(layers, dev, k=256, kr=256, perm=False, size="8b", dt=torch.float16):
     from transformers import LlamaConfig, LlamaForCausalLM
     from transformers.integrations.vptq import replace_with_vptq_linear
     from transformers.models.llama.modeling_llama import LlamaRotaryEmbedding
@@ -79,21 +79,21 @@ def build_model(layers, dev, k=256, kr=256, perm=False, size="8b"):
             if isinstance(mod, vptq.VQuantLinear):
                 mod.indices.data = torch.randint(-2**31, 2**31 - 1, mod.indices.shape, generator=g,
                                                  device=dev, dtype=torch.int64).to(torch.int32)
-                mod.centroids.weight.data = (torch.randn(mod.centroids.weight.shape, generator=g, device=dev) * 0.02).half()
+                mod.centroids.weight.data = (torch.randn(mod.centroids.weight.shape, generator=g, device=dev) * 0.02).to(dt)
                 if mod.enable_residual:
-                    mod.res_centroids.weight.data = (torch.randn(mod.res_centroids.weight.shape, generator=g, device=dev) * 0.005).half()
+                    mod.res_centroids.weight.data = (torch.randn(mod.res_centroids.weight.shape, generator=g, device=dev) * 0.005).to(dt)
                 I = mod.in_features
-                mod.weight_scale.data = (1 + 0.1 * torch.randn(I, generator=g, device=dev)).half()
-                mod.weight_bias.data = (0.002 * torch.randn(I, generator=g, device=dev)).half()
+                mod.weight_scale.data = (1 + 0.1 * torch.randn(I, generator=g, device=dev)).to(dt)
+                mod.weight_bias.data = (0.002 * torch.randn(I, generator=g, device=dev)).to(dt)
                 if perm:
                     mod.perm.data = torch.randperm(I, generator=g, device=dev).to(torch.int32).to(torch.int16)
                 qlayers.append(mod)
         for name, p in model.named_parameters():
             if p.dtype == torch.float32:          # embeddings, norms, lm_head
                 if "norm" in name:
-                    p.data = torch.ones(p.shape, device=dev, dtype=torch.float16)
+                    p.data = torch.ones(p.shape, device=dev, dtype=dt)
                 else:
-                    p.data = (torch.randn(p.shape, generator=g, device=dev) * 0.02).half()
+                    p.data = (torch.randn(p.shape, generator=g, device=dev) * 0.02).to(dt)
     model.model.rotary_emb = LlamaRotaryEmbedding(config=cfg, device=dev)
     vptq.layers.chain_prefetch(qlayers, circular=True)
     return model.eval(), cfg, qlayers
@@ -106,7 +106,7 @@ def run(args):
     def stage(msg):
         print(f"[stage] {msg}", file=sys.stderr, flush=True)
     stage("build")
-    model, cfg, qlayers = build_model(args.layers, dev, k=args.k, kr=args.kr, perm=args.perm, size=args.model)
+    model, cfg, qlayers = build_model(args.layers, dev, k=args.k, kr=args.kr, perm=args.perm, size=args.model, dt=torch.bfloat16 if args.dtype == "bf16" else torch.float16)
     fused = 0
     if args.fuse:
         import vptq
@@ -244,5 +244,6 @@ if __name__ == "__main__":
     ap.add_argument("--kr", type=int, default=256, help="residual codebook entries")
     ap.add_argument("--fuse", action="store_true", help="link_siblings: q/k/v and gate/up share one grouped launch")
     ap.add_argument("--batch", type=int, default=1, help="sequences decoded together: every VQuantLinear call of a step sees that many tokens")
+    ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"], help="dtype of the model and its VQuantLinear tensors")
     ap.add_argument("--out", default="")
     run(ap.parse_args())

@@ -66,8 +66,12 @@ constexpr int kMMaxSlots = 4;
 constexpr float kMSelKappa = 6.0f;
 constexpr int kMSelBit = 0x100;            // K256Layer::slots: selective roundings
 constexpr int kMSelMaxBlocks = 128;        // 16384 columns (staged: <= 14336)
-constexpr int kMSelRowGroups = 4;          // row groups per workgroup the corrections cover (16 waves = 4 x 4 rows)
-constexpr int kMSelBytes = kMSelMaxBlocks + kMSelRowGroups * 32 * 4;   // flags + corr
+constexpr int kMSelRowGroups = 16;         // row groups per workgroup the corrections cover (16 waves = 4 x 4 rows per round; gate / up of an
+                                           // 8B model in one grouped launch: 14 per workgroup)
+constexpr int kMSelMaxHot = 16;            // hot blocks per layer the corrections cover: the most dominant ones (a token with dozens of
+                                           // "dominant" blocks is a dense one - the folded form's regime - and the corrections are latency-bound work: the
+                                           // 14336-column down projection of a decoder, silu(gate) * up as input, had 50 of 112 blocks hot: 49 us for a 6 us launch)
+constexpr int kMSelBytes = 2 * kMSelMaxBlocks + 4 * kMSelRowGroups * 32 * 4;   // block magnitudes + corr [4 quarters of the hot blocks][row groups][32]
 // VPTQ_K256M_XDUP: one token - the staged activations are kept as DUPLICATED pairs (x, x), one
 // dword per column, so that the MFMA x operand (x * e_j) is two v_and_b32 with per-lane
 // constant masks instead of two v_perm_b32 (a three-source VOP3: ~5.5 vs ~3.3 cycles per
@@ -216,13 +220,14 @@ static __device__ __forceinline__ void gemv_k256m_body(const K256Layer& Ly, cons
   uint32_t* const slot_cnt = (uint32_t*)(red_b + TOK * kMWaves);  // [kMMaxSlots] waves that have arrived
   uint32_t* const slot_done = slot_cnt + kMMaxSlots;         // [kMMaxSlots] row groups finished + 1
   // one token: hot-block flags and corrections of the selective arithmetic in front of the slots
-  uint8_t* const hot_flag = (uint8_t*)(slot_done + kMMaxSlots + 8);     // [kMSelMaxBlocks]
-  float* const corr = (float*)(hot_flag + kMSelMaxBlocks);              // [kMSelRowGroups][32]
+  uint16_t* const hot_mag = (uint16_t*)(slot_done + kMMaxSlots + 8);    // [kMSelMaxBlocks]: largest |f16(s x)| of a block at or above its wave's threshold, else 0
+  float* const corr = (float*)(hot_mag + kMSelMaxBlocks);               // [4][kMSelRowGroups][32]
   float* const red = (float*)(slot_done + kMMaxSlots + 8) + (TOK == 1 ? kMSelBytes / 4 : 0);   // [K][TOK][kMWaves][32]
   const int K = Ly.slots & 0xff;  // partial-sum slots that fit into LDS (1..kMMaxSlots, host)
   constexpr bool kSelOk = FAST && (NST > 0) && TOK == 1;   // (fp16 and bf16: the corrections are VALU arithmetic in either type)
   const bool sel = kSelOk && (Ly.slots & kMSelBit) != 0;   // (wave-uniform)
   bool sel_any = false;                                     // ... and a block is hot: finish() adds the corrections
+  uint32_t sel_mg[(NST > 0 ? NST : 1)];                     // largest magnitude of this thread's 8 columns per staged chunk
 
   // ---- 2. the index queue: slot s holds sweep s (2048 columns x 4 rows, 16 bytes per lane)
   u32x4 iw[NS], s_raw[NQ], b_raw[NQ];
@@ -410,10 +415,9 @@ static __device__ __forceinline__ void gemv_k256m_body(const K256Layer& Ly, cons
           }
           if (thr == 0u) thr = 1u;                    // (all-zero activations: nothing is hot)
         }
+        // largest magnitude of this thread's 8 columns per staged chunk; of its block of 128 columns (16 consecutive lanes): DPP max
 #pragma unroll
         for (int k = 0; k < NST; ++k) {
-          const int want = k * kStageCols + tid * 8;
-          const bool valid = want < G;
           uint32_t mg = 0u;
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
@@ -421,15 +425,21 @@ static __device__ __forceinline__ void gemv_k256m_body(const K256Layer& Ly, cons
             mg = mg > lo ? mg : lo;
             mg = mg > hi ? mg : hi;
           }
-          // the 16 threads of a block of 128 columns are 16 consecutive lanes
-          const unsigned long long bal = __builtin_amdgcn_ballot_w64(valid && mg >= thr);
-          const bool hot = ((uint32_t)(bal >> (lane & 48)) & 0xffffu) != 0u;
-          if (valid && (lane & 15) == 0) hot_flag[want >> 7] = hot ? 1 : 0;   // one writer per block: no init, no atomics
-          if (hot && valid) {
-            lds_store16(xs_off + (uint32_t)want * kXB, u32x4{0u, 0u, 0u, 0u});   // (same thread, same address: behind its own store)
-            if constexpr (kXDup) lds_store16(xs_off + (uint32_t)want * kXB + 16u, u32x4{0u, 0u, 0u, 0u});
-            late_x[k] = u32x4{0u, 0u, 0u, 0u};                                  // ... and out of sum b x
+          const int want = k * kStageCols + tid * 8;
+          mg = want < G ? mg : 0u;
+          uint32_t bm = mg;
+          {
+            uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bm, 0x128, 0xf, 0xf, false);   // row_ror:8
+            bm = bm > o ? bm : o;
+            o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bm, 0x124, 0xf, 0xf, false);            // row_ror:4
+            bm = bm > o ? bm : o;
+            o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bm, 0x122, 0xf, 0xf, false);            // row_ror:2
+            bm = bm > o ? bm : o;
+            o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bm, 0x121, 0xf, 0xf, false);            // row_ror:1
+            bm = bm > o ? bm : o;
           }
+          sel_mg[k] = bm;
+          if (want < G && (lane & 15) == 0) hot_mag[want >> 7] = (uint16_t)(bm >= thr ? bm : 0u);   // one writer per block: no init, no atomics
         }
       }
     }
@@ -483,58 +493,110 @@ static __device__ __forceinline__ void gemv_k256m_body(const K256Layer& Ly, cons
   if constexpr (kSelOk) {
     if (sel) {
       const int nblk = (G + 127) >> 7;
-      const unsigned long long m0 = __builtin_amdgcn_ballot_w64(lane < nblk && hot_flag[lane] != 0);
-      const unsigned long long m1 = __builtin_amdgcn_ballot_w64(lane + 64 < nblk && hot_flag[lane + 64] != 0);
+      // every wave reads all block magnitudes (lane i: blocks i and i + 64) and keeps the kMSelMaxHot largest: the cut is found by
+      // bisection on the 15 magnitude bits (ballots + popcounts: scalar work), the same in every wave
+      const uint32_t g0 = lane < nblk ? hot_mag[lane] : 0u, g1 = lane + 64 < nblk ? hot_mag[lane + 64] : 0u;
+      uint32_t cut = 1u;
+      {
+        auto above = [&](uint32_t t) {
+          return __builtin_popcountll(__builtin_amdgcn_ballot_w64(g0 >= t)) + __builtin_popcountll(__builtin_amdgcn_ballot_w64(g1 >= t));
+        };
+        if (above(1u) > kMSelMaxHot) {
+          uint32_t lo = 1u, hi = 0x8000u;    // above(lo) > K >= above(hi)
+          while (hi - lo > 1u) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (above(mid) > kMSelMaxHot) lo = mid; else hi = mid;
+          }
+          cut = hi;
+        }
+      }
+      const unsigned long long m0 = __builtin_amdgcn_ballot_w64(g0 >= cut);
+      const unsigned long long m1 = __builtin_amdgcn_ballot_w64(g1 >= cut);
+      // the staging threads take their hot blocks out of the folded loop (zeros in LDS, out of sum b x); then everybody waits once more
+      {
+#pragma unroll
+        for (int k = 0; k < NST; ++k) {
+          const int want = k * kStageCols + tid * 8;
+          if (want < G) {
+            const int blk = want >> 7;
+            const bool hot = (((blk < 64 ? m0 : m1) >> (blk & 63)) & 1ull) != 0ull;
+            if (hot) {
+              lds_store16(xs_off + (uint32_t)want * kXB, u32x4{0u, 0u, 0u, 0u});
+              if constexpr (kXDup) lds_store16(xs_off + (uint32_t)want * kXB + 16u, u32x4{0u, 0u, 0u, 0u});
+              late_x[k] = u32x4{0u, 0u, 0u, 0u};
+            }
+          }
+        }
+      }
+      __syncthreads();   // (selective launches only)
       sel_any = (m0 | m1) != 0ull;   // (every wave reads the same flags: uniform over the workgroup)
       if (sel_any) {
         // wave w = (row group qi = w >> 2 of this workgroup, vector-row j = w & 3): the hot blocks' columns of that row, two per
         // lane, with the reference's roundings - w = f16(f16(f16(c + r) s) + b), vptq/ops/quant_gemm.py:121,155-156 - entries out of
         // the image (any replica: slot lane & 7), fp32 multiply-adds, one DPP sum per output.  Rare, short, not tuned.
-        const int qi = wave >> 2, jr = wave & 3;
-        const int rgq = bid + qi * step;
-        if (rgq < n_groups) {
-          const int rowq = rgq * kMRows + jr;
-          const char* const irow = (const char*)Ly.idx + (size_t)(rowq < N ? rowq : N - 1) * row_bytes;
-          float ac[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        // all 16 waves: wave w = (vector-row jr = w & 3, quarter w >> 2 of the hot blocks); the quarters' sums meet in finish(), in a
+        // fixed order.  Two hot blocks per trip: their index words, activations, scales and biases are requested together.
+        const int jr = wave & 3, quad = wave >> 2;
+        auto one_block = [&](const char* irow, int c, float (&ac)[8], bool on) __attribute__((always_inline)) {
+          const int cc = (on && c < G) ? c : 0;       // (G is a multiple of 8: whole pairs; an absent second block reads column 0)
+          const uint32_t iwd = *(const uint32_t*)as_global(irow + (size_t)cc * 2);
+          uint32_t xw;
+          if (PERM) {
+            const uint32_t pv = *(const uint32_t*)as_global(Ly.perm + cc);
+            xw = (uint32_t)as_global(Ly.x)[pv & 0xffffu] | ((uint32_t)as_global(Ly.x)[pv >> 16] << 16);
+          } else {
+            xw = *(const uint32_t*)as_global(Ly.x + cc);
+          }
+          if (!(on && c < G)) xw = 0u;                 // (... times zero)
+          const uint32_t sw = *(const uint32_t*)as_global(sp + cc), bw = *(const uint32_t*)as_global(bp + cc);
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const uint32_t e = (iwd >> (16 * h)) & 0xffffu;
+            const u32x4 ce = lds_load16((e & 255u) * 256u + ((uint32_t)lane & 7u) * 16u);
+            const u32x4 re = lds_load16((e >> 8) * 256u + (8u + ((uint32_t)lane & 7u)) * 16u);
+            const float xf = DT::half_of(xw, h);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              uint32_t w = DT::add2(ce[k], re[k]);
+              w = DT::mul2_bcast(w, sw, h);
+              w = DT::add2_bcast(w, bw, h);
+              ac[2 * k] = DT::fma_lo(w, xf, ac[2 * k]);
+              ac[2 * k + 1] = DT::fma_hi(w, xf, ac[2 * k + 1]);
+            }
+          }
+        };
+        // this quarter's hot blocks: every fourth set bit of (m0, m1)
+        int mine[kMSelMaxBlocks / 4];
+        int n_mine = 0;
+        {
+          int h = 0;
 #pragma unroll 1
           for (int half = 0; half < 2; ++half) {
             unsigned long long m = half ? m1 : m0;
             while (m) {
               const int bit = __builtin_ctzll(m);
               m &= m - 1ull;
-              const int c = (half * 64 + bit) * 128 + 2 * lane;
-              if (c >= G) continue;                 // (G is a multiple of 8: whole pairs)
-              const uint32_t iwd = *(const uint32_t*)as_global(irow + (size_t)c * 2);
-              uint32_t xw;
-              if (PERM) {
-                const uint32_t pv = *(const uint32_t*)as_global(Ly.perm + c);
-                xw = (uint32_t)as_global(Ly.x)[pv & 0xffffu] | ((uint32_t)as_global(Ly.x)[pv >> 16] << 16);
-              } else {
-                xw = *(const uint32_t*)as_global(Ly.x + c);
-              }
-              const uint32_t sw = *(const uint32_t*)as_global(sp + c), bw = *(const uint32_t*)as_global(bp + c);
-#pragma unroll
-              for (int h = 0; h < 2; ++h) {
-                const uint32_t e = (iwd >> (16 * h)) & 0xffffu;
-                const u32x4 ce = lds_load16((e & 255u) * 256u + ((uint32_t)lane & 7u) * 16u);
-                const u32x4 re = lds_load16((e >> 8) * 256u + (8u + ((uint32_t)lane & 7u)) * 16u);
-                const float xf = DT::half_of(xw, h);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                  uint32_t w = DT::add2(ce[k], re[k]);
-                  w = DT::mul2_bcast(w, sw, h);
-                  w = DT::add2_bcast(w, bw, h);
-                  ac[2 * k] = DT::fma_lo(w, xf, ac[2 * k]);
-                  ac[2 * k + 1] = DT::fma_hi(w, xf, ac[2 * k + 1]);
-                }
-              }
+              if ((h & 3) == quad && n_mine < kMSelMaxBlocks / 4) mine[n_mine++] = half * 64 + bit;
+              ++h;
             }
+          }
+        }
+#pragma unroll 1
+        for (int qi = 0; qi < kMSelRowGroups && bid + qi * step < n_groups; ++qi) {
+          const int rgq = bid + qi * step;
+          const int rowq = rgq * kMRows + jr;
+          const char* const irow = (const char*)Ly.idx + (size_t)(rowq < N ? rowq : N - 1) * row_bytes;
+          float ac[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+          for (int i = 0; i < n_mine; i += 2) {
+            one_block(irow, mine[i] * 128 + 2 * lane, ac, true);
+            one_block(irow, (i + 1 < n_mine ? mine[i + 1] : 0) * 128 + 2 * lane, ac, i + 1 < n_mine);
           }
 #pragma unroll
           for (int k = 0; k < 8; ++k) ac[k] = wave_sum(ac[k]);
-          if (lane == 0 && qi < kMSelRowGroups) {
+          if (lane == 0) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) corr[qi * 32 + jr * 8 + k] = ac[k];
+            for (int k = 0; k < 8; ++k) corr[(quad * kMSelRowGroups + qi) * 32 + jr * 8 + k] = ac[k];
           }
         }
         __syncthreads();   // (uniform: every wave took this branch)
@@ -816,7 +878,10 @@ static __device__ __forceinline__ void gemv_k256m_body(const K256Layer& Ly, cons
         auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(sum[t]), __float_as_uint(sum[t]), false, false);
         float total = (__uint_as_float(r[0]) + __uint_as_float(r[1])) + bdot[t];
         if constexpr (kSelOk) {
-          if (sel_any) total += corr[(q < kMSelRowGroups ? q : 0) * 32 + ol];   // (the hot blocks' columns, reference roundings)
+          if (sel_any) {   // (the hot blocks' columns, reference roundings: four quarters, a fixed order)
+            const float* const cq = corr + (q < kMSelRowGroups ? q : 0) * 32 + ol;
+            total += (cq[0] + cq[kMSelRowGroups * 32]) + (cq[2 * kMSelRowGroups * 32] + cq[3 * kMSelRowGroups * 32]);
+          }
         }
         if (store && t < tokens) {
           if (out_f32) ((float*)as_global(Ly.y))[(size_t)t * O + o] = total + bv;

@@ -151,26 +151,38 @@ class SiblingGroup:
         key = tuple(c[6] for c in caches)  # descriptor generations: a rebuilt descriptor never matches
         if self._arrays is None or self._arrays[0] != key:
             import ctypes as C
-            n = len(caches)
-            self._arrays = (key, (B.LayerDesc * n)(*[c[1] for c in caches]), (C.c_void_p * n)(),
-                            (C.c_void_p * n)(), B.lib().vptq_quant_gemv_grouped)
-        _, descs, xp, yp, fn = self._arrays
+            # one launch per ARITHMETIC: the members the load-time gate sends to the reference's roundings (VPTQ_GEMV_EXACT) go out as a
+            # launch of their own, so that one such layer does not drag its siblings out of the selective / folded form (bf16 layers sit
+            # close to the gate: with every group exact as soon as one member is, a decoder ran at the reference's speed)
+            parts = []
+            for want in (False, True):
+                idx = [i for i, c in enumerate(caches) if bool(c[9] & B.GEMV_EXACT) == want]
+                if idx:
+                    fl = 0
+                    for i in idx:
+                        fl |= caches[i][9]
+                    parts.append((idx, (B.LayerDesc * len(idx))(*[caches[i][1] for i in idx]), (C.c_void_p * len(idx))(),
+                                  (C.c_void_p * len(idx))(), fl))
+            self._arrays = (key, parts, B.lib().vptq_quant_gemv_grouped)
+        _, parts, fn = self._arrays
         ys = [torch.empty(xc.shape[:-1] + (m.out_features,), dtype=xc.dtype, device=dev)
               for m in self.members]
-        for i, y in enumerate(ys):
-            xp[i] = xc.data_ptr()
-            yp[i] = y.data_ptr()
         dev_index = caches[0][8]
-        flags = ops.quant_gemm_flags()
-        for c in caches:
-            flags |= c[9]     # one bias-dominated member: the whole launch in the reference's arithmetic
+        base_flags = ops.quant_gemm_flags()
+
+        def launch(sp):
+            for idx, descs, xp, yp, fl in parts:
+                for j, i in enumerate(idx):
+                    xp[j] = xc.data_ptr()
+                    yp[j] = ys[i].data_ptr()
+                rc = fn(descs, len(idx), xp, yp, tokens, base_flags | fl, sp)
+                if rc:
+                    B.check(rc, "vptq_quant_gemv_grouped")
         if torch.cuda.current_device() != dev_index:
             with torch.cuda.device(dev):
-                rc = fn(descs, len(ys), xp, yp, tokens, flags, B.current_stream_ptr(dev))
+                launch(B.current_stream_ptr(dev))
         else:
-            rc = fn(descs, len(ys), xp, yp, tokens, flags, _raw_stream(dev_index))
-        if rc:
-            B.check(rc, "vptq_quant_gemv_grouped")
+            launch(_raw_stream(dev_index))
         self._x, self._version = x, B.tensor_version(x)
         self._keep_x = xc
         self._out = {id(m): y for m, y in zip(self.members, ys) if m is not layer}
