@@ -1129,6 +1129,7 @@ constexpr int kHotRows = 64;          // vector-rows per workgroup: 4 rounds of 
                                       // every workgroup repeats the threshold / hot-block search (64 KiB out of the L2): 16 rows per
                                       // workgroup made that search 10 us per launch of 32 layers (rocprofv3, round 6), 64: a quarter
 constexpr int kHotMaxBlocks = 256;    // 32768 columns
+constexpr int kHotMaxHot = 16;        // hot blocks per layer the corrections cover (the most dominant ones)
 struct CHotArgs {
   uint32_t corr_off[kMaxGroup];   // byte offset of layer l's corrections from P.sync
   float kappa;
@@ -1204,6 +1205,43 @@ __global__ __launch_bounds__(256) void k256c_hot_kernel(const K256CParams P, con
   int nhot = 0;
 #pragma unroll
   for (int i = 0; i < kHotMaxBlocks / 32; ++i) nhot += __builtin_popcount(mask[i]);
+  // more than kHotMaxHot: the threshold goes up by a quarter until the most dominant blocks remain - a token with dozens of
+  // "dominant" blocks is a dense one (the folded form's regime), and the products below are latency-bound work.  Every workgroup
+  // of the layer walks the same sequence; the chain kernel reads the final threshold from the header.
+  for (int it = 0; it < 24 && nhot > kHotMaxHot; ++it) {
+    __syncthreads();
+    if (tid < kHotMaxBlocks / 32) mask[tid] = 0u;
+    __syncthreads();
+    const float tf = DT::to_float((uint16_t)thr) * 1.25f;
+    thr = tf < DT::kMaxFinite ? ((uint32_t)DT::from_float(tf) & 0x7fffu) + 1u : DT::kInfBits;
+    for (int base = 0; base < Ly.G; base += 512 * kPer) {
+      uint32_t xq[kPer];
+      if (base == 0) {
+#pragma unroll
+        for (int i = 0; i < kPer; ++i) xq[i] = xp0[i];
+      } else {
+        uint32_t xv[kPer], sv[kPer];
+#pragma unroll
+        for (int i = 0; i < kPer; ++i) {
+          const int c = base + i * 512 + 2 * tid;
+          const int cc = c < Ly.G ? c : 0;
+          xv[i] = *(const uint32_t*)(Ly.x + cc);
+          sv[i] = *(const uint32_t*)(Ly.scale + cc);
+        }
+#pragma unroll
+        for (int i = 0; i < kPer; ++i) xq[i] = base + i * 512 + 2 * tid < Ly.G ? DT::mul2(xv[i], sv[i]) : 0u;
+      }
+#pragma unroll
+      for (int i = 0; i < kPer; ++i) {
+        const int c = base + i * 512 + 2 * tid;
+        if ((xq[i] & 0x7fffu) >= thr || ((xq[i] >> 16) & 0x7fffu) >= thr) atomicOr(&mask[c >> 12], 1u << ((c >> 7) & 31));
+      }
+    }
+    __syncthreads();
+    nhot = 0;
+#pragma unroll
+    for (int i = 0; i < kHotMaxBlocks / 32; ++i) nhot += __builtin_popcount(mask[i]);
+  }
   if (blockIdx.x == 0 && tid == 0) {
     hdr[0] = thr; hdr[1] = (uint32_t)nhot; hdr[2] = H.corr_off[L]; hdr[3] = 0u;
   }
