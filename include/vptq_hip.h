@@ -106,7 +106,7 @@ enum {
    * that implement it (fp16 and bf16): the persistent chain launch (independent layers; needs the workspace
    * vptq_quant_gemv_chain_workspace_bytes_for(descs, n, flags) asks for - 16 bytes per layer + 4 per output: thresholds and
    * the hot blocks' exact products) and the persistent MFMA kernel of one-layer / grouped launches (1 token, up to
-   * 14336 columns, at most 4 row groups per workgroup; the threshold there is taken over the 512 columns a wave stages);
+   * 14336 columns, at most 16 row groups per workgroup; thresholds over the 512 columns a wave stages, then the 16 most dominant blocks);
    * every other kernel / layer / token count takes VPTQ_GEMV_EXACT instead (always at least as close to the reference).
    * With VPTQ_GEMV_EXACT set as well, EXACT wins.  Not bit-equivalent (55 - 65 % of the outputs bit-identical); counted on
    * checkpoint-like layers: 2 of 12 300 above the 1e-3 bar at 1.00e-3 / 1.09e-3 through the chain launch (folded form: 30
