@@ -167,7 +167,10 @@ static __device__ __forceinline__ void gemv_k256m_body(const K256Layer& Ly, cons
   // real contraction - see sweep() - and costs the same for 2, 3 or 4 tokens.
   static_assert(TOK == 1 || TOK == 2 || TOK == 4, "token slots");
   static_assert(TOK == 1 || (STAGE && FAST), "several tokens: folded form, staged activations");
-  constexpr int NQ = (FAST && STAGE) ? 1 : NS;  // queue slots for scale + (exact: bias | unstaged: x)
+  // bf16 exact form: scale and bias are staged in LDS beside the activations (6 bytes per column) instead of riding in the queue -
+  // its matrix-pipe roundings (sweep()) need the registers
+  constexpr bool kSB = !FAST && std::is_same<DT, BF16>::value;
+  constexpr int NQ = ((FAST && STAGE) || kSB) ? 1 : NS;  // queue slots for scale + (exact: bias | unstaged: x)
 
   const int bid = blockIdx.x;
   const int G = Ly.G, N = Ly.N, O = Ly.O;
@@ -213,9 +216,13 @@ static __device__ __forceinline__ void gemv_k256m_body(const K256Layer& Ly, cons
   constexpr bool kXDup = VPTQ_K256M_XDUP && TOK == 1 && STAGE;
   constexpr uint32_t kXB = kXDup ? 4u : 2u;  // staged bytes per column
   const uint32_t xs_stride = (uint32_t)G * kXB + 32u;
+  // bf16 exact form: the one-hot first operand e_j (1.0 at position j) and a second operand of ones
+  const u32x2 bf_id = u32x2{__builtin_amdgcn_perm(0x3f803f80u, 0u, selA[0]), __builtin_amdgcn_perm(0x3f803f80u, 0u, selB[0])};
+  const u32x2 bf_ones = u32x2{0x3f803f80u, 0x3f803f80u};
   const uint32_t maskA = j == 0 ? 0x0000ffffu : j == 1 ? 0xffff0000u : 0u;
   const uint32_t maskB = j == 2 ? 0x0000ffffu : j == 3 ? 0xffff0000u : 0u;
-  const uint32_t red_off = xs_off + (STAGE ? TOK * xs_stride : 0u);
+  const uint32_t sb_off = xs_off + xs_stride;   // (kSB) scale plane, then the bias plane: the activations' layout
+  const uint32_t red_off = xs_off + (STAGE ? TOK * xs_stride : 0u) + (kSB ? 2u * xs_stride : 0u);
   float* const red_b = (float*)(smem + red_off);        // [TOK][kMWaves]: sum b * x per wave
   uint32_t* const slot_cnt = (uint32_t*)(red_b + TOK * kMWaves);  // [kMMaxSlots] waves that have arrived
   uint32_t* const slot_done = slot_cnt + kMMaxSlots;         // [kMMaxSlots] row groups finished + 1
@@ -240,10 +247,10 @@ static __device__ __forceinline__ void gemv_k256m_body(const K256Layer& Ly, cons
     const uint32_t roff = (uint32_t)(row0 + j < N ? j : N - 1 - row0) * row_bytes;
     const int want = (cb * NS + s) * kMSweepCols + lane_cols;
     const uint32_t coff = (uint32_t)(want < G ? want : G - 8) * 2u;  // G % 8 == 0 (host check)
-    if (!FAST) {
+    if (!FAST && !kSB) {
       q_load(s_raw[NQ > 1 ? s : 0], sp, coff);
       q_load(b_raw[NQ > 1 ? s : 0], bp, coff);
-    } else if (!STAGE) {
+    } else if (FAST && !STAGE) {
       q_load(s_raw[NQ > 1 ? s : 0], sp, coff);
       q_load(b_raw[NQ > 1 ? s : 0], Ly.x, coff);
     }
@@ -298,7 +305,7 @@ static __device__ __forceinline__ void gemv_k256m_body(const K256Layer& Ly, cons
         const int col0 = want < G ? want : G - 8;
         const uint32_t off = (uint32_t)col0 * 2u;
         if (PERM) q_load(st_pv[k], Ly.perm, off);
-        if (FAST) {
+        if (FAST || kSB) {
           if constexpr (kAblNoScale) st_s[k] = u32x4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
           else q_load(st_s[k], sp, off);
           if (!kLateB) q_load(st_b[k], bp, off);
@@ -389,6 +396,10 @@ static __device__ __forceinline__ void gemv_k256m_body(const K256Layer& Ly, cons
           lds_store16(xs_off + t * xs_stride + (uint32_t)(valid ? want : G + 8) * 2u, v);
         }
       }
+      if constexpr (kSB) {
+        lds_store16(sb_off + (uint32_t)(valid ? want : G + 8) * 2u, st_s[k]);
+        lds_store16(sb_off + xs_stride + (uint32_t)(valid ? want : G + 8) * 2u, st_b[k]);
+      }
     }
     if constexpr (kSelOk) {
       if (sel) {
@@ -452,6 +463,7 @@ static __device__ __forceinline__ void gemv_k256m_body(const K256Layer& Ly, cons
       }
     }
     if (STAGE && tid < TOK) lds_store16(xs_off + tid * xs_stride + (uint32_t)G * kXB, u32x4{0, 0, 0, 0});
+    if (kSB && tid < 2) lds_store16(sb_off + tid * xs_stride + (uint32_t)G * 2u, u32x4{0, 0, 0, 0});   // columns past G: weight 0
     if (tid < 2 * kMMaxSlots) slot_cnt[tid] = 0u;
     if (FAST && !kLateB) {
 #pragma unroll
@@ -709,7 +721,10 @@ static __device__ __forceinline__ void gemv_k256m_body(const K256Layer& Ly, cons
 #endif
     // indices whose gathers are in flight ahead of the MFMAs (the exact form has 12 more
     // registers of scale / bias per sweep in its queue: one less)
-    constexpr int kAhead = FAST ? VPTQ_K256M_AHEAD : VPTQ_K256M_AHEAD - 1;
+#ifndef VPTQ_K256M_AHEAD_SB
+#define VPTQ_K256M_AHEAD_SB 1
+#endif
+    constexpr int kAhead = FAST ? VPTQ_K256M_AHEAD : kSB ? VPTQ_K256M_AHEAD_SB : VPTQ_K256M_AHEAD - 1;
     u32x4 cv[kAhead + 1], rv[kAhead + 1];
     auto gather = [&](int u) {
       const uint32_t w = words[u >> 1];
@@ -772,7 +787,46 @@ static __device__ __forceinline__ void gemv_k256m_body(const K256Layer& Ly, cons
           asm volatile("" :: "v"(r), "v"(c));
         }
       } else {
-        const u32x4 sv = s_raw[NQ > 1 ? s : 0], bv = b_raw[NQ > 1 ? s : 0];
+        u32x4 sv = s_raw[NQ > 1 ? s : 0], bv = b_raw[NQ > 1 ? s : 0];
+        if constexpr (kSB) {
+          if (u == 0) {
+            s_raw[0] = lds_load16(sb_off + (uint32_t)(want < G ? want : G) * 2u);
+            b_raw[0] = lds_load16(sb_off + xs_stride + (uint32_t)(want < G ? want : G) * 2u);
+          }
+          sv = s_raw[0];
+          bv = b_raw[0];
+        }
+        if constexpr (std::is_same<DT, BF16>::value) {
+          // bf16 (round 6): the reference's roundings are torch's bf16 ops - widen to fp32, operate, round - which on the VALU is
+          // unpack / fp32 op / v_cvt_pk_bf16_f32 per stage: ~68 instructions per index, 21 us per 8192^2 layer (gemv_k256.hip).  The
+          // matrix pipe widens for free: with the one-hot first operand e_j, lane j receives ITS OWN four second-operand values as
+          // fp32 (D[i][j] = sum_k I[i][k] B[k][j]); accumulating a second such product adds in fp32, a first operand s e_j multiplies.
+          // Every intermediate is a sum or a product of two bf16 values - exactly representable in fp32 or trivially rounded - so the
+          // results are the widened arithmetic's bit for bit (tools/mfma_bf16_exact_probe.hip: 0 of 4 M values differ on
+          // checkpoint-like, reference-test, wide-exponent and tie operands; an INFINITE or NaN weight turns its lane's other three
+          // values into NaN as well: 0 x inf).  11 MFMAs + 12 conversions per index.
+          const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+          const u32x2 so = u32x2{__builtin_amdgcn_perm(sv[q], 0u, selA[h]), __builtin_amdgcn_perm(sv[q], 0u, selB[h])};   // s e_j
+          const u32x2 bo = u32x2{__builtin_amdgcn_perm(bv[q], 0u, selA[h]), __builtin_amdgcn_perm(bv[q], 0u, selB[h])};   // b e_j
+          f32x4 d0 = DT::mfma4(bf_id, u32x2{c[0], c[1]}, z);
+          f32x4 d1 = DT::mfma4(bf_id, u32x2{c[2], c[3]}, z);
+          d0 = DT::mfma4(bf_id, u32x2{r[0], r[1]}, d0);                                       // c + r, fp32
+          d1 = DT::mfma4(bf_id, u32x2{r[2], r[3]}, d1);
+          const f32x4 bvec = DT::mfma4(bo, bf_ones, z);                                       // b in every register
+          u32x2 wa = u32x2{DT::pack(d0[0], d0[1]), DT::pack(d0[2], d0[3])};                   // first rounding
+          u32x2 wb = u32x2{DT::pack(d1[0], d1[1]), DT::pack(d1[2], d1[3])};
+          d0 = DT::mfma4(so, wa, z);                                                          // * s: exact products
+          d1 = DT::mfma4(so, wb, z);
+          wa = u32x2{DT::pack(d0[0], d0[1]), DT::pack(d0[2], d0[3])};                         // second rounding
+          wb = u32x2{DT::pack(d1[0], d1[1]), DT::pack(d1[2], d1[3])};
+          d0 = DT::mfma4(bf_id, wa, bvec);                                                    // + b, fp32
+          d1 = DT::mfma4(bf_id, wb, bvec);
+          wa = u32x2{DT::pack(d0[0], d0[1]), DT::pack(d0[2], d0[3])};                         // third rounding
+          wb = u32x2{DT::pack(d1[0], d1[1]), DT::pack(d1[2], d1[3])};
+          acc0 = DT::mfma4(xo, wa, acc0);
+          acc1 = DT::mfma4(xo, wb, acc1);
+          continue;
+        }
         uint32_t w2[4];
 #pragma unroll
         for (int p = 0; p < 4; ++p) w2[p] = DT::add2(c[p], r[p]);
@@ -1014,14 +1068,15 @@ static int device_cus() {
 
 // LDS bytes before the partial-sum slots: image + per token the staged activations (0 columns:
 // unstaged) and the per-wave sum b * x + slot counters
-static int lds_fixed_bytes(int staged_cols, int tok) {
+// sb: scale and bias planes behind the activations (bf16 exact form)
+static int lds_fixed_bytes(int staged_cols, int tok, bool sb) {
   const int xb = tok == 1 ? kMXBytes1 : 2;
-  return kMTableBytes + (staged_cols > 0 ? tok * (staged_cols * xb + 32) : 0) + tok * kMWaves * 4 + 64 + (tok == 1 ? kMSelBytes : 0);
+  return kMTableBytes + (staged_cols > 0 ? (tok + (sb ? 2 : 0)) * (staged_cols * xb + 32) : 0) + tok * kMWaves * 4 + 64 + (tok == 1 ? kMSelBytes : 0);
 }
 
 template <typename DT, int NS, int NST, bool PERM, bool FAST, int TOK>
 static hipError_t launch_m(const K256Params& P, int gx, int max_cols, hipStream_t st) {
-  const int fixed = lds_fixed_bytes(NST > 0 ? max_cols : 0, TOK);
+  const int fixed = lds_fixed_bytes(NST > 0 ? max_cols : 0, TOK, !FAST && std::is_same<DT, BF16>::value);
   const int slots = P.layer[0].slots & 0xff;  // set by launch_gemv_k256m (bit 8: selective roundings)
   if (slots < 1 || slots > kMMaxSlots) return hipErrorInvalidValue;
   const int lds = fixed + slots * kMRedSlot * TOK;
@@ -1073,8 +1128,8 @@ static hipError_t launch_m_shape(const K256Params& P, int gx, bool perm, int max
 }
 
 // partial-sum slots that fit beside everything else (0: the shape does not fit at all)
-static int lds_slots(int tok, int max_cols) {
-  const int left = kMMaxLds - lds_fixed_bytes(max_cols > kMMaxCols ? 0 : max_cols, tok);
+static int lds_slots(int tok, int max_cols, bool sb) {
+  const int left = kMMaxLds - lds_fixed_bytes(max_cols > kMMaxCols ? 0 : max_cols, tok, sb);
   const int slots = left < 0 ? 0 : left / (kMRedSlot * tok);
   return slots > kMMaxSlots ? kMMaxSlots : slots;
 }
@@ -1090,6 +1145,7 @@ hipError_t k256m_f16_exact(const K256Params& P, int gx, bool perm, int max_cols,
 hipError_t k256m_bf16(const K256Params& P, int gx, bool perm, int max_cols, hipStream_t st);
 hipError_t k256m_f16_tokens(const K256Params& P, int tok, int gx, bool perm, int max_cols, hipStream_t st);
 hipError_t k256m_bf16_tokens(const K256Params& P, int tok, int gx, bool perm, int max_cols, hipStream_t st);
+hipError_t k256m_bf16_exact(const K256Params& P, int gx, bool perm, int max_cols, hipStream_t st);
 
 #if K256M_PART(2)
 hipError_t k256m_f16_exact(const K256Params& P, int gx, bool perm, int max_cols, hipStream_t st) {
@@ -1110,6 +1166,9 @@ hipError_t k256m_bf16_tokens(const K256Params& P, int tok, int gx, bool perm, in
   return tok == 2 ? launch_m_shape<BF16, true, 2>(P, gx, perm, max_cols, st)
                   : launch_m_shape<BF16, true, 4>(P, gx, perm, max_cols, st);
 }
+hipError_t k256m_bf16_exact(const K256Params& P, int gx, bool perm, int max_cols, hipStream_t st) {
+  return launch_m_shape<BF16, false, 1>(P, gx, perm, max_cols, st);
+}
 #endif
 #if K256M_PART(1)
 hipError_t k256m_f16_fast(const K256Params& P, int gx, bool perm, int max_cols, hipStream_t st) {
@@ -1118,15 +1177,15 @@ hipError_t k256m_f16_fast(const K256Params& P, int gx, bool perm, int max_cols, 
 
 // tok = token slots of the instantiation (1, 2 or 4)
 bool gemv_k256m_supported(int tok, bool f16, bool fast, int max_cols, bool perm) {
-  // the exact form queues scale and bias with the index words: 6 and 7 sweeps spill
-  if (!fast && max_cols > 5 * kMSweepCols) return false;
+  // the fp16 exact form queues scale and bias with the index words: 6 and 7 sweeps spill (bf16: staged in LDS, see kSB)
+  if (!fast && f16 && max_cols > 5 * kMSweepCols) return false;
   // more columns than fit beside the image: unstaged variant (folded form, no permutation)
   if (max_cols > kMMaxCols && (!fast || perm || tok > 1)) return false;
   // several tokens: folded form, one staged copy of the activations per token slot
   if (tok != 1 && !((tok == 2 || tok == 4) && fast)) return false;
-  if (lds_slots(tok, max_cols) < 1) return false;
-  // bf16: folded form only (its exact form would run the widened arithmetic on the VALU)
-  return f16 || fast;
+  if (lds_slots(tok, max_cols, !f16 && !fast) < 1) return false;
+  // bf16: the folded form; the reference's roundings on the matrix pipe (round 6), one token
+  return f16 || fast || tok == 1;
 }
 
 int gemv_k256m_row_groups(int n_rows) { return (n_rows + kMRows - 1) / kMRows; }
@@ -1176,13 +1235,13 @@ hipError_t launch_gemv_k256m(K256Params& P, int tok, bool f16, bool fast, int ma
     if (share < 1) share = 1;
     if (share > groups) share = groups;
     P.layer[i].wgs = (int)share;
-    P.layer[i].slots = lds_slots(tok, max_cols) | (selective ? kMSelBit : 0);
+    P.layer[i].slots = lds_slots(tok, max_cols, !f16 && !fast) | (selective ? kMSelBit : 0);
     gx = (int)share > gx ? (int)share : gx;
   }
   if (tok != 1)
     return f16 ? k256m_f16_tokens(P, tok, gx, perm, max_cols, st)
                : k256m_bf16_tokens(P, tok, gx, perm, max_cols, st);
-  if (!f16) return k256m_bf16(P, gx, perm, max_cols, st);
+  if (!f16) return fast ? k256m_bf16(P, gx, perm, max_cols, st) : k256m_bf16_exact(P, gx, perm, max_cols, st);
   return fast ? k256m_f16_fast(P, gx, perm, max_cols, st) : k256m_f16_exact(P, gx, perm, max_cols, st);
 }
 #endif  // part 1
