@@ -287,6 +287,7 @@ def test_mfma_kernel_is_deterministic(I, O, dev):
     (4096, 1024, dict(dist="llm", bias=True)),        # 32 row groups: bf16 already takes it
     (8192 + 512, 264, dict(dist="llm")),
     (4104, 72, dict(enable_perm=True)),
+    (14336, 256, dict(dist="llm")),                   # 7 sweeps: scale and bias still fit beside the activations
     (16384, 64, dict(dist="llm")),                    # wider than the LDS can stage
 ])
 def test_mfma_kernel_bf16(I, O, kw, dev):
@@ -304,7 +305,7 @@ def test_mfma_kernel_bf16(I, O, kw, dev):
     want = vo.forward(L, x)
     expect_kernel(m, 1, MFMA, "gemv_k256m_kernel<fast>")
     # the reference's roundings: on the matrix pipe (round 6) while scale and bias fit into LDS beside the activations
-    exact_mfma = I <= 12288
+    exact_mfma = I <= 14336
     expect_kernel(m, 1, MFMA | EXACT, "gemv_k256m_kernel" if exact_mfma else "gemv_k256_kernel")
     expect_kernel(m, 2, MFMA | EXACT, "gemv_k256_kernel")
     expect_kernel(m, 1, EXACT, "gemv_k256m_kernel" if exact_mfma and (O + 31) // 32 >= 32 else "gemv_k256_kernel")

@@ -216,9 +216,8 @@ static __device__ __forceinline__ void gemv_k256m_body(const K256Layer& Ly, cons
   constexpr bool kXDup = VPTQ_K256M_XDUP && TOK == 1 && STAGE;
   constexpr uint32_t kXB = kXDup ? 4u : 2u;  // staged bytes per column
   const uint32_t xs_stride = (uint32_t)G * kXB + 32u;
-  // bf16 exact form: the one-hot first operand e_j (1.0 at position j) and a second operand of ones
+  // bf16 exact form: the one-hot first operand e_j (1.0 at position j)
   const u32x2 bf_id = u32x2{__builtin_amdgcn_perm(0x3f803f80u, 0u, selA[0]), __builtin_amdgcn_perm(0x3f803f80u, 0u, selB[0])};
-  const u32x2 bf_ones = u32x2{0x3f803f80u, 0x3f803f80u};
   const uint32_t maskA = j == 0 ? 0x0000ffffu : j == 1 ? 0xffff0000u : 0u;
   const uint32_t maskB = j == 2 ? 0x0000ffffu : j == 3 ? 0xffff0000u : 0u;
   const uint32_t sb_off = xs_off + xs_stride;   // (kSB) scale plane, then the bias plane: the activations' layout
@@ -229,7 +228,7 @@ static __device__ __forceinline__ void gemv_k256m_body(const K256Layer& Ly, cons
   // one token: hot-block flags and corrections of the selective arithmetic in front of the slots
   uint16_t* const hot_mag = (uint16_t*)(slot_done + kMMaxSlots + 8);    // [kMSelMaxBlocks]: largest |f16(s x)| of a block at or above its wave's threshold, else 0
   float* const corr = (float*)(hot_mag + kMSelMaxBlocks);               // [4][kMSelRowGroups][32]
-  float* const red = (float*)(slot_done + kMMaxSlots + 8) + (TOK == 1 ? kMSelBytes / 4 : 0);   // [K][TOK][kMWaves][32]
+  float* const red = (float*)(slot_done + kMMaxSlots + 8) + (TOK == 1 && !kSB ? kMSelBytes / 4 : 0);   // [K][TOK][kMWaves][32]
   const int K = Ly.slots & 0xff;  // partial-sum slots that fit into LDS (1..kMMaxSlots, host)
   constexpr bool kSelOk = FAST && (NST > 0) && TOK == 1;   // (fp16 and bf16: the corrections are VALU arithmetic in either type)
   const bool sel = kSelOk && (Ly.slots & kMSelBit) != 0;   // (wave-uniform)
@@ -721,6 +720,9 @@ static __device__ __forceinline__ void gemv_k256m_body(const K256Layer& Ly, cons
 #endif
     // indices whose gathers are in flight ahead of the MFMAs (the exact form has 12 more
     // registers of scale / bias per sweep in its queue: one less)
+#ifndef VPTQ_K256M_SB_UNFENCED
+#define VPTQ_K256M_SB_UNFENCED 0
+#endif
 #ifndef VPTQ_K256M_AHEAD_SB
 #define VPTQ_K256M_AHEAD_SB 1
 #endif
@@ -749,9 +751,9 @@ static __device__ __forceinline__ void gemv_k256m_body(const K256Layer& Ly, cons
 #ifndef VPTQ_K256M_FENCE_UNITS
 #define VPTQ_K256M_FENCE_UNITS 1
 #endif
-      if (VPTQ_K256M_FENCE_UNITS) __builtin_amdgcn_sched_barrier(0);
+      if (VPTQ_K256M_FENCE_UNITS && !(kSB && VPTQ_K256M_SB_UNFENCED)) __builtin_amdgcn_sched_barrier(0);
       if (u + kAhead < 8) gather(u + kAhead);
-      if (VPTQ_K256M_FENCE_UNITS) __builtin_amdgcn_sched_barrier(0);
+      if (VPTQ_K256M_FENCE_UNITS && !(kSB && VPTQ_K256M_SB_UNFENCED)) __builtin_amdgcn_sched_barrier(0);
       const int q = u >> 1, h = u & 1;
       const u32x4 c = cv[u % (kAhead + 1)], r = rv[u % (kAhead + 1)];
       u32x2 xo;
@@ -804,15 +806,21 @@ static __device__ __forceinline__ void gemv_k256m_body(const K256Layer& Ly, cons
           // Every intermediate is a sum or a product of two bf16 values - exactly representable in fp32 or trivially rounded - so the
           // results are the widened arithmetic's bit for bit (tools/mfma_bf16_exact_probe.hip: 0 of 4 M values differ on
           // checkpoint-like, reference-test, wide-exponent and tie operands; an INFINITE or NaN weight turns its lane's other three
-          // values into NaN as well: 0 x inf).  11 MFMAs + 12 conversions per index.
+          // values into NaN as well: 0 x inf).  11 MFMAs + 12 conversions + 8 v_perm_b32 per index; 8192^2: 21.7 -> 11.9 us per launch, 9.98 us
+          // per layer in a grouped launch.  Counters (profiles/r06/bf16_exact_mfma_pmc.json): the matrix pipe is 42 % busy and the time is
+          // 8 cycles per MFMA + 4 per VALU instruction, added up - an A/B without the per-unit fences and with a deeper gather lookahead
+          // (VPTQ_K256M_SB_UNFENCED, VPTQ_K256M_AHEAD_SB) changes nothing: issue bound, not latency bound.
           const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
           const u32x2 so = u32x2{__builtin_amdgcn_perm(sv[q], 0u, selA[h]), __builtin_amdgcn_perm(sv[q], 0u, selB[h])};   // s e_j
-          const u32x2 bo = u32x2{__builtin_amdgcn_perm(bv[q], 0u, selA[h]), __builtin_amdgcn_perm(bv[q], 0u, selB[h])};   // b e_j
           f32x4 d0 = DT::mfma4(bf_id, u32x2{c[0], c[1]}, z);
           f32x4 d1 = DT::mfma4(bf_id, u32x2{c[2], c[3]}, z);
           d0 = DT::mfma4(bf_id, u32x2{r[0], r[1]}, d0);                                       // c + r, fp32
           d1 = DT::mfma4(bf_id, u32x2{r[2], r[3]}, d1);
-          const f32x4 bvec = DT::mfma4(bo, bf_ones, z);                                       // b in every register
+          // b in every register: first operand = the bias of four columns as loaded (the same in all four lanes of a block), second
+          // operand = the one-hot that picks this column: no VALU work
+          const u32x2 one_hot = u32x2{(u & 3) == 0 ? 0x00003f80u : (u & 3) == 1 ? 0x3f800000u : 0u,
+                                      (u & 3) == 2 ? 0x00003f80u : (u & 3) == 3 ? 0x3f800000u : 0u};
+          const f32x4 bvec = DT::mfma4(u32x2{bv[(u >> 2) * 2], bv[(u >> 2) * 2 + 1]}, one_hot, z);
           u32x2 wa = u32x2{DT::pack(d0[0], d0[1]), DT::pack(d0[2], d0[3])};                   // first rounding
           u32x2 wb = u32x2{DT::pack(d1[0], d1[1]), DT::pack(d1[2], d1[3])};
           d0 = DT::mfma4(so, wa, z);                                                          // * s: exact products
@@ -1071,7 +1079,7 @@ static int device_cus() {
 // sb: scale and bias planes behind the activations (bf16 exact form)
 static int lds_fixed_bytes(int staged_cols, int tok, bool sb) {
   const int xb = tok == 1 ? kMXBytes1 : 2;
-  return kMTableBytes + (staged_cols > 0 ? (tok + (sb ? 2 : 0)) * (staged_cols * xb + 32) : 0) + tok * kMWaves * 4 + 64 + (tok == 1 ? kMSelBytes : 0);
+  return kMTableBytes + (staged_cols > 0 ? (tok + (sb ? 2 : 0)) * (staged_cols * xb + 32) : 0) + tok * kMWaves * 4 + 64 + (tok == 1 && !sb ? kMSelBytes : 0);   // (sb: no selective form, no corrections)
 }
 
 template <typename DT, int NS, int NST, bool PERM, bool FAST, int TOK>
