@@ -86,6 +86,31 @@ struct F16 {
   static __device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float c) {
     return __builtin_amdgcn_fdot2(__builtin_bit_cast(h2_t, a), __builtin_bit_cast(h2_t, b), c, false);
   }
+  // the forms the GEMV kernels' reference roundings use (bf16 has a shorter route for them, see BF16): here the same instructions
+  static __device__ __forceinline__ uint32_t add2_g(uint32_t a, uint32_t b) { return add2(a, b); }
+  static __device__ __forceinline__ uint32_t mul2_bcast_g(uint32_t a, uint32_t pair, int h) { return mul2_bcast(a, pair, h); }
+  static __device__ __forceinline__ uint32_t add2_bcast_g(uint32_t a, uint32_t pair, int h) { return add2_bcast(a, pair, h); }
+  static __device__ __forceinline__ float fma_lo_h_g(uint32_t w, uint32_t xpair, int h, float acc) { return fma_lo_h(w, xpair, h, acc); }
+  static __device__ __forceinline__ float fma_hi_h_g(uint32_t w, uint32_t xpair, int h, float acc) { return fma_hi_h(w, xpair, h, acc); }
+  // ... on four packed pairs (= 8 elements of one vector) at a time: w = f16(w + r); w = f16(f16(w * s) + b), s / b = half sh / bh of
+  // a pair register; acc[0..7] += w * x, x = half xh of a pair register
+  static __device__ __forceinline__ void add4(uint32_t (&w)[4], const uint32_t (&r)[4]) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) w[p] = add2(w[p], r[p]);
+  }
+  static __device__ __forceinline__ void scale_bias4(uint32_t (&w)[4], uint32_t spair, int sh, uint32_t bpair, int bh) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) w[p] = mul2_bcast(w[p], spair, sh);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) w[p] = add2_bcast(w[p], bpair, bh);
+  }
+  static __device__ __forceinline__ void fma4(float* acc, const uint32_t (&w)[4], uint32_t xpair, int xh) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      acc[2 * p] = fma_lo_h(w[p], xpair, xh, acc[2 * p]);
+      acc[2 * p + 1] = fma_hi_h(w[p], xpair, xh, acc[2 * p + 1]);
+    }
+  }
   // 16 independent 4x4x4 products, fp32 accumulate: v_mfma_f32_4x4x4_16b_f16.  Block b =
   // lanes 4b..4b+3; lane i supplies row i of the first matrix and column i of the second,
   // and receives column i of the result (register r = row r).
@@ -148,6 +173,99 @@ struct BF16 {
   }
   static __device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float c) {
     return __builtin_fmaf(lo(a), lo(b), __builtin_fmaf(hi(a), hi(b), c));
+  }
+  // ---- the reference's widened roundings WITHOUT unpacking (round 6).  v_dot2_f32_bf16 computes a.lo b.lo + a.hi b.hi + c in fp32
+  // from packed bf16 pairs: with b = (s, 0) that is lo(a) * s, with b = (1, 0) and c = widen(t) it is lo(a) + t, with b = (x, 0) and
+  // c = acc the multiply-add of the product.  tools/dot2_bf16_probe.hip, 4 M operands per family: products and sums round to the
+  // SAME bf16 as the widened arithmetic on checkpoint-like, reference-test, wide-exponent, tie and raw finite operands (a sum of two
+  // bf16 values is exact in fp32 or far from a bf16 tie; a product of two is exact); different: the sign of an exact zero, denormal
+  // results (flushed), and an infinite / NaN OTHER half of the pair (x 0 = NaN) - none of which a weight can carry into a sum that
+  // matters; the accumulate form differs from fmaf in the last fp32 bit now and then.  dequant.hip - whose W must be the reference's
+  // bit for bit, zeros' signs included - keeps the widened forms above.
+  typedef __bf16 bf2_t __attribute__((ext_vector_type(2)));
+  static __device__ __forceinline__ float dotp(uint32_t a, uint32_t b, float c) {
+    // (the builtin, not inline assembly: a dot instruction's result needs wait states before a VALU read, which the compiler inserts
+    // only for instructions it sees)
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2_t, a), __builtin_bit_cast(bf2_t, b), c, false);
+  }
+  // (1, 0) / (0, 1), hidden from the compiler: as a known constant it becomes the inline operand `1.0`, which the instruction reads
+  // as the 32-bit pattern 0x3f800000 = (0, 1) - the probe's first version added the wrong half
+  static __device__ __forceinline__ uint32_t one_lo() { uint32_t v = 0x00003f80u; asm("" : "+v"(v)); return v; }
+  static __device__ __forceinline__ uint32_t one_hi() { uint32_t v = 0x3f800000u; asm("" : "+v"(v)); return v; }
+  static __device__ __forceinline__ uint32_t add2_g(uint32_t a, uint32_t b) {
+    return pack(dotp(a, one_lo(), lo(b)), dotp(a, one_hi(), hi(b)));
+  }
+  static __device__ __forceinline__ uint32_t mul2_bcast_g(uint32_t a, uint32_t pair, int h) {
+    const uint32_t s0 = h ? pair >> 16 : pair & 0xffffu;          // (s, 0)
+    const uint32_t s1 = h ? pair & 0xffff0000u : pair << 16;      // (0, s)
+    return pack(dotp(a, s0, 0.f), dotp(a, s1, 0.f));
+  }
+  static __device__ __forceinline__ uint32_t add2_bcast_g(uint32_t a, uint32_t pair, int h) {
+    const float t = half_of(pair, h);
+    return pack(dotp(a, one_lo(), t), dotp(a, one_hi(), t));
+  }
+  static __device__ __forceinline__ float fma_lo_h_g(uint32_t w, uint32_t xpair, int h, float acc) {
+    return dotp(w, h ? xpair >> 16 : xpair & 0xffffu, acc);
+  }
+  static __device__ __forceinline__ float fma_hi_h_g(uint32_t w, uint32_t xpair, int h, float acc) {
+    return dotp(w, h ? xpair & 0xffff0000u : xpair << 16, acc);
+  }
+  // ---- the same on four packed pairs at a time, as ONE scheduled block each.  The builtin above lowers to v_dot2c_f32_bf16 (VOP2:
+  // D += a . b), which costs a v_mov per use to seed D, and the dot instructions' hazards (3 wait states before another VALU
+  // instruction reads a dot's result, 4 before one overwrites it) become s_nop between every dependent pair: gemv_sliced<EX> came out
+  // at 48 instructions + 8 s_nop per element against 56 widened - and no faster.  Here: the three-source form v_dot2_f32_bf16,
+  // stage-major over the four pairs so that every consumer is at least 3 instructions behind its producer; each block ends on 4
+  // non-dot instructions (or s_nop 3) so that whatever the compiler places behind it is safe.  8 dots + 4 conversions per stage.
+  static __device__ __forceinline__ void add4(uint32_t (&w)[4], const uint32_t (&r)[4]) {
+    float t0, t1, t2, t3, t4, t5, t6, t7;
+    const uint32_t ol = one_lo(), oh = one_hi();
+    asm("v_lshlrev_b32 %[t0], 16, %[r0]\n\tv_and_b32 %[t1], 0xffff0000, %[r0]\n\t"
+        "v_lshlrev_b32 %[t2], 16, %[r1]\n\tv_and_b32 %[t3], 0xffff0000, %[r1]\n\t"
+        "v_lshlrev_b32 %[t4], 16, %[r2]\n\tv_and_b32 %[t5], 0xffff0000, %[r2]\n\t"
+        "v_lshlrev_b32 %[t6], 16, %[r3]\n\tv_and_b32 %[t7], 0xffff0000, %[r3]\n\t"
+        "v_dot2_f32_bf16 %[t0], %[w0], %[ol], %[t0]\n\tv_dot2_f32_bf16 %[t1], %[w0], %[oh], %[t1]\n\t"
+        "v_dot2_f32_bf16 %[t2], %[w1], %[ol], %[t2]\n\tv_dot2_f32_bf16 %[t3], %[w1], %[oh], %[t3]\n\t"
+        "v_dot2_f32_bf16 %[t4], %[w2], %[ol], %[t4]\n\tv_dot2_f32_bf16 %[t5], %[w2], %[oh], %[t5]\n\t"
+        "v_dot2_f32_bf16 %[t6], %[w3], %[ol], %[t6]\n\tv_dot2_f32_bf16 %[t7], %[w3], %[oh], %[t7]\n\t"
+        "v_cvt_pk_bf16_f32 %[w0], %[t0], %[t1]\n\tv_cvt_pk_bf16_f32 %[w1], %[t2], %[t3]\n\t"
+        "v_cvt_pk_bf16_f32 %[w2], %[t4], %[t5]\n\tv_cvt_pk_bf16_f32 %[w3], %[t6], %[t7]"
+        : [w0] "+v"(w[0]), [w1] "+v"(w[1]), [w2] "+v"(w[2]), [w3] "+v"(w[3]), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2),
+          [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5), [t6] "=&v"(t6), [t7] "=&v"(t7)
+        : [r0] "v"(r[0]), [r1] "v"(r[1]), [r2] "v"(r[2]), [r3] "v"(r[3]), [ol] "v"(ol), [oh] "v"(oh));
+  }
+  static __device__ __forceinline__ void scale_bias4(uint32_t (&w)[4], uint32_t spair, int sh, uint32_t bpair, int bh) {
+    const uint32_t s0 = sh ? spair >> 16 : spair & 0xffffu;          // (s, 0)
+    const uint32_t s1 = sh ? spair & 0xffff0000u : spair << 16;      // (0, s)
+    const float b32 = half_of(bpair, bh);
+    const uint32_t ol = one_lo(), oh = one_hi();
+    float t0, t1, t2, t3, t4, t5, t6, t7;
+    asm("v_dot2_f32_bf16 %[t0], %[w0], %[s0], 0\n\tv_dot2_f32_bf16 %[t1], %[w0], %[s1], 0\n\t"
+        "v_dot2_f32_bf16 %[t2], %[w1], %[s0], 0\n\tv_dot2_f32_bf16 %[t3], %[w1], %[s1], 0\n\t"
+        "v_dot2_f32_bf16 %[t4], %[w2], %[s0], 0\n\tv_dot2_f32_bf16 %[t5], %[w2], %[s1], 0\n\t"
+        "v_dot2_f32_bf16 %[t6], %[w3], %[s0], 0\n\tv_dot2_f32_bf16 %[t7], %[w3], %[s1], 0\n\t"
+        "v_cvt_pk_bf16_f32 %[w0], %[t0], %[t1]\n\tv_cvt_pk_bf16_f32 %[w1], %[t2], %[t3]\n\t"
+        "v_cvt_pk_bf16_f32 %[w2], %[t4], %[t5]\n\tv_cvt_pk_bf16_f32 %[w3], %[t6], %[t7]\n\t"
+        "v_dot2_f32_bf16 %[t0], %[w0], %[ol], %[b]\n\tv_dot2_f32_bf16 %[t1], %[w0], %[oh], %[b]\n\t"
+        "v_dot2_f32_bf16 %[t2], %[w1], %[ol], %[b]\n\tv_dot2_f32_bf16 %[t3], %[w1], %[oh], %[b]\n\t"
+        "v_dot2_f32_bf16 %[t4], %[w2], %[ol], %[b]\n\tv_dot2_f32_bf16 %[t5], %[w2], %[oh], %[b]\n\t"
+        "v_dot2_f32_bf16 %[t6], %[w3], %[ol], %[b]\n\tv_dot2_f32_bf16 %[t7], %[w3], %[oh], %[b]\n\t"
+        "v_cvt_pk_bf16_f32 %[w0], %[t0], %[t1]\n\tv_cvt_pk_bf16_f32 %[w1], %[t2], %[t3]\n\t"
+        "v_cvt_pk_bf16_f32 %[w2], %[t4], %[t5]\n\tv_cvt_pk_bf16_f32 %[w3], %[t6], %[t7]"
+        : [w0] "+v"(w[0]), [w1] "+v"(w[1]), [w2] "+v"(w[2]), [w3] "+v"(w[3]), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2),
+          [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5), [t6] "=&v"(t6), [t7] "=&v"(t7)
+        : [s0] "v"(s0), [s1] "v"(s1), [b] "v"(b32), [ol] "v"(ol), [oh] "v"(oh));
+  }
+  static __device__ __forceinline__ void fma4(float* acc, const uint32_t (&w)[4], uint32_t xpair, int xh) {
+    const uint32_t x0 = xh ? xpair >> 16 : xpair & 0xffffu;          // (x, 0)
+    const uint32_t x1 = xh ? xpair & 0xffff0000u : xpair << 16;      // (0, x)
+    asm("v_dot2_f32_bf16 %[a0], %[w0], %[x0], %[a0]\n\tv_dot2_f32_bf16 %[a1], %[w0], %[x1], %[a1]\n\t"
+        "v_dot2_f32_bf16 %[a2], %[w1], %[x0], %[a2]\n\tv_dot2_f32_bf16 %[a3], %[w1], %[x1], %[a3]\n\t"
+        "v_dot2_f32_bf16 %[a4], %[w2], %[x0], %[a4]\n\tv_dot2_f32_bf16 %[a5], %[w2], %[x1], %[a5]\n\t"
+        "v_dot2_f32_bf16 %[a6], %[w3], %[x0], %[a6]\n\tv_dot2_f32_bf16 %[a7], %[w3], %[x1], %[a7]\n\t"
+        "s_nop 3"
+        : [a0] "+v"(acc[0]), [a1] "+v"(acc[1]), [a2] "+v"(acc[2]), [a3] "+v"(acc[3]), [a4] "+v"(acc[4]), [a5] "+v"(acc[5]),
+          [a6] "+v"(acc[6]), [a7] "+v"(acc[7])
+        : [w0] "v"(w[0]), [w1] "v"(w[1]), [w2] "v"(w[2]), [w3] "v"(w[3]), [x0] "v"(x0), [x1] "v"(x1));
   }
   static __device__ __forceinline__ f32x4 mfma4(u32x2 a, u32x2 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(s4_t, a),

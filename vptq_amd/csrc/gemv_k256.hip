@@ -224,21 +224,34 @@ static __device__ __forceinline__ void gemv_k256_body(const K256Layer& Ly, const
         }
         // stage-major order: the 8 independent pair-chains of the unit advance
         // together, so dependent packed-f16 ops are never back-to-back
+        if constexpr (std::is_same<DT, BF16>::value && !FAST) {
+          // bf16: the widened roundings from the packed pairs, one scheduled block of four pairs per stage (common.h, round 6)
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            uint32_t w[4] = {cv[u & 1][e][0], cv[u & 1][e][1], cv[u & 1][e][2], cv[u & 1][e][3]};
+            const uint32_t rr[4] = {rv[u & 1][e][0], rv[u & 1][e][1], rv[u & 1][e][2], rv[u & 1][e][3]};
+            BF16::add4(w, rr);
+            BF16::scale_bias4(w, s_raw[sw][k], e, b_raw[sw][k], e);
+#pragma unroll
+            for (int t = 0; t < TOK; ++t) BF16::fma4(&acc[t][r][0], w, x_raw[sw][t][k], e);
+          }
+          continue;
+        }
         uint32_t w2[2][4];
 #pragma unroll
         for (int e = 0; e < 2; ++e)
 #pragma unroll
-          for (int p = 0; p < 4; ++p) w2[e][p] = DT::add2(cv[u & 1][e][p], rv[u & 1][e][p]);
+          for (int p = 0; p < 4; ++p) w2[e][p] = DT::add2_g(cv[u & 1][e][p], rv[u & 1][e][p]);
         if (!FAST) {
           // column 2k+e uses half e of pair register k of scale / bias
 #pragma unroll
           for (int e = 0; e < 2; ++e)
 #pragma unroll
-            for (int p = 0; p < 4; ++p) w2[e][p] = DT::mul2_bcast(w2[e][p], s_raw[sw][k], e);
+            for (int p = 0; p < 4; ++p) w2[e][p] = DT::mul2_bcast_g(w2[e][p], s_raw[sw][k], e);
 #pragma unroll
           for (int e = 0; e < 2; ++e)
 #pragma unroll
-            for (int p = 0; p < 4; ++p) w2[e][p] = DT::add2_bcast(w2[e][p], b_raw[sw][k], e);
+            for (int p = 0; p < 4; ++p) w2[e][p] = DT::add2_bcast_g(w2[e][p], b_raw[sw][k], e);
         }
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
@@ -251,9 +264,9 @@ static __device__ __forceinline__ void gemv_k256_body(const K256Layer& Ly, const
                 acc[t][r][2 * p + 1] =
                     DT::fma_hi(w2[e][p], xs[t][2 * k + e], acc[t][r][2 * p + 1]);
               } else {
-                acc[t][r][2 * p] = DT::fma_lo_h(w2[e][p], x_raw[sw][t][k], e, acc[t][r][2 * p]);
+                acc[t][r][2 * p] = DT::fma_lo_h_g(w2[e][p], x_raw[sw][t][k], e, acc[t][r][2 * p]);
                 acc[t][r][2 * p + 1] =
-                    DT::fma_hi_h(w2[e][p], x_raw[sw][t][k], e, acc[t][r][2 * p + 1]);
+                    DT::fma_hi_h_g(w2[e][p], x_raw[sw][t][k], e, acc[t][r][2 * p + 1]);
               }
             }
           }

@@ -677,10 +677,10 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
     // EX: the weight as the reference rounds it - u = f16(c + r), t = f16(u * s), w = f16(t + b): three packed instructions per
     // pair of outputs, scale and bias broadcast out of the column's word by op_sel - then w x in fp32
     auto weight = [&](uint32_t ew, uint32_t rw, uint32_t sbw) __attribute__((always_inline)) -> uint32_t {
-      if constexpr (RES || RG) ew = DT::add2(ew, rw);
+      if constexpr (RES || RG) ew = DT::add2_g(ew, rw);
       if constexpr (EX) {
-        ew = DT::mul2_bcast(ew, sbw, 0);
-        ew = DT::add2_bcast(ew, sbw, 1);
+        ew = DT::mul2_bcast_g(ew, sbw, 0);
+        ew = DT::add2_bcast_g(ew, sbw, 1);
       }
       return ew;
     };
@@ -713,26 +713,24 @@ __global__ __launch_bounds__(kSLThreads) void gemv_sliced_kernel(const SlicedGro
         }
       }
     } else {
-      float xf[TOK];
-      xf[0] = DT::to_float((uint16_t)g_x[Bf]);
-      if constexpr (TOK >= 2) xf[1] = DT::to_float((uint16_t)(g_x[Bf] >> 16));
-      if constexpr (TOK == 3) xf[2] = DT::to_float((uint16_t)g_x2[Bf]);
+      // bf16: the widened arithmetic straight from the packed pairs, four pairs per scheduled block (common.h: BF16::add4 /
+      // scale_bias4 / fma4, round 6): 8 dot instructions + 4 conversions per rounding stage, 8 dot instructions per token's products
+      const uint32_t xw = g_x[Bf];   // token 0 (| token 1 << 16)
 #pragma unroll
-      for (int i = 0; i < V / 2; ++i) {
-        // (folded bf16: c x + r x, two pairs of multiply-adds - a widened add would cost more than it saves)
-        const uint32_t c0 = g_ent[Bf][i / 4][i % 4];
-        const uint32_t ew = EX ? weight(c0, RES ? g_rent[Bf][i % 4] : (RG ? rgq[RG ? S : 0][i / 4][i % 4] : 0u), g_sb[Bf]) : c0;
-        const float wl = DT::to_float((uint16_t)(ew & 0xffffu)), wh = DT::to_float((uint16_t)(ew >> 16));
-#pragma unroll
-        for (int t = 0; t < TOK; ++t) {
-          acc[t][2 * i] = __builtin_fmaf(wl, xf[t], acc[t][2 * i]);
-          acc[t][2 * i + 1] = __builtin_fmaf(wh, xf[t], acc[t][2 * i + 1]);
+      for (int g4 = 0; g4 < V / 8; ++g4) {
+        uint32_t w[4] = {g_ent[Bf][g4][0], g_ent[Bf][g4][1], g_ent[Bf][g4][2], g_ent[Bf][g4][3]};
+        [[maybe_unused]] uint32_t r[4] = {0u, 0u, 0u, 0u};
+        if constexpr (RES) { r[0] = g_rent[Bf][0]; r[1] = g_rent[Bf][1]; r[2] = g_rent[Bf][2]; r[3] = g_rent[Bf][3]; }
+        if constexpr (RG) { r[0] = rgq[RG ? S : 0][g4][0]; r[1] = rgq[RG ? S : 0][g4][1]; r[2] = rgq[RG ? S : 0][g4][2]; r[3] = rgq[RG ? S : 0][g4][3]; }
+        if constexpr (EX) {
+          if constexpr (RES || RG) BF16::add4(w, r);
+          BF16::scale_bias4(w, g_sb[Bf], 0, g_sb[Bf], 1);
         }
-        if constexpr (RES && !EX) {
-          const uint32_t rw = g_rent[Bf][i % 4];
-          acc[0][2 * i] = __builtin_fmaf(DT::to_float((uint16_t)(rw & 0xffffu)), xf[0], acc[0][2 * i]);
-          acc[0][2 * i + 1] = __builtin_fmaf(DT::to_float((uint16_t)(rw >> 16)), xf[0], acc[0][2 * i + 1]);
-        }
+        BF16::fma4(&acc[0][8 * g4], w, xw, 0);
+        if constexpr (TOK >= 2) BF16::fma4(&acc[TOK >= 2 ? 1 : 0][8 * g4], w, xw, 1);
+        if constexpr (TOK == 3) BF16::fma4(&acc[TOK == 3 ? 2 : 0][8 * g4], w, g_x2[Bf], 0);
+        // (folded bf16: c x + r x, two sets of multiply-adds - a widened add would cost more than it saves)
+        if constexpr (RES && !EX) BF16::fma4(&acc[0][8 * g4], r, xw, 0);
       }
     }
   };
