@@ -79,6 +79,10 @@ constexpr int kMSelBytes = 2 * kMSelMaxBlocks + 4 * kMSelRowGroups * 32 * 4;   /
 #ifndef VPTQ_K256M_XDUP
 #define VPTQ_K256M_XDUP 0
 #endif
+// VPTQ_K256M_SB_ALL (A/B): every exact instantiation stages scale and bias in LDS (default: bf16, and fp16 from 6 sweeps on)
+#ifndef VPTQ_K256M_SB_ALL
+#define VPTQ_K256M_SB_ALL 0
+#endif
 constexpr int kMXBytes1 = VPTQ_K256M_XDUP ? 4 : 2;  // staged bytes per column, one token
 
 // Timing-only ablations (tools/gpu_ablate.sh; the RESULTS of such a build are wrong): bit 0 no
@@ -169,7 +173,7 @@ static __device__ __forceinline__ void gemv_k256m_body(const K256Layer& Ly, cons
   static_assert(TOK == 1 || (STAGE && FAST), "several tokens: folded form, staged activations");
   // bf16 exact form: scale and bias are staged in LDS beside the activations (6 bytes per column) instead of riding in the queue -
   // its matrix-pipe roundings (sweep()) need the registers
-  constexpr bool kSB = !FAST && std::is_same<DT, BF16>::value;
+  constexpr bool kSB = !FAST && (std::is_same<DT, BF16>::value || NS > 5 || VPTQ_K256M_SB_ALL);   // (fp16, 6 and 7 sweeps: the queued form spills)
   constexpr int NQ = ((FAST && STAGE) || kSB) ? 1 : NS;  // queue slots for scale + (exact: bias | unstaged: x)
 
   const int bid = blockIdx.x;
@@ -1084,7 +1088,7 @@ static int lds_fixed_bytes(int staged_cols, int tok, bool sb) {
 
 template <typename DT, int NS, int NST, bool PERM, bool FAST, int TOK>
 static hipError_t launch_m(const K256Params& P, int gx, int max_cols, hipStream_t st) {
-  const int fixed = lds_fixed_bytes(NST > 0 ? max_cols : 0, TOK, !FAST && std::is_same<DT, BF16>::value);
+  const int fixed = lds_fixed_bytes(NST > 0 ? max_cols : 0, TOK, !FAST && (std::is_same<DT, BF16>::value || NS > 5 || VPTQ_K256M_SB_ALL));
   const int slots = P.layer[0].slots & 0xff;  // set by launch_gemv_k256m (bit 8: selective roundings)
   if (slots < 1 || slots > kMMaxSlots) return hipErrorInvalidValue;
   const int lds = fixed + slots * kMRedSlot * TOK;
@@ -1183,15 +1187,18 @@ hipError_t k256m_f16_fast(const K256Params& P, int gx, bool perm, int max_cols, 
   return launch_m_shape<F16, true, 1>(P, gx, perm, max_cols, st);
 }
 
+// exact form with scale and bias staged in LDS (kSB in the kernel): bf16, and fp16 from 6 sweeps on
+static bool sb_staged(bool f16, bool fast, int max_cols) {
+  return !fast && (!f16 || max_cols > 5 * kMSweepCols || VPTQ_K256M_SB_ALL);
+}
 // tok = token slots of the instantiation (1, 2 or 4)
 bool gemv_k256m_supported(int tok, bool f16, bool fast, int max_cols, bool perm) {
-  // the fp16 exact form queues scale and bias with the index words: 6 and 7 sweeps spill (bf16: staged in LDS, see kSB)
-  if (!fast && f16 && max_cols > 5 * kMSweepCols) return false;
+  // (the fp16 exact form queues scale and bias with the index words up to 5 sweeps; 6 and 7 sweeps - and bf16 - stage them in LDS: kSB)
   // more columns than fit beside the image: unstaged variant (folded form, no permutation)
   if (max_cols > kMMaxCols && (!fast || perm || tok > 1)) return false;
   // several tokens: folded form, one staged copy of the activations per token slot
   if (tok != 1 && !((tok == 2 || tok == 4) && fast)) return false;
-  if (lds_slots(tok, max_cols, !f16 && !fast) < 1) return false;
+  if (lds_slots(tok, max_cols, sb_staged(f16, fast, max_cols)) < 1) return false;
   // bf16: the folded form; the reference's roundings on the matrix pipe (round 6), one token
   return f16 || fast || tok == 1;
 }
@@ -1243,7 +1250,7 @@ hipError_t launch_gemv_k256m(K256Params& P, int tok, bool f16, bool fast, int ma
     if (share < 1) share = 1;
     if (share > groups) share = groups;
     P.layer[i].wgs = (int)share;
-    P.layer[i].slots = lds_slots(tok, max_cols, !f16 && !fast) | (selective ? kMSelBit : 0);
+    P.layer[i].slots = lds_slots(tok, max_cols, sb_staged(f16, fast, max_cols)) | (selective ? kMSelBit : 0);
     gx = (int)share > gx ? (int)share : gx;
   }
   if (tok != 1)
