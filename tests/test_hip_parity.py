@@ -288,6 +288,7 @@ def test_mfma_kernel_is_deterministic(I, O, dev):
     (8192 + 512, 264, dict(dist="llm")),
     (4104, 72, dict(enable_perm=True)),
     (14336, 256, dict(dist="llm")),                   # 7 sweeps: scale and bias still fit beside the activations
+    (2048, 4608, dict(dist="llm")),                   # 144 row groups
     (16384, 64, dict(dist="llm")),                    # wider than the LDS can stage
 ])
 def test_mfma_kernel_bf16(I, O, kw, dev):

@@ -490,7 +490,10 @@ static K256Choice choose_kernel(const VptqLayerDesc* descs, int n, int tokens, i
       gemv_k256m_supported(tok, f16, !exact, max_cols, perm)) {
     // fp16: from 144 row groups on (where the VALU kernel needs a second round of workgroups;
     // below, its shorter prologue wins - 4096^2, 2 tokens: 6.0 vs 6.9 us).  bf16: the VALU
-    // kernel runs widened arithmetic, the MFMA kernel's folded form is dtype agnostic.
+    // kernel runs widened arithmetic, the MFMA kernel's folded form is dtype agnostic and its exact form rounds on the matrix
+    // pipe: from 32 row groups on.  (Round 6 tried 144 for the exact form - on ONE layer replayed from L2 the VALU kernel's
+    // smaller row tiles win below that, 4096^2 7.1 vs 7.9 us, 8192 -> 1024 7.0 vs 10.9 - but over HBM-cold weights it is a tie
+    // at 4096^2 and the 8B-shaped decode loses 95 us per token: 1806 vs 1711.)
     const long long threshold = f16 ? 144 : 32;
     if (forced == 2 || (flags & VPTQ_GEMV_FORCE_MFMA) || row_groups >= threshold)
       c = {true, !exact, false};
