@@ -4,6 +4,7 @@ replayed interleaved on the same box: us per layer for
   single : one vptq_quant_gemv launch per layer (the library's default kernel)
   t1     : one launch of the chain kernel (gemv_k256c) per layer
   chainN : the ring as launches of N layers each (independent layers)
+  groupN : the ring as vptq_quant_gemv_grouped launches of N layers each (the sibling-group route of the module)
   dep    : the ring as ONE dependent chain (x of layer i + 1 is y of layer i)
   a trailing x (singlex, chain32x): the reference's roundings (VPTQ_GEMV_EXACT); chain32s: VPTQ_GEMV_SELECTIVE
 --soak S: every mode additionally replayed back to back for S seconds with package power / shader clock sampled
@@ -54,6 +55,21 @@ def main():
             d = m._descriptor()
             B.check(d[4](d[1], x.data_ptr(), y.data_ptr(), 1, fl, None, 0, B.current_stream_ptr(dev)), "gemv")
 
+    groups = {}
+
+    def run_group(n, fl=0):
+        # launches of n layers through vptq_quant_gemv_grouped (what SiblingGroup issues for q/k/v and gate/up)
+        import ctypes as C
+        if n not in groups:
+            gl = []
+            for i in range(0, R, n):
+                ds = [m._descriptor()[1] for m in ring[i:i + n]]
+                k = len(ds)
+                gl.append((k, (B.LayerDesc * k)(*ds), (C.c_void_p * k)(*[x.data_ptr()] * k), (C.c_void_p * k)(*[y.data_ptr() for y in ys[i:i + k]])))
+            groups[n] = gl
+        for k, arr, xp, yp in groups[n]:
+            B.check(B.lib().vptq_quant_gemv_grouped(arr, k, xp, yp, 1, fl, B.current_stream_ptr(dev)), "grouped")
+
     chains = {}
 
     def run_chain(n, dependent=False, fl=0):
@@ -78,6 +94,8 @@ def main():
             modes[name] = (lambda fl: (lambda: run_single(fl)))(fl)
         elif name == "t1":
             modes[name] = lambda: run_chain(1)
+        elif base.startswith("group"):
+            modes[name] = (lambda n, fl: (lambda: run_group(n, fl)))(int(base[5:]), fl)
         elif base.startswith("chain"):
             n = int(base[5:])
             modes[name] = (lambda n, fl: (lambda: run_chain(n, False, fl)))(n, fl)

@@ -516,8 +516,56 @@ const char* gemv_k256_group_name(const VptqLayerDesc* descs, int n, int tokens, 
   return choice_name(choose_kernel(descs, n, tokens, flags));
 }
 
+// A grouped launch of the persistent kernel lasts as long as its slowest workgroup: max over the layers of (row groups per
+// workgroup) row-group times + one prologue.  Three equal 8192^2 layers on 256 CUs are 768 row groups on 3 x 85 workgroups - four
+// per workgroup where three would do - and came out SLOWER than three launches (10.7 vs 9.5 us per layer, round 6,
+// profiles/r06/chain_vs_group.txt).  For 2 - 4 layers every split into launches is priced - sum over the launches of (units + rho),
+// rho = the fixed cost of a launch in row-group times (2.8 us against 0.76 / 0.48 / 1.09 ns per column of a row group: fp16
+// reference roundings / folded / bf16 reference roundings; calibrated on 8192^2 single and grouped launches) - and the cheapest is
+// issued.  part[i] = launch of layer i, numbered from 0 in order of first appearance.
+static int best_split(const VptqLayerDesc* descs, int n, K256Choice c, int* part) {
+  for (int i = 0; i < n; ++i) part[i] = 0;
+  if (!c.mfma || n < 2 || n > 4) return 1;
+  const bool f16 = descs[0].dtype == VPTQ_DTYPE_F16;
+  const double ns_per_col = c.fast ? 0.48 : f16 ? 0.76 : 1.09;
+  const double rho = 2800.0 / (ns_per_col * descs[0].group_size);
+  int rows[4];
+  for (int i = 0; i < n; ++i) rows[i] = descs[i].num_indices;
+  double best = 1e30;
+  int best_parts = 1, cur[4] = {0, 0, 0, 0};
+  // restricted growth strings: cur[0] = 0, cur[i] <= max(cur[0..i-1]) + 1
+  for (;;) {
+    int parts = 0;
+    for (int i = 0; i < n; ++i) parts = cur[i] + 1 > parts ? cur[i] + 1 : parts;
+    double cost = 0;
+    for (int q = 0; q < parts; ++q) {
+      int r[4], m = 0;
+      for (int i = 0; i < n; ++i) if (cur[i] == q) r[m++] = rows[i];
+      cost += gemv_k256m_launch_units(r, m) + rho;
+    }
+    if (cost < best - 1e-9) { best = cost; best_parts = parts; for (int i = 0; i < n; ++i) part[i] = cur[i]; }
+    int i = n - 1;
+    for (; i > 0; --i) {
+      int mx = 0;
+      for (int j = 0; j < i; ++j) mx = cur[j] > mx ? cur[j] : mx;
+      if (cur[i] <= mx) { ++cur[i]; break; }
+      cur[i] = 0;
+    }
+    if (i == 0) break;
+  }
+  return best_parts;
+}
+
+static hipError_t launch_gemv_k256_one(const VptqLayerDesc* descs, int n, const void* const* x, void* const* y, int tokens, int flags,
+                                       hipStream_t st, bool may_split);
+
 hipError_t launch_gemv_k256(const VptqLayerDesc* descs, int n, const void* const* x,
                             void* const* y, int tokens, int flags, hipStream_t st) {
+  return launch_gemv_k256_one(descs, n, x, y, tokens, flags, st, true);
+}
+
+static hipError_t launch_gemv_k256_one(const VptqLayerDesc* descs, int n, const void* const* x, void* const* y, int tokens, int flags,
+                                       hipStream_t st, bool may_split) {
   if (n < 1 || n > kMaxGroup) return hipErrorInvalidValue;
   K256Params P;
   P.n_layers = n;
@@ -528,6 +576,24 @@ hipError_t launch_gemv_k256(const VptqLayerDesc* descs, int n, const void* const
   const bool f16 = descs[0].dtype == VPTQ_DTYPE_F16;
   const K256Choice choice = choose_kernel(descs, n, tokens, flags);
   const bool mfma = choice.mfma, fast = choice.fast;
+  if (may_split && tokens == 1) {
+    int part[4];
+    const int parts = best_split(descs, n, choice, part);
+    if (parts > 1) {
+      // the same kernel and arithmetic as the group would have run (a part alone might fall under the row-group threshold)
+      const int sub_flags = flags | VPTQ_GEMV_FORCE_MFMA;
+      for (int q = 0; q < parts; ++q) {
+        VptqLayerDesc d[4];
+        const void* xs[4];
+        void* ys[4];
+        int m = 0;
+        for (int i = 0; i < n; ++i)
+          if (part[i] == q) { d[m] = descs[i]; xs[m] = x[i]; ys[m] = y[i]; ++m; }
+        if (hipError_t e = launch_gemv_k256_one(d, m, xs, ys, tokens, sub_flags, st, false); e != hipSuccess) return e;
+      }
+      return hipSuccess;
+    }
+  }
   int maxG = 0;
   bool perm = false;
   for (int i = 0; i < n; ++i) {

@@ -1208,12 +1208,32 @@ int gemv_k256m_row_groups(int n_rows) { return (n_rows + kMRows - 1) / kMRows; }
 // All layers of a grouped launch must have the same number of columns (checked by the
 // caller, launch_gemv_k256).  Fills in K256Layer::wgs: one workgroup per CU, shared out
 // between the layers in proportion to their row groups.
-// how many row groups a workgroup of layer `n_rows` walks at most when the launch has `total` row groups on `cus` CUs
-static int m_groups_per_wg(int groups, long long total, int cus) {
-  long long share = total > cus ? ((long long)groups * cus + total - 1) / total : groups;
-  if (share < 1) share = 1;
-  if (share > groups) share = groups;
-  return (int)((groups + share - 1) / share);
+// Workgroups per layer of one launch: one workgroup per CU (the LDS holds one), shared out in proportion to the layers' row
+// groups - and never more than `cus` in total: rounding every share up gave 3 x 86 = 258 workgroups for three equal layers
+// (q / k / v of an MHA model), two of which waited for a CU to come free (round 6).  While the sum is too large, the layer that
+// loses least - whose row groups per workgroup stay the lowest after giving one up - gives one up.
+static void m_shares(const int* groups, int n, int cus, int* share) {
+  long long total = 0;
+  for (int i = 0; i < n; ++i) total += groups[i];
+  long long sum = 0;
+  for (int i = 0; i < n; ++i) {
+    long long sh = total > cus ? ((long long)groups[i] * cus + total - 1) / total : groups[i];
+    if (sh < 1) sh = 1;
+    if (sh > groups[i]) sh = groups[i];
+    share[i] = (int)sh;
+    sum += sh;
+  }
+  while (sum > cus) {
+    int best = -1, best_units = 0;
+    for (int i = 0; i < n; ++i) {
+      if (share[i] <= 1) continue;
+      const int units = (groups[i] + share[i] - 2) / (share[i] - 1);   // row groups per workgroup with one workgroup less
+      if (best < 0 || units < best_units || (units == best_units && share[i] > share[best])) { best = i; best_units = units; }
+    }
+    if (best < 0) break;   // (more layers than CUs: cannot happen with kMaxGroup layers)
+    --share[best];
+    --sum;
+  }
 }
 static int m_cus() {
   static std::atomic<int> forced_wgs{-1};  // VPTQ_K256M_WGS: tuning override of the CU count
@@ -1221,15 +1241,27 @@ static int m_cus() {
   const int fw = forced_wgs.load();
   return fw > 0 ? fw : device_cus();
 }
+int gemv_k256m_launch_units(const int* n_rows, int n) {
+  if (n < 1 || n > kMaxGroup) return 0;
+  int groups[kMaxGroup], share[kMaxGroup], units = 0;
+  for (int i = 0; i < n; ++i) groups[i] = gemv_k256m_row_groups(n_rows[i]);
+  m_shares(groups, n, m_cus(), share);
+  for (int i = 0; i < n; ++i) {
+    const int u = (groups[i] + share[i] - 1) / share[i];
+    units = u > units ? u : units;
+  }
+  return units;
+}
 // VPTQ_GEMV_SELECTIVE in this kernel: one token, fp16, staged activations, the folded instantiation; every workgroup's row groups
 // must fit the corrections' LDS (kMSelRowGroups)
 bool gemv_k256m_selective_ok(const int* n_rows, int n, bool f16, int tok, int max_cols, bool perm) {
   if (tok != 1 || max_cols > kMMaxCols || max_cols > kMSelMaxBlocks * 128 || !gemv_k256m_supported(1, f16, true, max_cols, perm)) return false;
-  long long total = 0;
-  for (int i = 0; i < n; ++i) total += gemv_k256m_row_groups(n_rows[i]);
-  const int cus = m_cus();
+  if (n > kMaxGroup) return false;
+  int groups[kMaxGroup], share[kMaxGroup];
+  for (int i = 0; i < n; ++i) groups[i] = gemv_k256m_row_groups(n_rows[i]);
+  m_shares(groups, n, m_cus(), share);
   for (int i = 0; i < n; ++i)
-    if (m_groups_per_wg(gemv_k256m_row_groups(n_rows[i]), total, cus) > kMSelRowGroups) return false;
+    if ((groups[i] + share[i] - 1) / share[i] > kMSelRowGroups) return false;
   return true;
 }
 
@@ -1237,21 +1269,15 @@ hipError_t launch_gemv_k256m(K256Params& P, int tok, bool f16, bool fast, int ma
                              hipStream_t st, bool selective) {
   if (!gemv_k256m_supported(tok, f16, fast, max_cols, perm)) return hipErrorInvalidValue;
   if (selective && !(fast && tok == 1 && max_cols <= kMMaxCols)) return hipErrorInvalidValue;
-  static std::atomic<int> forced_wgs{-1};  // VPTQ_K256M_WGS: tuning override of the CU count
-  if (forced_wgs < 0) { const char* e = vptq::tune_env("VPTQ_K256M_WGS"); forced_wgs = e ? atoi(e) : 0; }
-  const int fw = forced_wgs.load();
-  const int cus = fw > 0 ? fw : device_cus();
-  long long total = 0;
-  for (int i = 0; i < P.n_layers; ++i) total += gemv_k256m_row_groups(P.layer[i].N);
+  if (P.n_layers > kMaxGroup) return hipErrorInvalidValue;
+  int groups[kMaxGroup], share[kMaxGroup];
+  for (int i = 0; i < P.n_layers; ++i) groups[i] = gemv_k256m_row_groups(P.layer[i].N);
+  m_shares(groups, P.n_layers, m_cus(), share);
   int gx = 0;
   for (int i = 0; i < P.n_layers; ++i) {
-    const int groups = gemv_k256m_row_groups(P.layer[i].N);
-    long long share = total > cus ? ((long long)groups * cus + total - 1) / total : groups;
-    if (share < 1) share = 1;
-    if (share > groups) share = groups;
-    P.layer[i].wgs = (int)share;
+    P.layer[i].wgs = share[i];
     P.layer[i].slots = lds_slots(tok, max_cols, sb_staged(f16, fast, max_cols)) | (selective ? kMSelBit : 0);
-    gx = (int)share > gx ? (int)share : gx;
+    gx = share[i] > gx ? share[i] : gx;
   }
   if (tok != 1)
     return f16 ? k256m_f16_tokens(P, tok, gx, perm, max_cols, st)

@@ -105,5 +105,7 @@ int gemv_k256m_row_groups(int n_rows);
 hipError_t launch_gemv_k256m(K256Params& P, int tok, bool f16, bool fast, int max_cols, bool perm,
                              hipStream_t st, bool selective = false);
 bool gemv_k256m_selective_ok(const int* n_rows, int n, bool f16, int tok, int max_cols, bool perm);
+// most row groups any workgroup of one launch of these layers walks (the launch's duration in units of one row group)
+int gemv_k256m_launch_units(const int* n_rows, int n);
 
 }  // namespace vptq
