@@ -308,7 +308,8 @@ def test_mfma_kernel_bf16(I, O, kw, dev):
     # the reference's roundings: on the matrix pipe (round 6) while scale and bias fit into LDS beside the activations
     exact_mfma = I <= 14336
     expect_kernel(m, 1, MFMA | EXACT, "gemv_k256m_kernel" if exact_mfma else "gemv_k256_kernel")
-    expect_kernel(m, 2, MFMA | EXACT, "gemv_k256_kernel")
+    expect_kernel(m, 2, MFMA | EXACT, "gemv_k256m_kernel" if exact_tokens_on_matrix_pipe(I, 2, "bf16") else "gemv_k256_kernel")
+    expect_kernel(m, 2, EXACT, "gemv_k256m_kernel" if exact_tokens_on_matrix_pipe(I, 2, "bf16") and (O + 31) // 32 >= 144 else "gemv_k256_kernel")
     expect_kernel(m, 1, EXACT, "gemv_k256m_kernel" if exact_mfma and (O + 31) // 32 >= 32 else "gemv_k256_kernel")
     expect_kernel(m, 1, VALU, "gemv_k256_kernel")
     expect_kernel(m, 1, 0, "gemv_k256m_kernel<fast>" if (O + 31) // 32 >= 32 else "gemv_k256_kernel")
@@ -342,6 +343,17 @@ MFMA_TOKEN_CASES = [
 ]
 
 
+def exact_tokens_on_matrix_pipe(I, tokens, dt):
+    """where the persistent kernel serves 2 - 4 tokens in the reference's roundings (round 6; gemv_k256m_supported): 2 token slots
+    at every width whose operands fit into LDS (activations per slot + scale + bias planes), 4 slots up to 2 (fp16) / 1 (bf16)
+    sweeps of 2048 columns (beyond: spills)"""
+    slots = 2 if tokens == 2 else 4
+    if slots == 4 and -(-I // 2048) > (2 if dt == "f16" else 1):
+        return False
+    lds = 65536 + (slots + 2) * (2 * I + 32) + slots * 64 + 64 + slots * 2048
+    return lds <= 160 * 1024
+
+
 @pytest.mark.parametrize("dt", ["f16", "bf16"])
 @pytest.mark.parametrize("I,O,kw,tokens", MFMA_TOKEN_CASES)
 def test_mfma_kernel_several_tokens(I, O, kw, tokens, dt, dev):
@@ -359,7 +371,17 @@ def test_mfma_kernel_several_tokens(I, O, kw, tokens, dt, dev):
     xt = bits_to_tensor(x, dt, dev).reshape(x.shape)
     want = vo.forward(L, x)
     expect_kernel(m, tokens, MFMA, "gemv_k256m_kernel<fast>")
-    expect_kernel(m, tokens, MFMA | EXACT, "gemv_k256_kernel")   # exact form: VALU kernel
+    # the reference's roundings: the one-token exact loop with a pair of MFMAs more per token, where it fits (round 6)
+    on_pipe = exact_tokens_on_matrix_pipe(I, tokens, dt)
+    expect_kernel(m, tokens, MFMA | EXACT, "gemv_k256m_kernel" if on_pipe else "gemv_k256_kernel")
+    ex = gemv_abi(m, xt, MFMA | EXACT)
+    assert rel_err(tensor_to_bits(ex), want, dt) <= (5e-4 if dt == "f16" else TOL[dt])
+    assert bit_identical_frac(tensor_to_bits(ex), want) >= 0.9
+    # same weights as the VALU kernel's exact form: fp32 outputs differ by the order of the fp32 sums only
+    ye, yv = gemv_abi(m, xt, MFMA | EXACT, out_f32=True).double(), gemv_abi(m, xt, VALU | EXACT, out_f32=True).double()
+    assert float((ye - yv).abs().max()) <= 2e-6 * float(yv.abs().max())
+    for _ in range(3):
+        assert torch.equal(gemv_abi(m, xt, MFMA | EXACT), ex)
     got_t = gemv_abi(m, xt, MFMA)
     got = tensor_to_bits(got_t)
     assert got.shape == want.shape
@@ -393,9 +415,10 @@ def test_mfma_kernel_is_the_default_for_large_launches(dev):
     m = spec_to_module(L, dev)
     expect_kernel(m, 1, 0, "gemv_k256m_kernel<fast>")
     expect_kernel(m, 1, EXACT, "gemv_k256m_kernel")
-    expect_kernel(m, 2, 0, "gemv_k256m_kernel<fast>")         # several tokens: folded form only
+    expect_kernel(m, 2, 0, "gemv_k256m_kernel<fast>")
     expect_kernel(m, 4, 0, "gemv_k256m_kernel<fast>")
-    expect_kernel(m, 4, EXACT, "gemv_k256_kernel")
+    expect_kernel(m, 2, EXACT, "gemv_k256m_kernel")            # several tokens in the reference's roundings (round 6)
+    expect_kernel(m, 4, EXACT, "gemv_k256m_kernel")            # (1 sweep: the 4-slot instantiation fits)
     small = spec_to_module(vo.make_layer(1024, 4096, dist="llm", seed=78), dev)
     expect_kernel(small, 1, 0, "gemv_k256_kernel<fast>")
     x = vo.from_f32(np.random.default_rng(3).standard_normal((1, 1, 1024)).astype(np.float32), "f16")

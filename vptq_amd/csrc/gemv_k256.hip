@@ -494,7 +494,9 @@ static K256Choice choose_kernel(const VptqLayerDesc* descs, int n, int tokens, i
     // pipe: from 32 row groups on.  (Round 6 tried 144 for the exact form - on ONE layer replayed from L2 the VALU kernel's
     // smaller row tiles win below that, 4096^2 7.1 vs 7.9 us, 8192 -> 1024 7.0 vs 10.9 - but over HBM-cold weights it is a tie
     // at 4096^2 and the 8B-shaped decode loses 95 us per token: 1806 vs 1711.)
-    const long long threshold = f16 ? 144 : 32;
+    // (several tokens in the reference's roundings, round 6: 144 for bf16 as well - 4096^2, 2 tokens: 9.1 us against the VALU
+    // kernel's 8.3; 8192 x 1024: 13.1 vs 8.1; from 144 row groups on the matrix pipe wins 10 - 50 %, tools/tokens_exact_check.py)
+    const long long threshold = f16 || (exact && tok > 1) ? 144 : 32;
     if (forced == 2 || (flags & VPTQ_GEMV_FORCE_MFMA) || row_groups >= threshold)
       c = {true, !exact, false};
   }

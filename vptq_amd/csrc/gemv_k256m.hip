@@ -170,10 +170,12 @@ static __device__ __forceinline__ void gemv_k256m_body(const K256Layer& Ly, cons
   // TOK = 2 / 4: up to TOK activation rows per launch (folded form, staged).  The MFMA is then a
   // real contraction - see sweep() - and costs the same for 2, 3 or 4 tokens.
   static_assert(TOK == 1 || TOK == 2 || TOK == 4, "token slots");
-  static_assert(TOK == 1 || (STAGE && FAST), "several tokens: folded form, staged activations");
+  static_assert(TOK == 1 || STAGE, "several tokens: staged activations");
   // bf16 exact form: scale and bias are staged in LDS beside the activations (6 bytes per column) instead of riding in the queue -
   // its matrix-pipe roundings (sweep()) need the registers
-  constexpr bool kSB = !FAST && (std::is_same<DT, BF16>::value || NS > 5 || VPTQ_K256M_SB_ALL);   // (fp16, 6 and 7 sweeps: the queued form spills)
+  // (fp16, 6 and 7 sweeps: the queued form spills; several tokens in the reference's roundings - round 6: the one-token loop with one
+  // pair of MFMAs more per token - always staged)
+  constexpr bool kSB = !FAST && (std::is_same<DT, BF16>::value || NS > 5 || TOK > 1 || VPTQ_K256M_SB_ALL);
   constexpr int NQ = ((FAST && STAGE) || kSB) ? 1 : NS;  // queue slots for scale + (exact: bias | unstaged: x)
 
   const int bid = blockIdx.x;
@@ -224,7 +226,7 @@ static __device__ __forceinline__ void gemv_k256m_body(const K256Layer& Ly, cons
   const u32x2 bf_id = u32x2{__builtin_amdgcn_perm(0x3f803f80u, 0u, selA[0]), __builtin_amdgcn_perm(0x3f803f80u, 0u, selB[0])};
   const uint32_t maskA = j == 0 ? 0x0000ffffu : j == 1 ? 0xffff0000u : 0u;
   const uint32_t maskB = j == 2 ? 0x0000ffffu : j == 3 ? 0xffff0000u : 0u;
-  const uint32_t sb_off = xs_off + xs_stride;   // (kSB) scale plane, then the bias plane: the activations' layout
+  const uint32_t sb_off = xs_off + (uint32_t)TOK * xs_stride;   // (kSB) scale plane, then the bias plane: the activations' layout
   const uint32_t red_off = xs_off + (STAGE ? TOK * xs_stride : 0u) + (kSB ? 2u * xs_stride : 0u);
   float* const red_b = (float*)(smem + red_off);        // [TOK][kMWaves]: sum b * x per wave
   uint32_t* const slot_cnt = (uint32_t*)(red_b + TOK * kMWaves);  // [kMMaxSlots] waves that have arrived
@@ -643,7 +645,8 @@ static __device__ __forceinline__ void gemv_k256m_body(const K256Layer& Ly, cons
 #define VPTQ_K256M_ADDFORM 0
 #endif
   constexpr bool kAcc4 = VPTQ_K256M_ACC4 && FAST && TOK == 1 && !VPTQ_K256M_ADDFORM;
-  constexpr int kNAcc = TOK == 1 ? (kAcc4 ? 4 : 2) : 8;
+  // (several tokens, reference roundings: a[2 t] / a[2 t + 1] = outputs 0-3 / 4-7 of token t, the one-token layout per token)
+  constexpr int kNAcc = TOK == 1 ? (kAcc4 ? 4 : 2) : (FAST ? 8 : 2 * TOK);
   struct Acc { f32x4 a[kNAcc]; };
   // Several tokens (TOK = 2 / 4): here the 4x4x4 MFMA is a real contraction.  Lane i of a block
   // supplies token i's f16(s * x) of TWO columns, twice (A row i = {x'[c0], x'[c1], x'[c0],
@@ -689,7 +692,7 @@ static __device__ __forceinline__ void gemv_k256m_body(const K256Layer& Ly, cons
                                 __builtin_amdgcn_perm(b1, b0, 0x05040100u)};
         const u32x2 whi = u32x2{__builtin_amdgcn_perm(a1, a0, 0x07060302u),
                                 __builtin_amdgcn_perm(b1, b0, 0x07060302u)};
-        constexpr int kE = TOK == 1 ? 0 : 2;  // (never run with one token)
+        constexpr int kE = (TOK == 1 || !FAST) ? 0 : 2;  // (never run with one token / in the reference's roundings)
         acc.a[kE * q] = DT::mfma4(xa, wlo, acc.a[kE * q]);
         acc.a[kE * q + kE / 2] = DT::mfma4(xa, whi, acc.a[kE * q + kE / 2]);
         // (fenced: the scheduler would transpose the whole pair first - 12 more live registers)
@@ -698,7 +701,7 @@ static __device__ __forceinline__ void gemv_k256m_body(const K256Layer& Ly, cons
     }
   };
   auto sweep = [&](auto first_c, int s, int cb, Acc& acc) {
-    if constexpr (TOK > 1) {
+    if constexpr (TOK > 1 && FAST) {
       sweep_tokens(s, acc);
       return;
     }
@@ -707,10 +710,26 @@ static __device__ __forceinline__ void gemv_k256m_body(const K256Layer& Ly, cons
     constexpr bool kBuild = !kCacheXo || decltype(first_c)::value;
     const int want = (cb * NS + s) * kMSweepCols + lane_cols;
     u32x4 xq = u32x4{0, 0, 0, 0}, xq2 = u32x4{0, 0, 0, 0};
+    [[maybe_unused]] u32x4 xqt[TOK > 1 ? TOK - 1 : 1];
+    // (reference roundings, several tokens) the weight operands of an index serve every token: one more pair of MFMAs + 2 v_perm_b32 each
+    auto more_tokens = [&](int q, int h, u32x2 wa, u32x2 wb) {
+      if constexpr (TOK > 1) {
+#pragma unroll
+        for (int t = 1; t < TOK; ++t) {
+          const u32x2 xt = u32x2{__builtin_amdgcn_perm(xqt[t - 1][q], 0u, selA[h]), __builtin_amdgcn_perm(xqt[t - 1][q], 0u, selB[h])};
+          acc.a[2 * t] = DT::mfma4(xt, wa, acc.a[2 * t]);
+          acc.a[2 * t + 1] = DT::mfma4(xt, wb, acc.a[2 * t + 1]);
+        }
+      }
+    };
     if (STAGE) {
       if (kBuild) {
         xq = lds_load16(xs_off + (uint32_t)(want < G ? want : G) * kXB);  // past G: zeros
         if (kXDup) xq2 = want < G ? lds_load16(xs_off + (uint32_t)want * 4u + 16u) : xq;
+      }
+      if constexpr (TOK > 1) {   // (reference roundings) the further tokens' activations of these 8 columns
+#pragma unroll
+        for (int t = 1; t < TOK; ++t) xqt[t - 1] = lds_load16(xs_off + (uint32_t)t * xs_stride + (uint32_t)(want < G ? want : G) * kXB);
       }
     } else {
       const uint32_t keep = want < G ? 0xffffffffu : 0u;  // columns past G contribute 0
@@ -837,6 +856,7 @@ static __device__ __forceinline__ void gemv_k256m_body(const K256Layer& Ly, cons
           wb = u32x2{DT::pack(d1[0], d1[1]), DT::pack(d1[2], d1[3])};
           acc0 = DT::mfma4(xo, wa, acc0);
           acc1 = DT::mfma4(xo, wb, acc1);
+          more_tokens(q, h, wa, wb);
           continue;
         }
         uint32_t w2[4];
@@ -848,6 +868,7 @@ static __device__ __forceinline__ void gemv_k256m_body(const K256Layer& Ly, cons
         for (int p = 0; p < 4; ++p) w2[p] = DT::add2_bcast(w2[p], bv[q], h);
         acc0 = DT::mfma4(xo, u32x2{w2[0], w2[1]}, acc0);
         acc1 = DT::mfma4(xo, u32x2{w2[2], w2[3]}, acc1);
+        more_tokens(q, h, u32x2{w2[0], w2[1]}, u32x2{w2[2], w2[3]});
       }
     }
   };
@@ -875,7 +896,7 @@ static __device__ __forceinline__ void gemv_k256m_body(const K256Layer& Ly, cons
 #pragma unroll
       for (int e = 0; e < 8; ++e)
 #pragma unroll
-        for (int t = 0; t < TOK; ++t) v[e * TOK + t] = acc.a[e][t];
+        for (int t = 0; t < TOK; ++t) v[e * TOK + t] = FAST ? acc.a[FAST ? e : 0][t] : acc.a[FAST ? 0 : 2 * t + (e >> 2)][e & 3];
     }
 #pragma unroll
     for (int i = 0; i < NV / 2; ++i) {
@@ -1088,7 +1109,7 @@ static int lds_fixed_bytes(int staged_cols, int tok, bool sb) {
 
 template <typename DT, int NS, int NST, bool PERM, bool FAST, int TOK>
 static hipError_t launch_m(const K256Params& P, int gx, int max_cols, hipStream_t st) {
-  const int fixed = lds_fixed_bytes(NST > 0 ? max_cols : 0, TOK, !FAST && (std::is_same<DT, BF16>::value || NS > 5 || VPTQ_K256M_SB_ALL));
+  const int fixed = lds_fixed_bytes(NST > 0 ? max_cols : 0, TOK, !FAST && (std::is_same<DT, BF16>::value || NS > 5 || TOK > 1 || VPTQ_K256M_SB_ALL));
   const int slots = P.layer[0].slots & 0xff;  // set by launch_gemv_k256m (bit 8: selective roundings)
   if (slots < 1 || slots > kMMaxSlots) return hipErrorInvalidValue;
   const int lds = fixed + slots * kMRedSlot * TOK;
@@ -1158,6 +1179,8 @@ hipError_t k256m_bf16(const K256Params& P, int gx, bool perm, int max_cols, hipS
 hipError_t k256m_f16_tokens(const K256Params& P, int tok, int gx, bool perm, int max_cols, hipStream_t st);
 hipError_t k256m_bf16_tokens(const K256Params& P, int tok, int gx, bool perm, int max_cols, hipStream_t st);
 hipError_t k256m_bf16_exact(const K256Params& P, int gx, bool perm, int max_cols, hipStream_t st);
+hipError_t k256m_f16_tokens_exact(const K256Params& P, int tok, int gx, bool perm, int max_cols, hipStream_t st);
+hipError_t k256m_bf16_tokens_exact(const K256Params& P, int tok, int gx, bool perm, int max_cols, hipStream_t st);
 
 #if K256M_PART(2)
 hipError_t k256m_f16_exact(const K256Params& P, int gx, bool perm, int max_cols, hipStream_t st) {
@@ -1182,25 +1205,40 @@ hipError_t k256m_bf16_exact(const K256Params& P, int gx, bool perm, int max_cols
   return launch_m_shape<BF16, false, 1>(P, gx, perm, max_cols, st);
 }
 #endif
+#if K256M_PART(5)
+hipError_t k256m_f16_tokens_exact(const K256Params& P, int tok, int gx, bool perm, int max_cols, hipStream_t st) {
+  return tok == 2 ? launch_m_shape<F16, false, 2>(P, gx, perm, max_cols, st)
+                  : launch_m_shape<F16, false, 4>(P, gx, perm, max_cols, st);
+}
+#endif
+#if K256M_PART(6)
+hipError_t k256m_bf16_tokens_exact(const K256Params& P, int tok, int gx, bool perm, int max_cols, hipStream_t st) {
+  return tok == 2 ? launch_m_shape<BF16, false, 2>(P, gx, perm, max_cols, st)
+                  : launch_m_shape<BF16, false, 4>(P, gx, perm, max_cols, st);
+}
+#endif
 #if K256M_PART(1)
 hipError_t k256m_f16_fast(const K256Params& P, int gx, bool perm, int max_cols, hipStream_t st) {
   return launch_m_shape<F16, true, 1>(P, gx, perm, max_cols, st);
 }
 
 // exact form with scale and bias staged in LDS (kSB in the kernel): bf16, and fp16 from 6 sweeps on
-static bool sb_staged(bool f16, bool fast, int max_cols) {
-  return !fast && (!f16 || max_cols > 5 * kMSweepCols || VPTQ_K256M_SB_ALL);
+static bool sb_staged(bool f16, bool fast, int max_cols, int tok) {
+  return !fast && (!f16 || max_cols > 5 * kMSweepCols || tok > 1 || VPTQ_K256M_SB_ALL);
 }
 // tok = token slots of the instantiation (1, 2 or 4)
 bool gemv_k256m_supported(int tok, bool f16, bool fast, int max_cols, bool perm) {
   // (the fp16 exact form queues scale and bias with the index words up to 5 sweeps; 6 and 7 sweeps - and bf16 - stage them in LDS: kSB)
   // more columns than fit beside the image: unstaged variant (folded form, no permutation)
   if (max_cols > kMMaxCols && (!fast || perm || tok > 1)) return false;
-  // several tokens: folded form, one staged copy of the activations per token slot
-  if (tok != 1 && !((tok == 2 || tok == 4) && fast)) return false;
-  if (lds_slots(tok, max_cols, sb_staged(f16, fast, max_cols)) < 1) return false;
-  // bf16: the folded form; the reference's roundings on the matrix pipe (round 6), one token
-  return f16 || fast || tok == 1;
+  // several tokens: one staged copy of the activations per token slot (the reference's roundings: scale and bias staged as well)
+  if (tok != 1 && !(tok == 2 || tok == 4)) return false;
+  // ... in the reference's roundings (round 6): the 4-slot instantiations keep 32 accumulator registers and spill from 3 (fp16) /
+  // 2 (bf16) sweeps on; two passes of the 2-slot kernel lose against the VALU kernel (tools/tokens_exact_check.py: 4096 x 14336
+  // bf16 30.2 vs 26.7 us, 4096^2 17.8 vs 10.0)
+  if (tok == 4 && !fast && max_cols > (f16 ? 2 : 1) * kMSweepCols) return false;
+  if (lds_slots(tok, max_cols, sb_staged(f16, fast, max_cols, tok)) < 1) return false;
+  return true;
 }
 
 int gemv_k256m_row_groups(int n_rows) { return (n_rows + kMRows - 1) / kMRows; }
@@ -1276,12 +1314,14 @@ hipError_t launch_gemv_k256m(K256Params& P, int tok, bool f16, bool fast, int ma
   int gx = 0;
   for (int i = 0; i < P.n_layers; ++i) {
     P.layer[i].wgs = share[i];
-    P.layer[i].slots = lds_slots(tok, max_cols, sb_staged(f16, fast, max_cols)) | (selective ? kMSelBit : 0);
+    P.layer[i].slots = lds_slots(tok, max_cols, sb_staged(f16, fast, max_cols, tok)) | (selective ? kMSelBit : 0);
     gx = share[i] > gx ? share[i] : gx;
   }
-  if (tok != 1)
+  if (tok != 1) {
+    if (!fast) return f16 ? k256m_f16_tokens_exact(P, tok, gx, perm, max_cols, st) : k256m_bf16_tokens_exact(P, tok, gx, perm, max_cols, st);
     return f16 ? k256m_f16_tokens(P, tok, gx, perm, max_cols, st)
                : k256m_bf16_tokens(P, tok, gx, perm, max_cols, st);
+  }
   if (!f16) return fast ? k256m_bf16(P, gx, perm, max_cols, st) : k256m_bf16_exact(P, gx, perm, max_cols, st);
   return fast ? k256m_f16_fast(P, gx, perm, max_cols, st) : k256m_f16_exact(P, gx, perm, max_cols, st);
 }
