@@ -119,7 +119,18 @@ def test_kernel_choice_without_gpu():
         assert name(big, tok) == b"gemv_k256m_kernel<fast>"
         assert name(small, tok) == (b"gemv_k256_kernel<fast>" if tok <= 2 else b"gemv_k256_kernel")
     assert name(big, 1, B.GEMV_EXACT) == b"gemv_k256m_kernel"
-    assert name(big, 2, B.GEMV_EXACT) == b"gemv_k256_kernel"        # several tokens: exact on the VALU
+    # several tokens in the reference's roundings (round 6): 2 token slots where they fit into LDS, 4 slots up to 2 (fp16) /
+    # 1 (bf16) sweeps of 2048 columns, from 144 row groups on - else the VALU kernel
+    assert name(big, 2, B.GEMV_EXACT) == b"gemv_k256m_kernel"
+    assert name(big, 3, B.GEMV_EXACT) == name(big, 4, B.GEMV_EXACT) == b"gemv_k256_kernel"     # 4 sweeps: 4 slots would spill
+    assert name(small, 2, B.GEMV_EXACT) == b"gemv_k256_kernel"                                # 128 row groups
+    tall, btall = _canonical_desc(4096, 14336), _canonical_desc(2048, 8192, dtype=1)
+    assert name(tall, 2, B.GEMV_EXACT) == name(tall, 4, B.GEMV_EXACT) == b"gemv_k256m_kernel"  # 2 sweeps, fp16
+    assert name(btall, 2, B.GEMV_EXACT) == name(btall, 3, B.GEMV_EXACT) == b"gemv_k256m_kernel"  # 1 sweep, bf16
+    assert name(bbig, 2, B.GEMV_EXACT) == b"gemv_k256m_kernel" and name(bbig, 4, B.GEMV_EXACT) == b"gemv_k256_kernel"
+    assert name(_canonical_desc(4096, 4096, dtype=1), 2, B.GEMV_EXACT) == b"gemv_k256_kernel"  # bf16 too: 144 row groups for several tokens
+    assert name(_canonical_desc(4096, 4096, dtype=1), 1, B.GEMV_EXACT) == b"gemv_k256m_kernel"  # (one token: from 32 on, matrix-pipe roundings)
+    assert name(_canonical_desc(14336, 8192), 1, B.GEMV_EXACT) == b"gemv_k256m_kernel"         # 7 sweeps: scale and bias staged in LDS
     assert name(big, 1, B.GEMV_FORCE_VALU) == b"gemv_k256_kernel<fast>"
     assert name(small, 1, B.GEMV_FORCE_MFMA) == b"gemv_k256m_kernel<fast>"
     assert name(big, 1, B.GEMV_FORCE_GENERIC) == b"gemv_generic_kernel"
