@@ -566,6 +566,47 @@ def test_grouped_launch_mixed_shapes_and_tokens(dev):
         assert rel_err(tensor_to_bits(y), w, "f16") <= 1e-3
 
 
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("shapes,tokens", [
+    ([(2048, 4096), (2048, 1024), (2048, 1024)], 2),      # 192 row groups, one sweep: 2 token slots on the matrix pipe
+    ([(2048, 4096), (2048, 1024)], 4),                    # 4 slots (one sweep)
+    ([(2048, 8192), (2048, 8192), (2048, 8192)], 1),      # three equal layers of 256 row groups: issued as {A, B} + {C}
+    ([(1024, 8192), (1024, 8192), (1024, 2048), (1024, 2048)], 1),
+])
+def test_grouped_launch_reference_roundings(shapes, tokens, dt, dev):
+    """vptq_quant_gemv_grouped with VPTQ_GEMV_EXACT over sibling-shaped groups (round 6: several tokens in the reference's roundings
+    on the matrix pipe, groups split into the cheapest set of launches): every layer against the oracle and bit for bit against
+    its own single launch of the same kernel family."""
+    from vptq_amd import _backend as B
+    from _gpu_util import module_desc
+    import ctypes as C
+    n = len(shapes)
+    I = shapes[0][0]
+    xb = vo.from_f32(np.random.default_rng(n + tokens).standard_normal((1, tokens, I)).astype(np.float32), dt)
+    x = bits_to_tensor(xb, dt, dev).reshape(1, tokens, I)
+    mods, want = [], []
+    for i, (_, O) in enumerate(shapes):
+        L = vo.make_layer(I, O, dist="llm", seed=90 + i, dtype=dt, bias=(i == 1))
+        mods.append(spec_to_module(L, dev))
+        want.append(vo.forward(L, xb))
+    descs = (B.LayerDesc * n)()
+    keep = []
+    for i, m in enumerate(mods):
+        d, k = module_desc(m)
+        descs[i] = d
+        keep.append(k)
+    assert B.lib().vptq_quant_gemv_grouped_kernel_name(descs, n, tokens, EXACT) == b"gemv_k256m_kernel"
+    ys = [torch.empty(1, tokens, O, device=dev, dtype=x.dtype) for _, O in shapes]
+    xp = (C.c_void_p * n)(*[x.data_ptr()] * n)
+    yp = (C.c_void_p * n)(*[t.data_ptr() for t in ys])
+    B.check(B.lib().vptq_quant_gemv_grouped(descs, n, xp, yp, tokens, EXACT, B.current_stream_ptr(dev)), "grouped")
+    torch.cuda.synchronize()
+    for m, y, w in zip(mods, ys, want):
+        assert rel_err(tensor_to_bits(y), w, dt) <= (5e-4 if dt == "f16" else TOL[dt])
+        assert bit_identical_frac(tensor_to_bits(y), w) >= 0.9
+        assert torch.equal(y, gemv_abi(m, x, EXACT | MFMA))   # the same loop, whatever the launch's share of the CUs
+
+
 def test_read_ahead_hint_does_not_change_results(dev):
     """chain_prefetch is a pure performance hint (also with a range smaller / larger than
     the layer's own index tensor and with perm)."""
