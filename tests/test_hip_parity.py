@@ -856,13 +856,12 @@ def test_many_token_routes_vs_reference_goldens(name, dev):
     routes = {"module": lambda: m(xt), "dense_cached": lambda: m._dense_cached(xt),
               "gemm_fused": lambda: ops.quant_gemm_fused(xt, m._descriptor()[1], L.out_features)}
     if T <= 64:
-        # the batched-decode kernels (launches of 16 tokens): the one-pass kernel (default from 5 tokens, both dtypes) and,
-        # fp16, the kernel with the reference's roundings
+        # the batched-decode kernels (launches of 16 tokens): the one-pass kernel (default from 5 tokens, both dtypes) and
+        # the kernel with the reference's roundings
         assert kernel_name(m, T) == "gemm_k256t_kernel"
         routes["gemm_k256t"] = lambda: gemv_abi(m, xt, 0)
-        if dt == "f16":
-            assert kernel_name(m, T, EXACT) == "gemm_k256_kernel"
-            routes["gemm_k256"] = lambda: gemv_abi(m, xt, EXACT)
+        assert kernel_name(m, T, EXACT) == "gemm_k256_kernel"      # (bf16 since round 6)
+        routes["gemm_k256"] = lambda: gemv_abi(m, xt, EXACT)
     errs = {}
     for rname, fn in routes.items():
         out = stored_rows(tensor_to_bits(fn()).reshape(1, T, -1), cfg)
@@ -1365,41 +1364,44 @@ GEMM_CASES = [
 ]
 
 
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
 @pytest.mark.parametrize("I,O,kw,tokens", GEMM_CASES)
-def test_batched_decode_kernel_vs_oracle(I, O, kw, tokens, dev):
-    """gemm_k256_kernel (canonical format, fp16, 5-16 tokens in one launch, VPTQ_GEMV_EXACT: since round 3 the default
+def test_batched_decode_kernel_vs_oracle(I, O, kw, tokens, dt, dev):
+    """gemm_k256_kernel (canonical format, 5-16 tokens in one launch, VPTQ_GEMV_EXACT: since round 3 the default
     for these token counts is the one-pass gemm_k256t, tests/test_gemm_k256t_gpu.py): dequantised tiles with
-    the reference's roundings -> LDS -> v_mfma_f32_16x16x16_f16, i.e. the arithmetic of the
-    reference's own path for these token counts, dequant + F.linear (quant_gemm.py:231-274)."""
+    the reference's roundings -> LDS -> v_mfma_f32_16x16x16_f16 / _bf16, i.e. the arithmetic of the
+    reference's own path for these token counts, dequant + F.linear (quant_gemm.py:231-274).  bf16 since round 6 (its
+    roundings as blocks of v_dot2_f32_bf16)."""
     kw = dict(kw)
     dist = kw.pop("dist", "ref-test")
-    L = vo.make_layer(I, O, dist=dist, seed=I + O + tokens, **kw)
+    L = vo.make_layer(I, O, dist=dist, seed=I + O + tokens, dtype=dt, **kw)
     rng = np.random.default_rng(tokens)
     xs = (0.02 + 0.5 * rng.standard_normal((1, tokens, I))) if dist == "ref-test" \
         else rng.standard_normal((1, tokens, I))
-    x = vo.from_f32(xs.astype(np.float32), "f16")
+    x = vo.from_f32(xs.astype(np.float32), dt)
     m = spec_to_module(L, dev)
+    tdt = torch.float16 if dt == "f16" else torch.bfloat16
     assert kernel_name(m, tokens, EXACT) == "gemm_k256_kernel" and kernel_name(m, tokens) == "gemm_k256t_kernel"
-    xt = bits_to_tensor(x, "f16", dev).reshape(x.shape)
+    xt = bits_to_tensor(x, dt, dev).reshape(x.shape)
     got = gemv_abi(m, xt, EXACT)
-    assert rel_err(tensor_to_bits(m(xt)), tensor_to_bits(got), "f16") <= 1e-3   # (the module's default route: the one-pass kernel)
+    assert rel_err(tensor_to_bits(m(xt)), tensor_to_bits(got), dt) <= TOL[dt]   # (the module's default route: the one-pass kernel)
     # bit-level partner on the GPU: HIP dequant (bit-exact W) + fp32 matmul, rounded once
     W = m.dequant().float()
     ref = (xt.float() @ W.t())
     if m.bias is not None:
         ref = ref + m.bias.float()
-    ref16 = tensor_to_bits(ref.to(torch.float16))
+    ref16 = tensor_to_bits(ref.to(tdt))
     gb = tensor_to_bits(got)
-    assert rel_err(gb, ref16, "f16") <= 1e-3 and bit_identical_frac(gb, ref16) >= 0.95   # (1 ulp of the largest output = 9.8e-4)
+    assert rel_err(gb, ref16, dt) <= TOL[dt] and bit_identical_frac(gb, ref16) >= 0.95   # (fp16: 1 ulp of the largest output = 9.8e-4)
     if I * O <= 2048 * 2048:
-        assert rel_err(gb, vo.forward(L, x), "f16") <= 1e-3
+        assert rel_err(gb, vo.forward(L, x), dt) <= TOL[dt]
     # every token row equals that token alone through the one-token kernel (exact form)
     one = tensor_to_bits(gemv_abi(m, xt[:, tokens - 1:tokens].contiguous(), EXACT))
-    assert rel_err(gb[:, tokens - 1:tokens], one, "f16") <= 1e-3
+    assert rel_err(gb[:, tokens - 1:tokens], one, dt) <= TOL[dt]
     # fp32 output
-    assert torch.equal(gemv_abi(m, xt, EXACT, out_f32=True).to(torch.float16), got)
+    assert torch.equal(gemv_abi(m, xt, EXACT, out_f32=True).to(tdt), got)
     from vptq_amd.utils.shard import forward_partial_f32
-    assert torch.equal(forward_partial_f32(m, xt).to(torch.float16), m(xt))   # (default route, fp32 partial sums)
+    assert torch.equal(forward_partial_f32(m, xt).to(tdt), m(xt))   # (default route, fp32 partial sums)
     # determinism
     assert torch.equal(gemv_abi(m, xt, EXACT), got)
 

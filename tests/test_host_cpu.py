@@ -139,9 +139,9 @@ def test_kernel_choice_without_gpu():
     assert name(big, 4) == b"gemv_k256m_kernel<fast>" and name(big, 5) == name(big, 16) == b"gemm_k256t_kernel"
     assert name(big, 64) == b"gemm_k256t_kernel" and name(big, 65) is None          # launches of 16 tokens
     assert name(big, 5, B.GEMV_EXACT) == name(big, 64, B.GEMV_EXACT) == b"gemm_k256_kernel"
-    # bf16 likewise (no batched kernel with the reference's roundings: launches of <= 4 tokens then)
+    # bf16 likewise (round 6: the batched kernel with the reference's roundings serves bf16 too)
     assert name(bbig, 4) == b"gemv_k256m_kernel<fast>" and name(bbig, 5) == name(bbig, 16) == name(bbig, 64) == b"gemm_k256t_kernel"
-    assert name(bbig, 65) is None and name(bbig, 5, B.GEMV_EXACT) == b"gemv_k256_kernel"
+    assert name(bbig, 65) is None and name(bbig, 5, B.GEMV_EXACT) == name(bbig, 64, B.GEMV_EXACT) == b"gemm_k256_kernel"
     assert lib.vptq_quant_gemv_workspace_bytes(bbig, 5, 0) == 64 * 4096 + 256 and lib.vptq_quant_gemv_workspace_bytes(bbig, 4, 0) == 0
     assert lib.vptq_quant_gemv_workspace_bytes(big, 16, 0) == 64 * 4096 + 256 and lib.vptq_quant_gemv_workspace_bytes(big, 16, B.GEMV_EXACT) == 0
     assert name(big, 2, B.GEMV_FORCE_BATCHED) == name(big, 16, B.GEMV_FORCE_BATCHED) == b"gemm_k256t_kernel"

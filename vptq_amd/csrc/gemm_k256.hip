@@ -25,8 +25,8 @@
 //  * at the end the 16 waves' partial D are summed through LDS and stored (+ output bias).
 // Per index: 2 address perms + 12 packed-f16 ops + 4 transposition perms on the VALU, 2
 // gathers + 16 bytes of LDS writes + 16 bytes of LDS operand reads; the MFMA work is 1 / 16 of
-// the instruction stream.  fp16 only (bf16 has no packed VALU arithmetic on gfx950: it keeps
-// the <= 4-token launches).
+// the instruction stream.  bf16 (round 6): the same tile, its roundings as blocks of v_dot2_f32_bf16 (common.h: BF16::add4 /
+// scale_bias4 - 44 instructions per index instead of 12) and v_mfma_f32_16x16x16_bf16; before, bf16 kept the <= 4-token launches.
 #include <stdlib.h>
 
 #include <type_traits>
@@ -73,10 +73,9 @@ static __device__ __forceinline__ uint32_t tile_row(int nb, int wq, int i, int k
   return (uint32_t)((((nb * 16 + wq) * 4 + i) * 4) + kg);
 }
 
-template <bool PERM, int NRG>
+template <typename DT, bool PERM, int NRG>
 static __device__ __forceinline__ void gemm_k256_pass(const GemmK256Params& P, unsigned char* gsmem,
                                                       const int rg0) {
-  using DT = F16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int G = P.G, N = P.N, O = P.O, tokens = P.tokens;
   const uint32_t row_bytes = (uint32_t)P.row_words * 4u;
@@ -177,14 +176,15 @@ static __device__ __forceinline__ void gemm_k256_pass(const GemmK256Params& P, u
         cB[h] = lds_load16(__builtin_amdgcn_perm(w, baseB, selGB[h]));
       }
 #pragma unroll
-      for (int h = 0; h < 2; ++h)
+      for (int h = 0; h < 2; ++h) {
+        // (four packed pairs per call: for bf16 each stage is one scheduled block of dot instructions, common.h)
+        uint32_t v[4] = {cA[h][0], cA[h][1], cA[h][2], cA[h][3]};
+        const uint32_t r[4] = {cB[h][0], cB[h][1], cB[h][2], cB[h][3]};
+        DT::add4(v, r);
+        DT::scale_bias4(v, sv[u0 >> 1], h, bv[u0 >> 1], h);
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-          uint32_t v = DT::add2(cA[h][p], cB[h][p]);
-          v = DT::mul2_bcast(v, sv[u0 >> 1], h);
-          v = DT::add2_bcast(v, bv[u0 >> 1], h);
-          w2[u0 + h][p] = dvalid ? v : 0u;
-        }
+        for (int p = 0; p < 4; ++p) w2[u0 + h][p] = dvalid ? v[p] : 0u;
+      }
     }
     // this slot's index words are consumed: request the step kQ ahead into it
     __builtin_amdgcn_sched_barrier(0);
@@ -214,8 +214,12 @@ static __device__ __forceinline__ void gemm_k256_pass(const GemmK256Params& P, u
         typedef __attribute__((address_space(3))) const u32x2 lds_u32x2_t;
         const u32x2 b = *(lds_u32x2_t*)(uintptr_t)(kGImage + tile_row(nb, wave, i, mkg) * 128u + pair * 16u +
                                                    ((uint32_t)mj & 1u) * 8u);
-        acc[g][nb] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(h4v_t, av),
-                                                           __builtin_bit_cast(h4v_t, b), acc[g][nb], 0, 0, 0);
+        if constexpr (std::is_same<DT, F16>::value)
+          acc[g][nb] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(h4v_t, av),
+                                                             __builtin_bit_cast(h4v_t, b), acc[g][nb], 0, 0, 0);
+        else
+          acc[g][nb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s4_t, av),
+                                                                 __builtin_bit_cast(s4_t, b), acc[g][nb], 0, 0, 0);
       }
     }
   };
@@ -253,7 +257,7 @@ static __device__ __forceinline__ void gemm_k256_pass(const GemmK256Params& P, u
   __syncthreads();
 }
 
-template <bool PERM>
+template <typename DT, bool PERM>
 __global__ __launch_bounds__(kGThreads) void gemm_k256_kernel(const GemmK256Params P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gsmem[];
   {
@@ -276,16 +280,15 @@ __global__ __launch_bounds__(kGThreads) void gemm_k256_kernel(const GemmK256Para
   const int grid = (int)gridDim.x;
   int left = ((int)P.n_groups - (int)blockIdx.x + grid - 1) / grid;
   int rg = blockIdx.x;
-  for (; left >= 4; left -= 4, rg += 4 * grid) gemm_k256_pass<PERM, 4>(P, gsmem, rg);
-  if (left >= 2) { gemm_k256_pass<PERM, 2>(P, gsmem, rg); left -= 2; rg += 2 * grid; }
-  if (left >= 1) gemm_k256_pass<PERM, 1>(P, gsmem, rg);
+  for (; left >= 4; left -= 4, rg += 4 * grid) gemm_k256_pass<DT, PERM, 4>(P, gsmem, rg);
+  if (left >= 2) { gemm_k256_pass<DT, PERM, 2>(P, gsmem, rg); left -= 2; rg += 2 * grid; }
+  if (left >= 1) gemm_k256_pass<DT, PERM, 1>(P, gsmem, rg);
 }
 
 // ---- host side -------------------------------------------------------------------
 bool gemm_k256_eligible(const VptqLayerDesc& d, int tokens, int flags) {
   (void)flags;
   if (!gemv_k256_eligible(d, 1)) return false;      // canonical format, norm on, aligned
-  if (d.dtype != VPTQ_DTYPE_F16) return false;
   if (d.group_size < 8 || (d.group_size & 7)) return false;
   if (d.perm && !(d.scale_permuted && d.bias_permuted)) return false;
   return tokens >= 1 && tokens <= 16;
@@ -313,19 +316,20 @@ hipError_t launch_gemm_k256(const VptqLayerDesc& d, const void* x, void* y, int 
     hipDeviceProp_t p;
     cus[dev] = hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
   }
-  static std::atomic<bool> attr_set[64];
-  if (!attr_set[dev]) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_k256_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kGLds);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute((const void*)gemm_k256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kGLds);
-    if (e != hipSuccess) return e;
-    attr_set[dev] = true;
-  }
   const int ncu = cus[dev].load();
   const int grid = P.n_groups < ncu ? P.n_groups : ncu;
-  if (d.perm) hipLaunchKernelGGL(gemm_k256_kernel<true>, dim3(grid), dim3(kGThreads), kGLds, st, P);
-  else hipLaunchKernelGGL(gemm_k256_kernel<false>, dim3(grid), dim3(kGThreads), kGLds, st, P);
-  return hipGetLastError();
+  auto go = [&](auto kern, std::atomic<bool>& done) -> hipError_t {
+    if (!done) {
+      if (hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kGLds); e != hipSuccess) return e;
+      done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kGThreads), kGLds, st, P);
+    return hipGetLastError();
+  };
+  static std::atomic<bool> attr_set[4][64];
+  if (d.dtype == VPTQ_DTYPE_F16)
+    return d.perm ? go(gemm_k256_kernel<F16, true>, attr_set[0][dev]) : go(gemm_k256_kernel<F16, false>, attr_set[1][dev]);
+  return d.perm ? go(gemm_k256_kernel<BF16, true>, attr_set[2][dev]) : go(gemm_k256_kernel<BF16, false>, attr_set[3][dev]);
 }
 
 }  // namespace vptq
