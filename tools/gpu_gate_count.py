@@ -136,7 +136,9 @@ def main_chain(a):
                 xs.append(make_x(m, XKINDS[(done + i + j) % len(XKINDS)], dt, dev, g))
             ch = GemvChain(ms)
             name = ch.kernel_name(flags=fl)
-            assert name == "gemv_k256c_kernel", name
+            # ("grouped": every layer of this list was turned to the reference's roundings by its load-time gate and the chain kernel has
+            # no bf16 form of them - the list then goes out as grouped launches)
+            assert name in ("gemv_k256c_kernel", "grouped"), name
             gated += sum(int(bool(m._descriptor()[9] & B.GEMV_EXACT)) for m in ms)
             if a.probe:
                 probes += [float(B.folded_probe_distance(m._descriptor()[1], m.in_features, m.out_features, m.weight_bias.data, dt, dev)) for m in ms]
