@@ -138,6 +138,9 @@ def fuzz_adversarial(a, dev):
         print(f"  {k:22s} gated={int(w['gated'])} " + " ".join(f"{n}={v:.2e}" for n, v in w.items() if n != "gated"))
 
 
+B_EXACT, B_MFMA = 1 << 2, 1 << 3   # VPTQ_GEMV_EXACT, VPTQ_GEMV_FORCE_MFMA
+
+
 def fuzz_tokens(a, dev):
     """random canonical layers x 2 ... 40 tokens through the library's default route with the scratch buffer
     (gemv_k256m for 2-4 tokens, gemm_k256t from 5: partial sweeps / row groups, perm, bias, launches of 16) against the
@@ -159,10 +162,13 @@ def fuzz_tokens(a, dev):
         m = spec_to_module(L, dev)
         xt = bits_to_tensor(x, dt, dev).reshape(x.shape)
         want = vo.forward(L, x)
-        name = kernel_name(m, min(tokens, 16))
-        got = gemv_abi(m, xt, 0)
+        # --exact: the reference's roundings (the product's default arithmetic): gemv_k256m / gemv_k256 for 2-4 tokens, gemm_k256 from 5;
+        # O is drawn tall now and then so that the persistent kernel's 144-row-group threshold is crossed
+        fl = (B_EXACT | (B_MFMA if (a.exact and c % 3 == 0 and tokens <= 4) else 0)) if a.exact else 0
+        name = kernel_name(m, min(tokens, 16), fl)
+        got = gemv_abi(m, xt, fl)
         torch.cuda.synchronize()
-        got2 = gemv_abi(m, xt, 0)
+        got2 = gemv_abi(m, xt, fl)
         torch.cuda.synchronize()
         assert torch.equal(got.view(torch.int16), got2.view(torch.int16)), (c, "not reproducible")
         e = rel_err(tensor_to_bits(got), want, dt)
@@ -331,6 +337,7 @@ def main():
     ap.add_argument("--lds-tall", action="store_true", help="tall layers of the LDS-resident formats (gemv_lds_mfma_kernel)")
     ap.add_argument("--adversarial", action="store_true", help="families built against the folded arithmetic")
     ap.add_argument("--tokens", action="store_true", help="random token counts 2 ... 40 through the default route")
+    ap.add_argument("--exact", action="store_true", help="--tokens: with VPTQ_GEMV_EXACT (every third small-token case also with FORCE_MFMA)")
     ap.add_argument("--chains", action="store_true", help="random chains through the persistent chain launch")
     ap.add_argument("--sliced", action="store_true", help="random k = 65536 layers over the sliced layout")
     a = ap.parse_args()
