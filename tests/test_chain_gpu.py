@@ -63,9 +63,8 @@ def test_independent_chain_every_layer_vs_oracle(dt, dev):
     from vptq_amd.ops.chain import GemvChain
     Ls, ms, xs = _build(SHAPES, dt, dev)
     chain = GemvChain(ms)
-    # (the default arithmetic - the reference's roundings - runs inside the chain launch for fp16; bf16 layers go out as
-    # grouped launches of the widened VALU kernel: test_independent_chain_folded covers the bf16 chain launch)
-    assert chain.kernel_name(1, CHAIN) == ("gemv_k256c_kernel" if dt == "f16" else "grouped")
+    # (the default arithmetic - the reference's roundings - runs inside the chain launch; bf16 since the end of round 6)
+    assert chain.kernel_name(1, CHAIN) == "gemv_k256c_kernel"
     xt = [bits_to_tensor(x, dt, dev).reshape(x.shape) for x in xs]
     ys = chain(xt, flags=CHAIN)
     torch.cuda.synchronize()
@@ -175,8 +174,8 @@ def test_chain_on_reference_goldens_at_baseline_sizes(name, arith, dev, request)
     m = spec_to_module(L, dev)
     xt = bits_to_tensor(x, dt, dev).reshape(x.shape)
     chain = GemvChain([m] * 6)
-    # (the reference's roundings run inside the chain launch for fp16; bf16 layers go out one launch per layer)
-    assert (chain.kernel_name(1, CHAIN) == "gemv_k256c_kernel") == (arith == "folded" or dt == "f16")
+    # (the reference's roundings run inside the chain launch, bf16 layers included since the end of round 6)
+    assert chain.kernel_name(1, CHAIN) == "gemv_k256c_kernel"
     ys = chain([xt] * 6, flags=CHAIN)
     torch.cuda.synchronize()
     err = rel_err(tensor_to_bits(ys[0]), y, dt)
@@ -234,29 +233,30 @@ def test_chain_in_a_hipgraph_and_long_chains(dev):
             assert err <= 1e-3, (rep, i, err)
 
 
-def test_chain_with_the_reference_roundings(dev):
-    """VPTQ_GEMV_EXACT inside the chain launch (fp16, independent layers): every weight rebuilt with the reference
-    CPU path's three roundings (vptq/ops/quant_gemm.py:143-158), so the outputs are the oracle's up to the order of
-    the fp32 sums - over every edge shape of the stream; bf16 and dependent chains take the per-layer kernels."""
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+def test_chain_with_the_reference_roundings(dt, dev):
+    """VPTQ_GEMV_EXACT inside the chain launch (independent layers; bf16 since the end of round 6: its roundings on the
+    matrix pipe): every weight rebuilt with the reference CPU path's three roundings (vptq/ops/quant_gemm.py:143-158), so
+    the outputs are the oracle's up to the order of the fp32 sums - over every edge shape of the stream; dependent chains
+    take the per-layer kernels."""
     from vptq_amd.ops.chain import GemvChain
     from vptq_amd import _backend as B
-    Ls, ms, xs = _build(SHAPES, "f16", dev)
+    tol = 1e-3 if dt == "f16" else 8e-3
+    Ls, ms, xs = _build(SHAPES, dt, dev)
     chain = GemvChain(ms)
     assert chain.kernel_name(1, CHAIN | B.GEMV_EXACT) == "gemv_k256c_kernel"
-    xt = [bits_to_tensor(x, "f16", dev).reshape(x.shape) for x in xs]
+    xt = [bits_to_tensor(x, dt, dev).reshape(x.shape) for x in xs]
     ys = chain(xt, flags=CHAIN | B.GEMV_EXACT)
     torch.cuda.synchronize()
     for L, m, x, xg, y in zip(Ls, ms, xs, xt, ys):
         want = vo.forward(L, x)
-        assert rel_err(tensor_to_bits(y), want, "f16") <= 1e-3, f"{L.in_features}x{L.out_features}"
+        assert rel_err(tensor_to_bits(y), want, dt) <= tol, f"{L.in_features}x{L.out_features}"
         assert bit_identical_frac(tensor_to_bits(y), want) >= 0.95, f"{L.in_features}x{L.out_features}"
         # the per-layer kernel with the same roundings: the same weights, another order of the sums
         assert bit_identical_frac(tensor_to_bits(y), tensor_to_bits(gemv_abi(m, xg, B.GEMV_EXACT))) >= 0.95
     y32 = chain(xt, flags=CHAIN | B.GEMV_EXACT | B.GEMV_OUT_F32)
     for a, b in zip(ys, y32):
-        assert torch.equal(b.half().view(torch.int16), a.view(torch.int16))
-    Lb, mb, xb = _build(SHAPES[:2], "bf16", dev)
-    assert GemvChain(mb).kernel_name(1, CHAIN | B.GEMV_EXACT) == "grouped"   # (bf16: no reference roundings in the chain kernel)
+        assert torch.equal(b.to(a.dtype).view(torch.int16), a.view(torch.int16))
 
 
 @pytest.mark.parametrize("exact", [False, True])

@@ -97,7 +97,7 @@ def test_chain_routing_without_gpu():
     # the reference's roundings inside the chain launch (round 4): fp16, independent layers
     assert name([big] * 32, flags=B.GEMV_EXACT) == b"gemv_k256c_kernel"
     assert name([big] * 32, flags=B.GEMV_EXACT | B.GEMV_CHAIN_DEPENDENT) == b"per-layer"
-    assert name([_canonical_desc(8192, 8192, dtype=1)] * 32, flags=B.GEMV_EXACT) == b"grouped"
+    assert name([_canonical_desc(8192, 8192, dtype=1)] * 32, flags=B.GEMV_EXACT) == b"gemv_k256c_kernel"   # (bf16 since the end of round 6)
     assert name([big] * 40) == b"gemv_k256c_kernel"            # two launches (32 + 8)
     assert lib.vptq_quant_gemv_chain_workspace_bytes(32, 0) == 0
     assert lib.vptq_quant_gemv_chain_workspace_bytes(32, B.GEMV_CHAIN_DEPENDENT) == 32 * 1024

@@ -292,7 +292,7 @@ static __device__ __forceinline__ void c_for_slots(F&& f) {
 template <typename DT, bool DEP, int MODE = kCModeFolded>
 __global__ __launch_bounds__(kCThreads) void gemv_k256c_kernel(const K256CParams P) {
   constexpr bool EXACT = MODE == kCModeExact, SEL = MODE == kCModeSel;
-  static_assert(MODE != kCModeExact || (std::is_same<DT, F16>::value && kCSub >= 2), "reference roundings in this loop: fp16");
+  static_assert(MODE != kCModeExact || kCSub >= 2, "reference roundings in this loop: pairs of row subgroups");
   static_assert(MODE == kCModeFolded || !DEP, "reference / selective roundings: independent layers");
   static_assert(!SEL || VPTQ_K256C_PROF == 0, "selective: P.sync carries the thresholds");
   constexpr uint32_t kCXsWave = c_xs_wave(MODE), kCRedOff = c_red_off(MODE), kCRedBOff = c_redb_off(MODE),
@@ -824,7 +824,8 @@ __global__ __launch_bounds__(kCThreads) void gemv_k256c_kernel(const K256CParams
     }
     const u32x4 xq = lds_load16(xq_addr);
     if constexpr (EXACT) { sq = lds_load16(xq_addr + 256u); bq = lds_load16(xq_addr + 512u); }
-    constexpr int kUnits = 8 * kCSub, kAhead = VPTQ_K256C_AHEAD, kNB = kAhead + 1;
+    // (bf16 reference roundings: 18 registers of rounding chains per index - one gather less in flight, or the loop spills)
+    constexpr int kUnits = 8 * kCSub, kAhead = (EXACT && std::is_same<DT, BF16>::value) ? 1 : VPTQ_K256C_AHEAD, kNB = kAhead + 1;
     u32x4 cv[kNB], rv[kNB];
     auto gather = [&](int t) {   // unit t = column t / kCSub of subgroup t % kCSub
       const int u = t / kCSub, q = t % kCSub;
@@ -842,6 +843,11 @@ __global__ __launch_bounds__(kCThreads) void gemv_k256c_kernel(const K256CParams
 #pragma unroll
     for (int t = 0; t < kAhead; ++t) gather(t);
     u32x2 xo = u32x2{0u, 0u};
+    // bf16, reference roundings (round 6): the matrix-pipe form of gemv_k256m.hip (one-hot operands widen for free: 11 MFMAs + 12
+    // conversions per index); per column: the scaled one-hot and the bias in every register
+    [[maybe_unused]] u32x2 so = u32x2{0u, 0u};
+    [[maybe_unused]] f32x4 bvec = f32x4{0.f, 0.f, 0.f, 0.f};
+    [[maybe_unused]] const u32x2 bf_id = u32x2{__builtin_amdgcn_perm(0x3f803f80u, 0u, selA[0]), __builtin_amdgcn_perm(0x3f803f80u, 0u, selB[0])};
 #pragma unroll
     for (int t = 0; t < kUnits; ++t) {
       // fenced: left alone, the scheduler sinks the gathers next to their use (LDS latency exposed)
@@ -852,7 +858,31 @@ __global__ __launch_bounds__(kCThreads) void gemv_k256c_kernel(const K256CParams
       if (q == 0)
         xo = u32x2{__builtin_amdgcn_perm(xq[u >> 1], 0u, selA[u & 1]), __builtin_amdgcn_perm(xq[u >> 1], 0u, selB[u & 1])};
       const u32x4 c = cv[t % kNB], r = rv[t % kNB];
-      if constexpr (EXACT) {
+      if constexpr (EXACT && std::is_same<DT, BF16>::value) {
+        const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (q == 0) {
+          so = u32x2{__builtin_amdgcn_perm(sq[u >> 1], 0u, selA[u & 1]), __builtin_amdgcn_perm(sq[u >> 1], 0u, selB[u & 1])};
+          const u32x2 one_hot = u32x2{(u & 3) == 0 ? 0x00003f80u : (u & 3) == 1 ? 0x3f800000u : 0u,
+                                      (u & 3) == 2 ? 0x00003f80u : (u & 3) == 3 ? 0x3f800000u : 0u};
+          bvec = DT::mfma4(u32x2{bq[(u >> 2) * 2], bq[(u >> 2) * 2 + 1]}, one_hot, z);
+        }
+        f32x4 d0 = DT::mfma4(bf_id, u32x2{c[0], c[1]}, z);
+        f32x4 d1 = DT::mfma4(bf_id, u32x2{c[2], c[3]}, z);
+        d0 = DT::mfma4(bf_id, u32x2{r[0], r[1]}, d0);
+        d1 = DT::mfma4(bf_id, u32x2{r[2], r[3]}, d1);
+        u32x2 wa = u32x2{DT::pack(d0[0], d0[1]), DT::pack(d0[2], d0[3])};
+        u32x2 wb = u32x2{DT::pack(d1[0], d1[1]), DT::pack(d1[2], d1[3])};
+        d0 = DT::mfma4(so, wa, z);
+        d1 = DT::mfma4(so, wb, z);
+        wa = u32x2{DT::pack(d0[0], d0[1]), DT::pack(d0[2], d0[3])};
+        wb = u32x2{DT::pack(d1[0], d1[1]), DT::pack(d1[2], d1[3])};
+        d0 = DT::mfma4(bf_id, wa, bvec);
+        d1 = DT::mfma4(bf_id, wb, bvec);
+        wa = u32x2{DT::pack(d0[0], d0[1]), DT::pack(d0[2], d0[3])};
+        wb = u32x2{DT::pack(d1[0], d1[1]), DT::pack(d1[2], d1[3])};
+        acc[q][0] = DT::mfma4(xo, wa, acc[q][0]);
+        acc[q][1] = DT::mfma4(xo, wb, acc[q][1]);
+      } else if constexpr (EXACT) {
         // both row subgroups of column u together, stage-major over 8 independent chains (dependent packed
         // operations back to back cost wait states); the scale / bias half of the column is picked by op_sel
         if ((q & 1) == 0) {   // (row subgroups q, q + 1)
@@ -1405,7 +1435,8 @@ static hipError_t launch_c(const K256CParams& P, int grid, hipStream_t st) {
 
 // the reference's roundings inside the chain launch: fp16, independent layers
 bool gemv_k256c_exact_ok(const VptqLayerDesc& d, bool dependent) {
-  return d.dtype == VPTQ_DTYPE_F16 && !dependent && VPTQ_K256C_PROF < 2;
+  (void)d;   // (bf16 since the end of round 6: its roundings on the matrix pipe)
+  return !dependent && VPTQ_K256C_PROF < 2;
 }
 // ... and where an activation column dominates only (VPTQ_GEMV_SELECTIVE): the same, + workspace (gemv_k256c_selective_bytes)
 bool gemv_k256c_selective_ok(const VptqLayerDesc& d, bool dependent) {
@@ -1537,9 +1568,9 @@ hipError_t launch_gemv_k256c(const VptqLayerDesc* descs, int n, const void* cons
 #endif
   }
   if (flags & VPTQ_GEMV_EXACT) {
-    if (!f16 || dependent) return hipErrorInvalidValue;   // (the caller routes those layer by layer)
+    if (dependent) return hipErrorInvalidValue;   // (the caller routes those layer by layer)
 #if VPTQ_K256C_PROF < 2
-    return launch_c<F16, false, kCModeExact>(P, grid, st);
+    return f16 ? launch_c<F16, false, kCModeExact>(P, grid, st) : launch_c<BF16, false, kCModeExact>(P, grid, st);
 #else
     return hipErrorInvalidValue;
 #endif
