@@ -917,8 +917,6 @@ def test_reference_goldens_other_formats(name, dev):
         assert err <= TOL[dt], (flags, seen[flags])
     if dt == "f16":
         assert seen[EXACT][2] >= 0.95 and seen[GENERIC][2] >= 0.95, seen
-    # (bf16, round 6: its roundings on the matrix pipe / as dot blocks - the same bits as the reference's widened arithmetic)
-    assert seen[EXACT][2] >= 0.95 and seen[MFMA | EXACT][2] >= 0.95 and seen[VALU | EXACT][2] >= 0.95, seen
     print(name, seen)
 
 

@@ -110,7 +110,6 @@ def main_chain(a):
     """the same families and activation kinds through the persistent chain launch, one arithmetic per run"""
     from vptq_amd.ops.chain import GemvChain
     dev = torch.device("cuda", 0)
-    assert a.dtype == "f16" or a.route != "chain-exact", "the chain kernel takes the reference's roundings as a whole for fp16 only"
     dt, bar = (torch.float16, 1e-3) if a.dtype == "f16" else (torch.bfloat16, 8e-3)
     # (descriptor flags: the call's flags decide on top of the load-time gate's EXACT - the gate of the arithmetic under test:
     # 6.5e-4 of probe distance for the selective form, 7.5e-4 for the folded one; chain-exact: no gate needed)
