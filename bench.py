@@ -973,6 +973,9 @@ def compact_line(out):
     oi = rf.get("opt_in_arithmetic") or {}
     if oi:
         r["opt_in_arithmetic"] = {k: {kk: round(float(vv), 4) for kk, vv in v.items()} for k, v in oi.items()}
+    bh = rf.get("bf16_headline_workload") or {}
+    if bh:
+        r["bf16_headline_workload"] = {k: (round(float(v), 4) if isinstance(v, (int, float)) else v) for k, v in bh.items()}
     c["roofline"] = r
     cb = out.get("cpu_baseline")
     if cb:
@@ -1294,8 +1297,10 @@ def main():
              "OPT-IN selective arithmetic, one launch per layer (what VQuantLinear.forward issues after vptq_amd.set_arithmetic('selective')): "
              "gemv_k256m_kernel<selective> - hot blocks found, zeroed and corrected inside the launch"),
             ("bf16_single_launch_per_layer", dict(H=H, mode="single", flags=EX, dtype=torch.bfloat16),
-             "bf16 layers (the dtype of most published checkpoints), one launch per layer, the default arithmetic: the reference's roundings are widened "
-             "VALU arithmetic there (gemv_k256_kernel)"),
+             "bf16 layers (the dtype of most published checkpoints), one launch per layer, the default arithmetic: the reference's three roundings "
+             "on the matrix pipe (round 6: one-hot MFMA operands widen for free; 21.7 us as widened VALU arithmetic before)"),
+            ("bf16_chain", dict(H=H, mode="chain", flags=EX, dtype=torch.bfloat16),
+             "bf16 layers, the headline workload (32 layers per persistent launch) in the default arithmetic: the same matrix-pipe roundings inside gemv_k256c"),
             ("selective_bf16_single_launch_per_layer", dict(H=H, mode="single", flags=B.GEMV_SELECTIVE, dtype=torch.bfloat16),
              "bf16 layers, OPT-IN selective arithmetic: the dtype-agnostic folded MFMA loop + widened corrections on the hot blocks only"),
             ("selective_chain", dict(H=H, mode="chain", flags=B.GEMV_SELECTIVE),
@@ -1319,7 +1324,7 @@ def main():
             ("folded_k8192_r256", dict(H=H, mode="single", flags=0, k=8192, kr=256), "k = 8192 + 256, opt-in folded arithmetic (MFMA accumulate)"),
         )
         core = ("single_launch_per_layer", "h4096", "selective_chain", "selective_single_launch_per_layer",
-                "bf16_single_launch_per_layer", "selective_bf16_single_launch_per_layer")   # the compact line's roofline.module_path / opt_in rows
+                "bf16_single_launch_per_layer", "bf16_chain", "selective_bf16_single_launch_per_layer")   # the compact line's roofline.module_path / opt_in rows
         for key, kw, what in table:
             if not a.extras and key not in core:
                 continue
@@ -1408,6 +1413,9 @@ def main():
             if "us_per_layer" in e:
                 oi[name] = {"GBps": e["GBps"], "frac": e["frac_of_8TBps"], "us_per_layer": e["us_per_layer"]}
         out["roofline"]["opt_in_arithmetic"] = oi
+        e = ex.get("bf16_chain") or {}
+        if "us_per_layer" in e:   # the headline workload on bf16 layers, default arithmetic (never `value`: BASELINE's metric is quoted on fp16)
+            out["roofline"]["bf16_headline_workload"] = {"GBps": e["GBps"], "frac": e["frac_of_8TBps"], "us_per_layer": e["us_per_layer"], "kernel": e["kernel"]}
     if rank == 0:
         emit(out)
     if dist is not None:
